@@ -1,0 +1,20 @@
+"""MI355X-native importance-weighted ELBO hot path of hughsalimbeni/DGPs_with_IWVI.
+
+Module names mirror the reference package (``layers``, ``models``, ``temp_workaround``); the
+GPflow-1.x pieces the reference takes from gpflow live in ``kernels``, ``features``,
+``mean_functions``, ``likelihoods`` and ``settings``.  All arithmetic is in
+``csrc/libiwvi_hip.so`` (hand-written gfx950 HIP behind the C-ABI of include/iwvi_hip.h).
+"""
+from . import settings  # noqa: F401
+from . import features, kernels, likelihoods, mean_functions  # noqa: F401
+from . import layers, models, temp_workaround  # noqa: F401
+from .layers import Encoder, GPLayer, LatentVariableLayer, RegularizerType  # noqa: F401
+from .models import DGP_IWVI, DGP_VI  # noqa: F401
+from .temp_workaround import (SharedMixedMok, gauss_kl,  # noqa: F401
+                              independent_multisample_sample_conditional,
+                              multisample_sample_conditional)
+
+__all__ = ["settings", "features", "kernels", "likelihoods", "mean_functions", "layers", "models",
+           "temp_workaround", "Encoder", "GPLayer", "LatentVariableLayer", "RegularizerType",
+           "DGP_IWVI", "DGP_VI", "SharedMixedMok", "gauss_kl",
+           "independent_multisample_sample_conditional", "multisample_sample_conditional"]

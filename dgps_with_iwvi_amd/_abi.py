@@ -1,0 +1,120 @@
+"""ctypes binding of libiwvi_hip.so (the C-ABI declared in include/iwvi_hip.h).
+
+The library is built in-tree by ``__graft_entry__.build()`` / ``make -C dgps_with_iwvi_amd/csrc``.
+There is deliberately NO fallback: if the shared object is missing, or a tensor is not on a
+ROCm device, every compute entry point raises.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libiwvi_hip.so")
+
+KERN_RBF, KERN_MATERN52 = 0, 1
+MF_ZERO, MF_IDENTITY, MF_LINEAR = 0, 1, 2
+MAX_LAYERS, MAX_R, MAX_P, MAX_D, MAX_M, MAX_KL, MAX_ENC = 8, 32, 32, 32, 512, 4, 8
+
+c_void_p, c_int, c_int64, c_float, c_double, c_size_t = (
+    ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_double, ctypes.c_size_t)
+
+
+class IwviError(RuntimeError):
+    pass
+
+
+class GpDesc(ctypes.Structure):
+    """struct iwvi_gp_desc (include/iwvi_hip.h)."""
+    _fields_ = [("Z", c_void_p), ("lengthscales", c_void_p), ("q_mu", c_void_p),
+                ("q_sqrt", c_void_p), ("state", c_void_p), ("variance", c_float),
+                ("jitter", c_double), ("M", ctypes.c_int32), ("D", ctypes.c_int32),
+                ("R", ctypes.c_int32), ("kern_type", ctypes.c_int32)]
+
+
+# name -> (restype, argtypes); every symbol include/iwvi_hip.h declares
+PROTOTYPES = {
+    "iwvi_version": (c_int, []),
+    "iwvi_last_error": (ctypes.c_char_p, []),
+    "iwvi_gp_state_bytes": (c_size_t, [c_int, c_int]),
+    "iwvi_gp_state_offsets": (c_int, [c_int, c_int, ctypes.POINTER(c_size_t)]),
+    "iwvi_gp_precompute": (c_int, [ctypes.POINTER(GpDesc), c_int, c_void_p]),
+    "iwvi_rbf_gram_sym": (c_int, [c_void_p, c_void_p, c_float, c_double, c_int, c_int, c_int,
+                                  c_void_p, c_void_p]),
+    "iwvi_chol_ws_bytes": (c_size_t, [c_int]),
+    "iwvi_chol_factor": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+    "iwvi_gp_layer_forward": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_float,
+                                      c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
+                                      c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "iwvi_gp_fullcov_ws_bytes": (c_size_t, [c_int64, c_int, c_int]),
+    "iwvi_gp_layer_fullcov": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p,
+                                      c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "iwvi_lv_layer_forward": (c_int, [c_void_p, c_void_p, c_void_p, ctypes.POINTER(c_void_p),
+                                      ctypes.POINTER(c_void_p), ctypes.POINTER(ctypes.c_int32), c_int,
+                                      c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                      c_int64, c_void_p]),
+    "iwvi_iw_elbo_reduce": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_int64, c_int, c_int,
+                                    c_int64, c_int64,
+                                    ctypes.POINTER(c_void_p), ctypes.POINTER(ctypes.c_int32), c_int,
+                                    ctypes.POINTER(c_void_p), c_int, c_double, c_int, c_int,
+                                    c_void_p, c_void_p, c_void_p, c_void_p]),
+    "iwvi_lse_merge": (c_int, [c_void_p, c_int, c_int64, c_int, ctypes.POINTER(c_void_p), c_int,
+                               c_double, c_void_p, c_void_p, c_void_p]),
+    "iwvi_gauss_kl": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "iwvi_fill_normal": (c_int, [c_void_p, c_int64, ctypes.c_uint64, ctypes.c_uint64, c_void_p]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load libiwvi_hip.so once; raise loudly if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise IwviError(
+                "HIP extension not built: %s is missing. Run `python -c 'import __graft_entry__ as g; "
+                "g.build()'` or `make -C dgps_with_iwvi_amd/csrc` (needs hipcc, gfx950)." % LIB_PATH)
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in PROTOTYPES.items():
+            fn = getattr(handle, name)
+            fn.restype, fn.argtypes = res, args
+        if handle.iwvi_version() != 1:
+            raise IwviError("libiwvi_hip.so ABI version %d != 1" % handle.iwvi_version())
+        _lib = handle
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise IwviError("libiwvi_hip: %s (code %d)" % (lib().iwvi_last_error().decode(), rc))
+
+
+def dev_tensor(t, name="tensor", dtype=torch.float32):
+    """Validate a tensor that is about to cross the C-ABI: ROCm device, dtype, contiguous."""
+    if not isinstance(t, torch.Tensor):
+        raise TypeError("%s must be a torch.Tensor" % name)
+    if not t.is_cuda:
+        raise IwviError(
+            "%s is on %s: the IW-ELBO hot path only exists as gfx950 HIP kernels "
+            "(there is no CPU fallback); move the model to a ROCm device" % (name, t.device))
+    if t.dtype != dtype:
+        raise TypeError("%s must be %s, got %s" % (name, dtype, t.dtype))
+    if not t.is_contiguous():
+        raise ValueError("%s must be contiguous" % name)
+    return t
+
+
+def ptr(t):
+    return None if t is None else c_void_p(t.data_ptr())
+
+
+def stream_ptr():
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr_array(tensors):
+    arr = (c_void_p * max(len(tensors), 1))()
+    for i, t in enumerate(tensors):
+        arr[i] = t.data_ptr()
+    return arr

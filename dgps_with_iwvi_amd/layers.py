@@ -1,0 +1,193 @@
+"""Layer classes of the reference's ``dgps_with_iwvi/layers.py`` with the same constructor and
+``propagate`` signatures; parameters are float32 torch tensors on a ROCm device and every
+forward runs in the HIP kernels behind include/iwvi_hip.h.
+
+Reference -> here: RegularizerType (layers.py:9-11), GPLayer (:14-50), LatentVariableLayer (:53-105),
+Encoder (:108-152).  Extra keyword ``z`` on ``propagate`` injects the N(0,1) draw the reference takes
+from ``tf.random_normal`` (temp_workaround.py:89,94; layers.py:86).
+"""
+import ctypes
+import enum
+
+import numpy as np
+import torch
+
+from . import _abi, settings
+from .features import InducingFeature, InducingPoints, MixedKernelSharedMof
+from .mean_functions import Zero
+from .temp_workaround import (GpState, SharedMixedMok, draw_normal, gauss_kl,
+                              multisample_sample_conditional, precompute_states)
+
+
+class RegularizerType(enum.Enum):
+    LOCAL = 0
+    GLOBAL = 1
+
+
+def _tensor(x, device=None):
+    t = torch.as_tensor(np.asarray(x, dtype=np.float32) if not isinstance(x, torch.Tensor) else x)
+    return t.to(dtype=settings.float_type, device=device or settings.default_device()).contiguous().clone()
+
+
+class GPLayer:
+    regularizer_type = RegularizerType.GLOBAL
+
+    def __init__(self, kern, Z, num_outputs, mean_function=None, name=None):
+        self.num_inducing = len(Z)
+        if self.num_inducing > _abi.MAX_M:
+            raise ValueError("num_inducing %d > %d" % (self.num_inducing, _abi.MAX_M))
+        self.feature = Z if isinstance(Z, InducingFeature) else InducingPoints(Z)
+        dev = self._Z().device
+        self.q_mu = torch.zeros(self.num_inducing, num_outputs, dtype=settings.float_type, device=dev)
+        # full [R, M, M] storage; like gpflow's LowerTriangular transform only the lower band is used
+        self.q_sqrt = torch.eye(self.num_inducing, dtype=settings.float_type, device=dev).repeat(num_outputs, 1, 1)
+        self.kern = kern.to(dev)
+        self.mean_function = (mean_function or Zero()).to(dev)
+        self.num_outputs = num_outputs
+        self.name = name
+        self._state = None
+
+    # -- plumbing -------------------------------------------------------------------------
+    def _Z(self):
+        f = self.feature.feat if isinstance(self.feature, MixedKernelSharedMof) else self.feature
+        return f.Z
+
+    def _base_kern(self):
+        return self.kern.kernel if isinstance(self.kern, SharedMixedMok) else self.kern
+
+    def to(self, device):
+        self.feature.to(device)
+        self.kern.to(device)
+        self.mean_function.to(device)
+        self.q_mu, self.q_sqrt = self.q_mu.to(device), self.q_sqrt.to(device)
+        self._state = None
+        return self
+
+    def state(self):
+        dev = self.q_mu.device
+        if self._state is None or self._state.buf.device != dev or \
+                (self._state.M, self._state.R) != (self.num_inducing, self.num_outputs):
+            self._state = GpState(self.num_inducing, self.num_outputs, dev)
+        return self._state
+
+    def state_desc(self):
+        """``iwvi_gp_desc`` of this layer's current parameters (for a batched precompute)."""
+        q_mu = _abi.dev_tensor(self.q_mu.contiguous(), "q_mu")
+        q_sqrt = _abi.dev_tensor(self.q_sqrt.contiguous(), "q_sqrt")
+        if q_sqrt.shape != (self.num_outputs, self.num_inducing, self.num_inducing):
+            raise ValueError("q_sqrt must be [R, M, M], got %s" % (tuple(q_sqrt.shape),))
+        return self.state().desc(_abi.dev_tensor(self._Z(), "Z"), self._base_kern(), q_mu, q_sqrt,
+                                 settings.jitter_level)
+
+    def precompute(self):
+        precompute_states([self.state_desc()])
+
+    @property
+    def kl(self):
+        """KL[q(u)||p(u)] of the last precompute (0-dim float64 device tensor)."""
+        return self.state().kl
+
+    # -- reference API --------------------------------------------------------------------
+    def propagate(self, F, full_cov=False, z=None, _precomputed=False, **kwargs):
+        """reference layers.py:35-50 -> (samples, mean, cov, kl)."""
+        if not _precomputed:
+            self.precompute()
+        plain_full = full_cov and not isinstance(self.kern, SharedMixedMok)
+        mf = None if plain_full else self.mean_function            # fused into the kernel epilogue
+        samples, mean, cov = multisample_sample_conditional(
+            F, self.feature, self.kern, self.q_mu, full_cov=full_cov, q_sqrt=self.q_sqrt, white=True,
+            z=z, state=self.state(), mean_function=mf, precomputed=True)
+        kl = self.kl                                               # layers.py:44 (computed by the precompute)
+        if plain_full and self.mean_function.mf_type != _abi.MF_ZERO:
+            m = self.mean_function
+            add = F if m.mf_type == _abi.MF_IDENTITY else F @ m.A + m.b
+            samples, mean = samples + add, mean + add              # layers.py:46-48
+        return samples, mean, cov, kl
+
+
+class Encoder:
+    """tanh MLP [input_dim, *network_dims, 2*latent_dim] with skip connections (reference :108-152).
+    Evaluated inside ``iwvi_lv_layer_forward``; ``__call__`` runs that kernel in encoder-only mode."""
+
+    def __init__(self, latent_dim, input_dim, network_dims, activation_func=None, name=None):
+        if activation_func is not None:
+            raise NotImplementedError("only the default tanh activation is implemented in the HIP kernel")
+        self.latent_dim = latent_dim
+        self.layer_dims = [input_dim, *network_dims, latent_dim * 2]
+        if len(self.layer_dims) - 1 > _abi.MAX_ENC:
+            raise ValueError("encoder deeper than %d layers" % _abi.MAX_ENC)
+        self.Ws, self.bs = [], []
+        for din, dout in zip(self.layer_dims[:-1], self.layer_dims[1:]):
+            xavier_std = (2. / (din + dout)) ** 0.5                                     # :124
+            self.Ws.append(_tensor(np.random.randn(din, dout) * xavier_std))
+            self.bs.append(_tensor(np.zeros(dout)))
+        self.name = name
+
+    def to(self, device):
+        self.Ws = [w.to(device) for w in self.Ws]
+        self.bs = [b.to(device) for b in self.bs]
+        return self
+
+    def abi_args(self):
+        Ws = [_abi.dev_tensor(w, "encoder W") for w in self.Ws]
+        bs = [_abi.dev_tensor(b, "encoder b") for b in self.bs]
+        dims = (ctypes.c_int32 * len(self.layer_dims))(*self.layer_dims)
+        return _abi.ptr_array(Ws), _abi.ptr_array(bs), dims, len(Ws), (Ws, bs)
+
+    def __call__(self, Z):
+        """-> (q_mu, q_sqrt), each [..., latent_dim]."""
+        Z = _abi.dev_tensor(Z.contiguous(), "encoder input")
+        lead, T = Z.shape[:-1], Z[..., 0].numel()
+        if Z.shape[-1] != self.layer_dims[0]:
+            raise ValueError("encoder expects %d features, got %d" % (self.layer_dims[0], Z.shape[-1]))
+        Lw = self.latent_dim
+        dummy = torch.zeros(T, 1, dtype=settings.float_type, device=Z.device)
+        mean = torch.empty(T, 1 + Lw, dtype=settings.float_type, device=Z.device)
+        cov = torch.empty(T, 1 + Lw, dtype=settings.float_type, device=Z.device)
+        Wp, bp, dims, n, keep = self.abi_args()
+        _abi.check(_abi.lib().iwvi_lv_layer_forward(
+            _abi.ptr(dummy), _abi.ptr(Z.reshape(T, -1)), None, Wp, bp, dims, n, 1, Lw, 0,
+            None, _abi.ptr(mean), _abi.ptr(cov), None, T, _abi.stream_ptr()))
+        return mean[:, 1:].reshape(*lead, Lw), cov[:, 1:].sqrt().reshape(*lead, Lw)
+
+
+class LatentVariableLayer:
+    regularizer_type = RegularizerType.LOCAL
+
+    def __init__(self, latent_dim, XY_dim=None, encoder=None, name=None):
+        self.latent_dim = latent_dim
+        if encoder is None:
+            assert XY_dim, 'must pass XY_dim or else an encoder'                        # :67
+            encoder = Encoder(latent_dim, XY_dim, [20, 20])
+        self.encoder = encoder
+        self.name = name
+
+    def to(self, device):
+        self.encoder.to(device)
+        return self
+
+    def propagate(self, F, inference_amorization_inputs=None, is_sampled_local_regularizer=False,
+                  z=None, **kwargs):
+        """reference layers.py:72-105 -> (samples, mean, cov, kl) with kl [..., latent_dim]."""
+        F = _abi.dev_tensor(F.contiguous(), "F")
+        lead, D = F.shape[:-1], F.shape[-1]
+        T, Lw = F[..., 0].numel(), self.latent_dim
+        dev = F.device
+        XY = inference_amorization_inputs
+        if XY is not None:
+            XY = _abi.dev_tensor(XY.contiguous(), "inference_amorization_inputs")
+            if XY.shape[:-1] != lead:
+                raise ValueError("inference_amorization_inputs %s does not match F %s" % (tuple(XY.shape), tuple(F.shape)))
+            if XY.shape[-1] != self.encoder.layer_dims[0]:
+                raise ValueError("encoder expects %d features, got %d" % (self.encoder.layer_dims[0], XY.shape[-1]))
+            XY = XY.reshape(T, -1)
+        z2 = draw_normal((T, Lw), dev) if z is None else _abi.dev_tensor(z.reshape(T, Lw).contiguous(), "z")
+        outs = [torch.empty(T, D + Lw, dtype=settings.float_type, device=dev) for _ in range(3)]
+        kl = torch.empty(T, Lw, dtype=settings.float_type, device=dev)
+        Wp, bp, dims, n, keep = self.encoder.abi_args()
+        _abi.check(_abi.lib().iwvi_lv_layer_forward(
+            _abi.ptr(F.reshape(T, D)), _abi.ptr(XY), _abi.ptr(z2), Wp, bp, dims, n, D, Lw,
+            1 if is_sampled_local_regularizer else 0,
+            _abi.ptr(outs[0]), _abi.ptr(outs[1]), _abi.ptr(outs[2]), _abi.ptr(kl), T, _abi.stream_ptr()))
+        s, m, c = (o.view(*lead, D + Lw) for o in outs)
+        return s, m, c, kl.view(*lead, Lw)

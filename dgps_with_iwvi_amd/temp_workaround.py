@@ -1,0 +1,255 @@
+"""Batched sparse-GP conditionals of the reference's ``dgps_with_iwvi/temp_workaround.py``,
+same names and argument meaning, executed by the gfx950 HIP kernels behind include/iwvi_hip.h.
+
+Reference -> here
+  independent_multisample_sample_conditional (temp_workaround.py:12-98)  -> same name
+  SharedMixedMok                             (temp_workaround.py:107-115) -> same name
+  multisample_sample_conditional             (temp_workaround.py:118-161) -> same name
+  gauss_kl                                   (temp_workaround.py:167-188) -> same name (KL branch)
+
+Deviations (all documented in DESIGN.md):
+  * noise is an explicit optional argument ``z`` (the reference draws tf.random_normal inside the graph);
+    z=None draws from the library's Philox stream;
+  * ``white=False`` (never used by GPLayer, layers.py:42) raises NotImplementedError;
+  * the full-covariance sample follows the intended ``fmean_SRN1 + chol(fvar) z`` (the reference's
+    line :95 has a broadcasting bug);
+  * float32 per-sample arithmetic with a float64 factorisation; variances are clamped at 0.
+"""
+import ctypes
+
+import torch
+
+from . import _abi, settings
+from .features import InducingPoints, MixedKernelSharedMof
+from .kernels import Stationary
+
+
+class SharedMixedMok:
+    """Linear mixing of latent GPs that share one kernel: f = W g, W [P, L] (reference :107-115)."""
+
+    def __init__(self, kernel, W, name=None):
+        self.kernel = kernel
+        W = torch.as_tensor(W) if not isinstance(W, torch.Tensor) else W
+        self.W = W.to(dtype=settings.float_type, device=settings.default_device()).contiguous().clone()
+        self.name = name
+
+    def to(self, device):
+        self.kernel.to(device)
+        self.W = self.W.to(device)
+        return self
+
+
+class GpState:
+    """Owner of one layer's per-step factorisation buffer (``iwvi_gp_desc.state``)."""
+
+    def __init__(self, M, R, device):
+        self.M, self.R = int(M), int(R)
+        nbytes = _abi.lib().iwvi_gp_state_bytes(self.M, self.R)
+        if nbytes == 0:
+            raise ValueError("bad layer size M=%d R=%d" % (M, R))
+        self.buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        offs = (ctypes.c_size_t * 8)()
+        _abi.check(_abi.lib().iwvi_gp_state_offsets(self.M, self.R, offs))
+        self.offsets = dict(zip(["Lm", "Linv", "LinvP", "LrTP", "QmuP", "Zs", "invls", "kl"], list(offs)))
+        self.Mp = (self.M + 31) // 32 * 32
+        self._keep = None
+
+    def view(self, name, dtype, numel):
+        off = self.offsets[name]
+        nbytes = numel * torch.empty((), dtype=dtype).element_size()
+        return self.buf[off:off + nbytes].view(dtype)
+
+    @property
+    def kl(self):
+        """0-dim float64 device tensor: KL[q(u) || p(u)] of the last precompute."""
+        return self.view("kl", torch.float64, 1)[0]
+
+    @property
+    def Lm(self):
+        return self.view("Lm", torch.float64, self.Mp * self.Mp).view(self.Mp, self.Mp)[:self.M, :self.M]
+
+    @property
+    def Linv(self):
+        return self.view("Linv", torch.float64, self.Mp * self.Mp).view(self.Mp, self.Mp)[:self.M, :self.M]
+
+    def desc(self, Z, kern, q_mu, q_sqrt, jitter):
+        M, D = Z.shape
+        R = q_mu.shape[1]
+        if (M, R) != (self.M, self.R):
+            raise ValueError("state sized for (M=%d,R=%d), got (M=%d,R=%d)" % (self.M, self.R, M, R))
+        d = _abi.GpDesc()
+        d.Z, d.lengthscales = Z.data_ptr(), kern.lengthscales.data_ptr()
+        d.q_mu, d.q_sqrt, d.state = q_mu.data_ptr(), q_sqrt.data_ptr(), self.buf.data_ptr()
+        d.variance, d.jitter = kern.variance, float(jitter)
+        d.M, d.D, d.R, d.kern_type = M, D, R, kern.kern_type
+        self._keep = (Z, q_mu, q_sqrt, kern.lengthscales)     # keep operands alive until the launch ran
+        return d
+
+
+def precompute_states(descs):
+    """One ``iwvi_gp_precompute`` call (two launches) for any number of GP layers."""
+    if not descs:
+        return
+    arr = (_abi.GpDesc * len(descs))(*descs)
+    _abi.check(_abi.lib().iwvi_gp_precompute(arr, len(descs), _abi.stream_ptr()))
+
+
+def _prep_q_sqrt(q_sqrt, f):
+    """q_sqrt None | [M,R] diagonal | [R,M,M] -> [R,M,M] (lower triangle is what the kernels read)."""
+    M, R = f.shape
+    if q_sqrt is None:
+        return torch.zeros(R, M, M, dtype=f.dtype, device=f.device)
+    if q_sqrt.dim() == 2:                                     # reference :72-73
+        return torch.diag_embed(q_sqrt.t().contiguous()).contiguous()
+    if q_sqrt.dim() == 3:                                     # reference :74-78
+        return q_sqrt.contiguous()
+    raise ValueError("Bad dimension for q_sqrt: %s" % str(q_sqrt.dim()))   # reference :80-81
+
+
+def _unwrap_feat(feat):
+    if isinstance(feat, InducingPoints):
+        return feat.Z
+    if isinstance(feat, torch.Tensor):
+        return feat
+    raise TypeError("feat must be InducingPoints")
+
+
+def draw_normal(shape, device):
+    """N(0,1) draws from the library's counter-based stream (``iwvi_fill_normal``)."""
+    out = torch.empty(shape, dtype=settings.float_type, device=device)
+    n = out.numel()
+    if n:
+        _abi.dev_tensor(out, "noise")
+        off = settings.next_noise_offset(n)
+        _abi.check(_abi.lib().iwvi_fill_normal(_abi.ptr(out), n, settings.seed, off, _abi.stream_ptr()))
+    return out
+
+
+def _forward_diag(state, kern, D, R, F2, z2, W, mean_function, want=(True, True, True)):
+    """[T, D] -> sample/mean/var [T, P] through ``iwvi_gp_layer_forward``."""
+    T = F2.shape[0]
+    P = W.shape[0] if W is not None else R
+    dev = F2.device
+    outs = [torch.empty(T, P, dtype=settings.float_type, device=dev) if w else None for w in want]
+    mf_type, mfA, mfb = _abi.MF_ZERO, None, None
+    if mean_function is not None:
+        mf_type, mfA, mfb = mean_function.mf_type, mean_function.A, mean_function.b
+        if mf_type == _abi.MF_LINEAR:
+            if tuple(mfA.shape) != (D, P):
+                raise ValueError("Linear mean function A is %s, layer needs (%d, %d)" % (tuple(mfA.shape), D, P))
+            _abi.dev_tensor(mfA, "mean_function.A")
+    _abi.check(_abi.lib().iwvi_gp_layer_forward(
+        _abi.ptr(state.buf), state.M, D, R, P, kern.kern_type, kern.variance,
+        _abi.ptr(F2), _abi.ptr(z2), _abi.ptr(W), mf_type, _abi.ptr(mfA), _abi.ptr(mfb),
+        _abi.ptr(outs[0]), _abi.ptr(outs[1]), _abi.ptr(outs[2]), T, _abi.stream_ptr()))
+    return outs
+
+
+def _check_common(Xnew, full_output_cov, white):
+    if full_output_cov:
+        raise NotImplementedError                              # reference :36-37
+    if not white:
+        raise NotImplementedError("only the whitened representation is on the hot path (layers.py:42)")
+    if Xnew.dim() not in (2, 3):
+        raise ValueError("Xnew must be [N, D] or [S, N, D]")
+
+
+def independent_multisample_sample_conditional(Xnew, feat, kern, f, *, full_cov=False, full_output_cov=False,
+                                               q_sqrt=None, white=False, z=None, state=None,
+                                               mean_function=None, precomputed=False):
+    """Multisample, single-output GP conditional (reference temp_workaround.py:12-98).
+
+    :param Xnew: [S, N, D] (also accepts [N, D], the 2-D ``sample_conditional`` path of :157-161)
+    :param f: [M, R];  q_sqrt: [R, M, M], [M, R] or None;  white must be True
+    :return: sample [S,N,R], mean [S,N,R], var [S,N,R] (full_cov=False) or [S,R,N,N] (full_cov=True);
+             for 2-D input: [N,R], [N,R], [N,R] | [R,N,N].
+    ``state``/``precomputed``/``mean_function`` are used by GPLayer to reuse the per-step factorisation
+    and to fuse the mean-function add; plain callers leave them at their defaults.
+    """
+    _check_common(Xnew, full_output_cov, white)
+    if not isinstance(kern, Stationary):
+        raise TypeError("kern must be a stationary kernel (RBF / Matern52)")
+    Z = _unwrap_feat(feat)
+    Xnew = _abi.dev_tensor(Xnew.contiguous(), "Xnew")
+    f = _abi.dev_tensor(f.contiguous(), "f")
+    M, R = f.shape
+    D = Xnew.shape[-1]
+    if Z.shape != (M, D):
+        raise ValueError("feature is %s, expected (%d, %d)" % (tuple(Z.shape), M, D))
+    if state is None:
+        state = GpState(M, R, Xnew.device)
+    if not precomputed:
+        precompute_states([state.desc(_abi.dev_tensor(Z, "Z"), kern, f, _abi.dev_tensor(_prep_q_sqrt(q_sqrt, f), "q_sqrt"),
+                                      settings.jitter_level)])
+    lead = Xnew.shape[:-1]
+    F2 = Xnew.reshape(-1, D)
+    T = F2.shape[0]
+    if not full_cov:
+        z2 = draw_normal((T, R), Xnew.device) if z is None else _abi.dev_tensor(z.reshape(T, R).contiguous(), "z")
+        s, m, v = _forward_diag(state, kern, D, R, F2, z2, None, mean_function)
+        return s.view(*lead, R), m.view(*lead, R), v.view(*lead, R)
+    # full covariance over the second axis (reference :45,56,83,93-96)
+    S, N = (1, lead[0]) if Xnew.dim() == 2 else lead
+    mean = torch.empty(S, N, R, dtype=settings.float_type, device=Xnew.device)
+    cov = torch.empty(S, R, N, N, dtype=settings.float_type, device=Xnew.device)
+    ws = torch.empty(_abi.lib().iwvi_gp_fullcov_ws_bytes(T, M, R), dtype=torch.uint8, device=Xnew.device)
+    _abi.check(_abi.lib().iwvi_gp_layer_fullcov(_abi.ptr(state.buf), M, D, R, kern.kern_type, kern.variance,
+                                               _abi.ptr(F2), S, N, _abi.ptr(mean), _abi.ptr(cov),
+                                               _abi.ptr(ws), _abi.stream_ptr()))
+    zz = draw_normal((S, R, N, 1), Xnew.device) if z is None else _abi.dev_tensor(z.reshape(S, R, N, 1).contiguous(), "z")
+    # K11 (dead code for the ELBO: the final layer's sample is never consumed, models.py:122-134).
+    # cholesky_ex does not throw on a singular block (X tiled over K gives rank-1 blocks); like the TF
+    # graph, a failed factorisation only poisons this never-fetched sample.
+    chol, _ = torch.linalg.cholesky_ex(cov)
+    sample = (mean.transpose(1, 2).unsqueeze(-1) + chol @ zz)[..., 0].transpose(1, 2)
+    if mean_function is not None and mean_function.mf_type != _abi.MF_ZERO:
+        raise NotImplementedError("full_cov with a fused mean function: add it in the caller")
+    if Xnew.dim() == 2:
+        return sample[0], mean[0], cov[0]
+    return sample, mean, cov
+
+
+def multisample_sample_conditional(Xnew, feat, kern, f, *, full_cov=False, full_output_cov=False,
+                                   q_sqrt=None, white=False, z=None, state=None, mean_function=None,
+                                   precomputed=False):
+    """Dispatcher of reference temp_workaround.py:118-161."""
+    if isinstance(kern, SharedMixedMok) and isinstance(feat, MixedKernelSharedMof):      # :123
+        _check_common(Xnew, False, white)
+        base, Z = kern.kernel, _unwrap_feat(feat.feat)
+        Xnew = _abi.dev_tensor(Xnew.contiguous(), "Xnew")
+        f = _abi.dev_tensor(f.contiguous(), "f")
+        M, R = f.shape
+        D = Xnew.shape[-1]
+        W = _abi.dev_tensor(kern.W, "W")
+        if W.shape[1] != R:
+            raise ValueError("W is %s but there are %d latent GPs" % (tuple(W.shape), R))
+        if state is None:
+            state = GpState(M, R, Xnew.device)
+        if not precomputed:
+            precompute_states([state.desc(_abi.dev_tensor(Z, "Z"), base, f,
+                                          _abi.dev_tensor(_prep_q_sqrt(q_sqrt, f), "q_sqrt"), settings.jitter_level)])
+        lead = Xnew.shape[:-1]
+        F2 = Xnew.reshape(-1, D)
+        T = F2.shape[0]
+        # full_cov is forced to False on this branch (reference :125-129, :134-138)
+        z2 = draw_normal((T, R), Xnew.device) if z is None else _abi.dev_tensor(z.reshape(T, R).contiguous(), "z")
+        s, m, v = _forward_diag(state, base, D, R, F2, z2, W, mean_function)   # mixing fused (:142-145)
+        P = W.shape[0]
+        return s.view(*lead, P), m.view(*lead, P), v.view(*lead, P)
+    assert not isinstance(kern, SharedMixedMok)                                          # :149
+    return independent_multisample_sample_conditional(
+        Xnew, feat, kern, f, full_cov=full_cov, full_output_cov=full_output_cov, q_sqrt=q_sqrt,
+        white=white, z=z, state=state, mean_function=mean_function, precomputed=precomputed)
+
+
+def gauss_kl(q_mu, q_sqrt, K=None):
+    """Whitened KL[q(u) || p(u)] summed over outputs (reference :167-188, KL branch :186-188).
+    Returns a 0-dim float64 device tensor.  The SGHMC branch (q_sqrt None) is out of scope."""
+    if q_sqrt is None or K is not None:
+        raise NotImplementedError("only the whitened KL branch is on the IW-ELBO path")
+    q_mu = _abi.dev_tensor(q_mu.contiguous(), "q_mu")
+    q_sqrt = _abi.dev_tensor(_prep_q_sqrt(q_sqrt, q_mu), "q_sqrt")
+    M, R = q_mu.shape
+    out = torch.empty(1, dtype=torch.float64, device=q_mu.device)
+    _abi.check(_abi.lib().iwvi_gauss_kl(_abi.ptr(q_mu), _abi.ptr(q_sqrt), M, R, _abi.ptr(out), _abi.stream_ptr()))
+    return out[0]

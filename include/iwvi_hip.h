@@ -1,0 +1,183 @@
+/*
+ * iwvi_hip.h -- C-ABI of the MI355X (gfx950) importance-weighted-ELBO hot path.
+ *
+ * The reference (hughsalimbeni/DGPs_with_IWVI) has no FFI: its hot path is a
+ * chain of TensorFlow-1/GPflow-1 ops behind Python class signatures.  Each entry
+ * point below replaces the op group named in its comment (file:line relative to
+ * the reference checkout); dgps_with_iwvi_amd/{temp_workaround,layers,models}.py
+ * bind them with ctypes and keep the reference's Python signatures.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the name ends in _host;
+ *     the caller (PyTorch-ROCm) owns every buffer; nothing is allocated here;
+ *   - `stream` is a hipStream_t passed as void*; all work is stream-ordered,
+ *     there is no global mutable state except the thread-local error string,
+ *     and no call synchronises the device (safe inside hipGraph capture);
+ *   - return 0 on success, negative IWVI_ERR_* otherwise, text in iwvi_last_error();
+ *   - dense row-major float32 tensors unless stated; "T" is the flattened sample
+ *     batch (B*K rows of the reference's [B, K, D] tensors, or N rows of [N, D]).
+ */
+#ifndef IWVI_HIP_H
+#define IWVI_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IWVI_ABI_VERSION 1
+
+enum {
+    IWVI_OK = 0,
+    IWVI_ERR_ARG = -1,      /* bad size / null pointer / unsupported combination */
+    IWVI_ERR_LAUNCH = -2,   /* hip launch or runtime error (text has hipGetErrorString) */
+    IWVI_ERR_UNSUPPORTED = -3
+};
+
+/* stationary kernels of gpflow.kernels used on the path (temp_workaround.py:39,44,45) */
+enum { IWVI_KERN_RBF = 0, IWVI_KERN_MATERN52 = 1 };
+
+/* gpflow.mean_functions used by GPLayer.propagate (layers.py:46-48) */
+enum { IWVI_MF_ZERO = 0, IWVI_MF_IDENTITY = 1, IWVI_MF_LINEAR = 2 };
+
+#define IWVI_MAX_LAYERS 8   /* GP layers batched into one precompute launch   */
+#define IWVI_MAX_R 32       /* latent GPs per layer                            */
+#define IWVI_MAX_P 32       /* mixed outputs per layer                         */
+#define IWVI_MAX_D 32       /* layer input dimension                           */
+#define IWVI_MAX_M 512      /* inducing points per layer                       */
+#define IWVI_MAX_KL 4       /* local-regulariser arrays fed to the ELBO reduce */
+#define IWVI_MAX_ENC 8      /* encoder MLP layers                              */
+
+int iwvi_version(void);
+const char* iwvi_last_error(void);
+
+/* ------------------------------------------------------------------------
+ * Per-step, per-GP-layer state ("the inducing-set factorisation").
+ * Replaces: Kuu(feat, kern, jitter) + tf.cholesky  (temp_workaround.py:39,48),
+ * the operand side of tf.matrix_triangular_solve (:51), tf.matrix_band_part of
+ * q_sqrt (:78) and gauss_kl (layers.py:44 -> temp_workaround.py:186-188).
+ *
+ * Mp = M rounded up to 32, nb = Mp/32.  The state buffer holds, in this order,
+ *   double  Lm   [Mp*Mp]   lower Cholesky factor of Kuu (padding rows = identity)
+ *   double  Linv [Mp*Mp]   Lm^-1
+ *   float   LinvP[nb*nb*1024]      Lm^-1, MFMA-fragment packed
+ *   float   LrTP [R*nb*nb*1024]    tril(q_sqrt[r])^T, packed
+ *   float   QmuP [nb*1024]         q_mu^T (R rows padded to 32), packed
+ *   float   Zs   [Mp*32]           Z / lengthscales, rows padded to 32 floats
+ *   float   invls[32]              1 / lengthscales (0 beyond D)
+ *   double  kl   [1]               KL[q(u) || p(u)], whitened, summed over R
+ * iwvi_gp_state_bytes() returns the size; offsets via iwvi_gp_state_offsets().
+ * ---------------------------------------------------------------------- */
+typedef struct iwvi_gp_desc {
+    const float* Z;            /* [M, D]  inducing inputs                        */
+    const float* lengthscales; /* [D]     ARD lengthscales                       */
+    const float* q_mu;         /* [M, R]                                         */
+    const float* q_sqrt;       /* [R, M, M]; only the lower triangle is read     */
+    void* state;               /* iwvi_gp_state_bytes(M, R) bytes, 256-B aligned */
+    float variance;            /* kernel variance sigma^2                        */
+    double jitter;             /* gpflow settings.numerics.jitter_level          */
+    int32_t M, D, R;
+    int32_t kern_type;         /* IWVI_KERN_*                                    */
+} iwvi_gp_desc;
+
+size_t iwvi_gp_state_bytes(int M, int R);
+/* offsets (bytes) of {Lm, Linv, LinvP, LrTP, QmuP, Zs, invls, kl} inside the state buffer */
+int iwvi_gp_state_offsets(int M, int R, size_t out_host[8]);
+
+/* factorise up to IWVI_MAX_LAYERS layers in two launches (Kuu+Cholesky, inverse+pack) */
+int iwvi_gp_precompute(const iwvi_gp_desc* layers_host, int n_layers, void* stream);
+
+/* K1: Kuu(feat, kern, jitter) in float64 (temp_workaround.py:39)  -> Kuu [M, M] double */
+int iwvi_rbf_gram_sym(const float* Z, const float* lengthscales, float variance, double jitter,
+                      int kern_type, int M, int D, double* Kuu, void* stream);
+/* K2: tf.cholesky(Kmm) in float64 (temp_workaround.py:48): A [M, M] (lower triangle read) ->
+ * Lout [M, M] lower factor (upper triangle zero); ws = iwvi_chol_ws_bytes(M) bytes of scratch */
+size_t iwvi_chol_ws_bytes(int M);
+int iwvi_chol_factor(const double* A, double* Lout, int M, void* ws, void* stream);
+
+/* ------------------------------------------------------------------------
+ * GPLayer forward on a flattened sample batch (diag / marginal variance).
+ * Replaces: Kuf (:44), matrix_triangular_solve (:51), Kdiag - sum A^2 (:59),
+ * A^T q_mu (:68), einsum('rMm,sMn->srmn') (:78), + sum LTA^2 (:85), the
+ * marginal sample (:89-91), SharedMixedMok mixing (:142-145) and the mean
+ * function add (layers.py:46-48) -- one fused launch, nothing spilled to HBM.
+ *
+ *   F      [T, D]   layer input
+ *   noise  [T, R]   N(0,1) draws (z of temp_workaround.py:89); may be NULL -> z = 0
+ *   W      [P, R]   SharedMixedMok.W, or NULL (then P must equal R)
+ *   mf_A   [D, P], mf_b [P]  for IWVI_MF_LINEAR (mf_b may be NULL)
+ *   sample/mean/var [T, P]   any may be NULL (not written)
+ * var is clamped at 0 (float32 cancellation can undershoot; the reference is fp64).
+ * ---------------------------------------------------------------------- */
+int iwvi_gp_layer_forward(const void* state, int M, int D, int R, int P,
+                          int kern_type, float variance,
+                          const float* F, const float* noise, const float* W,
+                          int mf_type, const float* mf_A, const float* mf_b,
+                          float* sample, float* mean, float* var,
+                          int64_t T, void* stream);
+
+/* Full covariance over the second axis (temp_workaround.py:45,56,83 with full_cov=True):
+ *   F [S, N, D] -> mean [S, N, R], cov [S, R, N, N].
+ * ws: iwvi_gp_fullcov_ws_bytes(S*N, M, R) bytes of scratch (A and LTA, as the reference
+ * materialises them). Plain kernels only (the SharedMixedMok branch forces full_cov=False). */
+size_t iwvi_gp_fullcov_ws_bytes(int64_t T, int M, int R);
+int iwvi_gp_layer_fullcov(const void* state, int M, int D, int R, int kern_type, float variance,
+                          const float* F, int64_t S, int64_t N,
+                          float* mean, float* cov, void* ws, void* stream);
+
+/* ------------------------------------------------------------------------
+ * LatentVariableLayer forward (layers.py:72-105) with its Encoder MLP (:137-152).
+ *   F   [T, D];  XY [T, XYdim] or NULL (prior mode, :73-81);  noise [T, Lw] or NULL
+ *   enc_W[i] [dims[i], dims[i+1]], enc_b[i] [dims[i+1]], dims_host[n_enc+1],
+ *   dims[0] = XYdim, dims[n_enc] = 2*Lw; tanh on all but the last layer, skip
+ *   connection where dims[i] == dims[i+1]; q_sqrt = softplus(raw - 3).
+ *   sample/mean/cov [T, D+Lw] (any may be NULL), kl [T, Lw]:
+ *   sampled_kl != 0 -> log q(W) - log p(W) (:98-100) else analytic KL (:101-103).
+ * ---------------------------------------------------------------------- */
+int iwvi_lv_layer_forward(const float* F, const float* XY, const float* noise,
+                          const float* const* enc_W_host, const float* const* enc_b_host,
+                          const int32_t* dims_host, int n_enc,
+                          int D, int Lw, int sampled_kl,
+                          float* sample, float* mean, float* cov, float* kl,
+                          int64_t T, void* stream);
+
+/* ------------------------------------------------------------------------
+ * The IW-ELBO reduction (models.py:133-150): Gaussian variational expectations
+ * (:134), sum over Dy (:138), minus local regularisers (:140-142), logsumexp over
+ * K minus log K (:148), sum over points * scale minus global KLs (:150).
+ *   fmean, fvar: Dy-wide rows, row of (point b, sample k) = b*stride_b + k*stride_k
+ *                (IW tiling [B,K,Dy]: stride_b = K, stride_k = 1; VI tiling [S*N,Dy]: 1, N);
+ *                fvar = diagonal variances;  Y [B, Dy]
+ *   kl_local[i] rows of kl_dims[i] floats, same row indexing, for i < n_kl
+ *   kl_global[i]: pointers to double scalars (state.kl of each GP layer), n_glob of them
+ *   out_lse_ms [B, 2] = (max_k L, sum_k exp(L - max)) per point, for K-sharded merging
+ *   out_logp   [B]     logsumexp - log(K_total)   (K_total = K when not sharded)
+ *   out_elbo   [1] double = sum(logp) * scale - sum(kl_global)
+ * Any out pointer may be NULL.  mode_vi != 0 -> reduce_mean over K instead (models.py:84).
+ * ---------------------------------------------------------------------- */
+int iwvi_iw_elbo_reduce(const float* fmean, const float* fvar, const float* Y,
+                        float lik_variance, int64_t B, int K, int Dy,
+                        int64_t stride_b, int64_t stride_k,
+                        const float* const* kl_local_host, const int32_t* kl_dims_host, int n_kl,
+                        const double* const* kl_global_host, int n_glob,
+                        double scale, int K_total, int mode_vi,
+                        float* out_lse_ms, float* out_logp, double* out_elbo, void* stream);
+
+/* Merge K-sharded partials after the RCCL exchange (not in the reference):
+ *   ms_all [G, B, 2] gathered (max, sumexp) pairs -> logp [B], elbo [1] as above. */
+int iwvi_lse_merge(const float* ms_all, int G, int64_t B, int K_total,
+                   const double* const* kl_global_host, int n_glob, double scale,
+                   float* out_logp, double* out_elbo, void* stream);
+
+/* whitened gauss_kl alone (temp_workaround.py:186-188), K14: -> kl [1] double */
+int iwvi_gauss_kl(const float* q_mu, const float* q_sqrt, int M, int R, double* kl, void* stream);
+
+/* counter-based N(0,1) fill (Philox4x32-10 + Box-Muller); stream documented in DESIGN.md */
+int iwvi_fill_normal(float* out, int64_t n, uint64_t seed, uint64_t offset, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IWVI_HIP_H */

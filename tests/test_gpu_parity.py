@@ -1,0 +1,340 @@
+"""GPU parity: every entry point of the C-ABI (through dgps_with_iwvi_amd) against the fp64 oracle
+on identical seeded inputs and injected noise.
+
+Stated float32 tolerances (BASELINE.md section 5 / SURVEY.md section 7.2, D=8 family):
+per-layer conditional mean rtol 2e-3 + atol 1e-3, variance atol 1e-4 (+ rtol 2e-3),
+ELBO relative 1e-4 (the ELBO is O(1e4) here, so this is the tightest check).
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import iwvi_oracle as O
+from oracle import svgp_closed_form as C
+from oracle.from_spec import build_oracle, oracle_noise
+
+pytestmark = pytest.mark.gpu
+
+MEAN_TOL = dict(rtol=2e-3, atol=1e-3)
+VAR_TOL = dict(rtol=2e-3, atol=1e-4)
+ELBO_RTOL = 1e-4
+
+
+def _t(a, dev, dtype=torch.float32):
+    return torch.as_tensor(np.asarray(a), dtype=dtype, device=dev)
+
+
+def _np(t):
+    return t.detach().double().cpu().numpy()
+
+
+# ------------------------------------------------------------------------------------------
+# K1 / K2 / precompute
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("M,D,R,kern", [(10, 1, 2, "matern"), (64, 8, 1, "rbf"), (100, 3, 2, "rbf"),
+                                        (128, 9, 5, "rbf"), (200, 8, 2, "rbf"), (256, 8, 3, "rbf")])
+def test_precompute_factorisation(gpu_device, M, D, R, kern):
+    """Kuu + tf.cholesky (temp_workaround.py:39,48), Lm^-1 and gauss_kl (:186-188) vs NumPy fp64."""
+    from dgps_with_iwvi_amd import kernels, settings
+    from dgps_with_iwvi_amd.temp_workaround import GpState, precompute_states
+    rng = np.random.default_rng(M + D)
+    Z = rng.standard_normal((M, D)).astype(np.float32)
+    ls = (0.7 + rng.random(D)).astype(np.float32) * np.sqrt(D)
+    q_mu = rng.standard_normal((M, R)).astype(np.float32)
+    q_sqrt = (rng.standard_normal((R, M, M)) * 0.2 + np.eye(M)).astype(np.float32)
+    kcls, ocls = (kernels.Matern52, O.Matern52) if kern == "matern" else (kernels.RBF, O.RBF)
+    k = kcls(D, variance=1.3, lengthscales=ls).to(gpu_device)
+    st = GpState(M, R, gpu_device)
+    precompute_states([st.desc(_t(Z, gpu_device), k, _t(q_mu, gpu_device), _t(q_sqrt, gpu_device),
+                               settings.jitter_level)])
+    torch.cuda.synchronize()
+    # the device factorises the Gram of the float32-rounded scaled inputs (DESIGN.md "Precision")
+    Zs = (Z.astype(np.float64) / ls.astype(np.float64)).astype(np.float32).astype(np.float64)
+    ok = ocls(D, variance=1.3, lengthscales=1.0)
+    Kuu = ok.K(Zs) + 1e-6 * np.eye(M)
+    if kern == "rbf":      # diff form vs expanded form: exact zero distance on the diagonal either way
+        pass
+    Lref = np.linalg.cholesky(Kuu)
+    np.testing.assert_allclose(_np(st.Lm), Lref, rtol=1e-8, atol=1e-9)
+    Linv = _np(st.Linv)
+    np.testing.assert_allclose(Linv @ Lref, np.eye(M), atol=1e-6)
+    np.testing.assert_allclose(float(st.kl.item()), O.gauss_kl(q_mu, q_sqrt), rtol=1e-6)
+
+
+def test_gram_and_cholesky_entry_points(gpu_device):
+    from dgps_with_iwvi_amd import _abi, kernels
+    rng = np.random.default_rng(0)
+    M, D = 100, 5
+    Z = rng.standard_normal((M, D)).astype(np.float32)
+    ls = np.full(D, np.sqrt(D), np.float32)
+    k = kernels.RBF(D, variance=0.9, lengthscales=ls).to(gpu_device)
+    K = _np(k.K(_t(Z, gpu_device)))
+    Zs = (Z.astype(np.float64) / ls).astype(np.float32).astype(np.float64)
+    np.testing.assert_allclose(K, O.RBF(D, 0.9, 1.0).K(Zs), rtol=1e-12, atol=1e-14)
+    A = K + 1e-6 * np.eye(M)
+    Ad = _t(A, gpu_device, torch.float64)
+    L = torch.empty_like(Ad)
+    ws = torch.empty(_abi.lib().iwvi_chol_ws_bytes(M), dtype=torch.uint8, device=gpu_device)
+    _abi.check(_abi.lib().iwvi_chol_factor(_abi.ptr(Ad), _abi.ptr(L), M, _abi.ptr(ws), _abi.stream_ptr()))
+    np.testing.assert_allclose(_np(L), np.linalg.cholesky(A), rtol=1e-8, atol=1e-10)
+
+
+# ------------------------------------------------------------------------------------------
+# GP layer forward (temp_workaround.py:12-98, 118-161; layers.py:35-50)
+# ------------------------------------------------------------------------------------------
+def _layer_case(seed, M, D, R, P, mixing, mf, S, N):
+    rng = np.random.default_rng(seed)
+    Z = rng.standard_normal((M, D)).astype(np.float32)
+    ls = ((0.8 + 0.4 * rng.random(D)) * np.sqrt(D)).astype(np.float32)
+    q_mu = rng.standard_normal((M, R)).astype(np.float32)
+    q_sqrt = (np.tril(rng.standard_normal((R, M, M))) * 0.1 / np.sqrt(M) + 0.5 * np.eye(M)).astype(np.float32)
+    W = rng.standard_normal((P, R)).astype(np.float32) if mixing else None
+    A = rng.standard_normal((D, P)).astype(np.float32) if mf == "linear" else None
+    b = rng.standard_normal(P).astype(np.float32) if mf == "linear" else None
+    X = rng.standard_normal((S, N, D)).astype(np.float32)
+    z = rng.standard_normal((S, N, R)).astype(np.float32)
+    return dict(Z=Z, ls=ls, q_mu=q_mu, q_sqrt=q_sqrt, W=W, A=A, b=b, X=X, z=z)
+
+
+def _run_layer(c, dev, D, R, mixing, mf, full_cov=False, z=None):
+    from dgps_with_iwvi_amd import features, kernels, mean_functions
+    from dgps_with_iwvi_amd.layers import GPLayer
+    from dgps_with_iwvi_amd.temp_workaround import SharedMixedMok
+    kern = kernels.RBF(D, variance=1.1, lengthscales=c["ls"])
+    feat = features.InducingPoints(c["Z"])
+    mfo = {"linear": lambda: mean_functions.Linear(c["A"], c["b"]), "identity": mean_functions.Identity,
+           "zero": lambda: None}[mf]()
+    if mixing:
+        layer = GPLayer(SharedMixedMok(kern, c["W"]), features.MixedKernelSharedMof(feat), R, mfo)
+    else:
+        layer = GPLayer(kern, feat, R, mfo)
+    layer.to(dev)
+    layer.q_mu, layer.q_sqrt = _t(c["q_mu"], dev), _t(c["q_sqrt"], dev)
+    return layer.propagate(_t(c["X"], dev), full_cov=full_cov, z=z)
+
+
+def _oracle_layer(c, D, R, mixing, mf, full_cov=False, z=None):
+    kern = O.RBF(D, variance=1.1, lengthscales=c["ls"])
+    mfo = {"linear": lambda: O.Linear(c["A"], c["b"]), "identity": O.Identity, "zero": lambda: None}[mf]()
+    layer = O.GPLayer(O.SharedMixedMok(kern, c["W"]) if mixing else kern, c["Z"], R, mfo)
+    layer.q_mu, layer.q_sqrt = c["q_mu"], c["q_sqrt"]
+    return layer.propagate(c["X"], full_cov=full_cov, z=z)
+
+
+@pytest.mark.parametrize("M,D,R,P,mixing,mf,S,N", [
+    (128, 9, 5, 8, True, "linear", 7, 20),      # headline inner layer (L1_G5): D_in 9 -> 8
+    (128, 8, 1, 1, False, "zero", 11, 20),      # headline final layer
+    (64, 1, 1, 1, False, "linear", 1, 33),      # config-1-like, ragged tile
+    (100, 3, 2, 2, False, "zero", 3, 5),        # M not a multiple of 32
+    (32, 4, 3, 4, True, "identity", 2, 1),      # single-sample rows, identity mean function
+    (256, 8, 5, 8, True, "linear", 4, 50),      # config 4 layer
+    (512, 8, 2, 8, True, "linear", 2, 40),      # config 5 width (one workgroup per CU)
+    (40, 17, 2, 2, False, "zero", 3, 7),        # D > 16 instantiation
+])
+def test_gp_layer_forward(gpu_device, M, D, R, P, mixing, mf, S, N):
+    c = _layer_case(M + D + R, M, D, R, P, mixing, mf, S, N)
+    s, m, v, kl = _run_layer(c, gpu_device, D, R, mixing, mf, z=_t(c["z"], gpu_device))
+    so, mo, vo, klo = _oracle_layer(c, D, R, mixing, mf, z=c["z"])
+    assert s.shape == so.shape and m.shape == mo.shape and v.shape == vo.shape
+    np.testing.assert_allclose(_np(m), mo, **MEAN_TOL)
+    np.testing.assert_allclose(_np(v), vo, **VAR_TOL)
+    np.testing.assert_allclose(_np(s), so, rtol=2e-3, atol=2e-3)
+    np.testing.assert_allclose(float(kl.item()), klo, rtol=1e-6)
+    # noise-injected sample identity: sample == mean + W (z * sqrt(var_g)) is implied by the above;
+    # with z = 0 the sample is exactly the mean
+    s0, m0, _, _ = _run_layer(c, gpu_device, D, R, mixing, mf, z=torch.zeros(S, N, R, device=gpu_device))
+    assert torch.equal(s0, m0)
+
+
+def test_gp_layer_2d_equals_3d_flat(gpu_device):
+    """[S,N,D] path == the 2-D path on the reshaped input."""
+    c = _layer_case(5, 64, 4, 2, 2, False, "zero", 6, 9)
+    z = _t(c["z"], gpu_device)
+    s3, m3, v3, _ = _run_layer(c, gpu_device, 4, 2, False, "zero", z=z)
+    c2 = dict(c, X=c["X"].reshape(54, 4))
+    s2, m2, v2, _ = _run_layer(c2, gpu_device, 4, 2, False, "zero", z=z.reshape(54, 2))
+    assert torch.equal(s3.reshape(54, 2), s2) and torch.equal(m3.reshape(54, 2), m2)
+    assert torch.equal(v3.reshape(54, 2), v2)
+
+
+def test_gp_layer_bit_reproducible(gpu_device):
+    c = _layer_case(9, 128, 8, 5, 8, True, "linear", 40, 20)
+    z = _t(c["z"], gpu_device)
+    a = _run_layer(c, gpu_device, 8, 5, True, "linear", z=z)
+    b = _run_layer(c, gpu_device, 8, 5, True, "linear", z=z)
+    for x, y in zip(a[:3], b[:3]):
+        assert torch.equal(x, y)
+
+
+@pytest.mark.parametrize("M,D,R,S,N", [(64, 3, 2, 4, 7), (128, 8, 1, 5, 20)])
+def test_gp_layer_full_cov(gpu_device, M, D, R, S, N):
+    """full covariance over the K axis (temp_workaround.py:45,56,83) and its diagonal."""
+    c = _layer_case(M + 1, M, D, R, R, False, "zero", S, N)
+    zf = np.random.default_rng(1).standard_normal((S, R, N, 1)).astype(np.float32)
+    s, m, cov, _ = _run_layer(c, gpu_device, D, R, False, "zero", full_cov=True, z=_t(zf, gpu_device))
+    so, mo, covo, _ = _oracle_layer(c, D, R, False, "zero", full_cov=True, z=zf)
+    assert cov.shape == (S, R, N, N)
+    np.testing.assert_allclose(_np(m), mo, **MEAN_TOL)
+    np.testing.assert_allclose(_np(cov), covo, rtol=2e-3, atol=1e-4)
+    np.testing.assert_allclose(_np(s), so, rtol=5e-3, atol=5e-3)
+    _, _, vd, _ = _run_layer(c, gpu_device, D, R, False, "zero", z=torch.zeros(S, N, R, device=gpu_device))
+    np.testing.assert_allclose(_np(torch.diagonal(cov, dim1=-2, dim2=-1).transpose(1, 2)), _np(vd),
+                               rtol=1e-4, atol=2e-5)
+
+
+def test_conditional_argument_errors(gpu_device):
+    """error behaviour of the reference: NotImplementedError for full_output_cov (:36-37),
+    ValueError for a bad q_sqrt rank (:80-81)."""
+    from dgps_with_iwvi_amd import features, kernels
+    from dgps_with_iwvi_amd.temp_workaround import independent_multisample_sample_conditional as cond
+    k = kernels.RBF(2).to(gpu_device)
+    feat = features.InducingPoints(np.zeros((4, 2), np.float32) + np.arange(4)[:, None]).to(gpu_device)
+    X = torch.zeros(2, 3, 2, device=gpu_device)
+    f = torch.zeros(4, 1, device=gpu_device)
+    with pytest.raises(NotImplementedError):
+        cond(X, feat, k, f, full_output_cov=True, white=True)
+    with pytest.raises(ValueError):
+        cond(X, feat, k, f, q_sqrt=torch.zeros(1, 1, 4, 4, device=gpu_device), white=True)
+    with pytest.raises(NotImplementedError):
+        cond(X, feat, k, f, white=False)
+    # diagonal q_sqrt [M, R] (:72-73) and q_sqrt None are accepted
+    s, m, v = cond(X, feat, k, f, q_sqrt=torch.ones(4, 1, device=gpu_device), white=True,
+                   z=torch.zeros(2, 3, 1, device=gpu_device))
+    assert m.shape == (2, 3, 1) and torch.isfinite(v).all()
+    cond(X, feat, k, f, q_sqrt=None, white=True)
+    # empty batch
+    s, m, v = cond(torch.zeros(0, 3, 2, device=gpu_device), feat, k, f, white=True)
+    assert s.shape == (0, 3, 1)
+
+
+# ------------------------------------------------------------------------------------------
+# LatentVariableLayer + Encoder (layers.py:72-152)
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("sampled", [True, False])
+def test_lv_layer(gpu_device, sampled):
+    from dgps_with_iwvi_amd.layers import Encoder, LatentVariableLayer
+    rng = np.random.default_rng(2)
+    B, K, D, XYd, Lw = 5, 7, 8, 9, 2
+    enc_o = O.Encoder(Lw, XYd, [20, 20], rng)
+    enc_o.bs = [rng.standard_normal(b.shape) * 0.2 for b in enc_o.bs]
+    enc = Encoder(Lw, XYd, [20, 20]).to(gpu_device)
+    enc.Ws = [_t(w, gpu_device) for w in enc_o.Ws]
+    enc.bs = [_t(b, gpu_device) for b in enc_o.bs]
+    F = rng.standard_normal((B, K, D)).astype(np.float32)
+    XY = rng.standard_normal((B, K, XYd)).astype(np.float32)
+    z = rng.standard_normal((B, K, Lw)).astype(np.float32)
+    lv = LatentVariableLayer(Lw, encoder=enc)
+    s, m, c, kl = lv.propagate(_t(F, gpu_device), _t(XY, gpu_device), sampled, z=_t(z, gpu_device))
+    so, mo, co, klo = O.LatentVariableLayer(Lw, encoder=enc_o).propagate(F, XY, sampled, z=z)
+    for a, b_ in ((s, so), (m, mo), (c, co), (kl, klo)):
+        np.testing.assert_allclose(_np(a), b_, rtol=1e-4, atol=1e-5)
+    qm, qs = enc(_t(XY, gpu_device))
+    qmo, qso = enc_o(XY)
+    np.testing.assert_allclose(_np(qm), qmo, rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(_np(qs), qso, rtol=1e-4, atol=1e-6)
+    # prior mode (layers.py:73-81): W = z, log q/p = 0
+    sp, mp, cp, klp = lv.propagate(_t(F, gpu_device), None, True, z=_t(z, gpu_device))
+    np.testing.assert_allclose(_np(sp[..., D:]), z, rtol=1e-6)
+    assert float(klp.abs().max()) < 1e-6 and float((cp[..., D:] - 1).abs().max()) == 0.0
+
+
+# ------------------------------------------------------------------------------------------
+# models: IW-ELBO (models.py:112-150), VI ELBO (:49-86)
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("L,M,K,B,lv", [(1, 64, 1, 40, False), (2, 128, 5, 64, False), (2, 128, 20, 48, True),
+                                        (3, 64, 7, 33, True), (2, 32, 70, 5, True)])
+def test_iw_elbo_matches_oracle(gpu_device, L, M, K, B, lv):
+    from dgps_with_iwvi_amd import synthetic
+    spec = synthetic.make_spec(L=L, M=M, B=B, K=K, with_lv=lv, seed=L * 100 + K)
+    zs = synthetic.make_noise(spec, seed=5)
+    model = synthetic.build_model(spec, gpu_device)
+    zd = [_t(z, gpu_device) for z in zs]
+    elbo = model.compute_log_likelihood(zd)
+    om = build_oracle(spec)
+    ref = om.build_likelihood(oracle_noise(spec, zs))
+    assert abs(elbo - ref) <= ELBO_RTOL * abs(ref), (elbo, ref)
+    # per-point log-weights and per-layer outputs
+    L_NK, _, means_o, covs_o, samples_o = om.log_weights(oracle_noise(spec, zs))
+    m_o = L_NK.max(1)
+    logp_o = m_o + np.log(np.exp(L_NK - m_o[:, None]).sum(1)) - np.log(K)
+    np.testing.assert_allclose(_np(model.E_log_p_Y(zd)), logp_o, rtol=2e-4, atol=2e-2)
+    fmean, fvar, _, _, samples, means, covs = model._forward_iw(zd)
+    for i in range(len(spec["layers"]) - 1):
+        np.testing.assert_allclose(_np(means[i]), means_o[i], **MEAN_TOL)
+        np.testing.assert_allclose(_np(samples[i]), samples_o[i], rtol=2e-3, atol=2e-3)
+    np.testing.assert_allclose(_np(fmean), means_o[-1], rtol=2e-3, atol=2e-3)
+    vo = np.diagonal(covs_o[-1], axis1=-2, axis2=-1).transpose(0, 2, 1)
+    np.testing.assert_allclose(_np(fvar), vo, rtol=5e-3, atol=2e-4)
+
+
+def test_full_cov_over_samples_flag_matches_diag(gpu_device):
+    """following the reference literally ([B,Dy,K,K] covariance then matrix_diag_part, models.py:133)
+    gives the same ELBO as asking the final layer for marginals."""
+    from dgps_with_iwvi_amd import synthetic
+    spec = synthetic.make_spec(L=2, M=64, B=12, K=6, with_lv=True, seed=8)
+    zs = [_t(z, gpu_device) for z in synthetic.make_noise(spec, seed=6)]
+    model = synthetic.build_model(spec, gpu_device)
+    a = model.compute_log_likelihood(zs)
+    model.full_cov_over_samples = True
+    zs_f = zs[:-1] + [torch.zeros(12, 1, 6, 1, device=gpu_device)]
+    b = model.compute_log_likelihood(zs_f)
+    assert abs(a - b) <= 2e-5 * abs(a)
+
+
+@pytest.mark.parametrize("K", [1, 4, 9])
+def test_one_layer_iwvi_equals_closed_form_svgp(gpu_device, K):
+    """mirrors reference tests/test_gp_layer.py:15-54 on the IW path: any K gives the SVGP bound."""
+    from dgps_with_iwvi_amd import features, kernels, likelihoods, mean_functions
+    from dgps_with_iwvi_amd.layers import GPLayer
+    from dgps_with_iwvi_amd.models import DGP_IWVI, DGP_VI
+    rng = np.random.default_rng(0)
+    N, M = 300, 100
+    X = np.linspace(0, 1, N).reshape(-1, 1)
+    Z = np.linspace(0, 1, M).reshape(-1, 1)
+    Y = np.sin(10 * X)
+    A = rng.standard_normal((1, 1))
+    q_mu = rng.standard_normal((M, 1)).astype(np.float32)
+    q_sqrt = (rng.standard_normal((1, M, M)) * 0.1).astype(np.float32)       # non-triangular on purpose
+    q_sqrt[0][np.diag_indices(M)] = np.abs(q_sqrt[0][np.diag_indices(M)]) + 0.5
+    ko = O.Matern52(1, lengthscales=0.1)
+    ref = C.svgp_elbo(X, Y, Z, ko, q_mu.astype(np.float64), q_sqrt.astype(np.float64), 0.1,
+                      O.Linear(A.astype(np.float32).astype(np.float64)))
+    for cls in (DGP_IWVI, DGP_VI):
+        layer = GPLayer(kernels.Matern52(1, lengthscales=0.1), features.InducingPoints(Z), 1,
+                        mean_functions.Linear(A))
+        layer.q_mu, layer.q_sqrt = _t(q_mu, gpu_device), _t(q_sqrt, gpu_device)
+        m = cls(X, Y, [layer], likelihoods.Gaussian(0.1), num_samples=K).to(gpu_device)
+        got = m.compute_log_likelihood()
+        # Matern52 with lengthscale 0.1 and 100 inducing points on [0,1] is ill-conditioned
+        # (cond(Kuu) ~ 1e7): the float32 tolerance is looser than for the D=8 benchmark family
+        assert abs(got - ref) <= 5e-3 * abs(ref), (cls.__name__, got, ref)
+
+
+def test_vi_elbo_and_predict_match_oracle(gpu_device):
+    from dgps_with_iwvi_amd import synthetic
+    from dgps_with_iwvi_amd.models import DGP_VI
+    spec = synthetic.make_spec(L=2, M=64, B=24, K=3, with_lv=True, seed=11)
+    S, B = 3, 24
+    rng = np.random.default_rng(12)
+    zs = [rng.standard_normal((S * B, l["latent_dim"] if l["type"] == "lv" else l["q_mu"].shape[1])).astype(np.float32)
+          for l in spec["layers"]]
+    model = synthetic.build_model(spec, gpu_device, cls=DGP_VI, num_samples=S)
+    got = model.compute_log_likelihood([_t(z, gpu_device) for z in zs])
+    ref = build_oracle(spec, iw=False, num_samples=S).build_likelihood(zs)
+    assert abs(got - ref) <= ELBO_RTOL * abs(ref), (got, ref)
+
+
+def test_fill_normal(gpu_device):
+    from dgps_with_iwvi_amd import _abi
+    n = 1 << 20
+    a = torch.empty(n, device=gpu_device)
+    b = torch.empty(n, device=gpu_device)
+    _abi.check(_abi.lib().iwvi_fill_normal(_abi.ptr(a), n, 7, 0, _abi.stream_ptr()))
+    _abi.check(_abi.lib().iwvi_fill_normal(_abi.ptr(b), n, 7, 0, _abi.stream_ptr()))
+    assert torch.equal(a, b)
+    assert abs(float(a.mean())) < 5e-3 and abs(float(a.var()) - 1) < 1e-2
+    assert abs(float((a ** 4).mean()) - 3) < 0.1
+    _abi.check(_abi.lib().iwvi_fill_normal(_abi.ptr(b), n - 4, 7, 1, _abi.stream_ptr()))
+    assert torch.equal(a[4:], b[:n - 4])                       # counter offset = 4 normals
+    _abi.check(_abi.lib().iwvi_fill_normal(_abi.ptr(b), n, 8, 0, _abi.stream_ptr()))
+    assert not torch.equal(a, b)
