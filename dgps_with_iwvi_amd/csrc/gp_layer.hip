@@ -301,8 +301,8 @@ static int layer_forward_impl(const void* state, int M, int D, int R, int P, int
                               int mf_type, const float* mf_A, const float* mf_b,
                               float* sample, float* mean, float* var, float* a_out, float* u_out,
                               int64_t T, hipStream_t stream) {
-    if (!state || !F) { set_error("iwvi_gp_layer_forward: null state or input"); return IWVI_ERR_ARG; }
     if (T <= 0) return IWVI_OK;                         // empty batch: nothing to do
+    if (!state || !F) { set_error("iwvi_gp_layer_forward: null state or input"); return IWVI_ERR_ARG; }
     if (M <= 0 || M > IWVI_MAX_M || D <= 0 || D > IWVI_MAX_D || R <= 0 || R > IWVI_MAX_R || P <= 0 || P > IWVI_MAX_P) {
         set_error("iwvi_gp_layer_forward: size out of range (M=%d D=%d R=%d P=%d)", M, D, R, P); return IWVI_ERR_ARG;
     }
@@ -354,8 +354,8 @@ extern "C" int iwvi_gp_layer_fullcov(const void* state, int M, int D, int R, int
                                      const float* F, int64_t S, int64_t N, float* mean, float* cov,
                                      void* ws, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
-    if (!state || !F || !cov || !ws) { set_error("iwvi_gp_layer_fullcov: null pointer"); return IWVI_ERR_ARG; }
     if (S <= 0 || N <= 0) return IWVI_OK;
+    if (!state || !F || !cov || !ws) { set_error("iwvi_gp_layer_fullcov: null pointer"); return IWVI_ERR_ARG; }
     if (N > 4096 || S > 0x7fffffffLL) { set_error("iwvi_gp_layer_fullcov: N=%lld > 4096 or S too large", (long long)N); return IWVI_ERR_ARG; }
     const int64_t T = S * N;
     const size_t Mp = (size_t)round_up(M, 32);

@@ -231,8 +231,8 @@ extern "C" int iwvi_lv_layer_forward(const float* F, const float* XY, const floa
                                      const int32_t* dims, int n_enc, int D, int Lw, int sampled_kl,
                                      float* sample, float* mean, float* cov, float* kl,
                                      int64_t T, void* stream_) {
-    if (!F) { set_error("iwvi_lv_layer_forward: null input"); return IWVI_ERR_ARG; }
     if (T <= 0) return IWVI_OK;
+    if (!F) { set_error("iwvi_lv_layer_forward: null input"); return IWVI_ERR_ARG; }
     if (D <= 0 || Lw <= 0) { set_error("iwvi_lv_layer_forward: bad D=%d or latent_dim=%d", D, Lw); return IWVI_ERR_ARG; }
     LvArgs g{};
     g.F = F; g.XY = XY; g.noise = noise; g.D = D; g.Lw = Lw; g.sampled_kl = sampled_kl;

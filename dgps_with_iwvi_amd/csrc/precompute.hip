@@ -258,7 +258,7 @@ __device__ void role_inverse(const PreLayer& L, int jb, double* X, double* S) {
     // already written by k_kuu_chol and are rewritten with identical values)
     for (int idx = tid; idx < Mp * 32; idx += blockDim.x) {
         int i = idx >> 5, c = idx & 31;
-        if (i >= cbase) L.Linv[(size_t)i * Mp + cbase + c] = (cbase + c <= i) ? X[i * XLD + c] : 0.0;
+        L.Linv[(size_t)i * Mp + cbase + c] = (cbase + c <= i) ? X[i * XLD + c] : 0.0;
     }
     // pack blocks (bi >= jb, bk = jb) as float32, masking the identity padding to zero
     const int nb = L.nb;
