@@ -1,0 +1,279 @@
+#!/usr/bin/env python3
+"""IW-ELBO samples/sec on MI355X (BASELINE.json metric) -- one JSON line on rank 0.
+
+A "step" is one full forward IW-ELBO evaluation (``DGP_IWVI._build_likelihood`` equivalent: the
+per-step K_uu Gram/Cholesky/inverse of every GP layer, on-device N(0,1) noise, LatentVariableLayer,
+all GP layers, Gaussian variational expectations, log-sum-exp over K, scaled sum minus the KLs) on
+one minibatch already resident in HBM.  Default workload = BASELINE.json configs[2] (the config the
+metric is quoted on): 2-layer DGP + LatentVariableLayer, M=128, K=20, batch=1024, Dx=8, Dy=1, R=5.
+
+  python bench.py [--gpus N --steps K --warmup W] [--config 1..4] [--shard k|n]
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+Multi-GPU (weak scaling, per-GPU work fixed):
+  --shard k (default): every rank holds the same B points and draws its own K importance samples
+      (global K = N*K); per step one RCCL all-gather of the per-point (max, sum-exp) pairs [B, 2]
+      and a merge kernel give the global log-sum-exp and ELBO (mode i);
+  --shard n: every rank owns B different points and all K samples; one scalar all-reduce per step.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+CONFIGS = {   # BASELINE.json configs[1..4]
+    1: dict(L=2, M=128, K=5, B=1024, with_lv=False),
+    2: dict(L=2, M=128, K=20, B=1024, with_lv=True),
+    3: dict(L=3, M=256, K=50, B=4096, with_lv=False),
+    4: dict(L=5, M=512, K=100, B=8192, with_lv=False),
+}
+PEAK_MFMA_F32 = 157.3e12     # MI355X_MICROARCH.md: dense f32-input MFMA peak
+
+
+def f_alg_layer(M, D, R, P):
+    """Algorithmic FLOPs per sample of one GP layer: Gram + triangular
+    Lm^-1 k + R triangular L_r^T a + mean + reductions + mixing/mean function."""
+    return (2 * M * D + 3 * M) + M * M + R * M * M + 2 * M * R + (2 * M + 2 * R * M) + 6 * R * P + 2 * D * P
+
+
+def f_alg_model(spec):
+    tot, per_layer = 0.0, []
+    for l in spec["layers"]:
+        if l["type"] == "lv":
+            f = 2.0 * sum(a * b for a, b in zip(l["dims"][:-1], l["dims"][1:])) + 20
+        else:
+            M, D = l["Z"].shape
+            R = l["q_mu"].shape[1]
+            P = l["W"].shape[0] if l["W"] is not None else R
+            f = f_alg_layer(M, D, R, P)
+        per_layer.append(f)
+        tot += f
+    return tot + 10, per_layer
+
+
+class Step:
+    """One ELBO evaluation with fixed buffers (capturable into a hipGraph)."""
+
+    def __init__(self, model, spec, dev, shard, world):
+        from dgps_with_iwvi_amd import _abi, settings
+        self.model, self.dev, self.shard, self.world = model, dev, shard, world
+        B, K = spec["B"], spec["K"]
+        self.B, self.K = B, K
+        self.noise_dims = [l["latent_dim"] if l["type"] == "lv" else l["q_mu"].shape[1] for l in spec["layers"]]
+        tot = sum(self.noise_dims)
+        self.noise = torch.empty(B * K * tot, dtype=torch.float32, device=dev)
+        self.rng_state = torch.zeros(2, dtype=torch.int64, device=dev)
+        self._abi, self._settings = _abi, settings
+        self.out = torch.zeros(1, dtype=torch.float64, device=dev)
+
+    def zs(self):
+        out, off = [], 0
+        n = self.B * self.K
+        for d in self.noise_dims:
+            out.append(self.noise[off:off + n * d].view(self.B, self.K, d))
+            off += n * d
+        return out
+
+    def run(self):
+        a = self._abi
+        # fresh noise every step, also under hipGraph replay: one Philox launch for all layers whose
+        # counter lives on the device and is advanced by the launch itself
+        a.check(a.lib().iwvi_fill_normal_dev(a.ptr(self.noise), self.noise.numel(), 1234, a.ptr(self.rng_state),
+                                             a.stream_ptr()))
+        m = self.model
+        if self.shard == "k" and self.world > 1:
+            self.ms, self.glob = m.lse_partials(self.zs(), K_total=self.K * self.world)
+            return self.ms
+        self.out = m._build_likelihood(self.zs())
+        return self.out
+
+
+def cpu_baseline(spec, seconds=12.0):
+    """The reference-equivalent CPU path (oracle/ref_torch_cpu.py, float64 like the reference) timed on
+    this host's cores on the SAME workload; bounded to ~`seconds` of CPU work."""
+    from dgps_with_iwvi_amd import synthetic
+    from oracle.ref_torch_cpu import CpuDGP
+    torch.set_num_threads(os.cpu_count() or 1)
+    zs = synthetic.make_noise(spec, seed=1)
+    m = CpuDGP(spec, torch.float64)
+    t0 = time.perf_counter()
+    m.elbo(zs)                                   # warm-up (also sizes the loop)
+    one = time.perf_counter() - t0
+    iters = int(max(2, min(200, seconds / max(one, 1e-3))))
+    times = []
+    for _ in range(iters):
+        t0 = time.perf_counter()
+        m.elbo(zs)
+        times.append(time.perf_counter() - t0)
+    med = float(np.median(times))
+    return dict(value=spec["B"] * spec["K"] / med, unit="samples/s", cores=torch.get_num_threads(), kind="port",
+                sample="%d full IW-ELBO evaluations of the same workload (B=%d, K=%d), float64 torch-CPU/MKL "
+                       "restatement of the reference op sequence, median" % (iters, spec["B"], spec["K"]),
+                ms_per_step=med * 1e3)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS))
+    ap.add_argument("--shard", choices=["k", "n"], default="k")
+    ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a ROCm device (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    if args.gpus != world and rank == 0:
+        print("note: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
+
+    from dgps_with_iwvi_amd import _abi, synthetic
+    _abi.lib()                                                   # fail loudly if the extension is missing
+    cfg = CONFIGS[args.config]
+    # parity=True: random q_mu / dense lower-triangular q_sqrt (a trained-like state).  The reference's
+    # initial values (q_mu = 0, q_sqrt = 1e-5 I) would feed the MFMAs mostly zeros and flatter the clock.
+    spec = synthetic.make_spec(seed=0, parity=True, n_data=65536, **cfg)
+    if args.shard == "n" and world > 1:                          # each rank owns different points
+        lo = (rank * cfg["B"]) % (spec["n_data"] - cfg["B"] + 1)
+        spec = dict(spec, X=spec["X"][lo:], Y=spec["Y"][lo:])
+    model = synthetic.build_model(spec, dev)
+    step = Step(model, spec, dev, args.shard, world)
+    B, K = cfg["B"], cfg["K"]
+    comm = torch.cuda.Stream(device=dev) if world > 1 else None
+    gathered = torch.empty(world, B, 2, dtype=torch.float32, device=dev) if world > 1 else None
+    elbo_acc = torch.zeros(1, dtype=torch.float64, device=dev)
+
+    # ---- capture -----------------------------------------------------------------------------
+    graph = None
+    step.run()
+    torch.cuda.synchronize()
+    if not args.no_graph:
+        s = torch.cuda.Stream(device=dev)
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            step.run()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=s):
+                step.run()
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+
+    def exchange():
+        """Per-step collective, on a side stream so that it overlaps the next step's kernels."""
+        if world == 1:
+            return
+        ev = torch.cuda.Event()
+        ev.record()
+        with torch.cuda.stream(comm):
+            comm.wait_event(ev)
+            if args.shard == "k":
+                dist.all_gather_into_tensor(gathered.view(-1), step.ms.view(-1))
+                glob = [g.reshape(1) for g in step.glob]
+                logp = torch.empty(B, dtype=torch.float32, device=dev)
+                _abi.check(_abi.lib().iwvi_lse_merge(_abi.ptr(gathered), world, B, K * world, _abi.ptr_array(glob),
+                                                     len(glob), float(spec["n_data"]) / B, _abi.ptr(logp),
+                                                     _abi.ptr(elbo_acc), _abi.stream_ptr()))
+            else:
+                elbo_acc.copy_(step.out.reshape(1))
+                dist.all_reduce(elbo_acc)
+
+    def one_step():
+        if graph is not None:
+            graph.replay()
+        else:
+            step.run()
+        exchange()
+
+    def fence():
+        if comm is not None:
+            torch.cuda.current_stream().wait_stream(comm)
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        one_step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    final_elbo = float((elbo_acc if world > 1 else step.out.reshape(1)).item())
+
+    # ---- dominant kernel: the inner G<R> layer forward, HIP events on its own stream -----------
+    from dgps_with_iwvi_amd.layers import GPLayer, LatentVariableLayer
+    gp_layers = [l for l in model.layers if isinstance(l, GPLayer)]
+    dom = gp_layers[0]
+    _, per_layer = f_alg_model(spec)
+    dom_flops = per_layer[[i for i, l in enumerate(model.layers) if l is dom][0]] * B * K
+    F_in = torch.randn(B, K, dom._Z().shape[1], device=dev)
+    z_in = torch.randn(B, K, dom.num_outputs, device=dev)
+    model.precompute()
+    for _ in range(5):
+        dom.propagate(F_in, z=z_in, _precomputed=True)
+    torch.cuda.synchronize()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    for a, b in evs:
+        a.record()
+        dom.propagate(F_in, z=z_in, _precomputed=True)
+        b.record()
+    torch.cuda.synchronize()
+    dom_ms = float(np.median([a.elapsed_time(b) for a, b in evs]))
+    achieved = dom_flops / (dom_ms * 1e-3)
+
+    if rank == 0:
+        total = float(B) * K * world * args.steps
+        res = {
+            "metric": "IW-ELBO samples/sec (KxN) at L=2, M=128, K=20",
+            "value": total / elapsed, "unit": "samples/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE.json configs[%d]: %s; Dx=8, Dy=1, inner layers G5 (R=5, P=8), RBF-ARD, "
+                                   "per-step Gram+Cholesky included, noise drawn on device" % (args.config, spec["name"]),
+                       "global_batch": B * (world if args.shard == "n" else 1),
+                       "K_total": K * (world if args.shard == "k" else 1),
+                       "sharding": ("none" if world == 1 else args.shard + "-shard"),
+                       "launch": "eager" if graph is None else "hipGraph replay"},
+            "elbo": final_elbo,
+            "roofline": {"bound": "mfma", "kernel": "k_gp_layer (inner G5 layer)", "achieved": achieved / 1e12,
+                         "peak": PEAK_MFMA_F32 / 1e12, "unit": "TFLOP/s", "frac": achieved / PEAK_MFMA_F32,
+                         "traffic": None, "launch_ms": dom_ms,
+                         "flops_per_launch": dom_flops},
+        }
+        tot_flops, _ = f_alg_model(spec)
+        res["model_frac_of_mfma_peak"] = res["value"] / world * tot_flops / PEAK_MFMA_F32
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(spec, args.cpu_seconds)
+            res["gpu_over_cpu"] = res["value"] / res["cpu_baseline"]["value"]
+        print(json.dumps(res))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

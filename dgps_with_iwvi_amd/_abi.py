@@ -62,6 +62,7 @@ PROTOTYPES = {
                                c_double, c_void_p, c_void_p, c_void_p]),
     "iwvi_gauss_kl": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "iwvi_fill_normal": (c_int, [c_void_p, c_int64, ctypes.c_uint64, ctypes.c_uint64, c_void_p]),
+    "iwvi_fill_normal_dev": (c_int, [c_void_p, c_int64, ctypes.c_uint64, c_void_p, c_void_p]),
 }
 
 _lib = None

@@ -200,8 +200,10 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c[4], uint32_t k0, uint32
     }
 }
 
-__global__ void k_fill_normal(float* out, long long n, uint64_t seed, uint64_t offset) {
+template <bool DEVCTR>
+__global__ void k_fill_normal(float* out, long long n, uint64_t seed, uint64_t offset, unsigned long long* state) {
     const long long nq = (n + 3) / 4;
+    if (DEVCTR) offset = state[0];            // every block reads the counter before any block can bump it
     for (long long q = blockIdx.x * (long long)blockDim.x + threadIdx.x; q < nq;
          q += (long long)gridDim.x * blockDim.x) {
         uint64_t ctr = offset + (uint64_t)q;
@@ -219,6 +221,14 @@ __global__ void k_fill_normal(float* out, long long n, uint64_t seed, uint64_t o
             v[2 * p] = rad * cs; v[2 * p + 1] = rad * sn;
         }
         for (int e = 0; e < 4; ++e) if (4 * q + e < n) out[4 * q + e] = v[e];
+    }
+    if (DEVCTR) {
+        // the last block of THIS launch to get here advances the counter for the next launch/replay
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned long long t = atomicAdd(&state[1], 1ULL);
+            if ((t + 1) % gridDim.x == 0) atomicAdd(&state[0], (unsigned long long)nq);
+        }
     }
 }
 
@@ -318,11 +328,22 @@ extern "C" int iwvi_lse_merge(const float* ms_all, int G, int64_t B, int K_total
     return check_launch("k_elbo_final(merge)");
 }
 
-extern "C" int iwvi_fill_normal(float* out, int64_t n, uint64_t seed, uint64_t offset, void* stream_) {
+static int fill_normal_impl(float* out, int64_t n, uint64_t seed, uint64_t offset, unsigned long long* state,
+                            hipStream_t stream) {
     if (n <= 0) return IWVI_OK;
     if (!out) { set_error("iwvi_fill_normal: null output"); return IWVI_ERR_ARG; }
     long long nq = (n + 3) / 4;
     long long blocks = (nq + 255) / 256; if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(k_fill_normal, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream_, out, (long long)n, seed, offset);
+    if (state) hipLaunchKernelGGL(k_fill_normal<true>, dim3((unsigned)blocks), dim3(256), 0, stream, out, (long long)n, seed, offset, state);
+    else hipLaunchKernelGGL(k_fill_normal<false>, dim3((unsigned)blocks), dim3(256), 0, stream, out, (long long)n, seed, offset, state);
     return check_launch("k_fill_normal");
+}
+
+extern "C" int iwvi_fill_normal(float* out, int64_t n, uint64_t seed, uint64_t offset, void* stream_) {
+    return fill_normal_impl(out, n, seed, offset, nullptr, (hipStream_t)stream_);
+}
+
+extern "C" int iwvi_fill_normal_dev(float* out, int64_t n, uint64_t seed, uint64_t* state, void* stream_) {
+    if (!state) { set_error("iwvi_fill_normal_dev: null state"); return IWVI_ERR_ARG; }
+    return fill_normal_impl(out, n, seed, 0, (unsigned long long*)state, (hipStream_t)stream_);
 }

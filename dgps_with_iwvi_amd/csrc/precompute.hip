@@ -354,11 +354,19 @@ __global__ __launch_bounds__(256) void k_gauss_kl(const float* q_mu, const float
 }
 
 static int ensure_lds_attr(const void* fn, size_t bytes) {
+    // remember the largest size configured per kernel: hipFuncSetAttribute is not a stream operation and
+    // must stay out of the steady state (and out of hipGraph capture)
+    static const void* fns[8]; static size_t sizes[8]; static int nf = 0;
+    for (int i = 0; i < nf; ++i) if (fns[i] == fn) { if (sizes[i] >= bytes) return IWVI_OK; break; }
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
     if (e != hipSuccess) {
         set_error("hipFuncSetAttribute(%zu B LDS): %s", bytes, hipGetErrorString(e));
         return IWVI_ERR_LAUNCH;
     }
+    int slot = -1;
+    for (int i = 0; i < nf; ++i) if (fns[i] == fn) slot = i;
+    if (slot < 0 && nf < 8) slot = nf++;
+    if (slot >= 0) { fns[slot] = fn; sizes[slot] = bytes; }
     return IWVI_OK;
 }
 

@@ -176,6 +176,10 @@ int iwvi_gauss_kl(const float* q_mu, const float* q_sqrt, int M, int R, double* 
 
 /* counter-based N(0,1) fill (Philox4x32-10 + Box-Muller); stream documented in DESIGN.md */
 int iwvi_fill_normal(float* out, int64_t n, uint64_t seed, uint64_t offset, void* stream);
+/* same stream, but the counter lives on the device: state[0] = counter (read by the launch, then advanced
+ * by ceil(n/4) by its last block), state[1] = internal ticket; zero both once. Lets a captured hipGraph
+ * draw fresh noise on every replay. */
+int iwvi_fill_normal_dev(float* out, int64_t n, uint64_t seed, uint64_t* state, void* stream);
 
 #ifdef __cplusplus
 }
