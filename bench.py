@@ -17,6 +17,7 @@ Multi-GPU (weak scaling, per-GPU work fixed):
   --shard n: every rank owns B different points and all K samples; one scalar all-reduce per step.
 """
 import argparse
+import ctypes
 import json
 import os
 import sys
@@ -187,10 +188,11 @@ def main():
             comm.wait_event(ev)
             if args.shard == "k":
                 dist.all_gather_into_tensor(gathered.view(-1), step.ms.view(-1))
-                glob = [g.reshape(1) for g in step.glob]
+                glob = [g.reshape(-1) for g in step.glob]
+                glob_n = (ctypes.c_int32 * len(glob))(*[g.numel() for g in glob])
                 logp = torch.empty(B, dtype=torch.float32, device=dev)
                 _abi.check(_abi.lib().iwvi_lse_merge(_abi.ptr(gathered), world, B, K * world, _abi.ptr_array(glob),
-                                                     len(glob), float(spec["n_data"]) / B, _abi.ptr(logp),
+                                                     glob_n, len(glob), float(spec["n_data"]) / B, _abi.ptr(logp),
                                                      _abi.ptr(elbo_acc), _abi.stream_ptr()))
             else:
                 elbo_acc.copy_(step.out.reshape(1))

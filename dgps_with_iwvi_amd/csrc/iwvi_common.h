@@ -16,7 +16,7 @@ static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 // ---- per-layer state layout (see include/iwvi_hip.h) ----------------------------------------
 struct StateLayout {
     int Mp, nb;
-    size_t off_Lm, off_Linv, off_LinvP, off_LrTP, off_QmuP, off_Zs, off_invls, off_kl, bytes;
+    size_t off_Lm, off_Linv, off_LinvP, off_LrTP, off_QmuP, off_Zs, off_invls, off_kl, off_ws, bytes;
 };
 static inline size_t align256(size_t x) { return (x + 255) & ~size_t(255); }
 static inline StateLayout state_layout(int M, int R) {
@@ -31,7 +31,12 @@ static inline StateLayout state_layout(int M, int R) {
     s.off_QmuP = o;  o = align256(o + sizeof(float) * s.nb * 1024);
     s.off_Zs = o;    o = align256(o + sizeof(float) * s.Mp * 32);
     s.off_invls = o; o = align256(o + sizeof(float) * 32);
-    s.off_kl = o;    o = align256(o + sizeof(double));
+    s.off_kl = o;    o = align256(o + sizeof(double) * IWVI_MAX_R);
+    {   // factorisation workspace: 16x16 blocks (17-double rows) of the lower triangle + inverses + scratch
+        const size_t nbk = s.Mp / 16;
+        const size_t blocks = nbk * (nbk + 1) / 2 + nbk + (nbk * nbk + 3) / 4;
+        s.off_ws = o; o = align256(o + sizeof(double) * blocks * 16 * 17);
+    }
     s.bytes = o;
     return s;
 }

@@ -144,7 +144,7 @@ __global__ __launch_bounds__(256) void k_elbo_points(ReduceArgs g) {
 struct FinalArgs {
     const float* logp; const float* ms_all; int G;
     long long B; int K_total; double scale;
-    const double* klg[MAX_GLOB]; int n_glob;
+    const double* klg[MAX_GLOB]; int klg_n[MAX_GLOB]; int n_glob;
     float* logp_out; double* elbo;
 };
 
@@ -177,7 +177,8 @@ __global__ __launch_bounds__(1024) void k_elbo_final(FinalArgs g) {
     }
     if (threadIdx.x == 0 && g.elbo) {
         double kl = 0.0;
-        for (int i = 0; i < g.n_glob; ++i) kl += *g.klg[i];
+        for (int i = 0; i < g.n_glob; ++i)
+            for (int c = 0; c < g.klg_n[i]; ++c) kl += g.klg[i][c];
         *g.elbo = red[0] * g.scale - kl;                                          // models.py:150
     }
 }
@@ -272,11 +273,13 @@ extern "C" int iwvi_lv_layer_forward(const float* F, const float* XY, const floa
     return check_launch("k_lv_layer");
 }
 
-static int fill_globals(FinalArgs& f, const double* const* klg, int n_glob) {
+static int fill_globals(FinalArgs& f, const double* const* klg, const int32_t* counts, int n_glob) {
     if (n_glob < 0 || n_glob > MAX_GLOB) { set_error("too many global KL terms (%d > %d)", n_glob, MAX_GLOB); return IWVI_ERR_ARG; }
     for (int i = 0; i < n_glob; ++i) {
         if (!klg || !klg[i]) { set_error("null global KL pointer %d", i); return IWVI_ERR_ARG; }
         f.klg[i] = klg[i];
+        f.klg_n[i] = counts ? counts[i] : 1;
+        if (f.klg_n[i] <= 0 || f.klg_n[i] > IWVI_MAX_R) { set_error("bad global KL count %d", f.klg_n[i]); return IWVI_ERR_ARG; }
     }
     f.n_glob = n_glob;
     return IWVI_OK;
@@ -286,7 +289,7 @@ extern "C" int iwvi_iw_elbo_reduce(const float* fmean, const float* fvar, const 
                                    float lik_variance, int64_t B, int K, int Dy,
                                    int64_t stride_b, int64_t stride_k,
                                    const float* const* kl_local, const int32_t* kl_dims, int n_kl,
-                                   const double* const* kl_global, int n_glob,
+                                   const double* const* kl_global, const int32_t* kl_global_counts, int n_glob,
                                    double scale, int K_total, int mode_vi,
                                    float* out_ms, float* out_logp, double* out_elbo, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
@@ -310,20 +313,20 @@ extern "C" int iwvi_iw_elbo_reduce(const float* fmean, const float* fvar, const 
     if (rc != IWVI_OK || !out_elbo) return rc;
     FinalArgs f{};
     f.logp = out_logp; f.B = B; f.K_total = g.K_total; f.scale = scale; f.elbo = out_elbo;
-    if ((rc = fill_globals(f, kl_global, n_glob)) != IWVI_OK) return rc;
+    if ((rc = fill_globals(f, kl_global, kl_global_counts, n_glob)) != IWVI_OK) return rc;
     hipLaunchKernelGGL(k_elbo_final, dim3(1), dim3(1024), 0, stream, f);
     return check_launch("k_elbo_final");
 }
 
 extern "C" int iwvi_lse_merge(const float* ms_all, int G, int64_t B, int K_total,
-                              const double* const* kl_global, int n_glob, double scale,
-                              float* out_logp, double* out_elbo, void* stream_) {
+                              const double* const* kl_global, const int32_t* kl_global_counts, int n_glob,
+                              double scale, float* out_logp, double* out_elbo, void* stream_) {
     if (!ms_all || G <= 0 || B <= 0 || K_total <= 0) { set_error("iwvi_lse_merge: bad argument"); return IWVI_ERR_ARG; }
     FinalArgs f{};
     f.ms_all = ms_all; f.G = G; f.B = B; f.K_total = K_total; f.scale = scale;
     f.logp_out = out_logp; f.elbo = out_elbo;
     int rc;
-    if ((rc = fill_globals(f, kl_global, n_glob)) != IWVI_OK) return rc;
+    if ((rc = fill_globals(f, kl_global, kl_global_counts, n_glob)) != IWVI_OK) return rc;
     hipLaunchKernelGGL(k_elbo_final, dim3(1), dim3(1024), 0, (hipStream_t)stream_, f);
     return check_launch("k_elbo_final(merge)");
 }

@@ -3,26 +3,37 @@
 // Replaces (reference file:line) Kuu + tf.cholesky (temp_workaround.py:39,48), the operand side of
 // tf.matrix_triangular_solve (:51), tf.matrix_band_part(q_sqrt) (:78) and gauss_kl (:186-188).
 //
-// Two launches for ALL layers of a model (grid.x = layer):
-//   k_kuu_chol : one 1024-thread workgroup per layer; Gram + blocked right-looking Cholesky (NB=16),
-//                matrix resident in LDS when Mp <= 128, in L2-resident global memory otherwise;
-//                also inverts every 16x16 diagonal block (needed by the panel solve anyway).
-//   k_inv_pack : (layer, role) workgroups: 32-wide column blocks of Lm^-1 by blocked forward
-//                substitution + packing, one role per latent GP for tril(q_sqrt)^T, one for q_mu^T + KL.
+// ONE launch for all layers of a model: grid = (layer, role), 1024-thread workgroups.
+//   role 0        Gram + Cholesky + triangular inverse + packing of Lm^-1   (the serial critical path)
+//   role 1..R     tril(q_sqrt[r])^T packing
+//   role R+1      q_mu^T packing + KL[q(u) || p(u)]
+// The factorisation works on 16x16 blocks of the lower triangle (row stride 17 doubles: conflict-free
+// ds_read_b64), resident in LDS for Mp <= 128 (78 KB) and in an L2-resident workspace otherwise:
+//   * diagonal block: one wave, row-per-lane in registers, pivots/columns broadcast with v_readlane
+//     (no LDS round trips, no barriers inside the 16 steps);
+//   * panel: one thread per row, forward substitution against the factored diagonal block;
+//   * trailing update: one wave per 16x16 output block, 4 outputs per lane;
+//   * Lm^-1 by recursive doubling over the block-triangular structure ([[A,0],[C,B]]^-1 =
+//     [[A^-1,0],[-B^-1 C A^-1, B^-1]]): log2(nblk) levels of two fully parallel block-GEMM stages
+//     instead of a sequential substitution.
 #include "iwvi_common.h"
+#include <cstdlib>
 
 namespace iwvi {
 
-constexpr int NB = 16;          // Cholesky / inverse block size
-constexpr int PLD = NB + 1;     // padded leading dimension of the LDS panels (doubles)
+constexpr int NB = 16;            // block size
+constexpr int BLD = NB + 1;       // padded row stride of a block (doubles)
+constexpr int BLK = NB * BLD;     // doubles per block
+constexpr int ZLD = 33;           // row stride of the LDS copy of Zs (floats)
 
 struct PreLayer {
     const float* Z; const float* ls; const float* q_mu; const float* q_sqrt;
     double* Lm; double* Linv; float* LinvP; float* LrTP; float* QmuP; float* Zs; float* invls; double* kl;
+    double* ws;
     double jitter; float variance;
     int M, D, R, Mp, nb, kern_type;
 };
-struct PreArgs { PreLayer L[IWVI_MAX_LAYERS]; int n; };
+struct PreArgs { PreLayer L[IWVI_MAX_LAYERS]; int n; int stop_after; };
 
 __device__ __forceinline__ double kern_value(double r2, int type, double var) {
     if (type == IWVI_KERN_MATERN52) {
@@ -33,95 +44,175 @@ __device__ __forceinline__ double kern_value(double r2, int type, double var) {
     return var * exp(-0.5 * r2);
 }
 
-__device__ __forceinline__ void wave_lds_sync() {
-    // single-wave producer/consumer through LDS: LDS ops of one wave retire in order; this only
-    // has to stop the compiler from moving the reads above the writes.
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-    __builtin_amdgcn_wave_barrier();
+__host__ __device__ __forceinline__ int boff(int bi, int bj) { return (bi * (bi + 1) / 2 + bj) * BLK; }
+
+// workspace carve (doubles): lower-triangle blocks | diagonal-block inverses | T scratch of the inversion
+struct WsLayout { int nbk; size_t blk, dinv, tbuf, total; };
+__host__ __device__ static inline WsLayout ws_layout(int Mp) {
+    WsLayout w;
+    w.nbk = Mp / NB;
+    w.blk = 0;
+    w.dinv = (size_t)(w.nbk * (w.nbk + 1) / 2) * BLK;
+    w.tbuf = w.dinv + (size_t)w.nbk * BLK;
+    w.total = w.tbuf + (size_t)((w.nbk * w.nbk + 3) / 4) * BLK;
+    return w;
 }
 
-// In-LDS factorisation of a 16x16 SPD block by ONE wave (lane & 15 = row), then its inverse.
-// Dg: in = SPD block (lower used), out = lower Cholesky factor.  Di: out = inverse of that factor.
-__device__ void factor_invert_16(double* Dg, double* Di, int lane) {
+__device__ __forceinline__ double readlane_d(double v, int src) {
+    int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+    int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+    return __hiloint2double(hi, lo);
+}
+
+// Cholesky of one 16x16 block by ONE wave: lane (l & 15) owns row l & 15 in registers; the pivot and the
+// freshly scaled column are broadcast with v_readlane, so the 16 steps need no LDS traffic and no barrier.
+// Writes the factor back (upper part zeroed) and 1/L[j][j] to rinv[0..15].
+__device__ __forceinline__ void diag_factor(double* D, double* rinv, int lane) {
     const int i = lane & 15;
-    const bool act = lane < 16;
+    double a[NB];
+#pragma clang loop unroll(full)
+    for (int k = 0; k < NB; ++k) a[k] = D[i * BLD + k];
+#pragma clang loop unroll(full)
     for (int j = 0; j < NB; ++j) {
-        double s = 0.0;
-        if (act && i >= j) {
-            s = Dg[i * PLD + j];
-            for (int k = 0; k < j; ++k) s -= Dg[i * PLD + k] * Dg[j * PLD + k];
-            Dg[i * PLD + j] = s;
+        const double ajj = readlane_d(a[j], j);
+        const double r = rsqrt(ajj);
+        const double lij = a[j] * r;
+        a[j] = lij;
+        if (lane == 0) rinv[j] = r;
+#pragma clang loop unroll(full)
+        for (int k = j + 1; k < NB; ++k) {
+            const double lkj = readlane_d(lij, k);
+            a[k] = fma(-lij, lkj, a[k]);
         }
-        wave_lds_sync();
-        if (act && i >= j) {
-            double djj = sqrt(Dg[j * PLD + j]);
-            // every lane i > j scales its own entry; lane j stores the pivot last (after the sync)
-            if (i > j) Dg[i * PLD + j] = s / djj;
-        }
-        wave_lds_sync();
-        if (act && i == j) Dg[j * PLD + j] = sqrt(s);
-        wave_lds_sync();
     }
-    // inverse: lane c owns column c of X = L^-1 (forward substitution on e_c)
-    if (act) {
-        const int c = i;
-        double x[NB];
-#pragma unroll
-        for (int r = 0; r < NB; ++r) {
-            double s = (r == c) ? 1.0 : 0.0;
-#pragma unroll
-            for (int k = 0; k < r; ++k) s -= Dg[r * PLD + k] * x[k];
-            x[r] = (r >= c) ? s / Dg[r * PLD + r] : 0.0;
-        }
-#pragma unroll
-        for (int r = 0; r < NB; ++r) Di[r * PLD + c] = x[r];
+    if (lane < NB) {
+#pragma clang loop unroll(full)
+        for (int k = 0; k < NB; ++k) D[i * BLD + k] = (k <= i) ? a[k] : 0.0;
     }
-    wave_lds_sync();
 }
 
-// Blocked right-looking Cholesky of A [n x n], leading dimension ld, lower triangle, in place.
-// A may live in LDS or in global memory (generic pointer). Linv receives the inverses of the 16x16
-// diagonal blocks (the rest of Linv is filled by k_inv_pack). smem: Dg, Di, P scratch.
-__device__ void chol_blocked(double* A, int n, int ld, double* Linv, int ldi,
-                             double* Dg, double* Di, double* P, int tid, int nthreads) {
-    const int lane = tid & 63, wave = tid >> 6;
-    for (int c0 = 0; c0 < n; c0 += NB) {
-        if (tid < NB * NB) {
-            int r = tid / NB, c = tid % NB;
-            Dg[r * PLD + c] = (c <= r) ? A[(size_t)(c0 + r) * ld + c0 + c] : 0.0;
-        }
-        __syncthreads();
-        if (wave == 0) factor_invert_16(Dg, Di, lane);
-        __syncthreads();
-        if (tid < NB * NB) {
-            int r = tid / NB, c = tid % NB;
-            if (c <= r) {
-                A[(size_t)(c0 + r) * ld + c0 + c] = Dg[r * PLD + c];
-                Linv[(size_t)(c0 + r) * ldi + c0 + c] = Di[r * PLD + c];
-            }
-        }
-        const int r0 = c0 + NB, nrem = n - r0;
-        // panel: L[i][c0+c] = sum_{k<=c} A[i][c0+k] * Dinv[c][k]
-        for (int idx = tid; idx < nrem * NB; idx += nthreads) {
-            int ii = idx / NB, c = idx % NB;
-            const double* arow = A + (size_t)(r0 + ii) * ld + c0;
-            double s = 0.0;
-            for (int k = 0; k <= c; ++k) s += arow[k] * Di[c * PLD + k];
-            P[ii * PLD + c] = s;
-        }
-        __syncthreads();
-        for (int idx = tid; idx < nrem * NB; idx += nthreads) {
-            int ii = idx / NB, c = idx % NB;
-            A[(size_t)(r0 + ii) * ld + c0 + c] = P[ii * PLD + c];
-        }
-        // trailing update (lower triangle incl. diagonal): A[i][k] -= sum_c P[i][c] P[k][c]
-        for (int idx = tid; idx < nrem * nrem; idx += nthreads) {
-            int ii = idx / nrem, kk = idx % nrem;
-            if (kk > ii) continue;
-            double s = 0.0;
+// inverse of a lower-triangular 16x16 block by ONE wave: lane c owns column c of X; L[r][k] is read
+// from the row-per-lane register copy by v_readlane (wave-uniform scalar operand).
+__device__ __forceinline__ void diag_inverse(const double* D, const double* rinv, double* X, int lane) {
+    const int i = lane & 15;
+    double a[NB];
+#pragma clang loop unroll(full)
+    for (int k = 0; k < NB; ++k) a[k] = D[i * BLD + k];
+    double x[NB];
+#pragma clang loop unroll(full)
+    for (int r = 0; r < NB; ++r) {
+        double s = (r == i) ? 1.0 : 0.0;
+#pragma clang loop unroll(full)
+        for (int k = 0; k < r; ++k) s = fma(-readlane_d(a[k], r), x[k], s);
+        x[r] = s * rinv[r];
+    }
+    if (lane < NB) {
+#pragma clang loop unroll(full)
+        for (int r = 0; r < NB; ++r) X[r * BLD + i] = (r >= i) ? x[r] : 0.0;
+    }
+}
+
+// one wave: acc(16x16) += sign * A * B^T (NT) or sign * A * B (NN) on v_mfma_f64_16x16x4_f64.
+// Operands: lane l feeds A[l&15][4kk + (l>>4)] and B[4kk + (l>>4)][l&15]; the accumulator register e of
+// lane l is C[(l>>4) + 4e][l&15] (f64 C/D map, cdna guide section 3).  Per 16-deep product a lane reads
+// 8 doubles from LDS instead of 80 for a VALU formulation, which was LDS-bandwidth bound.
+using f64x4 = __attribute__((ext_vector_type(4))) double;
+
+template <bool NT>
+__device__ __forceinline__ void blk_mma(f64x4& acc, const double* A, const double* B, int lane, double sign) {
+    const int r = lane & 15, g = lane >> 4;
 #pragma unroll
-            for (int c = 0; c < NB; ++c) s += P[ii * PLD + c] * P[kk * PLD + c];
-            A[(size_t)(r0 + ii) * ld + r0 + kk] -= s;
+    for (int kk = 0; kk < 4; ++kk) {
+        const double a = sign * A[r * BLD + 4 * kk + g];
+        const double b = NT ? B[r * BLD + 4 * kk + g] : B[(4 * kk + g) * BLD + r];
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+    }
+}
+__device__ __forceinline__ f64x4 blk_load(const double* C, int lane) {
+    const int c = lane & 15, g = lane >> 4;
+    f64x4 v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = C[(g + 4 * e) * BLD + c];
+    return v;
+}
+__device__ __forceinline__ void blk_store(double* C, const f64x4& v, int lane) {
+    const int c = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) C[(g + 4 * e) * BLD + c] = v[e];
+}
+
+// Blocked right-looking Cholesky on block storage. rinv: [16*nbk] reciprocal pivots.
+__device__ __forceinline__ void chol_blocks(double* blk, int nbk, double* rinv, int tid, int nthreads, int dbg = 0) {
+    const int lane = tid & 63, wave = tid >> 6, nw = nthreads >> 6;
+    for (int p = 0; p < nbk; ++p) {
+        double* Dpp = blk + boff(p, p);
+        if (wave == 0) diag_factor(Dpp, rinv + NB * p, lane);
+        __syncthreads();
+        if (dbg == 31) continue;
+        const int m = nbk - 1 - p;                       // block rows below the diagonal block
+        // panel: rows of blocks (bi, p), bi > p:  x L_pp^T = a  (forward substitution, one thread per row)
+        for (int t = tid; t < m * NB; t += nthreads) {
+            double* row = blk + boff(p + 1 + t / NB, p) + (t % NB) * BLD;
+            double x[NB];
+#pragma clang loop unroll(full)
+            for (int c = 0; c < NB; ++c) x[c] = row[c];
+#pragma clang loop unroll(full)
+            for (int c = 0; c < NB; ++c) {
+                double s = x[c];
+#pragma clang loop unroll(full)
+                for (int k = 0; k < c; ++k) s = fma(-x[k], Dpp[c * BLD + k], s);
+                x[c] = s * rinv[NB * p + c];
+            }
+#pragma clang loop unroll(full)
+            for (int c = 0; c < NB; ++c) row[c] = x[c];
+        }
+        __syncthreads();
+        if (dbg == 32) continue;
+        // trailing update: blocks (bi, bj), p < bj <= bi:  C -= P_bi P_bj^T
+        const int nout = m * (m + 1) / 2;
+        for (int o = wave; o < nout; o += nw) {
+            int ri = (int)((sqrtf(8.f * o + 1.f) - 1.f) * 0.5f);
+            while ((ri + 1) * (ri + 2) / 2 <= o) ++ri;
+            while (ri * (ri + 1) / 2 > o) --ri;
+            const int rj = o - ri * (ri + 1) / 2;
+            const int bi = p + 1 + ri, bj = p + 1 + rj;
+            double* C = blk + boff(bi, bj);
+            f64x4 acc = blk_load(C, lane);
+            blk_mma<true>(acc, blk + boff(bi, p), blk + boff(bj, p), lane, -1.0);
+            blk_store(C, acc, lane);
+        }
+        __syncthreads();
+    }
+}
+
+// X = L^-1 in place: off-diagonal blocks of blk become blocks of X, diagonal blocks of X live in dinv.
+__device__ __forceinline__ void invert_blocks(double* blk, double* dinv, double* tbuf, const double* rinv, int nbk,
+                              int tid, int nthreads) {
+    const int lane = tid & 63, wave = tid >> 6, nw = nthreads >> 6;
+    for (int b = wave; b < nbk; b += nw) diag_inverse(blk + boff(b, b), rinv + NB * b, dinv + (size_t)b * BLK, lane);
+    __syncthreads();
+    for (int s = 1; s < nbk; s *= 2) {
+        // stage 1: T_ij = sum_{k=j..aend-1} L_ik X_kj   (i in the B half, j in the A half of a 2s group)
+        for (int o = wave; o < nbk * nbk; o += nw) {
+            const int i = o / nbk, j = o - i * nbk;
+            if (i / (2 * s) != j / (2 * s) || (i % (2 * s)) < s || (j % (2 * s)) >= s) continue;
+            const int g = i / (2 * s), a0 = g * 2 * s, aend = a0 + s, b0 = aend;
+            f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+            for (int k = j; k < aend; ++k)
+                blk_mma<false>(acc, blk + boff(i, k), (k == j) ? dinv + (size_t)j * BLK : blk + boff(k, j), lane, 1.0);
+            blk_store(tbuf + (size_t)(g * s * s + (i - b0) * s + (j - a0)) * BLK, acc, lane);
+        }
+        __syncthreads();
+        // stage 2: X_ij = - sum_{k=b0..i} X_ik T_kj
+        for (int o = wave; o < nbk * nbk; o += nw) {
+            const int i = o / nbk, j = o - i * nbk;
+            if (i / (2 * s) != j / (2 * s) || (i % (2 * s)) < s || (j % (2 * s)) >= s) continue;
+            const int g = i / (2 * s), a0 = g * 2 * s, b0 = a0 + s;
+            f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+            for (int k = b0; k <= i; ++k)
+                blk_mma<false>(acc, (k == i) ? dinv + (size_t)i * BLK : blk + boff(i, k),
+                               tbuf + (size_t)(g * s * s + (k - b0) * s + (j - a0)) * BLK, lane, -1.0);
+            blk_store(blk + boff(i, j), acc, lane);
         }
         __syncthreads();
     }
@@ -129,52 +220,179 @@ __device__ void chol_blocked(double* A, int n, int ld, double* Linv, int ldi,
 
 extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
 
-// Gram (float64, from the float32-rounded scaled inducing inputs that Kuf also uses) + Cholesky.
-__global__ __launch_bounds__(1024) void k_kuu_chol(PreArgs args) {
-    const PreLayer& L = args.L[blockIdx.x];
+// element (i, k), k <= i, of the factor / of its inverse from block storage
+__device__ __forceinline__ double blk_get(const double* blk, int i, int k) {
+    return blk[boff(i >> 4, k >> 4) + (i & 15) * BLD + (k & 15)];
+}
+__device__ __forceinline__ double inv_get(const double* blk, const double* dinv, int i, int k) {
+    const int bi = i >> 4, bk = k >> 4;
+    return (bi == bk) ? dinv[(size_t)bi * BLK + (i & 15) * BLD + (k & 15)] : blk[boff(bi, bk) + (i & 15) * BLD + (k & 15)];
+}
+
+template <bool IN_LDS>
+__device__ void role_factor(const PreLayer& L, int stop_after) {
     const int tid = threadIdx.x, nthreads = blockDim.x;
     const int M = L.M, D = L.D, Mp = L.Mp;
+    const WsLayout w = ws_layout(Mp);
+    const int nbk = w.nbk;
+    // LDS carve: rinv [Mp] doubles | (IN_LDS: blocks, dinv, tbuf) | Zs copy [Mp][ZLD] floats
     double* sm = reinterpret_cast<double*>(smem_raw);
-    double* Dg = sm;
-    double* Di = Dg + NB * PLD;
-    double* P = Di + NB * PLD;
-    double* Alds = P + (size_t)(Mp - NB > 0 ? Mp - NB : 1) * PLD;
-    const bool in_lds = Mp <= 128;
-    double* A = in_lds ? Alds : L.Lm;
-    const int ld = Mp;
+    double* rinv = sm;
+    double* base = IN_LDS ? sm + Mp : L.ws;
+    double* blk = base + w.blk;
+    double* dinv = base + w.dinv;
+    double* tbuf = base + w.tbuf;
+    float* zs = reinterpret_cast<float*>(sm + Mp + (IN_LDS ? w.total : 0));
 
     for (int idx = tid; idx < Mp * 32; idx += nthreads) {
-        int m = idx >> 5, d = idx & 31;
+        const int m = idx >> 5, d = idx & 31;
         float v = 0.f;
         if (m < M && d < D) v = (float)((double)L.Z[(size_t)m * D + d] / (double)L.ls[d]);
         L.Zs[idx] = v;
+        zs[m * ZLD + d] = v;
     }
     if (tid < 32) L.invls[tid] = (tid < D) ? (float)(1.0 / (double)L.ls[tid]) : 0.f;
-    __syncthreads();   // Zs is read back below by other threads of this workgroup
-    for (int idx = tid; idx < Mp * Mp; idx += nthreads) {
-        int i = idx / Mp, j = idx % Mp;
-        if (j > i) { if (!in_lds) A[idx] = 0.0; else A[idx] = 0.0; continue; }
+    __syncthreads();
+    if (stop_after == 1) return;
+    // Gram of the float32-rounded scaled inducing inputs (the values K_uf also sees), lower blocks only
+    for (int idx = tid; idx < nbk * nbk * 256; idx += nthreads) {
+        const int b = idx >> 8, e = idx & 255;
+        const int bi = b / nbk, bj = b - bi * nbk;
+        if (bj > bi) continue;
+        const int i = NB * bi + (e >> 4), j = NB * bj + (e & 15);
         double v;
-        if (i >= M) v = (i == j) ? 1.0 : 0.0;           // identity padding
+        if (i >= M || j >= M) v = (i == j) ? 1.0 : 0.0;              // identity padding
         else {
             double r2 = 0.0;
             for (int d = 0; d < D; ++d) {
-                double df = (double)L.Zs[i * 32 + d] - (double)L.Zs[j * 32 + d];
-                r2 += df * df;
+                const double df = (double)zs[i * ZLD + d] - (double)zs[j * ZLD + d];
+                r2 = fma(df, df, r2);
             }
             v = kern_value(r2, L.kern_type, (double)L.variance);
             if (i == j) v += L.jitter;
         }
-        A[idx] = v;
+        blk[boff(bi, bj) + (e >> 4) * BLD + (e & 15)] = v;
     }
     __syncthreads();
-    chol_blocked(A, Mp, ld, L.Linv, Mp, Dg, Di, P, tid, nthreads);
-    if (in_lds) {
-        for (int idx = tid; idx < Mp * Mp; idx += nthreads) L.Lm[idx] = A[idx];
+    if (stop_after == 2) return;
+    chol_blocks(blk, nbk, rinv, tid, nthreads, stop_after);
+    if (stop_after == 3 || stop_after > 30) return;
+    for (int idx = tid; idx < Mp * Mp; idx += nthreads) {
+        const int i = idx / Mp, k = idx - i * Mp;
+        L.Lm[idx] = (k <= i) ? blk_get(blk, i, k) : 0.0;
+    }
+    __syncthreads();
+    if (stop_after == 4) return;
+    invert_blocks(blk, dinv, tbuf, rinv, nbk, tid, nthreads);
+    if (stop_after == 5) return;
+    for (int idx = tid; idx < Mp * Mp; idx += nthreads) {
+        const int i = idx / Mp, k = idx - i * Mp;
+        L.Linv[idx] = (k <= i) ? inv_get(blk, dinv, i, k) : 0.0;
+    }
+    // MFMA-fragment packed float32 Lm^-1 (blocks bi >= bk), identity padding masked to zero
+    const int nb = L.nb;
+    for (int idx = tid; idx < nb * nb * 1024; idx += nthreads) {
+        const int b = idx >> 10, e1 = idx & 1023;
+        const int bi = b / nb, bk = b - bi * nb;
+        if (bk > bi) continue;
+        const int q = e1 >> 8, lane = (e1 >> 2) & 63, e = e1 & 3;
+        const int i = 32 * bi + (lane & 31), k = 32 * bk + 8 * q + 4 * (lane >> 5) + e;
+        float v = 0.f;
+        if (i < M && k < M && k <= i) v = (float)inv_get(blk, dinv, i, k);
+        L.LinvP[idx] = v;
     }
 }
 
-// standalone Gram / Cholesky entry points (K1, K2) reuse the same device code
+__device__ __forceinline__ double block_sum(double v, double* red) {
+    red[threadIdx.x] = v;
+    __syncthreads();
+    for (int s = blockDim.x / 2; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    return red[0];
+}
+
+// Role r+1: pack tril(q_sqrt[r])^T into MFMA fragment order (blocks bi <= bk) and, from the same values,
+// this latent GP's share of the whitened KL:  kl[r] = 1/2 (|q_mu[:,r]|^2 - M - sum log L_ii^2 + |tril L|^2).
+// One float4 of the packed image per thread-iteration: 4 coalesced row reads, one 16-byte store.
+// Role 1 also packs q_mu^T (R rows padded to 32) for the mean jobs.
+__device__ void role_pack_r(const PreLayer& L, int r, double* red) {
+    const int nb = L.nb, M = L.M, R = L.R;
+    const float* q = L.q_sqrt + (size_t)r * M * M;
+    float4* dstm = reinterpret_cast<float4*>(L.LrTP + (size_t)r * nb * nb * 1024);
+    double acc = 0.0;
+    const int nvec = nb * nb * 256;
+    for (int v4 = threadIdx.x; v4 < nvec; v4 += blockDim.x) {
+        const int b = v4 >> 8, bi = b / nb, bk = b - bi * nb;
+        if (bi > bk) continue;
+        const int qq = (v4 >> 6) & 3, lane = v4 & 63;
+        const int i = 32 * bi + (lane & 31);
+        const int k0 = 32 * bk + 8 * qq + 4 * (lane >> 5);
+        float o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int k = k0 + e;                      // (L_r^T)[i][k] = L_r[k][i], non-zero for k >= i
+            float x = 0.f;
+            if (i < M && k < M && k >= i) x = q[(size_t)k * M + i];
+            o[e] = x;
+            acc += (double)x * (double)x;
+            if (k == i && i < M) acc -= log((double)x * (double)x);
+        }
+        dstm[v4] = make_float4(o[0], o[1], o[2], o[3]);
+    }
+    for (int m = threadIdx.x; m < M; m += blockDim.x) {
+        const double v = L.q_mu[(size_t)m * R + r];
+        acc += v * v;
+    }
+    if (r == 0) {
+        float4* dq = reinterpret_cast<float4*>(L.QmuP);
+        for (int v4 = threadIdx.x; v4 < nb * 256; v4 += blockDim.x) {
+            const int bk = v4 >> 8, qq = (v4 >> 6) & 3, lane = v4 & 63;
+            const int rr = lane & 31, k0 = 32 * bk + 8 * qq + 4 * (lane >> 5);
+            float o[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (rr < R && k0 + e < M) ? L.q_mu[(size_t)(k0 + e) * R + rr] : 0.f;
+            dq[v4] = make_float4(o[0], o[1], o[2], o[3]);
+        }
+    }
+    const double tot = block_sum(acc, red);
+    if (threadIdx.x == 0) L.kl[r] = 0.5 * (tot - (double)M);
+}
+
+// standalone whitened KL (iwvi_gauss_kl): sum over all R
+__device__ void role_kl_only(const float* q_mu, const float* q_sqrt, int M, int R, double* kl, double* red) {
+    double acc = 0.0;
+    for (size_t idx = threadIdx.x; idx < (size_t)M * R; idx += blockDim.x) { double v = q_mu[idx]; acc += v * v; }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    for (int row = wave; row < R * M; row += nw) {
+        const int i = row % M;
+        const float* q = q_sqrt + (size_t)row * M;
+        for (int j = lane; j <= i; j += 64) {
+            double v = q[j];
+            acc += v * v;
+            if (j == i) acc -= log(v * v);
+        }
+    }
+    const double tot = block_sum(acc, red);
+    if (threadIdx.x == 0) *kl = 0.5 * (tot - (double)M * R);
+}
+
+__global__ __launch_bounds__(1024) void k_precompute(PreArgs args) {
+    const PreLayer& L = args.L[blockIdx.x];
+    const int role = blockIdx.y;
+    if (role == 0) {
+        if (L.Mp <= 128) role_factor<true>(L, args.stop_after); else role_factor<false>(L, args.stop_after);
+    } else if (role <= L.R) {
+        role_pack_r(L, role - 1, reinterpret_cast<double*>(smem_raw));
+    }
+}
+
+__global__ __launch_bounds__(256) void k_gauss_kl(const float* q_mu, const float* q_sqrt, int M, int R,
+                                                   double* kl) {
+    role_kl_only(q_mu, q_sqrt, M, R, kl, reinterpret_cast<double*>(smem_raw));
+}
+
 __global__ void k_gram_sym(const float* Z, const float* ls, float variance, double jitter, int type,
                            int M, int D, double* K) {
     for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < (size_t)M * M;
@@ -192,165 +410,26 @@ __global__ void k_gram_sym(const float* Z, const float* ls, float variance, doub
     }
 }
 
-__global__ __launch_bounds__(1024) void k_chol_only(double* A, int M, double* scratch_inv) {
-    // A [M x M] row-major, M multiple of 16 handled by caller via padded copy in `scratch`
-    double* sm = reinterpret_cast<double*>(smem_raw);
-    double* Dg = sm;
-    double* Di = Dg + NB * PLD;
-    double* P = Di + NB * PLD;
-    chol_blocked(A, M, M, scratch_inv, M, Dg, Di, P, threadIdx.x, blockDim.x);
-}
 
-__global__ void k_pad_copy(const double* src, int M, double* dst, int Mp) {
-    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < (size_t)Mp * Mp;
-         idx += (size_t)gridDim.x * blockDim.x) {
-        int i = idx / Mp, j = idx % Mp;
-        dst[idx] = (i < M && j < M) ? src[(size_t)i * M + j] : ((i == j) ? 1.0 : 0.0);
+// standalone Cholesky (K2): dense A -> block storage in ws -> factor -> dense lower L
+__global__ __launch_bounds__(1024) void k_chol_only(const double* A, double* Lout, int M, int Mp, double* ws) {
+    const int tid = threadIdx.x, nthreads = blockDim.x;
+    const int nbk = Mp / NB;
+    double* rinv = reinterpret_cast<double*>(smem_raw);
+    double* blk = ws;
+    for (int idx = tid; idx < nbk * nbk * 256; idx += nthreads) {
+        const int b = idx >> 8, e = idx & 255;
+        const int bi = b / nbk, bj = b - bi * nbk;
+        if (bj > bi) continue;
+        const int i = NB * bi + (e >> 4), j = NB * bj + (e & 15);
+        blk[boff(bi, bj) + (e >> 4) * BLD + (e & 15)] = (i < M && j < M) ? A[(size_t)i * M + j] : ((i == j) ? 1.0 : 0.0);
     }
-}
-__global__ void k_unpad_copy(const double* src, int Mp, double* dst, int M) {
-    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < (size_t)M * M;
-         idx += (size_t)gridDim.x * blockDim.x) {
-        int i = idx / M, j = idx % M;
-        dst[idx] = (j <= i) ? src[(size_t)i * Mp + j] : 0.0;
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// k_inv_pack roles (blockIdx.y): [0, nb) inverse column block; [nb, nb+R) LrT pack; nb+R: q_mu + KL
-// ---------------------------------------------------------------------------------------------
-constexpr int XLD = 33;   // leading dimension of the LDS column buffer (doubles)
-
-__device__ void role_inverse(const PreLayer& L, int jb, double* X, double* S) {
-    const int tid = threadIdx.x;
-    const int Mp = L.Mp, M = L.M;
-    const int cbase = 32 * jb;
-    const int r = tid >> 4, c2 = tid & 15;            // 16 rows x (2 x 16 columns)
-    // rows above the column block are zero
-    for (int idx = tid; idx < Mp * 32; idx += blockDim.x) X[(idx >> 5) * XLD + (idx & 31)] = 0.0;
     __syncthreads();
-    for (int ib = 2 * jb; ib < Mp / NB; ++ib) {
-        const int row = NB * ib + r;
-        double s0 = (row == cbase + c2) ? 1.0 : 0.0;
-        double s1 = (row == cbase + c2 + 16) ? 1.0 : 0.0;
-        const double* lrow = L.Lm + (size_t)row * Mp;
-        for (int kk = cbase; kk < NB * ib; ++kk) {
-            double l = lrow[kk];
-            s0 -= l * X[kk * XLD + c2];
-            s1 -= l * X[kk * XLD + c2 + 16];
-        }
-        S[r * XLD + c2] = s0;
-        S[r * XLD + c2 + 16] = s1;
-        __syncthreads();
-        // X_ib = Dinv_ib * S   (Dinv_ib = lower 16x16 block of Linv on the diagonal)
-        const double* dinv = L.Linv + (size_t)(NB * ib + r) * Mp + NB * ib;
-        double x0 = 0.0, x1 = 0.0;
-        for (int t = 0; t <= r; ++t) {
-            double dv = dinv[t];
-            x0 += dv * S[t * XLD + c2];
-            x1 += dv * S[t * XLD + c2 + 16];
-        }
-        X[row * XLD + c2] = x0;
-        X[row * XLD + c2 + 16] = x1;
-        __syncthreads();
+    chol_blocks(blk, nbk, rinv, tid, nthreads);
+    for (int idx = tid; idx < M * M; idx += nthreads) {
+        const int i = idx / M, k = idx - i * M;
+        Lout[idx] = (k <= i) ? blk_get(blk, i, k) : 0.0;
     }
-    // write the float64 inverse (lower triangle of this column block; the 16x16 diagonal blocks were
-    // already written by k_kuu_chol and are rewritten with identical values)
-    for (int idx = tid; idx < Mp * 32; idx += blockDim.x) {
-        int i = idx >> 5, c = idx & 31;
-        L.Linv[(size_t)i * Mp + cbase + c] = (cbase + c <= i) ? X[i * XLD + c] : 0.0;
-    }
-    // pack blocks (bi >= jb, bk = jb) as float32, masking the identity padding to zero
-    const int nb = L.nb;
-    for (int bi = jb; bi < nb; ++bi) {
-        float* dst = L.LinvP + (size_t)(bi * nb + jb) * 1024;
-        for (int idx = tid; idx < 1024; idx += blockDim.x) {
-            int q = idx >> 8, lane = (idx >> 2) & 63, e = idx & 3;
-            int i = 32 * bi + (lane & 31);
-            int kc = 8 * q + 4 * (lane >> 5) + e;
-            float v = 0.f;
-            if (i < M && cbase + kc < M && cbase + kc <= i) v = (float)X[i * XLD + kc];
-            dst[idx] = v;
-        }
-    }
-}
-
-__device__ void role_pack_LrT(const PreLayer& L, int r) {
-    const int nb = L.nb, M = L.M;
-    const float* q = L.q_sqrt + (size_t)r * M * M;
-    float* base = L.LrTP + (size_t)r * nb * nb * 1024;
-    for (int bi = 0; bi < nb; ++bi)
-        for (int bk = bi; bk < nb; ++bk) {
-            float* dst = base + (size_t)(bi * nb + bk) * 1024;
-            for (int idx = threadIdx.x; idx < 1024; idx += blockDim.x) {
-                int qq = idx >> 8, lane = (idx >> 2) & 63, e = idx & 3;
-                int i = 32 * bi + (lane & 31);
-                int k = 32 * bk + 8 * qq + 4 * (lane >> 5) + e;
-                // (L_r^T)[i][k] = L_r[k][i], non-zero for k >= i
-                float v = 0.f;
-                if (i < M && k < M && k >= i) v = q[(size_t)k * M + i];
-                dst[idx] = v;
-            }
-        }
-}
-
-__device__ void role_qmu_kl(const PreLayer& L, double* red) {
-    const int nb = L.nb, M = L.M, R = L.R;
-    for (int bk = 0; bk < nb; ++bk) {
-        float* dst = L.QmuP + (size_t)bk * 1024;
-        for (int idx = threadIdx.x; idx < 1024; idx += blockDim.x) {
-            int qq = idx >> 8, lane = (idx >> 2) & 63, e = idx & 3;
-            int r = lane & 31;
-            int k = 32 * bk + 8 * qq + 4 * (lane >> 5) + e;
-            float v = 0.f;
-            if (r < R && k < M) v = L.q_mu[(size_t)k * R + r];
-            dst[idx] = v;
-        }
-    }
-    // KL = 0.5 * ( sum q_mu^2 - M R - sum log diag(L)^2 + sum tril(L)^2 )
-    double acc = 0.0;
-    for (size_t idx = threadIdx.x; idx < (size_t)M * R; idx += blockDim.x) {
-        double v = L.q_mu[idx];
-        acc += v * v;
-    }
-    for (size_t idx = threadIdx.x; idx < (size_t)R * M * M; idx += blockDim.x) {
-        int rc = idx % ((size_t)M * M);
-        int i = rc / M, j = rc % M;
-        if (j > i) continue;
-        double v = L.q_sqrt[idx];
-        acc += v * v;
-        if (i == j) acc -= log(v * v);
-    }
-    red[threadIdx.x] = acc;
-    __syncthreads();
-    for (int s = blockDim.x / 2; s > 0; s >>= 1) {
-        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) *L.kl = 0.5 * (red[0] - (double)M * R);
-}
-
-__global__ __launch_bounds__(256) void k_inv_pack(PreArgs args) {
-    const PreLayer& L = args.L[blockIdx.x];
-    const int role = blockIdx.y;
-    double* sm = reinterpret_cast<double*>(smem_raw);
-    if (role < L.nb) {
-        double* S = sm;
-        double* X = sm + NB * XLD;
-        role_inverse(L, role, X, S);
-    } else if (role < L.nb + L.R) {
-        role_pack_LrT(L, role - L.nb);
-    } else if (role == L.nb + L.R) {
-        role_qmu_kl(L, sm);
-    }
-}
-
-__global__ __launch_bounds__(256) void k_gauss_kl(const float* q_mu, const float* q_sqrt, int M, int R,
-                                                   double* kl) {
-    PreLayer L{};
-    L.q_mu = q_mu; L.q_sqrt = q_sqrt; L.M = M; L.R = R; L.nb = 0; L.kl = kl;
-    double* sm = reinterpret_cast<double*>(smem_raw);
-    role_qmu_kl(L, sm);
 }
 
 static int ensure_lds_attr(const void* fn, size_t bytes) {
@@ -370,10 +449,11 @@ static int ensure_lds_attr(const void* fn, size_t bytes) {
     return IWVI_OK;
 }
 
-static size_t chol_lds_bytes(int Mp) {
-    size_t d = 2 * NB * PLD + (size_t)(Mp - NB > 0 ? Mp - NB : 1) * PLD;
-    if (Mp <= 128) d += (size_t)Mp * Mp;
-    return d * sizeof(double);
+
+static size_t factor_lds_bytes(int Mp) {
+    size_t d = (size_t)Mp;                                   // rinv
+    if (Mp <= 128) d += ws_layout(Mp).total;                 // blocks + dinv + tbuf resident in LDS
+    return d * sizeof(double) + (size_t)Mp * ZLD * sizeof(float);
 }
 
 }  // namespace iwvi
@@ -399,7 +479,8 @@ extern "C" int iwvi_gp_precompute(const iwvi_gp_desc* layers, int n_layers, void
     for (int base = 0; base < n_layers; base += IWVI_MAX_LAYERS) {
         PreArgs a{};
         a.n = n_layers - base < IWVI_MAX_LAYERS ? n_layers - base : IWVI_MAX_LAYERS;
-        size_t lds_a = 0, lds_b = 0;
+        { const char* e = getenv("IWVI_DEBUG_STOP"); a.stop_after = e ? atoi(e) : 0; }
+        size_t lds = 1024 * sizeof(double);
         int max_roles = 0;
         for (int l = 0; l < a.n; ++l) {
             const iwvi_gp_desc& d = layers[base + l];
@@ -423,22 +504,17 @@ extern "C" int iwvi_gp_precompute(const iwvi_gp_desc* layers, int n_layers, void
             L.QmuP = (float*)(st + s.off_QmuP); L.Zs = (float*)(st + s.off_Zs);
             L.invls = (float*)(st + s.off_invls);
             L.kl = (double*)(st + s.off_kl);
+            L.ws = (double*)(st + s.off_ws);
             L.jitter = d.jitter; L.variance = d.variance;
             L.M = d.M; L.D = d.D; L.R = d.R; L.Mp = s.Mp; L.nb = s.nb; L.kern_type = d.kern_type;
-            size_t la = chol_lds_bytes(s.Mp);
-            size_t lb = sizeof(double) * ((size_t)NB * XLD + (size_t)s.Mp * XLD);
-            if (lb < 256 * sizeof(double)) lb = 256 * sizeof(double);
-            if (la > lds_a) lds_a = la;
-            if (lb > lds_b) lds_b = lb;
-            if (s.nb + d.R + 1 > max_roles) max_roles = s.nb + d.R + 1;
+            size_t la = factor_lds_bytes(s.Mp);
+            if (la > lds) lds = la;
+            if (d.R + 1 > max_roles) max_roles = d.R + 1;
         }
         int rc;
-        if ((rc = ensure_lds_attr((const void*)k_kuu_chol, lds_a)) != IWVI_OK) return rc;
-        if ((rc = ensure_lds_attr((const void*)k_inv_pack, lds_b)) != IWVI_OK) return rc;
-        hipLaunchKernelGGL(k_kuu_chol, dim3(a.n), dim3(1024), lds_a, stream, a);
-        if ((rc = check_launch("k_kuu_chol")) != IWVI_OK) return rc;
-        hipLaunchKernelGGL(k_inv_pack, dim3(a.n, max_roles), dim3(256), lds_b, stream, a);
-        if ((rc = check_launch("k_inv_pack")) != IWVI_OK) return rc;
+        if ((rc = ensure_lds_attr((const void*)k_precompute, lds)) != IWVI_OK) return rc;
+        hipLaunchKernelGGL(k_precompute, dim3(a.n, max_roles), dim3(1024), lds, stream, a);
+        if ((rc = check_launch("k_precompute")) != IWVI_OK) return rc;
     }
     return IWVI_OK;
 }
@@ -458,24 +534,17 @@ extern "C" int iwvi_rbf_gram_sym(const float* Z, const float* ls, float variance
 
 extern "C" size_t iwvi_chol_ws_bytes(int M) {
     if (M <= 0) return 0;
-    size_t Mp = (size_t)round_up(M, NB);
-    return 2 * Mp * Mp * sizeof(double);
+    return ws_layout(round_up(M, NB)).total * sizeof(double);
 }
 
 extern "C" int iwvi_chol_factor(const double* A, double* Lout, int M, void* ws, void* stream_) {
     if (!A || !Lout || !ws || M <= 0) { set_error("iwvi_chol_factor: bad argument"); return IWVI_ERR_ARG; }
-    if (M > 2048) { set_error("iwvi_chol_factor: M=%d too large (max 2048)", M); return IWVI_ERR_ARG; }
-    hipStream_t stream = (hipStream_t)stream_;
+    if (M > 1024) { set_error("iwvi_chol_factor: M=%d too large (max 1024)", M); return IWVI_ERR_ARG; }
     const int Mp = round_up(M, NB);
-    double* Ap = (double*)ws;
-    double* Ip = Ap + (size_t)Mp * Mp;       // receives the 16x16 diagonal-block inverses (by-product)
-    size_t lds = sizeof(double) * (2 * NB * PLD + (size_t)(Mp - NB > 0 ? Mp - NB : 1) * PLD);
+    size_t lds = sizeof(double) * (size_t)Mp;
     int rc;
     if ((rc = ensure_lds_attr((const void*)k_chol_only, lds)) != IWVI_OK) return rc;
-    int grid = (int)(((size_t)Mp * Mp + 255) / 256); if (grid > 1024) grid = 1024;
-    hipLaunchKernelGGL(k_pad_copy, dim3(grid), dim3(256), 0, stream, A, M, Ap, Mp);
-    hipLaunchKernelGGL(k_chol_only, dim3(1), dim3(1024), lds, stream, Ap, Mp, Ip);
-    hipLaunchKernelGGL(k_unpad_copy, dim3(grid), dim3(256), 0, stream, (const double*)Ap, Mp, Lout, M);
+    hipLaunchKernelGGL(k_chol_only, dim3(1), dim3(1024), lds, (hipStream_t)stream_, A, Lout, M, Mp, (double*)ws);
     return check_launch("k_chol_only");
 }
 

@@ -88,7 +88,7 @@ class GPLayer:
         return self.state().kl
 
     # -- reference API --------------------------------------------------------------------
-    def propagate(self, F, full_cov=False, z=None, _precomputed=False, **kwargs):
+    def propagate(self, F, full_cov=False, z=None, _precomputed=False, _kl_parts=False, **kwargs):
         """reference layers.py:35-50 -> (samples, mean, cov, kl)."""
         if not _precomputed:
             self.precompute()
@@ -97,7 +97,9 @@ class GPLayer:
         samples, mean, cov = multisample_sample_conditional(
             F, self.feature, self.kern, self.q_mu, full_cov=full_cov, q_sqrt=self.q_sqrt, white=True,
             z=z, state=self.state(), mean_function=mf, precomputed=True)
-        kl = self.kl                                               # layers.py:44 (computed by the precompute)
+        # layers.py:44 (computed by the precompute); _kl_parts hands the model the R per-GP shares
+        # so that the ELBO reduction sums them without an extra launch
+        kl = self.state().kl_parts if _kl_parts else self.kl
         if plain_full and self.mean_function.mf_type != _abi.MF_ZERO:
             m = self.mean_function
             add = F if m.mf_type == _abi.MF_IDENTITY else F @ m.A + m.b

@@ -68,7 +68,7 @@ class DGP_VI:
         precompute_states([l.state_desc() for l in self.layers if isinstance(l, GPLayer)])
 
     def propagate(self, X, full_cov=False, inference_amorization_inputs=None,
-                  is_sampled_local_regularizer=False, zs=None, _precomputed=False):
+                  is_sampled_local_regularizer=False, zs=None, _precomputed=False, _kl_parts=False):
         """reference models.py:31-46 -> (samples[1:], means, covs, kls, kl_types)."""
         if not _precomputed:
             self.precompute()
@@ -80,7 +80,7 @@ class DGP_VI:
             sample, mean, cov, kl = layer.propagate(samples[-1], full_cov=full_cov,
                                                     inference_amorization_inputs=inference_amorization_inputs,
                                                     is_sampled_local_regularizer=is_sampled_local_regularizer,
-                                                    z=z, _precomputed=True)
+                                                    z=z, _precomputed=True, _kl_parts=_kl_parts)
             samples.append(sample)
             means.append(mean)
             covs.append(cov)
@@ -100,16 +100,15 @@ class DGP_VI:
         if len(kls) > _abi.MAX_KL:
             raise ValueError("more than %d latent-variable layers" % _abi.MAX_KL)
         kl_dims = (ctypes.c_int32 * max(len(kls), 1))(*[k.shape[-1] for k in kls])
-        glob = [g.reshape(1) for g in global_kls]
-        for g in glob:
-            _abi.dev_tensor(g, "global kl", torch.float64)
+        glob = [_abi.dev_tensor(g.reshape(-1), "global kl", torch.float64) for g in global_kls]
+        glob_n = (ctypes.c_int32 * max(len(glob), 1))(*[g.numel() for g in glob])
         logp = torch.empty(B, dtype=settings.float_type, device=dev)
         elbo = torch.empty(1, dtype=torch.float64, device=dev)
         ms = torch.empty(B, 2, dtype=settings.float_type, device=dev) if want_ms else None
         scale = float(self.num_data) / float(B)                        # models.py:80-81, :144-145
         _abi.check(_abi.lib().iwvi_iw_elbo_reduce(
             _abi.ptr(fmean), _abi.ptr(fvar), _abi.ptr(Y), self.likelihood.variance, B, K, Dy,
-            stride_b, stride_k, _abi.ptr_array(kls), kl_dims, len(kls), _abi.ptr_array(glob), len(glob),
+            stride_b, stride_k, _abi.ptr_array(kls), kl_dims, len(kls), _abi.ptr_array(glob), glob_n, len(glob),
             scale, K_total or K, 1 if mode_vi else 0, _abi.ptr(ms), _abi.ptr(logp), _abi.ptr(elbo),
             _abi.stream_ptr()))
         return elbo[0], logp, ms
@@ -122,7 +121,7 @@ class DGP_VI:
         XY = torch.cat([X_tiled, Y_tiled], -1)                         # :53
         _, means, covs, kls, kl_types = self.propagate(X_tiled, full_cov=False,
                                                        inference_amorization_inputs=XY,
-                                                       is_sampled_local_regularizer=False, zs=zs)
+                                                       is_sampled_local_regularizer=False, zs=zs, _kl_parts=True)
         local_kls = [kl for kl, t in zip(kls, kl_types) if t is RegularizerType.LOCAL]
         global_kls = [kl for kl, t in zip(kls, kl_types) if t is RegularizerType.GLOBAL]
         elbo, _, _ = self._reduce(means[-1], covs[-1], self.Y, local_kls, global_kls, N, S,
@@ -168,7 +167,7 @@ class DGP_IWVI(DGP_VI):
         XY = torch.cat([X_tiled, Y_tiled], -1)                                       # :116
         samples, means, covs, kls, kl_types = self.propagate(
             X_tiled, full_cov=self.full_cov_over_samples, inference_amorization_inputs=XY,
-            is_sampled_local_regularizer=True, zs=zs)                                # :122-125
+            is_sampled_local_regularizer=True, zs=zs, _kl_parts=True)                # :122-125
         local_kls = [kl for kl, t in zip(kls, kl_types) if t is RegularizerType.LOCAL]
         global_kls = [kl for kl, t in zip(kls, kl_types) if t is RegularizerType.GLOBAL]
         cov = covs[-1]

@@ -60,9 +60,14 @@ class GpState:
         return self.buf[off:off + nbytes].view(dtype)
 
     @property
+    def kl_parts(self):
+        """[R] float64 device tensor: each latent GP's share of KL[q(u) || p(u)] (last precompute)."""
+        return self.view("kl", torch.float64, self.R)
+
+    @property
     def kl(self):
         """0-dim float64 device tensor: KL[q(u) || p(u)] of the last precompute."""
-        return self.view("kl", torch.float64, 1)[0]
+        return self.kl_parts.sum()
 
     @property
     def Lm(self):

@@ -67,7 +67,9 @@ const char* iwvi_last_error(void);
  *   float   QmuP [nb*1024]         q_mu^T (R rows padded to 32), packed
  *   float   Zs   [Mp*32]           Z / lengthscales, rows padded to 32 floats
  *   float   invls[32]              1 / lengthscales (0 beyond D)
- *   double  kl   [1]               KL[q(u) || p(u)], whitened, summed over R
+ *   double  kl   [IWVI_MAX_R]      kl[r] = latent GP r's share of the whitened KL[q(u) || p(u)]
+ *                                  (the layer's KL is the sum of the first R entries)
+ *   double  ws   [...]             factorisation workspace (16x16 blocks of the lower triangle)
  * iwvi_gp_state_bytes() returns the size; offsets via iwvi_gp_state_offsets().
  * ---------------------------------------------------------------------- */
 typedef struct iwvi_gp_desc {
@@ -86,7 +88,8 @@ size_t iwvi_gp_state_bytes(int M, int R);
 /* offsets (bytes) of {Lm, Linv, LinvP, LrTP, QmuP, Zs, invls, kl} inside the state buffer */
 int iwvi_gp_state_offsets(int M, int R, size_t out_host[8]);
 
-/* factorise up to IWVI_MAX_LAYERS layers in two launches (Kuu+Cholesky, inverse+pack) */
+/* factorise up to IWVI_MAX_LAYERS layers per launch: grid (layer, role) -- role 0 Gram + Cholesky +
+ * triangular inverse + packing, roles 1..R tril(q_sqrt[r])^T packing + KL share */
 int iwvi_gp_precompute(const iwvi_gp_desc* layers_host, int n_layers, void* stream);
 
 /* K1: Kuu(feat, kern, jitter) in float64 (temp_workaround.py:39)  -> Kuu [M, M] double */
@@ -151,7 +154,8 @@ int iwvi_lv_layer_forward(const float* F, const float* XY, const float* noise,
  *                (IW tiling [B,K,Dy]: stride_b = K, stride_k = 1; VI tiling [S*N,Dy]: 1, N);
  *                fvar = diagonal variances;  Y [B, Dy]
  *   kl_local[i] rows of kl_dims[i] floats, same row indexing, for i < n_kl
- *   kl_global[i]: pointers to double scalars (state.kl of each GP layer), n_glob of them
+ *   kl_global[i]: pointer to kl_global_counts[i] doubles (state.kl of GP layer i: its R KL shares;
+ *                 counts NULL -> 1 each), n_glob of them
  *   out_lse_ms [B, 2] = (max_k L, sum_k exp(L - max)) per point, for K-sharded merging
  *   out_logp   [B]     logsumexp - log(K_total)   (K_total = K when not sharded)
  *   out_elbo   [1] double = sum(logp) * scale - sum(kl_global)
@@ -161,15 +165,15 @@ int iwvi_iw_elbo_reduce(const float* fmean, const float* fvar, const float* Y,
                         float lik_variance, int64_t B, int K, int Dy,
                         int64_t stride_b, int64_t stride_k,
                         const float* const* kl_local_host, const int32_t* kl_dims_host, int n_kl,
-                        const double* const* kl_global_host, int n_glob,
+                        const double* const* kl_global_host, const int32_t* kl_global_counts_host, int n_glob,
                         double scale, int K_total, int mode_vi,
                         float* out_lse_ms, float* out_logp, double* out_elbo, void* stream);
 
 /* Merge K-sharded partials after the RCCL exchange (not in the reference):
  *   ms_all [G, B, 2] gathered (max, sumexp) pairs -> logp [B], elbo [1] as above. */
 int iwvi_lse_merge(const float* ms_all, int G, int64_t B, int K_total,
-                   const double* const* kl_global_host, int n_glob, double scale,
-                   float* out_logp, double* out_elbo, void* stream);
+                   const double* const* kl_global_host, const int32_t* kl_global_counts_host, int n_glob,
+                   double scale, float* out_logp, double* out_elbo, void* stream);
 
 /* whitened gauss_kl alone (temp_workaround.py:186-188), K14: -> kl [1] double */
 int iwvi_gauss_kl(const float* q_mu, const float* q_sqrt, int M, int R, double* kl, void* stream);
