@@ -45,19 +45,19 @@ PROTOTYPES = {
     "iwvi_chol_factor": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "iwvi_gp_layer_forward": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_float,
                                       c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
-                                      c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+                                      c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     "iwvi_gp_fullcov_ws_bytes": (c_size_t, [c_int64, c_int, c_int]),
     "iwvi_gp_layer_fullcov": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p,
                                       c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "iwvi_lv_layer_forward": (c_int, [c_void_p, c_void_p, c_void_p, ctypes.POINTER(c_void_p),
                                       ctypes.POINTER(c_void_p), ctypes.POINTER(ctypes.c_int32), c_int,
                                       c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
-                                      c_int64, c_void_p]),
+                                      c_int64, c_int, c_int, c_void_p]),
     "iwvi_iw_elbo_reduce": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_int64, c_int, c_int,
                                     c_int64, c_int64,
                                     ctypes.POINTER(c_void_p), ctypes.POINTER(ctypes.c_int32), c_int,
                                     ctypes.POINTER(c_void_p), ctypes.POINTER(ctypes.c_int32), c_int, c_double,
-                                    c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+                                    c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "iwvi_lse_merge": (c_int, [c_void_p, c_int, c_int64, c_int, ctypes.POINTER(c_void_p),
                                ctypes.POINTER(ctypes.c_int32), c_int, c_double, c_void_p, c_void_p, c_void_p]),
     "iwvi_gauss_kl": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),

@@ -29,7 +29,7 @@ struct LayerArgs {
     float* sample; float* mean; float* var;
     float* a_out; float* u_out;          // optional [T, Mp] / [R, T, Mp] (full-covariance path only)
     long long T;
-    int M, Mp, nb, D, R, P, kern_type, mf_type;
+    int M, Mp, nb, D, R, P, kern_type, mf_type, bcast_K;
     float variance;
     const float* invls;                  // [32] 1/lengthscale (state buffer)
 };
@@ -110,7 +110,7 @@ __global__ __launch_bounds__(256) void k_gp_layer(LayerArgs g) {
     for (int idx = tid; idx < 32 * 32; idx += blockDim.x) {
         int jj = idx >> 5, d = idx & 31;
         long long t = t0 + jj;
-        xraw[idx] = (t < g.T && d < D) ? g.F[t * D + d] : 0.f;
+        xraw[idx] = (t < g.T && d < D) ? g.F[(t / g.bcast_K) * D + d] : 0.f;
     }
     if (tid < 4) counters[tid] = 0;
     __syncthreads();
@@ -300,7 +300,7 @@ static int layer_forward_impl(const void* state, int M, int D, int R, int P, int
                               const float* F, const float* noise, const float* W,
                               int mf_type, const float* mf_A, const float* mf_b,
                               float* sample, float* mean, float* var, float* a_out, float* u_out,
-                              int64_t T, hipStream_t stream) {
+                              int64_t T, int bcast_K, hipStream_t stream) {
     if (T <= 0) return IWVI_OK;                         // empty batch: nothing to do
     if (!state || !F) { set_error("iwvi_gp_layer_forward: null state or input"); return IWVI_ERR_ARG; }
     if (M <= 0 || M > IWVI_MAX_M || D <= 0 || D > IWVI_MAX_D || R <= 0 || R > IWVI_MAX_R || P <= 0 || P > IWVI_MAX_P) {
@@ -311,6 +311,7 @@ static int layer_forward_impl(const void* state, int M, int D, int R, int P, int
     if (mf_type == IWVI_MF_LINEAR && !mf_A) { set_error("iwvi_gp_layer_forward: Linear mean function without A"); return IWVI_ERR_ARG; }
     if (mf_type < IWVI_MF_ZERO || mf_type > IWVI_MF_LINEAR) { set_error("iwvi_gp_layer_forward: unknown mean function %d", mf_type); return IWVI_ERR_UNSUPPORTED; }
     if (kern_type != IWVI_KERN_RBF && kern_type != IWVI_KERN_MATERN52) { set_error("iwvi_gp_layer_forward: unknown kernel type %d", kern_type); return IWVI_ERR_UNSUPPORTED; }
+    if (bcast_K < 1 || T % bcast_K != 0) { set_error("iwvi_gp_layer_forward: T=%lld is not a multiple of bcast_K=%d", (long long)T, bcast_K); return IWVI_ERR_ARG; }
     if ((T + 31) / 32 > 0x7fffffffLL) { set_error("iwvi_gp_layer_forward: T too large"); return IWVI_ERR_ARG; }
     StateLayout s = state_layout(M, R);
     const char* st = (const char*)state;
@@ -321,7 +322,7 @@ static int layer_forward_impl(const void* state, int M, int D, int R, int P, int
     g.F = F; g.noise = noise; g.W = W; g.mfA = mf_A; g.mfb = mf_b;
     g.sample = sample; g.mean = mean; g.var = var; g.a_out = a_out; g.u_out = u_out;
     g.T = T; g.M = M; g.Mp = s.Mp; g.nb = s.nb; g.D = D; g.R = R; g.P = P;
-    g.kern_type = kern_type; g.mf_type = mf_type; g.variance = variance;
+    g.kern_type = kern_type; g.mf_type = mf_type; g.variance = variance; g.bcast_K = bcast_K;
     size_t lds = layer_lds_floats(s.Mp, s.nb, R) * sizeof(float);
     if (lds > 160 * 1024) { set_error("iwvi_gp_layer_forward: M=%d, R=%d needs %zu B of LDS (> 160 KiB)", M, R, lds); return IWVI_ERR_UNSUPPORTED; }
     if (D <= 4) return launch_layer<4>(g, lds, stream);
@@ -339,9 +340,9 @@ using namespace iwvi;
 extern "C" int iwvi_gp_layer_forward(const void* state, int M, int D, int R, int P, int kern_type, float variance,
                                      const float* F, const float* noise, const float* W,
                                      int mf_type, const float* mf_A, const float* mf_b,
-                                     float* sample, float* mean, float* var, int64_t T, void* stream) {
+                                     float* sample, float* mean, float* var, int64_t T, int bcast_K, void* stream) {
     return layer_forward_impl(state, M, D, R, P, kern_type, variance, F, noise, W, mf_type, mf_A, mf_b,
-                              sample, mean, var, nullptr, nullptr, T, (hipStream_t)stream);
+                              sample, mean, var, nullptr, nullptr, T, bcast_K, (hipStream_t)stream);
 }
 
 extern "C" size_t iwvi_gp_fullcov_ws_bytes(int64_t T, int M, int R) {
@@ -362,7 +363,7 @@ extern "C" int iwvi_gp_layer_fullcov(const void* state, int M, int D, int R, int
     float* a = (float*)ws;
     float* u = a + (size_t)T * Mp;
     int rc = layer_forward_impl(state, M, D, R, R, kern_type, variance, F, nullptr, nullptr, IWVI_MF_ZERO,
-                                nullptr, nullptr, nullptr, mean, nullptr, a, u, T, stream);
+                                nullptr, nullptr, nullptr, mean, nullptr, a, u, T, 1, stream);
     if (rc != IWVI_OK) return rc;
     StateLayout sl = state_layout(M, R);
     const float* invls = (const float*)((const char*)state + sl.off_invls);

@@ -5,19 +5,22 @@
 namespace iwvi {
 
 // ------------------------------------------------------------------------------------------
-// LatentVariableLayer: one thread per sample; activations live in LDS as [feature][thread] (conflict
-// free), weights are wave-uniform so they come through the scalar cache.
+// LatentVariableLayer: 32 lanes cooperate on one encoder row (one lane per output unit of each MLP
+// layer, weights staged in LDS once per workgroup), then write that row's bcast_K samples.  In the
+// IW path the encoder input [x_b, y_b] is the same for all K samples of a point (models.py:113-116), so
+// the MLP runs once per point and F / XY are read untiled ([B, .] rows, bcast_K = K).
 // ------------------------------------------------------------------------------------------
-constexpr int LV_THREADS = 128;
+constexpr int LV_THREADS = 256;
+constexpr int LV_GROUPS = LV_THREADS / 32;
 constexpr int LV_MAXDIM = 64;
 
 struct LvArgs {
     const float* F; const float* XY; const float* noise;
     const float* W[IWVI_MAX_ENC]; const float* b[IWVI_MAX_ENC];
     int dims[IWVI_MAX_ENC + 1];
-    int n_enc, D, Lw, sampled_kl, maxdim;
+    int n_enc, D, Lw, sampled_kl, maxdim, bcast_K, bcast_F, wtotal;
     float* sample; float* mean; float* cov; float* kl;
-    long long T;
+    long long E;                      // encoder rows = T / bcast_K
 };
 
 extern __shared__ __attribute__((aligned(16))) unsigned char lv_smem[];
@@ -27,51 +30,76 @@ __device__ __forceinline__ float softplus_f(float x) {
 }
 
 __global__ __launch_bounds__(LV_THREADS) void k_lv_layer(LvArgs g) {
-    const int tid = threadIdx.x;
-    const long long t = (long long)blockIdx.x * LV_THREADS + tid;
-    const bool live = t < g.T;
-    float* act0 = reinterpret_cast<float*>(lv_smem);
-    float* act1 = act0 + (size_t)g.maxdim * LV_THREADS;
-    const int D = g.D, Lw = g.Lw;
+    const int tid = threadIdx.x, grp = tid >> 5, ln = tid & 31;
+    const long long e = (long long)blockIdx.x * LV_GROUPS + grp;
+    const bool live = e < g.E;
+    const int D = g.D, Lw = g.Lw, K = g.bcast_K, Do = D + Lw;
+    // LDS: weights+biases of all layers | per group: act[2][maxdim], frow[32]
+    float* wts = reinterpret_cast<float*>(lv_smem);
+    float* gbase = wts + g.wtotal + grp * (2 * g.maxdim + 32);
+    float* act0 = gbase;
+    float* act1 = gbase + g.maxdim;
+    float* frow = gbase + 2 * g.maxdim;
     if (g.XY) {
+        int off = 0;
+        for (int l = 0; l < g.n_enc; ++l) {
+            const int nW = g.dims[l] * g.dims[l + 1], nb = g.dims[l + 1];
+            for (int i = tid; i < nW; i += LV_THREADS) wts[off + i] = g.W[l][i];
+            for (int i = tid; i < nb; i += LV_THREADS) wts[off + nW + i] = g.b[l] ? g.b[l][i] : 0.f;
+            off += nW + nb;
+        }
         const int d0 = g.dims[0];
-        for (int i = 0; i < d0; ++i) act0[i * LV_THREADS + tid] = live ? g.XY[t * d0 + i] : 0.f;
-        float* in = act0; float* out = act1;
+        for (int i = ln; i < d0; i += 32) act0[i] = live ? g.XY[e * d0 + i] : 0.f;
+    }
+    if (ln < D) frow[ln] = (live && g.bcast_F) ? g.F[e * D + ln] : 0.f;
+    __syncthreads();
+    float* in = act0; float* out = act1;
+    if (g.XY) {
+        int off = 0;
         for (int l = 0; l < g.n_enc; ++l) {
             const int din = g.dims[l], dout = g.dims[l + 1];
-            const float* W = g.W[l]; const float* b = g.b[l];
-            for (int o = 0; o < dout; ++o) {
-                float acc = b ? b[o] : 0.f;
-                for (int i = 0; i < din; ++i) acc = fmaf(in[i * LV_THREADS + tid], W[i * dout + o], acc);
+            const float* W = wts + off; const float* b = W + din * dout;
+            for (int o = ln; o < dout; o += 32) {
+                float acc = b[o];
+                for (int i = 0; i < din; ++i) acc = fmaf(in[i], W[i * dout + o], acc);
                 if (l < g.n_enc - 1) acc = tanhf(acc);                         // layers.py:143-144
-                if (din == dout) acc += in[o * LV_THREADS + tid];              // layers.py:146-147
-                out[o * LV_THREADS + tid] = acc;
+                if (din == dout) acc += in[o];                                 // layers.py:146-147
+                out[o] = acc;
             }
+            off += din * dout + dout;
+            __syncthreads();
             float* tmp = in; in = out; out = tmp;
         }
-        if (in != act0) for (int i = 0; i < 2 * Lw; ++i) act0[i * LV_THREADS + tid] = in[i * LV_THREADS + tid];
     }
     if (!live) return;
-    const int Do = D + Lw;
-    for (int d = 0; d < D; ++d) {
-        float f = g.F[t * D + d];
-        if (g.sample) g.sample[t * Do + d] = f;
-        if (g.mean) g.mean[t * Do + d] = f;
-        if (g.cov) g.cov[t * Do + d] = 0.f;
+    // `in` holds [means (Lw) | raw (Lw)]; this group's K samples are rows e*K .. e*K+K-1 (contiguous)
+    const long long t0 = e * K;
+    for (int idx = ln; idx < K * Do; idx += 32) {
+        const int k = idx / Do, c = idx - k * Do;
+        float vs, vm, vc;
+        if (c < D) { vs = vm = g.bcast_F ? frow[c] : g.F[(t0 + k) * D + c]; vc = 0.f; }
+        else {
+            const int l = c - D;
+            float mu = 0.f, sg = 1.f;                                           // prior (layers.py:73-81)
+            if (g.XY) { mu = in[l]; sg = softplus_f(in[Lw + l] - 3.f); }
+            const float z = g.noise ? g.noise[(t0 + k) * Lw + l] : 0.f;
+            vs = fmaf(z, sg, mu); vm = mu; vc = sg * sg;                        // layers.py:86-91
+        }
+        if (g.sample) g.sample[t0 * Do + idx] = vs;
+        if (g.mean) g.mean[t0 * Do + idx] = vm;
+        if (g.cov) g.cov[t0 * Do + idx] = vc;
     }
-    for (int l = 0; l < Lw; ++l) {
-        float mu = 0.f, sg = 1.f;                                               // prior (layers.py:73-81)
-        if (g.XY) { mu = act0[l * LV_THREADS + tid]; sg = softplus_f(act0[(Lw + l) * LV_THREADS + tid] - 3.f); }
-        float z = g.noise ? g.noise[t * Lw + l] : 0.f;
-        float w = fmaf(z, sg, mu);                                              // layers.py:86-87
-        if (g.sample) g.sample[t * Do + D + l] = w;
-        if (g.mean) g.mean[t * Do + D + l] = mu;
-        if (g.cov) g.cov[t * Do + D + l] = sg * sg;
-        if (g.kl) {
+    if (g.kl) {
+        for (int idx = ln; idx < K * Lw; idx += 32) {
+            const int l = idx % Lw;
+            float mu = 0.f, sg = 1.f;
+            if (g.XY) { mu = in[l]; sg = softplus_f(in[Lw + l] - 3.f); }
+            const float z = g.noise ? g.noise[t0 * Lw + idx] : 0.f;
+            const float w = fmaf(z, sg, mu);
             float kl;
-            if (g.sampled_kl) kl = -0.5f * z * z - logf(sg) + 0.5f * w * w;     // log q(W) - log p(W)
-            else kl = 0.5f * (sg * sg + mu * mu - 1.f) - logf(sg);              // KL(N(mu,sg)||N(0,1))
-            g.kl[t * Lw + l] = kl;
+            if (g.sampled_kl) kl = -0.5f * z * z - logf(sg) + 0.5f * w * w;     // log q(W) - log p(W), :98-100
+            else kl = 0.5f * (sg * sg + mu * mu - 1.f) - logf(sg);              // KL(N(mu,sg)||N(0,1)), :101-103
+            g.kl[t0 * Lw + idx] = kl;
         }
     }
 }
@@ -86,58 +114,105 @@ struct ReduceArgs {
     long long B, stride_b, stride_k; int K, Dy, K_total, mode_vi;
     float lik_variance;
     float* ms; float* logp;
+    // fused final sum (last-arriving workgroup): out_elbo = sum(logp) * scale - sum(global KLs)
+    double* elbo; unsigned long long* ticket; double scale;
+    const double* klg[MAX_GLOB]; int klg_n[MAX_GLOB]; int n_glob;
 };
 
-__device__ __forceinline__ float wave_max(float v) {
+template <int SEG>
+__device__ __forceinline__ float seg_max(float v) {
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    for (int o = SEG / 2; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
     return v;
 }
-__device__ __forceinline__ float wave_sum(float v) {
+template <int SEG>
+__device__ __forceinline__ float seg_sum(float v) {
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    for (int o = SEG / 2; o > 0; o >>= 1) v += __shfl_xor(v, o);
     return v;
 }
 
-__global__ __launch_bounds__(256) void k_elbo_points(ReduceArgs g) {
-    const int lane = threadIdx.x & 63;
-    const long long b = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (b >= g.B) return;
+constexpr int ELBO_THREADS = 256;
+constexpr int ELBO_PTS = 64;            // points per workgroup
+
+// SEG lanes (a power of two <= 64, >= min(K, 64)) cooperate on one data point: Gaussian variational
+// expectations (models.py:134), minus local regularisers (:140-142), log-sum-exp over K (:148).  The last
+// workgroup to finish (agent-scope release / ticket / acquire, cdna guide G16) adds the points up in a
+// fixed order, so the ELBO (:150) is bit-reproducible and needs no second launch.
+template <int SEG>
+__global__ __launch_bounds__(ELBO_THREADS) void k_elbo(ReduceArgs g) {
+    __shared__ double red[ELBO_THREADS];
+    __shared__ int is_last;
+    const int tid = threadIdx.x, sl = tid % SEG, sg = tid / SEG;
+    constexpr int PPP = ELBO_THREADS / SEG;          // points per pass
     const int K = g.K, Dy = g.Dy;
-    const float c0 = -0.5f * 1.8378770664093453f - 0.5f * logf(g.lik_variance);   // -1/2 log 2pi - 1/2 log s2
+    const float c0 = -0.5f * 1.8378770664093453f - 0.5f * logf(g.lik_variance);
     const float inv2s = 0.5f / g.lik_variance;
-    // pass 1: log-weights of this point (kept in registers for K <= 64*4, recomputed otherwise)
-    float m = -INFINITY, ssum = 0.f, lsum = 0.f;
-    for (int k0 = 0; k0 < K; k0 += 64) {
-        const int k = k0 + lane;
-        float L = -INFINITY;
-        if (k < K) {
-            const long long t = b * g.stride_b + k * g.stride_k;
-            float acc = 0.f;
-            for (int d = 0; d < Dy; ++d) {
-                float df = g.Y[b * Dy + d] - g.fmean[t * Dy + d];
-                acc += c0 - (df * df + g.fvar[t * Dy + d]) * inv2s;                  // models.py:134
+    for (int pp = 0; pp < ELBO_PTS; pp += PPP) {
+        const long long b = (long long)blockIdx.x * ELBO_PTS + pp + sg;
+        const bool live = b < g.B;                    // uniform within a segment
+        float m = -INFINITY, ssum = 0.f, lsum = 0.f;
+        for (int k0 = 0; k0 < K; k0 += SEG) {
+            const int k = k0 + sl;
+            float L = -INFINITY;
+            if (live && k < K) {
+                const long long t = b * g.stride_b + k * g.stride_k;
+                float acc = 0.f;
+                for (int d = 0; d < Dy; ++d) {
+                    const float df = g.Y[b * Dy + d] - g.fmean[t * Dy + d];
+                    acc += c0 - (df * df + g.fvar[t * Dy + d]) * inv2s;
+                }
+                for (int i = 0; i < g.n_kl; ++i)
+                    for (int d = 0; d < g.kl_dims[i]; ++d) acc -= g.kl[i][t * g.kl_dims[i] + d];
+                L = acc;
             }
-            for (int i = 0; i < g.n_kl; ++i)
-                for (int d = 0; d < g.kl_dims[i]; ++d) acc -= g.kl[i][t * g.kl_dims[i] + d];   // :140-142
-            L = acc;
+            if (g.mode_vi) { lsum += seg_sum<SEG>((live && k < K) ? L : 0.f); continue; }
+            const float cm = seg_max<SEG>(L);
+            const float nm = fmaxf(m, cm);
+            const float e = (live && k < K) ? __expf(L - nm) : 0.f;
+            const float cs = seg_sum<SEG>(e);
+            ssum = (m == -INFINITY ? 0.f : ssum * __expf(m - nm)) + cs;
+            m = nm;
         }
-        if (g.mode_vi) { lsum += wave_sum(k < K ? L : 0.f); continue; }
-        // online log-sum-exp across 64-wide chunks
-        float cm = wave_max(L);
-        float nm = fmaxf(m, cm);
-        float e = (k < K) ? __expf(L - nm) : 0.f;
-        float cs = wave_sum(e);
-        ssum = ssum * __expf(m - nm) + cs;
-        m = nm;
+        if (live && sl == 0) {
+            if (g.mode_vi) {
+                if (g.logp) g.logp[b] = lsum / (float)K;                               // models.py:84
+            } else {
+                if (g.ms) { g.ms[2 * b] = m; g.ms[2 * b + 1] = ssum; }
+                if (g.logp) g.logp[b] = m + logf(ssum) - logf((float)g.K_total);      // models.py:148
+            }
+        }
     }
-    if (lane == 0) {
-        if (g.mode_vi) {
-            if (g.logp) g.logp[b] = lsum / (float)K;                               // models.py:84
-        } else {
-            if (g.ms) { g.ms[2 * b] = m; g.ms[2 * b + 1] = ssum; }
-            if (g.logp) g.logp[b] = m + logf(ssum) - logf((float)g.K_total);      // models.py:148
+    if (!g.elbo) return;
+    // ---- publish this workgroup's logp, draw a ticket, the last arriver sums everything ----
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned long long t = __hip_atomic_fetch_add(g.ticket, 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = ((t + 1) % gridDim.x) == 0;
+        if (last) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
+        is_last = last;
+    }
+    __syncthreads();
+    if (!is_last) return;
+    double acc = 0.0;
+    for (long long b = tid; b < g.B; b += ELBO_THREADS) acc += (double)g.logp[b];
+    red[tid] = acc;
+    __syncthreads();
+    for (int s2 = ELBO_THREADS / 2; s2 > 0; s2 >>= 1) {
+        if (tid < s2) red[tid] += red[tid + s2];
+        __syncthreads();
+    }
+    if (tid == 0) {
+        double kl = 0.0;
+        for (int i = 0; i < g.n_glob; ++i)
+            for (int c = 0; c < g.klg_n[i]; ++c) kl += g.klg[i][c];
+        *g.elbo = red[0] * g.scale - kl;                                              // models.py:150
     }
 }
 
@@ -241,14 +316,15 @@ extern "C" int iwvi_lv_layer_forward(const float* F, const float* XY, const floa
                                      const float* const* enc_W, const float* const* enc_b,
                                      const int32_t* dims, int n_enc, int D, int Lw, int sampled_kl,
                                      float* sample, float* mean, float* cov, float* kl,
-                                     int64_t T, void* stream_) {
+                                     int64_t T, int bcast_K, int bcast_F, void* stream_) {
     if (T <= 0) return IWVI_OK;
     if (!F) { set_error("iwvi_lv_layer_forward: null input"); return IWVI_ERR_ARG; }
-    if (D <= 0 || Lw <= 0) { set_error("iwvi_lv_layer_forward: bad D=%d or latent_dim=%d", D, Lw); return IWVI_ERR_ARG; }
+    if (D <= 0 || D > 32 || Lw <= 0) { set_error("iwvi_lv_layer_forward: bad D=%d (1..32) or latent_dim=%d", D, Lw); return IWVI_ERR_ARG; }
+    if (bcast_K < 1 || T % bcast_K != 0) { set_error("iwvi_lv_layer_forward: T=%lld is not a multiple of bcast_K=%d", (long long)T, bcast_K); return IWVI_ERR_ARG; }
     LvArgs g{};
     g.F = F; g.XY = XY; g.noise = noise; g.D = D; g.Lw = Lw; g.sampled_kl = sampled_kl;
-    g.sample = sample; g.mean = mean; g.cov = cov; g.kl = kl; g.T = T;
-    int maxdim = 2 * Lw;
+    g.sample = sample; g.mean = mean; g.cov = cov; g.kl = kl; g.E = T / bcast_K; g.bcast_K = bcast_K; g.bcast_F = (bcast_F || bcast_K == 1) ? 1 : 0;
+    int maxdim = 2 * Lw, wtotal = 0;
     if (XY) {
         if (!enc_W || !dims || n_enc <= 0 || n_enc > IWVI_MAX_ENC) {
             set_error("iwvi_lv_layer_forward: encoder with %d layers (1..%d supported)", n_enc, IWVI_MAX_ENC); return IWVI_ERR_ARG;
@@ -262,18 +338,20 @@ extern "C" int iwvi_lv_layer_forward(const float* F, const float* XY, const floa
         for (int i = 0; i < n_enc; ++i) {
             if (!enc_W[i]) { set_error("iwvi_lv_layer_forward: null encoder weight %d", i); return IWVI_ERR_ARG; }
             g.W[i] = enc_W[i]; g.b[i] = enc_b ? enc_b[i] : nullptr;
+            wtotal += dims[i] * dims[i + 1] + dims[i + 1];
         }
         g.n_enc = n_enc;
     }
     if (maxdim > LV_MAXDIM) { set_error("iwvi_lv_layer_forward: latent_dim too large"); return IWVI_ERR_ARG; }
-    g.maxdim = maxdim;
-    size_t lds = sizeof(float) * 2 * (size_t)maxdim * LV_THREADS;
-    long long blocks = (T + LV_THREADS - 1) / LV_THREADS;
+    g.maxdim = maxdim; g.wtotal = wtotal;
+    size_t lds = sizeof(float) * ((size_t)wtotal + (size_t)LV_GROUPS * (2 * maxdim + 32));
+    long long blocks = (g.E + LV_GROUPS - 1) / LV_GROUPS;
     hipLaunchKernelGGL(k_lv_layer, dim3((unsigned)blocks), dim3(LV_THREADS), lds, (hipStream_t)stream_, g);
     return check_launch("k_lv_layer");
 }
 
-static int fill_globals(FinalArgs& f, const double* const* klg, const int32_t* counts, int n_glob) {
+template <typename ArgsT>
+static int fill_globals(ArgsT& f, const double* const* klg, const int32_t* counts, int n_glob) {
     if (n_glob < 0 || n_glob > MAX_GLOB) { set_error("too many global KL terms (%d > %d)", n_glob, MAX_GLOB); return IWVI_ERR_ARG; }
     for (int i = 0; i < n_glob; ++i) {
         if (!klg || !klg[i]) { set_error("null global KL pointer %d", i); return IWVI_ERR_ARG; }
@@ -285,19 +363,27 @@ static int fill_globals(FinalArgs& f, const double* const* klg, const int32_t* c
     return IWVI_OK;
 }
 
+template <int SEG>
+static int launch_elbo(const ReduceArgs& g, hipStream_t stream) {
+    long long blocks = (g.B + ELBO_PTS - 1) / ELBO_PTS;
+    hipLaunchKernelGGL(k_elbo<SEG>, dim3((unsigned)blocks), dim3(ELBO_THREADS), 0, stream, g);
+    return check_launch("k_elbo");
+}
+
 extern "C" int iwvi_iw_elbo_reduce(const float* fmean, const float* fvar, const float* Y,
                                    float lik_variance, int64_t B, int K, int Dy,
                                    int64_t stride_b, int64_t stride_k,
                                    const float* const* kl_local, const int32_t* kl_dims, int n_kl,
                                    const double* const* kl_global, const int32_t* kl_global_counts, int n_glob,
                                    double scale, int K_total, int mode_vi,
-                                   float* out_ms, float* out_logp, double* out_elbo, void* stream_) {
+                                   float* out_ms, float* out_logp, double* out_elbo, uint64_t* ticket,
+                                   void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (!fmean || !fvar || !Y) { set_error("iwvi_iw_elbo_reduce: null input"); return IWVI_ERR_ARG; }
     if (B <= 0) { set_error("iwvi_iw_elbo_reduce: empty minibatch"); return IWVI_ERR_ARG; }
     if (K <= 0 || Dy <= 0 || !(lik_variance > 0.f)) { set_error("iwvi_iw_elbo_reduce: bad K=%d, Dy=%d or likelihood variance", K, Dy); return IWVI_ERR_ARG; }
     if (n_kl < 0 || n_kl > IWVI_MAX_KL) { set_error("iwvi_iw_elbo_reduce: %d local regularisers (max %d)", n_kl, IWVI_MAX_KL); return IWVI_ERR_ARG; }
-    if (out_elbo && !out_logp) { set_error("iwvi_iw_elbo_reduce: out_elbo needs out_logp as scratch"); return IWVI_ERR_ARG; }
+    if (out_elbo && (!out_logp || !ticket)) { set_error("iwvi_iw_elbo_reduce: out_elbo needs out_logp (scratch) and a zero-initialised ticket word"); return IWVI_ERR_ARG; }
     ReduceArgs g{};
     g.fmean = fmean; g.fvar = fvar; g.Y = Y; g.n_kl = n_kl;
     for (int i = 0; i < n_kl; ++i) {
@@ -307,15 +393,14 @@ extern "C" int iwvi_iw_elbo_reduce(const float* fmean, const float* fvar, const 
     g.stride_b = stride_b; g.stride_k = stride_k;
     g.B = B; g.K = K; g.Dy = Dy; g.K_total = K_total > 0 ? K_total : K; g.mode_vi = mode_vi;
     g.lik_variance = lik_variance; g.ms = out_ms; g.logp = out_logp;
-    long long blocks = (B + 3) / 4;
-    hipLaunchKernelGGL(k_elbo_points, dim3((unsigned)blocks), dim3(256), 0, stream, g);
-    int rc = check_launch("k_elbo_points");
-    if (rc != IWVI_OK || !out_elbo) return rc;
-    FinalArgs f{};
-    f.logp = out_logp; f.B = B; f.K_total = g.K_total; f.scale = scale; f.elbo = out_elbo;
-    if ((rc = fill_globals(f, kl_global, kl_global_counts, n_glob)) != IWVI_OK) return rc;
-    hipLaunchKernelGGL(k_elbo_final, dim3(1), dim3(1024), 0, stream, f);
-    return check_launch("k_elbo_final");
+    g.elbo = out_elbo; g.ticket = (unsigned long long*)ticket; g.scale = scale;
+    int rc;
+    if (out_elbo && (rc = fill_globals(g, kl_global, kl_global_counts, n_glob)) != IWVI_OK) return rc;
+    if (K <= 4) return launch_elbo<4>(g, stream);
+    if (K <= 8) return launch_elbo<8>(g, stream);
+    if (K <= 16) return launch_elbo<16>(g, stream);
+    if (K <= 32) return launch_elbo<32>(g, stream);
+    return launch_elbo<64>(g, stream);
 }
 
 extern "C" int iwvi_lse_merge(const float* ms_all, int G, int64_t B, int K_total,

@@ -88,15 +88,16 @@ class GPLayer:
         return self.state().kl
 
     # -- reference API --------------------------------------------------------------------
-    def propagate(self, F, full_cov=False, z=None, _precomputed=False, _kl_parts=False, **kwargs):
-        """reference layers.py:35-50 -> (samples, mean, cov, kl)."""
+    def propagate(self, F, full_cov=False, z=None, _precomputed=False, _kl_parts=False, _bcast_K=None, **kwargs):
+        """reference layers.py:35-50 -> (samples, mean, cov, kl).
+        ``_bcast_K`` (model-internal): F is the untiled [B, D] minibatch standing for [B, K, D]."""
         if not _precomputed:
             self.precompute()
         plain_full = full_cov and not isinstance(self.kern, SharedMixedMok)
         mf = None if plain_full else self.mean_function            # fused into the kernel epilogue
         samples, mean, cov = multisample_sample_conditional(
             F, self.feature, self.kern, self.q_mu, full_cov=full_cov, q_sqrt=self.q_sqrt, white=True,
-            z=z, state=self.state(), mean_function=mf, precomputed=True)
+            z=z, state=self.state(), mean_function=mf, precomputed=True, bcast_K=_bcast_K)
         # layers.py:44 (computed by the precompute); _kl_parts hands the model the R per-GP shares
         # so that the ELBO reduction sums them without an extra launch
         kl = self.state().kl_parts if _kl_parts else self.kl
@@ -149,7 +150,7 @@ class Encoder:
         Wp, bp, dims, n, keep = self.abi_args()
         _abi.check(_abi.lib().iwvi_lv_layer_forward(
             _abi.ptr(dummy), _abi.ptr(Z.reshape(T, -1)), None, Wp, bp, dims, n, 1, Lw, 0,
-            None, _abi.ptr(mean), _abi.ptr(cov), None, T, _abi.stream_ptr()))
+            None, _abi.ptr(mean), _abi.ptr(cov), None, T, 1, 1, _abi.stream_ptr()))
         return mean[:, 1:].reshape(*lead, Lw), cov[:, 1:].sqrt().reshape(*lead, Lw)
 
 
@@ -169,27 +170,37 @@ class LatentVariableLayer:
         return self
 
     def propagate(self, F, inference_amorization_inputs=None, is_sampled_local_regularizer=False,
-                  z=None, **kwargs):
-        """reference layers.py:72-105 -> (samples, mean, cov, kl) with kl [..., latent_dim]."""
+                  z=None, _bcast_K=None, _bcast_XY=None, **kwargs):
+        """reference layers.py:72-105 -> (samples, mean, cov, kl) with kl [..., latent_dim].
+        Model-internal: ``_bcast_K`` = F (and the encoder input) are the untiled [B, .] minibatch standing
+        for [B, K, .]; ``_bcast_XY`` = only the encoder input is untiled (F is already [B, K, D])."""
         F = _abi.dev_tensor(F.contiguous(), "F")
-        lead, D = F.shape[:-1], F.shape[-1]
-        T, Lw = F[..., 0].numel(), self.latent_dim
-        dev = F.device
+        D, Lw, dev = F.shape[-1], self.latent_dim, F.device
+        Kb = _bcast_K or _bcast_XY or 1
+        bcast_F = 1 if (_bcast_K or Kb == 1) else 0
+        if _bcast_K:
+            if F.dim() != 2:
+                raise ValueError("_bcast_K needs the untiled [B, D] input")
+            lead = (F.shape[0], _bcast_K)
+        else:
+            lead = F.shape[:-1]
+        T = int(np.prod(lead)) if len(lead) else 1
         XY = inference_amorization_inputs
         if XY is not None:
             XY = _abi.dev_tensor(XY.contiguous(), "inference_amorization_inputs")
-            if XY.shape[:-1] != lead:
-                raise ValueError("inference_amorization_inputs %s does not match F %s" % (tuple(XY.shape), tuple(F.shape)))
             if XY.shape[-1] != self.encoder.layer_dims[0]:
                 raise ValueError("encoder expects %d features, got %d" % (self.encoder.layer_dims[0], XY.shape[-1]))
-            XY = XY.reshape(T, -1)
+            XY = XY.reshape(-1, XY.shape[-1])
+            if XY.shape[0] * Kb != T:
+                raise ValueError("inference_amorization_inputs has %d rows, expected %d" % (XY.shape[0], T // Kb))
         z2 = draw_normal((T, Lw), dev) if z is None else _abi.dev_tensor(z.reshape(T, Lw).contiguous(), "z")
         outs = [torch.empty(T, D + Lw, dtype=settings.float_type, device=dev) for _ in range(3)]
         kl = torch.empty(T, Lw, dtype=settings.float_type, device=dev)
         Wp, bp, dims, n, keep = self.encoder.abi_args()
         _abi.check(_abi.lib().iwvi_lv_layer_forward(
-            _abi.ptr(F.reshape(T, D)), _abi.ptr(XY), _abi.ptr(z2), Wp, bp, dims, n, D, Lw,
+            _abi.ptr(F.reshape(-1, D)), _abi.ptr(XY), _abi.ptr(z2), Wp, bp, dims, n, D, Lw,
             1 if is_sampled_local_regularizer else 0,
-            _abi.ptr(outs[0]), _abi.ptr(outs[1]), _abi.ptr(outs[2]), _abi.ptr(kl), T, _abi.stream_ptr()))
+            _abi.ptr(outs[0]), _abi.ptr(outs[1]), _abi.ptr(outs[2]), _abi.ptr(kl), T, Kb, bcast_F,
+            _abi.stream_ptr()))
         s, m, c = (o.view(*lead, D + Lw) for o in outs)
         return s, m, c, kl.view(*lead, Lw)

@@ -41,6 +41,7 @@ class DGP_VI:
         self.layers = list(layers)
         self.name = name
         self.full_cov_over_samples = False
+        self._ticket = None
 
     # -- data ---------------------------------------------------------------------------------
     def next_minibatch(self):
@@ -105,12 +106,14 @@ class DGP_VI:
         logp = torch.empty(B, dtype=settings.float_type, device=dev)
         elbo = torch.empty(1, dtype=torch.float64, device=dev)
         ms = torch.empty(B, 2, dtype=settings.float_type, device=dev) if want_ms else None
+        if self._ticket is None or self._ticket.device != dev:
+            self._ticket = torch.zeros(1, dtype=torch.int64, device=dev)      # zeroed once, never per call
         scale = float(self.num_data) / float(B)                        # models.py:80-81, :144-145
         _abi.check(_abi.lib().iwvi_iw_elbo_reduce(
             _abi.ptr(fmean), _abi.ptr(fvar), _abi.ptr(Y), self.likelihood.variance, B, K, Dy,
             stride_b, stride_k, _abi.ptr_array(kls), kl_dims, len(kls), _abi.ptr_array(glob), glob_n, len(glob),
             scale, K_total or K, 1 if mode_vi else 0, _abi.ptr(ms), _abi.ptr(logp), _abi.ptr(elbo),
-            _abi.stream_ptr()))
+            _abi.ptr(self._ticket), _abi.stream_ptr()))
         return elbo[0], logp, ms
 
     def _build_likelihood(self, zs=None):
@@ -161,19 +164,47 @@ class DGP_VI:
 
 class DGP_IWVI(DGP_VI):
     def _forward_iw(self, zs=None):
+        """models.py:113-133.  Default: the tiling of X, Y over K (:113-116) happens inside the first
+        layer's kernel (``bcast_K``) and every layer returns marginal variances.  With
+        ``full_cov_over_samples`` the reference is followed literally (explicit tiling, full_cov=True,
+        matrix_diag_part of the [B, Dy, K, K] covariance)."""
         B, K = self.X.shape[0], self.num_samples
-        X_tiled = self.X[:, None, :].expand(B, K, self.X.shape[1]).contiguous()     # :113
-        Y_tiled = self.Y[:, None, :].expand(B, K, self.Y.shape[1]).contiguous()     # :114
-        XY = torch.cat([X_tiled, Y_tiled], -1)                                       # :116
-        samples, means, covs, kls, kl_types = self.propagate(
-            X_tiled, full_cov=self.full_cov_over_samples, inference_amorization_inputs=XY,
-            is_sampled_local_regularizer=True, zs=zs, _kl_parts=True)                # :122-125
+        if self.full_cov_over_samples:
+            X_tiled = self.X[:, None, :].expand(B, K, self.X.shape[1]).contiguous()     # :113
+            Y_tiled = self.Y[:, None, :].expand(B, K, self.Y.shape[1]).contiguous()     # :114
+            XY = torch.cat([X_tiled, Y_tiled], -1)                                       # :116
+            samples, means, covs, kls, kl_types = self.propagate(
+                X_tiled, full_cov=True, inference_amorization_inputs=XY,
+                is_sampled_local_regularizer=True, zs=zs, _kl_parts=True)                # :122-125
+        else:
+            self.precompute()
+            XY_b = self._xy_minibatch()
+            zs = [None] * len(self.layers) if zs is None else zs
+            if len(zs) != len(self.layers):
+                raise ValueError("zs needs one entry per layer")
+            samples, means, covs, kls, kl_types = [], [], [], [], []
+            F = self.X
+            for i, (layer, z) in enumerate(zip(self.layers, zs)):
+                kw = dict(_bcast_K=K) if i == 0 else dict(_bcast_XY=K)
+                s_, m_, c_, kl_ = layer.propagate(F, full_cov=False, inference_amorization_inputs=XY_b,
+                                                  is_sampled_local_regularizer=True, z=z, _precomputed=True,
+                                                  _kl_parts=True, **kw)
+                samples.append(s_); means.append(m_); covs.append(c_); kls.append(kl_)
+                kl_types.append(layer.regularizer_type)
+                F = s_
         local_kls = [kl for kl, t in zip(kls, kl_types) if t is RegularizerType.LOCAL]
         global_kls = [kl for kl, t in zip(kls, kl_types) if t is RegularizerType.GLOBAL]
         cov = covs[-1]
         if cov.dim() == 4:                                                            # [B, Dy, K, K]
             cov = torch.diagonal(cov, dim1=-2, dim2=-1).transpose(1, 2).contiguous()  # :133
         return means[-1], cov, local_kls, global_kls, samples, means, covs
+
+    def _xy_minibatch(self):
+        """[x_b, y_b] rows of the current minibatch (models.py:116 before tiling), cached per minibatch."""
+        key = (self.X.data_ptr(), self.Y.data_ptr(), self.X.shape[0])
+        if getattr(self, "_xy_key", None) != key:
+            self._xy_cache, self._xy_key = torch.cat([self.X, self.Y], -1).contiguous(), key
+        return self._xy_cache
 
     def _build_likelihood(self, zs=None):
         """The importance-weighted ELBO, reference models.py:112-150."""

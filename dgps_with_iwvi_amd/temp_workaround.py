@@ -92,7 +92,7 @@ class GpState:
 
 
 def precompute_states(descs):
-    """One ``iwvi_gp_precompute`` call (two launches) for any number of GP layers."""
+    """One ``iwvi_gp_precompute`` call (one launch per 8 layers) for any number of GP layers."""
     if not descs:
         return
     arr = (_abi.GpDesc * len(descs))(*descs)
@@ -130,9 +130,9 @@ def draw_normal(shape, device):
     return out
 
 
-def _forward_diag(state, kern, D, R, F2, z2, W, mean_function, want=(True, True, True)):
-    """[T, D] -> sample/mean/var [T, P] through ``iwvi_gp_layer_forward``."""
-    T = F2.shape[0]
+def _forward_diag(state, kern, D, R, F2, z2, W, mean_function, want=(True, True, True), bcast_K=1):
+    """[T/bcast_K, D] -> sample/mean/var [T, P] through ``iwvi_gp_layer_forward``."""
+    T = F2.shape[0] * bcast_K
     P = W.shape[0] if W is not None else R
     dev = F2.device
     outs = [torch.empty(T, P, dtype=settings.float_type, device=dev) if w else None for w in want]
@@ -146,7 +146,7 @@ def _forward_diag(state, kern, D, R, F2, z2, W, mean_function, want=(True, True,
     _abi.check(_abi.lib().iwvi_gp_layer_forward(
         _abi.ptr(state.buf), state.M, D, R, P, kern.kern_type, kern.variance,
         _abi.ptr(F2), _abi.ptr(z2), _abi.ptr(W), mf_type, _abi.ptr(mfA), _abi.ptr(mfb),
-        _abi.ptr(outs[0]), _abi.ptr(outs[1]), _abi.ptr(outs[2]), T, _abi.stream_ptr()))
+        _abi.ptr(outs[0]), _abi.ptr(outs[1]), _abi.ptr(outs[2]), T, bcast_K, _abi.stream_ptr()))
     return outs
 
 
@@ -161,7 +161,7 @@ def _check_common(Xnew, full_output_cov, white):
 
 def independent_multisample_sample_conditional(Xnew, feat, kern, f, *, full_cov=False, full_output_cov=False,
                                                q_sqrt=None, white=False, z=None, state=None,
-                                               mean_function=None, precomputed=False):
+                                               mean_function=None, precomputed=False, bcast_K=None):
     """Multisample, single-output GP conditional (reference temp_workaround.py:12-98).
 
     :param Xnew: [S, N, D] (also accepts [N, D], the 2-D ``sample_conditional`` path of :157-161)
@@ -189,9 +189,13 @@ def independent_multisample_sample_conditional(Xnew, feat, kern, f, *, full_cov=
     lead = Xnew.shape[:-1]
     F2 = Xnew.reshape(-1, D)
     T = F2.shape[0]
+    if bcast_K:                                   # Xnew [B, D] stands for [B, K, D] tiled over K
+        if full_cov or Xnew.dim() != 2:
+            raise ValueError("bcast_K needs a 2-D input and full_cov=False")
+        lead, T = (Xnew.shape[0], bcast_K), T * bcast_K
     if not full_cov:
         z2 = draw_normal((T, R), Xnew.device) if z is None else _abi.dev_tensor(z.reshape(T, R).contiguous(), "z")
-        s, m, v = _forward_diag(state, kern, D, R, F2, z2, None, mean_function)
+        s, m, v = _forward_diag(state, kern, D, R, F2, z2, None, mean_function, bcast_K=bcast_K or 1)
         return s.view(*lead, R), m.view(*lead, R), v.view(*lead, R)
     # full covariance over the second axis (reference :45,56,83,93-96)
     S, N = (1, lead[0]) if Xnew.dim() == 2 else lead
@@ -216,7 +220,7 @@ def independent_multisample_sample_conditional(Xnew, feat, kern, f, *, full_cov=
 
 def multisample_sample_conditional(Xnew, feat, kern, f, *, full_cov=False, full_output_cov=False,
                                    q_sqrt=None, white=False, z=None, state=None, mean_function=None,
-                                   precomputed=False):
+                                   precomputed=False, bcast_K=None):
     """Dispatcher of reference temp_workaround.py:118-161."""
     if isinstance(kern, SharedMixedMok) and isinstance(feat, MixedKernelSharedMof):      # :123
         _check_common(Xnew, False, white)
@@ -236,15 +240,19 @@ def multisample_sample_conditional(Xnew, feat, kern, f, *, full_cov=False, full_
         lead = Xnew.shape[:-1]
         F2 = Xnew.reshape(-1, D)
         T = F2.shape[0]
+        if bcast_K:
+            if Xnew.dim() != 2:
+                raise ValueError("bcast_K needs a 2-D input")
+            lead, T = (Xnew.shape[0], bcast_K), T * bcast_K
         # full_cov is forced to False on this branch (reference :125-129, :134-138)
         z2 = draw_normal((T, R), Xnew.device) if z is None else _abi.dev_tensor(z.reshape(T, R).contiguous(), "z")
-        s, m, v = _forward_diag(state, base, D, R, F2, z2, W, mean_function)   # mixing fused (:142-145)
+        s, m, v = _forward_diag(state, base, D, R, F2, z2, W, mean_function, bcast_K=bcast_K or 1)   # mixing fused (:142-145)
         P = W.shape[0]
         return s.view(*lead, P), m.view(*lead, P), v.view(*lead, P)
     assert not isinstance(kern, SharedMixedMok)                                          # :149
     return independent_multisample_sample_conditional(
         Xnew, feat, kern, f, full_cov=full_cov, full_output_cov=full_output_cov, q_sqrt=q_sqrt,
-        white=white, z=z, state=state, mean_function=mean_function, precomputed=precomputed)
+        white=white, z=z, state=state, mean_function=mean_function, precomputed=precomputed, bcast_K=bcast_K)
 
 
 def gauss_kl(q_mu, q_sqrt, K=None):

@@ -107,7 +107,8 @@ int iwvi_chol_factor(const double* A, double* Lout, int M, void* ws, void* strea
  * marginal sample (:89-91), SharedMixedMok mixing (:142-145) and the mean
  * function add (layers.py:46-48) -- one fused launch, nothing spilled to HBM.
  *
- *   F      [T, D]   layer input
+ *   F      [T/bcast_K, D]  layer input; bcast_K >= 1: every row stands for bcast_K consecutive samples
+ *                   (the tiling of models.py:113 done inside the kernel); 1 = F has T rows
  *   noise  [T, R]   N(0,1) draws (z of temp_workaround.py:89); may be NULL -> z = 0
  *   W      [P, R]   SharedMixedMok.W, or NULL (then P must equal R)
  *   mf_A   [D, P], mf_b [P]  for IWVI_MF_LINEAR (mf_b may be NULL)
@@ -119,7 +120,7 @@ int iwvi_gp_layer_forward(const void* state, int M, int D, int R, int P,
                           const float* F, const float* noise, const float* W,
                           int mf_type, const float* mf_A, const float* mf_b,
                           float* sample, float* mean, float* var,
-                          int64_t T, void* stream);
+                          int64_t T, int bcast_K, void* stream);
 
 /* Full covariance over the second axis (temp_workaround.py:45,56,83 with full_cov=True):
  *   F [S, N, D] -> mean [S, N, R], cov [S, R, N, N].
@@ -132,7 +133,9 @@ int iwvi_gp_layer_fullcov(const void* state, int M, int D, int R, int kern_type,
 
 /* ------------------------------------------------------------------------
  * LatentVariableLayer forward (layers.py:72-105) with its Encoder MLP (:137-152).
- *   F   [T, D];  XY [T, XYdim] or NULL (prior mode, :73-81);  noise [T, Lw] or NULL
+ *   F   [T/bcast_K, D] if bcast_F else [T, D];  XY [T/bcast_K, XYdim] or NULL (prior mode, :73-81);  noise [T, Lw] or NULL
+ *   bcast_K >= 1: every row of F / XY stands for bcast_K consecutive samples (the IW tiling of
+ *   models.py:113-116 done inside the kernel: the encoder runs once per data point); 1 = no tiling
  *   enc_W[i] [dims[i], dims[i+1]], enc_b[i] [dims[i+1]], dims_host[n_enc+1],
  *   dims[0] = XYdim, dims[n_enc] = 2*Lw; tanh on all but the last layer, skip
  *   connection where dims[i] == dims[i+1]; q_sqrt = softplus(raw - 3).
@@ -144,7 +147,7 @@ int iwvi_lv_layer_forward(const float* F, const float* XY, const float* noise,
                           const int32_t* dims_host, int n_enc,
                           int D, int Lw, int sampled_kl,
                           float* sample, float* mean, float* cov, float* kl,
-                          int64_t T, void* stream);
+                          int64_t T, int bcast_K, int bcast_F, void* stream);
 
 /* ------------------------------------------------------------------------
  * The IW-ELBO reduction (models.py:133-150): Gaussian variational expectations
@@ -159,6 +162,8 @@ int iwvi_lv_layer_forward(const float* F, const float* XY, const float* noise,
  *   out_lse_ms [B, 2] = (max_k L, sum_k exp(L - max)) per point, for K-sharded merging
  *   out_logp   [B]     logsumexp - log(K_total)   (K_total = K when not sharded)
  *   out_elbo   [1] double = sum(logp) * scale - sum(kl_global)
+ *   ticket     [1] device word, zeroed ONCE by the caller (never per call): the last workgroup to finish
+ *              performs the final sum, so the whole reduction is one launch; needed when out_elbo != NULL
  * Any out pointer may be NULL.  mode_vi != 0 -> reduce_mean over K instead (models.py:84).
  * ---------------------------------------------------------------------- */
 int iwvi_iw_elbo_reduce(const float* fmean, const float* fvar, const float* Y,
@@ -167,7 +172,7 @@ int iwvi_iw_elbo_reduce(const float* fmean, const float* fvar, const float* Y,
                         const float* const* kl_local_host, const int32_t* kl_dims_host, int n_kl,
                         const double* const* kl_global_host, const int32_t* kl_global_counts_host, int n_glob,
                         double scale, int K_total, int mode_vi,
-                        float* out_lse_ms, float* out_logp, double* out_elbo, void* stream);
+                        float* out_lse_ms, float* out_logp, double* out_elbo, uint64_t* ticket, void* stream);
 
 /* Merge K-sharded partials after the RCCL exchange (not in the reference):
  *   ms_all [G, B, 2] gathered (max, sumexp) pairs -> logp [B], elbo [1] as above. */
