@@ -344,3 +344,33 @@ def test_fill_normal(gpu_device):
     assert torch.equal(a[4:], b[:n - 4])                       # counter offset = 4 normals
     _abi.check(_abi.lib().iwvi_fill_normal(_abi.ptr(b), n, 8, 0, _abi.stream_ptr()))
     assert not torch.equal(a, b)
+
+
+# ------------------------------------------------------------------------------------------
+# committed golden vectors (tests/golden/*.npz; generator tests/golden/make_golden.py)
+# ------------------------------------------------------------------------------------------
+def _golden_paths():
+    import glob
+    import os
+    return sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "*.npz")))
+
+
+@pytest.mark.parametrize("path", _golden_paths(), ids=lambda p: p.split("/")[-1][:-4])
+def test_golden_fixture(gpu_device, path):
+    """HIP path vs the committed fp64 vectors: per-layer mean / var / sample, log-weights, ELBO."""
+    from dgps_with_iwvi_amd import synthetic
+    from test_golden import load
+    spec, zs, out = load(path)
+    model = synthetic.build_model(spec, gpu_device)
+    zd = [_t(z, gpu_device) for z in zs]
+    elbo = model.compute_log_likelihood(zd)
+    assert abs(elbo - float(out["elbo"])) <= ELBO_RTOL * abs(float(out["elbo"])), (elbo, float(out["elbo"]))
+    np.testing.assert_allclose(_np(model.E_log_p_Y(zd)), out["logp"], rtol=2e-4, atol=2e-2)
+    fmean, fvar, _, _, samples, means, covs = model._forward_iw(zd)
+    n = len(spec["layers"])
+    for i in range(n - 1):
+        np.testing.assert_allclose(_np(means[i]), out["mean%d" % i], **MEAN_TOL)
+        np.testing.assert_allclose(_np(covs[i]), out["var%d" % i], **VAR_TOL)
+        np.testing.assert_allclose(_np(samples[i]), out["sample%d" % i], rtol=2e-3, atol=2e-3)
+    np.testing.assert_allclose(_np(fmean), out["mean%d" % (n - 1)], rtol=2e-3, atol=2e-3)
+    np.testing.assert_allclose(_np(fvar), out["var%d" % (n - 1)], rtol=5e-3, atol=2e-4)
