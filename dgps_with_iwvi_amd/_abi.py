@@ -13,6 +13,10 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libiwvi_hip.so")
 
 KERN_RBF, KERN_MATERN52 = 0, 1
+LAYER_GP, LAYER_LV = 0, 1
+ABI_VERSION = 2
+GP_WANT_DENSE = 1
+MAX_STACK = 12
 MF_ZERO, MF_IDENTITY, MF_LINEAR = 0, 1, 2
 MAX_LAYERS, MAX_R, MAX_P, MAX_D, MAX_M, MAX_KL, MAX_ENC = 8, 32, 32, 32, 512, 4, 8
 
@@ -29,7 +33,21 @@ class GpDesc(ctypes.Structure):
     _fields_ = [("Z", c_void_p), ("lengthscales", c_void_p), ("q_mu", c_void_p),
                 ("q_sqrt", c_void_p), ("state", c_void_p), ("variance", c_float),
                 ("jitter", c_double), ("M", ctypes.c_int32), ("D", ctypes.c_int32),
-                ("R", ctypes.c_int32), ("kern_type", ctypes.c_int32)]
+                ("R", ctypes.c_int32), ("kern_type", ctypes.c_int32), ("flags", ctypes.c_int32)]
+
+
+class LayerDesc(ctypes.Structure):
+    """struct iwvi_layer_desc (include/iwvi_hip.h): one layer of the fused forward."""
+    _fields_ = [("type", ctypes.c_int32), ("state", c_void_p),
+                ("M", ctypes.c_int32), ("D", ctypes.c_int32), ("R", ctypes.c_int32), ("P", ctypes.c_int32),
+                ("kern_type", ctypes.c_int32), ("mf_type", ctypes.c_int32), ("variance", c_float),
+                ("W", c_void_p), ("mf_A", c_void_p), ("mf_b", c_void_p),
+                ("enc_W", ctypes.POINTER(c_void_p)), ("enc_b", ctypes.POINTER(c_void_p)),
+                ("enc_dims", ctypes.POINTER(ctypes.c_int32)),
+                ("n_enc", ctypes.c_int32), ("latent_dim", ctypes.c_int32), ("sampled_kl", ctypes.c_int32),
+                ("noise", c_void_p), ("zero_noise", ctypes.c_int32), ("noise_out", c_void_p),
+                ("sample", c_void_p), ("mean", c_void_p), ("var", c_void_p), ("kl_local", c_void_p),
+                ("a_out", c_void_p), ("u_out", c_void_p)]
 
 
 # name -> (restype, argtypes); every symbol include/iwvi_hip.h declares
@@ -52,7 +70,12 @@ PROTOTYPES = {
     "iwvi_lv_layer_forward": (c_int, [c_void_p, c_void_p, c_void_p, ctypes.POINTER(c_void_p),
                                       ctypes.POINTER(c_void_p), ctypes.POINTER(ctypes.c_int32), c_int,
                                       c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
-                                      c_int64, c_int, c_int, c_void_p]),
+                                      c_int64, c_void_p]),
+    "iwvi_dgp_forward": (c_int, [ctypes.POINTER(LayerDesc), c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int,
+                                 c_int64, c_int64, c_int64, c_float, ctypes.c_uint64, c_void_p, c_void_p, c_void_p]),
+    "iwvi_logw_reduce": (c_int, [c_void_p, c_int64, c_int, c_int64, c_int64, ctypes.POINTER(c_void_p),
+                                 ctypes.POINTER(ctypes.c_int32), c_int, c_double, c_int, c_int,
+                                 c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "iwvi_iw_elbo_reduce": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_int64, c_int, c_int,
                                     c_int64, c_int64,
                                     ctypes.POINTER(c_void_p), ctypes.POINTER(ctypes.c_int32), c_int,
@@ -80,8 +103,8 @@ def lib():
         for name, (res, args) in PROTOTYPES.items():
             fn = getattr(handle, name)
             fn.restype, fn.argtypes = res, args
-        if handle.iwvi_version() != 1:
-            raise IwviError("libiwvi_hip.so ABI version %d != 1" % handle.iwvi_version())
+        if handle.iwvi_version() != ABI_VERSION:
+            raise IwviError("libiwvi_hip.so ABI version %d != %d (rebuild: make -C dgps_with_iwvi_amd/csrc)" % (handle.iwvi_version(), ABI_VERSION))
         _lib = handle
     return _lib
 

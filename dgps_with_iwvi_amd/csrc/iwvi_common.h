@@ -11,29 +11,50 @@ namespace iwvi {
 void set_error(const char* fmt, ...);
 int check_launch(const char* what);
 
-static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+__host__ __device__ static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+// ---- MFMA operand packing (v_mfma_f32_16x16x4_f32) --------------------------------------------
+// A 16x16 block of a matrix G (rows = output rows, columns = contraction index k) is stored as 64
+// float4, one per lane: lane l = 16*g + i holds G[16*bi + i][16*bk + 4*g + s], s = 0..3.  MFMA step s
+// of a 16-deep chunk therefore contracts the k's {4g + s : g = 0..3}; the B operand uses the same
+// slot order: float4 (chunk c, g, column j) = { B[16c + 4g + s][j] }.  That is exactly what the four
+// accumulator registers of lane (g, j) hold for rows 16c + 4g .. +3 (C/D map: col = lane & 15,
+// row = 4*(lane >> 4) + reg), so a result tile is the next product's B operand without any shuffle.
+constexpr int BLK16 = 256;                       // floats per packed 16x16 block
+
+// triangular block storage, row-block major:
+//   lower (Lm^-1):               row-block bi holds blocks bk = 0..bi
+//   upper (tril(q_sqrt[r])^T):   row-block bi holds blocks bk = bi..nbk-1
+__host__ __device__ static inline int tri_lower_off(int bi) { return bi * (bi + 1) / 2; }
+__host__ __device__ static inline int tri_upper_off(int nbk, int bi) { return bi * nbk - bi * (bi - 1) / 2; }
+__host__ __device__ static inline int tri_blocks(int nbk) { return nbk * (nbk + 1) / 2; }
 
 // ---- per-layer state layout (see include/iwvi_hip.h) ----------------------------------------
 struct StateLayout {
-    int Mp, nb;
-    size_t off_Lm, off_Linv, off_LinvP, off_LrTP, off_QmuP, off_Zs, off_invls, off_kl, off_ws, bytes;
+    int Mp, nbk, nrb, nsteps;
+    size_t off_Lm, off_Linv, off_LinvP, off_LrTP, off_WqP, off_ZtP, off_zc, off_invls, off_kl, off_ws, bytes;
 };
 static inline size_t align256(size_t x) { return (x + 255) & ~size_t(255); }
+// ZtP is sized for the largest input dimension (IWVI_MAX_D) so that the layout depends on (M, R) only
 static inline StateLayout state_layout(int M, int R) {
     StateLayout s;
-    s.Mp = round_up(M, 32);
-    s.nb = s.Mp / 32;
+    s.Mp = round_up(M, 16);
+    s.nbk = s.Mp / 16;
+    s.nrb = (R + 15) / 16;
+    s.nsteps = round_up(IWVI_MAX_D + 2, 4) / 4;   // allocation; the packing uses the layer's own step count
+    const size_t ntri = (size_t)tri_blocks(s.nbk);
     size_t o = 0;
     s.off_Lm = o;    o = align256(o + sizeof(double) * s.Mp * s.Mp);
     s.off_Linv = o;  o = align256(o + sizeof(double) * s.Mp * s.Mp);
-    s.off_LinvP = o; o = align256(o + sizeof(float) * s.nb * s.nb * 1024);
-    s.off_LrTP = o;  o = align256(o + sizeof(float) * (size_t)R * s.nb * s.nb * 1024);
-    s.off_QmuP = o;  o = align256(o + sizeof(float) * s.nb * 1024);
-    s.off_Zs = o;    o = align256(o + sizeof(float) * s.Mp * 32);
+    s.off_LinvP = o; o = align256(o + sizeof(float) * ntri * BLK16);
+    s.off_LrTP = o;  o = align256(o + sizeof(float) * (size_t)R * ntri * BLK16);
+    s.off_WqP = o;   o = align256(o + sizeof(float) * (size_t)s.nrb * s.nbk * BLK16);
+    s.off_ZtP = o;   o = align256(o + sizeof(float) * (size_t)s.nbk * s.nsteps * 64);
+    s.off_zc = o;    o = align256(o + sizeof(float) * 32);
     s.off_invls = o; o = align256(o + sizeof(float) * 32);
     s.off_kl = o;    o = align256(o + sizeof(double) * IWVI_MAX_R);
     {   // factorisation workspace: 16x16 blocks (17-double rows) of the lower triangle + inverses + scratch
-        const size_t nbk = s.Mp / 16;
+        const size_t nbk = s.nbk;
         const size_t blocks = nbk * (nbk + 1) / 2 + nbk + (nbk * nbk + 3) / 4;
         s.off_ws = o; o = align256(o + sizeof(double) * blocks * 16 * 17);
     }
@@ -41,14 +62,32 @@ static inline StateLayout state_layout(int M, int R) {
     return s;
 }
 
-// MFMA-fragment packing of a [32*nbr x 32*nbk] matrix G for v_mfma_f32_32x32x2_f32:
-// block (bi, bk) is 1024 floats; float4 number (q*64 + lane) of the block holds
-//   G[32*bi + (lane & 31)][32*bk + 8*q + 4*(lane >> 5) + e],  e = 0..3,  q = 0..3
-// so one global_load_dwordx4 per lane (1 KiB per wave, fully coalesced) feeds four MFMAs whose
-// k-pairs are {8q+e, 8q+4+e} -- exactly the row pairs a 32x32 accumulator register holds, which
-// lets an accumulator tile be re-used as the next MFMA's B operand (cdna guide section 3).
-__host__ __device__ static inline size_t packed_index(int nbk, int bi, int bk, int q, int lane, int e) {
-    return ((size_t)(bi * nbk + bk) * 4 + q) * 256 + lane * 4 + e;
+// ---- Philox4x32-10 (shared by the standalone generator and the in-kernel draws) ---------------
+__device__ __forceinline__ void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
+        uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0;
+        uint32_t n1 = (uint32_t)p1;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+        uint32_t n3 = (uint32_t)p0;
+        c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+}
+// words (0,1) -> (r cos, r sin), words (2,3) likewise
+__device__ __forceinline__ void box_muller4(const uint32_t c[4], float v[4]) {
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        float u1 = ((float)c[2 * p] + 0.5f) * 2.3283064365386963e-10f;       // (0,1)
+        float u2 = ((float)c[2 * p + 1] + 0.5f) * 2.3283064365386963e-10f;
+        u1 = fminf(fmaxf(u1, 1.1754944e-38f), 0.99999994f);
+        float rad = sqrtf(-2.f * logf(u1));
+        float sn, cs;
+        sincosf(6.283185307179586f * u2, &sn, &cs);
+        v[2 * p] = rad * cs; v[2 * p + 1] = rad * sn;
+    }
 }
 
 }  // namespace iwvi

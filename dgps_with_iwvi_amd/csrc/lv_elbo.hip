@@ -1,115 +1,20 @@
-// LatentVariableLayer forward (+ Encoder MLP), the IW-ELBO reduction, the K-shard merge and the
-// counter-based normal generator.  Reference: layers.py:72-105,137-152; models.py:133-150.
+// The IW-ELBO reduction, the K-shard merge, the counter-based normal generator, and the single-layer
+// LatentVariableLayer entry point (on the fused kernel of dgp_forward.hip).
+// Reference: layers.py:72-105,137-152; models.py:133-150.
 #include "iwvi_common.h"
 
 namespace iwvi {
 
-// ------------------------------------------------------------------------------------------
-// LatentVariableLayer: 32 lanes cooperate on one encoder row (one lane per output unit of each MLP
-// layer, weights staged in LDS once per workgroup), then write that row's bcast_K samples.  In the
-// IW path the encoder input [x_b, y_b] is the same for all K samples of a point (models.py:113-116), so
-// the MLP runs once per point and F / XY are read untiled ([B, .] rows, bcast_K = K).
-// ------------------------------------------------------------------------------------------
-constexpr int LV_THREADS = 256;
-constexpr int LV_GROUPS = LV_THREADS / 32;
-constexpr int LV_MAXDIM = 64;
-
-struct LvArgs {
-    const float* F; const float* XY; const float* noise;
-    const float* W[IWVI_MAX_ENC]; const float* b[IWVI_MAX_ENC];
-    int dims[IWVI_MAX_ENC + 1];
-    int n_enc, D, Lw, sampled_kl, maxdim, bcast_K, bcast_F, wtotal;
-    float* sample; float* mean; float* cov; float* kl;
-    long long E;                      // encoder rows = T / bcast_K
-};
-
-extern __shared__ __attribute__((aligned(16))) unsigned char lv_smem[];
-
-__device__ __forceinline__ float softplus_f(float x) {
-    return x > 20.f ? x : log1pf(expf(x));
-}
-
-__global__ __launch_bounds__(LV_THREADS) void k_lv_layer(LvArgs g) {
-    const int tid = threadIdx.x, grp = tid >> 5, ln = tid & 31;
-    const long long e = (long long)blockIdx.x * LV_GROUPS + grp;
-    const bool live = e < g.E;
-    const int D = g.D, Lw = g.Lw, K = g.bcast_K, Do = D + Lw;
-    // LDS: weights+biases of all layers | per group: act[2][maxdim], frow[32]
-    float* wts = reinterpret_cast<float*>(lv_smem);
-    float* gbase = wts + g.wtotal + grp * (2 * g.maxdim + 32);
-    float* act0 = gbase;
-    float* act1 = gbase + g.maxdim;
-    float* frow = gbase + 2 * g.maxdim;
-    if (g.XY) {
-        int off = 0;
-        for (int l = 0; l < g.n_enc; ++l) {
-            const int nW = g.dims[l] * g.dims[l + 1], nb = g.dims[l + 1];
-            for (int i = tid; i < nW; i += LV_THREADS) wts[off + i] = g.W[l][i];
-            for (int i = tid; i < nb; i += LV_THREADS) wts[off + nW + i] = g.b[l] ? g.b[l][i] : 0.f;
-            off += nW + nb;
-        }
-        const int d0 = g.dims[0];
-        for (int i = ln; i < d0; i += 32) act0[i] = live ? g.XY[e * d0 + i] : 0.f;
-    }
-    if (ln < D) frow[ln] = (live && g.bcast_F) ? g.F[e * D + ln] : 0.f;
-    __syncthreads();
-    float* in = act0; float* out = act1;
-    if (g.XY) {
-        int off = 0;
-        for (int l = 0; l < g.n_enc; ++l) {
-            const int din = g.dims[l], dout = g.dims[l + 1];
-            const float* W = wts + off; const float* b = W + din * dout;
-            for (int o = ln; o < dout; o += 32) {
-                float acc = b[o];
-                for (int i = 0; i < din; ++i) acc = fmaf(in[i], W[i * dout + o], acc);
-                if (l < g.n_enc - 1) acc = tanhf(acc);                         // layers.py:143-144
-                if (din == dout) acc += in[o];                                 // layers.py:146-147
-                out[o] = acc;
-            }
-            off += din * dout + dout;
-            __syncthreads();
-            float* tmp = in; in = out; out = tmp;
-        }
-    }
-    if (!live) return;
-    // `in` holds [means (Lw) | raw (Lw)]; this group's K samples are rows e*K .. e*K+K-1 (contiguous)
-    const long long t0 = e * K;
-    for (int idx = ln; idx < K * Do; idx += 32) {
-        const int k = idx / Do, c = idx - k * Do;
-        float vs, vm, vc;
-        if (c < D) { vs = vm = g.bcast_F ? frow[c] : g.F[(t0 + k) * D + c]; vc = 0.f; }
-        else {
-            const int l = c - D;
-            float mu = 0.f, sg = 1.f;                                           // prior (layers.py:73-81)
-            if (g.XY) { mu = in[l]; sg = softplus_f(in[Lw + l] - 3.f); }
-            const float z = g.noise ? g.noise[(t0 + k) * Lw + l] : 0.f;
-            vs = fmaf(z, sg, mu); vm = mu; vc = sg * sg;                        // layers.py:86-91
-        }
-        if (g.sample) g.sample[t0 * Do + idx] = vs;
-        if (g.mean) g.mean[t0 * Do + idx] = vm;
-        if (g.cov) g.cov[t0 * Do + idx] = vc;
-    }
-    if (g.kl) {
-        for (int idx = ln; idx < K * Lw; idx += 32) {
-            const int l = idx % Lw;
-            float mu = 0.f, sg = 1.f;
-            if (g.XY) { mu = in[l]; sg = softplus_f(in[Lw + l] - 3.f); }
-            const float z = g.noise ? g.noise[t0 * Lw + idx] : 0.f;
-            const float w = fmaf(z, sg, mu);
-            float kl;
-            if (g.sampled_kl) kl = -0.5f * z * z - logf(sg) + 0.5f * w * w;     // log q(W) - log p(W), :98-100
-            else kl = 0.5f * (sg * sg + mu * mu - 1.f) - logf(sg);              // KL(N(mu,sg)||N(0,1)), :101-103
-            g.kl[t0 * Lw + idx] = kl;
-        }
-    }
-}
+int dgp_forward_impl(const iwvi_layer_desc* layers, int n_layers, const float* X, int Dx, const float* XY, int XYdim,
+                     const float* Y, int Dy, int64_t T, int64_t row_div, int64_t row_mod, float lik_variance,
+                     uint64_t seed, uint64_t* rng_state, float* out_logw, hipStream_t stream);
 
 // ------------------------------------------------------------------------------------------
 // IW-ELBO reduction: one wave per data point.
 // ------------------------------------------------------------------------------------------
 constexpr int MAX_GLOB = 16;
 struct ReduceArgs {
-    const float* fmean; const float* fvar; const float* Y;
+    const float* fmean; const float* fvar; const float* Y; const float* logw;
     const float* kl[IWVI_MAX_KL]; int kl_dims[IWVI_MAX_KL]; int n_kl;
     long long B, stride_b, stride_k; int K, Dy, K_total, mode_vi;
     float lik_variance;
@@ -158,12 +63,15 @@ __global__ __launch_bounds__(ELBO_THREADS) void k_elbo(ReduceArgs g) {
             if (live && k < K) {
                 const long long t = b * g.stride_b + k * g.stride_k;
                 float acc = 0.f;
-                for (int d = 0; d < Dy; ++d) {
-                    const float df = g.Y[b * Dy + d] - g.fmean[t * Dy + d];
-                    acc += c0 - (df * df + g.fvar[t * Dy + d]) * inv2s;
+                if (g.logw) acc = g.logw[t];                   // models.py:134-142 done by the fused forward
+                else {
+                    for (int d = 0; d < Dy; ++d) {
+                        const float df = g.Y[b * Dy + d] - g.fmean[t * Dy + d];
+                        acc += c0 - (df * df + g.fvar[t * Dy + d]) * inv2s;
+                    }
+                    for (int i = 0; i < g.n_kl; ++i)
+                        for (int d = 0; d < g.kl_dims[i]; ++d) acc -= g.kl[i][t * g.kl_dims[i] + d];
                 }
-                for (int i = 0; i < g.n_kl; ++i)
-                    for (int d = 0; d < g.kl_dims[i]; ++d) acc -= g.kl[i][t * g.kl_dims[i] + d];
                 L = acc;
             }
             if (g.mode_vi) { lsum += seg_sum<SEG>((live && k < K) ? L : 0.f); continue; }
@@ -191,8 +99,9 @@ __global__ __launch_bounds__(ELBO_THREADS) void k_elbo(ReduceArgs g) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const unsigned long long t = __hip_atomic_fetch_add(g.ticket, 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int last = ((t + 1) % gridDim.x) == 0;
+        const int last = (t == (unsigned long long)gridDim.x - 1);
         if (last) {
+            __hip_atomic_store(g.ticket, 0ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next call
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
@@ -262,20 +171,6 @@ __global__ __launch_bounds__(1024) void k_elbo_final(FinalArgs g) {
 // Philox4x32-10 + Box-Muller.  Element i of the output uses counter (offset + i/4, 0, 0, 0), key
 // (seed_lo, seed_hi), word i%4: words (0,1) -> (r cos, r sin), words (2,3) likewise.
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
-#pragma unroll
-    for (int r = 0; r < 10; ++r) {
-        uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
-        uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
-        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0;
-        uint32_t n1 = (uint32_t)p1;
-        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
-        uint32_t n3 = (uint32_t)p0;
-        c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
-        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-    }
-}
-
 template <bool DEVCTR>
 __global__ void k_fill_normal(float* out, long long n, uint64_t seed, uint64_t offset, unsigned long long* state) {
     const long long nq = (n + 3) / 4;
@@ -286,16 +181,7 @@ __global__ void k_fill_normal(float* out, long long n, uint64_t seed, uint64_t o
         uint32_t c[4] = {(uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, 0u};
         philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
         float v[4];
-#pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            float u1 = ((float)c[2 * p] + 0.5f) * 2.3283064365386963e-10f;       // (0,1)
-            float u2 = ((float)c[2 * p + 1] + 0.5f) * 2.3283064365386963e-10f;
-            u1 = fminf(fmaxf(u1, 1.1754944e-38f), 0.99999994f);
-            float rad = sqrtf(-2.f * logf(u1));
-            float sn, cs;
-            sincosf(6.283185307179586f * u2, &sn, &cs);
-            v[2 * p] = rad * cs; v[2 * p + 1] = rad * sn;
-        }
+        box_muller4(c, v);
         for (int e = 0; e < 4; ++e) if (4 * q + e < n) out[4 * q + e] = v[e];
     }
     if (DEVCTR) {
@@ -316,38 +202,17 @@ extern "C" int iwvi_lv_layer_forward(const float* F, const float* XY, const floa
                                      const float* const* enc_W, const float* const* enc_b,
                                      const int32_t* dims, int n_enc, int D, int Lw, int sampled_kl,
                                      float* sample, float* mean, float* cov, float* kl,
-                                     int64_t T, int bcast_K, int bcast_F, void* stream_) {
+                                     int64_t T, void* stream_) {
     if (T <= 0) return IWVI_OK;
     if (!F) { set_error("iwvi_lv_layer_forward: null input"); return IWVI_ERR_ARG; }
-    if (D <= 0 || D > 32 || Lw <= 0) { set_error("iwvi_lv_layer_forward: bad D=%d (1..32) or latent_dim=%d", D, Lw); return IWVI_ERR_ARG; }
-    if (bcast_K < 1 || T % bcast_K != 0) { set_error("iwvi_lv_layer_forward: T=%lld is not a multiple of bcast_K=%d", (long long)T, bcast_K); return IWVI_ERR_ARG; }
-    LvArgs g{};
-    g.F = F; g.XY = XY; g.noise = noise; g.D = D; g.Lw = Lw; g.sampled_kl = sampled_kl;
-    g.sample = sample; g.mean = mean; g.cov = cov; g.kl = kl; g.E = T / bcast_K; g.bcast_K = bcast_K; g.bcast_F = (bcast_F || bcast_K == 1) ? 1 : 0;
-    int maxdim = 2 * Lw, wtotal = 0;
-    if (XY) {
-        if (!enc_W || !dims || n_enc <= 0 || n_enc > IWVI_MAX_ENC) {
-            set_error("iwvi_lv_layer_forward: encoder with %d layers (1..%d supported)", n_enc, IWVI_MAX_ENC); return IWVI_ERR_ARG;
-        }
-        if (dims[n_enc] != 2 * Lw) { set_error("iwvi_lv_layer_forward: encoder output %d != 2*latent_dim %d", dims[n_enc], 2 * Lw); return IWVI_ERR_ARG; }
-        for (int i = 0; i <= n_enc; ++i) {
-            if (dims[i] <= 0 || dims[i] > LV_MAXDIM) { set_error("iwvi_lv_layer_forward: encoder width %d out of range (1..%d)", dims[i], LV_MAXDIM); return IWVI_ERR_ARG; }
-            g.dims[i] = dims[i];
-            if (dims[i] > maxdim) maxdim = dims[i];
-        }
-        for (int i = 0; i < n_enc; ++i) {
-            if (!enc_W[i]) { set_error("iwvi_lv_layer_forward: null encoder weight %d", i); return IWVI_ERR_ARG; }
-            g.W[i] = enc_W[i]; g.b[i] = enc_b ? enc_b[i] : nullptr;
-            wtotal += dims[i] * dims[i + 1] + dims[i + 1];
-        }
-        g.n_enc = n_enc;
-    }
-    if (maxdim > LV_MAXDIM) { set_error("iwvi_lv_layer_forward: latent_dim too large"); return IWVI_ERR_ARG; }
-    g.maxdim = maxdim; g.wtotal = wtotal;
-    size_t lds = sizeof(float) * ((size_t)wtotal + (size_t)LV_GROUPS * (2 * maxdim + 32));
-    long long blocks = (g.E + LV_GROUPS - 1) / LV_GROUPS;
-    hipLaunchKernelGGL(k_lv_layer, dim3((unsigned)blocks), dim3(LV_THREADS), lds, (hipStream_t)stream_, g);
-    return check_launch("k_lv_layer");
+    if (D <= 0 || D > IWVI_MAX_D || Lw <= 0) { set_error("iwvi_lv_layer_forward: bad D=%d (1..32) or latent_dim=%d", D, Lw); return IWVI_ERR_ARG; }
+    iwvi_layer_desc d{};
+    d.type = IWVI_LAYER_LV; d.D = D; d.latent_dim = Lw; d.sampled_kl = sampled_kl;
+    if (XY) { d.enc_W = enc_W; d.enc_b = enc_b; d.enc_dims = dims; d.n_enc = n_enc;
+              if (!enc_W || !dims) { set_error("iwvi_lv_layer_forward: encoder inputs without an encoder"); return IWVI_ERR_ARG; } }
+    d.noise = noise; d.zero_noise = 1; d.sample = sample; d.mean = mean; d.var = cov; d.kl_local = kl;
+    return dgp_forward_impl(&d, 1, F, D, XY, XY ? dims[0] : 0, nullptr, 0, T, 1, T, 1.f, 0, nullptr, nullptr,
+                            (hipStream_t)stream_);
 }
 
 template <typename ArgsT>
@@ -393,6 +258,28 @@ extern "C" int iwvi_iw_elbo_reduce(const float* fmean, const float* fvar, const 
     g.stride_b = stride_b; g.stride_k = stride_k;
     g.B = B; g.K = K; g.Dy = Dy; g.K_total = K_total > 0 ? K_total : K; g.mode_vi = mode_vi;
     g.lik_variance = lik_variance; g.ms = out_ms; g.logp = out_logp;
+    g.elbo = out_elbo; g.ticket = (unsigned long long*)ticket; g.scale = scale;
+    int rc;
+    if (out_elbo && (rc = fill_globals(g, kl_global, kl_global_counts, n_glob)) != IWVI_OK) return rc;
+    if (K <= 4) return launch_elbo<4>(g, stream);
+    if (K <= 8) return launch_elbo<8>(g, stream);
+    if (K <= 16) return launch_elbo<16>(g, stream);
+    if (K <= 32) return launch_elbo<32>(g, stream);
+    return launch_elbo<64>(g, stream);
+}
+
+extern "C" int iwvi_logw_reduce(const float* logw, int64_t B, int K, int64_t stride_b, int64_t stride_k,
+                                const double* const* kl_global, const int32_t* kl_global_counts, int n_glob,
+                                double scale, int K_total, int mode_vi,
+                                float* out_ms, float* out_logp, double* out_elbo, uint64_t* ticket, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!logw) { set_error("iwvi_logw_reduce: null input"); return IWVI_ERR_ARG; }
+    if (B <= 0 || K <= 0) { set_error("iwvi_logw_reduce: empty minibatch or K=%d", K); return IWVI_ERR_ARG; }
+    if (out_elbo && (!out_logp || !ticket)) { set_error("iwvi_logw_reduce: out_elbo needs out_logp (scratch) and a zero-initialised ticket word"); return IWVI_ERR_ARG; }
+    ReduceArgs g{};
+    g.logw = logw; g.stride_b = stride_b; g.stride_k = stride_k;
+    g.B = B; g.K = K; g.Dy = 1; g.K_total = K_total > 0 ? K_total : K; g.mode_vi = mode_vi;
+    g.lik_variance = 1.f; g.ms = out_ms; g.logp = out_logp;
     g.elbo = out_elbo; g.ticket = (unsigned long long*)ticket; g.scale = scale;
     int rc;
     if (out_elbo && (rc = fill_globals(g, kl_global, kl_global_counts, n_glob)) != IWVI_OK) return rc;

@@ -4,9 +4,9 @@
 // tf.matrix_triangular_solve (:51), tf.matrix_band_part(q_sqrt) (:78) and gauss_kl (:186-188).
 //
 // ONE launch for all layers of a model: grid = (layer, role), 1024-thread workgroups.
-//   role 0        Gram + Cholesky + triangular inverse + packing of Lm^-1   (the serial critical path)
-//   role 1..R     tril(q_sqrt[r])^T packing
-//   role R+1      q_mu^T packing + KL[q(u) || p(u)]
+//   role 0        Gram + Cholesky + triangular inverse + packing of Lm^-1, (Lm^-T q_mu)^T and the K_uf
+//                 operand Z~   (the serial critical path)
+//   role 1..R     tril(q_sqrt[r])^T packing + latent GP r's share of KL[q(u) || p(u)]
 // The factorisation works on 16x16 blocks of the lower triangle (row stride 17 doubles: conflict-free
 // ds_read_b64), resident in LDS for Mp <= 128 (78 KB) and in an L2-resident workspace otherwise:
 //   * diagonal block: one wave, row-per-lane in registers, pivots/columns broadcast with v_readlane
@@ -28,10 +28,10 @@ constexpr int ZLD = 33;           // row stride of the LDS copy of Zs (floats)
 
 struct PreLayer {
     const float* Z; const float* ls; const float* q_mu; const float* q_sqrt;
-    double* Lm; double* Linv; float* LinvP; float* LrTP; float* QmuP; float* Zs; float* invls; double* kl;
+    double* Lm; double* Linv; float* LinvP; float* LrTP; float* WqP; float* ZtP; float* zc; float* invls; double* kl;
     double* ws;
     double jitter; float variance;
-    int M, D, R, Mp, nb, kern_type;
+    int M, D, R, Mp, nbk, nrb, kern_type, flags;
 };
 struct PreArgs { PreLayer L[IWVI_MAX_LAYERS]; int n; int stop_after; };
 
@@ -232,10 +232,10 @@ __device__ __forceinline__ double inv_get(const double* blk, const double* dinv,
 template <bool IN_LDS>
 __device__ void role_factor(const PreLayer& L, int stop_after) {
     const int tid = threadIdx.x, nthreads = blockDim.x;
-    const int M = L.M, D = L.D, Mp = L.Mp;
+    const int M = L.M, D = L.D, Mp = L.Mp, R = L.R;
     const WsLayout w = ws_layout(Mp);
     const int nbk = w.nbk;
-    // LDS carve: rinv [Mp] doubles | (IN_LDS: blocks, dinv, tbuf) | Zs copy [Mp][ZLD] floats
+    // LDS carve: rinv [Mp] doubles | (IN_LDS: blocks, dinv, tbuf) | zs [Mp][ZLD] floats | zn [Mp] | zcs [32]
     double* sm = reinterpret_cast<double*>(smem_raw);
     double* rinv = sm;
     double* base = IN_LDS ? sm + Mp : L.ws;
@@ -243,18 +243,30 @@ __device__ void role_factor(const PreLayer& L, int stop_after) {
     double* dinv = base + w.dinv;
     double* tbuf = base + w.tbuf;
     float* zs = reinterpret_cast<float*>(sm + Mp + (IN_LDS ? w.total : 0));
+    float* zn = zs + (size_t)Mp * ZLD;          // |zs_m - zc|^2
+    float* zcs = zn + Mp;                       // centre of the scaled inducing inputs
 
+    // scaled inducing inputs, float32-rounded (the values the K_uf Gram also sees)
     for (int idx = tid; idx < Mp * 32; idx += nthreads) {
         const int m = idx >> 5, d = idx & 31;
         float v = 0.f;
         if (m < M && d < D) v = (float)((double)L.Z[(size_t)m * D + d] / (double)L.ls[d]);
-        L.Zs[idx] = v;
         zs[m * ZLD + d] = v;
     }
     if (tid < 32) L.invls[tid] = (tid < D) ? (float)(1.0 / (double)L.ls[tid]) : 0.f;
     __syncthreads();
+    // centre: K_uf is formed as exp2(x~ . z~) with |x|^2 + |z|^2 - 2 x.z expanded (like gpflow's
+    // square_dist); subtracting a common centre leaves r^2 unchanged and keeps the expansion well scaled
+    if (tid < 32) {
+        double acc = 0.0;
+        for (int m = 0; m < M; ++m) acc += (double)zs[m * ZLD + tid];
+        const float c = (tid < D) ? (float)(acc / (double)M) : 0.f;
+        zcs[tid] = c;
+        L.zc[tid] = c;
+    }
+    __syncthreads();
     if (stop_after == 1) return;
-    // Gram of the float32-rounded scaled inducing inputs (the values K_uf also sees), lower blocks only
+    // Gram of the float32-rounded scaled inducing inputs, lower blocks only
     for (int idx = tid; idx < nbk * nbk * 256; idx += nthreads) {
         const int b = idx >> 8, e = idx & 255;
         const int bi = b / nbk, bj = b - bi * nbk;
@@ -274,32 +286,78 @@ __device__ void role_factor(const PreLayer& L, int stop_after) {
         blk[boff(bi, bj) + (e >> 4) * BLD + (e & 15)] = v;
     }
     __syncthreads();
+    // K_uf operand Z~ (MFMA A fragments): RBF  z~ = [c zs, c, -c|zs|^2/2 + log2 var] with x~ = [xs, -|xs|^2/2, 1],
+    // c = log2 e, so that k = exp2(x~ . z~);  Matern52  z~ = [-2 zs, 1, |zs|^2] with x~ = [xs, |xs|^2, 1] -> r^2
+    for (int m = tid; m < Mp; m += nthreads) {
+        double n2 = 0.0;
+        for (int d = 0; d < D; ++d) {
+            const float c = zs[m * ZLD + d] - zcs[d];
+            zs[m * ZLD + d] = c;                                     // centred from here on
+            n2 = fma((double)c, (double)c, n2);
+        }
+        zn[m] = (float)n2;
+    }
+    __syncthreads();
+    {
+        const int nsteps = round_up(D + 2, 4) / 4;
+        const bool rbf = L.kern_type == IWVI_KERN_RBF;
+        const double c = 1.4426950408889634;
+        for (int idx = tid; idx < nbk * nsteps * 64; idx += nthreads) {
+            const int lane = idx & 63, s = (idx >> 6) % nsteps, bi = (idx >> 6) / nsteps;
+            const int m = 16 * bi + (lane & 15), f = 4 * s + (lane >> 4);
+            float v = 0.f;
+            if (m < M) {
+                if (f < D) v = rbf ? (float)(c * (double)zs[m * ZLD + f]) : -2.f * zs[m * ZLD + f];
+                else if (f == D) v = rbf ? (float)c : 1.f;
+                else if (f == D + 1) v = rbf ? (float)(-0.5 * c * (double)zn[m] + log2((double)L.variance)) : zn[m];
+            } else if (f == D + 1 && rbf) v = -1.0e30f;              // padding rows: k = exp2(-huge) = 0
+            L.ZtP[idx] = v;
+        }
+    }
+    __syncthreads();
     if (stop_after == 2) return;
     chol_blocks(blk, nbk, rinv, tid, nthreads, stop_after);
     if (stop_after == 3 || stop_after > 30) return;
-    for (int idx = tid; idx < Mp * Mp; idx += nthreads) {
-        const int i = idx / Mp, k = idx - i * Mp;
-        L.Lm[idx] = (k <= i) ? blk_get(blk, i, k) : 0.0;
+    if (L.flags & IWVI_GP_WANT_DENSE) {
+        for (int idx = tid; idx < Mp * Mp; idx += nthreads) {
+            const int i = idx / Mp, k = idx - i * Mp;
+            L.Lm[idx] = (k <= i) ? blk_get(blk, i, k) : 0.0;
+        }
+        __syncthreads();
     }
-    __syncthreads();
     if (stop_after == 4) return;
     invert_blocks(blk, dinv, tbuf, rinv, nbk, tid, nthreads);
     if (stop_after == 5) return;
-    for (int idx = tid; idx < Mp * Mp; idx += nthreads) {
-        const int i = idx / Mp, k = idx - i * Mp;
-        L.Linv[idx] = (k <= i) ? inv_get(blk, dinv, i, k) : 0.0;
+    if (L.flags & IWVI_GP_WANT_DENSE) {
+        for (int idx = tid; idx < Mp * Mp; idx += nthreads) {
+            const int i = idx / Mp, k = idx - i * Mp;
+            L.Linv[idx] = (k <= i) ? inv_get(blk, dinv, i, k) : 0.0;
+        }
     }
-    // MFMA-fragment packed float32 Lm^-1 (blocks bi >= bk), identity padding masked to zero
-    const int nb = L.nb;
-    for (int idx = tid; idx < nb * nb * 1024; idx += nthreads) {
-        const int b = idx >> 10, e1 = idx & 1023;
-        const int bi = b / nb, bk = b - bi * nb;
-        if (bk > bi) continue;
-        const int q = e1 >> 8, lane = (e1 >> 2) & 63, e = e1 & 3;
-        const int i = 32 * bi + (lane & 31), k = 32 * bk + 8 * q + 4 * (lane >> 5) + e;
+    // packed float32 Lm^-1: lower-triangular 16x16 blocks, row-block major; identity padding masked to zero
+    const int ntri = tri_blocks(nbk);
+    for (int idx = tid; idx < ntri * BLK16; idx += nthreads) {
+        const int b = idx >> 8, e1 = idx & 255;
+        int bi = (int)((sqrtf(8.f * b + 1.f) - 1.f) * 0.5f);
+        while (tri_lower_off(bi + 1) <= b) ++bi;
+        while (tri_lower_off(bi) > b) --bi;
+        const int bk = b - tri_lower_off(bi);
+        const int lane = e1 >> 2, s = e1 & 3;
+        const int i = 16 * bi + (lane & 15), k = 16 * bk + 4 * (lane >> 4) + s;
         float v = 0.f;
         if (i < M && k < M && k <= i) v = (float)inv_get(blk, dinv, i, k);
         L.LinvP[idx] = v;
+    }
+    // mean operand  Wq = (Lm^-T q_mu)^T  [R rows padded to 16*nrb][Mp]:  mean_r = k^T Lm^-T q_mu[:, r]
+    // (temp_workaround.py:68 with A = Lm^-1 k), so the mean needs K_uf only, not the solved A
+    const int nrb = L.nrb;
+    for (int idx = tid; idx < nrb * 16 * Mp; idx += nthreads) {
+        const int r = idx / Mp, m = idx - r * Mp;
+        double acc = 0.0;
+        if (r < R && m < M)
+            for (int i = m; i < M; ++i) acc = fma(inv_get(blk, dinv, i, m), (double)L.q_mu[(size_t)i * R + r], acc);
+        const int rb = r >> 4, ii = r & 15, bk = m >> 4, g = (m & 15) >> 2, s = m & 3;
+        L.WqP[((size_t)(rb * nbk + bk) * 64 + 16 * g + ii) * 4 + s] = (float)acc;
     }
 }
 
@@ -313,22 +371,22 @@ __device__ __forceinline__ double block_sum(double v, double* red) {
     return red[0];
 }
 
-// Role r+1: pack tril(q_sqrt[r])^T into MFMA fragment order (blocks bi <= bk) and, from the same values,
-// this latent GP's share of the whitened KL:  kl[r] = 1/2 (|q_mu[:,r]|^2 - M - sum log L_ii^2 + |tril L|^2).
-// One float4 of the packed image per thread-iteration: 4 coalesced row reads, one 16-byte store.
-// Role 1 also packs q_mu^T (R rows padded to 32) for the mean jobs.
+// Role r+1: pack tril(q_sqrt[r])^T into MFMA fragment order (upper-triangular 16x16 blocks, row-block
+// major) and, from the same values, this latent GP's share of the whitened KL:
+//   kl[r] = 1/2 (|q_mu[:,r]|^2 - M - sum log L_ii^2 + |tril L|^2).
+// One float4 of the packed image per thread-iteration, one 16-byte store.
 __device__ void role_pack_r(const PreLayer& L, int r, double* red) {
-    const int nb = L.nb, M = L.M, R = L.R;
+    const int nbk = L.nbk, M = L.M, R = L.R;
     const float* q = L.q_sqrt + (size_t)r * M * M;
-    float4* dstm = reinterpret_cast<float4*>(L.LrTP + (size_t)r * nb * nb * 1024);
+    float4* dstm = reinterpret_cast<float4*>(L.LrTP + (size_t)r * tri_blocks(nbk) * BLK16);
     double acc = 0.0;
-    const int nvec = nb * nb * 256;
+    const int nvec = nbk * nbk * 64;
     for (int v4 = threadIdx.x; v4 < nvec; v4 += blockDim.x) {
-        const int b = v4 >> 8, bi = b / nb, bk = b - bi * nb;
+        const int b = v4 >> 6, bi = b / nbk, bk = b - bi * nbk;
         if (bi > bk) continue;
-        const int qq = (v4 >> 6) & 3, lane = v4 & 63;
-        const int i = 32 * bi + (lane & 31);
-        const int k0 = 32 * bk + 8 * qq + 4 * (lane >> 5);
+        const int lane = v4 & 63;
+        const int i = 16 * bi + (lane & 15);
+        const int k0 = 16 * bk + 4 * (lane >> 4);
         float o[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -339,22 +397,11 @@ __device__ void role_pack_r(const PreLayer& L, int r, double* red) {
             acc += (double)x * (double)x;
             if (k == i && i < M) acc -= log((double)x * (double)x);
         }
-        dstm[v4] = make_float4(o[0], o[1], o[2], o[3]);
+        dstm[(size_t)(tri_upper_off(nbk, bi) + (bk - bi)) * 64 + lane] = make_float4(o[0], o[1], o[2], o[3]);
     }
     for (int m = threadIdx.x; m < M; m += blockDim.x) {
         const double v = L.q_mu[(size_t)m * R + r];
         acc += v * v;
-    }
-    if (r == 0) {
-        float4* dq = reinterpret_cast<float4*>(L.QmuP);
-        for (int v4 = threadIdx.x; v4 < nb * 256; v4 += blockDim.x) {
-            const int bk = v4 >> 8, qq = (v4 >> 6) & 3, lane = v4 & 63;
-            const int rr = lane & 31, k0 = 32 * bk + 8 * qq + 4 * (lane >> 5);
-            float o[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = (rr < R && k0 + e < M) ? L.q_mu[(size_t)(k0 + e) * R + rr] : 0.f;
-            dq[v4] = make_float4(o[0], o[1], o[2], o[3]);
-        }
     }
     const double tot = block_sum(acc, red);
     if (threadIdx.x == 0) L.kl[r] = 0.5 * (tot - (double)M);
@@ -453,7 +500,7 @@ static int ensure_lds_attr(const void* fn, size_t bytes) {
 static size_t factor_lds_bytes(int Mp) {
     size_t d = (size_t)Mp;                                   // rinv
     if (Mp <= 128) d += ws_layout(Mp).total;                 // blocks + dinv + tbuf resident in LDS
-    return d * sizeof(double) + (size_t)Mp * ZLD * sizeof(float);
+    return d * sizeof(double) + ((size_t)Mp * ZLD + Mp + 32) * sizeof(float);
 }
 
 }  // namespace iwvi
@@ -465,11 +512,11 @@ extern "C" size_t iwvi_gp_state_bytes(int M, int R) {
     return state_layout(M, R).bytes;
 }
 
-extern "C" int iwvi_gp_state_offsets(int M, int R, size_t out[8]) {
+extern "C" int iwvi_gp_state_offsets(int M, int R, size_t out[9]) {
     if (M <= 0 || R <= 0 || !out) { set_error("iwvi_gp_state_offsets: bad argument"); return IWVI_ERR_ARG; }
     StateLayout s = state_layout(M, R);
     out[0] = s.off_Lm; out[1] = s.off_Linv; out[2] = s.off_LinvP; out[3] = s.off_LrTP;
-    out[4] = s.off_QmuP; out[5] = s.off_Zs; out[6] = s.off_invls; out[7] = s.off_kl;
+    out[4] = s.off_WqP; out[5] = s.off_ZtP; out[6] = s.off_zc; out[7] = s.off_invls; out[8] = s.off_kl;
     return IWVI_OK;
 }
 
@@ -501,12 +548,12 @@ extern "C" int iwvi_gp_precompute(const iwvi_gp_desc* layers, int n_layers, void
             L.Z = d.Z; L.ls = d.lengthscales; L.q_mu = d.q_mu; L.q_sqrt = d.q_sqrt;
             L.Lm = (double*)(st + s.off_Lm); L.Linv = (double*)(st + s.off_Linv);
             L.LinvP = (float*)(st + s.off_LinvP); L.LrTP = (float*)(st + s.off_LrTP);
-            L.QmuP = (float*)(st + s.off_QmuP); L.Zs = (float*)(st + s.off_Zs);
-            L.invls = (float*)(st + s.off_invls);
+            L.WqP = (float*)(st + s.off_WqP); L.ZtP = (float*)(st + s.off_ZtP);
+            L.zc = (float*)(st + s.off_zc); L.invls = (float*)(st + s.off_invls);
             L.kl = (double*)(st + s.off_kl);
             L.ws = (double*)(st + s.off_ws);
             L.jitter = d.jitter; L.variance = d.variance;
-            L.M = d.M; L.D = d.D; L.R = d.R; L.Mp = s.Mp; L.nb = s.nb; L.kern_type = d.kern_type;
+            L.M = d.M; L.D = d.D; L.R = d.R; L.Mp = s.Mp; L.nbk = s.nbk; L.nrb = s.nrb; L.kern_type = d.kern_type; L.flags = d.flags;
             size_t la = factor_lds_bytes(s.Mp);
             if (la > lds) lds = la;
             if (d.R + 1 > max_roles) max_roles = d.R + 1;

@@ -87,17 +87,49 @@ class GPLayer:
         """KL[q(u)||p(u)] of the last precompute (0-dim float64 device tensor)."""
         return self.state().kl
 
+    def fused_desc(self, z=None, outputs=None, draw=True):
+        """``iwvi_layer_desc`` of this layer for ``iwvi_dgp_forward`` (state must be precomputed).
+        ``outputs``: optional dict sample/mean/var -> [T, P] tensors;  z: [T, R] noise, or None ->
+        drawn inside the kernel (``draw``) / zero."""
+        d = _abi.LayerDesc()
+        kern = self._base_kern()
+        M, D = self._Z().shape
+        R = self.num_outputs
+        W = _abi.dev_tensor(self.kern.W, "W") if isinstance(self.kern, SharedMixedMok) else None
+        P = W.shape[0] if W is not None else R
+        if W is not None and W.shape[1] != R:
+            raise ValueError("W is %s but there are %d latent GPs" % (tuple(W.shape), R))
+        mf = self.mean_function
+        d.type, d.state = _abi.LAYER_GP, self.state().buf.data_ptr()
+        d.M, d.D, d.R, d.P = M, D, R, P
+        d.kern_type, d.mf_type, d.variance = kern.kern_type, mf.mf_type, kern.variance
+        keep = [W]
+        if W is not None:
+            d.W = W.data_ptr()
+        if mf.mf_type == _abi.MF_LINEAR:
+            if tuple(mf.A.shape) != (D, P):
+                raise ValueError("Linear mean function A is %s, layer needs (%d, %d)" % (tuple(mf.A.shape), D, P))
+            d.mf_A = _abi.dev_tensor(mf.A, "mean_function.A").data_ptr()
+            if mf.b is not None:
+                d.mf_b = _abi.dev_tensor(mf.b, "mean_function.b").data_ptr()
+        if z is not None:
+            d.noise = _abi.dev_tensor(z, "z").data_ptr()
+            keep.append(z)
+        d.zero_noise = 0 if draw else 1
+        for k, t in (outputs or {}).items():
+            setattr(d, k, t.data_ptr())
+        return d, keep
+
     # -- reference API --------------------------------------------------------------------
-    def propagate(self, F, full_cov=False, z=None, _precomputed=False, _kl_parts=False, _bcast_K=None, **kwargs):
-        """reference layers.py:35-50 -> (samples, mean, cov, kl).
-        ``_bcast_K`` (model-internal): F is the untiled [B, D] minibatch standing for [B, K, D]."""
+    def propagate(self, F, full_cov=False, z=None, _precomputed=False, _kl_parts=False, **kwargs):
+        """reference layers.py:35-50 -> (samples, mean, cov, kl)."""
         if not _precomputed:
             self.precompute()
         plain_full = full_cov and not isinstance(self.kern, SharedMixedMok)
         mf = None if plain_full else self.mean_function            # fused into the kernel epilogue
         samples, mean, cov = multisample_sample_conditional(
             F, self.feature, self.kern, self.q_mu, full_cov=full_cov, q_sqrt=self.q_sqrt, white=True,
-            z=z, state=self.state(), mean_function=mf, precomputed=True, bcast_K=_bcast_K)
+            z=z, state=self.state(), mean_function=mf, precomputed=True)
         # layers.py:44 (computed by the precompute); _kl_parts hands the model the R per-GP shares
         # so that the ELBO reduction sums them without an extra launch
         kl = self.state().kl_parts if _kl_parts else self.kl
@@ -150,7 +182,7 @@ class Encoder:
         Wp, bp, dims, n, keep = self.abi_args()
         _abi.check(_abi.lib().iwvi_lv_layer_forward(
             _abi.ptr(dummy), _abi.ptr(Z.reshape(T, -1)), None, Wp, bp, dims, n, 1, Lw, 0,
-            None, _abi.ptr(mean), _abi.ptr(cov), None, T, 1, 1, _abi.stream_ptr()))
+            None, _abi.ptr(mean), _abi.ptr(cov), None, T, _abi.stream_ptr()))
         return mean[:, 1:].reshape(*lead, Lw), cov[:, 1:].sqrt().reshape(*lead, Lw)
 
 
@@ -169,38 +201,45 @@ class LatentVariableLayer:
         self.encoder.to(device)
         return self
 
+    def fused_desc(self, D, z=None, outputs=None, sampled_kl=True, use_encoder=True, draw=True):
+        """``iwvi_layer_desc`` of this layer for ``iwvi_dgp_forward`` (D = width of the incoming F)."""
+        d = _abi.LayerDesc()
+        d.type, d.D, d.latent_dim, d.sampled_kl = _abi.LAYER_LV, D, self.latent_dim, 1 if sampled_kl else 0
+        keep = []
+        if use_encoder:
+            Wp, bp, dims, n, k2 = self.encoder.abi_args()
+            d.enc_W, d.enc_b, d.enc_dims, d.n_enc = Wp, bp, dims, n
+            keep += [Wp, bp, dims, k2]
+        if z is not None:
+            d.noise = _abi.dev_tensor(z, "z").data_ptr()
+            keep.append(z)
+        d.zero_noise = 0 if draw else 1
+        for k, t in (outputs or {}).items():
+            setattr(d, k, t.data_ptr())
+        return d, keep
+
     def propagate(self, F, inference_amorization_inputs=None, is_sampled_local_regularizer=False,
-                  z=None, _bcast_K=None, _bcast_XY=None, **kwargs):
-        """reference layers.py:72-105 -> (samples, mean, cov, kl) with kl [..., latent_dim].
-        Model-internal: ``_bcast_K`` = F (and the encoder input) are the untiled [B, .] minibatch standing
-        for [B, K, .]; ``_bcast_XY`` = only the encoder input is untiled (F is already [B, K, D])."""
+                  z=None, **kwargs):
+        """reference layers.py:72-105 -> (samples, mean, cov, kl) with kl [..., latent_dim]."""
         F = _abi.dev_tensor(F.contiguous(), "F")
         D, Lw, dev = F.shape[-1], self.latent_dim, F.device
-        Kb = _bcast_K or _bcast_XY or 1
-        bcast_F = 1 if (_bcast_K or Kb == 1) else 0
-        if _bcast_K:
-            if F.dim() != 2:
-                raise ValueError("_bcast_K needs the untiled [B, D] input")
-            lead = (F.shape[0], _bcast_K)
-        else:
-            lead = F.shape[:-1]
+        lead = F.shape[:-1]
         T = int(np.prod(lead)) if len(lead) else 1
         XY = inference_amorization_inputs
         if XY is not None:
             XY = _abi.dev_tensor(XY.contiguous(), "inference_amorization_inputs")
+            if XY.shape[:-1] != lead:
+                raise ValueError("inference_amorization_inputs %s does not match F %s" % (tuple(XY.shape), tuple(F.shape)))
             if XY.shape[-1] != self.encoder.layer_dims[0]:
                 raise ValueError("encoder expects %d features, got %d" % (self.encoder.layer_dims[0], XY.shape[-1]))
-            XY = XY.reshape(-1, XY.shape[-1])
-            if XY.shape[0] * Kb != T:
-                raise ValueError("inference_amorization_inputs has %d rows, expected %d" % (XY.shape[0], T // Kb))
+            XY = XY.reshape(T, -1)
         z2 = draw_normal((T, Lw), dev) if z is None else _abi.dev_tensor(z.reshape(T, Lw).contiguous(), "z")
         outs = [torch.empty(T, D + Lw, dtype=settings.float_type, device=dev) for _ in range(3)]
         kl = torch.empty(T, Lw, dtype=settings.float_type, device=dev)
         Wp, bp, dims, n, keep = self.encoder.abi_args()
         _abi.check(_abi.lib().iwvi_lv_layer_forward(
-            _abi.ptr(F.reshape(-1, D)), _abi.ptr(XY), _abi.ptr(z2), Wp, bp, dims, n, D, Lw,
+            _abi.ptr(F.reshape(T, D)), _abi.ptr(XY), _abi.ptr(z2), Wp, bp, dims, n, D, Lw,
             1 if is_sampled_local_regularizer else 0,
-            _abi.ptr(outs[0]), _abi.ptr(outs[1]), _abi.ptr(outs[2]), _abi.ptr(kl), T, Kb, bcast_F,
-            _abi.stream_ptr()))
+            _abi.ptr(outs[0]), _abi.ptr(outs[1]), _abi.ptr(outs[2]), _abi.ptr(kl), T, _abi.stream_ptr()))
         s, m, c = (o.view(*lead, D + Lw) for o in outs)
         return s, m, c, kl.view(*lead, Lw)

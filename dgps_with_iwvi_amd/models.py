@@ -4,12 +4,17 @@ with the same constructor / method signatures, running on the HIP kernels behind
 ``DGP_IWVI._build_likelihood`` is the north-star function; ``E_log_p_Y`` (the name used in the older
 doubly-stochastic DGP code and in BASELINE.json) is an alias for its per-point log-weight stage.
 
+One ELBO evaluation is three launches: ``iwvi_gp_precompute`` (Gram + Cholesky + operand packing of every
+GP layer), ``iwvi_dgp_forward`` (the tiling of X/Y over K, every layer, the Gaussian variational
+expectation and the local regularisers, fused: a workgroup carries its samples through all layers in LDS)
+and ``iwvi_logw_reduce`` (log-sum-exp over K, scaled sum, minus the global KLs).
+
 Differences from the reference, all documented in DESIGN.md:
-  * ``zs`` (one N(0,1) array or None per layer) injects the noise tf.random_normal draws in-graph;
+  * ``zs`` (one N(0,1) array or None per layer) injects the noise tf.random_normal draws in-graph; None
+    draws inside the kernel from a counter-based Philox stream (``settings.seed``, per-model step counter);
   * the IW path asks the final layer for marginal variances only (``full_cov_over_samples=False``):
     the reference builds the [B, Dy, K, K] covariance and keeps its diagonal (models.py:129-133),
-    the result is identical; set the flag to follow the reference literally;
-  * all per-step Gram/Cholesky work of every GP layer is batched into one ``iwvi_gp_precompute`` call.
+    the result is identical; set the flag to follow the reference literally (layer-by-layer launches).
 """
 import ctypes
 
@@ -17,7 +22,7 @@ import numpy as np
 import torch
 
 from . import _abi, settings
-from .layers import GPLayer, RegularizerType
+from .layers import GPLayer, LatentVariableLayer, RegularizerType
 from .temp_workaround import draw_normal, precompute_states
 
 
@@ -41,7 +46,7 @@ class DGP_VI:
         self.layers = list(layers)
         self.name = name
         self.full_cov_over_samples = False
-        self._ticket = None
+        self._dev_words = None
 
     # -- data ---------------------------------------------------------------------------------
     def next_minibatch(self):
@@ -63,14 +68,21 @@ class DGP_VI:
             layer.to(device)
         return self
 
+    def _words(self):
+        """[ticket, rng step, rng ticket] device words, zeroed once (never per call)."""
+        dev = self.X.device
+        if self._dev_words is None or self._dev_words.device != dev:
+            self._dev_words = torch.zeros(4, dtype=torch.int64, device=dev)
+        return self._dev_words
+
     # -- reference API ------------------------------------------------------------------------
     def precompute(self):
-        """Gram + Cholesky + operand packing of every GP layer: one ABI call, two launches."""
+        """Gram + Cholesky + operand packing of every GP layer: one ABI call, one launch."""
         precompute_states([l.state_desc() for l in self.layers if isinstance(l, GPLayer)])
 
     def propagate(self, X, full_cov=False, inference_amorization_inputs=None,
                   is_sampled_local_regularizer=False, zs=None, _precomputed=False, _kl_parts=False):
-        """reference models.py:31-46 -> (samples[1:], means, covs, kls, kl_types)."""
+        """reference models.py:31-46 -> (samples[1:], means, covs, kls, kl_types); one launch per layer."""
         if not _precomputed:
             self.precompute()
         samples, means, covs, kls, kl_types = [X, ], [], [], [], []
@@ -89,9 +101,87 @@ class DGP_VI:
             kl_types.append(layer.regularizer_type)
         return samples[1:], means, covs, kls, kl_types
 
+    # -- fused forward ------------------------------------------------------------------------
+    def _fused_forward(self, T, row_div, row_mod, lead, zs=None, sampled_kl=True, want_layers=False,
+                       want_logw=True, use_encoder=True):
+        """``iwvi_dgp_forward`` over the current minibatch: every layer + log-weights in one launch.
+        Row t of the flattened batch reads data row (t // row_div) % row_mod.  Returns (logw [T] or None,
+        per-layer dict lists when ``want_layers``)."""
+        dev = self.X.device
+        n = len(self.layers)
+        if n > _abi.MAX_STACK:
+            raise ValueError("more than %d layers in one fused launch" % _abi.MAX_STACK)
+        zs = [None] * n if zs is None else zs
+        if len(zs) != n:
+            raise ValueError("zs needs one entry per layer")
+        X = _abi.dev_tensor(self.X.contiguous(), "X")
+        Y = _abi.dev_tensor(self.Y.contiguous(), "Y")
+        XY = self._xy_minibatch() if use_encoder and any(isinstance(l, LatentVariableLayer) for l in self.layers) else None
+        descs = (_abi.LayerDesc * n)()
+        keep, outs = [], []
+        D = X.shape[1]
+        for i, (layer, z) in enumerate(zip(self.layers, zs)):
+            if isinstance(layer, GPLayer):
+                R = layer.num_outputs
+                z2 = None if z is None else _abi.dev_tensor(z.reshape(T, R).contiguous(), "z")
+                o = None
+                if want_layers:
+                    P = layer.kern.W.shape[0] if hasattr(layer.kern, "W") else R
+                    o = {k: torch.empty(*lead, P, dtype=settings.float_type, device=dev) for k in ("sample", "mean", "var")}
+                d, k = layer.fused_desc(z2, o)
+                if d.D != D:
+                    raise ValueError("layer %d expects %d inputs, got %d" % (i, d.D, D))
+                D = d.P
+            elif isinstance(layer, LatentVariableLayer):
+                Lw = layer.latent_dim
+                z2 = None if z is None else _abi.dev_tensor(z.reshape(T, Lw).contiguous(), "z")
+                o = None
+                if want_layers:
+                    o = {k: torch.empty(*lead, D + Lw, dtype=settings.float_type, device=dev) for k in ("sample", "mean", "var")}
+                    o["kl_local"] = torch.empty(*lead, Lw, dtype=settings.float_type, device=dev)
+                d, k = layer.fused_desc(D, z2, o, sampled_kl=sampled_kl, use_encoder=use_encoder)
+                D += Lw
+            else:
+                raise TypeError("the fused forward knows GPLayer and LatentVariableLayer; use propagate() for custom layers")
+            descs[i] = d
+            keep.append(k)
+            outs.append(o)
+        logw = torch.empty(T, dtype=settings.float_type, device=dev) if want_logw else None
+        words = self._words()
+        _abi.check(_abi.lib().iwvi_dgp_forward(
+            descs, n, _abi.ptr(X), X.shape[1], _abi.ptr(XY), 0 if XY is None else XY.shape[1],
+            _abi.ptr(Y) if want_logw else None, Y.shape[1], T, row_div, row_mod, self.likelihood.variance,
+            settings.seed, ctypes.c_void_p(words.data_ptr() + 8), _abi.ptr(logw), _abi.stream_ptr()))
+        return logw, outs
+
+    def _xy_minibatch(self):
+        """[x_b, y_b] rows of the current minibatch (models.py:53 / :116 before tiling), cached per minibatch."""
+        key = (self.X.data_ptr(), self.Y.data_ptr(), self.X.shape[0])
+        if getattr(self, "_xy_key", None) != key:
+            self._xy_cache, self._xy_key = torch.cat([self.X, self.Y], -1).contiguous(), key
+        return self._xy_cache
+
+    def _global_kls(self):
+        return [l.state().kl_parts for l in self.layers if l.regularizer_type is RegularizerType.GLOBAL]
+
+    def _reduce_logw(self, logw, global_kls, B, K, stride_b, stride_k, mode_vi, want_ms=False, K_total=None):
+        """``iwvi_logw_reduce``: logsumexp/mean over K + scaled sum - global KLs (models.py:138-150, :69-86)."""
+        dev = logw.device
+        glob = [_abi.dev_tensor(g.reshape(-1), "global kl", torch.float64) for g in global_kls]
+        glob_n = (ctypes.c_int32 * max(len(glob), 1))(*[g.numel() for g in glob])
+        logp = torch.empty(B, dtype=settings.float_type, device=dev)
+        elbo = torch.empty(1, dtype=torch.float64, device=dev)
+        ms = torch.empty(B, 2, dtype=settings.float_type, device=dev) if want_ms else None
+        scale = float(self.num_data) / float(B)                        # models.py:80-81, :144-145
+        _abi.check(_abi.lib().iwvi_logw_reduce(
+            _abi.ptr(logw), B, K, stride_b, stride_k, _abi.ptr_array(glob), glob_n, len(glob),
+            scale, K_total or K, 1 if mode_vi else 0, _abi.ptr(ms), _abi.ptr(logp), _abi.ptr(elbo),
+            _abi.ptr(self._words()), _abi.stream_ptr()))
+        return elbo[0], logp, ms
+
     def _reduce(self, fmean, fvar, Y, local_kls, global_kls, B, K, stride_b, stride_k, mode_vi,
                 want_ms=False, K_total=None):
-        """``iwvi_iw_elbo_reduce``: var-exp + local terms + logsumexp/mean over K + scaled sum - global KLs."""
+        """``iwvi_iw_elbo_reduce`` on explicit final-layer moments (the layer-by-layer path)."""
         dev = fmean.device
         Dy = Y.shape[-1]
         fmean = _abi.dev_tensor(fmean.contiguous(), "final mean")
@@ -106,29 +196,21 @@ class DGP_VI:
         logp = torch.empty(B, dtype=settings.float_type, device=dev)
         elbo = torch.empty(1, dtype=torch.float64, device=dev)
         ms = torch.empty(B, 2, dtype=settings.float_type, device=dev) if want_ms else None
-        if self._ticket is None or self._ticket.device != dev:
-            self._ticket = torch.zeros(1, dtype=torch.int64, device=dev)      # zeroed once, never per call
         scale = float(self.num_data) / float(B)                        # models.py:80-81, :144-145
         _abi.check(_abi.lib().iwvi_iw_elbo_reduce(
             _abi.ptr(fmean), _abi.ptr(fvar), _abi.ptr(Y), self.likelihood.variance, B, K, Dy,
             stride_b, stride_k, _abi.ptr_array(kls), kl_dims, len(kls), _abi.ptr_array(glob), glob_n, len(glob),
             scale, K_total or K, 1 if mode_vi else 0, _abi.ptr(ms), _abi.ptr(logp), _abi.ptr(elbo),
-            _abi.ptr(self._ticket), _abi.stream_ptr()))
+            _abi.ptr(self._words()), _abi.stream_ptr()))
         return elbo[0], logp, ms
 
     def _build_likelihood(self, zs=None):
         """The VI bound, reference models.py:49-86 (2-D [S*N, D] tiling, mean over S)."""
         S, N = self.num_samples, self.X.shape[0]
-        X_tiled = self.X.repeat(S, 1)                                  # :50
-        Y_tiled = self.Y.repeat(S, 1)                                  # :51
-        XY = torch.cat([X_tiled, Y_tiled], -1)                         # :53
-        _, means, covs, kls, kl_types = self.propagate(X_tiled, full_cov=False,
-                                                       inference_amorization_inputs=XY,
-                                                       is_sampled_local_regularizer=False, zs=zs, _kl_parts=True)
-        local_kls = [kl for kl, t in zip(kls, kl_types) if t is RegularizerType.LOCAL]
-        global_kls = [kl for kl, t in zip(kls, kl_types) if t is RegularizerType.GLOBAL]
-        elbo, _, _ = self._reduce(means[-1], covs[-1], self.Y, local_kls, global_kls, N, S,
-                                  stride_b=1, stride_k=N, mode_vi=True)
+        self.precompute()
+        # tile(X, [S, 1]) (:50-53): row t = s*N + n reads data row t % N; analytic local KL (:58-61)
+        logw, _ = self._fused_forward(S * N, 1, N, (S * N,), zs=zs, sampled_kl=False)
+        elbo, _, _ = self._reduce_logw(logw, self._global_kls(), N, S, stride_b=1, stride_k=N, mode_vi=True)
         return elbo
 
     def compute_log_likelihood(self, zs=None):
@@ -164,10 +246,9 @@ class DGP_VI:
 
 class DGP_IWVI(DGP_VI):
     def _forward_iw(self, zs=None):
-        """models.py:113-133.  Default: the tiling of X, Y over K (:113-116) happens inside the first
-        layer's kernel (``bcast_K``) and every layer returns marginal variances.  With
-        ``full_cov_over_samples`` the reference is followed literally (explicit tiling, full_cov=True,
-        matrix_diag_part of the [B, Dy, K, K] covariance)."""
+        """models.py:113-133 with every per-layer output exposed (tests / API parity).  Default: one fused
+        launch, marginal variances everywhere.  With ``full_cov_over_samples`` the reference is followed
+        literally (explicit tiling, full_cov=True, matrix_diag_part of the [B, Dy, K, K] covariance)."""
         B, K = self.X.shape[0], self.num_samples
         if self.full_cov_over_samples:
             X_tiled = self.X[:, None, :].expand(B, K, self.X.shape[1]).contiguous()     # :113
@@ -176,56 +257,46 @@ class DGP_IWVI(DGP_VI):
             samples, means, covs, kls, kl_types = self.propagate(
                 X_tiled, full_cov=True, inference_amorization_inputs=XY,
                 is_sampled_local_regularizer=True, zs=zs, _kl_parts=True)                # :122-125
-        else:
-            self.precompute()
-            XY_b = self._xy_minibatch()
-            zs = [None] * len(self.layers) if zs is None else zs
-            if len(zs) != len(self.layers):
-                raise ValueError("zs needs one entry per layer")
-            samples, means, covs, kls, kl_types = [], [], [], [], []
-            F = self.X
-            for i, (layer, z) in enumerate(zip(self.layers, zs)):
-                kw = dict(_bcast_K=K) if i == 0 else dict(_bcast_XY=K)
-                s_, m_, c_, kl_ = layer.propagate(F, full_cov=False, inference_amorization_inputs=XY_b,
-                                                  is_sampled_local_regularizer=True, z=z, _precomputed=True,
-                                                  _kl_parts=True, **kw)
-                samples.append(s_); means.append(m_); covs.append(c_); kls.append(kl_)
-                kl_types.append(layer.regularizer_type)
-                F = s_
-        local_kls = [kl for kl, t in zip(kls, kl_types) if t is RegularizerType.LOCAL]
-        global_kls = [kl for kl, t in zip(kls, kl_types) if t is RegularizerType.GLOBAL]
-        cov = covs[-1]
-        if cov.dim() == 4:                                                            # [B, Dy, K, K]
-            cov = torch.diagonal(cov, dim1=-2, dim2=-1).transpose(1, 2).contiguous()  # :133
-        return means[-1], cov, local_kls, global_kls, samples, means, covs
+            local_kls = [kl for kl, t in zip(kls, kl_types) if t is RegularizerType.LOCAL]
+            global_kls = [kl for kl, t in zip(kls, kl_types) if t is RegularizerType.GLOBAL]
+            cov = covs[-1]
+            if cov.dim() == 4:                                                            # [B, Dy, K, K]
+                cov = torch.diagonal(cov, dim1=-2, dim2=-1).transpose(1, 2).contiguous()  # :133
+            return means[-1], cov, local_kls, global_kls, samples, means, covs
+        self.precompute()
+        _, outs = self._fused_forward(B * K, K, B, (B, K), zs=zs, sampled_kl=True, want_layers=True)
+        samples, means, covs = ([o[k] for o in outs] for k in ("sample", "mean", "var"))
+        local_kls = [o["kl_local"] for o, l in zip(outs, self.layers) if l.regularizer_type is RegularizerType.LOCAL]
+        return means[-1], covs[-1], local_kls, self._global_kls(), samples, means, covs
 
-    def _xy_minibatch(self):
-        """[x_b, y_b] rows of the current minibatch (models.py:116 before tiling), cached per minibatch."""
-        key = (self.X.data_ptr(), self.Y.data_ptr(), self.X.shape[0])
-        if getattr(self, "_xy_key", None) != key:
-            self._xy_cache, self._xy_key = torch.cat([self.X, self.Y], -1).contiguous(), key
-        return self._xy_cache
+    def _logw(self, zs=None):
+        """Per-sample log-weights L_NK [B*K] (models.py:134-142) and the global KL shares."""
+        B, K = self.X.shape[0], self.num_samples
+        if self.full_cov_over_samples:
+            return None
+        self.precompute()
+        logw, _ = self._fused_forward(B * K, K, B, (B, K), zs=zs, sampled_kl=True)
+        return logw
+
+    def _elbo_parts(self, zs=None, want_ms=False, K_total=None):
+        B, K = self.X.shape[0], self.num_samples
+        logw = self._logw(zs)
+        if logw is None:                                             # literal reference path
+            fmean, fvar, local_kls, global_kls, _, _, _ = self._forward_iw(zs)
+            return self._reduce(fmean, fvar, self.Y, local_kls, global_kls, B, K, stride_b=K, stride_k=1,
+                                mode_vi=False, want_ms=want_ms, K_total=K_total)
+        return self._reduce_logw(logw, self._global_kls(), B, K, stride_b=K, stride_k=1, mode_vi=False,
+                                 want_ms=want_ms, K_total=K_total)
 
     def _build_likelihood(self, zs=None):
         """The importance-weighted ELBO, reference models.py:112-150."""
-        B, K = self.X.shape[0], self.num_samples
-        fmean, fvar, local_kls, global_kls, _, _, _ = self._forward_iw(zs)
-        elbo, _, _ = self._reduce(fmean, fvar, self.Y, local_kls, global_kls, B, K,
-                                  stride_b=K, stride_k=1, mode_vi=False)
-        return elbo
+        return self._elbo_parts(zs)[0]
 
     def E_log_p_Y(self, zs=None):
         """Per-point ``logsumexp_k(L_nk) - log K`` [B] (models.py:134-148); name from BASELINE.json."""
-        B, K = self.X.shape[0], self.num_samples
-        fmean, fvar, local_kls, global_kls, _, _, _ = self._forward_iw(zs)
-        _, logp, _ = self._reduce(fmean, fvar, self.Y, local_kls, global_kls, B, K,
-                                  stride_b=K, stride_k=1, mode_vi=False)
-        return logp
+        return self._elbo_parts(zs)[1]
 
     def lse_partials(self, zs=None, K_total=None):
         """(max_k L, sum_k exp(L - max)) per point [B, 2] + the global KLs: the K-sharded exchange unit."""
-        B, K = self.X.shape[0], self.num_samples
-        fmean, fvar, local_kls, global_kls, _, _, _ = self._forward_iw(zs)
-        _, _, ms = self._reduce(fmean, fvar, self.Y, local_kls, global_kls, B, K, stride_b=K, stride_k=1,
-                                mode_vi=False, want_ms=True, K_total=K_total)
-        return ms, global_kls
+        _, _, ms = self._elbo_parts(zs, want_ms=True, K_total=K_total)
+        return ms, self._global_kls()

@@ -48,11 +48,12 @@ class GpState:
         if nbytes == 0:
             raise ValueError("bad layer size M=%d R=%d" % (M, R))
         self.buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
-        offs = (ctypes.c_size_t * 8)()
+        offs = (ctypes.c_size_t * 9)()
         _abi.check(_abi.lib().iwvi_gp_state_offsets(self.M, self.R, offs))
-        self.offsets = dict(zip(["Lm", "Linv", "LinvP", "LrTP", "QmuP", "Zs", "invls", "kl"], list(offs)))
-        self.Mp = (self.M + 31) // 32 * 32
+        self.offsets = dict(zip(["Lm", "Linv", "LinvP", "LrTP", "WqP", "ZtP", "zc", "invls", "kl"], list(offs)))
+        self.Mp = (self.M + 15) // 16 * 16
         self._keep = None
+        self._redo_dense = None
 
     def view(self, name, dtype, numel):
         off = self.offsets[name]
@@ -69,13 +70,23 @@ class GpState:
         """0-dim float64 device tensor: KL[q(u) || p(u)] of the last precompute."""
         return self.kl_parts.sum()
 
+    def _dense(self, name):
+        """The dense float64 factors are debug / API outputs: the hot path does not write them, so
+        reading one re-runs the last precompute with IWVI_GP_WANT_DENSE."""
+        if self._redo_dense is None:
+            raise RuntimeError("no precompute has run on this state yet")
+        d = self._redo_dense
+        d.flags = _abi.GP_WANT_DENSE
+        precompute_states([d])
+        return self.view(name, torch.float64, self.Mp * self.Mp).view(self.Mp, self.Mp)[:self.M, :self.M]
+
     @property
     def Lm(self):
-        return self.view("Lm", torch.float64, self.Mp * self.Mp).view(self.Mp, self.Mp)[:self.M, :self.M]
+        return self._dense("Lm")
 
     @property
     def Linv(self):
-        return self.view("Linv", torch.float64, self.Mp * self.Mp).view(self.Mp, self.Mp)[:self.M, :self.M]
+        return self._dense("Linv")
 
     def desc(self, Z, kern, q_mu, q_sqrt, jitter):
         M, D = Z.shape
@@ -86,8 +97,9 @@ class GpState:
         d.Z, d.lengthscales = Z.data_ptr(), kern.lengthscales.data_ptr()
         d.q_mu, d.q_sqrt, d.state = q_mu.data_ptr(), q_sqrt.data_ptr(), self.buf.data_ptr()
         d.variance, d.jitter = kern.variance, float(jitter)
-        d.M, d.D, d.R, d.kern_type = M, D, R, kern.kern_type
+        d.M, d.D, d.R, d.kern_type, d.flags = M, D, R, kern.kern_type, 0
         self._keep = (Z, q_mu, q_sqrt, kern.lengthscales)     # keep operands alive until the launch ran
+        self._redo_dense = d
         return d
 
 
@@ -130,9 +142,9 @@ def draw_normal(shape, device):
     return out
 
 
-def _forward_diag(state, kern, D, R, F2, z2, W, mean_function, want=(True, True, True), bcast_K=1):
-    """[T/bcast_K, D] -> sample/mean/var [T, P] through ``iwvi_gp_layer_forward``."""
-    T = F2.shape[0] * bcast_K
+def _forward_diag(state, kern, D, R, F2, z2, W, mean_function, want=(True, True, True)):
+    """[T, D] -> sample/mean/var [T, P] through ``iwvi_gp_layer_forward``."""
+    T = F2.shape[0]
     P = W.shape[0] if W is not None else R
     dev = F2.device
     outs = [torch.empty(T, P, dtype=settings.float_type, device=dev) if w else None for w in want]
@@ -146,7 +158,7 @@ def _forward_diag(state, kern, D, R, F2, z2, W, mean_function, want=(True, True,
     _abi.check(_abi.lib().iwvi_gp_layer_forward(
         _abi.ptr(state.buf), state.M, D, R, P, kern.kern_type, kern.variance,
         _abi.ptr(F2), _abi.ptr(z2), _abi.ptr(W), mf_type, _abi.ptr(mfA), _abi.ptr(mfb),
-        _abi.ptr(outs[0]), _abi.ptr(outs[1]), _abi.ptr(outs[2]), T, bcast_K, _abi.stream_ptr()))
+        _abi.ptr(outs[0]), _abi.ptr(outs[1]), _abi.ptr(outs[2]), T, 1, _abi.stream_ptr()))
     return outs
 
 
@@ -161,7 +173,7 @@ def _check_common(Xnew, full_output_cov, white):
 
 def independent_multisample_sample_conditional(Xnew, feat, kern, f, *, full_cov=False, full_output_cov=False,
                                                q_sqrt=None, white=False, z=None, state=None,
-                                               mean_function=None, precomputed=False, bcast_K=None):
+                                               mean_function=None, precomputed=False):
     """Multisample, single-output GP conditional (reference temp_workaround.py:12-98).
 
     :param Xnew: [S, N, D] (also accepts [N, D], the 2-D ``sample_conditional`` path of :157-161)
@@ -189,13 +201,9 @@ def independent_multisample_sample_conditional(Xnew, feat, kern, f, *, full_cov=
     lead = Xnew.shape[:-1]
     F2 = Xnew.reshape(-1, D)
     T = F2.shape[0]
-    if bcast_K:                                   # Xnew [B, D] stands for [B, K, D] tiled over K
-        if full_cov or Xnew.dim() != 2:
-            raise ValueError("bcast_K needs a 2-D input and full_cov=False")
-        lead, T = (Xnew.shape[0], bcast_K), T * bcast_K
     if not full_cov:
         z2 = draw_normal((T, R), Xnew.device) if z is None else _abi.dev_tensor(z.reshape(T, R).contiguous(), "z")
-        s, m, v = _forward_diag(state, kern, D, R, F2, z2, None, mean_function, bcast_K=bcast_K or 1)
+        s, m, v = _forward_diag(state, kern, D, R, F2, z2, None, mean_function)
         return s.view(*lead, R), m.view(*lead, R), v.view(*lead, R)
     # full covariance over the second axis (reference :45,56,83,93-96)
     S, N = (1, lead[0]) if Xnew.dim() == 2 else lead
@@ -220,7 +228,7 @@ def independent_multisample_sample_conditional(Xnew, feat, kern, f, *, full_cov=
 
 def multisample_sample_conditional(Xnew, feat, kern, f, *, full_cov=False, full_output_cov=False,
                                    q_sqrt=None, white=False, z=None, state=None, mean_function=None,
-                                   precomputed=False, bcast_K=None):
+                                   precomputed=False):
     """Dispatcher of reference temp_workaround.py:118-161."""
     if isinstance(kern, SharedMixedMok) and isinstance(feat, MixedKernelSharedMof):      # :123
         _check_common(Xnew, False, white)
@@ -240,19 +248,15 @@ def multisample_sample_conditional(Xnew, feat, kern, f, *, full_cov=False, full_
         lead = Xnew.shape[:-1]
         F2 = Xnew.reshape(-1, D)
         T = F2.shape[0]
-        if bcast_K:
-            if Xnew.dim() != 2:
-                raise ValueError("bcast_K needs a 2-D input")
-            lead, T = (Xnew.shape[0], bcast_K), T * bcast_K
         # full_cov is forced to False on this branch (reference :125-129, :134-138)
         z2 = draw_normal((T, R), Xnew.device) if z is None else _abi.dev_tensor(z.reshape(T, R).contiguous(), "z")
-        s, m, v = _forward_diag(state, base, D, R, F2, z2, W, mean_function, bcast_K=bcast_K or 1)   # mixing fused (:142-145)
+        s, m, v = _forward_diag(state, base, D, R, F2, z2, W, mean_function)   # mixing fused (:142-145)
         P = W.shape[0]
         return s.view(*lead, P), m.view(*lead, P), v.view(*lead, P)
     assert not isinstance(kern, SharedMixedMok)                                          # :149
     return independent_multisample_sample_conditional(
         Xnew, feat, kern, f, full_cov=full_cov, full_output_cov=full_output_cov, q_sqrt=q_sqrt,
-        white=white, z=z, state=state, mean_function=mean_function, precomputed=precomputed, bcast_K=bcast_K)
+        white=white, z=z, state=state, mean_function=mean_function, precomputed=precomputed)
 
 
 def gauss_kl(q_mu, q_sqrt, K=None):

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define IWVI_ABI_VERSION 1
+#define IWVI_ABI_VERSION 2
 
 enum {
     IWVI_OK = 0,
@@ -57,21 +57,27 @@ const char* iwvi_last_error(void);
  * Per-step, per-GP-layer state ("the inducing-set factorisation").
  * Replaces: Kuu(feat, kern, jitter) + tf.cholesky  (temp_workaround.py:39,48),
  * the operand side of tf.matrix_triangular_solve (:51), tf.matrix_band_part of
- * q_sqrt (:78) and gauss_kl (layers.py:44 -> temp_workaround.py:186-188).
+ * q_sqrt (:78), the operand side of Kuf (:44) and gauss_kl (layers.py:44 ->
+ * temp_workaround.py:186-188).
  *
- * Mp = M rounded up to 32, nb = Mp/32.  The state buffer holds, in this order,
- *   double  Lm   [Mp*Mp]   lower Cholesky factor of Kuu (padding rows = identity)
- *   double  Linv [Mp*Mp]   Lm^-1
- *   float   LinvP[nb*nb*1024]      Lm^-1, MFMA-fragment packed
- *   float   LrTP [R*nb*nb*1024]    tril(q_sqrt[r])^T, packed
- *   float   QmuP [nb*1024]         q_mu^T (R rows padded to 32), packed
- *   float   Zs   [Mp*32]           Z / lengthscales, rows padded to 32 floats
+ * Mp = M rounded up to 16, nbk = Mp/16, ntri = nbk(nbk+1)/2.  Packed operands are
+ * 16x16 blocks in v_mfma_f32_16x16x4_f32 fragment order.
+ * The state buffer holds, in this order,
+ *   double  Lm   [Mp*Mp]   lower Cholesky factor of Kuu   (written only with IWVI_GP_WANT_DENSE)
+ *   double  Linv [Mp*Mp]   Lm^-1                          (written only with IWVI_GP_WANT_DENSE)
+ *   float   LinvP[ntri*256]        Lm^-1, lower-triangular blocks, packed
+ *   float   LrTP [R*ntri*256]      tril(q_sqrt[r])^T, upper-triangular blocks, packed
+ *   float   WqP  [ceil(R/16)*nbk*256]  (Lm^-T q_mu)^T, packed  (mean = K_fu Lm^-T q_mu, :68)
+ *   float   ZtP  [nbk*9*64]        K_uf operand: augmented, centred, scaled inducing inputs
+ *   float   zc   [32]              centre of Z / lengthscales (0 beyond D)
  *   float   invls[32]              1 / lengthscales (0 beyond D)
  *   double  kl   [IWVI_MAX_R]      kl[r] = latent GP r's share of the whitened KL[q(u) || p(u)]
  *                                  (the layer's KL is the sum of the first R entries)
  *   double  ws   [...]             factorisation workspace (16x16 blocks of the lower triangle)
  * iwvi_gp_state_bytes() returns the size; offsets via iwvi_gp_state_offsets().
  * ---------------------------------------------------------------------- */
+#define IWVI_GP_WANT_DENSE 1   /* iwvi_gp_desc.flags: also write the dense float64 Lm and Lm^-1 */
+
 typedef struct iwvi_gp_desc {
     const float* Z;            /* [M, D]  inducing inputs                        */
     const float* lengthscales; /* [D]     ARD lengthscales                       */
@@ -82,11 +88,12 @@ typedef struct iwvi_gp_desc {
     double jitter;             /* gpflow settings.numerics.jitter_level          */
     int32_t M, D, R;
     int32_t kern_type;         /* IWVI_KERN_*                                    */
+    int32_t flags;             /* IWVI_GP_WANT_DENSE or 0                        */
 } iwvi_gp_desc;
 
 size_t iwvi_gp_state_bytes(int M, int R);
-/* offsets (bytes) of {Lm, Linv, LinvP, LrTP, QmuP, Zs, invls, kl} inside the state buffer */
-int iwvi_gp_state_offsets(int M, int R, size_t out_host[8]);
+/* offsets (bytes) of {Lm, Linv, LinvP, LrTP, WqP, ZtP, zc, invls, kl} inside the state buffer */
+int iwvi_gp_state_offsets(int M, int R, size_t out_host[9]);
 
 /* factorise up to IWVI_MAX_LAYERS layers per launch: grid (layer, role) -- role 0 Gram + Cholesky +
  * triangular inverse + packing, roles 1..R tril(q_sqrt[r])^T packing + KL share */
@@ -132,22 +139,82 @@ int iwvi_gp_layer_fullcov(const void* state, int M, int D, int R, int kern_type,
                           float* mean, float* cov, void* ws, void* stream);
 
 /* ------------------------------------------------------------------------
- * LatentVariableLayer forward (layers.py:72-105) with its Encoder MLP (:137-152).
- *   F   [T/bcast_K, D] if bcast_F else [T, D];  XY [T/bcast_K, XYdim] or NULL (prior mode, :73-81);  noise [T, Lw] or NULL
- *   bcast_K >= 1: every row of F / XY stands for bcast_K consecutive samples (the IW tiling of
- *   models.py:113-116 done inside the kernel: the encoder runs once per data point); 1 = no tiling
+ * The whole layer stack of DGP_VI.propagate (models.py:31-46) for a flattened sample batch in ONE
+ * launch, ending in the per-sample log-weight of models.py:134-142.  Every sample's path through the
+ * layers is independent of the other samples, so a workgroup keeps its chunk of samples in LDS from
+ * the tiled input (models.py:113-116) to the Gaussian variational expectation (:134); only the
+ * optional per-layer outputs and the log-weights [T] touch HBM.
+ *
+ * Row t of the batch stands for data row (t / row_div) % row_mod of X / XY / Y:
+ *   IW tiling [B, K, .] (models.py:113-116): row_div = K, row_mod = B;  VI tiling tile(X, [S, 1])
+ *   (:50-53): row_div = 1, row_mod = N;  an explicit [T, .] input: row_div = 1, row_mod = T.
+ * layers[i].type selects GPLayer (layers.py:35-50; state from iwvi_gp_precompute) or
+ * LatentVariableLayer (layers.py:72-105, encoder :137-152).  Per layer:
+ *   noise      [T, R] (GP) / [T, latent_dim] (LV) N(0,1) draws, or NULL: drawn in-kernel from the
+ *              counter-based stream (seed, step, layer, t) documented in DESIGN.md
+ *   noise_out  optional: the draws that were used
+ *   sample / mean / var   optional [T, P] (GP) or [T, D + latent_dim] (LV) outputs
+ *   kl_local   LV only, optional [T, latent_dim]: log q(W) - log p(W) (sampled_kl) or the analytic KL
+ * rng_state: 2 device words {step counter, ticket}, zeroed once by the caller; the launch reads the step
+ *   and its last workgroup advances it, so a replayed hipGraph draws fresh noise.  May be NULL when every
+ *   layer has explicit noise.
+ * Y / out_logw may be NULL (propagate only).  out_logw [T] = sum_d var_exp - sum local regularisers.
+ * ---------------------------------------------------------------------- */
+enum { IWVI_LAYER_GP = 0, IWVI_LAYER_LV = 1 };
+#define IWVI_MAX_STACK 12   /* layers (GP + LV) in one fused launch */
+
+typedef struct iwvi_layer_desc {
+    int32_t type;                   /* IWVI_LAYER_*                                          */
+    /* GP layer */
+    const void* state;              /* precomputed iwvi_gp_desc.state                        */
+    int32_t M, D, R, P;             /* inducing points, input dim, latent GPs, outputs       */
+    int32_t kern_type, mf_type;     /* IWVI_KERN_*, IWVI_MF_*                                */
+    float variance;
+    const float* W;                 /* [P, R] SharedMixedMok.W or NULL (then P == R)         */
+    const float* mf_A;              /* [D, P] for IWVI_MF_LINEAR                             */
+    const float* mf_b;              /* [P] or NULL                                           */
+    /* LV layer (D = input dim as above) */
+    const float* const* enc_W;      /* host array of n_enc device pointers, or NULL = prior  */
+    const float* const* enc_b;
+    const int32_t* enc_dims;        /* host: n_enc + 1 widths, [0] = XY width, [n] = 2*latent */
+    int32_t n_enc, latent_dim, sampled_kl;
+    /* both */
+    const float* noise;             /* explicit N(0,1) draws, or NULL                        */
+    int32_t zero_noise;             /* noise == NULL: 1 -> z = 0 (sample == mean), 0 -> draw in-kernel */
+    float* noise_out;
+    float* sample; float* mean; float* var;
+    float* kl_local;
+    float* a_out; float* u_out;     /* GP, single-layer calls only: A [T, Mp], L_r^T A [R, T, Mp] */
+} iwvi_layer_desc;
+
+int iwvi_dgp_forward(const iwvi_layer_desc* layers_host, int n_layers,
+                     const float* X, int Dx, const float* XY, int XYdim, const float* Y, int Dy,
+                     int64_t T, int64_t row_div, int64_t row_mod, float lik_variance,
+                     uint64_t seed, uint64_t* rng_state, float* out_logw, void* stream);
+
+/* models.py:138-150 on precomputed log-weights: logw row of (point b, sample k) = b*stride_b + k*stride_k;
+ * arguments as iwvi_iw_elbo_reduce. */
+int iwvi_logw_reduce(const float* logw, int64_t B, int K, int64_t stride_b, int64_t stride_k,
+                     const double* const* kl_global_host, const int32_t* kl_global_counts_host, int n_glob,
+                     double scale, int K_total, int mode_vi,
+                     float* out_lse_ms, float* out_logp, double* out_elbo, uint64_t* ticket, void* stream);
+
+/* ------------------------------------------------------------------------
+ * LatentVariableLayer forward alone (layers.py:72-105) with its Encoder MLP (:137-152).
+ *   F   [T, D];  XY [T, XYdim] or NULL (prior mode, :73-81);  noise [T, Lw] or NULL (z = 0)
  *   enc_W[i] [dims[i], dims[i+1]], enc_b[i] [dims[i+1]], dims_host[n_enc+1],
  *   dims[0] = XYdim, dims[n_enc] = 2*Lw; tanh on all but the last layer, skip
  *   connection where dims[i] == dims[i+1]; q_sqrt = softplus(raw - 3).
  *   sample/mean/cov [T, D+Lw] (any may be NULL), kl [T, Lw]:
  *   sampled_kl != 0 -> log q(W) - log p(W) (:98-100) else analytic KL (:101-103).
+ * (The IW path runs this layer inside iwvi_dgp_forward, once per data point.)
  * ---------------------------------------------------------------------- */
 int iwvi_lv_layer_forward(const float* F, const float* XY, const float* noise,
                           const float* const* enc_W_host, const float* const* enc_b_host,
                           const int32_t* dims_host, int n_enc,
                           int D, int Lw, int sampled_kl,
                           float* sample, float* mean, float* cov, float* kl,
-                          int64_t T, int bcast_K, int bcast_F, void* stream);
+                          int64_t T, void* stream);
 
 /* ------------------------------------------------------------------------
  * The IW-ELBO reduction (models.py:133-150): Gaussian variational expectations
@@ -163,7 +230,8 @@ int iwvi_lv_layer_forward(const float* F, const float* XY, const float* noise,
  *   out_logp   [B]     logsumexp - log(K_total)   (K_total = K when not sharded)
  *   out_elbo   [1] double = sum(logp) * scale - sum(kl_global)
  *   ticket     [1] device word, zeroed ONCE by the caller (never per call): the last workgroup to finish
- *              performs the final sum, so the whole reduction is one launch; needed when out_elbo != NULL
+ *              performs the final sum and re-zeroes it, so the whole reduction is one launch; needed when
+ *              out_elbo != NULL
  * Any out pointer may be NULL.  mode_vi != 0 -> reduce_mean over K instead (models.py:84).
  * ---------------------------------------------------------------------- */
 int iwvi_iw_elbo_reduce(const float* fmean, const float* fvar, const float* Y,
