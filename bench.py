@@ -16,6 +16,8 @@ Multi-GPU (weak scaling, per-GPU work fixed):
       and a merge kernel give the global log-sum-exp and ELBO (SURVEY.md section 8 row E, mode i);
   --shard n: every rank owns B different points and all K samples; one scalar all-reduce per step.
 """
+import os
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")   # kernel arguments in device memory (read before HIP initialises)
 import argparse
 import ctypes
 import json

@@ -8,34 +8,56 @@
 // layers is independent of the other samples, so nothing the reference materialises (Kmn, A, LTA, the tiled
 // inputs, the per-layer samples) reaches HBM unless the caller asks for a per-layer output.
 //
-// One 512-thread workgroup (8 waves, two per SIMD) owns a chunk of 16*NS samples, all layers.  Per GP layer:
+// One 512-thread workgroup (8 waves, two per SIMD) owns a chunk of 16*NS samples, all layers.
+//   prologue  every small operand of every layer (1/lengthscales, mixing W, mean-function A, the Gram operand
+//             Z~, encoder weights), the chunk's data rows and the injected noise are copied global -> LDS with
+//             asynchronous LDS-DMA loads, all in flight at once; in-kernel Philox draws overlap their latency.
+//   per GP layer:
 //   x~      augmented, scaled, centred inputs -> LDS (so that the Gram is one small MFMA product)
-//   Gram    k = exp2(Z~ x~)               16x16x4 MFMA, result already in B-operand order      -> LDS kuf
-//   stage 1 a = Lm^-1 k  (lower blocks),  mean = (Lm^-T q_mu)^T k                               -> LDS at, |a|^2
-//   stage 2 u_r = tril(q_sqrt_r)^T a (upper blocks) -> |u_r|^2 only (never stored)
+//   Gram    k = exp2(Z~ x~)   16x16x4 f32 MFMA, result already in B-operand order               -> LDS kuf
+//   stage 1 a = Lm^-1 k by blocked right-looking forward substitution (matrix_triangular_solve, :51): one wave
+//           per 16-sample sub-tile streams the packed factor once; a_j = Dinv_j r_j, then r_i -= L_ij a_j for all
+//           i > j (independent MFMA chains); the B operand is the result tile just computed, still in registers
+//           (accumulator layout == B layout)                                                     -> LDS at, |a|^2
+//   stage 2 u_r = tril(q_sqrt_r)^T a (upper blocks) -> |u_r|^2 only (never stored); mean = q_mu^T a
+//           a wave owns one 16-row block of the output for ALL NS sub-tiles: each 1-KiB packed A block is
+//           loaded once (coalesced, L2 -> registers, prefetched two blocks ahead, across job boundaries) and
+//           feeds 4*NS MFMAs; jobs come from an LDS counter in order of decreasing cost
 //   epilogue var, sample, mixing, mean function -> next layer's input in LDS (+ optional HBM outputs)
-// A wave owns one 16-row block of the output for ALL NS sample sub-tiles of the chunk: each 1-KiB packed A
-// block is loaded once (coalesced, straight from L2 to registers, prefetched one block ahead) and feeds
-// 4*NS MFMAs; B operands are ds_read_b128 of the LDS tile.  Row-block jobs are handed out from an LDS
-// counter in order of decreasing cost, so the triangular imbalance is absorbed inside the workgroup, and
-// every job writes its partial sums to its own LDS slot: results are bit-reproducible whichever wave ran it.
+// Every job writes its partial sums to its own LDS slot and they are added in a fixed order: results are
+// bit-reproducible whichever wave ran which job.
 #include "iwvi_common.h"
+#include <cstdlib>
 
 namespace iwvi {
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
+// streamed operands are read through explicitly global pointers: a generic (flat) load must be waited for with
+// vmcnt(0) before the next one issues, which would serialise the prefetch ring
+typedef const __attribute__((address_space(1))) f32x4* gptr4;
+typedef const __attribute__((address_space(1))) float* gptr1;
 
-constexpr int FW_THREADS = 512;
-constexpr int FW_WAVES = FW_THREADS / 64;
+static unsigned long long* g_stamp_buf = nullptr;   // diagnostic; see iwvi_debug_set_stamps
+static long long g_stamp_wgs = 0;
+
 constexpr int XSTR = 37;              // row stride (floats) of the activation tiles: D, P <= 32, D + 2 <= 36
 constexpr int FW_MAXNS = 5;
 
+constexpr int FW_THREADS = 512;
+constexpr int FW_WAVES = FW_THREADS / 64;
+
 struct FwGp {
-    const f32x4* LinvP; const f32x4* LrTP; const f32x4* WqP; const float* ZtP; const float* zc; const float* invls;
+    const f32x4* LsP; const f32x4* LrTP; const f32x4* QmuP; const float* ZtP; const float* cst;
     const float* W; const float* mfA; const float* mfb;
     float* a_out; float* u_out;
     int M, Mp, nbk, nrb, nsteps, R, P, kern_type, mf_type;
+    int zt_off;                       // LDS offset of the staged Z~ (floats), or -1: read it from L2
     float variance;
+    // static stage-2 schedule: wave w streams the (r-major, bi ascending) row-block jobs jb[w] .. jb[w+1]-1 of the
+    // contiguous LrTP image (nblk[w] packed blocks), after the q_mu^T row-blocks assigned to it (mean_wave)
+    unsigned short jb[FW_WAVES + 1];
+    unsigned short nblk[FW_WAVES];
+    signed char mean_wave[2];
 };
 struct FwLv {
     const float* W[IWVI_MAX_ENC]; const float* b[IWVI_MAX_ENC];
@@ -45,51 +67,48 @@ struct FwLv {
 };
 struct FwLayer {
     int type, D, zero_noise;
+    int c_off, z_off;                 // LDS offsets (floats): this layer's constants / its noise [dims][NSAMP]
     const float* noise; float* noise_out; float* sample; float* mean; float* var;
     union { FwGp gp; FwLv lv; };
 };
 // LDS carve, float offsets (all multiples of 4)
-struct FwLds { int xa, xb, xt, lw, rowi, pidx, asq, meanp, gbuf, obuf, cnt, scratch, total; };
+struct FwLds { int ltab, xa, xb, xt, lw, rowi, pidx, asq, meanp, gbuf, obuf, znoise, xyrows, cnt, scratch, total; };
 
-struct FwArgs {
-    FwLayer L[IWVI_MAX_STACK];
+// Kernel arguments.  The header is read through the scalar cache; the layer table is copied to LDS with
+// vector loads first thing (one round trip for all of it): read line by line through the scalar cache, a
+// cold 3-KiB kernarg segment costs a memory round trip per 64 bytes, serialised by the control flow.
+struct FwHead {
     int n_layers;
     const float* X; const float* XY; const float* Y;
     int Dx, XYdim, Dy;
-    long long T, row_div, row_mod;
+    long long T;
+    unsigned row_div, row_mod;       // T < 2^31 is enforced by the host
     float lik_variance;
     unsigned long long seed; unsigned long long* rng_state;
     float* out_logw;
+    unsigned long long* stamps;      // diagnostic only (iwvi_debug_set_stamps): 128 words per workgroup
+    int dbg;                         // diagnostic only (IWVI_DEBUG_ABLATE): timing ablations, results are wrong
     FwLds lds;
+};
+struct FwArgs {
+    FwHead h;
+    FwLayer L[IWVI_MAX_STACK];
 };
 
 __host__ __device__ static inline int up4(int x) { return (x + 3) & ~3; }
 
+// constant-block layout of a GP layer in LDS: invls[32] | zc[32] | zmax2, pad | W[P*R] | mfA[D*P] | mfb[P] | (Z~)
+__host__ __device__ static inline int gpc_W() { return IWVI_CST_FLOATS; }
+__host__ __device__ static inline int gpc_A(int P, int R) { return IWVI_CST_FLOATS + up4(P * R); }
+__host__ __device__ static inline int gpc_b(int D, int P, int R) { return gpc_A(P, R) + up4(D * P); }
+__host__ __device__ static inline int gpc_size(int D, int P, int R) { return gpc_b(D, P, R) + up4(P); }
+
 // scratch needs (floats) of a layer for a chunk of nsamp samples
 static inline int gp_scratch_floats(int Mp, int nbk, int R, int nsamp) {
-    // Gram tile + solved tile; |u|^2 slots alias the (dead) Gram tile when they fit, else get their own region
-    return 2 * Mp * nsamp + (R * nbk > Mp ? R * nbk * nsamp : 0);
+    // Gram tile + solved tile; the |u|^2 slots [wave][r] alias the (dead) Gram tile when they fit, else get their own region
+    return 2 * Mp * nsamp + (FW_WAVES * R > Mp ? FW_WAVES * R * nsamp : 0);
 }
-static inline int lv_scratch_floats(int wtotal, int maxdim, int Lw, int nsamp) {
-    return up4(wtotal) + 2 * nsamp * up4(maxdim);
-}
-static inline FwLds fw_lds_layout(int nsamp, int maxR, int maxP, int max_nbk, int scratch) {
-    FwLds l; int o = 0;
-    l.xa = o; o += up4(nsamp * XSTR);
-    l.xb = o; o += up4(nsamp * XSTR);
-    l.xt = o; o += up4(nsamp * XSTR);
-    l.lw = o; o += nsamp;
-    l.rowi = o; o += nsamp;
-    l.pidx = o; o += nsamp;
-    l.asq = o; o += max_nbk * nsamp;
-    l.meanp = o; o += maxR * nsamp;
-    l.gbuf = o; o += 3 * maxR * nsamp;
-    l.obuf = o; o += 2 * maxP * nsamp;
-    l.cnt = o; o += 4;
-    l.scratch = o; o += up4(scratch);
-    l.total = o;
-    return l;
-}
+static inline int lv_scratch_floats(int maxdim, int nsamp) { return 2 * nsamp * up4(maxdim); }
 
 __device__ __forceinline__ float kern_from_acc(float acc, int type, float var) {
     if (type == IWVI_KERN_MATERN52) {
@@ -101,64 +120,140 @@ __device__ __forceinline__ float kern_from_acc(float acc, int type, float var) {
     return __builtin_amdgcn_exp2f(acc);            // log2(var) is folded into Z~
 }
 
-// acc[t] += A(row-block, chunks c0 .. c0+nch-1) * B(chunks, sub-tile t); Ablk = first packed block of the run,
-// Bt = the LDS tile at chunk c0.  One 1-KiB A load (prefetched one block ahead) per 4*NS MFMAs.
-template <int NS>
-__device__ __forceinline__ void mma_rowblock(const f32x4* __restrict__ Ablk, int nch, const f32x4* Bt, int lane,
-                                             f32x4 (&acc)[NS]) {
-    constexpr int NSAMP = 16 * NS;
-    const int g = lane >> 4, j = lane & 15;
-    const f32x4* Ap = Ablk + lane;
-    const f32x4* Bp = Bt + g * NSAMP + j;
-    f32x4 a = Ap[0];
-    for (int c = 0; c < nch; ++c) {
-        const f32x4 an = Ap[(size_t)(c + 1 < nch ? c + 1 : c) * 64];
-        f32x4 b[NS];
-#pragma unroll
-        for (int t = 0; t < NS; ++t) b[t] = Bp[16 * t];
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-#pragma unroll
-            for (int t = 0; t < NS; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b[t][s], acc[t], 0, 0, 0);
-        }
-        a = an;
-        Bp += 4 * NSAMP;
+// asynchronous global -> LDS copy of n floats (LDS-DMA, no VGPR round trip, nothing waits until the caller's
+// vmcnt(0) + barrier).  One wave-instruction moves 64 consecutive floats; dst + i0 is wave-uniform.
+__device__ __forceinline__ void async_copy_f32(const float* __restrict__ src, float* lds_dst, int n, int tid) {
+    const int lane = tid & 63;
+    for (int i0 = (tid & ~63); i0 < n; i0 += FW_THREADS) {
+        const int i = i0 + lane;
+        if (i < n)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + i),
+                                             (__attribute__((address_space(3))) void*)(lds_dst + i0), 4, 0, 0);
     }
 }
 
 // sum over the 16 rows of a result block, per sample column: 4 registers, then across the 4 lane groups
-__device__ __forceinline__ float colsumsq(const f32x4& v) {
+__device__ __forceinline__ float colsumsq4(const f32x4& v) {
     float s = v[0] * v[0];
     s = fmaf(v[1], v[1], s); s = fmaf(v[2], v[2], s); s = fmaf(v[3], v[3], s);
+    return s;
+}
+__device__ __forceinline__ float xgroup_sum(float s) {
     s += __shfl_xor(s, 16);
     s += __shfl_xor(s, 32);
     return s;
 }
 
-// N(0,1) draw for (layer li, sample t, component r): Philox4x32-10 with
-//   counter = (t_lo, t_hi, li * 256 + r / 4, step_lo), key = (seed_lo, seed_hi ^ step_hi), word r % 4
-__device__ __forceinline__ float draw_normal_at(unsigned long long seed, unsigned long long step, int li,
-                                                long long t, int r) {
-    uint32_t c[4] = {(uint32_t)t, (uint32_t)((unsigned long long)t >> 32), (uint32_t)(li * 256 + (r >> 2)), (uint32_t)step};
+// N(0,1) draws for (layer li, sample t), components 4q .. 4q+3: Philox4x32-10 with
+//   counter = (t_lo, t_hi, li * 256 + q, step_lo), key = (seed_lo, seed_hi ^ step_hi)
+__device__ __forceinline__ void draw_normal4(unsigned long long seed, unsigned long long step, int li,
+                                             long long t, int q, float v[4]) {
+    uint32_t c[4] = {(uint32_t)t, (uint32_t)((unsigned long long)t >> 32), (uint32_t)(li * 256 + q), (uint32_t)step};
     philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32) ^ (uint32_t)(step >> 32));
-    float v[4];
     box_muller4(c, v);
-    return v[r & 3];
 }
 
 __device__ __forceinline__ float softplus_f(float x) { return x > 20.f ? x : log1pf(expf(x)); }
 
 extern __shared__ __attribute__((aligned(16))) unsigned char fw_smem[];
 
-template <int NS>
-__global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs g) {
+// diagnostic phase stamps: [k] = 100 MHz wall clock, [64 + k] = shader clock; written only when registered
+#define FW_STAMP(k) do { if (g.stamps && tid == 0 && (k) < 64) { \
+        g.stamps[(size_t)blockIdx.x * 128 + (k)] = wall_clock64(); \
+        g.stamps[(size_t)blockIdx.x * 128 + 64 + (k)] = clock64(); } } while (0)
+
+// wave-uniform copies of values that were read from the LDS copy of the layer table
+__device__ __forceinline__ int ufirst(int v) { return __builtin_amdgcn_readfirstlane(v); }
+template <class T>
+__device__ __forceinline__ T* ufirst(T* p) {
+    const unsigned long long v = (unsigned long long)p;
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
+    return (T*)(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ FwGp uniform_gp(const FwGp& s) {
+    FwGp G;
+    G.LsP = ufirst(s.LsP); G.LrTP = ufirst(s.LrTP); G.QmuP = ufirst(s.QmuP); G.ZtP = ufirst(s.ZtP); G.cst = ufirst(s.cst);
+    G.W = ufirst(s.W); G.mfA = ufirst(s.mfA); G.mfb = ufirst(s.mfb); G.a_out = ufirst(s.a_out); G.u_out = ufirst(s.u_out);
+    G.M = ufirst(s.M); G.Mp = ufirst(s.Mp); G.nbk = ufirst(s.nbk); G.nrb = ufirst(s.nrb); G.nsteps = ufirst(s.nsteps);
+    G.R = ufirst(s.R); G.P = ufirst(s.P); G.kern_type = ufirst(s.kern_type); G.mf_type = ufirst(s.mf_type);
+    G.zt_off = ufirst(s.zt_off); G.variance = __int_as_float(ufirst(__float_as_int(s.variance)));
+#pragma unroll
+    for (int w = 0; w <= FW_WAVES; ++w) G.jb[w] = (unsigned short)ufirst((int)s.jb[w]);
+#pragma unroll
+    for (int w = 0; w < FW_WAVES; ++w) G.nblk[w] = (unsigned short)ufirst((int)s.nblk[w]);
+    G.mean_wave[0] = (signed char)ufirst((int)s.mean_wave[0]); G.mean_wave[1] = (signed char)ufirst((int)s.mean_wave[1]);
+    return G;
+}
+
+// one MFMA adds a value across the four 16-lane groups: D[i][j] = sum_k 1 * B[k][j], B[k][j] = lane (k, j)
+__device__ __forceinline__ float xgroup_sum_mfma(float s) {
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    const f32x4 d = __builtin_amdgcn_mfma_f32_16x16x4f32(1.0f, s, z, 0, 0, 0);
+    return d[0];
+}
+
+// ---- stage 1, fully unrolled for NBK <= 8 (M <= 128): right-looking blocked forward substitution with every
+// right-hand-side block r_i in registers.  Column bj: a_bj = Dinv_bj r_bj (4 dependent MFMAs), then the NBK-1-bj
+// updates r_i += (-L(i,bj)) a_bj are independent accumulator chains interleaved at the MFMA issue rate; the next
+// column's packed blocks are loaded while this one computes.
+template <int NS, int NBK>
+__device__ __forceinline__ float stage1_unrolled(gptr4 Ap, const f32x4* kuf, f32x4* at, int tcol, int gq,
+                                                 float* a_out_row /* or nullptr */) {
     constexpr int NSAMP = 16 * NS;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    f32x4 r[NBK], A[NBK];
+#pragma unroll
+    for (int i = 0; i < NBK; ++i) A[i] = Ap[(size_t)i * 64];
+#pragma unroll
+    for (int i = 0; i < NBK; ++i) r[i] = kuf[(i * 4 + gq) * NSAMP + tcol];
+    int q = NBK;
+    float ssq = 0.f;
+#pragma unroll
+    for (int bj = 0; bj < NBK; ++bj) {
+        f32x4 An[NBK];
+#pragma unroll
+        for (int i = 0; i < NBK - bj - 1; ++i) An[i] = Ap[(size_t)(q + i) * 64];
+        q += NBK - bj - 1;
+        f32x4 res = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 4; ++s) res = __builtin_amdgcn_mfma_f32_16x16x4f32(A[0][s], r[bj][s], res, 0, 0, 0);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+#pragma unroll
+            for (int bi = bj + 1; bi < NBK; ++bi)
+                r[bi] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[bi - bj][s], res[s], r[bi], 0, 0, 0);
+        }
+        at[(bj * 4 + gq) * NSAMP + tcol] = res;
+        ssq += colsumsq4(res);
+        if (a_out_row) *reinterpret_cast<f32x4*>(a_out_row + 16 * bj + 4 * gq) = res;
+#pragma unroll
+        for (int i = 0; i < NBK - bj - 1; ++i) A[i] = An[i];
+    }
+    return ssq;
+}
+
+template <int NS>
+__global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
+    constexpr int NSAMP = 16 * NS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int gq = lane >> 4, jq = lane & 15;
+    const FwHead& g = gk.h;                                       // scalar path (first kernarg lines)
     const long long t0 = (long long)blockIdx.x * NSAMP;
     const int nvalid = (int)((g.T - t0) < (long long)NSAMP ? (g.T - t0) : (long long)NSAMP);
 
     float* sm = reinterpret_cast<float*>(fw_smem);
+    // ---- layer table: kernarg -> LDS, every dword in flight at once ------------------------------------
+    {
+#if defined(__HIP_DEVICE_COMPILE__)
+        const uint32_t* ka = (const uint32_t*)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(FwArgs, L) / 4;
+#else
+        const uint32_t* ka = nullptr;
+#endif
+        uint32_t* dst = reinterpret_cast<uint32_t*>(sm + g.lds.ltab);
+        const int nw = g.n_layers * (int)(sizeof(FwLayer) / 4);
+        for (int i = tid; i < nw; i += FW_THREADS) dst[i] = ka[i];
+    }
+    const FwLayer* LT = reinterpret_cast<const FwLayer*>(sm + g.lds.ltab);
     float* xin = sm + g.lds.xa;
     float* xout = sm + g.lds.xb;
     float* xt = sm + g.lds.xt;
@@ -169,72 +264,144 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs g) {
     float* meanp = sm + g.lds.meanp;
     float* gbuf = sm + g.lds.gbuf;
     float* obuf = sm + g.lds.obuf;
+    float* znoise = sm + g.lds.znoise;
+    float* xyrows = sm + g.lds.xyrows;
     int* counters = reinterpret_cast<int*>(sm + g.lds.cnt);
     float* scratch = sm + g.lds.scratch;
 
     const unsigned long long step = g.rng_state ? g.rng_state[0] : 0ULL;
+    FW_STAMP(0);
 
-    // ---- the chunk's rows of X (models.py:113 / :50 tiling done here) -----------------------------
-    const long long p_first = t0 / g.row_div;
+    // ================= prologue: everything small -> LDS, all loads in flight at once ==================
+    const unsigned ut0 = (unsigned)t0, uT = (unsigned)g.T;
+    const unsigned p_first = ut0 / g.row_div;
+    const unsigned p_last = (ut0 + nvalid - 1) / g.row_div;
+    const int npts = (int)(p_last - p_first) + 1;                 // distinct data points in this chunk
     if (tid < NSAMP) {
-        const long long t = t0 + tid;
-        const long long p = (t < g.T ? t : g.T - 1) / g.row_div;
-        rowi[tid] = (int)(p % g.row_mod);
+        const unsigned t = ut0 + tid;
+        const unsigned p = (t < uT ? t : uT - 1) / g.row_div;
+        const int row = (int)(p % g.row_mod);
+        rowi[tid] = row;
         pidx[tid] = (int)(p - p_first);
         lw[tid] = 0.f;
     }
-    __syncthreads();
+    // the chunk's rows of X (models.py:113 / :50 tiling done here) and of the encoder input
     for (int idx = tid; idx < NSAMP * g.Dx; idx += FW_THREADS) {
         const int j = idx / g.Dx, d = idx - j * g.Dx;
-        xin[j * XSTR + d] = (j < nvalid) ? g.X[(size_t)rowi[j] * g.Dx + d] : 0.f;
+        const unsigned t = ut0 + j;
+        const unsigned row = ((t < uT ? t : uT - 1) / g.row_div) % g.row_mod;
+        xin[j * XSTR + d] = (j < nvalid) ? g.X[(size_t)row * g.Dx + d] : 0.f;
     }
+    if (g.XY) {
+        const int xs = up4(g.XYdim);
+        for (int idx = tid; idx < npts * g.XYdim; idx += FW_THREADS) {
+            const int p = idx / g.XYdim, i = idx - p * g.XYdim;
+            const unsigned row = (p_first + p) % g.row_mod;
+            xyrows[p * xs + i] = g.XY[(size_t)row * g.XYdim + i];
+        }
+    }
+    __syncthreads();                                              // layer table (and rowi / pidx) visible
+    FW_STAMP(56);
+    for (int li = 0; li < g.n_layers; ++li) {
+        const FwLayer& L = LT[li];
+        float* cst = sm + ufirst(L.c_off);
+        if (ufirst(L.type) == IWVI_LAYER_GP) {
+            const FwGp G = uniform_gp(L.gp);
+            const int D = ufirst(L.D);
+            async_copy_f32(G.cst, cst, IWVI_CST_FLOATS, tid);                      // invls[32] | zc[32] | zmax2
+            if (G.W) async_copy_f32(G.W, cst + gpc_W(), G.P * G.R, tid);
+            if (G.mf_type == IWVI_MF_LINEAR) {
+                async_copy_f32(G.mfA, cst + gpc_A(G.P, G.R), D * G.P, tid);
+                if (G.mfb) async_copy_f32(G.mfb, cst + gpc_b(D, G.P, G.R), G.P, tid);
+            }
+            if (G.zt_off >= 0) async_copy_f32(G.ZtP, sm + G.zt_off, G.nbk * G.nsteps * 64, tid);
+        } else {
+            const FwLv& V = L.lv;
+            const int n_enc = ufirst(V.n_enc);
+            int off = 0;
+            for (int l = 0; l < n_enc; ++l) {
+                const int nW = ufirst(V.dims[l]) * ufirst(V.dims[l + 1]), nbias = ufirst(V.dims[l + 1]);
+                async_copy_f32(ufirst(V.W[l]), cst + off, nW, tid);
+                const float* bl = ufirst(V.b[l]);
+                if (bl) async_copy_f32(bl, cst + off + nW, nbias, tid);
+                off += nW + nbias;
+            }
+        }
+        // injected noise [T, dims] -> znoise[z_off + r * NSAMP + j] (a gather: the DMA source is per lane)
+        const float* noise = ufirst(L.noise);
+        if (noise) {
+            const int dims = ufirst((L.type == IWVI_LAYER_GP) ? L.gp.R : L.lv.Lw);
+            float* zdst = znoise + ufirst(L.z_off);
+            for (int i0 = (tid & ~63); i0 < dims * NSAMP; i0 += FW_THREADS) {
+                const int i = i0 + lane, r = i / NSAMP, j = i - r * NSAMP;
+                if (i < dims * NSAMP && j < nvalid)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(noise + (size_t)(t0 + j) * dims + r),
+                                                     (__attribute__((address_space(3))) void*)(zdst + i0), 4, 0, 0);
+            }
+        }
+    }
+    FW_STAMP(57);
+    // in-kernel draws (layers without injected noise), 4 normals per Philox call; overlaps the copies above
+    for (int li = 0; li < g.n_layers; ++li) {
+        const FwLayer& L = LT[li];
+        if (ufirst(L.noise) != nullptr) continue;
+        const int dims = ufirst((L.type == IWVI_LAYER_GP) ? L.gp.R : L.lv.Lw);
+        const int zero_noise = ufirst(L.zero_noise);
+        float* zdst = znoise + ufirst(L.z_off);
+        const int nq = (dims + 3) >> 2;
+        for (int idx = tid; idx < nq * NSAMP; idx += FW_THREADS) {
+            const int q = idx / NSAMP, j = idx - q * NSAMP;
+            float v[4] = {0.f, 0.f, 0.f, 0.f};
+            if (!zero_noise && j < nvalid) draw_normal4(g.seed, step, li, t0 + j, q, v);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (4 * q + e < dims) zdst[(4 * q + e) * NSAMP + j] = v[e];
+        }
+    }
+    FW_STAMP(58);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    FW_STAMP(59);
     __syncthreads();
+    FW_STAMP(1);
 
     for (int li = 0; li < g.n_layers; ++li) {
-        const FwLayer& L = g.L[li];
-        const int D = L.D;
-        if (L.type == IWVI_LAYER_LV) {
+        const FwLayer& L = LT[li];
+        const int D = ufirst(L.D);
+        const float* cst = sm + ufirst(L.c_off);
+        const float* zl = znoise + ufirst(L.z_off);
+        float* const o_sample = ufirst(L.sample); float* const o_mean = ufirst(L.mean); float* const o_var = ufirst(L.var);
+        float* const o_noise = ufirst(L.noise_out);
+        if (ufirst(L.type) == IWVI_LAYER_LV) {
             // ================= LatentVariableLayer (layers.py:72-105) =================================
             const FwLv& V = L.lv;
-            const int Lw = V.Lw, Do = D + Lw;
-            const int npts = pidx[nvalid - 1] + 1;               // distinct data points in this chunk
-            const int mdim = up4(V.maxdim);
-            float* wts = scratch;
-            float* act0 = scratch + up4(V.wtotal);
+            const int Lw = ufirst(V.Lw), Do = D + Lw, n_enc = ufirst(V.n_enc), sampled_kl = ufirst(V.sampled_kl);
+            float* const o_kl = ufirst(V.kl_local);
+            const int mdim = up4(ufirst(V.maxdim));
+            float* act0 = scratch;
             float* act1 = act0 + NSAMP * mdim;
-            float* in = act0; float* out = act1;
-            if (V.n_enc > 0) {
+            const float* in = xyrows; int in_str = up4(g.XYdim);
+            float* out = act0;
+            {
                 int off = 0;
-                for (int l = 0; l < V.n_enc; ++l) {
-                    const int nW = V.dims[l] * V.dims[l + 1], nbias = V.dims[l + 1];
-                    for (int i = tid; i < nW; i += FW_THREADS) wts[off + i] = V.W[l][i];
-                    for (int i = tid; i < nbias; i += FW_THREADS) wts[off + nW + i] = V.b[l] ? V.b[l][i] : 0.f;
-                    off += nW + nbias;
-                }
-                const int d0 = V.dims[0];
-                for (int idx = tid; idx < npts * d0; idx += FW_THREADS) {
-                    const int p = idx / d0, i = idx - p * d0;
-                    const long long row = (p_first + p) % g.row_mod;
-                    act0[p * mdim + i] = g.XY[(size_t)row * g.XYdim + i];
-                }
-                __syncthreads();
-                off = 0;
-                for (int l = 0; l < V.n_enc; ++l) {
-                    const int din = V.dims[l], dout = V.dims[l + 1];
-                    const float* W = wts + off; const float* b = W + din * dout;
+                for (int l = 0; l < n_enc; ++l) {                                    // encoder, once per data point
+                    const int din = ufirst(V.dims[l]), dout = ufirst(V.dims[l + 1]);
+                    const float* W = cst + off; const float* b = W + din * dout;
                     for (int idx = tid; idx < npts * dout; idx += FW_THREADS) {
                         const int p = idx / dout, o = idx - p * dout;
                         float acc = b[o];
-                        for (int i = 0; i < din; ++i) acc = fmaf(in[p * mdim + i], W[i * dout + o], acc);
-                        if (l < V.n_enc - 1) acc = tanhf(acc);                       // layers.py:143-144
-                        if (din == dout) acc += in[p * mdim + o];                    // layers.py:146-147
+#pragma unroll 8
+                        for (int i = 0; i < din; ++i) acc = fmaf(in[p * in_str + i], W[i * dout + o], acc);
+                        if (l < n_enc - 1) acc = tanhf(acc);                         // layers.py:143-144
+                        if (din == dout) acc += in[p * in_str + o];                  // layers.py:146-147
                         out[p * mdim + o] = acc;
                     }
                     off += din * dout + dout;
                     __syncthreads();
-                    float* tmp = in; in = out; out = tmp;
+                    in = out; in_str = mdim;
+                    out = (out == act0) ? act1 : act0;
                 }
             }
+            FW_STAMP(2 + li * 6 + 1);
             // `in` rows hold [means (Lw) | raw (Lw)] per distinct point
             for (int idx = tid; idx < NSAMP * D; idx += FW_THREADS) {
                 const int j = idx / D, c = idx - j * D;
@@ -242,9 +409,9 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs g) {
                 xout[j * XSTR + c] = v;
                 if (j < nvalid) {
                     const long long t = t0 + j;
-                    if (L.sample) L.sample[t * Do + c] = v;
-                    if (L.mean) L.mean[t * Do + c] = v;
-                    if (L.var) L.var[t * Do + c] = 0.f;
+                    if (o_sample) o_sample[t * Do + c] = v;
+                    if (o_mean) o_mean[t * Do + c] = v;
+                    if (o_var) o_var[t * Do + c] = 0.f;
                 }
             }
             if (tid < NSAMP) {
@@ -253,40 +420,47 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs g) {
                 float klsum = 0.f;
                 for (int l = 0; l < Lw; ++l) {
                     float mu = 0.f, sg = 1.f;                                        // prior (layers.py:73-81)
-                    if (V.n_enc > 0) { mu = in[pidx[j] * mdim + l]; sg = softplus_f(in[pidx[j] * mdim + Lw + l] - 3.f); }
-                    float z = 0.f;
-                    if (j < nvalid) z = L.noise ? L.noise[t * Lw + l] : (L.zero_noise ? 0.f : draw_normal_at(g.seed, step, li, t, l));
+                    if (n_enc > 0) { mu = in[pidx[j] * in_str + l]; sg = softplus_f(in[pidx[j] * in_str + Lw + l] - 3.f); }
+                    const float z = (j < nvalid) ? zl[l * NSAMP + j] : 0.f;
                     const float w = fmaf(z, sg, mu);                                 // layers.py:86-87
                     float kl;
-                    if (V.sampled_kl) kl = -0.5f * z * z - logf(sg) + 0.5f * w * w;  // log q(W) - log p(W), :98-100
-                    else kl = 0.5f * (sg * sg + mu * mu - 1.f) - logf(sg);           // KL(N(mu,sg)||N(0,1)), :101-103
+                    if (sampled_kl) kl = -0.5f * z * z - __logf(sg) + 0.5f * w * w;  // log q(W) - log p(W), :98-100
+                    else kl = 0.5f * (sg * sg + mu * mu - 1.f) - __logf(sg);         // KL(N(mu,sg)||N(0,1)), :101-103
                     klsum += kl;
                     xout[j * XSTR + D + l] = w;
                     if (j < nvalid) {
-                        if (V.kl_local) V.kl_local[t * Lw + l] = kl;
-                        if (L.noise_out) L.noise_out[t * Lw + l] = z;
-                        if (L.sample) L.sample[t * Do + D + l] = w;                  // layers.py:89-91
-                        if (L.mean) L.mean[t * Do + D + l] = mu;
-                        if (L.var) L.var[t * Do + D + l] = sg * sg;
+                        if (o_kl) o_kl[t * Lw + l] = kl;
+                        if (o_noise) o_noise[t * Lw + l] = z;
+                        if (o_sample) o_sample[t * Do + D + l] = w;                  // layers.py:89-91
+                        if (o_mean) o_mean[t * Do + D + l] = mu;
+                        if (o_var) o_var[t * Do + D + l] = sg * sg;
                     }
                 }
                 lw[j] += klsum;
             }
             __syncthreads();
+            FW_STAMP(2 + li * 6 + 5);
         } else {
             // ================= GPLayer (layers.py:35-50) ==============================================
-            const FwGp& G = L.gp;
+            const FwGp G = uniform_gp(L.gp);
             const int nbk = G.nbk, R = G.R, P = G.P, nsteps = G.nsteps;
             f32x4* kuf = reinterpret_cast<f32x4*>(scratch);
             f32x4* at = reinterpret_cast<f32x4*>(scratch + (size_t)G.Mp * NSAMP);
-            float* usq = (R * nbk <= G.Mp) ? scratch : scratch + (size_t)2 * G.Mp * NSAMP;
+            float* usq = (FW_WAVES * R <= G.Mp) ? scratch : scratch + (size_t)2 * G.Mp * NSAMP;   // [wave][r][NSAMP]
             const bool rbf = G.kern_type == IWVI_KERN_RBF;
+            const float* invls = cst; const float* zc = cst + 32;
+            const float* Wm = cst + gpc_W(); const float* mfA = cst + gpc_A(P, R); const float* mfb = cst + gpc_b(D, P, R);
+            // Gram form: the expanded |x|^2 + |z|^2 - 2 x.z (one small MFMA product) has an absolute error of
+            // ~eps * (|x|^2 + |z|^2); use it only while the inducing cloud is compact in lengthscale units,
+            // else difference the coordinates directly (error ~eps * r^2)
+            const bool gram_mfma = __float_as_int(cst[64]) <= __float_as_int(4.0f);   // zmax2 >= 0: int compare is exact
 
             // ---- x~ = [x/l - zc, -|.|^2/2 (RBF) or |.|^2 (Matern52), 1, 0..] ----------------------------
             if (tid < NSAMP) {
                 float n2 = 0.f;
+#pragma unroll 4
                 for (int d = 0; d < D; ++d) {
-                    const float v = fmaf(xin[tid * XSTR + d], G.invls[d], -G.zc[d]);
+                    const float v = fmaf(xin[tid * XSTR + d], invls[d], -zc[d]);
                     xt[tid * XSTR + d] = v;
                     n2 = fmaf(v, v, n2);
                 }
@@ -296,115 +470,279 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs g) {
             }
             if (tid < 4) counters[tid] = 0;
             __syncthreads();
+            FW_STAMP(2 + li * 6 + 0);
 
-            // ---- Gram: kuf block bi = kernel(Z~_bi x~^T), written in B-operand order -----------------------
+            // ---- Gram: kuf block bi = kernel(Z_bi, x), written in B-operand order ---------------------------
             for (int bi = wave; bi < nbk; bi += FW_WAVES) {
                 f32x4 acc[NS];
 #pragma unroll
                 for (int t = 0; t < NS; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-                const float* zp = G.ZtP + (size_t)bi * nsteps * 64 + lane;
-                for (int s = 0; s < nsteps; ++s) {
-                    const float a = zp[s * 64];
+                if (gram_mfma) {
+                    if (G.zt_off >= 0) {
+                        const float* zp = sm + G.zt_off + (size_t)bi * nsteps * 64 + lane;      // staged in LDS
+                        for (int s = 0; s < nsteps; ++s) {
+                            const float a = zp[s * 64];
 #pragma unroll
-                    for (int t = 0; t < NS; ++t)
-                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, xt[(16 * t + jq) * XSTR + 4 * s + gq], acc[t], 0, 0, 0);
-                }
-#pragma unroll
-                for (int t = 0; t < NS; ++t) {
-                    f32x4 k;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) k[e] = kern_from_acc(acc[t][e], G.kern_type, G.variance);
-                    kuf[(bi * 4 + gq) * NSAMP + 16 * t + jq] = k;
-                }
-            }
-            __syncthreads();
-
-            // ---- stage 1: mean row-blocks (cost nbk) then a-blocks nbk-1 .. 0 (cost bi + 1) -------------
-            {
-                const int nmb = G.nrb, njobs = nmb + nbk;
-                for (;;) {
-                    int job = 0;
-                    if (lane == 0) job = atomicAdd(&counters[0], 1);
-                    job = __builtin_amdgcn_readfirstlane(job);
-                    if (job >= njobs) break;
-                    f32x4 acc[NS];
-#pragma unroll
-                    for (int t = 0; t < NS; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-                    if (job < nmb) {
-                        mma_rowblock<NS>(G.WqP + (size_t)job * nbk * 64, nbk, kuf, lane, acc);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const int r = 16 * job + 4 * gq + e;
-                            if (r < R) {
-#pragma unroll
-                                for (int t = 0; t < NS; ++t) meanp[r * NSAMP + 16 * t + jq] = acc[t][e];
-                            }
+                            for (int t = 0; t < NS; ++t)
+                                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, xt[(16 * t + jq) * XSTR + 4 * s + gq], acc[t], 0, 0, 0);
                         }
                     } else {
-                        const int bi = nbk - 1 - (job - nmb);
-                        mma_rowblock<NS>(G.LinvP + (size_t)tri_lower_off(bi) * 64, bi + 1, kuf, lane, acc);
+                        gptr1 zp = (gptr1)G.ZtP + (size_t)bi * nsteps * 64 + lane;              // from L2
+                        for (int s = 0; s < nsteps; ++s) {
+                            const float a = zp[s * 64];
+#pragma unroll
+                            for (int t = 0; t < NS; ++t)
+                                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, xt[(16 * t + jq) * XSTR + 4 * s + gq], acc[t], 0, 0, 0);
+                        }
+                    }
+                } else {
+                    // direct form: Z~ holds c*zs (RBF, c = log2 e) or -2*zs (Matern52) for rows 16bi+4g .. +3 of
+                    // feature d at [(bi*nsteps + d/4)*64 + 16*(d%4) + 4g .. +3]; acc becomes what the MFMA form yields
+                    const float sx = rbf ? 1.4426950408889634f : -2.f;
+                    for (int d = 0; d < D; ++d) {
+                        const size_t zi = ((size_t)bi * nsteps + (d >> 2)) * 64 + 16 * (d & 3) + 4 * gq;
+                        const f32x4 z4 = (G.zt_off >= 0) ? *reinterpret_cast<const f32x4*>(sm + G.zt_off + zi)
+                                                         : *((gptr4)(G.ZtP + zi));
 #pragma unroll
                         for (int t = 0; t < NS; ++t) {
-                            at[(bi * 4 + gq) * NSAMP + 16 * t + jq] = acc[t];
-                            const float s = colsumsq(acc[t]);
-                            if (gq == 0) asq[bi * NSAMP + 16 * t + jq] = s;
-                            if (G.a_out) {
-                                const int j = 16 * t + jq;
-                                if (j < nvalid)
-                                    *reinterpret_cast<f32x4*>(G.a_out + (size_t)(t0 + j) * G.Mp + 16 * bi + 4 * gq) = acc[t];
+                            const float xv = sx * xt[(16 * t + jq) * XSTR + d];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) { const float df = xv - z4[e]; acc[t][e] = fmaf(df, df, acc[t][e]); }
+                        }
+                    }
+                    // RBF: sum = c^2 r^2 -> exponent -r^2 c / 2 + log2 var;  Matern52: sum = 4 r^2 -> r^2
+                    const float sc = rbf ? -0.5f / 1.4426950408889634f : 0.25f;
+                    const float of = rbf ? __log2f(G.variance) : 0.f;
+#pragma unroll
+                    for (int t = 0; t < NS; ++t)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            acc[t][e] = fmaf(acc[t][e], sc, of);
+                }
+                // padded inducing rows (M not a multiple of 16) must give k = 0: the forward substitution carries them
+                const int mrow = 16 * bi + 4 * gq;
+                if (rbf) {
+#pragma unroll
+                    for (int t = 0; t < NS; ++t) {
+                        f32x4 k;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) k[e] = (mrow + e < G.M) ? __builtin_amdgcn_exp2f(acc[t][e]) : 0.f;   // log2(var) folded in
+                        kuf[(bi * 4 + gq) * NSAMP + 16 * t + jq] = k;
+                    }
+                } else {
+#pragma unroll
+                    for (int t = 0; t < NS; ++t) {
+                        f32x4 k;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) k[e] = (mrow + e < G.M) ? kern_from_acc(acc[t][e], G.kern_type, G.variance) : 0.f;
+                        kuf[(bi * 4 + gq) * NSAMP + 16 * t + jq] = k;
+                    }
+                }
+            }
+            __syncthreads();
+            FW_STAMP(2 + li * 6 + 1);
+
+            // ---- stage 1: a = Lm^-1 k, right-looking blocked forward substitution, one wave per sub-tile ------
+            // packed stream, column bj: [Dinv(bj), -L(bj+1,bj) .. -L(nbk-1,bj)];  a_bj = Dinv_bj r_bj, then
+            // r_bi += (-L(bi,bj)) a_bj for every bi > bj: independent MFMA chains, B operand = a_bj in registers.
+            // r lives in the `at` tile (first touched from the Gram tile); the freshly updated r_{bj+1} is handed
+            // to the next column in registers, so the dependent chain never waits for LDS.
+            if (wave < NS) {
+                const int tcol = 16 * wave + jq;                  // this lane's sample column
+                gptr4 Ap = (gptr4)G.LsP + lane;
+                float* arow = (G.a_out && tcol < nvalid) ? G.a_out + (size_t)(t0 + tcol) * G.Mp : nullptr;
+                float ssq = 0.f;
+                switch (nbk) {
+                    case 1: ssq = stage1_unrolled<NS, 1>(Ap, kuf, at, tcol, gq, arow); break;
+                    case 2: ssq = stage1_unrolled<NS, 2>(Ap, kuf, at, tcol, gq, arow); break;
+                    case 3: ssq = stage1_unrolled<NS, 3>(Ap, kuf, at, tcol, gq, arow); break;
+                    case 4: ssq = stage1_unrolled<NS, 4>(Ap, kuf, at, tcol, gq, arow); break;
+                    case 5: ssq = stage1_unrolled<NS, 5>(Ap, kuf, at, tcol, gq, arow); break;
+                    case 6: ssq = stage1_unrolled<NS, 6>(Ap, kuf, at, tcol, gq, arow); break;
+                    case 7: ssq = stage1_unrolled<NS, 7>(Ap, kuf, at, tcol, gq, arow); break;
+                    case 8: ssq = stage1_unrolled<NS, 8>(Ap, kuf, at, tcol, gq, arow); break;
+                    default: {
+                        // generic column-at-a-time form with the right-hand sides in the LDS tile
+                    const int ntri = tri_blocks(nbk);
+                    f32x4 ring[4];
+                    ring[0] = Ap[0];
+                    ring[1] = Ap[(size_t)(1 < ntri ? 1 : ntri - 1) * 64];
+                    ring[2] = Ap[(size_t)(2 < ntri ? 2 : ntri - 1) * 64];
+                    f32x4 xcur = kuf[gq * NSAMP + tcol];             // r_0
+                    f32x4 res = {0.f, 0.f, 0.f, 0.f};
+                    int bi = 0, bj = 0;
+                    for (int q0 = 0; q0 < ntri; q0 += 4) {
+    #pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const int q = q0 + u;
+                            if (q < ntri) {
+                                if (!(g.dbg & 1)) ring[(u + 3) & 3] = Ap[(size_t)(q + 3 < ntri ? q + 3 : ntri - 1) * 64];
+                                const f32x4 a_cur = ring[u];
+                                if (bi == bj) {
+                                    res = f32x4{0.f, 0.f, 0.f, 0.f};
+    #pragma unroll
+                                    for (int s = 0; s < 4; ++s) res = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[s], xcur[s], res, 0, 0, 0);
+                                    at[(bj * 4 + gq) * NSAMP + tcol] = res;
+                                    ssq += colsumsq4(res);
+                                    if (G.a_out && tcol < nvalid)
+                                        *reinterpret_cast<f32x4*>(G.a_out + (size_t)(t0 + tcol) * G.Mp + 16 * bj + 4 * gq) = res;
+                                } else {
+                                    const f32x4* src = (bj == 0) ? kuf : at;
+                                    f32x4 y = (g.dbg & 2) ? xcur : src[(bi * 4 + gq) * NSAMP + tcol];
+    #pragma unroll
+                                    for (int s = 0; s < 4; ++s) y = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[s], res[s], y, 0, 0, 0);
+                                    if (bi == bj + 1) xcur = y;                  // next column's right-hand side, kept in registers
+                                    else if (!(g.dbg & 2)) at[(bi * 4 + gq) * NSAMP + tcol] = y;
+                                    else asm volatile("" :: "v"(y));
+                                }
+                                ++bi;
+                                if (bi == nbk) { ++bj; bi = bj; }
+                            }
+                        }
+                    }
+                    }
+                }
+                ssq = xgroup_sum_mfma(ssq);
+                if (gq == 0) asq[tcol] = ssq;
+            }
+            __syncthreads();
+            FW_STAMP(2 + li * 6 + 2);
+
+            // ---- stage 2: u block (r, bi) = sum_{bk >= bi} LrT(bi, bk) a(bk), only |u|^2 kept; mean = q_mu^T a ----
+            {
+                const int ntri = tri_blocks(nbk);
+                // (a) q_mu^T row-blocks assigned to this wave: mean = q_mu^T a  (temp_workaround.py:68)
+                for (int rb = 0; rb < G.nrb; ++rb) {
+                    if (G.mean_wave[rb] != wave) continue;
+                    gptr4 P = (gptr4)G.QmuP + (size_t)rb * nbk * 64 + lane;
+                    f32x4 acc[NS];
+#pragma unroll
+                    for (int t = 0; t < NS; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    f32x4 a_cur = P[0];
+                    const f32x4* Bp = at + (size_t)gq * NSAMP + jq;
+                    for (int c = 0; c < nbk; ++c) {
+                        const f32x4 a_nx = P[(size_t)(c + 1 < nbk ? c + 1 : c) * 64];
+#pragma unroll
+                        for (int s = 0; s < 4; ++s) {
+#pragma unroll
+                            for (int t = 0; t < NS; ++t)
+                                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[s], Bp[16 * t][s], acc[t], 0, 0, 0);
+                        }
+                        a_cur = a_nx; Bp += 4 * NSAMP;
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int r = 16 * rb + 4 * gq + e;
+                        if (r < R) {
+#pragma unroll
+                            for (int t = 0; t < NS; ++t) meanp[r * NSAMP + 16 * t + jq] = acc[t][e];
+                        }
+                    }
+                }
+                if (g.stamps && lane == 0 && li == 1) g.stamps[(size_t)blockIdx.x * 128 + 100 + wave] = clock64();
+                // (b) this wave's contiguous run of (r, bi) row-block jobs: one linear stream of packed blocks
+                const int j0 = G.jb[wave], j1 = G.jb[wave + 1], nblocks = G.nblk[wave];
+                if (j0 < j1) {
+                    int r = j0 / nbk, bi = j0 - r * nbk;
+                    gptr4 P = (gptr4)G.LrTP + ((size_t)r * ntri + tri_upper_off(nbk, bi)) * 64 + lane;
+                    f32x4 ring[4];
+                    ring[0] = P[0];
+                    ring[1] = P[(size_t)(1 < nblocks ? 1 : nblocks - 1) * 64];
+                    ring[2] = P[(size_t)(2 < nblocks ? 2 : nblocks - 1) * 64];
+                    f32x4 acc[NS];
+                    float ssq[NS];
+#pragma unroll
+                    for (int t = 0; t < NS; ++t) { acc[t] = f32x4{0.f, 0.f, 0.f, 0.f}; ssq[t] = 0.f; }
+                    const f32x4* Bp = at + (size_t)(bi * 4 + gq) * NSAMP + jq;
+                    int c = nbk - bi;                             // chunks left in the current job
+                    // B tiles are read one block ahead into the other of two register sets (static alternation: the loop
+                    // is unrolled by 4), so the LDS latency hides behind this block's MFMAs
+                    f32x4 bA[NS], bB[NS];
+#pragma unroll
+                    for (int t = 0; t < NS; ++t) bA[t] = Bp[16 * t];
+                    for (int q0 = 0; q0 < nblocks; q0 += 4) {
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const int q = q0 + u;
+                            if (q < nblocks) {
+                                ring[(u + 3) & 3] = P[(size_t)(q + 3 < nblocks ? q + 3 : nblocks - 1) * 64];
+                                const f32x4 a_cur = ring[u];
+                                // where the next block's B tile lives: next chunk of this job, else the first chunk of the next job
+                                const int bin = (c > 1) ? bi : (bi + 1 == nbk ? 0 : bi + 1);
+                                const f32x4* Bn = (c > 1) ? Bp + 4 * NSAMP : at + (size_t)(bin * 4 + gq) * NSAMP + jq;
+                                if ((u & 1) == 0) {
+#pragma unroll
+                                    for (int t = 0; t < NS; ++t) bB[t] = Bn[16 * t];
+#pragma unroll
+                                    for (int s = 0; s < 4; ++s) {
+#pragma unroll
+                                        for (int t = 0; t < NS; ++t)
+                                            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[s], bA[t][s], acc[t], 0, 0, 0);
+                                    }
+                                } else {
+#pragma unroll
+                                    for (int t = 0; t < NS; ++t) bA[t] = Bn[16 * t];
+#pragma unroll
+                                    for (int s = 0; s < 4; ++s) {
+#pragma unroll
+                                        for (int t = 0; t < NS; ++t)
+                                            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[s], bB[t][s], acc[t], 0, 0, 0);
+                                    }
+                                }
+                                Bp = Bn;
+                                if (--c == 0) {
+                                    // row-block (r, bi) complete: add its squares, start the next one
+                                    if (G.u_out) {
+#pragma unroll
+                                        for (int t = 0; t < NS; ++t) {
+                                            const int j = 16 * t + jq;
+                                            if (j < nvalid)
+                                                *reinterpret_cast<f32x4*>(G.u_out + ((size_t)r * g.T + (t0 + j)) * G.Mp + 16 * bi + 4 * gq) = acc[t];
+                                        }
+                                    }
+#pragma unroll
+                                    for (int t = 0; t < NS; ++t) { ssq[t] += colsumsq4(acc[t]); acc[t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+                                    ++bi;
+                                    if (bi == nbk || q == nblocks - 1) {
+                                        // this wave's share of |u_r|^2 -> its own slot [wave][r]
+#pragma unroll
+                                        for (int t = 0; t < NS; ++t) {
+                                            const float sq = xgroup_sum_mfma(ssq[t]);
+                                            if (gq == 0) usq[(wave * R + r) * NSAMP + 16 * t + jq] = sq;
+                                            ssq[t] = 0.f;
+                                        }
+                                        if (bi == nbk) { bi = 0; ++r; }
+                                    }
+                                    c = nbk - bi;
+                                }
                             }
                         }
                     }
                 }
             }
+            if (g.stamps && lane == 0 && li == 1) g.stamps[(size_t)blockIdx.x * 128 + 110 + wave] = clock64();
             __syncthreads();
-
-            // ---- stage 2: u block (r, bi) = sum_{bk >= bi} LrT(bi, bk) a(bk); only |u|^2 is kept ------------
-            {
-                const int njobs = R * nbk, ntri = tri_blocks(nbk);
-                for (;;) {
-                    int job = 0;
-                    if (lane == 0) job = atomicAdd(&counters[1], 1);
-                    job = __builtin_amdgcn_readfirstlane(job);
-                    if (job >= njobs) break;
-                    const int bi = job / R, r = job - bi * R;
-                    f32x4 acc[NS];
-#pragma unroll
-                    for (int t = 0; t < NS; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-                    mma_rowblock<NS>(G.LrTP + ((size_t)r * ntri + tri_upper_off(nbk, bi)) * 64, nbk - bi,
-                                     at + (size_t)bi * 4 * NSAMP, lane, acc);
-#pragma unroll
-                    for (int t = 0; t < NS; ++t) {
-                        const float s = colsumsq(acc[t]);
-                        if (gq == 0) usq[(r * nbk + bi) * NSAMP + 16 * t + jq] = s;
-                        if (G.u_out) {
-                            const int j = 16 * t + jq;
-                            if (j < nvalid)
-                                *reinterpret_cast<f32x4*>(G.u_out + ((size_t)r * g.T + (t0 + j)) * G.Mp + 16 * bi + 4 * gq) = acc[t];
-                        }
-                    }
-                }
-            }
-            __syncthreads();
+            FW_STAMP(2 + li * 6 + 3);
 
             // ---- epilogue (i): per (sample, latent GP): variance, sample (temp_workaround.py:59,85,89-91) ----
             for (int idx = tid; idx < NSAMP * R; idx += FW_THREADS) {
                 const int r = idx / NSAMP, j = idx - r * NSAMP;
-                const long long t = t0 + j;
-                float a2 = 0.f, u2 = 0.f;
-                for (int i = 0; i < nbk; ++i) { a2 += asq[i * NSAMP + j]; u2 += usq[(r * nbk + i) * NSAMP + j]; }
-                const float mu = meanp[r * NSAMP + j];
-                const float v = fmaxf(G.variance - a2 + u2, 0.f);
-                float z = 0.f;
-                if (j < nvalid) {
-                    z = L.noise ? L.noise[t * R + r] : (L.zero_noise ? 0.f : draw_normal_at(g.seed, step, li, t, r));
-                    if (L.noise_out) L.noise_out[t * R + r] = z;
+                float u2 = 0.f;
+#pragma unroll
+                for (int w = 0; w < FW_WAVES; ++w) {                                  // waves whose job run touches r
+                    const int ja = G.jb[w], jz = G.jb[w + 1];
+                    if (ja < jz && ja < (r + 1) * nbk && jz > r * nbk) u2 += usq[(w * R + r) * NSAMP + j];
                 }
+                const float mu = meanp[r * NSAMP + j];
+                const float v = fmaxf(G.variance - asq[j] + u2, 0.f);
+                const float z = (j < nvalid) ? zl[r * NSAMP + j] : 0.f;
+                if (o_noise && j < nvalid) o_noise[(t0 + j) * R + r] = z;
                 gbuf[(0 * R + r) * NSAMP + j] = mu;
                 gbuf[(1 * R + r) * NSAMP + j] = v;
                 gbuf[(2 * R + r) * NSAMP + j] = fmaf(z, sqrtf(v), mu);
             }
             __syncthreads();
+            FW_STAMP(2 + li * 6 + 4);
             // ---- epilogue (ii): mixing (:142-145) + mean function (layers.py:46-48) -> next layer's input ----
             const bool last = (li == g.n_layers - 1);
             for (int idx = tid; idx < NSAMP * P; idx += FW_THREADS) {
@@ -413,8 +751,9 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs g) {
                 float o_s, o_m, o_v;
                 if (G.W) {
                     o_s = o_m = o_v = 0.f;
+#pragma unroll 4
                     for (int r = 0; r < R; ++r) {
-                        const float w = G.W[p * R + r];
+                        const float w = Wm[p * R + r];
                         o_m = fmaf(w, gbuf[(0 * R + r) * NSAMP + j], o_m);
                         o_v = fmaf(w * w, gbuf[(1 * R + r) * NSAMP + j], o_v);
                         o_s = fmaf(w, gbuf[(2 * R + r) * NSAMP + j], o_s);
@@ -425,18 +764,20 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs g) {
                 float mf = 0.f;
                 if (G.mf_type == IWVI_MF_IDENTITY) mf = xin[j * XSTR + p];
                 else if (G.mf_type == IWVI_MF_LINEAR) {
-                    for (int d = 0; d < D; ++d) mf = fmaf(xin[j * XSTR + d], G.mfA[d * P + p], mf);
-                    if (G.mfb) mf += G.mfb[p];
+#pragma unroll 4
+                    for (int d = 0; d < D; ++d) mf = fmaf(xin[j * XSTR + d], mfA[d * P + p], mf);
+                    if (G.mfb) mf += mfb[p];
                 }
                 xout[j * XSTR + p] = o_s + mf;
                 if (last) { obuf[p * NSAMP + j] = o_m + mf; obuf[(P + p) * NSAMP + j] = o_v; }
                 if (j < nvalid) {
-                    if (L.sample) L.sample[t * P + p] = o_s + mf;
-                    if (L.mean) L.mean[t * P + p] = o_m + mf;
-                    if (L.var) L.var[t * P + p] = o_v;
+                    if (o_sample) o_sample[t * P + p] = o_s + mf;
+                    if (o_mean) o_mean[t * P + p] = o_m + mf;
+                    if (o_var) o_var[t * P + p] = o_v;
                 }
             }
             __syncthreads();
+            FW_STAMP(2 + li * 6 + 5);
         }
         float* tmp = xin; xin = xout; xout = tmp;
     }
@@ -454,6 +795,7 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs g) {
         }
         g.out_logw[t0 + tid] = acc - lw[tid];
     }
+    FW_STAMP(63);
     // ---- advance the noise stream once every workgroup has read the step counter --------------------
     if (g.rng_state) {
         __syncthreads();
@@ -479,6 +821,80 @@ static int launch_forward(const FwArgs& a, unsigned grid, size_t lds_bytes, hipS
     return check_launch("k_dgp_forward");
 }
 
+// Static stage-2 schedule of a GP layer: the R*nbk row-block jobs (r-major, bi ascending; job (r, bi) costs
+// nbk - bi blocks) are cut into FW_WAVES contiguous runs with the smallest possible maximum cost; the q_mu^T
+// row-blocks (cost nbk each) go to the last waves and count against them.
+static void plan_stage2(FwGp& G) {
+    const int nbk = G.nbk, R = G.R, njobs = R * nbk;
+    int pre[FW_WAVES] = {0};
+    G.mean_wave[0] = G.mean_wave[1] = -1;
+    for (int rb = 0; rb < G.nrb && rb < 2; ++rb) { G.mean_wave[rb] = (signed char)(FW_WAVES - 1 - rb); pre[FW_WAVES - 1 - rb] += nbk; }
+    auto cost = [&](int j) { return nbk - (j % nbk); };
+    auto fits = [&](int limit, unsigned short* jb, unsigned short* nb) {
+        int j = 0;
+        for (int w = 0; w < FW_WAVES; ++w) {
+            int load = pre[w], blocks = 0;
+            if (jb) jb[w] = (unsigned short)j;
+            while (j < njobs && load + cost(j) <= limit) { load += cost(j); blocks += cost(j); ++j; }
+            if (nb) nb[w] = (unsigned short)blocks;
+        }
+        if (jb) jb[FW_WAVES] = (unsigned short)j;
+        return j == njobs;
+    };
+    int lo = nbk, hi = R * tri_blocks(nbk) + 2 * nbk;
+    while (lo < hi) { const int mid = (lo + hi) / 2; if (fits(mid, nullptr, nullptr)) hi = mid; else lo = mid + 1; }
+    fits(lo, G.jb, G.nblk);
+}
+
+// LDS image for a chunk of nsamp samples; fills the per-layer offsets of `a`.  stage_zt: keep every GP layer's
+// Gram operand Z~ in LDS for the whole launch.
+static size_t fw_plan_lds(FwArgs& a, int nsamp, int maxR, int maxP, bool stage_zt) {
+    int scratch = 0, zdims = 0, o = 0;
+    FwLds& l = a.h.lds;
+    l.ltab = o; o += up4((int)(sizeof(FwLayer) / 4) * a.h.n_layers);
+    l.xa = o; o += up4(nsamp * XSTR);
+    l.xb = o; o += up4(nsamp * XSTR);
+    l.xt = o; o += up4(nsamp * XSTR);
+    l.lw = o; o += nsamp;
+    l.rowi = o; o += nsamp;
+    l.pidx = o; o += nsamp;
+    l.asq = o; o += nsamp;
+    l.meanp = o; o += maxR * nsamp;
+    l.gbuf = o; o += 3 * maxR * nsamp;
+    l.obuf = o; o += 2 * maxP * nsamp;
+    l.xyrows = o; o += a.h.XY ? nsamp * up4(a.h.XYdim) : 0;
+    for (int i = 0; i < a.h.n_layers; ++i) {
+        FwLayer& L = a.L[i];
+        L.c_off = o;
+        if (L.type == IWVI_LAYER_GP) {
+            FwGp& G = L.gp;
+            o += gpc_size(L.D, G.P, G.R);
+            G.zt_off = -1;
+            if (stage_zt) { G.zt_off = o; o += G.nbk * G.nsteps * 64; }
+            zdims += G.R;
+            const int need = gp_scratch_floats(G.Mp, G.nbk, G.R, nsamp);
+            if (need > scratch) scratch = need;
+        } else {
+            o += up4(L.lv.wtotal);
+            zdims += L.lv.Lw;
+            const int need = lv_scratch_floats(L.lv.maxdim, nsamp);
+            if (need > scratch) scratch = need;
+        }
+    }
+    l.znoise = o;
+    int z = 0;
+    for (int i = 0; i < a.h.n_layers; ++i) {
+        FwLayer& L = a.L[i];
+        L.z_off = z;
+        z += ((L.type == IWVI_LAYER_GP) ? L.gp.R : L.lv.Lw) * nsamp;
+    }
+    o += up4(zdims * nsamp);
+    l.cnt = o; o += 4;
+    l.scratch = o; o += up4(scratch);
+    l.total = o;
+    return (size_t)o * sizeof(float);
+}
+
 int dgp_forward_impl(const iwvi_layer_desc* layers, int n_layers, const float* X, int Dx, const float* XY, int XYdim,
                      const float* Y, int Dy, int64_t T, int64_t row_div, int64_t row_mod, float lik_variance,
                      uint64_t seed, uint64_t* rng_state, float* out_logw, hipStream_t stream) {
@@ -486,13 +902,13 @@ int dgp_forward_impl(const iwvi_layer_desc* layers, int n_layers, const float* X
     if (!layers || n_layers <= 0 || n_layers > IWVI_MAX_STACK) { set_error("iwvi_dgp_forward: %d layers (1..%d supported)", n_layers, IWVI_MAX_STACK); return IWVI_ERR_ARG; }
     if (!X || Dx <= 0 || Dx > IWVI_MAX_D) { set_error("iwvi_dgp_forward: null X or Dx=%d out of range (1..%d)", Dx, IWVI_MAX_D); return IWVI_ERR_ARG; }
     if (row_div < 1 || row_mod < 1) { set_error("iwvi_dgp_forward: row_div=%lld / row_mod=%lld must be >= 1", (long long)row_div, (long long)row_mod); return IWVI_ERR_ARG; }
-    if (row_mod > 0x7fffffffLL) { set_error("iwvi_dgp_forward: more than 2^31 data rows"); return IWVI_ERR_ARG; }
+    if (row_mod > 0x7fffffffLL || row_div > 0x7fffffffLL || T > 0x7fffffffLL - 4096) { set_error("iwvi_dgp_forward: more than 2^31 rows / samples"); return IWVI_ERR_ARG; }
     if (out_logw && (!Y || Dy <= 0 || Dy > IWVI_MAX_P || !(lik_variance > 0.f))) { set_error("iwvi_dgp_forward: out_logw needs Y, 1 <= Dy <= %d and a positive likelihood variance", IWVI_MAX_P); return IWVI_ERR_ARG; }
     FwArgs a{};
-    a.n_layers = n_layers; a.X = X; a.XY = XY; a.Y = Y; a.Dx = Dx; a.XYdim = XYdim; a.Dy = Dy;
-    a.T = T; a.row_div = row_div; a.row_mod = row_mod; a.lik_variance = lik_variance;
-    a.seed = seed; a.rng_state = (unsigned long long*)rng_state; a.out_logw = out_logw;
-    int D = Dx, maxR = 1, maxP = 1, max_nbk = 1;
+    a.h.n_layers = n_layers; a.h.X = X; a.h.XY = nullptr; a.h.Y = Y; a.h.Dx = Dx; a.h.XYdim = XYdim; a.h.Dy = Dy;
+    a.h.T = T; a.h.row_div = (unsigned)row_div; a.h.row_mod = (unsigned)row_mod; a.h.lik_variance = lik_variance;
+    a.h.seed = seed; a.h.rng_state = (unsigned long long*)rng_state; a.h.out_logw = out_logw;
+    int D = Dx, maxR = 1, maxP = 1;
     bool need_rng = false;
     for (int i = 0; i < n_layers; ++i) {
         const iwvi_layer_desc& d = layers[i];
@@ -515,15 +931,15 @@ int dgp_forward_impl(const iwvi_layer_desc* layers, int n_layers, const float* X
             const StateLayout s = state_layout(d.M, d.R);
             const char* st = (const char*)d.state;
             FwGp& G = L.gp;
-            G.LinvP = (const f32x4*)(st + s.off_LinvP); G.LrTP = (const f32x4*)(st + s.off_LrTP);
-            G.WqP = (const f32x4*)(st + s.off_WqP); G.ZtP = (const float*)(st + s.off_ZtP);
-            G.zc = (const float*)(st + s.off_zc); G.invls = (const float*)(st + s.off_invls);
+            G.LsP = (const f32x4*)(st + s.off_LsP); G.LrTP = (const f32x4*)(st + s.off_LrTP);
+            G.QmuP = (const f32x4*)(st + s.off_QmuP); G.ZtP = (const float*)(st + s.off_ZtP);
+            G.cst = (const float*)(st + s.off_cst);
             G.W = d.W; G.mfA = d.mf_A; G.mfb = d.mf_b; G.a_out = d.a_out; G.u_out = d.u_out;
             G.M = d.M; G.Mp = s.Mp; G.nbk = s.nbk; G.nrb = s.nrb; G.nsteps = round_up(D + 2, 4) / 4;
             G.R = d.R; G.P = d.P; G.kern_type = d.kern_type; G.mf_type = d.mf_type; G.variance = d.variance;
+            plan_stage2(G);
             if (d.R > maxR) maxR = d.R;
             if (d.P > maxP) maxP = d.P;
-            if (s.nbk > max_nbk) max_nbk = s.nbk;
             D = d.P;
         } else if (d.type == IWVI_LAYER_LV) {
             FwLv& V = L.lv;
@@ -546,6 +962,7 @@ int dgp_forward_impl(const iwvi_layer_desc* layers, int n_layers, const float* X
                     V.wtotal += d.enc_dims[k] * d.enc_dims[k + 1] + d.enc_dims[k + 1];
                 }
                 V.n_enc = d.n_enc;
+                a.h.XY = XY;
             }
             if (D + d.latent_dim > maxP) maxP = D + d.latent_dim;
             D += d.latent_dim;
@@ -555,40 +972,24 @@ int dgp_forward_impl(const iwvi_layer_desc* layers, int n_layers, const float* X
         if (layers[n_layers - 1].type != IWVI_LAYER_GP || D != Dy) { set_error("iwvi_dgp_forward: the last layer must be a GP layer with P == Dy (%d vs %d)", D, Dy); return IWVI_ERR_ARG; }
     }
     if (need_rng && !rng_state) { set_error("iwvi_dgp_forward: a layer draws its own noise but rng_state is NULL"); return IWVI_ERR_ARG; }
-    // chunk size: the largest NS (16*NS samples per workgroup) whose LDS image fits, then no larger than
-    // what gives every CU a workgroup
-    int ns_max = 0; FwLds lay{};
-    for (int ns = FW_MAXNS; ns >= 1; --ns) {
-        const int nsamp = 16 * ns;
-        int scratch = 0;
-        for (int i = 0; i < n_layers; ++i) {
-            const FwLayer& L = a.L[i];
-            const int need = L.type == IWVI_LAYER_GP ? gp_scratch_floats(L.gp.Mp, L.gp.nbk, L.gp.R, nsamp)
-                                                     : lv_scratch_floats(L.lv.wtotal, L.lv.maxdim, L.lv.Lw, nsamp);
-            if (need > scratch) scratch = need;
-        }
-        lay = fw_lds_layout(nsamp, maxR, maxP, max_nbk, scratch);
-        if ((size_t)lay.total * sizeof(float) <= 160 * 1024) { ns_max = ns; break; }
-    }
-    if (ns_max == 0) { set_error("iwvi_dgp_forward: the layer stack needs %zu B of LDS per 16 samples (> 160 KiB)", (size_t)lay.total * sizeof(float)); return IWVI_ERR_UNSUPPORTED; }
+    // chunk size: 16*NS samples per workgroup, NS no larger than what gives every CU a workgroup, then the
+    // largest that fits the LDS (with Z~ staged if that fits too)
+    const size_t LDS_MAX = 160 * 1024;
     int ns = (int)((T + 16 * 256 - 1) / (16 * 256));
-    if (ns > ns_max) ns = ns_max;
+    if (ns > FW_MAXNS) ns = FW_MAXNS;
     if (ns < 1) ns = 1;
-    if (ns != ns_max) {
-        const int nsamp = 16 * ns;
-        int scratch = 0;
-        for (int i = 0; i < n_layers; ++i) {
-            const FwLayer& L = a.L[i];
-            const int need = L.type == IWVI_LAYER_GP ? gp_scratch_floats(L.gp.Mp, L.gp.nbk, L.gp.R, nsamp)
-                                                     : lv_scratch_floats(L.lv.wtotal, L.lv.maxdim, L.lv.Lw, nsamp);
-            if (need > scratch) scratch = need;
-        }
-        lay = fw_lds_layout(nsamp, maxR, maxP, max_nbk, scratch);
+    size_t lds_bytes = 0;
+    for (; ns >= 1; --ns) {
+        lds_bytes = fw_plan_lds(a, 16 * ns, maxR, maxP, true);
+        if (lds_bytes <= LDS_MAX) break;
+        lds_bytes = fw_plan_lds(a, 16 * ns, maxR, maxP, false);
+        if (lds_bytes <= LDS_MAX) break;
     }
-    a.lds = lay;
+    if (ns < 1) { set_error("iwvi_dgp_forward: the layer stack needs %zu B of LDS per 16 samples (> 160 KiB)", lds_bytes); return IWVI_ERR_UNSUPPORTED; }
     const long long chunks = (T + 16 * ns - 1) / (16 * ns);
     if (chunks > 0x7fffffffLL) { set_error("iwvi_dgp_forward: T too large"); return IWVI_ERR_ARG; }
-    const size_t lds_bytes = (size_t)lay.total * sizeof(float);
+    a.h.stamps = (g_stamp_buf && chunks <= g_stamp_wgs) ? g_stamp_buf : nullptr;
+    { static int dbg = -1; if (dbg < 0) { const char* e = getenv("IWVI_DEBUG_ABLATE"); dbg = e ? atoi(e) : 0; } a.h.dbg = dbg; }
     switch (ns) {
         case 1: return launch_forward<1>(a, (unsigned)chunks, lds_bytes, stream);
         case 2: return launch_forward<2>(a, (unsigned)chunks, lds_bytes, stream);
@@ -608,4 +1009,12 @@ extern "C" int iwvi_dgp_forward(const iwvi_layer_desc* layers, int n_layers, con
                                 float* out_logw, void* stream) {
     return dgp_forward_impl(layers, n_layers, X, Dx, XY, XYdim, Y, Dy, T, row_div, row_mod, lik_variance, seed,
                             rng_state, out_logw, (hipStream_t)stream);
+}
+
+/* diagnostic (not part of the drop-in surface): register a device buffer of 128 * max_workgroups 64-bit words;
+ * every fused-forward launch with at most max_workgroups workgroups then stamps its phase boundaries
+ * ([k] 100 MHz wall clock, [64 + k] shader clock) into it.  NULL switches stamping off. */
+extern "C" void iwvi_debug_set_stamps(void* buf, int64_t max_workgroups) {
+    iwvi::g_stamp_buf = (unsigned long long*)buf;
+    iwvi::g_stamp_wgs = buf ? max_workgroups : 0;
 }

@@ -105,7 +105,7 @@ extern "C" int iwvi_gp_layer_fullcov(const void* state, int M, int D, int R, int
                                 nullptr, nullptr, nullptr, mean, nullptr, a, u, T, 1, stream);
     if (rc != IWVI_OK) return rc;
     StateLayout sl = state_layout(M, R);
-    const float* invls = (const float*)((const char*)state + sl.off_invls);
+    const float* invls = (const float*)((const char*)state + sl.off_cst);
     hipLaunchKernelGGL(k_fullcov, dim3((unsigned)S, (unsigned)R), dim3(256), 0, stream, F, invls,
                        (const float*)a, (const float*)u, cov, (long long)S, (int)N, D, (int)Mp, R, kern_type, variance);
     return check_launch("k_fullcov");

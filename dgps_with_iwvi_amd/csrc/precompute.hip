@@ -4,9 +4,9 @@
 // tf.matrix_triangular_solve (:51), tf.matrix_band_part(q_sqrt) (:78) and gauss_kl (:186-188).
 //
 // ONE launch for all layers of a model: grid = (layer, role), 1024-thread workgroups.
-//   role 0        Gram + Cholesky + triangular inverse + packing of Lm^-1, (Lm^-T q_mu)^T and the K_uf
-//                 operand Z~   (the serial critical path)
-//   role 1..R     tril(q_sqrt[r])^T packing + latent GP r's share of KL[q(u) || p(u)]
+//   role 0        Gram + Cholesky + inverses of the diagonal 16x16 blocks + packing of the forward-substitution
+//                 stream and of the K_uf operand Z~   (the serial critical path)
+//   role 1..R     tril(q_sqrt[r])^T packing + latent GP r's share of KL[q(u) || p(u)] (role 1 also packs q_mu^T)
 // The factorisation works on 16x16 blocks of the lower triangle (row stride 17 doubles: conflict-free
 // ds_read_b64), resident in LDS for Mp <= 128 (78 KB) and in an L2-resident workspace otherwise:
 //   * diagonal block: one wave, row-per-lane in registers, pivots/columns broadcast with v_readlane
@@ -28,12 +28,15 @@ constexpr int ZLD = 33;           // row stride of the LDS copy of Zs (floats)
 
 struct PreLayer {
     const float* Z; const float* ls; const float* q_mu; const float* q_sqrt;
-    double* Lm; double* Linv; float* LinvP; float* LrTP; float* WqP; float* ZtP; float* zc; float* invls; double* kl;
+    double* Lm; double* Linv; float* LsP; float* LrTP; float* QmuP; float* ZtP; float* cst; double* kl;
     double* ws;
     double jitter; float variance;
     int M, D, R, Mp, nbk, nrb, kern_type, flags;
 };
-struct PreArgs { PreLayer L[IWVI_MAX_LAYERS]; int n; int stop_after; };
+struct PreArgs { PreLayer L[IWVI_MAX_LAYERS]; int n; int stop_after; unsigned long long* stamps; };
+
+static unsigned long long* g_pre_stamps = nullptr;   // diagnostic; see iwvi_debug_set_pre_stamps
+#define PRE_STAMP(k) do { if (stamps && threadIdx.x == 0) stamps[(size_t)blockIdx.x * 16 + (k)] = wall_clock64(); } while (0)
 
 __device__ __forceinline__ double kern_value(double r2, int type, double var) {
     if (type == IWVI_KERN_MATERN52) {
@@ -230,9 +233,10 @@ __device__ __forceinline__ double inv_get(const double* blk, const double* dinv,
 }
 
 template <bool IN_LDS>
-__device__ void role_factor(const PreLayer& L, int stop_after) {
+__device__ void role_factor(const PreLayer& L, int stop_after, unsigned long long* stamps) {
+    PRE_STAMP(0);
     const int tid = threadIdx.x, nthreads = blockDim.x;
-    const int M = L.M, D = L.D, Mp = L.Mp, R = L.R;
+    const int M = L.M, D = L.D, Mp = L.Mp;
     const WsLayout w = ws_layout(Mp);
     const int nbk = w.nbk;
     // LDS carve: rinv [Mp] doubles | (IN_LDS: blocks, dinv, tbuf) | zs [Mp][ZLD] floats | zn [Mp] | zcs [32]
@@ -253,7 +257,7 @@ __device__ void role_factor(const PreLayer& L, int stop_after) {
         if (m < M && d < D) v = (float)((double)L.Z[(size_t)m * D + d] / (double)L.ls[d]);
         zs[m * ZLD + d] = v;
     }
-    if (tid < 32) L.invls[tid] = (tid < D) ? (float)(1.0 / (double)L.ls[tid]) : 0.f;
+    if (tid < 32) L.cst[tid] = (tid < D) ? (float)(1.0 / (double)L.ls[tid]) : 0.f;
     __syncthreads();
     // centre: K_uf is formed as exp2(x~ . z~) with |x|^2 + |z|^2 - 2 x.z expanded (like gpflow's
     // square_dist); subtracting a common centre leaves r^2 unchanged and keeps the expansion well scaled
@@ -262,9 +266,10 @@ __device__ void role_factor(const PreLayer& L, int stop_after) {
         for (int m = 0; m < M; ++m) acc += (double)zs[m * ZLD + tid];
         const float c = (tid < D) ? (float)(acc / (double)M) : 0.f;
         zcs[tid] = c;
-        L.zc[tid] = c;
+        L.cst[32 + tid] = c;
     }
     __syncthreads();
+    PRE_STAMP(1);
     if (stop_after == 1) return;
     // Gram of the float32-rounded scaled inducing inputs, lower blocks only
     for (int idx = tid; idx < nbk * nbk * 256; idx += nthreads) {
@@ -298,6 +303,12 @@ __device__ void role_factor(const PreLayer& L, int stop_after) {
         zn[m] = (float)n2;
     }
     __syncthreads();
+    if (tid < 64) {                                                  // extent of the inducing cloud in lengthscale units:
+        float mx = 0.f;                                              // the layer kernel picks its Gram form by it
+        for (int m = tid; m < M; m += 64) mx = fmaxf(mx, zn[m]);
+        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+        if (tid == 0) L.cst[64] = mx;
+    }
     {
         const int nsteps = round_up(D + 2, 4) / 4;
         const bool rbf = L.kern_type == IWVI_KERN_RBF;
@@ -315,50 +326,51 @@ __device__ void role_factor(const PreLayer& L, int stop_after) {
         }
     }
     __syncthreads();
+    PRE_STAMP(2);
     if (stop_after == 2) return;
     chol_blocks(blk, nbk, rinv, tid, nthreads, stop_after);
+    PRE_STAMP(3);
     if (stop_after == 3 || stop_after > 30) return;
+    // inverses of the diagonal 16x16 blocks (one wave each) -- all the forward substitution of the layer
+    // kernel needs; the full triangular inverse is only formed for the dense debug outputs
+    {
+        const int lane = tid & 63, wave = tid >> 6, nw = nthreads >> 6;
+        for (int b = wave; b < nbk; b += nw) diag_inverse(blk + boff(b, b), rinv + NB * b, dinv + (size_t)b * BLK, lane);
+    }
+    __syncthreads();
+    PRE_STAMP(4);
+    // packed float32 solve stream, column-block major: column bj = [L(bj,bj)^-1, -L(bj+1,bj), .., -L(nbk-1,bj)]
+    // (the order a right-looking forward substitution consumes it); identity padding -> 0
+    const int ntri = tri_blocks(nbk);
+    for (int idx = tid; idx < ntri * BLK16; idx += nthreads) {
+        const int b = idx >> 8, e1 = idx & 255;
+        int bj = 0;
+        while (bj + 1 < nbk && tri_upper_off(nbk, bj + 1) <= b) ++bj;
+        const int bi = bj + (b - tri_upper_off(nbk, bj));
+        const int lane = e1 >> 2, s = e1 & 3;
+        const int ii = lane & 15, kk = 4 * (lane >> 4) + s;
+        const int i = 16 * bi + ii, k = 16 * bj + kk;
+        float v = 0.f;
+        if (i < M && k < M) {
+            if (bi > bj) v = -(float)blk[boff(bi, bj) + ii * BLD + kk];
+            else if (kk <= ii) v = (float)dinv[(size_t)bi * BLK + ii * BLD + kk];
+        } else if (bi == bj && i == k) v = 1.f;            // padded rows solve to 0 against k = 0 anyway
+        L.LsP[idx] = v;
+    }
+    PRE_STAMP(5);
     if (L.flags & IWVI_GP_WANT_DENSE) {
         for (int idx = tid; idx < Mp * Mp; idx += nthreads) {
             const int i = idx / Mp, k = idx - i * Mp;
             L.Lm[idx] = (k <= i) ? blk_get(blk, i, k) : 0.0;
         }
         __syncthreads();
-    }
-    if (stop_after == 4) return;
-    invert_blocks(blk, dinv, tbuf, rinv, nbk, tid, nthreads);
-    if (stop_after == 5) return;
-    if (L.flags & IWVI_GP_WANT_DENSE) {
+        invert_blocks(blk, dinv, tbuf, rinv, nbk, tid, nthreads);
         for (int idx = tid; idx < Mp * Mp; idx += nthreads) {
             const int i = idx / Mp, k = idx - i * Mp;
             L.Linv[idx] = (k <= i) ? inv_get(blk, dinv, i, k) : 0.0;
         }
     }
-    // packed float32 Lm^-1: lower-triangular 16x16 blocks, row-block major; identity padding masked to zero
-    const int ntri = tri_blocks(nbk);
-    for (int idx = tid; idx < ntri * BLK16; idx += nthreads) {
-        const int b = idx >> 8, e1 = idx & 255;
-        int bi = (int)((sqrtf(8.f * b + 1.f) - 1.f) * 0.5f);
-        while (tri_lower_off(bi + 1) <= b) ++bi;
-        while (tri_lower_off(bi) > b) --bi;
-        const int bk = b - tri_lower_off(bi);
-        const int lane = e1 >> 2, s = e1 & 3;
-        const int i = 16 * bi + (lane & 15), k = 16 * bk + 4 * (lane >> 4) + s;
-        float v = 0.f;
-        if (i < M && k < M && k <= i) v = (float)inv_get(blk, dinv, i, k);
-        L.LinvP[idx] = v;
-    }
-    // mean operand  Wq = (Lm^-T q_mu)^T  [R rows padded to 16*nrb][Mp]:  mean_r = k^T Lm^-T q_mu[:, r]
-    // (temp_workaround.py:68 with A = Lm^-1 k), so the mean needs K_uf only, not the solved A
-    const int nrb = L.nrb;
-    for (int idx = tid; idx < nrb * 16 * Mp; idx += nthreads) {
-        const int r = idx / Mp, m = idx - r * Mp;
-        double acc = 0.0;
-        if (r < R && m < M)
-            for (int i = m; i < M; ++i) acc = fma(inv_get(blk, dinv, i, m), (double)L.q_mu[(size_t)i * R + r], acc);
-        const int rb = r >> 4, ii = r & 15, bk = m >> 4, g = (m & 15) >> 2, s = m & 3;
-        L.WqP[((size_t)(rb * nbk + bk) * 64 + 16 * g + ii) * 4 + s] = (float)acc;
-    }
+    PRE_STAMP(6);
 }
 
 __device__ __forceinline__ double block_sum(double v, double* red) {
@@ -403,6 +415,18 @@ __device__ void role_pack_r(const PreLayer& L, int r, double* red) {
         const double v = L.q_mu[(size_t)m * R + r];
         acc += v * v;
     }
+    if (r == 0) {
+        // q_mu^T as MFMA A blocks [nrb][nbk]: row = latent GP (padded to 16), k = inducing point
+        float4* dq = reinterpret_cast<float4*>(L.QmuP);
+        for (int v4 = threadIdx.x; v4 < L.nrb * nbk * 64; v4 += blockDim.x) {
+            const int b = v4 >> 6, rb = b / nbk, bk = b - rb * nbk, lane = v4 & 63;
+            const int rr = 16 * rb + (lane & 15), k0 = 16 * bk + 4 * (lane >> 4);
+            float o[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (rr < R && k0 + e < M) ? L.q_mu[(size_t)(k0 + e) * R + rr] : 0.f;
+            dq[v4] = make_float4(o[0], o[1], o[2], o[3]);
+        }
+    }
     const double tot = block_sum(acc, red);
     if (threadIdx.x == 0) L.kl[r] = 0.5 * (tot - (double)M);
 }
@@ -429,7 +453,7 @@ __global__ __launch_bounds__(1024) void k_precompute(PreArgs args) {
     const PreLayer& L = args.L[blockIdx.x];
     const int role = blockIdx.y;
     if (role == 0) {
-        if (L.Mp <= 128) role_factor<true>(L, args.stop_after); else role_factor<false>(L, args.stop_after);
+        if (L.Mp <= 128) role_factor<true>(L, args.stop_after, args.stamps); else role_factor<false>(L, args.stop_after, args.stamps);
     } else if (role <= L.R) {
         role_pack_r(L, role - 1, reinterpret_cast<double*>(smem_raw));
     }
@@ -512,11 +536,11 @@ extern "C" size_t iwvi_gp_state_bytes(int M, int R) {
     return state_layout(M, R).bytes;
 }
 
-extern "C" int iwvi_gp_state_offsets(int M, int R, size_t out[9]) {
+extern "C" int iwvi_gp_state_offsets(int M, int R, size_t out[8]) {
     if (M <= 0 || R <= 0 || !out) { set_error("iwvi_gp_state_offsets: bad argument"); return IWVI_ERR_ARG; }
     StateLayout s = state_layout(M, R);
-    out[0] = s.off_Lm; out[1] = s.off_Linv; out[2] = s.off_LinvP; out[3] = s.off_LrTP;
-    out[4] = s.off_WqP; out[5] = s.off_ZtP; out[6] = s.off_zc; out[7] = s.off_invls; out[8] = s.off_kl;
+    out[0] = s.off_Lm; out[1] = s.off_Linv; out[2] = s.off_LsP; out[3] = s.off_LrTP;
+    out[4] = s.off_QmuP; out[5] = s.off_ZtP; out[6] = s.off_cst; out[7] = s.off_kl;
     return IWVI_OK;
 }
 
@@ -527,6 +551,7 @@ extern "C" int iwvi_gp_precompute(const iwvi_gp_desc* layers, int n_layers, void
         PreArgs a{};
         a.n = n_layers - base < IWVI_MAX_LAYERS ? n_layers - base : IWVI_MAX_LAYERS;
         { const char* e = getenv("IWVI_DEBUG_STOP"); a.stop_after = e ? atoi(e) : 0; }
+        a.stamps = g_pre_stamps;
         size_t lds = 1024 * sizeof(double);
         int max_roles = 0;
         for (int l = 0; l < a.n; ++l) {
@@ -547,9 +572,9 @@ extern "C" int iwvi_gp_precompute(const iwvi_gp_desc* layers, int n_layers, void
             PreLayer& L = a.L[l];
             L.Z = d.Z; L.ls = d.lengthscales; L.q_mu = d.q_mu; L.q_sqrt = d.q_sqrt;
             L.Lm = (double*)(st + s.off_Lm); L.Linv = (double*)(st + s.off_Linv);
-            L.LinvP = (float*)(st + s.off_LinvP); L.LrTP = (float*)(st + s.off_LrTP);
-            L.WqP = (float*)(st + s.off_WqP); L.ZtP = (float*)(st + s.off_ZtP);
-            L.zc = (float*)(st + s.off_zc); L.invls = (float*)(st + s.off_invls);
+            L.LsP = (float*)(st + s.off_LsP); L.LrTP = (float*)(st + s.off_LrTP);
+            L.QmuP = (float*)(st + s.off_QmuP); L.ZtP = (float*)(st + s.off_ZtP);
+            L.cst = (float*)(st + s.off_cst);
             L.kl = (double*)(st + s.off_kl);
             L.ws = (double*)(st + s.off_ws);
             L.jitter = d.jitter; L.variance = d.variance;
@@ -600,3 +625,6 @@ extern "C" int iwvi_gauss_kl(const float* q_mu, const float* q_sqrt, int M, int 
     hipLaunchKernelGGL(k_gauss_kl, dim3(1), dim3(256), 256 * sizeof(double), (hipStream_t)stream_, q_mu, q_sqrt, M, R, kl);
     return check_launch("k_gauss_kl");
 }
+
+/* diagnostic: 16 words per layer of phase stamps (100 MHz wall clock) written by the factorisation role */
+extern "C" void iwvi_debug_set_pre_stamps(void* buf) { iwvi::g_pre_stamps = (unsigned long long*)buf; }

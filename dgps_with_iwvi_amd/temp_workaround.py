@@ -48,9 +48,9 @@ class GpState:
         if nbytes == 0:
             raise ValueError("bad layer size M=%d R=%d" % (M, R))
         self.buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
-        offs = (ctypes.c_size_t * 9)()
+        offs = (ctypes.c_size_t * 8)()
         _abi.check(_abi.lib().iwvi_gp_state_offsets(self.M, self.R, offs))
-        self.offsets = dict(zip(["Lm", "Linv", "LinvP", "LrTP", "WqP", "ZtP", "zc", "invls", "kl"], list(offs)))
+        self.offsets = dict(zip(["Lm", "Linv", "LsP", "LrTP", "QmuP", "ZtP", "cst", "kl"], list(offs)))
         self.Mp = (self.M + 15) // 16 * 16
         self._keep = None
         self._redo_dense = None

@@ -65,12 +65,12 @@ const char* iwvi_last_error(void);
  * The state buffer holds, in this order,
  *   double  Lm   [Mp*Mp]   lower Cholesky factor of Kuu   (written only with IWVI_GP_WANT_DENSE)
  *   double  Linv [Mp*Mp]   Lm^-1                          (written only with IWVI_GP_WANT_DENSE)
- *   float   LinvP[ntri*256]        Lm^-1, lower-triangular blocks, packed
+ *   float   LsP  [ntri*256]        forward-substitution stream of matrix_triangular_solve (:51): row-block bi =
+ *                                  [-Lm(bi,0) .. -Lm(bi,bi-1), Lm(bi,bi)^-1], packed
  *   float   LrTP [R*ntri*256]      tril(q_sqrt[r])^T, upper-triangular blocks, packed
- *   float   WqP  [ceil(R/16)*nbk*256]  (Lm^-T q_mu)^T, packed  (mean = K_fu Lm^-T q_mu, :68)
+ *   float   QmuP [ceil(R/16)*nbk*256]  q_mu^T, packed  (mean = A^T q_mu, :68)
  *   float   ZtP  [nbk*9*64]        K_uf operand: augmented, centred, scaled inducing inputs
- *   float   zc   [32]              centre of Z / lengthscales (0 beyond D)
- *   float   invls[32]              1 / lengthscales (0 beyond D)
+ *   float   cst  [64]              1 / lengthscales [32] | centre of Z / lengthscales [32]  (0 beyond D)
  *   double  kl   [IWVI_MAX_R]      kl[r] = latent GP r's share of the whitened KL[q(u) || p(u)]
  *                                  (the layer's KL is the sum of the first R entries)
  *   double  ws   [...]             factorisation workspace (16x16 blocks of the lower triangle)
@@ -92,8 +92,8 @@ typedef struct iwvi_gp_desc {
 } iwvi_gp_desc;
 
 size_t iwvi_gp_state_bytes(int M, int R);
-/* offsets (bytes) of {Lm, Linv, LinvP, LrTP, WqP, ZtP, zc, invls, kl} inside the state buffer */
-int iwvi_gp_state_offsets(int M, int R, size_t out_host[9]);
+/* offsets (bytes) of {Lm, Linv, LsP, LrTP, QmuP, ZtP, cst, kl} inside the state buffer */
+int iwvi_gp_state_offsets(int M, int R, size_t out_host[8]);
 
 /* factorise up to IWVI_MAX_LAYERS layers per launch: grid (layer, role) -- role 0 Gram + Cholesky +
  * triangular inverse + packing, roles 1..R tril(q_sqrt[r])^T packing + KL share */
