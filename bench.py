@@ -216,7 +216,7 @@ def main():
     dom_flops = tot_flops * B * K
     model.precompute()
     NREP = 20
-    fwd = lambda: model._fused_forward(B * K, K, B, (B, K))
+    fwd = lambda: model._fused_forward(B * K, K, B, (B, K), elbo=dict(B=B, K=K, stride_b=K, stride_k=1, mode_vi=False))
     fwd()
     torch.cuda.synchronize()
     s2 = torch.cuda.Stream(device=dev)

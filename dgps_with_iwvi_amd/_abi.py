@@ -50,6 +50,15 @@ class LayerDesc(ctypes.Structure):
                 ("a_out", c_void_p), ("u_out", c_void_p)]
 
 
+class ElboDesc(ctypes.Structure):
+    """struct iwvi_elbo_desc (include/iwvi_hip.h): the reduction fused into the tail of the forward launch."""
+    _fields_ = [("B", c_int64), ("K", ctypes.c_int32), ("stride_b", c_int64), ("stride_k", c_int64),
+                ("kl_global", ctypes.POINTER(c_void_p)), ("kl_global_counts", ctypes.POINTER(ctypes.c_int32)),
+                ("n_glob", ctypes.c_int32), ("scale", c_double), ("K_total", ctypes.c_int32),
+                ("mode_vi", ctypes.c_int32), ("out_lse_ms", c_void_p), ("out_logp", c_void_p),
+                ("out_elbo", c_void_p), ("ws", c_void_p)]
+
+
 # name -> (restype, argtypes); every symbol include/iwvi_hip.h declares
 PROTOTYPES = {
     "iwvi_version": (c_int, []),
@@ -72,7 +81,8 @@ PROTOTYPES = {
                                       c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                       c_int64, c_void_p]),
     "iwvi_dgp_forward": (c_int, [ctypes.POINTER(LayerDesc), c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int,
-                                 c_int64, c_int64, c_int64, c_float, ctypes.c_uint64, c_void_p, c_void_p, c_void_p]),
+                                 c_int64, c_int64, c_int64, c_float, ctypes.c_uint64, c_void_p, c_void_p,
+                                 ctypes.POINTER(ElboDesc), c_void_p]),
     "iwvi_logw_reduce": (c_int, [c_void_p, c_int64, c_int, c_int64, c_int64, ctypes.POINTER(c_void_p),
                                  ctypes.POINTER(ctypes.c_int32), c_int, c_double, c_int, c_int,
                                  c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -36,6 +36,8 @@ using f32x4 = __attribute__((ext_vector_type(4))) float;
 // vmcnt(0) before the next one issues, which would serialise the prefetch ring
 typedef const __attribute__((address_space(1))) f32x4* gptr4;
 typedef const __attribute__((address_space(1))) float* gptr1;
+typedef __attribute__((address_space(1))) float* gout1;          // outputs: a flat store poisons the vmcnt bookkeeping
+typedef __attribute__((address_space(1))) f32x4* gout4;
 
 static unsigned long long* g_stamp_buf = nullptr;   // diagnostic; see iwvi_debug_set_stamps
 static long long g_stamp_wgs = 0;
@@ -52,6 +54,7 @@ struct FwGp {
     float* a_out; float* u_out;
     int M, Mp, nbk, nrb, nsteps, R, P, kern_type, mf_type;
     int zt_off;                       // LDS offset of the staged Z~ (floats), or -1: read it from L2
+    int ls_off;                       // LDS offset of the staged solve stream LsP, or -1: stream it from L2
     float variance;
     // static stage-2 schedule: wave w streams the (r-major, bi ascending) row-block jobs jb[w] .. jb[w+1]-1 of the
     // contiguous LrTP image (nblk[w] packed blocks), after the q_mu^T row-blocks assigned to it (mean_wave)
@@ -77,6 +80,15 @@ struct FwLds { int ltab, xa, xb, xt, lw, rowi, pidx, asq, meanp, gbuf, obuf, zno
 // Kernel arguments.  The header is read through the scalar cache; the layer table is copied to LDS with
 // vector loads first thing (one round trip for all of it): read line by line through the scalar cache, a
 // cold 3-KiB kernarg segment costs a memory round trip per 64 bytes, serialised by the control flow.
+constexpr int FW_MAX_GLOB = 16;
+// optional tail: the last workgroup to finish performs models.py:138-150 on the log-weights
+struct FwElbo {
+    int enabled, K, K_total, mode_vi, n_glob;
+    long long B, stride_b, stride_k;
+    double scale;
+    const double* klg[FW_MAX_GLOB]; int klg_n[FW_MAX_GLOB];
+    float* ms; float* logp; double* elbo; double* ws;
+};
 struct FwHead {
     int n_layers;
     const float* X; const float* XY; const float* Y;
@@ -89,6 +101,7 @@ struct FwHead {
     unsigned long long* stamps;      // diagnostic only (iwvi_debug_set_stamps): 128 words per workgroup
     int dbg;                         // diagnostic only (IWVI_DEBUG_ABLATE): timing ablations, results are wrong
     FwLds lds;
+    FwElbo e;
 };
 struct FwArgs {
     FwHead h;
@@ -105,8 +118,9 @@ __host__ __device__ static inline int gpc_size(int D, int P, int R) { return gpc
 
 // scratch needs (floats) of a layer for a chunk of nsamp samples
 static inline int gp_scratch_floats(int Mp, int nbk, int R, int nsamp) {
-    // Gram tile + solved tile; the |u|^2 slots [wave][r] alias the (dead) Gram tile when they fit, else get their own region
-    return 2 * Mp * nsamp + (FW_WAVES * R > Mp ? FW_WAVES * R * nsamp : 0);
+    // one tile: the Gram tile is solved in place (a wave reads and overwrites only its own sample columns), plus
+    // the |u|^2 slots [wave][r]
+    return Mp * nsamp + FW_WAVES * R * nsamp;
 }
 static inline int lv_scratch_floats(int maxdim, int nsamp) { return 2 * nsamp * up4(maxdim); }
 
@@ -178,11 +192,8 @@ __device__ __forceinline__ FwGp uniform_gp(const FwGp& s) {
     G.M = ufirst(s.M); G.Mp = ufirst(s.Mp); G.nbk = ufirst(s.nbk); G.nrb = ufirst(s.nrb); G.nsteps = ufirst(s.nsteps);
     G.R = ufirst(s.R); G.P = ufirst(s.P); G.kern_type = ufirst(s.kern_type); G.mf_type = ufirst(s.mf_type);
     G.zt_off = ufirst(s.zt_off); G.variance = __int_as_float(ufirst(__float_as_int(s.variance)));
-#pragma unroll
-    for (int w = 0; w <= FW_WAVES; ++w) G.jb[w] = (unsigned short)ufirst((int)s.jb[w]);
-#pragma unroll
-    for (int w = 0; w < FW_WAVES; ++w) G.nblk[w] = (unsigned short)ufirst((int)s.nblk[w]);
-    G.mean_wave[0] = (signed char)ufirst((int)s.mean_wave[0]); G.mean_wave[1] = (signed char)ufirst((int)s.mean_wave[1]);
+    G.ls_off = ufirst(s.ls_off);
+    // jb / nblk / mean_wave stay in the LDS table: indexing a register copy by the wave id would put it in scratch
     return G;
 }
 
@@ -197,9 +208,9 @@ __device__ __forceinline__ float xgroup_sum_mfma(float s) {
 // right-hand-side block r_i in registers.  Column bj: a_bj = Dinv_bj r_bj (4 dependent MFMAs), then the NBK-1-bj
 // updates r_i += (-L(i,bj)) a_bj are independent accumulator chains interleaved at the MFMA issue rate; the next
 // column's packed blocks are loaded while this one computes.
-template <int NS, int NBK>
-__device__ __forceinline__ float stage1_unrolled(gptr4 Ap, const f32x4* kuf, f32x4* at, int tcol, int gq,
-                                                 float* a_out_row /* or nullptr */) {
+template <int NS, int NBK, class AP>
+__device__ __forceinline__ float stage1_unrolled(AP Ap, const f32x4* kuf, f32x4* at, int tcol, int gq,
+                                                 gout1 a_out_row /* or nullptr */) {
     constexpr int NSAMP = 16 * NS;
     f32x4 r[NBK], A[NBK];
 #pragma unroll
@@ -225,7 +236,7 @@ __device__ __forceinline__ float stage1_unrolled(gptr4 Ap, const f32x4* kuf, f32
         }
         at[(bj * 4 + gq) * NSAMP + tcol] = res;
         ssq += colsumsq4(res);
-        if (a_out_row) *reinterpret_cast<f32x4*>(a_out_row + 16 * bj + 4 * gq) = res;
+        if (a_out_row) *((gout4)(a_out_row + 16 * bj + 4 * gq)) = res;
 #pragma unroll
         for (int i = 0; i < NBK - bj - 1; ++i) A[i] = An[i];
     }
@@ -369,13 +380,13 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
         const int D = ufirst(L.D);
         const float* cst = sm + ufirst(L.c_off);
         const float* zl = znoise + ufirst(L.z_off);
-        float* const o_sample = ufirst(L.sample); float* const o_mean = ufirst(L.mean); float* const o_var = ufirst(L.var);
-        float* const o_noise = ufirst(L.noise_out);
+        const gout1 o_sample = (gout1)ufirst(L.sample), o_mean = (gout1)ufirst(L.mean), o_var = (gout1)ufirst(L.var);
+        const gout1 o_noise = (gout1)ufirst(L.noise_out);
         if (ufirst(L.type) == IWVI_LAYER_LV) {
             // ================= LatentVariableLayer (layers.py:72-105) =================================
             const FwLv& V = L.lv;
             const int Lw = ufirst(V.Lw), Do = D + Lw, n_enc = ufirst(V.n_enc), sampled_kl = ufirst(V.sampled_kl);
-            float* const o_kl = ufirst(V.kl_local);
+            const gout1 o_kl = (gout1)ufirst(V.kl_local);
             const int mdim = up4(ufirst(V.maxdim));
             float* act0 = scratch;
             float* act1 = act0 + NSAMP * mdim;
@@ -445,8 +456,8 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
             const FwGp G = uniform_gp(L.gp);
             const int nbk = G.nbk, R = G.R, P = G.P, nsteps = G.nsteps;
             f32x4* kuf = reinterpret_cast<f32x4*>(scratch);
-            f32x4* at = reinterpret_cast<f32x4*>(scratch + (size_t)G.Mp * NSAMP);
-            float* usq = (FW_WAVES * R <= G.Mp) ? scratch : scratch + (size_t)2 * G.Mp * NSAMP;   // [wave][r][NSAMP]
+            f32x4* at = kuf;                                       // solved in place (stage 1)
+            float* usq = scratch + (size_t)G.Mp * NSAMP;           // [wave][r][NSAMP]
             const bool rbf = G.kern_type == IWVI_KERN_RBF;
             const float* invls = cst; const float* zc = cst + 32;
             const float* Wm = cst + gpc_W(); const float* mfA = cst + gpc_A(P, R); const float* mfb = cst + gpc_b(D, P, R);
@@ -469,6 +480,8 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
                 for (int d = D + 2; d < 4 * nsteps; ++d) xt[tid * XSTR + d] = 0.f;
             }
             if (tid < 4) counters[tid] = 0;
+            // the layer's forward-substitution stream -> LDS while x~ and the Gram run (all NS solving waves read it)
+            if (G.ls_off >= 0) async_copy_f32(reinterpret_cast<const float*>(G.LsP), sm + G.ls_off, tri_blocks(nbk) * BLK16, tid);
             __syncthreads();
             FW_STAMP(2 + li * 6 + 0);
 
@@ -539,6 +552,7 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
                     }
                 }
             }
+            if (G.ls_off >= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             FW_STAMP(2 + li * 6 + 1);
 
@@ -550,8 +564,21 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
             if (wave < NS) {
                 const int tcol = 16 * wave + jq;                  // this lane's sample column
                 gptr4 Ap = (gptr4)G.LsP + lane;
-                float* arow = (G.a_out && tcol < nvalid) ? G.a_out + (size_t)(t0 + tcol) * G.Mp : nullptr;
+                const gout1 arow = (G.a_out && tcol < nvalid) ? (gout1)G.a_out + (size_t)(t0 + tcol) * G.Mp : (gout1)nullptr;
                 float ssq = 0.f;
+                if (G.ls_off >= 0 && nbk <= 8) {
+                    const f32x4* Al = reinterpret_cast<const f32x4*>(sm + G.ls_off) + lane;      // staged in LDS
+                    switch (nbk) {
+                        case 1: ssq = stage1_unrolled<NS, 1>(Al, kuf, at, tcol, gq, arow); break;
+                        case 2: ssq = stage1_unrolled<NS, 2>(Al, kuf, at, tcol, gq, arow); break;
+                        case 3: ssq = stage1_unrolled<NS, 3>(Al, kuf, at, tcol, gq, arow); break;
+                        case 4: ssq = stage1_unrolled<NS, 4>(Al, kuf, at, tcol, gq, arow); break;
+                        case 5: ssq = stage1_unrolled<NS, 5>(Al, kuf, at, tcol, gq, arow); break;
+                        case 6: ssq = stage1_unrolled<NS, 6>(Al, kuf, at, tcol, gq, arow); break;
+                        case 7: ssq = stage1_unrolled<NS, 7>(Al, kuf, at, tcol, gq, arow); break;
+                        default: ssq = stage1_unrolled<NS, 8>(Al, kuf, at, tcol, gq, arow); break;
+                    }
+                } else
                 switch (nbk) {
                     case 1: ssq = stage1_unrolled<NS, 1>(Ap, kuf, at, tcol, gq, arow); break;
                     case 2: ssq = stage1_unrolled<NS, 2>(Ap, kuf, at, tcol, gq, arow); break;
@@ -585,9 +612,9 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
                                     at[(bj * 4 + gq) * NSAMP + tcol] = res;
                                     ssq += colsumsq4(res);
                                     if (G.a_out && tcol < nvalid)
-                                        *reinterpret_cast<f32x4*>(G.a_out + (size_t)(t0 + tcol) * G.Mp + 16 * bj + 4 * gq) = res;
+                                        *((gout4)((gout1)G.a_out + (size_t)(t0 + tcol) * G.Mp + 16 * bj + 4 * gq)) = res;
                                 } else {
-                                    const f32x4* src = (bj == 0) ? kuf : at;
+                                    const f32x4* src = at;                        // == kuf: solved in place
                                     f32x4 y = (g.dbg & 2) ? xcur : src[(bi * 4 + gq) * NSAMP + tcol];
     #pragma unroll
                                     for (int s = 0; s < 4; ++s) y = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[s], res[s], y, 0, 0, 0);
@@ -611,9 +638,10 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
             // ---- stage 2: u block (r, bi) = sum_{bk >= bi} LrT(bi, bk) a(bk), only |u|^2 kept; mean = q_mu^T a ----
             {
                 const int ntri = tri_blocks(nbk);
+                if (wave >= FW_WAVES / 2) __builtin_amdgcn_s_setprio(1);   // the second-dispatched half loses issue arbitration otherwise
                 // (a) q_mu^T row-blocks assigned to this wave: mean = q_mu^T a  (temp_workaround.py:68)
                 for (int rb = 0; rb < G.nrb; ++rb) {
-                    if (G.mean_wave[rb] != wave) continue;
+                    if (ufirst((int)L.gp.mean_wave[rb]) != wave) continue;
                     gptr4 P = (gptr4)G.QmuP + (size_t)rb * nbk * 64 + lane;
                     f32x4 acc[NS];
 #pragma unroll
@@ -641,7 +669,7 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
                 }
                 if (g.stamps && lane == 0 && li == 1) g.stamps[(size_t)blockIdx.x * 128 + 100 + wave] = clock64();
                 // (b) this wave's contiguous run of (r, bi) row-block jobs: one linear stream of packed blocks
-                const int j0 = G.jb[wave], j1 = G.jb[wave + 1], nblocks = G.nblk[wave];
+                const int j0 = ufirst((int)L.gp.jb[wave]), j1 = ufirst((int)L.gp.jb[wave + 1]), nblocks = ufirst((int)L.gp.nblk[wave]);
                 if (j0 < j1) {
                     int r = j0 / nbk, bi = j0 - r * nbk;
                     gptr4 P = (gptr4)G.LrTP + ((size_t)r * ntri + tri_upper_off(nbk, bi)) * 64 + lane;
@@ -697,7 +725,7 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
                                         for (int t = 0; t < NS; ++t) {
                                             const int j = 16 * t + jq;
                                             if (j < nvalid)
-                                                *reinterpret_cast<f32x4*>(G.u_out + ((size_t)r * g.T + (t0 + j)) * G.Mp + 16 * bi + 4 * gq) = acc[t];
+                                                *((gout4)((gout1)G.u_out + ((size_t)r * g.T + (t0 + j)) * G.Mp + 16 * bi + 4 * gq)) = acc[t];
                                         }
                                     }
 #pragma unroll
@@ -720,6 +748,7 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
                     }
                 }
             }
+            __builtin_amdgcn_s_setprio(0);
             if (g.stamps && lane == 0 && li == 1) g.stamps[(size_t)blockIdx.x * 128 + 110 + wave] = clock64();
             __syncthreads();
             FW_STAMP(2 + li * 6 + 3);
@@ -730,7 +759,7 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
                 float u2 = 0.f;
 #pragma unroll
                 for (int w = 0; w < FW_WAVES; ++w) {                                  // waves whose job run touches r
-                    const int ja = G.jb[w], jz = G.jb[w + 1];
+                    const int ja = L.gp.jb[w], jz = L.gp.jb[w + 1];
                     if (ja < jz && ja < (r + 1) * nbk && jz > r * nbk) u2 += usq[(w * R + r) * NSAMP + j];
                 }
                 const float mu = meanp[r * NSAMP + j];
@@ -784,6 +813,10 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
 
     // ---- per-sample log-weight: Gaussian variational expectation (models.py:134,138) minus the local
     //      regularisers (:140-142) ----------------------------------------------------------------------
+    // chunk-local reduction: with the IW tiling and K | NSAMP every data point's K samples sit in one chunk, so
+    // logsumexp_k happens here from LDS and only one partial sum per workgroup crosses workgroups
+    const bool local_lse = g.e.enabled && g.e.ws && !g.e.mode_vi && g.e.stride_k == 1 && g.e.stride_b == g.e.K &&
+                           (NSAMP % g.e.K) == 0;
     if (g.out_logw && tid < nvalid) {
         const int Dy = g.Dy;
         const float c0 = -0.5f * 1.8378770664093453f - 0.5f * logf(g.lik_variance);
@@ -793,17 +826,96 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
             const float df = g.Y[(size_t)rowi[tid] * Dy + d] - obuf[d * NSAMP + tid];
             acc += c0 - (df * df + obuf[(Dy + d) * NSAMP + tid]) * inv2s;
         }
-        g.out_logw[t0 + tid] = acc - lw[tid];
+        const float lwv = acc - lw[tid];
+        // write-through (sc1) store: the last workgroup may read every log-weight without an acquire fence
+        __hip_atomic_store(g.out_logw + t0 + tid, lwv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        lw[tid] = lwv;
     }
     FW_STAMP(63);
-    // ---- advance the noise stream once every workgroup has read the step counter --------------------
-    if (g.rng_state) {
+    if (local_lse) {
+        const FwElbo& E = g.e;
+        const int K = E.K, npl = nvalid / K;                      // complete points of this chunk
+        __syncthreads();
+        float lp = 0.f;
+        if (tid < npl) {
+            float m = -INFINITY;
+            for (int k = 0; k < K; ++k) m = fmaxf(m, lw[tid * K + k]);
+            float ssum = 0.f;
+            for (int k = 0; k < K; ++k) ssum += __expf(lw[tid * K + k] - m);
+            lp = m + logf(ssum) - logf((float)E.K_total);                              // models.py:148
+            const long long b = t0 / K + tid;
+            if (E.ms) { E.ms[2 * b] = m; E.ms[2 * b + 1] = ssum; }
+            if (E.logp) E.logp[b] = lp;
+            xt[tid] = lp;
+        }
         __syncthreads();
         if (tid == 0) {
-            const unsigned long long tk = atomicAdd(&g.rng_state[1], 1ULL);
-            if (tk == (unsigned long long)gridDim.x - 1) {
-                atomicExch(&g.rng_state[1], 0ULL);
-                atomicAdd(&g.rng_state[0], 1ULL);
+            double part = 0.0;
+            for (int p = 0; p < npl; ++p) part += (double)xt[p];                       // fixed order
+            __hip_atomic_store(E.ws + blockIdx.x, part, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    // ---- one ticket per workgroup: the last arriver advances the noise stream (every workgroup has read the
+    //      step counter by then) and, if asked, finishes the IW-ELBO reduction of models.py:138-150 ----------
+    if (g.rng_state) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's stores have left
+        __syncthreads();
+        if (tid == 0) {
+            const unsigned long long tk = __hip_atomic_fetch_add(&g.rng_state[1], 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int last = (tk == (unsigned long long)gridDim.x - 1);
+            if (last) {
+                __hip_atomic_store(&g.rng_state[1], 0ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_fetch_add(&g.rng_state[0], 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            counters[2] = last;
+        }
+        __syncthreads();
+        if (g.e.enabled && counters[2]) {
+            const FwElbo& E = g.e;
+            double acc = 0.0;
+            if (local_lse) {
+                for (int i = tid; i < (int)gridDim.x; i += FW_THREADS)
+                    acc += __hip_atomic_load(E.ws + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                const int K = E.K;
+                for (long long b = tid; b < E.B; b += FW_THREADS) {
+                    const float* row = g.out_logw + b * E.stride_b;
+                    float m = -INFINITY, ssum = 0.f, lsum = 0.f;
+                    for (int k0 = 0; k0 < K; k0 += 8) {
+                        float Lv[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u)                                    // 8 independent write-through-coherent loads
+                            Lv[u] = (k0 + u < K) ? __hip_atomic_load(row + (k0 + u) * E.stride_k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : -INFINITY;
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            if (k0 + u < K) {
+                                lsum += Lv[u];
+                                if (Lv[u] > m) { ssum = ssum * __expf(m - Lv[u]) + 1.f; m = Lv[u]; }
+                                else ssum += __expf(Lv[u] - m);
+                            }
+                        }
+                    }
+                    float lp;
+                    if (E.mode_vi) lp = lsum / (float)K;                               // models.py:84
+                    else {
+                        lp = m + logf(ssum) - logf((float)E.K_total);                  // models.py:148
+                        if (E.ms) { E.ms[2 * b] = m; E.ms[2 * b + 1] = ssum; }
+                    }
+                    if (E.logp) E.logp[b] = lp;
+                    acc += (double)lp;
+                }
+            }
+            // deterministic block sum: lanes by shuffles, then the 8 wave partials in a fixed order
+            for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+            double* wsum = reinterpret_cast<double*>(sm + g.lds.xa);
+            if (lane == 0) wsum[wave] = acc;
+            __syncthreads();
+            if (tid == 0 && E.elbo) {
+                double tot = 0.0, kl = 0.0;
+                for (int w = 0; w < FW_WAVES; ++w) tot += wsum[w];
+                for (int i = 0; i < E.n_glob; ++i)
+                    for (int c = 0; c < E.klg_n[i]; ++c) kl += E.klg[i][c];
+                *E.elbo = tot * E.scale - kl;                                          // models.py:150
             }
         }
     }
@@ -848,8 +960,8 @@ static void plan_stage2(FwGp& G) {
 
 // LDS image for a chunk of nsamp samples; fills the per-layer offsets of `a`.  stage_zt: keep every GP layer's
 // Gram operand Z~ in LDS for the whole launch.
-static size_t fw_plan_lds(FwArgs& a, int nsamp, int maxR, int maxP, bool stage_zt) {
-    int scratch = 0, zdims = 0, o = 0;
+static size_t fw_plan_lds(FwArgs& a, int nsamp, int maxR, int maxP, bool stage_zt, bool stage_ls) {
+    int scratch = 0, zdims = 0, o = 0, ls_max = 0;
     FwLds& l = a.h.lds;
     l.ltab = o; o += up4((int)(sizeof(FwLayer) / 4) * a.h.n_layers);
     l.xa = o; o += up4(nsamp * XSTR);
@@ -871,6 +983,8 @@ static size_t fw_plan_lds(FwArgs& a, int nsamp, int maxR, int maxP, bool stage_z
             o += gpc_size(L.D, G.P, G.R);
             G.zt_off = -1;
             if (stage_zt) { G.zt_off = o; o += G.nbk * G.nsteps * 64; }
+            G.ls_off = -1;
+            if (stage_ls && G.nbk <= 8 && tri_blocks(G.nbk) * BLK16 > ls_max) ls_max = tri_blocks(G.nbk) * BLK16;
             zdims += G.R;
             const int need = gp_scratch_floats(G.Mp, G.nbk, G.R, nsamp);
             if (need > scratch) scratch = need;
@@ -880,6 +994,11 @@ static size_t fw_plan_lds(FwArgs& a, int nsamp, int maxR, int maxP, bool stage_z
             const int need = lv_scratch_floats(L.lv.maxdim, nsamp);
             if (need > scratch) scratch = need;
         }
+    }
+    if (ls_max > 0) {                                   // one staging buffer, reused layer after layer
+        for (int i = 0; i < a.h.n_layers; ++i)
+            if (a.L[i].type == IWVI_LAYER_GP && a.L[i].gp.nbk <= 8) a.L[i].gp.ls_off = o;
+        o += ls_max;
     }
     l.znoise = o;
     int z = 0;
@@ -897,7 +1016,7 @@ static size_t fw_plan_lds(FwArgs& a, int nsamp, int maxR, int maxP, bool stage_z
 
 int dgp_forward_impl(const iwvi_layer_desc* layers, int n_layers, const float* X, int Dx, const float* XY, int XYdim,
                      const float* Y, int Dy, int64_t T, int64_t row_div, int64_t row_mod, float lik_variance,
-                     uint64_t seed, uint64_t* rng_state, float* out_logw, hipStream_t stream) {
+                     uint64_t seed, uint64_t* rng_state, float* out_logw, const iwvi_elbo_desc* elbo, hipStream_t stream) {
     if (T <= 0) return IWVI_OK;                         // empty batch: nothing to do
     if (!layers || n_layers <= 0 || n_layers > IWVI_MAX_STACK) { set_error("iwvi_dgp_forward: %d layers (1..%d supported)", n_layers, IWVI_MAX_STACK); return IWVI_ERR_ARG; }
     if (!X || Dx <= 0 || Dx > IWVI_MAX_D) { set_error("iwvi_dgp_forward: null X or Dx=%d out of range (1..%d)", Dx, IWVI_MAX_D); return IWVI_ERR_ARG; }
@@ -972,6 +1091,23 @@ int dgp_forward_impl(const iwvi_layer_desc* layers, int n_layers, const float* X
         if (layers[n_layers - 1].type != IWVI_LAYER_GP || D != Dy) { set_error("iwvi_dgp_forward: the last layer must be a GP layer with P == Dy (%d vs %d)", D, Dy); return IWVI_ERR_ARG; }
     }
     if (need_rng && !rng_state) { set_error("iwvi_dgp_forward: a layer draws its own noise but rng_state is NULL"); return IWVI_ERR_ARG; }
+    if (elbo) {
+        if (!out_logw || !rng_state) { set_error("iwvi_dgp_forward: the fused ELBO needs out_logw and rng_state (its ticket word)"); return IWVI_ERR_ARG; }
+        if (elbo->B <= 0 || elbo->K <= 0 || elbo->n_glob < 0 || elbo->n_glob > FW_MAX_GLOB) { set_error("iwvi_dgp_forward: bad ELBO descriptor (B=%lld K=%d n_glob=%d)", (long long)elbo->B, elbo->K, elbo->n_glob); return IWVI_ERR_ARG; }
+        const int64_t last_row = (elbo->B - 1) * elbo->stride_b + (int64_t)(elbo->K - 1) * elbo->stride_k;
+        if (elbo->stride_b < 0 || elbo->stride_k < 0 || last_row >= T) { set_error("iwvi_dgp_forward: ELBO strides address row %lld of %lld", (long long)last_row, (long long)T); return IWVI_ERR_ARG; }
+        FwElbo& E = a.h.e;
+        E.enabled = 1; E.K = elbo->K; E.K_total = elbo->K_total > 0 ? elbo->K_total : elbo->K; E.mode_vi = elbo->mode_vi;
+        E.B = elbo->B; E.stride_b = elbo->stride_b; E.stride_k = elbo->stride_k; E.scale = elbo->scale;
+        E.n_glob = elbo->n_glob;
+        for (int i = 0; i < elbo->n_glob; ++i) {
+            if (!elbo->kl_global || !elbo->kl_global[i]) { set_error("iwvi_dgp_forward: null global KL pointer %d", i); return IWVI_ERR_ARG; }
+            E.klg[i] = elbo->kl_global[i];
+            E.klg_n[i] = elbo->kl_global_counts ? elbo->kl_global_counts[i] : 1;
+            if (E.klg_n[i] <= 0 || E.klg_n[i] > IWVI_MAX_R) { set_error("iwvi_dgp_forward: bad global KL count %d", E.klg_n[i]); return IWVI_ERR_ARG; }
+        }
+        E.ms = elbo->out_lse_ms; E.logp = elbo->out_logp; E.elbo = elbo->out_elbo; E.ws = elbo->ws;
+    }
     // chunk size: 16*NS samples per workgroup, NS no larger than what gives every CU a workgroup, then the
     // largest that fits the LDS (with Z~ staged if that fits too)
     const size_t LDS_MAX = 160 * 1024;
@@ -980,9 +1116,11 @@ int dgp_forward_impl(const iwvi_layer_desc* layers, int n_layers, const float* X
     if (ns < 1) ns = 1;
     size_t lds_bytes = 0;
     for (; ns >= 1; --ns) {
-        lds_bytes = fw_plan_lds(a, 16 * ns, maxR, maxP, true);
+        lds_bytes = fw_plan_lds(a, 16 * ns, maxR, maxP, true, true);
         if (lds_bytes <= LDS_MAX) break;
-        lds_bytes = fw_plan_lds(a, 16 * ns, maxR, maxP, false);
+        lds_bytes = fw_plan_lds(a, 16 * ns, maxR, maxP, true, false);
+        if (lds_bytes <= LDS_MAX) break;
+        lds_bytes = fw_plan_lds(a, 16 * ns, maxR, maxP, false, false);
         if (lds_bytes <= LDS_MAX) break;
     }
     if (ns < 1) { set_error("iwvi_dgp_forward: the layer stack needs %zu B of LDS per 16 samples (> 160 KiB)", lds_bytes); return IWVI_ERR_UNSUPPORTED; }
@@ -1006,9 +1144,9 @@ using namespace iwvi;
 extern "C" int iwvi_dgp_forward(const iwvi_layer_desc* layers, int n_layers, const float* X, int Dx,
                                 const float* XY, int XYdim, const float* Y, int Dy, int64_t T, int64_t row_div,
                                 int64_t row_mod, float lik_variance, uint64_t seed, uint64_t* rng_state,
-                                float* out_logw, void* stream) {
+                                float* out_logw, const iwvi_elbo_desc* elbo, void* stream) {
     return dgp_forward_impl(layers, n_layers, X, Dx, XY, XYdim, Y, Dy, T, row_div, row_mod, lik_variance, seed,
-                            rng_state, out_logw, (hipStream_t)stream);
+                            rng_state, out_logw, elbo, (hipStream_t)stream);
 }
 
 /* diagnostic (not part of the drop-in surface): register a device buffer of 128 * max_workgroups 64-bit words;

@@ -8,7 +8,7 @@ using f32x4 = __attribute__((ext_vector_type(4))) float;
 
 int dgp_forward_impl(const iwvi_layer_desc* layers, int n_layers, const float* X, int Dx, const float* XY, int XYdim,
                      const float* Y, int Dy, int64_t T, int64_t row_div, int64_t row_mod, float lik_variance,
-                     uint64_t seed, uint64_t* rng_state, float* out_logw, hipStream_t stream);
+                     uint64_t seed, uint64_t* rng_state, float* out_logw, const iwvi_elbo_desc* elbo, hipStream_t stream);
 
 __device__ __forceinline__ float kern_value_f32(float r2, int type, float var) {
     if (type == IWVI_KERN_MATERN52) {
@@ -69,7 +69,7 @@ static int layer_forward_impl(const void* state, int M, int D, int R, int P, int
     d.mf_type = mf_type; d.variance = variance; d.W = W; d.mf_A = mf_A; d.mf_b = mf_b;
     d.noise = noise; d.sample = sample; d.mean = mean; d.var = var; d.a_out = a_out; d.u_out = u_out;
     d.zero_noise = 1;        // noise == NULL means z = 0 for this entry point (include/iwvi_hip.h)
-    return dgp_forward_impl(&d, 1, F, D, nullptr, 0, nullptr, 0, T, bcast_K, T / bcast_K, 1.f, 0, nullptr, nullptr, stream);
+    return dgp_forward_impl(&d, 1, F, D, nullptr, 0, nullptr, 0, T, bcast_K, T / bcast_K, 1.f, 0, nullptr, nullptr, nullptr, stream);
 }
 
 }  // namespace iwvi

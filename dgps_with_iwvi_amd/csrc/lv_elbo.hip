@@ -7,7 +7,7 @@ namespace iwvi {
 
 int dgp_forward_impl(const iwvi_layer_desc* layers, int n_layers, const float* X, int Dx, const float* XY, int XYdim,
                      const float* Y, int Dy, int64_t T, int64_t row_div, int64_t row_mod, float lik_variance,
-                     uint64_t seed, uint64_t* rng_state, float* out_logw, hipStream_t stream);
+                     uint64_t seed, uint64_t* rng_state, float* out_logw, const iwvi_elbo_desc* elbo, hipStream_t stream);
 
 // ------------------------------------------------------------------------------------------
 // IW-ELBO reduction: one wave per data point.
@@ -211,7 +211,7 @@ extern "C" int iwvi_lv_layer_forward(const float* F, const float* XY, const floa
     if (XY) { d.enc_W = enc_W; d.enc_b = enc_b; d.enc_dims = dims; d.n_enc = n_enc;
               if (!enc_W || !dims) { set_error("iwvi_lv_layer_forward: encoder inputs without an encoder"); return IWVI_ERR_ARG; } }
     d.noise = noise; d.zero_noise = 1; d.sample = sample; d.mean = mean; d.var = cov; d.kl_local = kl;
-    return dgp_forward_impl(&d, 1, F, D, XY, XY ? dims[0] : 0, nullptr, 0, T, 1, T, 1.f, 0, nullptr, nullptr,
+    return dgp_forward_impl(&d, 1, F, D, XY, XY ? dims[0] : 0, nullptr, 0, T, 1, T, 1.f, 0, nullptr, nullptr, nullptr,
                             (hipStream_t)stream_);
 }
 

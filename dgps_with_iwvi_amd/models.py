@@ -4,10 +4,10 @@ with the same constructor / method signatures, running on the HIP kernels behind
 ``DGP_IWVI._build_likelihood`` is the north-star function; ``E_log_p_Y`` (the name used in the older
 doubly-stochastic DGP code and in BASELINE.json) is an alias for its per-point log-weight stage.
 
-One ELBO evaluation is three launches: ``iwvi_gp_precompute`` (Gram + Cholesky + operand packing of every
-GP layer), ``iwvi_dgp_forward`` (the tiling of X/Y over K, every layer, the Gaussian variational
-expectation and the local regularisers, fused: a workgroup carries its samples through all layers in LDS)
-and ``iwvi_logw_reduce`` (log-sum-exp over K, scaled sum, minus the global KLs).
+One ELBO evaluation is two launches: ``iwvi_gp_precompute`` (Gram + Cholesky + operand packing of every
+GP layer) and ``iwvi_dgp_forward`` (the tiling of X/Y over K, every layer, the Gaussian variational
+expectation and the local regularisers, fused: a workgroup carries its samples through all layers in LDS;
+the last workgroup to finish does the log-sum-exp over K, the scaled sum and subtracts the global KLs).
 
 Differences from the reference, all documented in DESIGN.md:
   * ``zs`` (one N(0,1) array or None per layer) injects the noise tf.random_normal draws in-graph; None
@@ -103,10 +103,11 @@ class DGP_VI:
 
     # -- fused forward ------------------------------------------------------------------------
     def _fused_forward(self, T, row_div, row_mod, lead, zs=None, sampled_kl=True, want_layers=False,
-                       want_logw=True, use_encoder=True):
+                       want_logw=True, use_encoder=True, elbo=None):
         """``iwvi_dgp_forward`` over the current minibatch: every layer + log-weights in one launch.
-        Row t of the flattened batch reads data row (t // row_div) % row_mod.  Returns (logw [T] or None,
-        per-layer dict lists when ``want_layers``)."""
+        Row t of the flattened batch reads data row (t // row_div) % row_mod.  ``elbo`` = dict(B, K, stride_b,
+        stride_k, mode_vi, want_ms, K_total): also run the reduction of models.py:138-150 in the tail of the
+        launch.  Returns (logw [T] or None, per-layer dict lists when ``want_layers``, (elbo, logp, ms) or None)."""
         dev = self.X.device
         n = len(self.layers)
         if n > _abi.MAX_STACK:
@@ -148,11 +149,31 @@ class DGP_VI:
             outs.append(o)
         logw = torch.empty(T, dtype=settings.float_type, device=dev) if want_logw else None
         words = self._words()
+        ed, red = None, None
+        if elbo is not None:
+            B, K = elbo["B"], elbo["K"]
+            glob = [_abi.dev_tensor(g.reshape(-1), "global kl", torch.float64) for g in self._global_kls()]
+            glob_p = _abi.ptr_array(glob)
+            glob_n = (ctypes.c_int32 * max(len(glob), 1))(*[g.numel() for g in glob])
+            logp = torch.empty(B, dtype=settings.float_type, device=dev)
+            val = torch.empty(1, dtype=torch.float64, device=dev)
+            ms = torch.empty(B, 2, dtype=settings.float_type, device=dev) if elbo.get("want_ms") else None
+            ed = _abi.ElboDesc()
+            ed.B, ed.K, ed.stride_b, ed.stride_k = B, K, elbo["stride_b"], elbo["stride_k"]
+            ed.kl_global, ed.kl_global_counts, ed.n_glob = glob_p, glob_n, len(glob)
+            ed.scale = float(self.num_data) / float(B)                     # models.py:80-81, :144-145
+            ed.K_total, ed.mode_vi = elbo.get("K_total") or K, 1 if elbo["mode_vi"] else 0
+            ed.out_lse_ms = None if ms is None else ms.data_ptr()
+            ws = torch.empty((T + 15) // 16, dtype=torch.float64, device=dev)
+            ed.out_logp, ed.out_elbo, ed.ws = logp.data_ptr(), val.data_ptr(), ws.data_ptr()
+            keep.append((glob, glob_p, glob_n, ws))
+            red = (val[0], logp, ms)
         _abi.check(_abi.lib().iwvi_dgp_forward(
             descs, n, _abi.ptr(X), X.shape[1], _abi.ptr(XY), 0 if XY is None else XY.shape[1],
             _abi.ptr(Y) if want_logw else None, Y.shape[1], T, row_div, row_mod, self.likelihood.variance,
-            settings.seed, ctypes.c_void_p(words.data_ptr() + 8), _abi.ptr(logw), _abi.stream_ptr()))
-        return logw, outs
+            settings.seed, ctypes.c_void_p(words.data_ptr() + 8), _abi.ptr(logw),
+            None if ed is None else ctypes.byref(ed), _abi.stream_ptr()))
+        return logw, outs, red
 
     def _xy_minibatch(self):
         """[x_b, y_b] rows of the current minibatch (models.py:53 / :116 before tiling), cached per minibatch."""
@@ -209,9 +230,9 @@ class DGP_VI:
         S, N = self.num_samples, self.X.shape[0]
         self.precompute()
         # tile(X, [S, 1]) (:50-53): row t = s*N + n reads data row t % N; analytic local KL (:58-61)
-        logw, _ = self._fused_forward(S * N, 1, N, (S * N,), zs=zs, sampled_kl=False)
-        elbo, _, _ = self._reduce_logw(logw, self._global_kls(), N, S, stride_b=1, stride_k=N, mode_vi=True)
-        return elbo
+        _, _, red = self._fused_forward(S * N, 1, N, (S * N,), zs=zs, sampled_kl=False,
+                                        elbo=dict(B=N, K=S, stride_b=1, stride_k=N, mode_vi=True))
+        return red[0]
 
     def compute_log_likelihood(self, zs=None):
         """gpflow ``Model.compute_log_likelihood`` (reference tests/test_gp_layer.py:50): host float."""
@@ -264,7 +285,7 @@ class DGP_IWVI(DGP_VI):
                 cov = torch.diagonal(cov, dim1=-2, dim2=-1).transpose(1, 2).contiguous()  # :133
             return means[-1], cov, local_kls, global_kls, samples, means, covs
         self.precompute()
-        _, outs = self._fused_forward(B * K, K, B, (B, K), zs=zs, sampled_kl=True, want_layers=True)
+        _, outs, _ = self._fused_forward(B * K, K, B, (B, K), zs=zs, sampled_kl=True, want_layers=True)
         samples, means, covs = ([o[k] for o in outs] for k in ("sample", "mean", "var"))
         local_kls = [o["kl_local"] for o, l in zip(outs, self.layers) if l.regularizer_type is RegularizerType.LOCAL]
         return means[-1], covs[-1], local_kls, self._global_kls(), samples, means, covs
@@ -275,18 +296,18 @@ class DGP_IWVI(DGP_VI):
         if self.full_cov_over_samples:
             return None
         self.precompute()
-        logw, _ = self._fused_forward(B * K, K, B, (B, K), zs=zs, sampled_kl=True)
-        return logw
+        return self._fused_forward(B * K, K, B, (B, K), zs=zs, sampled_kl=True)[0]
 
     def _elbo_parts(self, zs=None, want_ms=False, K_total=None):
         B, K = self.X.shape[0], self.num_samples
-        logw = self._logw(zs)
-        if logw is None:                                             # literal reference path
+        if self.full_cov_over_samples:                               # literal reference path, layer by layer
             fmean, fvar, local_kls, global_kls, _, _, _ = self._forward_iw(zs)
             return self._reduce(fmean, fvar, self.Y, local_kls, global_kls, B, K, stride_b=K, stride_k=1,
                                 mode_vi=False, want_ms=want_ms, K_total=K_total)
-        return self._reduce_logw(logw, self._global_kls(), B, K, stride_b=K, stride_k=1, mode_vi=False,
-                                 want_ms=want_ms, K_total=K_total)
+        self.precompute()
+        return self._fused_forward(B * K, K, B, (B, K), zs=zs, sampled_kl=True,
+                                   elbo=dict(B=B, K=K, stride_b=K, stride_k=1, mode_vi=False, want_ms=want_ms,
+                                             K_total=K_total))[2]
 
     def _build_likelihood(self, zs=None):
         """The importance-weighted ELBO, reference models.py:112-150."""

@@ -187,10 +187,25 @@ typedef struct iwvi_layer_desc {
     float* a_out; float* u_out;     /* GP, single-layer calls only: A [T, Mp], L_r^T A [R, T, Mp] */
 } iwvi_layer_desc;
 
+/* Optional tail of the same launch: the last workgroup to finish performs models.py:138-150 on out_logw
+ * (logsumexp over K minus log K, or the mean over S of :84; sum over points * scale; minus the global KLs),
+ * so that one IW-ELBO evaluation is two launches (iwvi_gp_precompute + iwvi_dgp_forward).  Fields as the
+ * arguments of iwvi_logw_reduce; needs rng_state (its second word is the arrival ticket). */
+typedef struct iwvi_elbo_desc {
+    int64_t B; int32_t K;
+    int64_t stride_b, stride_k;
+    const double* const* kl_global; const int32_t* kl_global_counts; int32_t n_glob;
+    double scale; int32_t K_total, mode_vi;
+    float* out_lse_ms; float* out_logp; double* out_elbo;
+    double* ws;                     /* optional scratch, ceil(T/16) doubles: one partial sum per workgroup when every
+                                     * point's K samples sit in one chunk; NULL -> the last workgroup reads all of out_logw */
+} iwvi_elbo_desc;
+
 int iwvi_dgp_forward(const iwvi_layer_desc* layers_host, int n_layers,
                      const float* X, int Dx, const float* XY, int XYdim, const float* Y, int Dy,
                      int64_t T, int64_t row_div, int64_t row_mod, float lik_variance,
-                     uint64_t seed, uint64_t* rng_state, float* out_logw, void* stream);
+                     uint64_t seed, uint64_t* rng_state, float* out_logw,
+                     const iwvi_elbo_desc* elbo /* or NULL */, void* stream);
 
 /* models.py:138-150 on precomputed log-weights: logw row of (point b, sample k) = b*stride_b + k*stride_k;
  * arguments as iwvi_iw_elbo_reduce. */

@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""Summarise gpurun_out/prof_<tag>/ (scripts/profile_round.sh) into one small JSON + CSV for profiles/.
+
+Per kernel: calls, average duration (kernel trace), and per-dispatch averages of every collected counter.
+Derived for the forward kernel: MFMA busy fraction (SQ_VALU_MFMA_BUSY_CYCLES / (SQ_BUSY_CYCLES per SE...)) is
+reported raw -- the gfx950 derived-metric XML is missing in ROCm 7.2, so the raw counters are kept and the
+formula used is stated next to each derived number.  HBM traffic: FETCH_SIZE is doubled (gfx950 reports half
+of a wide coalesced read, MI355X_MICROARCH.md section HBM), WRITE_SIZE is taken as is; both are in KiB."""
+import csv, glob, json, os, sys
+from collections import defaultdict
+
+tag = sys.argv[1]
+root = os.path.join("gpurun_out", "prof_" + tag)
+out = {"tag": tag, "kernels": {}}
+
+def short(name):
+    return name.split("(")[0].replace("void ", "").strip()
+
+# kernel trace: durations
+for f in glob.glob(os.path.join(root, "trace", "**", "*kernel_trace.csv"), recursive=True):
+    acc = defaultdict(list)
+    for row in csv.DictReader(open(f)):
+        acc[short(row["Kernel_Name"])].append(int(row["End_Timestamp"]) - int(row["Start_Timestamp"]))
+    for k, v in acc.items():
+        if k.startswith("iwvi::"):
+            out["kernels"].setdefault(k, {})["calls"] = len(v)
+            out["kernels"][k]["avg_ns"] = sum(v) / len(v)
+            v2 = sorted(v); out["kernels"][k]["median_ns"] = v2[len(v2) // 2]
+# counters
+for p in ("pmc1", "pmc2", "pmc3"):
+    for f in glob.glob(os.path.join(root, p, "**", "*counter_collection.csv"), recursive=True):
+        acc = defaultdict(lambda: defaultdict(list))
+        for row in csv.DictReader(open(f)):
+            k = short(row["Kernel_Name"])
+            if k.startswith("iwvi::"):
+                acc[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
+        for k, cs in acc.items():
+            d = out["kernels"].setdefault(k, {}).setdefault("counters_per_dispatch", {})
+            for c, v in cs.items():
+                d[c] = sum(v) / len(v)
+for k, d in out["kernels"].items():
+    c = d.get("counters_per_dispatch", {})
+    der = {}
+    if "FETCH_SIZE" in c: der["hbm_read_bytes(FETCH_SIZE*1024*2)"] = c["FETCH_SIZE"] * 1024 * 2
+    if "WRITE_SIZE" in c: der["hbm_write_bytes(WRITE_SIZE*1024)"] = c["WRITE_SIZE"] * 1024
+    if "SQ_VALU_MFMA_BUSY_CYCLES" in c and "GRBM_GUI_ACTIVE" in c and c["GRBM_GUI_ACTIVE"] > 0:
+        # busy cycles are summed over the 1024 SIMDs; GRBM_GUI_ACTIVE is summed over the 8 XCDs
+        der["mfma_busy_frac(SQ_VALU_MFMA_BUSY_CYCLES/(1024*GRBM_GUI_ACTIVE/8))"] = c["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024 * c["GRBM_GUI_ACTIVE"] / 8)
+    if "SQ_INSTS_VALU_MFMA_MOPS_F32" in c and "avg_ns" in d:
+        der["mfma_f32_flops_per_s(MOPS*512/avg_ns)"] = c["SQ_INSTS_VALU_MFMA_MOPS_F32"] * 512 / (d["avg_ns"] * 1e-9)
+    d["derived"] = der
+os.makedirs("profiles", exist_ok=True)
+with open(os.path.join("profiles", tag + "_summary.json"), "w") as fh:
+    json.dump(out, fh, indent=1, sort_keys=True)
+for f in glob.glob(os.path.join(root, "trace", "**", "*kernel_stats.csv"), recursive=True):
+    rows = [r for r in csv.reader(open(f))]
+    with open(os.path.join("profiles", tag + "_kernel_stats.csv"), "w") as fh:
+        w = csv.writer(fh)
+        for r in rows:
+            if r and (r[0] == "Name" or "iwvi::" in r[0]): w.writerow(r)
+print(json.dumps(out, indent=1, sort_keys=True))
