@@ -16,7 +16,7 @@ KERN_RBF, KERN_MATERN52 = 0, 1
 LAYER_GP, LAYER_LV = 0, 1
 ABI_VERSION = 2
 GP_WANT_DENSE = 1
-MAX_STACK = 12
+MAX_STACK = 8
 MF_ZERO, MF_IDENTITY, MF_LINEAR = 0, 1, 2
 MAX_LAYERS, MAX_R, MAX_P, MAX_D, MAX_M, MAX_KL, MAX_ENC = 8, 32, 32, 32, 512, 4, 8
 

@@ -100,12 +100,20 @@ struct FwHead {
     float* out_logw;
     unsigned long long* stamps;      // diagnostic only (iwvi_debug_set_stamps): 128 words per workgroup
     int dbg;                         // diagnostic only (IWVI_DEBUG_ABLATE): timing ablations, results are wrong
+    int ncopy;
     FwLds lds;
     FwElbo e;
 };
+// prologue work lists, built by the host: plain contiguous copies global -> LDS (every small operand of every layer)
+// and the per-layer noise slots; they ride in the LDS copy of the table, one entry per wave-iteration
+struct FwCopy { const float* src; int n; int dst; };           // n floats to LDS float offset dst; n < 0: 16-byte pieces
+struct FwNoise { const float* src; int dims, z_off, zero, layer; };
+constexpr int FW_MAX_COPY = 6 * IWVI_MAX_STACK;
 struct FwArgs {
     FwHead h;
     FwLayer L[IWVI_MAX_STACK];
+    FwNoise N[IWVI_MAX_STACK];
+    FwCopy C[FW_MAX_COPY];
 };
 
 __host__ __device__ static inline int up4(int x) { return (x + 3) & ~3; }
@@ -146,6 +154,17 @@ __device__ __forceinline__ void async_copy_f32(const float* __restrict__ src, fl
     }
 }
 
+// same with 16 bytes per lane (1 KiB per wave-instruction); src and dst 16-byte aligned, n a multiple of 4
+__device__ __forceinline__ void async_copy_f32x4(const float* __restrict__ src, float* lds_dst, int n, int tid) {
+    const int lane = tid & 63, n4 = n >> 2;
+    for (int i0 = (tid & ~63); i0 < n4; i0 += FW_THREADS) {
+        const int i = i0 + lane;
+        if (i < n4)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 4 * i),
+                                             (__attribute__((address_space(3))) void*)(lds_dst + 4 * i0), 16, 0, 0);
+    }
+}
+
 // sum over the 16 rows of a result block, per sample column: 4 registers, then across the 4 lane groups
 __device__ __forceinline__ float colsumsq4(const f32x4& v) {
     float s = v[0] * v[0];
@@ -167,7 +186,7 @@ __device__ __forceinline__ void draw_normal4(unsigned long long seed, unsigned l
     box_muller4(c, v);
 }
 
-__device__ __forceinline__ float softplus_f(float x) { return x > 20.f ? x : log1pf(expf(x)); }
+__device__ __forceinline__ float softplus_f(float x) { return x > 20.f ? x : log1pf(__expf(x)); }
 
 extern __shared__ __attribute__((aligned(16))) unsigned char fw_smem[];
 
@@ -261,10 +280,17 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
         const uint32_t* ka = nullptr;
 #endif
         uint32_t* dst = reinterpret_cast<uint32_t*>(sm + g.lds.ltab);
-        const int nw = g.n_layers * (int)(sizeof(FwLayer) / 4);
-        for (int i = tid; i < nw; i += FW_THREADS) dst[i] = ka[i];
+        // layers | noise plan | copy list are contiguous in FwArgs; copy only what is in use
+        const int nl = g.n_layers * (int)(sizeof(FwLayer) / 4);
+        for (int i = tid; i < nl; i += FW_THREADS) dst[i] = ka[i];
+        constexpr int offN = (int)((offsetof(FwArgs, N) - offsetof(FwArgs, L)) / 4), offC = (int)((offsetof(FwArgs, C) - offsetof(FwArgs, L)) / 4);
+        const int nn = g.n_layers * (int)(sizeof(FwNoise) / 4), nc = g.ncopy * (int)(sizeof(FwCopy) / 4);
+        for (int i = tid; i < nn; i += FW_THREADS) dst[offN + i] = ka[offN + i];
+        for (int i = tid; i < nc; i += FW_THREADS) dst[offC + i] = ka[offC + i];
     }
     const FwLayer* LT = reinterpret_cast<const FwLayer*>(sm + g.lds.ltab);
+    const FwNoise* NT = reinterpret_cast<const FwNoise*>(sm + g.lds.ltab + (offsetof(FwArgs, N) - offsetof(FwArgs, L)) / 4);
+    const FwCopy* CT = reinterpret_cast<const FwCopy*>(sm + g.lds.ltab + (offsetof(FwArgs, C) - offsetof(FwArgs, L)) / 4);
     float* xin = sm + g.lds.xa;
     float* xout = sm + g.lds.xb;
     float* xt = sm + g.lds.xt;
@@ -313,60 +339,54 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
     }
     __syncthreads();                                              // layer table (and rowi / pidx) visible
     FW_STAMP(56);
+    // copy list: one entry per wave at a time, all DMA loads in flight together
+    for (int ci = wave; ci < g.ncopy; ci += FW_WAVES) {
+        const float* src = ufirst(CT[ci].src);
+        const int n = ufirst(CT[ci].n);
+        float* dst = sm + ufirst(CT[ci].dst);
+        const int wl = lane;                                       // this wave alone moves the entry
+        if (!src) { for (int i = wl; i < n; i += 64) dst[i] = 0.f; }           // absent operand (e.g. no encoder bias)
+        else if (n < 0) { for (int i0 = 0; i0 < (-n >> 2); i0 += 64) if (i0 + wl < (-n >> 2))
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 4 * (i0 + wl)),
+                                                 (__attribute__((address_space(3))) void*)(dst + 4 * i0), 16, 0, 0); }
+        else { for (int i0 = 0; i0 < n; i0 += 64) if (i0 + wl < n)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + i0 + wl),
+                                                 (__attribute__((address_space(3))) void*)(dst + i0), 4, 0, 0); }
+    }
+    // injected noise [T, dims] -> znoise[z_off + r * NSAMP + j] (a gather: the DMA source is per lane)
     for (int li = 0; li < g.n_layers; ++li) {
-        const FwLayer& L = LT[li];
-        float* cst = sm + ufirst(L.c_off);
-        if (ufirst(L.type) == IWVI_LAYER_GP) {
-            const FwGp G = uniform_gp(L.gp);
-            const int D = ufirst(L.D);
-            async_copy_f32(G.cst, cst, IWVI_CST_FLOATS, tid);                      // invls[32] | zc[32] | zmax2
-            if (G.W) async_copy_f32(G.W, cst + gpc_W(), G.P * G.R, tid);
-            if (G.mf_type == IWVI_MF_LINEAR) {
-                async_copy_f32(G.mfA, cst + gpc_A(G.P, G.R), D * G.P, tid);
-                if (G.mfb) async_copy_f32(G.mfb, cst + gpc_b(D, G.P, G.R), G.P, tid);
-            }
-            if (G.zt_off >= 0) async_copy_f32(G.ZtP, sm + G.zt_off, G.nbk * G.nsteps * 64, tid);
-        } else {
-            const FwLv& V = L.lv;
-            const int n_enc = ufirst(V.n_enc);
-            int off = 0;
-            for (int l = 0; l < n_enc; ++l) {
-                const int nW = ufirst(V.dims[l]) * ufirst(V.dims[l + 1]), nbias = ufirst(V.dims[l + 1]);
-                async_copy_f32(ufirst(V.W[l]), cst + off, nW, tid);
-                const float* bl = ufirst(V.b[l]);
-                if (bl) async_copy_f32(bl, cst + off + nW, nbias, tid);
-                off += nW + nbias;
-            }
-        }
-        // injected noise [T, dims] -> znoise[z_off + r * NSAMP + j] (a gather: the DMA source is per lane)
-        const float* noise = ufirst(L.noise);
-        if (noise) {
-            const int dims = ufirst((L.type == IWVI_LAYER_GP) ? L.gp.R : L.lv.Lw);
-            float* zdst = znoise + ufirst(L.z_off);
-            for (int i0 = (tid & ~63); i0 < dims * NSAMP; i0 += FW_THREADS) {
-                const int i = i0 + lane, r = i / NSAMP, j = i - r * NSAMP;
-                if (i < dims * NSAMP && j < nvalid)
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(noise + (size_t)(t0 + j) * dims + r),
-                                                     (__attribute__((address_space(3))) void*)(zdst + i0), 4, 0, 0);
-            }
+        const float* noise = ufirst(NT[li].src);
+        if (!noise) continue;
+        const int dims = ufirst(NT[li].dims);
+        float* zdst = znoise + ufirst(NT[li].z_off);
+        for (int i0 = (tid & ~63); i0 < dims * NSAMP; i0 += FW_THREADS) {
+            const int i = i0 + lane, r = i / NSAMP, j = i - r * NSAMP;
+            if (i < dims * NSAMP && j < nvalid)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(noise + (size_t)(t0 + j) * dims + r),
+                                                 (__attribute__((address_space(3))) void*)(zdst + i0), 4, 0, 0);
         }
     }
     FW_STAMP(57);
-    // in-kernel draws (layers without injected noise), 4 normals per Philox call; overlaps the copies above
-    for (int li = 0; li < g.n_layers; ++li) {
-        const FwLayer& L = LT[li];
-        if (ufirst(L.noise) != nullptr) continue;
-        const int dims = ufirst((L.type == IWVI_LAYER_GP) ? L.gp.R : L.lv.Lw);
-        const int zero_noise = ufirst(L.zero_noise);
-        float* zdst = znoise + ufirst(L.z_off);
-        const int nq = (dims + 3) >> 2;
-        for (int idx = tid; idx < nq * NSAMP; idx += FW_THREADS) {
-            const int q = idx / NSAMP, j = idx - q * NSAMP;
+    // in-kernel draws (layers without injected noise), 4 normals per Philox call, overlapping the copies above.
+    // All (layer, 4-component group, sample) items form ONE flat index space spread over the whole workgroup.
+    {
+        int total = 0;
+        for (int li = 0; li < g.n_layers; ++li)
+            if (ufirst(NT[li].src) == nullptr) total += ((ufirst(NT[li].dims) + 3) >> 2) * NSAMP;
+        for (int idx = tid; idx < total; idx += FW_THREADS) {
+            int li = 0, rem = idx, dims = 0, z_off = 0, zero = 0;
+            for (int l = 0; l < g.n_layers; ++l) {
+                if (NT[l].src != nullptr) continue;
+                const int cnt = ((NT[l].dims + 3) >> 2) * NSAMP;
+                if (rem < cnt) { li = l; dims = NT[l].dims; z_off = NT[l].z_off; zero = NT[l].zero; break; }
+                rem -= cnt;
+            }
+            const int q = rem / NSAMP, j = rem - q * NSAMP;
             float v[4] = {0.f, 0.f, 0.f, 0.f};
-            if (!zero_noise && j < nvalid) draw_normal4(g.seed, step, li, t0 + j, q, v);
+            if (!zero && j < nvalid) draw_normal4(g.seed, step, li, t0 + j, q, v);
 #pragma unroll
             for (int e = 0; e < 4; ++e)
-                if (4 * q + e < dims) zdst[(4 * q + e) * NSAMP + j] = v[e];
+                if (4 * q + e < dims) znoise[z_off + (4 * q + e) * NSAMP + j] = v[e];
         }
     }
     FW_STAMP(58);
@@ -481,7 +501,7 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
             }
             if (tid < 4) counters[tid] = 0;
             // the layer's forward-substitution stream -> LDS while x~ and the Gram run (all NS solving waves read it)
-            if (G.ls_off >= 0) async_copy_f32(reinterpret_cast<const float*>(G.LsP), sm + G.ls_off, tri_blocks(nbk) * BLK16, tid);
+            if (G.ls_off >= 0) async_copy_f32x4(reinterpret_cast<const float*>(G.LsP), sm + G.ls_off, tri_blocks(nbk) * BLK16, tid);
             __syncthreads();
             FW_STAMP(2 + li * 6 + 0);
 
@@ -639,6 +659,7 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
             {
                 const int ntri = tri_blocks(nbk);
                 if (wave >= FW_WAVES / 2) __builtin_amdgcn_s_setprio(1);   // the second-dispatched half loses issue arbitration otherwise
+                for (int i = lane; i < R * NSAMP; i += 64) usq[wave * R * NSAMP + i] = 0.f;   // slots this wave will not fill
                 // (a) q_mu^T row-blocks assigned to this wave: mean = q_mu^T a  (temp_workaround.py:68)
                 for (int rb = 0; rb < G.nrb; ++rb) {
                     if (ufirst((int)L.gp.mean_wave[rb]) != wave) continue;
@@ -758,10 +779,7 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
                 const int r = idx / NSAMP, j = idx - r * NSAMP;
                 float u2 = 0.f;
 #pragma unroll
-                for (int w = 0; w < FW_WAVES; ++w) {                                  // waves whose job run touches r
-                    const int ja = L.gp.jb[w], jz = L.gp.jb[w + 1];
-                    if (ja < jz && ja < (r + 1) * nbk && jz > r * nbk) u2 += usq[(w * R + r) * NSAMP + j];
-                }
+                for (int w = 0; w < FW_WAVES; ++w) u2 += usq[(w * R + r) * NSAMP + j];   // fixed order: bit-reproducible
                 const float mu = meanp[r * NSAMP + j];
                 const float v = fmaxf(G.variance - asq[j] + u2, 0.f);
                 const float z = (j < nvalid) ? zl[r * NSAMP + j] : 0.f;
@@ -774,18 +792,24 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
             FW_STAMP(2 + li * 6 + 4);
             // ---- epilogue (ii): mixing (:142-145) + mean function (layers.py:46-48) -> next layer's input ----
             const bool last = (li == g.n_layers - 1);
+            const bool need_mv = last || o_mean || o_var;         // inner layers only hand their sample on
             for (int idx = tid; idx < NSAMP * P; idx += FW_THREADS) {
                 const int p = idx / NSAMP, j = idx - p * NSAMP;
                 const long long t = t0 + j;
                 float o_s, o_m, o_v;
                 if (G.W) {
                     o_s = o_m = o_v = 0.f;
+                    if (need_mv) {
 #pragma unroll 4
-                    for (int r = 0; r < R; ++r) {
-                        const float w = Wm[p * R + r];
-                        o_m = fmaf(w, gbuf[(0 * R + r) * NSAMP + j], o_m);
-                        o_v = fmaf(w * w, gbuf[(1 * R + r) * NSAMP + j], o_v);
-                        o_s = fmaf(w, gbuf[(2 * R + r) * NSAMP + j], o_s);
+                        for (int r = 0; r < R; ++r) {
+                            const float w = Wm[p * R + r];
+                            o_m = fmaf(w, gbuf[(0 * R + r) * NSAMP + j], o_m);
+                            o_v = fmaf(w * w, gbuf[(1 * R + r) * NSAMP + j], o_v);
+                            o_s = fmaf(w, gbuf[(2 * R + r) * NSAMP + j], o_s);
+                        }
+                    } else {
+#pragma unroll 8
+                        for (int r = 0; r < R; ++r) o_s = fmaf(Wm[p * R + r], gbuf[(2 * R + r) * NSAMP + j], o_s);
                     }
                 } else {
                     o_m = gbuf[(0 * R + p) * NSAMP + j]; o_v = gbuf[(1 * R + p) * NSAMP + j]; o_s = gbuf[(2 * R + p) * NSAMP + j];
@@ -793,7 +817,7 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
                 float mf = 0.f;
                 if (G.mf_type == IWVI_MF_IDENTITY) mf = xin[j * XSTR + p];
                 else if (G.mf_type == IWVI_MF_LINEAR) {
-#pragma unroll 4
+#pragma unroll 8
                     for (int d = 0; d < D; ++d) mf = fmaf(xin[j * XSTR + d], mfA[d * P + p], mf);
                     if (G.mfb) mf += mfb[p];
                 }
@@ -963,7 +987,7 @@ static void plan_stage2(FwGp& G) {
 static size_t fw_plan_lds(FwArgs& a, int nsamp, int maxR, int maxP, bool stage_zt, bool stage_ls) {
     int scratch = 0, zdims = 0, o = 0, ls_max = 0;
     FwLds& l = a.h.lds;
-    l.ltab = o; o += up4((int)(sizeof(FwLayer) / 4) * a.h.n_layers);
+    l.ltab = o; o += up4((int)((sizeof(FwArgs) - offsetof(FwArgs, L)) / 4));
     l.xa = o; o += up4(nsamp * XSTR);
     l.xb = o; o += up4(nsamp * XSTR);
     l.xt = o; o += up4(nsamp * XSTR);
@@ -1008,6 +1032,41 @@ static size_t fw_plan_lds(FwArgs& a, int nsamp, int maxR, int maxP, bool stage_z
         z += ((L.type == IWVI_LAYER_GP) ? L.gp.R : L.lv.Lw) * nsamp;
     }
     o += up4(zdims * nsamp);
+    // work lists of the prologue
+    a.h.ncopy = 0;
+    auto add_copy = [&](const float* src, int n, int dst, bool vec) {
+        if (!src || n <= 0) return;
+        FwCopy& c = a.C[a.h.ncopy++];
+        const bool v16 = vec && (n % 4 == 0) && (dst % 4 == 0) && (((uintptr_t)src) % 16 == 0);
+        c.src = src; c.n = v16 ? -n : n; c.dst = dst;
+    };
+    for (int i = 0; i < a.h.n_layers; ++i) {
+        FwLayer& L = a.L[i];
+        FwNoise& nz = a.N[i];
+        nz.src = L.noise; nz.zero = L.zero_noise; nz.z_off = L.z_off; nz.layer = i;
+        if (L.type == IWVI_LAYER_GP) {
+            const FwGp& G = L.gp;
+            nz.dims = G.R;
+            add_copy(G.cst, IWVI_CST_FLOATS, L.c_off, true);                           // invls[32] | zc[32] | zmax2
+            add_copy(G.W, G.P * G.R, L.c_off + gpc_W(), true);
+            if (G.mf_type == IWVI_MF_LINEAR) {
+                add_copy(G.mfA, L.D * G.P, L.c_off + gpc_A(G.P, G.R), true);
+                add_copy(G.mfb, G.P, L.c_off + gpc_b(L.D, G.P, G.R), true);
+            }
+            if (G.zt_off >= 0) add_copy(G.ZtP, G.nbk * G.nsteps * 64, G.zt_off, true);
+        } else {
+            const FwLv& V = L.lv;
+            nz.dims = V.Lw;
+            int off = 0;
+            for (int k = 0; k < V.n_enc; ++k) {
+                const int nW = V.dims[k] * V.dims[k + 1], nb = V.dims[k + 1];
+                add_copy(V.W[k], nW, L.c_off + off, true);
+                if (V.b[k]) add_copy(V.b[k], nb, L.c_off + off + nW, true);
+                else { FwCopy& c = a.C[a.h.ncopy++]; c.src = nullptr; c.n = nb; c.dst = L.c_off + off + nW; }
+                off += nW + nb;
+            }
+        }
+    }
     l.cnt = o; o += 4;
     l.scratch = o; o += up4(scratch);
     l.total = o;

@@ -161,7 +161,7 @@ int iwvi_gp_layer_fullcov(const void* state, int M, int D, int R, int kern_type,
  * Y / out_logw may be NULL (propagate only).  out_logw [T] = sum_d var_exp - sum local regularisers.
  * ---------------------------------------------------------------------- */
 enum { IWVI_LAYER_GP = 0, IWVI_LAYER_LV = 1 };
-#define IWVI_MAX_STACK 12   /* layers (GP + LV) in one fused launch */
+#define IWVI_MAX_STACK 8    /* layers (GP + LV) in one fused launch */
 
 typedef struct iwvi_layer_desc {
     int32_t type;                   /* IWVI_LAYER_*                                          */
