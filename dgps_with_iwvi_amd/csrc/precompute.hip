@@ -38,13 +38,39 @@ struct PreArgs { PreLayer L[IWVI_MAX_LAYERS]; int n; int stop_after; unsigned lo
 static unsigned long long* g_pre_stamps = nullptr;   // diagnostic; see iwvi_debug_set_pre_stamps
 #define PRE_STAMP(k) do { if (stamps && threadIdx.x == 0) stamps[(size_t)blockIdx.x * 16 + (k)] = wall_clock64(); } while (0)
 
+// exp(-x) for x >= 0 in float64, ~2e-16 relative: n = rint(-x log2 e), t = -x - n ln2 (two-term), degree-12 Taylor
+// on |t| <= ln2/2 (remainder < 3e-17), scaled by 2^n through the exponent field.  About 25 fp64 instructions
+// against ~100 for the library exp; the Gram is 8k of these on one CU, on the critical path of every step.
+__device__ __forceinline__ double exp_neg(double x) {
+    if (x > 700.0) return 0.0;
+    const double y = -x;
+    const double n = rint(y * 1.4426950408889634074);
+    double t = fma(-n, 6.93147180369123816490e-01, y);
+    t = fma(-n, 1.90821492927058770002e-10, t);
+    double p = 2.08767569878680989792e-09;          // 1/12!
+    p = fma(p, t, 2.50521083854417187751e-08);      // 1/11!
+    p = fma(p, t, 2.75573192239858906526e-07);      // 1/10!
+    p = fma(p, t, 2.75573192239858906526e-06);      // 1/9!
+    p = fma(p, t, 2.48015873015873015873e-05);      // 1/8!
+    p = fma(p, t, 1.98412698412698412698e-04);      // 1/7!
+    p = fma(p, t, 1.38888888888888888889e-03);      // 1/6!
+    p = fma(p, t, 8.33333333333333333333e-03);      // 1/5!
+    p = fma(p, t, 4.16666666666666666667e-02);      // 1/4!
+    p = fma(p, t, 1.66666666666666666667e-01);      // 1/3!
+    p = fma(p, t, 0.5);
+    p = fma(p, t, 1.0);
+    p = fma(p, t, 1.0);
+    const int e = (int)n;                            // >= -1010
+    return __hiloint2double(__double2hiint(p) + (e << 20), __double2loint(p));
+}
+
 __device__ __forceinline__ double kern_value(double r2, int type, double var) {
     if (type == IWVI_KERN_MATERN52) {
         const double s5 = 2.23606797749978969641;
         double r = sqrt(r2 + 1e-12);
-        return var * (1.0 + s5 * r + (5.0 / 3.0) * r * r) * exp(-s5 * r);
+        return var * (1.0 + s5 * r + (5.0 / 3.0) * r * r) * exp_neg(s5 * r);
     }
-    return var * exp(-0.5 * r2);
+    return var * exp_neg(0.5 * r2);
 }
 
 __host__ __device__ __forceinline__ int boff(int bi, int bj) { return (bi * (bi + 1) / 2 + bj) * BLK; }
@@ -67,14 +93,22 @@ __device__ __forceinline__ double readlane_d(double v, int src) {
     return __hiloint2double(hi, lo);
 }
 
-// Cholesky of one 16x16 block by ONE wave: lane (l & 15) owns row l & 15 in registers; the pivot and the
-// freshly scaled column are broadcast with v_readlane, so the 16 steps need no LDS traffic and no barrier.
-// Writes the factor back (upper part zeroed) and 1/L[j][j] to rinv[0..15].
-__device__ __forceinline__ void diag_factor(double* D, double* rinv, int lane) {
-    const int i = lane & 15;
+// Cholesky of one 16x16 diagonal block, the triangular solve of up to two 16-row blocks below it AND the inverse
+// of the factor, by ONE wave: lane l owns one row in registers -- lanes 0-15 the diagonal block's rows, lanes
+// 16-47 the rows of blocks p+1, p+2 of the column, lanes 48-63 the rows of an identity block.  The pivot and the
+// freshly scaled column are broadcast with v_readlane from the diagonal block's lanes, and the very same
+// per-column operations (scale by 1/l_jj, subtract l_ij l_kj) that factor the diagonal block perform
+// x L_pp^T = a on every other row -- at no extra instruction.  For the identity rows the solution is L_pp^-T,
+// which is all the inverse the rest of the pipeline needs.  16 steps, no LDS traffic, no barrier.
+// win = number of blocks below carried along (<= 2).  Writes the factor back (upper part of the diagonal block
+// zeroed), X = L_pp^-T to xT (row i, column k at [i*BLD + k]) and 1/L[j][j] to rinv[0..15].
+__device__ __forceinline__ void diag_factor_window(double* blk, int p, int win, double* xT, double* rinv, int lane) {
+    const int i = lane & 15, lb = lane >> 4;
+    const bool ident = lb == 3, live = lb <= win;
+    double* rowp = ident ? xT + i * BLD : blk + boff(p + (live ? lb : 0), p) + i * BLD;
     double a[NB];
 #pragma clang loop unroll(full)
-    for (int k = 0; k < NB; ++k) a[k] = D[i * BLD + k];
+    for (int k = 0; k < NB; ++k) a[k] = ident ? (k == i ? 1.0 : 0.0) : rowp[k];
 #pragma clang loop unroll(full)
     for (int j = 0; j < NB; ++j) {
         const double ajj = readlane_d(a[j], j);
@@ -88,9 +122,9 @@ __device__ __forceinline__ void diag_factor(double* D, double* rinv, int lane) {
             a[k] = fma(-lij, lkj, a[k]);
         }
     }
-    if (lane < NB) {
+    if (live || ident) {
 #pragma clang loop unroll(full)
-        for (int k = 0; k < NB; ++k) D[i * BLD + k] = (k <= i) ? a[k] : 0.0;
+        for (int k = 0; k < NB; ++k) rowp[k] = (lb > 0 || k <= i) ? a[k] : 0.0;
     }
 }
 
@@ -145,31 +179,35 @@ __device__ __forceinline__ void blk_store(double* C, const f64x4& v, int lane) {
 }
 
 // Blocked right-looking Cholesky on block storage. rinv: [16*nbk] reciprocal pivots.
-__device__ __forceinline__ void chol_blocks(double* blk, int nbk, double* rinv, int tid, int nthreads, int dbg = 0) {
+// Per block column p: wave 0 factors the diagonal block, solves the next two block rows and inverts the factor in
+// the same pass (diag_factor_window; xT + p*BLK receives L_pp^-T); meanwhile the other waves post-process column
+// p-1, which is final by then (POST: the packed float32 solve stream of that column -- see role_factor).  Then
+// the panel blocks beyond the window as one f64-MFMA product each, L(i,p) = A(i,p) L_pp^-T, and the trailing
+// update (one wave per block, f64 MFMA).
+template <class POST>
+__device__ __forceinline__ void chol_blocks(double* blk, int nbk, double* rinv, double* xT, int tid, int nthreads, int dbg, POST post,
+                                            unsigned long long* stamps = nullptr) {
     const int lane = tid & 63, wave = tid >> 6, nw = nthreads >> 6;
     for (int p = 0; p < nbk; ++p) {
-        double* Dpp = blk + boff(p, p);
-        if (wave == 0) diag_factor(Dpp, rinv + NB * p, lane);
-        __syncthreads();
-        if (dbg == 31) continue;
         const int m = nbk - 1 - p;                       // block rows below the diagonal block
-        // panel: rows of blocks (bi, p), bi > p:  x L_pp^T = a  (forward substitution, one thread per row)
-        for (int t = tid; t < m * NB; t += nthreads) {
-            double* row = blk + boff(p + 1 + t / NB, p) + (t % NB) * BLD;
-            double x[NB];
-#pragma clang loop unroll(full)
-            for (int c = 0; c < NB; ++c) x[c] = row[c];
-#pragma clang loop unroll(full)
-            for (int c = 0; c < NB; ++c) {
-                double s = x[c];
-#pragma clang loop unroll(full)
-                for (int k = 0; k < c; ++k) s = fma(-x[k], Dpp[c * BLD + k], s);
-                x[c] = s * rinv[NB * p + c];
-            }
-#pragma clang loop unroll(full)
-            for (int c = 0; c < NB; ++c) row[c] = x[c];
-        }
+        const int win = m < 2 ? m : 2;                   // of which the factoring wave carries this many
+        if (p == 1) PRE_STAMP(10);
+        if (wave == 0) diag_factor_window(blk, p, win, xT + (size_t)p * BLK, rinv + NB * p, lane);
+        if (p == 1) PRE_STAMP(11);
+        if (wave != 0 && p > 0) post(p - 1, tid - 64, nthreads - 64);
         __syncthreads();
+        if (p == 1) PRE_STAMP(12);
+        if (dbg == 31) continue;
+        // panel blocks beyond the window: L(bi, p) = A(bi, p) L_pp^-T, one wave per block, in place
+        if (m > win) {
+            for (int b = wave; b < m - win; b += nw) {
+                double* A = blk + boff(p + 1 + win + b, p);
+                f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+                blk_mma<false>(acc, A, xT + (size_t)p * BLK, lane, 1.0);
+                blk_store(A, acc, lane);
+            }
+            __syncthreads();
+        }
         if (dbg == 32) continue;
         // trailing update: blocks (bi, bj), p < bj <= bi:  C -= P_bi P_bj^T
         const int nout = m * (m + 1) / 2;
@@ -184,9 +222,13 @@ __device__ __forceinline__ void chol_blocks(double* blk, int nbk, double* rinv, 
             blk_mma<true>(acc, blk + boff(bi, p), blk + boff(bj, p), lane, -1.0);
             blk_store(C, acc, lane);
         }
-        __syncthreads();
+        if (m > 0) __syncthreads();
+        if (p == 1) PRE_STAMP(13);
     }
+    post(nbk - 1, tid, nthreads);                        // the last column (everyone)
+    __syncthreads();
 }
+struct NoPost { __device__ void operator()(int, int, int) const {} };
 
 // X = L^-1 in place: off-diagonal blocks of blk become blocks of X, diagonal blocks of X live in dinv.
 __device__ __forceinline__ void invert_blocks(double* blk, double* dinv, double* tbuf, const double* rinv, int nbk,
@@ -249,6 +291,7 @@ __device__ void role_factor(const PreLayer& L, int stop_after, unsigned long lon
     float* zs = reinterpret_cast<float*>(sm + Mp + (IN_LDS ? w.total : 0));
     float* zn = zs + (size_t)Mp * ZLD;          // |zs_m - zc|^2
     float* zcs = zn + Mp;                       // centre of the scaled inducing inputs
+    double* znd = reinterpret_cast<double*>(zcs + 32);   // the same squared norms in float64 (Gram)
 
     // scaled inducing inputs, float32-rounded (the values the K_uf Gram also sees)
     for (int idx = tid; idx < Mp * 32; idx += nthreads) {
@@ -269,50 +312,66 @@ __device__ void role_factor(const PreLayer& L, int stop_after, unsigned long lon
         L.cst[32 + tid] = c;
     }
     __syncthreads();
-    PRE_STAMP(1);
-    if (stop_after == 1) return;
-    // Gram of the float32-rounded scaled inducing inputs, lower blocks only
-    for (int idx = tid; idx < nbk * nbk * 256; idx += nthreads) {
-        const int b = idx >> 8, e = idx & 255;
-        const int bi = b / nbk, bj = b - bi * nbk;
-        if (bj > bi) continue;
-        const int i = NB * bi + (e >> 4), j = NB * bj + (e & 15);
-        double v;
-        if (i >= M || j >= M) v = (i == j) ? 1.0 : 0.0;              // identity padding
-        else {
-            double r2 = 0.0;
-            for (int d = 0; d < D; ++d) {
-                const double df = (double)zs[i * ZLD + d] - (double)zs[j * ZLD + d];
-                r2 = fma(df, df, r2);
-            }
-            v = kern_value(r2, L.kern_type, (double)L.variance);
-            if (i == j) v += L.jitter;
-        }
-        blk[boff(bi, bj) + (e >> 4) * BLD + (e & 15)] = v;
-    }
-    __syncthreads();
-    // K_uf operand Z~ (MFMA A fragments): RBF  z~ = [c zs, c, -c|zs|^2/2 + log2 var] with x~ = [xs, -|xs|^2/2, 1],
-    // c = log2 e, so that k = exp2(x~ . z~);  Matern52  z~ = [-2 zs, 1, |zs|^2] with x~ = [xs, |xs|^2, 1] -> r^2
-    for (int m = tid; m < Mp; m += nthreads) {
-        double n2 = 0.0;
+    for (int m = tid; m < Mp; m += nthreads) {                       // centred (and re-rounded) from here on: the
+        double n2 = 0.0;                                             // values K_uu and K_uf both see
         for (int d = 0; d < D; ++d) {
             const float c = zs[m * ZLD + d] - zcs[d];
-            zs[m * ZLD + d] = c;                                     // centred from here on
+            zs[m * ZLD + d] = c;
             n2 = fma((double)c, (double)c, n2);
         }
+        znd[m] = n2;
         zn[m] = (float)n2;
     }
     __syncthreads();
+    PRE_STAMP(1);
+    if (stop_after == 1) return;
+    // Gram in float64, lower blocks only, one wave per 16x16 block: z_i . z_j by v_mfma_f64_16x16x4_f64 (the inner
+    // dimension is D <= 32), then r^2 = |z_i|^2 + |z_j|^2 - 2 z_i.z_j and the kernel value: ~35 fp64 instructions
+    // per element instead of ~100 -- on one CU this loop is the critical path of every step
+    {
+        const int lane = tid & 63, wave = tid >> 6, nw = nthreads >> 6;
+        const int r = lane & 15, g = lane >> 4, nk4 = (D + 3) >> 2;
+        const int nlow = nbk * (nbk + 1) / 2;
+        for (int o = wave; o < nlow; o += nw) {
+            int bi = (int)((sqrtf(8.f * o + 1.f) - 1.f) * 0.5f);
+            while ((bi + 1) * (bi + 2) / 2 <= o) ++bi;
+            while (bi * (bi + 1) / 2 > o) --bi;
+            const int bj = o - bi * (bi + 1) / 2;
+            f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+            for (int kk = 0; kk < nk4; ++kk) {
+                const double a = (double)zs[(NB * bi + r) * ZLD + 4 * kk + g];
+                const double b = (double)zs[(NB * bj + r) * ZLD + 4 * kk + g];
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+            }
+            const int j = NB * bj + r;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int i = NB * bi + g + 4 * e;                   // f64 C/D map: row = (lane >> 4) + 4 * reg
+                double v;
+                if (i >= M || j >= M) v = (i == j) ? 1.0 : 0.0;      // identity padding
+                else {
+                    const double r2 = fmax(znd[i] + znd[j] - 2.0 * acc[e], 0.0);
+                    v = kern_value(r2, L.kern_type, (double)L.variance);
+                    if (i == j) v += L.jitter;
+                }
+                blk[boff(bi, bj) + (g + 4 * e) * BLD + r] = v;
+            }
+        }
+    }
+    __syncthreads();
+    PRE_STAMP(8);
     if (tid < 64) {                                                  // extent of the inducing cloud in lengthscale units:
         float mx = 0.f;                                              // the layer kernel picks its Gram form by it
         for (int m = tid; m < M; m += 64) mx = fmaxf(mx, zn[m]);
         for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
         if (tid == 0) L.cst[64] = mx;
     }
+    PRE_STAMP(9);
     {
         const int nsteps = round_up(D + 2, 4) / 4;
         const bool rbf = L.kern_type == IWVI_KERN_RBF;
         const double c = 1.4426950408889634;
+        const double l2v = log2((double)L.variance);
         for (int idx = tid; idx < nbk * nsteps * 64; idx += nthreads) {
             const int lane = idx & 63, s = (idx >> 6) % nsteps, bi = (idx >> 6) / nsteps;
             const int m = 16 * bi + (lane & 15), f = 4 * s + (lane >> 4);
@@ -320,7 +379,7 @@ __device__ void role_factor(const PreLayer& L, int stop_after, unsigned long lon
             if (m < M) {
                 if (f < D) v = rbf ? (float)(c * (double)zs[m * ZLD + f]) : -2.f * zs[m * ZLD + f];
                 else if (f == D) v = rbf ? (float)c : 1.f;
-                else if (f == D + 1) v = rbf ? (float)(-0.5 * c * (double)zn[m] + log2((double)L.variance)) : zn[m];
+                else if (f == D + 1) v = rbf ? (float)(-0.5 * c * znd[m] + l2v) : zn[m];
             } else if (f == D + 1 && rbf) v = -1.0e30f;              // padding rows: k = exp2(-huge) = 0
             L.ZtP[idx] = v;
         }
@@ -328,35 +387,37 @@ __device__ void role_factor(const PreLayer& L, int stop_after, unsigned long lon
     __syncthreads();
     PRE_STAMP(2);
     if (stop_after == 2) return;
-    chol_blocks(blk, nbk, rinv, tid, nthreads, stop_after);
+    // post-processing of a finished block column bj, run by the waves that do not factor: the packed float32 solve
+    // stream of the column (its first block is the inverse of the diagonal block, from the factoring wave), column-block major: [L(bj,bj)^-1, -L(bj+1,bj), .., -L(nbk-1,bj)]; identity padding -> 0
+    auto post = [&](int bj, int t, int nt) {
+        const int w = t >> 6, ln = t & 63;
+        float* dst = L.LsP + (size_t)tri_upper_off(nbk, bj) * BLK16;
+        if (w == 0) {
+            for (int e1 = ln; e1 < BLK16; e1 += 64) {            // L(bj,bj)^-1 = transpose of the factoring wave's L^-T
+                const int lane = e1 >> 2, sgm = e1 & 3;
+                const int ii = lane & 15, kk = 4 * (lane >> 4) + sgm;
+                const int i = 16 * bj + ii, k = 16 * bj + kk;
+                float v = 0.f;
+                if (i < M && k < M) { if (kk <= ii) v = (float)dinv[(size_t)bj * BLK + kk * BLD + ii]; }
+                else if (i == k) v = 1.f;                        // padded rows solve to 0 against k = 0 anyway
+                dst[e1] = v;
+            }
+        } else {
+            const int nblk = nbk - 1 - bj;
+            for (int idx = t - 64; idx < nblk * BLK16; idx += nt - 64) {
+                const int b = idx >> 8, e1 = idx & 255;
+                const int bi = bj + 1 + b;
+                const int lane = e1 >> 2, sgm = e1 & 3;
+                const int ii = lane & 15, kk = 4 * (lane >> 4) + sgm;
+                const int i = 16 * bi + ii, k = 16 * bj + kk;
+                dst[(size_t)(1 + b) * BLK16 + e1] = (i < M && k < M) ? -(float)blk[boff(bi, bj) + ii * BLD + kk] : 0.f;
+            }
+        }
+    };
+    chol_blocks(blk, nbk, rinv, dinv, tid, nthreads, stop_after, post, stamps);
     PRE_STAMP(3);
     if (stop_after == 3 || stop_after > 30) return;
-    // inverses of the diagonal 16x16 blocks (one wave each) -- all the forward substitution of the layer
-    // kernel needs; the full triangular inverse is only formed for the dense debug outputs
-    {
-        const int lane = tid & 63, wave = tid >> 6, nw = nthreads >> 6;
-        for (int b = wave; b < nbk; b += nw) diag_inverse(blk + boff(b, b), rinv + NB * b, dinv + (size_t)b * BLK, lane);
-    }
-    __syncthreads();
     PRE_STAMP(4);
-    // packed float32 solve stream, column-block major: column bj = [L(bj,bj)^-1, -L(bj+1,bj), .., -L(nbk-1,bj)]
-    // (the order a right-looking forward substitution consumes it); identity padding -> 0
-    const int ntri = tri_blocks(nbk);
-    for (int idx = tid; idx < ntri * BLK16; idx += nthreads) {
-        const int b = idx >> 8, e1 = idx & 255;
-        int bj = 0;
-        while (bj + 1 < nbk && tri_upper_off(nbk, bj + 1) <= b) ++bj;
-        const int bi = bj + (b - tri_upper_off(nbk, bj));
-        const int lane = e1 >> 2, s = e1 & 3;
-        const int ii = lane & 15, kk = 4 * (lane >> 4) + s;
-        const int i = 16 * bi + ii, k = 16 * bj + kk;
-        float v = 0.f;
-        if (i < M && k < M) {
-            if (bi > bj) v = -(float)blk[boff(bi, bj) + ii * BLD + kk];
-            else if (kk <= ii) v = (float)dinv[(size_t)bi * BLK + ii * BLD + kk];
-        } else if (bi == bj && i == k) v = 1.f;            // padded rows solve to 0 against k = 0 anyway
-        L.LsP[idx] = v;
-    }
     PRE_STAMP(5);
     if (L.flags & IWVI_GP_WANT_DENSE) {
         for (int idx = tid; idx < Mp * Mp; idx += nthreads) {
@@ -496,7 +557,7 @@ __global__ __launch_bounds__(1024) void k_chol_only(const double* A, double* Lou
         blk[boff(bi, bj) + (e >> 4) * BLD + (e & 15)] = (i < M && j < M) ? A[(size_t)i * M + j] : ((i == j) ? 1.0 : 0.0);
     }
     __syncthreads();
-    chol_blocks(blk, nbk, rinv, tid, nthreads);
+    chol_blocks(blk, nbk, rinv, ws + (size_t)(nbk * (nbk + 1) / 2) * BLK, tid, nthreads, 0, NoPost());
     for (int idx = tid; idx < M * M; idx += nthreads) {
         const int i = idx / M, k = idx - i * M;
         Lout[idx] = (k <= i) ? blk_get(blk, i, k) : 0.0;
@@ -524,7 +585,7 @@ static int ensure_lds_attr(const void* fn, size_t bytes) {
 static size_t factor_lds_bytes(int Mp) {
     size_t d = (size_t)Mp;                                   // rinv
     if (Mp <= 128) d += ws_layout(Mp).total;                 // blocks + dinv + tbuf resident in LDS
-    return d * sizeof(double) + ((size_t)Mp * ZLD + Mp + 32) * sizeof(float);
+    return d * sizeof(double) + ((size_t)Mp * ZLD + Mp + 32) * sizeof(float) + (size_t)Mp * sizeof(double) + 8;
 }
 
 }  // namespace iwvi

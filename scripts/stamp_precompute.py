@@ -29,3 +29,6 @@ d = np.diff(r, axis=1) * 10e-3
 for n, col in zip(names, d.T):
     print("%-10s med %6.2f us" % (n, np.median(col)))
 print("total      med %6.2f us" % np.median((r[:, 6] - r[:, 0]) * 10e-3))
+r2 = np.stack(rows)[:, 0, :].astype(np.float64)
+for a, b, n in ((1, 8, "gram (mfma)"), (8, 9, "zmax"), (9, 2, "ZtP"), (10, 11, "p=1 factor(w0)"), (11, 12, "p=1 wait others (post)"), (12, 13, "p=1 panel+trailing")):
+    print("%-24s med %6.2f us" % (n, np.median((r2[:, b] - r2[:, a]) * 10e-3)))

@@ -48,8 +48,11 @@ def test_precompute_factorisation(gpu_device, M, D, R, kern):
     precompute_states([st.desc(_t(Z, gpu_device), k, _t(q_mu, gpu_device), _t(q_sqrt, gpu_device),
                                settings.jitter_level)])
     torch.cuda.synchronize()
-    # the device factorises the Gram of the float32-rounded scaled inputs (DESIGN.md "Precision")
-    Zs = (Z.astype(np.float64) / ls.astype(np.float64)).astype(np.float32).astype(np.float64)
+    # the device factorises the Gram of the float32-rounded, centred scaled inputs -- the values K_uf also
+    # sees (DESIGN.md "Precision"): Zs = fl32(Z / ls), zc = fl32(mean_m Zs), Zs <- fl32(Zs - zc)
+    Zs32 = (Z.astype(np.float64) / ls.astype(np.float64)).astype(np.float32)
+    zc = Zs32.astype(np.float64).mean(0).astype(np.float32)
+    Zs = (Zs32 - zc).astype(np.float32).astype(np.float64)
     ok = ocls(D, variance=float(np.float32(1.3)), lengthscales=1.0)   # the ABI takes a float32 variance
     Kuu = ok.K(Zs) + 1e-6 * np.eye(M)
     # cond(Kuu) reaches 1e6..1e8 here, so two float64 factorisations agree entry-wise only to
