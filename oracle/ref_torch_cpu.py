@@ -57,7 +57,10 @@ class CpuDGP:
         else:
             fvar = (L["var"] - (A * A).sum(-2))[:, None].repeat(1, R, 1)                           # :59-60
         fmean = A.transpose(1, 2) @ L["q_mu"][None].repeat(S, 1, 1)                                # :68
-        LTA = torch.einsum('rMm,sMn->srmn', L["q_sqrt"], A)                                        # :78
+        # :78 einsum('rMm,sMn->srmn') evaluated the way TF evaluates it: one GEMM [R*m, M] x [M, S*N] on the
+        # un-transposed solve result, then the reshape/transposes -- the [S,R,M,N] intermediate is materialised
+        LTA = (L["q_sqrt"].transpose(1, 2).reshape(R * M, M) @ A.permute(1, 0, 2).reshape(M, S * N))
+        LTA = LTA.reshape(R, M, S, N).permute(2, 0, 1, 3)
         if full_cov:
             fvar = fvar + LTA.transpose(2, 3) @ LTA                                                # :83
             return fmean, fmean, fvar
