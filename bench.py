@@ -19,7 +19,6 @@ Multi-GPU (weak scaling, per-GPU work fixed):
 import os
 os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")   # kernel arguments in device memory (read before HIP initialises)
 import argparse
-import ctypes
 import json
 import os
 import sys
@@ -154,9 +153,10 @@ def main():
     model = synthetic.build_model(spec, dev)
     step = Step(model, spec, dev, args.shard, world)
     B, K = cfg["B"], cfg["K"]
-    comm = torch.cuda.Stream(device=dev) if world > 1 else None
-    gathered = torch.empty(world, B, 2, dtype=torch.float32, device=dev) if world > 1 else None
-    elbo_acc = torch.zeros(1, dtype=torch.float64, device=dev)
+    xch = None
+    if world > 1:
+        from dgps_with_iwvi_amd.sharding import OverlappedExchange
+        xch = OverlappedExchange(args.shard, world, B, K * world, float(spec["n_data"]) / B, dev)
 
     # ---- capture -----------------------------------------------------------------------------
     graph = None
@@ -173,36 +173,20 @@ def main():
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
 
-    def exchange():
-        """Per-step collective, on a side stream so that it overlaps the next step's kernels."""
-        if world == 1:
-            return
-        ev = torch.cuda.Event()
-        ev.record()
-        with torch.cuda.stream(comm):
-            comm.wait_event(ev)
-            if args.shard == "k":
-                dist.all_gather_into_tensor(gathered.view(-1), step.ms.view(-1))
-                glob = [g.reshape(-1) for g in step.glob]
-                glob_n = (ctypes.c_int32 * len(glob))(*[g.numel() for g in glob])
-                logp = torch.empty(B, dtype=torch.float32, device=dev)
-                _abi.check(_abi.lib().iwvi_lse_merge(_abi.ptr(gathered), world, B, K * world, _abi.ptr_array(glob),
-                                                     glob_n, len(glob), float(spec["n_data"]) / B, _abi.ptr(logp),
-                                                     _abi.ptr(elbo_acc), _abi.stream_ptr()))
-            else:
-                elbo_acc.copy_(step.out.reshape(1))
-                dist.all_reduce(elbo_acc)
-
     def one_step():
         if graph is not None:
             graph.replay()
         else:
             step.run()
-        exchange()
+        if xch is not None:          # per-step collective on a side stream: overlaps the next step's kernels
+            if args.shard == "k":
+                xch.submit(step.ms, step.glob)
+            else:
+                xch.submit(step.out)
 
     def fence():
-        if comm is not None:
-            torch.cuda.current_stream().wait_stream(comm)
+        if xch is not None:
+            xch.finish()
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
@@ -220,7 +204,7 @@ def main():
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
-    final_elbo = float((elbo_acc if world > 1 else step.out.reshape(1)).item())
+    final_elbo = float((xch.result if xch is not None else step.out.reshape(1)).item())
 
     # ---- dominant kernel: the fused forward (all layers), HIP events around a graph of back-to-back launches
     tot_flops, _ = f_alg_model(spec)

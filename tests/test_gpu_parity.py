@@ -377,3 +377,23 @@ def test_golden_fixture(gpu_device, path):
         np.testing.assert_allclose(_np(samples[i]), out["sample%d" % i], rtol=2e-3, atol=2e-3)
     np.testing.assert_allclose(_np(fmean), out["mean%d" % (n - 1)], rtol=2e-3, atol=2e-3)
     np.testing.assert_allclose(_np(fvar), out["var%d" % (n - 1)], rtol=5e-3, atol=2e-4)
+
+
+def test_k_shard_merge_on_one_gpu(gpu_device):
+    """K-sharding: two 'ranks' with 4 + 3 importance samples on this one GPU; the
+    gathered (max, sumexp) pairs merged by iwvi_lse_merge give the unsharded IW-ELBO and the torch merge."""
+    from dgps_with_iwvi_amd import sharding, synthetic
+    spec = synthetic.make_spec(L=2, M=32, B=40, K=7, with_lv=True, seed=31, n_data=512)
+    zs = synthetic.make_noise(spec, seed=32)
+    full = synthetic.build_model(spec, gpu_device)
+    ref = full.compute_log_likelihood([_t(z, gpu_device) for z in zs])
+    parts, k0 = [], 0
+    for Kr in sharding.split_samples(7, 2):
+        m = synthetic.build_model(spec, gpu_device, num_samples=Kr)
+        ms, glob = m.lse_partials([_t(z[:, k0:k0 + Kr], gpu_device) for z in zs], K_total=7)
+        parts.append(ms)
+        k0 += Kr
+    gathered = torch.stack(parts)
+    logp, elbo = sharding.merge_lse(gathered, 7, glob, spec["n_data"] / 40)
+    assert abs(float(elbo.item()) - ref) <= 1e-6 * abs(ref), (float(elbo.item()), ref)
+    np.testing.assert_allclose(_np(logp), _np(sharding.merge_lse_reference(gathered.double(), 7)), rtol=1e-5, atol=1e-4)

@@ -1,0 +1,88 @@
+"""Multi-process (world_size 2, gloo, CPU) tests of the sharding host logic (dgps_with_iwvi_amd/sharding.py).
+
+No HIP kernel runs here: each rank's partial results come from the fp64 oracle (test infrastructure) and are
+pushed through the same collectives, layouts and merge formulae the GPU ranks use; the merged ELBO must equal
+the unsharded oracle's.  Covers K-shard with an uneven split (K = 7 over 2 ranks) and N-shard."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from dgps_with_iwvi_amd import sharding, synthetic
+from oracle.from_spec import build_oracle, oracle_noise
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, mode, q):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        K_total, B = 7, 12
+        spec = synthetic.make_spec(L=2, M=16, B=B * (world if mode == "n" else 1), K=K_total, Dx=3, R=2, with_lv=True,
+                                   seed=21, n_data=4096)
+        zs = synthetic.make_noise(spec, seed=22)                     # [B, K, .] for the WHOLE job
+        full = build_oracle(spec)
+        ref = full.build_likelihood(oracle_noise(spec, zs))
+        if mode == "k":
+            Ks = sharding.split_samples(K_total, world)
+            k0 = sum(Ks[:rank])
+            sl = slice(k0, k0 + Ks[rank])
+            m = build_oracle(spec, num_samples=Ks[rank])
+            L_NK, global_kls, _, _, _ = m.log_weights(oracle_noise(spec, [z[:, sl] for z in zs]))
+            mx = L_NK.max(1)
+            ms = torch.tensor(np.stack([mx, np.exp(L_NK - mx[:, None]).sum(1)], 1))       # [B, 2] exchange unit
+            got = sharding.k_shard_elbo(ms, float(np.sum(global_kls)), K_total, spec["n_data"] / B)
+        else:
+            lo, hi = sharding.split_points(spec["B"], world)[rank]
+            sub = dict(spec, X=spec["X"][lo:hi], Y=spec["Y"][lo:hi], B=hi - lo)
+            m = build_oracle(sub)
+            local = m.build_likelihood(oracle_noise(sub, [z[lo:hi] for z in zs]))       # scaled by n_data / B_local
+            got = sharding.n_shard_elbo(torch.tensor(local, dtype=torch.float64))
+        q.put((rank, float(got), float(ref)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["k", "n"])
+def test_sharded_elbo_equals_unsharded(mode):
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, mode, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, got, ref in res:
+        assert abs(got - ref) <= 1e-9 * abs(ref), (mode, rank, got, ref)
+    assert res[0][1] == res[1][1]                                    # every rank holds the same answer
+
+
+def test_split_helpers():
+    assert sharding.split_samples(20, 8) == [3, 3, 3, 3, 2, 2, 2, 2]
+    assert sum(sharding.split_samples(100, 8)) == 100 and sharding.split_samples(50, 8)[:2] == [7, 7]
+    with pytest.raises(ValueError):
+        sharding.split_samples(3, 8)
+    r = sharding.split_points(1030, 8)
+    assert r[0] == (0, 129) and r[-1][1] == 1030 and all(b - a in (128, 129) for a, b in r)
+
+
+def test_merge_reference_matches_logsumexp():
+    rng = np.random.default_rng(0)
+    L = rng.standard_normal((6, 11)) * 5
+    parts = [L[:, :4], L[:, 4:9], L[:, 9:]]
+    ms = torch.tensor(np.stack([np.stack([p.max(1), np.exp(p - p.max(1, keepdims=True)).sum(1)], 1) for p in parts]))
+    got = sharding.merge_lse_reference(ms, 11).numpy()
+    ref = np.log(np.exp(L).sum(1)) - np.log(11)
+    np.testing.assert_allclose(got, ref, rtol=1e-12)
