@@ -1,0 +1,45 @@
+"""The C-ABI library loads on a GPU-less host and exports every function include/iwvi_hip.h declares, with the
+ctypes prototypes of dgps_with_iwvi_amd/_abi.py covering all of them (no compute call is made here)."""
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    text = open(os.path.join(ROOT, "include", "iwvi_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(iwvi_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_declares_the_expected_surface():
+    names = _declared()
+    for must in ("iwvi_gp_precompute", "iwvi_dgp_forward", "iwvi_gp_layer_forward", "iwvi_lv_layer_forward",
+                 "iwvi_iw_elbo_reduce", "iwvi_logw_reduce", "iwvi_lse_merge", "iwvi_gauss_kl", "iwvi_version"):
+        assert must in names
+
+
+def test_library_exports_every_declared_symbol():
+    from dgps_with_iwvi_amd import _abi
+    if not os.path.exists(_abi.LIB_PATH):
+        pytest.skip("libiwvi_hip.so not built (run __graft_entry__.build())")
+    lib = _abi.lib()
+    names = _declared()
+    missing = [n for n in names if not hasattr(lib, n)]
+    assert not missing, missing
+    unbound = [n for n in names if n not in _abi.PROTOTYPES]
+    assert not unbound, "no ctypes prototype for %s" % unbound
+    assert lib.iwvi_version() == _abi.ABI_VERSION
+
+
+def test_product_path_has_no_cpu_fallback():
+    """A CPU tensor must be refused loudly (the oracle is test infrastructure, never a fallback)."""
+    import torch
+    from dgps_with_iwvi_amd import _abi
+    with pytest.raises(_abi.IwviError):
+        _abi.dev_tensor(torch.zeros(3), "x")
+    src = "".join(open(os.path.join(ROOT, "dgps_with_iwvi_amd", f)).read()
+                  for f in os.listdir(os.path.join(ROOT, "dgps_with_iwvi_amd")) if f.endswith(".py"))
+    assert "import oracle" not in src and "from oracle" not in src
