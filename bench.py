@@ -237,6 +237,15 @@ def main():
     dom_ms = float(np.median([a.elapsed_time(b) for a, b in evs])) / NREP
     achieved = dom_flops / (dom_ms * 1e-3)
 
+    # HBM bytes per launch of the dominant kernel from the committed PMC profile of this very workload (the counters
+    # need their own rocprofv3 passes and cannot be read live); null for any other workload
+    traffic, traffic_src = None, None
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "traffic_latest.json")))
+        if args.config == 2 and world == 1:
+            traffic, traffic_src = tj["hbm_bytes"], tj["source"]
+    except Exception:
+        pass
     if rank == 0:
         total = float(B) * K * world * args.steps
         res = {
@@ -253,7 +262,7 @@ def main():
             "elbo": final_elbo,
             "roofline": {"bound": "mfma", "kernel": "k_dgp_forward (all layers fused, one launch per ELBO evaluation)", "achieved": achieved / 1e12,
                          "peak": PEAK_MFMA_F32 / 1e12, "unit": "TFLOP/s", "frac": achieved / PEAK_MFMA_F32,
-                         "traffic": None, "launch_ms": dom_ms,
+                         "traffic": traffic, "traffic_source": traffic_src, "launch_ms": dom_ms,
                          "flops_per_launch": dom_flops},
         }
         res["model_frac_of_mfma_peak"] = res["value"] / world * tot_flops / PEAK_MFMA_F32
