@@ -209,7 +209,7 @@ def main():
     # ---- dominant kernel: the fused forward (all layers), HIP events around a graph of back-to-back launches
     tot_flops, _ = f_alg_model(spec)
     dom_flops = tot_flops * B * K
-    model.precompute()
+    model.precompute(with_encoders=True)
     NREP = 20
     fwd = lambda: model._fused_forward(B * K, K, B, (B, K), elbo=dict(B=B, K=K, stride_b=K, stride_k=1, mode_vi=False))
     fwd()

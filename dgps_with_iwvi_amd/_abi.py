@@ -36,6 +36,13 @@ class GpDesc(ctypes.Structure):
                 ("R", ctypes.c_int32), ("kern_type", ctypes.c_int32), ("flags", ctypes.c_int32)]
 
 
+class EncDesc(ctypes.Structure):
+    """struct iwvi_enc_desc (include/iwvi_hip.h): an encoder evaluated inside the precompute launch."""
+    _fields_ = [("XY", c_void_p), ("rows", c_int64), ("enc_W", ctypes.POINTER(c_void_p)),
+                ("enc_b", ctypes.POINTER(c_void_p)), ("dims", ctypes.POINTER(ctypes.c_int32)),
+                ("n_enc", ctypes.c_int32), ("latent_dim", ctypes.c_int32), ("out", c_void_p)]
+
+
 class LayerDesc(ctypes.Structure):
     """struct iwvi_layer_desc (include/iwvi_hip.h): one layer of the fused forward."""
     _fields_ = [("type", ctypes.c_int32), ("state", c_void_p),
@@ -45,6 +52,7 @@ class LayerDesc(ctypes.Structure):
                 ("enc_W", ctypes.POINTER(c_void_p)), ("enc_b", ctypes.POINTER(c_void_p)),
                 ("enc_dims", ctypes.POINTER(ctypes.c_int32)),
                 ("n_enc", ctypes.c_int32), ("latent_dim", ctypes.c_int32), ("sampled_kl", ctypes.c_int32),
+                ("enc_out", c_void_p),
                 ("noise", c_void_p), ("zero_noise", ctypes.c_int32), ("noise_out", c_void_p),
                 ("sample", c_void_p), ("mean", c_void_p), ("var", c_void_p), ("kl_local", c_void_p),
                 ("a_out", c_void_p), ("u_out", c_void_p)]
@@ -66,6 +74,7 @@ PROTOTYPES = {
     "iwvi_gp_state_bytes": (c_size_t, [c_int, c_int]),
     "iwvi_gp_state_offsets": (c_int, [c_int, c_int, ctypes.POINTER(c_size_t)]),
     "iwvi_gp_precompute": (c_int, [ctypes.POINTER(GpDesc), c_int, c_void_p]),
+    "iwvi_model_precompute": (c_int, [ctypes.POINTER(GpDesc), c_int, ctypes.POINTER(EncDesc), c_int, c_void_p]),
     "iwvi_rbf_gram_sym": (c_int, [c_void_p, c_void_p, c_float, c_double, c_int, c_int, c_int,
                                   c_void_p, c_void_p]),
     "iwvi_chol_ws_bytes": (c_size_t, [c_int]),

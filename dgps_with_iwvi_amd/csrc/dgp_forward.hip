@@ -42,7 +42,7 @@ typedef __attribute__((address_space(1))) f32x4* gout4;
 static unsigned long long* g_stamp_buf = nullptr;   // diagnostic; see iwvi_debug_set_stamps
 static long long g_stamp_wgs = 0;
 
-constexpr int XSTR = 37;              // row stride (floats) of the activation tiles: D, P <= 32, D + 2 <= 36
+constexpr int XSTR_MAX = 37;          // largest row stride (floats) of the activation tiles: D, P <= 32, D + 2 <= 36
 constexpr int FW_MAXNS = 5;
 
 constexpr int FW_THREADS = 512;
@@ -64,6 +64,7 @@ struct FwGp {
 };
 struct FwLv {
     const float* W[IWVI_MAX_ENC]; const float* b[IWVI_MAX_ENC];
+    const float* enc_out;             // precomputed encoder output [data rows, 2*Lw] (iwvi_model_precompute), or NULL
     float* kl_local;
     int dims[IWVI_MAX_ENC + 1];
     int n_enc, Lw, sampled_kl, wtotal, maxdim;
@@ -101,6 +102,7 @@ struct FwHead {
     unsigned long long* stamps;      // diagnostic only (iwvi_debug_set_stamps): 128 words per workgroup
     int dbg;                         // diagnostic only (IWVI_DEBUG_ABLATE): timing ablations, results are wrong
     int ncopy;
+    int xstr;                        // row stride of the activation tiles: odd, >= max(D + 2 padded to 4, P) of the stack
     FwLds lds;
     FwElbo e;
 };
@@ -268,6 +270,7 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int gq = lane >> 4, jq = lane & 15;
     const FwHead& g = gk.h;                                       // scalar path (first kernarg lines)
+    const int XSTR = g.xstr;
     const long long t0 = (long long)blockIdx.x * NSAMP;
     const int nvalid = (int)((g.T - t0) < (long long)NSAMP ? (g.T - t0) : (long long)NSAMP);
 
@@ -339,6 +342,19 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
     }
     __syncthreads();                                              // layer table (and rowi / pidx) visible
     FW_STAMP(56);
+    // precomputed encoder outputs of the chunk's distinct data points -> the LV layer's constant block
+    for (int li = 0; li < g.n_layers; ++li) {
+        if (ufirst(LT[li].type) != IWVI_LAYER_LV) continue;
+        const float* eo = ufirst(LT[li].lv.enc_out);
+        if (!eo) continue;
+        const int no = 2 * ufirst(LT[li].lv.Lw);
+        float* dst = sm + ufirst(LT[li].c_off);
+        for (int idx = tid; idx < npts * no; idx += FW_THREADS) {
+            const int p = idx / no, o = idx - p * no;
+            const unsigned row = (p_first + p) % g.row_mod;
+            dst[idx] = ((gptr1)eo)[(size_t)row * no + o];
+        }
+    }
     // copy list: one entry per wave at a time, all DMA loads in flight together
     for (int ci = wave; ci < g.ncopy; ci += FW_WAVES) {
         const float* src = ufirst(CT[ci].src);
@@ -412,7 +428,9 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
             float* act1 = act0 + NSAMP * mdim;
             const float* in = xyrows; int in_str = up4(g.XYdim);
             float* out = act0;
-            {
+            const bool pre_enc = ufirst(V.enc_out) != nullptr;    // encoder already evaluated by iwvi_model_precompute
+            if (pre_enc) { in = cst; in_str = 2 * Lw; }
+            else {
                 int off = 0;
                 for (int l = 0; l < n_enc; ++l) {                                    // encoder, once per data point
                     const int din = ufirst(V.dims[l]), dout = ufirst(V.dims[l + 1]);
@@ -451,7 +469,7 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
                 float klsum = 0.f;
                 for (int l = 0; l < Lw; ++l) {
                     float mu = 0.f, sg = 1.f;                                        // prior (layers.py:73-81)
-                    if (n_enc > 0) { mu = in[pidx[j] * in_str + l]; sg = softplus_f(in[pidx[j] * in_str + Lw + l] - 3.f); }
+                    if (n_enc > 0 || pre_enc) { mu = in[pidx[j] * in_str + l]; sg = softplus_f(in[pidx[j] * in_str + Lw + l] - 3.f); }
                     const float z = (j < nvalid) ? zl[l * NSAMP + j] : 0.f;
                     const float w = fmaf(z, sg, mu);                                 // layers.py:86-87
                     float kl;
@@ -499,7 +517,8 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
                 xt[tid * XSTR + D + 1] = 1.f;
                 for (int d = D + 2; d < 4 * nsteps; ++d) xt[tid * XSTR + d] = 0.f;
             }
-            if (tid < 4) counters[tid] = 0;
+            if (tid < 12) counters[tid] = 0;                       // job counters + the 8 column flags of the shared solve
+            for (int i = tid; i < 4 * NSAMP; i += FW_THREADS) asq[i] = 0.f;
             // the layer's forward-substitution stream -> LDS while x~ and the Gram run (all NS solving waves read it)
             if (G.ls_off >= 0) async_copy_f32x4(reinterpret_cast<const float*>(G.LsP), sm + G.ls_off, tri_blocks(nbk) * BLK16, tid);
             __syncthreads();
@@ -650,8 +669,9 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
                     }
                 }
                 ssq = xgroup_sum_mfma(ssq);
-                if (gq == 0) asq[tcol] = ssq;
+                if (gq == 0) asq[tcol] = ssq;                         // slot 0; slots 1..3 stay zero
             }
+            if (g.stamps && lane == 0 && li == 1) g.stamps[(size_t)blockIdx.x * 128 + 118 + wave] = clock64();
             __syncthreads();
             FW_STAMP(2 + li * 6 + 2);
 
@@ -781,7 +801,8 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
 #pragma unroll
                 for (int w = 0; w < FW_WAVES; ++w) u2 += usq[(w * R + r) * NSAMP + j];   // fixed order: bit-reproducible
                 const float mu = meanp[r * NSAMP + j];
-                const float v = fmaxf(G.variance - asq[j] + u2, 0.f);
+                const float a2 = ((asq[j] + asq[NSAMP + j]) + asq[2 * NSAMP + j]) + asq[3 * NSAMP + j];   // fixed order
+                const float v = fmaxf(G.variance - a2 + u2, 0.f);
                 const float z = (j < nvalid) ? zl[r * NSAMP + j] : 0.f;
                 if (o_noise && j < nvalid) o_noise[(t0 + j) * R + r] = z;
                 gbuf[(0 * R + r) * NSAMP + j] = mu;
@@ -988,13 +1009,13 @@ static size_t fw_plan_lds(FwArgs& a, int nsamp, int maxR, int maxP, bool stage_z
     int scratch = 0, zdims = 0, o = 0, ls_max = 0;
     FwLds& l = a.h.lds;
     l.ltab = o; o += up4((int)((sizeof(FwArgs) - offsetof(FwArgs, L)) / 4));
-    l.xa = o; o += up4(nsamp * XSTR);
-    l.xb = o; o += up4(nsamp * XSTR);
-    l.xt = o; o += up4(nsamp * XSTR);
+    l.xa = o; o += up4(nsamp * a.h.xstr);
+    l.xb = o; o += up4(nsamp * a.h.xstr);
+    l.xt = o; o += up4(nsamp * a.h.xstr);
     l.lw = o; o += nsamp;
     l.rowi = o; o += nsamp;
     l.pidx = o; o += nsamp;
-    l.asq = o; o += nsamp;
+    l.asq = o; o += 4 * nsamp;
     l.meanp = o; o += maxR * nsamp;
     l.gbuf = o; o += 3 * maxR * nsamp;
     l.obuf = o; o += 2 * maxP * nsamp;
@@ -1013,7 +1034,7 @@ static size_t fw_plan_lds(FwArgs& a, int nsamp, int maxR, int maxP, bool stage_z
             const int need = gp_scratch_floats(G.Mp, G.nbk, G.R, nsamp);
             if (need > scratch) scratch = need;
         } else {
-            o += up4(L.lv.wtotal);
+            o += up4(L.lv.enc_out ? nsamp * 2 * L.lv.Lw : L.lv.wtotal);
             zdims += L.lv.Lw;
             const int need = lv_scratch_floats(L.lv.maxdim, nsamp);
             if (need > scratch) scratch = need;
@@ -1067,7 +1088,7 @@ static size_t fw_plan_lds(FwArgs& a, int nsamp, int maxR, int maxP, bool stage_z
             }
         }
     }
-    l.cnt = o; o += 4;
+    l.cnt = o; o += 12;
     l.scratch = o; o += up4(scratch);
     l.total = o;
     return (size_t)o * sizeof(float);
@@ -1123,8 +1144,8 @@ int dgp_forward_impl(const iwvi_layer_desc* layers, int n_layers, const float* X
             FwLv& V = L.lv;
             if (d.latent_dim <= 0 || D + d.latent_dim > IWVI_MAX_D) { set_error("iwvi_lv_layer_forward: bad D=%d (1..32) or latent_dim=%d", D, d.latent_dim); return IWVI_ERR_ARG; }
             V.Lw = d.latent_dim; V.sampled_kl = d.sampled_kl; V.kl_local = d.kl_local;
-            V.n_enc = 0; V.wtotal = 0; V.maxdim = 2 * d.latent_dim;
-            if (d.enc_W) {
+            V.n_enc = 0; V.wtotal = 0; V.maxdim = 2 * d.latent_dim; V.enc_out = d.enc_out;
+            if (d.enc_W && !d.enc_out) {
                 if (!XY || XYdim <= 0) { set_error("iwvi_dgp_forward: layer %d has an encoder but there are no encoder inputs", i); return IWVI_ERR_ARG; }
                 if (!d.enc_dims || d.n_enc <= 0 || d.n_enc > IWVI_MAX_ENC) { set_error("iwvi_lv_layer_forward: encoder with %d layers (1..%d supported)", d.n_enc, IWVI_MAX_ENC); return IWVI_ERR_ARG; }
                 if (d.enc_dims[0] != XYdim) { set_error("iwvi_lv_layer_forward: encoder expects %d inputs, XY has %d", d.enc_dims[0], XYdim); return IWVI_ERR_ARG; }
@@ -1166,6 +1187,16 @@ int dgp_forward_impl(const iwvi_layer_desc* layers, int n_layers, const float* X
             if (E.klg_n[i] <= 0 || E.klg_n[i] > IWVI_MAX_R) { set_error("iwvi_dgp_forward: bad global KL count %d", E.klg_n[i]); return IWVI_ERR_ARG; }
         }
         E.ms = elbo->out_lse_ms; E.logp = elbo->out_logp; E.elbo = elbo->out_elbo; E.ws = elbo->ws;
+    }
+    {   // activation row stride: room for the widest layer input + 2 (x~), padded to a multiple of 4, and the widest output; odd
+        int wmax = Dx + 2, dcur = Dx;
+        for (int i = 0; i < n_layers; ++i) {
+            const FwLayer& L = a.L[i];
+            dcur = (L.type == IWVI_LAYER_GP) ? L.gp.P : dcur + L.lv.Lw;
+            if (dcur + 2 > wmax) wmax = dcur + 2;
+        }
+        a.h.xstr = round_up(wmax, 4) + 1;
+        if (a.h.xstr > XSTR_MAX) a.h.xstr = XSTR_MAX;
     }
     // chunk size: 16*NS samples per workgroup, NS no larger than what gives every CU a workgroup, then the
     // largest that fits the LDS (with Z~ staged if that fits too)

@@ -33,7 +33,14 @@ struct PreLayer {
     double jitter; float variance;
     int M, D, R, Mp, nbk, nrb, kern_type, flags;
 };
-struct PreArgs { PreLayer L[IWVI_MAX_LAYERS]; int n; int stop_after; unsigned long long* stamps; };
+// an Encoder MLP (layers.py:137-152) evaluated for every row of the minibatch in the same launch: it does not
+// depend on the factorisation, so it rides on otherwise idle CUs instead of the critical path of the layer kernel
+struct PreEnc {
+    const float* XY; float* out; const float* W[IWVI_MAX_ENC]; const float* b[IWVI_MAX_ENC];
+    long long rows; int dims[IWVI_MAX_ENC + 1]; int n_enc, Lw, blk0, nblk;
+};
+constexpr int PRE_MAX_ENC = 2;
+struct PreArgs { PreLayer L[IWVI_MAX_LAYERS]; int n; int stop_after; unsigned long long* stamps; PreEnc E[PRE_MAX_ENC]; int n_enc; };
 
 static unsigned long long* g_pre_stamps = nullptr;   // diagnostic; see iwvi_debug_set_pre_stamps
 #define PRE_STAMP(k) do { if (stamps && threadIdx.x == 0) stamps[(size_t)blockIdx.x * 16 + (k)] = wall_clock64(); } while (0)
@@ -510,7 +517,63 @@ __device__ void role_kl_only(const float* q_mu, const float* q_sqrt, int M, int 
     if (threadIdx.x == 0) *kl = 0.5 * (tot - (double)M * R);
 }
 
+// rows [ENC_ROWS * blk, ENC_ROWS * (blk + 1)) of one encoder: weights and both activation buffers in LDS, one
+// (row, output unit) item per thread-iteration, one barrier per MLP layer
+constexpr int ENC_ROWS = 256;
+__device__ void role_encoder(const PreEnc& E, int blk) {
+    float* wts = reinterpret_cast<float*>(smem_raw);
+    int wtotal = 0, mdim = 2 * E.Lw;
+    for (int l = 0; l < E.n_enc; ++l) {
+        const int nW = E.dims[l] * E.dims[l + 1], nb = E.dims[l + 1];
+        for (int i = threadIdx.x; i < nW; i += blockDim.x) wts[wtotal + i] = E.W[l][i];
+        for (int i = threadIdx.x; i < nb; i += blockDim.x) wts[wtotal + nW + i] = E.b[l] ? E.b[l][i] : 0.f;
+        wtotal += nW + nb;
+        if (E.dims[l] > mdim) mdim = E.dims[l];
+        if (E.dims[l + 1] > mdim) mdim = E.dims[l + 1];
+    }
+    mdim |= 1;                                             // odd row stride: conflict-free column walks
+    float* act0 = wts + ((wtotal + 3) & ~3);
+    float* act1 = act0 + ENC_ROWS * mdim;
+    const long long row0 = (long long)blk * ENC_ROWS;
+    const int nrows = (int)((E.rows - row0) < ENC_ROWS ? (E.rows - row0) : ENC_ROWS);
+    const int d0 = E.dims[0];
+    for (int idx = threadIdx.x; idx < nrows * d0; idx += blockDim.x) {
+        const int r = idx / d0, i = idx - r * d0;
+        act0[r * mdim + i] = E.XY[(row0 + r) * d0 + i];
+    }
+    __syncthreads();
+    float* in = act0; float* out = act1;
+    int off = 0;
+    for (int l = 0; l < E.n_enc; ++l) {
+        const int din = E.dims[l], dout = E.dims[l + 1];
+        const float* W = wts + off; const float* b = W + din * dout;
+        for (int idx = threadIdx.x; idx < nrows * dout; idx += blockDim.x) {
+            const int r = idx / dout, o = idx - r * dout;
+            float acc = b[o];
+            for (int i = 0; i < din; ++i) acc = fmaf(in[r * mdim + i], W[i * dout + o], acc);
+            if (l < E.n_enc - 1) acc = tanhf(acc);                         // layers.py:143-144
+            if (din == dout) acc += in[r * mdim + o];                       // layers.py:146-147
+            out[r * mdim + o] = acc;
+        }
+        off += din * dout + dout;
+        __syncthreads();
+        float* t = in; in = out; out = t;
+    }
+    const int no = 2 * E.Lw;                               // [means | raw]; q_sqrt = softplus(raw - 3)
+    for (int idx = threadIdx.x; idx < nrows * no; idx += blockDim.x) {
+        const int r = idx / no, o = idx - r * no;
+        E.out[(row0 + r) * no + o] = in[r * mdim + o];
+    }
+}
+
 __global__ __launch_bounds__(1024) void k_precompute(PreArgs args) {
+    if ((int)blockIdx.x >= args.n) {                       // encoder blocks follow the GP layers in x
+        if (blockIdx.y != 0) return;
+        const int b = blockIdx.x - args.n;
+        for (int e = 0; e < args.n_enc; ++e)
+            if (b >= args.E[e].blk0 && b < args.E[e].blk0 + args.E[e].nblk) role_encoder(args.E[e], b - args.E[e].blk0);
+        return;
+    }
     const PreLayer& L = args.L[blockIdx.x];
     const int role = blockIdx.y;
     if (role == 0) {
@@ -606,8 +669,14 @@ extern "C" int iwvi_gp_state_offsets(int M, int R, size_t out[8]) {
 }
 
 extern "C" int iwvi_gp_precompute(const iwvi_gp_desc* layers, int n_layers, void* stream_) {
+    return iwvi_model_precompute(layers, n_layers, nullptr, 0, stream_);
+}
+
+extern "C" int iwvi_model_precompute(const iwvi_gp_desc* layers, int n_layers, const iwvi_enc_desc* encs, int n_encs,
+                                     void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (!layers || n_layers <= 0) { set_error("iwvi_gp_precompute: no layers"); return IWVI_ERR_ARG; }
+    if (n_encs < 0 || n_encs > PRE_MAX_ENC || (n_encs > 0 && !encs)) { set_error("iwvi_model_precompute: %d encoders (0..%d supported)", n_encs, PRE_MAX_ENC); return IWVI_ERR_ARG; }
     for (int base = 0; base < n_layers; base += IWVI_MAX_LAYERS) {
         PreArgs a{};
         a.n = n_layers - base < IWVI_MAX_LAYERS ? n_layers - base : IWVI_MAX_LAYERS;
@@ -644,9 +713,36 @@ extern "C" int iwvi_gp_precompute(const iwvi_gp_desc* layers, int n_layers, void
             if (la > lds) lds = la;
             if (d.R + 1 > max_roles) max_roles = d.R + 1;
         }
+        int enc_blocks = 0;
+        if (base == 0) {                                   // encoders ride with the first batch of layers
+            for (int e = 0; e < n_encs; ++e) {
+                const iwvi_enc_desc& d = encs[e];
+                if (!d.XY || !d.out || !d.enc_W || !d.dims || d.rows <= 0 || d.n_enc <= 0 || d.n_enc > IWVI_MAX_ENC || d.latent_dim <= 0) {
+                    set_error("iwvi_model_precompute: bad encoder descriptor %d", e); return IWVI_ERR_ARG;
+                }
+                if (d.dims[d.n_enc] != 2 * d.latent_dim) { set_error("iwvi_model_precompute: encoder output %d != 2*latent_dim %d", d.dims[d.n_enc], 2 * d.latent_dim); return IWVI_ERR_ARG; }
+                PreEnc& E = a.E[e];
+                size_t w = 0;
+                for (int k = 0; k <= d.n_enc; ++k) {
+                    if (d.dims[k] <= 0 || d.dims[k] > 64) { set_error("iwvi_model_precompute: encoder width %d out of range (1..64)", d.dims[k]); return IWVI_ERR_ARG; }
+                    E.dims[k] = d.dims[k];
+                }
+                for (int k = 0; k < d.n_enc; ++k) {
+                    if (!d.enc_W[k]) { set_error("iwvi_model_precompute: null encoder weight %d", k); return IWVI_ERR_ARG; }
+                    E.W[k] = d.enc_W[k]; E.b[k] = d.enc_b ? d.enc_b[k] : nullptr;
+                    w += (size_t)d.dims[k] * d.dims[k + 1] + d.dims[k + 1];
+                }
+                E.XY = d.XY; E.out = d.out; E.rows = d.rows; E.n_enc = d.n_enc; E.Lw = d.latent_dim;
+                E.blk0 = enc_blocks; E.nblk = (int)((d.rows + ENC_ROWS - 1) / ENC_ROWS);
+                enc_blocks += E.nblk;
+                const size_t need = (w + 4 + 2 * (size_t)ENC_ROWS * 65) * sizeof(float);   // weights + two activation buffers
+                if (need > lds) lds = need;
+            }
+            a.n_enc = n_encs;
+        }
         int rc;
         if ((rc = ensure_lds_attr((const void*)k_precompute, lds)) != IWVI_OK) return rc;
-        hipLaunchKernelGGL(k_precompute, dim3(a.n, max_roles), dim3(1024), lds, stream, a);
+        hipLaunchKernelGGL(k_precompute, dim3(a.n + enc_blocks, max_roles), dim3(1024), lds, stream, a);
         if ((rc = check_launch("k_precompute")) != IWVI_OK) return rc;
     }
     return IWVI_OK;

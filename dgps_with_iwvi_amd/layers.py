@@ -201,12 +201,31 @@ class LatentVariableLayer:
         self.encoder.to(device)
         return self
 
-    def fused_desc(self, D, z=None, outputs=None, sampled_kl=True, use_encoder=True, draw=True):
-        """``iwvi_layer_desc`` of this layer for ``iwvi_dgp_forward`` (D = width of the incoming F)."""
+    def enc_desc(self, XY):
+        """``iwvi_enc_desc``: evaluate this layer's encoder for every row of XY [rows, XY_dim] inside the
+        model's precompute launch; the result lands in ``self._enc_out`` [rows, 2*latent_dim]."""
+        XY = _abi.dev_tensor(XY.contiguous(), "encoder input")
+        if XY.shape[-1] != self.encoder.layer_dims[0]:
+            raise ValueError("encoder expects %d features, got %d" % (self.encoder.layer_dims[0], XY.shape[-1]))
+        rows = XY.shape[0]
+        if getattr(self, "_enc_out", None) is None or self._enc_out.shape[0] != rows or self._enc_out.device != XY.device:
+            self._enc_out = torch.empty(rows, 2 * self.latent_dim, dtype=settings.float_type, device=XY.device)
+        Wp, bp, dims, n, k2 = self.encoder.abi_args()
+        e = _abi.EncDesc()
+        e.XY, e.rows, e.enc_W, e.enc_b, e.dims, e.n_enc = XY.data_ptr(), rows, Wp, bp, dims, n
+        e.latent_dim, e.out = self.latent_dim, self._enc_out.data_ptr()
+        return e, (XY, Wp, bp, dims, k2)
+
+    def fused_desc(self, D, z=None, outputs=None, sampled_kl=True, use_encoder=True, draw=True, enc_out=None):
+        """``iwvi_layer_desc`` of this layer for ``iwvi_dgp_forward`` (D = width of the incoming F).
+        ``enc_out``: precomputed encoder output [rows, 2*latent_dim] (``enc_desc``) instead of the weights."""
         d = _abi.LayerDesc()
         d.type, d.D, d.latent_dim, d.sampled_kl = _abi.LAYER_LV, D, self.latent_dim, 1 if sampled_kl else 0
         keep = []
-        if use_encoder:
+        if use_encoder and enc_out is not None:
+            d.enc_out = _abi.dev_tensor(enc_out, "enc_out").data_ptr()
+            keep.append(enc_out)
+        elif use_encoder:
             Wp, bp, dims, n, k2 = self.encoder.abi_args()
             d.enc_W, d.enc_b, d.enc_dims, d.n_enc = Wp, bp, dims, n
             keep += [Wp, bp, dims, k2]

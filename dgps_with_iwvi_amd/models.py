@@ -76,9 +76,19 @@ class DGP_VI:
         return self._dev_words
 
     # -- reference API ------------------------------------------------------------------------
-    def precompute(self):
-        """Gram + Cholesky + operand packing of every GP layer: one ABI call, one launch."""
-        precompute_states([l.state_desc() for l in self.layers if isinstance(l, GPLayer)])
+    def precompute(self, with_encoders=False):
+        """Gram + Cholesky + operand packing of every GP layer: one ABI call, one launch.  ``with_encoders``:
+        the same launch also evaluates the encoder MLP of every latent-variable layer on the current minibatch
+        (it does not depend on the factorisation, so it runs beside it instead of inside the layer kernel)."""
+        encs, keep = [], []
+        if with_encoders:
+            for l in self.layers:
+                if isinstance(l, LatentVariableLayer) and len(encs) < 2:
+                    e, k = l.enc_desc(self._xy_minibatch())
+                    encs.append(e)
+                    keep.append(k)
+                    l._enc_key = self._mb_key()
+        precompute_states([l.state_desc() for l in self.layers if isinstance(l, GPLayer)], encs)
 
     def propagate(self, X, full_cov=False, inference_amorization_inputs=None,
                   is_sampled_local_regularizer=False, zs=None, _precomputed=False, _kl_parts=False):
@@ -140,7 +150,9 @@ class DGP_VI:
                 if want_layers:
                     o = {k: torch.empty(*lead, D + Lw, dtype=settings.float_type, device=dev) for k in ("sample", "mean", "var")}
                     o["kl_local"] = torch.empty(*lead, Lw, dtype=settings.float_type, device=dev)
-                d, k = layer.fused_desc(D, z2, o, sampled_kl=sampled_kl, use_encoder=use_encoder)
+                # encoder output of THIS minibatch from the last precompute launch, if there is one
+                eo = layer._enc_out if (use_encoder and getattr(layer, "_enc_key", None) == self._mb_key()) else None
+                d, k = layer.fused_desc(D, z2, o, sampled_kl=sampled_kl, use_encoder=use_encoder, enc_out=eo)
                 D += Lw
             else:
                 raise TypeError("the fused forward knows GPLayer and LatentVariableLayer; use propagate() for custom layers")
@@ -174,6 +186,9 @@ class DGP_VI:
             settings.seed, ctypes.c_void_p(words.data_ptr() + 8), _abi.ptr(logw),
             None if ed is None else ctypes.byref(ed), _abi.stream_ptr()))
         return logw, outs, red
+
+    def _mb_key(self):
+        return (self.X.data_ptr(), self.Y.data_ptr(), self.X.shape[0])
 
     def _xy_minibatch(self):
         """[x_b, y_b] rows of the current minibatch (models.py:53 / :116 before tiling), cached per minibatch."""
@@ -228,7 +243,7 @@ class DGP_VI:
     def _build_likelihood(self, zs=None):
         """The VI bound, reference models.py:49-86 (2-D [S*N, D] tiling, mean over S)."""
         S, N = self.num_samples, self.X.shape[0]
-        self.precompute()
+        self.precompute(with_encoders=True)
         # tile(X, [S, 1]) (:50-53): row t = s*N + n reads data row t % N; analytic local KL (:58-61)
         _, _, red = self._fused_forward(S * N, 1, N, (S * N,), zs=zs, sampled_kl=False,
                                         elbo=dict(B=N, K=S, stride_b=1, stride_k=N, mode_vi=True))
@@ -284,7 +299,7 @@ class DGP_IWVI(DGP_VI):
             if cov.dim() == 4:                                                            # [B, Dy, K, K]
                 cov = torch.diagonal(cov, dim1=-2, dim2=-1).transpose(1, 2).contiguous()  # :133
             return means[-1], cov, local_kls, global_kls, samples, means, covs
-        self.precompute()
+        self.precompute(with_encoders=True)
         _, outs, _ = self._fused_forward(B * K, K, B, (B, K), zs=zs, sampled_kl=True, want_layers=True)
         samples, means, covs = ([o[k] for o in outs] for k in ("sample", "mean", "var"))
         local_kls = [o["kl_local"] for o, l in zip(outs, self.layers) if l.regularizer_type is RegularizerType.LOCAL]
@@ -295,7 +310,7 @@ class DGP_IWVI(DGP_VI):
         B, K = self.X.shape[0], self.num_samples
         if self.full_cov_over_samples:
             return None
-        self.precompute()
+        self.precompute(with_encoders=True)
         return self._fused_forward(B * K, K, B, (B, K), zs=zs, sampled_kl=True)[0]
 
     def _elbo_parts(self, zs=None, want_ms=False, K_total=None):
@@ -304,7 +319,7 @@ class DGP_IWVI(DGP_VI):
             fmean, fvar, local_kls, global_kls, _, _, _ = self._forward_iw(zs)
             return self._reduce(fmean, fvar, self.Y, local_kls, global_kls, B, K, stride_b=K, stride_k=1,
                                 mode_vi=False, want_ms=want_ms, K_total=K_total)
-        self.precompute()
+        self.precompute(with_encoders=True)
         return self._fused_forward(B * K, K, B, (B, K), zs=zs, sampled_kl=True,
                                    elbo=dict(B=B, K=K, stride_b=K, stride_k=1, mode_vi=False, want_ms=want_ms,
                                              K_total=K_total))[2]

@@ -103,12 +103,17 @@ class GpState:
         return d
 
 
-def precompute_states(descs):
-    """One ``iwvi_gp_precompute`` call (one launch per 8 layers) for any number of GP layers."""
+def precompute_states(descs, encs=()):
+    """One ``iwvi_model_precompute`` call (one launch per 8 layers) for any number of GP layers, plus the
+    encoder MLPs of the model's latent-variable layers in the same launch (``encs``: EncDesc list)."""
     if not descs:
         return
     arr = (_abi.GpDesc * len(descs))(*descs)
-    _abi.check(_abi.lib().iwvi_gp_precompute(arr, len(descs), _abi.stream_ptr()))
+    if encs:
+        earr = (_abi.EncDesc * len(encs))(*encs)
+        _abi.check(_abi.lib().iwvi_model_precompute(arr, len(descs), earr, len(encs), _abi.stream_ptr()))
+    else:
+        _abi.check(_abi.lib().iwvi_gp_precompute(arr, len(descs), _abi.stream_ptr()))
 
 
 def _prep_q_sqrt(q_sqrt, f):

@@ -99,6 +99,19 @@ int iwvi_gp_state_offsets(int M, int R, size_t out_host[8]);
  * triangular inverse + packing, roles 1..R tril(q_sqrt[r])^T packing + KL share */
 int iwvi_gp_precompute(const iwvi_gp_desc* layers_host, int n_layers, void* stream);
 
+/* The same launch can also evaluate the Encoder MLP of a LatentVariableLayer (layers.py:137-152) for every row of
+ * the minibatch: it does not depend on the factorisation, so it runs on otherwise idle CUs, off the critical
+ * path of iwvi_dgp_forward (which then takes iwvi_layer_desc.enc_out instead of the weights).
+ *   XY [rows, dims[0]];  enc_W[i] [dims[i], dims[i+1]], enc_b[i] [dims[i+1]] (host arrays of device pointers);
+ *   out [rows, 2*latent_dim] = (means | raw), q_sqrt = softplus(raw - 3). */
+typedef struct iwvi_enc_desc {
+    const float* XY; int64_t rows;
+    const float* const* enc_W; const float* const* enc_b; const int32_t* dims; int32_t n_enc, latent_dim;
+    float* out;
+} iwvi_enc_desc;
+int iwvi_model_precompute(const iwvi_gp_desc* layers_host, int n_layers,
+                          const iwvi_enc_desc* encs_host, int n_encs, void* stream);
+
 /* K1: Kuu(feat, kern, jitter) in float64 (temp_workaround.py:39)  -> Kuu [M, M] double */
 int iwvi_rbf_gram_sym(const float* Z, const float* lengthscales, float variance, double jitter,
                       int kern_type, int M, int D, double* Kuu, void* stream);
@@ -178,6 +191,7 @@ typedef struct iwvi_layer_desc {
     const float* const* enc_b;
     const int32_t* enc_dims;        /* host: n_enc + 1 widths, [0] = XY width, [n] = 2*latent */
     int32_t n_enc, latent_dim, sampled_kl;
+    const float* enc_out;           /* [data rows, 2*latent_dim] from iwvi_model_precompute: used instead of enc_W    */
     /* both */
     const float* noise;             /* explicit N(0,1) draws, or NULL                        */
     int32_t zero_noise;             /* noise == NULL: 1 -> z = 0 (sample == mean), 0 -> draw in-kernel */

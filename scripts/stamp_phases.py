@@ -19,7 +19,7 @@ lib.iwvi_debug_set_stamps.restype = None
 lib.iwvi_debug_set_stamps.argtypes = [ctypes.c_void_p, ctypes.c_int64]
 NW = 4096
 buf = torch.zeros(NW * 128, dtype=torch.int64, device=dev)
-m.precompute()
+m.precompute(with_encoders=True)
 for _ in range(3):
     m._fused_forward(B * K, K, B, (B, K))
 torch.cuda.synchronize()
@@ -57,3 +57,6 @@ st = cyc[:, 2 + 1 * 6 + 2].astype(np.float64)[:, None]      # stage-1 end stamp 
 print("stage 2 (layer 1) per wave: start / end cycles after the stage-1 barrier (median over workgroups)")
 print("  start", np.round(np.median(w0 - st, 0)).astype(int))
 print("  end  ", np.round(np.median(w1 - st, 0)).astype(int))
+
+s1 = full[:, 118:126].astype(np.float64); g0 = cyc[:, 2 + 1 * 6 + 1].astype(np.float64)[:, None]
+print("stage 1 (layer 1) per wave end, cycles after the Gram barrier:", np.round(np.median(s1 - g0, 0)).astype(int))
