@@ -311,12 +311,22 @@ __device__ void role_factor(const PreLayer& L, int stop_after, unsigned long lon
     __syncthreads();
     // centre: K_uf is formed as exp2(x~ . z~) with |x|^2 + |z|^2 - 2 x.z expanded (like gpflow's
     // square_dist); subtracting a common centre leaves r^2 unchanged and keeps the expansion well scaled
-    if (tid < 32) {
-        double acc = 0.0;
-        for (int m = 0; m < M; ++m) acc += (double)zs[m * ZLD + tid];
-        const float c = (tid < D) ? (float)(acc / (double)M) : 0.f;
-        zcs[tid] = c;
-        L.cst[32 + tid] = c;
+    {   // column means of zs: 32 partial sums per column, then one thread per column adds them in a fixed order
+        double* partd = znd + Mp;                                    // [32][32] partial sums
+        const int d = tid & 31, pr = tid >> 5;                       // 32 parts (1024 threads)
+        if (pr < 32) {
+            double acc = 0.0;
+            for (int m = pr; m < M; m += 32) acc += (double)zs[m * ZLD + d];
+            partd[pr * 32 + d] = acc;
+        }
+        __syncthreads();
+        if (tid < 32) {
+            double acc = 0.0;
+            for (int q = 0; q < 32; ++q) acc += partd[q * 32 + tid];
+            const float c = (tid < D) ? (float)(acc / (double)M) : 0.f;
+            zcs[tid] = c;
+            L.cst[32 + tid] = c;
+        }
     }
     __syncthreads();
     for (int m = tid; m < Mp; m += nthreads) {                       // centred (and re-rounded) from here on: the
@@ -648,7 +658,7 @@ static int ensure_lds_attr(const void* fn, size_t bytes) {
 static size_t factor_lds_bytes(int Mp) {
     size_t d = (size_t)Mp;                                   // rinv
     if (Mp <= 128) d += ws_layout(Mp).total;                 // blocks + dinv + tbuf resident in LDS
-    return d * sizeof(double) + ((size_t)Mp * ZLD + Mp + 32) * sizeof(float) + (size_t)Mp * sizeof(double) + 8;
+    return d * sizeof(double) + ((size_t)Mp * ZLD + Mp + 32) * sizeof(float) + ((size_t)Mp + 1024) * sizeof(double) + 8;
 }
 
 }  // namespace iwvi
