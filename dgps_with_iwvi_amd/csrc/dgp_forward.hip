@@ -48,7 +48,7 @@ constexpr int FW_MAXNS = 5;
 constexpr int FW_THREADS = 512;
 constexpr int FW_WAVES = FW_THREADS / 64;
 
-struct FwGp {
+struct alignas(16) FwGp {             // copied LDS -> registers in 16-byte pieces
     const f32x4* LsP; const f32x4* LrTP; const f32x4* QmuP; const float* ZtP; const float* cst;
     const float* W; const float* mfA; const float* mfb;
     float* a_out; float* u_out;
@@ -207,14 +207,20 @@ __device__ __forceinline__ T* ufirst(T* p) {
     return (T*)(((unsigned long long)hi << 32) | lo);
 }
 __device__ __forceinline__ FwGp uniform_gp(const FwGp& s) {
+    // all words of the descriptor are loaded first (wide LDS reads, one wait), then made wave-uniform: reading
+    // field by field costs an LDS round trip per field
+    constexpr int NW = (int)(sizeof(FwGp) / 4);
+    static_assert(sizeof(FwGp) % 16 == 0, "FwGp is copied in 16-byte pieces");
+    uint32_t w[NW];
+    const uint4* src = reinterpret_cast<const uint4*>(&s);
+#pragma unroll
+    for (int i = 0; i < NW / 4; ++i) { const uint4 v = src[i]; w[4 * i] = v.x; w[4 * i + 1] = v.y; w[4 * i + 2] = v.z; w[4 * i + 3] = v.w; }
+#pragma unroll
+    for (int i = 0; i < NW; ++i) w[i] = (uint32_t)__builtin_amdgcn_readfirstlane((int)w[i]);
     FwGp G;
-    G.LsP = ufirst(s.LsP); G.LrTP = ufirst(s.LrTP); G.QmuP = ufirst(s.QmuP); G.ZtP = ufirst(s.ZtP); G.cst = ufirst(s.cst);
-    G.W = ufirst(s.W); G.mfA = ufirst(s.mfA); G.mfb = ufirst(s.mfb); G.a_out = ufirst(s.a_out); G.u_out = ufirst(s.u_out);
-    G.M = ufirst(s.M); G.Mp = ufirst(s.Mp); G.nbk = ufirst(s.nbk); G.nrb = ufirst(s.nrb); G.nsteps = ufirst(s.nsteps);
-    G.R = ufirst(s.R); G.P = ufirst(s.P); G.kern_type = ufirst(s.kern_type); G.mf_type = ufirst(s.mf_type);
-    G.zt_off = ufirst(s.zt_off); G.variance = __int_as_float(ufirst(__float_as_int(s.variance)));
-    G.ls_off = ufirst(s.ls_off);
-    // jb / nblk / mean_wave stay in the LDS table: indexing a register copy by the wave id would put it in scratch
+    __builtin_memcpy(&G, w, sizeof(FwGp));
+    // (jb / nblk / mean_wave are read from the LDS table where they are indexed by the wave id: a register copy
+    // indexed at run time would be placed in scratch)
     return G;
 }
 
