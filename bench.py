@@ -159,6 +159,12 @@ def main():
         xch = OverlappedExchange(args.shard, world, B, K * world, float(spec["n_data"]) / B, dev)
 
     # ---- capture -----------------------------------------------------------------------------
+    # steps per graph replay: every step is the complete evaluation (fresh noise from the device counter); several
+    # per replay only spares the host-side launch between them.  Multi-GPU runs exchange after every step: one each.
+    spg = 1
+    if world == 1 and not args.no_graph:
+        import math
+        spg = math.gcd(math.gcd(args.steps, args.warmup) if args.warmup else args.steps, int(os.environ.get("IWVI_BENCH_SPG", "10")))
     graph = None
     step.run()
     torch.cuda.synchronize()
@@ -169,7 +175,8 @@ def main():
             step.run()
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph, stream=s):
-                step.run()
+                for _ in range(spg):
+                    step.run()
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
 
@@ -192,11 +199,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    for _ in range(args.warmup // spg):
         one_step()
     fence()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(args.steps // spg):
         one_step()
     fence()
     elapsed = time.perf_counter() - t0
@@ -258,7 +265,7 @@ def main():
                        "global_batch": B * (world if args.shard == "n" else 1),
                        "K_total": K * (world if args.shard == "k" else 1),
                        "sharding": ("none" if world == 1 else args.shard + "-shard"),
-                       "launch": "eager" if graph is None else "hipGraph replay"},
+                       "launch": "eager" if graph is None else ("hipGraph replay, %d steps per replay" % spg)},
             "elbo": final_elbo,
             "roofline": {"bound": "mfma", "kernel": "k_dgp_forward (all layers fused, one launch per ELBO evaluation)", "achieved": achieved / 1e12,
                          "peak": PEAK_MFMA_F32 / 1e12, "unit": "TFLOP/s", "frac": achieved / PEAK_MFMA_F32,

@@ -27,7 +27,10 @@
 // Every job writes its partial sums to its own LDS slot and they are added in a fixed order: results are
 // bit-reproducible whichever wave ran which job.
 #include "iwvi_common.h"
+#include <algorithm>
+#include <cmath>
 #include <cstdlib>
+#include <vector>
 
 namespace iwvi {
 
@@ -56,9 +59,9 @@ struct alignas(16) FwGp {             // copied LDS -> registers in 16-byte piec
     int zt_off;                       // LDS offset of the staged Z~ (floats), or -1: read it from L2
     int ls_off;                       // LDS offset of the staged solve stream LsP, or -1: stream it from L2
     float variance;
-    // static stage-2 schedule: wave w streams the (r-major, bi ascending) row-block jobs jb[w] .. jb[w+1]-1 of the
+    // static stage-2 schedule: wave w streams a run of (r-major, bi ascending) row-block jobs of the
     // contiguous LrTP image (nblk[w] packed blocks), after the q_mu^T row-blocks assigned to it (mean_wave)
-    unsigned short jb[FW_WAVES + 1];
+    unsigned char jr[FW_WAVES], jbi[FW_WAVES];   // first job of wave w: latent GP jr[w], row-block jbi[w]
     unsigned short nblk[FW_WAVES];
     signed char mean_wave[2];
 };
@@ -69,12 +72,22 @@ struct FwLv {
     int dims[IWVI_MAX_ENC + 1];
     int n_enc, Lw, sampled_kl, wtotal, maxdim;
 };
-struct FwLayer {
-    int type, D, zero_noise;
-    int c_off, z_off;                 // LDS offsets (floats): this layer's constants / its noise [dims][NSAMP]
+// leading fields of a layer descriptor; nx_*: the following layer when that is a GP layer (its Gram operand is
+// produced by this layer's last phase)
+#define FW_LAYER_HEAD \
+    int type, D, zero_noise; \
+    int c_off, z_off;                 /* LDS offsets (floats): this layer's constants / its noise [dims][NSAMP] */ \
+    int nx_gp, nx_c_off, nx_nsteps, nx_rbf; \
+    int nx_ls_off, nx_ls_n;           /* the next staged solve stream: LDS offset (or -1) and length in floats */ \
+    const float* nx_ls; \
     const float* noise; float* noise_out; float* sample; float* mean; float* var;
+struct alignas(16) FwLayerHead { FW_LAYER_HEAD };
+struct FwLayer {
+    FW_LAYER_HEAD
     union { FwGp gp; FwLv lv; };
 };
+struct FwHeadGp { FwLayerHead h; FwGp gp; };      // how a GP layer's descriptor starts: one batched LDS read
+static_assert(offsetof(FwLayer, gp) == sizeof(FwLayerHead) && offsetof(FwHeadGp, gp) == sizeof(FwLayerHead), "layer head layout");
 // LDS carve, float offsets (all multiples of 4)
 struct FwLds { int ltab, xa, xb, xt, lw, rowi, pidx, asq, meanp, gbuf, obuf, znoise, xyrows, cnt, scratch, total; };
 
@@ -102,6 +115,7 @@ struct FwHead {
     unsigned long long* stamps;      // diagnostic only (iwvi_debug_set_stamps): 128 words per workgroup
     int dbg;                         // diagnostic only (IWVI_DEBUG_ABLATE): timing ablations, results are wrong
     int ncopy;
+    int ls_first;                    // first GP layer whose solve stream is staged in LDS (fetched in the prologue), or -1
     int xstr;                        // row stride of the activation tiles: odd, >= max(D + 2 padded to 4, P) of the stack
     FwLds lds;
     FwElbo e;
@@ -206,22 +220,36 @@ __device__ __forceinline__ T* ufirst(T* p) {
     const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
     return (T*)(((unsigned long long)hi << 32) | lo);
 }
-__device__ __forceinline__ FwGp uniform_gp(const FwGp& s) {
+template <class T>
+__device__ __forceinline__ T uniform_words(const T& s) {
     // all words of the descriptor are loaded first (wide LDS reads, one wait), then made wave-uniform: reading
     // field by field costs an LDS round trip per field
-    constexpr int NW = (int)(sizeof(FwGp) / 4);
-    static_assert(sizeof(FwGp) % 16 == 0, "FwGp is copied in 16-byte pieces");
+    constexpr int NW = (int)(sizeof(T) / 4);
+    static_assert(sizeof(T) % 16 == 0, "copied in 16-byte pieces");
     uint32_t w[NW];
     const uint4* src = reinterpret_cast<const uint4*>(&s);
 #pragma unroll
     for (int i = 0; i < NW / 4; ++i) { const uint4 v = src[i]; w[4 * i] = v.x; w[4 * i + 1] = v.y; w[4 * i + 2] = v.z; w[4 * i + 3] = v.w; }
 #pragma unroll
     for (int i = 0; i < NW; ++i) w[i] = (uint32_t)__builtin_amdgcn_readfirstlane((int)w[i]);
-    FwGp G;
-    __builtin_memcpy(&G, w, sizeof(FwGp));
+    T G;
+    __builtin_memcpy(&G, w, sizeof(T));
     // (jb / nblk / mean_wave are read from the LDS table where they are indexed by the wave id: a register copy
     // indexed at run time would be placed in scratch)
     return G;
+}
+
+// sum_k a[k * sa] * b[k * sb], k < n, accumulated in index order.  The loads of eight terms are issued together
+// (clamped indices, masked products): a plain run-time-trip loop pays one LDS round trip per term.
+__device__ __forceinline__ float dot_lds(const float* a, int sa, const float* b, int sb, int n, float acc = 0.f) {
+    for (int k0 = 0; k0 < n; k0 += 8) {
+        float av[8], bv[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const int k = (k0 + e < n) ? k0 + e : n - 1; av[e] = a[k * sa]; bv[e] = b[k * sb]; }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc = fmaf((k0 + e < n) ? av[e] : 0.f, bv[e], acc);
+    }
+    return acc;
 }
 
 // one MFMA adds a value across the four 16-lane groups: D[i][j] = sum_k 1 * B[k][j], B[k][j] = lane (k, j)
@@ -229,6 +257,31 @@ __device__ __forceinline__ float xgroup_sum_mfma(float s) {
     const f32x4 z = {0.f, 0.f, 0.f, 0.f};
     const f32x4 d = __builtin_amdgcn_mfma_f32_16x16x4f32(1.0f, s, z, 0, 0, 0);
     return d[0];
+}
+
+// Gram operand of a GP layer for one 16-sample sub-tile, by one whole wave: lane (gq, jq) takes coordinates
+// gq, gq + 4, .. of sample jq's input row xr and writes x~ = [x/l - zc, -|.|^2/2 (RBF) or |.|^2 (Matern52), 1, 0..]
+// (4 * nsteps entries) to xo; the norm is summed over the four coordinate groups with one MFMA.
+__device__ __forceinline__ void xt_subtile(const float* xr, float* xo, const float* invls, const float* zc, int D, int nsteps,
+                                           bool rbf, int gq) {
+    float n2 = 0.f;
+    for (int d0 = 0; d0 < D; d0 += 16) {                           // loads first (clamped), then arithmetic, masked stores
+        float xv[4], il[4], zz[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int d = d0 + 4 * u + gq, dc = d < D ? d : D - 1; xv[u] = xr[dc]; il[u] = invls[dc]; zz[u] = zc[dc]; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int d = d0 + 4 * u + gq;
+            const float v = fmaf(xv[u], il[u], -zz[u]);
+            if (d < D) { xo[d] = v; n2 = fmaf(v, v, n2); }
+        }
+    }
+    n2 = xgroup_sum_mfma(n2);
+    if (gq == 0) {
+        xo[D] = rbf ? -0.5f * n2 : n2;
+        xo[D + 1] = 1.f;
+        for (int d = D + 2; d < 4 * nsteps; ++d) xo[d] = 0.f;
+    }
 }
 
 // ---- stage 1, fully unrolled for NBK <= 8 (M <= 128): right-looking blocked forward substitution with every
@@ -375,6 +428,10 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + i0 + wl),
                                                  (__attribute__((address_space(3))) void*)(dst + i0), 4, 0, 0); }
     }
+    if (g.ls_first >= 0) {                                         // 36 KiB at M = 128: spread over every wave
+        const FwGp& G0 = LT[g.ls_first].gp;
+        async_copy_f32x4(reinterpret_cast<const float*>(ufirst(G0.LsP)), sm + ufirst(G0.ls_off), tri_blocks(ufirst(G0.nbk)) * BLK16, tid);
+    }
     // injected noise [T, dims] -> znoise[z_off + r * NSAMP + j] (a gather: the DMA source is per lane)
     for (int li = 0; li < g.n_layers; ++li) {
         const float* noise = ufirst(NT[li].src);
@@ -417,14 +474,21 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
     __syncthreads();
     FW_STAMP(1);
 
+    int xt_for = -1;                                              // layer whose Gram operand x~ is already in `xt`
     for (int li = 0; li < g.n_layers; ++li) {
         const FwLayer& L = LT[li];
-        const int D = ufirst(L.D);
-        const float* cst = sm + ufirst(L.c_off);
-        const float* zl = znoise + ufirst(L.z_off);
-        const gout1 o_sample = (gout1)ufirst(L.sample), o_mean = (gout1)ufirst(L.mean), o_var = (gout1)ufirst(L.var);
-        const gout1 o_noise = (gout1)ufirst(L.noise_out);
-        if (ufirst(L.type) == IWVI_LAYER_LV) {
+        const FwHeadGp U = uniform_words(reinterpret_cast<const FwHeadGp&>(L));   // (gp part meaningful for GP layers only)
+        const FwLayerHead& H = U.h;
+        const int D = H.D;
+        const float* cst = sm + H.c_off;
+        const float* zl = znoise + H.z_off;
+        const gout1 o_sample = (gout1)H.sample, o_mean = (gout1)H.mean, o_var = (gout1)H.var;
+        const gout1 o_noise = (gout1)H.noise_out;
+        // a following GP layer gets its Gram operand from this layer's last phase (no phase of its own)
+        const bool nx_gp = H.nx_gp != 0, nx_rbf = H.nx_rbf != 0;
+        const float* nx_cst = sm + H.nx_c_off;
+        const int nx_nsteps = H.nx_nsteps;
+        if (H.type == IWVI_LAYER_LV) {
             // ================= LatentVariableLayer (layers.py:72-105) =================================
             const FwLv& V = L.lv;
             const int Lw = ufirst(V.Lw), Do = D + Lw, n_enc = ufirst(V.n_enc), sampled_kl = ufirst(V.sampled_kl);
@@ -459,7 +523,7 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
             FW_STAMP(2 + li * 6 + 1);
             // `in` rows hold [means (Lw) | raw (Lw)] per distinct point
             for (int idx = tid; idx < NSAMP * D; idx += FW_THREADS) {
-                const int j = idx / D, c = idx - j * D;
+                const int c = idx / NSAMP, j = idx - c * NSAMP;    // column-major: the divisor is a compile-time constant
                 const float v = xin[j * XSTR + c];
                 xout[j * XSTR + c] = v;
                 if (j < nvalid) {
@@ -469,35 +533,41 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
                     if (o_var) o_var[t * Do + c] = 0.f;
                 }
             }
-            if (tid < NSAMP) {
-                const int j = tid;
-                const long long t = t0 + j;
-                float klsum = 0.f;
-                for (int l = 0; l < Lw; ++l) {
-                    float mu = 0.f, sg = 1.f;                                        // prior (layers.py:73-81)
-                    if (n_enc > 0 || pre_enc) { mu = in[pidx[j] * in_str + l]; sg = softplus_f(in[pidx[j] * in_str + Lw + l] - 3.f); }
-                    const float z = (j < nvalid) ? zl[l * NSAMP + j] : 0.f;
-                    const float w = fmaf(z, sg, mu);                                 // layers.py:86-87
-                    float kl;
-                    if (sampled_kl) kl = -0.5f * z * z - __logf(sg) + 0.5f * w * w;  // log q(W) - log p(W), :98-100
-                    else kl = 0.5f * (sg * sg + mu * mu - 1.f) - __logf(sg);         // KL(N(mu,sg)||N(0,1)), :101-103
-                    klsum += kl;
-                    xout[j * XSTR + D + l] = w;
-                    if (j < nvalid) {
-                        if (o_kl) o_kl[t * Lw + l] = kl;
-                        if (o_noise) o_noise[t * Lw + l] = z;
-                        if (o_sample) o_sample[t * Do + D + l] = w;                  // layers.py:89-91
-                        if (o_mean) o_mean[t * Do + D + l] = mu;
-                        if (o_var) o_var[t * Do + D + l] = sg * sg;
+            if (wave < NS) {                                       // wave t: sub-tile t; its lanes gq == 0: one sample each
+                const int j = 16 * wave + jq;
+                if (gq == 0) {
+                    const long long t = t0 + j;
+                    float klsum = 0.f;
+                    for (int l = 0; l < Lw; ++l) {
+                        float mu = 0.f, sg = 1.f;                                        // prior (layers.py:73-81)
+                        if (n_enc > 0 || pre_enc) { mu = in[pidx[j] * in_str + l]; sg = softplus_f(in[pidx[j] * in_str + Lw + l] - 3.f); }
+                        const float z = (j < nvalid) ? zl[l * NSAMP + j] : 0.f;
+                        const float w = fmaf(z, sg, mu);                                 // layers.py:86-87
+                        float kl;
+                        if (sampled_kl) kl = -0.5f * z * z - __logf(sg) + 0.5f * w * w;  // log q(W) - log p(W), :98-100
+                        else kl = 0.5f * (sg * sg + mu * mu - 1.f) - __logf(sg);         // KL(N(mu,sg)||N(0,1)), :101-103
+                        klsum += kl;
+                        xout[j * XSTR + D + l] = w;
+                        xin[j * XSTR + D + l] = w;                                       // completes row j for x~ below
+                        if (j < nvalid) {
+                            if (o_kl) o_kl[t * Lw + l] = kl;
+                            if (o_noise) o_noise[t * Lw + l] = z;
+                            if (o_sample) o_sample[t * Do + D + l] = w;                  // layers.py:89-91
+                            if (o_mean) o_mean[t * Do + D + l] = mu;
+                            if (o_var) o_var[t * Do + D + l] = sg * sg;
+                        }
                     }
+                    lw[j] += klsum;
                 }
-                lw[j] += klsum;
+                // (LDS operations of one wave complete in order: the row written above is what is read here)
+                if (nx_gp) xt_subtile(xin + j * XSTR, xt + j * XSTR, nx_cst, nx_cst + 32, Do, nx_nsteps, nx_rbf, gq);
             }
+            if (nx_gp) xt_for = li + 1;
             __syncthreads();
             FW_STAMP(2 + li * 6 + 5);
         } else {
             // ================= GPLayer (layers.py:35-50) ==============================================
-            const FwGp G = uniform_gp(L.gp);
+            const FwGp& G = U.gp;
             const int nbk = G.nbk, R = G.R, P = G.P, nsteps = G.nsteps;
             f32x4* kuf = reinterpret_cast<f32x4*>(scratch);
             f32x4* at = kuf;                                       // solved in place (stage 1)
@@ -510,24 +580,13 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
             // else difference the coordinates directly (error ~eps * r^2)
             const bool gram_mfma = __float_as_int(cst[64]) <= __float_as_int(4.0f);   // zmax2 >= 0: int compare is exact
 
-            // ---- x~ = [x/l - zc, -|.|^2/2 (RBF) or |.|^2 (Matern52), 1, 0..] ----------------------------
-            if (tid < NSAMP) {
-                float n2 = 0.f;
-#pragma unroll 4
-                for (int d = 0; d < D; ++d) {
-                    const float v = fmaf(xin[tid * XSTR + d], invls[d], -zc[d]);
-                    xt[tid * XSTR + d] = v;
-                    n2 = fmaf(v, v, n2);
-                }
-                xt[tid * XSTR + D] = rbf ? -0.5f * n2 : n2;
-                xt[tid * XSTR + D + 1] = 1.f;
-                for (int d = D + 2; d < 4 * nsteps; ++d) xt[tid * XSTR + d] = 0.f;
+            // ---- x~ (only when the layer before did not already leave it in `xt`) -------------------------
+            if (xt_for != li) {
+                if (wave < NS) xt_subtile(xin + (16 * wave + jq) * XSTR, xt + (16 * wave + jq) * XSTR, invls, zc, D, nsteps, rbf, gq);
+                __syncthreads();
             }
-            if (tid < 12) counters[tid] = 0;                       // job counters + the 8 column flags of the shared solve
-            for (int i = tid; i < 4 * NSAMP; i += FW_THREADS) asq[i] = 0.f;
-            // the layer's forward-substitution stream -> LDS while x~ and the Gram run (all NS solving waves read it)
-            if (G.ls_off >= 0) async_copy_f32x4(reinterpret_cast<const float*>(G.LsP), sm + G.ls_off, tri_blocks(nbk) * BLK16, tid);
-            __syncthreads();
+            // (the layer's forward-substitution stream is already on its way to LDS: prologue for the first GP
+            // layer, the previous GP layer's stage 2 for the others)
             FW_STAMP(2 + li * 6 + 0);
 
             // ---- Gram: kuf block bi = kernel(Z_bi, x), written in B-operand order ---------------------------
@@ -606,6 +665,25 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
             // r_bi += (-L(bi,bj)) a_bj for every bi > bj: independent MFMA chains, B operand = a_bj in registers.
             // r lives in the `at` tile (first touched from the Gram tile); the freshly updated r_{bj+1} is handed
             // to the next column in registers, so the dependent chain never waits for LDS.
+            // stage 2's first operands are requested now (nothing in them depends on the solve), so that its MFMAs
+            // start right behind the barrier that ends stage 1
+            const int ntri = tri_blocks(nbk);
+            const int s2_nblocks = ufirst((int)L.gp.nblk[wave]);   // runs are dealt to waves by load, not in order
+            const int s2_mw0 = ufirst((int)L.gp.mean_wave[0]), s2_mw1 = ufirst((int)L.gp.mean_wave[1]);
+            const int s2_r0 = ufirst((int)L.gp.jr[wave]), s2_bi0 = ufirst((int)L.gp.jbi[wave]);
+            gptr4 s2_P = (gptr4)G.LrTP + ((size_t)s2_r0 * ntri + tri_upper_off(nbk, s2_bi0)) * 64 + lane;
+            f32x4 ring[4];
+            ring[0] = ring[1] = ring[2] = ring[3] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (s2_nblocks > 0) {
+                ring[0] = s2_P[0];
+                ring[1] = s2_P[(size_t)(1 < s2_nblocks ? 1 : s2_nblocks - 1) * 64];
+                ring[2] = s2_P[(size_t)(2 < s2_nblocks ? 2 : s2_nblocks - 1) * 64];
+            }
+            if (wave >= NS) {
+                // the waves without a sub-tile to solve clear every |u|^2 slot meanwhile (stage 2 fills only some)
+                f32x4* uz = reinterpret_cast<f32x4*>(usq);
+                for (int i = (wave - NS) * 64 + lane; i < (FW_WAVES * R * NSAMP) / 4; i += (FW_WAVES - NS) * 64) uz[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
             if (wave < NS) {
                 const int tcol = 16 * wave + jq;                  // this lane's sample column
                 gptr4 Ap = (gptr4)G.LsP + lane;
@@ -675,20 +753,20 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
                     }
                 }
                 ssq = xgroup_sum_mfma(ssq);
-                if (gq == 0) asq[tcol] = ssq;                         // slot 0; slots 1..3 stay zero
+                if (gq == 0) asq[tcol] = ssq;
             }
             if (g.stamps && lane == 0 && li == 1) g.stamps[(size_t)blockIdx.x * 128 + 118 + wave] = clock64();
             __syncthreads();
             FW_STAMP(2 + li * 6 + 2);
+            // the staging buffer is free again: the next GP layer's forward-substitution stream lands under stage 2
+            if (H.nx_ls_off >= 0) async_copy_f32x4(H.nx_ls, sm + H.nx_ls_off, H.nx_ls_n, tid);
 
             // ---- stage 2: u block (r, bi) = sum_{bk >= bi} LrT(bi, bk) a(bk), only |u|^2 kept; mean = q_mu^T a ----
             {
-                const int ntri = tri_blocks(nbk);
                 if (wave >= FW_WAVES / 2) __builtin_amdgcn_s_setprio(1);   // the second-dispatched half loses issue arbitration otherwise
-                for (int i = lane; i < R * NSAMP; i += 64) usq[wave * R * NSAMP + i] = 0.f;   // slots this wave will not fill
                 // (a) q_mu^T row-blocks assigned to this wave: mean = q_mu^T a  (temp_workaround.py:68)
                 for (int rb = 0; rb < G.nrb; ++rb) {
-                    if (ufirst((int)L.gp.mean_wave[rb]) != wave) continue;
+                    if ((rb == 0 ? s2_mw0 : s2_mw1) != wave) continue;
                     gptr4 P = (gptr4)G.QmuP + (size_t)rb * nbk * 64 + lane;
                     f32x4 acc[NS];
 #pragma unroll
@@ -716,14 +794,10 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
                 }
                 if (g.stamps && lane == 0 && li == 1) g.stamps[(size_t)blockIdx.x * 128 + 100 + wave] = clock64();
                 // (b) this wave's contiguous run of (r, bi) row-block jobs: one linear stream of packed blocks
-                const int j0 = ufirst((int)L.gp.jb[wave]), j1 = ufirst((int)L.gp.jb[wave + 1]), nblocks = ufirst((int)L.gp.nblk[wave]);
-                if (j0 < j1) {
-                    int r = j0 / nbk, bi = j0 - r * nbk;
-                    gptr4 P = (gptr4)G.LrTP + ((size_t)r * ntri + tri_upper_off(nbk, bi)) * 64 + lane;
-                    f32x4 ring[4];
-                    ring[0] = P[0];
-                    ring[1] = P[(size_t)(1 < nblocks ? 1 : nblocks - 1) * 64];
-                    ring[2] = P[(size_t)(2 < nblocks ? 2 : nblocks - 1) * 64];
+                const int nblocks = s2_nblocks;
+                if (nblocks > 0) {
+                    int r = s2_r0, bi = s2_bi0;
+                    gptr4 P = s2_P;
                     f32x4 acc[NS];
                     float ssq[NS];
 #pragma unroll
@@ -807,8 +881,7 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
 #pragma unroll
                 for (int w = 0; w < FW_WAVES; ++w) u2 += usq[(w * R + r) * NSAMP + j];   // fixed order: bit-reproducible
                 const float mu = meanp[r * NSAMP + j];
-                const float a2 = ((asq[j] + asq[NSAMP + j]) + asq[2 * NSAMP + j]) + asq[3 * NSAMP + j];   // fixed order
-                const float v = fmaxf(G.variance - a2 + u2, 0.f);
+                const float v = fmaxf(G.variance - asq[j] + u2, 0.f);
                 const float z = (j < nvalid) ? zl[r * NSAMP + j] : 0.f;
                 if (o_noise && j < nvalid) o_noise[(t0 + j) * R + r] = z;
                 gbuf[(0 * R + r) * NSAMP + j] = mu;
@@ -817,45 +890,115 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
             }
             __syncthreads();
             FW_STAMP(2 + li * 6 + 4);
-            // ---- epilogue (ii): mixing (:142-145) + mean function (layers.py:46-48) -> next layer's input ----
+            // ---- epilogue (ii): mixing (:142-145) + linear mean function (layers.py:46-48) as ONE small MFMA product
+            //      out[p][j] = sum_k A[p][k] B[k][j],  A = [W | mfA^T],  B = [f_r(j) ; x_d(j)]:
+            //      wave t owns sample sub-tile t; the result lands as 4 outputs p = 4gq .. 4gq+3 of sample 16t + jq
+            //      per lane, from which the next GP layer's x~ row is formed on the spot.
             const bool last = (li == g.n_layers - 1);
             const bool need_mv = last || o_mean || o_var;         // inner layers only hand their sample on
-            for (int idx = tid; idx < NSAMP * P; idx += FW_THREADS) {
-                const int p = idx / NSAMP, j = idx - p * NSAMP;
+            if (wave < NS) {
+                const int j = 16 * wave + jq;
                 const long long t = t0 + j;
-                float o_s, o_m, o_v;
-                if (G.W) {
-                    o_s = o_m = o_v = 0.f;
-                    if (need_mv) {
-#pragma unroll 4
-                        for (int r = 0; r < R; ++r) {
-                            const float w = Wm[p * R + r];
-                            o_m = fmaf(w, gbuf[(0 * R + r) * NSAMP + j], o_m);
-                            o_v = fmaf(w * w, gbuf[(1 * R + r) * NSAMP + j], o_v);
-                            o_s = fmaf(w, gbuf[(2 * R + r) * NSAMP + j], o_s);
-                        }
-                    } else {
-#pragma unroll 8
-                        for (int r = 0; r < R; ++r) o_s = fmaf(Wm[p * R + r], gbuf[(2 * R + r) * NSAMP + j], o_s);
+                const int Dm = (G.mf_type == IWVI_MF_LINEAR) ? D : 0;
+                const int npb = (P + 15) >> 4;                    // 16-row blocks of outputs: 1 or 2
+                const bool hasW = G.W != nullptr;
+                const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+                f32x4 acc_s[2] = {zero4, zero4}, acc_m[2] = {zero4, zero4}, acc_v[2] = {zero4, zero4};
+                const float* gm = gbuf; const float* gv = gbuf + R * NSAMP; const float* gs = gbuf + 2 * R * NSAMP;
+                // K is laid out [R latent GPs padded to a multiple of 4 | D inputs]: every MFMA step is wholly one kind,
+                // so the two loops below carry no lane-dependent choice of source (loads from clamped, valid addresses;
+                // the A entry of a padded k or p is zero)
+                const int p_lo = jq, p_hi = 16 + jq;              // A operand rows of the two output blocks (lane i = jq)
+                const int pc_lo = p_lo < P ? p_lo : P - 1, pc_hi = p_hi < P ? p_hi : P - 1;
+                for (int k0 = 0; k0 < R; k0 += 4) {
+                    const int k = k0 + gq, kc = k < R ? k : R - 1;
+                    const float bs = gs[kc * NSAMP + j];
+                    float a_lo = hasW ? Wm[pc_lo * R + kc] : (pc_lo == kc ? 1.f : 0.f);
+                    a_lo = (k < R && p_lo < P) ? a_lo : 0.f;
+                    acc_s[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_lo, bs, acc_s[0], 0, 0, 0);
+                    float a_hi = 0.f;
+                    if (npb > 1) {
+                        a_hi = hasW ? Wm[pc_hi * R + kc] : (pc_hi == kc ? 1.f : 0.f);
+                        a_hi = (k < R && p_hi < P) ? a_hi : 0.f;
+                        acc_s[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_hi, bs, acc_s[1], 0, 0, 0);
                     }
-                } else {
-                    o_m = gbuf[(0 * R + p) * NSAMP + j]; o_v = gbuf[(1 * R + p) * NSAMP + j]; o_s = gbuf[(2 * R + p) * NSAMP + j];
+                    if (need_mv) {
+                        const float bm = gm[kc * NSAMP + j], bv = gv[kc * NSAMP + j];
+                        acc_m[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_lo, bm, acc_m[0], 0, 0, 0);
+                        acc_v[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_lo * a_lo, bv, acc_v[0], 0, 0, 0);
+                        if (npb > 1) {
+                            acc_m[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_hi, bm, acc_m[1], 0, 0, 0);
+                            acc_v[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_hi * a_hi, bv, acc_v[1], 0, 0, 0);
+                        }
+                    }
                 }
-                float mf = 0.f;
-                if (G.mf_type == IWVI_MF_IDENTITY) mf = xin[j * XSTR + p];
-                else if (G.mf_type == IWVI_MF_LINEAR) {
-#pragma unroll 8
-                    for (int d = 0; d < D; ++d) mf = fmaf(xin[j * XSTR + d], mfA[d * P + p], mf);
-                    if (G.mfb) mf += mfb[p];
+                for (int d0 = 0; d0 < Dm; d0 += 4) {             // linear mean function rows: sample and mean alike
+                    const int d = d0 + gq, dc = d < Dm ? d : Dm - 1;
+                    const float bx = xin[j * XSTR + dc];
+                    float a_lo = mfA[dc * P + pc_lo];
+                    a_lo = (d < Dm && p_lo < P) ? a_lo : 0.f;
+                    acc_s[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_lo, bx, acc_s[0], 0, 0, 0);
+                    if (need_mv) acc_m[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_lo, bx, acc_m[0], 0, 0, 0);
+                    if (npb > 1) {
+                        float a_hi = mfA[dc * P + pc_hi];
+                        a_hi = (d < Dm && p_hi < P) ? a_hi : 0.f;
+                        acc_s[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_hi, bx, acc_s[1], 0, 0, 0);
+                        if (need_mv) acc_m[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_hi, bx, acc_m[1], 0, 0, 0);
+                    }
                 }
-                xout[j * XSTR + p] = o_s + mf;
-                if (last) { obuf[p * NSAMP + j] = o_m + mf; obuf[(P + p) * NSAMP + j] = o_v; }
-                if (j < nvalid) {
-                    if (o_sample) o_sample[t * P + p] = o_s + mf;
-                    if (o_mean) o_mean[t * P + p] = o_m + mf;
-                    if (o_var) o_var[t * P + p] = o_v;
+                // what the product does not already carry: identity mean function, or the linear one's bias
+                const bool mf_id = G.mf_type == IWVI_MF_IDENTITY, mf_b = G.mf_type == IWVI_MF_LINEAR && G.mfb;
+                const float* mfp = mf_id ? xin + j * XSTR : (mf_b ? mfb : cst);
+                float n2 = 0.f;
+#pragma unroll
+                for (int pb = 0; pb < 2; ++pb) {
+                    if (pb < npb) {
+                        const int p0 = 16 * pb + 4 * gq;
+                        float os[4], mfv[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int pc = (p0 + e < P) ? p0 + e : P - 1;
+                            mfv[e] = mfp[pc];                      // unconditional load, selected after
+                            mfv[e] = (mf_id || mf_b) ? mfv[e] : 0.f;
+                            os[e] = acc_s[pb][e] + mfv[e];
+                        }
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) if (p0 + e < P) xout[j * XSTR + p0 + e] = os[e];
+                        if (nx_gp) {                              // next layer's x~ entries p0 .. p0+3 and their squares
+                            const f32x4 il = *reinterpret_cast<const f32x4*>(nx_cst + p0), zz = *reinterpret_cast<const f32x4*>(nx_cst + 32 + p0);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const float v = fmaf(os[e], il[e], -zz[e]);
+                                if (p0 + e < P) { xt[j * XSTR + p0 + e] = v; n2 = fmaf(v, v, n2); }
+                            }
+                        }
+                        if (last) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                if (p0 + e < P) { obuf[(p0 + e) * NSAMP + j] = acc_m[pb][e] + mfv[e]; obuf[(P + p0 + e) * NSAMP + j] = acc_v[pb][e]; }
+                        }
+                        if ((o_sample || o_mean || o_var) && j < nvalid) {     // requested outputs (not on the training path)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                if (p0 + e < P) {
+                                    if (o_sample) o_sample[t * P + p0 + e] = os[e];
+                                    if (o_mean) o_mean[t * P + p0 + e] = acc_m[pb][e] + mfv[e];
+                                    if (o_var) o_var[t * P + p0 + e] = acc_v[pb][e];
+                                }
+                            }
+                        }
+                    }
+                }
+                if (nx_gp) {
+                    n2 = xgroup_sum_mfma(n2);
+                    if (gq == 0) {
+                        xt[j * XSTR + P] = nx_rbf ? -0.5f * n2 : n2;
+                        xt[j * XSTR + P + 1] = 1.f;
+                        for (int d = P + 2; d < 4 * nx_nsteps; ++d) xt[j * XSTR + d] = 0.f;
+                    }
                 }
             }
+            if (nx_gp) xt_for = li + 1;
             __syncthreads();
             FW_STAMP(2 + li * 6 + 5);
         }
@@ -988,25 +1131,63 @@ static int launch_forward(const FwArgs& a, unsigned grid, size_t lds_bytes, hipS
 // nbk - bi blocks) are cut into FW_WAVES contiguous runs with the smallest possible maximum cost; the q_mu^T
 // row-blocks (cost nbk each) go to the last waves and count against them.
 static void plan_stage2(FwGp& G) {
-    const int nbk = G.nbk, R = G.R, njobs = R * nbk;
-    int pre[FW_WAVES] = {0};
-    G.mean_wave[0] = G.mean_wave[1] = -1;
-    for (int rb = 0; rb < G.nrb && rb < 2; ++rb) { G.mean_wave[rb] = (signed char)(FW_WAVES - 1 - rb); pre[FW_WAVES - 1 - rb] += nbk; }
-    auto cost = [&](int j) { return nbk - (j % nbk); };
-    auto fits = [&](int limit, unsigned short* jb, unsigned short* nb) {
-        int j = 0;
-        for (int w = 0; w < FW_WAVES; ++w) {
-            int load = pre[w], blocks = 0;
-            if (jb) jb[w] = (unsigned short)j;
-            while (j < njobs && load + cost(j) <= limit) { load += cost(j); blocks += cost(j); ++j; }
-            if (nb) nb[w] = (unsigned short)blocks;
-        }
-        if (jb) jb[FW_WAVES] = (unsigned short)j;
-        return j == njobs;
+    // cost model: a job (r, bi) streams nbk - bi packed blocks, a q_mu^T row-block nbk; the two waves w and
+    // w + FW_WAVES/2 share a SIMD (and its MFMA pipe), so the quantity to level is the load per SIMD pair
+    const int nbk = G.nbk, R = G.R, njobs = R * nbk, W = FW_WAVES, nm = G.nrb < 2 ? G.nrb : 2;
+    std::vector<int> pref(njobs + 1, 0);
+    for (int j = 0; j < njobs; ++j) pref[j + 1] = pref[j] + (nbk - (j % nbk));
+    struct Eval { int maxpair, sq, maxseg; bool operator<(const Eval& o) const {
+        return maxpair != o.maxpair ? maxpair < o.maxpair : (sq != o.sq ? sq < o.sq : maxseg < o.maxseg); } };
+    int load[FW_WAVES], order[FW_WAVES];
+    auto loads = [&](const int* b) {
+        for (int k = 0; k < W; ++k) { load[k] = pref[b[k + 1]] - pref[b[k]]; order[k] = k; }
+        std::sort(order, order + W, [&](int x, int y) { return load[x] != load[y] ? load[x] < load[y] : x < y; });
+        for (int i = 0; i < nm; ++i) load[order[i]] += nbk;            // q_mu^T row-blocks ride on the lightest runs
+        std::sort(order, order + W, [&](int x, int y) { return load[x] != load[y] ? load[x] > load[y] : x < y; });
     };
-    int lo = nbk, hi = R * tri_blocks(nbk) + 2 * nbk;
-    while (lo < hi) { const int mid = (lo + hi) / 2; if (fits(mid, nullptr, nullptr)) hi = mid; else lo = mid + 1; }
-    fits(lo, G.jb, G.nblk);
+    auto evaluate = [&](const int* b) {
+        loads(b);
+        Eval e{0, 0, load[order[0]]};
+        for (int i = 0; i < W / 2; ++i) { const int p = load[order[i]] + load[order[W - 1 - i]]; e.maxpair = p > e.maxpair ? p : e.maxpair; e.sq += p * p; }
+        return e;
+    };
+    int b[FW_WAVES + 1];
+    b[0] = 0; b[W] = njobs;
+    for (int k = 1; k < W; ++k) {                                      // start: boundaries nearest the equal split
+        const double target = (double)pref[njobs] * k / W;
+        int best = b[k - 1];
+        for (int j = b[k - 1]; j <= njobs; ++j) if (std::fabs(pref[j] - target) < std::fabs(pref[best] - target)) best = j;
+        b[k] = best;
+    }
+    Eval best = evaluate(b);
+    for (bool improved = true; improved;) {                            // boundary moves while the pair maximum drops
+        improved = false;
+        for (int i = 1; i < W; ++i) {
+            for (int d : {-1, 1, -2, 2}) {
+                const int old = b[i], nb = old + d;
+                if (nb < b[i - 1] || nb > b[i + 1]) continue;
+                b[i] = nb;
+                const Eval e = evaluate(b);
+                if (e < best) { best = e; improved = true; } else b[i] = old;
+            }
+        }
+    }
+    // runs sorted by load: the i-th heaviest and the i-th lightest share SIMD i
+    loads(b);
+    G.mean_wave[0] = G.mean_wave[1] = -1;
+    int run_wave[FW_WAVES];
+    for (int i = 0; i < W / 2; ++i) { run_wave[order[i]] = i; run_wave[order[W - 1 - i]] = i + W / 2; }
+    {   // the lightest runs (which carry the q_mu^T row-blocks) as ranked before the row-blocks were added
+        int seg[FW_WAVES], ord2[FW_WAVES];
+        for (int k = 0; k < W; ++k) { seg[k] = pref[b[k + 1]] - pref[b[k]]; ord2[k] = k; }
+        std::sort(ord2, ord2 + W, [&](int x, int y) { return seg[x] != seg[y] ? seg[x] < seg[y] : x < y; });
+        for (int i = 0; i < nm; ++i) G.mean_wave[i] = (signed char)run_wave[ord2[i]];
+    }
+    for (int k = 0; k < W; ++k) {
+        G.jr[run_wave[k]] = (unsigned char)(b[k] / nbk);
+        G.jbi[run_wave[k]] = (unsigned char)(b[k] % nbk);
+        G.nblk[run_wave[k]] = (unsigned short)(pref[b[k + 1]] - pref[b[k]]);
+    }
 }
 
 // LDS image for a chunk of nsamp samples; fills the per-layer offsets of `a`.  stage_zt: keep every GP layer's
@@ -1021,7 +1202,7 @@ static size_t fw_plan_lds(FwArgs& a, int nsamp, int maxR, int maxP, bool stage_z
     l.lw = o; o += nsamp;
     l.rowi = o; o += nsamp;
     l.pidx = o; o += nsamp;
-    l.asq = o; o += 4 * nsamp;
+    l.asq = o; o += nsamp;
     l.meanp = o; o += maxR * nsamp;
     l.gbuf = o; o += 3 * maxR * nsamp;
     l.obuf = o; o += 2 * maxP * nsamp;
@@ -1046,9 +1227,19 @@ static size_t fw_plan_lds(FwArgs& a, int nsamp, int maxR, int maxP, bool stage_z
             if (need > scratch) scratch = need;
         }
     }
+    for (int i = 0; i < a.h.n_layers; ++i) {            // who hands whom a ready Gram operand
+        FwLayer& L = a.L[i];
+        const bool nx = i + 1 < a.h.n_layers && a.L[i + 1].type == IWVI_LAYER_GP;
+        L.nx_gp = nx ? 1 : 0;
+        L.nx_c_off = nx ? a.L[i + 1].c_off : L.c_off;
+        L.nx_nsteps = nx ? a.L[i + 1].gp.nsteps : 0;
+        L.nx_rbf = (nx && a.L[i + 1].gp.kern_type == IWVI_KERN_RBF) ? 1 : 0;
+        L.nx_ls_off = -1; L.nx_ls_n = 0; L.nx_ls = nullptr;
+    }
+    int ls_first = -1;
     if (ls_max > 0) {                                   // one staging buffer, reused layer after layer
         for (int i = 0; i < a.h.n_layers; ++i)
-            if (a.L[i].type == IWVI_LAYER_GP && a.L[i].gp.nbk <= 8) a.L[i].gp.ls_off = o;
+            if (a.L[i].type == IWVI_LAYER_GP && a.L[i].gp.nbk <= 8) { a.L[i].gp.ls_off = o; if (ls_first < 0) ls_first = i; }
         o += ls_max;
     }
     l.znoise = o;
@@ -1067,6 +1258,20 @@ static size_t fw_plan_lds(FwArgs& a, int nsamp, int maxR, int maxP, bool stage_z
         const bool v16 = vec && (n % 4 == 0) && (dst % 4 == 0) && (((uintptr_t)src) % 16 == 0);
         c.src = src; c.n = v16 ? -n : n; c.dst = dst;
     };
+    // the first staged GP layer's forward-substitution stream rides in the prologue; every later one is fetched by
+    // the GP layer before it, once that layer's solve has released the buffer
+    a.h.ls_first = ls_first;
+    for (int i = 0; i < a.h.n_layers; ++i) {
+        if (a.L[i].type != IWVI_LAYER_GP) continue;
+        for (int j = i + 1; j < a.h.n_layers; ++j) {
+            if (a.L[j].type != IWVI_LAYER_GP) continue;
+            if (a.L[j].gp.ls_off >= 0) {
+                a.L[i].nx_ls_off = a.L[j].gp.ls_off; a.L[i].nx_ls_n = tri_blocks(a.L[j].gp.nbk) * BLK16;
+                a.L[i].nx_ls = reinterpret_cast<const float*>(a.L[j].gp.LsP);
+            }
+            break;
+        }
+    }
     for (int i = 0; i < a.h.n_layers; ++i) {
         FwLayer& L = a.L[i];
         FwNoise& nz = a.N[i];

@@ -60,3 +60,5 @@ print("  end  ", np.round(np.median(w1 - st, 0)).astype(int))
 
 s1 = full[:, 118:126].astype(np.float64); g0 = cyc[:, 2 + 1 * 6 + 1].astype(np.float64)[:, None]
 print("stage 1 (layer 1) per wave end, cycles after the Gram barrier:", np.round(np.median(s1 - g0, 0)).astype(int))
+
+
