@@ -890,13 +890,54 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
             }
             __syncthreads();
             FW_STAMP(2 + li * 6 + 4);
-            // ---- epilogue (ii): mixing (:142-145) + linear mean function (layers.py:46-48) as ONE small MFMA product
-            //      out[p][j] = sum_k A[p][k] B[k][j],  A = [W | mfA^T],  B = [f_r(j) ; x_d(j)]:
+            // ---- epilogue (ii): mixing (:142-145) + linear mean function (layers.py:46-48); ahead of another GP layer
+            //      as ONE small MFMA product out[p][j] = sum_k A[p][k] B[k][j],  A = [W | mfA^T],  B = [f_r(j) ; x_d(j)]:
             //      wave t owns sample sub-tile t; the result lands as 4 outputs p = 4gq .. 4gq+3 of sample 16t + jq
             //      per lane, from which the next GP layer's x~ row is formed on the spot.
             const bool last = (li == g.n_layers - 1);
             const bool need_mv = last || o_mean || o_var;         // inner layers only hand their sample on
-            if (wave < NS) {
+            if (!nx_gp) {
+                // nothing downstream needs an x~ row (last layer, or an LV layer next): a handful of outputs per
+                // sample, one thread per (output, sample), dot products straight from LDS
+                for (int idx = tid; idx < NSAMP * P; idx += FW_THREADS) {
+                    const int p = idx / NSAMP, j = idx - p * NSAMP;
+                    const long long t = t0 + j;
+                    float o_s, o_m, o_v;
+                    if (G.W) {
+                        o_s = o_m = o_v = 0.f;
+                        if (need_mv) {
+                            for (int r0 = 0; r0 < R; r0 += 4) {
+                                float w[4], gm[4], gv[4], gs[4];
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) {
+                                    const int r = (r0 + e < R) ? r0 + e : R - 1;
+                                    w[e] = (r0 + e < R) ? Wm[p * R + r] : 0.f;
+                                    gm[e] = gbuf[(0 * R + r) * NSAMP + j]; gv[e] = gbuf[(1 * R + r) * NSAMP + j]; gs[e] = gbuf[(2 * R + r) * NSAMP + j];
+                                }
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) {
+                                    o_m = fmaf(w[e], gm[e], o_m); o_v = fmaf(w[e] * w[e], gv[e], o_v); o_s = fmaf(w[e], gs[e], o_s);
+                                }
+                            }
+                        } else o_s = dot_lds(Wm + p * R, 1, gbuf + 2 * R * NSAMP + j, NSAMP, R);
+                    } else {
+                        o_m = gbuf[(0 * R + p) * NSAMP + j]; o_v = gbuf[(1 * R + p) * NSAMP + j]; o_s = gbuf[(2 * R + p) * NSAMP + j];
+                    }
+                    float mf = 0.f;
+                    if (G.mf_type == IWVI_MF_IDENTITY) mf = xin[j * XSTR + p];
+                    else if (G.mf_type == IWVI_MF_LINEAR) {
+                        mf = dot_lds(xin + j * XSTR, 1, mfA + p, P, D);
+                        if (G.mfb) mf += mfb[p];
+                    }
+                    xout[j * XSTR + p] = o_s + mf;
+                    if (last) { obuf[p * NSAMP + j] = o_m + mf; obuf[(P + p) * NSAMP + j] = o_v; }
+                    if (j < nvalid) {
+                        if (o_sample) o_sample[t * P + p] = o_s + mf;
+                        if (o_mean) o_mean[t * P + p] = o_m + mf;
+                        if (o_var) o_var[t * P + p] = o_v;
+                    }
+                }
+            } else if (wave < NS) {
                 const int j = 16 * wave + jq;
                 const long long t = t0 + j;
                 const int Dm = (G.mf_type == IWVI_MF_LINEAR) ? D : 0;
