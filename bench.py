@@ -61,7 +61,7 @@ def f_alg_model(spec):
 
 
 class Step:
-    """One ELBO evaluation = 3 launches (precompute, fused forward, reduce), capturable into a hipGraph.
+    """One ELBO evaluation = 2 launches (precompute incl. the encoder; fused layer stack + ELBO tail), capturable into a hipGraph.
     Noise is drawn inside the forward kernel from its counter-based stream; the step counter lives on the
     device and is advanced by the launch itself, so every graph replay sees fresh noise."""
 
