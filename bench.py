@@ -65,17 +65,19 @@ class Step:
     Noise is drawn inside the forward kernel from its counter-based stream; the step counter lives on the
     device and is advanced by the launch itself, so every graph replay sees fresh noise."""
 
-    def __init__(self, model, spec, dev, shard, world):
+    def __init__(self, model, spec, dev, shard, world, exchange=None):
         self.model, self.dev, self.shard, self.world = model, dev, shard, world
+        self.exchange = (world > 1) if exchange is None else exchange
         self.B, self.K = spec["B"], spec["K"]
         self.out = torch.zeros(1, dtype=torch.float64, device=dev)
 
-    def run(self):
+    def run(self, out=None):
+        """``out``: the exchange staging buffer this evaluation's result goes to ([B, 2] pairs / 1-element ELBO)."""
         m = self.model
-        if self.shard == "k" and self.world > 1:
-            self.ms, self.glob = m.lse_partials(K_total=self.K * self.world)
+        if self.shard == "k" and self.exchange:
+            self.ms, self.glob = m.lse_partials(K_total=self.K * self.world, out=out)
             return self.ms
-        self.out = m._build_likelihood()
+        self.out = m._build_likelihood(out=out)
         return self.out
 
 
@@ -131,13 +133,20 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm device (the HIP path has no CPU fallback)")
+    local %= torch.cuda.device_count()                           # (several ranks on one device only in plumbing tests)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
-    if world > 1:
+    force_xch = world == 1 and os.environ.get("IWVI_BENCH_FORCE_XCH") == "1"   # plumbing test: the exchange path on one rank
+    if world > 1 or force_xch:
         import torch.distributed as dist
+        os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        backend = os.environ.get("IWVI_BENCH_BACKEND", "nccl")   # "nccl" is RCCL on ROCm; "gloo" only for plumbing tests
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     if args.gpus != world and rank == 0:
         print("note: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
 
@@ -151,45 +160,62 @@ def main():
         lo = (rank * cfg["B"]) % (spec["n_data"] - cfg["B"] + 1)
         spec = dict(spec, X=spec["X"][lo:], Y=spec["Y"][lo:])
     model = synthetic.build_model(spec, dev)
-    step = Step(model, spec, dev, args.shard, world)
+    step = Step(model, spec, dev, args.shard, world, exchange=(world > 1 or force_xch))
     B, K = cfg["B"], cfg["K"]
-    xch = None
-    if world > 1:
-        from dgps_with_iwvi_amd.sharding import OverlappedExchange
-        xch = OverlappedExchange(args.shard, world, B, K * world, float(spec["n_data"]) / B, dev)
-
     # ---- capture -----------------------------------------------------------------------------
     # steps per graph replay: every step is the complete evaluation (fresh noise from the device counter); several
-    # per replay only spares the host-side launch between them.  Multi-GPU runs exchange after every step: one each.
+    # per replay only spares the host-side launch between them.  Multi-GPU runs exchange the replay's evaluations in
+    # one collective (they are independent of each other; see sharding.OverlappedExchange).
+    import math
     spg = 1
-    if world == 1 and not args.no_graph:
-        import math
+    if not args.no_graph:
         spg = math.gcd(math.gcd(args.steps, args.warmup) if args.warmup else args.steps, int(os.environ.get("IWVI_BENCH_SPG", "10")))
+    xch = None
+    if world > 1 or force_xch:
+        # multi-GPU: the evaluations of one graph replay are exchanged in one collective on a side stream
+        from dgps_with_iwvi_amd.sharding import OverlappedExchange
+        xch = OverlappedExchange(args.shard, world, B, K * world, float(spec["n_data"]) / B, dev, steps=spg)
     graph = None
     step.run()
     torch.cuda.synchronize()
+
     if not args.no_graph:
         s = torch.cuda.Stream(device=dev)
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
             step.run()
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph, stream=s):
-                for _ in range(spg):
-                    step.run()
+            if xch is None:
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph, stream=s):
+                    for _ in range(spg):
+                        step.run()
+            else:
+                # one graph per staging slot: spg complete evaluations, each writing its result into the slot
+                graph = []
+                for slot in range(xch.depth):
+                    gph = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(gph, stream=s):
+                        for view in xch.slot_views(slot):
+                            step.run(out=view)
+                    graph.append(gph)
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
 
     def one_step():
-        if graph is not None:
-            graph.replay()
-        else:
-            step.run()
-        if xch is not None:          # per-step collective on a side stream: overlaps the next step's kernels
-            if args.shard == "k":
-                xch.submit(step.ms, step.glob)
+        """spg evaluations (one graph replay), plus their exchange when sharded."""
+        if xch is None:
+            if graph is not None:
+                graph.replay()
             else:
-                xch.submit(step.out)
+                step.run()
+            return
+        slot = xch.before_step()
+        if graph is not None:
+            graph[slot].replay()
+        else:
+            for view in xch.slot_views(slot):
+                step.run(out=view)
+        xch.submit(global_kls=getattr(step, "glob", None))
 
     def fence():
         if xch is not None:
@@ -205,13 +231,14 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps // spg):
         one_step()
+    t_enqueued = time.perf_counter() - t0                        # host side done; the device may still be running
     fence()
     elapsed = time.perf_counter() - t0
     if dist is not None:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
-    final_elbo = float((xch.result if xch is not None else step.out.reshape(1)).item())
+    final_elbo = float((xch.finish()[-1] if xch is not None else step.out.reshape(1)).item())
 
     # ---- dominant kernel: the fused forward (all layers), HIP events around a graph of back-to-back launches
     tot_flops, _ = f_alg_model(spec)
@@ -265,8 +292,9 @@ def main():
                        "global_batch": B * (world if args.shard == "n" else 1),
                        "K_total": K * (world if args.shard == "k" else 1),
                        "sharding": ("none" if world == 1 else args.shard + "-shard"),
-                       "launch": "eager" if graph is None else ("hipGraph replay, %d steps per replay" % spg)},
+                       "launch": "eager" if graph is None else ("hipGraph replay, %d steps per replay" % spg) + ("" if xch is None else ", one exchange per replay")},
             "elbo": final_elbo,
+            "host_enqueue_ms_per_step": t_enqueued / args.steps * 1e3,
             "roofline": {"bound": "mfma", "kernel": "k_dgp_forward (all layers fused, one launch per ELBO evaluation)", "achieved": achieved / 1e12,
                          "peak": PEAK_MFMA_F32 / 1e12, "unit": "TFLOP/s", "frac": achieved / PEAK_MFMA_F32,
                          "traffic": traffic, "traffic_source": traffic_src, "launch_ms": dom_ms,

@@ -102,6 +102,8 @@ PROTOTYPES = {
                                     c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "iwvi_lse_merge": (c_int, [c_void_p, c_int, c_int64, c_int, ctypes.POINTER(c_void_p),
                                ctypes.POINTER(ctypes.c_int32), c_int, c_double, c_void_p, c_void_p, c_void_p]),
+    "iwvi_lse_merge_steps": (c_int, [c_void_p, c_int, c_int, c_int64, c_int, ctypes.POINTER(c_void_p),
+                                     ctypes.POINTER(ctypes.c_int32), c_int, c_double, c_void_p, c_void_p, c_void_p]),
     "iwvi_gauss_kl": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "iwvi_fill_normal": (c_int, [c_void_p, c_int64, ctypes.c_uint64, ctypes.c_uint64, c_void_p]),
     "iwvi_fill_normal_dev": (c_int, [c_void_p, c_int64, ctypes.c_uint64, c_void_p, c_void_p]),

@@ -127,7 +127,8 @@ __global__ __launch_bounds__(ELBO_THREADS) void k_elbo(ReduceArgs g) {
 
 struct FinalArgs {
     const float* logp; const float* ms_all; int G;
-    long long B; int K_total; double scale;
+    long long B; long long rstride;      // points between two ranks' partials of one evaluation (B, or n_steps * B when batched)
+    int K_total; double scale;
     const double* klg[MAX_GLOB]; int klg_n[MAX_GLOB]; int n_glob;
     float* logp_out; double* elbo;
 };
@@ -136,18 +137,21 @@ struct FinalArgs {
 __global__ __launch_bounds__(1024) void k_elbo_final(FinalArgs g) {
     __shared__ double red[1024];
     double acc = 0.0;
+    // block e: evaluation e of a batch laid out [rank][evaluation][B][2] (a single evaluation: one block, rstride = B)
+    const float* ms = g.ms_all ? g.ms_all + (size_t)blockIdx.x * g.B * 2 : nullptr;
+    float* lpo = g.logp_out ? g.logp_out + (size_t)blockIdx.x * g.B : nullptr;
     for (long long b = threadIdx.x; b < g.B; b += blockDim.x) {
         float lp;
-        if (g.ms_all) {
+        if (ms) {
             float m = -INFINITY;
-            for (int r = 0; r < g.G; ++r) m = fmaxf(m, g.ms_all[((size_t)r * g.B + b) * 2]);
+            for (int r = 0; r < g.G; ++r) m = fmaxf(m, ms[((size_t)r * g.rstride + b) * 2]);
             float s = 0.f;
             for (int r = 0; r < g.G; ++r) {
-                const float* p = g.ms_all + ((size_t)r * g.B + b) * 2;
+                const float* p = ms + ((size_t)r * g.rstride + b) * 2;
                 s += p[1] * __expf(p[0] - m);
             }
             lp = m + logf(s) - logf((float)g.K_total);
-            if (g.logp_out) g.logp_out[b] = lp;
+            if (lpo) lpo[b] = lp;
         } else {
             lp = g.logp[b];
         }
@@ -163,7 +167,7 @@ __global__ __launch_bounds__(1024) void k_elbo_final(FinalArgs g) {
         double kl = 0.0;
         for (int i = 0; i < g.n_glob; ++i)
             for (int c = 0; c < g.klg_n[i]; ++c) kl += g.klg[i][c];
-        *g.elbo = red[0] * g.scale - kl;                                          // models.py:150
+        g.elbo[blockIdx.x] = red[0] * g.scale - kl;                               // models.py:150
     }
 }
 
@@ -295,12 +299,25 @@ extern "C" int iwvi_lse_merge(const float* ms_all, int G, int64_t B, int K_total
                               double scale, float* out_logp, double* out_elbo, void* stream_) {
     if (!ms_all || G <= 0 || B <= 0 || K_total <= 0) { set_error("iwvi_lse_merge: bad argument"); return IWVI_ERR_ARG; }
     FinalArgs f{};
-    f.ms_all = ms_all; f.G = G; f.B = B; f.K_total = K_total; f.scale = scale;
+    f.ms_all = ms_all; f.G = G; f.B = B; f.rstride = B; f.K_total = K_total; f.scale = scale;
     f.logp_out = out_logp; f.elbo = out_elbo;
     int rc;
     if ((rc = fill_globals(f, kl_global, kl_global_counts, n_glob)) != IWVI_OK) return rc;
     hipLaunchKernelGGL(k_elbo_final, dim3(1), dim3(1024), 0, (hipStream_t)stream_, f);
     return check_launch("k_elbo_final(merge)");
+}
+
+extern "C" int iwvi_lse_merge_steps(const float* ms_all, int G, int n_steps, int64_t B, int K_total,
+                                    const double* const* kl_global, const int32_t* kl_global_counts, int n_glob,
+                                    double scale, float* out_logp, double* out_elbo, void* stream_) {
+    if (!ms_all || !out_elbo || G <= 0 || n_steps <= 0 || B <= 0 || K_total <= 0) { set_error("iwvi_lse_merge_steps: bad argument"); return IWVI_ERR_ARG; }
+    FinalArgs f{};
+    f.ms_all = ms_all; f.G = G; f.B = B; f.rstride = (long long)n_steps * B; f.K_total = K_total; f.scale = scale;
+    f.logp_out = out_logp; f.elbo = out_elbo;
+    int rc;
+    if ((rc = fill_globals(f, kl_global, kl_global_counts, n_glob)) != IWVI_OK) return rc;
+    hipLaunchKernelGGL(k_elbo_final, dim3(n_steps), dim3(1024), 0, (hipStream_t)stream_, f);
+    return check_launch("k_elbo_final(merge, batched)");
 }
 
 static int fill_normal_impl(float* out, int64_t n, uint64_t seed, uint64_t offset, unsigned long long* state,

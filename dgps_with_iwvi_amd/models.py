@@ -168,8 +168,16 @@ class DGP_VI:
             glob_p = _abi.ptr_array(glob)
             glob_n = (ctypes.c_int32 * max(len(glob), 1))(*[g.numel() for g in glob])
             logp = torch.empty(B, dtype=settings.float_type, device=dev)
-            val = torch.empty(1, dtype=torch.float64, device=dev)
-            ms = torch.empty(B, 2, dtype=settings.float_type, device=dev) if elbo.get("want_ms") else None
+            # caller-provided result buffers (e.g. a slot of an exchange staging ring) or fresh ones
+            val = elbo.get("elbo_out")
+            val = torch.empty(1, dtype=torch.float64, device=dev) if val is None else _abi.dev_tensor(val.view(-1), "elbo_out", torch.float64)
+            ms = elbo.get("ms_out")
+            if ms is not None:
+                ms = _abi.dev_tensor(ms, "ms_out", settings.float_type)
+                if tuple(ms.shape) != (B, 2):
+                    raise ValueError("ms_out must be [B, 2]")
+            elif elbo.get("want_ms"):
+                ms = torch.empty(B, 2, dtype=settings.float_type, device=dev)
             ed = _abi.ElboDesc()
             ed.B, ed.K, ed.stride_b, ed.stride_k = B, K, elbo["stride_b"], elbo["stride_k"]
             ed.kl_global, ed.kl_global_counts, ed.n_glob = glob_p, glob_n, len(glob)
@@ -313,7 +321,7 @@ class DGP_IWVI(DGP_VI):
         self.precompute(with_encoders=True)
         return self._fused_forward(B * K, K, B, (B, K), zs=zs, sampled_kl=True)[0]
 
-    def _elbo_parts(self, zs=None, want_ms=False, K_total=None):
+    def _elbo_parts(self, zs=None, want_ms=False, K_total=None, ms_out=None, elbo_out=None):
         B, K = self.X.shape[0], self.num_samples
         if self.full_cov_over_samples:                               # literal reference path, layer by layer
             fmean, fvar, local_kls, global_kls, _, _, _ = self._forward_iw(zs)
@@ -322,17 +330,18 @@ class DGP_IWVI(DGP_VI):
         self.precompute(with_encoders=True)
         return self._fused_forward(B * K, K, B, (B, K), zs=zs, sampled_kl=True,
                                    elbo=dict(B=B, K=K, stride_b=K, stride_k=1, mode_vi=False, want_ms=want_ms,
-                                             K_total=K_total))[2]
+                                             K_total=K_total, ms_out=ms_out, elbo_out=elbo_out))[2]
 
-    def _build_likelihood(self, zs=None):
-        """The importance-weighted ELBO, reference models.py:112-150."""
-        return self._elbo_parts(zs)[0]
+    def _build_likelihood(self, zs=None, out=None):
+        """The importance-weighted ELBO, reference models.py:112-150 (``out``: optional 1-element float64 result buffer)."""
+        return self._elbo_parts(zs, elbo_out=out)[0]
 
     def E_log_p_Y(self, zs=None):
         """Per-point ``logsumexp_k(L_nk) - log K`` [B] (models.py:134-148); name from BASELINE.json."""
         return self._elbo_parts(zs)[1]
 
-    def lse_partials(self, zs=None, K_total=None):
-        """(max_k L, sum_k exp(L - max)) per point [B, 2] + the global KLs: the K-sharded exchange unit."""
-        _, _, ms = self._elbo_parts(zs, want_ms=True, K_total=K_total)
+    def lse_partials(self, zs=None, K_total=None, out=None):
+        """(max_k L, sum_k exp(L - max)) per point [B, 2] + the global KLs: the K-sharded exchange unit
+        (``out``: optional [B, 2] buffer to write the pairs into)."""
+        _, _, ms = self._elbo_parts(zs, want_ms=True, K_total=K_total, ms_out=out)
         return ms, self._global_kls()

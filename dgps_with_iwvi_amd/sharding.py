@@ -12,7 +12,7 @@ Parameters are replicated and every rank recomputes the (tiny) K_uu factorisatio
   scalar all-reduce of the per-rank ELBO estimates (their mean: the KL terms are identical on every rank).
 
 Messages are latency-bound (a few KiB), so the exchange runs on a side stream from a small staging ring and
-overlaps the next evaluation's kernels.
+overlaps the next evaluations' kernels; a forward-only loop may put several evaluations into one collective.
 """
 import ctypes
 
@@ -82,47 +82,80 @@ def n_shard_elbo(local_elbo, group=None):
 
 
 class OverlappedExchange:
-    """Per-step exchange on a side stream, overlapping the next step's kernels (GPU only).
+    """Exchange of ``steps`` consecutive, independent evaluations in ONE collective on a side stream, overlapping
+    the next evaluations' kernels (GPU only).
 
-    The step's output lives in a buffer that the next (graph-replayed) step overwrites, so the main stream first
-    copies it into one of ``depth`` staging slots; the side stream then runs the collective (+ merge) from that
-    slot.  Before a slot is reused the main stream waits for the exchange that last read it."""
+    The evaluations write their results straight into a staging slot (``slot_views(slot)[e]``: a [B, 2] buffer of
+    (max, sumexp) pairs for the K-shard, a 1-element float64 for the N-shard -- pass it as ``out=`` to
+    ``lse_partials`` / ``_build_likelihood``, typically inside a captured graph, one graph per slot).  ``submit``
+    then runs, on the side stream, one all-gather of the whole slot [steps, B, 2] + ``iwvi_lse_merge_steps``
+    (K-shard) or one all-reduce of [steps] (N-shard).  The messages are a few KiB to a few hundred KiB and
+    latency-bound, so one collective per ``steps`` evaluations costs about what one per evaluation does.
+    A forward-only evaluation loop can batch like this because evaluation e+1 does not consume evaluation e's
+    result; a training loop would exchange every step (``steps=1``).
+    Before a slot is overwritten the main stream waits for the exchange that last read it (``before_step``).
+    Everything the per-call path touches (buffers, events, the merge's argument block) is created once."""
 
-    def __init__(self, mode, world, B, K_total, scale, device, depth=2, group=None):
+    def __init__(self, mode, world, B, K_total, scale, device, depth=2, group=None, steps=1):
         assert mode in ("k", "n")
-        self.mode, self.world, self.B, self.K_total, self.scale, self.group = mode, world, B, K_total, scale, group
+        self.mode, self.world, self.B, self.K_total, self.scale, self.group = mode, world, B, K_total, float(scale), group
+        self.steps = steps
         self.comm = torch.cuda.Stream(device=device)
         self.depth, self.i = depth, 0
-        shape = (B, 2) if mode == "k" else (1,)
+        shape = (steps, B, 2) if mode == "k" else (steps,)
         dtype = torch.float32 if mode == "k" else torch.float64
         self.stage = [torch.zeros(shape, dtype=dtype, device=device) for _ in range(depth)]
-        self.done = [None] * depth
+        self.ready = [torch.cuda.Event() for _ in range(depth)]
+        self.done = [torch.cuda.Event() for _ in range(depth)]
+        self.used = [False] * depth
         self.gathered = torch.empty((world,) + shape, dtype=dtype, device=device) if mode == "k" else None
-        self.result = torch.zeros(1, dtype=torch.float64, device=device)
+        self.result = torch.zeros(steps, dtype=torch.float64, device=device)     # the last exchanged slot's ELBOs
+        self._glob_key, self._glob_args = None, None
 
-    def submit(self, out, global_kls=None):
-        """out: ms [B, 2] (K-shard) or the local ELBO (N-shard), produced on the current stream."""
-        slot = self.i % self.depth
+    def slot(self):
+        return self.i % self.depth
+
+    def slot_views(self, slot):
+        """Per-evaluation output buffers of a slot: [B, 2] float32 views (K-shard) / 1-element float64 views."""
+        st = self.stage[slot]
+        return [st[e] if self.mode == "k" else st[e:e + 1] for e in range(self.steps)]
+
+    def _merge_args(self, global_kls):
+        key = tuple(int(g.data_ptr()) for g in global_kls)
+        if key != self._glob_key:
+            glob = [_abi.dev_tensor(g.reshape(-1), "global kl", torch.float64) for g in global_kls]
+            self._glob_keep = glob
+            self._glob_args = (_abi.ptr_array(glob), (ctypes.c_int32 * max(len(glob), 1))(*[g.numel() for g in glob]), len(glob))
+            self._glob_key = key
+        return self._glob_args
+
+    def before_step(self):
+        """Main stream: make sure the slot about to be overwritten is no longer being read; returns the slot."""
+        slot = self.slot()
+        if self.used[slot]:
+            torch.cuda.current_stream().wait_event(self.done[slot])
+        return slot
+
+    def submit(self, global_kls=None):
+        """Exchange the slot the evaluations just issued on the current stream have filled."""
+        slot = self.slot()
         self.i += 1
         main = torch.cuda.current_stream()
-        if self.done[slot] is not None:
-            main.wait_event(self.done[slot])
-        self.stage[slot].copy_(out.reshape(self.stage[slot].shape), non_blocking=True)
-        ready = torch.cuda.Event()
-        ready.record(main)
+        self.ready[slot].record(main)
+        self.used[slot] = True
         with torch.cuda.stream(self.comm):
-            self.comm.wait_event(ready)
+            self.comm.wait_event(self.ready[slot])
             if self.mode == "k":
                 dist.all_gather_into_tensor(self.gathered.view(-1), self.stage[slot].view(-1), group=self.group)
-                _, elbo = merge_lse(self.gathered, self.K_total, global_kls, self.scale)
-                self.result.copy_(elbo.reshape(1))
+                arr, counts, n = self._merge_args(global_kls)
+                _abi.check(_abi.lib().iwvi_lse_merge_steps(_abi.ptr(self.gathered), self.world, self.steps, self.B, self.K_total,
+                                                           arr, counts, n, self.scale, None, _abi.ptr(self.result), _abi.stream_ptr()))
             else:
                 dist.all_reduce(self.stage[slot], op=dist.ReduceOp.SUM, group=self.group)
-                self.result.copy_(self.stage[slot] / self.world)
-            ev = torch.cuda.Event()
-            ev.record(self.comm)
-            self.done[slot] = ev
+                self.result.copy_(self.stage[slot], non_blocking=True)     # sums over ranks; finish() divides
+            self.done[slot].record(self.comm)
 
     def finish(self):
+        """Wait for the exchanges; returns the last slot's per-evaluation ELBOs [steps]."""
         torch.cuda.current_stream().wait_stream(self.comm)
-        return self.result
+        return self.result / self.world if self.mode == "n" else self.result

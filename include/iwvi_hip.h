@@ -277,6 +277,12 @@ int iwvi_lse_merge(const float* ms_all, int G, int64_t B, int K_total,
                    const double* const* kl_global_host, const int32_t* kl_global_counts_host, int n_glob,
                    double scale, float* out_logp, double* out_elbo, void* stream);
 
+/* The same for n_steps independent evaluations exchanged in ONE all-gather (forward-only evaluation loops amortise
+ * the latency-bound collective this way): ms_all [G, n_steps, B, 2] -> logp [n_steps, B] (or NULL), elbo [n_steps]. */
+int iwvi_lse_merge_steps(const float* ms_all, int G, int n_steps, int64_t B, int K_total,
+                         const double* const* kl_global_host, const int32_t* kl_global_counts_host, int n_glob,
+                         double scale, float* out_logp, double* out_elbo, void* stream);
+
 /* whitened gauss_kl alone (temp_workaround.py:186-188), K14: -> kl [1] double */
 int iwvi_gauss_kl(const float* q_mu, const float* q_sqrt, int M, int R, double* kl, void* stream);
 

@@ -397,3 +397,28 @@ def test_k_shard_merge_on_one_gpu(gpu_device):
     logp, elbo = sharding.merge_lse(gathered, 7, glob, spec["n_data"] / 40)
     assert abs(float(elbo.item()) - ref) <= 1e-6 * abs(ref), (float(elbo.item()), ref)
     np.testing.assert_allclose(_np(logp), _np(sharding.merge_lse_reference(gathered.double(), 7)), rtol=1e-5, atol=1e-4)
+
+
+@pytest.mark.gpu
+def test_batched_merge_matches_per_evaluation_merge():
+    """iwvi_lse_merge_steps on [G, steps, B, 2] == iwvi_lse_merge on each evaluation's [G, B, 2] slice."""
+    import ctypes
+    from dgps_with_iwvi_amd import _abi
+    from dgps_with_iwvi_amd.sharding import merge_lse
+    dev = torch.device("cuda:0")
+    G, S, B, K_total, scale = 3, 4, 257, 12, 7.5
+    gen = torch.Generator().manual_seed(5)
+    ms = torch.empty(G, S, B, 2)
+    ms[..., 0] = torch.randn(G, S, B, generator=gen) * 3 - 50
+    ms[..., 1] = torch.rand(G, S, B, generator=gen) * 3 + 1
+    ms = ms.to(dev)
+    kl = [torch.tensor([1.25, 0.5], dtype=torch.float64, device=dev), torch.tensor([2.0], dtype=torch.float64, device=dev)]
+    logp = torch.empty(S, B, dtype=torch.float32, device=dev)
+    elbo = torch.empty(S, dtype=torch.float64, device=dev)
+    glob_n = (ctypes.c_int32 * 2)(2, 1)
+    _abi.check(_abi.lib().iwvi_lse_merge_steps(_abi.ptr(ms), G, S, B, K_total, _abi.ptr_array(kl), glob_n, 2, scale,
+                                               _abi.ptr(logp), _abi.ptr(elbo), _abi.stream_ptr()))
+    for e in range(S):
+        lp, el = merge_lse(ms[:, e].contiguous(), K_total, kl, scale)
+        assert torch.equal(lp, logp[e])
+        assert float(el) == float(elbo[e])
