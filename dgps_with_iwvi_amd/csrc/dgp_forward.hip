@@ -672,6 +672,17 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
             const int s2_mw0 = ufirst((int)L.gp.mean_wave[0]), s2_mw1 = ufirst((int)L.gp.mean_wave[1]);
             const int s2_r0 = ufirst((int)L.gp.jr[wave]), s2_bi0 = ufirst((int)L.gp.jbi[wave]);
             gptr4 s2_P = (gptr4)G.LrTP + ((size_t)s2_r0 * ntri + tri_upper_off(nbk, s2_bi0)) * 64 + lane;
+            // the NEXT GP layer's forward-substitution stream is fetched into registers now and parked in the staging
+            // buffer once this layer's stage 2 is over (the buffer is busy until the solve below ends; an LDS-DMA left
+            // pending across stage 2 would make every LDS read there wait for all outstanding loads)
+            constexpr int LSN = (36 * 64 + FW_THREADS - 1) / FW_THREADS;   // tri_blocks(8) packed blocks of 64 float4
+            f32x4 lsn[LSN];
+            const int lsn4 = H.nx_ls_off >= 0 ? H.nx_ls_n >> 2 : 0;
+#pragma unroll
+            for (int i = 0; i < LSN; ++i) {
+                lsn[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (tid + i * FW_THREADS < lsn4) lsn[i] = ((gptr4)H.nx_ls)[tid + i * FW_THREADS];
+            }
             f32x4 ring[4];
             ring[0] = ring[1] = ring[2] = ring[3] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (s2_nblocks > 0) {
@@ -758,9 +769,6 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
             if (g.stamps && lane == 0 && li == 1) g.stamps[(size_t)blockIdx.x * 128 + 118 + wave] = clock64();
             __syncthreads();
             FW_STAMP(2 + li * 6 + 2);
-            // the staging buffer is free again: the next GP layer's forward-substitution stream lands under stage 2
-            if (H.nx_ls_off >= 0) async_copy_f32x4(H.nx_ls, sm + H.nx_ls_off, H.nx_ls_n, tid);
-
             // ---- stage 2: u block (r, bi) = sum_{bk >= bi} LrT(bi, bk) a(bk), only |u|^2 kept; mean = q_mu^T a ----
             {
                 if (wave >= FW_WAVES / 2) __builtin_amdgcn_s_setprio(1);   // the second-dispatched half loses issue arbitration otherwise
@@ -802,13 +810,17 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
                     float ssq[NS];
 #pragma unroll
                     for (int t = 0; t < NS; ++t) { acc[t] = f32x4{0.f, 0.f, 0.f, 0.f}; ssq[t] = 0.f; }
-                    const f32x4* Bp = at + (size_t)(bi * 4 + gq) * NSAMP + jq;
+                    const f32x4* Bbase = at + (size_t)gq * NSAMP + jq;   // B tile of block-row b: Bbase + b * 4 * NSAMP
+                    int brow = bi;                                // block-row of the B tile in use (wave-uniform)
                     int c = nbk - bi;                             // chunks left in the current job
                     // B tiles are read one block ahead into the other of two register sets (static alternation: the loop
-                    // is unrolled by 4), so the LDS latency hides behind this block's MFMAs
+                    // is unrolled by 4), so the LDS latency hides behind this block's MFMAs.  The body of a block is one
+                    // basic block (the next tile's row is a scalar select, not a branch) so that its operand fetches can be
+                    // scheduled BETWEEN its MFMAs: issued in front of them they would wait for the VALU port behind the
+                    // MFMA burst of the wave sharing this SIMD.
                     f32x4 bA[NS], bB[NS];
 #pragma unroll
-                    for (int t = 0; t < NS; ++t) bA[t] = Bp[16 * t];
+                    for (int t = 0; t < NS; ++t) bA[t] = Bbase[(size_t)brow * (4 * NSAMP) + 16 * t];
                     for (int q0 = 0; q0 < nblocks; q0 += 4) {
 #pragma unroll
                         for (int u = 0; u < 4; ++u) {
@@ -817,8 +829,8 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
                                 ring[(u + 3) & 3] = P[(size_t)(q + 3 < nblocks ? q + 3 : nblocks - 1) * 64];
                                 const f32x4 a_cur = ring[u];
                                 // where the next block's B tile lives: next chunk of this job, else the first chunk of the next job
-                                const int bin = (c > 1) ? bi : (bi + 1 == nbk ? 0 : bi + 1);
-                                const f32x4* Bn = (c > 1) ? Bp + 4 * NSAMP : at + (size_t)(bin * 4 + gq) * NSAMP + jq;
+                                const int brow_n = (c > 1) ? brow + 1 : (bi + 1 == nbk ? 0 : bi + 1);
+                                const f32x4* Bn = Bbase + (size_t)brow_n * (4 * NSAMP);
                                 if ((u & 1) == 0) {
 #pragma unroll
                                     for (int t = 0; t < NS; ++t) bB[t] = Bn[16 * t];
@@ -838,7 +850,16 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
                                             acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[s], bB[t][s], acc[t], 0, 0, 0);
                                     }
                                 }
-                                Bp = Bn;
+                                // issue order of the block: MFMA, the ring load, then an LDS read after every other MFMA
+                                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+#pragma unroll
+                                for (int t = 0; t < NS; ++t) {
+                                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                                }
+                                __builtin_amdgcn_sched_group_barrier(0x008, 4 * NS - 1 - 2 * NS, 0);
+                                brow = brow_n;
                                 if (--c == 0) {
                                     // row-block (r, bi) complete: add its squares, start the next one
                                     if (G.u_out) {
@@ -871,6 +892,9 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
             }
             __builtin_amdgcn_s_setprio(0);
             if (g.stamps && lane == 0 && li == 1) g.stamps[(size_t)blockIdx.x * 128 + 110 + wave] = clock64();
+#pragma unroll
+            for (int i = 0; i < LSN; ++i)
+                if (tid + i * FW_THREADS < lsn4) reinterpret_cast<f32x4*>(sm + H.nx_ls_off)[tid + i * FW_THREADS] = lsn[i];
             __syncthreads();
             FW_STAMP(2 + li * 6 + 3);
 
