@@ -103,32 +103,68 @@ __device__ __forceinline__ double readlane_d(double v, int src) {
 // Cholesky of one 16x16 diagonal block, the triangular solve of up to two 16-row blocks below it AND the inverse
 // of the factor, by ONE wave: lane l owns one row in registers -- lanes 0-15 the diagonal block's rows, lanes
 // 16-47 the rows of blocks p+1, p+2 of the column, lanes 48-63 the rows of an identity block.  The pivot and the
-// freshly scaled column are broadcast with v_readlane from the diagonal block's lanes, and the very same
+// freshly scaled column are broadcast from the diagonal block's rows, and the very same
 // per-column operations (scale by 1/l_jj, subtract l_ij l_kj) that factor the diagonal block perform
 // x L_pp^T = a on every other row -- at no extra instruction.  For the identity rows the solution is L_pp^-T,
 // which is all the inverse the rest of the pipeline needs.  16 steps, no LDS traffic, no barrier.
 // win = number of blocks below carried along (<= 2).  Writes the factor back (upper part of the diagonal block
 // zeroed), X = L_pp^-T to xT (row i, column k at [i*BLD + k]) and 1/L[j][j] to rinv[0..15].
+// The broadcasts are DPP operands, not instructions: every 16-lane group also carries the diagonal block's rows
+// (dg), so "l_kj" for any lane is lane k of its own row of 16 -- v_fmac_f64 with row_newbcast:k reads it in
+// place.  Per (column j, later column k): two v_fmac_f64_dpp (own row, diagonal-block copy) instead of two
+// v_readlane + one fma, and no SGPR traffic; the pass is bound by the instruction count of this one wave.
+template <int K>
+__device__ __forceinline__ void fmac_neg_bcast(double& d, double bsrc, double s1) {
+    asm volatile("v_fmac_f64_dpp %0, -%1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(d) : "v"(bsrc), "v"(s1), "n"(K));
+}
+template <int K>
+__device__ __forceinline__ double bcast_row(double v) {       // lane K of each row of 16; s_nop: the source may have just been written
+    double r;
+    asm volatile("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v), "n"(K));
+    return r;
+}
+template <int J, int K>
+struct WindowUpd {
+    static __device__ __forceinline__ void run(double (&a)[NB], double (&dg)[NB], double ld, double lij) {
+        fmac_neg_bcast<K>(a[K], ld, lij);                        // a[k]  -= l_kj * l_ij
+        fmac_neg_bcast<K>(dg[K], ld, ld);                        // diagonal-block copy of the same update
+        WindowUpd<J, K + 1>::run(a, dg, ld, lij);
+    }
+};
+template <int J>
+struct WindowUpd<J, NB> { static __device__ __forceinline__ void run(double (&)[NB], double (&)[NB], double, double) {} };
+template <int J>
+struct WindowCol {
+    static __device__ __forceinline__ void run(double (&a)[NB], double (&dg)[NB], double& rkeep, int i) {
+        const double ajj = bcast_row<J>(dg[J]);
+        // 1/sqrt(pivot): hardware seed (v_rsq_f64, ~2^-26) + one Newton step (-> ~1e-15); the pivot is positive (jitter)
+        const double y0 = __builtin_amdgcn_rsq(ajj);
+        const double e = fma(-(ajj * y0), y0, 1.0);
+        const double r = fma(0.5 * y0, e, y0);
+        const double lij = a[J] * r;
+        double ld = dg[J] * r;
+        a[J] = lij;
+        rkeep = (i == J) ? r : rkeep;
+        asm volatile("s_nop 1" : "+v"(ld));                       // ld: VALU write -> DPP read needs two wait states (tied to ld)
+        dg[J] = ld;
+        WindowUpd<J, J + 1>::run(a, dg, ld, lij);
+        WindowCol<J + 1>::run(a, dg, rkeep, i);
+    }
+};
+template <>
+struct WindowCol<NB> { static __device__ __forceinline__ void run(double (&)[NB], double (&)[NB], double&, int) {} };
+
 __device__ __forceinline__ void diag_factor_window(double* blk, int p, int win, double* xT, double* rinv, int lane) {
     const int i = lane & 15, lb = lane >> 4;
     const bool ident = lb == 3, live = lb <= win;
     double* rowp = ident ? xT + i * BLD : blk + boff(p + (live ? lb : 0), p) + i * BLD;
-    double a[NB];
+    const double* drow = blk + boff(p, p) + i * BLD;            // row i of the diagonal block: a copy in every group
+    double a[NB], dg[NB];
 #pragma clang loop unroll(full)
-    for (int k = 0; k < NB; ++k) a[k] = ident ? (k == i ? 1.0 : 0.0) : rowp[k];
-#pragma clang loop unroll(full)
-    for (int j = 0; j < NB; ++j) {
-        const double ajj = readlane_d(a[j], j);
-        const double r = rsqrt(ajj);
-        const double lij = a[j] * r;
-        a[j] = lij;
-        if (lane == 0) rinv[j] = r;
-#pragma clang loop unroll(full)
-        for (int k = j + 1; k < NB; ++k) {
-            const double lkj = readlane_d(lij, k);
-            a[k] = fma(-lij, lkj, a[k]);
-        }
-    }
+    for (int k = 0; k < NB; ++k) { a[k] = ident ? (k == i ? 1.0 : 0.0) : rowp[k]; dg[k] = drow[k]; }
+    double rkeep = 0.0;                              // lane j keeps 1/l_jj: one store after the pass
+    WindowCol<0>::run(a, dg, rkeep, i);
+    if (lane < NB) rinv[lane] = rkeep;
     if (live || ident) {
 #pragma clang loop unroll(full)
         for (int k = 0; k < NB; ++k) rowp[k] = (lb > 0 || k <= i) ? a[k] : 0.0;
