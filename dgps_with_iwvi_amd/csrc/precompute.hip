@@ -49,8 +49,8 @@ static unsigned long long* g_pre_stamps = nullptr;   // diagnostic; see iwvi_deb
 // on |t| <= ln2/2 (remainder < 3e-17), scaled by 2^n through the exponent field.  About 25 fp64 instructions
 // against ~100 for the library exp; the Gram is 8k of these on one CU, on the critical path of every step.
 __device__ __forceinline__ double exp_neg(double x) {
-    if (x > 700.0) return 0.0;
-    const double y = -x;
+    const bool big = x > 700.0;                     // -> 0, selected at the end: no branch, so that the independent
+    const double y = -fmin(x, 700.0);               // evaluations of one lane interleave instead of running one by one
     const double n = rint(y * 1.4426950408889634074);
     double t = fma(-n, 6.93147180369123816490e-01, y);
     t = fma(-n, 1.90821492927058770002e-10, t);
@@ -68,7 +68,7 @@ __device__ __forceinline__ double exp_neg(double x) {
     p = fma(p, t, 1.0);
     p = fma(p, t, 1.0);
     const int e = (int)n;                            // >= -1010
-    return __hiloint2double(__double2hiint(p) + (e << 20), __double2loint(p));
+    return big ? 0.0 : __hiloint2double(__double2hiint(p) + (e << 20), __double2loint(p));
 }
 
 __device__ __forceinline__ double kern_value(double r2, int type, double var) {
@@ -154,16 +154,22 @@ struct WindowCol {
 template <>
 struct WindowCol<NB> { static __device__ __forceinline__ void run(double (&)[NB], double (&)[NB], double&, int) {} };
 
-__device__ __forceinline__ void diag_factor_window(double* blk, int p, int win, double* xT, double* rinv, int lane) {
+__device__ __forceinline__ void diag_factor_window(double* blk, int p, int win, double* xT, double* rinv, int lane, unsigned long long* st = nullptr) {
     const int i = lane & 15, lb = lane >> 4;
     const bool ident = lb == 3, live = lb <= win;
     double* rowp = ident ? xT + i * BLD : blk + boff(p + (live ? lb : 0), p) + i * BLD;
     const double* drow = blk + boff(p, p) + i * BLD;            // row i of the diagonal block: a copy in every group
     double a[NB], dg[NB];
+    int io = i;                                      // opaque copy: keeps the 16 identity-row constants from being hoisted out
+    asm volatile("" : "+v"(io));                     // of the caller's column loop, where they would live in scratch memory
 #pragma clang loop unroll(full)
-    for (int k = 0; k < NB; ++k) { a[k] = ident ? (k == i ? 1.0 : 0.0) : rowp[k]; dg[k] = drow[k]; }
+    for (int k = 0; k < NB; ++k) { a[k] = rowp[k]; dg[k] = drow[k]; }   // all loads first, unconditionally (xT is valid memory)
+#pragma clang loop unroll(full)
+    for (int k = 0; k < NB; ++k) a[k] = ident ? (k == io ? 1.0 : 0.0) : a[k];
+    if (st && lane == 0) { asm volatile("s_waitcnt lgkmcnt(0) vmcnt(0)" ::: "memory"); st[14] = wall_clock64(); }
     double rkeep = 0.0;                              // lane j keeps 1/l_jj: one store after the pass
     WindowCol<0>::run(a, dg, rkeep, i);
+    if (st && lane == 0) st[15] = wall_clock64();
     if (lane < NB) rinv[lane] = rkeep;
     if (live || ident) {
 #pragma clang loop unroll(full)
@@ -221,48 +227,68 @@ __device__ __forceinline__ void blk_store(double* C, const f64x4& v, int lane) {
     for (int e = 0; e < 4; ++e) C[(g + 4 * e) * BLD + c] = v[e];
 }
 
-// Blocked right-looking Cholesky on block storage. rinv: [16*nbk] reciprocal pivots.
-// Per block column p: wave 0 factors the diagonal block, solves the next two block rows and inverts the factor in
-// the same pass (diag_factor_window; xT + p*BLK receives L_pp^-T); meanwhile the other waves post-process column
-// p-1, which is final by then (POST: the packed float32 solve stream of that column -- see role_factor).  Then
-// the panel blocks beyond the window as one f64-MFMA product each, L(i,p) = A(i,p) L_pp^-T, and the trailing
-// update (one wave per block, f64 MFMA).
-template <class POST>
-__device__ __forceinline__ void chol_blocks(double* blk, int nbk, double* rinv, double* xT, int tid, int nthreads, int dbg, POST post,
-                                            unsigned long long* stamps = nullptr) {
+// Blocked LEFT-looking Cholesky on block storage, with the matrix generated column by column.  rinv: [16*nbk]
+// reciprocal pivots.  The 16-column diagonal pass is a serial, instruction-bound chain of ONE wave (diag_factor_window:
+// factor, the next two block rows and L_pp^-T in one pass), so everything else is arranged to run beside it:
+//   up front   gen(0), gen(1): block columns 0 and 1 of the matrix (every wave)
+//   step p, A  wave 0: the diagonal pass of column p            | the other waves, one block each:
+//                                                               |   column p+1 catches up with columns k < p
+//                                                               |   (left-looking: C(i,p+1) -= L(i,k) L(p+1,k)^T),
+//                                                               |   gen(p+2), and post(p-1) (column p-1 is final)
+//   step p, B  one wave per block row i > p: L(i,p) = A(i,p) L_pp^-T for the rows beyond the pass's window, then
+//              C(i,p+1) -= L(i,p) L(p+1,p)^T  -- after which column p+1 is ready for its diagonal pass.
+// Two barriers per step; no trailing update ever sits on the critical path.
+template <class GEN, class POST>
+__device__ __forceinline__ void chol_blocks(double* blk, int nbk, double* rinv, double* xT, int tid, int nthreads, GEN gen, POST post,
+                                            unsigned long long* stamps = nullptr, int dbg = 0) {
     const int lane = tid & 63, wave = tid >> 6, nw = nthreads >> 6;
+    gen(0, nbk < 2 ? 1 : 2, wave, nw);
+    __syncthreads();
     for (int p = 0; p < nbk; ++p) {
         const int m = nbk - 1 - p;                       // block rows below the diagonal block
         const int win = m < 2 ? m : 2;                   // of which the factoring wave carries this many
         if (p == 1) PRE_STAMP(10);
-        if (wave == 0) diag_factor_window(blk, p, win, xT + (size_t)p * BLK, rinv + NB * p, lane);
-        if (p == 1) PRE_STAMP(11);
-        if (wave != 0 && p > 0) post(p - 1, tid - 64, nthreads - 64);
+        if (p == 1 && blockIdx.x == 0 && stamps && threadIdx.x == 0) stamps[7 * 16 + 10] = wall_clock64();
+        if (wave == 0) {
+            __builtin_amdgcn_s_setprio(3);               // the serial pass is the critical path: its LDS traffic goes first
+            diag_factor_window(blk, p, win, xT + (size_t)p * BLK, rinv + NB * p, lane, (stamps && p == 1) ? stamps + (size_t)blockIdx.x * 16 : nullptr);
+            __builtin_amdgcn_s_setprio(0);
+            if (p == 1) PRE_STAMP(11);
+        } else if (dbg != 77 && ((wave & 3) != 0 || nw < 8)) {
+            // the workers: every wave that does not share wave 0's SIMD (waves 4, 8, .. would slow the serial pass down)
+            const int w = (nw < 8) ? wave - 1 : wave - 1 - (wave >> 2), nwo = (nw < 8) ? nw - 1 : nw - (nw >> 2);
+            // column p+1 catches up with the factored columns k < p
+            if (p > 0) {
+                for (int b = w; b < m; b += nwo) {
+                    const int bi = p + 1 + b;
+                    double* C = blk + boff(bi, p + 1);
+                    f64x4 acc = blk_load(C, lane);
+                    for (int k = 0; k < p; ++k) blk_mma<true>(acc, blk + boff(bi, k), blk + boff(p + 1, k), lane, -1.0);
+                    blk_store(C, acc, lane);
+                }
+            }
+            if (stamps && blockIdx.x == 0 && p == 1 && lane == 0 && (w == 0 || w == 6)) stamps[7 * 16 + (w == 0 ? 3 : 5)] = wall_clock64();
+            int wg = w;                                  // generation starts with the workers the catch-up left idle
+            if (p > 0 && m < nwo) { wg = w - m; if (wg < 0) wg += nwo; }
+            if (p + 2 < nbk) gen(p + 2, p + 3, wg, nwo);
+            if (stamps && blockIdx.x == 0 && p == 1 && lane == 0 && w == 6) stamps[7 * 16 + 6] = wall_clock64();
+            if (p > 0) post(p - 1, w * 64 + lane, nwo * 64);
+            if (stamps && blockIdx.x == 0 && p == 1 && lane == 0 && (w == 0 || w == 6)) stamps[7 * 16 + (w == 0 ? 4 : 7)] = wall_clock64();
+        }
         __syncthreads();
         if (p == 1) PRE_STAMP(12);
-        if (dbg == 31) continue;
-        // panel blocks beyond the window: L(bi, p) = A(bi, p) L_pp^-T, one wave per block, in place
-        if (m > win) {
-            for (int b = wave; b < m - win; b += nw) {
-                double* A = blk + boff(p + 1 + win + b, p);
+        // block rows below: finish column p (rows beyond the window) and bring column p+1 up to date with it
+        for (int b = wave; b < m; b += nw) {
+            const int bi = p + 1 + b;
+            double* A = blk + boff(bi, p);
+            if (b >= win) {
                 f64x4 acc = {0.0, 0.0, 0.0, 0.0};
                 blk_mma<false>(acc, A, xT + (size_t)p * BLK, lane, 1.0);
                 blk_store(A, acc, lane);
             }
-            __syncthreads();
-        }
-        if (dbg == 32) continue;
-        // trailing update: blocks (bi, bj), p < bj <= bi:  C -= P_bi P_bj^T
-        const int nout = m * (m + 1) / 2;
-        for (int o = wave; o < nout; o += nw) {
-            int ri = (int)((sqrtf(8.f * o + 1.f) - 1.f) * 0.5f);
-            while ((ri + 1) * (ri + 2) / 2 <= o) ++ri;
-            while (ri * (ri + 1) / 2 > o) --ri;
-            const int rj = o - ri * (ri + 1) / 2;
-            const int bi = p + 1 + ri, bj = p + 1 + rj;
-            double* C = blk + boff(bi, bj);
+            double* C = blk + boff(bi, p + 1);
             f64x4 acc = blk_load(C, lane);
-            blk_mma<true>(acc, blk + boff(bi, p), blk + boff(bj, p), lane, -1.0);
+            blk_mma<true>(acc, A, blk + boff(p + 1, p), lane, -1.0);
             blk_store(C, acc, lane);
         }
         if (m > 0) __syncthreads();
@@ -271,6 +297,7 @@ __device__ __forceinline__ void chol_blocks(double* blk, int nbk, double* rinv, 
     post(nbk - 1, tid, nthreads);                        // the last column (everyone)
     __syncthreads();
 }
+struct NoGen { __device__ void operator()(int, int, int, int) const {} };
 struct NoPost { __device__ void operator()(int, int, int) const {} };
 
 // X = L^-1 in place: off-diagonal blocks of blk become blocks of X, diagonal blocks of X live in dinv.
@@ -380,39 +407,38 @@ __device__ void role_factor(const PreLayer& L, int stop_after, unsigned long lon
     if (stop_after == 1) return;
     // Gram in float64, lower blocks only, one wave per 16x16 block: z_i . z_j by v_mfma_f64_16x16x4_f64 (the inner
     // dimension is D <= 32), then r^2 = |z_i|^2 + |z_j|^2 - 2 z_i.z_j and the kernel value: ~35 fp64 instructions
-    // per element instead of ~100 -- on one CU this loop is the critical path of every step
-    {
-        const int lane = tid & 63, wave = tid >> 6, nw = nthreads >> 6;
+    // per element instead of ~100.  Generated block column by block column, two columns ahead of the
+    // factorisation, by the waves that are not busy with the diagonal pass (chol_blocks).
+    auto gen = [&](int bj0, int bj1, int w, int nwv) {
+        const int lane = tid & 63;
         const int r = lane & 15, g = lane >> 4, nk4 = (D + 3) >> 2;
-        const int nlow = nbk * (nbk + 1) / 2;
-        for (int o = wave; o < nlow; o += nw) {
-            int bi = (int)((sqrtf(8.f * o + 1.f) - 1.f) * 0.5f);
-            while ((bi + 1) * (bi + 2) / 2 <= o) ++bi;
-            while (bi * (bi + 1) / 2 > o) --bi;
-            const int bj = o - bi * (bi + 1) / 2;
-            f64x4 acc = {0.0, 0.0, 0.0, 0.0};
-            for (int kk = 0; kk < nk4; ++kk) {
-                const double a = (double)zs[(NB * bi + r) * ZLD + 4 * kk + g];
-                const double b = (double)zs[(NB * bj + r) * ZLD + 4 * kk + g];
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
-            }
-            const int j = NB * bj + r;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int i = NB * bi + g + 4 * e;                   // f64 C/D map: row = (lane >> 4) + 4 * reg
-                double v;
-                if (i >= M || j >= M) v = (i == j) ? 1.0 : 0.0;      // identity padding
-                else {
-                    const double r2 = fmax(znd[i] + znd[j] - 2.0 * acc[e], 0.0);
-                    v = kern_value(r2, L.kern_type, (double)L.variance);
-                    if (i == j) v += L.jitter;
+        int o = w;
+        for (int bj = bj0; bj < bj1; ++bj) {
+            const int nb_col = nbk - bj;
+            for (; o < nb_col; o += nwv) {
+                const int bi = bj + o;
+                f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+                for (int kk = 0; kk < nk4; ++kk) {
+                    const double a = (double)zs[(NB * bi + r) * ZLD + 4 * kk + g];
+                    const double b = (double)zs[(NB * bj + r) * ZLD + 4 * kk + g];
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
                 }
-                blk[boff(bi, bj) + (g + 4 * e) * BLD + r] = v;
+                const int j = NB * bj + r;
+                const double nj = znd[j];
+                const bool pad_blk = (NB * bi + NB > M) || (NB * bj + NB > M);   // only the last block row / column can hold padding
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int i = NB * bi + g + 4 * e;                   // f64 C/D map: row = (lane >> 4) + 4 * reg
+                    const double r2 = fmax(znd[i] + nj - 2.0 * acc[e], 0.0);
+                    double v = kern_value(r2, L.kern_type, (double)L.variance);
+                    if (bi == bj) v += (i == j) ? L.jitter : 0.0;
+                    if (pad_blk) v = (i >= M || j >= M) ? ((i == j) ? 1.0 : 0.0) : v;   // identity padding
+                    blk[boff(bi, bj) + (g + 4 * e) * BLD + r] = v;
+                }
             }
+            o -= nb_col;                                                 // continue the round-robin in the next column
         }
-    }
-    __syncthreads();
-    PRE_STAMP(8);
+    };
     if (tid < 64) {                                                  // extent of the inducing cloud in lengthscale units:
         float mx = 0.f;                                              // the layer kernel picks its Gram form by it
         for (int m = tid; m < M; m += 64) mx = fmaxf(mx, zn[m]);
@@ -443,31 +469,39 @@ __device__ void role_factor(const PreLayer& L, int stop_after, unsigned long lon
     // post-processing of a finished block column bj, run by the waves that do not factor: the packed float32 solve
     // stream of the column (its first block is the inverse of the diagonal block, from the factoring wave), column-block major: [L(bj,bj)^-1, -L(bj+1,bj), .., -L(nbk-1,bj)]; identity padding -> 0
     auto post = [&](int bj, int t, int nt) {
-        const int w = t >> 6, ln = t & 63;
-        float* dst = L.LsP + (size_t)tri_upper_off(nbk, bj) * BLK16;
-        if (w == 0) {
-            for (int e1 = ln; e1 < BLK16; e1 += 64) {            // L(bj,bj)^-1 = transpose of the factoring wave's L^-T
-                const int lane = e1 >> 2, sgm = e1 & 3;
-                const int ii = lane & 15, kk = 4 * (lane >> 4) + sgm;
-                const int i = 16 * bj + ii, k = 16 * bj + kk;
-                float v = 0.f;
-                if (i < M && k < M) { if (kk <= ii) v = (float)dinv[(size_t)bj * BLK + kk * BLD + ii]; }
-                else if (i == k) v = 1.f;                        // padded rows solve to 0 against k = 0 anyway
-                dst[e1] = v;
+        // one item = one lane's four consecutive floats of a packed block (one 16-byte store): lane (g, ii) holds
+        // G[ii][4g .. 4g+3]; item 0..63 of block 0 is the diagonal block's inverse, then the blocks below it
+        float4* dst = reinterpret_cast<float4*>(L.LsP + (size_t)tri_upper_off(nbk, bj) * BLK16);
+        const int nblk = nbk - bj;                               // diagonal block + the blocks below it
+        const bool full = (M == Mp);
+        for (int it = t; it < nblk * 64; it += nt) {
+            const int b = it >> 6, ln = it & 63;
+            const int ii = ln & 15, k0 = 4 * (ln >> 4);
+            float v[4];
+            if (b == 0) {                                        // L(bj,bj)^-1 = transpose of the factoring wave's L^-T
+#pragma unroll
+                for (int sgm = 0; sgm < 4; ++sgm) {
+                    const int kk = k0 + sgm;
+                    const double x = dinv[(size_t)bj * BLK + kk * BLD + ii];
+                    const int i = 16 * bj + ii, k = 16 * bj + kk;
+                    float f = (kk <= ii) ? (float)x : 0.f;
+                    if (!full) f = (i < M && k < M) ? f : ((i == k) ? 1.f : 0.f);   // padded rows solve to 0 against k = 0 anyway
+                    v[sgm] = f;
+                }
+            } else {
+                const int bi = bj + b;
+                const double* src = blk + boff(bi, bj) + ii * BLD + k0;
+#pragma unroll
+                for (int sgm = 0; sgm < 4; ++sgm) {
+                    float f = -(float)src[sgm];
+                    if (!full) f = (16 * bi + ii < M && 16 * bj + k0 + sgm < M) ? f : 0.f;
+                    v[sgm] = f;
+                }
             }
-        } else {
-            const int nblk = nbk - 1 - bj;
-            for (int idx = t - 64; idx < nblk * BLK16; idx += nt - 64) {
-                const int b = idx >> 8, e1 = idx & 255;
-                const int bi = bj + 1 + b;
-                const int lane = e1 >> 2, sgm = e1 & 3;
-                const int ii = lane & 15, kk = 4 * (lane >> 4) + sgm;
-                const int i = 16 * bi + ii, k = 16 * bj + kk;
-                dst[(size_t)(1 + b) * BLK16 + e1] = (i < M && k < M) ? -(float)blk[boff(bi, bj) + ii * BLD + kk] : 0.f;
-            }
+            dst[it] = make_float4(v[0], v[1], v[2], v[3]);
         }
     };
-    chol_blocks(blk, nbk, rinv, dinv, tid, nthreads, stop_after, post, stamps);
+    chol_blocks(blk, nbk, rinv, dinv, tid, nthreads, gen, post, stamps, stop_after);
     PRE_STAMP(3);
     if (stop_after == 3 || stop_after > 30) return;
     PRE_STAMP(4);
@@ -666,7 +700,7 @@ __global__ __launch_bounds__(1024) void k_chol_only(const double* A, double* Lou
         blk[boff(bi, bj) + (e >> 4) * BLD + (e & 15)] = (i < M && j < M) ? A[(size_t)i * M + j] : ((i == j) ? 1.0 : 0.0);
     }
     __syncthreads();
-    chol_blocks(blk, nbk, rinv, ws + (size_t)(nbk * (nbk + 1) / 2) * BLK, tid, nthreads, 0, NoPost());
+    chol_blocks(blk, nbk, rinv, ws + (size_t)(nbk * (nbk + 1) / 2) * BLK, tid, nthreads, NoGen(), NoPost());
     for (int idx = tid; idx < M * M; idx += nthreads) {
         const int i = idx / M, k = idx - i * M;
         Lout[idx] = (k <= i) ? blk_get(blk, i, k) : 0.0;
