@@ -234,12 +234,13 @@ __device__ __forceinline__ void blk_store(double* C, const f64x4& v, int lane) {
 //   step p, A  wave 0: the diagonal pass of column p            | the other waves, one block each:
 //                                                               |   column p+1 catches up with columns k < p
 //                                                               |   (left-looking: C(i,p+1) -= L(i,k) L(p+1,k)^T),
-//                                                               |   gen(p+2), and post(p-1) (column p-1 is final)
+//                                                               |   gen(p+2), and post(p-1) (column p-1 is final);
+//                                                               |   beside the last pass: tail()
 //   step p, B  one wave per block row i > p: L(i,p) = A(i,p) L_pp^-T for the rows beyond the pass's window, then
 //              C(i,p+1) -= L(i,p) L(p+1,p)^T  -- after which column p+1 is ready for its diagonal pass.
 // Two barriers per step; no trailing update ever sits on the critical path.
-template <class GEN, class POST>
-__device__ __forceinline__ void chol_blocks(double* blk, int nbk, double* rinv, double* xT, int tid, int nthreads, GEN gen, POST post,
+template <class GEN, class POST, class TAIL>
+__device__ __forceinline__ void chol_blocks(double* blk, int nbk, double* rinv, double* xT, int tid, int nthreads, GEN gen, POST post, TAIL tail,
                                             unsigned long long* stamps = nullptr, int dbg = 0) {
     const int lane = tid & 63, wave = tid >> 6, nw = nthreads >> 6;
     gen(0, nbk < 2 ? 1 : 2, wave, nw);
@@ -248,7 +249,6 @@ __device__ __forceinline__ void chol_blocks(double* blk, int nbk, double* rinv, 
         const int m = nbk - 1 - p;                       // block rows below the diagonal block
         const int win = m < 2 ? m : 2;                   // of which the factoring wave carries this many
         if (p == 1) PRE_STAMP(10);
-        if (p == 1 && blockIdx.x == 0 && stamps && threadIdx.x == 0) stamps[7 * 16 + 10] = wall_clock64();
         if (wave == 0) {
             __builtin_amdgcn_s_setprio(3);               // the serial pass is the critical path: its LDS traffic goes first
             diag_factor_window(blk, p, win, xT + (size_t)p * BLK, rinv + NB * p, lane, (stamps && p == 1) ? stamps + (size_t)blockIdx.x * 16 : nullptr);
@@ -267,13 +267,11 @@ __device__ __forceinline__ void chol_blocks(double* blk, int nbk, double* rinv, 
                     blk_store(C, acc, lane);
                 }
             }
-            if (stamps && blockIdx.x == 0 && p == 1 && lane == 0 && (w == 0 || w == 6)) stamps[7 * 16 + (w == 0 ? 3 : 5)] = wall_clock64();
             int wg = w;                                  // generation starts with the workers the catch-up left idle
             if (p > 0 && m < nwo) { wg = w - m; if (wg < 0) wg += nwo; }
             if (p + 2 < nbk) gen(p + 2, p + 3, wg, nwo);
-            if (stamps && blockIdx.x == 0 && p == 1 && lane == 0 && w == 6) stamps[7 * 16 + 6] = wall_clock64();
             if (p > 0) post(p - 1, w * 64 + lane, nwo * 64);
-            if (stamps && blockIdx.x == 0 && p == 1 && lane == 0 && (w == 0 || w == 6)) stamps[7 * 16 + (w == 0 ? 4 : 7)] = wall_clock64();
+            if (p == nbk - 1) tail(w * 64 + lane, nwo * 64);     // work nobody waits for, beside the last (otherwise idle) pass
         }
         __syncthreads();
         if (p == 1) PRE_STAMP(12);
@@ -298,6 +296,7 @@ __device__ __forceinline__ void chol_blocks(double* blk, int nbk, double* rinv, 
     __syncthreads();
 }
 struct NoGen { __device__ void operator()(int, int, int, int) const {} };
+struct NoTail { __device__ void operator()(int, int) const {} };
 struct NoPost { __device__ void operator()(int, int, int) const {} };
 
 // X = L^-1 in place: off-diagonal blocks of blk become blocks of X, diagonal blocks of X live in dinv.
@@ -439,20 +438,23 @@ __device__ void role_factor(const PreLayer& L, int stop_after, unsigned long lon
             o -= nb_col;                                                 // continue the round-robin in the next column
         }
     };
-    if (tid < 64) {                                                  // extent of the inducing cloud in lengthscale units:
-        float mx = 0.f;                                              // the layer kernel picks its Gram form by it
-        for (int m = tid; m < M; m += 64) mx = fmaxf(mx, zn[m]);
-        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
-        if (tid == 0) L.cst[64] = mx;
-    }
-    PRE_STAMP(9);
-    {
+    // what only the layer kernel needs (nothing here waits for it): done by the worker waves beside the last diagonal pass
+    auto tail = [&](int t, int nt) {
+        if (t < 64) {                                                // extent of the inducing cloud in lengthscale units:
+            float mx = 0.f;                                          // the layer kernel picks its Gram form by it
+            for (int m = t; m < M; m += 64) mx = fmaxf(mx, zn[m]);
+            for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+            if (t == 0) L.cst[64] = mx;
+        }
+        // Gram operand of K_uf in A-fragment order
         const int nsteps = round_up(D + 2, 4) / 4;
         const bool rbf = L.kern_type == IWVI_KERN_RBF;
         const double c = 1.4426950408889634;
         const double l2v = log2((double)L.variance);
-        for (int idx = tid; idx < nbk * nsteps * 64; idx += nthreads) {
-            const int lane = idx & 63, s = (idx >> 6) % nsteps, bi = (idx >> 6) / nsteps;
+        const float rns = 1.0f / (float)nsteps;
+        for (int idx = t; idx < nbk * nsteps * 64; idx += nt) {
+            const int lane = idx & 63, wb = idx >> 6;
+            const int bi = (int)(((float)wb + 0.5f) * rns), s = wb - bi * nsteps;   // exact for these small integers
             const int m = 16 * bi + (lane & 15), f = 4 * s + (lane >> 4);
             float v = 0.f;
             if (m < M) {
@@ -462,8 +464,7 @@ __device__ void role_factor(const PreLayer& L, int stop_after, unsigned long lon
             } else if (f == D + 1 && rbf) v = -1.0e30f;              // padding rows: k = exp2(-huge) = 0
             L.ZtP[idx] = v;
         }
-    }
-    __syncthreads();
+    };
     PRE_STAMP(2);
     if (stop_after == 2) return;
     // post-processing of a finished block column bj, run by the waves that do not factor: the packed float32 solve
@@ -501,7 +502,7 @@ __device__ void role_factor(const PreLayer& L, int stop_after, unsigned long lon
             dst[it] = make_float4(v[0], v[1], v[2], v[3]);
         }
     };
-    chol_blocks(blk, nbk, rinv, dinv, tid, nthreads, gen, post, stamps, stop_after);
+    chol_blocks(blk, nbk, rinv, dinv, tid, nthreads, gen, post, tail, stamps, stop_after);
     PRE_STAMP(3);
     if (stop_after == 3 || stop_after > 30) return;
     PRE_STAMP(4);
@@ -700,7 +701,7 @@ __global__ __launch_bounds__(1024) void k_chol_only(const double* A, double* Lou
         blk[boff(bi, bj) + (e >> 4) * BLD + (e & 15)] = (i < M && j < M) ? A[(size_t)i * M + j] : ((i == j) ? 1.0 : 0.0);
     }
     __syncthreads();
-    chol_blocks(blk, nbk, rinv, ws + (size_t)(nbk * (nbk + 1) / 2) * BLK, tid, nthreads, NoGen(), NoPost());
+    chol_blocks(blk, nbk, rinv, ws + (size_t)(nbk * (nbk + 1) / 2) * BLK, tid, nthreads, NoGen(), NoPost(), NoTail());
     for (int idx = tid; idx < M * M; idx += nthreads) {
         const int i = idx / M, k = idx - i * M;
         Lout[idx] = (k <= i) ? blk_get(blk, i, k) : 0.0;

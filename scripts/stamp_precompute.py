@@ -24,15 +24,12 @@ for _ in range(20):
     rows.append(buf.view(8, 16).cpu().numpy().copy())
 lib.iwvi_debug_set_pre_stamps(None)
 r = np.stack(rows)[:, 0, :7].astype(np.float64)      # layer 0
-names = ["Zs+centre", "zmax+Zt", "Gram+cholesky", "-", "-", "(dense)"]
+names = ["Zs+centre", "-", "Gram+cholesky (+Z~, zmax beside the last pass)", "-", "-", "(dense)"]
 d = np.diff(r, axis=1) * 10e-3
 for n, col in zip(names, d.T):
     print("%-10s med %6.2f us" % (n, np.median(col)))
 print("total      med %6.2f us" % np.median((r[:, 6] - r[:, 0]) * 10e-3))
 r2 = np.stack(rows)[:, 0, :].astype(np.float64)
-for a, b, n in ((1, 9, "zmax"), (9, 2, "ZtP"), (10, 11, "p=1 diagonal pass (w0)"), (10, 14, "   rows loaded"), (14, 15, "   16 columns"), (15, 11, "   stored"), (11, 12, "p=1 wait for the other waves"), (12, 13, "p=1 rows below")):
+for a, b, n in ((10, 11, "p=1 diagonal pass (w0)"), (10, 14, "   rows loaded"), (14, 15, "   16 columns"), (15, 11, "   stored"), (11, 12, "p=1 wait for the other waves"), (12, 13, "p=1 rows below")):
     print("%-24s med %6.2f us" % (n, np.median((r2[:, b] - r2[:, a]) * 10e-3)))
 
-r7 = np.stack(rows)[:, 7, :].astype(np.float64)
-for a, b, n in ((10, 3, "worker 0: catch-up block done"), (3, 4, "worker 0: post done"), (10, 5, "worker 6: reaches gen"), (5, 6, "worker 6: gen block done"), (6, 7, "worker 6: post done")):
-    print("%-32s med %6.2f us" % (n, np.median((r7[:, b] - r7[:, a]) * 10e-3)))
