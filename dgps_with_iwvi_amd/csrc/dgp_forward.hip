@@ -122,7 +122,7 @@ struct FwHead {
 };
 // prologue work lists, built by the host: plain contiguous copies global -> LDS (every small operand of every layer)
 // and the per-layer noise slots; they ride in the LDS copy of the table, one entry per wave-iteration
-struct FwCopy { const float* src; int n; int dst; };           // n floats to LDS float offset dst; n < 0: 16-byte pieces
+struct alignas(16) FwCopy { const float* src; int n; int dst; };           // n floats to LDS float offset dst; n < 0: 16-byte pieces
 struct FwNoise { const float* src; int dims, z_off, zero, layer; };
 constexpr int FW_MAX_COPY = 6 * IWVI_MAX_STACK;
 struct FwArgs {
@@ -238,6 +238,11 @@ __device__ __forceinline__ T uniform_words(const T& s) {
     // indexed at run time would be placed in scratch)
     return G;
 }
+
+// x / n for 0 <= x < 2^20 and a small positive divisor, through the reciprocal rcp = 1.0f / n: exact there
+// ((x + 0.5) / n is at least 0.5 / n away from an integer, the product's rounding error is far smaller);
+// a run-time integer division costs ~40 instructions per lane
+__device__ __forceinline__ int div_small(int x, float rcp) { return (int)(((float)x + 0.5f) * rcp); }
 
 // sum_k a[k * sa] * b[k * sb], k < n, accumulated in index order.  The loads of eight terms are issued together
 // (clamped indices, masked products): a plain run-time-trip loop pays one LDS round trip per term.
@@ -376,27 +381,39 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
     const unsigned p_first = ut0 / g.row_div;
     const unsigned p_last = (ut0 + nvalid - 1) / g.row_div;
     const int npts = (int)(p_last - p_first) + 1;                 // distinct data points in this chunk
+    // data row of sample j of the chunk: ((t0 + j) / row_div) % row_mod without a per-lane division: the uniform parts
+    // once, the small remainders through a reciprocal (row_div, row_mod < 2^31; j < NSAMP)
+    const unsigned rem0 = ut0 - p_first * (unsigned)g.row_div;    // (t0 + j) / row_div = p_first + (rem0 + j) / row_div
+    const unsigned pf_mod = p_first % (unsigned)g.row_mod;
+    const float rcp_div = 1.0f / (float)g.row_div;
+    const bool small_div = g.row_div < (1 << 18), wide_mod = g.row_mod >= NSAMP;
+    auto point_of = [&](int j) -> unsigned {                      // index of sample j's data point relative to p_first
+        const unsigned tj = ut0 + j < uT ? (unsigned)j : (uT - 1 - ut0);
+        return small_div ? (unsigned)div_small((int)(rem0 + tj), rcp_div) : (rem0 + tj) / (unsigned)g.row_div;
+    };
+    auto row_of = [&](unsigned dp) -> unsigned {                  // data row of point p_first + dp
+        unsigned r = pf_mod + dp;
+        if (wide_mod) { if (r >= (unsigned)g.row_mod) r -= (unsigned)g.row_mod; } else r %= (unsigned)g.row_mod;
+        return r;
+    };
     if (tid < NSAMP) {
-        const unsigned t = ut0 + tid;
-        const unsigned p = (t < uT ? t : uT - 1) / g.row_div;
-        const int row = (int)(p % g.row_mod);
-        rowi[tid] = row;
-        pidx[tid] = (int)(p - p_first);
+        const unsigned dp = point_of(tid);
+        rowi[tid] = (int)row_of(dp);
+        pidx[tid] = (int)dp;
         lw[tid] = 0.f;
     }
     // the chunk's rows of X (models.py:113 / :50 tiling done here) and of the encoder input
     for (int idx = tid; idx < NSAMP * g.Dx; idx += FW_THREADS) {
-        const int j = idx / g.Dx, d = idx - j * g.Dx;
-        const unsigned t = ut0 + j;
-        const unsigned row = ((t < uT ? t : uT - 1) / g.row_div) % g.row_mod;
+        const int d = idx / NSAMP, j = idx - d * NSAMP;            // (compile-time divisor)
+        const unsigned row = row_of(point_of(j));
         xin[j * XSTR + d] = (j < nvalid) ? g.X[(size_t)row * g.Dx + d] : 0.f;
     }
     if (g.XY) {
         const int xs = up4(g.XYdim);
+        const float rcp = 1.0f / (float)g.XYdim;
         for (int idx = tid; idx < npts * g.XYdim; idx += FW_THREADS) {
-            const int p = idx / g.XYdim, i = idx - p * g.XYdim;
-            const unsigned row = (p_first + p) % g.row_mod;
-            xyrows[p * xs + i] = g.XY[(size_t)row * g.XYdim + i];
+            const int p = div_small(idx, rcp), i = idx - p * g.XYdim;
+            xyrows[p * xs + i] = g.XY[(size_t)row_of((unsigned)p) * g.XYdim + i];
         }
     }
     __syncthreads();                                              // layer table (and rowi / pidx) visible
@@ -408,17 +425,25 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
         if (!eo) continue;
         const int no = 2 * ufirst(LT[li].lv.Lw);
         float* dst = sm + ufirst(LT[li].c_off);
-        for (int idx = tid; idx < npts * no; idx += FW_THREADS) {
-            const int p = idx / no, o = idx - p * no;
-            const unsigned row = (p_first + p) % g.row_mod;
-            dst[idx] = ((gptr1)eo)[(size_t)row * no + o];
+        const float rcp = 1.0f / (float)no;
+        for (int i0 = (tid & ~63); i0 < npts * no; i0 += FW_THREADS) {     // a gather by LDS-DMA: nothing waits here
+            const int idx = i0 + lane;
+            const int p = div_small(idx < npts * no ? idx : 0, rcp), o = idx - p * no;
+            if (idx < npts * no)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(eo + (size_t)row_of((unsigned)p) * no + o),
+                                                 (__attribute__((address_space(3))) void*)(dst + i0), 4, 0, 0);
         }
     }
     // copy list: one entry per wave at a time, all DMA loads in flight together
+    if (g.ls_first >= 0) {                                         // the largest piece first (36 KiB at M = 128), spread over every wave
+        const FwGp& G0 = LT[g.ls_first].gp;
+        async_copy_f32x4(reinterpret_cast<const float*>(ufirst(G0.LsP)), sm + ufirst(G0.ls_off), tri_blocks(ufirst(G0.nbk)) * BLK16, tid);
+    }
     for (int ci = wave; ci < g.ncopy; ci += FW_WAVES) {
-        const float* src = ufirst(CT[ci].src);
-        const int n = ufirst(CT[ci].n);
-        float* dst = sm + ufirst(CT[ci].dst);
+        const FwCopy ce = uniform_words(CT[ci]);                   // one 16-byte LDS read per entry
+        const float* src = ce.src;
+        const int n = ce.n;
+        float* dst = sm + ce.dst;
         const int wl = lane;                                       // this wave alone moves the entry
         if (!src) { for (int i = wl; i < n; i += 64) dst[i] = 0.f; }           // absent operand (e.g. no encoder bias)
         else if (n < 0) { for (int i0 = 0; i0 < (-n >> 2); i0 += 64) if (i0 + wl < (-n >> 2))
@@ -427,10 +452,6 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
         else { for (int i0 = 0; i0 < n; i0 += 64) if (i0 + wl < n)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + i0 + wl),
                                                  (__attribute__((address_space(3))) void*)(dst + i0), 4, 0, 0); }
-    }
-    if (g.ls_first >= 0) {                                         // 36 KiB at M = 128: spread over every wave
-        const FwGp& G0 = LT[g.ls_first].gp;
-        async_copy_f32x4(reinterpret_cast<const float*>(ufirst(G0.LsP)), sm + ufirst(G0.ls_off), tri_blocks(ufirst(G0.nbk)) * BLK16, tid);
     }
     // injected noise [T, dims] -> znoise[z_off + r * NSAMP + j] (a gather: the DMA source is per lane)
     for (int li = 0; li < g.n_layers; ++li) {
