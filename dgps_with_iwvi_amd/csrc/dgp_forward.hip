@@ -113,7 +113,6 @@ struct FwHead {
     unsigned long long seed; unsigned long long* rng_state;
     float* out_logw;
     unsigned long long* stamps;      // diagnostic only (iwvi_debug_set_stamps): 128 words per workgroup
-    int dbg;                         // diagnostic only (IWVI_DEBUG_ABLATE): timing ablations, results are wrong
     int ncopy;
     int ls_first;                    // first GP layer whose solve stream is staged in LDS (fetched in the prologue), or -1
     int xstr;                        // row stride of the activation tiles: odd, >= max(D + 2 padded to 4, P) of the stack
@@ -758,7 +757,7 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
                         for (int u = 0; u < 4; ++u) {
                             const int q = q0 + u;
                             if (q < ntri) {
-                                if (!(g.dbg & 1)) ring[(u + 3) & 3] = Ap[(size_t)(q + 3 < ntri ? q + 3 : ntri - 1) * 64];
+                                ring[(u + 3) & 3] = Ap[(size_t)(q + 3 < ntri ? q + 3 : ntri - 1) * 64];
                                 const f32x4 a_cur = ring[u];
                                 if (bi == bj) {
                                     res = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -770,12 +769,11 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
                                         *((gout4)((gout1)G.a_out + (size_t)(t0 + tcol) * G.Mp + 16 * bj + 4 * gq)) = res;
                                 } else {
                                     const f32x4* src = at;                        // == kuf: solved in place
-                                    f32x4 y = (g.dbg & 2) ? xcur : src[(bi * 4 + gq) * NSAMP + tcol];
+                                    f32x4 y = src[(bi * 4 + gq) * NSAMP + tcol];
     #pragma unroll
                                     for (int s = 0; s < 4; ++s) y = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[s], res[s], y, 0, 0, 0);
                                     if (bi == bj + 1) xcur = y;                  // next column's right-hand side, kept in registers
-                                    else if (!(g.dbg & 2)) at[(bi * 4 + gq) * NSAMP + tcol] = y;
-                                    else asm volatile("" :: "v"(y));
+                                    else at[(bi * 4 + gq) * NSAMP + tcol] = y;
                                 }
                                 ++bi;
                                 if (bi == nbk) { ++bj; bi = bj; }
@@ -1514,7 +1512,6 @@ int dgp_forward_impl(const iwvi_layer_desc* layers, int n_layers, const float* X
     const long long chunks = (T + 16 * ns - 1) / (16 * ns);
     if (chunks > 0x7fffffffLL) { set_error("iwvi_dgp_forward: T too large"); return IWVI_ERR_ARG; }
     a.h.stamps = (g_stamp_buf && chunks <= g_stamp_wgs) ? g_stamp_buf : nullptr;
-    { static int dbg = -1; if (dbg < 0) { const char* e = getenv("IWVI_DEBUG_ABLATE"); dbg = e ? atoi(e) : 0; } a.h.dbg = dbg; }
     switch (ns) {
         case 1: return launch_forward<1>(a, (unsigned)chunks, lds_bytes, stream);
         case 2: return launch_forward<2>(a, (unsigned)chunks, lds_bytes, stream);

@@ -241,7 +241,7 @@ __device__ __forceinline__ void blk_store(double* C, const f64x4& v, int lane) {
 // Two barriers per step; no trailing update ever sits on the critical path.
 template <class GEN, class POST, class TAIL>
 __device__ __forceinline__ void chol_blocks(double* blk, int nbk, double* rinv, double* xT, int tid, int nthreads, GEN gen, POST post, TAIL tail,
-                                            unsigned long long* stamps = nullptr, int dbg = 0) {
+                                            unsigned long long* stamps = nullptr) {
     const int lane = tid & 63, wave = tid >> 6, nw = nthreads >> 6;
     gen(0, nbk < 2 ? 1 : 2, wave, nw);
     __syncthreads();
@@ -254,7 +254,7 @@ __device__ __forceinline__ void chol_blocks(double* blk, int nbk, double* rinv, 
             diag_factor_window(blk, p, win, xT + (size_t)p * BLK, rinv + NB * p, lane, (stamps && p == 1) ? stamps + (size_t)blockIdx.x * 16 : nullptr);
             __builtin_amdgcn_s_setprio(0);
             if (p == 1) PRE_STAMP(11);
-        } else if (dbg != 77 && ((wave & 3) != 0 || nw < 8)) {
+        } else if ((wave & 3) != 0 || nw < 8) {
             // the workers: every wave that does not share wave 0's SIMD (waves 4, 8, .. would slow the serial pass down)
             const int w = (nw < 8) ? wave - 1 : wave - 1 - (wave >> 2), nwo = (nw < 8) ? nw - 1 : nw - (nw >> 2);
             // column p+1 catches up with the factored columns k < p
@@ -502,7 +502,7 @@ __device__ void role_factor(const PreLayer& L, int stop_after, unsigned long lon
             dst[it] = make_float4(v[0], v[1], v[2], v[3]);
         }
     };
-    chol_blocks(blk, nbk, rinv, dinv, tid, nthreads, gen, post, tail, stamps, stop_after);
+    chol_blocks(blk, nbk, rinv, dinv, tid, nthreads, gen, post, tail, stamps);
     PRE_STAMP(3);
     if (stop_after == 3 || stop_after > 30) return;
     PRE_STAMP(4);
