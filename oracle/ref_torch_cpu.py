@@ -68,6 +68,11 @@ class CpuDGP:
         return fmean + z * fvar ** 0.5, fmean, fvar                                                # :91
 
     def elbo(self, zs):
+        return float(self.elbo_tensor(zs))
+
+    def elbo_tensor(self, zs):
+        """The IW-ELBO as a tensor (differentiable w.r.t. whichever parameter tensors require grad: the gradient
+        oracle of oracle/grad_oracle.py)."""
         B, K = self.X.shape[0], self.K
         F = self.X[:, None, :].repeat(1, K, 1)                                                     # models.py:113
         Yt = self.Y[:, None, :].repeat(1, K, 1)
@@ -106,10 +111,11 @@ class CpuDGP:
                                - torch.log(torch.diagonal(Lq, dim1=-2, dim2=-1) ** 2).sum() + (Lq ** 2).sum()))
         if cov.dim() == 4:
             cov = torch.diagonal(cov, dim1=-2, dim2=-1).transpose(1, 2)                            # models.py:133
-        ve = -0.5 * math.log(2 * math.pi) - 0.5 * math.log(self.lik_var) \
-            - 0.5 * ((Yt - mean) ** 2 + cov) / self.lik_var                                        # :134
+        lik_var = torch.as_tensor(self.lik_var, dtype=self.dtype)
+        ve = -0.5 * math.log(2 * math.pi) - 0.5 * torch.log(lik_var) \
+            - 0.5 * ((Yt - mean) ** 2 + cov) / lik_var                                             # :134
         L_NK = ve.sum(2)
         for kl in local:
             L_NK = L_NK - kl.sum(2)
         logp = torch.logsumexp(L_NK, 1) - math.log(K)                                              # :148
-        return float(logp.sum() * (self.n_data / B) - sum(glob))                                   # :150
+        return logp.sum() * (self.n_data / B) - sum(glob)                                          # :150

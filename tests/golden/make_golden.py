@@ -31,6 +31,9 @@ CASES = {
 }
 
 
+GRAD_CASES = ("tiny_L2_lv", "mid_L2_lv")
+
+
 def spec_to_arrays(spec):
     out = dict(X=spec["X"][:spec["B"]], Y=spec["Y"][:spec["B"]], B=spec["B"], K=spec["K"],
                lik_var=spec["lik_var"], n_data=spec["n_data"], n_layers=len(spec["layers"]))
@@ -105,6 +108,14 @@ def main():
         path = os.path.join(here, name + ".npz")
         np.savez_compressed(path, **arrays)
         print("%-12s %6.1f KB  elbo=%.6f" % (name, os.path.getsize(path) / 1024, arrays["out_elbo"]))
+        if name in GRAD_CASES:
+            # target vectors for the backward pass: d ELBO / d parameters from the
+            # gradient oracle (torch autodiff of the fp64 restatement, pinned by finite differences)
+            from oracle.grad_oracle import iw_elbo_and_gradients
+            val, grads = iw_elbo_and_gradients(spec, zs)
+            gpath = os.path.join(here, "grad_" + name + ".npz")
+            np.savez_compressed(gpath, elbo=val, **{k.replace(".", "_"): v for k, v in grads.items()})
+            print("%-12s %6.1f KB  (gradients, %d arrays)" % ("grad_" + name, os.path.getsize(gpath) / 1024, len(grads)))
 
 
 if __name__ == "__main__":

@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(HERE, "golden"))
 from make_golden import CASES, arrays_to_spec, oracle_outputs   # noqa: E402
 
-FIXTURES = sorted(glob.glob(os.path.join(HERE, "golden", "*.npz")))
+FIXTURES = sorted(p for p in glob.glob(os.path.join(HERE, "golden", "*.npz")) if not os.path.basename(p).startswith("grad_"))
 
 
 def load(path):
