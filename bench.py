@@ -169,7 +169,8 @@ def main():
     import math
     spg = 1
     if not args.no_graph:
-        spg = math.gcd(math.gcd(args.steps, args.warmup) if args.warmup else args.steps, int(os.environ.get("IWVI_BENCH_SPG", "10")))
+        cap = int(os.environ.get("IWVI_BENCH_SPG", "10"))
+        spg = max(d for d in range(1, cap + 1) if args.steps % d == 0)      # the timed region is exactly --steps evaluations
     xch = None
     if world > 1 or force_xch:
         # multi-GPU: the evaluations of one graph replay are exchanged in one collective on a side stream
@@ -227,6 +228,8 @@ def main():
 
     for _ in range(args.warmup // spg):
         one_step()
+    for _ in range(args.warmup % spg):                           # the rest of the warm-up, one evaluation at a time (not exchanged)
+        step.run()
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps // spg):
