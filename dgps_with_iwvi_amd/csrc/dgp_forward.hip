@@ -327,6 +327,65 @@ __device__ __forceinline__ float stage1_unrolled(AP Ap, const f32x4* kuf, f32x4*
     return ssq;
 }
 
+// ---- the fifth sub-tile of an 80-sample chunk (M = 128: an 8 x 8 block system) ---------------------------------
+// Five single-wave solves on four SIMDs leave one SIMD with two of them while the others idle half of stage 1.  The
+// fifth solve is therefore cut ONCE, as a 2 x 2 system of 4 x 4 block systems:
+//     a_top = L11^-1 k_top          (solve4<0>, the wave on SIMD 0)
+//     r_bot = k_bot - L21 a_top     (one block row per wave, four waves, one per SIMD: the only parallel part)
+//     a_bot = L22^-1 r_bot          (solve4<4>, the wave on SIMD 1)
+// with two LDS hand-offs (a flag after a_top, an arrival count after r_bot).  Every SIMD then carries ~200 MFMAs
+// instead of 288 / 144 / 144 / 144.  solve4<R0>: the 4 x 4 block system of rows and columns R0 .. R0+3; r[] in
+// registers; results go to the `at` tile (and a_out); returns this lane's share of |a|^2.
+template <int NS, int R0>
+__device__ __forceinline__ float solve4(const f32x4* Al, f32x4 (&r)[4], f32x4* at, int tcol, int gq, gout1 a_out_row) {
+    constexpr int NSAMP = 16 * NS;
+    float ssq = 0.f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int bj = R0 + c, col = tri_upper_off(8, bj);       // packed column bj: [Dinv(bj), -L(bj+1,bj), ..]
+        const f32x4 Dv = Al[(size_t)col * 64];
+        f32x4 An[3];
+#pragma unroll
+        for (int i = c + 1; i < 4; ++i) An[i - c - 1] = Al[(size_t)(col + i - c) * 64];
+        f32x4 res = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 4; ++s) res = __builtin_amdgcn_mfma_f32_16x16x4f32(Dv[s], r[c][s], res, 0, 0, 0);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+#pragma unroll
+            for (int i = c + 1; i < 4; ++i) r[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(An[i - c - 1][s], res[s], r[i], 0, 0, 0);
+        }
+        at[(bj * 4 + gq) * NSAMP + tcol] = res;
+        ssq += colsumsq4(res);
+        if (a_out_row) *((gout4)(a_out_row + 16 * bj + 4 * gq)) = res;
+    }
+    return ssq;
+}
+// r_bi = k_bi - sum_{j<4} L(bi,j) a_j for one block row bi >= 4 (a_j from registers or from the `at` tile), two
+// accumulators so that the 16 MFMAs are two chains of 8
+template <int NS>
+__device__ __forceinline__ f32x4 row_minus_L21(const f32x4* Al, const f32x4 (&a)[4], f32x4 k, int bi) {
+    f32x4 r0 = k, r1 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 A[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) A[j] = Al[(size_t)(tri_upper_off(8, j) + bi - j) * 64];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        r0 = __builtin_amdgcn_mfma_f32_16x16x4f32(A[0][s], a[0][s], r0, 0, 0, 0);
+        r1 = __builtin_amdgcn_mfma_f32_16x16x4f32(A[1][s], a[1][s], r1, 0, 0, 0);
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        r0 = __builtin_amdgcn_mfma_f32_16x16x4f32(A[2][s], a[2][s], r0, 0, 0, 0);
+        r1 = __builtin_amdgcn_mfma_f32_16x16x4f32(A[3][s], a[3][s], r1, 0, 0, 0);
+    }
+    return r0 + r1;
+}
+__device__ __forceinline__ void lds_wait_ge(int* flag, int v) {
+    while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < v) __builtin_amdgcn_s_sleep(2);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
 template <int NS>
 __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
     constexpr int NSAMP = 16 * NS;
@@ -610,6 +669,7 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
             FW_STAMP(2 + li * 6 + 0);
 
             // ---- Gram: kuf block bi = kernel(Z_bi, x), written in B-operand order ---------------------------
+            if (tid < 2) counters[4 + tid] = 0;                    // hand-off words of the split fifth solve (stage 1)
             for (int bi = wave; bi < nbk; bi += FW_WAVES) {
                 f32x4 acc[NS];
 #pragma unroll
@@ -710,12 +770,53 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
                 ring[1] = s2_P[(size_t)(1 < s2_nblocks ? 1 : s2_nblocks - 1) * 64];
                 ring[2] = s2_P[(size_t)(2 < s2_nblocks ? 2 : s2_nblocks - 1) * 64];
             }
+            // five sub-tiles, M = 128, solve stream staged: the fifth solve is split over waves 4-7 (see solve4)
+            const bool split5 = (NS == FW_MAXNS) && nbk == 8 && G.ls_off >= 0;
+            const int nchain = split5 ? NS - 1 : NS;
             if (wave >= NS) {
-                // the waves without a sub-tile to solve clear every |u|^2 slot meanwhile (stage 2 fills only some)
+                // the waves without a sub-tile of their own clear every |u|^2 slot first (stage 2 fills only some)
                 f32x4* uz = reinterpret_cast<f32x4*>(usq);
                 for (int i = (wave - NS) * 64 + lane; i < (FW_WAVES * R * NSAMP) / 4; i += (FW_WAVES - NS) * 64) uz[i] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
-            if (wave < NS) {
+            if (split5 && wave >= FW_WAVES / 2) {
+                const int c = wave - FW_WAVES / 2, bi = 4 + c, tcol = 16 * (NS - 1) + jq;
+                const f32x4* Al = reinterpret_cast<const f32x4*>(sm + G.ls_off) + lane;
+                const gout1 arow = (G.a_out && tcol < nvalid) ? (gout1)G.a_out + (size_t)(t0 + tcol) * G.Mp : (gout1)nullptr;
+                int* flag = counters + 4;                          // [0]: a_top is in the tile; [1]: rows of r_bot written
+                __builtin_amdgcn_s_setprio(2);                     // the split solve is the long dependent path of the phase
+                f32x4 a[4];
+                float ssq = 0.f;
+                if (c == 0) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) a[i] = kuf[(i * 4 + gq) * NSAMP + tcol];
+                    ssq = solve4<NS, 0>(Al, a, at, tcol, gq, arow);          // leaves a_top in a[] (and in the tile)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) a[i] = at[(i * 4 + gq) * NSAMP + tcol];
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    if (lane == 0) __hip_atomic_store(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                } else {
+                    lds_wait_ge(flag, 1);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) a[i] = at[(i * 4 + gq) * NSAMP + tcol];
+                }
+                const f32x4 rb = row_minus_L21<NS>(Al, a, kuf[(bi * 4 + gq) * NSAMP + tcol], bi);
+                at[(bi * 4 + gq) * NSAMP + tcol] = rb;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                if (lane == 0) __hip_atomic_fetch_add(flag + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                float ssq_b = 0.f;
+                if (c == 1) {
+                    lds_wait_ge(flag + 1, 4);
+                    f32x4 r[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) r[i] = at[((4 + i) * 4 + gq) * NSAMP + tcol];
+                    ssq_b = solve4<NS, 4>(Al, r, at, tcol, gq, arow);
+                }
+                // |a|^2 of these columns: the top half from wave 4 (slot 0), the bottom half from wave 5 (slot 1)
+                if (c == 0) { ssq = xgroup_sum_mfma(ssq); if (gq == 0) asq[tcol] = ssq; }
+                if (c == 1) { ssq_b = xgroup_sum_mfma(ssq_b); if (gq == 0) asq[NSAMP + tcol] = ssq_b; }
+                __builtin_amdgcn_s_setprio(0);
+            }
+            if (wave < nchain) {
                 const int tcol = 16 * wave + jq;                  // this lane's sample column
                 gptr4 Ap = (gptr4)G.LsP + lane;
                 const gout1 arow = (G.a_out && tcol < nvalid) ? (gout1)G.a_out + (size_t)(t0 + tcol) * G.Mp : (gout1)nullptr;
@@ -783,7 +884,7 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
                     }
                 }
                 ssq = xgroup_sum_mfma(ssq);
-                if (gq == 0) asq[tcol] = ssq;
+                if (gq < 2) asq[gq * NSAMP + tcol] = gq == 0 ? ssq : 0.f;   // slot 0 carries it; slot 1 is for a split solve
             }
             if (g.stamps && lane == 0 && li == 1) g.stamps[(size_t)blockIdx.x * 128 + 118 + wave] = clock64();
             __syncthreads();
@@ -924,7 +1025,7 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
 #pragma unroll
                 for (int w = 0; w < FW_WAVES; ++w) u2 += usq[(w * R + r) * NSAMP + j];   // fixed order: bit-reproducible
                 const float mu = meanp[r * NSAMP + j];
-                const float v = fmaxf(G.variance - asq[j] + u2, 0.f);
+                const float v = fmaxf(G.variance - (asq[j] + asq[NSAMP + j]) + u2, 0.f);
                 const float z = (j < nvalid) ? zl[r * NSAMP + j] : 0.f;
                 if (o_noise && j < nvalid) o_noise[(t0 + j) * R + r] = z;
                 gbuf[(0 * R + r) * NSAMP + j] = mu;
@@ -1286,7 +1387,7 @@ static size_t fw_plan_lds(FwArgs& a, int nsamp, int maxR, int maxP, bool stage_z
     l.lw = o; o += nsamp;
     l.rowi = o; o += nsamp;
     l.pidx = o; o += nsamp;
-    l.asq = o; o += nsamp;
+    l.asq = o; o += 2 * nsamp;
     l.meanp = o; o += maxR * nsamp;
     l.gbuf = o; o += 3 * maxR * nsamp;
     l.obuf = o; o += 2 * maxP * nsamp;
