@@ -736,17 +736,8 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
                     }
                 }
             }
-            if (G.ls_off >= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            FW_STAMP(2 + li * 6 + 1);
-
-            // ---- stage 1: a = Lm^-1 k, right-looking blocked forward substitution, one wave per sub-tile ------
-            // packed stream, column bj: [Dinv(bj), -L(bj+1,bj) .. -L(nbk-1,bj)];  a_bj = Dinv_bj r_bj, then
-            // r_bi += (-L(bi,bj)) a_bj for every bi > bj: independent MFMA chains, B operand = a_bj in registers.
-            // r lives in the `at` tile (first touched from the Gram tile); the freshly updated r_{bj+1} is handed
-            // to the next column in registers, so the dependent chain never waits for LDS.
-            // stage 2's first operands are requested now (nothing in them depends on the solve), so that its MFMAs
-            // start right behind the barrier that ends stage 1
+            // stage 2's first operands are requested here, in the shadow of the Gram phase's barrier (nothing in them
+            // depends on the Gram or the solve), so that its MFMAs start right behind the barrier that ends stage 1
             const int ntri = tri_blocks(nbk);
             const int s2_nblocks = ufirst((int)L.gp.nblk[wave]);   // runs are dealt to waves by load, not in order
             const int s2_mw0 = ufirst((int)L.gp.mean_wave[0]), s2_mw1 = ufirst((int)L.gp.mean_wave[1]);
@@ -770,6 +761,14 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
                 ring[1] = s2_P[(size_t)(1 < s2_nblocks ? 1 : s2_nblocks - 1) * 64];
                 ring[2] = s2_P[(size_t)(2 < s2_nblocks ? 2 : s2_nblocks - 1) * 64];
             }
+            __syncthreads();                                      // (the staged solve stream was complete before this layer began)
+            FW_STAMP(2 + li * 6 + 1);
+
+            // ---- stage 1: a = Lm^-1 k, right-looking blocked forward substitution, one wave per sub-tile ------
+            // packed stream, column bj: [Dinv(bj), -L(bj+1,bj) .. -L(nbk-1,bj)];  a_bj = Dinv_bj r_bj, then
+            // r_bi += (-L(bi,bj)) a_bj for every bi > bj: independent MFMA chains, B operand = a_bj in registers.
+            // r lives in the `at` tile (first touched from the Gram tile); the freshly updated r_{bj+1} is handed
+            // to the next column in registers, so the dependent chain never waits for LDS.
             // five sub-tiles, M = 128, solve stream staged: the fifth solve is split over waves 4-7 (see solve4)
             const bool split5 = (NS == FW_MAXNS) && nbk == 8 && G.ls_off >= 0;
             const int nchain = split5 ? NS - 1 : NS;
