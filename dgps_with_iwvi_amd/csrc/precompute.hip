@@ -107,8 +107,8 @@ __device__ __forceinline__ double readlane_d(double v, int src) {
 // per-column operations (scale by 1/l_jj, subtract l_ij l_kj) that factor the diagonal block perform
 // x L_pp^T = a on every other row -- at no extra instruction.  For the identity rows the solution is L_pp^-T,
 // which is all the inverse the rest of the pipeline needs.  16 steps, no LDS traffic, no barrier.
-// win = number of blocks below carried along (<= 2).  Writes the factor back (upper part of the diagonal block
-// zeroed), X = L_pp^-T to xT (row i, column k at [i*BLD + k]) and 1/L[j][j] to rinv[0..15].
+// win = number of blocks below carried along (<= 2).  Writes the factor back (the strict upper part of the diagonal
+// block is left as computed: nothing reads it), X = L_pp^-T to xT (row i, column k at [i*BLD + k]) and 1/L[j][j] to rinv[0..15].
 // The broadcasts are DPP operands, not instructions: every 16-lane group also carries the diagonal block's rows
 // (dg), so "l_kj" for any lane is lane k of its own row of 16 -- v_fmac_f64 with row_newbcast:k reads it in
 // place.  Per (column j, later column k): two v_fmac_f64_dpp (own row, diagonal-block copy) instead of two
@@ -173,7 +173,7 @@ __device__ __forceinline__ void diag_factor_window(double* blk, int p, int win, 
     if (lane < NB) rinv[lane] = rkeep;
     if (live || ident) {
 #pragma clang loop unroll(full)
-        for (int k = 0; k < NB; ++k) rowp[k] = (lb > 0 || k <= i) ? a[k] : 0.0;
+        for (int k = 0; k < NB; ++k) rowp[k] = a[k];              // (the diagonal block's strict upper part is never read)
     }
 }
 
