@@ -1,0 +1,139 @@
+"""Model factory: the layer stack of the reference's experiments from a ``configuration`` string
+(reference ``experiments/build_models.py:176-268``; SURVEY.md section 8 row F4 -- host code around the hot path).
+
+``build_model(ARGS, X, Y)`` with ``ARGS.mode`` in {'VI', 'IWAE'}, ``ARGS.configuration`` such as ``'L1_G5'`` or
+``'G5_G5'`` ('G<r>': a GP layer of r latent GPs mixed to the input width, 'L<d>': a latent-variable layer of d
+dimensions), ``ARGS.M`` inducing points, ``ARGS.likelihood_variance``, ``ARGS.minibatch_size``,
+``ARGS.num_IW_samples``.  What the reference builds around the model for *training* (natural-gradient + Adam
+ops, SGHMC, the CVAE baseline) belongs to the backward pass (row F1) and is not provided: those modes raise.
+
+Initial values follow the reference: first-layer inducing inputs by k-means of X (or X padded with N(0,1) rows when
+N <= M), deeper layers N(0,1) with their first columns taken from them (:218-219, :239-240); RBF-ARD kernels with
+lengthscales sqrt(D_in), variance 1 (:212, :238); mixing W = leading right-singular vectors of X (:186, :216-217);
+identity-padded linear mean function (:205-208); inner-layer q_sqrt scaled by 1e-5 (:276-278).
+"""
+import numpy as np
+import torch
+from scipy.cluster.vq import kmeans2
+
+from . import settings
+from .features import InducingPoints, MixedKernelSharedMof
+from .kernels import RBF
+from .layers import GPLayer, LatentVariableLayer
+from .likelihoods import Gaussian
+from .mean_functions import Linear
+from .models import DGP_IWVI, DGP_VI
+from .temp_workaround import SharedMixedMok
+
+
+def parse_configuration(configuration):
+    """'L1_G5_G5' -> [('L', 1), ('G', 5), ('G', 5)]; '' -> [] (a single GP layer: SVGP)."""
+    out = []
+    for tok in (configuration.split("_") if configuration else []):
+        if len(tok) < 2 or tok[0] not in "GL" or not tok[1:].isdigit():
+            raise ValueError("configuration token %r: expected G<num_gps> or L<latent_dim>" % tok)
+        out.append((tok[0], int(tok[1:])))
+    return out
+
+
+def build_layers(configuration, X, M, rng=None):
+    """The reference's layer stack (everything but the model object): list of layers, on the CPU."""
+    rng = np.random if rng is None else rng
+    X = np.asarray(X, dtype=np.float64)
+    N, D = X.shape
+    if N > M:
+        Z = kmeans2(X, M, minit="points")[0]
+    else:
+        Z = np.concatenate([X.copy(), rng.randn(M - N, D)], 0)
+    P = np.linalg.svd(X, full_matrices=False)[2]
+    DX, DY = D, 1
+    D_in = D_out = D
+    layers = []
+    for kind, d in parse_configuration(configuration):
+        if kind == "G":
+            A = np.zeros((D_in, D_out))
+            k = min(D_in, D_out)
+            A[:k, :k] = np.eye(k)
+            W = np.zeros((D_out, d))
+            W[:, :min(d, DX)] = P[:, :min(d, DX)]
+            ZZ = rng.randn(M, D_in)
+            ZZ[:, :min(D_in, DX)] = Z[:, :min(D_in, DX)]
+            kern = SharedMixedMok(RBF(D_in, lengthscales=float(D_in) ** 0.5, variance=1.0, ARD=True), W=W)
+            layer = GPLayer(kern, MixedKernelSharedMof(InducingPoints(ZZ)), d, mean_function=Linear(A=A))
+            layer.q_sqrt = layer.q_sqrt * 1e-5                       # inner layers start nearly deterministic
+            layers.append(layer)
+            D_in = D_out
+        else:
+            D_in += d
+            layers.append(LatentVariableLayer(d, XY_dim=DX + 1))
+    ZZ = rng.randn(M, D_in)
+    ZZ[:, :min(D_in, DX)] = Z[:, :min(D_in, DX)]
+    layers.append(GPLayer(RBF(D_in, lengthscales=float(D_in) ** 0.5, variance=1.0, ARD=True), InducingPoints(ZZ), DY))
+    return layers
+
+
+def build_model(ARGS, X, Y, apply_name=True, device=None):
+    if ARGS.mode not in ("VI", "IWAE"):
+        raise NotImplementedError("mode %r: only the VI / IWAE forward models are built here (training ops, SGHMC "
+                                  "and the CVAE baseline are outside the hot path)" % (ARGS.mode,))
+    layers = build_layers(ARGS.configuration, X, ARGS.M)
+    lik = Gaussian(ARGS.likelihood_variance)
+    name = "Model" if apply_name else None
+    if ARGS.mode == "VI":
+        model = DGP_VI(X, Y, layers, lik, minibatch_size=ARGS.minibatch_size, name=name)
+    else:
+        model = DGP_IWVI(X, Y, layers, lik, minibatch_size=ARGS.minibatch_size,
+                         num_samples=ARGS.num_IW_samples, name=name)
+    return model.to(device or settings.default_device())
+
+
+# ---- checkpoint / resume of the parameters (reference: gpflow Saver, run_conditional_density_estimation.py:95-125) ----
+def state_dict(model):
+    """Every parameter tensor of the stack, as CPU float arrays keyed 'layers.<i>.<name>'."""
+    out = {"likelihood.variance": np.float64(model.likelihood.variance)}
+    for i, layer in enumerate(model.layers):
+        p = "layers.%d." % i
+        if isinstance(layer, GPLayer):
+            kern = layer._base_kern()
+            out[p + "Z"] = layer._Z().detach().cpu().numpy()
+            out[p + "lengthscales"] = torch.as_tensor(kern.lengthscales).detach().cpu().numpy()
+            out[p + "variance"] = np.float64(kern.variance)
+            out[p + "q_mu"] = layer.q_mu.detach().cpu().numpy()
+            out[p + "q_sqrt"] = layer.q_sqrt.detach().cpu().numpy()
+            if isinstance(layer.kern, SharedMixedMok):
+                out[p + "W"] = layer.kern.W.detach().cpu().numpy()
+        elif isinstance(layer, LatentVariableLayer) and layer.encoder is not None:
+            for j, (w, b) in enumerate(zip(layer.encoder.Ws, layer.encoder.bs)):
+                out[p + "enc_W%d" % j] = w.detach().cpu().numpy()
+                out[p + "enc_b%d" % j] = b.detach().cpu().numpy()
+    return out
+
+
+def load_state_dict(model, state):
+    dev = model.X.device
+    t = lambda a: torch.as_tensor(np.asarray(a), dtype=settings.float_type, device=dev)
+    model.likelihood.variance = float(state["likelihood.variance"])
+    for i, layer in enumerate(model.layers):
+        p = "layers.%d." % i
+        if isinstance(layer, GPLayer):
+            kern = layer._base_kern()
+            layer._Z().copy_(t(state[p + "Z"]))
+            kern.lengthscales = t(state[p + "lengthscales"])
+            kern.variance = float(state[p + "variance"])
+            layer.q_mu, layer.q_sqrt = t(state[p + "q_mu"]), t(state[p + "q_sqrt"])
+            if isinstance(layer.kern, SharedMixedMok):
+                layer.kern.W = t(state[p + "W"])
+            layer._state = None                                       # factorisation depends on Z / lengthscales
+        elif isinstance(layer, LatentVariableLayer) and layer.encoder is not None:
+            layer.encoder.Ws = [t(state[p + "enc_W%d" % j]) for j in range(len(layer.encoder.Ws))]
+            layer.encoder.bs = [t(state[p + "enc_b%d" % j]) for j in range(len(layer.encoder.bs))]
+    return model
+
+
+def save_checkpoint(model, path):
+    np.savez(path, **state_dict(model))
+
+
+def load_checkpoint(model, path):
+    with np.load(path) as f:
+        return load_state_dict(model, {k: f[k] for k in f.files})
