@@ -13,19 +13,25 @@
 //             Z~, encoder weights), the chunk's data rows and the injected noise are copied global -> LDS with
 //             asynchronous LDS-DMA loads, all in flight at once; in-kernel Philox draws overlap their latency.
 //   per GP layer:
-//   x~      augmented, scaled, centred inputs -> LDS (so that the Gram is one small MFMA product)
+//   x~      augmented, scaled, centred inputs (so that the Gram is one small MFMA product): produced by the
+//           PREVIOUS layer's last phase straight from its results; only a first GP layer has a phase of its own
 //   Gram    k = exp2(Z~ x~)   16x16x4 f32 MFMA, result already in B-operand order               -> LDS kuf
 //   stage 1 a = Lm^-1 k by blocked right-looking forward substitution (matrix_triangular_solve, :51): one wave
-//           per 16-sample sub-tile streams the packed factor once; a_j = Dinv_j r_j, then r_i -= L_ij a_j for all
-//           i > j (independent MFMA chains); the B operand is the result tile just computed, still in registers
-//           (accumulator layout == B layout)                                                     -> LDS at, |a|^2
+//           per 16-sample sub-tile streams the packed factor (staged in LDS one layer ahead); a_j = Dinv_j r_j, then
+//           r_i -= L_ij a_j for all i > j (independent MFMA chains); the B operand is the result tile just computed,
+//           still in registers (accumulator layout == B layout).  With five sub-tiles on four SIMDs the fifth solve
+//           is cut once into a 2 x 2 block system and spread over four waves (solve4)            -> LDS at, |a|^2
 //   stage 2 u_r = tril(q_sqrt_r)^T a (upper blocks) -> |u_r|^2 only (never stored); mean = q_mu^T a
 //           a wave owns one 16-row block of the output for ALL NS sub-tiles: each 1-KiB packed A block is
-//           loaded once (coalesced, L2 -> registers, prefetched two blocks ahead, across job boundaries) and
-//           feeds 4*NS MFMAs; jobs come from an LDS counter in order of decreasing cost
-//   epilogue var, sample, mixing, mean function -> next layer's input in LDS (+ optional HBM outputs)
-// Every job writes its partial sums to its own LDS slot and they are added in a fixed order: results are
-// bit-reproducible whichever wave ran which job.
+//           loaded once (coalesced, L2 -> registers, prefetched three blocks ahead, across job boundaries) and
+//           feeds 4*NS MFMAs; the row-block jobs are dealt to the waves by the host (plan_stage2) in contiguous
+//           runs levelled per SIMD pair; a block's operand fetches are scheduled between its MFMAs
+//   epilogue var, sample; mixing + mean function as one small MFMA product that also emits the next layer's x~
+//           (+ optional HBM outputs)
+//   tail    per-sample log-weight, chunk-local logsumexp over K, one partial per workgroup; the last workgroup to
+//           arrive finishes the ELBO (models.py:138-150) and advances the device-resident noise counter
+// Every partial sum goes to its own LDS slot / workspace word and is added in a fixed order: results are
+// bit-reproducible.
 #include "iwvi_common.h"
 #include <algorithm>
 #include <cmath>
