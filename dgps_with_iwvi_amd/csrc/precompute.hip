@@ -3,19 +3,22 @@
 // Replaces (reference file:line) Kuu + tf.cholesky (temp_workaround.py:39,48), the operand side of
 // tf.matrix_triangular_solve (:51), tf.matrix_band_part(q_sqrt) (:78) and gauss_kl (:186-188).
 //
-// ONE launch for all layers of a model: grid = (layer, role), 1024-thread workgroups.
+// ONE launch for all layers of a model: grid = (layer, role) + encoder blocks, 1024-thread workgroups.
 //   role 0        Gram + Cholesky + inverses of the diagonal 16x16 blocks + packing of the forward-substitution
 //                 stream and of the K_uf operand Z~   (the serial critical path)
 //   role 1..R     tril(q_sqrt[r])^T packing + latent GP r's share of KL[q(u) || p(u)] (role 1 also packs q_mu^T)
+//   encoder       the LV layer's MLP on the minibatch's data rows (layers.py:137-152), 256 rows per block
 // The factorisation works on 16x16 blocks of the lower triangle (row stride 17 doubles: conflict-free
-// ds_read_b64), resident in LDS for Mp <= 128 (78 KB) and in an L2-resident workspace otherwise:
-//   * diagonal block: one wave, row-per-lane in registers, pivots/columns broadcast with v_readlane
-//     (no LDS round trips, no barriers inside the 16 steps);
-//   * panel: one thread per row, forward substitution against the factored diagonal block;
-//   * trailing update: one wave per 16x16 output block, 4 outputs per lane;
-//   * Lm^-1 by recursive doubling over the block-triangular structure ([[A,0],[C,B]]^-1 =
-//     [[A^-1,0],[-B^-1 C A^-1, B^-1]]): log2(nblk) levels of two fully parallel block-GEMM stages
-//     instead of a sequential substitution.
+// ds_read_b64), resident in LDS for Mp <= 128 (78 KB) and in an L2-resident workspace otherwise.  It is
+// left-looking and generates the matrix as it goes (chol_blocks):
+//   * diagonal pass: one wave, row-per-lane in registers over a 64-row window (diagonal block, two block rows
+//     below it, identity rows that come out as L^-T); pivot-row broadcasts are DPP row_newbcast operands of
+//     v_fmac_f64 -- no LDS round trips, no barriers, no SGPR traffic inside the 16 steps;
+//   * beside it, the other waves: Gram block column p+2 (f64 MFMA dot products + exp), column p+1's catch-up
+//     with the factored columns (f64 MFMA), column p-1's packed float32 stream;
+//   * after it: one wave per block row finishes column p and applies it to column p+1.
+// Dense Lm / Lm^-1 (debug / API parity only, IWVI_GP_WANT_DENSE): Lm^-1 by recursive doubling over the
+// block-triangular structure ([[A,0],[C,B]]^-1 = [[A^-1,0],[-B^-1 C A^-1, B^-1]]).
 #include "iwvi_common.h"
 #include <cstdlib>
 
