@@ -128,7 +128,7 @@ struct FwHead {
 // prologue work lists, built by the host: plain contiguous copies global -> LDS (every small operand of every layer)
 // and the per-layer noise slots; they ride in the LDS copy of the table, one entry per wave-iteration
 struct alignas(16) FwCopy { const float* src; int n; int dst; };           // n floats to LDS float offset dst; n < 0: 16-byte pieces
-struct FwNoise { const float* src; int dims, z_off, zero, layer; };
+struct alignas(16) FwNoise { const float* src; int dims, z_off, zero, layer; int pad[2]; };   // 32 bytes: one batched LDS read
 constexpr int FW_MAX_COPY = 6 * IWVI_MAX_STACK;
 struct FwArgs {
     FwHead h;
@@ -517,42 +517,39 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + i0 + wl),
                                                  (__attribute__((address_space(3))) void*)(dst + i0), 4, 0, 0); }
     }
-    // injected noise [T, dims] -> znoise[z_off + r * NSAMP + j] (a gather: the DMA source is per lane)
-    for (int li = 0; li < g.n_layers; ++li) {
-        const float* noise = ufirst(NT[li].src);
-        if (!noise) continue;
-        const int dims = ufirst(NT[li].dims);
-        float* zdst = znoise + ufirst(NT[li].z_off);
-        for (int i0 = (tid & ~63); i0 < dims * NSAMP; i0 += FW_THREADS) {
-            const int i = i0 + lane, r = i / NSAMP, j = i - r * NSAMP;
-            if (i < dims * NSAMP && j < nvalid)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(noise + (size_t)(t0 + j) * dims + r),
-                                                 (__attribute__((address_space(3))) void*)(zdst + i0), 4, 0, 0);
+    // noise of every layer -> znoise[z_off + r * NSAMP + j].  Injected [T, dims]: a gather by LDS-DMA (the source is per
+    // lane).  Drawn here: 4 normals per Philox call, the (layer, 4-component group, sample) items of all layers laid end
+    // to end over the workgroup's threads (one item per thread while they fit), overlapping the copies above.
+    {
+        int base = 0;                                              // first thread of the current layer's items
+        for (int li = 0; li < g.n_layers; ++li) {
+            const FwNoise nz = uniform_words(NT[li]);              // one LDS round trip per layer
+            const int dims = nz.dims;
+            float* zdst = znoise + nz.z_off;
+            if (nz.src) {
+                for (int i0 = (tid & ~63); i0 < dims * NSAMP; i0 += FW_THREADS) {
+                    const int i = i0 + lane, r = i / NSAMP, j = i - r * NSAMP;
+                    if (i < dims * NSAMP && j < nvalid)
+                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(nz.src + (size_t)(t0 + j) * dims + r),
+                                                         (__attribute__((address_space(3))) void*)(zdst + i0), 4, 0, 0);
+                }
+                continue;
+            }
+            const int cnt = ((dims + 3) >> 2) * NSAMP;
+            int k = tid - base;
+            if (k < 0) k += FW_THREADS;
+            for (; k < cnt; k += FW_THREADS) {
+                const int q = k / NSAMP, j = k - q * NSAMP;
+                float v[4] = {0.f, 0.f, 0.f, 0.f};
+                if (!nz.zero && j < nvalid) draw_normal4(g.seed, step, li, t0 + j, q, v);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (4 * q + e < dims) zdst[(4 * q + e) * NSAMP + j] = v[e];
+            }
+            base = (base + cnt) & (FW_THREADS - 1);
         }
     }
     FW_STAMP(57);
-    // in-kernel draws (layers without injected noise), 4 normals per Philox call, overlapping the copies above.
-    // All (layer, 4-component group, sample) items form ONE flat index space spread over the whole workgroup.
-    {
-        int total = 0;
-        for (int li = 0; li < g.n_layers; ++li)
-            if (ufirst(NT[li].src) == nullptr) total += ((ufirst(NT[li].dims) + 3) >> 2) * NSAMP;
-        for (int idx = tid; idx < total; idx += FW_THREADS) {
-            int li = 0, rem = idx, dims = 0, z_off = 0, zero = 0;
-            for (int l = 0; l < g.n_layers; ++l) {
-                if (NT[l].src != nullptr) continue;
-                const int cnt = ((NT[l].dims + 3) >> 2) * NSAMP;
-                if (rem < cnt) { li = l; dims = NT[l].dims; z_off = NT[l].z_off; zero = NT[l].zero; break; }
-                rem -= cnt;
-            }
-            const int q = rem / NSAMP, j = rem - q * NSAMP;
-            float v[4] = {0.f, 0.f, 0.f, 0.f};
-            if (!zero && j < nvalid) draw_normal4(g.seed, step, li, t0 + j, q, v);
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-                if (4 * q + e < dims) znoise[z_off + (4 * q + e) * NSAMP + j] = v[e];
-        }
-    }
     FW_STAMP(58);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     FW_STAMP(59);
