@@ -187,7 +187,7 @@ def main():
             step.run()
             if xch is None:
                 graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph, stream=s):
+                with torch.cuda.graph(graph, stream=s, capture_error_mode="thread_local"):
                     for _ in range(spg):
                         step.run()
             else:
@@ -195,7 +195,7 @@ def main():
                 graph = []
                 for slot in range(xch.depth):
                     gph = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(gph, stream=s):
+                    with torch.cuda.graph(gph, stream=s, capture_error_mode="thread_local"):
                         for view in xch.slot_views(slot):
                             step.run(out=view)
                     graph.append(gph)
@@ -256,7 +256,7 @@ def main():
     with torch.cuda.stream(s2):
         fwd()
         g2 = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g2, stream=s2):
+        with torch.cuda.graph(g2, stream=s2, capture_error_mode="thread_local"):
             for _ in range(NREP):
                 keep_logw = fwd()
     torch.cuda.current_stream().wait_stream(s2)
