@@ -32,7 +32,9 @@ def _np(t):
 # K1 / K2 / precompute
 # ------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("M,D,R,kern", [(10, 1, 2, "matern"), (64, 8, 1, "rbf"), (100, 3, 2, "rbf"),
-                                        (128, 9, 5, "rbf"), (200, 8, 2, "rbf"), (256, 8, 3, "rbf")])
+                                        (128, 9, 5, "rbf"), (200, 8, 2, "rbf"), (256, 8, 3, "rbf"),
+                                        (128, 1, 1, "rbf"),      # dense 1-D cloud: K_uu is numerically rank-deficient, jitter decides
+                                        (512, 8, 1, "rbf")])     # the largest supported inducing set
 def test_precompute_factorisation(gpu_device, M, D, R, kern):
     """Kuu + tf.cholesky (temp_workaround.py:39,48), Lm^-1 and gauss_kl (:186-188) vs NumPy fp64."""
     from dgps_with_iwvi_amd import kernels, settings
