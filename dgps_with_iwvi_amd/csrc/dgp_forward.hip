@@ -846,40 +846,50 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
                     case 7: ssq = stage1_unrolled<NS, 7>(Ap, kuf, at, tcol, gq, arow); break;
                     case 8: ssq = stage1_unrolled<NS, 8>(Ap, kuf, at, tcol, gq, arow); break;
                     default: {
-                        // generic column-at-a-time form with the right-hand sides in the LDS tile
-                    const int ntri = tri_blocks(nbk);
-                    f32x4 ring[4];
-                    ring[0] = Ap[0];
-                    ring[1] = Ap[(size_t)(1 < ntri ? 1 : ntri - 1) * 64];
-                    ring[2] = Ap[(size_t)(2 < ntri ? 2 : ntri - 1) * 64];
+                        // generic column-at-a-time form (M > 128): right-hand sides in the LDS tile, the packed factor
+                        // streamed from L2.  Column bj: a_bj = Dinv_bj r_bj (4 dependent MFMAs), then the updates of the
+                        // rows below it four block rows at a time -- four independent accumulator chains in flight, their
+                        // A blocks requested one group ahead -- so the phase is bound by MFMA issue, not by the latency of
+                        // one dependent chain per block.  (Clamped indices: a short last group recomputes its last row,
+                        // nothing of it is written back.)
                     f32x4 xcur = kuf[gq * NSAMP + tcol];             // r_0
-                    f32x4 res = {0.f, 0.f, 0.f, 0.f};
-                    int bi = 0, bj = 0;
-                    for (int q0 = 0; q0 < ntri; q0 += 4) {
-    #pragma unroll
-                        for (int u = 0; u < 4; ++u) {
-                            const int q = q0 + u;
-                            if (q < ntri) {
-                                ring[(u + 3) & 3] = Ap[(size_t)(q + 3 < ntri ? q + 3 : ntri - 1) * 64];
-                                const f32x4 a_cur = ring[u];
-                                if (bi == bj) {
-                                    res = f32x4{0.f, 0.f, 0.f, 0.f};
-    #pragma unroll
-                                    for (int s = 0; s < 4; ++s) res = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[s], xcur[s], res, 0, 0, 0);
-                                    at[(bj * 4 + gq) * NSAMP + tcol] = res;
-                                    ssq += colsumsq4(res);
-                                    if (G.a_out && tcol < nvalid)
-                                        *((gout4)((gout1)G.a_out + (size_t)(t0 + tcol) * G.Mp + 16 * bj + 4 * gq)) = res;
-                                } else {
-                                    const f32x4* src = at;                        // == kuf: solved in place
-                                    f32x4 y = src[(bi * 4 + gq) * NSAMP + tcol];
-    #pragma unroll
-                                    for (int s = 0; s < 4; ++s) y = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[s], res[s], y, 0, 0, 0);
-                                    if (bi == bj + 1) xcur = y;                  // next column's right-hand side, kept in registers
-                                    else at[(bi * 4 + gq) * NSAMP + tcol] = y;
+                    for (int bj = 0; bj < nbk; ++bj) {
+                        const size_t col = (size_t)tri_upper_off(nbk, bj);
+                        const int m = nbk - 1 - bj;                  // block rows below
+                        const f32x4 Dv = Ap[col * 64];
+                        f32x4 An[4];
+#pragma unroll
+                        for (int gi = 0; gi < 4; ++gi) An[gi] = Ap[(col + 1 + (m > 0 ? (gi < m ? gi : m - 1) : -1)) * 64];
+                        f32x4 res = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int s = 0; s < 4; ++s) res = __builtin_amdgcn_mfma_f32_16x16x4f32(Dv[s], xcur[s], res, 0, 0, 0);
+                        at[(bj * 4 + gq) * NSAMP + tcol] = res;
+                        ssq += colsumsq4(res);
+                        if (G.a_out && tcol < nvalid)
+                            *((gout4)((gout1)G.a_out + (size_t)(t0 + tcol) * G.Mp + 16 * bj + 4 * gq)) = res;
+                        for (int b0 = 0; b0 < m; b0 += 4) {
+                            f32x4 A[4], y[4];
+#pragma unroll
+                            for (int gi = 0; gi < 4; ++gi) {
+                                A[gi] = An[gi];
+                                const int b = b0 + gi < m ? b0 + gi : m - 1;
+                                y[gi] = at[((bj + 1 + b) * 4 + gq) * NSAMP + tcol];
+                            }
+                            if (b0 + 4 < m) {
+#pragma unroll
+                                for (int gi = 0; gi < 4; ++gi) An[gi] = Ap[(col + 1 + (b0 + 4 + gi < m ? b0 + 4 + gi : m - 1)) * 64];
+                            }
+#pragma unroll
+                            for (int s = 0; s < 4; ++s) {
+#pragma unroll
+                                for (int gi = 0; gi < 4; ++gi) y[gi] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[gi][s], res[s], y[gi], 0, 0, 0);
+                            }
+#pragma unroll
+                            for (int gi = 0; gi < 4; ++gi) {
+                                if (b0 + gi < m) {
+                                    if (b0 + gi == 0) xcur = y[gi];      // next column's right-hand side, kept in registers
+                                    else at[((bj + 1 + b0 + gi) * 4 + gq) * NSAMP + tcol] = y[gi];
                                 }
-                                ++bi;
-                                if (bi == nbk) { ++bj; bi = bj; }
                             }
                         }
                     }

@@ -17,7 +17,7 @@ B, K = cfg["B"], cfg["K"]
 lib = _abi.lib()
 lib.iwvi_debug_set_stamps.restype = None
 lib.iwvi_debug_set_stamps.argtypes = [ctypes.c_void_p, ctypes.c_int64]
-NW = 4096
+NW = 32768
 buf = torch.zeros(NW * 128, dtype=torch.int64, device=dev)
 m.precompute(with_encoders=True)
 for _ in range(3):
