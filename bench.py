@@ -160,6 +160,7 @@ def main():
         lo = (rank * cfg["B"]) % (spec["n_data"] - cfg["B"] + 1)
         spec = dict(spec, X=spec["X"][lo:], Y=spec["Y"][lo:])
     model = synthetic.build_model(spec, dev)
+    model.lv_in_precompute = os.environ.get("IWVI_BENCH_LV_PRE", "0") == "1"   # leading LV layer inside the precompute launch
     step = Step(model, spec, dev, args.shard, world, exchange=(world > 1 or force_xch))
     B, K = cfg["B"], cfg["K"]
     # ---- capture -----------------------------------------------------------------------------

@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libiwvi_hip.so")
 
 KERN_RBF, KERN_MATERN52 = 0, 1
 LAYER_GP, LAYER_LV = 0, 1
-ABI_VERSION = 2
+ABI_VERSION = 3
 GP_WANT_DENSE = 1
 MAX_STACK = 8
 MF_ZERO, MF_IDENTITY, MF_LINEAR = 0, 1, 2
@@ -40,7 +40,10 @@ class EncDesc(ctypes.Structure):
     """struct iwvi_enc_desc (include/iwvi_hip.h): an encoder evaluated inside the precompute launch."""
     _fields_ = [("XY", c_void_p), ("rows", c_int64), ("enc_W", ctypes.POINTER(c_void_p)),
                 ("enc_b", ctypes.POINTER(c_void_p)), ("dims", ctypes.POINTER(ctypes.c_int32)),
-                ("n_enc", ctypes.c_int32), ("latent_dim", ctypes.c_int32), ("out", c_void_p)]
+                ("n_enc", ctypes.c_int32), ("latent_dim", ctypes.c_int32), ("out", c_void_p),
+                ("X", c_void_p), ("Dx", ctypes.c_int32), ("K", ctypes.c_int32), ("sampled_kl", ctypes.c_int32),
+                ("layer_index", ctypes.c_int32), ("seed", ctypes.c_uint64), ("rng_state", c_void_p),
+                ("sample_X", c_void_p), ("sample_kl", c_void_p), ("sample_z", c_void_p)]
 
 
 class LayerDesc(ctypes.Structure):
@@ -64,7 +67,8 @@ class ElboDesc(ctypes.Structure):
                 ("kl_global", ctypes.POINTER(c_void_p)), ("kl_global_counts", ctypes.POINTER(ctypes.c_int32)),
                 ("n_glob", ctypes.c_int32), ("scale", c_double), ("K_total", ctypes.c_int32),
                 ("mode_vi", ctypes.c_int32), ("out_lse_ms", c_void_p), ("out_logp", c_void_p),
-                ("out_elbo", c_void_p), ("ws", c_void_p)]
+                ("out_elbo", c_void_p), ("ws", c_void_p), ("lw_init", c_void_p), ("noise_layer_base", ctypes.c_int32),
+                ("x_per_sample", ctypes.c_int32)]
 
 
 # name -> (restype, argtypes); every symbol include/iwvi_hip.h declares

@@ -121,6 +121,9 @@ struct FwHead {
     unsigned long long* stamps;      // diagnostic only (iwvi_debug_set_stamps): 128 words per workgroup
     int ncopy;
     int ls_first;                    // first GP layer whose solve stream is staged in LDS (fetched in the prologue), or -1
+    const float* lw_init;            // optional [T]: local regularisers of layers evaluated before this launch (summed per sample)
+    int layer_base;                  // index of this stack's first layer in the model (keys the noise streams)
+    int x_per_sample;                // X has one row per sample (the output of a layer evaluated before this launch)
     int xstr;                        // row stride of the activation tiles: odd, >= max(D + 2 padded to 4, P) of the stack
     FwLds lds;
     FwElbo e;
@@ -200,15 +203,6 @@ __device__ __forceinline__ float xgroup_sum(float s) {
 
 // N(0,1) draws for (layer li, sample t), components 4q .. 4q+3: Philox4x32-10 with
 //   counter = (t_lo, t_hi, li * 256 + q, step_lo), key = (seed_lo, seed_hi ^ step_hi)
-__device__ __forceinline__ void draw_normal4(unsigned long long seed, unsigned long long step, int li,
-                                             long long t, int q, float v[4]) {
-    uint32_t c[4] = {(uint32_t)t, (uint32_t)((unsigned long long)t >> 32), (uint32_t)(li * 256 + q), (uint32_t)step};
-    philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32) ^ (uint32_t)(step >> 32));
-    box_muller4(c, v);
-}
-
-__device__ __forceinline__ float softplus_f(float x) { return x > 20.f ? x : log1pf(__expf(x)); }
-
 extern __shared__ __attribute__((aligned(16))) unsigned char fw_smem[];
 
 // diagnostic phase stamps: [k] = 100 MHz wall clock, [64 + k] = shader clock; written only when registered
@@ -464,12 +458,12 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
         const unsigned dp = point_of(tid);
         rowi[tid] = (int)row_of(dp);
         pidx[tid] = (int)dp;
-        lw[tid] = 0.f;
+        lw[tid] = (g.lw_init && tid < nvalid) ? g.lw_init[t0 + tid] : 0.f;
     }
     // the chunk's rows of X (models.py:113 / :50 tiling done here) and of the encoder input
     for (int idx = tid; idx < NSAMP * g.Dx; idx += FW_THREADS) {
         const int d = idx / NSAMP, j = idx - d * NSAMP;            // (compile-time divisor)
-        const unsigned row = row_of(point_of(j));
+        const unsigned row = g.x_per_sample ? ut0 + (unsigned)(j < nvalid ? j : nvalid - 1) : row_of(point_of(j));
         xin[j * XSTR + d] = (j < nvalid) ? g.X[(size_t)row * g.Dx + d] : 0.f;
     }
     if (g.XY) {
@@ -541,7 +535,7 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
             for (; k < cnt; k += FW_THREADS) {
                 const int q = k / NSAMP, j = k - q * NSAMP;
                 float v[4] = {0.f, 0.f, 0.f, 0.f};
-                if (!nz.zero && j < nvalid) draw_normal4(g.seed, step, li, t0 + j, q, v);
+                if (!nz.zero && j < nvalid) draw_normal4(g.seed, step, g.layer_base + li, t0 + j, q, v);
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
                     if (4 * q + e < dims) zdst[(4 * q + e) * NSAMP + j] = v[e];
@@ -1595,6 +1589,7 @@ int dgp_forward_impl(const iwvi_layer_desc* layers, int n_layers, const float* X
             if (E.klg_n[i] <= 0 || E.klg_n[i] > IWVI_MAX_R) { set_error("iwvi_dgp_forward: bad global KL count %d", E.klg_n[i]); return IWVI_ERR_ARG; }
         }
         E.ms = elbo->out_lse_ms; E.logp = elbo->out_logp; E.elbo = elbo->out_elbo; E.ws = elbo->ws;
+        a.h.lw_init = elbo->lw_init; a.h.layer_base = elbo->noise_layer_base; a.h.x_per_sample = elbo->x_per_sample;
     }
     {   // activation row stride: room for the widest layer input + 2 (x~), padded to a multiple of 4, and the widest output; odd
         int wmax = Dx + 2, dcur = Dx;

@@ -91,4 +91,13 @@ __device__ __forceinline__ void box_muller4(const uint32_t c[4], float v[4]) {
     }
 }
 
+// the layer stack's own noise stream: 4 normals for (layer li, sample t, component group q) of evaluation `step`
+__device__ __forceinline__ void draw_normal4(unsigned long long seed, unsigned long long step, int li,
+                                             long long t, int q, float v[4]) {
+    uint32_t c[4] = {(uint32_t)t, (uint32_t)((unsigned long long)t >> 32), (uint32_t)(li * 256 + q), (uint32_t)step};
+    philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32) ^ (uint32_t)(step >> 32));
+    box_muller4(c, v);
+}
+__device__ __forceinline__ float softplus_f(float x) { return x > 20.f ? x : log1pf(__expf(x)); }
+
 }  // namespace iwvi

@@ -41,6 +41,10 @@ struct PreLayer {
 struct PreEnc {
     const float* XY; float* out; const float* W[IWVI_MAX_ENC]; const float* b[IWVI_MAX_ENC];
     long long rows; int dims[IWVI_MAX_ENC + 1]; int n_enc, Lw, blk0, nblk;
+    // sampling tail (sample_X != nullptr): see iwvi_enc_desc
+    const float* X; int Dx, K, sampled_kl, layer_index;
+    unsigned long long seed; const unsigned long long* rng_state;
+    float* sample_X; float* sample_kl; float* sample_z;
 };
 constexpr int PRE_MAX_ENC = 2;
 struct PreArgs { PreLayer L[IWVI_MAX_LAYERS]; int n; int stop_after; unsigned long long* stamps; PreEnc E[PRE_MAX_ENC]; int n_enc; };
@@ -648,6 +652,33 @@ __device__ void role_encoder(const PreEnc& E, int blk) {
         const int r = idx / no, o = idx - r * no;
         E.out[(row0 + r) * no + o] = in[r * mdim + o];
     }
+    if (!E.sample_X) return;
+    // the LatentVariableLayer itself for these rows' K samples each (layers.py:83-103), from the activations still in LDS
+    const unsigned long long step = E.rng_state ? E.rng_state[0] : 0ULL;
+    const int Lw = E.Lw, Dx = E.Dx, Do = Dx + Lw, K = E.K;
+    for (int idx = threadIdx.x; idx < nrows * K; idx += blockDim.x) {
+        const int r = idx / K;
+        const long long t = row0 * K + idx;
+        float* xo = E.sample_X + t * Do;
+        for (int d = 0; d < Dx; ++d) xo[d] = E.X[(row0 + r) * Dx + d];
+        float klsum = 0.f;
+        for (int q = 0; 4 * q < Lw; ++q) {
+            float z4[4];
+            draw_normal4(E.seed, step, E.layer_index, t, q, z4);
+            for (int e = 0; e < 4 && 4 * q + e < Lw; ++e) {
+                const int l = 4 * q + e;
+                const float mu = in[r * mdim + l], sg = softplus_f(in[r * mdim + Lw + l] - 3.f), z = z4[e];
+                const float w = fmaf(z, sg, mu);                                   // layers.py:86-87
+                float kl;
+                if (E.sampled_kl) kl = -0.5f * z * z - __logf(sg) + 0.5f * w * w;  // log q(W) - log p(W), :98-100
+                else kl = 0.5f * (sg * sg + mu * mu - 1.f) - __logf(sg);           // KL(N(mu,sg)||N(0,1)), :101-103
+                klsum += kl;
+                xo[Dx + l] = w;
+                if (E.sample_z) E.sample_z[t * Lw + l] = z;
+            }
+        }
+        E.sample_kl[t] = klsum;
+    }
 }
 
 __global__ __launch_bounds__(1024) void k_precompute(PreArgs args) {
@@ -817,6 +848,12 @@ extern "C" int iwvi_model_precompute(const iwvi_gp_desc* layers, int n_layers, c
                     w += (size_t)d.dims[k] * d.dims[k + 1] + d.dims[k + 1];
                 }
                 E.XY = d.XY; E.out = d.out; E.rows = d.rows; E.n_enc = d.n_enc; E.Lw = d.latent_dim;
+                E.sample_X = d.sample_X; E.sample_kl = d.sample_kl; E.sample_z = d.sample_z;
+                if (d.sample_X) {
+                    if (!d.X || !d.sample_kl || d.Dx <= 0 || d.Dx + d.latent_dim > IWVI_MAX_D || d.K <= 0) { set_error("iwvi_model_precompute: bad sampling tail of encoder %d", e); return IWVI_ERR_ARG; }
+                    E.X = d.X; E.Dx = d.Dx; E.K = d.K; E.sampled_kl = d.sampled_kl; E.layer_index = d.layer_index;
+                    E.seed = d.seed; E.rng_state = (const unsigned long long*)d.rng_state;
+                }
                 E.blk0 = enc_blocks; E.nblk = (int)((d.rows + ENC_ROWS - 1) / ENC_ROWS);
                 enc_blocks += E.nblk;
                 const size_t need = (w + 4 + 2 * (size_t)ENC_ROWS * 65) * sizeof(float);   // weights + two activation buffers

@@ -201,9 +201,13 @@ class LatentVariableLayer:
         self.encoder.to(device)
         return self
 
-    def enc_desc(self, XY):
+    def enc_desc(self, XY, sample=None):
         """``iwvi_enc_desc``: evaluate this layer's encoder for every row of XY [rows, XY_dim] inside the
-        model's precompute launch; the result lands in ``self._enc_out`` [rows, 2*latent_dim]."""
+        model's precompute launch; the result lands in ``self._enc_out`` [rows, 2*latent_dim].
+
+        ``sample`` = dict(X [rows, Dx], K, sampled_kl, layer_index, seed, rng_state (device address), want_z):
+        the same launch also evaluates the layer itself (layers.py:83-103) for K samples of every row, into
+        ``self._smp_X`` [rows*K, Dx+latent_dim], ``self._smp_kl`` [rows*K] and, on request, ``self._smp_z``."""
         XY = _abi.dev_tensor(XY.contiguous(), "encoder input")
         if XY.shape[-1] != self.encoder.layer_dims[0]:
             raise ValueError("encoder expects %d features, got %d" % (self.encoder.layer_dims[0], XY.shape[-1]))
@@ -214,7 +218,26 @@ class LatentVariableLayer:
         e = _abi.EncDesc()
         e.XY, e.rows, e.enc_W, e.enc_b, e.dims, e.n_enc = XY.data_ptr(), rows, Wp, bp, dims, n
         e.latent_dim, e.out = self.latent_dim, self._enc_out.data_ptr()
-        return e, (XY, Wp, bp, dims, k2)
+        keep = [XY, Wp, bp, dims, k2]
+        if sample is not None:
+            X = _abi.dev_tensor(sample["X"].contiguous(), "X")
+            if X.shape[0] != rows:
+                raise ValueError("X and the encoder input need the same number of rows")
+            K, Dx, Lw = int(sample["K"]), X.shape[1], self.latent_dim
+            cur = getattr(self, "_smp_X", None)
+            if cur is None or tuple(cur.shape) != (rows * K, Dx + Lw) or cur.device != XY.device:
+                self._smp_X = torch.empty(rows * K, Dx + Lw, dtype=settings.float_type, device=XY.device)
+                self._smp_kl = torch.empty(rows * K, dtype=settings.float_type, device=XY.device)
+                self._smp_z = None
+            if sample.get("want_z") and self._smp_z is None:
+                self._smp_z = torch.empty(rows * K, Lw, dtype=settings.float_type, device=XY.device)
+            e.X, e.Dx, e.K = X.data_ptr(), Dx, K
+            e.sampled_kl, e.layer_index = 1 if sample.get("sampled_kl", True) else 0, int(sample.get("layer_index", 0))
+            e.seed, e.rng_state = int(sample["seed"]), sample["rng_state"]
+            e.sample_X, e.sample_kl = self._smp_X.data_ptr(), self._smp_kl.data_ptr()
+            e.sample_z = self._smp_z.data_ptr() if sample.get("want_z") else None
+            keep.append(X)
+        return e, tuple(keep)
 
     def fused_desc(self, D, z=None, outputs=None, sampled_kl=True, use_encoder=True, draw=True, enc_out=None):
         """``iwvi_layer_desc`` of this layer for ``iwvi_dgp_forward`` (D = width of the incoming F).

@@ -46,6 +46,10 @@ class DGP_VI:
         self.layers = list(layers)
         self.name = name
         self.full_cov_over_samples = False
+        # IW-ELBO only: evaluate a leading latent-variable layer inside the precompute launch (beside the
+        # factorisations) instead of inside the layer kernel; keep_lv_noise exports its draws (tests)
+        self.lv_in_precompute = False
+        self.keep_lv_noise = False
         self._dev_words = None
 
     # -- data ---------------------------------------------------------------------------------
@@ -76,15 +80,21 @@ class DGP_VI:
         return self._dev_words
 
     # -- reference API ------------------------------------------------------------------------
-    def precompute(self, with_encoders=False):
+    def precompute(self, with_encoders=False, sample_first=None):
         """Gram + Cholesky + operand packing of every GP layer: one ABI call, one launch.  ``with_encoders``:
         the same launch also evaluates the encoder MLP of every latent-variable layer on the current minibatch
-        (it does not depend on the factorisation, so it runs beside it instead of inside the layer kernel)."""
+        (it does not depend on the factorisation, so it runs beside it instead of inside the layer kernel).
+        ``sample_first`` = dict(K, sampled_kl, want_z): a latent-variable layer at position 0 is evaluated in full
+        there (its K samples per row, their regulariser); ``_fused_forward(stack_from=1)`` continues from it."""
         encs, keep = [], []
         if with_encoders:
-            for l in self.layers:
+            for i, l in enumerate(self.layers):
                 if isinstance(l, LatentVariableLayer) and len(encs) < 2:
-                    e, k = l.enc_desc(self._xy_minibatch())
+                    smp = None
+                    if sample_first is not None and i == 0:
+                        smp = dict(sample_first, X=self.X, layer_index=0, seed=settings.seed,
+                                   rng_state=ctypes.c_void_p(self._words().data_ptr() + 8))
+                    e, k = l.enc_desc(self._xy_minibatch(), sample=smp)
                     encs.append(e)
                     keep.append(k)
                     l._enc_key = self._mb_key()
@@ -113,25 +123,34 @@ class DGP_VI:
 
     # -- fused forward ------------------------------------------------------------------------
     def _fused_forward(self, T, row_div, row_mod, lead, zs=None, sampled_kl=True, want_layers=False,
-                       want_logw=True, use_encoder=True, elbo=None):
+                       want_logw=True, use_encoder=True, elbo=None, stack_from=0):
         """``iwvi_dgp_forward`` over the current minibatch: every layer + log-weights in one launch.
         Row t of the flattened batch reads data row (t // row_div) % row_mod.  ``elbo`` = dict(B, K, stride_b,
         stride_k, mode_vi, want_ms, K_total): also run the reduction of models.py:138-150 in the tail of the
-        launch.  Returns (logw [T] or None, per-layer dict lists when ``want_layers``, (elbo, logp, ms) or None)."""
+        launch.  Returns (logw [T] or None, per-layer dict lists when ``want_layers``, (elbo, logp, ms) or None).
+        ``stack_from=1`` (needs ``elbo``): layer 0 was evaluated by ``precompute(sample_first=...)``; the launch
+        starts from its samples [T, Dx+Lw] and its per-sample regulariser."""
         dev = self.X.device
-        n = len(self.layers)
+        layers = self.layers[stack_from:]
+        n = len(layers)
         if n > _abi.MAX_STACK:
             raise ValueError("more than %d layers in one fused launch" % _abi.MAX_STACK)
         zs = [None] * n if zs is None else zs
         if len(zs) != n:
             raise ValueError("zs needs one entry per layer")
-        X = _abi.dev_tensor(self.X.contiguous(), "X")
+        if stack_from:
+            first = self.layers[0]
+            if stack_from != 1 or elbo is None or getattr(first, "_smp_X", None) is None or first._smp_X.shape[0] != T:
+                raise ValueError("stack_from=1 needs elbo and precompute(sample_first=...) on this minibatch")
+            X = first._smp_X
+        else:
+            X = _abi.dev_tensor(self.X.contiguous(), "X")
         Y = _abi.dev_tensor(self.Y.contiguous(), "Y")
-        XY = self._xy_minibatch() if use_encoder and any(isinstance(l, LatentVariableLayer) for l in self.layers) else None
+        XY = self._xy_minibatch() if use_encoder and any(isinstance(l, LatentVariableLayer) for l in layers) else None
         descs = (_abi.LayerDesc * n)()
         keep, outs = [], []
         D = X.shape[1]
-        for i, (layer, z) in enumerate(zip(self.layers, zs)):
+        for i, (layer, z) in enumerate(zip(layers, zs)):
             if isinstance(layer, GPLayer):
                 R = layer.num_outputs
                 z2 = None if z is None else _abi.dev_tensor(z.reshape(T, R).contiguous(), "z")
@@ -186,6 +205,8 @@ class DGP_VI:
             ed.out_lse_ms = None if ms is None else ms.data_ptr()
             ws = torch.empty((T + 15) // 16, dtype=torch.float64, device=dev)
             ed.out_logp, ed.out_elbo, ed.ws = logp.data_ptr(), val.data_ptr(), ws.data_ptr()
+            if stack_from:
+                ed.lw_init, ed.noise_layer_base, ed.x_per_sample = self.layers[0]._smp_kl.data_ptr(), stack_from, 1
             keep.append((glob, glob_p, glob_n, ws))
             red = (val[0], logp, ms)
         _abi.check(_abi.lib().iwvi_dgp_forward(
@@ -327,10 +348,15 @@ class DGP_IWVI(DGP_VI):
             fmean, fvar, local_kls, global_kls, _, _, _ = self._forward_iw(zs)
             return self._reduce(fmean, fvar, self.Y, local_kls, global_kls, B, K, stride_b=K, stride_k=1,
                                 mode_vi=False, want_ms=want_ms, K_total=K_total)
+        el = dict(B=B, K=K, stride_b=K, stride_k=1, mode_vi=False, want_ms=want_ms, K_total=K_total,
+                  ms_out=ms_out, elbo_out=elbo_out)
+        if self.lv_in_precompute and isinstance(self.layers[0], LatentVariableLayer) and (zs is None or zs[0] is None):
+            # the leading latent-variable layer rides in the precompute launch, beside the factorisations
+            self.precompute(with_encoders=True, sample_first=dict(K=K, sampled_kl=True, want_z=self.keep_lv_noise))
+            return self._fused_forward(B * K, K, B, (B, K), zs=None if zs is None else zs[1:], sampled_kl=True,
+                                       elbo=el, stack_from=1)[2]
         self.precompute(with_encoders=True)
-        return self._fused_forward(B * K, K, B, (B, K), zs=zs, sampled_kl=True,
-                                   elbo=dict(B=B, K=K, stride_b=K, stride_k=1, mode_vi=False, want_ms=want_ms,
-                                             K_total=K_total, ms_out=ms_out, elbo_out=elbo_out))[2]
+        return self._fused_forward(B * K, K, B, (B, K), zs=zs, sampled_kl=True, elbo=el)[2]
 
     def _build_likelihood(self, zs=None, out=None):
         """The importance-weighted ELBO, reference models.py:112-150 (``out``: optional 1-element float64 result buffer)."""

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define IWVI_ABI_VERSION 2
+#define IWVI_ABI_VERSION 3
 
 enum {
     IWVI_OK = 0,
@@ -108,6 +108,16 @@ typedef struct iwvi_enc_desc {
     const float* XY; int64_t rows;
     const float* const* enc_W; const float* const* enc_b; const int32_t* dims; int32_t n_enc, latent_dim;
     float* out;
+    /* optional sampling tail (sample_X == NULL: absent).  For the IW tiling -- K samples per data row, sample
+     * t = row * K + k -- the whole LatentVariableLayer is evaluated here instead of in the layer kernel (it needs
+     * nothing from the factorisation): W = q_mu + z softplus(raw - 3) (layers.py:83-87), with z drawn from the same
+     * counter-based stream the layer kernel would use for layer `layer_index` of evaluation *rng_state. */
+    const float* X; int32_t Dx;          /* data rows [rows, Dx] (the minibatch, untiled) */
+    int32_t K, sampled_kl, layer_index;
+    uint64_t seed; const uint64_t* rng_state;
+    float* sample_X;                     /* [rows * K, Dx + latent_dim] = concat(X tiled, W)          (layers.py:89) */
+    float* sample_kl;                    /* [rows * K] local regulariser summed over the latent dims  (:98-103)      */
+    float* sample_z;                     /* optional [rows * K, latent_dim]: the draws                               */
 } iwvi_enc_desc;
 int iwvi_model_precompute(const iwvi_gp_desc* layers_host, int n_layers,
                           const iwvi_enc_desc* encs_host, int n_encs, void* stream);
@@ -213,6 +223,13 @@ typedef struct iwvi_elbo_desc {
     float* out_lse_ms; float* out_logp; double* out_elbo;
     double* ws;                     /* optional scratch, ceil(T/16) doubles: one partial sum per workgroup when every
                                      * point's K samples sit in one chunk; NULL -> the last workgroup reads all of out_logw */
+    /* when the leading LatentVariableLayer was evaluated by iwvi_model_precompute (iwvi_enc_desc.sample_X): its local
+     * regulariser per sample [T] (subtracted from the log-weights like models.py:141-142), and the position of this
+     * stack's first layer in the model, so that its noise streams do not collide with that layer's; x_per_sample:
+     * X is that layer's output [T, Dx], one row per sample (Y and XY keep the row_div / row_mod mapping). */
+    const float* lw_init;
+    int32_t noise_layer_base;
+    int32_t x_per_sample;
 } iwvi_elbo_desc;
 
 int iwvi_dgp_forward(const iwvi_layer_desc* layers_host, int n_layers,

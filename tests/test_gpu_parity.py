@@ -278,6 +278,45 @@ def test_iw_elbo_matches_oracle(gpu_device, L, M, K, B, lv):
     np.testing.assert_allclose(_np(fvar), vo, rtol=5e-3, atol=2e-4)
 
 
+@pytest.mark.parametrize("L,M,K,B", [(2, 128, 20, 48), (3, 64, 7, 33), (2, 32, 70, 5), (2, 128, 20, 1024)])
+def test_lv_layer_in_the_precompute_launch(gpu_device, L, M, K, B):
+    """``lv_in_precompute``: the leading latent-variable layer (layers.py:83-103) evaluated by the precompute
+    launch and handed to the layer kernel as [T, Dx+Lw] rows + per-sample regulariser.  (1) against the oracle on
+    the draws it exported; (2) same Philox streams as the in-kernel layer -> the same estimate from both routes."""
+    from dgps_with_iwvi_amd import synthetic
+    spec = synthetic.make_spec(L=L, M=M, B=B, K=K, with_lv=True, seed=L * 10 + K)
+    zs = synthetic.make_noise(spec, seed=9)
+    model = synthetic.build_model(spec, gpu_device)
+    model.lv_in_precompute, model.keep_lv_noise = True, True
+    zd = [None] + [_t(z, gpu_device) for z in zs[1:]]
+    logp = model.E_log_p_Y(zd)
+    z0 = _np(model.layers[0]._smp_z).reshape(B, K, -1)
+    assert abs(z0.mean()) < 5.0 / np.sqrt(z0.size) and abs(z0.std() - 1) < 0.05
+    elbo = model.compute_log_likelihood(zd)                      # the step counter moved on: new LV draws
+    z1 = _np(model.layers[0]._smp_z).reshape(B, K, -1)
+    assert np.abs(z1 - z0).max() > 0.1
+    if B * K <= 2000:
+        om = build_oracle(spec)
+        L_NK = om.log_weights(oracle_noise(spec, [z0] + zs[1:]))[0]
+        m_o = L_NK.max(1)
+        logp_o = m_o + np.log(np.exp(L_NK - m_o[:, None]).sum(1)) - np.log(K)
+        np.testing.assert_allclose(_np(logp), logp_o, rtol=2e-4, atol=2e-2)
+        ref = om.build_likelihood(oracle_noise(spec, [z1] + zs[1:]))
+        assert abs(elbo - ref) <= ELBO_RTOL * abs(ref), (elbo, ref)
+    # route 2: the layer inside the layer kernel, fed the exported draws
+    model.lv_in_precompute = False
+    e2 = model.compute_log_likelihood([_t(z1, gpu_device)] + zd[1:])
+    assert abs(elbo - e2) <= 2e-6 * abs(e2), (elbo, e2)
+    # in-kernel draws everywhere: both routes key the streams by (seed, step, model layer index, sample, quad)
+    step = int(model._words()[1])
+    a = model.compute_log_likelihood(None)
+    model._words()[1] = step
+    model.lv_in_precompute = True
+    b = model.compute_log_likelihood(None)
+    assert abs(a - b) <= 2e-6 * abs(a), (a, b)
+    assert int(model._words()[1]) == step + 1
+
+
 def test_full_cov_over_samples_flag_matches_diag(gpu_device):
     """following the reference literally ([B,Dy,K,K] covariance then matrix_diag_part, models.py:133)
     gives the same ELBO as asking the final layer for marginals."""
