@@ -71,6 +71,18 @@ class ElboDesc(ctypes.Structure):
                 ("x_per_sample", ctypes.c_int32)]
 
 
+class GpBwdDesc(ctypes.Structure):
+    """struct iwvi_gp_bwd_desc (include/iwvi_hip.h): adjoint of one GP layer."""
+    _fields_ = [("state", c_void_p), ("Z", c_void_p), ("lengthscales", c_void_p), ("q_mu", c_void_p),
+                ("q_sqrt", c_void_p), ("variance", c_float),
+                ("M", ctypes.c_int32), ("D", ctypes.c_int32), ("R", ctypes.c_int32), ("P", ctypes.c_int32),
+                ("kern_type", ctypes.c_int32), ("W", c_void_p), ("mf_type", ctypes.c_int32), ("mf_A", c_void_p),
+                ("F", c_void_p), ("noise", c_void_p), ("A", c_void_p), ("U", c_void_p),
+                ("d_sample", c_void_p), ("d_mean", c_void_p), ("d_var", c_void_p), ("kl_weight", c_double),
+                ("dF", c_void_p), ("dZ", c_void_p), ("dls", c_void_p), ("dvariance", c_void_p),
+                ("dq_mu", c_void_p), ("dq_sqrt", c_void_p)]
+
+
 # name -> (restype, argtypes); every symbol include/iwvi_hip.h declares
 PROTOTYPES = {
     "iwvi_version": (c_int, []),
@@ -83,6 +95,8 @@ PROTOTYPES = {
                                   c_void_p, c_void_p]),
     "iwvi_chol_ws_bytes": (c_size_t, [c_int]),
     "iwvi_chol_factor": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+    "iwvi_gp_layer_backward_ws_bytes": (c_size_t, [c_int64, c_int, c_int, c_int]),
+    "iwvi_gp_layer_backward": (c_int, [ctypes.POINTER(GpBwdDesc), c_int64, c_void_p, c_void_p]),
     "iwvi_gp_layer_forward": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_float,
                                       c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
                                       c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),

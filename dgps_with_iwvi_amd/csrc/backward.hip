@@ -1,0 +1,452 @@
+// Backward pass of the IW-ELBO path (the reference obtains these gradients from
+// TensorFlow's autodiff of the graph built by models.py:112-150, experiments/build_models.py:284-304).
+// gfx950 only.  First, correct, version: layer by layer, intermediates in HBM, float32 MFMA products for everything
+// that sums over samples, float64 for the Cholesky adjoint.  Not yet fused like the forward.
+//
+// One GP layer (temp_workaround.py:39-91 + :142-145 + layers.py:46-48), per sample t with a = Lm^-1 k(Z, x),
+// u_r = L_r^T a, mu_r = a . q_mu_r, v_r = s2 - |a|^2 + |u_r|^2, g_r = mu_r + eps_r sqrt(v_r), f = W g + x A:
+//   heads     dmu_r = W^T (df_s + df_m),  dv_r = (W*W)^T df_v + (W^T df_s)_r eps_r / (2 sqrt v_r)
+//   da        = sum_r [ q_mu_r dmu_r + 2 dv_r (L_r u_r - a) ]                  (row GEMMs on U_r, L_r^T)
+//   dk        = Lm^-T da                                                       (row GEMM with Lm^-1)
+//   c_m       = -1/2 k_m dk_m ;  dx~ = 2 x~ sum_m c_m - 2 C Z~ ;  dZ~ = 2 Z~ o colsum(C) - 2 C^T X~
+//   dq_mu     = A^T dMU ;  dL_r = tril(2 A^T diag(dv_r) U_r) ;  dLm = -tril(dK^T A)   (split-K GEMMs over samples)
+//   dKuu      = 1/2 (S + S^T),  S = Lm^-T Phi(Lm^T dLm) Lm^-1                  (float64)
+// and the closed-form gradient of the whitened KL (temp_workaround.py:186-188) with weight -kl_weight.
+#include "iwvi_common.h"
+#include <cmath>
+
+namespace iwvi {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ------------------------------------------------------------------------------------------------------------
+// C[m, n] = alpha * sum_k s * A(m, k) * B(k, n) (+ beta * C), any strides; s = scale[k] or scale[m] (optional).
+// 64x64 output tile per workgroup, 16-deep LDS stages, v_mfma_f32_16x16x4_f32: wave w owns rows 16w..16w+15.
+// nsplit > 1: workgroup z sums k in [z*kchunk, (z+1)*kchunk) into part[z][M][N] (summed by k_reduce_parts, in
+// float64, in a fixed order: the gradients are bit-reproducible).
+// ------------------------------------------------------------------------------------------------------------
+struct GemmArgs {
+    const float* A; long long a_sm, a_sk;
+    const float* B; long long b_sk, b_sn;
+    const float* scale; long long s_stride; int scale_on_k;
+    float* C; long long ldc;
+    float* part;
+    int M, N, K, nsplit, kchunk;
+    float alpha, beta;
+    int b_keep_n_ge_k;                  // B(k, n) read as 0 where n < k (a lower-triangular matrix indexed [n][k])
+};
+constexpr int GT = 64, GK = 16, GLD = GT + 4;
+
+__global__ __launch_bounds__(256) void k_gemm(GemmArgs g) {
+    __shared__ float As[GK][GLD];
+    __shared__ float Bs[GK][GLD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m0 = blockIdx.y * GT, n0 = blockIdx.x * GT;
+    const int kb = (int)blockIdx.z * g.kchunk;
+    const int ke = (kb + g.kchunk < g.K) ? kb + g.kchunk : g.K;
+    const bool a_k_contig = g.a_sk == 1, b_n_contig = g.b_sn == 1;
+    f32x4 acc[4];
+    for (int j = 0; j < 4; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int k0 = kb; k0 < ke; k0 += GK) {
+        for (int i = 0; i < 4; ++i) {
+            const int idx = tid + 256 * i;
+            int m, k;
+            if (a_k_contig) { m = idx >> 4; k = idx & 15; } else { k = idx >> 6; m = idx & 63; }
+            const int gm = m0 + m, gk = k0 + k;
+            float v = 0.f;
+            if (gm < g.M && gk < ke) {
+                v = g.A[gm * g.a_sm + gk * g.a_sk];
+                if (g.scale) v *= g.scale[(g.scale_on_k ? gk : gm) * g.s_stride];
+            }
+            As[k][m] = v;
+            int n;
+            if (b_n_contig) { k = idx >> 6; n = idx & 63; } else { n = idx >> 4; k = idx & 15; }
+            const int gn = n0 + n, gk2 = k0 + k;
+            float w = 0.f;
+            if (gn < g.N && gk2 < ke && (!g.b_keep_n_ge_k || gn >= gk2)) w = g.B[gk2 * g.b_sk + gn * g.b_sn];
+            Bs[k][n] = w;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const float a = As[4 * kk + (lane >> 4)][16 * wave + (lane & 15)];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float b = Bs[4 * kk + (lane >> 4)][16 * j + (lane & 15)];
+                acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[j], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+    for (int j = 0; j < 4; ++j)
+        for (int v = 0; v < 4; ++v) {
+            const int m = m0 + 16 * wave + 4 * (lane >> 4) + v, n = n0 + 16 * j + (lane & 15);
+            if (m >= g.M || n >= g.N) continue;
+            if (g.nsplit > 1) g.part[((size_t)blockIdx.z * g.M + m) * g.N + n] = acc[j][v];
+            else {
+                float* c = g.C + m * g.ldc + n;
+                *c = g.alpha * acc[j][v] + (g.beta != 0.f ? g.beta * *c : 0.f);
+            }
+        }
+}
+
+// out[m, n] = alpha * sum_s part[s][m][n] (+ beta * out); tri: entries above the diagonal become 0.  Either output
+// may be null (float / double).
+struct ReduceArgs { const float* part; int S, M, N; float* out; double* out64; long long ldo; double alpha, beta; int tri; };
+__global__ void k_reduce_parts(ReduceArgs r) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= r.M * r.N) return;
+    const int m = idx / r.N, n = idx - m * r.N;
+    double s = 0.0;
+    for (int k = 0; k < r.S; ++k) s += (double)r.part[(size_t)k * r.M * r.N + idx];
+    s *= r.alpha;
+    if (r.tri && n > m) s = 0.0;
+    if (r.out) { float* o = r.out + m * r.ldo + n; *o = (float)(s + (r.beta != 0.0 ? r.beta * (double)*o : 0.0)); }
+    if (r.out64) { double* o = r.out64 + m * r.ldo + n; *o = s + (r.beta != 0.0 ? r.beta * *o : 0.0); }
+}
+
+static int gemm(hipStream_t st, GemmArgs g, float* part_ws, size_t part_floats, float* out, double* out64, long long ldo,
+                double alpha, double beta, int tri) {
+    // split-K form: C / alpha / beta of `g` unused; the reduction writes out / out64
+    const int kchunk = 512;
+    g.nsplit = (g.K + kchunk - 1) / kchunk; g.kchunk = kchunk;
+    if (g.nsplit < 2) { g.nsplit = 2; g.kchunk = round_up((g.K + 1) / 2, GK); if (g.kchunk < GK) g.kchunk = GK; }
+    if ((size_t)g.nsplit * g.M * g.N > part_floats) { set_error("backward: split-K workspace too small"); return IWVI_ERR_ARG; }
+    g.part = part_ws;
+    hipLaunchKernelGGL(k_gemm, dim3((g.N + GT - 1) / GT, (g.M + GT - 1) / GT, g.nsplit), dim3(256), 0, st, g);
+    ReduceArgs r{part_ws, g.nsplit, g.M, g.N, out, out64, ldo, alpha, beta, tri};
+    hipLaunchKernelGGL(k_reduce_parts, dim3((g.M * g.N + 255) / 256), dim3(256), 0, st, r);
+    return check_launch("k_gemm (split-K)");
+}
+static int gemm_rows(hipStream_t st, GemmArgs g) {     // many rows, short K: direct store
+    g.nsplit = 1; g.kchunk = round_up(g.K, GK); g.part = nullptr;
+    hipLaunchKernelGGL(k_gemm, dim3((g.N + GT - 1) / GT, (g.M + GT - 1) / GT, 1), dim3(256), 0, st, g);
+    return check_launch("k_gemm (rows)");
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// per-sample heads: one wave per sample
+// ------------------------------------------------------------------------------------------------------------
+struct HeadArgs {
+    const float* A; const float* U; const float* eps; const float* W; const float* mfA;
+    const float* dFs; const float* dFm; const float* dFv;
+    float* DMU; float* DV2; float* SDV; float* dF;
+    long long T; int M, Mp, D, R, P, mf_type; float variance;
+};
+__device__ __forceinline__ float wave_sum(float v) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__global__ __launch_bounds__(256) void k_bw_heads(HeadArgs h) {
+    const int lane = threadIdx.x & 63;
+    const long long t = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= h.T) return;
+    const float* a = h.A + t * h.Mp;
+    float aa = 0.f;
+    for (int m = lane; m < h.M; m += 64) aa = fmaf(a[m], a[m], aa);
+    aa = wave_sum(aa);
+    float mine_dv = 0.f, mine_dmu = 0.f;                  // lane r keeps latent r's heads
+    for (int r = 0; r < h.R; ++r) {
+        const float* u = h.U + ((size_t)r * h.T + t) * h.Mp;
+        float uu = 0.f;
+        for (int m = lane; m < h.M; m += 64) uu = fmaf(u[m], u[m], uu);
+        uu = wave_sum(uu);
+        float dg = 0.f, dm = 0.f, dvv = 0.f;
+        if (h.W) {
+            for (int p = 0; p < h.P; ++p) {
+                const float w = h.W[p * h.R + r];
+                if (h.dFs) dg = fmaf(w, h.dFs[t * h.P + p], dg);
+                if (h.dFm) dm = fmaf(w, h.dFm[t * h.P + p], dm);
+                if (h.dFv) dvv = fmaf(w * w, h.dFv[t * h.P + p], dvv);
+            }
+        } else {
+            if (h.dFs) dg = h.dFs[t * h.P + r];
+            if (h.dFm) dm = h.dFm[t * h.P + r];
+            if (h.dFv) dvv = h.dFv[t * h.P + r];
+        }
+        const float v = h.variance - aa + uu;
+        float dv = dvv;
+        if (v > 0.f) { if (h.eps) dv += dg * h.eps[t * h.R + r] * 0.5f / sqrtf(v); } else dv = 0.f;   // the forward clamps v at 0
+        if (lane == r) { mine_dv = dv; mine_dmu = dg + dm; }
+    }
+    if (lane < h.R) { h.DMU[t * h.R + lane] = mine_dmu; h.DV2[t * h.R + lane] = 2.f * mine_dv; }
+    const float sdv = wave_sum(lane < h.R ? mine_dv : 0.f);
+    if (lane == 0) h.SDV[t] = sdv;
+    // the mean function's share of dF (layers.py:46-48: added to the samples and to the mean)
+    if (h.dF) for (int d = lane; d < h.D; d += 64) {
+        float acc = 0.f;
+        if (h.mf_type == IWVI_MF_LINEAR) {
+            for (int p = 0; p < h.P; ++p) {
+                float up = 0.f;
+                if (h.dFs) up += h.dFs[t * h.P + p];
+                if (h.dFm) up += h.dFm[t * h.P + p];
+                acc = fmaf(h.mfA[d * h.P + p], up, acc);
+            }
+        } else if (h.mf_type == IWVI_MF_IDENTITY) {
+            if (h.dFs) acc += h.dFs[t * h.P + d];
+            if (h.dFm) acc += h.dFm[t * h.P + d];
+        }
+        h.dF[t * h.D + d] = acc;
+    }
+}
+
+// DA[t, m] -= 2 * SDV[t] * A[t, m]
+__global__ void k_bw_axpy(float* DA, const float* A, const float* SDV, long long T, int M, int Mp) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= T * M) return;
+    const long long t = idx / M; const int m = (int)(idx - t * M);
+    DA[idx] = fmaf(-2.f * SDV[t], A[t * Mp + m], DA[idx]);
+}
+
+// K_uf entries again (RBF, direct differences), c = -1/2 k dk written over DA; per-sample sum_m c and sum_m k dk
+struct KernArgs { const float* F; const float* Zt; const float* invls; const float* DK; float* C; float* RS; long long T; int M, D; float variance; };
+__global__ __launch_bounds__(256) void k_bw_kernel(KernArgs a) {
+    const int lane = threadIdx.x & 63;
+    const long long t = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= a.T) return;
+    float xt[IWVI_MAX_D];
+    for (int d = 0; d < a.D; ++d) xt[d] = a.F[t * a.D + d] * a.invls[d];
+    float sc = 0.f, skd = 0.f;
+    for (int m = lane; m < a.M; m += 64) {
+        float d2 = 0.f;
+        for (int d = 0; d < a.D; ++d) { const float e = xt[d] - a.Zt[m * a.D + d]; d2 = fmaf(e, e, d2); }
+        const float k = a.variance * __expf(-0.5f * d2);
+        const float kd = k * a.DK[t * a.M + m];
+        a.C[t * a.M + m] = -0.5f * kd;
+        sc += -0.5f * kd; skd += kd;
+    }
+    sc = wave_sum(sc); skd = wave_sum(skd);
+    if (lane == 0) { a.RS[2 * t] = sc; a.RS[2 * t + 1] = skd; }
+}
+
+// dx~ = 2 x~ rowsum(C) - 2 C Z~ ;  dF += dx~ * invls ;  Q = dx~ o x (its column sums are d/d invls through x~)
+__global__ void k_bw_dx(const float* F, const float* invls, const float* RS, const float* CZ, float* dF, float* Q, long long T, int D) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= T * D) return;
+    const long long t = idx / D; const int d = (int)(idx - t * D);
+    const float x = F[idx], il = invls[d];
+    const float dxt = 2.f * (x * il) * RS[2 * t] - 2.f * CZ[idx];
+    if (dF) dF[idx] = fmaf(dxt, il, dF[idx]);
+    Q[idx] = dxt * x;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// float64 side: small dense products for the Cholesky adjoint, K_uu's own gradient, final assembly
+// ------------------------------------------------------------------------------------------------------------
+// C[i, j] = sum_k A(i, k) B(k, j); post = 1: Phi (strict upper -> 0, diagonal halved)
+__global__ void k_dmm(const double* A, long long a_si, long long a_sk, const double* B, long long b_sk, long long b_sj,
+                      double* C, int n, int ldc, int post) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;
+    if (j >= n) return;
+    double s = 0.0;
+    for (int k = 0; k < n; ++k) s = fma(A[i * a_si + k * a_sk], B[k * b_sk + j * b_sj], s);
+    if (post == 1) s = (j > i) ? 0.0 : (j == i ? 0.5 * s : s);
+    C[(size_t)i * ldc + j] = s;
+}
+__global__ void k_prep(const float* Z, const float* ls, const double* Linv64, int Mp, float* Zt, float* invls, float* LinvF, int M, int D) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < D) invls[idx] = 1.f / ls[idx];
+    if (idx < M * D) Zt[idx] = Z[idx] / ls[idx % D];
+    if (idx < M * M) { const int i = idx / M, j = idx - i * M; LinvF[idx] = j <= i ? (float)Linv64[(size_t)i * Mp + j] : 0.f; }
+}
+// row m of K_uu: dZ~_uu[m, :] = -2 sum_n Sbar_mn K_mn (z~_m - z~_n),  dvar_m = sum_n Sbar_mn K_mn / s2,  Sbar = (S + S^T)/2
+__global__ __launch_bounds__(256) void k_kuu_bwd(const float* Zt, const double* S, int M, int D, double variance, double* dZt_uu, double* dvar_m) {
+    __shared__ double red[256];
+    const int m = blockIdx.x, tid = threadIdx.x;
+    double acc[IWVI_MAX_D + 1];
+    for (int d = 0; d <= D; ++d) acc[d] = 0.0;
+    for (int n = tid; n < M; n += 256) {
+        double d2 = 0.0;
+        for (int d = 0; d < D; ++d) { const double e = (double)Zt[m * D + d] - (double)Zt[n * D + d]; d2 += e * e; }
+        const double k = variance * exp(-0.5 * d2);
+        const double sk = 0.5 * (S[(size_t)m * M + n] + S[(size_t)n * M + m]) * k;
+        for (int d = 0; d < D; ++d) acc[d] += -2.0 * sk * ((double)Zt[m * D + d] - (double)Zt[n * D + d]);
+        acc[D] += sk / variance;
+    }
+    for (int d = 0; d <= D; ++d) {
+        red[tid] = acc[d];
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
+        if (tid == 0) { if (d < D) dZt_uu[m * D + d] = red[0]; else dvar_m[m] = red[0]; }
+        __syncthreads();
+    }
+}
+struct FinalArgsB {
+    const float* Z; const float* ls; const float* q_mu; const float* q_sqrt; const float* Zt; const float* invls;
+    const float* colsumC; const float* CtF; const float* sums; const float* dinvls_x; const double* dZt_uu; const double* dvar_m;
+    float* dZ; float* dls; float* dvariance; float* dq_mu; float* dq_sqrt;
+    int M, D, R; double kl_weight, variance;
+};
+// one workgroup: dZ, dls, dvariance and the KL terms
+__global__ __launch_bounds__(256) void k_bw_final(FinalArgsB f) {
+    __shared__ double dil[IWVI_MAX_D];
+    const int tid = threadIdx.x;
+    if (tid < f.D) dil[tid] = 0.0;
+    __syncthreads();
+    if (tid < f.D) {                                        // thread d walks its column: fixed order
+        const int d = tid;
+        double s = (double)f.dinvls_x[d];
+        for (int m = 0; m < f.M; ++m) {
+            const double zt = f.Zt[m * f.D + d];
+            const double dzt = 2.0 * zt * (double)f.colsumC[m] - 2.0 * (double)f.invls[d] * (double)f.CtF[m * f.D + d] + f.dZt_uu[m * f.D + d];
+            if (f.dZ) f.dZ[m * f.D + d] = (float)(dzt * (double)f.invls[d]);
+            s += dzt * (double)f.Z[m * f.D + d];
+        }
+        if (f.dls) f.dls[d] = (float)(-s * (double)f.invls[d] * (double)f.invls[d]);
+    }
+    if (tid == 0 && f.dvariance) {
+        double s = (double)f.sums[0] + (double)f.sums[1] / f.variance;     // sum_t sum_r dv_r  +  sum k dk / s2
+        for (int m = 0; m < f.M; ++m) s += f.dvar_m[m];
+        f.dvariance[0] = (float)s;
+    }
+    // - kl_weight * d KL: KL = 1/2 (sum q_mu^2 - R M - sum log L_ii^2 + sum L^2)   (temp_workaround.py:186-188)
+    if (f.dq_mu) for (int i = tid; i < f.M * f.R; i += 256) f.dq_mu[i] = (float)((double)f.dq_mu[i] - f.kl_weight * (double)f.q_mu[i]);
+    if (f.dq_sqrt) for (long long i = tid; i < (long long)f.R * f.M * f.M; i += 256) {
+        const int c = (int)(i % f.M), r_ = (int)((i / f.M) % f.M);
+        if (c > r_) { f.dq_sqrt[i] = 0.f; continue; }
+        const double L = f.q_sqrt[i];
+        f.dq_sqrt[i] = (float)((double)f.dq_sqrt[i] - f.kl_weight * (L - (c == r_ ? 1.0 / L : 0.0)));
+    }
+}
+
+struct BwdWs {
+    float *DMU, *DV2, *SDV, *DA, *DK, *CZ, *Q, *RS, *part, *LinvF, *Zt, *invls, *colsumC, *CtF, *sums, *dinvls_x, *one;
+    double *Lbar, *T1, *T2, *S, *dZt_uu, *dvar_m;
+    size_t part_floats, bytes;
+};
+static BwdWs bwd_layout(char* base, long long T, int M, int D, int R) {
+    BwdWs w; size_t o = 0;
+    auto take = [&](size_t bytes) { char* p = base ? base + o : nullptr; o = align256(o + bytes); return p; };
+    const int nsplit = (int)((T + 511) / 512) + 2;
+    w.DMU = (float*)take(sizeof(float) * T * R); w.DV2 = (float*)take(sizeof(float) * T * R); w.SDV = (float*)take(sizeof(float) * T);
+    w.DA = (float*)take(sizeof(float) * T * M); w.DK = (float*)take(sizeof(float) * T * M);
+    w.CZ = (float*)take(sizeof(float) * T * D); w.Q = (float*)take(sizeof(float) * T * D); w.RS = (float*)take(sizeof(float) * T * 2);
+    w.part_floats = (size_t)nsplit * M * M;
+    w.part = (float*)take(sizeof(float) * w.part_floats);
+    w.LinvF = (float*)take(sizeof(float) * M * M); w.Zt = (float*)take(sizeof(float) * M * D); w.invls = (float*)take(sizeof(float) * IWVI_MAX_D);
+    w.colsumC = (float*)take(sizeof(float) * M); w.CtF = (float*)take(sizeof(float) * M * D); w.sums = (float*)take(sizeof(float) * 4);
+    w.dinvls_x = (float*)take(sizeof(float) * IWVI_MAX_D); w.one = (float*)take(sizeof(float) * 4);
+    w.Lbar = (double*)take(sizeof(double) * M * M); w.T1 = (double*)take(sizeof(double) * M * M); w.T2 = (double*)take(sizeof(double) * M * M);
+    w.S = (double*)take(sizeof(double) * M * M); w.dZt_uu = (double*)take(sizeof(double) * M * D); w.dvar_m = (double*)take(sizeof(double) * M);
+    w.bytes = o;
+    return w;
+}
+__global__ void k_set_one(float* p) { if (threadIdx.x < 4) p[threadIdx.x] = 1.f; }
+
+}  // namespace iwvi
+
+using namespace iwvi;
+
+extern "C" size_t iwvi_gp_layer_backward_ws_bytes(int64_t T, int M, int D, int R) {
+    if (T <= 0 || M <= 0 || D <= 0 || R <= 0) return 0;
+    return bwd_layout(nullptr, T, M, D, R).bytes;
+}
+
+extern "C" int iwvi_gp_layer_backward(const iwvi_gp_bwd_desc* dp, int64_t T, void* ws_, void* stream_) {
+    if (!dp || !ws_ || T <= 0) { set_error("iwvi_gp_layer_backward: bad argument"); return IWVI_ERR_ARG; }
+    const iwvi_gp_bwd_desc& d = *dp;
+    if (!d.state || !d.Z || !d.lengthscales || !d.q_mu || !d.q_sqrt || !d.F || !d.A || !d.U) { set_error("iwvi_gp_layer_backward: null input"); return IWVI_ERR_ARG; }
+    if (d.M <= 0 || d.M > IWVI_MAX_M || d.D <= 0 || d.D > IWVI_MAX_D || d.R <= 0 || d.R > IWVI_MAX_R || d.P <= 0 || d.P > IWVI_MAX_P || T >= (1LL << 31) / (d.M > d.D ? d.M : d.D)) {
+        set_error("iwvi_gp_layer_backward: size out of range"); return IWVI_ERR_ARG;
+    }
+    if (d.kern_type != IWVI_KERN_RBF) { set_error("iwvi_gp_layer_backward: only the RBF kernel has a backward pass so far"); return IWVI_ERR_UNSUPPORTED; }
+    if (!d.W && d.P != d.R) { set_error("iwvi_gp_layer_backward: P != R without a mixing matrix"); return IWVI_ERR_ARG; }
+    if (d.mf_type == IWVI_MF_LINEAR && !d.mf_A) { set_error("iwvi_gp_layer_backward: linear mean function without A"); return IWVI_ERR_ARG; }
+    if (d.mf_type == IWVI_MF_IDENTITY && d.P != d.D) { set_error("iwvi_gp_layer_backward: identity mean function needs P == D"); return IWVI_ERR_ARG; }
+    if (d.d_sample && !d.noise) { set_error("iwvi_gp_layer_backward: d_sample needs the forward's draws"); return IWVI_ERR_ARG; }
+    hipStream_t st = (hipStream_t)stream_;
+    const int M = d.M, D = d.D, R = d.R;
+    const StateLayout sl = state_layout(M, R);
+    const int Mp = sl.Mp;
+    const double* Lm64 = (const double*)((const char*)d.state + sl.off_Lm);
+    const double* Linv64 = (const double*)((const char*)d.state + sl.off_Linv);
+    BwdWs w = bwd_layout((char*)ws_, T, M, D, R);
+    int rc;
+    hipLaunchKernelGGL(k_set_one, dim3(1), dim3(64), 0, st, w.one);
+    {
+        const int n = M * M > M * D ? M * M : M * D;
+        hipLaunchKernelGGL(k_prep, dim3((n + 255) / 256), dim3(256), 0, st, d.Z, d.lengthscales, Linv64, Mp, w.Zt, w.invls, w.LinvF, M, D);
+    }
+    HeadArgs h{d.A, d.U, d.noise, d.W, d.mf_A, d.d_sample, d.d_mean, d.d_var, w.DMU, w.DV2, w.SDV, d.dF, T, M, Mp, D, R, d.P, d.mf_type, d.variance};
+    hipLaunchKernelGGL(k_bw_heads, dim3((unsigned)((T + 3) / 4)), dim3(256), 0, st, h);
+    if ((rc = check_launch("k_bw_heads")) != IWVI_OK) return rc;
+    // DA = DMU q_mu^T
+    GemmArgs g{};
+    g.A = w.DMU; g.a_sm = R; g.a_sk = 1; g.B = d.q_mu; g.b_sk = 1; g.b_sn = R; g.C = w.DA; g.ldc = M; g.M = (int)T; g.N = M; g.K = R; g.alpha = 1.f; g.beta = 0.f;
+    if ((rc = gemm_rows(st, g)) != IWVI_OK) return rc;
+    // DA += (2 dv_r) o (U_r L_r^T)
+    for (int r = 0; r < R; ++r) {
+        GemmArgs q{};
+        q.A = d.U + (size_t)r * T * Mp; q.a_sm = Mp; q.a_sk = 1;
+        q.B = d.q_sqrt + (size_t)r * M * M; q.b_sk = 1; q.b_sn = M; q.b_keep_n_ge_k = 1;      // B(k = j, n = i) = L_r[i][j], i >= j
+        q.scale = w.DV2 + r; q.s_stride = R; q.scale_on_k = 0;
+        q.C = w.DA; q.ldc = M; q.M = (int)T; q.N = M; q.K = M; q.alpha = 1.f; q.beta = 1.f;
+        if ((rc = gemm_rows(st, q)) != IWVI_OK) return rc;
+    }
+    hipLaunchKernelGGL(k_bw_axpy, dim3((unsigned)((T * M + 255) / 256)), dim3(256), 0, st, w.DA, d.A, w.SDV, (long long)T, M, Mp);
+    // DK = DA Lm^-1
+    {
+        GemmArgs q{};
+        q.A = w.DA; q.a_sm = M; q.a_sk = 1; q.B = w.LinvF; q.b_sk = M; q.b_sn = 1;
+        q.C = w.DK; q.ldc = M; q.M = (int)T; q.N = M; q.K = M; q.alpha = 1.f; q.beta = 0.f;
+        if ((rc = gemm_rows(st, q)) != IWVI_OK) return rc;
+    }
+    // dLm = -tril(DK^T A)  (float64 copy for the adjoint of the factorisation)
+    {
+        GemmArgs q{};
+        q.A = w.DK; q.a_sm = 1; q.a_sk = M; q.B = d.A; q.b_sk = Mp; q.b_sn = 1; q.M = M; q.N = M; q.K = (int)T;
+        if ((rc = gemm(st, q, w.part, w.part_floats, nullptr, w.Lbar, M, -1.0, 0.0, 1)) != IWVI_OK) return rc;
+    }
+    // dq_mu = A^T DMU
+    if (d.dq_mu) {
+        GemmArgs q{};
+        q.A = d.A; q.a_sm = 1; q.a_sk = Mp; q.B = w.DMU; q.b_sk = R; q.b_sn = 1; q.M = M; q.N = R; q.K = (int)T;
+        if ((rc = gemm(st, q, w.part, w.part_floats, d.dq_mu, nullptr, R, 1.0, 0.0, 0)) != IWVI_OK) return rc;
+    }
+    // dL_r = tril(A^T diag(2 dv_r) U_r)
+    if (d.dq_sqrt) for (int r = 0; r < R; ++r) {
+        GemmArgs q{};
+        q.A = d.A; q.a_sm = 1; q.a_sk = Mp; q.B = d.U + (size_t)r * T * Mp; q.b_sk = Mp; q.b_sn = 1;
+        q.scale = w.DV2 + r; q.s_stride = R; q.scale_on_k = 1; q.M = M; q.N = M; q.K = (int)T;
+        if ((rc = gemm(st, q, w.part, w.part_floats, d.dq_sqrt + (size_t)r * M * M, nullptr, M, 1.0, 0.0, 1)) != IWVI_OK) return rc;
+    }
+    // C = -1/2 K o DK (over DA), per-sample sums
+    KernArgs ka{d.F, w.Zt, w.invls, w.DK, w.DA, w.RS, T, M, D, d.variance};
+    hipLaunchKernelGGL(k_bw_kernel, dim3((unsigned)((T + 3) / 4)), dim3(256), 0, st, ka);
+    if ((rc = check_launch("k_bw_kernel")) != IWVI_OK) return rc;
+    // CZ = C Z~
+    {
+        GemmArgs q{};
+        q.A = w.DA; q.a_sm = M; q.a_sk = 1; q.B = w.Zt; q.b_sk = D; q.b_sn = 1;
+        q.C = w.CZ; q.ldc = D; q.M = (int)T; q.N = D; q.K = M; q.alpha = 1.f; q.beta = 0.f;
+        if ((rc = gemm_rows(st, q)) != IWVI_OK) return rc;
+    }
+    hipLaunchKernelGGL(k_bw_dx, dim3((unsigned)((T * D + 255) / 256)), dim3(256), 0, st, d.F, w.invls, w.RS, w.CZ, d.dF, w.Q, (long long)T, D);
+    // sums over samples: C^T F, colsum(C), colsum(Q), (sum SDV, sum k dk)
+    {
+        GemmArgs q{};
+        q.A = w.DA; q.a_sm = 1; q.a_sk = M; q.B = d.F; q.b_sk = D; q.b_sn = 1; q.M = M; q.N = D; q.K = (int)T;
+        if ((rc = gemm(st, q, w.part, w.part_floats, w.CtF, nullptr, D, 1.0, 0.0, 0)) != IWVI_OK) return rc;
+        q.B = w.one; q.b_sk = 0; q.b_sn = 0; q.N = 1;
+        if ((rc = gemm(st, q, w.part, w.part_floats, w.colsumC, nullptr, 1, 1.0, 0.0, 0)) != IWVI_OK) return rc;
+        q.A = w.Q; q.a_sm = 1; q.a_sk = D; q.M = D;
+        if ((rc = gemm(st, q, w.part, w.part_floats, w.dinvls_x, nullptr, 1, 1.0, 0.0, 0)) != IWVI_OK) return rc;
+        q.A = w.SDV; q.a_sm = 0; q.a_sk = 1; q.M = 1;
+        if ((rc = gemm(st, q, w.part, w.part_floats, w.sums, nullptr, 1, 1.0, 0.0, 0)) != IWVI_OK) return rc;
+        q.A = w.RS + 1; q.a_sm = 0; q.a_sk = 2; q.M = 1;
+        if ((rc = gemm(st, q, w.part, w.part_floats, w.sums + 1, nullptr, 1, 1.0, 0.0, 0)) != IWVI_OK) return rc;
+    }
+    // adjoint of Lm = chol(Kuu): S = Lm^-T Phi(Lm^T Lbar) Lm^-1
+    {
+        const dim3 grid((M + 127) / 128, M), block(128);
+        hipLaunchKernelGGL(k_dmm, grid, block, 0, st, Lm64, 1LL, (long long)Mp, (const double*)w.Lbar, (long long)M, 1LL, w.T1, M, M, 1);
+        hipLaunchKernelGGL(k_dmm, grid, block, 0, st, Linv64, 1LL, (long long)Mp, (const double*)w.T1, (long long)M, 1LL, w.T2, M, M, 0);
+        hipLaunchKernelGGL(k_dmm, grid, block, 0, st, (const double*)w.T2, (long long)M, 1LL, Linv64, (long long)Mp, 1LL, w.S, M, M, 0);
+        hipLaunchKernelGGL(k_kuu_bwd, dim3(M), dim3(256), 0, st, w.Zt, (const double*)w.S, M, D, (double)d.variance, w.dZt_uu, w.dvar_m);
+        if ((rc = check_launch("cholesky adjoint")) != IWVI_OK) return rc;
+    }
+    FinalArgsB f{d.Z, d.lengthscales, d.q_mu, d.q_sqrt, w.Zt, w.invls, w.colsumC, w.CtF, w.sums, w.dinvls_x, w.dZt_uu, w.dvar_m,
+                 d.dZ, d.dls, d.dvariance, d.dq_mu, d.dq_sqrt, M, D, R, d.kl_weight, (double)d.variance};
+    hipLaunchKernelGGL(k_bw_final, dim3(1), dim3(256), 0, st, f);
+    return check_launch("k_bw_final");
+}

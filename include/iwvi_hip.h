@@ -238,6 +238,35 @@ int iwvi_dgp_forward(const iwvi_layer_desc* layers_host, int n_layers,
                      uint64_t seed, uint64_t* rng_state, float* out_logw,
                      const iwvi_elbo_desc* elbo /* or NULL */, void* stream);
 
+/* ----------------------------------------------------------------------
+ * Backward pass (the reference gets these from TensorFlow's autodiff of the graph of
+ * models.py:112-150, experiments/build_models.py:284-304).  Layer by layer; RBF kernels.
+ *
+ * iwvi_gp_layer_backward: adjoint of iwvi_gp_layer_forward for T samples.
+ *   state                  as precomputed WITH IWVI_GP_WANT_DENSE (the dense float64 Lm and Lm^-1 are read)
+ *   F [T, D]               the layer's input rows (per sample)
+ *   noise [T, R]           the draws the forward used (needed when d_sample is given)
+ *   A [T, Mp], U [R, T, Mp]  a = Lm^-1 k and u_r = L_r^T a as the forward wrote them (a_out / u_out)
+ *   d_sample/d_mean/d_var [T, P]  upstream gradients, any may be NULL (= 0)
+ *   kl_weight              the objective contains -kl_weight * KL[q(u)||p(u)] of this layer (1 for the ELBO)
+ *   outputs (any may be NULL): dF [T, D], dZ [M, D], dls [D], dvariance [1], dq_mu [M, R],
+ *                          dq_sqrt [R, M, M] (lower triangle; zeros above)
+ *   ws                     iwvi_gp_layer_backward_ws_bytes(T, M, D, R) bytes
+ * ---------------------------------------------------------------------- */
+typedef struct iwvi_gp_bwd_desc {
+    const void* state;
+    const float* Z; const float* lengthscales; const float* q_mu; const float* q_sqrt;
+    float variance;
+    int32_t M, D, R, P, kern_type;
+    const float* W; int32_t mf_type; const float* mf_A;
+    const float* F; const float* noise; const float* A; const float* U;
+    const float* d_sample; const float* d_mean; const float* d_var;
+    double kl_weight;
+    float* dF; float* dZ; float* dls; float* dvariance; float* dq_mu; float* dq_sqrt;
+} iwvi_gp_bwd_desc;
+size_t iwvi_gp_layer_backward_ws_bytes(int64_t T, int M, int D, int R);
+int iwvi_gp_layer_backward(const iwvi_gp_bwd_desc* desc, int64_t T, void* ws, void* stream);
+
 /* models.py:138-150 on precomputed log-weights: logw row of (point b, sample k) = b*stride_b + k*stride_k;
  * arguments as iwvi_iw_elbo_reduce. */
 int iwvi_logw_reduce(const float* logw, int64_t B, int K, int64_t stride_b, int64_t stride_k,

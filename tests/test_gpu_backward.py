@@ -1,0 +1,80 @@
+"""Backward pass against reverse-mode autodiff of the float64 restatement
+(oracle/ref_torch_cpu.py, oracle/grad_oracle.py) -- the way the reference itself gets gradients
+(TensorFlow autodiff, experiments/build_models.py:284-304).  Tolerance: float32 kernels vs float64 oracle,
+max-norm relative 3e-3 per gradient array (stated per assert)."""
+import math
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle.ref_torch_cpu import CpuDGP   # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+def _close(name, got, ref, rtol=3e-3):
+    got, ref = np.asarray(got, dtype=np.float64), np.asarray(ref, dtype=np.float64)
+    assert got.shape == ref.shape, (name, got.shape, ref.shape)
+    scale = max(np.abs(ref).max(), 1e-12)
+    err = np.abs(got - ref).max()
+    assert err <= rtol * scale, "%s: max err %.3e vs scale %.3e" % (name, err, scale)
+
+
+def _layer_reference(spec, li, F, z, cs, cm, cv, klw):
+    """d/d{F, Z, ls, var, q_mu, q_sqrt} of sum(cs*sample + cm*mean + cv*var) - klw*KL for GP layer li (float64 autograd)."""
+    m = CpuDGP(spec, torch.float64)
+    L = m.layers[li]
+    leaf = lambda a: torch.as_tensor(np.asarray(a, dtype=np.float64)).clone().requires_grad_(True)
+    P = {k: leaf(L[k].detach().numpy()) for k in ("Z", "ls", "q_mu")}
+    P["q_sqrt"] = leaf(L["q_sqrt"].detach().numpy())
+    P["var"] = leaf(L["var"])
+    Ft = leaf(F)
+    Ld = dict(L, Z=P["Z"], ls=P["ls"], q_mu=P["q_mu"], q_sqrt=torch.tril(P["q_sqrt"]), var=P["var"])
+    s, mu, v = m._conditional(Ld, Ft[None], False, torch.as_tensor(z, dtype=torch.float64)[None])
+    if L["W"] is not None:
+        s, mu, v = s @ L["W"].T, mu @ L["W"].T, v @ (L["W"] ** 2).T
+    if L["A"] is not None:
+        s, mu = s + Ft[None] @ L["A"], mu + Ft[None] @ L["A"]
+    M, R = L["q_mu"].shape
+    Lq = Ld["q_sqrt"]
+    kl = 0.5 * ((P["q_mu"] ** 2).sum() - M * R - torch.log(torch.diagonal(Lq, dim1=-2, dim2=-1) ** 2).sum() + (Lq ** 2).sum())
+    t = lambda a: torch.as_tensor(a, dtype=torch.float64)[None]
+    obj = (t(cs) * s).sum() + (t(cm) * mu).sum() + (t(cv) * v).sum() - klw * kl
+    obj.backward()
+    g = {k: p.grad.numpy() for k, p in P.items()}
+    g["F"] = Ft.grad.numpy()
+    return g
+
+
+@pytest.mark.parametrize("M,T,li", [(32, 70, 0), (128, 300, 0), (128, 300, 1), (40, 129, 0), (256, 520, 1)])
+def test_gp_layer_backward_matches_autodiff(gpu_device, M, T, li):
+    from dgps_with_iwvi_amd import synthetic, backward
+    spec = synthetic.make_spec(L=2, M=M, B=8, K=2, with_lv=False, seed=M + li)
+    model = synthetic.build_model(spec, gpu_device)
+    layer = model.layers[li]
+    rng = np.random.default_rng(T)
+    D, R = layer._Z().shape[1], layer.num_outputs
+    P = spec["layers"][li]["W"].shape[0] if spec["layers"][li]["W"] is not None else R
+    F = rng.standard_normal((T, D)).astype(np.float32)
+    z = rng.standard_normal((T, R)).astype(np.float32)
+    cs, cm, cv = (rng.standard_normal((T, P)).astype(np.float32) for _ in range(3))
+    dev = gpu_device
+    tt = lambda a: torch.as_tensor(a, device=dev)
+    saved = backward.gp_forward_saved(layer, tt(F), tt(z))
+    np.testing.assert_array_equal(saved.noise.cpu().numpy(), z)
+    out = backward.gp_backward(layer, saved, tt(cs), tt(cm), tt(cv), kl_weight=0.7)
+    ref = _layer_reference(spec, li, F, z, cs, cm, cv, 0.7)
+    _close("dF", out["dF"].cpu(), ref["F"])
+    _close("dq_mu", out["dq_mu"].cpu(), ref["q_mu"])
+    _close("dq_sqrt", out["dq_sqrt"].cpu(), np.tril(ref["q_sqrt"]))
+    _close("dZ", out["dZ"].cpu(), ref["Z"])
+    _close("dls", out["dls"].cpu(), ref["ls"])
+    _close("dvariance", out["dvariance"].cpu()[0], ref["var"])
+    # deterministic: the split-K partials are summed in a fixed order
+    out2 = backward.gp_backward(layer, saved, tt(cs), tt(cm), tt(cv), kl_weight=0.7)
+    for k in out:
+        assert torch.equal(out[k], out2[k]), k
