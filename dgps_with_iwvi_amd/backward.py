@@ -90,3 +90,101 @@ def gp_backward(layer, saved, d_sample=None, d_mean=None, d_var=None, kl_weight=
     ws = torch.empty(_abi.lib().iwvi_gp_layer_backward_ws_bytes(T, M, D, R), dtype=torch.uint8, device=dev)
     _abi.check(_abi.lib().iwvi_gp_layer_backward(ctypes.byref(b), T, ws.data_ptr(), _abi.stream_ptr()))
     return out
+
+
+def lv_backward(layer, XY, mu, sigma, eps, dF_next, col0, w, B, K, sampled_kl=True):
+    """``iwvi_lv_layer_backward`` + ``iwvi_encoder_backward`` -> (dW list, db list) of the layer's encoder."""
+    dev = mu.device
+    Lw = layer.latent_dim
+    ft = settings.float_type
+    d_enc = torch.empty(B, 2 * Lw, dtype=ft, device=dev)
+    _abi.check(_abi.lib().iwvi_lv_layer_backward(
+        _abi.ptr(mu), _abi.ptr(sigma), _abi.ptr(eps), _abi.ptr(dF_next), 0 if dF_next is None else dF_next.shape[1], col0,
+        _abi.ptr(w), Lw, B, K, 1 if sampled_kl else 0, _abi.ptr(d_enc), _abi.stream_ptr()))
+    Wp, bp, dims, n, keep = layer.encoder.abi_args()
+    dW = [torch.empty_like(t) for t in keep[0]]
+    db = [torch.empty_like(t) for t in keep[1]]
+    dWp, dbp = _abi.ptr_array(dW), _abi.ptr_array(db)
+    ws = torch.empty(_abi.lib().iwvi_encoder_backward_ws_bytes(B, dims, n), dtype=torch.uint8, device=dev)
+    XY = _abi.dev_tensor(XY.contiguous(), "encoder input")
+    _abi.check(_abi.lib().iwvi_encoder_backward(_abi.ptr(XY), B, Wp, bp, dims, n, _abi.ptr(d_enc), dWp, dbp,
+                                               ws.data_ptr(), _abi.stream_ptr()))
+    return dW, db
+
+
+def iw_elbo_and_gradients(model, zs=None):
+    """The IW-ELBO of the current minibatch (models.py:112-150) and its gradient w.r.t. every parameter the
+    reference trains (build_models.py:284-304): -> (elbo [0-dim float64 tensor], dict) with the names of
+    oracle/grad_oracle.py: 'l<i>.Z', 'l<i>.ls', 'l<i>.var', 'l<i>.q_mu', 'l<i>.q_sqrt', 'l<i>.encW<j>',
+    'l<i>.encb<j>', 'lik_var'.  ``zs``: one noise tensor per layer ([B, K, dim]) or None -> drawn."""
+    from .layers import LatentVariableLayer
+    from .temp_workaround import draw_normal
+    dev = model.X.device
+    ft = settings.float_type
+    B, K = model.X.shape[0], model.num_samples
+    T = B * K
+    layers = model.layers
+    zs = [None] * len(layers) if zs is None else zs
+    if len(zs) != len(layers):
+        raise ValueError("zs needs one entry per layer")
+    X = _abi.dev_tensor(model.X.contiguous(), "X")
+    Y = _abi.dev_tensor(model.Y.contiguous(), "Y")
+    F = X[:, None, :].expand(B, K, X.shape[1]).reshape(T, -1).contiguous()          # models.py:113
+    XY = XYt = None
+    if any(isinstance(l, LatentVariableLayer) for l in layers):
+        XY = model._xy_minibatch()
+        XYt = XY[:, None, :].expand(B, K, XY.shape[1]).reshape(T, -1).contiguous()
+    words = model._words()
+    saved = []
+    for layer, z in zip(layers, zs):
+        if isinstance(layer, LatentVariableLayer):
+            Lw = layer.latent_dim
+            eps = draw_normal((T, Lw), dev) if z is None else _abi.dev_tensor(z.reshape(T, Lw).contiguous(), "z")
+            mu, sg = layer.encoder(XY)
+            smp, _, _, kl = layer.propagate(F, XYt, True, z=eps)
+            saved.append(("lv", mu.contiguous(), sg.contiguous(), eps, kl.reshape(T, Lw), F.shape[1]))
+            F = smp.reshape(T, -1)
+        elif isinstance(layer, GPLayer):
+            R = layer.num_outputs
+            eps = draw_normal((T, R), dev) if z is None else z.reshape(T, R)
+            s = gp_forward_saved(layer, F, eps, words)
+            saved.append(("gp", s))
+            F = s.sample
+        else:
+            raise TypeError("the backward pass knows GPLayer and LatentVariableLayer")
+    if saved[-1][0] != "gp":
+        raise ValueError("the last layer must be a GPLayer")
+    fin = saved[-1][1]
+    Dy = Y.shape[1]
+    kls = [s[4] for s in saved if s[0] == "lv"]
+    klp = _abi.ptr_array(kls)
+    kld = (ctypes.c_int32 * max(len(kls), 1))(*[k.shape[1] for k in kls])
+    w = torch.empty(T, dtype=ft, device=dev)
+    d_mean, d_var = torch.empty(T, Dy, dtype=ft, device=dev), torch.empty(T, Dy, dtype=ft, device=dev)
+    sums = torch.empty(2, dtype=torch.float64, device=dev)
+    ws = torch.empty(2 * B, dtype=torch.float64, device=dev)
+    scale = float(model.num_data) / float(B)
+    _abi.check(_abi.lib().iwvi_iw_elbo_backward(
+        _abi.ptr(fin.mean), _abi.ptr(fin.var), _abi.ptr(Y), Dy, klp, kld, len(kls), B, K,
+        float(model.likelihood.variance), scale, _abi.ptr(w), _abi.ptr(d_mean), _abi.ptr(d_var),
+        ctypes.c_void_p(sums.data_ptr()), ctypes.c_void_p(ws.data_ptr()), _abi.stream_ptr()))
+    grads = {"lik_var": sums[1]}
+    elbo = scale * sums[0]
+    dF = None
+    for i in range(len(layers) - 1, -1, -1):
+        layer, s = layers[i], saved[i]
+        if s[0] == "gp":
+            last = i == len(layers) - 1
+            g = gp_backward(layer, s[1], d_sample=None if last else dF, d_mean=d_mean if last else None,
+                            d_var=d_var if last else None, kl_weight=1.0, want_dF=i > 0)
+            elbo = elbo - layer.kl
+            for k_out, k_name in (("dZ", "Z"), ("dls", "ls"), ("dvariance", "var"), ("dq_mu", "q_mu"), ("dq_sqrt", "q_sqrt")):
+                grads["l%d.%s" % (i, k_name)] = g[k_out]
+            dF = g.get("dF")
+        else:
+            _, mu, sg, eps, _, D_in = s
+            dW, db = lv_backward(layer, XY, mu, sg, eps, dF, D_in, w, B, K, True)
+            for j, (a, b) in enumerate(zip(dW, db)):
+                grads["l%d.encW%d" % (i, j)], grads["l%d.encb%d" % (i, j)] = a, b
+            dF = None if (dF is None or i == 0) else dF[:, :D_in].contiguous()
+    return elbo, grads

@@ -333,6 +333,124 @@ static BwdWs bwd_layout(char* base, long long T, int M, int D, int R) {
 }
 __global__ void k_set_one(float* p) { if (threadIdx.x < 4) p[threadIdx.x] = 1.f; }
 
+
+// ------------------------------------------------------------------------------------------------------------
+// ELBO tail (models.py:134-150), one thread per data point: L_nk, softmax over the K samples, heads of the final layer
+// ------------------------------------------------------------------------------------------------------------
+struct ElboBwdArgs {
+    const float* fmean; const float* fvar; const float* Y; int Dy;
+    const float* kl[IWVI_MAX_KL]; int kl_dims[IWVI_MAX_KL]; int n_kl;
+    long long B; int K; float lik_var; double scale;
+    float* w; float* d_mean; float* d_var; double* part;   // part[0..B) = lse - log K, part[B..2B) = d lik_var share
+};
+__global__ void k_elbo_bwd(ElboBwdArgs a) {
+    const long long b = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= a.B) return;
+    const float s = a.lik_var, c0 = -0.5f * logf(6.283185307179586f * s);
+    auto logw = [&](long long t) {
+        float l = 0.f;
+        for (int j = 0; j < a.Dy; ++j) {
+            const float e = a.Y[b * a.Dy + j] - a.fmean[t * a.Dy + j];
+            l += c0 - 0.5f * (e * e + a.fvar[t * a.Dy + j]) / s;
+        }
+        for (int i = 0; i < a.n_kl; ++i)
+            for (int q = 0; q < a.kl_dims[i]; ++q) l -= a.kl[i][t * a.kl_dims[i] + q];
+        return l;
+    };
+    float mx = -INFINITY;
+    for (int k = 0; k < a.K; ++k) mx = fmaxf(mx, logw(b * a.K + k));
+    double se = 0.0;
+    for (int k = 0; k < a.K; ++k) se += (double)__expf(logw(b * a.K + k) - mx);
+    a.part[b] = (double)mx + log(se) - log((double)a.K);
+    double ds = 0.0;
+    for (int k = 0; k < a.K; ++k) {
+        const long long t = b * a.K + k;
+        const float wt = (float)(a.scale * (double)__expf(logw(t) - mx) / se);
+        if (a.w) a.w[t] = wt;
+        for (int j = 0; j < a.Dy; ++j) {
+            const float e = a.Y[b * a.Dy + j] - a.fmean[t * a.Dy + j], v = a.fvar[t * a.Dy + j];
+            if (a.d_mean) a.d_mean[t * a.Dy + j] = wt * e / s;
+            if (a.d_var) a.d_var[t * a.Dy + j] = -0.5f * wt / s;
+            ds += (double)wt * (-0.5 / (double)s + 0.5 * ((double)e * e + (double)v) / ((double)s * s));
+        }
+    }
+    a.part[a.B + b] = ds;
+}
+// out[i] = sum of part[i*n .. (i+1)*n), one workgroup per i, fixed order
+__global__ __launch_bounds__(256) void k_dsum(const double* part, long long n, double* out) {
+    __shared__ double red[256];
+    const double* p = part + (size_t)blockIdx.x * n;
+    double s = 0.0;
+    for (long long i = threadIdx.x; i < n; i += 256) s += p[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+    if (threadIdx.x == 0) out[blockIdx.x] = red[0];
+}
+
+// LatentVariableLayer (layers.py:83-103): W = mu + eps sigma; d(enc_out) [B, 2 Lw] = sum over the K samples of (dmu | draw)
+struct LvBwdArgs {
+    const float* mu; const float* sigma; const float* eps; const float* dFn; int ld, col0;
+    const float* w; int Lw; long long B; int K, sampled; float* d_out;
+};
+__global__ void k_lv_bwd(LvBwdArgs a) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= a.B * a.Lw) return;
+    const long long b = idx / a.Lw; const int l = (int)(idx - b * a.Lw);
+    const float mu = a.mu[idx], sg = a.sigma[idx];
+    float dmu = 0.f, dsg = 0.f;
+    for (int k = 0; k < a.K; ++k) {
+        const long long t = b * a.K + k;
+        const float e = a.eps[t * a.Lw + l], W = fmaf(e, sg, mu);
+        const float dfw = a.dFn ? a.dFn[t * a.ld + a.col0 + l] : 0.f;
+        const float dkl = a.w ? -a.w[t] : 0.f;                 // L_nk contains -kl (models.py:141-142)
+        if (a.sampled) { const float dW = dfw + dkl * W; dmu += dW; dsg += dW * e - dkl / sg; }
+        else { dmu += dfw + dkl * mu; dsg += dfw * e + dkl * (sg - 1.f / sg); }
+    }
+    a.d_out[b * 2 * a.Lw + l] = dmu;
+    a.d_out[b * 2 * a.Lw + a.Lw + l] = dsg * (1.f - __expf(-sg));      // sigma = softplus(raw - 3): d sigma / d raw = 1 - exp(-sigma)
+}
+
+// Encoder MLP (layers.py:137-152), one thread per row: activations of every layer -> acts, then deltas (d / d pre-activation)
+struct EncBwdArgs {
+    const float* XY; long long rows; const float* W[IWVI_MAX_ENC]; const float* b[IWVI_MAX_ENC]; int dims[IWVI_MAX_ENC + 1]; int n;
+    const float* d_out; float* acts[IWVI_MAX_ENC + 1]; float* delta[IWVI_MAX_ENC];
+};
+__global__ void k_enc_bwd(EncBwdArgs a) {
+    const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= a.rows) return;
+    for (int i = 0; i < a.dims[0]; ++i) a.acts[0][r * a.dims[0] + i] = a.XY[r * a.dims[0] + i];
+    for (int l = 0; l < a.n; ++l) {
+        const int din = a.dims[l], dout = a.dims[l + 1];
+        const float* in = a.acts[l] + r * din;
+        for (int o = 0; o < dout; ++o) {
+            float acc = a.b[l] ? a.b[l][o] : 0.f;
+            for (int i = 0; i < din; ++i) acc = fmaf(in[i], a.W[l][i * dout + o], acc);
+            if (l < a.n - 1) acc = tanhf(acc);
+            if (din == dout) acc += in[o];
+            a.acts[l + 1][r * dout + o] = acc;
+        }
+    }
+    float cur[64], prev[64];
+    const int dl = a.dims[a.n];
+    for (int o = 0; o < dl; ++o) cur[o] = a.d_out[r * dl + o];
+    for (int l = a.n - 1; l >= 0; --l) {
+        const int din = a.dims[l], dout = a.dims[l + 1];
+        const bool skip = din == dout;
+        for (int i = 0; i < din; ++i) prev[i] = skip ? cur[i] : 0.f;
+        for (int o = 0; o < dout; ++o) {
+            float dlin = cur[o];
+            if (l < a.n - 1) {
+                const float act = a.acts[l + 1][r * dout + o] - (skip ? a.acts[l][r * din + o] : 0.f);
+                dlin *= 1.f - act * act;
+            }
+            a.delta[l][r * dout + o] = dlin;
+            for (int i = 0; i < din; ++i) prev[i] = fmaf(dlin, a.W[l][i * dout + o], prev[i]);
+        }
+        for (int i = 0; i < din; ++i) cur[i] = prev[i];
+    }
+}
+
 }  // namespace iwvi
 
 using namespace iwvi;
@@ -449,4 +567,87 @@ extern "C" int iwvi_gp_layer_backward(const iwvi_gp_bwd_desc* dp, int64_t T, voi
                  d.dZ, d.dls, d.dvariance, d.dq_mu, d.dq_sqrt, M, D, R, d.kl_weight, (double)d.variance};
     hipLaunchKernelGGL(k_bw_final, dim3(1), dim3(256), 0, st, f);
     return check_launch("k_bw_final");
+}
+
+extern "C" int iwvi_iw_elbo_backward(const float* fmean, const float* fvar, const float* Y, int Dy,
+                                     const float* const* kl_local, const int32_t* kl_dims, int n_local,
+                                     int64_t B, int K, float lik_variance, double scale,
+                                     float* out_w, float* d_mean, float* d_var,
+                                     double* out_sums /* [2]: sum_n (lse - log K), d/d lik_variance */, double* ws, void* stream_) {
+    if (!fmean || !fvar || !Y || !out_sums || !ws || Dy <= 0 || B <= 0 || K <= 0 || n_local < 0 || n_local > IWVI_MAX_KL || !(lik_variance > 0.f)) {
+        set_error("iwvi_iw_elbo_backward: bad argument"); return IWVI_ERR_ARG;
+    }
+    hipStream_t st = (hipStream_t)stream_;
+    ElboBwdArgs a{};
+    a.fmean = fmean; a.fvar = fvar; a.Y = Y; a.Dy = Dy; a.n_kl = n_local;
+    for (int i = 0; i < n_local; ++i) {
+        if (!kl_local || !kl_local[i] || !kl_dims || kl_dims[i] <= 0) { set_error("iwvi_iw_elbo_backward: bad local regulariser %d", i); return IWVI_ERR_ARG; }
+        a.kl[i] = kl_local[i]; a.kl_dims[i] = kl_dims[i];
+    }
+    a.B = B; a.K = K; a.lik_var = lik_variance; a.scale = scale; a.w = out_w; a.d_mean = d_mean; a.d_var = d_var; a.part = ws;
+    hipLaunchKernelGGL(k_elbo_bwd, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, st, a);
+    hipLaunchKernelGGL(k_dsum, dim3(2), dim3(256), 0, st, (const double*)ws, (long long)B, out_sums);
+    return check_launch("k_elbo_bwd");
+}
+
+extern "C" int iwvi_lv_layer_backward(const float* mu, const float* sigma, const float* noise,
+                                      const float* dF_next, int ld_next, int col0, const float* w,
+                                      int latent_dim, int64_t B, int K, int sampled_kl, float* d_enc_out, void* stream_) {
+    if (!mu || !sigma || !noise || !d_enc_out || latent_dim <= 0 || B <= 0 || K <= 0 || (dF_next && (ld_next < col0 + latent_dim || col0 < 0))) {
+        set_error("iwvi_lv_layer_backward: bad argument"); return IWVI_ERR_ARG;
+    }
+    LvBwdArgs a{mu, sigma, noise, dF_next, ld_next, col0, w, latent_dim, B, K, sampled_kl, d_enc_out};
+    hipLaunchKernelGGL(k_lv_bwd, dim3((unsigned)((B * latent_dim + 63) / 64)), dim3(64), 0, (hipStream_t)stream_, a);
+    return check_launch("k_lv_bwd");
+}
+
+static size_t enc_bwd_layout(int64_t rows, const int32_t* dims, int n, size_t* acts_off, size_t* delta_off, size_t* part_off, size_t* part_floats) {
+    size_t o = 0;
+    int wmax = 1;
+    for (int l = 0; l <= n; ++l) { if (acts_off) acts_off[l] = o; o = align256(o + sizeof(float) * rows * dims[l]); if (dims[l] > wmax) wmax = dims[l]; }
+    for (int l = 0; l < n; ++l) { if (delta_off) delta_off[l] = o; o = align256(o + sizeof(float) * rows * dims[l + 1]); }
+    const size_t pf = (size_t)((rows + 511) / 512 + 2) * wmax * wmax;
+    if (part_off) *part_off = o;
+    if (part_floats) *part_floats = pf;
+    o = align256(o + sizeof(float) * pf);
+    o = align256(o + 16);                               // the constant 1
+    return o;
+}
+extern "C" size_t iwvi_encoder_backward_ws_bytes(int64_t rows, const int32_t* dims, int n_enc) {
+    if (rows <= 0 || !dims || n_enc <= 0 || n_enc > IWVI_MAX_ENC) return 0;
+    return enc_bwd_layout(rows, dims, n_enc, nullptr, nullptr, nullptr, nullptr);
+}
+extern "C" int iwvi_encoder_backward(const float* XY, int64_t rows, const float* const* enc_W, const float* const* enc_b,
+                                     const int32_t* dims, int n_enc, const float* d_out,
+                                     float* const* dW, float* const* db, void* ws_, void* stream_) {
+    if (!XY || !enc_W || !dims || !d_out || !dW || !ws_ || rows <= 0 || n_enc <= 0 || n_enc > IWVI_MAX_ENC) { set_error("iwvi_encoder_backward: bad argument"); return IWVI_ERR_ARG; }
+    for (int l = 0; l <= n_enc; ++l) if (dims[l] <= 0 || dims[l] > 64) { set_error("iwvi_encoder_backward: encoder width %d out of range (1..64)", dims[l]); return IWVI_ERR_ARG; }
+    hipStream_t st = (hipStream_t)stream_;
+    size_t ao[IWVI_MAX_ENC + 1], d_off[IWVI_MAX_ENC], po, pf;
+    const size_t total = enc_bwd_layout(rows, dims, n_enc, ao, d_off, &po, &pf);
+    char* base = (char*)ws_;
+    float* one = (float*)(base + total - 256);
+    EncBwdArgs a{};
+    a.XY = XY; a.rows = rows; a.n = n_enc; a.d_out = d_out;
+    for (int l = 0; l <= n_enc; ++l) { a.dims[l] = dims[l]; a.acts[l] = (float*)(base + ao[l]); }
+    for (int l = 0; l < n_enc; ++l) {
+        if (!enc_W[l] || !dW[l]) { set_error("iwvi_encoder_backward: null weight %d", l); return IWVI_ERR_ARG; }
+        a.W[l] = enc_W[l]; a.b[l] = enc_b ? enc_b[l] : nullptr; a.delta[l] = (float*)(base + d_off[l]);
+    }
+    hipLaunchKernelGGL(k_set_one, dim3(1), dim3(64), 0, st, one);
+    hipLaunchKernelGGL(k_enc_bwd, dim3((unsigned)((rows + 63) / 64)), dim3(64), 0, st, a);
+    int rc;
+    if ((rc = check_launch("k_enc_bwd")) != IWVI_OK) return rc;
+    float* part = (float*)(base + po);
+    for (int l = 0; l < n_enc; ++l) {
+        const int din = dims[l], dout = dims[l + 1];
+        GemmArgs q{};                                   // dW_l = acts_l^T delta_l
+        q.A = a.acts[l]; q.a_sm = 1; q.a_sk = din; q.B = a.delta[l]; q.b_sk = dout; q.b_sn = 1; q.M = din; q.N = dout; q.K = (int)rows;
+        if ((rc = gemm(st, q, part, pf, dW[l], nullptr, dout, 1.0, 0.0, 0)) != IWVI_OK) return rc;
+        if (db && db[l]) {
+            q.A = a.delta[l]; q.a_sm = 1; q.a_sk = dout; q.B = one; q.b_sk = 0; q.b_sn = 0; q.M = dout; q.N = 1;
+            if ((rc = gemm(st, q, part, pf, db[l], nullptr, 1, 1.0, 0.0, 0)) != IWVI_OK) return rc;
+        }
+    }
+    return IWVI_OK;
 }

@@ -267,6 +267,30 @@ typedef struct iwvi_gp_bwd_desc {
 size_t iwvi_gp_layer_backward_ws_bytes(int64_t T, int M, int D, int R);
 int iwvi_gp_layer_backward(const iwvi_gp_bwd_desc* desc, int64_t T, void* ws, void* stream);
 
+/* Adjoint of the ELBO tail (models.py:134-150) for the IW tiling (sample t = b*K + k):
+ *   L_nk = sum_dy varexp(Y; fmean, fvar) - sum_i sum_q kl_local[i][t, q];  ELBO = scale * sum_n (lse_k L_nk - log K) - KL.
+ * out_w [T] = d ELBO / d L_nk (scale * softmax over k), d_mean / d_var [T, Dy] = heads of the final layer,
+ * out_sums[0] = sum_n (lse - log K), out_sums[1] = d ELBO / d lik_variance;  ws: 2*B doubles. Outputs may be NULL
+ * except out_sums. */
+int iwvi_iw_elbo_backward(const float* fmean, const float* fvar, const float* Y, int Dy,
+                          const float* const* kl_local, const int32_t* kl_dims, int n_local,
+                          int64_t B, int K, float lik_variance, double scale,
+                          float* out_w, float* d_mean, float* d_var, double* out_sums, double* ws, void* stream);
+
+/* Adjoint of the LatentVariableLayer (layers.py:83-103): mu, sigma [B, latent_dim] (the encoder's outputs per data
+ * row), noise [T, latent_dim] (the draws), dF_next [T, ld_next] = gradient w.r.t. the layer's output rows (columns
+ * col0 .. col0+latent_dim-1 are W's; may be NULL), w [T] = d ELBO / d L_nk (the regulariser enters with -1; may be
+ * NULL).  d_enc_out [B, 2*latent_dim] = gradient w.r.t. the encoder's (means | raw) output. */
+int iwvi_lv_layer_backward(const float* mu, const float* sigma, const float* noise,
+                           const float* dF_next, int ld_next, int col0, const float* w,
+                           int latent_dim, int64_t B, int K, int sampled_kl, float* d_enc_out, void* stream);
+
+/* Adjoint of the Encoder MLP (layers.py:137-152): d_out [rows, dims[n_enc]] -> dW[i] [dims[i], dims[i+1]], db[i]. */
+size_t iwvi_encoder_backward_ws_bytes(int64_t rows, const int32_t* dims, int n_enc);
+int iwvi_encoder_backward(const float* XY, int64_t rows, const float* const* enc_W, const float* const* enc_b,
+                          const int32_t* dims, int n_enc, const float* d_out,
+                          float* const* dW, float* const* db, void* ws, void* stream);
+
 /* models.py:138-150 on precomputed log-weights: logw row of (point b, sample k) = b*stride_b + k*stride_k;
  * arguments as iwvi_iw_elbo_reduce. */
 int iwvi_logw_reduce(const float* logw, int64_t B, int K, int64_t stride_b, int64_t stride_k,

@@ -78,3 +78,41 @@ def test_gp_layer_backward_matches_autodiff(gpu_device, M, T, li):
     out2 = backward.gp_backward(layer, saved, tt(cs), tt(cm), tt(cv), kl_weight=0.7)
     for k in out:
         assert torch.equal(out[k], out2[k]), k
+
+
+def _model_grads(gpu_device, spec, zs):
+    from dgps_with_iwvi_amd import synthetic, backward
+    model = synthetic.build_model(spec, gpu_device)
+    elbo, grads = backward.iw_elbo_and_gradients(model, [torch.as_tensor(np.asarray(z, dtype=np.float32), device=gpu_device) for z in zs])
+    return float(elbo), {k: v.detach().cpu().numpy() for k, v in grads.items()}
+
+
+@pytest.mark.parametrize("name", ["tiny_L2_lv", "mid_L2_lv"])
+def test_iw_elbo_gradients_match_golden(gpu_device, name):
+    """tests/golden/grad_*.npz: d ELBO / d parameters from the gradient oracle (float64 autodiff, pinned by finite differences)."""
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, here)
+    from test_golden import load
+    spec, zs, _ = load(os.path.join(here, "golden", name + ".npz"))
+    with np.load(os.path.join(here, "golden", "grad_" + name + ".npz")) as f:
+        ref = {k: f[k] for k in f.files}
+    elbo, grads = _model_grads(gpu_device, spec, zs)
+    assert abs(elbo - float(ref["elbo"])) <= 2e-4 * abs(float(ref["elbo"])), (elbo, float(ref["elbo"]))
+    assert sorted(k.replace(".", "_") for k in grads) == sorted(k for k in ref if k != "elbo")
+    for k, v in grads.items():
+        r = ref[k.replace(".", "_")]
+        _close(k, v.reshape(r.shape), r, rtol=5e-3)
+
+
+@pytest.mark.parametrize("L,M,K,B,lv", [(2, 64, 5, 16, True), (3, 32, 4, 12, True), (2, 128, 3, 40, False), (1, 48, 6, 10, False)])
+def test_iw_elbo_gradients_match_oracle(gpu_device, L, M, K, B, lv):
+    from dgps_with_iwvi_amd import synthetic
+    from oracle.grad_oracle import iw_elbo_and_gradients
+    spec = synthetic.make_spec(L=L, M=M, B=B, K=K, with_lv=lv, seed=7 * L + K)
+    zs = synthetic.make_noise(spec, seed=2)
+    val, ref = iw_elbo_and_gradients(spec, zs)
+    elbo, grads = _model_grads(gpu_device, spec, zs)
+    assert abs(elbo - val) <= 2e-4 * abs(val), (elbo, val)
+    assert sorted(grads) == sorted(ref)
+    for k, v in grads.items():
+        _close(k, v.reshape(ref[k].shape), ref[k], rtol=5e-3)
