@@ -83,6 +83,12 @@ class GpBwdDesc(ctypes.Structure):
                 ("dq_mu", c_void_p), ("dq_sqrt", c_void_p)]
 
 
+class AdamTensor(ctypes.Structure):
+    """struct iwvi_adam_tensor (include/iwvi_hip.h)."""
+    _fields_ = [("param", c_void_p), ("grad", c_void_p), ("x", c_void_p), ("m", c_void_p), ("v", c_void_p),
+                ("n", c_int64), ("transform", ctypes.c_int32)]
+
+
 # name -> (restype, argtypes); every symbol include/iwvi_hip.h declares
 PROTOTYPES = {
     "iwvi_version": (c_int, []),
@@ -106,6 +112,10 @@ PROTOTYPES = {
     "iwvi_encoder_backward": (c_int, [c_void_p, c_int64, ctypes.POINTER(c_void_p), ctypes.POINTER(c_void_p),
                                       ctypes.POINTER(ctypes.c_int32), c_int, c_void_p,
                                       ctypes.POINTER(c_void_p), ctypes.POINTER(c_void_p), c_void_p, c_void_p]),
+    "iwvi_natgrad_ws_bytes": (c_size_t, [c_int]),
+    "iwvi_natgrad_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_double, c_void_p, c_void_p]),
+    "iwvi_adam_step": (c_int, [ctypes.POINTER(AdamTensor), c_int, c_double, c_double, c_double, c_double, c_int64,
+                               c_int, c_int, c_void_p]),
     "iwvi_gp_layer_forward": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_float,
                                       c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
                                       c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),

@@ -451,6 +451,90 @@ __global__ void k_enc_bwd(EncBwdArgs a) {
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------
+// Optimiser steps of experiments/build_models.py:284-304: natural gradient on the final layer's (q_mu, q_sqrt)
+// (GPflow NatGradOptimizer, natural parameterisation) and Adam on everything else (TensorFlow AdamOptimizer on
+// GPflow's unconstrained variables).  float64 for the natural-gradient algebra, like the reference.
+// ------------------------------------------------------------------------------------------------------------
+// C[i, j] = alpha * sum_k A(i, k) B(k, j) + beta * E[i, j];  post 1: Phi, post 2: nothing
+struct DmmArgs { const double* A; long long a_si, a_sk; const double* B; long long b_sk, b_sj; double* C; long long ldc;
+                 int I, J, K; double alpha; const double* E; long long lde; double beta; int post; };
+__global__ void k_dmm2(DmmArgs a) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;
+    if (j >= a.J) return;
+    double s = 0.0;
+    for (int k = 0; k < a.K; ++k) s = fma(a.A[i * a.a_si + k * a.a_sk], a.B[k * a.b_sk + j * a.b_sj], s);
+    s *= a.alpha;
+    if (a.E) s += a.beta * a.E[i * a.lde + j];
+    if (a.post == 1) s = (j > i) ? 0.0 : (j == i ? 0.5 * s : s);
+    a.C[i * a.ldc + j] = s;
+}
+static void dmm(hipStream_t st, const double* A, long long a_si, long long a_sk, const double* B, long long b_sk, long long b_sj,
+                double* C, long long ldc, int I, int J, int K, double alpha = 1.0, const double* E = nullptr, long long lde = 0, double beta = 0.0, int post = 0) {
+    DmmArgs a{A, a_si, a_sk, B, b_sk, b_sj, C, ldc, I, J, K, alpha, E, lde, beta, post};
+    hipLaunchKernelGGL(k_dmm2, dim3((J + 127) / 128, I), dim3(J < 128 ? 64 : 128), 0, st, a);
+}
+// X = L^-1 for lower-triangular L [n, n] (row-major): thread j solves L x = e_j by forward substitution; zeros above
+__global__ void k_tri_inv(const double* L, double* X, int n) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    for (int i = 0; i < j; ++i) X[(size_t)i * n + j] = 0.0;
+    for (int i = j; i < n; ++i) {
+        double s = (i == j) ? 1.0 : 0.0;
+        for (int k = j; k < i; ++k) s = fma(-L[(size_t)i * n + k], X[(size_t)k * n + j], s);
+        X[(size_t)i * n + j] = s / L[(size_t)i * n + i];
+    }
+}
+__global__ void k_f2d(const float* src, long long ld, double* dst, int rows, int cols, double scale, int tril) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= rows * cols) return;
+    const int i = idx / cols, j = idx - i * cols;
+    dst[idx] = (tril && j > i) ? 0.0 : scale * (double)src[i * ld + j];
+}
+__global__ void k_d2f(const double* src, float* dst, long long ld, int rows, int cols, int tril) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= rows * cols) return;
+    const int i = idx / cols, j = idx - i * cols;
+    dst[i * ld + j] = (tril && j > i) ? 0.f : (float)src[idx];
+}
+__global__ void k_axpby(const double* x, double a, const double* y, double b, double* out, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = a * x[i] + b * y[i];
+}
+__global__ void k_symmetrise(double* Q, int n) {       // Q <- (Q + Q^T) / 2, one thread per (i >= j)
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n * n) return;
+    const int i = idx / n, j = idx - i * n;
+    if (j > i) return;
+    const double v = 0.5 * (Q[(size_t)i * n + j] + Q[(size_t)j * n + i]);
+    Q[(size_t)i * n + j] = v; Q[(size_t)j * n + i] = v;
+}
+
+// Adam on GPflow's unconstrained variables.  transform 1 = positive: p = softplus(x) + 1e-6 (gpflow.transforms.Log1pe)
+struct AdamTensor { float* p; const float* g; float* x; float* m; float* v; long long n; int transform; };
+constexpr int ADAM_MAX = 48;
+struct AdamArgs { AdamTensor t[ADAM_MAX]; int n; float lr_t, b1, b2, eps, sign; int init; };
+__global__ void k_adam(AdamArgs a) {
+    const AdamTensor& T = a.t[blockIdx.y];
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < T.n; i += (long long)gridDim.x * blockDim.x) {
+        if (a.init) {
+            const float p = T.p[i];
+            float x = p;
+            if (T.transform == 1) { const float y = p - 1e-6f; x = y > 20.f ? y : logf(expm1f(y)); }
+            T.x[i] = x; T.m[i] = 0.f; T.v[i] = 0.f;
+            continue;
+        }
+        float x = T.x[i], g = a.sign * T.g[i];
+        if (T.transform == 1) g *= 1.f - __expf(-(T.p[i] - 1e-6f));          // d softplus(x) / dx = sigmoid(x)
+        const float m = a.b1 * T.m[i] + (1.f - a.b1) * g;
+        const float v = a.b2 * T.v[i] + (1.f - a.b2) * g * g;
+        x -= a.lr_t * m / (sqrtf(v) + a.eps);
+        T.m[i] = m; T.v[i] = v; T.x[i] = x;
+        T.p[i] = (T.transform == 1) ? (x > 20.f ? x : log1pf(__expf(x))) + 1e-6f : x;
+    }
+}
+
 }  // namespace iwvi
 
 using namespace iwvi;
@@ -650,4 +734,79 @@ extern "C" int iwvi_encoder_backward(const float* XY, int64_t rows, const float*
         }
     }
     return IWVI_OK;
+}
+
+extern "C" size_t iwvi_natgrad_ws_bytes(int M) {
+    if (M <= 0 || M > IWVI_MAX_M) return 0;
+    return align256(sizeof(double) * (size_t)M * M) * 8 + align256(sizeof(double) * M) * 4 + align256(iwvi_chol_ws_bytes(M)) + 256;
+}
+
+// GPflow 1.x NatGradOptimizer (natural parameterisation, XiNat) on a whitened (q_mu [M, R], q_sqrt [R, M, M]):
+//   eta = (m, S + m m^T), theta = (S^-1 m, -1/2 S^-1);  theta <- theta - gamma dLoss/d eta;  back through
+//   natural_to_meanvarsqrt (cholesky(-2 theta_2), its inverse, S = X^T X, mu = S theta_1, cholesky(S)).
+// dq_mu / dq_sqrt are gradients of the objective that is MAXIMISED (the ELBO): loss = -ELBO.
+extern "C" int iwvi_natgrad_step(float* q_mu, float* q_sqrt, const float* dq_mu, const float* dq_sqrt,
+                                 int M, int R, double gamma, void* ws_, void* stream_) {
+    if (!q_mu || !q_sqrt || !dq_mu || !dq_sqrt || !ws_ || M <= 0 || M > IWVI_MAX_M || R <= 0 || R > IWVI_MAX_R) { set_error("iwvi_natgrad_step: bad argument"); return IWVI_ERR_ARG; }
+    hipStream_t st = (hipStream_t)stream_;
+    char* base = (char*)ws_; size_t o = 0;
+    auto mat = [&]() { double* p = (double*)(base + o); o += align256(sizeof(double) * (size_t)M * M); return p; };
+    auto vec = [&]() { double* p = (double*)(base + o); o += align256(sizeof(double) * M); return p; };
+    double *L = mat(), *Lbar = mat(), *Linv = mat(), *T1 = mat(), *T2 = mat(), *Sbar = mat(), *Sinv = mat(), *Pn = mat();
+    double *m = vec(), *mbar = vec(), *th1 = vec(), *tmp = vec();
+    void* cws = base + o;
+    const int nb = (M * M + 255) / 256;
+    int rc;
+    for (int r = 0; r < R; ++r) {
+        hipLaunchKernelGGL(k_f2d, dim3(nb), dim3(256), 0, st, (const float*)(q_sqrt + (size_t)r * M * M), (long long)M, L, M, M, 1.0, 1);
+        hipLaunchKernelGGL(k_f2d, dim3(nb), dim3(256), 0, st, dq_sqrt + (size_t)r * M * M, (long long)M, Lbar, M, M, -1.0, 1);
+        hipLaunchKernelGGL(k_f2d, dim3((M + 255) / 256), dim3(256), 0, st, (const float*)(q_mu + r), (long long)R, m, M, 1, 1.0, 0);
+        hipLaunchKernelGGL(k_f2d, dim3((M + 255) / 256), dim3(256), 0, st, dq_mu + r, (long long)R, mbar, M, 1, -1.0, 0);
+        hipLaunchKernelGGL(k_tri_inv, dim3((M + 63) / 64), dim3(64), 0, st, (const double*)L, Linv, M);
+        // dLoss/dS (symmetric) from dLoss/dL: Sbar = sym(L^-T Phi(L^T Lbar) L^-1)
+        dmm(st, L, 1, M, Lbar, M, 1, T1, M, M, M, M, 1.0, nullptr, 0, 0.0, 1);
+        dmm(st, Linv, 1, M, T1, M, 1, T2, M, M, M, M);
+        dmm(st, T2, M, 1, Linv, M, 1, Sbar, M, M, M, M);
+        hipLaunchKernelGGL(k_symmetrise, dim3(nb), dim3(256), 0, st, Sbar, M);
+        // g1 = mbar - 2 Sbar m  (d/d eta_1),  g2 = Sbar  (d/d eta_2)
+        dmm(st, Sbar, M, 1, m, 1, 1, tmp, 1, M, 1, M, -2.0, mbar, 1, 1.0);
+        // theta_1 = S^-1 m, theta_2 = -1/2 S^-1, S^-1 = L^-T L^-1
+        dmm(st, Linv, 1, M, Linv, M, 1, Sinv, M, M, M, M);
+        dmm(st, Sinv, M, 1, m, 1, 1, th1, 1, M, 1, M);
+        // theta_1' = theta_1 - gamma g1 (into mbar);  -2 theta_2' = S^-1 + 2 gamma Sbar (into Pn)
+        hipLaunchKernelGGL(k_axpby, dim3((M + 255) / 256), dim3(256), 0, st, (const double*)th1, 1.0, (const double*)tmp, -gamma, mbar, M);
+        hipLaunchKernelGGL(k_axpby, dim3(nb), dim3(256), 0, st, (const double*)Sinv, 1.0, (const double*)Sbar, 2.0 * gamma, Pn, M * M);
+        // natural_to_meanvarsqrt
+        if ((rc = iwvi_chol_factor(Pn, T1, M, cws, stream_)) != IWVI_OK) return rc;
+        hipLaunchKernelGGL(k_tri_inv, dim3((M + 63) / 64), dim3(64), 0, st, (const double*)T1, T2, M);
+        dmm(st, T2, 1, M, T2, M, 1, Sbar, M, M, M, M);                                   // S' = X^T X
+        dmm(st, Sbar, M, 1, mbar, 1, 1, m, 1, M, 1, M);                                  // mu' = S' theta_1'
+        if ((rc = iwvi_chol_factor(Sbar, L, M, cws, stream_)) != IWVI_OK) return rc;
+        hipLaunchKernelGGL(k_d2f, dim3(nb), dim3(256), 0, st, (const double*)L, q_sqrt + (size_t)r * M * M, (long long)M, M, M, 1);
+        hipLaunchKernelGGL(k_d2f, dim3((M + 255) / 256), dim3(256), 0, st, (const double*)m, q_mu + r, (long long)R, M, 1, 0);
+        if ((rc = check_launch("iwvi_natgrad_step")) != IWVI_OK) return rc;
+    }
+    return IWVI_OK;
+}
+
+// TensorFlow AdamOptimizer (lr_t = lr sqrt(1 - beta2^t) / (1 - beta1^t); x -= lr_t m / (sqrt v + eps)) on the
+// unconstrained variables; `maximise` != 0: the gradients are of an objective to maximise (the ELBO).
+// init != 0: x <- transform^-1(param), m = v = 0 (no step).
+extern "C" int iwvi_adam_step(const iwvi_adam_tensor* tensors, int n_tensors, double lr, double beta1, double beta2,
+                              double eps, int64_t t, int maximise, int init, void* stream_) {
+    if (!tensors || n_tensors <= 0 || n_tensors > ADAM_MAX || (!init && t < 1)) { set_error("iwvi_adam_step: bad argument (at most %d tensors)", ADAM_MAX); return IWVI_ERR_ARG; }
+    AdamArgs a{};
+    long long nmax = 1;
+    for (int i = 0; i < n_tensors; ++i) {
+        const iwvi_adam_tensor& s = tensors[i];
+        if (!s.param || !s.x || !s.m || !s.v || (!init && !s.grad) || s.n <= 0 || (s.transform != 0 && s.transform != 1)) { set_error("iwvi_adam_step: bad tensor %d", i); return IWVI_ERR_ARG; }
+        a.t[i] = AdamTensor{s.param, s.grad, s.x, s.m, s.v, (long long)s.n, s.transform};
+        if (s.n > nmax) nmax = s.n;
+    }
+    a.n = n_tensors; a.init = init;
+    a.lr_t = init ? 0.f : (float)(lr * sqrt(1.0 - pow(beta2, (double)t)) / (1.0 - pow(beta1, (double)t)));
+    a.b1 = (float)beta1; a.b2 = (float)beta2; a.eps = (float)eps; a.sign = maximise ? -1.f : 1.f;
+    long long blocks = (nmax + 255) / 256; if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(k_adam, dim3((unsigned)blocks, n_tensors), dim3(256), 0, (hipStream_t)stream_, a);
+    return check_launch("k_adam");
 }

@@ -1,0 +1,114 @@
+"""The reference's training step (experiments/build_models.py:270-304) on the GPU: per step
+``op_increment`` -> ``op_ng`` (GPflow NatGradOptimizer on the final layer's (q_mu, q_sqrt), gamma with a staircase
+exponential decay) -> ``op_adam`` (TensorFlow AdamOptimizer on every other trainable parameter, lr with the same
+decay).  Each op evaluates the IW-ELBO and its gradient on its own fresh samples, like two ``session.run`` calls.
+
+Trainable set as built by ``build_models.py`` with its defaults (``fix_linear=True``): inner layers Z, lengthscales,
+q_mu, q_sqrt (kernel variance fixed, :213; W and the mean function fixed, :226-227); final layer Z, lengthscales,
+kernel variance; encoders; the likelihood variance.  Gradients: ``backward.iw_elbo_and_gradients``; update rules:
+``iwvi_natgrad_step`` / ``iwvi_adam_step`` (csrc/backward.hip)."""
+import ctypes
+
+import torch
+
+from . import _abi, settings
+from .backward import iw_elbo_and_gradients
+from .layers import GPLayer, LatentVariableLayer
+
+
+def staircase_decay(base, step, rate, every=1000):
+    """tf.train.exponential_decay(base, step, every, rate, staircase=True)."""
+    return base * rate ** (step // every)
+
+
+class Trainer:
+    def __init__(self, model, lr=5e-3, gamma=1e-2, lr_decay=0.98, gamma_decay=0.98, fix_linear=True,
+                 beta1=0.9, beta2=0.999, epsilon=1e-8):
+        if not fix_linear:
+            raise NotImplementedError("gradients of the mixing matrix W and the linear mean function are not built yet "
+                                      "(the reference's default fix_linear=True keeps them fixed)")
+        self.model = model
+        self.lr, self.gamma, self.lr_decay, self.gamma_decay = lr, gamma, lr_decay, gamma_decay
+        self.betas, self.epsilon = (beta1, beta2), epsilon
+        self.global_step = 0
+        self.adam_t = 0
+        dev = model.X.device
+        ft = settings.float_type
+        self.final = model.layers[-1]
+        if not isinstance(self.final, GPLayer):
+            raise ValueError("the last layer must be a GPLayer")
+        # (gradient name, get tensor, transform); host scalars get a 1-element device master that is copied back
+        self._entries = []
+        self._scalars = []                                     # (device tensor, setter)
+        n = len(model.layers)
+        for i, l in enumerate(model.layers):
+            if isinstance(l, LatentVariableLayer):
+                for j in range(len(l.encoder.Ws)):
+                    self._entries.append(("l%d.encW%d" % (i, j), l.encoder.Ws[j], 0))
+                    self._entries.append(("l%d.encb%d" % (i, j), l.encoder.bs[j], 0))
+                continue
+            k = l._base_kern()
+            self._entries.append(("l%d.Z" % i, l._Z(), 0))
+            self._entries.append(("l%d.ls" % i, k.lengthscales, 1))
+            if i == n - 1:
+                t = torch.full((1,), k.variance, dtype=ft, device=dev)
+                self._entries.append(("l%d.var" % i, t, 1))
+                self._scalars.append((t, lambda v, k=k: setattr(k, "variance", v)))
+            else:
+                self._entries.append(("l%d.q_mu" % i, l.q_mu, 0))
+                self._entries.append(("l%d.q_sqrt" % i, l.q_sqrt, 0))
+        t = torch.full((1,), model.likelihood.variance, dtype=ft, device=dev)
+        self._entries.append(("lik_var", t, 1))
+        self._scalars.append((t, lambda v: setattr(model.likelihood, "variance", v)))
+        for name, t, _ in self._entries:
+            _abi.dev_tensor(t, name)
+        self._state = [tuple(torch.empty_like(t) for _ in range(3)) for _, t, _ in self._entries]
+        self._adam_call(None, init=True)
+        M = self.final.num_inducing
+        self._ng_ws = torch.empty(_abi.lib().iwvi_natgrad_ws_bytes(M), dtype=torch.uint8, device=dev)
+
+    def _adam_call(self, grads, init=False, lr=0.0):
+        n = len(self._entries)
+        arr = (_abi.AdamTensor * n)()
+        keep = []
+        for i, ((name, p, tr), (x, m, v)) in enumerate(zip(self._entries, self._state)):
+            a = arr[i]
+            a.param, a.x, a.m, a.v, a.n, a.transform = p.data_ptr(), x.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), tr
+            if not init:
+                g = _abi.dev_tensor(grads[name].reshape(-1).to(settings.float_type).contiguous(), "grad " + name)
+                if g.numel() != p.numel():
+                    raise ValueError("gradient %s has %d entries, parameter has %d" % (name, g.numel(), p.numel()))
+                keep.append(g)
+                a.grad = g.data_ptr()
+        _abi.check(_abi.lib().iwvi_adam_step(arr, n, lr, self.betas[0], self.betas[1], self.epsilon,
+                                            max(self.adam_t, 1), 1, 1 if init else 0, _abi.stream_ptr()))
+        return keep
+
+    def natgrad_op(self, zs=None):
+        """``op_ng``: one ELBO + gradient evaluation, natural-gradient step on the final layer's q(u)."""
+        elbo, g = iw_elbo_and_gradients(self.model, zs)
+        i = len(self.model.layers) - 1
+        f = self.final
+        gamma = staircase_decay(self.gamma, self.global_step, self.gamma_decay)
+        dq_mu = _abi.dev_tensor(g["l%d.q_mu" % i].contiguous(), "dq_mu")
+        dq_sqrt = _abi.dev_tensor(g["l%d.q_sqrt" % i].contiguous(), "dq_sqrt")
+        _abi.check(_abi.lib().iwvi_natgrad_step(_abi.ptr(f.q_mu), _abi.ptr(f.q_sqrt), _abi.ptr(dq_mu), _abi.ptr(dq_sqrt),
+                                               f.num_inducing, f.num_outputs, gamma, self._ng_ws.data_ptr(), _abi.stream_ptr()))
+        return elbo
+
+    def adam_op(self, zs=None):
+        """``op_adam``: one ELBO + gradient evaluation, Adam step on everything but the final layer's q(u)."""
+        elbo, g = iw_elbo_and_gradients(self.model, zs)
+        self.adam_t += 1
+        self._adam_call(g, lr=staircase_decay(self.lr, self.global_step, self.lr_decay))
+        if self._scalars:                                      # host copies of the scalar parameters (one small D2H)
+            vals = torch.cat([t for t, _ in self._scalars]).tolist()
+            for (_, setter), v in zip(self._scalars, vals):
+                setter(float(v))
+        return elbo
+
+    def step(self, zs_ng=None, zs_adam=None):
+        """``model.train_op`` (build_models.py:297-300); returns the ELBO seen by the Adam op."""
+        self.global_step += 1
+        self.natgrad_op(zs_ng)
+        return self.adam_op(zs_adam)

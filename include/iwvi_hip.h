@@ -291,6 +291,21 @@ int iwvi_encoder_backward(const float* XY, int64_t rows, const float* const* enc
                           const int32_t* dims, int n_enc, const float* d_out,
                           float* const* dW, float* const* db, void* ws, void* stream);
 
+/* Optimiser steps of experiments/build_models.py:284-304.
+ * iwvi_natgrad_step: GPflow NatGradOptimizer (natural parameterisation) on a whitened (q_mu [M, R], q_sqrt [R, M, M]),
+ * in place, float64 inside; dq_mu / dq_sqrt = gradients of the ELBO (the objective that is maximised).
+ * iwvi_adam_step: TensorFlow AdamOptimizer on GPflow's unconstrained variables; transform 0 = identity,
+ * 1 = positive (param = softplus(x) + 1e-6); x/m/v are the optimiser's state (same length as param);
+ * init != 0 fills them from the current parameter values instead of stepping; t = 1-based step count. */
+size_t iwvi_natgrad_ws_bytes(int M);
+int iwvi_natgrad_step(float* q_mu, float* q_sqrt, const float* dq_mu, const float* dq_sqrt,
+                      int M, int R, double gamma, void* ws, void* stream);
+typedef struct iwvi_adam_tensor {
+    float* param; const float* grad; float* x; float* m; float* v; int64_t n; int32_t transform;
+} iwvi_adam_tensor;
+int iwvi_adam_step(const iwvi_adam_tensor* tensors_host, int n_tensors, double lr, double beta1, double beta2,
+                   double eps, int64_t t, int maximise, int init, void* stream);
+
 /* models.py:138-150 on precomputed log-weights: logw row of (point b, sample k) = b*stride_b + k*stride_k;
  * arguments as iwvi_iw_elbo_reduce. */
 int iwvi_logw_reduce(const float* logw, int64_t B, int K, int64_t stride_b, int64_t stride_k,

@@ -1,0 +1,47 @@
+"""Wall time of one IW-ELBO value + gradient evaluation (backward.iw_elbo_and_gradients) and of one training step
+(training.Trainer.step = NatGrad op + Adam op, two gradient evaluations) at a BASELINE.json configuration.
+Usage: python scripts/time_backward.py [--config 2] [--iters 20]"""
+import argparse
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from dgps_with_iwvi_amd import synthetic, backward   # noqa: E402
+from dgps_with_iwvi_amd.training import Trainer   # noqa: E402
+
+CONFIGS = {1: dict(L=2, M=128, K=5, B=1024, with_lv=False), 2: dict(L=2, M=128, K=20, B=1024, with_lv=True),
+           3: dict(L=3, M=256, K=50, B=4096, with_lv=False)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--config", type=int, default=2)
+    ap.add_argument("--iters", type=int, default=20)
+    a = ap.parse_args()
+    dev = torch.device("cuda:0")
+    spec = synthetic.make_spec(**CONFIGS[a.config], seed=0)
+    model = synthetic.build_model(spec, dev)
+
+    def timed(fn, n):
+        fn(); fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n * 1e3
+
+    fwd = timed(lambda: model._build_likelihood(), a.iters)
+    grad = timed(lambda: backward.iw_elbo_and_gradients(model), a.iters)
+    tr = Trainer(model)
+    step = timed(lambda: tr.step(), a.iters)
+    T = spec["B"] * spec["K"]
+    print("config %d: forward (fused, eager) %.3f ms | value+gradient %.3f ms (%.2e samples/s) | training step %.3f ms"
+          % (a.config, fwd, grad, T / grad * 1e3, step))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,171 @@
+"""The training step of experiments/build_models.py:284-304 on the GPU (NatGrad on the final layer's q(u), Adam on the
+rest) against the NumPy float64 optimiser oracle (oracle/optim_oracle.py) driven by the gradient oracle."""
+import copy
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import optim_oracle as oo   # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+def _t(a, dev):
+    return torch.as_tensor(np.asarray(a, dtype=np.float32), device=dev)
+
+
+@pytest.mark.parametrize("M,R", [(8, 1), (40, 2), (128, 1)])
+def test_natgrad_step_matches_oracle(gpu_device, M, R):
+    import ctypes
+    from dgps_with_iwvi_amd import _abi
+    rng = np.random.default_rng(M)
+    q_mu = rng.standard_normal((M, R)).astype(np.float32)
+    q_sqrt = (np.tril(rng.standard_normal((R, M, M))) * 0.1 + np.eye(M)).astype(np.float32)
+    g_mu = rng.standard_normal((M, R)).astype(np.float32)            # gradients of the ELBO
+    g_sqrt = np.tril(rng.standard_normal((R, M, M))).astype(np.float32) * 0.5
+    ref_mu, ref_sqrt = oo.natgrad_step(q_mu, q_sqrt, -g_mu.astype(np.float64), -g_sqrt.astype(np.float64), 0.05)
+    d_mu, d_sqrt, dg_mu, dg_sqrt = (_t(a, gpu_device) for a in (q_mu, q_sqrt, g_mu, g_sqrt))
+    ws = torch.empty(_abi.lib().iwvi_natgrad_ws_bytes(M), dtype=torch.uint8, device=gpu_device)
+    _abi.check(_abi.lib().iwvi_natgrad_step(_abi.ptr(d_mu), _abi.ptr(d_sqrt), _abi.ptr(dg_mu), _abi.ptr(dg_sqrt), M, R, 0.05,
+                                           ws.data_ptr(), _abi.stream_ptr()))
+    np.testing.assert_allclose(d_mu.cpu().numpy(), ref_mu, rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(d_sqrt.cpu().numpy(), ref_sqrt, rtol=2e-5, atol=2e-6)
+    assert float(torch.triu(d_sqrt, 1).abs().max()) == 0.0
+
+
+def test_adam_steps_match_oracle(gpu_device):
+    from dgps_with_iwvi_amd import _abi
+    rng = np.random.default_rng(0)
+    shapes, pos = [(7, 3), (5,), (1,), (300,)], [False, True, True, False]
+    params = [rng.standard_normal(s) if not p else rng.uniform(0.05, 3.0, s) for s, p in zip(shapes, pos)]
+    ref = oo.Adam(params, pos, lr=0.01)
+    dp = [_t(p, gpu_device) for p in params]
+    st = [tuple(torch.empty_like(p) for _ in range(3)) for p in dp]
+
+    def call(grads, t, init):
+        arr = (_abi.AdamTensor * len(dp))()
+        keep = []
+        for i, p in enumerate(dp):
+            a = arr[i]
+            a.param, a.x, a.m, a.v, a.n, a.transform = p.data_ptr(), st[i][0].data_ptr(), st[i][1].data_ptr(), st[i][2].data_ptr(), p.numel(), int(pos[i])
+            if grads is not None:
+                keep.append(_t(grads[i], gpu_device)); a.grad = keep[-1].data_ptr()
+        _abi.check(_abi.lib().iwvi_adam_step(arr, len(dp), 0.01, 0.9, 0.999, 1e-8, t, 0, init, _abi.stream_ptr()))
+        torch.cuda.synchronize()
+
+    call(None, 1, 1)
+    for t in range(1, 6):
+        grads = [rng.standard_normal(s) for s in shapes]
+        new = ref.step(grads)
+        call(grads, t, 0)
+        for got, want in zip(dp, new):
+            np.testing.assert_allclose(got.cpu().numpy(), want, rtol=3e-5, atol=3e-6)
+
+
+class _OracleTrainer:
+    """The same step on the NumPy side: gradient oracle + optimiser oracle, parameters kept in the spec."""
+
+    def __init__(self, spec, lr, gamma):
+        from oracle.grad_oracle import iw_elbo_and_gradients
+        self.grad = iw_elbo_and_gradients
+        self.spec, self.lr, self.gamma = spec, lr, gamma
+        self.n = len(spec["layers"])
+        self.names, pos = [], []
+        for i, l in enumerate(spec["layers"]):
+            if l["type"] == "lv":
+                for j in range(len(l["enc_W"])):
+                    self.names += ["l%d.encW%d" % (i, j), "l%d.encb%d" % (i, j)]; pos += [False, False]
+            elif i == self.n - 1:
+                self.names += ["l%d.Z" % i, "l%d.ls" % i, "l%d.var" % i]; pos += [False, True, True]
+            else:
+                self.names += ["l%d.Z" % i, "l%d.ls" % i, "l%d.q_mu" % i, "l%d.q_sqrt" % i]; pos += [False, True, False, False]
+        self.names.append("lik_var"); pos.append(True)
+        self.adam = oo.Adam([self.get(k) for k in self.names], pos, lr)
+        self.signif = None       # per parameter: entries whose gradient was never negligible (Adam normalises the step
+        #                          size, so an entry with a ~0 gradient moves by ~lr in the direction of rounding noise)
+
+    def get(self, name):
+        if name == "lik_var":
+            return np.asarray(self.spec["lik_var"], dtype=np.float64)
+        i, key = name.split(".")
+        l = self.spec["layers"][int(i[1:])]
+        if key.startswith("encW"):
+            return l["enc_W"][int(key[4:])]
+        if key.startswith("encb"):
+            return l["enc_b"][int(key[4:])]
+        return np.asarray(l[key], dtype=np.float64)
+
+    def put(self, name, v):
+        if name == "lik_var":
+            self.spec["lik_var"] = float(v); return
+        i, key = name.split(".")
+        l = self.spec["layers"][int(i[1:])]
+        if key.startswith("encW"):
+            l["enc_W"][int(key[4:])] = v
+        elif key.startswith("encb"):
+            l["enc_b"][int(key[4:])] = v
+        elif key == "var":
+            l[key] = float(v)
+        else:
+            l[key] = v
+
+    def step(self, zs_ng, zs_adam):
+        f = self.spec["layers"][-1]
+        _, g = self.grad(self.spec, zs_ng)
+        i = self.n - 1
+        f["q_mu"], f["q_sqrt"] = oo.natgrad_step(f["q_mu"], f["q_sqrt"], -g["l%d.q_mu" % i], -g["l%d.q_sqrt" % i], self.gamma)
+        val, g = self.grad(self.spec, zs_adam)
+        sig = [np.abs(np.asarray(g[k])) > 1e-3 * max(np.abs(np.asarray(g[k])).max(), 1e-300) for k in self.names]
+        self.signif = sig if self.signif is None else [a & b for a, b in zip(self.signif, sig)]
+        new = self.adam.step([-np.asarray(g[k]) for k in self.names])
+        for k, v in zip(self.names, new):
+            self.put(k, v)
+        return val
+
+
+@pytest.mark.parametrize("L,M,K,B,lv", [(2, 32, 4, 12, True), (2, 64, 3, 16, False)])
+def test_training_steps_follow_the_oracle_loop(gpu_device, L, M, K, B, lv):
+    from dgps_with_iwvi_amd import synthetic
+    from dgps_with_iwvi_amd.training import Trainer
+    spec = synthetic.make_spec(L=L, M=M, B=B, K=K, with_lv=lv, seed=11)
+    model = synthetic.build_model(spec, gpu_device)
+    ospec = copy.deepcopy(spec)
+    tr = Trainer(model, lr=5e-3, gamma=1e-2)
+    ot = _OracleTrainer(ospec, 5e-3, 1e-2)
+    for s in range(3):
+        zs_a, zs_b = synthetic.make_noise(spec, seed=100 + 2 * s), synthetic.make_noise(spec, seed=101 + 2 * s)
+        e_gpu = float(tr.step([_t(z, gpu_device) for z in zs_a], [_t(z, gpu_device) for z in zs_b]))
+        e_ref = ot.step(zs_a, zs_b)
+        assert abs(e_gpu - e_ref) <= 3e-4 * abs(e_ref), (s, e_gpu, e_ref)
+    sig = dict(zip(ot.names, ot.signif))
+    n_sig = n_all = 0
+    for name, p, _ in tr._entries:
+        ref = np.asarray(ot.get(name), dtype=np.float64).reshape(-1)
+        got = p.detach().cpu().numpy().astype(np.float64).reshape(-1)
+        m = np.asarray(sig[name]).reshape(-1)
+        n_sig += int(m.sum()); n_all += m.size
+        np.testing.assert_allclose(got[m], ref[m], rtol=2e-4, atol=2e-4, err_msg=name)
+        np.testing.assert_allclose(got, ref, rtol=0, atol=3.5 * 5e-3, err_msg=name)      # nobody moves further than 3 Adam steps
+    assert n_sig > 0.5 * n_all
+    f, fo = model.layers[-1], ospec["layers"][-1]
+    np.testing.assert_allclose(f.q_mu.cpu().numpy(), fo["q_mu"], rtol=2e-3, atol=2e-4)
+    np.testing.assert_allclose(f.q_sqrt.cpu().numpy(), fo["q_sqrt"], rtol=2e-3, atol=2e-4)
+    assert model.likelihood.variance == pytest.approx(ospec["lik_var"], rel=1e-3)
+
+
+def test_training_raises_the_bound_on_fixed_noise(gpu_device):
+    from dgps_with_iwvi_amd import synthetic
+    from dgps_with_iwvi_amd.training import Trainer
+    spec = synthetic.make_spec(L=2, M=32, B=64, K=5, with_lv=True, seed=5)
+    model = synthetic.build_model(spec, gpu_device)
+    zs = [_t(z, gpu_device) for z in synthetic.make_noise(spec, seed=1)]
+    before = model.compute_log_likelihood(zs)
+    tr = Trainer(model, lr=5e-3, gamma=1e-2)
+    for _ in range(25):
+        tr.step()
+    after = model.compute_log_likelihood(zs)
+    assert after > before, (before, after)
