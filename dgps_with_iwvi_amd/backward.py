@@ -22,17 +22,27 @@ def _words(device):
     return torch.zeros(4, dtype=torch.int64, device=device)
 
 
-def gp_forward_saved(layer, F, z=None, words=None):
+def precompute_dense(layers):
+    """One precompute launch for all GP layers with IWVI_GP_WANT_DENSE (the adjoints read the dense Lm, Lm^-1)."""
+    descs = []
+    for l in layers:
+        if isinstance(l, GPLayer):
+            d = l.state_desc()
+            d.flags = _abi.GP_WANT_DENSE
+            descs.append(d)
+    precompute_states(descs)
+
+
+def gp_forward_saved(layer, F, z=None, words=None, precomputed=False):
     """``GPLayer.propagate`` on per-sample rows F [T, D] (marginal variances) that also keeps a = Lm^-1 k,
-    u_r = L_r^T a and the draws.  Factorises with IWVI_GP_WANT_DENSE: the adjoint reads the dense Lm, Lm^-1."""
+    u_r = L_r^T a and the draws.  Factorises with IWVI_GP_WANT_DENSE unless ``precomputed`` (``precompute_dense``)."""
     if not isinstance(layer, GPLayer):
         raise TypeError("gp_forward_saved needs a GPLayer")
     F = _abi.dev_tensor(F.contiguous(), "F")
     T, D = F.shape
     dev = F.device
-    d = layer.state_desc()
-    d.flags = _abi.GP_WANT_DENSE
-    precompute_states([d])
+    if not precomputed:
+        precompute_dense([layer])
     R, Mp = layer.num_outputs, layer.state().Mp
     P = layer.kern.W.shape[0] if isinstance(layer.kern, SharedMixedMok) else R
     s = GpSaved()
@@ -135,6 +145,7 @@ def iw_elbo_and_gradients(model, zs=None):
         XY = model._xy_minibatch()
         XYt = XY[:, None, :].expand(B, K, XY.shape[1]).reshape(T, -1).contiguous()
     words = model._words()
+    precompute_dense(layers)
     saved = []
     for layer, z in zip(layers, zs):
         if isinstance(layer, LatentVariableLayer):
@@ -147,7 +158,7 @@ def iw_elbo_and_gradients(model, zs=None):
         elif isinstance(layer, GPLayer):
             R = layer.num_outputs
             eps = draw_normal((T, R), dev) if z is None else z.reshape(T, R)
-            s = gp_forward_saved(layer, F, eps, words)
+            s = gp_forward_saved(layer, F, eps, words, precomputed=True)
             saved.append(("gp", s))
             F = s.sample
         else:

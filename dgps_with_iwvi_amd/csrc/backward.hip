@@ -34,6 +34,11 @@ struct GemmArgs {
     int M, N, K, nsplit, kchunk;
     float alpha, beta;
     int b_keep_n_ge_k;                  // B(k, n) read as 0 where n < k (a lower-triangular matrix indexed [n][k])
+    // fast path only.  K = nseg segments of kseg: segment s reads A + s*a_seg, B + s*b_seg, scale + s*s_seg (a sum of
+    // products in one launch).  nbatch independent products (blockIdx.z = batch*nsplit + split): batch b reads
+    // B + b*b_batch, scale + b*s_batch and writes part + b*nsplit*M*N.
+    int kseg; long long a_seg, b_seg, s_seg;
+    int nbatch; long long b_batch, s_batch;
 };
 constexpr int GT = 64, GK = 16, GLD = GT + 4;
 
@@ -90,40 +95,163 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs g) {
         }
 }
 
-// out[m, n] = alpha * sum_s part[s][m][n] (+ beta * out); tri: entries above the diagonal become 0.  Either output
-// may be null (float / double).
-struct ReduceArgs { const float* part; int S, M, N; float* out; double* out64; long long ldo; double alpha, beta; int tri; };
-__global__ void k_reduce_parts(ReduceArgs r) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= r.M * r.N) return;
-    const int m = idx / r.N, n = idx - m * r.N;
-    double s = 0.0;
-    for (int k = 0; k < r.S; ++k) s += (double)r.part[(size_t)k * r.M * r.N + idx];
-    s *= r.alpha;
-    if (r.tri && n > m) s = 0.0;
-    if (r.out) { float* o = r.out + m * r.ldo + n; *o = (float)(s + (r.beta != 0.0 ? r.beta * (double)*o : 0.0)); }
-    if (r.out64) { double* o = r.out64 + m * r.ldo + n; *o = s + (r.beta != 0.0 ? r.beta * *o : 0.0); }
+
+// Fast path: full 64x64 tiles, 16-deep stages, float4 global loads (one per operand per thread per stage), LDS double
+// buffer (one barrier per stage, next stage's loads in flight under the MFMAs), 2x2 MFMA tiles per wave.
+// A_KC: A's k index is contiguous (else its m index); B_NC: B's n index is contiguous (else its k index).
+template <bool A_KC, bool B_NC>
+__global__ __launch_bounds__(256) void k_gemm_fast(GemmArgs g) {
+    __shared__ __attribute__((aligned(16))) float As[2][GK][GLD];
+    __shared__ __attribute__((aligned(16))) float Bs[2][GK][GLD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
+    const int m0 = blockIdx.y * GT, n0 = blockIdx.x * GT;
+    const int batch = (int)blockIdx.z / g.nsplit, split = (int)blockIdx.z - batch * g.nsplit;
+    const int kb = split * g.kchunk;
+    const int ke = (kb + g.kchunk < g.K) ? kb + g.kchunk : g.K;
+    const float* Bb = g.B + batch * g.b_batch;
+    const float* Sb = g.scale ? g.scale + batch * g.s_batch : nullptr;
+    // this thread's slot in a stage: A_KC: (m = tid/4, k = 4*(tid%4)..+3); else (k = tid/16, m = 4*(tid%16)..+3)
+    const int am = A_KC ? tid >> 2 : (tid & 15) * 4, ak = A_KC ? (tid & 3) * 4 : tid >> 4;
+    const int bn = B_NC ? (tid & 15) * 4 : tid >> 2, bk = B_NC ? tid >> 4 : (tid & 3) * 4;
+    f32x4 ra, rb;
+    auto fetch = [&](int k0) {
+        const int seg = k0 / g.kseg, kl = k0 - seg * g.kseg;             // a stage never straddles a segment (kseg % 16 == 0)
+        const float* A = g.A + seg * g.a_seg; const float* B = Bb + seg * g.b_seg;
+        ra = *reinterpret_cast<const f32x4*>(A + (long long)(m0 + am) * g.a_sm + (long long)(kl + ak) * g.a_sk);
+        rb = *reinterpret_cast<const f32x4*>(B + (long long)(kl + bk) * g.b_sk + (long long)(n0 + bn) * g.b_sn);
+        if (Sb) {
+            const float* S = Sb + seg * g.s_seg;
+            if (g.scale_on_k) {
+                if (A_KC) for (int e = 0; e < 4; ++e) ra[e] *= S[(long long)(kl + ak + e) * g.s_stride];
+                else ra *= S[(long long)(kl + ak) * g.s_stride];
+            } else {
+                if (A_KC) ra *= S[(long long)(m0 + am) * g.s_stride];
+                else for (int e = 0; e < 4; ++e) ra[e] *= S[(long long)(m0 + am + e) * g.s_stride];
+            }
+        }
+        if (g.b_keep_n_ge_k)
+            for (int e = 0; e < 4; ++e) { const int n = n0 + bn + (B_NC ? e : 0), k = kl + bk + (B_NC ? 0 : e); if (n < k) rb[e] = 0.f; }
+    };
+    auto stash = [&](int buf) {
+        if (A_KC) for (int e = 0; e < 4; ++e) As[buf][ak + e][am] = ra[e];
+        else *reinterpret_cast<f32x4*>(&As[buf][ak][am]) = ra;
+        if (B_NC) *reinterpret_cast<f32x4*>(&Bs[buf][bk][bn]) = rb;
+        else for (int e = 0; e < 4; ++e) Bs[buf][bk + e][bn] = rb[e];
+    };
+    f32x4 acc[2][2];
+    for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    fetch(kb); stash(0);
+    __syncthreads();
+    int buf = 0;
+    for (int k0 = kb; k0 < ke; k0 += GK, buf ^= 1) {
+        const bool more = k0 + GK < ke;
+        if (more) fetch(k0 + GK);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const int kr = 4 * kk + (lane >> 4);
+            const float a0 = As[buf][kr][wm + (lane & 15)], a1 = As[buf][kr][wm + 16 + (lane & 15)];
+            const float b0 = Bs[buf][kr][wn + (lane & 15)], b1 = Bs[buf][kr][wn + 16 + (lane & 15)];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        if (more) stash(buf ^ 1);
+        __syncthreads();
+    }
+    float* part = g.part ? g.part + ((size_t)batch * g.nsplit + split) * g.M * g.N : nullptr;
+    for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int v = 0; v < 4; ++v) {
+        const int m = m0 + wm + 16 * i + 4 * (lane >> 4) + v, n = n0 + wn + 16 * j + (lane & 15);
+        if (part) part[(size_t)m * g.N + n] = acc[i][j][v];
+        else {
+            float* c = g.C + m * g.ldc + n;
+            *c = g.alpha * acc[i][j][v] + (g.beta != 0.f ? g.beta * *c : 0.f);
+        }
+    }
+}
+static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+// launch on the fast path if the shapes allow it; returns false otherwise (caller falls back to k_gemm)
+static bool launch_fast(hipStream_t st, const GemmArgs& g) {
+    const bool a_kc = g.a_sk == 1, a_mc = g.a_sm == 1, b_nc = g.b_sn == 1, b_kc = g.b_sk == 1;
+    if (!(a_kc || a_mc) || !(b_nc || b_kc)) return false;
+    if (g.M % GT || g.N % GT || g.kseg % GK || g.K % g.kseg || g.kchunk % GK || (g.K % g.kchunk && g.nsplit > 1) || g.K % GK) return false;
+    if (g.kseg != g.K && g.kchunk % g.kseg && g.kseg % g.kchunk) return false;
+    const long long a_ld = a_kc ? g.a_sm : g.a_sk, b_ld = b_nc ? g.b_sk : g.b_sn;
+    if (a_ld % 4 || b_ld % 4 || g.a_seg % 4 || g.b_seg % 4 || g.b_batch % 4 || !aligned16(g.A) || !aligned16(g.B)) return false;
+    const dim3 grid(g.N / GT, g.M / GT, g.nsplit * g.nbatch), block(256);
+    if (a_kc && b_nc) hipLaunchKernelGGL((k_gemm_fast<true, true>), grid, block, 0, st, g);
+    else if (a_kc) hipLaunchKernelGGL((k_gemm_fast<true, false>), grid, block, 0, st, g);
+    else if (b_nc) hipLaunchKernelGGL((k_gemm_fast<false, true>), grid, block, 0, st, g);
+    else hipLaunchKernelGGL((k_gemm_fast<false, false>), grid, block, 0, st, g);
+    return true;
 }
 
+// out[m, n] = alpha * sum_s part[s][m][n] (+ beta * out); tri: entries above the diagonal become 0.  Either output
+// may be null (float / double).
+struct ReduceArgs { const float* part; int S, M, N; float* out; double* out64; long long ldo; double alpha, beta; int tri; long long out_batch; };
+__global__ __launch_bounds__(256) void k_reduce_parts(ReduceArgs r) {
+    // 64 outputs per workgroup; the S partials of an output are summed by 4 threads (contiguous quarters, in order),
+    // then combined in a fixed order: deterministic whatever the launch geometry
+    __shared__ double red[4][64];
+    const int o = threadIdx.x & 63, gq = threadIdx.x >> 6;
+    const int idx = blockIdx.x * 64 + o, b = blockIdx.y;
+    const size_t MN = (size_t)r.M * r.N;
+    const float* part = r.part + (size_t)b * r.S * MN;
+    double s = 0.0;
+    if (idx < r.M * r.N) {
+        const int per = (r.S + 3) / 4, k0 = gq * per, k1 = (k0 + per < r.S) ? k0 + per : r.S;
+#pragma unroll 8
+        for (int k = k0; k < k1; ++k) s += (double)part[(size_t)k * MN + idx];
+    }
+    red[gq][o] = s;
+    __syncthreads();
+    if (gq != 0 || idx >= r.M * r.N) return;
+    s = ((red[0][o] + red[1][o]) + red[2][o]) + red[3][o];
+    const int m = idx / r.N, n = idx - m * r.N;
+    s *= r.alpha;
+    if (r.tri && n > m) s = 0.0;
+    if (r.out) { float* q = r.out + b * r.out_batch + m * r.ldo + n; *q = (float)(s + (r.beta != 0.0 ? r.beta * (double)*q : 0.0)); }
+    if (r.out64) { double* q = r.out64 + b * r.out_batch + m * r.ldo + n; *q = s + (r.beta != 0.0 ? r.beta * *q : 0.0); }
+}
+
+// split-K product(s) summed over many samples: out (+ b*out_batch) = alpha * A^T-style product, reduced in float64
 static int gemm(hipStream_t st, GemmArgs g, float* part_ws, size_t part_floats, float* out, double* out64, long long ldo,
-                double alpha, double beta, int tri) {
-    // split-K form: C / alpha / beta of `g` unused; the reduction writes out / out64
+                double alpha, double beta, int tri, int nbatch = 1, long long b_batch = 0, long long s_batch = 0, long long out_batch = 0) {
     const int kchunk = 512;
     g.nsplit = (g.K + kchunk - 1) / kchunk; g.kchunk = kchunk;
     if (g.nsplit < 2) { g.nsplit = 2; g.kchunk = round_up((g.K + 1) / 2, GK); if (g.kchunk < GK) g.kchunk = GK; }
-    if ((size_t)g.nsplit * g.M * g.N > part_floats) { set_error("backward: split-K workspace too small"); return IWVI_ERR_ARG; }
+    g.kseg = g.K; g.a_seg = g.b_seg = g.s_seg = 0; g.nbatch = nbatch; g.b_batch = b_batch; g.s_batch = s_batch;
+    if ((size_t)g.nsplit * nbatch * g.M * g.N > part_floats) { set_error("backward: split-K workspace too small"); return IWVI_ERR_ARG; }
     g.part = part_ws;
-    hipLaunchKernelGGL(k_gemm, dim3((g.N + GT - 1) / GT, (g.M + GT - 1) / GT, g.nsplit), dim3(256), 0, st, g);
-    ReduceArgs r{part_ws, g.nsplit, g.M, g.N, out, out64, ldo, alpha, beta, tri};
-    hipLaunchKernelGGL(k_reduce_parts, dim3((g.M * g.N + 255) / 256), dim3(256), 0, st, r);
+    if (!launch_fast(st, g)) {
+        for (int b = 0; b < nbatch; ++b) {
+            GemmArgs q = g;
+            q.B = g.B + b * b_batch; if (g.scale) q.scale = g.scale + b * s_batch;
+            q.part = part_ws + (size_t)b * g.nsplit * g.M * g.N;
+            hipLaunchKernelGGL(k_gemm, dim3((g.N + GT - 1) / GT, (g.M + GT - 1) / GT, g.nsplit), dim3(256), 0, st, q);
+        }
+    }
+    ReduceArgs r{part_ws, g.nsplit, g.M, g.N, out, out64, ldo, alpha, beta, tri, out_batch};
+    hipLaunchKernelGGL(k_reduce_parts, dim3((g.M * g.N + 63) / 64, nbatch), dim3(256), 0, st, r);
     return check_launch("k_gemm (split-K)");
 }
-static int gemm_rows(hipStream_t st, GemmArgs g) {     // many rows, short K: direct store
-    g.nsplit = 1; g.kchunk = round_up(g.K, GK); g.part = nullptr;
-    hipLaunchKernelGGL(k_gemm, dim3((g.N + GT - 1) / GT, (g.M + GT - 1) / GT, 1), dim3(256), 0, st, g);
+// many rows, short K: direct store.  nseg > 1: the sum of nseg products (segment strides a_seg / b_seg / s_seg)
+static int gemm_rows(hipStream_t st, GemmArgs g, int nseg = 1, long long a_seg = 0, long long b_seg = 0, long long s_seg = 0) {
+    g.nsplit = 1; g.part = nullptr; g.nbatch = 1; g.b_batch = g.s_batch = 0;
+    g.kseg = g.K; g.K *= nseg; g.a_seg = a_seg; g.b_seg = b_seg; g.s_seg = s_seg; g.kchunk = round_up(g.K, GK);
+    if (launch_fast(st, g)) return check_launch("k_gemm_fast (rows)");
+    const float beta = g.beta;
+    for (int sgi = 0; sgi < nseg; ++sgi) {
+        GemmArgs q = g;
+        q.K = g.kseg; q.kchunk = round_up(q.K, GK); q.A = g.A + sgi * a_seg; q.B = g.B + sgi * b_seg; if (g.scale) q.scale = g.scale + sgi * s_seg;
+        q.beta = sgi == 0 ? beta : 1.f;
+        hipLaunchKernelGGL(k_gemm, dim3((g.N + GT - 1) / GT, (g.M + GT - 1) / GT, 1), dim3(256), 0, st, q);
+    }
     return check_launch("k_gemm (rows)");
 }
 
+// (thin() is defined after k_thin)
 // ------------------------------------------------------------------------------------------------------------
 // per-sample heads: one wave per sample
 // ------------------------------------------------------------------------------------------------------------
@@ -190,56 +318,150 @@ __global__ __launch_bounds__(256) void k_bw_heads(HeadArgs h) {
     }
 }
 
-// DA[t, m] -= 2 * SDV[t] * A[t, m]
-__global__ void k_bw_axpy(float* DA, const float* A, const float* SDV, long long T, int M, int Mp) {
+// DA[t, m] = sum_r DMU[t, r] q_mu[m, r] - 2 SDV[t] A[t, m]   (the U_r L_r^T products are accumulated on top)
+__global__ void k_bw_da_init(float* DA, const float* A, const float* SDV, const float* DMU, const float* q_mu, long long T, int M, int Mp, int R) {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= T * M) return;
     const long long t = idx / M; const int m = (int)(idx - t * M);
-    DA[idx] = fmaf(-2.f * SDV[t], A[t * Mp + m], DA[idx]);
+    float acc = -2.f * SDV[t] * A[t * Mp + m];
+    for (int r = 0; r < R; ++r) acc = fmaf(DMU[t * R + r], q_mu[m * R + r], acc);
+    DA[idx] = acc;
 }
 
-// K_uf entries again (RBF, direct differences), c = -1/2 k dk written over DA; per-sample sum_m c and sum_m k dk
-struct KernArgs { const float* F; const float* Zt; const float* invls; const float* DK; float* C; float* RS; long long T; int M, D; float variance; };
+// One wave per sample: K_uf entries again (RBF, direct differences), c = -1/2 k dk written over DA, then
+// dx~ = 2 x~ sum_m c_m - 2 sum_m c_m z~_m, dF += dx~ * invls, and the per-sample row of column-sum inputs
+// Qx[t] = (dx~ o x [D] | sum_r dv_r | sum_m k dk).
+struct KernArgs { const float* F; const float* Zt; const float* invls; const float* DK; float* C; const float* SDV; float* dF; float* Qx;
+                  long long T; int M, D; float variance; };
+template <int DM>                       // D <= DM: the per-dimension arrays stay in registers
 __global__ __launch_bounds__(256) void k_bw_kernel(KernArgs a) {
     const int lane = threadIdx.x & 63;
     const long long t = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (t >= a.T) return;
-    float xt[IWVI_MAX_D];
-    for (int d = 0; d < a.D; ++d) xt[d] = a.F[t * a.D + d] * a.invls[d];
+    float xt[DM], cz[DM];
+#pragma unroll
+    for (int d = 0; d < DM; ++d) { xt[d] = d < a.D ? a.F[t * a.D + d] * a.invls[d] : 0.f; cz[d] = 0.f; }
     float sc = 0.f, skd = 0.f;
     for (int m = lane; m < a.M; m += 64) {
-        float d2 = 0.f;
-        for (int d = 0; d < a.D; ++d) { const float e = xt[d] - a.Zt[m * a.D + d]; d2 = fmaf(e, e, d2); }
+        float d2 = 0.f, z[DM];
+#pragma unroll
+        for (int d = 0; d < DM; ++d) { z[d] = d < a.D ? a.Zt[m * a.D + d] : 0.f; const float e = xt[d] - z[d]; d2 = fmaf(e, e, d2); }
         const float k = a.variance * __expf(-0.5f * d2);
         const float kd = k * a.DK[t * a.M + m];
-        a.C[t * a.M + m] = -0.5f * kd;
-        sc += -0.5f * kd; skd += kd;
+        const float c = -0.5f * kd;
+        a.C[t * a.M + m] = c;
+        sc += c; skd += kd;
+#pragma unroll
+        for (int d = 0; d < DM; ++d) cz[d] = fmaf(c, z[d], cz[d]);
     }
     sc = wave_sum(sc); skd = wave_sum(skd);
-    if (lane == 0) { a.RS[2 * t] = sc; a.RS[2 * t + 1] = skd; }
+    const int W = a.D + 2;
+#pragma unroll
+    for (int d = 0; d < DM; ++d) {
+        if (d < a.D) {
+        const float czd = wave_sum(cz[d]);
+        if (lane == 0) {
+            const float dxt = 2.f * xt[d] * sc - 2.f * czd;
+            if (a.dF) a.dF[t * a.D + d] = fmaf(dxt, a.invls[d], a.dF[t * a.D + d]);
+            a.Qx[t * W + d] = dxt * a.F[t * a.D + d];
+        }
+        }
+    }
+    if (lane == 0) { a.Qx[t * W + a.D] = a.SDV[t]; a.Qx[t * W + a.D + 1] = skd; }
 }
 
-// dx~ = 2 x~ rowsum(C) - 2 C Z~ ;  dF += dx~ * invls ;  Q = dx~ o x (its column sums are d/d invls through x~)
-__global__ void k_bw_dx(const float* F, const float* invls, const float* RS, const float* CZ, float* dF, float* Q, long long T, int D) {
-    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= T * D) return;
-    const long long t = idx / D; const int d = (int)(idx - t * D);
-    const float x = F[idx], il = invls[d];
-    const float dxt = 2.f * (x * il) * RS[2 * t] - 2.f * CZ[idx];
-    if (dF) dF[idx] = fmaf(dxt, il, dF[idx]);
-    Q[idx] = dxt * x;
+// Thin sums over samples: part[blk][m][n] = sum_{t in chunk} X[t*ldx + m] * Y(t, n), n < N + ones, N <= 64; the extra
+// column (ones) is the plain column sum.  Thread = column m, rows in a fixed order; chunks summed by k_reduce_parts.
+constexpr int THIN_ROWS = 64;
+struct ThinArgs { const float* X; long long ldx; const float* Y; long long ldy; int N, ones; long long T; int M; float* part; };
+template <int NM>                       // N <= NM: the accumulators stay in registers
+__global__ __launch_bounds__(256) void k_thin(ThinArgs a) {
+    // chunk of 64 rows per workgroup: its rows of Y staged in LDS, wave w takes rows 16w..16w+15, lanes over the columns
+    // of X (64 at a time), the four waves' partial sums combined through LDS in a fixed order
+    __shared__ float ys[THIN_ROWS * (NM > 1 ? NM : 1)];
+    __shared__ float red[4][64][NM + 1];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long long t0 = (long long)blockIdx.x * THIN_ROWS;
+    const int nrows = (int)((a.T - t0) < THIN_ROWS ? (a.T - t0) : THIN_ROWS);
+    if (a.N > 0) {
+        // rows beyond the end are zero-filled: they meet x = 0 below, and 0 * (stale LDS bits) could be NaN
+        if (a.ldy == a.N) for (int i = tid; i < THIN_ROWS * a.N; i += 256) ys[i] = i < nrows * a.N ? a.Y[t0 * a.ldy + i] : 0.f;
+        else for (int i = tid; i < THIN_ROWS * a.N; i += 256) { const int r = i / a.N; ys[i] = r < nrows ? a.Y[(t0 + r) * a.ldy + (i - r * a.N)] : 0.f; }
+    }
+    __syncthreads();
+    const int NN = a.N + a.ones;
+    for (int mb = 0; mb < a.M; mb += 64) {
+        const int m = mb + lane;
+        float x[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { const int r = 16 * wave + i; x[i] = (m < a.M && r < nrows) ? a.X[(t0 + r) * a.ldx + m] : 0.f; }
+        float acc[NM], ones = 0.f;
+#pragma unroll
+        for (int n = 0; n < NM; ++n) acc[n] = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int r = 16 * wave + i;
+#pragma unroll
+            for (int n = 0; n < NM; ++n) if (n < a.N) acc[n] = fmaf(x[i], ys[r * a.N + n], acc[n]);
+            ones += x[i];
+        }
+#pragma unroll
+        for (int n = 0; n < NM; ++n) red[wave][lane][n] = acc[n];
+        red[wave][lane][NM] = ones;
+        __syncthreads();
+        for (int i = tid; i < 64 * NN; i += 256) {
+            const int l = i / NN, n = i - l * NN, c = (n < a.N) ? n : NM;
+            if (mb + l < a.M)
+                a.part[((size_t)blockIdx.x * a.M + mb + l) * NN + n] = ((red[0][l][c] + red[1][l][c]) + red[2][l][c]) + red[3][l][c];
+        }
+        __syncthreads();
+    }
+}
+
+// out[m, n] = sum_t X[t, m] Y[t, n] (n < N) and, with ones, out[m, N] = sum_t X[t, m];  out is [M, N + ones]
+static int thin(hipStream_t st, const float* X, long long ldx, int M, const float* Y, long long ldy, int N, int ones, long long T,
+                float* part_ws, size_t part_floats, float* out, int ldo = 0) {
+    if (ldo == 0) ldo = N + ones;
+    if (N > 32) {                                          // columns of Y in two passes (LDS budget of k_thin)
+        int rc = thin(st, X, ldx, M, Y, ldy, 32, 0, T, part_ws, part_floats, out, ldo);
+        if (rc != IWVI_OK) return rc;
+        return thin(st, X, ldx, M, Y + 32, ldy, N - 32, ones, T, part_ws, part_floats, out + 32, ldo);
+    }
+    const int nblk = (int)((T + THIN_ROWS - 1) / THIN_ROWS), NN = N + ones;
+    if ((size_t)nblk * M * NN > part_floats) { set_error("backward: thin-reduction workspace too small"); return IWVI_ERR_ARG; }
+    ThinArgs a{X, ldx, Y, ldy, N, ones, T, M, part_ws};
+    const dim3 grid(nblk), block(256);
+    if (N <= 1) hipLaunchKernelGGL(k_thin<1>, grid, block, 0, st, a);
+    else if (N <= 8) hipLaunchKernelGGL(k_thin<8>, grid, block, 0, st, a);
+    else if (N <= 16) hipLaunchKernelGGL(k_thin<16>, grid, block, 0, st, a);
+    else hipLaunchKernelGGL(k_thin<32>, grid, block, 0, st, a);
+    ReduceArgs r{part_ws, nblk, M, NN, out, nullptr, ldo, 1.0, 0.0, 0, 0};
+    hipLaunchKernelGGL(k_reduce_parts, dim3((M * NN + 63) / 64, 1), dim3(256), 0, st, r);
+    return check_launch("k_thin");
 }
 
 // ------------------------------------------------------------------------------------------------------------
 // float64 side: small dense products for the Cholesky adjoint, K_uu's own gradient, final assembly
 // ------------------------------------------------------------------------------------------------------------
-// C[i, j] = sum_k A(i, k) B(k, j); post = 1: Phi (strict upper -> 0, diagonal halved)
-__global__ void k_dmm(const double* A, long long a_si, long long a_sk, const double* B, long long b_sk, long long b_sj,
-                      double* C, int n, int ldc, int post) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;
-    if (j >= n) return;
+// C[i, j] = sum_k A(i, k) B(k, j); post = 1: Phi (strict upper -> 0, diagonal halved).  16x16 tiles through LDS.
+__global__ __launch_bounds__(256) void k_dmm(const double* A, long long a_si, long long a_sk, const double* B, long long b_sk, long long b_sj,
+                                             double* C, int n, int ldc, int post) {
+    __shared__ double As[16][17], Bs[16][17];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int i = blockIdx.y * 16 + ty, j = blockIdx.x * 16 + tx;
     double s = 0.0;
-    for (int k = 0; k < n; ++k) s = fma(A[i * a_si + k * a_sk], B[k * b_sk + j * b_sj], s);
+    for (int k0 = 0; k0 < n; k0 += 16) {
+        // load so that the contiguous index of each operand runs along tx
+        if (a_sk == 1) As[ty][tx] = (i < n && k0 + tx < n) ? A[i * a_si + (k0 + tx)] : 0.0;
+        else { const int ii = blockIdx.y * 16 + tx, kk = k0 + ty; As[tx][ty] = (ii < n && kk < n) ? A[ii * a_si + kk * a_sk] : 0.0; }
+        if (b_sj == 1) Bs[ty][tx] = (k0 + ty < n && j < n) ? B[(k0 + ty) * b_sk + j] : 0.0;
+        else { const int jj = blockIdx.x * 16 + ty, kk = k0 + tx; Bs[tx][ty] = (jj < n && kk < n) ? B[kk * b_sk + jj * b_sj] : 0.0; }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 16; ++k) s = fma(As[ty][k], Bs[k][tx], s);
+        __syncthreads();
+    }
+    if (i >= n || j >= n) return;
     if (post == 1) s = (j > i) ? 0.0 : (j == i ? 0.5 * s : s);
     C[(size_t)i * ldc + j] = s;
 }
@@ -277,40 +499,42 @@ struct FinalArgsB {
     float* dZ; float* dls; float* dvariance; float* dq_mu; float* dq_sqrt;
     int M, D, R; double kl_weight, variance;
 };
-// one workgroup: dZ, dls, dvariance and the KL terms
-__global__ __launch_bounds__(256) void k_bw_final(FinalArgsB f) {
-    __shared__ double dil[IWVI_MAX_D];
-    const int tid = threadIdx.x;
-    if (tid < f.D) dil[tid] = 0.0;
-    __syncthreads();
-    if (tid < f.D) {                                        // thread d walks its column: fixed order
-        const int d = tid;
-        double s = (double)f.dinvls_x[d];
-        for (int m = 0; m < f.M; ++m) {
+// workgroup d < D: dZ[:, d] and dls[d]; workgroup D: dvariance.  One wave each, lanes over m, fixed reduction tree.
+__global__ __launch_bounds__(64) void k_bw_final(FinalArgsB f) {
+    const int d = blockIdx.x, lane = threadIdx.x;
+    auto wsum = [&](double v) { for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64); return v; };
+    if (d < f.D) {
+        const double il = (double)f.invls[d];
+        double s = 0.0;
+        for (int m = lane; m < f.M; m += 64) {
             const double zt = f.Zt[m * f.D + d];
-            const double dzt = 2.0 * zt * (double)f.colsumC[m] - 2.0 * (double)f.invls[d] * (double)f.CtF[m * f.D + d] + f.dZt_uu[m * f.D + d];
-            if (f.dZ) f.dZ[m * f.D + d] = (float)(dzt * (double)f.invls[d]);
+            const double dzt = 2.0 * zt * (double)f.colsumC[m * (f.D + 1) + f.D] - 2.0 * il * (double)f.CtF[m * (f.D + 1) + d] + f.dZt_uu[m * f.D + d];
+            if (f.dZ) f.dZ[m * f.D + d] = (float)(dzt * il);
             s += dzt * (double)f.Z[m * f.D + d];
         }
-        if (f.dls) f.dls[d] = (float)(-s * (double)f.invls[d] * (double)f.invls[d]);
+        s = wsum(s) + (double)f.dinvls_x[d];
+        if (lane == 0 && f.dls) f.dls[d] = (float)(-s * il * il);
+    } else if (f.dvariance) {
+        double s = 0.0;
+        for (int m = lane; m < f.M; m += 64) s += f.dvar_m[m];
+        s = wsum(s) + (double)f.sums[0] + (double)f.sums[1] / f.variance;     // + sum_t sum_r dv_r  +  sum k dk / s2
+        if (lane == 0) f.dvariance[0] = (float)s;
     }
-    if (tid == 0 && f.dvariance) {
-        double s = (double)f.sums[0] + (double)f.sums[1] / f.variance;     // sum_t sum_r dv_r  +  sum k dk / s2
-        for (int m = 0; m < f.M; ++m) s += f.dvar_m[m];
-        f.dvariance[0] = (float)s;
-    }
-    // - kl_weight * d KL: KL = 1/2 (sum q_mu^2 - R M - sum log L_ii^2 + sum L^2)   (temp_workaround.py:186-188)
-    if (f.dq_mu) for (int i = tid; i < f.M * f.R; i += 256) f.dq_mu[i] = (float)((double)f.dq_mu[i] - f.kl_weight * (double)f.q_mu[i]);
-    if (f.dq_sqrt) for (long long i = tid; i < (long long)f.R * f.M * f.M; i += 256) {
+}
+// - kl_weight * d KL: KL = 1/2 (sum q_mu^2 - R M - sum log L_ii^2 + sum L^2)   (temp_workaround.py:186-188)
+__global__ void k_bw_kl(FinalArgsB f) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (f.dq_mu && i < f.M * f.R) f.dq_mu[i] = (float)((double)f.dq_mu[i] - f.kl_weight * (double)f.q_mu[i]);
+    if (f.dq_sqrt && i < (long long)f.R * f.M * f.M) {
         const int c = (int)(i % f.M), r_ = (int)((i / f.M) % f.M);
-        if (c > r_) { f.dq_sqrt[i] = 0.f; continue; }
+        if (c > r_) { f.dq_sqrt[i] = 0.f; return; }
         const double L = f.q_sqrt[i];
         f.dq_sqrt[i] = (float)((double)f.dq_sqrt[i] - f.kl_weight * (L - (c == r_ ? 1.0 / L : 0.0)));
     }
 }
 
 struct BwdWs {
-    float *DMU, *DV2, *SDV, *DA, *DK, *CZ, *Q, *RS, *part, *LinvF, *Zt, *invls, *colsumC, *CtF, *sums, *dinvls_x, *one;
+    float *DMU, *DV2, *SDV, *DA, *DK, *Qx, *part, *LinvF, *Zt, *invls, *CtF1, *Qsum;
     double *Lbar, *T1, *T2, *S, *dZt_uu, *dvar_m;
     size_t part_floats, bytes;
 };
@@ -320,18 +544,27 @@ static BwdWs bwd_layout(char* base, long long T, int M, int D, int R) {
     const int nsplit = (int)((T + 511) / 512) + 2;
     w.DMU = (float*)take(sizeof(float) * T * R); w.DV2 = (float*)take(sizeof(float) * T * R); w.SDV = (float*)take(sizeof(float) * T);
     w.DA = (float*)take(sizeof(float) * T * M); w.DK = (float*)take(sizeof(float) * T * M);
-    w.CZ = (float*)take(sizeof(float) * T * D); w.Q = (float*)take(sizeof(float) * T * D); w.RS = (float*)take(sizeof(float) * T * 2);
-    w.part_floats = (size_t)nsplit * M * M;
+    w.Qx = (float*)take(sizeof(float) * T * (D + 2));
+    w.part_floats = (size_t)nsplit * M * M * R;
+    {   // thin reductions: ceil(T / THIN_ROWS) chunks of [max(M, D + 2)][max(D + 1, R)]
+        const size_t thin = (size_t)((T + THIN_ROWS - 1) / THIN_ROWS) * (M > D + 2 ? M : D + 2) * (D + 1 > R ? D + 1 : R);
+        if (thin > w.part_floats) w.part_floats = thin;
+    }
     w.part = (float*)take(sizeof(float) * w.part_floats);
     w.LinvF = (float*)take(sizeof(float) * M * M); w.Zt = (float*)take(sizeof(float) * M * D); w.invls = (float*)take(sizeof(float) * IWVI_MAX_D);
-    w.colsumC = (float*)take(sizeof(float) * M); w.CtF = (float*)take(sizeof(float) * M * D); w.sums = (float*)take(sizeof(float) * 4);
-    w.dinvls_x = (float*)take(sizeof(float) * IWVI_MAX_D); w.one = (float*)take(sizeof(float) * 4);
+    w.CtF1 = (float*)take(sizeof(float) * M * (D + 1)); w.Qsum = (float*)take(sizeof(float) * (IWVI_MAX_D + 2));
     w.Lbar = (double*)take(sizeof(double) * M * M); w.T1 = (double*)take(sizeof(double) * M * M); w.T2 = (double*)take(sizeof(double) * M * M);
     w.S = (double*)take(sizeof(double) * M * M); w.dZt_uu = (double*)take(sizeof(double) * M * D); w.dvar_m = (double*)take(sizeof(double) * M);
     w.bytes = o;
     return w;
 }
-__global__ void k_set_one(float* p) { if (threadIdx.x < 4) p[threadIdx.x] = 1.f; }
+// both [dout, din + 1] (rows = output unit; last column = bias gradient) -> dW [din, dout], db [dout]
+__global__ void k_enc_unpack(const float* both, int din, int dout, float* dW, float* db) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= dout * (din + 1)) return;
+    const int o = idx / (din + 1), i = idx - o * (din + 1);
+    if (i < din) dW[i * dout + o] = both[idx]; else if (db) db[o] = both[idx];
+}
 
 
 // ------------------------------------------------------------------------------------------------------------
@@ -343,8 +576,9 @@ struct ElboBwdArgs {
     long long B; int K; float lik_var; double scale;
     float* w; float* d_mean; float* d_var; double* part;   // part[0..B) = lse - log K, part[B..2B) = d lik_var share
 };
-__global__ void k_elbo_bwd(ElboBwdArgs a) {
-    const long long b = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(256) void k_elbo_bwd(ElboBwdArgs a) {      // one wave per data point, lanes over its K samples
+    const int lane = threadIdx.x & 63;
+    const long long b = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (b >= a.B) return;
     const float s = a.lik_var, c0 = -0.5f * logf(6.283185307179586f * s);
     auto logw = [&](long long t) {
@@ -358,12 +592,13 @@ __global__ void k_elbo_bwd(ElboBwdArgs a) {
         return l;
     };
     float mx = -INFINITY;
-    for (int k = 0; k < a.K; ++k) mx = fmaxf(mx, logw(b * a.K + k));
+    for (int k = lane; k < a.K; k += 64) mx = fmaxf(mx, logw(b * a.K + k));
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
     double se = 0.0;
-    for (int k = 0; k < a.K; ++k) se += (double)__expf(logw(b * a.K + k) - mx);
-    a.part[b] = (double)mx + log(se) - log((double)a.K);
+    for (int k = lane; k < a.K; k += 64) se += (double)__expf(logw(b * a.K + k) - mx);
+    for (int o = 32; o > 0; o >>= 1) se += __shfl_xor(se, o, 64);
     double ds = 0.0;
-    for (int k = 0; k < a.K; ++k) {
+    for (int k = lane; k < a.K; k += 64) {
         const long long t = b * a.K + k;
         const float wt = (float)(a.scale * (double)__expf(logw(t) - mx) / se);
         if (a.w) a.w[t] = wt;
@@ -374,7 +609,8 @@ __global__ void k_elbo_bwd(ElboBwdArgs a) {
             ds += (double)wt * (-0.5 / (double)s + 0.5 * ((double)e * e + (double)v) / ((double)s * s));
         }
     }
-    a.part[a.B + b] = ds;
+    for (int o = 32; o > 0; o >>= 1) ds += __shfl_xor(ds, o, 64);
+    if (lane == 0) { a.part[b] = (double)mx + log(se) - log((double)a.K); a.part[a.B + b] = ds; }
 }
 // out[i] = sum of part[i*n .. (i+1)*n), one workgroup per i, fixed order
 __global__ __launch_bounds__(256) void k_dsum(const double* part, long long n, double* out) {
@@ -416,41 +652,63 @@ struct EncBwdArgs {
     const float* XY; long long rows; const float* W[IWVI_MAX_ENC]; const float* b[IWVI_MAX_ENC]; int dims[IWVI_MAX_ENC + 1]; int n;
     const float* d_out; float* acts[IWVI_MAX_ENC + 1]; float* delta[IWVI_MAX_ENC];
 };
-__global__ void k_enc_bwd(EncBwdArgs a) {
-    const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= a.rows) return;
-    for (int i = 0; i < a.dims[0]; ++i) a.acts[0][r * a.dims[0] + i] = a.XY[r * a.dims[0] + i];
+constexpr int ER = 32, ELD = 65;        // rows per workgroup, row stride of an activation tile in LDS
+// 32 rows per workgroup, activations and deltas in LDS, threads over (row, unit)
+__global__ __launch_bounds__(256) void k_enc_bwd(EncBwdArgs a) {
+    extern __shared__ float esm[];
+    const int tid = threadIdx.x;
+    const long long row0 = (long long)blockIdx.x * ER;
+    const int nrows = (int)((a.rows - row0) < ER ? (a.rows - row0) : ER);
+    float* acts = esm;                                   // [n + 1][ER][ELD]
+    float* cur = esm + (size_t)(a.n + 1) * ER * ELD;     // d / d layer output
+    float* dl = cur + ER * ELD;                          // d / d pre-activation
+    float* prev = dl + ER * ELD;
+    for (int idx = tid; idx < nrows * a.dims[0]; idx += 256) {
+        const int r = idx / a.dims[0], i = idx - r * a.dims[0];
+        const float v = a.XY[(row0 + r) * a.dims[0] + i];
+        acts[r * ELD + i] = v; a.acts[0][(row0 + r) * a.dims[0] + i] = v;
+    }
+    __syncthreads();
     for (int l = 0; l < a.n; ++l) {
         const int din = a.dims[l], dout = a.dims[l + 1];
-        const float* in = a.acts[l] + r * din;
-        for (int o = 0; o < dout; ++o) {
+        const float* in = acts + (size_t)l * ER * ELD; float* out = acts + (size_t)(l + 1) * ER * ELD;
+        for (int idx = tid; idx < nrows * dout; idx += 256) {
+            const int r = idx / dout, o = idx - r * dout;
             float acc = a.b[l] ? a.b[l][o] : 0.f;
-            for (int i = 0; i < din; ++i) acc = fmaf(in[i], a.W[l][i * dout + o], acc);
+            for (int i = 0; i < din; ++i) acc = fmaf(in[r * ELD + i], a.W[l][i * dout + o], acc);
             if (l < a.n - 1) acc = tanhf(acc);
-            if (din == dout) acc += in[o];
-            a.acts[l + 1][r * dout + o] = acc;
+            if (din == dout) acc += in[r * ELD + o];
+            out[r * ELD + o] = acc;
+            if (l < a.n - 1) a.acts[l + 1][(row0 + r) * dout + o] = acc;
         }
+        __syncthreads();
     }
-    float cur[64], prev[64];
-    const int dl = a.dims[a.n];
-    for (int o = 0; o < dl; ++o) cur[o] = a.d_out[r * dl + o];
+    const int dlast = a.dims[a.n];
+    for (int idx = tid; idx < nrows * dlast; idx += 256) { const int r = idx / dlast, o = idx - r * dlast; cur[r * ELD + o] = a.d_out[(row0 + r) * dlast + o]; }
+    __syncthreads();
     for (int l = a.n - 1; l >= 0; --l) {
         const int din = a.dims[l], dout = a.dims[l + 1];
         const bool skip = din == dout;
-        for (int i = 0; i < din; ++i) prev[i] = skip ? cur[i] : 0.f;
-        for (int o = 0; o < dout; ++o) {
-            float dlin = cur[o];
-            if (l < a.n - 1) {
-                const float act = a.acts[l + 1][r * dout + o] - (skip ? a.acts[l][r * din + o] : 0.f);
-                dlin *= 1.f - act * act;
-            }
-            a.delta[l][r * dout + o] = dlin;
-            for (int i = 0; i < din; ++i) prev[i] = fmaf(dlin, a.W[l][i * dout + o], prev[i]);
+        const float* in = acts + (size_t)l * ER * ELD; const float* out = acts + (size_t)(l + 1) * ER * ELD;
+        for (int idx = tid; idx < nrows * dout; idx += 256) {
+            const int r = idx / dout, o = idx - r * dout;
+            float v = cur[r * ELD + o];
+            if (l < a.n - 1) { const float act = out[r * ELD + o] - (skip ? in[r * ELD + o] : 0.f); v *= 1.f - act * act; }
+            dl[r * ELD + o] = v;
+            a.delta[l][(row0 + r) * dout + o] = v;
         }
-        for (int i = 0; i < din; ++i) cur[i] = prev[i];
+        __syncthreads();
+        for (int idx = tid; idx < nrows * din; idx += 256) {
+            const int r = idx / din, i = idx - r * din;
+            float acc = skip ? cur[r * ELD + i] : 0.f;
+            for (int o = 0; o < dout; ++o) acc = fmaf(dl[r * ELD + o], a.W[l][i * dout + o], acc);
+            prev[r * ELD + i] = acc;
+        }
+        __syncthreads();
+        for (int idx = tid; idx < nrows * din; idx += 256) { const int r = idx / din, i = idx - r * din; cur[r * ELD + i] = prev[r * ELD + i]; }
+        __syncthreads();
     }
 }
-
 
 // ------------------------------------------------------------------------------------------------------------
 // Optimiser steps of experiments/build_models.py:284-304: natural gradient on the final layer's (q_mu, q_sqrt)
@@ -475,15 +733,21 @@ static void dmm(hipStream_t st, const double* A, long long a_si, long long a_sk,
     DmmArgs a{A, a_si, a_sk, B, b_sk, b_sj, C, ldc, I, J, K, alpha, E, lde, beta, post};
     hipLaunchKernelGGL(k_dmm2, dim3((J + 127) / 128, I), dim3(J < 128 ? 64 : 128), 0, st, a);
 }
-// X = L^-1 for lower-triangular L [n, n] (row-major): thread j solves L x = e_j by forward substitution; zeros above
-__global__ void k_tri_inv(const double* L, double* X, int n) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= n) return;
-    for (int i = 0; i < j; ++i) X[(size_t)i * n + j] = 0.0;
+// X = L^-1 for lower-triangular L [n, n] (row-major): one wave per column j solves L x = e_j by forward substitution,
+// x in LDS, each row's dot product spread over the lanes; zeros above the diagonal
+__global__ __launch_bounds__(64) void k_tri_inv(const double* L, double* X, int n) {
+    __shared__ double x[IWVI_MAX_M];
+    const int j = blockIdx.x, lane = threadIdx.x;
+    for (int i = lane; i < j; i += 64) X[(size_t)i * n + j] = 0.0;
     for (int i = j; i < n; ++i) {
-        double s = (i == j) ? 1.0 : 0.0;
-        for (int k = j; k < i; ++k) s = fma(-L[(size_t)i * n + k], X[(size_t)k * n + j], s);
-        X[(size_t)i * n + j] = s / L[(size_t)i * n + i];
+        double s = 0.0;
+        for (int k = j + lane; k < i; k += 64) s = fma(L[(size_t)i * n + k], x[k], s);
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        if (lane == 0) {
+            const double v = ((i == j ? 1.0 : 0.0) - s) / L[(size_t)i * n + i];
+            x[i] = v; X[(size_t)i * n + j] = v;
+        }
+        __syncthreads();
     }
 }
 __global__ void k_f2d(const float* src, long long ld, double* dst, int rows, int cols, double scale, int tril) {
@@ -564,7 +828,6 @@ extern "C" int iwvi_gp_layer_backward(const iwvi_gp_bwd_desc* dp, int64_t T, voi
     const double* Linv64 = (const double*)((const char*)d.state + sl.off_Linv);
     BwdWs w = bwd_layout((char*)ws_, T, M, D, R);
     int rc;
-    hipLaunchKernelGGL(k_set_one, dim3(1), dim3(64), 0, st, w.one);
     {
         const int n = M * M > M * D ? M * M : M * D;
         hipLaunchKernelGGL(k_prep, dim3((n + 255) / 256), dim3(256), 0, st, d.Z, d.lengthscales, Linv64, Mp, w.Zt, w.invls, w.LinvF, M, D);
@@ -572,20 +835,17 @@ extern "C" int iwvi_gp_layer_backward(const iwvi_gp_bwd_desc* dp, int64_t T, voi
     HeadArgs h{d.A, d.U, d.noise, d.W, d.mf_A, d.d_sample, d.d_mean, d.d_var, w.DMU, w.DV2, w.SDV, d.dF, T, M, Mp, D, R, d.P, d.mf_type, d.variance};
     hipLaunchKernelGGL(k_bw_heads, dim3((unsigned)((T + 3) / 4)), dim3(256), 0, st, h);
     if ((rc = check_launch("k_bw_heads")) != IWVI_OK) return rc;
-    // DA = DMU q_mu^T
-    GemmArgs g{};
-    g.A = w.DMU; g.a_sm = R; g.a_sk = 1; g.B = d.q_mu; g.b_sk = 1; g.b_sn = R; g.C = w.DA; g.ldc = M; g.M = (int)T; g.N = M; g.K = R; g.alpha = 1.f; g.beta = 0.f;
-    if ((rc = gemm_rows(st, g)) != IWVI_OK) return rc;
-    // DA += (2 dv_r) o (U_r L_r^T)
-    for (int r = 0; r < R; ++r) {
+    // DA = DMU q_mu^T - 2 SDV o A
+    hipLaunchKernelGGL(k_bw_da_init, dim3((unsigned)((T * M + 255) / 256)), dim3(256), 0, st, w.DA, d.A, (const float*)w.SDV, (const float*)w.DMU, d.q_mu, (long long)T, M, Mp, R);
+    // DA += sum_r (2 dv_r) o (U_r L_r^T): one launch, R segments of M along the contraction
+    {
         GemmArgs q{};
-        q.A = d.U + (size_t)r * T * Mp; q.a_sm = Mp; q.a_sk = 1;
-        q.B = d.q_sqrt + (size_t)r * M * M; q.b_sk = 1; q.b_sn = M; q.b_keep_n_ge_k = 1;      // B(k = j, n = i) = L_r[i][j], i >= j
-        q.scale = w.DV2 + r; q.s_stride = R; q.scale_on_k = 0;
+        q.A = d.U; q.a_sm = Mp; q.a_sk = 1;
+        q.B = d.q_sqrt; q.b_sk = 1; q.b_sn = M; q.b_keep_n_ge_k = 1;                          // B(k = j, n = i) = L_r[i][j], i >= j
+        q.scale = w.DV2; q.s_stride = R; q.scale_on_k = 0;
         q.C = w.DA; q.ldc = M; q.M = (int)T; q.N = M; q.K = M; q.alpha = 1.f; q.beta = 1.f;
-        if ((rc = gemm_rows(st, q)) != IWVI_OK) return rc;
+        if ((rc = gemm_rows(st, q, R, (long long)T * Mp, (long long)M * M, 1)) != IWVI_OK) return rc;
     }
-    hipLaunchKernelGGL(k_bw_axpy, dim3((unsigned)((T * M + 255) / 256)), dim3(256), 0, st, w.DA, d.A, w.SDV, (long long)T, M, Mp);
     // DK = DA Lm^-1
     {
         GemmArgs q{};
@@ -600,56 +860,40 @@ extern "C" int iwvi_gp_layer_backward(const iwvi_gp_bwd_desc* dp, int64_t T, voi
         if ((rc = gemm(st, q, w.part, w.part_floats, nullptr, w.Lbar, M, -1.0, 0.0, 1)) != IWVI_OK) return rc;
     }
     // dq_mu = A^T DMU
-    if (d.dq_mu) {
+    if (d.dq_mu && (rc = thin(st, d.A, Mp, M, w.DMU, R, R, 0, T, w.part, w.part_floats, d.dq_mu)) != IWVI_OK) return rc;
+    // dL_r = tril(A^T diag(2 dv_r) U_r), all r in one batched launch
+    if (d.dq_sqrt) {
         GemmArgs q{};
-        q.A = d.A; q.a_sm = 1; q.a_sk = Mp; q.B = w.DMU; q.b_sk = R; q.b_sn = 1; q.M = M; q.N = R; q.K = (int)T;
-        if ((rc = gemm(st, q, w.part, w.part_floats, d.dq_mu, nullptr, R, 1.0, 0.0, 0)) != IWVI_OK) return rc;
+        q.A = d.A; q.a_sm = 1; q.a_sk = Mp; q.B = d.U; q.b_sk = Mp; q.b_sn = 1;
+        q.scale = w.DV2; q.s_stride = R; q.scale_on_k = 1; q.M = M; q.N = M; q.K = (int)T;
+        if ((rc = gemm(st, q, w.part, w.part_floats, d.dq_sqrt, nullptr, M, 1.0, 0.0, 1, R, (long long)T * Mp, 1, (long long)M * M)) != IWVI_OK) return rc;
     }
-    // dL_r = tril(A^T diag(2 dv_r) U_r)
-    if (d.dq_sqrt) for (int r = 0; r < R; ++r) {
-        GemmArgs q{};
-        q.A = d.A; q.a_sm = 1; q.a_sk = Mp; q.B = d.U + (size_t)r * T * Mp; q.b_sk = Mp; q.b_sn = 1;
-        q.scale = w.DV2 + r; q.s_stride = R; q.scale_on_k = 1; q.M = M; q.N = M; q.K = (int)T;
-        if ((rc = gemm(st, q, w.part, w.part_floats, d.dq_sqrt + (size_t)r * M * M, nullptr, M, 1.0, 0.0, 1)) != IWVI_OK) return rc;
+    // C = -1/2 K o DK (over DA), dx~, dF, per-sample rows of the column sums
+    KernArgs ka{d.F, w.Zt, w.invls, w.DK, w.DA, w.SDV, d.dF, w.Qx, T, M, D, d.variance};
+    {
+        const dim3 grid((unsigned)((T + 3) / 4)), block(256);
+        if (D <= 4) hipLaunchKernelGGL(k_bw_kernel<4>, grid, block, 0, st, ka);
+        else if (D <= 8) hipLaunchKernelGGL(k_bw_kernel<8>, grid, block, 0, st, ka);
+        else if (D <= 16) hipLaunchKernelGGL(k_bw_kernel<16>, grid, block, 0, st, ka);
+        else hipLaunchKernelGGL(k_bw_kernel<32>, grid, block, 0, st, ka);
     }
-    // C = -1/2 K o DK (over DA), per-sample sums
-    KernArgs ka{d.F, w.Zt, w.invls, w.DK, w.DA, w.RS, T, M, D, d.variance};
-    hipLaunchKernelGGL(k_bw_kernel, dim3((unsigned)((T + 3) / 4)), dim3(256), 0, st, ka);
     if ((rc = check_launch("k_bw_kernel")) != IWVI_OK) return rc;
-    // CZ = C Z~
-    {
-        GemmArgs q{};
-        q.A = w.DA; q.a_sm = M; q.a_sk = 1; q.B = w.Zt; q.b_sk = D; q.b_sn = 1;
-        q.C = w.CZ; q.ldc = D; q.M = (int)T; q.N = D; q.K = M; q.alpha = 1.f; q.beta = 0.f;
-        if ((rc = gemm_rows(st, q)) != IWVI_OK) return rc;
-    }
-    hipLaunchKernelGGL(k_bw_dx, dim3((unsigned)((T * D + 255) / 256)), dim3(256), 0, st, d.F, w.invls, w.RS, w.CZ, d.dF, w.Q, (long long)T, D);
-    // sums over samples: C^T F, colsum(C), colsum(Q), (sum SDV, sum k dk)
-    {
-        GemmArgs q{};
-        q.A = w.DA; q.a_sm = 1; q.a_sk = M; q.B = d.F; q.b_sk = D; q.b_sn = 1; q.M = M; q.N = D; q.K = (int)T;
-        if ((rc = gemm(st, q, w.part, w.part_floats, w.CtF, nullptr, D, 1.0, 0.0, 0)) != IWVI_OK) return rc;
-        q.B = w.one; q.b_sk = 0; q.b_sn = 0; q.N = 1;
-        if ((rc = gemm(st, q, w.part, w.part_floats, w.colsumC, nullptr, 1, 1.0, 0.0, 0)) != IWVI_OK) return rc;
-        q.A = w.Q; q.a_sm = 1; q.a_sk = D; q.M = D;
-        if ((rc = gemm(st, q, w.part, w.part_floats, w.dinvls_x, nullptr, 1, 1.0, 0.0, 0)) != IWVI_OK) return rc;
-        q.A = w.SDV; q.a_sm = 0; q.a_sk = 1; q.M = 1;
-        if ((rc = gemm(st, q, w.part, w.part_floats, w.sums, nullptr, 1, 1.0, 0.0, 0)) != IWVI_OK) return rc;
-        q.A = w.RS + 1; q.a_sm = 0; q.a_sk = 2; q.M = 1;
-        if ((rc = gemm(st, q, w.part, w.part_floats, w.sums + 1, nullptr, 1, 1.0, 0.0, 0)) != IWVI_OK) return rc;
-    }
+    // sums over samples: C^T [F | 1]  and the column sums of Qx = (dx~ o x | sum_r dv_r | sum_m k dk)
+    if ((rc = thin(st, w.DA, M, M, d.F, D, D, 1, T, w.part, w.part_floats, w.CtF1)) != IWVI_OK) return rc;
+    if ((rc = thin(st, w.Qx, D + 2, D + 2, nullptr, 0, 0, 1, T, w.part, w.part_floats, w.Qsum)) != IWVI_OK) return rc;
     // adjoint of Lm = chol(Kuu): S = Lm^-T Phi(Lm^T Lbar) Lm^-1
     {
-        const dim3 grid((M + 127) / 128, M), block(128);
+        const dim3 grid((M + 15) / 16, (M + 15) / 16), block(256);
         hipLaunchKernelGGL(k_dmm, grid, block, 0, st, Lm64, 1LL, (long long)Mp, (const double*)w.Lbar, (long long)M, 1LL, w.T1, M, M, 1);
         hipLaunchKernelGGL(k_dmm, grid, block, 0, st, Linv64, 1LL, (long long)Mp, (const double*)w.T1, (long long)M, 1LL, w.T2, M, M, 0);
         hipLaunchKernelGGL(k_dmm, grid, block, 0, st, (const double*)w.T2, (long long)M, 1LL, Linv64, (long long)Mp, 1LL, w.S, M, M, 0);
         hipLaunchKernelGGL(k_kuu_bwd, dim3(M), dim3(256), 0, st, w.Zt, (const double*)w.S, M, D, (double)d.variance, w.dZt_uu, w.dvar_m);
         if ((rc = check_launch("cholesky adjoint")) != IWVI_OK) return rc;
     }
-    FinalArgsB f{d.Z, d.lengthscales, d.q_mu, d.q_sqrt, w.Zt, w.invls, w.colsumC, w.CtF, w.sums, w.dinvls_x, w.dZt_uu, w.dvar_m,
+    FinalArgsB f{d.Z, d.lengthscales, d.q_mu, d.q_sqrt, w.Zt, w.invls, w.CtF1, w.CtF1, w.Qsum + D, w.Qsum, w.dZt_uu, w.dvar_m,
                  d.dZ, d.dls, d.dvariance, d.dq_mu, d.dq_sqrt, M, D, R, d.kl_weight, (double)d.variance};
-    hipLaunchKernelGGL(k_bw_final, dim3(1), dim3(256), 0, st, f);
+    hipLaunchKernelGGL(k_bw_final, dim3(D + 1), dim3(64), 0, st, f);
+    hipLaunchKernelGGL(k_bw_kl, dim3((unsigned)(((long long)R * M * M + 255) / 256)), dim3(256), 0, st, f);
     return check_launch("k_bw_final");
 }
 
@@ -669,7 +913,7 @@ extern "C" int iwvi_iw_elbo_backward(const float* fmean, const float* fvar, cons
         a.kl[i] = kl_local[i]; a.kl_dims[i] = kl_dims[i];
     }
     a.B = B; a.K = K; a.lik_var = lik_variance; a.scale = scale; a.w = out_w; a.d_mean = d_mean; a.d_var = d_var; a.part = ws;
-    hipLaunchKernelGGL(k_elbo_bwd, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, st, a);
+    hipLaunchKernelGGL(k_elbo_bwd, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, st, a);
     hipLaunchKernelGGL(k_dsum, dim3(2), dim3(256), 0, st, (const double*)ws, (long long)B, out_sums);
     return check_launch("k_elbo_bwd");
 }
@@ -690,11 +934,12 @@ static size_t enc_bwd_layout(int64_t rows, const int32_t* dims, int n, size_t* a
     int wmax = 1;
     for (int l = 0; l <= n; ++l) { if (acts_off) acts_off[l] = o; o = align256(o + sizeof(float) * rows * dims[l]); if (dims[l] > wmax) wmax = dims[l]; }
     for (int l = 0; l < n; ++l) { if (delta_off) delta_off[l] = o; o = align256(o + sizeof(float) * rows * dims[l + 1]); }
-    const size_t pf = (size_t)((rows + 511) / 512 + 2) * wmax * wmax;
+    const size_t pf = (size_t)((rows + THIN_ROWS - 1) / THIN_ROWS) * wmax * (wmax + 1);
     if (part_off) *part_off = o;
     if (part_floats) *part_floats = pf;
     o = align256(o + sizeof(float) * pf);
-    o = align256(o + 16);                               // the constant 1
+    o = align256(o + sizeof(float) * 64 * 65);          // [dout][din + 1] staging of one layer's (dW ; db)
+    o += 256;
     return o;
 }
 extern "C" size_t iwvi_encoder_backward_ws_bytes(int64_t rows, const int32_t* dims, int n_enc) {
@@ -710,7 +955,6 @@ extern "C" int iwvi_encoder_backward(const float* XY, int64_t rows, const float*
     size_t ao[IWVI_MAX_ENC + 1], d_off[IWVI_MAX_ENC], po, pf;
     const size_t total = enc_bwd_layout(rows, dims, n_enc, ao, d_off, &po, &pf);
     char* base = (char*)ws_;
-    float* one = (float*)(base + total - 256);
     EncBwdArgs a{};
     a.XY = XY; a.rows = rows; a.n = n_enc; a.d_out = d_out;
     for (int l = 0; l <= n_enc; ++l) { a.dims[l] = dims[l]; a.acts[l] = (float*)(base + ao[l]); }
@@ -718,20 +962,26 @@ extern "C" int iwvi_encoder_backward(const float* XY, int64_t rows, const float*
         if (!enc_W[l] || !dW[l]) { set_error("iwvi_encoder_backward: null weight %d", l); return IWVI_ERR_ARG; }
         a.W[l] = enc_W[l]; a.b[l] = enc_b ? enc_b[l] : nullptr; a.delta[l] = (float*)(base + d_off[l]);
     }
-    hipLaunchKernelGGL(k_set_one, dim3(1), dim3(64), 0, st, one);
-    hipLaunchKernelGGL(k_enc_bwd, dim3((unsigned)((rows + 63) / 64)), dim3(64), 0, st, a);
+    const size_t elds = sizeof(float) * (size_t)(n_enc + 4) * ER * ELD;
     int rc;
+    {   // once per process: allow the largest encoder (hipFuncSetAttribute is not a stream operation)
+        static bool done = false;
+        if (!done) {
+            const size_t most = sizeof(float) * (size_t)(IWVI_MAX_ENC + 4) * ER * ELD;
+            hipError_t e = hipFuncSetAttribute((const void*)k_enc_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)most);
+            if (e != hipSuccess) { set_error("hipFuncSetAttribute(%zu B LDS): %s", most, hipGetErrorString(e)); return IWVI_ERR_LAUNCH; }
+            done = true;
+        }
+    }
+    hipLaunchKernelGGL(k_enc_bwd, dim3((unsigned)((rows + ER - 1) / ER)), dim3(256), elds, st, a);
     if ((rc = check_launch("k_enc_bwd")) != IWVI_OK) return rc;
     float* part = (float*)(base + po);
+    float* both = (float*)(base + total - 256 - align256(sizeof(float) * 64 * 65));
     for (int l = 0; l < n_enc; ++l) {
         const int din = dims[l], dout = dims[l + 1];
-        GemmArgs q{};                                   // dW_l = acts_l^T delta_l
-        q.A = a.acts[l]; q.a_sm = 1; q.a_sk = din; q.B = a.delta[l]; q.b_sk = dout; q.b_sn = 1; q.M = din; q.N = dout; q.K = (int)rows;
-        if ((rc = gemm(st, q, part, pf, dW[l], nullptr, dout, 1.0, 0.0, 0)) != IWVI_OK) return rc;
-        if (db && db[l]) {
-            q.A = a.delta[l]; q.a_sm = 1; q.a_sk = dout; q.B = one; q.b_sk = 0; q.b_sn = 0; q.M = dout; q.N = 1;
-            if ((rc = gemm(st, q, part, pf, db[l], nullptr, 1, 1.0, 0.0, 0)) != IWVI_OK) return rc;
-        }
+        // [dW_l ; db_l] as delta_l^T [acts_l | 1] -> both [dout, din + 1]
+        if ((rc = thin(st, a.delta[l], dout, dout, a.acts[l], din, din, 1, rows, part, pf, both)) != IWVI_OK) return rc;
+        hipLaunchKernelGGL(k_enc_unpack, dim3((dout * (din + 1) + 255) / 256), dim3(256), 0, st, (const float*)both, din, dout, dW[l], db ? db[l] : nullptr);
     }
     return IWVI_OK;
 }
@@ -762,7 +1012,7 @@ extern "C" int iwvi_natgrad_step(float* q_mu, float* q_sqrt, const float* dq_mu,
         hipLaunchKernelGGL(k_f2d, dim3(nb), dim3(256), 0, st, dq_sqrt + (size_t)r * M * M, (long long)M, Lbar, M, M, -1.0, 1);
         hipLaunchKernelGGL(k_f2d, dim3((M + 255) / 256), dim3(256), 0, st, (const float*)(q_mu + r), (long long)R, m, M, 1, 1.0, 0);
         hipLaunchKernelGGL(k_f2d, dim3((M + 255) / 256), dim3(256), 0, st, dq_mu + r, (long long)R, mbar, M, 1, -1.0, 0);
-        hipLaunchKernelGGL(k_tri_inv, dim3((M + 63) / 64), dim3(64), 0, st, (const double*)L, Linv, M);
+        hipLaunchKernelGGL(k_tri_inv, dim3(M), dim3(64), 0, st, (const double*)L, Linv, M);
         // dLoss/dS (symmetric) from dLoss/dL: Sbar = sym(L^-T Phi(L^T Lbar) L^-1)
         dmm(st, L, 1, M, Lbar, M, 1, T1, M, M, M, M, 1.0, nullptr, 0, 0.0, 1);
         dmm(st, Linv, 1, M, T1, M, 1, T2, M, M, M, M);
@@ -778,7 +1028,7 @@ extern "C" int iwvi_natgrad_step(float* q_mu, float* q_sqrt, const float* dq_mu,
         hipLaunchKernelGGL(k_axpby, dim3(nb), dim3(256), 0, st, (const double*)Sinv, 1.0, (const double*)Sbar, 2.0 * gamma, Pn, M * M);
         // natural_to_meanvarsqrt
         if ((rc = iwvi_chol_factor(Pn, T1, M, cws, stream_)) != IWVI_OK) return rc;
-        hipLaunchKernelGGL(k_tri_inv, dim3((M + 63) / 64), dim3(64), 0, st, (const double*)T1, T2, M);
+        hipLaunchKernelGGL(k_tri_inv, dim3(M), dim3(64), 0, st, (const double*)T1, T2, M);
         dmm(st, T2, 1, M, T2, M, 1, Sbar, M, M, M, M);                                   // S' = X^T X
         dmm(st, Sbar, M, 1, mbar, 1, 1, m, 1, M, 1, M);                                  // mu' = S' theta_1'
         if ((rc = iwvi_chol_factor(Sbar, L, M, cws, stream_)) != IWVI_OK) return rc;

@@ -116,3 +116,39 @@ def test_iw_elbo_gradients_match_oracle(gpu_device, L, M, K, B, lv):
     assert sorted(grads) == sorted(ref)
     for k, v in grads.items():
         _close(k, v.reshape(ref[k].shape), ref[k], rtol=5e-3)
+
+
+@pytest.mark.parametrize("dims,rows", [([9, 20, 20, 2], 100), ([5, 48, 48, 40, 4], 333), ([3, 64, 2], 64)])
+def test_encoder_backward_matches_autodiff(gpu_device, dims, rows):
+    """iwvi_encoder_backward (layers.py:137-152: tanh MLP with skip connections where widths match) vs float64 autograd."""
+    import ctypes
+    from dgps_with_iwvi_amd import _abi
+    rng = np.random.default_rng(len(dims) * rows)
+    XY = rng.standard_normal((rows, dims[0]))
+    Ws = [rng.standard_normal((a, b)) * (2.0 / (a + b)) ** 0.5 for a, b in zip(dims[:-1], dims[1:])]
+    bs = [rng.standard_normal(b) * 0.1 for b in dims[1:]]
+    dout = rng.standard_normal((rows, dims[-1]))
+    tW = [torch.tensor(w, requires_grad=True) for w in Ws]
+    tb = [torch.tensor(b, requires_grad=True) for b in bs]
+    H = torch.tensor(XY)
+    for i, (W, b) in enumerate(zip(tW, tb)):
+        H0 = H
+        H = H @ W + b
+        if i < len(tW) - 1:
+            H = torch.tanh(H)
+        if W.shape[0] == W.shape[1]:
+            H = H + H0
+    (H * torch.tensor(dout)).sum().backward()
+    dev = gpu_device
+    f32 = lambda a: torch.as_tensor(np.asarray(a, dtype=np.float32), device=dev)
+    dW_in, db_in = [f32(w) for w in Ws], [f32(b) for b in bs]
+    dW, db = [torch.empty_like(w) for w in dW_in], [torch.empty_like(b) for b in db_in]
+    cd = (ctypes.c_int32 * len(dims))(*dims)
+    n = len(Ws)
+    ws = torch.empty(_abi.lib().iwvi_encoder_backward_ws_bytes(rows, cd, n), dtype=torch.uint8, device=dev)
+    xy, do = f32(XY), f32(dout)
+    _abi.check(_abi.lib().iwvi_encoder_backward(_abi.ptr(xy), rows, _abi.ptr_array(dW_in), _abi.ptr_array(db_in), cd, n, _abi.ptr(do),
+                                               _abi.ptr_array(dW), _abi.ptr_array(db), ws.data_ptr(), _abi.stream_ptr()))
+    for i in range(n):
+        _close("dW%d" % i, dW[i].cpu(), tW[i].grad.numpy(), rtol=1e-4)
+        _close("db%d" % i, db[i].cpu(), tb[i].grad.numpy(), rtol=1e-4)
