@@ -159,3 +159,26 @@ class OverlappedExchange:
         """Wait for the exchanges; returns the last slot's per-evaluation ELBOs [steps]."""
         torch.cuda.current_stream().wait_stream(self.comm)
         return self.result / self.world if self.mode == "n" else self.result
+
+
+def allreduce_gradients(grads, weight=None, group=None):
+    """Data-parallel (N-shard) training: every rank holds d ELBO_r / d theta of its own points, with
+    ELBO_r = (num_data / B_r) * sum_{n in rank} (...) - KL (models.py:144-150 on the local minibatch).  The job's
+    gradient is the B_r / B weighted mean (the KL terms then count once): ONE all-reduce of one flat bucket
+    (parameters are <= R*M^2 floats per layer, a few MiB in all -- a single ring pass over xGMI), then views back.
+    ``weight`` = B_r / B (default 1 / world: equal local batches).  Returns the same dict, reduced in place."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return grads
+    world = dist.get_world_size(group)
+    w = 1.0 / world if weight is None else float(weight)
+    names = sorted(grads)
+    flat = [grads[k].reshape(-1) for k in names]
+    dtype = torch.float64 if any(t.dtype == torch.float64 for t in flat) else flat[0].dtype
+    bucket = torch.cat([t.to(dtype) for t in flat]) * w
+    dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=group)
+    o = 0
+    for k, t in zip(names, flat):
+        n = t.numel()
+        grads[k] = bucket[o:o + n].to(grads[k].dtype).reshape(grads[k].shape)
+        o += n
+    return grads

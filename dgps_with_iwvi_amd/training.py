@@ -23,11 +23,15 @@ def staircase_decay(base, step, rate, every=1000):
 
 class Trainer:
     def __init__(self, model, lr=5e-3, gamma=1e-2, lr_decay=0.98, gamma_decay=0.98, fix_linear=True,
-                 beta1=0.9, beta2=0.999, epsilon=1e-8):
+                 beta1=0.9, beta2=0.999, epsilon=1e-8, group=None, shard_weight=None):
+        """``group`` / ``shard_weight``: data-parallel training over the ranks of a torch.distributed group (each rank's
+        model holds its own minibatch rows, N-shard): gradients are merged by ``sharding.allreduce_gradients`` with
+        weight B_rank / B_job (default 1 / world) before either update, so every rank applies the same step."""
         if not fix_linear:
             raise NotImplementedError("gradients of the mixing matrix W and the linear mean function are not built yet "
                                       "(the reference's default fix_linear=True keeps them fixed)")
         self.model = model
+        self.group, self.shard_weight = group, shard_weight
         self.lr, self.gamma, self.lr_decay, self.gamma_decay = lr, gamma, lr_decay, gamma_decay
         self.betas, self.epsilon = (beta1, beta2), epsilon
         self.global_step = 0
@@ -84,9 +88,16 @@ class Trainer:
                                             max(self.adam_t, 1), 1, 1 if init else 0, _abi.stream_ptr()))
         return keep
 
+    def _gradients(self, zs):
+        from .sharding import allreduce_gradients
+        elbo, g = iw_elbo_and_gradients(self.model, zs)
+        g["__elbo__"] = elbo.reshape(1)                          # rides in the same bucket: the job's bound
+        g = allreduce_gradients(g, weight=self.shard_weight, group=self.group)
+        return g.pop("__elbo__")[0], g
+
     def natgrad_op(self, zs=None):
         """``op_ng``: one ELBO + gradient evaluation, natural-gradient step on the final layer's q(u)."""
-        elbo, g = iw_elbo_and_gradients(self.model, zs)
+        elbo, g = self._gradients(zs)
         i = len(self.model.layers) - 1
         f = self.final
         gamma = staircase_decay(self.gamma, self.global_step, self.gamma_decay)
@@ -98,7 +109,7 @@ class Trainer:
 
     def adam_op(self, zs=None):
         """``op_adam``: one ELBO + gradient evaluation, Adam step on everything but the final layer's q(u)."""
-        elbo, g = iw_elbo_and_gradients(self.model, zs)
+        elbo, g = self._gradients(zs)
         self.adam_t += 1
         self._adam_call(g, lr=staircase_decay(self.lr, self.global_step, self.lr_decay))
         if self._scalars:                                      # host copies of the scalar parameters (one small D2H)

@@ -52,6 +52,43 @@ def _worker(rank, world, port, mode, q):
         dist.destroy_process_group()
 
 
+def _grad_worker(rank, world, port, q):
+    """N-shard training: each rank's gradient (gradient oracle on its points) through sharding.allreduce_gradients."""
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle.grad_oracle import iw_elbo_and_gradients
+        spec = synthetic.make_spec(L=2, M=12, B=10, K=4, Dx=3, R=2, with_lv=True, seed=31, n_data=2048)
+        zs = synthetic.make_noise(spec, seed=32)
+        _, ref = iw_elbo_and_gradients(spec, zs)
+        lo, hi = sharding.split_points(spec["B"], world)[rank] if world == 2 else (0, spec["B"])
+        lo, hi = (0, 7) if rank == 0 else (7, 10)                   # uneven on purpose: weights B_r / B
+        sub = dict(spec, X=spec["X"][lo:hi], Y=spec["Y"][lo:hi], B=hi - lo)
+        _, g = iw_elbo_and_gradients(sub, [z[lo:hi] for z in zs])
+        g = {k: torch.tensor(np.asarray(v)) for k, v in g.items()}
+        g = sharding.allreduce_gradients(g, weight=(hi - lo) / spec["B"])
+        err = max(float(np.abs(g[k].numpy() - ref[k]).max() / max(np.abs(ref[k]).max(), 1e-12)) for k in ref)
+        q.put((rank, err, float(g["lik_var"])))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_data_parallel_gradient_equals_unsharded():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_grad_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, err, _ in res:
+        assert err <= 1e-10, (rank, err)
+    assert res[0][2] == res[1][2]
+
+
 @pytest.mark.parametrize("mode", ["k", "n"])
 def test_sharded_elbo_equals_unsharded(mode):
     world, port = 2, _free_port()
