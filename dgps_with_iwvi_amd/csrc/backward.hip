@@ -39,6 +39,8 @@ struct GemmArgs {
     // B + b*b_batch, scale + b*s_batch and writes part + b*nsplit*M*N.
     int kseg; long long a_seg, b_seg, s_seg;
     int nbatch; long long b_batch, s_batch;
+    int tri_out;                        // split-K products whose strict upper triangle is discarded: those tiles are skipped
+    int b_lower_kn;                     // B(k, n) = 0 for k < n (a lower-triangular matrix indexed [k][n]): k starts at the tile's n0
 };
 constexpr int GT = 64, GK = 16, GLD = GT + 4;
 
@@ -96,59 +98,82 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs g) {
 }
 
 
-// Fast path: full 64x64 tiles, 16-deep stages, float4 global loads (one per operand per thread per stage), LDS double
-// buffer (one barrier per stage, next stage's loads in flight under the MFMAs), 2x2 MFMA tiles per wave.
+// Fast path: full 64x64 tiles, 32-deep stages, float4 global loads (two per operand per thread per stage: a row of a
+// k-contiguous operand contributes 128 contiguous bytes), LDS double buffer (one barrier per stage, the next stage's
+// loads in flight under the MFMAs), 2x2 MFMA tiles per wave.
 // A_KC: A's k index is contiguous (else its m index); B_NC: B's n index is contiguous (else its k index).
+constexpr int GKF = 32;
 template <bool A_KC, bool B_NC>
 __global__ __launch_bounds__(256) void k_gemm_fast(GemmArgs g) {
-    __shared__ __attribute__((aligned(16))) float As[2][GK][GLD];
-    __shared__ __attribute__((aligned(16))) float Bs[2][GK][GLD];
+    __shared__ __attribute__((aligned(16))) float As[2][GKF][GLD];
+    __shared__ __attribute__((aligned(16))) float Bs[2][GKF][GLD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
     const int m0 = blockIdx.y * GT, n0 = blockIdx.x * GT;
+    if (g.tri_out && n0 > m0) return;                                     // strictly above the diagonal: discarded by the reduction
     const int batch = (int)blockIdx.z / g.nsplit, split = (int)blockIdx.z - batch * g.nsplit;
     const int kb = split * g.kchunk;
     const int ke = (kb + g.kchunk < g.K) ? kb + g.kchunk : g.K;
     const float* Bb = g.B + batch * g.b_batch;
     const float* Sb = g.scale ? g.scale + batch * g.s_batch : nullptr;
-    // this thread's slot in a stage: A_KC: (m = tid/4, k = 4*(tid%4)..+3); else (k = tid/16, m = 4*(tid%16)..+3)
-    const int am = A_KC ? tid >> 2 : (tid & 15) * 4, ak = A_KC ? (tid & 3) * 4 : tid >> 4;
-    const int bn = B_NC ? (tid & 15) * 4 : tid >> 2, bk = B_NC ? tid >> 4 : (tid & 3) * 4;
-    f32x4 ra, rb;
+    // this thread's two slots in a stage (j = 0, 1).  k-contiguous operand: (row = tid/8 + 32 j, k = 4*(tid%8)..+3);
+    // row-contiguous operand: (k = tid/16 + 16 j, row = 4*(tid%16)..+3)
+    const int am = A_KC ? tid >> 3 : (tid & 15) * 4, ak = A_KC ? (tid & 7) * 4 : tid >> 4;
+    const int bn = B_NC ? (tid & 15) * 4 : tid >> 3, bk = B_NC ? tid >> 4 : (tid & 7) * 4;
+    constexpr int AMJ = A_KC ? 32 : 0, AKJ = A_KC ? 0 : 16, BNJ = B_NC ? 0 : 32, BKJ = B_NC ? 16 : 0;
+    f32x4 ra[2], rb[2];
     auto fetch = [&](int k0) {
-        const int seg = k0 / g.kseg, kl = k0 - seg * g.kseg;             // a stage never straddles a segment (kseg % 16 == 0)
+        const int seg = k0 / g.kseg, kl = k0 - seg * g.kseg;             // a stage never straddles a segment (kseg % 32 == 0)
         const float* A = g.A + seg * g.a_seg; const float* B = Bb + seg * g.b_seg;
-        ra = *reinterpret_cast<const f32x4*>(A + (long long)(m0 + am) * g.a_sm + (long long)(kl + ak) * g.a_sk);
-        rb = *reinterpret_cast<const f32x4*>(B + (long long)(kl + bk) * g.b_sk + (long long)(n0 + bn) * g.b_sn);
-        if (Sb) {
-            const float* S = Sb + seg * g.s_seg;
-            if (g.scale_on_k) {
-                if (A_KC) for (int e = 0; e < 4; ++e) ra[e] *= S[(long long)(kl + ak + e) * g.s_stride];
-                else ra *= S[(long long)(kl + ak) * g.s_stride];
-            } else {
-                if (A_KC) ra *= S[(long long)(m0 + am) * g.s_stride];
-                else for (int e = 0; e < 4; ++e) ra[e] *= S[(long long)(m0 + am + e) * g.s_stride];
+        const float* S = Sb ? Sb + seg * g.s_seg : nullptr;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int m = m0 + am + AMJ * j, ka = kl + ak + AKJ * j, n = n0 + bn + BNJ * j, kq = kl + bk + BKJ * j;
+            ra[j] = *reinterpret_cast<const f32x4*>(A + (long long)m * g.a_sm + (long long)ka * g.a_sk);
+            rb[j] = *reinterpret_cast<const f32x4*>(B + (long long)kq * g.b_sk + (long long)n * g.b_sn);
+            if (S) {
+                if (g.scale_on_k) {
+                    if (A_KC) for (int e = 0; e < 4; ++e) ra[j][e] *= S[(long long)(ka + e) * g.s_stride];
+                    else ra[j] *= S[(long long)ka * g.s_stride];
+                } else {
+                    if (A_KC) ra[j] *= S[(long long)m * g.s_stride];
+                    else for (int e = 0; e < 4; ++e) ra[j][e] *= S[(long long)(m + e) * g.s_stride];
+                }
             }
+            if (g.b_keep_n_ge_k)
+                for (int e = 0; e < 4; ++e) { const int nn = n + (B_NC ? e : 0), kk = kq + (B_NC ? 0 : e); if (nn < kk) rb[j][e] = 0.f; }
         }
-        if (g.b_keep_n_ge_k)
-            for (int e = 0; e < 4; ++e) { const int n = n0 + bn + (B_NC ? e : 0), k = kl + bk + (B_NC ? 0 : e); if (n < k) rb[e] = 0.f; }
     };
     auto stash = [&](int buf) {
-        if (A_KC) for (int e = 0; e < 4; ++e) As[buf][ak + e][am] = ra[e];
-        else *reinterpret_cast<f32x4*>(&As[buf][ak][am]) = ra;
-        if (B_NC) *reinterpret_cast<f32x4*>(&Bs[buf][bk][bn]) = rb;
-        else for (int e = 0; e < 4; ++e) Bs[buf][bk + e][bn] = rb[e];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int m = am + AMJ * j, ka = ak + AKJ * j, n = bn + BNJ * j, kq = bk + BKJ * j;
+            if (A_KC) for (int e = 0; e < 4; ++e) As[buf][ka + e][m] = ra[j][e];
+            else *reinterpret_cast<f32x4*>(&As[buf][ka][m]) = ra[j];
+            if (B_NC) *reinterpret_cast<f32x4*>(&Bs[buf][kq][n]) = rb[j];
+            else for (int e = 0; e < 4; ++e) Bs[buf][kq + e][n] = rb[j][e];
+        }
     };
     f32x4 acc[2][2];
     for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    fetch(kb); stash(0);
+    // stage list.  Split-K: [kb, ke) of the one segment.  Row products: per segment only the k range where the
+    // triangular B operand is non-zero for this tile's columns (k < n0 + 64 for L^T-type, k >= n0 for L-type).
+    int lo = kb, ns = (ke - kb) / GKF;
+    if (g.nsplit == 1) {
+        lo = g.b_lower_kn ? n0 : 0;
+        const int hi = g.b_keep_n_ge_k ? (n0 + GT < g.kseg ? n0 + GT : g.kseg) : g.kseg;
+        ns = hi > lo ? (hi - lo) / GKF : 0;
+    }
+    const int nstage = (g.nsplit == 1) ? ns * (g.K / g.kseg) : ns;
+    auto stage_k = [&](int i) { if (g.nsplit > 1) return lo + GKF * i; const int seg = i / ns; return seg * g.kseg + lo + GKF * (i - seg * ns); };
+    if (nstage > 0) { fetch(stage_k(0)); stash(0); }
     __syncthreads();
     int buf = 0;
-    for (int k0 = kb; k0 < ke; k0 += GK, buf ^= 1) {
-        const bool more = k0 + GK < ke;
-        if (more) fetch(k0 + GK);
+    for (int i = 0; i < nstage; ++i, buf ^= 1) {
+        const bool more = i + 1 < nstage;
+        if (more) fetch(stage_k(i + 1));
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
+        for (int kk = 0; kk < GKF / 4; ++kk) {
             const int kr = 4 * kk + (lane >> 4);
             const float a0 = As[buf][kr][wm + (lane & 15)], a1 = As[buf][kr][wm + 16 + (lane & 15)];
             const float b0 = Bs[buf][kr][wn + (lane & 15)], b1 = Bs[buf][kr][wn + 16 + (lane & 15)];
@@ -175,7 +200,7 @@ static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 static bool launch_fast(hipStream_t st, const GemmArgs& g) {
     const bool a_kc = g.a_sk == 1, a_mc = g.a_sm == 1, b_nc = g.b_sn == 1, b_kc = g.b_sk == 1;
     if (!(a_kc || a_mc) || !(b_nc || b_kc)) return false;
-    if (g.M % GT || g.N % GT || g.kseg % GK || g.K % g.kseg || g.kchunk % GK || (g.K % g.kchunk && g.nsplit > 1) || g.K % GK) return false;
+    if (g.M % GT || g.N % GT || g.kseg % GKF || g.K % g.kseg || g.kchunk % GKF || (g.K % g.kchunk && g.nsplit > 1) || g.K % GKF) return false;
     if (g.kseg != g.K && g.kchunk % g.kseg && g.kseg % g.kchunk) return false;
     const long long a_ld = a_kc ? g.a_sm : g.a_sk, b_ld = b_nc ? g.b_sk : g.b_sn;
     if (a_ld % 4 || b_ld % 4 || g.a_seg % 4 || g.b_seg % 4 || g.b_batch % 4 || !aligned16(g.A) || !aligned16(g.B)) return false;
@@ -850,13 +875,13 @@ extern "C" int iwvi_gp_layer_backward(const iwvi_gp_bwd_desc* dp, int64_t T, voi
     {
         GemmArgs q{};
         q.A = w.DA; q.a_sm = M; q.a_sk = 1; q.B = w.LinvF; q.b_sk = M; q.b_sn = 1;
-        q.C = w.DK; q.ldc = M; q.M = (int)T; q.N = M; q.K = M; q.alpha = 1.f; q.beta = 0.f;
+        q.C = w.DK; q.ldc = M; q.M = (int)T; q.N = M; q.K = M; q.alpha = 1.f; q.beta = 0.f; q.b_lower_kn = 1;
         if ((rc = gemm_rows(st, q)) != IWVI_OK) return rc;
     }
     // dLm = -tril(DK^T A)  (float64 copy for the adjoint of the factorisation)
     {
         GemmArgs q{};
-        q.A = w.DK; q.a_sm = 1; q.a_sk = M; q.B = d.A; q.b_sk = Mp; q.b_sn = 1; q.M = M; q.N = M; q.K = (int)T;
+        q.A = w.DK; q.a_sm = 1; q.a_sk = M; q.B = d.A; q.b_sk = Mp; q.b_sn = 1; q.M = M; q.N = M; q.K = (int)T; q.tri_out = 1;
         if ((rc = gemm(st, q, w.part, w.part_floats, nullptr, w.Lbar, M, -1.0, 0.0, 1)) != IWVI_OK) return rc;
     }
     // dq_mu = A^T DMU
@@ -865,7 +890,7 @@ extern "C" int iwvi_gp_layer_backward(const iwvi_gp_bwd_desc* dp, int64_t T, voi
     if (d.dq_sqrt) {
         GemmArgs q{};
         q.A = d.A; q.a_sm = 1; q.a_sk = Mp; q.B = d.U; q.b_sk = Mp; q.b_sn = 1;
-        q.scale = w.DV2; q.s_stride = R; q.scale_on_k = 1; q.M = M; q.N = M; q.K = (int)T;
+        q.scale = w.DV2; q.s_stride = R; q.scale_on_k = 1; q.M = M; q.N = M; q.K = (int)T; q.tri_out = 1;
         if ((rc = gemm(st, q, w.part, w.part_floats, d.dq_sqrt, nullptr, M, 1.0, 0.0, 1, R, (long long)T * Mp, 1, (long long)M * M)) != IWVI_OK) return rc;
     }
     // C = -1/2 K o DK (over DA), dx~, dF, per-sample rows of the column sums

@@ -20,6 +20,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--config", type=int, default=2)
     ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--only-gradient", action="store_true", help="time only the value+gradient evaluation (for kernel profiles)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     spec = synthetic.make_spec(**CONFIGS[a.config], seed=0)
@@ -34,11 +35,15 @@ def main():
         torch.cuda.synchronize()
         return (time.perf_counter() - t0) / n * 1e3
 
+    T = spec["B"] * spec["K"]
+    if a.only_gradient:
+        grad = timed(lambda: backward.iw_elbo_and_gradients(model), a.iters)
+        print("config %d: value+gradient %.3f ms (%d evaluations incl. 2 warm-up)" % (a.config, grad, a.iters + 2))
+        return
     fwd = timed(lambda: model._build_likelihood(), a.iters)
     grad = timed(lambda: backward.iw_elbo_and_gradients(model), a.iters)
     tr = Trainer(model)
     step = timed(lambda: tr.step(), a.iters)
-    T = spec["B"] * spec["K"]
     print("config %d: forward (fused, eager) %.3f ms | value+gradient %.3f ms (%.2e samples/s) | training step %.3f ms"
           % (a.config, fwd, grad, T / grad * 1e3, step))
 
