@@ -84,7 +84,31 @@ def build_model(ARGS, X, Y, apply_name=True, device=None):
     else:
         model = DGP_IWVI(X, Y, layers, lik, minibatch_size=ARGS.minibatch_size,
                          num_samples=ARGS.num_IW_samples, name=name)
-    return model.to(device or settings.default_device())
+    model = model.to(device or settings.default_device())
+    attach_train_op(model, ARGS)
+    return model
+
+
+def attach_train_op(model, ARGS):
+    """``model.train_op()`` / ``model.global_step`` as built by the reference (build_models.py:270-304): NatGrad on the
+    final layer's q(u) then Adam on the rest, lr / gamma with a staircase decay.  The optimiser state lives in a
+    ``training.Trainer`` created at the first call (it needs the ROCm device).  IWAE models only: the adjoint kernels
+    implement the importance-weighted tiling of models.py:112-150."""
+    state = {}
+
+    def trainer():
+        if "t" not in state:
+            if not isinstance(model, DGP_IWVI):
+                raise NotImplementedError("the training op is built for mode 'IWAE' (DGP_IWVI) only")
+            from .training import Trainer
+            state["t"] = Trainer(model, lr=getattr(ARGS, "lr", 5e-3), gamma=getattr(ARGS, "gamma", 1e-2),
+                                 lr_decay=getattr(ARGS, "lr_decay", 0.98), gamma_decay=getattr(ARGS, "gamma_decay", 0.98),
+                                 fix_linear=getattr(ARGS, "fix_linear", True))
+        return state["t"]
+
+    model.trainer = trainer
+    model.train_op = lambda: trainer().step()
+    return model
 
 
 # ---- checkpoint / resume of the parameters (reference: gpflow Saver, run_conditional_density_estimation.py:95-125) ----
