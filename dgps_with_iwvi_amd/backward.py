@@ -76,6 +76,10 @@ def gp_backward(layer, saved, d_sample=None, d_mean=None, d_var=None, kl_weight=
                dq_sqrt=torch.empty(R, M, M, dtype=ft, device=dev))
     if want_dF:
         out["dF"] = torch.empty(T, D, dtype=ft, device=dev)
+    if W is not None:
+        out["dW"] = torch.empty(P, R, dtype=ft, device=dev)
+    if layer.mean_function.mf_type == _abi.MF_LINEAR:
+        out["dmf_A"] = torch.empty(D, P, dtype=ft, device=dev)
     b = _abi.GpBwdDesc()
     Z, q_mu, q_sqrt = (_abi.dev_tensor(t.contiguous(), n) for t, n in ((layer._Z(), "Z"), (layer.q_mu, "q_mu"), (layer.q_sqrt, "q_sqrt")))
     b.state, b.Z, b.lengthscales = layer.state().buf.data_ptr(), Z.data_ptr(), kern.lengthscales.data_ptr()
@@ -125,8 +129,8 @@ def lv_backward(layer, XY, mu, sigma, eps, dF_next, col0, w, B, K, sampled_kl=Tr
 def iw_elbo_and_gradients(model, zs=None):
     """The IW-ELBO of the current minibatch (models.py:112-150) and its gradient w.r.t. every parameter the
     reference trains (build_models.py:284-304): -> (elbo [0-dim float64 tensor], dict) with the names of
-    oracle/grad_oracle.py: 'l<i>.Z', 'l<i>.ls', 'l<i>.var', 'l<i>.q_mu', 'l<i>.q_sqrt', 'l<i>.encW<j>',
-    'l<i>.encb<j>', 'lik_var'.  ``zs``: one noise tensor per layer ([B, K, dim]) or None -> drawn."""
+    oracle/grad_oracle.py: 'l<i>.Z', 'l<i>.ls', 'l<i>.var', 'l<i>.q_mu', 'l<i>.q_sqrt', 'l<i>.W', 'l<i>.mfA' (layers with
+    a mixing matrix / linear mean function), 'l<i>.encW<j>', 'l<i>.encb<j>', 'lik_var'.  ``zs``: one noise tensor per layer ([B, K, dim]) or None -> drawn."""
     from .layers import LatentVariableLayer
     from .temp_workaround import draw_normal
     dev = model.X.device
@@ -189,8 +193,10 @@ def iw_elbo_and_gradients(model, zs=None):
             g = gp_backward(layer, s[1], d_sample=None if last else dF, d_mean=d_mean if last else None,
                             d_var=d_var if last else None, kl_weight=1.0, want_dF=i > 0)
             elbo = elbo - layer.kl
-            for k_out, k_name in (("dZ", "Z"), ("dls", "ls"), ("dvariance", "var"), ("dq_mu", "q_mu"), ("dq_sqrt", "q_sqrt")):
-                grads["l%d.%s" % (i, k_name)] = g[k_out]
+            for k_out, k_name in (("dZ", "Z"), ("dls", "ls"), ("dvariance", "var"), ("dq_mu", "q_mu"), ("dq_sqrt", "q_sqrt"),
+                                  ("dW", "W"), ("dmf_A", "mfA")):
+                if k_out in g:
+                    grads["l%d.%s" % (i, k_name)] = g[k_out]
             dF = g.get("dF")
         else:
             _, mu, sg, eps, _, D_in = s

@@ -285,6 +285,7 @@ struct HeadArgs {
     const float* dFs; const float* dFm; const float* dFv;
     float* DMU; float* DV2; float* SDV; float* dF;
     long long T; int M, Mp, D, R, P, mf_type; float variance;
+    const float* q_mu; float* GMV;      // optional [T, 3R] = (g_r | mu_r | v_r) per sample, for the mixing matrix's gradient
 };
 __device__ __forceinline__ float wave_sum(float v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -304,6 +305,16 @@ __global__ __launch_bounds__(256) void k_bw_heads(HeadArgs h) {
         float uu = 0.f;
         for (int m = lane; m < h.M; m += 64) uu = fmaf(u[m], u[m], uu);
         uu = wave_sum(uu);
+        if (h.GMV) {
+            float mu = 0.f;
+            for (int m = lane; m < h.M; m += 64) mu = fmaf(a[m], h.q_mu[m * h.R + r], mu);
+            mu = wave_sum(mu);
+            if (lane == 0) {
+                const float vr = fmaxf(h.variance - aa + uu, 0.f);
+                float* o = h.GMV + t * 3 * h.R;
+                o[r] = mu + (h.eps ? h.eps[t * h.R + r] : 0.f) * sqrtf(vr); o[h.R + r] = mu; o[2 * h.R + r] = vr;
+            }
+        }
         float dg = 0.f, dm = 0.f, dvv = 0.f;
         if (h.W) {
             for (int p = 0; p < h.P; ++p) {
@@ -558,9 +569,18 @@ __global__ void k_bw_kl(FinalArgsB f) {
     }
 }
 
+// dW[p, r] = S1 + S2 + 2 W o S3 with S1 = dFs^T G, S2 = dFm^T MU, S3 = dFv^T V;  dA = F^T dFs + F^T dFm
+__global__ void k_lin_combine(const float* s1, const float* s2, const float* s3, const float* W, float* dW, int n_w,
+                              const float* a1, const float* a2, float* dA, int n_a) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (dW && i < n_w) dW[i] = (s1 ? s1[i] : 0.f) + (s2 ? s2[i] : 0.f) + (s3 ? 2.f * W[i] * s3[i] : 0.f);
+    if (dA && i < n_a) dA[i] = (a1 ? a1[i] : 0.f) + (a2 ? a2[i] : 0.f);
+}
+
 struct BwdWs {
     float *DMU, *DV2, *SDV, *DA, *DK, *Qx, *part, *LinvF, *Zt, *invls, *CtF1, *Qsum;
     double *Lbar, *T1, *T2, *S, *dZt_uu, *dvar_m;
+    float *GMV, *lin;                   // [T, 3R];  3 [P, R] + 2 [D, P] partial results
     size_t part_floats, bytes;
 };
 static BwdWs bwd_layout(char* base, long long T, int M, int D, int R) {
@@ -571,8 +591,8 @@ static BwdWs bwd_layout(char* base, long long T, int M, int D, int R) {
     w.DA = (float*)take(sizeof(float) * T * M); w.DK = (float*)take(sizeof(float) * T * M);
     w.Qx = (float*)take(sizeof(float) * T * (D + 2));
     w.part_floats = (size_t)nsplit * M * M * R;
-    {   // thin reductions: ceil(T / THIN_ROWS) chunks of [max(M, D + 2)][max(D + 1, R)]
-        const size_t thin = (size_t)((T + THIN_ROWS - 1) / THIN_ROWS) * (M > D + 2 ? M : D + 2) * (D + 1 > R ? D + 1 : R);
+    {   // thin reductions: ceil(T / THIN_ROWS) chunks of at most [max(M, 34)][33]
+        const size_t thin = (size_t)((T + THIN_ROWS - 1) / THIN_ROWS) * (M > 34 ? M : 34) * 33;
         if (thin > w.part_floats) w.part_floats = thin;
     }
     w.part = (float*)take(sizeof(float) * w.part_floats);
@@ -580,6 +600,8 @@ static BwdWs bwd_layout(char* base, long long T, int M, int D, int R) {
     w.CtF1 = (float*)take(sizeof(float) * M * (D + 1)); w.Qsum = (float*)take(sizeof(float) * (IWVI_MAX_D + 2));
     w.Lbar = (double*)take(sizeof(double) * M * M); w.T1 = (double*)take(sizeof(double) * M * M); w.T2 = (double*)take(sizeof(double) * M * M);
     w.S = (double*)take(sizeof(double) * M * M); w.dZt_uu = (double*)take(sizeof(double) * M * D); w.dvar_m = (double*)take(sizeof(double) * M);
+    w.GMV = (float*)take(sizeof(float) * T * 3 * R);
+    w.lin = (float*)take(sizeof(float) * (3 * IWVI_MAX_P * IWVI_MAX_R + 2 * IWVI_MAX_D * IWVI_MAX_P));
     w.bytes = o;
     return w;
 }
@@ -857,7 +879,8 @@ extern "C" int iwvi_gp_layer_backward(const iwvi_gp_bwd_desc* dp, int64_t T, voi
         const int n = M * M > M * D ? M * M : M * D;
         hipLaunchKernelGGL(k_prep, dim3((n + 255) / 256), dim3(256), 0, st, d.Z, d.lengthscales, Linv64, Mp, w.Zt, w.invls, w.LinvF, M, D);
     }
-    HeadArgs h{d.A, d.U, d.noise, d.W, d.mf_A, d.d_sample, d.d_mean, d.d_var, w.DMU, w.DV2, w.SDV, d.dF, T, M, Mp, D, R, d.P, d.mf_type, d.variance};
+    HeadArgs h{d.A, d.U, d.noise, d.W, d.mf_A, d.d_sample, d.d_mean, d.d_var, w.DMU, w.DV2, w.SDV, d.dF, T, M, Mp, D, R, d.P, d.mf_type, d.variance,
+               d.q_mu, (d.dW && d.W) ? w.GMV : nullptr};
     hipLaunchKernelGGL(k_bw_heads, dim3((unsigned)((T + 3) / 4)), dim3(256), 0, st, h);
     if ((rc = check_launch("k_bw_heads")) != IWVI_OK) return rc;
     // DA = DMU q_mu^T - 2 SDV o A
@@ -914,6 +937,23 @@ extern "C" int iwvi_gp_layer_backward(const iwvi_gp_bwd_desc* dp, int64_t T, voi
         hipLaunchKernelGGL(k_dmm, grid, block, 0, st, (const double*)w.T2, (long long)M, 1LL, Linv64, (long long)Mp, 1LL, w.S, M, M, 0);
         hipLaunchKernelGGL(k_kuu_bwd, dim3(M), dim3(256), 0, st, w.Zt, (const double*)w.S, M, D, (double)d.variance, w.dZt_uu, w.dvar_m);
         if ((rc = check_launch("cholesky adjoint")) != IWVI_OK) return rc;
+    }
+    // mixing matrix and linear mean function (trainable when the reference runs with fix_linear=False, build_models.py:224-227)
+    if ((d.dW && d.W) || (d.dmf_A && d.mf_type == IWVI_MF_LINEAR)) {
+        const int P = d.P;
+        float* s[3] = {nullptr, nullptr, nullptr}; float* a12[2] = {nullptr, nullptr};
+        const float* ups[3] = {d.d_sample, d.d_mean, d.d_var};
+        if (d.dW && d.W) for (int i = 0; i < 3; ++i) if (ups[i]) {
+            s[i] = w.lin + i * IWVI_MAX_P * IWVI_MAX_R;
+            if ((rc = thin(st, ups[i], P, P, w.GMV + i * R, 3 * R, R, 0, T, w.part, w.part_floats, s[i])) != IWVI_OK) return rc;
+        }
+        if (d.dmf_A && d.mf_type == IWVI_MF_LINEAR) for (int i = 0; i < 2; ++i) if (ups[i]) {
+            a12[i] = w.lin + 3 * IWVI_MAX_P * IWVI_MAX_R + i * IWVI_MAX_D * IWVI_MAX_P;
+            if ((rc = thin(st, d.F, D, D, ups[i], P, P, 0, T, w.part, w.part_floats, a12[i])) != IWVI_OK) return rc;
+        }
+        const int n_w = (d.dW && d.W) ? P * R : 0, n_a = (d.dmf_A && d.mf_type == IWVI_MF_LINEAR) ? D * P : 0;
+        hipLaunchKernelGGL(k_lin_combine, dim3(((n_w > n_a ? n_w : n_a) + 255) / 256), dim3(256), 0, st, (const float*)s[0], (const float*)s[1], (const float*)s[2],
+                           d.W, n_w ? d.dW : nullptr, n_w, (const float*)a12[0], (const float*)a12[1], n_a ? d.dmf_A : nullptr, n_a);
     }
     FinalArgsB f{d.Z, d.lengthscales, d.q_mu, d.q_sqrt, w.Zt, w.invls, w.CtF1, w.CtF1, w.Qsum + D, w.Qsum, w.dZt_uu, w.dvar_m,
                  d.dZ, d.dls, d.dvariance, d.dq_mu, d.dq_sqrt, M, D, R, d.kl_weight, (double)d.variance};

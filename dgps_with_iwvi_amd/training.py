@@ -4,7 +4,7 @@ exponential decay) -> ``op_adam`` (TensorFlow AdamOptimizer on every other train
 decay).  Each op evaluates the IW-ELBO and its gradient on its own fresh samples, like two ``session.run`` calls.
 
 Trainable set as built by ``build_models.py`` with its defaults (``fix_linear=True``): inner layers Z, lengthscales,
-q_mu, q_sqrt (kernel variance fixed, :213; W and the mean function fixed, :226-227); final layer Z, lengthscales,
+q_mu, q_sqrt (kernel variance fixed, :213; W and the linear mean function's A too unless ``fix_linear=False``, :224-227); final layer Z, lengthscales,
 kernel variance; encoders; the likelihood variance.  Gradients: ``backward.iw_elbo_and_gradients``; update rules:
 ``iwvi_natgrad_step`` / ``iwvi_adam_step`` (csrc/backward.hip)."""
 import ctypes
@@ -14,6 +14,7 @@ import torch
 from . import _abi, settings
 from .backward import iw_elbo_and_gradients
 from .layers import GPLayer, LatentVariableLayer
+from .temp_workaround import SharedMixedMok
 
 
 def staircase_decay(base, step, rate, every=1000):
@@ -27,9 +28,6 @@ class Trainer:
         """``group`` / ``shard_weight``: data-parallel training over the ranks of a torch.distributed group (each rank's
         model holds its own minibatch rows, N-shard): gradients are merged by ``sharding.allreduce_gradients`` with
         weight B_rank / B_job (default 1 / world) before either update, so every rank applies the same step."""
-        if not fix_linear:
-            raise NotImplementedError("gradients of the mixing matrix W and the linear mean function are not built yet "
-                                      "(the reference's default fix_linear=True keeps them fixed)")
         self.model = model
         self.group, self.shard_weight = group, shard_weight
         self.lr, self.gamma, self.lr_decay, self.gamma_decay = lr, gamma, lr_decay, gamma_decay
@@ -61,6 +59,11 @@ class Trainer:
             else:
                 self._entries.append(("l%d.q_mu" % i, l.q_mu, 0))
                 self._entries.append(("l%d.q_sqrt" % i, l.q_sqrt, 0))
+            if not fix_linear:                                 # build_models.py:224-227
+                if isinstance(l.kern, SharedMixedMok):
+                    self._entries.append(("l%d.W" % i, l.kern.W, 0))
+                if l.mean_function.mf_type == _abi.MF_LINEAR:
+                    self._entries.append(("l%d.mfA" % i, l.mean_function.A, 0))
         t = torch.full((1,), model.likelihood.variance, dtype=ft, device=dev)
         self._entries.append(("lik_var", t, 1))
         self._scalars.append((t, lambda v: setattr(model.likelihood, "variance", v)))

@@ -250,7 +250,7 @@ int iwvi_dgp_forward(const iwvi_layer_desc* layers_host, int n_layers,
  *   d_sample/d_mean/d_var [T, P]  upstream gradients, any may be NULL (= 0)
  *   kl_weight              the objective contains -kl_weight * KL[q(u)||p(u)] of this layer (1 for the ELBO)
  *   outputs (any may be NULL): dF [T, D], dZ [M, D], dls [D], dvariance [1], dq_mu [M, R],
- *                          dq_sqrt [R, M, M] (lower triangle; zeros above)
+ *                          dq_sqrt [R, M, M] (lower triangle; zeros above), dW [P, R], dmf_A [D, P]
  *   ws                     iwvi_gp_layer_backward_ws_bytes(T, M, D, R) bytes
  * ---------------------------------------------------------------------- */
 typedef struct iwvi_gp_bwd_desc {
@@ -263,6 +263,7 @@ typedef struct iwvi_gp_bwd_desc {
     const float* d_sample; const float* d_mean; const float* d_var;
     double kl_weight;
     float* dF; float* dZ; float* dls; float* dvariance; float* dq_mu; float* dq_sqrt;
+    float* dW; float* dmf_A;        /* optional: [P, R] (SharedMixedMok.W), [D, P] (Linear mean function A) */
 } iwvi_gp_bwd_desc;
 size_t iwvi_gp_layer_backward_ws_bytes(int64_t T, int M, int D, int R);
 int iwvi_gp_layer_backward(const iwvi_gp_bwd_desc* desc, int64_t T, void* ws, void* stream);

@@ -8,7 +8,7 @@ the reparameterised gradient is deterministic.  Pinned by central finite differe
 restatement (tests/test_grad_oracle.py).
 
 Parameters differentiated, per layer:  GP: Z [M, D], lengthscales [D], kernel variance, q_mu [M, R],
-q_sqrt [R, M, M] (lower triangle);  LV: encoder weights and biases;  plus the likelihood variance."""
+q_sqrt [R, M, M] (lower triangle), mixing matrix W [P, R] and linear mean function A [D, P] where present;  LV: encoder weights and biases;  plus the likelihood variance."""
 import numpy as np
 import torch
 
@@ -16,7 +16,7 @@ from .ref_torch_cpu import CpuDGP
 
 
 def iw_elbo_and_gradients(spec, zs):
-    """Returns (elbo, {name: ndarray}); names: 'l<i>.Z', 'l<i>.ls', 'l<i>.var', 'l<i>.q_mu', 'l<i>.q_sqrt',
+    """Returns (elbo, {name: ndarray}); names: 'l<i>.Z', 'l<i>.ls', 'l<i>.var', 'l<i>.q_mu', 'l<i>.q_sqrt', 'l<i>.W', 'l<i>.mfA',
     'l<i>.encW<j>', 'l<i>.encb<j>', 'lik_var'."""
     m = CpuDGP(spec, torch.float64)
     params = {}
@@ -40,6 +40,12 @@ def iw_elbo_and_gradients(spec, zs):
             params["l%d.q_sqrt" % i] = raw
             L["var"] = leaf(L["var"])
             params["l%d.var" % i] = L["var"]
+            if L["W"] is not None:                             # trainable when the reference runs with fix_linear=False
+                L["W"] = leaf(L["W"].detach().numpy())
+                params["l%d.W" % i] = L["W"]
+            if L["A"] is not None:
+                L["A"] = leaf(L["A"].detach().numpy())
+                params["l%d.mfA" % i] = L["A"]
     m.lik_var = leaf(m.lik_var)
     params["lik_var"] = m.lik_var
     val = m.elbo_tensor(zs)

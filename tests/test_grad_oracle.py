@@ -32,6 +32,8 @@ def _perturbed(spec, name, direction, eps):
         L["enc_b"][int(key[4:])] = L["enc_b"][int(key[4:])] + eps * direction
     elif key == "var":
         L["var"] = float(L["var"] + eps * direction)
+    elif key == "mfA":
+        L["mf"] = (L["mf"][0], L["mf"][1] + eps * direction) + tuple(L["mf"][2:])
     else:
         L[key] = L[key] + eps * direction
     return s
@@ -48,6 +50,8 @@ def test_autodiff_gradients_match_finite_differences(case):
                 L[k] = v.astype(np.float64)
             elif isinstance(v, list) and v and isinstance(v[0], np.ndarray):
                 L[k] = [a.astype(np.float64) for a in v]
+            elif isinstance(v, tuple):
+                L[k] = tuple(a.astype(np.float64) if isinstance(a, np.ndarray) else a for a in v)
     zs = [z.astype(np.float64) for z in synthetic.make_noise(spec, seed=3)]
     val, grads = iw_elbo_and_gradients(spec, zs)
     assert abs(val - _numpy_elbo(spec, zs)) <= 1e-9 * abs(val)
