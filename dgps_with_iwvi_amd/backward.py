@@ -205,3 +205,41 @@ def iw_elbo_and_gradients(model, zs=None):
                 grads["l%d.encW%d" % (i, j)], grads["l%d.encb%d" % (i, j)] = a, b
             dF = None if (dF is None or i == 0) else dF[:, :D_in].contiguous()
     return elbo, grads
+
+
+def parameter_list(model):
+    """[(name, tensor)] of the model's tensor parameters, named like the gradients (host-scalar parameters -- kernel
+    and likelihood variances -- are not tensors and are left to ``training.Trainer``)."""
+    from .layers import LatentVariableLayer
+    out = []
+    for i, l in enumerate(model.layers):
+        if isinstance(l, LatentVariableLayer):
+            for j, (w, b) in enumerate(zip(l.encoder.Ws, l.encoder.bs)):
+                out += [("l%d.encW%d" % (i, j), w), ("l%d.encb%d" % (i, j), b)]
+        elif isinstance(l, GPLayer):
+            out += [("l%d.Z" % i, l._Z()), ("l%d.ls" % i, l._base_kern().lengthscales), ("l%d.q_mu" % i, l.q_mu), ("l%d.q_sqrt" % i, l.q_sqrt)]
+            if isinstance(l.kern, SharedMixedMok):
+                out.append(("l%d.W" % i, l.kern.W))
+            if l.mean_function.mf_type == _abi.MF_LINEAR:
+                out.append(("l%d.mfA" % i, l.mean_function.A))
+    return out
+
+
+class IwElbo(torch.autograd.Function):
+    """The IW-ELBO as a differentiable torch op: ``IwElbo.apply(model, zs, *tensors)`` with
+    ``tensors = [t for _, t in parameter_list(model)]`` -- the model's OWN parameter tensors (the kernels read the
+    model; the arguments only tell autograd where the gradients go).  Forward and backward are the hand-written HIP
+    kernels (``iw_elbo_and_gradients``); nothing is traced."""
+
+    @staticmethod
+    def forward(ctx, model, zs, *tensors):
+        params = parameter_list(model)
+        if len(tensors) != len(params) or any(a.data_ptr() != b.data_ptr() for a, (_, b) in zip(tensors, params)):
+            raise ValueError("pass the model's own parameter tensors, in parameter_list(model) order")
+        elbo, grads = iw_elbo_and_gradients(model, zs)
+        ctx.grads = [grads[n].reshape(t.shape).to(t.dtype) for n, t in params]
+        return elbo.clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        return (None, None) + tuple((g * gr.to(torch.float64)).to(gr.dtype) for gr in ctx.grads)
