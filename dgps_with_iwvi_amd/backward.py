@@ -126,21 +126,28 @@ def lv_backward(layer, XY, mu, sigma, eps, dF_next, col0, w, B, K, sampled_kl=Tr
     return dW, db
 
 
-def iw_elbo_and_gradients(model, zs=None):
-    """The IW-ELBO of the current minibatch (models.py:112-150) and its gradient w.r.t. every parameter the
+def iw_elbo_and_gradients(model, zs=None, mode_vi=None):
+    """``mode_vi`` (default: the model is a DGP_VI, not a DGP_IWVI): the bound of models.py:49-86 instead -- analytic
+    local KL, mean over the S samples; ``zs`` then in that model's layout [S*N, dim] (S-major tiling, models.py:50).
+
+    The IW-ELBO of the current minibatch (models.py:112-150) and its gradient w.r.t. every parameter the
     reference trains (build_models.py:284-304): -> (elbo [0-dim float64 tensor], dict) with the names of
     oracle/grad_oracle.py: 'l<i>.Z', 'l<i>.ls', 'l<i>.var', 'l<i>.q_mu', 'l<i>.q_sqrt', 'l<i>.W', 'l<i>.mfA' (layers with
     a mixing matrix / linear mean function), 'l<i>.encW<j>', 'l<i>.encb<j>', 'lik_var'.  ``zs``: one noise tensor per layer ([B, K, dim]) or None -> drawn."""
     from .layers import LatentVariableLayer
+    from .models import DGP_IWVI
     from .temp_workaround import draw_normal
     dev = model.X.device
     ft = settings.float_type
     B, K = model.X.shape[0], model.num_samples
     T = B * K
     layers = model.layers
-    zs = [None] * len(layers) if zs is None else zs
+    mode_vi = (not isinstance(model, DGP_IWVI)) if mode_vi is None else bool(mode_vi)
+    zs = [None] * len(layers) if zs is None else list(zs)
     if len(zs) != len(layers):
         raise ValueError("zs needs one entry per layer")
+    if mode_vi:                                                  # [S*N, dim] -> the kernels' point-major order t = n*S + s
+        zs = [None if z is None else z.reshape(K, B, -1).transpose(0, 1).contiguous() for z in zs]
     X = _abi.dev_tensor(model.X.contiguous(), "X")
     Y = _abi.dev_tensor(model.Y.contiguous(), "Y")
     F = X[:, None, :].expand(B, K, X.shape[1]).reshape(T, -1).contiguous()          # models.py:113
@@ -156,7 +163,7 @@ def iw_elbo_and_gradients(model, zs=None):
             Lw = layer.latent_dim
             eps = draw_normal((T, Lw), dev) if z is None else _abi.dev_tensor(z.reshape(T, Lw).contiguous(), "z")
             mu, sg = layer.encoder(XY)
-            smp, _, _, kl = layer.propagate(F, XYt, True, z=eps)
+            smp, _, _, kl = layer.propagate(F, XYt, not mode_vi, z=eps)
             saved.append(("lv", mu.contiguous(), sg.contiguous(), eps, kl.reshape(T, Lw), F.shape[1]))
             F = smp.reshape(T, -1)
         elif isinstance(layer, GPLayer):
@@ -181,7 +188,7 @@ def iw_elbo_and_gradients(model, zs=None):
     scale = float(model.num_data) / float(B)
     _abi.check(_abi.lib().iwvi_iw_elbo_backward(
         _abi.ptr(fin.mean), _abi.ptr(fin.var), _abi.ptr(Y), Dy, klp, kld, len(kls), B, K,
-        float(model.likelihood.variance), scale, _abi.ptr(w), _abi.ptr(d_mean), _abi.ptr(d_var),
+        float(model.likelihood.variance), scale, 1 if mode_vi else 0, _abi.ptr(w), _abi.ptr(d_mean), _abi.ptr(d_var),
         ctypes.c_void_p(sums.data_ptr()), ctypes.c_void_p(ws.data_ptr()), _abi.stream_ptr()))
     grads = {"lik_var": sums[1]}
     elbo = scale * sums[0]
@@ -200,7 +207,7 @@ def iw_elbo_and_gradients(model, zs=None):
             dF = g.get("dF")
         else:
             _, mu, sg, eps, _, D_in = s
-            dW, db = lv_backward(layer, XY, mu, sg, eps, dF, D_in, w, B, K, True)
+            dW, db = lv_backward(layer, XY, mu, sg, eps, dF, D_in, w, B, K, not mode_vi)
             for j, (a, b) in enumerate(zip(dW, db)):
                 grads["l%d.encW%d" % (i, j)], grads["l%d.encb%d" % (i, j)] = a, b
             dF = None if (dF is None or i == 0) else dF[:, :D_in].contiguous()

@@ -92,14 +92,12 @@ def build_model(ARGS, X, Y, apply_name=True, device=None):
 def attach_train_op(model, ARGS):
     """``model.train_op()`` / ``model.global_step`` as built by the reference (build_models.py:270-304): NatGrad on the
     final layer's q(u) then Adam on the rest, lr / gamma with a staircase decay.  The optimiser state lives in a
-    ``training.Trainer`` created at the first call (it needs the ROCm device).  IWAE models only: the adjoint kernels
-    implement the importance-weighted tiling of models.py:112-150."""
+    ``training.Trainer`` created at the first call (it needs the ROCm device).  Modes 'IWAE' (models.py:112-150) and
+    'VI' (:49-86: uniform sample weights, analytic local KL)."""
     state = {}
 
     def trainer():
         if "t" not in state:
-            if not isinstance(model, DGP_IWVI):
-                raise NotImplementedError("the training op is built for mode 'IWAE' (DGP_IWVI) only")
             from .training import Trainer
             state["t"] = Trainer(model, lr=getattr(ARGS, "lr", 5e-3), gamma=getattr(ARGS, "gamma", 1e-2),
                                  lr_decay=getattr(ARGS, "lr_decay", 0.98), gamma_decay=getattr(ARGS, "gamma_decay", 0.98),

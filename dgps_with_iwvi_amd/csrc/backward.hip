@@ -620,7 +620,7 @@ __global__ void k_enc_unpack(const float* both, int din, int dout, float* dW, fl
 struct ElboBwdArgs {
     const float* fmean; const float* fvar; const float* Y; int Dy;
     const float* kl[IWVI_MAX_KL]; int kl_dims[IWVI_MAX_KL]; int n_kl;
-    long long B; int K; float lik_var; double scale;
+    long long B; int K; float lik_var; double scale; int mode_vi;
     float* w; float* d_mean; float* d_var; double* part;   // part[0..B) = lse - log K, part[B..2B) = d lik_var share
 };
 __global__ __launch_bounds__(256) void k_elbo_bwd(ElboBwdArgs a) {      // one wave per data point, lanes over its K samples
@@ -639,15 +639,20 @@ __global__ __launch_bounds__(256) void k_elbo_bwd(ElboBwdArgs a) {      // one w
         return l;
     };
     float mx = -INFINITY;
-    for (int k = lane; k < a.K; k += 64) mx = fmaxf(mx, logw(b * a.K + k));
-    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
     double se = 0.0;
-    for (int k = lane; k < a.K; k += 64) se += (double)__expf(logw(b * a.K + k) - mx);
-    for (int o = 32; o > 0; o >>= 1) se += __shfl_xor(se, o, 64);
+    if (a.mode_vi) {                                    // models.py:84: mean over the samples -> uniform weights
+        for (int k = lane; k < a.K; k += 64) se += (double)logw(b * a.K + k);
+        for (int o = 32; o > 0; o >>= 1) se += __shfl_xor(se, o, 64);
+    } else {
+        for (int k = lane; k < a.K; k += 64) mx = fmaxf(mx, logw(b * a.K + k));
+        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+        for (int k = lane; k < a.K; k += 64) se += (double)__expf(logw(b * a.K + k) - mx);
+        for (int o = 32; o > 0; o >>= 1) se += __shfl_xor(se, o, 64);
+    }
     double ds = 0.0;
     for (int k = lane; k < a.K; k += 64) {
         const long long t = b * a.K + k;
-        const float wt = (float)(a.scale * (double)__expf(logw(t) - mx) / se);
+        const float wt = a.mode_vi ? (float)(a.scale / (double)a.K) : (float)(a.scale * (double)__expf(logw(t) - mx) / se);
         if (a.w) a.w[t] = wt;
         for (int j = 0; j < a.Dy; ++j) {
             const float e = a.Y[b * a.Dy + j] - a.fmean[t * a.Dy + j], v = a.fvar[t * a.Dy + j];
@@ -657,7 +662,7 @@ __global__ __launch_bounds__(256) void k_elbo_bwd(ElboBwdArgs a) {      // one w
         }
     }
     for (int o = 32; o > 0; o >>= 1) ds += __shfl_xor(ds, o, 64);
-    if (lane == 0) { a.part[b] = (double)mx + log(se) - log((double)a.K); a.part[a.B + b] = ds; }
+    if (lane == 0) { a.part[b] = a.mode_vi ? se / (double)a.K : (double)mx + log(se) - log((double)a.K); a.part[a.B + b] = ds; }
 }
 // out[i] = sum of part[i*n .. (i+1)*n), one workgroup per i, fixed order
 __global__ __launch_bounds__(256) void k_dsum(const double* part, long long n, double* out) {
@@ -964,7 +969,7 @@ extern "C" int iwvi_gp_layer_backward(const iwvi_gp_bwd_desc* dp, int64_t T, voi
 
 extern "C" int iwvi_iw_elbo_backward(const float* fmean, const float* fvar, const float* Y, int Dy,
                                      const float* const* kl_local, const int32_t* kl_dims, int n_local,
-                                     int64_t B, int K, float lik_variance, double scale,
+                                     int64_t B, int K, float lik_variance, double scale, int mode_vi,
                                      float* out_w, float* d_mean, float* d_var,
                                      double* out_sums /* [2]: sum_n (lse - log K), d/d lik_variance */, double* ws, void* stream_) {
     if (!fmean || !fvar || !Y || !out_sums || !ws || Dy <= 0 || B <= 0 || K <= 0 || n_local < 0 || n_local > IWVI_MAX_KL || !(lik_variance > 0.f)) {
@@ -977,7 +982,7 @@ extern "C" int iwvi_iw_elbo_backward(const float* fmean, const float* fvar, cons
         if (!kl_local || !kl_local[i] || !kl_dims || kl_dims[i] <= 0) { set_error("iwvi_iw_elbo_backward: bad local regulariser %d", i); return IWVI_ERR_ARG; }
         a.kl[i] = kl_local[i]; a.kl_dims[i] = kl_dims[i];
     }
-    a.B = B; a.K = K; a.lik_var = lik_variance; a.scale = scale; a.w = out_w; a.d_mean = d_mean; a.d_var = d_var; a.part = ws;
+    a.B = B; a.K = K; a.lik_var = lik_variance; a.scale = scale; a.mode_vi = mode_vi; a.w = out_w; a.d_mean = d_mean; a.d_var = d_var; a.part = ws;
     hipLaunchKernelGGL(k_elbo_bwd, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, st, a);
     hipLaunchKernelGGL(k_dsum, dim3(2), dim3(256), 0, st, (const double*)ws, (long long)B, out_sums);
     return check_launch("k_elbo_bwd");

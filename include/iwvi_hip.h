@@ -272,10 +272,10 @@ int iwvi_gp_layer_backward(const iwvi_gp_bwd_desc* desc, int64_t T, void* ws, vo
  *   L_nk = sum_dy varexp(Y; fmean, fvar) - sum_i sum_q kl_local[i][t, q];  ELBO = scale * sum_n (lse_k L_nk - log K) - KL.
  * out_w [T] = d ELBO / d L_nk (scale * softmax over k), d_mean / d_var [T, Dy] = heads of the final layer,
  * out_sums[0] = sum_n (lse - log K), out_sums[1] = d ELBO / d lik_variance;  ws: 2*B doubles. Outputs may be NULL
- * except out_sums. */
+ * except out_sums.  mode_vi != 0: the bound of DGP_VI (models.py:84: mean over the samples instead of the logsumexp). */
 int iwvi_iw_elbo_backward(const float* fmean, const float* fvar, const float* Y, int Dy,
                           const float* const* kl_local, const int32_t* kl_dims, int n_local,
-                          int64_t B, int K, float lik_variance, double scale,
+                          int64_t B, int K, float lik_variance, double scale, int mode_vi,
                           float* out_w, float* d_mean, float* d_var, double* out_sums, double* ws, void* stream);
 
 /* Adjoint of the LatentVariableLayer (layers.py:83-103): mu, sigma [B, latent_dim] (the encoder's outputs per data

@@ -15,7 +15,7 @@ import torch
 from .ref_torch_cpu import CpuDGP
 
 
-def iw_elbo_and_gradients(spec, zs):
+def iw_elbo_and_gradients(spec, zs, mode_vi=False):
     """Returns (elbo, {name: ndarray}); names: 'l<i>.Z', 'l<i>.ls', 'l<i>.var', 'l<i>.q_mu', 'l<i>.q_sqrt', 'l<i>.W', 'l<i>.mfA',
     'l<i>.encW<j>', 'l<i>.encb<j>', 'lik_var'."""
     m = CpuDGP(spec, torch.float64)
@@ -48,7 +48,7 @@ def iw_elbo_and_gradients(spec, zs):
                 params["l%d.mfA" % i] = L["A"]
     m.lik_var = leaf(m.lik_var)
     params["lik_var"] = m.lik_var
-    val = m.elbo_tensor(zs)
+    val = m.elbo_tensor(zs, mode_vi=mode_vi)      # mode_vi: the DGP_VI bound (models.py:49-86), same noise layout
     val.backward()
     grads = {k: (np.zeros(tuple(v.shape)) if v.grad is None else v.grad.detach().numpy().copy()) for k, v in params.items()}
     return float(val.detach()), grads

@@ -70,9 +70,10 @@ class CpuDGP:
     def elbo(self, zs):
         return float(self.elbo_tensor(zs))
 
-    def elbo_tensor(self, zs):
+    def elbo_tensor(self, zs, mode_vi=False):
         """The IW-ELBO as a tensor (differentiable w.r.t. whichever parameter tensors require grad: the gradient
-        oracle of oracle/grad_oracle.py)."""
+        oracle of oracle/grad_oracle.py).  ``mode_vi``: the bound of DGP_VI instead (models.py:49-86: analytic local KL,
+        mean over the samples), same [B, K, .] noise layout."""
         B, K = self.X.shape[0], self.K
         F = self.X[:, None, :].repeat(1, K, 1)                                                     # models.py:113
         Yt = self.Y[:, None, :].repeat(1, K, 1)
@@ -95,7 +96,10 @@ class CpuDGP:
                 sg = torch.nn.functional.softplus(raw - 3.0)
                 Wl = mu + z * sg
                 F = torch.cat([F, Wl], -1)
-                local.append((-0.5 * ((Wl - mu) / sg) ** 2 - torch.log(sg)) - (-0.5 * Wl ** 2))    # :98-100
+                if mode_vi:
+                    local.append(0.5 * (sg ** 2 + mu ** 2 - 1.0) - torch.log(sg) + 0.0 * Wl)       # layers.py:101-103
+                else:
+                    local.append((-0.5 * ((Wl - mu) / sg) ** 2 - torch.log(sg)) - (-0.5 * Wl ** 2))    # :98-100
                 continue
             if L["W"] is not None:                                                                 # SharedMixedMok branch
                 s, m, v = self._conditional(L, F, False, z)
@@ -117,5 +121,5 @@ class CpuDGP:
         L_NK = ve.sum(2)
         for kl in local:
             L_NK = L_NK - kl.sum(2)
-        logp = torch.logsumexp(L_NK, 1) - math.log(K)                                              # :148
+        logp = L_NK.mean(1) if mode_vi else torch.logsumexp(L_NK, 1) - math.log(K)                 # :84 / :148
         return logp.sum() * (self.n_data / B) - sum(glob)                                          # :150

@@ -82,3 +82,16 @@ def test_gradient_fixture_is_reproduced(name):
     for k, v in grads.items():
         ref = g[k.replace(".", "_")]
         assert np.allclose(v, ref, rtol=1e-8, atol=1e-10 * max(1.0, float(np.abs(ref).max()))), k
+
+
+def test_vi_mode_of_the_torch_restatement_equals_the_numpy_oracle():
+    """mode_vi (models.py:49-86: analytic local KL, mean over S) of the differentiable restatement against the
+    independent NumPy oracle's DGP_VI; noise [B, S, .] here, [S*B, .] (S-major tiling, models.py:50) there."""
+    from oracle.ref_torch_cpu import CpuDGP
+    import torch
+    spec = synthetic.make_spec(L=2, M=16, B=7, K=4, Dx=3, R=2, with_lv=True, seed=5, n_data=500)
+    zs = synthetic.make_noise(spec, seed=6)
+    val = float(CpuDGP(spec, torch.float64).elbo_tensor(zs, mode_vi=True))
+    zs_sn = [np.asarray(z).transpose(1, 0, 2).reshape(-1, z.shape[-1]) for z in zs]
+    ref = build_oracle(spec, iw=False).build_likelihood(zs_sn)
+    assert abs(val - ref) <= 1e-9 * abs(ref), (val, ref)
