@@ -43,3 +43,28 @@ def test_product_path_has_no_cpu_fallback():
     src = "".join(open(os.path.join(ROOT, "dgps_with_iwvi_amd", f)).read()
                   for f in os.listdir(os.path.join(ROOT, "dgps_with_iwvi_amd")) if f.endswith(".py"))
     assert "import oracle" not in src and "from oracle" not in src
+
+
+def test_training_entry_points_refuse_bad_arguments_without_touching_the_gpu():
+    """Argument validation happens before any HIP call: error code + text, on a GPU-less host too."""
+    import ctypes
+    from dgps_with_iwvi_amd import _abi
+    if not os.path.exists(_abi.LIB_PATH):
+        pytest.skip("libiwvi_hip.so not built (run __graft_entry__.build())")
+    lib = _abi.lib()
+    assert lib.iwvi_gp_layer_backward_ws_bytes(0, 128, 8, 5) == 0
+    assert lib.iwvi_gp_layer_backward_ws_bytes(20480, 128, 9, 5) > 20480 * 128 * 4 * 2
+    assert lib.iwvi_natgrad_ws_bytes(0) == 0 and lib.iwvi_natgrad_ws_bytes(128) > 8 * 128 * 128 * 8
+    d = _abi.GpBwdDesc()
+    assert lib.iwvi_gp_layer_backward(ctypes.byref(d), 16, None, None) == -1          # IWVI_ERR_ARG: no workspace
+    assert b"iwvi_gp_layer_backward" in lib.iwvi_last_error()
+    assert lib.iwvi_iw_elbo_backward(None, None, None, 1, None, None, 0, 4, 2, 0.1, 1.0, 0, None, None, None, None, None, None) == -1
+    assert lib.iwvi_lv_layer_backward(None, None, None, None, 0, 0, None, 1, 4, 2, 1, None, None) == -1
+    assert lib.iwvi_natgrad_step(None, None, None, None, 8, 1, 0.1, None, None) == -1
+    arr = (_abi.AdamTensor * 1)()
+    assert lib.iwvi_adam_step(arr, 0, 1e-3, 0.9, 0.999, 1e-8, 1, 1, 0, None) == -1
+    assert lib.iwvi_adam_step(arr, 1, 1e-3, 0.9, 0.999, 1e-8, 1, 1, 0, None) == -1     # null tensor pointers
+    assert b"iwvi_adam_step" in lib.iwvi_last_error()
+    dims = (ctypes.c_int32 * 3)(9, 20, 2)
+    assert lib.iwvi_encoder_backward_ws_bytes(0, dims, 2) == 0 and lib.iwvi_encoder_backward_ws_bytes(64, dims, 2) > 0
+    assert lib.iwvi_encoder_backward(None, 64, None, None, dims, 2, None, None, None, None, None) == -1
