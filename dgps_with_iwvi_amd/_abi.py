@@ -112,6 +112,7 @@ PROTOTYPES = {
     "iwvi_encoder_backward": (c_int, [c_void_p, c_int64, ctypes.POINTER(c_void_p), ctypes.POINTER(c_void_p),
                                       ctypes.POINTER(ctypes.c_int32), c_int, c_void_p,
                                       ctypes.POINTER(c_void_p), ctypes.POINTER(c_void_p), c_void_p, c_void_p]),
+    "iwvi_kde_loglik": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "iwvi_natgrad_ws_bytes": (c_size_t, [c_int]),
     "iwvi_natgrad_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_double, c_void_p, c_void_p]),
     "iwvi_adam_step": (c_int, [ctypes.POINTER(AdamTensor), c_int, c_double, c_double, c_double, c_double, c_int64,

@@ -339,3 +339,46 @@ extern "C" int iwvi_fill_normal_dev(float* out, int64_t n, uint64_t seed, uint64
     if (!state) { set_error("iwvi_fill_normal_dev: null state"); return IWVI_ERR_ARG; }
     return fill_normal_impl(out, n, seed, 0, (unsigned long long*)state, (hipStream_t)stream_);
 }
+
+// ------------------------------------------------------------------------------------------------------------
+// Test log-likelihood of experiments/run_conditional_density_estimation.py:148-169, batched: per test point a
+// Gaussian kernel-density estimate over its S predictive samples with Silverman's bandwidth (:158-162), the log
+// density at the observed y, and the squared error of the sample mean (:165).  One wave per point, lanes over S.
+// ------------------------------------------------------------------------------------------------------------
+namespace iwvi {
+__device__ __forceinline__ double wsum_d(double v) { for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64); return v; }
+__global__ __launch_bounds__(256) void k_kde_loglik(const float* samples, long long sstride, long long nstride, const float* y,
+                                                    long long N, int S, float* logp, float* sqerr, float* stats) {
+    const int lane = threadIdx.x & 63;
+    const long long n = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;
+    const float* s = samples + n * nstride;
+    double sum = 0.0;
+    for (int i = lane; i < S; i += 64) sum += (double)s[i * sstride];
+    const double mean = wsum_d(sum) / S;
+    double ss = 0.0;
+    for (int i = lane; i < S; i += 64) { const double e = (double)s[i * sstride] - mean; ss += e * e; }
+    const double sd = sqrt(wsum_d(ss) / S);                              // np.std: population standard deviation
+    const double bw = 1.06 * sd * pow((double)S, -0.2);                  // Silverman (1986), :158
+    const double yy = (double)y[n];
+    float mx = -INFINITY;
+    for (int i = lane; i < S; i += 64) { const double e = (yy - (double)s[i * sstride]) / bw; mx = fmaxf(mx, (float)(-0.5 * e * e)); }
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    double se = 0.0;
+    for (int i = lane; i < S; i += 64) { const double e = (yy - (double)s[i * sstride]) / bw; se += exp(-0.5 * e * e - (double)mx); }
+    se = wsum_d(se);
+    if (lane == 0) {
+        if (logp) logp[n] = (float)((double)mx + log(se) - log((double)S * bw) - 0.9189385332046727);   // - log sqrt(2 pi)
+        if (sqerr) sqerr[n] = (float)((mean - yy) * (mean - yy));
+        if (stats) { stats[2 * n] = (float)mean; stats[2 * n + 1] = (float)sd; }
+    }
+}
+}  // namespace iwvi
+
+extern "C" int iwvi_kde_loglik(const float* samples, int64_t sample_stride, int64_t point_stride, const float* y,
+                               int64_t N, int S, float* out_logp, float* out_sqerr, float* out_mean_std, void* stream_) {
+    if (!samples || !y || N <= 0 || S <= 1 || sample_stride <= 0 || point_stride <= 0) { iwvi::set_error("iwvi_kde_loglik: bad argument"); return IWVI_ERR_ARG; }
+    hipLaunchKernelGGL(iwvi::k_kde_loglik, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, (hipStream_t)stream_, samples,
+                       (long long)sample_stride, (long long)point_stride, y, (long long)N, S, out_logp, out_sqerr, out_mean_std);
+    return iwvi::check_launch("k_kde_loglik");
+}

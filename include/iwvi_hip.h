@@ -292,6 +292,13 @@ int iwvi_encoder_backward(const float* XY, int64_t rows, const float* const* enc
                           const int32_t* dims, int n_enc, const float* d_out,
                           float* const* dW, float* const* db, void* ws, void* stream);
 
+/* Test log-likelihood of experiments/run_conditional_density_estimation.py:148-169, batched over the test points:
+ * samples: S predictive draws per point (element (s, n) at samples[s*sample_stride + n*point_stride]); y [N].
+ * Gaussian KDE with Silverman's bandwidth 1.06 std S^(-1/5) (:158-162) -> out_logp [N]; squared error of the
+ * sample mean (:165) -> out_sqerr [N]; optional out_mean_std [N, 2].  Outputs may be NULL. */
+int iwvi_kde_loglik(const float* samples, int64_t sample_stride, int64_t point_stride, const float* y,
+                    int64_t N, int S, float* out_logp, float* out_sqerr, float* out_mean_std, void* stream);
+
 /* Optimiser steps of experiments/build_models.py:284-304.
  * iwvi_natgrad_step: GPflow NatGradOptimizer (natural parameterisation) on a whitened (q_mu [M, R], q_sqrt [R, M, M]),
  * in place, float64 inside; dq_mu / dq_sqrt = gradients of the ELBO (the objective that is maximised).
