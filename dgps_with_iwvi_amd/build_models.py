@@ -4,8 +4,9 @@
 ``build_model(ARGS, X, Y)`` with ``ARGS.mode`` in {'VI', 'IWAE'}, ``ARGS.configuration`` such as ``'L1_G5'`` or
 ``'G5_G5'`` ('G<r>': a GP layer of r latent GPs mixed to the input width, 'L<d>': a latent-variable layer of d
 dimensions), ``ARGS.M`` inducing points, ``ARGS.likelihood_variance``, ``ARGS.minibatch_size``,
-``ARGS.num_IW_samples``.  What the reference builds around the model for *training* (natural-gradient + Adam
-ops, SGHMC, the CVAE baseline) belongs to the backward pass (row F1) and is not provided: those modes raise.
+``ARGS.num_IW_samples``.  The training op the reference attaches (``model.train_op``: natural gradient + Adam,
+:270-304) is ``attach_train_op`` over ``training.Trainer`` (row F1); SGHMC and the CVAE baseline are out of scope
+and raise.
 
 Initial values follow the reference: first-layer inducing inputs by k-means of X (or X padded with N(0,1) rows when
 N <= M), deeper layers N(0,1) with their first columns taken from them (:218-219, :239-240); RBF-ARD kernels with

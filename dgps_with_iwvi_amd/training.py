@@ -93,6 +93,7 @@ class Trainer:
 
     def _gradients(self, zs):
         from .sharding import allreduce_gradients
+        self.model.next_minibatch()                              # gpflow.Minibatch: a new batch per session.run (models.py:21-26)
         elbo, g = iw_elbo_and_gradients(self.model, zs)
         g["__elbo__"] = elbo.reshape(1)                          # rides in the same bucket: the job's bound
         g = allreduce_gradients(g, weight=self.shard_weight, group=self.group)

@@ -40,3 +40,13 @@ def test_evaluate_reproduces_the_reference_loop_on_the_same_samples(gpu_device):
     lp, _, ms = evaluation.kde_log_density(smp, torch.as_tensor(np.asarray(Yt[:8], dtype=np.float32), device=gpu_device))
     ref_lp, _ = kde_loglik(smp.cpu().numpy(), Yt[:8])
     np.testing.assert_allclose(lp.cpu().numpy(), ref_lp, rtol=5e-5, atol=5e-5)
+
+
+def test_experiment_end_to_end_trains_and_improves_the_test_log_likelihood(gpu_device):
+    """scripts/run_experiment.py = the reference's experiment script on a synthetic bimodal conditional density:
+    factory -> train_op (NatGrad + Adam, fresh minibatches) -> KDE test log-likelihood."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts"))
+    import run_experiment
+    res = run_experiment.main(["--iterations", "300", "--n_train", "1000", "--n_test", "200", "--num_predict_samples", "500"])
+    assert res["test_loglik"] > res["test_loglik_before_training"] + 0.3, res
+    assert np.isfinite(res["test_rmse"]) and res["ms_per_iteration"] < 50
