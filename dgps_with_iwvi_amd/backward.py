@@ -106,14 +106,17 @@ def gp_backward(layer, saved, d_sample=None, d_mean=None, d_var=None, kl_weight=
     return out
 
 
-def lv_backward(layer, XY, mu, sigma, eps, dF_next, col0, w, B, K, sampled_kl=True):
-    """``iwvi_lv_layer_backward`` + ``iwvi_encoder_backward`` -> (dW list, db list) of the layer's encoder."""
-    dev = mu.device
+def lv_backward(layer, XY, enc_out, eps, dF_next, col0, w, B, K, sampled_kl=True):
+    """``iwvi_lv_layer_backward`` + ``iwvi_encoder_backward`` -> (dW list, db list) of the layer's encoder.
+    ``enc_out`` [B, 2*latent_dim] = (means | raw) as the precompute launch leaves it (``layer._enc_out``)."""
+    dev = enc_out.device
     Lw = layer.latent_dim
     ft = settings.float_type
+    enc_out = _abi.dev_tensor(enc_out, "enc_out")
     d_enc = torch.empty(B, 2 * Lw, dtype=ft, device=dev)
     _abi.check(_abi.lib().iwvi_lv_layer_backward(
-        _abi.ptr(mu), _abi.ptr(sigma), _abi.ptr(eps), _abi.ptr(dF_next), 0 if dF_next is None else dF_next.shape[1], col0,
+        ctypes.c_void_p(enc_out.data_ptr()), ctypes.c_void_p(enc_out.data_ptr() + 4 * Lw), 2 * Lw, 1,
+        _abi.ptr(eps), _abi.ptr(dF_next), 0 if dF_next is None else dF_next.shape[1], col0,
         _abi.ptr(w), Lw, B, K, 1 if sampled_kl else 0, _abi.ptr(d_enc), _abi.stream_ptr()))
     Wp, bp, dims, n, keep = layer.encoder.abi_args()
     dW = [torch.empty_like(t) for t in keep[0]]
@@ -150,35 +153,39 @@ def iw_elbo_and_gradients(model, zs=None, mode_vi=None):
         zs = [None if z is None else z.reshape(K, B, -1).transpose(0, 1).contiguous() for z in zs]
     X = _abi.dev_tensor(model.X.contiguous(), "X")
     Y = _abi.dev_tensor(model.Y.contiguous(), "Y")
-    F = X[:, None, :].expand(B, K, X.shape[1]).reshape(T, -1).contiguous()          # models.py:113
-    XY = XYt = None
-    if any(isinstance(l, LatentVariableLayer) for l in layers):
-        XY = model._xy_minibatch()
-        XYt = XY[:, None, :].expand(B, K, XY.shape[1]).reshape(T, -1).contiguous()
-    words = model._words()
-    precompute_dense(layers)
-    saved = []
-    for layer, z in zip(layers, zs):
-        if isinstance(layer, LatentVariableLayer):
-            Lw = layer.latent_dim
-            eps = draw_normal((T, Lw), dev) if z is None else _abi.dev_tensor(z.reshape(T, Lw).contiguous(), "z")
-            mu, sg = layer.encoder(XY)
-            smp, _, _, kl = layer.propagate(F, XYt, not mode_vi, z=eps)
-            saved.append(("lv", mu.contiguous(), sg.contiguous(), eps, kl.reshape(T, Lw), F.shape[1]))
-            F = smp.reshape(T, -1)
-        elif isinstance(layer, GPLayer):
-            R = layer.num_outputs
-            eps = draw_normal((T, R), dev) if z is None else z.reshape(T, R)
-            s = gp_forward_saved(layer, F, eps, words, precomputed=True)
-            saved.append(("gp", s))
-            F = s.sample
-        else:
+    for layer in layers:
+        if not isinstance(layer, (GPLayer, LatentVariableLayer)):
             raise TypeError("the backward pass knows GPLayer and LatentVariableLayer")
+    has_lv = any(isinstance(l, LatentVariableLayer) for l in layers)
+    XY = model._xy_minibatch() if has_lv else None
+    # forward: one factorisation launch (dense factors, encoders) + ONE fused layer launch that also leaves what the
+    # adjoints need in HBM (a = Lm^-1 k, u_r = L_r^T a, the draws, every layer's output rows)
+    model.precompute(with_encoders=True, dense=True)
+    zflat = [None if z is None else z.reshape(T, -1) for z in zs]
+    _, outs, _ = model._fused_forward(T, K, B, (T,), zs=zflat, sampled_kl=not mode_vi, want_layers=True, want_logw=False,
+                                      want_saved=True)
+    if any(z is None for z in zs):
+        model._words()[1] += 1                                   # the next evaluation draws fresh noise (the ELBO tail, which
+        #                                                          advances the device counter in the forward path, is not run here)
+    saved = []
+    F = None
+    for i, (layer, o) in enumerate(zip(layers, outs)):
+        if F is None and isinstance(layer, GPLayer):                              # first layer: the tiled inputs (models.py:113)
+            F = X[:, None, :].expand(B, K, X.shape[1]).reshape(T, -1).contiguous()
+        if isinstance(layer, LatentVariableLayer):
+            D_in = X.shape[1] if F is None else F.shape[1]
+            saved.append(("lv", layer._enc_out, o["noise_out"], o["kl_local"], D_in))
+        else:
+            s = GpSaved()
+            s.F, s.T, s.A, s.U, s.noise = F, T, o["a_out"], o["u_out"], o["noise_out"]
+            s.sample, s.mean, s.var = o["sample"], o["mean"], o["var"]
+            saved.append(("gp", s))
+        F = o["sample"]
     if saved[-1][0] != "gp":
         raise ValueError("the last layer must be a GPLayer")
     fin = saved[-1][1]
     Dy = Y.shape[1]
-    kls = [s[4] for s in saved if s[0] == "lv"]
+    kls = [s[3] for s in saved if s[0] == "lv"]
     klp = _abi.ptr_array(kls)
     kld = (ctypes.c_int32 * max(len(kls), 1))(*[k.shape[1] for k in kls])
     w = torch.empty(T, dtype=ft, device=dev)
@@ -206,8 +213,8 @@ def iw_elbo_and_gradients(model, zs=None, mode_vi=None):
                     grads["l%d.%s" % (i, k_name)] = g[k_out]
             dF = g.get("dF")
         else:
-            _, mu, sg, eps, _, D_in = s
-            dW, db = lv_backward(layer, XY, mu, sg, eps, dF, D_in, w, B, K, not mode_vi)
+            _, enc_out, eps, _, D_in = s
+            dW, db = lv_backward(layer, XY, enc_out, eps, dF, D_in, w, B, K, not mode_vi)
             for j, (a, b) in enumerate(zip(dW, db)):
                 grads["l%d.encW%d" % (i, j)], grads["l%d.encb%d" % (i, j)] = a, b
             dF = None if (dF is None or i == 0) else dF[:, :D_in].contiguous()

@@ -678,14 +678,16 @@ __global__ __launch_bounds__(256) void k_dsum(const double* part, long long n, d
 
 // LatentVariableLayer (layers.py:83-103): W = mu + eps sigma; d(enc_out) [B, 2 Lw] = sum over the K samples of (dmu | draw)
 struct LvBwdArgs {
-    const float* mu; const float* sigma; const float* eps; const float* dFn; int ld, col0;
+    const float* mu; const float* sigma; int ld_enc, raw; const float* eps; const float* dFn; int ld, col0;
     const float* w; int Lw; long long B; int K, sampled; float* d_out;
 };
 __global__ void k_lv_bwd(LvBwdArgs a) {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= a.B * a.Lw) return;
     const long long b = idx / a.Lw; const int l = (int)(idx - b * a.Lw);
-    const float mu = a.mu[idx], sg = a.sigma[idx];
+    const float mu = a.mu[b * a.ld_enc + l];
+    float sg = a.sigma[b * a.ld_enc + l];
+    if (a.raw) sg = softplus_f(sg - 3.f);
     float dmu = 0.f, dsg = 0.f;
     for (int k = 0; k < a.K; ++k) {
         const long long t = b * a.K + k;
@@ -988,13 +990,13 @@ extern "C" int iwvi_iw_elbo_backward(const float* fmean, const float* fvar, cons
     return check_launch("k_elbo_bwd");
 }
 
-extern "C" int iwvi_lv_layer_backward(const float* mu, const float* sigma, const float* noise,
+extern "C" int iwvi_lv_layer_backward(const float* mu, const float* sigma, int ld_enc, int sigma_is_raw, const float* noise,
                                       const float* dF_next, int ld_next, int col0, const float* w,
                                       int latent_dim, int64_t B, int K, int sampled_kl, float* d_enc_out, void* stream_) {
-    if (!mu || !sigma || !noise || !d_enc_out || latent_dim <= 0 || B <= 0 || K <= 0 || (dF_next && (ld_next < col0 + latent_dim || col0 < 0))) {
+    if (!mu || !sigma || !noise || !d_enc_out || latent_dim <= 0 || ld_enc < latent_dim || B <= 0 || K <= 0 || (dF_next && (ld_next < col0 + latent_dim || col0 < 0))) {
         set_error("iwvi_lv_layer_backward: bad argument"); return IWVI_ERR_ARG;
     }
-    LvBwdArgs a{mu, sigma, noise, dF_next, ld_next, col0, w, latent_dim, B, K, sampled_kl, d_enc_out};
+    LvBwdArgs a{mu, sigma, ld_enc, sigma_is_raw, noise, dF_next, ld_next, col0, w, latent_dim, B, K, sampled_kl, d_enc_out};
     hipLaunchKernelGGL(k_lv_bwd, dim3((unsigned)((B * latent_dim + 63) / 64)), dim3(64), 0, (hipStream_t)stream_, a);
     return check_launch("k_lv_bwd");
 }

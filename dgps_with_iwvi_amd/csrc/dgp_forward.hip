@@ -1528,7 +1528,6 @@ int dgp_forward_impl(const iwvi_layer_desc* layers, int n_layers, const float* X
             if (d.mf_type == IWVI_MF_LINEAR && !d.mf_A) { set_error("iwvi_gp_layer_forward: Linear mean function without A"); return IWVI_ERR_ARG; }
             if (d.mf_type < IWVI_MF_ZERO || d.mf_type > IWVI_MF_LINEAR) { set_error("iwvi_gp_layer_forward: unknown mean function %d", d.mf_type); return IWVI_ERR_UNSUPPORTED; }
             if (d.kern_type != IWVI_KERN_RBF && d.kern_type != IWVI_KERN_MATERN52) { set_error("iwvi_gp_layer_forward: unknown kernel type %d", d.kern_type); return IWVI_ERR_UNSUPPORTED; }
-            if ((d.a_out || d.u_out) && n_layers != 1) { set_error("iwvi_dgp_forward: a_out / u_out are single-layer outputs"); return IWVI_ERR_ARG; }
             const StateLayout s = state_layout(d.M, d.R);
             const char* st = (const char*)d.state;
             FwGp& G = L.gp;

@@ -80,7 +80,7 @@ class DGP_VI:
         return self._dev_words
 
     # -- reference API ------------------------------------------------------------------------
-    def precompute(self, with_encoders=False, sample_first=None):
+    def precompute(self, with_encoders=False, sample_first=None, dense=False):
         """Gram + Cholesky + operand packing of every GP layer: one ABI call, one launch.  ``with_encoders``:
         the same launch also evaluates the encoder MLP of every latent-variable layer on the current minibatch
         (it does not depend on the factorisation, so it runs beside it instead of inside the layer kernel).
@@ -98,7 +98,11 @@ class DGP_VI:
                     encs.append(e)
                     keep.append(k)
                     l._enc_key = self._mb_key()
-        precompute_states([l.state_desc() for l in self.layers if isinstance(l, GPLayer)], encs)
+        descs = [l.state_desc() for l in self.layers if isinstance(l, GPLayer)]
+        if dense:                                                    # the adjoints read the dense float64 Lm, Lm^-1
+            for d in descs:
+                d.flags = _abi.GP_WANT_DENSE
+        precompute_states(descs, encs)
 
     def propagate(self, X, full_cov=False, inference_amorization_inputs=None,
                   is_sampled_local_regularizer=False, zs=None, _precomputed=False, _kl_parts=False):
@@ -123,7 +127,7 @@ class DGP_VI:
 
     # -- fused forward ------------------------------------------------------------------------
     def _fused_forward(self, T, row_div, row_mod, lead, zs=None, sampled_kl=True, want_layers=False,
-                       want_logw=True, use_encoder=True, elbo=None, stack_from=0):
+                       want_logw=True, use_encoder=True, elbo=None, stack_from=0, want_saved=False):
         """``iwvi_dgp_forward`` over the current minibatch: every layer + log-weights in one launch.
         Row t of the flattened batch reads data row (t // row_div) % row_mod.  ``elbo`` = dict(B, K, stride_b,
         stride_k, mode_vi, want_ms, K_total): also run the reduction of models.py:138-150 in the tail of the
@@ -158,6 +162,11 @@ class DGP_VI:
                 if want_layers:
                     P = layer.kern.W.shape[0] if hasattr(layer.kern, "W") else R
                     o = {k: torch.empty(*lead, P, dtype=settings.float_type, device=dev) for k in ("sample", "mean", "var")}
+                    if want_saved:                               # what the adjoint of this layer needs (backward.py)
+                        Mp = layer.state().Mp
+                        o["a_out"] = torch.empty(T, Mp, dtype=settings.float_type, device=dev)
+                        o["u_out"] = torch.empty(R, T, Mp, dtype=settings.float_type, device=dev)
+                        o["noise_out"] = torch.empty(T, R, dtype=settings.float_type, device=dev)
                 d, k = layer.fused_desc(z2, o)
                 if d.D != D:
                     raise ValueError("layer %d expects %d inputs, got %d" % (i, d.D, D))
@@ -169,6 +178,8 @@ class DGP_VI:
                 if want_layers:
                     o = {k: torch.empty(*lead, D + Lw, dtype=settings.float_type, device=dev) for k in ("sample", "mean", "var")}
                     o["kl_local"] = torch.empty(*lead, Lw, dtype=settings.float_type, device=dev)
+                    if want_saved:
+                        o["noise_out"] = torch.empty(T, Lw, dtype=settings.float_type, device=dev)
                 # encoder output of THIS minibatch from the last precompute launch, if there is one
                 eo = layer._enc_out if (use_encoder and getattr(layer, "_enc_key", None) == self._mb_key()) else None
                 d, k = layer.fused_desc(D, z2, o, sampled_kl=sampled_kl, use_encoder=use_encoder, enc_out=eo)

@@ -208,7 +208,7 @@ typedef struct iwvi_layer_desc {
     float* noise_out;
     float* sample; float* mean; float* var;
     float* kl_local;
-    float* a_out; float* u_out;     /* GP, single-layer calls only: A [T, Mp], L_r^T A [R, T, Mp] */
+    float* a_out; float* u_out;     /* GP, optional (what the adjoint needs): A [T, Mp], L_r^T A [R, T, Mp] */
 } iwvi_layer_desc;
 
 /* Optional tail of the same launch: the last workgroup to finish performs models.py:138-150 on out_logw
@@ -281,8 +281,10 @@ int iwvi_iw_elbo_backward(const float* fmean, const float* fvar, const float* Y,
 /* Adjoint of the LatentVariableLayer (layers.py:83-103): mu, sigma [B, latent_dim] (the encoder's outputs per data
  * row), noise [T, latent_dim] (the draws), dF_next [T, ld_next] = gradient w.r.t. the layer's output rows (columns
  * col0 .. col0+latent_dim-1 are W's; may be NULL), w [T] = d ELBO / d L_nk (the regulariser enters with -1; may be
- * NULL).  d_enc_out [B, 2*latent_dim] = gradient w.r.t. the encoder's (means | raw) output. */
-int iwvi_lv_layer_backward(const float* mu, const float* sigma, const float* noise,
+ * NULL).  d_enc_out [B, 2*latent_dim] = gradient w.r.t. the encoder's (means | raw) output.  mu / sigma rows have stride
+ * ld_enc; sigma_is_raw != 0: `sigma` holds the encoder's raw output (sigma = softplus(raw - 3)), so that the [B, 2*latent_dim]
+ * block iwvi_model_precompute leaves can be passed as (out, out + latent_dim, 2*latent_dim, 1). */
+int iwvi_lv_layer_backward(const float* mu, const float* sigma, int ld_enc, int sigma_is_raw, const float* noise,
                            const float* dF_next, int ld_next, int col0, const float* w,
                            int latent_dim, int64_t B, int K, int sampled_kl, float* d_enc_out, void* stream);
 
