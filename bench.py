@@ -81,6 +81,32 @@ class Step:
         return self.out
 
 
+def training_leg(model, samples, iters=20):
+    """Informational, outside the timed region of the headline metric: the same workload through the backward pass
+     -- one IW-ELBO value + gradient evaluation, and one training step of the reference
+    (NatGrad op + Adam op = two gradient evaluations, experiments/build_models.py:297-300), eager launches."""
+    try:
+        from dgps_with_iwvi_amd import backward
+        from dgps_with_iwvi_amd.training import Trainer
+
+        def timed(fn):
+            fn(); fn()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(iters):
+                fn()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) / iters * 1e3
+
+        grad_ms = timed(lambda: backward.iw_elbo_and_gradients(model))
+        tr = Trainer(model)
+        step_ms = timed(tr.step)
+        return {"value_and_gradient_ms": grad_ms, "gradient_samples_per_s": samples / grad_ms * 1e3, "train_step_ms": step_ms,
+                "note": "layer-by-layer adjoint kernels, first version (DESIGN.md section 5b); runs after the timed region and changes the model's parameters"}
+    except Exception as e:                                   # never let the informational leg take the bench line down
+        return {"error": "%s: %s" % (type(e).__name__, e)}
+
+
 def cpu_baseline(spec, seconds=12.0):
     """The reference-equivalent CPU path (oracle/ref_torch_cpu.py, float64 like the reference) timed on
     this host's cores on the SAME workload; bounded to ~`seconds` of CPU work.  The thread count is the
@@ -126,6 +152,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--no-train-leg", action="store_true", help="skip the (informational) training-step timing")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -308,6 +335,8 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(spec, args.cpu_seconds)
             res["gpu_over_cpu"] = res["value"] / res["cpu_baseline"]["value"]
+        if world == 1 and not args.no_train_leg:
+            res["training_step"] = training_leg(model, B * K)
         print(json.dumps(res))
     if dist is not None:
         dist.destroy_process_group()
