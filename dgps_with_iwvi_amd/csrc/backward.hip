@@ -14,6 +14,7 @@
 // and the closed-form gradient of the whitened KL (temp_workaround.py:186-188) with weight -kl_weight.
 #include "iwvi_common.h"
 #include <cmath>
+#include <cstdlib>
 
 namespace iwvi {
 
@@ -195,7 +196,107 @@ __global__ __launch_bounds__(256) void k_gemm_fast(GemmArgs g) {
         }
     }
 }
+// Larger tiles for the same job when M and N allow it: 128x128 per workgroup, 16-deep stages, each wave a 64x64 quadrant as
+// 2x2 v_mfma_f32_32x32x2_f32 tiles (64 accumulator registers): four times the MFMA work per barrier and per byte staged of
+// the 64x64 kernel, whose MFMA pipe was measured 20 % busy.
+constexpr int BT = 128, BK = 16, BLD = BT + 4;
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+template <bool A_KC, bool B_NC>
+__global__ __launch_bounds__(256) void k_gemm_big(GemmArgs g) {
+    __shared__ __attribute__((aligned(16))) float As[2][BK][BLD];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BK][BLD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+    const int m0 = blockIdx.y * BT, n0 = blockIdx.x * BT;
+    if (g.tri_out && n0 > m0) return;
+    const int batch = (int)blockIdx.z / g.nsplit, split = (int)blockIdx.z - batch * g.nsplit;
+    const int kb = split * g.kchunk;
+    const int ke = (kb + g.kchunk < g.K) ? kb + g.kchunk : g.K;
+    const float* Bb = g.B + batch * g.b_batch;
+    const float* Sb = g.scale ? g.scale + batch * g.s_batch : nullptr;
+    // two slots per operand per stage (j = 0, 1).  k-contiguous: (row = tid/4 + 64 j, k = 4*(tid%4)..+3);
+    // row-contiguous: (k = tid/32 + 8 j, row = 4*(tid%32)..+3)
+    const int am = A_KC ? tid >> 2 : (tid & 31) * 4, ak = A_KC ? (tid & 3) * 4 : tid >> 5;
+    const int bn = B_NC ? (tid & 31) * 4 : tid >> 2, bk = B_NC ? tid >> 5 : (tid & 3) * 4;
+    constexpr int AMJ = A_KC ? 64 : 0, AKJ = A_KC ? 0 : 8, BNJ = B_NC ? 0 : 64, BKJ = B_NC ? 8 : 0;
+    f32x4 ra[2], rb[2];
+    auto fetch = [&](int k0) {
+        const int seg = k0 / g.kseg, kl = k0 - seg * g.kseg;
+        const float* A = g.A + seg * g.a_seg; const float* B = Bb + seg * g.b_seg;
+        const float* S = Sb ? Sb + seg * g.s_seg : nullptr;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int m = m0 + am + AMJ * j, ka = kl + ak + AKJ * j, n = n0 + bn + BNJ * j, kq = kl + bk + BKJ * j;
+            ra[j] = *reinterpret_cast<const f32x4*>(A + (long long)m * g.a_sm + (long long)ka * g.a_sk);
+            rb[j] = *reinterpret_cast<const f32x4*>(B + (long long)kq * g.b_sk + (long long)n * g.b_sn);
+            if (S) {
+                if (g.scale_on_k) {
+                    if (A_KC) for (int e = 0; e < 4; ++e) ra[j][e] *= S[(long long)(ka + e) * g.s_stride];
+                    else ra[j] *= S[(long long)ka * g.s_stride];
+                } else {
+                    if (A_KC) ra[j] *= S[(long long)m * g.s_stride];
+                    else for (int e = 0; e < 4; ++e) ra[j][e] *= S[(long long)(m + e) * g.s_stride];
+                }
+            }
+            if (g.b_keep_n_ge_k)
+                for (int e = 0; e < 4; ++e) { const int nn = n + (B_NC ? e : 0), kk = kq + (B_NC ? 0 : e); if (nn < kk) rb[j][e] = 0.f; }
+        }
+    };
+    auto stash = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int m = am + AMJ * j, ka = ak + AKJ * j, n = bn + BNJ * j, kq = bk + BKJ * j;
+            if (A_KC) for (int e = 0; e < 4; ++e) As[buf][ka + e][m] = ra[j][e];
+            else *reinterpret_cast<f32x4*>(&As[buf][ka][m]) = ra[j];
+            if (B_NC) *reinterpret_cast<f32x4*>(&Bs[buf][kq][n]) = rb[j];
+            else for (int e = 0; e < 4; ++e) Bs[buf][kq + e][n] = rb[j][e];
+        }
+    };
+    f32x16 acc[2][2];
+    for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
+    int lo = kb, ns = (ke - kb) / BK;
+    if (g.nsplit == 1) {
+        lo = g.b_lower_kn ? n0 : 0;
+        const int hi = g.b_keep_n_ge_k ? (n0 + BT < g.kseg ? n0 + BT : g.kseg) : g.kseg;
+        ns = hi > lo ? (hi - lo) / BK : 0;
+    }
+    const int nstage = (g.nsplit == 1) ? ns * (g.K / g.kseg) : ns;
+    auto stage_k = [&](int i) { if (g.nsplit > 1) return lo + BK * i; const int seg = i / ns; return seg * g.kseg + lo + BK * (i - seg * ns); };
+    if (nstage > 0) { fetch(stage_k(0)); stash(0); }
+    __syncthreads();
+    int buf = 0;
+    for (int i = 0; i < nstage; ++i, buf ^= 1) {
+        const bool more = i + 1 < nstage;
+        if (more) fetch(stage_k(i + 1));
+#pragma unroll
+        for (int kk = 0; kk < BK / 2; ++kk) {
+            const int kr = 2 * kk + (lane >> 5);
+            const float a0 = As[buf][kr][wm + (lane & 31)], a1 = As[buf][kr][wm + 32 + (lane & 31)];
+            const float b0 = Bs[buf][kr][wn + (lane & 31)], b1 = Bs[buf][kr][wn + 32 + (lane & 31)];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        if (more) stash(buf ^ 1);
+        __syncthreads();
+    }
+    float* part = g.part ? g.part + ((size_t)batch * g.nsplit + split) * g.M * g.N : nullptr;
+    for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int v = 0; v < 16; ++v) {
+        // 32x32 accumulator: register v of lane l = row 8*(v/4) + 4*(l/32) + v%4, column l%32
+        const int m = m0 + wm + 32 * i + 8 * (v >> 2) + 4 * (lane >> 5) + (v & 3), n = n0 + wn + 32 * j + (lane & 31);
+        if (part) part[(size_t)m * g.N + n] = acc[i][j][v];
+        else {
+            float* c = g.C + m * g.ldc + n;
+            *c = g.alpha * acc[i][j][v] + (g.beta != 0.f ? g.beta * *c : 0.f);
+        }
+    }
+}
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+static bool use_big_tiles(const GemmArgs& g) {
+    if (g.M % BT || g.N % BT || getenv("IWVI_BW_SMALL_TILES")) return false;
+    return (long long)(g.M / BT) * (g.N / BT) * g.nsplit * g.nbatch >= 512;
+}
 // launch on the fast path if the shapes allow it; returns false otherwise (caller falls back to k_gemm)
 static bool launch_fast(hipStream_t st, const GemmArgs& g) {
     const bool a_kc = g.a_sk == 1, a_mc = g.a_sm == 1, b_nc = g.b_sn == 1, b_kc = g.b_sk == 1;
@@ -204,6 +305,16 @@ static bool launch_fast(hipStream_t st, const GemmArgs& g) {
     if (g.kseg != g.K && g.kchunk % g.kseg && g.kseg % g.kchunk) return false;
     const long long a_ld = a_kc ? g.a_sm : g.a_sk, b_ld = b_nc ? g.b_sk : g.b_sn;
     if (a_ld % 4 || b_ld % 4 || g.a_seg % 4 || g.b_seg % 4 || g.b_batch % 4 || !aligned16(g.A) || !aligned16(g.B)) return false;
+    // 128x128 tiles only when they still give every CU two workgroups (measured: at M = 128 / T = 20480 -- 160 big tiles --
+    // they are 10 % slower than the 64x64 ones, at M = 256 / T = 204800 2 % faster)
+    if (use_big_tiles(g)) {
+        const dim3 gridb(g.N / BT, g.M / BT, g.nsplit * g.nbatch), blockb(256);
+        if (a_kc && b_nc) hipLaunchKernelGGL((k_gemm_big<true, true>), gridb, blockb, 0, st, g);
+        else if (a_kc) hipLaunchKernelGGL((k_gemm_big<true, false>), gridb, blockb, 0, st, g);
+        else if (b_nc) hipLaunchKernelGGL((k_gemm_big<false, true>), gridb, blockb, 0, st, g);
+        else hipLaunchKernelGGL((k_gemm_big<false, false>), gridb, blockb, 0, st, g);
+        return true;
+    }
     const dim3 grid(g.N / GT, g.M / GT, g.nsplit * g.nbatch), block(256);
     if (a_kc && b_nc) hipLaunchKernelGGL((k_gemm_fast<true, true>), grid, block, 0, st, g);
     else if (a_kc) hipLaunchKernelGGL((k_gemm_fast<true, false>), grid, block, 0, st, g);
@@ -586,7 +697,7 @@ struct BwdWs {
 static BwdWs bwd_layout(char* base, long long T, int M, int D, int R) {
     BwdWs w; size_t o = 0;
     auto take = [&](size_t bytes) { char* p = base ? base + o : nullptr; o = align256(o + bytes); return p; };
-    const int nsplit = (int)((T + 511) / 512) + 2;
+    const int nsplit = (int)((T + 255) / 256) + 2;
     w.DMU = (float*)take(sizeof(float) * T * R); w.DV2 = (float*)take(sizeof(float) * T * R); w.SDV = (float*)take(sizeof(float) * T);
     w.DA = (float*)take(sizeof(float) * T * M); w.DK = (float*)take(sizeof(float) * T * M);
     w.Qx = (float*)take(sizeof(float) * T * (D + 2));
