@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libiwvi_hip.so")
 
 KERN_RBF, KERN_MATERN52 = 0, 1
 LAYER_GP, LAYER_LV = 0, 1
-ABI_VERSION = 3
+ABI_VERSION = 4
 GP_WANT_DENSE = 1
 MAX_STACK = 8
 MF_ZERO, MF_IDENTITY, MF_LINEAR = 0, 1, 2
@@ -58,7 +58,7 @@ class LayerDesc(ctypes.Structure):
                 ("enc_out", c_void_p),
                 ("noise", c_void_p), ("zero_noise", ctypes.c_int32), ("noise_out", c_void_p),
                 ("sample", c_void_p), ("mean", c_void_p), ("var", c_void_p), ("kl_local", c_void_p),
-                ("a_out", c_void_p), ("u_out", c_void_p)]
+                ("a_out", c_void_p), ("u_out", c_void_p), ("gmv_out", c_void_p)]
 
 
 class ElboDesc(ctypes.Structure):
@@ -77,7 +77,7 @@ class GpBwdDesc(ctypes.Structure):
                 ("q_sqrt", c_void_p), ("variance", c_float),
                 ("M", ctypes.c_int32), ("D", ctypes.c_int32), ("R", ctypes.c_int32), ("P", ctypes.c_int32),
                 ("kern_type", ctypes.c_int32), ("W", c_void_p), ("mf_type", ctypes.c_int32), ("mf_A", c_void_p),
-                ("F", c_void_p), ("noise", c_void_p), ("A", c_void_p), ("U", c_void_p),
+                ("F", c_void_p), ("noise", c_void_p), ("A", c_void_p), ("U", c_void_p), ("GMV", c_void_p),
                 ("d_sample", c_void_p), ("d_mean", c_void_p), ("d_var", c_void_p), ("kl_weight", c_double),
                 ("dF", c_void_p), ("dZ", c_void_p), ("dls", c_void_p), ("dvariance", c_void_p),
                 ("dq_mu", c_void_p), ("dq_sqrt", c_void_p), ("dW", c_void_p), ("dmf_A", c_void_p)]

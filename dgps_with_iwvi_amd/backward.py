@@ -15,7 +15,7 @@ from .temp_workaround import precompute_states
 
 class GpSaved:
     """What one GP layer's forward leaves for its adjoint."""
-    __slots__ = ("F", "noise", "A", "U", "sample", "mean", "var", "T")
+    __slots__ = ("F", "noise", "A", "U", "sample", "mean", "var", "T", "GMV")
 
 
 def _words(device):
@@ -46,7 +46,7 @@ def gp_forward_saved(layer, F, z=None, words=None, precomputed=False):
     R, Mp = layer.num_outputs, layer.state().Mp
     P = layer.kern.W.shape[0] if isinstance(layer.kern, SharedMixedMok) else R
     s = GpSaved()
-    s.F, s.T = F, T
+    s.F, s.T, s.GMV = F, T, None
     s.A = torch.empty(T, Mp, dtype=settings.float_type, device=dev)
     s.U = torch.empty(R, T, Mp, dtype=settings.float_type, device=dev)
     s.noise = torch.empty(T, R, dtype=settings.float_type, device=dev)
@@ -93,6 +93,8 @@ def gp_backward(layer, saved, d_sample=None, d_mean=None, d_var=None, kl_weight=
     if mf.mf_type == _abi.MF_LINEAR:
         b.mf_A = _abi.dev_tensor(mf.A, "mean_function.A").data_ptr()
     b.F, b.noise, b.A, b.U = saved.F.data_ptr(), saved.noise.data_ptr(), saved.A.data_ptr(), saved.U.data_ptr()
+    if saved.GMV is not None:
+        b.GMV = saved.GMV.data_ptr()
     for name, t in (("d_sample", d_sample), ("d_mean", d_mean), ("d_var", d_var)):
         if t is not None:
             t = _abi.dev_tensor(t.reshape(T, P).contiguous(), name)
@@ -177,7 +179,7 @@ def iw_elbo_and_gradients(model, zs=None, mode_vi=None):
             saved.append(("lv", layer._enc_out, o["noise_out"], o["kl_local"], D_in))
         else:
             s = GpSaved()
-            s.F, s.T, s.A, s.U, s.noise = F, T, o["a_out"], o["u_out"], o["noise_out"]
+            s.F, s.T, s.A, s.U, s.noise, s.GMV = F, T, o["a_out"], o["u_out"], o["noise_out"], o["gmv_out"]
             s.sample, s.mean, s.var = o["sample"], o["mean"], o["var"]
             saved.append(("gp", s))
         F = o["sample"]

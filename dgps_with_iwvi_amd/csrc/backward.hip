@@ -397,6 +397,7 @@ struct HeadArgs {
     float* DMU; float* DV2; float* SDV; float* dF;
     long long T; int M, Mp, D, R, P, mf_type; float variance;
     const float* q_mu; float* GMV;      // optional [T, 3R] = (g_r | mu_r | v_r) per sample, for the mixing matrix's gradient
+    const float* gmv_in;                // optional: the same block as the forward left it (then A and U are not read here)
 };
 __device__ __forceinline__ float wave_sum(float v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -408,15 +409,19 @@ __global__ __launch_bounds__(256) void k_bw_heads(HeadArgs h) {
     if (t >= h.T) return;
     const float* a = h.A + t * h.Mp;
     float aa = 0.f;
-    for (int m = lane; m < h.M; m += 64) aa = fmaf(a[m], a[m], aa);
-    aa = wave_sum(aa);
+    if (!h.gmv_in) {
+        for (int m = lane; m < h.M; m += 64) aa = fmaf(a[m], a[m], aa);
+        aa = wave_sum(aa);
+    }
     float mine_dv = 0.f, mine_dmu = 0.f;                  // lane r keeps latent r's heads
     for (int r = 0; r < h.R; ++r) {
-        const float* u = h.U + ((size_t)r * h.T + t) * h.Mp;
         float uu = 0.f;
-        for (int m = lane; m < h.M; m += 64) uu = fmaf(u[m], u[m], uu);
-        uu = wave_sum(uu);
-        if (h.GMV) {
+        if (!h.gmv_in) {
+            const float* u = h.U + ((size_t)r * h.T + t) * h.Mp;
+            for (int m = lane; m < h.M; m += 64) uu = fmaf(u[m], u[m], uu);
+            uu = wave_sum(uu);
+        }
+        if (h.GMV && !h.gmv_in) {
             float mu = 0.f;
             for (int m = lane; m < h.M; m += 64) mu = fmaf(a[m], h.q_mu[m * h.R + r], mu);
             mu = wave_sum(mu);
@@ -439,7 +444,7 @@ __global__ __launch_bounds__(256) void k_bw_heads(HeadArgs h) {
             if (h.dFm) dm = h.dFm[t * h.P + r];
             if (h.dFv) dvv = h.dFv[t * h.P + r];
         }
-        const float v = h.variance - aa + uu;
+        const float v = h.gmv_in ? h.gmv_in[t * 3 * h.R + 2 * h.R + r] : h.variance - aa + uu;
         float dv = dvv;
         if (v > 0.f) { if (h.eps) dv += dg * h.eps[t * h.R + r] * 0.5f / sqrtf(v); } else dv = 0.f;   // the forward clamps v at 0
         if (lane == r) { mine_dv = dv; mine_dmu = dg + dm; }
@@ -998,7 +1003,8 @@ extern "C" int iwvi_gp_layer_backward(const iwvi_gp_bwd_desc* dp, int64_t T, voi
         hipLaunchKernelGGL(k_prep, dim3((n + 255) / 256), dim3(256), 0, st, d.Z, d.lengthscales, Linv64, Mp, w.Zt, w.invls, w.LinvF, M, D);
     }
     HeadArgs h{d.A, d.U, d.noise, d.W, d.mf_A, d.d_sample, d.d_mean, d.d_var, w.DMU, w.DV2, w.SDV, d.dF, T, M, Mp, D, R, d.P, d.mf_type, d.variance,
-               d.q_mu, (d.dW && d.W) ? w.GMV : nullptr};
+               d.q_mu, (d.dW && d.W && !d.GMV) ? w.GMV : nullptr, d.GMV};
+    const float* gmv = d.GMV ? d.GMV : w.GMV;
     hipLaunchKernelGGL(k_bw_heads, dim3((unsigned)((T + 3) / 4)), dim3(256), 0, st, h);
     if ((rc = check_launch("k_bw_heads")) != IWVI_OK) return rc;
     // DA = DMU q_mu^T - 2 SDV o A
@@ -1063,7 +1069,7 @@ extern "C" int iwvi_gp_layer_backward(const iwvi_gp_bwd_desc* dp, int64_t T, voi
         const float* ups[3] = {d.d_sample, d.d_mean, d.d_var};
         if (d.dW && d.W) for (int i = 0; i < 3; ++i) if (ups[i]) {
             s[i] = w.lin + i * IWVI_MAX_P * IWVI_MAX_R;
-            if ((rc = thin(st, ups[i], P, P, w.GMV + i * R, 3 * R, R, 0, T, w.part, w.part_floats, s[i])) != IWVI_OK) return rc;
+            if ((rc = thin(st, ups[i], P, P, gmv + i * R, 3 * R, R, 0, T, w.part, w.part_floats, s[i])) != IWVI_OK) return rc;
         }
         if (d.dmf_A && d.mf_type == IWVI_MF_LINEAR) for (int i = 0; i < 2; ++i) if (ups[i]) {
             a12[i] = w.lin + 3 * IWVI_MAX_P * IWVI_MAX_R + i * IWVI_MAX_D * IWVI_MAX_P;

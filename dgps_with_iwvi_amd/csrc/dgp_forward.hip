@@ -86,7 +86,8 @@ struct FwLv {
     int nx_gp, nx_c_off, nx_nsteps, nx_rbf; \
     int nx_ls_off, nx_ls_n;           /* the next staged solve stream: LDS offset (or -1) and length in floats */ \
     const float* nx_ls; \
-    const float* noise; float* noise_out; float* sample; float* mean; float* var;
+    const float* noise; float* noise_out; float* sample; float* mean; float* var; \
+    float* gmv_out; float* spare_;    /* GP: [T, 3R] = (sample | mean | variance) of the latent GPs before mixing */
 struct alignas(16) FwLayerHead { FW_LAYER_HEAD };
 struct FwLayer {
     FW_LAYER_HEAD
@@ -1034,9 +1035,14 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
                 const float v = fmaxf(G.variance - (asq[j] + asq[NSAMP + j]) + u2, 0.f);
                 const float z = (j < nvalid) ? zl[r * NSAMP + j] : 0.f;
                 if (o_noise && j < nvalid) o_noise[(t0 + j) * R + r] = z;
+                const float gs = fmaf(z, sqrtf(v), mu);
                 gbuf[(0 * R + r) * NSAMP + j] = mu;
                 gbuf[(1 * R + r) * NSAMP + j] = v;
-                gbuf[(2 * R + r) * NSAMP + j] = fmaf(z, sqrtf(v), mu);
+                gbuf[(2 * R + r) * NSAMP + j] = gs;
+                if (H.gmv_out && j < nvalid) {                   // what the adjoint's heads need per latent GP (csrc/backward.hip)
+                    const gout1 o = (gout1)H.gmv_out + (size_t)(t0 + j) * 3 * R;
+                    o[r] = gs; o[R + r] = mu; o[2 * R + r] = v;
+                }
             }
             __syncthreads();
             FW_STAMP(2 + li * 6 + 4);
@@ -1516,6 +1522,7 @@ int dgp_forward_impl(const iwvi_layer_desc* layers, int n_layers, const float* X
         FwLayer& L = a.L[i];
         L.type = d.type; L.D = D; L.zero_noise = d.zero_noise;
         L.noise = d.noise; L.noise_out = d.noise_out; L.sample = d.sample; L.mean = d.mean; L.var = d.var;
+        L.gmv_out = (d.type == IWVI_LAYER_GP) ? d.gmv_out : nullptr;
         if (!d.noise && !d.zero_noise) need_rng = true;
         if (d.type == IWVI_LAYER_GP) {
             if (d.D != D) { set_error("iwvi_dgp_forward: layer %d expects D=%d but its input has %d columns", i, d.D, D); return IWVI_ERR_ARG; }

@@ -167,6 +167,7 @@ class DGP_VI:
                         o["a_out"] = torch.empty(T, Mp, dtype=settings.float_type, device=dev)
                         o["u_out"] = torch.empty(R, T, Mp, dtype=settings.float_type, device=dev)
                         o["noise_out"] = torch.empty(T, R, dtype=settings.float_type, device=dev)
+                        o["gmv_out"] = torch.empty(T, 3 * R, dtype=settings.float_type, device=dev)
                 d, k = layer.fused_desc(z2, o)
                 if d.D != D:
                     raise ValueError("layer %d expects %d inputs, got %d" % (i, d.D, D))

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define IWVI_ABI_VERSION 3
+#define IWVI_ABI_VERSION 4
 
 enum {
     IWVI_OK = 0,
@@ -209,6 +209,7 @@ typedef struct iwvi_layer_desc {
     float* sample; float* mean; float* var;
     float* kl_local;
     float* a_out; float* u_out;     /* GP, optional (what the adjoint needs): A [T, Mp], L_r^T A [R, T, Mp] */
+    float* gmv_out;                 /* GP, optional: [T, 3R] = (sample | mean | variance) of the R latent GPs before mixing */
 } iwvi_layer_desc;
 
 /* Optional tail of the same launch: the last workgroup to finish performs models.py:138-150 on out_logw
@@ -247,6 +248,7 @@ int iwvi_dgp_forward(const iwvi_layer_desc* layers_host, int n_layers,
  *   F [T, D]               the layer's input rows (per sample)
  *   noise [T, R]           the draws the forward used (needed when d_sample is given)
  *   A [T, Mp], U [R, T, Mp]  a = Lm^-1 k and u_r = L_r^T a as the forward wrote them (a_out / u_out)
+ *   GMV [T, 3R]            optional, the forward's gmv_out
  *   d_sample/d_mean/d_var [T, P]  upstream gradients, any may be NULL (= 0)
  *   kl_weight              the objective contains -kl_weight * KL[q(u)||p(u)] of this layer (1 for the ELBO)
  *   outputs (any may be NULL): dF [T, D], dZ [M, D], dls [D], dvariance [1], dq_mu [M, R],
@@ -260,6 +262,7 @@ typedef struct iwvi_gp_bwd_desc {
     int32_t M, D, R, P, kern_type;
     const float* W; int32_t mf_type; const float* mf_A;
     const float* F; const float* noise; const float* A; const float* U;
+    const float* GMV;               /* optional: the forward's gmv_out [T, 3R]; spares the adjoint a pass over A and U */
     const float* d_sample; const float* d_mean; const float* d_var;
     double kl_weight;
     float* dF; float* dZ; float* dls; float* dvariance; float* dq_mu; float* dq_sqrt;
