@@ -487,39 +487,55 @@ struct KernArgs { const float* F; const float* Zt; const float* invls; const flo
                   long long T; int M, D; float variance; };
 template <int DM>                       // D <= DM: the per-dimension arrays stay in registers
 __global__ __launch_bounds__(256) void k_bw_kernel(KernArgs a) {
-    const int lane = threadIdx.x & 63;
-    const long long t = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (t >= a.T) return;
+    // 16 lanes per sample (16 samples per workgroup): lane `sub` takes columns m0 + 4 sub .. + 3 of every 64-column step
+    // (one float4 of dK in, one of c out: a sample's row moves as full 256-byte segments), and the D + 2 per-sample sums
+    // are 4-step reductions inside the 16-lane group.
+    const int sub = threadIdx.x & 15;
+    const long long t = (long long)blockIdx.x * 16 + (threadIdx.x >> 4);
+    const bool live = t < a.T;
+    const long long tt = live ? t : a.T - 1;
+    auto gsum = [](float v) { for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64); return v; };
     float xt[DM], cz[DM];
 #pragma unroll
-    for (int d = 0; d < DM; ++d) { xt[d] = d < a.D ? a.F[t * a.D + d] * a.invls[d] : 0.f; cz[d] = 0.f; }
+    for (int d = 0; d < DM; ++d) { xt[d] = d < a.D ? a.F[tt * a.D + d] * a.invls[d] : 0.f; cz[d] = 0.f; }
     float sc = 0.f, skd = 0.f;
-    for (int m = lane; m < a.M; m += 64) {
-        float d2 = 0.f, z[DM];
+    const bool vec = (a.M & 3) == 0;
+    for (int m0 = 0; m0 < a.M; m0 += 64) {
+        const int mb = m0 + 4 * sub;
+        float dk[4] = {0.f, 0.f, 0.f, 0.f}, c[4];
+        if (vec) { if (mb < a.M) { const f32x4 v = *reinterpret_cast<const f32x4*>(a.DK + tt * a.M + mb); dk[0] = v[0]; dk[1] = v[1]; dk[2] = v[2]; dk[3] = v[3]; } }
+        else for (int e = 0; e < 4; ++e) if (mb + e < a.M) dk[e] = a.DK[tt * a.M + mb + e];
 #pragma unroll
-        for (int d = 0; d < DM; ++d) { z[d] = d < a.D ? a.Zt[m * a.D + d] : 0.f; const float e = xt[d] - z[d]; d2 = fmaf(e, e, d2); }
-        const float k = a.variance * __expf(-0.5f * d2);
-        const float kd = k * a.DK[t * a.M + m];
-        const float c = -0.5f * kd;
-        a.C[t * a.M + m] = c;
-        sc += c; skd += kd;
+        for (int e = 0; e < 4; ++e) {
+            const int m = (mb + e < a.M) ? mb + e : a.M - 1;
+            float d2 = 0.f, z[DM];
 #pragma unroll
-        for (int d = 0; d < DM; ++d) cz[d] = fmaf(c, z[d], cz[d]);
+            for (int d = 0; d < DM; ++d) { z[d] = d < a.D ? a.Zt[m * a.D + d] : 0.f; const float q = xt[d] - z[d]; d2 = fmaf(q, q, d2); }
+            const float kd = (mb + e < a.M) ? a.variance * __expf(-0.5f * d2) * dk[e] : 0.f;
+            c[e] = -0.5f * kd;
+            sc += c[e]; skd += kd;
+#pragma unroll
+            for (int d = 0; d < DM; ++d) cz[d] = fmaf(c[e], z[d], cz[d]);
+        }
+        if (live) {
+            if (vec) { if (mb < a.M) *reinterpret_cast<f32x4*>(a.C + t * a.M + mb) = f32x4{c[0], c[1], c[2], c[3]}; }
+            else for (int e = 0; e < 4; ++e) if (mb + e < a.M) a.C[t * a.M + mb + e] = c[e];
+        }
     }
-    sc = wave_sum(sc); skd = wave_sum(skd);
+    sc = gsum(sc); skd = gsum(skd);
     const int W = a.D + 2;
 #pragma unroll
     for (int d = 0; d < DM; ++d) {
         if (d < a.D) {
-        const float czd = wave_sum(cz[d]);
-        if (lane == 0) {
-            const float dxt = 2.f * xt[d] * sc - 2.f * czd;
-            if (a.dF) a.dF[t * a.D + d] = fmaf(dxt, a.invls[d], a.dF[t * a.D + d]);
-            a.Qx[t * W + d] = dxt * a.F[t * a.D + d];
-        }
+            const float czd = gsum(cz[d]);
+            if (live && sub == 0) {
+                const float dxt = 2.f * xt[d] * sc - 2.f * czd;
+                if (a.dF) a.dF[t * a.D + d] = fmaf(dxt, a.invls[d], a.dF[t * a.D + d]);
+                a.Qx[t * W + d] = dxt * a.F[t * a.D + d];
+            }
         }
     }
-    if (lane == 0) { a.Qx[t * W + a.D] = a.SDV[t]; a.Qx[t * W + a.D + 1] = skd; }
+    if (live && sub == 0) { a.Qx[t * W + a.D] = a.SDV[t]; a.Qx[t * W + a.D + 1] = skd; }
 }
 
 // Thin sums over samples: part[blk][m][n] = sum_{t in chunk} X[t*ldx + m] * Y(t, n), n < N + ones, N <= 64; the extra
@@ -1043,7 +1059,7 @@ extern "C" int iwvi_gp_layer_backward(const iwvi_gp_bwd_desc* dp, int64_t T, voi
     // C = -1/2 K o DK (over DA), dx~, dF, per-sample rows of the column sums
     KernArgs ka{d.F, w.Zt, w.invls, w.DK, w.DA, w.SDV, d.dF, w.Qx, T, M, D, d.variance};
     {
-        const dim3 grid((unsigned)((T + 3) / 4)), block(256);
+        const dim3 grid((unsigned)((T + 15) / 16)), block(256);
         if (D <= 4) hipLaunchKernelGGL(k_bw_kernel<4>, grid, block, 0, st, ka);
         else if (D <= 8) hipLaunchKernelGGL(k_bw_kernel<8>, grid, block, 0, st, ka);
         else if (D <= 16) hipLaunchKernelGGL(k_bw_kernel<16>, grid, block, 0, st, ka);
