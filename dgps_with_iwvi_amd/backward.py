@@ -192,15 +192,18 @@ def iw_elbo_and_gradients(model, zs=None, mode_vi=None):
     kld = (ctypes.c_int32 * max(len(kls), 1))(*[k.shape[1] for k in kls])
     w = torch.empty(T, dtype=ft, device=dev)
     d_mean, d_var = torch.empty(T, Dy, dtype=ft, device=dev), torch.empty(T, Dy, dtype=ft, device=dev)
-    sums = torch.empty(2, dtype=torch.float64, device=dev)
+    sums = torch.empty(3, dtype=torch.float64, device=dev)
+    glob = [_abi.dev_tensor(g.reshape(-1), "global kl", torch.float64) for g in model._global_kls()]
+    glob_p = _abi.ptr_array(glob)
+    glob_n = (ctypes.c_int32 * max(len(glob), 1))(*[g.numel() for g in glob])
     ws = torch.empty(2 * B, dtype=torch.float64, device=dev)
     scale = float(model.num_data) / float(B)
     _abi.check(_abi.lib().iwvi_iw_elbo_backward(
         _abi.ptr(fin.mean), _abi.ptr(fin.var), _abi.ptr(Y), Dy, klp, kld, len(kls), B, K,
         float(model.likelihood.variance), scale, 1 if mode_vi else 0, _abi.ptr(w), _abi.ptr(d_mean), _abi.ptr(d_var),
-        ctypes.c_void_p(sums.data_ptr()), ctypes.c_void_p(ws.data_ptr()), _abi.stream_ptr()))
+        glob_p, glob_n, len(glob), ctypes.c_void_p(sums.data_ptr()), ctypes.c_void_p(ws.data_ptr()), _abi.stream_ptr()))
     grads = {"lik_var": sums[1]}
-    elbo = scale * sums[0]
+    elbo = sums[2]                                               # scale * sum_n(...) - sum of the global KLs, formed on the device
     dF = None
     for i in range(len(layers) - 1, -1, -1):
         layer, s = layers[i], saved[i]
@@ -208,7 +211,6 @@ def iw_elbo_and_gradients(model, zs=None, mode_vi=None):
             last = i == len(layers) - 1
             g = gp_backward(layer, s[1], d_sample=None if last else dF, d_mean=d_mean if last else None,
                             d_var=d_var if last else None, kl_weight=1.0, want_dF=i > 0)
-            elbo = elbo - layer.kl
             for k_out, k_name in (("dZ", "Z"), ("dls", "ls"), ("dvariance", "var"), ("dq_mu", "q_mu"), ("dq_sqrt", "q_sqrt"),
                                   ("dW", "W"), ("dmf_A", "mfA")):
                 if k_out in g:

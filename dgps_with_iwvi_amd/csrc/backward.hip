@@ -737,13 +737,6 @@ static BwdWs bwd_layout(char* base, long long T, int M, int D, int R) {
     w.bytes = o;
     return w;
 }
-// both [dout, din + 1] (rows = output unit; last column = bias gradient) -> dW [din, dout], db [dout]
-__global__ void k_enc_unpack(const float* both, int din, int dout, float* dW, float* db) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= dout * (din + 1)) return;
-    const int o = idx / (din + 1), i = idx - o * (din + 1);
-    if (i < din) dW[i * dout + o] = both[idx]; else if (db) db[o] = both[idx];
-}
 
 
 // ------------------------------------------------------------------------------------------------------------
@@ -796,16 +789,26 @@ __global__ __launch_bounds__(256) void k_elbo_bwd(ElboBwdArgs a) {      // one w
     for (int o = 32; o > 0; o >>= 1) ds += __shfl_xor(ds, o, 64);
     if (lane == 0) { a.part[b] = a.mode_vi ? se / (double)a.K : (double)mx + log(se) - log((double)a.K); a.part[a.B + b] = ds; }
 }
-// out[i] = sum of part[i*n .. (i+1)*n), one workgroup per i, fixed order
-__global__ __launch_bounds__(256) void k_dsum(const double* part, long long n, double* out) {
+// out[0] = sum part[0..n), out[1] = sum part[n..2n), out[2] = scale * out[0] - sum of the global KL shares (the bound)
+struct ElboFinishArgs { const double* part; long long n; double scale; const double* klg[IWVI_MAX_LAYERS]; int kln[IWVI_MAX_LAYERS]; int n_glob; double* out; };
+__global__ __launch_bounds__(256) void k_elbo_finish(ElboFinishArgs a) {
     __shared__ double red[256];
-    const double* p = part + (size_t)blockIdx.x * n;
-    double s = 0.0;
-    for (long long i = threadIdx.x; i < n; i += 256) s += p[i];
-    red[threadIdx.x] = s;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
-    if (threadIdx.x == 0) out[blockIdx.x] = red[0];
+    double tot[2];
+    for (int i = 0; i < 2; ++i) {
+        const double* p = a.part + (size_t)i * a.n;
+        double s = 0.0;
+        for (long long k = threadIdx.x; k < a.n; k += 256) s += p[k];
+        red[threadIdx.x] = s;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+        tot[i] = red[0];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        double kl = 0.0;
+        for (int i = 0; i < a.n_glob; ++i) for (int q = 0; q < a.kln[i]; ++q) kl += a.klg[i][q];
+        a.out[0] = tot[0]; a.out[1] = tot[1]; a.out[2] = a.scale * tot[0] - kl;
+    }
 }
 
 // LatentVariableLayer (layers.py:83-103): W = mu + eps sigma; d(enc_out) [B, 2 Lw] = sum over the K samples of (dmu | draw)
@@ -836,7 +839,8 @@ __global__ void k_lv_bwd(LvBwdArgs a) {
 // Encoder MLP (layers.py:137-152), one thread per row: activations of every layer -> acts, then deltas (d / d pre-activation)
 struct EncBwdArgs {
     const float* XY; long long rows; const float* W[IWVI_MAX_ENC]; const float* b[IWVI_MAX_ENC]; int dims[IWVI_MAX_ENC + 1]; int n;
-    const float* d_out; float* acts[IWVI_MAX_ENC + 1]; float* delta[IWVI_MAX_ENC];
+    const float* d_out;
+    float* part; int woff[IWVI_MAX_ENC], boff[IWVI_MAX_ENC], ptot;     // part[workgroup][ptot]: this workgroup's share of (dW_l | db_l)
 };
 constexpr int ER = 32, ELD = 65;        // rows per workgroup, row stride of an activation tile in LDS
 // 32 rows per workgroup, activations and deltas in LDS, threads over (row, unit)
@@ -852,7 +856,7 @@ __global__ __launch_bounds__(256) void k_enc_bwd(EncBwdArgs a) {
     for (int idx = tid; idx < nrows * a.dims[0]; idx += 256) {
         const int r = idx / a.dims[0], i = idx - r * a.dims[0];
         const float v = a.XY[(row0 + r) * a.dims[0] + i];
-        acts[r * ELD + i] = v; a.acts[0][(row0 + r) * a.dims[0] + i] = v;
+        acts[r * ELD + i] = v;
     }
     __syncthreads();
     for (int l = 0; l < a.n; ++l) {
@@ -865,7 +869,6 @@ __global__ __launch_bounds__(256) void k_enc_bwd(EncBwdArgs a) {
             if (l < a.n - 1) acc = tanhf(acc);
             if (din == dout) acc += in[r * ELD + o];
             out[r * ELD + o] = acc;
-            if (l < a.n - 1) a.acts[l + 1][(row0 + r) * dout + o] = acc;
         }
         __syncthreads();
     }
@@ -881,9 +884,22 @@ __global__ __launch_bounds__(256) void k_enc_bwd(EncBwdArgs a) {
             float v = cur[r * ELD + o];
             if (l < a.n - 1) { const float act = out[r * ELD + o] - (skip ? in[r * ELD + o] : 0.f); v *= 1.f - act * act; }
             dl[r * ELD + o] = v;
-            a.delta[l][(row0 + r) * dout + o] = v;
         }
         __syncthreads();
+        // this workgroup's rows' share of dW_l = in^T dl and db_l = colsum(dl), rows in a fixed order
+        float* pw = a.part + (size_t)blockIdx.x * a.ptot;
+        for (int idx = tid; idx < din * dout + dout; idx += 256) {
+            float acc = 0.f;
+            if (idx < din * dout) {
+                const int i = idx / dout, o = idx - i * dout;
+                for (int r = 0; r < nrows; ++r) acc = fmaf(in[r * ELD + i], dl[r * ELD + o], acc);
+                pw[a.woff[l] + idx] = acc;
+            } else {
+                const int o = idx - din * dout;
+                for (int r = 0; r < nrows; ++r) acc += dl[r * ELD + o];
+                pw[a.boff[l] + o] = acc;
+            }
+        }
         for (int idx = tid; idx < nrows * din; idx += 256) {
             const int r = idx / din, i = idx - r * din;
             float acc = skip ? cur[r * ELD + i] : 0.f;
@@ -894,6 +910,17 @@ __global__ __launch_bounds__(256) void k_enc_bwd(EncBwdArgs a) {
         for (int idx = tid; idx < nrows * din; idx += 256) { const int r = idx / din, i = idx - r * din; cur[r * ELD + i] = prev[r * ELD + i]; }
         __syncthreads();
     }
+}
+
+// every encoder parameter = sum over the workgroups' shares (fixed order), scattered to its tensor
+struct EncReduceArgs { const float* part; int nblk, ptot, n; int off[2 * IWVI_MAX_ENC], len[2 * IWVI_MAX_ENC]; float* dst[2 * IWVI_MAX_ENC]; };
+__global__ void k_enc_reduce(EncReduceArgs a) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= a.ptot) return;
+    double s = 0.0;
+    for (int b = 0; b < a.nblk; ++b) s += (double)a.part[(size_t)b * a.ptot + idx];
+    for (int j = 0; j < a.n; ++j)
+        if (idx >= a.off[j] && idx < a.off[j] + a.len[j]) { if (a.dst[j]) a.dst[j][idx - a.off[j]] = (float)s; return; }
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -1098,7 +1125,7 @@ extern "C" int iwvi_gp_layer_backward(const iwvi_gp_bwd_desc* dp, int64_t T, voi
     FinalArgsB f{d.Z, d.lengthscales, d.q_mu, d.q_sqrt, w.Zt, w.invls, w.CtF1, w.CtF1, w.Qsum + D, w.Qsum, w.dZt_uu, w.dvar_m,
                  d.dZ, d.dls, d.dvariance, d.dq_mu, d.dq_sqrt, M, D, R, d.kl_weight, (double)d.variance};
     hipLaunchKernelGGL(k_bw_final, dim3(D + 1), dim3(64), 0, st, f);
-    hipLaunchKernelGGL(k_bw_kl, dim3((unsigned)(((long long)R * M * M + 255) / 256)), dim3(256), 0, st, f);
+    hipLaunchKernelGGL(k_bw_kl, dim3((unsigned)(((long long)R * M * M + 255) / 256)), dim3(256), 0, st, f);   // (independent of k_bw_final)
     return check_launch("k_bw_final");
 }
 
@@ -1106,8 +1133,10 @@ extern "C" int iwvi_iw_elbo_backward(const float* fmean, const float* fvar, cons
                                      const float* const* kl_local, const int32_t* kl_dims, int n_local,
                                      int64_t B, int K, float lik_variance, double scale, int mode_vi,
                                      float* out_w, float* d_mean, float* d_var,
-                                     double* out_sums /* [2]: sum_n (lse - log K), d/d lik_variance */, double* ws, void* stream_) {
-    if (!fmean || !fvar || !Y || !out_sums || !ws || Dy <= 0 || B <= 0 || K <= 0 || n_local < 0 || n_local > IWVI_MAX_KL || !(lik_variance > 0.f)) {
+                                     const double* const* kl_global, const int32_t* kl_global_counts, int n_glob,
+                                     double* out_sums /* [3]: sum_n (lse - log K), d/d lik_variance, the bound */, double* ws, void* stream_) {
+    if (!fmean || !fvar || !Y || !out_sums || !ws || Dy <= 0 || B <= 0 || K <= 0 || n_local < 0 || n_local > IWVI_MAX_KL || !(lik_variance > 0.f) ||
+        n_glob < 0 || n_glob > IWVI_MAX_LAYERS) {
         set_error("iwvi_iw_elbo_backward: bad argument"); return IWVI_ERR_ARG;
     }
     hipStream_t st = (hipStream_t)stream_;
@@ -1119,7 +1148,13 @@ extern "C" int iwvi_iw_elbo_backward(const float* fmean, const float* fvar, cons
     }
     a.B = B; a.K = K; a.lik_var = lik_variance; a.scale = scale; a.mode_vi = mode_vi; a.w = out_w; a.d_mean = d_mean; a.d_var = d_var; a.part = ws;
     hipLaunchKernelGGL(k_elbo_bwd, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, st, a);
-    hipLaunchKernelGGL(k_dsum, dim3(2), dim3(256), 0, st, (const double*)ws, (long long)B, out_sums);
+    ElboFinishArgs fa{};
+    fa.part = ws; fa.n = B; fa.scale = scale; fa.n_glob = n_glob; fa.out = out_sums;
+    for (int i = 0; i < n_glob; ++i) {
+        if (!kl_global || !kl_global[i] || !kl_global_counts || kl_global_counts[i] <= 0) { set_error("iwvi_iw_elbo_backward: bad global KL %d", i); return IWVI_ERR_ARG; }
+        fa.klg[i] = kl_global[i]; fa.kln[i] = kl_global_counts[i];
+    }
+    hipLaunchKernelGGL(k_elbo_finish, dim3(1), dim3(256), 0, st, fa);
     return check_launch("k_elbo_bwd");
 }
 
@@ -1134,22 +1169,15 @@ extern "C" int iwvi_lv_layer_backward(const float* mu, const float* sigma, int l
     return check_launch("k_lv_bwd");
 }
 
-static size_t enc_bwd_layout(int64_t rows, const int32_t* dims, int n, size_t* acts_off, size_t* delta_off, size_t* part_off, size_t* part_floats) {
-    size_t o = 0;
-    int wmax = 1;
-    for (int l = 0; l <= n; ++l) { if (acts_off) acts_off[l] = o; o = align256(o + sizeof(float) * rows * dims[l]); if (dims[l] > wmax) wmax = dims[l]; }
-    for (int l = 0; l < n; ++l) { if (delta_off) delta_off[l] = o; o = align256(o + sizeof(float) * rows * dims[l + 1]); }
-    const size_t pf = (size_t)((rows + THIN_ROWS - 1) / THIN_ROWS) * wmax * (wmax + 1);
-    if (part_off) *part_off = o;
-    if (part_floats) *part_floats = pf;
-    o = align256(o + sizeof(float) * pf);
-    o = align256(o + sizeof(float) * 64 * 65);          // [dout][din + 1] staging of one layer's (dW ; db)
-    o += 256;
-    return o;
+static int enc_param_total(const int32_t* dims, int n) {
+    int p = 0;
+    for (int l = 0; l < n; ++l) p += dims[l] * dims[l + 1] + dims[l + 1];
+    return p;
 }
 extern "C" size_t iwvi_encoder_backward_ws_bytes(int64_t rows, const int32_t* dims, int n_enc) {
     if (rows <= 0 || !dims || n_enc <= 0 || n_enc > IWVI_MAX_ENC) return 0;
-    return enc_bwd_layout(rows, dims, n_enc, nullptr, nullptr, nullptr, nullptr);
+    for (int l = 0; l <= n_enc; ++l) if (dims[l] <= 0 || dims[l] > 64) return 0;
+    return align256(sizeof(float) * (size_t)((rows + ER - 1) / ER) * enc_param_total(dims, n_enc)) + 256;
 }
 extern "C" int iwvi_encoder_backward(const float* XY, int64_t rows, const float* const* enc_W, const float* const* enc_b,
                                      const int32_t* dims, int n_enc, const float* d_out,
@@ -1157,16 +1185,20 @@ extern "C" int iwvi_encoder_backward(const float* XY, int64_t rows, const float*
     if (!XY || !enc_W || !dims || !d_out || !dW || !ws_ || rows <= 0 || n_enc <= 0 || n_enc > IWVI_MAX_ENC) { set_error("iwvi_encoder_backward: bad argument"); return IWVI_ERR_ARG; }
     for (int l = 0; l <= n_enc; ++l) if (dims[l] <= 0 || dims[l] > 64) { set_error("iwvi_encoder_backward: encoder width %d out of range (1..64)", dims[l]); return IWVI_ERR_ARG; }
     hipStream_t st = (hipStream_t)stream_;
-    size_t ao[IWVI_MAX_ENC + 1], d_off[IWVI_MAX_ENC], po, pf;
-    const size_t total = enc_bwd_layout(rows, dims, n_enc, ao, d_off, &po, &pf);
-    char* base = (char*)ws_;
     EncBwdArgs a{};
-    a.XY = XY; a.rows = rows; a.n = n_enc; a.d_out = d_out;
-    for (int l = 0; l <= n_enc; ++l) { a.dims[l] = dims[l]; a.acts[l] = (float*)(base + ao[l]); }
+    EncReduceArgs r{};
+    a.XY = XY; a.rows = rows; a.n = n_enc; a.d_out = d_out; a.part = (float*)ws_;
+    int off = 0;
+    for (int l = 0; l <= n_enc; ++l) a.dims[l] = dims[l];
     for (int l = 0; l < n_enc; ++l) {
         if (!enc_W[l] || !dW[l]) { set_error("iwvi_encoder_backward: null weight %d", l); return IWVI_ERR_ARG; }
-        a.W[l] = enc_W[l]; a.b[l] = enc_b ? enc_b[l] : nullptr; a.delta[l] = (float*)(base + d_off[l]);
+        a.W[l] = enc_W[l]; a.b[l] = enc_b ? enc_b[l] : nullptr;
+        a.woff[l] = off; r.off[2 * l] = off; r.len[2 * l] = dims[l] * dims[l + 1]; r.dst[2 * l] = dW[l]; off += dims[l] * dims[l + 1];
+        a.boff[l] = off; r.off[2 * l + 1] = off; r.len[2 * l + 1] = dims[l + 1]; r.dst[2 * l + 1] = db ? db[l] : nullptr; off += dims[l + 1];
     }
+    a.ptot = off;
+    const int nblk = (int)((rows + ER - 1) / ER);
+    r.part = a.part; r.nblk = nblk; r.ptot = off; r.n = 2 * n_enc;
     const size_t elds = sizeof(float) * (size_t)(n_enc + 4) * ER * ELD;
     int rc;
     {   // once per process: allow the largest encoder (hipFuncSetAttribute is not a stream operation)
@@ -1178,17 +1210,10 @@ extern "C" int iwvi_encoder_backward(const float* XY, int64_t rows, const float*
             done = true;
         }
     }
-    hipLaunchKernelGGL(k_enc_bwd, dim3((unsigned)((rows + ER - 1) / ER)), dim3(256), elds, st, a);
+    hipLaunchKernelGGL(k_enc_bwd, dim3((unsigned)nblk), dim3(256), elds, st, a);
     if ((rc = check_launch("k_enc_bwd")) != IWVI_OK) return rc;
-    float* part = (float*)(base + po);
-    float* both = (float*)(base + total - 256 - align256(sizeof(float) * 64 * 65));
-    for (int l = 0; l < n_enc; ++l) {
-        const int din = dims[l], dout = dims[l + 1];
-        // [dW_l ; db_l] as delta_l^T [acts_l | 1] -> both [dout, din + 1]
-        if ((rc = thin(st, a.delta[l], dout, dout, a.acts[l], din, din, 1, rows, part, pf, both)) != IWVI_OK) return rc;
-        hipLaunchKernelGGL(k_enc_unpack, dim3((dout * (din + 1) + 255) / 256), dim3(256), 0, st, (const float*)both, din, dout, dW[l], db ? db[l] : nullptr);
-    }
-    return IWVI_OK;
+    hipLaunchKernelGGL(k_enc_reduce, dim3((off + 255) / 256), dim3(256), 0, st, r);
+    return check_launch("k_enc_reduce");
 }
 
 extern "C" size_t iwvi_natgrad_ws_bytes(int M) {
