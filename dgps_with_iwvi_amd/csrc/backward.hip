@@ -351,14 +351,67 @@ __global__ __launch_bounds__(256) void k_reduce_parts(ReduceArgs r) {
     if (r.out64) { double* q = r.out64 + b * r.out_batch + m * r.ldo + n; *q = s + (r.beta != 0.0 ? r.beta * *q : 0.0); }
 }
 
+// Deferred reductions: the split-K / thin products of one layer park their partial sums in disjoint slices of the
+// workspace and ONE launch sums them all (grid.y = job), instead of one small launch behind every product.
+constexpr int RQ_MAX = 12;
+struct ReduceJobs { ReduceArgs j[RQ_MAX]; int nb[RQ_MAX]; int n, maxnb; };
+__global__ __launch_bounds__(256) void k_reduce_multi(ReduceJobs q) {
+    __shared__ double red[4][64];
+    const int job = blockIdx.y / q.maxnb, b = blockIdx.y - job * q.maxnb;  // (job, batch)
+    if (job >= q.n) return;
+    const ReduceArgs& r = q.j[job];
+    if (b >= q.nb[job] || (int)blockIdx.x * 64 >= r.M * r.N) return;
+    const int o = threadIdx.x & 63, gq = threadIdx.x >> 6;
+    const int idx = blockIdx.x * 64 + o;
+    const size_t MN = (size_t)r.M * r.N;
+    const float* part = r.part + (size_t)b * r.S * MN;
+    double s = 0.0;
+    if (idx < r.M * r.N) {
+        const int per = (r.S + 3) / 4, k0 = gq * per, k1 = (k0 + per < r.S) ? k0 + per : r.S;
+#pragma unroll 8
+        for (int k = k0; k < k1; ++k) s += (double)part[(size_t)k * MN + idx];
+    }
+    red[gq][o] = s;
+    __syncthreads();
+    if (gq != 0 || idx >= r.M * r.N) return;
+    s = ((red[0][o] + red[1][o]) + red[2][o]) + red[3][o];
+    const int m = idx / r.N, n = idx - m * r.N;
+    s *= r.alpha;
+    if (r.tri && n > m) s = 0.0;
+    if (r.out) { float* p = r.out + b * r.out_batch + m * r.ldo + n; *p = (float)(s + (r.beta != 0.0 ? r.beta * (double)*p : 0.0)); }
+    if (r.out64) { double* p = r.out64 + b * r.out_batch + m * r.ldo + n; *p = s + (r.beta != 0.0 ? r.beta * *p : 0.0); }
+}
+struct ReduceQueue {
+    float* base; size_t cap, used; ReduceJobs q; int maxblk;
+    ReduceQueue(float* b, size_t c) : base(b), cap(c), used(0), maxblk(0) { q.n = 0; q.maxnb = 1; }
+    float* take(size_t n) { if (used + n > cap) return nullptr; float* p = base + used; used += (n + 63) & ~size_t(63); return p; }
+    bool push(const ReduceArgs& r, int nbatch) {
+        if (q.n >= RQ_MAX || nbatch > 32) return false;
+        q.j[q.n] = r; q.nb[q.n] = nbatch; ++q.n;
+        if (nbatch > q.maxnb) q.maxnb = nbatch;
+        const int nb = (r.M * r.N + 63) / 64; if (nb > maxblk) maxblk = nb;
+        return true;
+    }
+    int flush(hipStream_t st) {
+        if (q.n == 0) return IWVI_OK;
+        hipLaunchKernelGGL(k_reduce_multi, dim3(maxblk, q.maxnb * q.n), dim3(256), 0, st, q);
+        q.n = 0; q.maxnb = 1; maxblk = 0; used = 0;
+        return check_launch("k_reduce_multi");
+    }
+};
+
 // split-K product(s) summed over many samples: out (+ b*out_batch) = alpha * A^T-style product, reduced in float64
 static int gemm(hipStream_t st, GemmArgs g, float* part_ws, size_t part_floats, float* out, double* out64, long long ldo,
-                double alpha, double beta, int tri, int nbatch = 1, long long b_batch = 0, long long s_batch = 0, long long out_batch = 0) {
+                double alpha, double beta, int tri, int nbatch = 1, long long b_batch = 0, long long s_batch = 0, long long out_batch = 0,
+                ReduceQueue* rq = nullptr) {
     const int kchunk = 512;
     g.nsplit = (g.K + kchunk - 1) / kchunk; g.kchunk = kchunk;
     if (g.nsplit < 2) { g.nsplit = 2; g.kchunk = round_up((g.K + 1) / 2, GK); if (g.kchunk < GK) g.kchunk = GK; }
     g.kseg = g.K; g.a_seg = g.b_seg = g.s_seg = 0; g.nbatch = nbatch; g.b_batch = b_batch; g.s_batch = s_batch;
-    if ((size_t)g.nsplit * nbatch * g.M * g.N > part_floats) { set_error("backward: split-K workspace too small"); return IWVI_ERR_ARG; }
+    if (rq) {                                              // own slice of the workspace; summed by the queue's one launch
+        part_ws = rq->take((size_t)g.nsplit * nbatch * g.M * g.N);
+        if (!part_ws) { set_error("backward: split-K workspace too small"); return IWVI_ERR_ARG; }
+    } else if ((size_t)g.nsplit * nbatch * g.M * g.N > part_floats) { set_error("backward: split-K workspace too small"); return IWVI_ERR_ARG; }
     g.part = part_ws;
     if (!launch_fast(st, g)) {
         for (int b = 0; b < nbatch; ++b) {
@@ -369,6 +422,7 @@ static int gemm(hipStream_t st, GemmArgs g, float* part_ws, size_t part_floats, 
         }
     }
     ReduceArgs r{part_ws, g.nsplit, g.M, g.N, out, out64, ldo, alpha, beta, tri, out_batch};
+    if (rq && rq->push(r, nbatch)) return check_launch("k_gemm (split-K)");
     hipLaunchKernelGGL(k_reduce_parts, dim3((g.M * g.N + 63) / 64, nbatch), dim3(256), 0, st, r);
     return check_launch("k_gemm (split-K)");
 }
@@ -588,15 +642,18 @@ __global__ __launch_bounds__(256) void k_thin(ThinArgs a) {
 
 // out[m, n] = sum_t X[t, m] Y[t, n] (n < N) and, with ones, out[m, N] = sum_t X[t, m];  out is [M, N + ones]
 static int thin(hipStream_t st, const float* X, long long ldx, int M, const float* Y, long long ldy, int N, int ones, long long T,
-                float* part_ws, size_t part_floats, float* out, int ldo = 0) {
+                float* part_ws, size_t part_floats, float* out, int ldo = 0, ReduceQueue* rq = nullptr) {
     if (ldo == 0) ldo = N + ones;
     if (N > 32) {                                          // columns of Y in two passes (LDS budget of k_thin)
-        int rc = thin(st, X, ldx, M, Y, ldy, 32, 0, T, part_ws, part_floats, out, ldo);
+        int rc = thin(st, X, ldx, M, Y, ldy, 32, 0, T, part_ws, part_floats, out, ldo, rq);
         if (rc != IWVI_OK) return rc;
-        return thin(st, X, ldx, M, Y + 32, ldy, N - 32, ones, T, part_ws, part_floats, out + 32, ldo);
+        return thin(st, X, ldx, M, Y + 32, ldy, N - 32, ones, T, part_ws, part_floats, out + 32, ldo, rq);
     }
     const int nblk = (int)((T + THIN_ROWS - 1) / THIN_ROWS), NN = N + ones;
-    if ((size_t)nblk * M * NN > part_floats) { set_error("backward: thin-reduction workspace too small"); return IWVI_ERR_ARG; }
+    if (rq) {
+        part_ws = rq->take((size_t)nblk * M * NN);
+        if (!part_ws) { set_error("backward: thin-reduction workspace too small"); return IWVI_ERR_ARG; }
+    } else if ((size_t)nblk * M * NN > part_floats) { set_error("backward: thin-reduction workspace too small"); return IWVI_ERR_ARG; }
     ThinArgs a{X, ldx, Y, ldy, N, ones, T, M, part_ws};
     const dim3 grid(nblk), block(256);
     if (N <= 1) hipLaunchKernelGGL(k_thin<1>, grid, block, 0, st, a);
@@ -604,6 +661,7 @@ static int thin(hipStream_t st, const float* X, long long ldx, int M, const floa
     else if (N <= 16) hipLaunchKernelGGL(k_thin<16>, grid, block, 0, st, a);
     else hipLaunchKernelGGL(k_thin<32>, grid, block, 0, st, a);
     ReduceArgs r{part_ws, nblk, M, NN, out, nullptr, ldo, 1.0, 0.0, 0, 0};
+    if (rq && rq->push(r, 1)) return check_launch("k_thin");
     hipLaunchKernelGGL(k_reduce_parts, dim3((M * NN + 63) / 64, 1), dim3(256), 0, st, r);
     return check_launch("k_thin");
 }
@@ -722,10 +780,10 @@ static BwdWs bwd_layout(char* base, long long T, int M, int D, int R) {
     w.DMU = (float*)take(sizeof(float) * T * R); w.DV2 = (float*)take(sizeof(float) * T * R); w.SDV = (float*)take(sizeof(float) * T);
     w.DA = (float*)take(sizeof(float) * T * M); w.DK = (float*)take(sizeof(float) * T * M);
     w.Qx = (float*)take(sizeof(float) * T * (D + 2));
-    w.part_floats = (size_t)nsplit * M * M * R;
+    w.part_floats = (size_t)nsplit * M * M * (R + 1);          // dLm + the R batched dL_r, parked together
     {   // thin reductions: ceil(T / THIN_ROWS) chunks of at most [max(M, 34)][33]
         const size_t thin = (size_t)((T + THIN_ROWS - 1) / THIN_ROWS) * (M > 34 ? M : 34) * 33;
-        if (thin > w.part_floats) w.part_floats = thin;
+        w.part_floats += 8 * thin + 1024;                      // + up to 8 thin products
     }
     w.part = (float*)take(sizeof(float) * w.part_floats);
     w.LinvF = (float*)take(sizeof(float) * M * M); w.Zt = (float*)take(sizeof(float) * M * D); w.invls = (float*)take(sizeof(float) * IWVI_MAX_D);
@@ -1050,6 +1108,7 @@ extern "C" int iwvi_gp_layer_backward(const iwvi_gp_bwd_desc* dp, int64_t T, voi
     const float* gmv = d.GMV ? d.GMV : w.GMV;
     hipLaunchKernelGGL(k_bw_heads, dim3((unsigned)((T + 3) / 4)), dim3(256), 0, st, h);
     if ((rc = check_launch("k_bw_heads")) != IWVI_OK) return rc;
+    ReduceQueue rq(w.part, w.part_floats);                 // every sum over samples below is finished by ONE launch (rq.flush)
     // DA = DMU q_mu^T - 2 SDV o A
     hipLaunchKernelGGL(k_bw_da_init, dim3((unsigned)((T * M + 255) / 256)), dim3(256), 0, st, w.DA, d.A, (const float*)w.SDV, (const float*)w.DMU, d.q_mu, (long long)T, M, Mp, R);
     // DA += sum_r (2 dv_r) o (U_r L_r^T): one launch, R segments of M along the contraction
@@ -1072,16 +1131,16 @@ extern "C" int iwvi_gp_layer_backward(const iwvi_gp_bwd_desc* dp, int64_t T, voi
     {
         GemmArgs q{};
         q.A = w.DK; q.a_sm = 1; q.a_sk = M; q.B = d.A; q.b_sk = Mp; q.b_sn = 1; q.M = M; q.N = M; q.K = (int)T; q.tri_out = 1;
-        if ((rc = gemm(st, q, w.part, w.part_floats, nullptr, w.Lbar, M, -1.0, 0.0, 1)) != IWVI_OK) return rc;
+        if ((rc = gemm(st, q, w.part, w.part_floats, nullptr, w.Lbar, M, -1.0, 0.0, 1, 1, 0, 0, 0, &rq)) != IWVI_OK) return rc;
     }
     // dq_mu = A^T DMU
-    if (d.dq_mu && (rc = thin(st, d.A, Mp, M, w.DMU, R, R, 0, T, w.part, w.part_floats, d.dq_mu)) != IWVI_OK) return rc;
+    if (d.dq_mu && (rc = thin(st, d.A, Mp, M, w.DMU, R, R, 0, T, w.part, w.part_floats, d.dq_mu, 0, &rq)) != IWVI_OK) return rc;
     // dL_r = tril(A^T diag(2 dv_r) U_r), all r in one batched launch
     if (d.dq_sqrt) {
         GemmArgs q{};
         q.A = d.A; q.a_sm = 1; q.a_sk = Mp; q.B = d.U; q.b_sk = Mp; q.b_sn = 1;
         q.scale = w.DV2; q.s_stride = R; q.scale_on_k = 1; q.M = M; q.N = M; q.K = (int)T; q.tri_out = 1;
-        if ((rc = gemm(st, q, w.part, w.part_floats, d.dq_sqrt, nullptr, M, 1.0, 0.0, 1, R, (long long)T * Mp, 1, (long long)M * M)) != IWVI_OK) return rc;
+        if ((rc = gemm(st, q, w.part, w.part_floats, d.dq_sqrt, nullptr, M, 1.0, 0.0, 1, R, (long long)T * Mp, 1, (long long)M * M, &rq)) != IWVI_OK) return rc;
     }
     // C = -1/2 K o DK (over DA), dx~, dF, per-sample rows of the column sums
     KernArgs ka{d.F, w.Zt, w.invls, w.DK, w.DA, w.SDV, d.dF, w.Qx, T, M, D, d.variance};
@@ -1094,8 +1153,24 @@ extern "C" int iwvi_gp_layer_backward(const iwvi_gp_bwd_desc* dp, int64_t T, voi
     }
     if ((rc = check_launch("k_bw_kernel")) != IWVI_OK) return rc;
     // sums over samples: C^T [F | 1]  and the column sums of Qx = (dx~ o x | sum_r dv_r | sum_m k dk)
-    if ((rc = thin(st, w.DA, M, M, d.F, D, D, 1, T, w.part, w.part_floats, w.CtF1)) != IWVI_OK) return rc;
-    if ((rc = thin(st, w.Qx, D + 2, D + 2, nullptr, 0, 0, 1, T, w.part, w.part_floats, w.Qsum)) != IWVI_OK) return rc;
+    if ((rc = thin(st, w.DA, M, M, d.F, D, D, 1, T, w.part, w.part_floats, w.CtF1, 0, &rq)) != IWVI_OK) return rc;
+    if ((rc = thin(st, w.Qx, D + 2, D + 2, nullptr, 0, 0, 1, T, w.part, w.part_floats, w.Qsum, 0, &rq)) != IWVI_OK) return rc;
+    // mixing matrix and linear mean function (trainable when the reference runs with fix_linear=False, build_models.py:224-227)
+    const bool lin_on = (d.dW && d.W) || (d.dmf_A && d.mf_type == IWVI_MF_LINEAR);
+    float* s[3] = {nullptr, nullptr, nullptr}; float* a12[2] = {nullptr, nullptr};
+    if (lin_on) {
+        const int P = d.P;
+        const float* ups[3] = {d.d_sample, d.d_mean, d.d_var};
+        if (d.dW && d.W) for (int i = 0; i < 3; ++i) if (ups[i]) {
+            s[i] = w.lin + i * IWVI_MAX_P * IWVI_MAX_R;
+            if ((rc = thin(st, ups[i], P, P, gmv + i * R, 3 * R, R, 0, T, w.part, w.part_floats, s[i], 0, &rq)) != IWVI_OK) return rc;
+        }
+        if (d.dmf_A && d.mf_type == IWVI_MF_LINEAR) for (int i = 0; i < 2; ++i) if (ups[i]) {
+            a12[i] = w.lin + 3 * IWVI_MAX_P * IWVI_MAX_R + i * IWVI_MAX_D * IWVI_MAX_P;
+            if ((rc = thin(st, d.F, D, D, ups[i], P, P, 0, T, w.part, w.part_floats, a12[i], 0, &rq)) != IWVI_OK) return rc;
+        }
+    }
+    if ((rc = rq.flush(st)) != IWVI_OK) return rc;
     // adjoint of Lm = chol(Kuu): S = Lm^-T Phi(Lm^T Lbar) Lm^-1
     {
         const dim3 grid((M + 15) / 16, (M + 15) / 16), block(256);
@@ -1105,19 +1180,8 @@ extern "C" int iwvi_gp_layer_backward(const iwvi_gp_bwd_desc* dp, int64_t T, voi
         hipLaunchKernelGGL(k_kuu_bwd, dim3(M), dim3(256), 0, st, w.Zt, (const double*)w.S, M, D, (double)d.variance, w.dZt_uu, w.dvar_m);
         if ((rc = check_launch("cholesky adjoint")) != IWVI_OK) return rc;
     }
-    // mixing matrix and linear mean function (trainable when the reference runs with fix_linear=False, build_models.py:224-227)
-    if ((d.dW && d.W) || (d.dmf_A && d.mf_type == IWVI_MF_LINEAR)) {
+    if (lin_on) {
         const int P = d.P;
-        float* s[3] = {nullptr, nullptr, nullptr}; float* a12[2] = {nullptr, nullptr};
-        const float* ups[3] = {d.d_sample, d.d_mean, d.d_var};
-        if (d.dW && d.W) for (int i = 0; i < 3; ++i) if (ups[i]) {
-            s[i] = w.lin + i * IWVI_MAX_P * IWVI_MAX_R;
-            if ((rc = thin(st, ups[i], P, P, gmv + i * R, 3 * R, R, 0, T, w.part, w.part_floats, s[i])) != IWVI_OK) return rc;
-        }
-        if (d.dmf_A && d.mf_type == IWVI_MF_LINEAR) for (int i = 0; i < 2; ++i) if (ups[i]) {
-            a12[i] = w.lin + 3 * IWVI_MAX_P * IWVI_MAX_R + i * IWVI_MAX_D * IWVI_MAX_P;
-            if ((rc = thin(st, d.F, D, D, ups[i], P, P, 0, T, w.part, w.part_floats, a12[i])) != IWVI_OK) return rc;
-        }
         const int n_w = (d.dW && d.W) ? P * R : 0, n_a = (d.dmf_A && d.mf_type == IWVI_MF_LINEAR) ? D * P : 0;
         hipLaunchKernelGGL(k_lin_combine, dim3(((n_w > n_a ? n_w : n_a) + 255) / 256), dim3(256), 0, st, (const float*)s[0], (const float*)s[1], (const float*)s[2],
                            d.W, n_w ? d.dW : nullptr, n_w, (const float*)a12[0], (const float*)a12[1], n_a ? d.dmf_A : nullptr, n_a);
