@@ -325,7 +325,8 @@ static bool launch_fast(hipStream_t st, const GemmArgs& g) {
 
 // out[m, n] = alpha * sum_s part[s][m][n] (+ beta * out); tri: entries above the diagonal become 0.  Either output
 // may be null (float / double).
-struct ReduceArgs { const float* part; int S, M, N; float* out; double* out64; long long ldo; double alpha, beta; int tri; long long out_batch; };
+struct ReduceArgs { const float* part; int S, M, N; float* out; double* out64; long long ldo; double alpha, beta; int tri; long long out_batch;
+                    const float* add; double add_coef; int add_diag_inv; };   // + add_coef * (add[.] - (m == n ? 1 / add[.] : 0)): the KL gradient rides along
 __global__ __launch_bounds__(256) void k_reduce_parts(ReduceArgs r) {
     // 64 outputs per workgroup; the S partials of an output are summed by 4 threads (contiguous quarters, in order),
     // then combined in a fixed order: deterministic whatever the launch geometry
@@ -346,6 +347,7 @@ __global__ __launch_bounds__(256) void k_reduce_parts(ReduceArgs r) {
     s = ((red[0][o] + red[1][o]) + red[2][o]) + red[3][o];
     const int m = idx / r.N, n = idx - m * r.N;
     s *= r.alpha;
+    if (r.add) { const double v = (double)r.add[b * r.out_batch + m * r.ldo + n]; s += r.add_coef * (v - ((r.add_diag_inv && m == n) ? 1.0 / v : 0.0)); }
     if (r.tri && n > m) s = 0.0;
     if (r.out) { float* q = r.out + b * r.out_batch + m * r.ldo + n; *q = (float)(s + (r.beta != 0.0 ? r.beta * (double)*q : 0.0)); }
     if (r.out64) { double* q = r.out64 + b * r.out_batch + m * r.ldo + n; *q = s + (r.beta != 0.0 ? r.beta * *q : 0.0); }
@@ -377,6 +379,7 @@ __global__ __launch_bounds__(256) void k_reduce_multi(ReduceJobs q) {
     s = ((red[0][o] + red[1][o]) + red[2][o]) + red[3][o];
     const int m = idx / r.N, n = idx - m * r.N;
     s *= r.alpha;
+    if (r.add) { const double v = (double)r.add[b * r.out_batch + m * r.ldo + n]; s += r.add_coef * (v - ((r.add_diag_inv && m == n) ? 1.0 / v : 0.0)); }
     if (r.tri && n > m) s = 0.0;
     if (r.out) { float* p = r.out + b * r.out_batch + m * r.ldo + n; *p = (float)(s + (r.beta != 0.0 ? r.beta * (double)*p : 0.0)); }
     if (r.out64) { double* p = r.out64 + b * r.out_batch + m * r.ldo + n; *p = s + (r.beta != 0.0 ? r.beta * *p : 0.0); }
@@ -403,7 +406,7 @@ struct ReduceQueue {
 // split-K product(s) summed over many samples: out (+ b*out_batch) = alpha * A^T-style product, reduced in float64
 static int gemm(hipStream_t st, GemmArgs g, float* part_ws, size_t part_floats, float* out, double* out64, long long ldo,
                 double alpha, double beta, int tri, int nbatch = 1, long long b_batch = 0, long long s_batch = 0, long long out_batch = 0,
-                ReduceQueue* rq = nullptr) {
+                ReduceQueue* rq = nullptr, const float* add = nullptr, double add_coef = 0.0, int add_diag_inv = 0) {
     const int kchunk = 512;
     g.nsplit = (g.K + kchunk - 1) / kchunk; g.kchunk = kchunk;
     if (g.nsplit < 2) { g.nsplit = 2; g.kchunk = round_up((g.K + 1) / 2, GK); if (g.kchunk < GK) g.kchunk = GK; }
@@ -421,7 +424,7 @@ static int gemm(hipStream_t st, GemmArgs g, float* part_ws, size_t part_floats, 
             hipLaunchKernelGGL(k_gemm, dim3((g.N + GT - 1) / GT, (g.M + GT - 1) / GT, g.nsplit), dim3(256), 0, st, q);
         }
     }
-    ReduceArgs r{part_ws, g.nsplit, g.M, g.N, out, out64, ldo, alpha, beta, tri, out_batch};
+    ReduceArgs r{part_ws, g.nsplit, g.M, g.N, out, out64, ldo, alpha, beta, tri, out_batch, add, add_coef, add_diag_inv};
     if (rq && rq->push(r, nbatch)) return check_launch("k_gemm (split-K)");
     hipLaunchKernelGGL(k_reduce_parts, dim3((g.M * g.N + 63) / 64, nbatch), dim3(256), 0, st, r);
     return check_launch("k_gemm (split-K)");
@@ -642,12 +645,13 @@ __global__ __launch_bounds__(256) void k_thin(ThinArgs a) {
 
 // out[m, n] = sum_t X[t, m] Y[t, n] (n < N) and, with ones, out[m, N] = sum_t X[t, m];  out is [M, N + ones]
 static int thin(hipStream_t st, const float* X, long long ldx, int M, const float* Y, long long ldy, int N, int ones, long long T,
-                float* part_ws, size_t part_floats, float* out, int ldo = 0, ReduceQueue* rq = nullptr) {
+                float* part_ws, size_t part_floats, float* out, int ldo = 0, ReduceQueue* rq = nullptr,
+                const float* add = nullptr, double add_coef = 0.0) {
     if (ldo == 0) ldo = N + ones;
     if (N > 32) {                                          // columns of Y in two passes (LDS budget of k_thin)
-        int rc = thin(st, X, ldx, M, Y, ldy, 32, 0, T, part_ws, part_floats, out, ldo, rq);
+        int rc = thin(st, X, ldx, M, Y, ldy, 32, 0, T, part_ws, part_floats, out, ldo, rq, add, add_coef);
         if (rc != IWVI_OK) return rc;
-        return thin(st, X, ldx, M, Y + 32, ldy, N - 32, ones, T, part_ws, part_floats, out + 32, ldo, rq);
+        return thin(st, X, ldx, M, Y + 32, ldy, N - 32, ones, T, part_ws, part_floats, out + 32, ldo, rq, add ? add + 32 : nullptr, add_coef);
     }
     const int nblk = (int)((T + THIN_ROWS - 1) / THIN_ROWS), NN = N + ones;
     if (rq) {
@@ -660,7 +664,7 @@ static int thin(hipStream_t st, const float* X, long long ldx, int M, const floa
     else if (N <= 8) hipLaunchKernelGGL(k_thin<8>, grid, block, 0, st, a);
     else if (N <= 16) hipLaunchKernelGGL(k_thin<16>, grid, block, 0, st, a);
     else hipLaunchKernelGGL(k_thin<32>, grid, block, 0, st, a);
-    ReduceArgs r{part_ws, nblk, M, NN, out, nullptr, ldo, 1.0, 0.0, 0, 0};
+    ReduceArgs r{part_ws, nblk, M, NN, out, nullptr, ldo, 1.0, 0.0, 0, 0, add, add_coef, 0};
     if (rq && rq->push(r, 1)) return check_launch("k_thin");
     hipLaunchKernelGGL(k_reduce_parts, dim3((M * NN + 63) / 64, 1), dim3(256), 0, st, r);
     return check_launch("k_thin");
@@ -747,18 +751,6 @@ __global__ __launch_bounds__(64) void k_bw_final(FinalArgsB f) {
         if (lane == 0) f.dvariance[0] = (float)s;
     }
 }
-// - kl_weight * d KL: KL = 1/2 (sum q_mu^2 - R M - sum log L_ii^2 + sum L^2)   (temp_workaround.py:186-188)
-__global__ void k_bw_kl(FinalArgsB f) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (f.dq_mu && i < f.M * f.R) f.dq_mu[i] = (float)((double)f.dq_mu[i] - f.kl_weight * (double)f.q_mu[i]);
-    if (f.dq_sqrt && i < (long long)f.R * f.M * f.M) {
-        const int c = (int)(i % f.M), r_ = (int)((i / f.M) % f.M);
-        if (c > r_) { f.dq_sqrt[i] = 0.f; return; }
-        const double L = f.q_sqrt[i];
-        f.dq_sqrt[i] = (float)((double)f.dq_sqrt[i] - f.kl_weight * (L - (c == r_ ? 1.0 / L : 0.0)));
-    }
-}
-
 // dW[p, r] = S1 + S2 + 2 W o S3 with S1 = dFs^T G, S2 = dFm^T MU, S3 = dFv^T V;  dA = F^T dFs + F^T dFm
 __global__ void k_lin_combine(const float* s1, const float* s2, const float* s3, const float* W, float* dW, int n_w,
                               const float* a1, const float* a2, float* dA, int n_a) {
@@ -1134,13 +1126,15 @@ extern "C" int iwvi_gp_layer_backward(const iwvi_gp_bwd_desc* dp, int64_t T, voi
         if ((rc = gemm(st, q, w.part, w.part_floats, nullptr, w.Lbar, M, -1.0, 0.0, 1, 1, 0, 0, 0, &rq)) != IWVI_OK) return rc;
     }
     // dq_mu = A^T DMU
-    if (d.dq_mu && (rc = thin(st, d.A, Mp, M, w.DMU, R, R, 0, T, w.part, w.part_floats, d.dq_mu, 0, &rq)) != IWVI_OK) return rc;
+    // (- kl_weight * dKL/dq_mu = - kl_weight * q_mu rides in the reduction; temp_workaround.py:186-188)
+    if (d.dq_mu && (rc = thin(st, d.A, Mp, M, w.DMU, R, R, 0, T, w.part, w.part_floats, d.dq_mu, 0, &rq, d.q_mu, -d.kl_weight)) != IWVI_OK) return rc;
     // dL_r = tril(A^T diag(2 dv_r) U_r), all r in one batched launch
     if (d.dq_sqrt) {
         GemmArgs q{};
         q.A = d.A; q.a_sm = 1; q.a_sk = Mp; q.B = d.U; q.b_sk = Mp; q.b_sn = 1;
         q.scale = w.DV2; q.s_stride = R; q.scale_on_k = 1; q.M = M; q.N = M; q.K = (int)T; q.tri_out = 1;
-        if ((rc = gemm(st, q, w.part, w.part_floats, d.dq_sqrt, nullptr, M, 1.0, 0.0, 1, R, (long long)T * Mp, 1, (long long)M * M, &rq)) != IWVI_OK) return rc;
+        // (- kl_weight * dKL/dL_r = - kl_weight * (L_r - diag(1 / L_ii)) rides in the reduction)
+        if ((rc = gemm(st, q, w.part, w.part_floats, d.dq_sqrt, nullptr, M, 1.0, 0.0, 1, R, (long long)T * Mp, 1, (long long)M * M, &rq, d.q_sqrt, -d.kl_weight, 1)) != IWVI_OK) return rc;
     }
     // C = -1/2 K o DK (over DA), dx~, dF, per-sample rows of the column sums
     KernArgs ka{d.F, w.Zt, w.invls, w.DK, w.DA, w.SDV, d.dF, w.Qx, T, M, D, d.variance};
@@ -1189,7 +1183,6 @@ extern "C" int iwvi_gp_layer_backward(const iwvi_gp_bwd_desc* dp, int64_t T, voi
     FinalArgsB f{d.Z, d.lengthscales, d.q_mu, d.q_sqrt, w.Zt, w.invls, w.CtF1, w.CtF1, w.Qsum + D, w.Qsum, w.dZt_uu, w.dvar_m,
                  d.dZ, d.dls, d.dvariance, d.dq_mu, d.dq_sqrt, M, D, R, d.kl_weight, (double)d.variance};
     hipLaunchKernelGGL(k_bw_final, dim3(D + 1), dim3(64), 0, st, f);
-    hipLaunchKernelGGL(k_bw_kl, dim3((unsigned)(((long long)R * M * M + 255) / 256)), dim3(256), 0, st, f);   // (independent of k_bw_final)
     return check_launch("k_bw_final");
 }
 
