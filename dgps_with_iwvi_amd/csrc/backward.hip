@@ -40,10 +40,22 @@ struct GemmArgs {
     // B + b*b_batch, scale + b*s_batch and writes part + b*nsplit*M*N.
     int kseg; long long a_seg, b_seg, s_seg;
     int nbatch; long long b_batch, s_batch;
+    // optional epilogue of a row product (replaces beta * C): + sum_r e_dmu[m, r] e_qmu[n, r] - 2 e_sdv[m] e_A[m * e_lda + n]
+    const float* e_dmu; const float* e_qmu; const float* e_sdv; const float* e_A; long long e_lda; int e_R;
     int tri_out;                        // split-K products whose strict upper triangle is discarded: those tiles are skipped
     int b_lower_kn;                     // B(k, n) = 0 for k < n (a lower-triangular matrix indexed [k][n]): k starts at the tile's n0
 };
 constexpr int GT = 64, GK = 16, GLD = GT + 4;
+
+__device__ __forceinline__ float gemm_epilogue(const GemmArgs& g, int m, int n, float acc) {
+    float v = g.alpha * acc;
+    if (g.e_dmu) {
+        float e = -2.f * g.e_sdv[m] * g.e_A[m * g.e_lda + n];
+        for (int r = 0; r < g.e_R; ++r) e = fmaf(g.e_dmu[(long long)m * g.e_R + r], g.e_qmu[(long long)n * g.e_R + r], e);
+        return v + e;
+    }
+    return v + (g.beta != 0.f ? g.beta * g.C[m * g.ldc + n] : 0.f);
+}
 
 __global__ __launch_bounds__(256) void k_gemm(GemmArgs g) {
     __shared__ float As[GK][GLD];
@@ -91,10 +103,7 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs g) {
             const int m = m0 + 16 * wave + 4 * (lane >> 4) + v, n = n0 + 16 * j + (lane & 15);
             if (m >= g.M || n >= g.N) continue;
             if (g.nsplit > 1) g.part[((size_t)blockIdx.z * g.M + m) * g.N + n] = acc[j][v];
-            else {
-                float* c = g.C + m * g.ldc + n;
-                *c = g.alpha * acc[j][v] + (g.beta != 0.f ? g.beta * *c : 0.f);
-            }
+            else g.C[m * g.ldc + n] = gemm_epilogue(g, m, n, acc[j][v]);
         }
 }
 
@@ -190,10 +199,7 @@ __global__ __launch_bounds__(256) void k_gemm_fast(GemmArgs g) {
     for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int v = 0; v < 4; ++v) {
         const int m = m0 + wm + 16 * i + 4 * (lane >> 4) + v, n = n0 + wn + 16 * j + (lane & 15);
         if (part) part[(size_t)m * g.N + n] = acc[i][j][v];
-        else {
-            float* c = g.C + m * g.ldc + n;
-            *c = g.alpha * acc[i][j][v] + (g.beta != 0.f ? g.beta * *c : 0.f);
-        }
+        else g.C[m * g.ldc + n] = gemm_epilogue(g, m, n, acc[i][j][v]);
     }
 }
 // Larger tiles for the same job when M and N allow it: 128x128 per workgroup, 16-deep stages, each wave a 64x64 quadrant as
@@ -286,10 +292,7 @@ __global__ __launch_bounds__(256) void k_gemm_big(GemmArgs g) {
         // 32x32 accumulator: register v of lane l = row 8*(v/4) + 4*(l/32) + v%4, column l%32
         const int m = m0 + wm + 32 * i + 8 * (v >> 2) + 4 * (lane >> 5) + (v & 3), n = n0 + wn + 32 * j + (lane & 31);
         if (part) part[(size_t)m * g.N + n] = acc[i][j][v];
-        else {
-            float* c = g.C + m * g.ldc + n;
-            *c = g.alpha * acc[i][j][v] + (g.beta != 0.f ? g.beta * *c : 0.f);
-        }
+        else g.C[m * g.ldc + n] = gemm_epilogue(g, m, n, acc[i][j][v]);
     }
 }
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -439,6 +442,7 @@ static int gemm_rows(hipStream_t st, GemmArgs g, int nseg = 1, long long a_seg =
         GemmArgs q = g;
         q.K = g.kseg; q.kchunk = round_up(q.K, GK); q.A = g.A + sgi * a_seg; q.B = g.B + sgi * b_seg; if (g.scale) q.scale = g.scale + sgi * s_seg;
         q.beta = sgi == 0 ? beta : 1.f;
+        if (sgi > 0) q.e_dmu = nullptr;                    // the epilogue terms enter once
         hipLaunchKernelGGL(k_gemm, dim3((g.N + GT - 1) / GT, (g.M + GT - 1) / GT, 1), dim3(256), 0, st, q);
     }
     return check_launch("k_gemm (rows)");
@@ -525,16 +529,6 @@ __global__ __launch_bounds__(256) void k_bw_heads(HeadArgs h) {
         }
         h.dF[t * h.D + d] = acc;
     }
-}
-
-// DA[t, m] = sum_r DMU[t, r] q_mu[m, r] - 2 SDV[t] A[t, m]   (the U_r L_r^T products are accumulated on top)
-__global__ void k_bw_da_init(float* DA, const float* A, const float* SDV, const float* DMU, const float* q_mu, long long T, int M, int Mp, int R) {
-    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= T * M) return;
-    const long long t = idx / M; const int m = (int)(idx - t * M);
-    float acc = -2.f * SDV[t] * A[t * Mp + m];
-    for (int r = 0; r < R; ++r) acc = fmaf(DMU[t * R + r], q_mu[m * R + r], acc);
-    DA[idx] = acc;
 }
 
 // One wave per sample: K_uf entries again (RBF, direct differences), c = -1/2 k dk written over DA, then
@@ -1101,15 +1095,15 @@ extern "C" int iwvi_gp_layer_backward(const iwvi_gp_bwd_desc* dp, int64_t T, voi
     hipLaunchKernelGGL(k_bw_heads, dim3((unsigned)((T + 3) / 4)), dim3(256), 0, st, h);
     if ((rc = check_launch("k_bw_heads")) != IWVI_OK) return rc;
     ReduceQueue rq(w.part, w.part_floats);                 // every sum over samples below is finished by ONE launch (rq.flush)
-    // DA = DMU q_mu^T - 2 SDV o A
-    hipLaunchKernelGGL(k_bw_da_init, dim3((unsigned)((T * M + 255) / 256)), dim3(256), 0, st, w.DA, d.A, (const float*)w.SDV, (const float*)w.DMU, d.q_mu, (long long)T, M, Mp, R);
-    // DA += sum_r (2 dv_r) o (U_r L_r^T): one launch, R segments of M along the contraction
+    // DA = DMU q_mu^T - 2 SDV o A + sum_r (2 dv_r) o (U_r L_r^T): ONE launch -- R segments of M along the contraction, the
+    // first two terms in the epilogue
     {
         GemmArgs q{};
         q.A = d.U; q.a_sm = Mp; q.a_sk = 1;
         q.B = d.q_sqrt; q.b_sk = 1; q.b_sn = M; q.b_keep_n_ge_k = 1;                          // B(k = j, n = i) = L_r[i][j], i >= j
         q.scale = w.DV2; q.s_stride = R; q.scale_on_k = 0;
-        q.C = w.DA; q.ldc = M; q.M = (int)T; q.N = M; q.K = M; q.alpha = 1.f; q.beta = 1.f;
+        q.C = w.DA; q.ldc = M; q.M = (int)T; q.N = M; q.K = M; q.alpha = 1.f; q.beta = 0.f;
+        q.e_dmu = w.DMU; q.e_qmu = d.q_mu; q.e_sdv = w.SDV; q.e_A = d.A; q.e_lda = Mp; q.e_R = R;
         if ((rc = gemm_rows(st, q, R, (long long)T * Mp, (long long)M * M, 1)) != IWVI_OK) return rc;
     }
     // DK = DA Lm^-1
