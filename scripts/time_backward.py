@@ -42,6 +42,22 @@ def main():
         return
     fwd = timed(lambda: model._build_likelihood(), a.iters)
     grad = timed(lambda: backward.iw_elbo_and_gradients(model), a.iters)
+    graph_ms = float("nan")
+    try:                                                      # the same evaluation replayed from a hipGraph (no host work per launch)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                backward.iw_elbo_and_gradients(model)
+        torch.cuda.current_stream().wait_stream(side)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):
+            out = backward.iw_elbo_and_gradients(model)
+        graph_ms = timed(g.replay, a.iters)
+        e1 = float(out[0]); g.replay(); torch.cuda.synchronize(); e2 = float(out[0])
+        print("graph replay: %.3f ms per value+gradient; two replays give different noise: %s (%.4f, %.4f)" % (graph_ms, e1 != e2, e1, e2))
+    except Exception as e:
+        print("graph capture failed: %s: %s" % (type(e).__name__, e))
     tr = Trainer(model)
     step = timed(lambda: tr.step(), a.iters)
     print("config %d: forward (fused, eager) %.3f ms | value+gradient %.3f ms (%.2e samples/s) | training step %.3f ms"
