@@ -106,7 +106,7 @@ PROTOTYPES = {
     "iwvi_iw_elbo_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, ctypes.POINTER(c_void_p),
                                       ctypes.POINTER(ctypes.c_int32), c_int, c_int64, c_int, c_float, c_double, c_int,
                                       c_void_p, c_void_p, c_void_p, ctypes.POINTER(c_void_p), ctypes.POINTER(ctypes.c_int32), c_int,
-                                      c_void_p, c_void_p, c_void_p]),
+                                      c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "iwvi_lv_layer_backward": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p,
                                        c_int, c_int64, c_int, c_int, c_void_p, c_void_p]),
     "iwvi_encoder_backward_ws_bytes": (c_size_t, [c_int64, ctypes.POINTER(ctypes.c_int32), c_int]),

@@ -131,9 +131,14 @@ def lv_backward(layer, XY, enc_out, eps, dF_next, col0, w, B, K, sampled_kl=True
     return dW, db
 
 
-def iw_elbo_and_gradients(model, zs=None, mode_vi=None):
+def iw_elbo_and_gradients(model, zs=None, mode_vi=None, exchange=None, K_total=None, kl_weight=1.0):
     """``mode_vi`` (default: the model is a DGP_VI, not a DGP_IWVI): the bound of models.py:49-86 instead -- analytic
     local KL, mean over the S samples; ``zs`` then in that model's layout [S*N, dim] (S-major tiling, models.py:50).
+
+    K-sharded training (``sharding.k_shard_gradients``): ``exchange(ms [B, 2]) -> lse [B]`` turns this rank's per-point
+    (max, sum exp) pairs into the logsumexp over ALL ``K_total`` samples of the job; the gradients returned are then
+    this rank's share (weights exp(L - lse)), to be SUMMED over the ranks, with the KL terms weighted ``kl_weight``
+    (1 / world) so that they count once; the value returned is the job's bound.
 
     The IW-ELBO of the current minibatch (models.py:112-150) and its gradient w.r.t. every parameter the
     reference trains (build_models.py:284-304): -> (elbo [0-dim float64 tensor], dict) with the names of
@@ -198,10 +203,17 @@ def iw_elbo_and_gradients(model, zs=None, mode_vi=None):
     glob_n = (ctypes.c_int32 * max(len(glob), 1))(*[g.numel() for g in glob])
     ws = torch.empty(2 * B, dtype=torch.float64, device=dev)
     scale = float(model.num_data) / float(B)
+    lse_g = None
+    if exchange is not None:
+        if mode_vi:
+            raise ValueError("the K-sharded exchange is for the importance-weighted bound")
+        _, _, ms = model._reduce(fin.mean, fin.var, Y, kls, [], B, K, stride_b=K, stride_k=1, mode_vi=False, want_ms=True)
+        lse_g = _abi.dev_tensor(exchange(ms).to(ft).contiguous(), "lse_global")
     _abi.check(_abi.lib().iwvi_iw_elbo_backward(
         _abi.ptr(fin.mean), _abi.ptr(fin.var), _abi.ptr(Y), Dy, klp, kld, len(kls), B, K,
         float(model.likelihood.variance), scale, 1 if mode_vi else 0, _abi.ptr(w), _abi.ptr(d_mean), _abi.ptr(d_var),
-        glob_p, glob_n, len(glob), ctypes.c_void_p(sums.data_ptr()), ctypes.c_void_p(ws.data_ptr()), _abi.stream_ptr()))
+        glob_p, glob_n, len(glob), _abi.ptr(lse_g), int(K_total or K),
+        ctypes.c_void_p(sums.data_ptr()), ctypes.c_void_p(ws.data_ptr()), _abi.stream_ptr()))
     grads = {"lik_var": sums[1]}
     elbo = sums[2]                                               # scale * sum_n(...) - sum of the global KLs, formed on the device
     dF = None
@@ -210,7 +222,7 @@ def iw_elbo_and_gradients(model, zs=None, mode_vi=None):
         if s[0] == "gp":
             last = i == len(layers) - 1
             g = gp_backward(layer, s[1], d_sample=None if last else dF, d_mean=d_mean if last else None,
-                            d_var=d_var if last else None, kl_weight=1.0, want_dF=i > 0)
+                            d_var=d_var if last else None, kl_weight=kl_weight, want_dF=i > 0)
             for k_out, k_name in (("dZ", "Z"), ("dls", "ls"), ("dvariance", "var"), ("dq_mu", "q_mu"), ("dq_sqrt", "q_sqrt"),
                                   ("dW", "W"), ("dmf_A", "mfA")):
                 if k_out in g:

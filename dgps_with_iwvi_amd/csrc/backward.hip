@@ -790,6 +790,7 @@ struct ElboBwdArgs {
     const float* fmean; const float* fvar; const float* Y; int Dy;
     const float* kl[IWVI_MAX_KL]; int kl_dims[IWVI_MAX_KL]; int n_kl;
     long long B; int K; float lik_var; double scale; int mode_vi;
+    const float* lse_global; int K_total;   // K-sharded: logsumexp over ALL the job's samples of each point (after the exchange)
     float* w; float* d_mean; float* d_var; double* part;   // part[0..B) = lse - log K, part[B..2B) = d lik_var share
 };
 __global__ __launch_bounds__(256) void k_elbo_bwd(ElboBwdArgs a) {      // one wave per data point, lanes over its K samples
@@ -812,6 +813,8 @@ __global__ __launch_bounds__(256) void k_elbo_bwd(ElboBwdArgs a) {      // one w
     if (a.mode_vi) {                                    // models.py:84: mean over the samples -> uniform weights
         for (int k = lane; k < a.K; k += 64) se += (double)logw(b * a.K + k);
         for (int o = 32; o > 0; o >>= 1) se += __shfl_xor(se, o, 64);
+    } else if (a.lse_global) {                          // weights against the whole job's normaliser: exp(L - LSE)
+        mx = a.lse_global[b]; se = 1.0;
     } else {
         for (int k = lane; k < a.K; k += 64) mx = fmaxf(mx, logw(b * a.K + k));
         for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
@@ -831,7 +834,7 @@ __global__ __launch_bounds__(256) void k_elbo_bwd(ElboBwdArgs a) {      // one w
         }
     }
     for (int o = 32; o > 0; o >>= 1) ds += __shfl_xor(ds, o, 64);
-    if (lane == 0) { a.part[b] = a.mode_vi ? se / (double)a.K : (double)mx + log(se) - log((double)a.K); a.part[a.B + b] = ds; }
+    if (lane == 0) { a.part[b] = a.mode_vi ? se / (double)a.K : (double)mx + log(se) - log((double)(a.lse_global ? a.K_total : a.K)); a.part[a.B + b] = ds; }
 }
 // out[0] = sum part[0..n), out[1] = sum part[n..2n), out[2] = scale * out[0] - sum of the global KL shares (the bound)
 struct ElboFinishArgs { const double* part; long long n; double scale; const double* klg[IWVI_MAX_LAYERS]; int kln[IWVI_MAX_LAYERS]; int n_glob; double* out; };
@@ -1185,6 +1188,7 @@ extern "C" int iwvi_iw_elbo_backward(const float* fmean, const float* fvar, cons
                                      int64_t B, int K, float lik_variance, double scale, int mode_vi,
                                      float* out_w, float* d_mean, float* d_var,
                                      const double* const* kl_global, const int32_t* kl_global_counts, int n_glob,
+                                     const float* lse_global, int K_total,
                                      double* out_sums /* [3]: sum_n (lse - log K), d/d lik_variance, the bound */, double* ws, void* stream_) {
     if (!fmean || !fvar || !Y || !out_sums || !ws || Dy <= 0 || B <= 0 || K <= 0 || n_local < 0 || n_local > IWVI_MAX_KL || !(lik_variance > 0.f) ||
         n_glob < 0 || n_glob > IWVI_MAX_LAYERS) {
@@ -1197,7 +1201,8 @@ extern "C" int iwvi_iw_elbo_backward(const float* fmean, const float* fvar, cons
         if (!kl_local || !kl_local[i] || !kl_dims || kl_dims[i] <= 0) { set_error("iwvi_iw_elbo_backward: bad local regulariser %d", i); return IWVI_ERR_ARG; }
         a.kl[i] = kl_local[i]; a.kl_dims[i] = kl_dims[i];
     }
-    a.B = B; a.K = K; a.lik_var = lik_variance; a.scale = scale; a.mode_vi = mode_vi; a.w = out_w; a.d_mean = d_mean; a.d_var = d_var; a.part = ws;
+    if (lse_global && (mode_vi || K_total < K)) { set_error("iwvi_iw_elbo_backward: lse_global needs the IW bound and K_total >= K"); return IWVI_ERR_ARG; }
+    a.B = B; a.K = K; a.lik_var = lik_variance; a.scale = scale; a.mode_vi = mode_vi; a.lse_global = lse_global; a.K_total = K_total; a.w = out_w; a.d_mean = d_mean; a.d_var = d_var; a.part = ws;
     hipLaunchKernelGGL(k_elbo_bwd, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, st, a);
     ElboFinishArgs fa{};
     fa.part = ws; fa.n = B; fa.scale = scale; fa.n_glob = n_glob; fa.out = out_sums;

@@ -182,3 +182,30 @@ def allreduce_gradients(grads, weight=None, group=None):
         grads[k] = bucket[o:o + n].to(grads[k].dtype).reshape(grads[k].shape)
         o += n
     return grads
+
+
+def lse_from_pairs(ms_all):
+    """Gathered (max, sum exp) pairs [G, B, 2] -> logsumexp over all the job's samples [B] (not yet minus log K)."""
+    m = ms_all[..., 0].max(0).values
+    return m + torch.log((ms_all[..., 1] * torch.exp(ms_all[..., 0] - m)).sum(0))
+
+
+def k_shard_gradients(model, zs=None, K_total=None, group=None):
+    """K-sharded training step input: every rank holds all B points and its own K_r of the job's K_total importance
+    samples.  One all-gather of the [B, 2] pairs (the exchange of the forward path) gives the job's logsumexp per
+    point; each rank's adjoint then runs with its share of the softmax weights, and ONE all-reduce (sum) of the flat
+    gradient bucket finishes d ELBO / d theta -- the KL terms enter with 1 / world per rank.  -> (elbo, grads)."""
+    from .backward import iw_elbo_and_gradients
+    world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+    K_total = int(K_total or model.num_samples * world)
+
+    def exchange(ms):
+        if world == 1:
+            return lse_from_pairs(ms[None])
+        gathered = torch.empty((world,) + tuple(ms.shape), dtype=ms.dtype, device=ms.device)
+        dist.all_gather_into_tensor(gathered.view(-1), ms.contiguous().view(-1), group=group)
+        return lse_from_pairs(gathered)
+
+    elbo, g = iw_elbo_and_gradients(model, zs, exchange=exchange, K_total=K_total, kl_weight=1.0 / world)
+    g = allreduce_gradients(g, weight=1.0, group=group)             # a sum: the shares add up
+    return elbo, g

@@ -24,12 +24,14 @@ def staircase_decay(base, step, rate, every=1000):
 
 class Trainer:
     def __init__(self, model, lr=5e-3, gamma=1e-2, lr_decay=0.98, gamma_decay=0.98, fix_linear=True,
-                 beta1=0.9, beta2=0.999, epsilon=1e-8, group=None, shard_weight=None):
+                 beta1=0.9, beta2=0.999, epsilon=1e-8, group=None, shard_weight=None, shard="n"):
         """``group`` / ``shard_weight``: data-parallel training over the ranks of a torch.distributed group (each rank's
         model holds its own minibatch rows, N-shard): gradients are merged by ``sharding.allreduce_gradients`` with
-        weight B_rank / B_job (default 1 / world) before either update, so every rank applies the same step."""
+        weight B_rank / B_job (default 1 / world) before either update, so every rank applies the same step.
+        ``shard="k"``: every rank holds all the points and its own share of the importance samples instead
+        (``sharding.k_shard_gradients``: one all-gather of the per-point pairs + one gradient all-reduce)."""
         self.model = model
-        self.group, self.shard_weight = group, shard_weight
+        self.group, self.shard_weight, self.shard = group, shard_weight, shard
         self.lr, self.gamma, self.lr_decay, self.gamma_decay = lr, gamma, lr_decay, gamma_decay
         self.betas, self.epsilon = (beta1, beta2), epsilon
         self.global_step = 0
@@ -92,8 +94,10 @@ class Trainer:
         return keep
 
     def _gradients(self, zs):
-        from .sharding import allreduce_gradients
+        from .sharding import allreduce_gradients, k_shard_gradients
         self.model.next_minibatch()                              # gpflow.Minibatch: a new batch per session.run (models.py:21-26)
+        if self.shard == "k":
+            return k_shard_gradients(self.model, zs, group=self.group)
         elbo, g = iw_elbo_and_gradients(self.model, zs)
         g["__elbo__"] = elbo.reshape(1)                          # rides in the same bucket: the job's bound
         g = allreduce_gradients(g, weight=self.shard_weight, group=self.group)

@@ -276,12 +276,15 @@ int iwvi_gp_layer_backward(const iwvi_gp_bwd_desc* desc, int64_t T, void* ws, vo
  * out_w [T] = d ELBO / d L_nk (scale * softmax over k), d_mean / d_var [T, Dy] = heads of the final layer,
  * out_sums[0] = sum_n (lse - log K), out_sums[1] = d ELBO / d lik_variance, out_sums[2] = the bound itself
  * (scale * out_sums[0] - the sum of the kl_global arrays, as iwvi_elbo_desc);  ws: 2*B doubles. Outputs may be NULL
- * except out_sums.  mode_vi != 0: the bound of DGP_VI (models.py:84: mean over the samples instead of the logsumexp). */
+ * except out_sums.  lse_global [B] (or NULL): K-sharded training -- the logsumexp of every point over ALL the job's
+ * K_total samples (after the exchange of iwvi_lse_merge); the weights are then exp(L - lse_global), this rank's share of the
+ * softmax, and out_sums[0] / [2] are the job's.  mode_vi != 0: the bound of DGP_VI (models.py:84: mean over the samples instead of the logsumexp). */
 int iwvi_iw_elbo_backward(const float* fmean, const float* fvar, const float* Y, int Dy,
                           const float* const* kl_local, const int32_t* kl_dims, int n_local,
                           int64_t B, int K, float lik_variance, double scale, int mode_vi,
                           float* out_w, float* d_mean, float* d_var,
                           const double* const* kl_global, const int32_t* kl_global_counts, int n_glob,
+                          const float* lse_global, int K_total,
                           double* out_sums, double* ws, void* stream);
 
 /* Adjoint of the LatentVariableLayer (layers.py:83-103): mu, sigma [B, latent_dim] (the encoder's outputs per data

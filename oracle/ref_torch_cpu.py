@@ -71,9 +71,16 @@ class CpuDGP:
         return float(self.elbo_tensor(zs))
 
     def elbo_tensor(self, zs, mode_vi=False):
-        """The IW-ELBO as a tensor (differentiable w.r.t. whichever parameter tensors require grad: the gradient
-        oracle of oracle/grad_oracle.py).  ``mode_vi``: the bound of DGP_VI instead (models.py:49-86: analytic local KL,
-        mean over the samples), same [B, K, .] noise layout."""
+        L_NK, glob = self.log_weights_tensor(zs, mode_vi)
+        B, K = L_NK.shape
+        logp = L_NK.mean(1) if mode_vi else torch.logsumexp(L_NK, 1) - math.log(K)                 # :84 / :148
+        return logp.sum() * (self.n_data / B) - glob                                               # :150
+
+    def log_weights_tensor(self, zs, mode_vi=False):
+        """Per-sample log-weights L_NK [B, K] (models.py:134-142) and the summed global KL, as tensors.  ``elbo_tensor``
+        (the IW-ELBO, differentiable w.r.t. whichever parameter tensors require grad: the gradient oracle of
+        oracle/grad_oracle.py) is built on it.  ``mode_vi``: the bound of DGP_VI instead (models.py:49-86: analytic
+        local KL, mean over the samples), same [B, K, .] noise layout."""
         B, K = self.X.shape[0], self.K
         F = self.X[:, None, :].repeat(1, K, 1)                                                     # models.py:113
         Yt = self.Y[:, None, :].repeat(1, K, 1)
@@ -121,5 +128,4 @@ class CpuDGP:
         L_NK = ve.sum(2)
         for kl in local:
             L_NK = L_NK - kl.sum(2)
-        logp = L_NK.mean(1) if mode_vi else torch.logsumexp(L_NK, 1) - math.log(K)                 # :84 / :148
-        return logp.sum() * (self.n_data / B) - sum(glob)                                          # :150
+        return L_NK, sum(glob)

@@ -58,7 +58,7 @@ def test_training_entry_points_refuse_bad_arguments_without_touching_the_gpu():
     d = _abi.GpBwdDesc()
     assert lib.iwvi_gp_layer_backward(ctypes.byref(d), 16, None, None) == -1          # IWVI_ERR_ARG: no workspace
     assert b"iwvi_gp_layer_backward" in lib.iwvi_last_error()
-    assert lib.iwvi_iw_elbo_backward(None, None, None, 1, None, None, 0, 4, 2, 0.1, 1.0, 0, None, None, None, None, None, 0, None, None, None) == -1
+    assert lib.iwvi_iw_elbo_backward(None, None, None, 1, None, None, 0, 4, 2, 0.1, 1.0, 0, None, None, None, None, None, 0, None, 0, None, None, None) == -1
     assert lib.iwvi_lv_layer_backward(None, None, 1, 0, None, None, 0, 0, None, 1, 4, 2, 1, None, None) == -1
     assert lib.iwvi_natgrad_step(None, None, None, None, 8, 1, 0.1, None, None) == -1
     arr = (_abi.AdamTensor * 1)()

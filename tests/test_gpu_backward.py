@@ -195,3 +195,32 @@ def test_vi_bound_gradients_match_oracle(gpu_device, L, M, S, B, lv):
     assert sorted(grads) == sorted(ref)
     for k, v in grads.items():
         _close(k, v.cpu().numpy().reshape(ref[k].shape), ref[k], rtol=5e-3)
+
+
+def test_k_sharded_gradients_add_up_to_the_unsharded_gradient(gpu_device):
+    """Two K-shards evaluated one after the other on one GPU (uneven split 4 + 3 of K = 7): the shares computed against the
+    merged logsumexp, with the KL terms at 1/2 each, sum to the gradient of the unsharded model -- and of the oracle."""
+    from dgps_with_iwvi_amd import synthetic, backward, sharding
+    from oracle.grad_oracle import iw_elbo_and_gradients
+    K, B = 7, 10
+    spec = synthetic.make_spec(L=2, M=32, B=B, K=K, with_lv=True, seed=17)
+    zs = synthetic.make_noise(spec, seed=18)
+    val, ref = iw_elbo_and_gradients(spec, zs)
+    tt = lambda a: torch.as_tensor(np.asarray(a, dtype=np.float32), device=gpu_device)
+    shards = [(0, 4), (4, 7)]
+    models = [synthetic.build_model(dict(spec, K=hi - lo), gpu_device) for lo, hi in shards]
+    pairs = []
+    for (lo, hi), m in zip(shards, models):                          # pass 1: every shard's per-point (max, sum exp)
+        def record(ms):
+            pairs.append(ms.clone())
+            return sharding.lse_from_pairs(ms[None])
+        backward.iw_elbo_and_gradients(m, [tt(z[:, lo:hi]) for z in zs], exchange=record, K_total=K)
+    lse = sharding.lse_from_pairs(torch.stack(pairs))
+    total, elbos = None, []
+    for (lo, hi), m in zip(shards, models):                          # pass 2: the shares against the merged normaliser
+        e, g = backward.iw_elbo_and_gradients(m, [tt(z[:, lo:hi]) for z in zs], exchange=lambda ms: lse, K_total=K, kl_weight=0.5)
+        elbos.append(float(e))
+        total = g if total is None else {k: total[k] + g[k] for k in g}
+    assert abs(elbos[0] - val) <= 2e-4 * abs(val) and abs(elbos[1] - val) <= 2e-4 * abs(val), (elbos, val)
+    for k, v in total.items():
+        _close(k, v.cpu().numpy().reshape(ref[k].shape), ref[k], rtol=5e-3)

@@ -73,6 +73,61 @@ def _grad_worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
+def _kgrad_worker(rank, world, port, q):
+    """K-shard training: each rank's share of the gradient -- autodiff of sum_n sum_{k in rank} sg(exp(L_nk - LSE_n)) L_nk * scale
+    - KL / world on the float64 restatement, LSE from sharding.lse_from_pairs on the all-gathered pairs -- summed by
+    sharding.allreduce_gradients(weight=1): equals the unsharded gradient oracle."""
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle.grad_oracle import iw_elbo_and_gradients
+        from oracle.ref_torch_cpu import CpuDGP
+        K = 7
+        spec = synthetic.make_spec(L=2, M=12, B=9, K=K, Dx=3, R=2, with_lv=True, seed=41, n_data=1024)
+        zs = synthetic.make_noise(spec, seed=42)
+        val, ref = iw_elbo_and_gradients(spec, zs)
+        Ks = sharding.split_samples(K, world)
+        k0 = sum(Ks[:rank]); sl = slice(k0, k0 + Ks[rank])
+        m = CpuDGP(dict(spec, K=Ks[rank]), torch.float64)
+        leaves = {}
+        for i, L in enumerate(m.layers):
+            if L["type"] == "lv":
+                L["W"] = [w.clone().requires_grad_(True) for w in L["W"]]
+                leaves["l%d.encW0" % i] = L["W"][0]
+            else:
+                L["q_mu"] = L["q_mu"].clone().requires_grad_(True); leaves["l%d.q_mu" % i] = L["q_mu"]
+                L["Z"] = L["Z"].clone().requires_grad_(True); leaves["l%d.Z" % i] = L["Z"]
+        L_NK, glob = m.log_weights_tensor([z[:, sl] for z in zs])
+        mx = L_NK.detach().max(1).values
+        ms = torch.stack([mx, torch.exp(L_NK.detach() - mx[:, None]).sum(1)], 1)               # the forward path's exchange unit
+        gathered = torch.empty((world,) + tuple(ms.shape), dtype=ms.dtype)
+        dist.all_gather_into_tensor(gathered.view(-1), ms.contiguous().view(-1))
+        lse = sharding.lse_from_pairs(gathered)
+        share = (torch.exp(L_NK.detach() - lse[:, None]) * L_NK).sum() * (spec["n_data"] / spec["B"]) - glob / world
+        share.backward()
+        g = sharding.allreduce_gradients({k: v.grad.clone() for k, v in leaves.items()}, weight=1.0)
+        err = max(float(np.abs(g[k].numpy() - ref[k]).max() / max(np.abs(ref[k]).max(), 1e-12)) for k in g)
+        bound = float((lse - np.log(K)).sum() * (spec["n_data"] / spec["B"]) - glob.detach())
+        q.put((rank, err, abs(bound - val) / abs(val)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_k_sharded_gradient_shares_sum_to_the_unsharded_gradient():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_kgrad_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, err, verr in res:
+        assert err <= 1e-10 and verr <= 1e-12, (rank, err, verr)
+
+
 def test_data_parallel_gradient_equals_unsharded():
     world, port = 2, _free_port()
     ctx = mp.get_context("spawn")
