@@ -13,6 +13,17 @@ from .layers import GPLayer, SharedMixedMok
 from .temp_workaround import precompute_states
 
 
+_SIDE = {}
+
+
+def _side_stream(device):
+    """One extra HIP stream per device: a layer's parameter-gradient branch runs there beside the adjoint of the layer below."""
+    key = (device.type, device.index)
+    if key not in _SIDE:
+        _SIDE[key] = torch.cuda.Stream(device=device)
+    return _SIDE[key]
+
+
 class GpSaved:
     """What one GP layer's forward leaves for its adjoint."""
     __slots__ = ("F", "noise", "A", "U", "sample", "mean", "var", "T", "GMV")
@@ -62,7 +73,7 @@ def gp_forward_saved(layer, F, z=None, words=None, precomputed=False):
     return s
 
 
-def gp_backward(layer, saved, d_sample=None, d_mean=None, d_var=None, kl_weight=1.0, want_dF=True):
+def gp_backward(layer, saved, d_sample=None, d_mean=None, d_var=None, kl_weight=1.0, want_dF=True, side_stream=None, keep=None):
     """``iwvi_gp_layer_backward``: upstream gradients [T, P] -> dict(dF [T, D], dZ, dls, dvariance, dq_mu, dq_sqrt)."""
     dev = saved.F.device
     T, D = saved.F.shape
@@ -87,7 +98,7 @@ def gp_backward(layer, saved, d_sample=None, d_mean=None, d_var=None, kl_weight=
     b.M, b.D, b.R, b.P, b.kern_type = M, D, R, P, kern.kern_type
     mf = layer.mean_function
     b.mf_type = mf.mf_type
-    keep = [Z, q_mu, q_sqrt, W]
+    keep_t = [Z, q_mu, q_sqrt, W]
     if W is not None:
         b.W = W.data_ptr()
     if mf.mf_type == _abi.MF_LINEAR:
@@ -98,12 +109,15 @@ def gp_backward(layer, saved, d_sample=None, d_mean=None, d_var=None, kl_weight=
     for name, t in (("d_sample", d_sample), ("d_mean", d_mean), ("d_var", d_var)):
         if t is not None:
             t = _abi.dev_tensor(t.reshape(T, P).contiguous(), name)
-            keep.append(t)
+            keep_t.append(t)
             setattr(b, name, t.data_ptr())
     b.kl_weight = float(kl_weight)
     for k, t in out.items():
         setattr(b, k, t.data_ptr())
     ws = torch.empty(_abi.lib().iwvi_gp_layer_backward_ws_bytes(T, M, D, R), dtype=torch.uint8, device=dev)
+    if side_stream is not None:                                  # parameter gradients beside the next layer's adjoint
+        b.side_stream = ctypes.c_void_p(side_stream.cuda_stream)
+        keep.append((ws, out, keep_t))                           # alive until the caller has joined the streams
     _abi.check(_abi.lib().iwvi_gp_layer_backward(ctypes.byref(b), T, ws.data_ptr(), _abi.stream_ptr()))
     return out
 
@@ -131,7 +145,7 @@ def lv_backward(layer, XY, enc_out, eps, dF_next, col0, w, B, K, sampled_kl=True
     return dW, db
 
 
-def iw_elbo_and_gradients(model, zs=None, mode_vi=None, exchange=None, K_total=None, kl_weight=1.0):
+def iw_elbo_and_gradients(model, zs=None, mode_vi=None, exchange=None, K_total=None, kl_weight=1.0, overlap=True):
     """``mode_vi`` (default: the model is a DGP_VI, not a DGP_IWVI): the bound of models.py:49-86 instead -- analytic
     local KL, mean over the S samples; ``zs`` then in that model's layout [S*N, dim] (S-major tiling, models.py:50).
 
@@ -215,6 +229,9 @@ def iw_elbo_and_gradients(model, zs=None, mode_vi=None, exchange=None, K_total=N
         glob_p, glob_n, len(glob), _abi.ptr(lse_g), int(K_total or K),
         ctypes.c_void_p(sums.data_ptr()), ctypes.c_void_p(ws.data_ptr()), _abi.stream_ptr()))
     grads = {"lik_var": sums[1]}
+    cur = torch.cuda.current_stream()
+    side = _side_stream(dev) if overlap else None
+    held = []
     elbo = sums[2]                                               # scale * sum_n(...) - sum of the global KLs, formed on the device
     dF = None
     for i in range(len(layers) - 1, -1, -1):
@@ -222,7 +239,8 @@ def iw_elbo_and_gradients(model, zs=None, mode_vi=None, exchange=None, K_total=N
         if s[0] == "gp":
             last = i == len(layers) - 1
             g = gp_backward(layer, s[1], d_sample=None if last else dF, d_mean=d_mean if last else None,
-                            d_var=d_var if last else None, kl_weight=kl_weight, want_dF=i > 0)
+                            d_var=d_var if last else None, kl_weight=kl_weight, want_dF=i > 0,
+                            side_stream=side if i > 0 else None, keep=held)
             for k_out, k_name in (("dZ", "Z"), ("dls", "ls"), ("dvariance", "var"), ("dq_mu", "q_mu"), ("dq_sqrt", "q_sqrt"),
                                   ("dW", "W"), ("dmf_A", "mfA")):
                 if k_out in g:
@@ -234,6 +252,9 @@ def iw_elbo_and_gradients(model, zs=None, mode_vi=None, exchange=None, K_total=N
             for j, (a, b) in enumerate(zip(dW, db)):
                 grads["l%d.encW%d" % (i, j)], grads["l%d.encb%d" % (i, j)] = a, b
             dF = None if (dF is None or i == 0) else dF[:, :D_in].contiguous()
+    if side is not None:
+        cur.wait_stream(side)                                    # join: the parameter gradients are complete on the caller's stream
+    del held
     return elbo, grads
 
 

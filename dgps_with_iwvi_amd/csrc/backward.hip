@@ -1116,6 +1116,27 @@ extern "C" int iwvi_gp_layer_backward(const iwvi_gp_bwd_desc* dp, int64_t T, voi
         q.C = w.DK; q.ldc = M; q.M = (int)T; q.N = M; q.K = M; q.alpha = 1.f; q.beta = 0.f; q.b_lower_kn = 1;
         if ((rc = gemm_rows(st, q)) != IWVI_OK) return rc;
     }
+    // C = -1/2 K o DK (over DA), dx~, dF, per-sample rows of the column sums
+    KernArgs ka{d.F, w.Zt, w.invls, w.DK, w.DA, w.SDV, d.dF, w.Qx, T, M, D, d.variance};
+    {
+        const dim3 grid((unsigned)((T + 15) / 16)), block(256);
+        if (D <= 4) hipLaunchKernelGGL(k_bw_kernel<4>, grid, block, 0, st, ka);
+        else if (D <= 8) hipLaunchKernelGGL(k_bw_kernel<8>, grid, block, 0, st, ka);
+        else if (D <= 16) hipLaunchKernelGGL(k_bw_kernel<16>, grid, block, 0, st, ka);
+        else hipLaunchKernelGGL(k_bw_kernel<32>, grid, block, 0, st, ka);
+    }
+    if ((rc = check_launch("k_bw_kernel")) != IWVI_OK) return rc;
+    // Everything the layer below needs (dF) is now queued on `st`.  What follows only produces this layer's parameter
+    // gradients: with a side stream it runs beside the next layer's adjoint instead of ahead of it.
+    hipStream_t main_st = st;
+    if (d.side_stream) {
+        hipEvent_t ev;
+        if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess || hipEventRecord(ev, main_st) != hipSuccess ||
+            hipStreamWaitEvent((hipStream_t)d.side_stream, ev, 0) != hipSuccess) { set_error("iwvi_gp_layer_backward: stream fork failed"); return IWVI_ERR_LAUNCH; }
+        (void)hipEventDestroy(ev);                         // (released once the recorded work has passed it)
+        st = (hipStream_t)d.side_stream;
+    }
+    (void)main_st;
     // dLm = -tril(DK^T A)  (float64 copy for the adjoint of the factorisation)
     {
         GemmArgs q{};
@@ -1133,16 +1154,6 @@ extern "C" int iwvi_gp_layer_backward(const iwvi_gp_bwd_desc* dp, int64_t T, voi
         // (- kl_weight * dKL/dL_r = - kl_weight * (L_r - diag(1 / L_ii)) rides in the reduction)
         if ((rc = gemm(st, q, w.part, w.part_floats, d.dq_sqrt, nullptr, M, 1.0, 0.0, 1, R, (long long)T * Mp, 1, (long long)M * M, &rq, d.q_sqrt, -d.kl_weight, 1)) != IWVI_OK) return rc;
     }
-    // C = -1/2 K o DK (over DA), dx~, dF, per-sample rows of the column sums
-    KernArgs ka{d.F, w.Zt, w.invls, w.DK, w.DA, w.SDV, d.dF, w.Qx, T, M, D, d.variance};
-    {
-        const dim3 grid((unsigned)((T + 15) / 16)), block(256);
-        if (D <= 4) hipLaunchKernelGGL(k_bw_kernel<4>, grid, block, 0, st, ka);
-        else if (D <= 8) hipLaunchKernelGGL(k_bw_kernel<8>, grid, block, 0, st, ka);
-        else if (D <= 16) hipLaunchKernelGGL(k_bw_kernel<16>, grid, block, 0, st, ka);
-        else hipLaunchKernelGGL(k_bw_kernel<32>, grid, block, 0, st, ka);
-    }
-    if ((rc = check_launch("k_bw_kernel")) != IWVI_OK) return rc;
     // sums over samples: C^T [F | 1]  and the column sums of Qx = (dx~ o x | sum_r dv_r | sum_m k dk)
     if ((rc = thin(st, w.DA, M, M, d.F, D, D, 1, T, w.part, w.part_floats, w.CtF1, 0, &rq)) != IWVI_OK) return rc;
     if ((rc = thin(st, w.Qx, D + 2, D + 2, nullptr, 0, 0, 1, T, w.part, w.part_floats, w.Qsum, 0, &rq)) != IWVI_OK) return rc;

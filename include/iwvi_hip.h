@@ -267,6 +267,9 @@ typedef struct iwvi_gp_bwd_desc {
     double kl_weight;
     float* dF; float* dZ; float* dls; float* dvariance; float* dq_mu; float* dq_sqrt;
     float* dW; float* dmf_A;        /* optional: [P, R] (SharedMixedMok.W), [D, P] (Linear mean function A) */
+    void* side_stream;              /* optional hipStream_t: once dF is queued on `stream`, the parameter gradients of this
+                                     * layer are queued there (after an event), so that they overlap the adjoint of the layer
+                                     * below; the caller joins the two streams before reading the parameter gradients */
 } iwvi_gp_bwd_desc;
 size_t iwvi_gp_layer_backward_ws_bytes(int64_t T, int M, int D, int R);
 int iwvi_gp_layer_backward(const iwvi_gp_bwd_desc* desc, int64_t T, void* ws, void* stream);
