@@ -978,11 +978,22 @@ __global__ void k_enc_reduce(EncReduceArgs a) {
 // C[i, j] = alpha * sum_k A(i, k) B(k, j) + beta * E[i, j];  post 1: Phi, post 2: nothing
 struct DmmArgs { const double* A; long long a_si, a_sk; const double* B; long long b_sk, b_sj; double* C; long long ldc;
                  int I, J, K; double alpha; const double* E; long long lde; double beta; int post; };
-__global__ void k_dmm2(DmmArgs a) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;
-    if (j >= a.J) return;
+__global__ __launch_bounds__(256) void k_dmm2(DmmArgs a) {               // 16x16 output tile per workgroup, operands through LDS
+    __shared__ double As[16][17], Bs[16][17];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int i = blockIdx.y * 16 + ty, j = blockIdx.x * 16 + tx;
     double s = 0.0;
-    for (int k = 0; k < a.K; ++k) s = fma(a.A[i * a.a_si + k * a.a_sk], a.B[k * a.b_sk + j * a.b_sj], s);
+    for (int k0 = 0; k0 < a.K; k0 += 16) {
+        if (a.a_sk == 1) As[ty][tx] = (i < a.I && k0 + tx < a.K) ? a.A[i * a.a_si + (k0 + tx)] : 0.0;
+        else { const int ii = blockIdx.y * 16 + tx, kk = k0 + ty; As[tx][ty] = (ii < a.I && kk < a.K) ? a.A[ii * a.a_si + kk * a.a_sk] : 0.0; }
+        if (a.b_sj == 1 || a.J == 1) Bs[ty][tx] = (k0 + ty < a.K && j < a.J) ? a.B[(k0 + ty) * a.b_sk + j * a.b_sj] : 0.0;
+        else { const int jj = blockIdx.x * 16 + ty, kk = k0 + tx; Bs[tx][ty] = (jj < a.J && kk < a.K) ? a.B[kk * a.b_sk + jj * a.b_sj] : 0.0; }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 16; ++k) s = fma(As[ty][k], Bs[k][tx], s);
+        __syncthreads();
+    }
+    if (i >= a.I || j >= a.J) return;
     s *= a.alpha;
     if (a.E) s += a.beta * a.E[i * a.lde + j];
     if (a.post == 1) s = (j > i) ? 0.0 : (j == i ? 0.5 * s : s);
@@ -991,8 +1002,69 @@ __global__ void k_dmm2(DmmArgs a) {
 static void dmm(hipStream_t st, const double* A, long long a_si, long long a_sk, const double* B, long long b_sk, long long b_sj,
                 double* C, long long ldc, int I, int J, int K, double alpha = 1.0, const double* E = nullptr, long long lde = 0, double beta = 0.0, int post = 0) {
     DmmArgs a{A, a_si, a_sk, B, b_sk, b_sj, C, ldc, I, J, K, alpha, E, lde, beta, post};
-    hipLaunchKernelGGL(k_dmm2, dim3((J + 127) / 128, I), dim3(J < 128 ? 64 : 128), 0, st, a);
+    hipLaunchKernelGGL(k_dmm2, dim3((J + 15) / 16, (I + 15) / 16), dim3(256), 0, st, a);
 }
+// X = L^-1 for n <= TRI_SMALL in ONE workgroup, 16x16 blocks of X in LDS: the diagonal blocks by substitution (a lane per
+// column), then block diagonal d = 1, 2, ...: X(i, i-d) = -X(i, i) * sum_{k=i-d}^{i-1} L(i, k) X(k, i-d); one barrier per d.
+constexpr int TRI_SMALL = 160;
+__global__ __launch_bounds__(256) void k_tri_inv_small(const double* L, double* X, int n) {
+    extern __shared__ double xs[];                       // lower-triangular blocks, row-block major: block (i, j) at tri(i) + j
+    const int nb = (n + 15) / 16, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    auto blk = [&](int i, int j) { return xs + (size_t)(i * (i + 1) / 2 + j) * 256; };
+    auto Lel = [&](int r, int c) { return (r < n && c < n) ? L[(size_t)r * n + c] : (r == c ? 1.0 : 0.0); };   // identity padding
+    double* scratch = xs + (size_t)(nb * (nb + 1) / 2) * 256 + wave * 256;
+    for (int i = wave; i < nb; i += 4) {
+        if (lane < 16) {
+            double x[16];
+            const int j = lane;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                double acc = (r == j) ? 1.0 : 0.0;
+#pragma unroll
+                for (int k = 0; k < 16; ++k) if (k < r && k >= j) acc = fma(-Lel(16 * i + r, 16 * i + k), x[k], acc);
+                x[r] = (r >= j) ? acc / Lel(16 * i + r, 16 * i + r) : 0.0;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) blk(i, i)[r * 16 + j] = x[r];
+        }
+    }
+    __syncthreads();
+    for (int d = 1; d < nb; ++d) {
+        for (int i = d + wave; i < nb; i += 4) {
+            const int j = i - d;
+            // T = sum_k L(i, k) X(k, j), k = j .. i-1   (4 outputs per lane: rows 4*(lane/16)+v, column lane%16)
+            double t[4] = {0.0, 0.0, 0.0, 0.0};
+            const int c = lane & 15, r0 = 4 * (lane >> 4);
+            for (int k = j; k < i; ++k) {
+                const double* xk = blk(k, j);
+                for (int q = 0; q < 16; ++q) {
+                    const double xv = xk[q * 16 + c];
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) t[v] = fma(Lel(16 * i + r0 + v, 16 * k + q), xv, t[v]);
+                }
+            }
+#pragma unroll
+            for (int v = 0; v < 4; ++v) scratch[(r0 + v) * 16 + c] = t[v];
+            __builtin_amdgcn_wave_barrier();
+            double o[4] = {0.0, 0.0, 0.0, 0.0};
+            const double* xi = blk(i, i);
+            for (int q = 0; q < 16; ++q) {
+                const double tv = scratch[q * 16 + c];
+#pragma unroll
+                for (int v = 0; v < 4; ++v) o[v] = fma(-xi[(r0 + v) * 16 + q], tv, o[v]);
+            }
+#pragma unroll
+            for (int v = 0; v < 4; ++v) blk(i, j)[(r0 + v) * 16 + c] = o[v];
+            __builtin_amdgcn_wave_barrier();
+        }
+        __syncthreads();
+    }
+    for (int idx = tid; idx < n * n; idx += 256) {
+        const int r = idx / n, c = idx - r * n;
+        X[idx] = (c <= r) ? blk(r >> 4, c >> 4)[(r & 15) * 16 + (c & 15)] : 0.0;
+    }
+}
+static int tri_inverse(hipStream_t st, const double* L, double* X, int n);
 // X = L^-1 for lower-triangular L [n, n] (row-major): one wave per column j solves L x = e_j by forward substitution,
 // x in LDS, each row's dot product spread over the lanes; zeros above the diagonal
 __global__ __launch_bounds__(64) void k_tri_inv(const double* L, double* X, int n) {
@@ -1009,6 +1081,24 @@ __global__ __launch_bounds__(64) void k_tri_inv(const double* L, double* X, int 
         }
         __syncthreads();
     }
+}
+static int tri_inverse(hipStream_t st, const double* L, double* X, int n) {
+    if (n <= TRI_SMALL) {
+        const int nb = (n + 15) / 16;
+        const size_t lds = sizeof(double) * ((size_t)(nb * (nb + 1) / 2) * 256 + 4 * 256);
+        static bool done = false;
+        if (!done) {
+            const int nbm = (TRI_SMALL + 15) / 16;
+            const size_t most = sizeof(double) * ((size_t)(nbm * (nbm + 1) / 2) * 256 + 4 * 256);
+            hipError_t e = hipFuncSetAttribute((const void*)k_tri_inv_small, hipFuncAttributeMaxDynamicSharedMemorySize, (int)most);
+            if (e != hipSuccess) { set_error("hipFuncSetAttribute(%zu B LDS): %s", most, hipGetErrorString(e)); return IWVI_ERR_LAUNCH; }
+            done = true;
+        }
+        hipLaunchKernelGGL(k_tri_inv_small, dim3(1), dim3(256), lds, st, L, X, n);
+    } else {
+        hipLaunchKernelGGL(k_tri_inv, dim3(n), dim3(64), 0, st, L, X, n);
+    }
+    return check_launch("triangular inverse");
 }
 __global__ void k_f2d(const float* src, long long ld, double* dst, int rows, int cols, double scale, int tril) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1309,7 +1399,7 @@ extern "C" int iwvi_natgrad_step(float* q_mu, float* q_sqrt, const float* dq_mu,
         hipLaunchKernelGGL(k_f2d, dim3(nb), dim3(256), 0, st, dq_sqrt + (size_t)r * M * M, (long long)M, Lbar, M, M, -1.0, 1);
         hipLaunchKernelGGL(k_f2d, dim3((M + 255) / 256), dim3(256), 0, st, (const float*)(q_mu + r), (long long)R, m, M, 1, 1.0, 0);
         hipLaunchKernelGGL(k_f2d, dim3((M + 255) / 256), dim3(256), 0, st, dq_mu + r, (long long)R, mbar, M, 1, -1.0, 0);
-        hipLaunchKernelGGL(k_tri_inv, dim3(M), dim3(64), 0, st, (const double*)L, Linv, M);
+        if ((rc = tri_inverse(st, L, Linv, M)) != IWVI_OK) return rc;
         // dLoss/dS (symmetric) from dLoss/dL: Sbar = sym(L^-T Phi(L^T Lbar) L^-1)
         dmm(st, L, 1, M, Lbar, M, 1, T1, M, M, M, M, 1.0, nullptr, 0, 0.0, 1);
         dmm(st, Linv, 1, M, T1, M, 1, T2, M, M, M, M);
@@ -1325,7 +1415,7 @@ extern "C" int iwvi_natgrad_step(float* q_mu, float* q_sqrt, const float* dq_mu,
         hipLaunchKernelGGL(k_axpby, dim3(nb), dim3(256), 0, st, (const double*)Sinv, 1.0, (const double*)Sbar, 2.0 * gamma, Pn, M * M);
         // natural_to_meanvarsqrt
         if ((rc = iwvi_chol_factor(Pn, T1, M, cws, stream_)) != IWVI_OK) return rc;
-        hipLaunchKernelGGL(k_tri_inv, dim3(M), dim3(64), 0, st, (const double*)T1, T2, M);
+        if ((rc = tri_inverse(st, T1, T2, M)) != IWVI_OK) return rc;
         dmm(st, T2, 1, M, T2, M, 1, Sbar, M, M, M, M);                                   // S' = X^T X
         dmm(st, Sbar, M, 1, mbar, 1, 1, m, 1, M, 1, M);                                  // mu' = S' theta_1'
         if ((rc = iwvi_chol_factor(Sbar, L, M, cws, stream_)) != IWVI_OK) return rc;
