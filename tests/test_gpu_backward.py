@@ -116,6 +116,14 @@ def test_iw_elbo_gradients_match_oracle(gpu_device, L, M, K, B, lv):
     assert sorted(grads) == sorted(ref)
     for k, v in grads.items():
         _close(k, v.reshape(ref[k].shape), ref[k], rtol=5e-3)
+    # bit-reproducible, with and without the side-stream overlap of the parameter-gradient branches
+    from dgps_with_iwvi_amd import backward
+    model = synthetic.build_model(spec, gpu_device)
+    zd = [torch.as_tensor(np.asarray(z, dtype=np.float32), device=gpu_device) for z in zs]
+    runs = [backward.iw_elbo_and_gradients(model, zd, overlap=o)[1] for o in (True, True, False)]
+    torch.cuda.synchronize()
+    for k in runs[0]:
+        assert torch.equal(runs[0][k], runs[1][k]) and torch.equal(runs[0][k], runs[2][k]), k
 
 
 @pytest.mark.parametrize("dims,rows", [([9, 20, 20, 2], 100), ([5, 48, 48, 40, 4], 333), ([3, 64, 2], 64)])
