@@ -133,30 +133,55 @@ def state_dict(model):
 
 
 def load_state_dict(model, state):
+    """In place (``copy_``) wherever the stored array has the parameter's shape, so that a ``training.Trainer`` built on the
+    model keeps pointing at live tensors; a parameter of another shape is replaced."""
     dev = model.X.device
     t = lambda a: torch.as_tensor(np.asarray(a), dtype=settings.float_type, device=dev)
+
+    def put(obj, name, value, index=None):
+        cur = getattr(obj, name) if index is None else getattr(obj, name)[index]
+        new = t(value)
+        if isinstance(cur, torch.Tensor) and cur.shape == new.shape and cur.device == new.device:
+            with torch.no_grad():
+                cur.copy_(new)
+        elif index is None:
+            setattr(obj, name, new)
+        else:
+            getattr(obj, name)[index] = new
+
     model.likelihood.variance = float(state["likelihood.variance"])
     for i, layer in enumerate(model.layers):
         p = "layers.%d." % i
         if isinstance(layer, GPLayer):
             kern = layer._base_kern()
-            layer._Z().copy_(t(state[p + "Z"]))
-            kern.lengthscales = t(state[p + "lengthscales"])
+            with torch.no_grad():
+                layer._Z().copy_(t(state[p + "Z"]))
+            put(kern, "lengthscales", state[p + "lengthscales"])
             kern.variance = float(state[p + "variance"])
-            layer.q_mu, layer.q_sqrt = t(state[p + "q_mu"]), t(state[p + "q_sqrt"])
+            put(layer, "q_mu", state[p + "q_mu"])
+            put(layer, "q_sqrt", state[p + "q_sqrt"])
             if isinstance(layer.kern, SharedMixedMok):
-                layer.kern.W = t(state[p + "W"])
+                put(layer.kern, "W", state[p + "W"])
             layer._state = None                                       # factorisation depends on Z / lengthscales
         elif isinstance(layer, LatentVariableLayer) and layer.encoder is not None:
-            layer.encoder.Ws = [t(state[p + "enc_W%d" % j]) for j in range(len(layer.encoder.Ws))]
-            layer.encoder.bs = [t(state[p + "enc_b%d" % j]) for j in range(len(layer.encoder.bs))]
+            for j in range(len(layer.encoder.Ws)):
+                put(layer.encoder, "Ws", state[p + "enc_W%d" % j], j)
+                put(layer.encoder, "bs", state[p + "enc_b%d" % j], j)
     return model
 
 
-def save_checkpoint(model, path):
-    np.savez(path, **state_dict(model))
+def save_checkpoint(model, path, trainer=None):
+    """Parameters (+ the optimiser state of ``trainer``: Adam moments and unconstrained variables, step counters) -> .npz."""
+    out = state_dict(model)
+    if trainer is not None:
+        out.update({"trainer." + k: v for k, v in trainer.state_dict().items()})
+    np.savez(path, **out)
 
 
-def load_checkpoint(model, path):
+def load_checkpoint(model, path, trainer=None):
     with np.load(path) as f:
-        return load_state_dict(model, {k: f[k] for k in f.files})
+        state = {k: f[k] for k in f.files}
+    load_state_dict(model, {k: v for k, v in state.items() if not k.startswith("trainer.")})
+    if trainer is not None:
+        trainer.load_state_dict({k[len("trainer."):]: v for k, v in state.items() if k.startswith("trainer.")})
+    return model

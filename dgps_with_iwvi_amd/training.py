@@ -9,6 +9,7 @@ kernel variance; encoders; the likelihood variance.  Gradients: ``backward.iw_el
 ``iwvi_natgrad_step`` / ``iwvi_adam_step`` (csrc/backward.hip)."""
 import ctypes
 
+import numpy as np
 import torch
 
 from . import _abi, settings
@@ -131,3 +132,22 @@ class Trainer:
         self.global_step += 1
         self.natgrad_op(zs_ng)
         return self.adam_op(zs_adam)
+
+    # -- checkpoint / resume (reference: gpflow Saver of the whole session, run_conditional_density_estimation.py:95-125) --
+    def state_dict(self):
+        out = {"global_step": np.int64(self.global_step), "adam_t": np.int64(self.adam_t)}
+        for (name, _, _), (x, m, v) in zip(self._entries, self._state):
+            out["x." + name], out["m." + name], out["v." + name] = (a.detach().cpu().numpy() for a in (x, m, v))
+        return out
+
+    def load_state_dict(self, state):
+        """After the model's parameters have been restored in place: the optimiser's own state and the step counters.
+        The host scalars' device masters are refreshed from the model."""
+        self.global_step, self.adam_t = int(state["global_step"]), int(state["adam_t"])
+        for (name, _, _), (x, m, v) in zip(self._entries, self._state):
+            for key, dst in (("x.", x), ("m.", m), ("v.", v)):
+                dst.copy_(torch.as_tensor(np.asarray(state[key + name]), dtype=dst.dtype, device=dst.device).reshape(dst.shape))
+        for (name, p, _), (x, _, _) in zip(self._entries, self._state):
+            if p.numel() == 1 and name.endswith(("var", "lik_var")):
+                p.copy_(torch.nn.functional.softplus(x) + 1e-6)          # the master of a host scalar, from its unconstrained value
+        return self

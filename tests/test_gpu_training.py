@@ -180,3 +180,31 @@ def test_training_raises_the_bound_on_fixed_noise(gpu_device):
         tr.step()
     after = model.compute_log_likelihood(zs)
     assert after > before, (before, after)
+
+
+def test_checkpoint_resume_continues_the_same_trajectory(gpu_device, tmp_path):
+    """Parameters + optimiser state through build_models.save_checkpoint / load_checkpoint: 3 steps, save, restore into a
+    fresh model and trainer, 2 more steps == 5 uninterrupted steps (same injected noise), bit for bit."""
+    from dgps_with_iwvi_amd import synthetic, build_models
+    from dgps_with_iwvi_amd.training import Trainer
+    spec = synthetic.make_spec(L=2, M=32, B=12, K=4, with_lv=True, seed=23)
+    noise = [[_t(z, gpu_device) for z in synthetic.make_noise(spec, seed=300 + s)] for s in range(10)]
+
+    def run(model, tr, steps):
+        for s in steps:
+            tr.step(noise[2 * s], noise[2 * s + 1])
+
+    a = synthetic.build_model(spec, gpu_device); ta = Trainer(a)
+    run(a, ta, range(5))
+    b = synthetic.build_model(spec, gpu_device); tb = Trainer(b)
+    run(b, tb, range(3))
+    path = str(tmp_path / "ckpt.npz")
+    build_models.save_checkpoint(b, path, tb)
+    c = synthetic.build_model(spec, gpu_device); tc = Trainer(c)
+    build_models.load_checkpoint(c, path, tc)
+    assert tc.global_step == 3 and tc.adam_t == 3
+    run(c, tc, range(3, 5))
+    for (name, pa, _), (_, pc, _) in zip(ta._entries, tc._entries):
+        assert torch.equal(pa, pc), name
+    assert torch.equal(a.layers[-1].q_mu, c.layers[-1].q_mu) and torch.equal(a.layers[-1].q_sqrt, c.layers[-1].q_sqrt)
+    assert a.likelihood.variance == c.likelihood.variance
