@@ -589,6 +589,258 @@ __global__ __launch_bounds__(256) void k_bw_kernel(KernArgs a) {
     if (live && sub == 0) { a.Qx[t * W + a.D] = a.SDV[t]; a.Qx[t * W + a.D + 1] = skd; }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// The per-sample chain of one layer in ONE launch (M a multiple of 64 up to 256, T a multiple of 64, the forward's gmv
+// block at hand): a workgroup owns 64 samples and carries them through
+//   heads -> DA = DMU q_mu^T - 2 SDV o A + sum_r (2 dv_r) o (U_r L_r^T)  (tile kept in LDS)
+//         -> DK = DA Lm^-1 (A operand straight from that tile)  -> kernel adjoint c = -1/2 k o dk, dx~, dF,
+// so that DA never touches HBM, dK is read back from LDS, and four launches (and their ramps) become one.
+// Outputs for the sums over samples that follow: DMU, DV2, SDV, DK, C (into the DA buffer), Qx.
+// ------------------------------------------------------------------------------------------------------------
+struct MidArgs {
+    const float* GMV; const float* eps; const float* W; const float* mfA; const float* dFs; const float* dFm; const float* dFv;
+    float* DMU; float* DV2; float* SDV; float* dF; int P, mf_type;
+    const float* U; const float* A; int Mp; const float* q_sqrt; const float* q_mu;
+    const float* LinvF; float* DK;
+    const float* F; const float* Zt; const float* invls; float* C; float* Qx;
+    long long T; int M, D, R; float variance;
+};
+template <int NP, int DM>                // M = 64 NP;  D <= DM
+__global__ __launch_bounds__(256) void k_bw_mid(MidArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float msm[];
+    const int M = 64 * NP, LDT = M + 4;
+    float* tile = msm;                                       // [64][M + 4]: DA, then dK
+    float* As = tile + 64 * LDT;                             // [2][GKF][GLD]
+    float* Bs = As + 2 * GKF * GLD;                          // [2][GKF][GLD]
+    float* dmu_s = Bs + 2 * GKF * GLD;                       // [64][R]
+    float* dv2_s = dmu_s + 64 * a.R;                         // [64][R]
+    float* sdv_s = dv2_s + 64 * a.R;                         // [64]
+    float* dfi_s = sdv_s + 64;                               // [64][D]: the mean function's share of dF
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long long t0 = (long long)blockIdx.x * 64;
+    const int R = a.R, D = a.D, P = a.P;
+    auto AS = [&](int buf, int k, int m) -> float& { return As[(buf * GKF + k) * GLD + m]; };
+    auto BS = [&](int buf, int k, int n) -> float& { return Bs[(buf * GKF + k) * GLD + n]; };
+
+    // ---- heads (layers.py:46-48, temp_workaround.py:85-91, :142-145), one thread per sample
+    if (tid < 64) {
+        const long long t = t0 + tid;
+        float sdv = 0.f;
+        for (int r = 0; r < R; ++r) {
+            float dg = 0.f, dm = 0.f, dvv = 0.f;
+            if (a.W) {
+                for (int p = 0; p < P; ++p) {
+                    const float w = a.W[p * R + r];
+                    if (a.dFs) dg = fmaf(w, a.dFs[t * P + p], dg);
+                    if (a.dFm) dm = fmaf(w, a.dFm[t * P + p], dm);
+                    if (a.dFv) dvv = fmaf(w * w, a.dFv[t * P + p], dvv);
+                }
+            } else {
+                if (a.dFs) dg = a.dFs[t * P + r];
+                if (a.dFm) dm = a.dFm[t * P + r];
+                if (a.dFv) dvv = a.dFv[t * P + r];
+            }
+            const float v = a.GMV[t * 3 * R + 2 * R + r];
+            float dv = dvv;
+            if (v > 0.f) { if (a.eps) dv += dg * a.eps[t * R + r] * 0.5f / sqrtf(v); } else dv = 0.f;
+            dmu_s[tid * R + r] = dg + dm; dv2_s[tid * R + r] = 2.f * dv; sdv += dv;
+            a.DMU[t * R + r] = dg + dm; a.DV2[t * R + r] = 2.f * dv;
+        }
+        sdv_s[tid] = sdv; a.SDV[t] = sdv;
+    }
+    for (int idx = tid; idx < 64 * D; idx += 256) {
+        const int j = idx / D, d = idx - j * D;
+        const long long t = t0 + j;
+        float acc = 0.f;
+        if (a.mf_type == IWVI_MF_LINEAR) {
+            for (int p = 0; p < P; ++p) {
+                float up = 0.f;
+                if (a.dFs) up += a.dFs[t * P + p];
+                if (a.dFm) up += a.dFm[t * P + p];
+                acc = fmaf(a.mfA[d * P + p], up, acc);
+            }
+        } else if (a.mf_type == IWVI_MF_IDENTITY) {
+            if (a.dFs) acc += a.dFs[t * P + d];
+            if (a.dFm) acc += a.dFm[t * P + d];
+        }
+        dfi_s[idx] = acc;
+    }
+    __syncthreads();
+
+    const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
+    const int sm_ = tid >> 3, sk_ = (tid & 7) * 4;          // slot of a k-contiguous operand: (row = tid/8 + 32 j, k = 4 (tid%8) ..)
+    const int nk_ = tid >> 4, nn_ = (tid & 15) * 4;         // slot of a row-contiguous operand: (k = tid/16 + 16 j, col = 4 (tid%16) ..)
+    // ---- DA tile: for each 64-column pass, R segments of the contraction (k < n0 + 64 only: L_r is lower triangular)
+    for (int np = 0; np < NP; ++np) {
+        const int n0 = 64 * np, hi = n0 + 64, ns = hi / GKF, nstage = ns * R;
+        f32x4 acc[2][2];
+        for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        f32x4 ra[2], rb[2];
+        auto fetch = [&](int s) {
+            const int r = s / ns, kl = (s - r * ns) * GKF;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int m = sm_ + 32 * j, k = kl + sk_;
+                ra[j] = *reinterpret_cast<const f32x4*>(a.U + ((size_t)r * a.T + t0 + m) * a.Mp + k);
+                ra[j] *= dv2_s[m * R + r];
+                const int n = n0 + sm_ + 32 * j;
+                rb[j] = *reinterpret_cast<const f32x4*>(a.q_sqrt + ((size_t)r * M + n) * M + k);      // B(k, n) = L_r[n][k], n >= k
+                for (int e = 0; e < 4; ++e) if (n < k + e) rb[j][e] = 0.f;
+            }
+        };
+        auto stash = [&](int buf) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) for (int e = 0; e < 4; ++e) { AS(buf, sk_ + e, sm_ + 32 * j) = ra[j][e]; BS(buf, sk_ + e, sm_ + 32 * j) = rb[j][e]; }
+        };
+        fetch(0); stash(0);
+        __syncthreads();
+        int buf = 0;
+        for (int s = 0; s < nstage; ++s, buf ^= 1) {
+            const bool more = s + 1 < nstage;
+            if (more) fetch(s + 1);
+#pragma unroll
+            for (int kk = 0; kk < GKF / 4; ++kk) {
+                const int kr = 4 * kk + (lane >> 4);
+                const float a0 = AS(buf, kr, wm + (lane & 15)), a1 = AS(buf, kr, wm + 16 + (lane & 15));
+                const float b0 = BS(buf, kr, wn + (lane & 15)), b1 = BS(buf, kr, wn + 16 + (lane & 15));
+                acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b1, acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b0, acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc[1][1], 0, 0, 0);
+            }
+            if (more) stash(buf ^ 1);
+            __syncthreads();
+        }
+        for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int v = 0; v < 4; ++v) {
+            const int m = wm + 16 * i + 4 * (lane >> 4) + v, n = n0 + wn + 16 * j + (lane & 15);
+            float e = -2.f * sdv_s[m] * a.A[(t0 + m) * a.Mp + n];
+            for (int r = 0; r < R; ++r) e = fmaf(dmu_s[m * R + r], a.q_mu[n * R + r], e);
+            tile[m * LDT + n] = acc[i][j][v] + e;
+        }
+    }
+    __syncthreads();
+
+    // ---- dK = DA Lm^-1: A operand from the tile, B = Lm^-1 rows k >= n0 staged through LDS; all passes' accumulators are
+    //      kept so that the tile can be overwritten only once every pass has read it
+    f32x4 acc2[NP][2][2];
+    for (int np = 0; np < NP; ++np) {
+        const int n0 = 64 * np, nstage = (M - n0) / GKF;
+        for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) acc2[np][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        f32x4 rb[2];
+        auto fetch = [&](int s) {
+            const int kl = n0 + s * GKF;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) rb[j] = *reinterpret_cast<const f32x4*>(a.LinvF + (size_t)(kl + nk_ + 16 * j) * M + n0 + nn_);
+        };
+        auto stash = [&](int buf) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) *reinterpret_cast<f32x4*>(&BS(buf, nk_ + 16 * j, nn_)) = rb[j];
+        };
+        fetch(0); stash(0);
+        __syncthreads();
+        int buf = 0;
+        for (int s = 0; s < nstage; ++s, buf ^= 1) {
+            const bool more = s + 1 < nstage;
+            if (more) fetch(s + 1);
+            const int kb = n0 + s * GKF;
+#pragma unroll
+            for (int kk = 0; kk < GKF / 4; ++kk) {
+                const int kr = 4 * kk + (lane >> 4);
+                const float a0 = tile[(wm + (lane & 15)) * LDT + kb + kr], a1 = tile[(wm + 16 + (lane & 15)) * LDT + kb + kr];
+                const float b0 = BS(buf, kr, wn + (lane & 15)), b1 = BS(buf, kr, wn + 16 + (lane & 15));
+                acc2[np][0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc2[np][0][0], 0, 0, 0);
+                acc2[np][0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b1, acc2[np][0][1], 0, 0, 0);
+                acc2[np][1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b0, acc2[np][1][0], 0, 0, 0);
+                acc2[np][1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc2[np][1][1], 0, 0, 0);
+            }
+            if (more) stash(buf ^ 1);
+            __syncthreads();
+        }
+    }
+    for (int np = 0; np < NP; ++np)
+        for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int v = 0; v < 4; ++v) {
+            const int m = wm + 16 * i + 4 * (lane >> 4) + v, n = 64 * np + wn + 16 * j + (lane & 15);
+            tile[m * LDT + n] = acc2[np][i][j][v];
+            a.DK[(t0 + m) * M + n] = acc2[np][i][j][v];
+        }
+    __syncthreads();
+
+    // ---- kernel adjoint (RBF, direct differences), 16 lanes per sample, 16 samples per round
+    const int sub = tid & 15;
+    auto gsum = [](float v) { for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64); return v; };
+    for (int round = 0; round < 4; ++round) {
+        const int j = 16 * round + (tid >> 4);
+        const long long t = t0 + j;
+        float xt[DM], cz[DM];
+#pragma unroll
+        for (int d = 0; d < DM; ++d) { xt[d] = d < D ? a.F[t * D + d] * a.invls[d] : 0.f; cz[d] = 0.f; }
+        float sc = 0.f, skd = 0.f;
+        for (int m0 = 0; m0 < M; m0 += 64) {
+            const int mb = m0 + 4 * sub;
+            const f32x4 dk = *reinterpret_cast<const f32x4*>(&tile[j * LDT + mb]);
+            f32x4 c;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float d2 = 0.f, z[DM];
+#pragma unroll
+                for (int d = 0; d < DM; ++d) { z[d] = d < D ? a.Zt[(mb + e) * D + d] : 0.f; const float q = xt[d] - z[d]; d2 = fmaf(q, q, d2); }
+                const float kd = a.variance * __expf(-0.5f * d2) * dk[e];
+                c[e] = -0.5f * kd;
+                sc += c[e]; skd += kd;
+#pragma unroll
+                for (int d = 0; d < DM; ++d) cz[d] = fmaf(c[e], z[d], cz[d]);
+            }
+            *reinterpret_cast<f32x4*>(a.C + t * M + mb) = c;
+        }
+        sc = gsum(sc); skd = gsum(skd);
+        const int Wq = D + 2;
+#pragma unroll
+        for (int d = 0; d < DM; ++d) {
+            if (d < D) {
+                const float czd = gsum(cz[d]);
+                if (sub == 0) {
+                    const float dxt = 2.f * xt[d] * sc - 2.f * czd;
+                    if (a.dF) a.dF[t * D + d] = fmaf(dxt, a.invls[d], dfi_s[j * D + d]);
+                    a.Qx[t * Wq + d] = dxt * a.F[t * D + d];
+                }
+            }
+        }
+        if (sub == 0) { a.Qx[t * Wq + D] = sdv_s[j]; a.Qx[t * Wq + D + 1] = skd; }
+    }
+}
+template <int NP>
+static void launch_mid_d(hipStream_t st, const MidArgs& a, dim3 grid, size_t lds) {
+    if (a.D <= 8) hipLaunchKernelGGL((k_bw_mid<NP, 8>), grid, dim3(256), lds, st, a);
+    else if (a.D <= 16) hipLaunchKernelGGL((k_bw_mid<NP, 16>), grid, dim3(256), lds, st, a);
+    else hipLaunchKernelGGL((k_bw_mid<NP, 32>), grid, dim3(256), lds, st, a);
+}
+// returns 1 if the fused kernel was launched, 0 if the shapes do not allow it, < 0 on error
+static int launch_mid(hipStream_t st, const MidArgs& a) {
+    const int M = a.M;
+    if (!a.GMV || M % 64 || M > 256 || M == 192 || a.T % 64 || a.Mp != M || getenv("IWVI_BW_UNFUSED")) return 0;
+    // measured (configs[1] / [2] / [3]): -3.5 % of the whole evaluation at M = 128, T = 20480; +7 % at T = 5120 (80 workgroups
+    // for 256 CUs) and +10 % at M = 256 (105 KB of LDS: one workgroup per CU) -- so only where it wins, unless forced
+    if (!getenv("IWVI_BW_FUSED") && (M > 128 || a.T < 16384)) return 0;
+    if (!aligned16(a.U) || !aligned16(a.q_sqrt) || !aligned16(a.LinvF) || !aligned16(a.C)) return 0;
+    const size_t lds = sizeof(float) * ((size_t)64 * (M + 4) + 4 * GKF * GLD + (size_t)64 * (2 * a.R + 1) + (size_t)64 * a.D);
+    static bool done = false;
+    if (!done) {
+        const size_t most = sizeof(float) * ((size_t)64 * 260 + 4 * GKF * GLD + (size_t)64 * (2 * IWVI_MAX_R + 1) + (size_t)64 * IWVI_MAX_D);
+        const void* fns[] = {(const void*)k_bw_mid<1, 8>, (const void*)k_bw_mid<1, 16>, (const void*)k_bw_mid<1, 32>,
+                             (const void*)k_bw_mid<2, 8>, (const void*)k_bw_mid<2, 16>, (const void*)k_bw_mid<2, 32>,
+                             (const void*)k_bw_mid<4, 8>, (const void*)k_bw_mid<4, 16>, (const void*)k_bw_mid<4, 32>};
+        for (const void* f : fns)
+            if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)most) != hipSuccess) { set_error("hipFuncSetAttribute(k_bw_mid)"); return IWVI_ERR_LAUNCH; }
+        done = true;
+    }
+    const dim3 grid((unsigned)(a.T / 64));
+    if (M == 64) launch_mid_d<1>(st, a, grid, lds);
+    else if (M == 128) launch_mid_d<2>(st, a, grid, lds);
+    else launch_mid_d<4>(st, a, grid, lds);
+    const int rc = check_launch("k_bw_mid");
+    return rc == IWVI_OK ? 1 : rc;
+}
+
 // Thin sums over samples: part[blk][m][n] = sum_{t in chunk} X[t*ldx + m] * Y(t, n), n < N + ones, N <= 64; the extra
 // column (ones) is the plain column sum.  Thread = column m, rows in a fixed order; chunks summed by k_reduce_parts.
 constexpr int THIN_ROWS = 64;
@@ -1182,40 +1434,47 @@ extern "C" int iwvi_gp_layer_backward(const iwvi_gp_bwd_desc* dp, int64_t T, voi
         const int n = M * M > M * D ? M * M : M * D;
         hipLaunchKernelGGL(k_prep, dim3((n + 255) / 256), dim3(256), 0, st, d.Z, d.lengthscales, Linv64, Mp, w.Zt, w.invls, w.LinvF, M, D);
     }
-    HeadArgs h{d.A, d.U, d.noise, d.W, d.mf_A, d.d_sample, d.d_mean, d.d_var, w.DMU, w.DV2, w.SDV, d.dF, T, M, Mp, D, R, d.P, d.mf_type, d.variance,
-               d.q_mu, (d.dW && d.W && !d.GMV) ? w.GMV : nullptr, d.GMV};
     const float* gmv = d.GMV ? d.GMV : w.GMV;
-    hipLaunchKernelGGL(k_bw_heads, dim3((unsigned)((T + 3) / 4)), dim3(256), 0, st, h);
-    if ((rc = check_launch("k_bw_heads")) != IWVI_OK) return rc;
     ReduceQueue rq(w.part, w.part_floats);                 // every sum over samples below is finished by ONE launch (rq.flush)
-    // DA = DMU q_mu^T - 2 SDV o A + sum_r (2 dv_r) o (U_r L_r^T): ONE launch -- R segments of M along the contraction, the
-    // first two terms in the epilogue
-    {
-        GemmArgs q{};
-        q.A = d.U; q.a_sm = Mp; q.a_sk = 1;
-        q.B = d.q_sqrt; q.b_sk = 1; q.b_sn = M; q.b_keep_n_ge_k = 1;                          // B(k = j, n = i) = L_r[i][j], i >= j
-        q.scale = w.DV2; q.s_stride = R; q.scale_on_k = 0;
-        q.C = w.DA; q.ldc = M; q.M = (int)T; q.N = M; q.K = M; q.alpha = 1.f; q.beta = 0.f;
-        q.e_dmu = w.DMU; q.e_qmu = d.q_mu; q.e_sdv = w.SDV; q.e_A = d.A; q.e_lda = Mp; q.e_R = R;
-        if ((rc = gemm_rows(st, q, R, (long long)T * Mp, (long long)M * M, 1)) != IWVI_OK) return rc;
+    MidArgs ma{d.GMV, d.noise, d.W, d.mf_A, d.d_sample, d.d_mean, d.d_var, w.DMU, w.DV2, w.SDV, d.dF, d.P, d.mf_type,
+               d.U, d.A, Mp, d.q_sqrt, d.q_mu, w.LinvF, w.DK, d.F, w.Zt, w.invls, w.DA, w.Qx, (long long)T, M, D, R, d.variance};
+    const int fused = launch_mid(st, ma);                  // heads + DA + dK + kernel adjoint in one launch where the shapes allow
+    if (fused < 0) return fused;
+    if (!fused) {
+        HeadArgs h{d.A, d.U, d.noise, d.W, d.mf_A, d.d_sample, d.d_mean, d.d_var, w.DMU, w.DV2, w.SDV, d.dF, T, M, Mp, D, R, d.P, d.mf_type, d.variance,
+                   d.q_mu, (d.dW && d.W && !d.GMV) ? w.GMV : nullptr, d.GMV};
+        hipLaunchKernelGGL(k_bw_heads, dim3((unsigned)((T + 3) / 4)), dim3(256), 0, st, h);
+        if ((rc = check_launch("k_bw_heads")) != IWVI_OK) return rc;
+        // DA = DMU q_mu^T - 2 SDV o A + sum_r (2 dv_r) o (U_r L_r^T): ONE launch -- R segments of M along the contraction, the
+        // first two terms in the epilogue
+        {
+            GemmArgs q{};
+            q.A = d.U; q.a_sm = Mp; q.a_sk = 1;
+            q.B = d.q_sqrt; q.b_sk = 1; q.b_sn = M; q.b_keep_n_ge_k = 1;                          // B(k = j, n = i) = L_r[i][j], i >= j
+            q.scale = w.DV2; q.s_stride = R; q.scale_on_k = 0;
+            q.C = w.DA; q.ldc = M; q.M = (int)T; q.N = M; q.K = M; q.alpha = 1.f; q.beta = 0.f;
+            q.e_dmu = w.DMU; q.e_qmu = d.q_mu; q.e_sdv = w.SDV; q.e_A = d.A; q.e_lda = Mp; q.e_R = R;
+            if ((rc = gemm_rows(st, q, R, (long long)T * Mp, (long long)M * M, 1)) != IWVI_OK) return rc;
+        }
+        // DK = DA Lm^-1
+        {
+            GemmArgs q{};
+            q.A = w.DA; q.a_sm = M; q.a_sk = 1; q.B = w.LinvF; q.b_sk = M; q.b_sn = 1;
+            q.C = w.DK; q.ldc = M; q.M = (int)T; q.N = M; q.K = M; q.alpha = 1.f; q.beta = 0.f; q.b_lower_kn = 1;
+            if ((rc = gemm_rows(st, q)) != IWVI_OK) return rc;
+        }
+        // C = -1/2 K o DK (over DA), dx~, dF, per-sample rows of the column sums
+        KernArgs ka{d.F, w.Zt, w.invls, w.DK, w.DA, w.SDV, d.dF, w.Qx, T, M, D, d.variance};
+        {
+            const dim3 grid((unsigned)((T + 15) / 16)), block(256);
+            if (D <= 4) hipLaunchKernelGGL(k_bw_kernel<4>, grid, block, 0, st, ka);
+            else if (D <= 8) hipLaunchKernelGGL(k_bw_kernel<8>, grid, block, 0, st, ka);
+            else if (D <= 16) hipLaunchKernelGGL(k_bw_kernel<16>, grid, block, 0, st, ka);
+            else hipLaunchKernelGGL(k_bw_kernel<32>, grid, block, 0, st, ka);
+        }
+        if ((rc = check_launch("k_bw_kernel")) != IWVI_OK) return rc;
+
     }
-    // DK = DA Lm^-1
-    {
-        GemmArgs q{};
-        q.A = w.DA; q.a_sm = M; q.a_sk = 1; q.B = w.LinvF; q.b_sk = M; q.b_sn = 1;
-        q.C = w.DK; q.ldc = M; q.M = (int)T; q.N = M; q.K = M; q.alpha = 1.f; q.beta = 0.f; q.b_lower_kn = 1;
-        if ((rc = gemm_rows(st, q)) != IWVI_OK) return rc;
-    }
-    // C = -1/2 K o DK (over DA), dx~, dF, per-sample rows of the column sums
-    KernArgs ka{d.F, w.Zt, w.invls, w.DK, w.DA, w.SDV, d.dF, w.Qx, T, M, D, d.variance};
-    {
-        const dim3 grid((unsigned)((T + 15) / 16)), block(256);
-        if (D <= 4) hipLaunchKernelGGL(k_bw_kernel<4>, grid, block, 0, st, ka);
-        else if (D <= 8) hipLaunchKernelGGL(k_bw_kernel<8>, grid, block, 0, st, ka);
-        else if (D <= 16) hipLaunchKernelGGL(k_bw_kernel<16>, grid, block, 0, st, ka);
-        else hipLaunchKernelGGL(k_bw_kernel<32>, grid, block, 0, st, ka);
-    }
-    if ((rc = check_launch("k_bw_kernel")) != IWVI_OK) return rc;
     // Everything the layer below needs (dF) is now queued on `st`.  What follows only produces this layer's parameter
     // gradients: with a side stream it runs beside the next layer's adjoint instead of ahead of it.
     hipStream_t main_st = st;

@@ -80,6 +80,9 @@ def test_gp_layer_backward_matches_autodiff(gpu_device, M, T, li):
         assert torch.equal(out[k], out2[k]), k
 
 
+os.environ.setdefault("IWVI_BW_FUSED", "1")      # exercise the fused per-sample kernel wherever the shapes allow it (it is gated by size otherwise)
+
+
 def _model_grads(gpu_device, spec, zs):
     from dgps_with_iwvi_amd import synthetic, backward
     model = synthetic.build_model(spec, gpu_device)
@@ -104,7 +107,9 @@ def test_iw_elbo_gradients_match_golden(gpu_device, name):
         _close(k, v.reshape(r.shape), r, rtol=5e-3)
 
 
-@pytest.mark.parametrize("L,M,K,B,lv", [(2, 64, 5, 16, True), (3, 32, 4, 12, True), (2, 128, 3, 40, False), (1, 48, 6, 10, False)])
+@pytest.mark.parametrize("L,M,K,B,lv", [(2, 64, 5, 16, True), (3, 32, 4, 12, True), (2, 128, 3, 40, False), (1, 48, 6, 10, False),
+                                        # T = B*K a multiple of 64 and M in {64, 128, 256}: the fused per-sample kernel (k_bw_mid)
+                                        (2, 64, 4, 16, True), (2, 128, 8, 16, True), (3, 128, 4, 32, False), (2, 256, 8, 8, True)])
 def test_iw_elbo_gradients_match_oracle(gpu_device, L, M, K, B, lv):
     from dgps_with_iwvi_amd import synthetic
     from oracle.grad_oracle import iw_elbo_and_gradients
