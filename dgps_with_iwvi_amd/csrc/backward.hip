@@ -112,11 +112,15 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs g) {
 // k-contiguous operand contributes 128 contiguous bytes), LDS double buffer (one barrier per stage, the next stage's
 // loads in flight under the MFMAs), 2x2 MFMA tiles per wave.
 // A_KC: A's k index is contiguous (else its m index); B_NC: B's n index is contiguous (else its k index).
-constexpr int GKF = 32;
+constexpr int GKF = 32, KLD = GKF + 4, OPB = 64 * KLD;     // (OPB floats per operand buffer: 64 x 36 >= 32 x 68)
 template <bool A_KC, bool B_NC>
 __global__ __launch_bounds__(256) void k_gemm_fast(GemmArgs g) {
-    __shared__ __attribute__((aligned(16))) float As[2][GKF][GLD];
-    __shared__ __attribute__((aligned(16))) float Bs[2][GKF][GLD];
+    // a k-contiguous operand is kept [row][k] (row stride KLD: float4 stores, no transposition; the MFMA's reads -- 16 rows x
+    // 4 k per instruction -- land 2 per bank, the minimum for 64 lanes), a row-contiguous one [k][row] (row stride GLD)
+    __shared__ __attribute__((aligned(16))) float Asm[2 * OPB];
+    __shared__ __attribute__((aligned(16))) float Bsm[2 * OPB];
+    auto AS = [&](int buf, int k, int m) -> float& { return A_KC ? Asm[buf * OPB + m * KLD + k] : Asm[buf * OPB + k * GLD + m]; };
+    auto BS = [&](int buf, int k, int n) -> float& { return B_NC ? Bsm[buf * OPB + k * GLD + n] : Bsm[buf * OPB + n * KLD + k]; };
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
     const int m0 = blockIdx.y * GT, n0 = blockIdx.x * GT;
@@ -158,10 +162,8 @@ __global__ __launch_bounds__(256) void k_gemm_fast(GemmArgs g) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int m = am + AMJ * j, ka = ak + AKJ * j, n = bn + BNJ * j, kq = bk + BKJ * j;
-            if (A_KC) for (int e = 0; e < 4; ++e) As[buf][ka + e][m] = ra[j][e];
-            else *reinterpret_cast<f32x4*>(&As[buf][ka][m]) = ra[j];
-            if (B_NC) *reinterpret_cast<f32x4*>(&Bs[buf][kq][n]) = rb[j];
-            else for (int e = 0; e < 4; ++e) Bs[buf][kq + e][n] = rb[j][e];
+            *reinterpret_cast<f32x4*>(&AS(buf, ka, m)) = ra[j];            // 4 consecutive k (A_KC) or 4 consecutive rows: contiguous either way
+            *reinterpret_cast<f32x4*>(&BS(buf, kq, n)) = rb[j];
         }
     };
     f32x4 acc[2][2];
@@ -185,8 +187,8 @@ __global__ __launch_bounds__(256) void k_gemm_fast(GemmArgs g) {
 #pragma unroll
         for (int kk = 0; kk < GKF / 4; ++kk) {
             const int kr = 4 * kk + (lane >> 4);
-            const float a0 = As[buf][kr][wm + (lane & 15)], a1 = As[buf][kr][wm + 16 + (lane & 15)];
-            const float b0 = Bs[buf][kr][wn + (lane & 15)], b1 = Bs[buf][kr][wn + 16 + (lane & 15)];
+            const float a0 = AS(buf, kr, wm + (lane & 15)), a1 = AS(buf, kr, wm + 16 + (lane & 15));
+            const float b0 = BS(buf, kr, wn + (lane & 15)), b1 = BS(buf, kr, wn + 16 + (lane & 15));
             acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc[0][0], 0, 0, 0);
             acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b1, acc[0][1], 0, 0, 0);
             acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b0, acc[1][0], 0, 0, 0);
@@ -610,17 +612,18 @@ __global__ __launch_bounds__(256) void k_bw_mid(MidArgs a) {
     extern __shared__ __attribute__((aligned(16))) float msm[];
     const int M = 64 * NP, LDT = M + 4;
     float* tile = msm;                                       // [64][M + 4]: DA, then dK
-    float* As = tile + 64 * LDT;                             // [2][GKF][GLD]
-    float* Bs = As + 2 * GKF * GLD;                          // [2][GKF][GLD]
-    float* dmu_s = Bs + 2 * GKF * GLD;                       // [64][R]
+    float* As = tile + 64 * LDT;                             // 2 operand buffers of OPB floats
+    float* Bs = As + 2 * OPB;
+    float* dmu_s = Bs + 2 * OPB;                             // [64][R]
     float* dv2_s = dmu_s + 64 * a.R;                         // [64][R]
     float* sdv_s = dv2_s + 64 * a.R;                         // [64]
     float* dfi_s = sdv_s + 64;                               // [64][D]: the mean function's share of dF
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const long long t0 = (long long)blockIdx.x * 64;
     const int R = a.R, D = a.D, P = a.P;
-    auto AS = [&](int buf, int k, int m) -> float& { return As[(buf * GKF + k) * GLD + m]; };
-    auto BS = [&](int buf, int k, int n) -> float& { return Bs[(buf * GKF + k) * GLD + n]; };
+    auto AK = [&](int buf, int k, int m) -> float& { return As[buf * OPB + m * KLD + k]; };      // k-contiguous operands: [row][k]
+    auto BK = [&](int buf, int k, int n) -> float& { return Bs[buf * OPB + n * KLD + k]; };
+    auto BS = [&](int buf, int k, int n) -> float& { return Bs[buf * OPB + k * GLD + n]; };      // row-contiguous: [k][row]
 
     // ---- heads (layers.py:46-48, temp_workaround.py:85-91, :142-145), one thread per sample
     if (tid < 64) {
@@ -690,7 +693,7 @@ __global__ __launch_bounds__(256) void k_bw_mid(MidArgs a) {
         };
         auto stash = [&](int buf) {
 #pragma unroll
-            for (int j = 0; j < 2; ++j) for (int e = 0; e < 4; ++e) { AS(buf, sk_ + e, sm_ + 32 * j) = ra[j][e]; BS(buf, sk_ + e, sm_ + 32 * j) = rb[j][e]; }
+            for (int j = 0; j < 2; ++j) { *reinterpret_cast<f32x4*>(&AK(buf, sk_, sm_ + 32 * j)) = ra[j]; *reinterpret_cast<f32x4*>(&BK(buf, sk_, sm_ + 32 * j)) = rb[j]; }
         };
         fetch(0); stash(0);
         __syncthreads();
@@ -701,8 +704,8 @@ __global__ __launch_bounds__(256) void k_bw_mid(MidArgs a) {
 #pragma unroll
             for (int kk = 0; kk < GKF / 4; ++kk) {
                 const int kr = 4 * kk + (lane >> 4);
-                const float a0 = AS(buf, kr, wm + (lane & 15)), a1 = AS(buf, kr, wm + 16 + (lane & 15));
-                const float b0 = BS(buf, kr, wn + (lane & 15)), b1 = BS(buf, kr, wn + 16 + (lane & 15));
+                const float a0 = AK(buf, kr, wm + (lane & 15)), a1 = AK(buf, kr, wm + 16 + (lane & 15));
+                const float b0 = BK(buf, kr, wn + (lane & 15)), b1 = BK(buf, kr, wn + 16 + (lane & 15));
                 acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc[0][0], 0, 0, 0);
                 acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b1, acc[0][1], 0, 0, 0);
                 acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b0, acc[1][0], 0, 0, 0);
@@ -822,10 +825,10 @@ static int launch_mid(hipStream_t st, const MidArgs& a) {
     // for 256 CUs) and +10 % at M = 256 (105 KB of LDS: one workgroup per CU) -- so only where it wins, unless forced
     if (!getenv("IWVI_BW_FUSED") && (M > 128 || a.T < 16384)) return 0;
     if (!aligned16(a.U) || !aligned16(a.q_sqrt) || !aligned16(a.LinvF) || !aligned16(a.C)) return 0;
-    const size_t lds = sizeof(float) * ((size_t)64 * (M + 4) + 4 * GKF * GLD + (size_t)64 * (2 * a.R + 1) + (size_t)64 * a.D);
+    const size_t lds = sizeof(float) * ((size_t)64 * (M + 4) + 4 * OPB + (size_t)64 * (2 * a.R + 1) + (size_t)64 * a.D);
     static bool done = false;
     if (!done) {
-        const size_t most = sizeof(float) * ((size_t)64 * 260 + 4 * GKF * GLD + (size_t)64 * (2 * IWVI_MAX_R + 1) + (size_t)64 * IWVI_MAX_D);
+        const size_t most = sizeof(float) * ((size_t)64 * 260 + 4 * OPB + (size_t)64 * (2 * IWVI_MAX_R + 1) + (size_t)64 * IWVI_MAX_D);
         const void* fns[] = {(const void*)k_bw_mid<1, 8>, (const void*)k_bw_mid<1, 16>, (const void*)k_bw_mid<1, 32>,
                              (const void*)k_bw_mid<2, 8>, (const void*)k_bw_mid<2, 16>, (const void*)k_bw_mid<2, 32>,
                              (const void*)k_bw_mid<4, 8>, (const void*)k_bw_mid<4, 16>, (const void*)k_bw_mid<4, 32>};
