@@ -5,7 +5,7 @@
 #   usage: scripts/profile_round.sh <tag> [bench args...]
 set -u
 TAG=${1:-rXX}; shift || true
-ARGS=${@:---steps 40 --warmup 5 --no-cpu-baseline --no-graph}
+ARGS=${@:---steps 40 --warmup 5 --no-cpu-baseline --no-train-leg --no-graph}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
