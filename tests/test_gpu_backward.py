@@ -109,7 +109,9 @@ def test_iw_elbo_gradients_match_golden(gpu_device, name):
 
 @pytest.mark.parametrize("L,M,K,B,lv", [(2, 64, 5, 16, True), (3, 32, 4, 12, True), (2, 128, 3, 40, False), (1, 48, 6, 10, False),
                                         # T = B*K a multiple of 64 and M in {64, 128, 256}: the fused per-sample kernel (k_bw_mid)
-                                        (2, 64, 4, 16, True), (2, 128, 8, 16, True), (3, 128, 4, 32, False), (2, 256, 8, 8, True)])
+                                        (2, 64, 4, 16, True), (2, 128, 8, 16, True), (3, 128, 4, 32, False), (2, 256, 8, 8, True),
+                                        # ragged: M not a multiple of 16 (padded states), odd B and K
+                                        (2, 40, 3, 7, True), (3, 50, 5, 3, False)])
 def test_iw_elbo_gradients_match_oracle(gpu_device, L, M, K, B, lv):
     from dgps_with_iwvi_amd import synthetic
     from oracle.grad_oracle import iw_elbo_and_gradients
