@@ -1,7 +1,12 @@
 // Backward pass of the IW-ELBO path (the reference obtains these gradients from
 // TensorFlow's autodiff of the graph built by models.py:112-150, experiments/build_models.py:284-304).
-// gfx950 only.  First, correct, version: layer by layer, intermediates in HBM, float32 MFMA products for everything
-// that sums over samples, float64 for the Cholesky adjoint.  Not yet fused like the forward.
+// gfx950 only.  Layer by layer in reverse; the forward (one fused launch) leaves a, u_r, the draws and the per-latent moments
+// in HBM.  float32 MFMA products for everything that sums over samples, float64 for the Cholesky adjoint, every sum over
+// samples in a fixed order (bit-reproducible gradients).  Per layer: a main chain that produces dF for the layer below
+// (k_bw_mid where its shapes allow, else heads / segmented GEMM / GEMM / kernel adjoint), then a parameter branch -- split-K and
+// thin products parked in the workspace, ONE deferred reduction, Cholesky adjoint, assembly -- that can run on a side stream
+// beside the layer below.  Also here: the ELBO tail, latent-variable layer and encoder adjoints, and the two optimiser steps
+// of the reference (NatGrad, Adam).  Measured state and what is next: DESIGN.md section 5b.
 //
 // One GP layer (temp_workaround.py:39-91 + :142-145 + layers.py:46-48), per sample t with a = Lm^-1 k(Z, x),
 // u_r = L_r^T a, mu_r = a . q_mu_r, v_r = s2 - |a|^2 + |u_r|^2, g_r = mu_r + eps_r sqrt(v_r), f = W g + x A:
