@@ -63,7 +63,8 @@ def gp_forward_saved(layer, F, z=None, words=None, precomputed=False):
     s.noise = torch.empty(T, R, dtype=settings.float_type, device=dev)
     s.sample, s.mean, s.var = (torch.empty(T, P, dtype=settings.float_type, device=dev) for _ in range(3))
     z2 = None if z is None else _abi.dev_tensor(z.reshape(T, R).contiguous(), "z")
-    outs = dict(sample=s.sample, mean=s.mean, var=s.var, a_out=s.A, u_out=s.U, noise_out=s.noise)
+    s.GMV = torch.empty(T, 3 * R, dtype=settings.float_type, device=dev)
+    outs = dict(sample=s.sample, mean=s.mean, var=s.var, a_out=s.A, u_out=s.U, noise_out=s.noise, gmv_out=s.GMV)
     ld, keep = layer.fused_desc(z2, outs)
     descs = (_abi.LayerDesc * 1)(ld)
     words = _words(dev) if words is None else words

@@ -538,11 +538,28 @@ __global__ __launch_bounds__(256) void k_bw_heads(HeadArgs h) {
     }
 }
 
+// kernel value and its derivative w.r.t. the squared scaled distance (GPflow 1.x Stationary kernels, as csrc/precompute.hip):
+//   RBF       k = s2 exp(-d2 / 2)                                   dk/dd2 = -k / 2
+//   Matern52  k = s2 (1 + a r + a^2 r^2 / 3) exp(-a r), a = sqrt 5  dk/dd2 = -(5/6) s2 (1 + a r) exp(-a r),  r = sqrt(d2 + 1e-12)
+__device__ __forceinline__ float fast_exp(float x) { return __expf(x); }
+__device__ __forceinline__ double fast_exp(double x) { return exp(x); }
+template <class T>
+__device__ __forceinline__ void kern_and_grad(T d2, int type, T var, T& k, T& g) {
+    if (type == IWVI_KERN_MATERN52) {
+        const T a = (T)2.23606797749978969641, r = sqrt(d2 + (T)1e-12), e = fast_exp(-a * r);
+        k = var * ((T)1 + a * r + (T)(5.0 / 3.0) * r * r) * e;
+        g = -var * (T)(5.0 / 6.0) * ((T)1 + a * r) * e;
+    } else {
+        k = var * fast_exp((T)-0.5 * d2);
+        g = (T)-0.5 * k;
+    }
+}
+
 // One wave per sample: K_uf entries again (RBF, direct differences), c = -1/2 k dk written over DA, then
 // dx~ = 2 x~ sum_m c_m - 2 sum_m c_m z~_m, dF += dx~ * invls, and the per-sample row of column-sum inputs
 // Qx[t] = (dx~ o x [D] | sum_r dv_r | sum_m k dk).
 struct KernArgs { const float* F; const float* Zt; const float* invls; const float* DK; float* C; const float* SDV; float* dF; float* Qx;
-                  long long T; int M, D; float variance; };
+                  long long T; int M, D; float variance; int kern_type; };
 template <int DM>                       // D <= DM: the per-dimension arrays stay in registers
 __global__ __launch_bounds__(256) void k_bw_kernel(KernArgs a) {
     // 16 lanes per sample (16 samples per workgroup): lane `sub` takes columns m0 + 4 sub .. + 3 of every 64-column step
@@ -569,8 +586,10 @@ __global__ __launch_bounds__(256) void k_bw_kernel(KernArgs a) {
             float d2 = 0.f, z[DM];
 #pragma unroll
             for (int d = 0; d < DM; ++d) { z[d] = d < a.D ? a.Zt[m * a.D + d] : 0.f; const float q = xt[d] - z[d]; d2 = fmaf(q, q, d2); }
-            const float kd = (mb + e < a.M) ? a.variance * __expf(-0.5f * d2) * dk[e] : 0.f;
-            c[e] = -0.5f * kd;
+            float kv, kg;
+            kern_and_grad<float>(d2, a.kern_type, a.variance, kv, kg);
+            const float kd = (mb + e < a.M) ? kv * dk[e] : 0.f;
+            c[e] = (mb + e < a.M) ? kg * dk[e] : 0.f;
             sc += c[e]; skd += kd;
 #pragma unroll
             for (int d = 0; d < DM; ++d) cz[d] = fmaf(c[e], z[d], cz[d]);
@@ -610,7 +629,7 @@ struct MidArgs {
     const float* U; const float* A; int Mp; const float* q_sqrt; const float* q_mu;
     const float* LinvF; float* DK;
     const float* F; const float* Zt; const float* invls; float* C; float* Qx;
-    long long T; int M, D, R; float variance;
+    long long T; int M, D, R; float variance; int kern_type;
 };
 template <int NP, int DM>                // M = 64 NP;  D <= DM
 __global__ __launch_bounds__(256) void k_bw_mid(MidArgs a) {
@@ -792,8 +811,10 @@ __global__ __launch_bounds__(256) void k_bw_mid(MidArgs a) {
                 float d2 = 0.f, z[DM];
 #pragma unroll
                 for (int d = 0; d < DM; ++d) { z[d] = d < D ? a.Zt[(mb + e) * D + d] : 0.f; const float q = xt[d] - z[d]; d2 = fmaf(q, q, d2); }
-                const float kd = a.variance * __expf(-0.5f * d2) * dk[e];
-                c[e] = -0.5f * kd;
+                float kv, kg;
+                kern_and_grad<float>(d2, a.kern_type, a.variance, kv, kg);
+                const float kd = kv * dk[e];
+                c[e] = kg * dk[e];
                 sc += c[e]; skd += kd;
 #pragma unroll
                 for (int d = 0; d < DM; ++d) cz[d] = fmaf(c[e], z[d], cz[d]);
@@ -955,8 +976,8 @@ __global__ void k_prep(const float* Z, const float* ls, const double* Linv64, in
     if (idx < M * D) Zt[idx] = Z[idx] / ls[idx % D];
     if (idx < M * M) { const int i = idx / M, j = idx - i * M; LinvF[idx] = j <= i ? (float)Linv64[(size_t)i * Mp + j] : 0.f; }
 }
-// row m of K_uu: dZ~_uu[m, :] = -2 sum_n Sbar_mn K_mn (z~_m - z~_n),  dvar_m = sum_n Sbar_mn K_mn / s2,  Sbar = (S + S^T)/2
-__global__ __launch_bounds__(256) void k_kuu_bwd(const float* Zt, const double* S, int M, int D, double variance, double* dZt_uu, double* dvar_m) {
+// row m of K_uu: dZ~_uu[m, :] = 4 sum_n Sbar_mn dK_mn/dd2 (z~_m - z~_n),  dvar_m = sum_n Sbar_mn K_mn / s2,  Sbar = (S + S^T)/2
+__global__ __launch_bounds__(256) void k_kuu_bwd(const float* Zt, const double* S, int M, int D, double variance, int kern_type, double* dZt_uu, double* dvar_m) {
     __shared__ double red[256];
     const int m = blockIdx.x, tid = threadIdx.x;
     double acc[IWVI_MAX_D + 1];
@@ -964,10 +985,11 @@ __global__ __launch_bounds__(256) void k_kuu_bwd(const float* Zt, const double* 
     for (int n = tid; n < M; n += 256) {
         double d2 = 0.0;
         for (int d = 0; d < D; ++d) { const double e = (double)Zt[m * D + d] - (double)Zt[n * D + d]; d2 += e * e; }
-        const double k = variance * exp(-0.5 * d2);
-        const double sk = 0.5 * (S[(size_t)m * M + n] + S[(size_t)n * M + m]) * k;
-        for (int d = 0; d < D; ++d) acc[d] += -2.0 * sk * ((double)Zt[m * D + d] - (double)Zt[n * D + d]);
-        acc[D] += sk / variance;
+        double k, g;
+        kern_and_grad<double>(d2, kern_type, variance, k, g);
+        const double sb = 0.5 * (S[(size_t)m * M + n] + S[(size_t)n * M + m]);
+        for (int d = 0; d < D; ++d) acc[d] += 4.0 * sb * g * ((double)Zt[m * D + d] - (double)Zt[n * D + d]);   // both (m, n) and (n, m)
+        acc[D] += sb * k / variance;
     }
     for (int d = 0; d <= D; ++d) {
         red[tid] = acc[d];
@@ -1425,7 +1447,7 @@ extern "C" int iwvi_gp_layer_backward(const iwvi_gp_bwd_desc* dp, int64_t T, voi
     if (d.M <= 0 || d.M > IWVI_MAX_M || d.D <= 0 || d.D > IWVI_MAX_D || d.R <= 0 || d.R > IWVI_MAX_R || d.P <= 0 || d.P > IWVI_MAX_P || T >= (1LL << 31) / (d.M > d.D ? d.M : d.D)) {
         set_error("iwvi_gp_layer_backward: size out of range"); return IWVI_ERR_ARG;
     }
-    if (d.kern_type != IWVI_KERN_RBF) { set_error("iwvi_gp_layer_backward: only the RBF kernel has a backward pass so far"); return IWVI_ERR_UNSUPPORTED; }
+    if (d.kern_type != IWVI_KERN_RBF && d.kern_type != IWVI_KERN_MATERN52) { set_error("iwvi_gp_layer_backward: unknown kernel type %d", d.kern_type); return IWVI_ERR_UNSUPPORTED; }
     if (!d.W && d.P != d.R) { set_error("iwvi_gp_layer_backward: P != R without a mixing matrix"); return IWVI_ERR_ARG; }
     if (d.mf_type == IWVI_MF_LINEAR && !d.mf_A) { set_error("iwvi_gp_layer_backward: linear mean function without A"); return IWVI_ERR_ARG; }
     if (d.mf_type == IWVI_MF_IDENTITY && d.P != d.D) { set_error("iwvi_gp_layer_backward: identity mean function needs P == D"); return IWVI_ERR_ARG; }
@@ -1445,7 +1467,7 @@ extern "C" int iwvi_gp_layer_backward(const iwvi_gp_bwd_desc* dp, int64_t T, voi
     const float* gmv = d.GMV ? d.GMV : w.GMV;
     ReduceQueue rq(w.part, w.part_floats);                 // every sum over samples below is finished by ONE launch (rq.flush)
     MidArgs ma{d.GMV, d.noise, d.W, d.mf_A, d.d_sample, d.d_mean, d.d_var, w.DMU, w.DV2, w.SDV, d.dF, d.P, d.mf_type,
-               d.U, d.A, Mp, d.q_sqrt, d.q_mu, w.LinvF, w.DK, d.F, w.Zt, w.invls, w.DA, w.Qx, (long long)T, M, D, R, d.variance};
+               d.U, d.A, Mp, d.q_sqrt, d.q_mu, w.LinvF, w.DK, d.F, w.Zt, w.invls, w.DA, w.Qx, (long long)T, M, D, R, d.variance, d.kern_type};
     const int fused = launch_mid(st, ma);                  // heads + DA + dK + kernel adjoint in one launch where the shapes allow
     if (fused < 0) return fused;
     if (!fused) {
@@ -1472,7 +1494,7 @@ extern "C" int iwvi_gp_layer_backward(const iwvi_gp_bwd_desc* dp, int64_t T, voi
             if ((rc = gemm_rows(st, q)) != IWVI_OK) return rc;
         }
         // C = -1/2 K o DK (over DA), dx~, dF, per-sample rows of the column sums
-        KernArgs ka{d.F, w.Zt, w.invls, w.DK, w.DA, w.SDV, d.dF, w.Qx, T, M, D, d.variance};
+        KernArgs ka{d.F, w.Zt, w.invls, w.DK, w.DA, w.SDV, d.dF, w.Qx, T, M, D, d.variance, d.kern_type};
         {
             const dim3 grid((unsigned)((T + 15) / 16)), block(256);
             if (D <= 4) hipLaunchKernelGGL(k_bw_kernel<4>, grid, block, 0, st, ka);
@@ -1536,7 +1558,7 @@ extern "C" int iwvi_gp_layer_backward(const iwvi_gp_bwd_desc* dp, int64_t T, voi
         hipLaunchKernelGGL(k_dmm, grid, block, 0, st, Lm64, 1LL, (long long)Mp, (const double*)w.Lbar, (long long)M, 1LL, w.T1, M, M, 1);
         hipLaunchKernelGGL(k_dmm, grid, block, 0, st, Linv64, 1LL, (long long)Mp, (const double*)w.T1, (long long)M, 1LL, w.T2, M, M, 0);
         hipLaunchKernelGGL(k_dmm, grid, block, 0, st, (const double*)w.T2, (long long)M, 1LL, Linv64, (long long)Mp, 1LL, w.S, M, M, 0);
-        hipLaunchKernelGGL(k_kuu_bwd, dim3(M), dim3(256), 0, st, w.Zt, (const double*)w.S, M, D, (double)d.variance, w.dZt_uu, w.dvar_m);
+        hipLaunchKernelGGL(k_kuu_bwd, dim3(M), dim3(256), 0, st, w.Zt, (const double*)w.S, M, D, (double)d.variance, d.kern_type, w.dZt_uu, w.dvar_m);
         if ((rc = check_launch("cholesky adjoint")) != IWVI_OK) return rc;
     }
     if (lin_on) {

@@ -241,7 +241,7 @@ int iwvi_dgp_forward(const iwvi_layer_desc* layers_host, int n_layers,
 
 /* ----------------------------------------------------------------------
  * Backward pass (the reference gets these from TensorFlow's autodiff of the graph of
- * models.py:112-150, experiments/build_models.py:284-304).  Layer by layer; RBF kernels.
+ * models.py:112-150, experiments/build_models.py:284-304).  Layer by layer; RBF and Matern-5/2 kernels.
  *
  * iwvi_gp_layer_backward: adjoint of iwvi_gp_layer_forward for T samples.
  *   state                  as precomputed WITH IWVI_GP_WANT_DENSE (the dense float64 Lm and Lm^-1 are read)

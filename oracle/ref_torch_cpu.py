@@ -25,6 +25,21 @@ def _rbf(X, X2, ls, var):
     return var * torch.exp(-0.5 * d)
 
 
+def _matern52(X, X2, ls, var):
+    """GPflow 1.x Matern52 (r = sqrt(scaled square distance + 1e-12)), as oracle/iwvi_oracle.py."""
+    X = X / ls
+    Xs = (X * X).sum(-1)
+    if X2 is None:
+        X2, X2s = X, Xs
+    else:
+        X2 = X2 / ls
+        X2s = (X2 * X2).sum(-1)
+    d = -2 * X @ X2.transpose(-1, -2) + Xs[..., :, None] + X2s[..., None, :]
+    r = torch.sqrt(d + 1e-12)
+    s5 = math.sqrt(5.0)
+    return var * (1.0 + s5 * r + 5.0 / 3.0 * r * r) * torch.exp(-s5 * r)
+
+
 class CpuDGP:
     def __init__(self, spec, dtype=torch.float64):
         self.dtype = dtype
@@ -46,13 +61,14 @@ class CpuDGP:
         S, N, D = F.shape
         M = L["Z"].shape[0]
         R = L["q_mu"].shape[1]
-        Kmm = _rbf(L["Z"], None, L["ls"], L["var"]) + 1e-6 * torch.eye(M, dtype=self.dtype)      # :39
-        Kmn = _rbf(L["Z"], F.reshape(S * N, D), L["ls"], L["var"])                                # :44
+        _k = _matern52 if L.get("kern") == "matern52" else _rbf
+        Kmm = _k(L["Z"], None, L["ls"], L["var"]) + 1e-6 * torch.eye(M, dtype=self.dtype)        # :39
+        Kmn = _k(L["Z"], F.reshape(S * N, D), L["ls"], L["var"])                                  # :44
         Lm = torch.linalg.cholesky(Kmm)                                                           # :48
         A = torch.linalg.solve_triangular(Lm, Kmn, upper=False)                                   # :51
         A = A.reshape(M, S, N).permute(1, 0, 2)                                                   # :52
         if full_cov:
-            Knn = _rbf(F, None, L["ls"], L["var"])                                                # :45
+            Knn = _k(F, None, L["ls"], L["var"])                                                  # :45
             fvar = (Knn - A.transpose(1, 2) @ A)[:, None].repeat(1, R, 1, 1)                       # :56-57
         else:
             fvar = (L["var"] - (A * A).sum(-2))[:, None].repeat(1, R, 1)                           # :59-60

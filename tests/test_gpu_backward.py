@@ -24,7 +24,7 @@ def _close(name, got, ref, rtol=3e-3):
     assert err <= rtol * scale, "%s: max err %.3e vs scale %.3e" % (name, err, scale)
 
 
-def _layer_reference(spec, li, F, z, cs, cm, cv, klw):
+def _layer_reference(spec, li, F, z, cs, cm, cv, klw, kern=None):
     """d/d{F, Z, ls, var, q_mu, q_sqrt} of sum(cs*sample + cm*mean + cv*var) - klw*KL for GP layer li (float64 autograd)."""
     m = CpuDGP(spec, torch.float64)
     L = m.layers[li]
@@ -33,7 +33,7 @@ def _layer_reference(spec, li, F, z, cs, cm, cv, klw):
     P["q_sqrt"] = leaf(L["q_sqrt"].detach().numpy())
     P["var"] = leaf(L["var"])
     Ft = leaf(F)
-    Ld = dict(L, Z=P["Z"], ls=P["ls"], q_mu=P["q_mu"], q_sqrt=torch.tril(P["q_sqrt"]), var=P["var"])
+    Ld = dict(L, Z=P["Z"], ls=P["ls"], q_mu=P["q_mu"], q_sqrt=torch.tril(P["q_sqrt"]), var=P["var"], kern=kern)
     s, mu, v = m._conditional(Ld, Ft[None], False, torch.as_tensor(z, dtype=torch.float64)[None])
     if L["W"] is not None:
         s, mu, v = s @ L["W"].T, mu @ L["W"].T, v @ (L["W"] ** 2).T
@@ -88,6 +88,40 @@ def _model_grads(gpu_device, spec, zs):
     model = synthetic.build_model(spec, gpu_device)
     elbo, grads = backward.iw_elbo_and_gradients(model, [torch.as_tensor(np.asarray(z, dtype=np.float32), device=gpu_device) for z in zs])
     return float(elbo), {k: v.detach().cpu().numpy() for k, v in grads.items()}
+
+
+@pytest.mark.parametrize("M,T,li", [(32, 70, 0), (128, 256, 1), (64, 16384, 0)])
+def test_matern52_layer_backward_matches_autodiff(gpu_device, M, T, li):
+    """The adjoint of a layer with a Matern-5/2 kernel (the forward supports it; dk/dd2 = -(5/6) s2 (1 + sqrt5 r) exp(-sqrt5 r))."""
+    from dgps_with_iwvi_amd import synthetic, backward, kernels
+    spec = synthetic.make_spec(L=2, M=M, B=8, K=2, with_lv=False, seed=3 * M + li)
+    model = synthetic.build_model(spec, gpu_device)
+    layer = model.layers[li]
+    old = layer._base_kern()
+    new = kernels.Matern52(old.input_dim, variance=old.variance, lengthscales=old.lengthscales, ARD=True).to(gpu_device)
+    if hasattr(layer.kern, "kernel"):
+        layer.kern.kernel = new
+    else:
+        layer.kern = new
+    rng = np.random.default_rng(T)
+    D, R = layer._Z().shape[1], layer.num_outputs
+    P = spec["layers"][li]["W"].shape[0] if spec["layers"][li]["W"] is not None else R
+    F = rng.standard_normal((T, D)).astype(np.float32)
+    z = rng.standard_normal((T, R)).astype(np.float32)
+    cs, cm, cv = (rng.standard_normal((T, P)).astype(np.float32) for _ in range(3))
+    tt = lambda a: torch.as_tensor(a, device=gpu_device)
+    saved = backward.gp_forward_saved(layer, tt(F), tt(z))
+    out = backward.gp_backward(layer, saved, tt(cs), tt(cm), tt(cv), kl_weight=1.0)
+    Tr = min(T, 512)                                             # the float64 reference on a prefix (the rest has zero cotangent)
+    if Tr < T:
+        cs[Tr:], cm[Tr:], cv[Tr:] = 0, 0, 0
+        out = backward.gp_backward(layer, saved, tt(cs), tt(cm), tt(cv), kl_weight=1.0)
+    ref = _layer_reference(spec, li, F[:Tr], z[:Tr], cs[:Tr], cm[:Tr], cv[:Tr], 1.0, kern="matern52")
+    _close("dF", out["dF"].cpu()[:Tr], ref["F"])
+    for k_out, k_ref in (("dq_mu", "q_mu"), ("dZ", "Z"), ("dls", "ls")):
+        _close(k_out, out[k_out].cpu(), ref[k_ref])
+    _close("dq_sqrt", out["dq_sqrt"].cpu(), np.tril(ref["q_sqrt"]))
+    _close("dvariance", out["dvariance"].cpu()[0], ref["var"])
 
 
 @pytest.mark.parametrize("name", ["tiny_L2_lv", "mid_L2_lv"])

@@ -95,3 +95,15 @@ def test_vi_mode_of_the_torch_restatement_equals_the_numpy_oracle():
     zs_sn = [np.asarray(z).transpose(1, 0, 2).reshape(-1, z.shape[-1]) for z in zs]
     ref = build_oracle(spec, iw=False).build_likelihood(zs_sn)
     assert abs(val - ref) <= 1e-9 * abs(ref), (val, ref)
+
+
+def test_matern52_of_the_torch_restatement_equals_the_numpy_oracle():
+    import torch
+    from oracle import iwvi_oracle as O
+    from oracle.ref_torch_cpu import _matern52
+    rng = np.random.default_rng(3)
+    X, X2, ls = rng.standard_normal((7, 3)), rng.standard_normal((5, 3)), np.array([0.7, 1.3, 2.0])
+    k = O.Matern52(3, variance=1.7, lengthscales=ls)
+    t = lambda a: torch.as_tensor(a, dtype=torch.float64)
+    np.testing.assert_allclose(_matern52(t(X), t(X2), t(ls), 1.7).numpy(), k.K(X, X2), rtol=1e-12)
+    np.testing.assert_allclose(_matern52(t(X), None, t(ls), 1.7).numpy(), k.K(X), rtol=1e-12, atol=1e-12)
