@@ -413,11 +413,19 @@ struct ReduceQueue {
     }
 };
 
+// samples per split: 512, or the smallest multiple of 512 that keeps the number of splits <= 256 -- one that divides K when
+// there is one nearby (the fast GEMM path needs whole chunks)
+static int splitk_chunk(long long K) {
+    long long q = (K + 512LL * 256 - 1) / (512LL * 256);
+    if (q < 1) q = 1;
+    for (long long t = q; t < q + 64; ++t) if (K % (512 * t) == 0) return (int)(512 * t);
+    return (int)(512 * q);
+}
 // split-K product(s) summed over many samples: out (+ b*out_batch) = alpha * A^T-style product, reduced in float64
 static int gemm(hipStream_t st, GemmArgs g, float* part_ws, size_t part_floats, float* out, double* out64, long long ldo,
                 double alpha, double beta, int tri, int nbatch = 1, long long b_batch = 0, long long s_batch = 0, long long out_batch = 0,
                 ReduceQueue* rq = nullptr, const float* add = nullptr, double add_coef = 0.0, int add_diag_inv = 0) {
-    const int kchunk = 512;
+    const int kchunk = splitk_chunk(g.K);                   // 512 samples per split, more once that would exceed 256 splits
     g.nsplit = (g.K + kchunk - 1) / kchunk; g.kchunk = kchunk;
     if (g.nsplit < 2) { g.nsplit = 2; g.kchunk = round_up((g.K + 1) / 2, GK); if (g.kchunk < GK) g.kchunk = GK; }
     g.kseg = g.K; g.a_seg = g.b_seg = g.s_seg = 0; g.nbatch = nbatch; g.b_batch = b_batch; g.s_batch = s_batch;
@@ -873,7 +881,8 @@ static int launch_mid(hipStream_t st, const MidArgs& a) {
 // Thin sums over samples: part[blk][m][n] = sum_{t in chunk} X[t*ldx + m] * Y(t, n), n < N + ones, N <= 64; the extra
 // column (ones) is the plain column sum.  Thread = column m, rows in a fixed order; chunks summed by k_reduce_parts.
 constexpr int THIN_ROWS = 64;
-struct ThinArgs { const float* X; long long ldx; const float* Y; long long ldy; int N, ones; long long T; int M; float* part; };
+struct ThinArgs { const float* X; long long ldx; const float* Y; long long ldy; int N, ones; long long T; int M; float* part; int chunks; };
+static int thin_chunks(long long T) { return (int)((T + (long long)THIN_ROWS * 1024 - 1) / ((long long)THIN_ROWS * 1024)); }   // 64-row chunks per workgroup: <= 1024 partials
 template <int NM>                       // N <= NM: the accumulators stay in registers
 __global__ __launch_bounds__(256) void k_thin(ThinArgs a) {
     // chunk of 64 rows per workgroup: its rows of Y staged in LDS, wave w takes rows 16w..16w+15, lanes over the columns
@@ -881,29 +890,33 @@ __global__ __launch_bounds__(256) void k_thin(ThinArgs a) {
     __shared__ float ys[THIN_ROWS * (NM > 1 ? NM : 1)];
     __shared__ float red[4][64][NM + 1];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const long long t0 = (long long)blockIdx.x * THIN_ROWS;
-    const int nrows = (int)((a.T - t0) < THIN_ROWS ? (a.T - t0) : THIN_ROWS);
-    if (a.N > 0) {
-        // rows beyond the end are zero-filled: they meet x = 0 below, and 0 * (stale LDS bits) could be NaN
-        if (a.ldy == a.N) for (int i = tid; i < THIN_ROWS * a.N; i += 256) ys[i] = i < nrows * a.N ? a.Y[t0 * a.ldy + i] : 0.f;
-        else for (int i = tid; i < THIN_ROWS * a.N; i += 256) { const int r = i / a.N; ys[i] = r < nrows ? a.Y[(t0 + r) * a.ldy + (i - r * a.N)] : 0.f; }
-    }
-    __syncthreads();
     const int NN = a.N + a.ones;
     for (int mb = 0; mb < a.M; mb += 64) {
         const int m = mb + lane;
-        float x[16];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) { const int r = 16 * wave + i; x[i] = (m < a.M && r < nrows) ? a.X[(t0 + r) * a.ldx + m] : 0.f; }
         float acc[NM], ones = 0.f;
 #pragma unroll
         for (int n = 0; n < NM; ++n) acc[n] = 0.f;
+        for (int ch = 0; ch < a.chunks; ++ch) {                      // this workgroup's 64-row chunks, in order
+            const long long t0 = ((long long)blockIdx.x * a.chunks + ch) * THIN_ROWS;
+            if (t0 >= a.T) break;
+            const int nrows = (int)((a.T - t0) < THIN_ROWS ? (a.T - t0) : THIN_ROWS);
+            __syncthreads();                                         // the previous chunk's readers are done with ys
+            if (a.N > 0) {
+                // rows beyond the end are zero-filled: they meet x = 0 below, and 0 * (stale LDS bits) could be NaN
+                if (a.ldy == a.N) for (int i = tid; i < THIN_ROWS * a.N; i += 256) ys[i] = i < nrows * a.N ? a.Y[t0 * a.ldy + i] : 0.f;
+                else for (int i = tid; i < THIN_ROWS * a.N; i += 256) { const int r = i / a.N; ys[i] = r < nrows ? a.Y[(t0 + r) * a.ldy + (i - r * a.N)] : 0.f; }
+            }
+            __syncthreads();
+            float x[16];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int r = 16 * wave + i;
+            for (int i = 0; i < 16; ++i) { const int r = 16 * wave + i; x[i] = (m < a.M && r < nrows) ? a.X[(t0 + r) * a.ldx + m] : 0.f; }
 #pragma unroll
-            for (int n = 0; n < NM; ++n) if (n < a.N) acc[n] = fmaf(x[i], ys[r * a.N + n], acc[n]);
-            ones += x[i];
+            for (int i = 0; i < 16; ++i) {
+                const int r = 16 * wave + i;
+#pragma unroll
+                for (int n = 0; n < NM; ++n) if (n < a.N) acc[n] = fmaf(x[i], ys[r * a.N + n], acc[n]);
+                ones += x[i];
+            }
         }
 #pragma unroll
         for (int n = 0; n < NM; ++n) red[wave][lane][n] = acc[n];
@@ -928,12 +941,13 @@ static int thin(hipStream_t st, const float* X, long long ldx, int M, const floa
         if (rc != IWVI_OK) return rc;
         return thin(st, X, ldx, M, Y + 32, ldy, N - 32, ones, T, part_ws, part_floats, out + 32, ldo, rq, add ? add + 32 : nullptr, add_coef);
     }
-    const int nblk = (int)((T + THIN_ROWS - 1) / THIN_ROWS), NN = N + ones;
+    const int chunks = thin_chunks(T);
+    const int nblk = (int)((T + (long long)THIN_ROWS * chunks - 1) / ((long long)THIN_ROWS * chunks)), NN = N + ones;
     if (rq) {
         part_ws = rq->take((size_t)nblk * M * NN);
         if (!part_ws) { set_error("backward: thin-reduction workspace too small"); return IWVI_ERR_ARG; }
     } else if ((size_t)nblk * M * NN > part_floats) { set_error("backward: thin-reduction workspace too small"); return IWVI_ERR_ARG; }
-    ThinArgs a{X, ldx, Y, ldy, N, ones, T, M, part_ws};
+    ThinArgs a{X, ldx, Y, ldy, N, ones, T, M, part_ws, chunks};
     const dim3 grid(nblk), block(256);
     if (N <= 1) hipLaunchKernelGGL(k_thin<1>, grid, block, 0, st, a);
     else if (N <= 8) hipLaunchKernelGGL(k_thin<8>, grid, block, 0, st, a);
@@ -1044,13 +1058,13 @@ struct BwdWs {
 static BwdWs bwd_layout(char* base, long long T, int M, int D, int R) {
     BwdWs w; size_t o = 0;
     auto take = [&](size_t bytes) { char* p = base ? base + o : nullptr; o = align256(o + bytes); return p; };
-    const int nsplit = (int)((T + 255) / 256) + 2;
+    const int nsplit = (int)((T + splitk_chunk(T) - 1) / splitk_chunk(T)) + 2;
     w.DMU = (float*)take(sizeof(float) * T * R); w.DV2 = (float*)take(sizeof(float) * T * R); w.SDV = (float*)take(sizeof(float) * T);
     w.DA = (float*)take(sizeof(float) * T * M); w.DK = (float*)take(sizeof(float) * T * M);
     w.Qx = (float*)take(sizeof(float) * T * (D + 2));
     w.part_floats = (size_t)nsplit * M * M * (R + 1);          // dLm + the R batched dL_r, parked together
     {   // thin reductions: ceil(T / THIN_ROWS) chunks of at most [max(M, 34)][33]
-        const size_t thin = (size_t)((T + THIN_ROWS - 1) / THIN_ROWS) * (M > 34 ? M : 34) * 33;
+        const size_t thin = (size_t)((T + (long long)THIN_ROWS * thin_chunks(T) - 1) / ((long long)THIN_ROWS * thin_chunks(T))) * (M > 34 ? M : 34) * 33;
         w.part_floats += 8 * thin + 1024;                      // + up to 8 thin products
     }
     w.part = (float*)take(sizeof(float) * w.part_floats);
