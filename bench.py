@@ -256,9 +256,15 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup // spg):
+    # warm-up: whole replays (at least one when anything is exchanged or replayed from a graph: the first collective creates
+    # the RCCL communicator and the first replay uploads the graph -- neither may land in the timed region), then the rest
+    # of --warmup one evaluation at a time
+    n_warm = args.warmup // spg
+    if n_warm == 0 and (xch is not None or graph is not None):
+        n_warm = 1
+    for _ in range(n_warm):
         one_step()
-    for _ in range(args.warmup % spg):                           # the rest of the warm-up, one evaluation at a time (not exchanged)
+    for _ in range(max(0, args.warmup - n_warm * spg)):
         step.run()
     fence()
     t0 = time.perf_counter()
