@@ -177,8 +177,10 @@ def main():
     if args.gpus != world and rank == 0:
         print("note: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
 
-    from dgps_with_iwvi_amd import _abi, synthetic
+    from dgps_with_iwvi_amd import _abi, settings, synthetic
     _abi.lib()                                                   # fail loudly if the extension is missing
+    if world > 1:
+        settings.set_seed(settings.seed + 7919 * rank)           # every rank its own Philox key: the job's K_total samples are distinct
     cfg = CONFIGS[args.config]
     # parity=True: random q_mu / dense lower-triangular q_sqrt (a trained-like state).  The reference's
     # initial values (q_mu = 0, q_sqrt = 1e-5 I) would feed the MFMAs mostly zeros and flatter the clock.

@@ -191,7 +191,10 @@ def lse_from_pairs(ms_all):
 
 
 def k_shard_gradients(model, zs=None, K_total=None, group=None):
-    """K-sharded training step input: every rank holds all B points and its own K_r of the job's K_total importance
+    """(Every rank must draw its own noise: give each a different ``settings.set_seed`` -- the kernels key their Philox
+    streams by (seed, step, layer, sample, quad), so equal seeds would duplicate the samples across ranks.)
+
+    K-sharded training step input: every rank holds all B points and its own K_r of the job's K_total importance
     samples.  One all-gather of the [B, 2] pairs (the exchange of the forward path) gives the job's logsumexp per
     point; each rank's adjoint then runs with its share of the softmax weights, and ONE all-reduce (sum) of the flat
     gradient bucket finishes d ELBO / d theta -- the KL terms enter with 1 / world per rank.  -> (elbo, grads)."""
