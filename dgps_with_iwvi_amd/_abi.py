@@ -81,7 +81,7 @@ class GpBwdDesc(ctypes.Structure):
                 ("d_sample", c_void_p), ("d_mean", c_void_p), ("d_var", c_void_p), ("kl_weight", c_double),
                 ("dF", c_void_p), ("dZ", c_void_p), ("dls", c_void_p), ("dvariance", c_void_p),
                 ("dq_mu", c_void_p), ("dq_sqrt", c_void_p), ("dW", c_void_p), ("dmf_A", c_void_p),
-                ("side_stream", c_void_p)]
+                ("side_stream", c_void_p), ("side_stream2", c_void_p)]
 
 
 class AdamTensor(ctypes.Structure):

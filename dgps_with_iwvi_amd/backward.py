@@ -16,9 +16,10 @@ from .temp_workaround import precompute_states
 _SIDE = {}
 
 
-def _side_stream(device):
-    """One extra HIP stream per device: a layer's parameter-gradient branch runs there beside the adjoint of the layer below."""
-    key = (device.type, device.index)
+def _side_stream(device, which=0):
+    """Two extra HIP streams per device: a layer's parameter-gradient branch runs there (as two concurrent chains) beside the
+    adjoint of the layer below."""
+    key = (device.type, device.index, which)
     if key not in _SIDE:
         _SIDE[key] = torch.cuda.Stream(device=device)
     return _SIDE[key]
@@ -74,7 +75,8 @@ def gp_forward_saved(layer, F, z=None, words=None, precomputed=False):
     return s
 
 
-def gp_backward(layer, saved, d_sample=None, d_mean=None, d_var=None, kl_weight=1.0, want_dF=True, side_stream=None, keep=None):
+def gp_backward(layer, saved, d_sample=None, d_mean=None, d_var=None, kl_weight=1.0, want_dF=True, side_stream=None, keep=None,
+                side_stream2=None):
     """``iwvi_gp_layer_backward``: upstream gradients [T, P] -> dict(dF [T, D], dZ, dls, dvariance, dq_mu, dq_sqrt)."""
     dev = saved.F.device
     T, D = saved.F.shape
@@ -118,6 +120,8 @@ def gp_backward(layer, saved, d_sample=None, d_mean=None, d_var=None, kl_weight=
     ws = torch.empty(_abi.lib().iwvi_gp_layer_backward_ws_bytes(T, M, D, R), dtype=torch.uint8, device=dev)
     if side_stream is not None:                                  # parameter gradients beside the next layer's adjoint
         b.side_stream = ctypes.c_void_p(side_stream.cuda_stream)
+        if side_stream2 is not None:
+            b.side_stream2 = ctypes.c_void_p(side_stream2.cuda_stream)
         keep.append((ws, out, keep_t))                           # alive until the caller has joined the streams
     _abi.check(_abi.lib().iwvi_gp_layer_backward(ctypes.byref(b), T, ws.data_ptr(), _abi.stream_ptr()))
     return out
@@ -232,6 +236,7 @@ def iw_elbo_and_gradients(model, zs=None, mode_vi=None, exchange=None, K_total=N
     grads = {"lik_var": sums[1]}
     cur = torch.cuda.current_stream()
     side = _side_stream(dev) if overlap else None
+    side2 = _side_stream(dev, 1) if overlap else None
     held = []
     elbo = sums[2]                                               # scale * sum_n(...) - sum of the global KLs, formed on the device
     dF = None
@@ -241,7 +246,10 @@ def iw_elbo_and_gradients(model, zs=None, mode_vi=None, exchange=None, K_total=N
             last = i == len(layers) - 1
             g = gp_backward(layer, s[1], d_sample=None if last else dF, d_mean=d_mean if last else None,
                             d_var=d_var if last else None, kl_weight=kl_weight, want_dF=i > 0,
-                            side_stream=side if i > 0 else None, keep=held)
+                            side_stream=side if i > 0 else None, keep=held,
+                            # two concurrent chains only in the window where it was measured to pay (configs[2]: -4 %); smaller jobs are
+                            # host-bound (+8 % at configs[1]), larger ones fill the GPU on their own (+3 % at configs[3])
+                            side_stream2=side2 if (1 << 20) <= T * layer.num_inducing <= (1 << 23) else None)
             for k_out, k_name in (("dZ", "Z"), ("dls", "ls"), ("dvariance", "var"), ("dq_mu", "q_mu"), ("dq_sqrt", "q_sqrt"),
                                   ("dW", "W"), ("dmf_A", "mfA")):
                 if k_out in g:
@@ -255,6 +263,7 @@ def iw_elbo_and_gradients(model, zs=None, mode_vi=None, exchange=None, K_total=N
             dF = None if (dF is None or i == 0) else dF[:, :D_in].contiguous()
     if side is not None:
         cur.wait_stream(side)                                    # join: the parameter gradients are complete on the caller's stream
+        cur.wait_stream(side2)
     del held
     return elbo, grads
 

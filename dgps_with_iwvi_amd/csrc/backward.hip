@@ -1479,7 +1479,6 @@ extern "C" int iwvi_gp_layer_backward(const iwvi_gp_bwd_desc* dp, int64_t T, voi
         hipLaunchKernelGGL(k_prep, dim3((n + 255) / 256), dim3(256), 0, st, d.Z, d.lengthscales, Linv64, Mp, w.Zt, w.invls, w.LinvF, M, D);
     }
     const float* gmv = d.GMV ? d.GMV : w.GMV;
-    ReduceQueue rq(w.part, w.part_floats);                 // every sum over samples below is finished by ONE launch (rq.flush)
     MidArgs ma{d.GMV, d.noise, d.W, d.mf_A, d.d_sample, d.d_mean, d.d_var, w.DMU, w.DV2, w.SDV, d.dF, d.P, d.mf_type,
                d.U, d.A, Mp, d.q_sqrt, d.q_mu, w.LinvF, w.DK, d.F, w.Zt, w.invls, w.DA, w.Qx, (long long)T, M, D, R, d.variance, d.kern_type};
     const int fused = launch_mid(st, ma);                  // heads + DA + dK + kernel adjoint in one launch where the shapes allow
@@ -1520,36 +1519,61 @@ extern "C" int iwvi_gp_layer_backward(const iwvi_gp_bwd_desc* dp, int64_t T, voi
 
     }
     // Everything the layer below needs (dF) is now queued on `st`.  What follows only produces this layer's parameter
-    // gradients: with a side stream it runs beside the next layer's adjoint instead of ahead of it.
-    hipStream_t main_st = st;
+    // gradients: with side streams it runs beside the next layer's adjoint instead of ahead of it, as two chains --
+    //   A: dLm -> its reduction -> Cholesky adjoint -> K_uu's gradient          B: every other sum over samples -> one reduction
+    // -- that meet in the final assembly (on B's stream).
+    hipStream_t stA = st, stB = st;
+    hipEvent_t evA = nullptr;
     if (d.side_stream) {
+        stA = (hipStream_t)d.side_stream;
+        stB = d.side_stream2 ? (hipStream_t)d.side_stream2 : stA;
         hipEvent_t ev;
-        if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess || hipEventRecord(ev, main_st) != hipSuccess ||
-            hipStreamWaitEvent((hipStream_t)d.side_stream, ev, 0) != hipSuccess) { set_error("iwvi_gp_layer_backward: stream fork failed"); return IWVI_ERR_LAUNCH; }
+        if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess || hipEventRecord(ev, st) != hipSuccess ||
+            hipStreamWaitEvent(stA, ev, 0) != hipSuccess || (stB != stA && hipStreamWaitEvent(stB, ev, 0) != hipSuccess)) {
+            set_error("iwvi_gp_layer_backward: stream fork failed"); return IWVI_ERR_LAUNCH;
+        }
         (void)hipEventDestroy(ev);                         // (released once the recorded work has passed it)
-        st = (hipStream_t)d.side_stream;
     }
-    (void)main_st;
-    // dLm = -tril(DK^T A)  (float64 copy for the adjoint of the factorisation)
+    const size_t partA = (size_t)((T + splitk_chunk(T) - 1) / splitk_chunk(T) + 2) * M * M;
+    const bool two_q = d.side_stream && d.side_stream2 && d.side_stream2 != d.side_stream;
+    ReduceQueue rqA(w.part, two_q ? partA : 0), rqB(w.part + (two_q ? partA : 0), w.part_floats - (two_q ? partA : 0));
+    // ---- chain A: dLm = -tril(DK^T A)  (float64, for the adjoint of the factorisation), then S = Lm^-T Phi(Lm^T Lbar) Lm^-1
+    const bool two = stB != stA;
+    auto chol_adjoint = [&](hipStream_t s_) {
+        const dim3 grid((M + 15) / 16, (M + 15) / 16), block(256);
+        hipLaunchKernelGGL(k_dmm, grid, block, 0, s_, Lm64, 1LL, (long long)Mp, (const double*)w.Lbar, (long long)M, 1LL, w.T1, M, M, 1);
+        hipLaunchKernelGGL(k_dmm, grid, block, 0, s_, Linv64, 1LL, (long long)Mp, (const double*)w.T1, (long long)M, 1LL, w.T2, M, M, 0);
+        hipLaunchKernelGGL(k_dmm, grid, block, 0, s_, (const double*)w.T2, (long long)M, 1LL, Linv64, (long long)Mp, 1LL, w.S, M, M, 0);
+        hipLaunchKernelGGL(k_kuu_bwd, dim3(M), dim3(256), 0, s_, w.Zt, (const double*)w.S, M, D, (double)d.variance, d.kern_type, w.dZt_uu, w.dvar_m);
+        return check_launch("cholesky adjoint");
+    };
     {
         GemmArgs q{};
         q.A = w.DK; q.a_sm = 1; q.a_sk = M; q.B = d.A; q.b_sk = Mp; q.b_sn = 1; q.M = M; q.N = M; q.K = (int)T; q.tri_out = 1;
-        if ((rc = gemm(st, q, w.part, w.part_floats, nullptr, w.Lbar, M, -1.0, 0.0, 1, 1, 0, 0, 0, &rq)) != IWVI_OK) return rc;
+        if ((rc = gemm(stA, q, w.part, w.part_floats, nullptr, w.Lbar, M, -1.0, 0.0, 1, 1, 0, 0, 0, two ? &rqA : &rqB)) != IWVI_OK) return rc;
+        if (two) {                                         // its own reduction and the float64 chain, concurrently with chain B
+            if ((rc = rqA.flush(stA)) != IWVI_OK || (rc = chol_adjoint(stA)) != IWVI_OK) return rc;
+            if (hipEventCreateWithFlags(&evA, hipEventDisableTiming) != hipSuccess || hipEventRecord(evA, stA) != hipSuccess) {
+                set_error("iwvi_gp_layer_backward: stream join failed"); return IWVI_ERR_LAUNCH;
+            }
+        }
     }
+    // ---- chain B
+    st = stB;
     // dq_mu = A^T DMU
     // (- kl_weight * dKL/dq_mu = - kl_weight * q_mu rides in the reduction; temp_workaround.py:186-188)
-    if (d.dq_mu && (rc = thin(st, d.A, Mp, M, w.DMU, R, R, 0, T, w.part, w.part_floats, d.dq_mu, 0, &rq, d.q_mu, -d.kl_weight)) != IWVI_OK) return rc;
+    if (d.dq_mu && (rc = thin(st, d.A, Mp, M, w.DMU, R, R, 0, T, w.part, w.part_floats, d.dq_mu, 0, &rqB, d.q_mu, -d.kl_weight)) != IWVI_OK) return rc;
     // dL_r = tril(A^T diag(2 dv_r) U_r), all r in one batched launch
     if (d.dq_sqrt) {
         GemmArgs q{};
         q.A = d.A; q.a_sm = 1; q.a_sk = Mp; q.B = d.U; q.b_sk = Mp; q.b_sn = 1;
         q.scale = w.DV2; q.s_stride = R; q.scale_on_k = 1; q.M = M; q.N = M; q.K = (int)T; q.tri_out = 1;
         // (- kl_weight * dKL/dL_r = - kl_weight * (L_r - diag(1 / L_ii)) rides in the reduction)
-        if ((rc = gemm(st, q, w.part, w.part_floats, d.dq_sqrt, nullptr, M, 1.0, 0.0, 1, R, (long long)T * Mp, 1, (long long)M * M, &rq, d.q_sqrt, -d.kl_weight, 1)) != IWVI_OK) return rc;
+        if ((rc = gemm(st, q, w.part, w.part_floats, d.dq_sqrt, nullptr, M, 1.0, 0.0, 1, R, (long long)T * Mp, 1, (long long)M * M, &rqB, d.q_sqrt, -d.kl_weight, 1)) != IWVI_OK) return rc;
     }
     // sums over samples: C^T [F | 1]  and the column sums of Qx = (dx~ o x | sum_r dv_r | sum_m k dk)
-    if ((rc = thin(st, w.DA, M, M, d.F, D, D, 1, T, w.part, w.part_floats, w.CtF1, 0, &rq)) != IWVI_OK) return rc;
-    if ((rc = thin(st, w.Qx, D + 2, D + 2, nullptr, 0, 0, 1, T, w.part, w.part_floats, w.Qsum, 0, &rq)) != IWVI_OK) return rc;
+    if ((rc = thin(st, w.DA, M, M, d.F, D, D, 1, T, w.part, w.part_floats, w.CtF1, 0, &rqB)) != IWVI_OK) return rc;
+    if ((rc = thin(st, w.Qx, D + 2, D + 2, nullptr, 0, 0, 1, T, w.part, w.part_floats, w.Qsum, 0, &rqB)) != IWVI_OK) return rc;
     // mixing matrix and linear mean function (trainable when the reference runs with fix_linear=False, build_models.py:224-227)
     const bool lin_on = (d.dW && d.W) || (d.dmf_A && d.mf_type == IWVI_MF_LINEAR);
     float* s[3] = {nullptr, nullptr, nullptr}; float* a12[2] = {nullptr, nullptr};
@@ -1558,28 +1582,24 @@ extern "C" int iwvi_gp_layer_backward(const iwvi_gp_bwd_desc* dp, int64_t T, voi
         const float* ups[3] = {d.d_sample, d.d_mean, d.d_var};
         if (d.dW && d.W) for (int i = 0; i < 3; ++i) if (ups[i]) {
             s[i] = w.lin + i * IWVI_MAX_P * IWVI_MAX_R;
-            if ((rc = thin(st, ups[i], P, P, gmv + i * R, 3 * R, R, 0, T, w.part, w.part_floats, s[i], 0, &rq)) != IWVI_OK) return rc;
+            if ((rc = thin(st, ups[i], P, P, gmv + i * R, 3 * R, R, 0, T, w.part, w.part_floats, s[i], 0, &rqB)) != IWVI_OK) return rc;
         }
         if (d.dmf_A && d.mf_type == IWVI_MF_LINEAR) for (int i = 0; i < 2; ++i) if (ups[i]) {
             a12[i] = w.lin + 3 * IWVI_MAX_P * IWVI_MAX_R + i * IWVI_MAX_D * IWVI_MAX_P;
-            if ((rc = thin(st, d.F, D, D, ups[i], P, P, 0, T, w.part, w.part_floats, a12[i], 0, &rq)) != IWVI_OK) return rc;
+            if ((rc = thin(st, d.F, D, D, ups[i], P, P, 0, T, w.part, w.part_floats, a12[i], 0, &rqB)) != IWVI_OK) return rc;
         }
     }
-    if ((rc = rq.flush(st)) != IWVI_OK) return rc;
-    // adjoint of Lm = chol(Kuu): S = Lm^-T Phi(Lm^T Lbar) Lm^-1
-    {
-        const dim3 grid((M + 15) / 16, (M + 15) / 16), block(256);
-        hipLaunchKernelGGL(k_dmm, grid, block, 0, st, Lm64, 1LL, (long long)Mp, (const double*)w.Lbar, (long long)M, 1LL, w.T1, M, M, 1);
-        hipLaunchKernelGGL(k_dmm, grid, block, 0, st, Linv64, 1LL, (long long)Mp, (const double*)w.T1, (long long)M, 1LL, w.T2, M, M, 0);
-        hipLaunchKernelGGL(k_dmm, grid, block, 0, st, (const double*)w.T2, (long long)M, 1LL, Linv64, (long long)Mp, 1LL, w.S, M, M, 0);
-        hipLaunchKernelGGL(k_kuu_bwd, dim3(M), dim3(256), 0, st, w.Zt, (const double*)w.S, M, D, (double)d.variance, d.kern_type, w.dZt_uu, w.dvar_m);
-        if ((rc = check_launch("cholesky adjoint")) != IWVI_OK) return rc;
-    }
+    if ((rc = rqB.flush(st)) != IWVI_OK) return rc;
+    if (!two && (rc = chol_adjoint(st)) != IWVI_OK) return rc;     // one stream: after the single reduction, as before
     if (lin_on) {
         const int P = d.P;
         const int n_w = (d.dW && d.W) ? P * R : 0, n_a = (d.dmf_A && d.mf_type == IWVI_MF_LINEAR) ? D * P : 0;
         hipLaunchKernelGGL(k_lin_combine, dim3(((n_w > n_a ? n_w : n_a) + 255) / 256), dim3(256), 0, st, (const float*)s[0], (const float*)s[1], (const float*)s[2],
                            d.W, n_w ? d.dW : nullptr, n_w, (const float*)a12[0], (const float*)a12[1], n_a ? d.dmf_A : nullptr, n_a);
+    }
+    if (evA) {                                             // the assembly needs chain A's dZt_uu / dvar_m
+        if (hipStreamWaitEvent(stB, evA, 0) != hipSuccess) { set_error("iwvi_gp_layer_backward: stream join failed"); return IWVI_ERR_LAUNCH; }
+        (void)hipEventDestroy(evA);
     }
     FinalArgsB f{d.Z, d.lengthscales, d.q_mu, d.q_sqrt, w.Zt, w.invls, w.CtF1, w.CtF1, w.Qsum + D, w.Qsum, w.dZt_uu, w.dvar_m,
                  d.dZ, d.dls, d.dvariance, d.dq_mu, d.dq_sqrt, M, D, R, d.kl_weight, (double)d.variance};

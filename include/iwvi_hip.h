@@ -270,6 +270,8 @@ typedef struct iwvi_gp_bwd_desc {
     void* side_stream;              /* optional hipStream_t: once dF is queued on `stream`, the parameter gradients of this
                                      * layer are queued there (after an event), so that they overlap the adjoint of the layer
                                      * below; the caller joins the two streams before reading the parameter gradients */
+    void* side_stream2;             /* optional second side stream: the parameter branch then runs as two concurrent chains
+                                     * (Cholesky adjoint | the other sums over samples); join both */
 } iwvi_gp_bwd_desc;
 size_t iwvi_gp_layer_backward_ws_bytes(int64_t T, int M, int D, int R);
 int iwvi_gp_layer_backward(const iwvi_gp_bwd_desc* desc, int64_t T, void* ws, void* stream);
