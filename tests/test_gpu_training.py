@@ -18,7 +18,7 @@ def _t(a, dev):
     return torch.as_tensor(np.asarray(a, dtype=np.float32), device=dev)
 
 
-@pytest.mark.parametrize("M,R", [(8, 1), (40, 2), (128, 1)])
+@pytest.mark.parametrize("M,R", [(8, 1), (40, 2), (128, 1), (200, 1)])      # 200: the wave-per-column triangular inverse (M > 160)
 def test_natgrad_step_matches_oracle(gpu_device, M, R):
     import ctypes
     from dgps_with_iwvi_amd import _abi
@@ -26,7 +26,7 @@ def test_natgrad_step_matches_oracle(gpu_device, M, R):
     q_mu = rng.standard_normal((M, R)).astype(np.float32)
     q_sqrt = (np.tril(rng.standard_normal((R, M, M))) * 0.1 + np.eye(M)).astype(np.float32)
     g_mu = rng.standard_normal((M, R)).astype(np.float32)            # gradients of the ELBO
-    g_sqrt = np.tril(rng.standard_normal((R, M, M))).astype(np.float32) * 0.5
+    g_sqrt = np.tril(rng.standard_normal((R, M, M))).astype(np.float32) * np.float32(0.5 * min(1.0, (64.0 / M) ** 0.5))   # keeps -2 theta_2' positive definite
     ref_mu, ref_sqrt = oo.natgrad_step(q_mu, q_sqrt, -g_mu.astype(np.float64), -g_sqrt.astype(np.float64), 0.05)
     d_mu, d_sqrt, dg_mu, dg_sqrt = (_t(a, gpu_device) for a in (q_mu, q_sqrt, g_mu, g_sqrt))
     ws = torch.empty(_abi.lib().iwvi_natgrad_ws_bytes(M), dtype=torch.uint8, device=gpu_device)
