@@ -122,8 +122,14 @@ class Trainer:
         self.adam_t += 1
         self._adam_call(g, lr=staircase_decay(self.lr, self.global_step, self.lr_decay))
         if self._scalars:                                      # host copies of the scalar parameters (one small D2H)
-            vals = torch.cat([t for t, _ in self._scalars]).tolist()
-            for (_, setter), v in zip(self._scalars, vals):
+            # the same transfer carries a health word: the bound and the final layer's q(u) must be finite (a natural-gradient
+            # step that leaves -2 theta_2 indefinite makes TensorFlow's Cholesky raise in the reference; here it would go on as NaN)
+            ok = (torch.isfinite(elbo) & torch.isfinite(self.final.q_sqrt).all() & torch.isfinite(self.final.q_mu).all()).to(settings.float_type)
+            vals = torch.cat([t for t, _ in self._scalars] + [ok.reshape(1)]).tolist()
+            if vals[-1] != 1.0:
+                raise FloatingPointError("training step %d: non-finite bound or final-layer q(u) (the natural-gradient step left the "
+                                         "precision matrix indefinite: lower gamma)" % self.global_step)
+            for (_, setter), v in zip(self._scalars, vals[:-1]):
                 setter(float(v))
         return elbo
 

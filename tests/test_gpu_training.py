@@ -208,3 +208,16 @@ def test_checkpoint_resume_continues_the_same_trajectory(gpu_device, tmp_path):
         assert torch.equal(pa, pc), name
     assert torch.equal(a.layers[-1].q_mu, c.layers[-1].q_mu) and torch.equal(a.layers[-1].q_sqrt, c.layers[-1].q_sqrt)
     assert a.likelihood.variance == c.likelihood.variance
+
+
+def test_a_diverged_natural_gradient_step_is_reported(gpu_device):
+    """gamma far too large: -2 theta_2 turns indefinite, the Cholesky inside the step produces NaN; the trainer says so (the
+    reference's TensorFlow Cholesky would raise at the same point) instead of training on."""
+    from dgps_with_iwvi_amd import synthetic
+    from dgps_with_iwvi_amd.training import Trainer
+    spec = synthetic.make_spec(L=2, M=32, B=16, K=4, with_lv=True, seed=2)
+    model = synthetic.build_model(spec, gpu_device)
+    tr = Trainer(model, gamma=1e6)
+    with pytest.raises(FloatingPointError):
+        for _ in range(3):
+            tr.step()
