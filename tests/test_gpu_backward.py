@@ -275,14 +275,18 @@ def test_k_sharded_gradients_add_up_to_the_unsharded_gradient(gpu_device):
         _close(k, v.cpu().numpy().reshape(ref[k].shape), ref[k], rtol=5e-3)
 
 
-def test_full_size_gradient_agrees_with_central_differences_of_the_forward(gpu_device):
-    """BASELINE.json configs[2] at full size (20480 samples, where the float64 oracle is out of reach for a routine test): for a
+@pytest.mark.parametrize("cfg,names", [
+    (dict(L=2, M=128, B=1024, K=20, with_lv=True), ("l1.q_mu", "l1.Z", "l2.q_mu", "l1.ls", "l0.encW0", "l2.Z", "l1.q_sqrt", "l2.ls")),
+    (dict(L=3, M=256, B=4096, K=50, with_lv=False), ("l0.q_mu", "l1.Z", "l2.q_mu", "l0.ls", "l1.q_sqrt", "l2.Z"))],
+    ids=["configs2", "configs3"])
+def test_full_size_gradient_agrees_with_central_differences_of_the_forward(gpu_device, cfg, names):
+    """BASELINE.json configs[2] / configs[3] at full size (20480 / 204800 samples, where the float64 oracle is out of reach for a routine test): for a
     random direction d in each parameter group, the directional derivative g . d of the HIP backward pass against the central
     difference (ELBO(theta + eps d) - ELBO(theta - eps d)) / (2 eps) of the HIP forward path on the same injected noise.  The
     forward is float32 (relative noise ~1e-6 of |ELBO| ~ 6e6), so eps is sized to lift the difference two orders above it;
     tolerance 2 % (what is left is the truncation error of the difference quotient at eps = 0.02)."""
     from dgps_with_iwvi_amd import synthetic, backward
-    spec = synthetic.make_spec(L=2, M=128, B=1024, K=20, with_lv=True, seed=0, parity=True, n_data=65536)
+    spec = synthetic.make_spec(seed=0, parity=True, n_data=65536, **cfg)
     model = synthetic.build_model(spec, gpu_device)
     zs = [torch.as_tensor(np.asarray(z, dtype=np.float32), device=gpu_device) for z in synthetic.make_noise(spec, seed=1)]
     elbo0, grads = backward.iw_elbo_and_gradients(model, zs)
@@ -291,7 +295,7 @@ def test_full_size_gradient_agrees_with_central_differences_of_the_forward(gpu_d
     gen = torch.Generator(device="cpu").manual_seed(5)
     params = dict(backward.parameter_list(model))
     noise = 2e-6 * abs(f0)
-    for name in ("l1.q_mu", "l1.Z", "l2.q_mu", "l1.ls", "l0.encW0", "l2.Z", "l1.q_sqrt", "l2.ls"):
+    for name in names:
         p, g = params[name], grads[name].reshape(params[name].shape).double()
         d = torch.randn(p.shape, generator=gen).to(gpu_device)
         d = d / d.norm()
