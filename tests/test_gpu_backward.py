@@ -277,10 +277,11 @@ def test_k_sharded_gradients_add_up_to_the_unsharded_gradient(gpu_device):
 
 @pytest.mark.parametrize("cfg,names", [
     (dict(L=2, M=128, B=1024, K=20, with_lv=True), ("l1.q_mu", "l1.Z", "l2.q_mu", "l1.ls", "l0.encW0", "l2.Z", "l1.q_sqrt", "l2.ls")),
-    (dict(L=3, M=256, B=4096, K=50, with_lv=False), ("l0.q_mu", "l1.Z", "l2.q_mu", "l0.ls", "l1.q_sqrt", "l2.Z"))],
-    ids=["configs2", "configs3"])
+    (dict(L=3, M=256, B=4096, K=50, with_lv=False), ("l0.q_mu", "l1.Z", "l2.q_mu", "l0.ls", "l1.q_sqrt", "l2.Z")),
+    (dict(L=5, M=512, B=8192, K=100, with_lv=False), ("l0.q_mu", "l2.Z", "l4.q_mu", "l3.ls"))],
+    ids=["configs2", "configs3", "configs4"])
 def test_full_size_gradient_agrees_with_central_differences_of_the_forward(gpu_device, cfg, names):
-    """BASELINE.json configs[2] / configs[3] at full size (20480 / 204800 samples, where the float64 oracle is out of reach for a routine test): for a
+    """BASELINE.json configs[2] / [3] / [4] at full size (20480 / 204800 / 819200 samples, where the float64 oracle is out of reach for a routine test): for a
     random direction d in each parameter group, the directional derivative g . d of the HIP backward pass against the central
     difference (ELBO(theta + eps d) - ELBO(theta - eps d)) / (2 eps) of the HIP forward path on the same injected noise.  The
     forward is float32 (relative noise ~1e-6 of |ELBO| ~ 6e6), so eps is sized to lift the difference two orders above it;
