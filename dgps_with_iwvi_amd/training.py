@@ -28,7 +28,8 @@ class Trainer:
                  beta1=0.9, beta2=0.999, epsilon=1e-8, group=None, shard_weight=None, shard="n"):
         """``group`` / ``shard_weight``: data-parallel training over the ranks of a torch.distributed group (each rank's
         model holds its own minibatch rows, N-shard): gradients are merged by ``sharding.allreduce_gradients`` with
-        weight B_rank / B_job (default 1 / world) before either update, so every rank applies the same step.
+        weight B_rank / B_job (default 1 / world) before either update, so every rank applies the same step.  (Give every
+        rank its own rows of the data set: the minibatch iterator is seeded identically everywhere, models.py:25-26.)
         ``shard="k"``: every rank holds all the points and its own share of the importance samples instead
         (``sharding.k_shard_gradients``: one all-gather of the per-point pairs + one gradient all-reduce)."""
         self.model = model
