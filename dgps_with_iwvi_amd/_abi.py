@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libiwvi_hip.so")
 
 KERN_RBF, KERN_MATERN52 = 0, 1
 LAYER_GP, LAYER_LV = 0, 1
-ABI_VERSION = 4
+ABI_VERSION = 5
 GP_WANT_DENSE = 1
 MAX_STACK = 8
 MF_ZERO, MF_IDENTITY, MF_LINEAR = 0, 1, 2
@@ -124,7 +124,9 @@ PROTOTYPES = {
                                       c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     "iwvi_gp_fullcov_ws_bytes": (c_size_t, [c_int64, c_int, c_int]),
     "iwvi_gp_layer_fullcov": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p,
-                                      c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
+                                      c_int64, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "iwvi_mvn_sample_ws_bytes": (c_size_t, [c_int64, c_int, c_int]),
+    "iwvi_mvn_sample": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_float, c_void_p, c_void_p]),
     "iwvi_lv_layer_forward": (c_int, [c_void_p, c_void_p, c_void_p, ctypes.POINTER(c_void_p),
                                       ctypes.POINTER(c_void_p), ctypes.POINTER(ctypes.c_int32), c_int,
                                       c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
@@ -145,6 +147,9 @@ PROTOTYPES = {
     "iwvi_lse_merge_steps": (c_int, [c_void_p, c_int, c_int, c_int64, c_int, ctypes.POINTER(c_void_p),
                                      ctypes.POINTER(ctypes.c_int32), c_int, c_double, c_void_p, c_void_p, c_void_p]),
     "iwvi_gauss_kl": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "iwvi_gaussian_var_exp": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_int64, c_int, c_int64, c_int64,
+                                      c_void_p, c_void_p]),
+    "iwvi_unwhiten": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "iwvi_fill_normal": (c_int, [c_void_p, c_int64, ctypes.c_uint64, ctypes.c_uint64, c_void_p]),
     "iwvi_fill_normal_dev": (c_int, [c_void_p, c_int64, ctypes.c_uint64, c_void_p, c_void_p]),
 }

@@ -182,6 +182,13 @@ def iw_elbo_and_gradients(model, zs=None, mode_vi=None, exchange=None, K_total=N
     for layer in layers:
         if not isinstance(layer, (GPLayer, LatentVariableLayer)):
             raise TypeError("the backward pass knows GPLayer and LatentVariableLayer")
+    if not mode_vi and getattr(model, "_joint_over_samples", lambda: False)():
+        raise NotImplementedError("an inner GPLayer with a plain (non-SharedMixedMok) kernel draws its K samples jointly "
+                                  "(temp_workaround.py:149-155); the hand-written adjoints cover the marginal-sampling stacks only")
+    n_lv = sum(isinstance(l, LatentVariableLayer) for l in layers)
+    if n_lv > 2:
+        raise NotImplementedError("the backward pass reads the encoder outputs of the precompute launch, which evaluates at most "
+                                  "2 latent-variable layers (%d in this model)" % n_lv)
     has_lv = any(isinstance(l, LatentVariableLayer) for l in layers)
     XY = model._xy_minibatch() if has_lv else None
     # forward: one factorisation launch (dense factors, encoders) + ONE fused layer launch that also leaves what the
@@ -190,9 +197,7 @@ def iw_elbo_and_gradients(model, zs=None, mode_vi=None, exchange=None, K_total=N
     zflat = [None if z is None else z.reshape(T, -1) for z in zs]
     _, outs, _ = model._fused_forward(T, K, B, (T,), zs=zflat, sampled_kl=not mode_vi, want_layers=True, want_logw=False,
                                       want_saved=True)
-    if any(z is None for z in zs):
-        model._words()[1] += 1                                   # the next evaluation draws fresh noise (the ELBO tail, which
-        #                                                          advances the device counter in the forward path, is not run here)
+    # (the layer launch itself advances the device-resident noise counter: the next evaluation draws fresh noise)
     saved = []
     F = None
     for i, (layer, o) in enumerate(zip(layers, outs)):

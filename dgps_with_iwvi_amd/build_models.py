@@ -125,10 +125,23 @@ def state_dict(model):
             out[p + "q_sqrt"] = layer.q_sqrt.detach().cpu().numpy()
             if isinstance(layer.kern, SharedMixedMok):
                 out[p + "W"] = layer.kern.W.detach().cpu().numpy()
+            if layer.mean_function.A is not None:                     # Linear: trainable when fix_linear=False (:224-227)
+                out[p + "mf_A"] = layer.mean_function.A.detach().cpu().numpy()
+                out[p + "mf_b"] = layer.mean_function.b.detach().cpu().numpy()
         elif isinstance(layer, LatentVariableLayer) and layer.encoder is not None:
             for j, (w, b) in enumerate(zip(layer.encoder.Ws, layer.encoder.bs)):
                 out[p + "enc_W%d" % j] = w.detach().cpu().numpy()
                 out[p + "enc_b%d" % j] = b.detach().cpu().numpy()
+    # the session state a tf.train.Saver restores besides the variables: where the shuffled minibatch iterator stands
+    # (gpflow.Minibatch(seed=0), models.py:25-26) and the noise streams' counters
+    kind, keys, pos, has_gauss, cached = model._mb_rng.get_state()
+    out["minibatch.rng_keys"], out["minibatch.rng_pos"] = np.asarray(keys), np.int64(pos)
+    out["minibatch.pos"] = np.int64(model._mb_pos)
+    if model._mb_perm is not None:
+        out["minibatch.perm"] = model._mb_perm.detach().cpu().numpy()
+    if model._dev_words is not None:
+        out["rng.step"] = np.int64(int(model._dev_words[1].item()))
+    out["rng.seed"], out["rng.offset"] = np.int64(settings.seed), np.int64(settings._offset)
     return out
 
 
@@ -162,11 +175,28 @@ def load_state_dict(model, state):
             put(layer, "q_sqrt", state[p + "q_sqrt"])
             if isinstance(layer.kern, SharedMixedMok):
                 put(layer.kern, "W", state[p + "W"])
+            if layer.mean_function.A is not None and p + "mf_A" in state:
+                put(layer.mean_function, "A", state[p + "mf_A"])
+                put(layer.mean_function, "b", state[p + "mf_b"])
             layer._state = None                                       # factorisation depends on Z / lengthscales
         elif isinstance(layer, LatentVariableLayer) and layer.encoder is not None:
             for j in range(len(layer.encoder.Ws)):
                 put(layer.encoder, "Ws", state[p + "enc_W%d" % j], j)
                 put(layer.encoder, "bs", state[p + "enc_b%d" % j], j)
+    if "minibatch.rng_keys" in state:                                 # resume the batch order and the noise streams
+        model._mb_rng.set_state(("MT19937", np.asarray(state["minibatch.rng_keys"], dtype=np.uint32),
+                                 int(state["minibatch.rng_pos"]), 0, 0.0))
+        model._mb_pos = int(state["minibatch.pos"])
+        model._mb_perm = (torch.as_tensor(np.asarray(state["minibatch.perm"]), device=dev)
+                          if "minibatch.perm" in state else None)
+        if model.minibatch_size is not None and model._mb_perm is not None and model._mb_pos > 0:
+            b = min(model.minibatch_size, model._X_all.shape[0])
+            idx = model._mb_perm[model._mb_pos - b:model._mb_pos]     # the batch the saved model was looking at
+            model.X, model.Y = model._X_all[idx].contiguous(), model._Y_all[idx].contiguous()
+        model._mb_serial += 1
+        if "rng.step" in state:
+            model._words()[1] = int(state["rng.step"])
+        settings.seed, settings._offset = int(state["rng.seed"]), int(state["rng.offset"])
     return model
 
 

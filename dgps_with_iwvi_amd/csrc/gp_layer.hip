@@ -19,6 +19,7 @@ __device__ __forceinline__ float kern_value_f32(float r2, int type, float var) {
     return var * __expf(-0.5f * r2);
 }
 
+constexpr int FULLCOV_ROWS = 32;
 // cov[s][r][i][j] = k(x_si, x_sj) - a_si . a_sj + u_rsi . u_rsj      (temp_workaround.py:45,56,83)
 __global__ __launch_bounds__(256) void k_fullcov(const float* __restrict__ F, const float* __restrict__ invls,
                                                  const float* __restrict__ a, const float* __restrict__ u,
@@ -30,8 +31,11 @@ __global__ __launch_bounds__(256) void k_fullcov(const float* __restrict__ F, co
     const float* as = a + (size_t)s * N * Mp;
     const float* us = u + ((size_t)r * T + (size_t)s * N) * Mp;
     float* out = cov + ((size_t)s * R + r) * N * N;
-    for (int idx = threadIdx.x; idx < N * N; idx += blockDim.x) {
-        const int i = idx / N, jx = idx - i * N;
+    // blockIdx.z = a strip of rows (FULLCOV_ROWS of them), so that a single large block (predict_f_full_cov on a
+    // test set: S = 1, N in the thousands) still fills the chip
+    const int i_lo = blockIdx.z * FULLCOV_ROWS, i_hi = min(N, i_lo + FULLCOV_ROWS);
+    for (long long idx = (long long)i_lo * N + threadIdx.x; idx < (long long)i_hi * N; idx += blockDim.x) {
+        const int i = (int)(idx / N), jx = (int)(idx - (long long)i * N);
         if (jx > i) continue;
         float r2 = 0.f;
         for (int d = 0; d < D; ++d) {
@@ -52,6 +56,48 @@ __global__ __launch_bounds__(256) void k_fullcov(const float* __restrict__ F, co
         acc = acc - da + du;
         out[(size_t)i * N + jx] = acc;
         out[(size_t)jx * N + i] = acc;
+    }
+}
+
+// sample[s, n, r] = mean[s, n, r] + (chol(cov[s, r] + jitter I) z[s, r])[n]      (temp_workaround.py:93-96)
+// One workgroup per (s, r): the N x N block is factorised in LDS (float32, right-looking, column at a time -- on the
+// IW path N is the number of importance samples); N > MVN_LDS_N works in a caller-provided global scratch instead
+// (correct, latency-bound: only the 2-D predict path with a consumed inner-layer sample gets there).
+// A non-positive pivot poisons the block's sample with NaN like a failed tf.cholesky.
+constexpr int MVN_LDS_N = 192;
+__global__ __launch_bounds__(256) void k_mvn_sample(const float* __restrict__ mean, const float* __restrict__ cov,
+                                                    const float* __restrict__ z, float* __restrict__ sample,
+                                                    int N, int R, float jitter, float* __restrict__ scratch) {
+    extern __shared__ float mvn_sm[];
+    const long long s = blockIdx.x;
+    const int r = blockIdx.y, tid = threadIdx.x;
+    float* Lm = scratch ? scratch + ((size_t)s * R + r) * ((size_t)N * N + N) : mvn_sm;   // [N, N] lower triangle
+    float* zz = Lm + (size_t)N * N;                                                        // [N]
+    const float* C = cov + ((size_t)s * R + r) * N * N;
+    for (long long idx = tid; idx < (long long)N * N; idx += 256) {
+        const int i = (int)(idx / N), k = (int)(idx - (long long)i * N);
+        Lm[idx] = (k <= i) ? C[idx] + (k == i ? jitter : 0.f) : 0.f;
+    }
+    for (int i = tid; i < N; i += 256) zz[i] = z[((size_t)s * R + r) * N + i];
+    for (int j = 0; j < N; ++j) {
+        __syncthreads();
+        const float d = Lm[(size_t)j * N + j];
+        const float inv = d > 0.f ? rsqrtf(d) : __builtin_nanf("");
+        __syncthreads();
+        for (int i = j + 1 + tid; i < N; i += 256) Lm[(size_t)i * N + j] *= inv;
+        if (tid == 0) Lm[(size_t)j * N + j] = d * inv;
+        __syncthreads();
+        const long long n = N - j - 1;
+        for (long long idx = tid; idx < n * n; idx += 256) {
+            const int i = j + 1 + (int)(idx / n), k = j + 1 + (int)(idx % n);
+            if (k <= i) Lm[(size_t)i * N + k] = fmaf(-Lm[(size_t)i * N + j], Lm[(size_t)k * N + j], Lm[(size_t)i * N + k]);
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < N; i += 256) {
+        float acc = 0.f;
+        for (int k = 0; k <= i; ++k) acc = fmaf(Lm[(size_t)i * N + k], zz[k], acc);
+        sample[((size_t)s * N + i) * R + r] = mean[((size_t)s * N + i) * R + r] + acc;
     }
 }
 
@@ -91,22 +137,46 @@ extern "C" size_t iwvi_gp_fullcov_ws_bytes(int64_t T, int M, int R) {
 }
 
 extern "C" int iwvi_gp_layer_fullcov(const void* state, int M, int D, int R, int kern_type, float variance,
-                                     const float* F, int64_t S, int64_t N, float* mean, float* cov,
-                                     void* ws, void* stream_) {
+                                     const float* F, int64_t S, int64_t N,
+                                     int mf_type, const float* mf_A, const float* mf_b,
+                                     float* mean, float* cov, void* ws, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (S <= 0 || N <= 0) return IWVI_OK;
     if (!state || !F || !cov || !ws) { set_error("iwvi_gp_layer_fullcov: null pointer"); return IWVI_ERR_ARG; }
-    if (N > 4096 || S > 0x7fffffffLL) { set_error("iwvi_gp_layer_fullcov: N=%lld > 4096 or S too large", (long long)N); return IWVI_ERR_ARG; }
+    if (N > 46340 || S > 0x7fffffffLL) { set_error("iwvi_gp_layer_fullcov: N=%lld > 46340 or S too large", (long long)N); return IWVI_ERR_ARG; }
     const int64_t T = S * N;
     const size_t Mp = (size_t)round_up(M, 16);
     float* a = (float*)ws;
     float* u = a + (size_t)T * Mp;
-    int rc = layer_forward_impl(state, M, D, R, R, kern_type, variance, F, nullptr, nullptr, IWVI_MF_ZERO,
-                                nullptr, nullptr, nullptr, mean, nullptr, a, u, T, 1, stream);
+    int rc = layer_forward_impl(state, M, D, R, R, kern_type, variance, F, nullptr, nullptr, mf_type,
+                                mf_A, mf_b, nullptr, mean, nullptr, a, u, T, 1, stream);
     if (rc != IWVI_OK) return rc;
     StateLayout sl = state_layout(M, R);
     const float* invls = (const float*)((const char*)state + sl.off_cst);
-    hipLaunchKernelGGL(k_fullcov, dim3((unsigned)S, (unsigned)R), dim3(256), 0, stream, F, invls,
+    hipLaunchKernelGGL(k_fullcov, dim3((unsigned)S, (unsigned)R, (unsigned)((N + FULLCOV_ROWS - 1) / FULLCOV_ROWS)), dim3(256), 0, stream, F, invls,
                        (const float*)a, (const float*)u, cov, (long long)S, (int)N, D, (int)Mp, R, kern_type, variance);
     return check_launch("k_fullcov");
+}
+
+extern "C" size_t iwvi_mvn_sample_ws_bytes(int64_t S, int N, int R) {
+    if (S <= 0 || N <= MVN_LDS_N || R <= 0) return 0;
+    return sizeof(float) * (size_t)S * R * ((size_t)N * N + N);
+}
+
+extern "C" int iwvi_mvn_sample(const float* mean, const float* cov, const float* z, float* sample,
+                               int64_t S, int N, int R, float jitter, void* ws, void* stream_) {
+    if (S <= 0 || N <= 0) return IWVI_OK;
+    if (!mean || !cov || !z || !sample) { set_error("iwvi_mvn_sample: null pointer"); return IWVI_ERR_ARG; }
+    if (N > 46340 || R <= 0 || R > 65535 || S > 0x7fffffffLL) { set_error("iwvi_mvn_sample: bad size (S=%lld N=%d R=%d)", (long long)S, N, R); return IWVI_ERR_ARG; }
+    if (N > MVN_LDS_N && !ws) { set_error("iwvi_mvn_sample: N=%d > %d needs the scratch of iwvi_mvn_sample_ws_bytes", N, MVN_LDS_N); return IWVI_ERR_ARG; }
+    const size_t lds = N > MVN_LDS_N ? 0 : sizeof(float) * ((size_t)N * N + N);
+    static bool attr_set = false;          // not a stream operation: once, outside any capture's steady state
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_mvn_sample, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) { set_error("iwvi_mvn_sample: hipFuncSetAttribute: %s", hipGetErrorString(e)); return IWVI_ERR_LAUNCH; }
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_mvn_sample, dim3((unsigned)S, (unsigned)R), dim3(256), lds, (hipStream_t)stream_,
+                       mean, cov, z, sample, N, R, jitter, N > MVN_LDS_N ? (float*)ws : (float*)nullptr);
+    return check_launch("k_mvn_sample");
 }

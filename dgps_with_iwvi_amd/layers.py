@@ -121,22 +121,18 @@ class GPLayer:
         return d, keep
 
     # -- reference API --------------------------------------------------------------------
-    def propagate(self, F, full_cov=False, z=None, _precomputed=False, _kl_parts=False, **kwargs):
-        """reference layers.py:35-50 -> (samples, mean, cov, kl)."""
+    def propagate(self, F, full_cov=False, z=None, _precomputed=False, _kl_parts=False, _want_sample=True, **kwargs):
+        """reference layers.py:35-50 -> (samples, mean, cov, kl).  ``_want_sample=False``: the caller does not consume this
+        layer's sample (the final layer of a predict call, models.py:89-91), so a full-covariance draw is skipped."""
         if not _precomputed:
             self.precompute()
-        plain_full = full_cov and not isinstance(self.kern, SharedMixedMok)
-        mf = None if plain_full else self.mean_function            # fused into the kernel epilogue
         samples, mean, cov = multisample_sample_conditional(
             F, self.feature, self.kern, self.q_mu, full_cov=full_cov, q_sqrt=self.q_sqrt, white=True,
-            z=z, state=self.state(), mean_function=mf, precomputed=True)
+            z=z, state=self.state(), mean_function=self.mean_function,      # layers.py:46-48 fused into the kernels
+            precomputed=True, want_sample=_want_sample)
         # layers.py:44 (computed by the precompute); _kl_parts hands the model the R per-GP shares
         # so that the ELBO reduction sums them without an extra launch
         kl = self.state().kl_parts if _kl_parts else self.kl
-        if plain_full and self.mean_function.mf_type != _abi.MF_ZERO:
-            m = self.mean_function
-            add = F if m.mf_type == _abi.MF_IDENTITY else F @ m.A + m.b
-            samples, mean = samples + add, mean + add              # layers.py:46-48
         return samples, mean, cov, kl
 
 

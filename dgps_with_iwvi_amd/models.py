@@ -15,6 +15,10 @@ Differences from the reference, all documented in DESIGN.md:
   * the IW path asks the final layer for marginal variances only (``full_cov_over_samples=False``):
     the reference builds the [B, Dy, K, K] covariance and keeps its diagonal (models.py:129-133),
     the result is identical; set the flag to follow the reference literally (layer-by-layer launches).
+    Inner layers: a SharedMixedMok layer samples marginally in the reference too (temp_workaround.py:125-129), so the
+    fused launch is exact for the benchmark family; an inner GPLayer with a PLAIN kernel draws its K samples per point
+    jointly there (:149-155, full_cov=True) -- such a model is detected (``_joint_over_samples``) and evaluated along
+    the literal layer-by-layer path, never with marginal draws.
 """
 import ctypes
 
@@ -40,6 +44,7 @@ class DGP_VI:
         self.minibatch_size = minibatch_size
         self._mb_rng = np.random.RandomState(0)                       # Minibatch(seed=0), models.py:25-26
         self._mb_perm, self._mb_pos = None, 0
+        self._mb_serial = 0                                           # bumped by every minibatch change: cache key
         self.X, self.Y = self._X_all, self._Y_all
         if minibatch_size is not None:
             self.next_minibatch()
@@ -57,17 +62,20 @@ class DGP_VI:
         """Advance to the next minibatch (shuffled epochs, X and Y aligned like gpflow.Minibatch)."""
         if self.minibatch_size is None:
             return
-        n, b = self.num_data, min(self.minibatch_size, self.num_data)
+        n = self._X_all.shape[0]          # the rows THIS model holds (num_data may be the job total of a data-parallel run)
+        b = min(self.minibatch_size, n)
         if self._mb_perm is None or self._mb_pos + b > n:
             self._mb_perm = torch.as_tensor(self._mb_rng.permutation(n), device=self._X_all.device)
             self._mb_pos = 0
         idx = self._mb_perm[self._mb_pos:self._mb_pos + b]
         self._mb_pos += b
         self.X, self.Y = self._X_all[idx].contiguous(), self._Y_all[idx].contiguous()
+        self._mb_serial += 1         # the caching allocator reuses addresses: pointers alone cannot key the per-minibatch caches
 
     def to(self, device):
         self._X_all, self._Y_all = self._X_all.to(device), self._Y_all.to(device)
         self.X, self.Y = self.X.to(device), self.Y.to(device)
+        self._mb_serial += 1
         for layer in self.layers:
             layer.to(device)
         return self
@@ -105,19 +113,21 @@ class DGP_VI:
         precompute_states(descs, encs)
 
     def propagate(self, X, full_cov=False, inference_amorization_inputs=None,
-                  is_sampled_local_regularizer=False, zs=None, _precomputed=False, _kl_parts=False):
-        """reference models.py:31-46 -> (samples[1:], means, covs, kls, kl_types); one launch per layer."""
+                  is_sampled_local_regularizer=False, zs=None, _precomputed=False, _kl_parts=False, _last_sample=True):
+        """reference models.py:31-46 -> (samples[1:], means, covs, kls, kl_types); one launch per layer.
+        ``_last_sample=False``: the final layer's sample is not needed (None is returned in its place)."""
         if not _precomputed:
             self.precompute()
         samples, means, covs, kls, kl_types = [X, ], [], [], [], []
         zs = [None] * len(self.layers) if zs is None else zs
         if len(zs) != len(self.layers):
             raise ValueError("zs needs one entry per layer")
-        for layer, z in zip(self.layers, zs):
+        for i, (layer, z) in enumerate(zip(self.layers, zs)):
             sample, mean, cov, kl = layer.propagate(samples[-1], full_cov=full_cov,
                                                     inference_amorization_inputs=inference_amorization_inputs,
                                                     is_sampled_local_regularizer=is_sampled_local_regularizer,
-                                                    z=z, _precomputed=True, _kl_parts=_kl_parts)
+                                                    z=z, _precomputed=True, _kl_parts=_kl_parts,
+                                                    _want_sample=_last_sample or i + 1 < len(self.layers))
             samples.append(sample)
             means.append(mean)
             covs.append(cov)
@@ -229,11 +239,15 @@ class DGP_VI:
         return logw, outs, red
 
     def _mb_key(self):
-        return (self.X.data_ptr(), self.Y.data_ptr(), self.X.shape[0])
+        return (self._mb_serial, self.X.data_ptr(), self.Y.data_ptr(), self.X.shape[0])
+
+    def invalidate_minibatch_caches(self):
+        """Call after changing ``model.X`` / ``model.Y`` IN PLACE (the [x, y] rows and encoder outputs are cached per minibatch)."""
+        self._mb_serial += 1
 
     def _xy_minibatch(self):
         """[x_b, y_b] rows of the current minibatch (models.py:53 / :116 before tiling), cached per minibatch."""
-        key = (self.X.data_ptr(), self.Y.data_ptr(), self.X.shape[0])
+        key = self._mb_key()
         if getattr(self, "_xy_key", None) != key:
             self._xy_cache, self._xy_key = torch.cat([self.X, self.Y], -1).contiguous(), key
         return self._xy_cache
@@ -297,7 +311,7 @@ class DGP_VI:
     likelihood_tensor = property(lambda self: self._build_likelihood())
 
     def _build_predict(self, X, full_cov=False, zs=None):
-        _, means, covs, _, _ = self.propagate(X, full_cov=full_cov, zs=zs)   # :89-91
+        _, means, covs, _, _ = self.propagate(X, full_cov=full_cov, zs=zs, _last_sample=False)   # :89-91
         return means[-1], covs[-1]
 
     def predict_f(self, X, zs=None):
@@ -322,18 +336,27 @@ class DGP_VI:
 
 
 class DGP_IWVI(DGP_VI):
-    def _forward_iw(self, zs=None):
+    def _joint_over_samples(self):
+        """True when some non-final GPLayer has a plain kernel and K > 1: the reference then samples that layer with the
+        full [K, K] covariance over the importance samples (models.py:122-125 -> temp_workaround.py:149-155), which the
+        fused marginal-sampling launch does not reproduce."""
+        return self.num_samples > 1 and any(isinstance(l, GPLayer) and not hasattr(l.kern, "W") for l in self.layers[:-1])
+
+    def _literal(self):
+        return self.full_cov_over_samples or self._joint_over_samples()
+
+    def _forward_iw(self, zs=None, _last_sample=True):
         """models.py:113-133 with every per-layer output exposed (tests / API parity).  Default: one fused
         launch, marginal variances everywhere.  With ``full_cov_over_samples`` the reference is followed
         literally (explicit tiling, full_cov=True, matrix_diag_part of the [B, Dy, K, K] covariance)."""
         B, K = self.X.shape[0], self.num_samples
-        if self.full_cov_over_samples:
+        if self._literal():
             X_tiled = self.X[:, None, :].expand(B, K, self.X.shape[1]).contiguous()     # :113
             Y_tiled = self.Y[:, None, :].expand(B, K, self.Y.shape[1]).contiguous()     # :114
             XY = torch.cat([X_tiled, Y_tiled], -1)                                       # :116
             samples, means, covs, kls, kl_types = self.propagate(
                 X_tiled, full_cov=True, inference_amorization_inputs=XY,
-                is_sampled_local_regularizer=True, zs=zs, _kl_parts=True)                # :122-125
+                is_sampled_local_regularizer=True, zs=zs, _kl_parts=True, _last_sample=_last_sample)   # :122-125
             local_kls = [kl for kl, t in zip(kls, kl_types) if t is RegularizerType.LOCAL]
             global_kls = [kl for kl, t in zip(kls, kl_types) if t is RegularizerType.GLOBAL]
             cov = covs[-1]
@@ -349,15 +372,15 @@ class DGP_IWVI(DGP_VI):
     def _logw(self, zs=None):
         """Per-sample log-weights L_NK [B*K] (models.py:134-142) and the global KL shares."""
         B, K = self.X.shape[0], self.num_samples
-        if self.full_cov_over_samples:
+        if self._literal():
             return None
         self.precompute(with_encoders=True)
         return self._fused_forward(B * K, K, B, (B, K), zs=zs, sampled_kl=True)[0]
 
     def _elbo_parts(self, zs=None, want_ms=False, K_total=None, ms_out=None, elbo_out=None):
         B, K = self.X.shape[0], self.num_samples
-        if self.full_cov_over_samples:                               # literal reference path, layer by layer
-            fmean, fvar, local_kls, global_kls, _, _, _ = self._forward_iw(zs)
+        if self._literal():                                          # literal reference path, layer by layer
+            fmean, fvar, local_kls, global_kls, _, _, _ = self._forward_iw(zs, _last_sample=False)
             return self._reduce(fmean, fvar, self.Y, local_kls, global_kls, B, K, stride_b=K, stride_k=1,
                                 mode_vi=False, want_ms=want_ms, K_total=K_total)
         el = dict(B=B, K=K, stride_b=K, stride_k=1, mode_vi=False, want_ms=want_ms, K_total=K_total,

@@ -184,6 +184,38 @@ def allreduce_gradients(grads, weight=None, group=None):
     return grads
 
 
+def resolve_n_shard(model, group=None, num_data_total=None):
+    """N-shard bookkeeping, once, at trainer construction.  The reference scales the data term by ``num_data / B``
+    with ``num_data = X.shape[0]`` (models.py:18,80-81); a rank built from ITS OWN rows of the data set therefore holds
+    a local ``num_data`` and would weigh the likelihood 1 / world too lightly against the KL terms after the
+    1 / world gradient average.  This sets ``model.num_data`` to the job total -- ``num_data_total`` if given, else the
+    all-reduced sum of the ranks' row counts when ``model.num_data`` still is the constructor's default (the local row
+    count), else the value the caller set, which must then agree on every rank -- and returns
+    ``(num_data_total, weight)`` with weight = B_rank / B_job for ``allreduce_gradients``."""
+    world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+    rows = int(model._X_all.shape[0])
+    B = int(model.X.shape[0])
+    if world == 1:
+        if num_data_total is not None:
+            model.num_data = int(num_data_total)
+        return int(model.num_data), 1.0
+    dev = model._X_all.device if dist.get_backend(group) != "gloo" else torch.device("cpu")
+    v = torch.tensor([rows, B, int(model.num_data), -int(model.num_data)], dtype=torch.int64, device=dev)
+    tot = v.clone()
+    dist.all_reduce(tot, op=dist.ReduceOp.SUM, group=group)
+    mx = v.clone()
+    dist.all_reduce(mx, op=dist.ReduceOp.MAX, group=group)
+    if num_data_total is None:
+        if int(model.num_data) == rows:                       # untouched default: local rows -> the job's rows
+            num_data_total = int(tot[0])
+        else:                                                 # set by the caller: it has to be the same number everywhere
+            if int(mx[2]) != -int(mx[3]):
+                raise ValueError("model.num_data differs between ranks (%d..%d): pass num_data_total" % (-int(mx[3]), int(mx[2])))
+            num_data_total = int(model.num_data)
+    model.num_data = int(num_data_total)
+    return int(num_data_total), float(B) / float(int(tot[1]))
+
+
 def lse_from_pairs(ms_all):
     """Gathered (max, sum exp) pairs [G, B, 2] -> logsumexp over all the job's samples [B] (not yet minus log K)."""
     m = ms_all[..., 0].max(0).values

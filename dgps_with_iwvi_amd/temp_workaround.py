@@ -10,7 +10,8 @@ Reference -> here
 Deviations (all documented in DESIGN.md):
   * noise is an explicit optional argument ``z`` (the reference draws tf.random_normal inside the graph);
     z=None draws from the library's Philox stream;
-  * ``white=False`` (never used by GPLayer, layers.py:42) raises NotImplementedError;
+  * ``white=False`` (:63-65; never used by GPLayer, layers.py:42): the second back-substitution is applied once to
+    the operands -- f_w = Lm^-1 f, q_sqrt_w = Lm^-1 tril(q_sqrt) (``iwvi_unwhiten``) -- instead of per sample;
   * the full-covariance sample follows the intended ``fmean_SRN1 + chol(fvar) z`` (the reference's
     line :95 has a broadcasting bug, SURVEY.md section 3.3);
   * float32 per-sample arithmetic with a float64 factorisation; variances are clamped at 0.
@@ -167,28 +168,50 @@ def _forward_diag(state, kern, D, R, F2, z2, W, mean_function, want=(True, True,
     return outs
 
 
-def _check_common(Xnew, full_output_cov, white):
+def _check_common(Xnew, full_output_cov, white, precomputed=False):
     if full_output_cov:
         raise NotImplementedError                              # reference :36-37
-    if not white:
-        raise NotImplementedError("only the whitened representation is on the hot path (layers.py:42)")
+    if not white and precomputed:
+        raise ValueError("a precomputed state holds whitened operands; white=False needs precomputed=False")
     if Xnew.dim() not in (2, 3):
         raise ValueError("Xnew must be [N, D] or [S, N, D]")
 
 
+def _factorise(state, Z, kern, f, q_sqrt, white):
+    """Fill ``state`` for q(u) = (f, q_sqrt).  white=False (reference :63-65): the extra solve with Lm^T is folded
+    into the operands once -- f_w = Lm^-1 f, q_sqrt_w[r] = Lm^-1 tril(q_sqrt[r]) -- and the whitened kernels run unchanged."""
+    Z = _abi.dev_tensor(Z, "Z")
+    q3 = _abi.dev_tensor(_prep_q_sqrt(q_sqrt, f), "q_sqrt")
+    d = state.desc(Z, kern, f, q3, settings.jitter_level)
+    if white:
+        precompute_states([d])
+        return
+    d.flags = _abi.GP_WANT_DENSE
+    precompute_states([d])
+    M, R = f.shape
+    f_w, q_w = torch.empty_like(f), torch.empty_like(q3)
+    _abi.check(_abi.lib().iwvi_unwhiten(_abi.ptr(state.buf), M, R, _abi.ptr(f), _abi.ptr(q3) if q_sqrt is not None else None,
+                                        _abi.ptr(f_w), _abi.ptr(q_w) if q_sqrt is not None else None, _abi.stream_ptr()))
+    if q_sqrt is None:
+        q_w.zero_()
+    precompute_states([state.desc(Z, kern, f_w, q_w, settings.jitter_level)])
+
+
 def independent_multisample_sample_conditional(Xnew, feat, kern, f, *, full_cov=False, full_output_cov=False,
                                                q_sqrt=None, white=False, z=None, state=None,
-                                               mean_function=None, precomputed=False):
+                                               mean_function=None, precomputed=False, want_sample=True):
     """Multisample, single-output GP conditional (reference temp_workaround.py:12-98).
 
     :param Xnew: [S, N, D] (also accepts [N, D], the 2-D ``sample_conditional`` path of :157-161)
-    :param f: [M, R];  q_sqrt: [R, M, M], [M, R] or None;  white must be True
+    :param f: [M, R];  q_sqrt: [R, M, M], [M, R] or None;  white: whitened representation of q(u) or not
     :return: sample [S,N,R], mean [S,N,R], var [S,N,R] (full_cov=False) or [S,R,N,N] (full_cov=True);
              for 2-D input: [N,R], [N,R], [N,R] | [R,N,N].
     ``state``/``precomputed``/``mean_function`` are used by GPLayer to reuse the per-step factorisation
-    and to fuse the mean-function add; plain callers leave them at their defaults.
+    and to fuse the mean-function add; plain callers leave them at their defaults.  ``want_sample=False`` (full_cov
+    only) returns None for the sample: a TF graph never evaluates an unfetched sample (models.py:89-91 fetches the
+    final mean and covariance only), an eager library has to be told.
     """
-    _check_common(Xnew, full_output_cov, white)
+    _check_common(Xnew, full_output_cov, white, precomputed)
     if not isinstance(kern, Stationary):
         raise TypeError("kern must be a stationary kernel (RBF / Matern52)")
     Z = _unwrap_feat(feat)
@@ -201,8 +224,7 @@ def independent_multisample_sample_conditional(Xnew, feat, kern, f, *, full_cov=
     if state is None:
         state = GpState(M, R, Xnew.device)
     if not precomputed:
-        precompute_states([state.desc(_abi.dev_tensor(Z, "Z"), kern, f, _abi.dev_tensor(_prep_q_sqrt(q_sqrt, f), "q_sqrt"),
-                                      settings.jitter_level)])
+        _factorise(state, Z, kern, f, q_sqrt, white)
     lead = Xnew.shape[:-1]
     F2 = Xnew.reshape(-1, D)
     T = F2.shape[0]
@@ -215,17 +237,29 @@ def independent_multisample_sample_conditional(Xnew, feat, kern, f, *, full_cov=
     mean = torch.empty(S, N, R, dtype=settings.float_type, device=Xnew.device)
     cov = torch.empty(S, R, N, N, dtype=settings.float_type, device=Xnew.device)
     ws = torch.empty(_abi.lib().iwvi_gp_fullcov_ws_bytes(T, M, R), dtype=torch.uint8, device=Xnew.device)
+    mf_type, mfA, mfb = _abi.MF_ZERO, None, None
+    if mean_function is not None:                              # layers.py:46-48, fused: the sample below inherits it
+        mf_type, mfA, mfb = mean_function.mf_type, mean_function.A, mean_function.b
+        if mf_type == _abi.MF_LINEAR and tuple(mfA.shape) != (D, R):
+            raise ValueError("Linear mean function A is %s, layer needs (%d, %d)" % (tuple(mfA.shape), D, R))
+        if mf_type == _abi.MF_IDENTITY and D != R:
+            raise ValueError("Identity mean function needs D == R")
     _abi.check(_abi.lib().iwvi_gp_layer_fullcov(_abi.ptr(state.buf), M, D, R, kern.kern_type, kern.variance,
-                                               _abi.ptr(F2), S, N, _abi.ptr(mean), _abi.ptr(cov),
-                                               _abi.ptr(ws), _abi.stream_ptr()))
+                                               _abi.ptr(F2), S, N, mf_type, _abi.ptr(mfA), _abi.ptr(mfb),
+                                               _abi.ptr(mean), _abi.ptr(cov), _abi.ptr(ws), _abi.stream_ptr()))
+    if not want_sample:
+        return (None, mean[0], cov[0]) if Xnew.dim() == 2 else (None, mean, cov)
     zz = draw_normal((S, R, N, 1), Xnew.device) if z is None else _abi.dev_tensor(z.reshape(S, R, N, 1).contiguous(), "z")
-    # K11 (dead code for the ELBO: the final layer's sample is never consumed, models.py:122-134).
-    # cholesky_ex does not throw on a singular block (X tiled over K gives rank-1 blocks); like the TF
-    # graph, a failed factorisation only poisons this never-fetched sample.
-    chol, _ = torch.linalg.cholesky_ex(cov)
-    sample = (mean.transpose(1, 2).unsqueeze(-1) + chol @ zz)[..., 0].transpose(1, 2)
-    if mean_function is not None and mean_function.mf_type != _abi.MF_ZERO:
-        raise NotImplementedError("full_cov with a fused mean function: add it in the caller")
+    # K11: the jointly Gaussian sample (:93-96).  For the FINAL layer this is dead code for the ELBO (its sample is never
+    # consumed, models.py:122-134) and the block may be singular (X tiled over K gives rank-1 blocks): like the TF graph,
+    # a failed factorisation only poisons this sample (NaN), not the mean / covariance.  The 2-D gpflow path adds jitter
+    # inside its _sample_mvn, the 3-D path of this file (:94-95) does not.
+    sample = torch.empty(S, N, R, dtype=settings.float_type, device=Xnew.device)
+    nws = _abi.lib().iwvi_mvn_sample_ws_bytes(S, N, R)
+    ws2 = torch.empty(nws, dtype=torch.uint8, device=Xnew.device) if nws else None
+    _abi.check(_abi.lib().iwvi_mvn_sample(_abi.ptr(mean), _abi.ptr(cov), _abi.ptr(zz), _abi.ptr(sample), S, N, R,
+                                          settings.jitter_level if Xnew.dim() == 2 else 0.0, _abi.ptr(ws2),
+                                          _abi.stream_ptr()))
     if Xnew.dim() == 2:
         return sample[0], mean[0], cov[0]
     return sample, mean, cov
@@ -233,10 +267,10 @@ def independent_multisample_sample_conditional(Xnew, feat, kern, f, *, full_cov=
 
 def multisample_sample_conditional(Xnew, feat, kern, f, *, full_cov=False, full_output_cov=False,
                                    q_sqrt=None, white=False, z=None, state=None, mean_function=None,
-                                   precomputed=False):
+                                   precomputed=False, want_sample=True):
     """Dispatcher of reference temp_workaround.py:118-161."""
     if isinstance(kern, SharedMixedMok) and isinstance(feat, MixedKernelSharedMof):      # :123
-        _check_common(Xnew, False, white)
+        _check_common(Xnew, False, white, precomputed)
         base, Z = kern.kernel, _unwrap_feat(feat.feat)
         Xnew = _abi.dev_tensor(Xnew.contiguous(), "Xnew")
         f = _abi.dev_tensor(f.contiguous(), "f")
@@ -248,8 +282,7 @@ def multisample_sample_conditional(Xnew, feat, kern, f, *, full_cov=False, full_
         if state is None:
             state = GpState(M, R, Xnew.device)
         if not precomputed:
-            precompute_states([state.desc(_abi.dev_tensor(Z, "Z"), base, f,
-                                          _abi.dev_tensor(_prep_q_sqrt(q_sqrt, f), "q_sqrt"), settings.jitter_level)])
+            _factorise(state, Z, base, f, q_sqrt, white)
         lead = Xnew.shape[:-1]
         F2 = Xnew.reshape(-1, D)
         T = F2.shape[0]
@@ -261,7 +294,7 @@ def multisample_sample_conditional(Xnew, feat, kern, f, *, full_cov=False, full_
     assert not isinstance(kern, SharedMixedMok)                                          # :149
     return independent_multisample_sample_conditional(
         Xnew, feat, kern, f, full_cov=full_cov, full_output_cov=full_output_cov, q_sqrt=q_sqrt,
-        white=white, z=z, state=state, mean_function=mean_function, precomputed=precomputed)
+        white=white, z=z, state=state, mean_function=mean_function, precomputed=precomputed, want_sample=want_sample)
 
 
 def gauss_kl(q_mu, q_sqrt, K=None):

@@ -25,15 +25,25 @@ def staircase_decay(base, step, rate, every=1000):
 
 class Trainer:
     def __init__(self, model, lr=5e-3, gamma=1e-2, lr_decay=0.98, gamma_decay=0.98, fix_linear=True,
-                 beta1=0.9, beta2=0.999, epsilon=1e-8, group=None, shard_weight=None, shard="n"):
+                 beta1=0.9, beta2=0.999, epsilon=1e-8, group=None, shard_weight=None, shard="n", num_data_total=None):
         """``group`` / ``shard_weight``: data-parallel training over the ranks of a torch.distributed group (each rank's
         model holds its own minibatch rows, N-shard): gradients are merged by ``sharding.allreduce_gradients`` with
-        weight B_rank / B_job (default 1 / world) before either update, so every rank applies the same step.  (Give every
-        rank its own rows of the data set: the minibatch iterator is seeded identically everywhere, models.py:25-26.)
+        weight B_rank / B_job (default: from the all-reduced local batch sizes) before either update, so every rank
+        applies the same step.  Give every rank its own rows of the data set (the minibatch iterator is seeded identically
+        everywhere, models.py:25-26); the data term must still be scaled by the JOB's ``num_data`` (models.py:18,80-81), so
+        ``model.num_data`` is set to ``num_data_total`` -- by default the sum of the ranks' row counts
+        (``sharding.resolve_n_shard``).
         ``shard="k"``: every rank holds all the points and its own share of the importance samples instead
         (``sharding.k_shard_gradients``: one all-gather of the per-point pairs + one gradient all-reduce)."""
         self.model = model
         self.group, self.shard_weight, self.shard = group, shard_weight, shard
+        if shard == "n" and (group is not None or num_data_total is not None):
+            from .sharding import resolve_n_shard
+            _, w = resolve_n_shard(model, group, num_data_total)
+            if self.shard_weight is None:
+                self.shard_weight = w
+        elif num_data_total is not None:
+            model.num_data = int(num_data_total)
         self.lr, self.gamma, self.lr_decay, self.gamma_decay = lr, gamma, lr_decay, gamma_decay
         self.betas, self.epsilon = (beta1, beta2), epsilon
         self.global_step = 0

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define IWVI_ABI_VERSION 4
+#define IWVI_ABI_VERSION 5
 
 enum {
     IWVI_OK = 0,
@@ -153,13 +153,24 @@ int iwvi_gp_layer_forward(const void* state, int M, int D, int R, int P,
                           int64_t T, int bcast_K, void* stream);
 
 /* Full covariance over the second axis (temp_workaround.py:45,56,83 with full_cov=True):
- *   F [S, N, D] -> mean [S, N, R], cov [S, R, N, N].
+ *   F [S, N, D] -> mean [S, N, R] (+ the layer's mean function, layers.py:46-48: mf_type / mf_A [D, R] / mf_b [R] as
+ *   iwvi_gp_layer_forward), cov [S, R, N, N].
  * ws: iwvi_gp_fullcov_ws_bytes(S*N, M, R) bytes of scratch (A and LTA, as the reference
  * materialises them). Plain kernels only (the SharedMixedMok branch forces full_cov=False). */
 size_t iwvi_gp_fullcov_ws_bytes(int64_t T, int M, int R);
 int iwvi_gp_layer_fullcov(const void* state, int M, int D, int R, int kern_type, float variance,
                           const float* F, int64_t S, int64_t N,
+                          int mf_type, const float* mf_A, const float* mf_b,
                           float* mean, float* cov, void* ws, void* stream);
+
+/* The jointly Gaussian sample of the full-covariance branch (temp_workaround.py:93-96, with the intended
+ * fmean_SRN1 of :95):  sample[s, n, r] = mean[s, n, r] + (chol(cov[s, r] + jitter I) z[s, r])[n].
+ * mean, sample [S, N, R]; cov [S, R, N, N]; z [S, R, N].  N <= 192 (N is the importance-sample axis on the IW path)
+ * factorises in LDS; larger N needs ws = iwvi_mvn_sample_ws_bytes(S, N, R) bytes of scratch (0 for N <= 192) and is
+ * latency-bound.  A non-positive pivot gives NaN for that block's sample (a failed tf.cholesky), nothing else is touched. */
+size_t iwvi_mvn_sample_ws_bytes(int64_t S, int N, int R);
+int iwvi_mvn_sample(const float* mean, const float* cov, const float* z, float* sample,
+                    int64_t S, int N, int R, float jitter, void* ws, void* stream);
 
 /* ------------------------------------------------------------------------
  * The whole layer stack of DGP_VI.propagate (models.py:31-46) for a flattened sample batch in ONE
@@ -394,6 +405,22 @@ int iwvi_lse_merge_steps(const float* ms_all, int G, int n_steps, int64_t B, int
 
 /* whitened gauss_kl alone (temp_workaround.py:186-188), K14: -> kl [1] double */
 int iwvi_gauss_kl(const float* q_mu, const float* q_sqrt, int M, int R, double* kl, void* stream);
+
+/* gpflow Gaussian.variational_expectations as a callable (the reference calls it on explicit moments,
+ * models.py:66,134):  out[t, d] = -1/2 log 2pi - 1/2 log s2 - 1/2 ((Y[row(t), d] - Fmu[t, d])^2 + Fvar[t, d]) / s2,
+ * row(t) = (t / row_div) % row_mod (the tilings of iwvi_dgp_forward; Y already tiled: row_div = 1, row_mod = T).
+ * Fmu, Fvar, out [T, Dy].  (The hot path never calls this: the expectation is fused into iwvi_dgp_forward's tail.) */
+int iwvi_gaussian_var_exp(const float* Fmu, const float* Fvar, const float* Y, float lik_variance,
+                          int64_t T, int Dy, int64_t row_div, int64_t row_mod, float* out, void* stream);
+
+/* white=False (temp_workaround.py:63-65: "another backsubstitution in the unwhitened case").  The unwhitened
+ * q(u) = N(f, q_sqrt q_sqrt^T) gives the same conditional as the whitened one with f_w = Lm^-1 f and
+ * q_sqrt_w[r] = Lm^-1 tril(q_sqrt[r]) (lower triangular again), so the back-substitution is applied ONCE to the
+ * operands (float64 accumulate) instead of per sample; the caller then runs iwvi_gp_precompute on (f_w, q_sqrt_w).
+ * state: precomputed WITH IWVI_GP_WANT_DENSE for the same (M, R) (the dense Lm^-1 is read);
+ * f [M, R], q_sqrt [R, M, M] or NULL -> f_w [M, R], q_sqrt_w [R, M, M]. */
+int iwvi_unwhiten(const void* state, int M, int R, const float* f, const float* q_sqrt,
+                  float* f_w, float* q_sqrt_w, void* stream);
 
 /* counter-based N(0,1) fill (Philox4x32-10 + Box-Muller); stream documented in DESIGN.md */
 int iwvi_fill_normal(float* out, int64_t n, uint64_t seed, uint64_t offset, void* stream);

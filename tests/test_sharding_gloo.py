@@ -73,6 +73,69 @@ def _grad_worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
+class _LocalRows:
+    """What ``sharding.resolve_n_shard`` reads of a model: a rank built from ITS OWN rows (models.py:18: num_data = X.shape[0])."""
+
+    def __init__(self, X, B):
+        self._X_all = torch.as_tensor(X)
+        self.X = self._X_all[:B]
+        self.num_data = self._X_all.shape[0]
+
+
+def _num_data_worker(rank, world, port, q):
+    """every rank constructs its model from its own rows; the job's data-term scale must still be N_total / B.
+    resolve_n_shard fixes model.num_data and the gradient weight; the merged oracle gradient equals the unsharded one."""
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle.grad_oracle import iw_elbo_and_gradients
+        n_tot, rows = 30, [(0, 18), (18, 30)][rank]                 # uneven row counts AND uneven minibatches
+        Bs = [6, 4]
+        spec = synthetic.make_spec(L=2, M=12, B=10, K=3, Dx=3, R=2, with_lv=True, seed=51, n_data=n_tot)
+        zs = synthetic.make_noise(spec, seed=52)
+        # the job's minibatch = rank 0's first 6 local rows + rank 1's first 4 local rows
+        pick = np.r_[0:6, 18:22]
+        job = dict(spec, X=spec["X"][pick], Y=spec["Y"][pick])
+        _, ref = iw_elbo_and_gradients(job, zs)
+        fake = _LocalRows(spec["X"][rows[0]:rows[1]], Bs[rank])
+        assert fake.num_data == rows[1] - rows[0]
+        total, w = sharding.resolve_n_shard(fake)
+        assert total == n_tot and fake.num_data == n_tot and abs(w - Bs[rank] / 10.0) < 1e-15
+        lo = 0 if rank == 0 else 6
+        sub = dict(spec, X=spec["X"][rows[0]:rows[0] + Bs[rank]], Y=spec["Y"][rows[0]:rows[0] + Bs[rank]], B=Bs[rank],
+                   n_data=fake.num_data)
+        _, g = iw_elbo_and_gradients(sub, [z[lo:lo + Bs[rank]] for z in zs])
+        g = sharding.allreduce_gradients({k: torch.tensor(np.asarray(v)) for k, v in g.items()}, weight=w)
+        err = max(float(np.abs(g[k].numpy() - ref[k]).max() / max(np.abs(ref[k]).max(), 1e-12)) for k in ref)
+        # a caller-set num_data that disagrees between ranks is an error, an agreeing one is kept
+        fake2 = _LocalRows(spec["X"][rows[0]:rows[1]], Bs[rank]); fake2.num_data = 1000 + rank
+        try:
+            sharding.resolve_n_shard(fake2)
+            bad = False
+        except ValueError:
+            bad = True
+        fake3 = _LocalRows(spec["X"][rows[0]:rows[1]], Bs[rank]); fake3.num_data = 4096
+        ok3 = sharding.resolve_n_shard(fake3)[0] == 4096
+        q.put((rank, err, bad and ok3))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_ranks_built_from_local_rows_get_the_job_num_data():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_num_data_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, err, flags in res:
+        assert err <= 1e-10 and flags, (rank, err, flags)
+
+
 def _kgrad_worker(rank, world, port, q):
     """K-shard training: each rank's share of the gradient -- autodiff of sum_n sum_{k in rank} sg(exp(L_nk - LSE_n)) L_nk * scale
     - KL / world on the float64 restatement, LSE from sharding.lse_from_pairs on the all-gathered pairs -- summed by
