@@ -71,13 +71,14 @@ class Step:
         self.B, self.K = spec["B"], spec["K"]
         self.out = torch.zeros(1, dtype=torch.float64, device=dev)
 
-    def run(self, out=None):
-        """``out``: the exchange staging buffer this evaluation's result goes to ([B, 2] pairs / 1-element ELBO)."""
+    def run(self, out=None, zs=None):
+        """``out``: the exchange staging buffer this evaluation's result goes to ([B, 2] pairs / 1-element ELBO);
+        ``zs``: injected noise (the --check leg), None = drawn on the device."""
         m = self.model
         if self.shard == "k" and self.exchange:
-            self.ms, self.glob = m.lse_partials(K_total=self.K * self.world, out=out)
+            self.ms, self.glob = m.lse_partials(zs, K_total=self.K * self.world, out=out)
             return self.ms
-        self.out = m._build_likelihood(out=out)
+        self.out = m._build_likelihood(zs, out=out)
         return self.out
 
 
@@ -107,8 +108,9 @@ def training_leg(model, samples, iters=20):
         return {"error": "%s: %s" % (type(e).__name__, e)}
 
 
-def cpu_baseline(spec, seconds=12.0):
-    """The reference-equivalent CPU path (oracle/ref_torch_cpu.py, float64 like the reference) timed on
+def cpu_baseline(spec, seconds=12.0, dtype=torch.float64):
+    """The reference-equivalent CPU path (oracle/ref_torch_cpu.py; float64 like the reference, and float32 = the
+    precision the device path computes in) timed on
     this host's cores on the SAME workload; bounded to ~`seconds` of CPU work.  The thread count is the
     best of {all hardware threads, 1/2, 1/4 of them, 32, 16, 8, 4}: oversubscribing small
     batched matmuls with 256 threads is slower than fewer threads, and the baseline should be the host's best."""
@@ -116,7 +118,7 @@ def cpu_baseline(spec, seconds=12.0):
     from oracle.ref_torch_cpu import CpuDGP
     ncpu = os.cpu_count() or 1
     zs = synthetic.make_noise(spec, seed=1)
-    m = CpuDGP(spec, torch.float64)
+    m = CpuDGP(spec, dtype)
     best = None
     for nt in sorted({ncpu, max(1, ncpu // 2), max(1, ncpu // 4), min(32, ncpu), min(16, ncpu), min(8, ncpu), min(4, ncpu)}, reverse=True):
         torch.set_num_threads(nt)
@@ -136,9 +138,10 @@ def cpu_baseline(spec, seconds=12.0):
         times.append(time.perf_counter() - t0)
     med = float(np.median(times))
     return dict(value=spec["B"] * spec["K"] / med, unit="samples/s", cores=nt, kind="port",
-                sample="%d full IW-ELBO evaluations of the same workload (B=%d, K=%d), float64 torch-CPU/MKL "
+                sample="%d full IW-ELBO evaluations of the same workload (B=%d, K=%d), %s torch-CPU/MKL "
                        "restatement of the reference op sequence (materialised Kmn, A, LTA, full K x K final "
-                       "covariance), %d threads of %d, median" % (iters, spec["B"], spec["K"], nt, ncpu),
+                       "covariance), %d threads of %d, median" % (iters, spec["B"], spec["K"],
+                                                                  "float64" if dtype == torch.float64 else "float32", nt, ncpu),
                 ms_per_step=med * 1e3)
 
 
@@ -153,6 +156,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-train-leg", action="store_true", help="skip the (informational) training-step timing")
+    ap.add_argument("--check", action="store_true",
+                    help="after the timed region: one evaluation on INJECTED job-wide noise through the very same sharded path "
+                         "(graph-free), and on rank 0 the unsharded evaluation of the whole job on the same noise; both go into the JSON")
+    ap.add_argument("--median-iters", type=int, default=60, help="hipEvent-timed single-evaluation replays for ms_per_step_median")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -283,6 +290,62 @@ def main():
         elapsed = float(tmax.item())
     final_elbo = float((xch.finish()[-1] if xch is not None else step.out.reshape(1)).item())
 
+    # ---- --check: the sharded path against the unsharded job on injected noise (multi-rank correctness, no timing) ----------
+    check = None
+    if args.check:
+        Kt = K * (world if args.shard == "k" else 1)
+        Bt = B * (world if args.shard == "n" else 1)
+        job_spec = synthetic.make_spec(seed=0, parity=True, n_data=65536, **dict(cfg, K=Kt, B=Bt))
+        zjob = synthetic.make_noise(job_spec, seed=123, K=Kt, B=Bt)
+        if args.shard == "k":
+            zloc = [z[:, rank * K:(rank + 1) * K] for z in zjob]
+        else:
+            zloc = [z[rank * B:(rank + 1) * B] for z in zjob]
+        zloc = [torch.as_tensor(np.ascontiguousarray(z), dtype=torch.float32, device=dev) for z in zloc]
+        if xch is not None:
+            slot = xch.before_step()
+            views = xch.slot_views(slot)
+            for view in views:                                   # every evaluation of the slot on the same noise
+                step.run(out=view, zs=zloc)
+            xch.submit(global_kls=getattr(step, "glob", None))
+            got = [float(v) for v in xch.finish().tolist()]
+        else:
+            got = [float(step.run(zs=zloc).reshape(1).item())]
+        fence()
+        check = {"sharded_elbo": got[0], "all_steps_equal": all(g == got[0] for g in got), "K_total": Kt, "B_total": Bt}
+        if rank == 0:
+            full = synthetic.build_model(job_spec, dev)
+            check["unsharded_elbo"] = float(full._build_likelihood(
+                [torch.as_tensor(z, dtype=torch.float32, device=dev) for z in zjob]).item())
+            check["rel_diff"] = abs(check["sharded_elbo"] - check["unsharded_elbo"]) / abs(check["unsharded_elbo"])
+
+    # ---- SURVEY.md section 8(d) protocol: median of >= 50 hipEvent-timed iterations, one complete evaluation per iteration
+    #      (own graph of 1 evaluation: precompute + fused forward; fresh device-drawn noise every replay) ------------------
+    med = None
+    if world == 1 and args.median_iters > 0:
+        s3 = torch.cuda.Stream(device=dev)
+        s3.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s3):
+            model._build_likelihood()
+            g1 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g1, stream=s3, capture_error_mode="thread_local"):
+                keep1 = model._build_likelihood()
+        torch.cuda.current_stream().wait_stream(s3)
+        torch.cuda.synchronize()
+        for _ in range(10):
+            g1.replay()
+        torch.cuda.synchronize()
+        evs1 = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.median_iters)]
+        for a, b in evs1:
+            a.record()
+            g1.replay()
+            b.record()
+        torch.cuda.synchronize()
+        ts = np.array([a.elapsed_time(b) for a, b in evs1])
+        med = {"ms_per_step_median": float(np.median(ts)), "p10": float(np.percentile(ts, 10)), "p90": float(np.percentile(ts, 90)),
+               "iters": int(args.median_iters), "warmup": 10,
+               "how": "hipEvents around single-evaluation hipGraph replays (one precompute + one fused forward each), back to back"}
+
     # ---- dominant kernel: the fused forward (all layers), HIP events around a graph of back-to-back launches
     tot_flops, _ = f_alg_model(spec)
     dom_flops = tot_flops * B * K
@@ -337,6 +400,7 @@ def main():
                        "sharding": ("none" if world == 1 else args.shard + "-shard"),
                        "launch": "eager" if graph is None else ("hipGraph replay, %d steps per replay" % spg) + ("" if xch is None else ", one exchange per replay")},
             "elbo": final_elbo,
+            "n_ranks_seen": (dist.get_world_size() if dist is not None else 1),
             "host_enqueue_ms_per_step": t_enqueued / args.steps * 1e3,
             "roofline": {"bound": "mfma", "kernel": "k_dgp_forward (all layers fused, one launch per ELBO evaluation)", "achieved": achieved / 1e12,
                          "peak": PEAK_MFMA_F32 / 1e12, "unit": "TFLOP/s", "frac": achieved / PEAK_MFMA_F32,
@@ -344,8 +408,16 @@ def main():
                          "flops_per_launch": dom_flops},
         }
         res["model_frac_of_mfma_peak"] = res["value"] / world * tot_flops / PEAK_MFMA_F32
+        if med is not None:
+            res.update({"ms_per_step_median": med["ms_per_step_median"], "median_protocol": med})
+        if check is not None:
+            res["check"] = check
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(spec, args.cpu_seconds)
+            try:                                                 # float32 on the CPU: the precision the device path computes in
+                res["cpu_baseline_fp32"] = cpu_baseline(spec, args.cpu_seconds * 0.5, torch.float32)
+            except Exception as e:                               # (a float32 Cholesky of K_uu + 1e-6 I may fail on the host)
+                res["cpu_baseline_fp32"] = {"error": "%s: %s" % (type(e).__name__, e)}
             res["gpu_over_cpu"] = res["value"] / res["cpu_baseline"]["value"]
         if world == 1 and not args.no_train_leg:
             res["training_step"] = training_leg(model, B * K)

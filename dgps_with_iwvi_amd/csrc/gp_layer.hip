@@ -63,7 +63,11 @@ __global__ __launch_bounds__(256) void k_fullcov(const float* __restrict__ F, co
 // One workgroup per (s, r): the N x N block is factorised in LDS (float32, right-looking, column at a time -- on the
 // IW path N is the number of importance samples); N > MVN_LDS_N works in a caller-provided global scratch instead
 // (correct, latency-bound: only the 2-D predict path with a consumed inner-layer sample gets there).
-// A non-positive pivot poisons the block's sample with NaN like a failed tf.cholesky.
+// The block is a float32 difference k - a.a + u.u: for (near-)singular blocks -- X tiled over K gives rank-1 blocks,
+// a "zero" inner layer gives pure rounding noise -- it is indefinite by rounding where the float64 reference's is barely
+// positive.  So the factorisation is the rounding-tolerant PSD form: a non-positive pivot zeroes its column (no component
+// along that direction) and every entry is clamped to |L_ij| <= sqrt(C_ii), the bound any PSD factor obeys, which keeps
+// a tiny pivot from amplifying rounding noise.  On a well-conditioned block this is the plain Cholesky factor.
 constexpr int MVN_LDS_N = 192;
 __global__ __launch_bounds__(256) void k_mvn_sample(const float* __restrict__ mean, const float* __restrict__ cov,
                                                     const float* __restrict__ z, float* __restrict__ sample,
@@ -71,21 +75,28 @@ __global__ __launch_bounds__(256) void k_mvn_sample(const float* __restrict__ me
     extern __shared__ float mvn_sm[];
     const long long s = blockIdx.x;
     const int r = blockIdx.y, tid = threadIdx.x;
-    float* Lm = scratch ? scratch + ((size_t)s * R + r) * ((size_t)N * N + N) : mvn_sm;   // [N, N] lower triangle
-    float* zz = Lm + (size_t)N * N;                                                        // [N]
+    float* Lm = scratch ? scratch + ((size_t)s * R + r) * ((size_t)N * N + 2 * N) : mvn_sm;   // [N, N] lower triangle
+    float* zz = Lm + (size_t)N * N;                                                            // [N]
+    float* bound = zz + N;                                                                     // [N] sqrt(max(C_ii, 0))
     const float* C = cov + ((size_t)s * R + r) * N * N;
     for (long long idx = tid; idx < (long long)N * N; idx += 256) {
         const int i = (int)(idx / N), k = (int)(idx - (long long)i * N);
         Lm[idx] = (k <= i) ? C[idx] + (k == i ? jitter : 0.f) : 0.f;
     }
-    for (int i = tid; i < N; i += 256) zz[i] = z[((size_t)s * R + r) * N + i];
+    for (int i = tid; i < N; i += 256) {
+        zz[i] = z[((size_t)s * R + r) * N + i];
+        bound[i] = sqrtf(fmaxf(C[(size_t)i * N + i] + jitter, 0.f));
+    }
     for (int j = 0; j < N; ++j) {
         __syncthreads();
         const float d = Lm[(size_t)j * N + j];
-        const float inv = d > 0.f ? rsqrtf(d) : __builtin_nanf("");
+        const float inv = d > 0.f ? rsqrtf(d) : 0.f;
         __syncthreads();
-        for (int i = j + 1 + tid; i < N; i += 256) Lm[(size_t)i * N + j] *= inv;
-        if (tid == 0) Lm[(size_t)j * N + j] = d * inv;
+        for (int i = j + 1 + tid; i < N; i += 256) {
+            const float b = bound[i];
+            Lm[(size_t)i * N + j] = fminf(fmaxf(Lm[(size_t)i * N + j] * inv, -b), b);
+        }
+        if (tid == 0) Lm[(size_t)j * N + j] = d > 0.f ? fminf(d * inv, bound[j]) : 0.f;
         __syncthreads();
         const long long n = N - j - 1;
         for (long long idx = tid; idx < n * n; idx += 256) {
@@ -160,7 +171,7 @@ extern "C" int iwvi_gp_layer_fullcov(const void* state, int M, int D, int R, int
 
 extern "C" size_t iwvi_mvn_sample_ws_bytes(int64_t S, int N, int R) {
     if (S <= 0 || N <= MVN_LDS_N || R <= 0) return 0;
-    return sizeof(float) * (size_t)S * R * ((size_t)N * N + N);
+    return sizeof(float) * (size_t)S * R * ((size_t)N * N + 2 * (size_t)N);
 }
 
 extern "C" int iwvi_mvn_sample(const float* mean, const float* cov, const float* z, float* sample,
@@ -169,7 +180,7 @@ extern "C" int iwvi_mvn_sample(const float* mean, const float* cov, const float*
     if (!mean || !cov || !z || !sample) { set_error("iwvi_mvn_sample: null pointer"); return IWVI_ERR_ARG; }
     if (N > 46340 || R <= 0 || R > 65535 || S > 0x7fffffffLL) { set_error("iwvi_mvn_sample: bad size (S=%lld N=%d R=%d)", (long long)S, N, R); return IWVI_ERR_ARG; }
     if (N > MVN_LDS_N && !ws) { set_error("iwvi_mvn_sample: N=%d > %d needs the scratch of iwvi_mvn_sample_ws_bytes", N, MVN_LDS_N); return IWVI_ERR_ARG; }
-    const size_t lds = N > MVN_LDS_N ? 0 : sizeof(float) * ((size_t)N * N + N);
+    const size_t lds = N > MVN_LDS_N ? 0 : sizeof(float) * ((size_t)N * N + 2 * (size_t)N);
     static bool attr_set = false;          // not a stream operation: once, outside any capture's steady state
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)k_mvn_sample, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

@@ -251,9 +251,9 @@ def independent_multisample_sample_conditional(Xnew, feat, kern, f, *, full_cov=
         return (None, mean[0], cov[0]) if Xnew.dim() == 2 else (None, mean, cov)
     zz = draw_normal((S, R, N, 1), Xnew.device) if z is None else _abi.dev_tensor(z.reshape(S, R, N, 1).contiguous(), "z")
     # K11: the jointly Gaussian sample (:93-96).  For the FINAL layer this is dead code for the ELBO (its sample is never
-    # consumed, models.py:122-134) and the block may be singular (X tiled over K gives rank-1 blocks): like the TF graph,
-    # a failed factorisation only poisons this sample (NaN), not the mean / covariance.  The 2-D gpflow path adds jitter
-    # inside its _sample_mvn, the 3-D path of this file (:94-95) does not.
+    # consumed, models.py:122-134) and the block may be singular (X tiled over K gives rank-1 blocks): the kernel's
+    # factorisation is rounding-tolerant (non-positive pivot -> zero column) where tf.cholesky would fail.  The 2-D
+    # gpflow path adds jitter inside its _sample_mvn, the 3-D path of this file (:94-95) does not.
     sample = torch.empty(S, N, R, dtype=settings.float_type, device=Xnew.device)
     nws = _abi.lib().iwvi_mvn_sample_ws_bytes(S, N, R)
     ws2 = torch.empty(nws, dtype=torch.uint8, device=Xnew.device) if nws else None

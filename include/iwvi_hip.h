@@ -167,7 +167,9 @@ int iwvi_gp_layer_fullcov(const void* state, int M, int D, int R, int kern_type,
  * fmean_SRN1 of :95):  sample[s, n, r] = mean[s, n, r] + (chol(cov[s, r] + jitter I) z[s, r])[n].
  * mean, sample [S, N, R]; cov [S, R, N, N]; z [S, R, N].  N <= 192 (N is the importance-sample axis on the IW path)
  * factorises in LDS; larger N needs ws = iwvi_mvn_sample_ws_bytes(S, N, R) bytes of scratch (0 for N <= 192) and is
- * latency-bound.  A non-positive pivot gives NaN for that block's sample (a failed tf.cholesky), nothing else is touched. */
+ * latency-bound.  Rounding-tolerant PSD factorisation: the block is a float32 difference k - a.a + u.u and (near-)singular
+ * blocks (X tiled over K: rank 1) are indefinite by rounding, so a non-positive pivot zeroes its column instead of
+ * failing like tf.cholesky, and entries are clamped to |L_ij| <= sqrt(C_ii); on a well-conditioned block this is chol(). */
 size_t iwvi_mvn_sample_ws_bytes(int64_t S, int N, int R);
 int iwvi_mvn_sample(const float* mean, const float* cov, const float* z, float* sample,
                     int64_t S, int N, int R, float jitter, void* ws, void* stream);

@@ -1,0 +1,112 @@
+"""Multi-rank plumbing of bench.py and sharding.OverlappedExchange on ONE GPU (the pool hands out one GPU at a time; the
+8-GPU run is the driver's).  bench.py is started as FRESH child processes -- 2 ranks over gloo, both on cuda:0 -- exactly
+as ``python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`` would start it (same env contract), with
+``--check``: after its timed region every rank evaluates its shard of ONE job-wide injected noise draw through the very
+path the timed loop uses (per-slot hipGraphs aside), rank 0 also evaluates the unsharded job, and the JSON line carries both."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _run_bench(world, shard, extra=(), backend="gloo", timeout=600):
+    port = _free_port()
+    procs = []
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), IWVI_BENCH_BACKEND=backend, HSA_ENABLE_IPC_MODE_LEGACY="0")
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "8", "--warmup", "2", "--config", "1",
+               "--shard", shard, "--check", "--no-cpu-baseline", "--no-train-leg", *extra]
+        procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=ROOT))
+    outs = []
+    for p in procs:
+        try:
+            out, err = p.communicate(timeout=timeout)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append((p.returncode, out, err))
+    for rc, out, err in outs:
+        assert rc == 0, err[-3000:]
+    lines = [l for l in outs[0][1].splitlines() if l.startswith("{")]
+    assert len(lines) == 1, outs[0][1]
+    assert all(not l.startswith("{") for _, o, _ in outs[1:] for l in o.splitlines())     # only rank 0 prints
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("shard", ["k", "n"])
+def test_bench_two_ranks_on_one_gpu_merges_to_the_unsharded_elbo(gpu_device, shard):
+    res = _run_bench(2, shard)
+    assert res["n_gpus"] == 2 and res["n_ranks_seen"] == 2 and res["steps"] == 8
+    assert res["config"]["sharding"] == shard + "-shard" and "one exchange per replay" in res["config"]["launch"]
+    c = res["check"]
+    assert c["K_total"] == (10 if shard == "k" else 5) and c["B_total"] == (1024 if shard == "k" else 2048)
+    assert c["all_steps_equal"]
+    # float32 logsumexp merged in a different order than the single-rank reduction
+    assert c["rel_diff"] <= 2e-6, c
+    assert np.isfinite(res["value"]) and res["value"] > 0 and np.isfinite(res["elbo"])
+
+
+def test_bench_single_rank_line_has_the_contract_fields(gpu_device):
+    res = _run_bench(1, "k", extra=("--median-iters", "50"))
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "ms_per_step_median", "n_ranks_seen"):
+        assert k in res, k
+    assert res["n_ranks_seen"] == 1 and res["median_protocol"]["iters"] == 50
+    assert res["check"]["rel_diff"] == 0.0                       # no sharding: the same evaluation twice
+    r = res["roofline"]
+    assert r["bound"] == "mfma" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+
+
+def test_overlapped_exchange_slot_reuse(gpu_device):
+    """depth-2 staging ring, 7 submits of 3 evaluations each on a 1-rank RCCL communicator: every exchanged slot returns
+    the ELBOs of exactly the evaluations written into it (no slot is overwritten while its exchange is still reading it)."""
+    import torch.distributed as dist
+    from dgps_with_iwvi_amd import sharding, synthetic
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(_free_port())
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=gpu_device)
+    try:
+        spec = synthetic.make_spec(L=2, M=32, B=64, K=6, with_lv=True, seed=3, n_data=4096)
+        model = synthetic.build_model(spec, gpu_device)
+        rng = np.random.default_rng(0)
+        for mode in ("k", "n"):
+            xch = sharding.OverlappedExchange(mode, 1, 64, 6, 4096 / 64, gpu_device, depth=2, steps=3)
+            want, got = [], []
+            for it in range(7):
+                slot = xch.before_step()
+                assert slot == it % 2
+                row = []
+                for view in xch.slot_views(slot):
+                    zs = [torch.as_tensor(z, dtype=torch.float32, device=gpu_device) for z in synthetic.make_noise(spec, seed=int(rng.integers(1 << 30)))]
+                    if mode == "k":
+                        _, glob = model.lse_partials(zs, K_total=6, out=view)
+                    else:
+                        model._build_likelihood(zs, out=view)
+                        glob = None
+                    row.append(zs)
+                xch.submit(global_kls=glob)
+                if it % 3 == 2:                                   # sometimes drain, sometimes let two exchanges be in flight
+                    got.append(xch.finish().clone())
+                    want.append(row)
+            got.append(xch.finish().clone())
+            want.append(row)
+            for g, row in zip(got, want):
+                ref = [model.compute_log_likelihood(zs) for zs in row]
+                np.testing.assert_allclose(g.cpu().numpy(), ref, rtol=2e-6)
+    finally:
+        dist.destroy_process_group()

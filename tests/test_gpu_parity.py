@@ -471,19 +471,23 @@ def test_batched_merge_matches_per_evaluation_merge():
 # size-independent properties of the estimator (and against itself across decompositions)
 # ------------------------------------------------------------------------------------------
 FULL = dict(L=2, M=128, B=1024, K=20, with_lv=True, seed=0, parity=True, n_data=65536)    # BASELINE.json configs[2]
+FULL_CFG = {"configs2": {},                                   # 2-layer DGP + LatentVariableLayer, M=128, K=20, batch=1024
+            "configs1": dict(K=5, with_lv=False)}             # 2-layer DGP, RBF, M=128, K=5, batch=1024
+both_full_configs = pytest.mark.parametrize("cfg", ["configs2", "configs1"])
 
 
-def _full_model(gpu_device, **over):
+def _full_model(gpu_device, cfg="configs2", **over):
     from dgps_with_iwvi_amd import synthetic
-    spec = synthetic.make_spec(**dict(FULL, **over))
+    spec = synthetic.make_spec(**dict(FULL, **dict(FULL_CFG[cfg], **over)))
     return spec, synthetic.build_model(spec, gpu_device)
 
 
-def test_full_size_reproducible_and_jensen_ordered(gpu_device):
+@both_full_configs
+def test_full_size_reproducible_and_jensen_ordered(gpu_device, cfg):
     """Same injected noise -> bit-identical ELBO; logsumexp_k(L) - log K >= mean_k(L) for every point (Jensen),
     and the fused tail's per-point values equal those recomputed from the exported log-weights."""
     from dgps_with_iwvi_amd import synthetic
-    spec, model = _full_model(gpu_device)
+    spec, model = _full_model(gpu_device, cfg)
     zs = [_t(z, gpu_device) for z in synthetic.make_noise(spec, seed=3)]
     a, b = model.compute_log_likelihood(zs), model.compute_log_likelihood(zs)
     assert a == b
@@ -497,12 +501,13 @@ def test_full_size_reproducible_and_jensen_ordered(gpu_device):
     assert abs(a - elbo_ref) <= 2e-6 * abs(elbo_ref)
 
 
-def test_full_size_invariant_under_sample_permutation(gpu_device):
+@both_full_configs
+def test_full_size_invariant_under_sample_permutation(gpu_device, cfg):
     """Permuting the K importance samples of every point (their noise) leaves the per-point estimate unchanged up to
     float32 rounding (a sample's sub-tile decides the summation order of its solve; log-weights are O(100) with
     sensitivity 1 / lik_variance)."""
     from dgps_with_iwvi_amd import synthetic
-    spec, model = _full_model(gpu_device)
+    spec, model = _full_model(gpu_device, cfg)
     zs = synthetic.make_noise(spec, seed=4)
     perm = np.random.default_rng(0).permutation(spec["K"])
     lp0 = _np(model.E_log_p_Y([_t(z, gpu_device) for z in zs]))
@@ -510,14 +515,15 @@ def test_full_size_invariant_under_sample_permutation(gpu_device):
     np.testing.assert_allclose(lp0, lp1, rtol=5e-5, atol=5e-3)
 
 
-def test_full_size_k_shards_merge_to_the_unsharded_value(gpu_device):
-    """K = 20 as 8 uneven shards (3,3,3,3,2,2,2,2: the 8-GPU split) merged with iwvi_lse_merge == one evaluation."""
+@both_full_configs
+def test_full_size_k_shards_merge_to_the_unsharded_value(gpu_device, cfg):
+    """K = 20 as 8 uneven shards (3,3,3,3,2,2,2,2: the 8-GPU split; K = 5 as 4 shards) merged with iwvi_lse_merge == one evaluation."""
     from dgps_with_iwvi_amd import sharding, synthetic
-    spec, model = _full_model(gpu_device)
+    spec, model = _full_model(gpu_device, cfg)
     zs = synthetic.make_noise(spec, seed=5)
     ref = model.compute_log_likelihood([_t(z, gpu_device) for z in zs])
     parts, k0, glob = [], 0, None
-    for Kr in sharding.split_samples(spec["K"], 8):
+    for Kr in sharding.split_samples(spec["K"], 8 if spec["K"] >= 8 else 4):
         m = synthetic.build_model(spec, gpu_device, num_samples=Kr)
         ms, glob = m.lse_partials([_t(z[:, k0:k0 + Kr], gpu_device) for z in zs], K_total=spec["K"])
         parts.append(ms.clone())
@@ -526,10 +532,11 @@ def test_full_size_k_shards_merge_to_the_unsharded_value(gpu_device):
     assert abs(float(elbo.item()) - ref) <= 2e-6 * abs(ref), (float(elbo.item()), ref)
 
 
-def test_full_size_scale_is_linear_in_num_data(gpu_device):
+@both_full_configs
+def test_full_size_scale_is_linear_in_num_data(gpu_device, cfg):
     """ELBO(n) = (n / B) sum_b logp_b - KL: two values of num_data differ by exactly the scaled data term."""
     from dgps_with_iwvi_amd import synthetic
-    spec, model = _full_model(gpu_device)
+    spec, model = _full_model(gpu_device, cfg)
     zs = [_t(z, gpu_device) for z in synthetic.make_noise(spec, seed=6)]
     e1 = model.compute_log_likelihood(zs)
     s = float(model.E_log_p_Y(zs).double().sum())

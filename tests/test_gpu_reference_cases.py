@@ -1,0 +1,432 @@
+"""GPU mirrors of the ONLY numerically asserted tests the reference holds (tests/test_gp_layer.py:15-54 and :57-96),
+run through the reference's own import names (``dgps_with_iwvi.*`` -- the alias package), plus oracle parity of the
+prediction paths (reference models.py:88-107), the diagonal / unwhitened q(u) branches of the conditional
+(temp_workaround.py:63-65, :72-73), the public ``gauss_kl`` and ``Gaussian.variational_expectations``, a model whose
+inner layer samples jointly over K (temp_workaround.py:149-155), and multi-layer models at M = 256 / 512.
+
+Tolerances are float32-per-sample vs the float64 oracle and are written at every assert.  The SVGP side of the two
+mirrored tests is oracle/svgp_closed_form.py (GPflow is not installable).
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import iwvi_oracle as O
+from oracle import svgp_closed_form as C
+from oracle.from_spec import build_oracle, oracle_noise
+
+pytestmark = pytest.mark.gpu
+
+
+def _t(a, dev, dtype=torch.float32):
+    return torch.as_tensor(np.asarray(a), dtype=dtype, device=dev)
+
+
+def _np(t):
+    return t.detach().double().cpu().numpy()
+
+
+def _f32(a):
+    return np.asarray(a, np.float32).astype(np.float64)
+
+
+# ------------------------------------------------------------------------------------------
+# (a) reference tests/test_gp_layer.py:15-54 -- test_gp_layer, at the reference's own sizes
+# ------------------------------------------------------------------------------------------
+def test_reference_test_gp_layer(gpu_device):
+    """N = 10001 training points, M = 100, Matern52(lengthscale 0.1) + Linear mean function, Gaussian(0.1); random
+    (non-triangular) q_sqrt.  ``compute_log_likelihood`` and ``predict_f_full_cov`` mean + [R, N, N] covariance of a
+    one-layer DGP_VI against the closed-form SVGP.  The reference predicts on N-1 = 10000 points (an 800 MB float64
+    covariance per copy on the oracle side); the covariance is compared on every 5th of those (2000 points), the mean and
+    the bound at full size."""
+    from dgps_with_iwvi.layers import GPLayer                      # the reference's import lines (:11-12)
+    from dgps_with_iwvi.models import DGP_VI
+    from dgps_with_iwvi import kernels, likelihoods, mean_functions
+    N, M, Dy = 10001, 100, 1
+    np.random.seed(0)
+    X = np.linspace(0, 1, N).reshape(-1, 1)
+    Z = np.linspace(0, 1, M).reshape(-1, 1)
+    Xs = np.linspace(0, 1, N - 1).reshape(-1, 1)
+    Y = np.concatenate([np.sin(10 * X), np.cos(10 * X)], 1)[:, 0:1]
+    A = _f32(np.random.randn(1, Dy))
+    q_mu = _f32(np.random.randn(M, Dy))
+    q_sqrt = _f32(np.random.randn(Dy, M, M))
+    # the device holds float32 inputs: give the oracle the same rounded numbers
+    X32, Z32, Xs32, Y32 = _f32(X), _f32(Z), _f32(Xs), _f32(Y)
+    ko = O.Matern52(1, lengthscales=float(np.float32(0.1)))
+    mfo = O.Linear(A)
+    L1 = C.svgp_elbo(X32, Y32, Z32, ko, q_mu, q_sqrt, float(np.float32(1e-1)), mfo)
+
+    kern = kernels.Matern52(1, lengthscales=0.1)
+    layer = GPLayer(kern, Z, Dy, mean_functions.Linear(A))
+    m_dgp = DGP_VI(X, Y, [layer], likelihoods.Gaussian(variance=1e-1), num_samples=1).to(gpu_device)
+    m_dgp.layers[0].q_mu = _t(q_mu, gpu_device)
+    m_dgp.layers[0].q_sqrt = _t(q_sqrt, gpu_device)
+    L2 = m_dgp.compute_log_likelihood()
+    # Kuu of 100 Matern points with lengthscale 0.1 on [0,1] has cond ~ 1e7 and q_sqrt has O(1) entries everywhere:
+    # the float32 per-sample solve keeps ~3 digits of the variance term (DESIGN.md "Precision")
+    assert abs(L1 - L2) <= 5e-3 * abs(L1), (L1, L2)
+
+    m2, v2 = m_dgp.predict_f_full_cov(Xs)
+    assert m2.shape == (N - 1, Dy) and v2.shape == (Dy, N - 1, N - 1)
+    m1, _ = C.svgp_predict(Xs32, Z32, ko, q_mu, q_sqrt, mfo, full_cov=False)
+    np.testing.assert_allclose(_np(m2), m1, rtol=2e-3, atol=2e-2)          # |mean| is O(10): q_mu ~ N(0,1) through 100 points
+    sub = slice(0, N - 1, 5)
+    _, v1 = C.svgp_predict(Xs32[sub], Z32, ko, q_mu, q_sqrt, mfo)
+    v2s = _np(v2[:, sub][:, :, sub])
+    scale = np.abs(v1).max()
+    assert np.abs(v2s - v1).max() <= 5e-3 * scale, (np.abs(v2s - v1).max(), scale)
+    # symmetric, and its diagonal is what predict_f returns
+    assert torch.equal(v2[0, :64, :64], v2[0, :64, :64].T)
+    _, vd = m_dgp.predict_f(Xs)
+    np.testing.assert_allclose(_np(torch.diagonal(v2, dim1=-2, dim2=-1)).T, _np(vd), rtol=1e-3, atol=1e-3 * scale)
+
+
+# ------------------------------------------------------------------------------------------
+# (b) reference tests/test_gp_layer.py:57-96 -- test_dgp_zero_inner_layers
+# ------------------------------------------------------------------------------------------
+def _zero_inner_case():
+    N, Dy = 10, 2
+    rng = np.random.RandomState(1)
+    X = np.linspace(0, 1, N).reshape(-1, 1)
+    Xs = np.linspace(0, 1, N - 1).reshape(-1, 1)
+    Y = np.concatenate([np.sin(10 * X), np.cos(10 * X)], 1)
+    A = _f32(rng.randn(1, 2))
+    q_mu = _f32(rng.randn(N, Dy))
+    q_sqrt = _f32(rng.randn(Dy, N, N))
+    return N, Dy, X, Xs, Y, A, q_mu, q_sqrt
+
+
+@pytest.mark.parametrize("inner_noise", ["zero", "random"])
+def test_reference_test_dgp_zero_inner_layers(gpu_device, inner_noise):
+    """A first layer with RBF(variance=1e-6), Identity mean function, q_sqrt * 1e-12, Z = X and jitter 1e-18
+    (``temp_settings``) passes its input through, so the 2-layer DGP's ``predict_f_full_cov`` equals the 1-layer SVGP's.
+    The reference asserts atol = rtol = 1e-5 in float64 with the inner layer's random draw left in.  Here the inner
+    layer's marginal variance (true value ~1e-15: Xs lies between the inducing inputs of a kernel with lengthscale 1) is
+    the float32 difference ``1e-6 - |a|^2``, i.e. rounding noise of order 1e-6 * 2^-24 * cond: with ``inner_noise='zero'``
+    (injected z = 0, the sample IS the mean = x exactly) the only error left is the outer layer's float32 arithmetic;
+    with the random draw the input of the outer layer is perturbed by z * sqrt(rounding noise) and the tolerance says so."""
+    from dgps_with_iwvi.layers import GPLayer
+    from dgps_with_iwvi.models import DGP_VI
+    from dgps_with_iwvi import kernels, likelihoods, mean_functions, settings
+    N, Dy, X, Xs, Y, A, q_mu, q_sqrt = _zero_inner_case()
+    X32, Xs32 = _f32(X), _f32(Xs)
+    ko = O.Matern52(1, lengthscales=float(np.float32(0.1)))
+    # the SVGP at the SAME jitter as the DGP's outer layer (the reference builds it outside temp_settings, with 1e-6:
+    # the 1e-5 tolerance of its assert absorbs that; the closed form here removes it)
+    m1, v1 = C.svgp_predict(Xs32, X32, ko, q_mu, q_sqrt, O.Linear(A), jitter=1e-18)
+    with settings.temp_settings(jitter=1e-18):
+        m_dgp = DGP_VI(X, Y, [
+            GPLayer(kernels.RBF(1, variance=1e-6), X, 1, mean_functions.Identity()),
+            GPLayer(kernels.Matern52(1, lengthscales=0.1), X, Dy, mean_functions.Linear(A))],
+            likelihoods.Gaussian(variance=1e-1)).to(gpu_device)
+        m_dgp.layers[-1].q_mu = _t(q_mu, gpu_device)
+        m_dgp.layers[-1].q_sqrt = _t(q_sqrt, gpu_device)
+        m_dgp.layers[0].q_sqrt = m_dgp.layers[0].q_sqrt * 1e-12
+        zs = None
+        if inner_noise == "zero":
+            zs = [torch.zeros(1, 1, N - 1, 1, device=gpu_device), None]       # full-cov noise layout [S, R, N, 1]
+        m2, v2 = m_dgp.predict_f_full_cov(Xs, zs=zs)
+        # the inner layer alone: mean == x (q_mu = 0, Identity), variance ~ 0
+        s0, mean0, cov0, _ = m_dgp.layers[0].propagate(_t(Xs, gpu_device), full_cov=False, z=torch.zeros(N - 1, 1, device=gpu_device))
+    assert torch.equal(mean0, _t(Xs, gpu_device)) and torch.equal(s0, mean0)
+    assert float(cov0.max()) <= 1e-6 and float(cov0.min()) >= 0.0             # clamped float32 rounding of 1e-6 - |a|^2
+    assert m2.shape == (N - 1, Dy) and v2.shape == (Dy, N - 1, N - 1)
+    vs = np.abs(v1).max()
+    if inner_noise == "zero":
+        # Z = X with lengthscale 0.1 at spacing 0.11: Kuu is well conditioned, float32 keeps ~5 digits
+        np.testing.assert_allclose(_np(m2), m1, atol=2e-4, rtol=2e-4)
+        assert np.abs(_np(v2) - v1).max() <= 2e-4 * vs
+    else:
+        # inner sample = x + z * sqrt(var), var <= ~1e-7 of rounding noise -> |dx| <~ 1e-3; the outer mean has slope
+        # ~|q_mu| / lengthscale ~ 30 there
+        np.testing.assert_allclose(_np(m2), m1, atol=5e-2, rtol=5e-2)
+        assert np.abs(_np(v2) - v1).max() <= 5e-2 * vs
+
+
+# ------------------------------------------------------------------------------------------
+# (c) prediction paths, reference models.py:88-107 (row F3)
+# ------------------------------------------------------------------------------------------
+def _predict_case(gpu_device, cls_name="DGP_IWVI", L=2, M=64, with_lv=True, seed=17):
+    from dgps_with_iwvi_amd import synthetic
+    from dgps_with_iwvi_amd import models
+    spec = synthetic.make_spec(L=L, M=M, B=24, K=3, with_lv=with_lv, seed=seed, n_data=400)
+    model = synthetic.build_model(spec, gpu_device, cls=getattr(models, cls_name))
+    om = build_oracle(spec, iw=cls_name == "DGP_IWVI")
+    return spec, model, om
+
+
+def _layer_noise(spec, lead, rng):
+    return [rng.standard_normal(lead + (l["latent_dim"] if l["type"] == "lv" else l["q_mu"].shape[1],)).astype(np.float32)
+            for l in spec["layers"]]
+
+
+@pytest.mark.parametrize("cls_name,with_lv", [("DGP_IWVI", True), ("DGP_VI", True), ("DGP_IWVI", False)])
+def test_predict_f_matches_oracle(gpu_device, cls_name, with_lv):
+    """``predict_f`` = ``_build_predict(X, full_cov=False)`` (models.py:89-91): 2-D inputs, latent-variable layer in
+    PRIOR mode (layers.py:73-81: no recognition inputs -> W = z), marginal variances."""
+    spec, model, om = _predict_case(gpu_device, cls_name, with_lv=with_lv)
+    rng = np.random.default_rng(3)
+    Xs = _f32(rng.standard_normal((37, 8)))
+    zs = _layer_noise(spec, (37,), rng)
+    m, v = model.predict_f(_t(Xs, gpu_device), zs=[_t(z, gpu_device) for z in zs])
+    mo, vo = om.build_predict(Xs, full_cov=False, zs=zs)
+    assert m.shape == mo.shape and v.shape == vo.shape
+    np.testing.assert_allclose(_np(m), mo, rtol=2e-3, atol=2e-3)
+    np.testing.assert_allclose(_np(v), vo, rtol=5e-3, atol=2e-4)
+
+
+def test_predict_f_full_cov_two_layers_matches_oracle(gpu_device):
+    """``predict_f_full_cov`` on a 2-layer model: the inner (SharedMixedMok) layer samples marginally
+    (temp_workaround.py:134-138), the final layer returns [R, N, N] (:157-161)."""
+    spec, model, om = _predict_case(gpu_device, "DGP_VI", with_lv=False)
+    rng = np.random.default_rng(4)
+    Xs = _f32(rng.standard_normal((29, 8)))
+    zs = _layer_noise(spec, (29,), rng)
+    m, v = model.predict_f_full_cov(_t(Xs, gpu_device), zs=[_t(zs[0], gpu_device), None])
+    mo, vo = om.build_predict(Xs, full_cov=True, zs=[zs[0], None])
+    assert v.shape == (1, 29, 29) == vo.shape
+    np.testing.assert_allclose(_np(m), mo, rtol=2e-3, atol=2e-3)
+    np.testing.assert_allclose(_np(v), vo, rtol=5e-3, atol=2e-4)
+
+
+def test_predict_f_multisample_matches_oracle(gpu_device):
+    """``predict_f_multisample(X, S)`` (models.py:95-99): X tiled to [S, N, D], the 3-D conditional, prior-mode LV layer."""
+    spec, model, om = _predict_case(gpu_device)
+    rng = np.random.default_rng(5)
+    S, N = 6, 21
+    Xs = _f32(rng.standard_normal((N, 8)))
+    zs = _layer_noise(spec, (S, N), rng)
+    m, v = model.predict_f_multisample(_t(Xs, gpu_device), S, zs=[_t(z, gpu_device) for z in zs])
+    _, means, covs, _, _ = om.propagate(np.tile(Xs[None], [S, 1, 1]), zs=zs)     # :97-98
+    assert m.shape == (S, N, 1)
+    np.testing.assert_allclose(_np(m), means[-1], rtol=2e-3, atol=2e-3)
+    np.testing.assert_allclose(_np(v), covs[-1], rtol=5e-3, atol=2e-4)
+    # different draws of the latent variable give different predictive means (the model is not degenerate)
+    assert float(m.std(0).mean()) > 1e-3
+
+
+def test_predict_y_samples_matches_oracle(gpu_device):
+    """``predict_y_samples`` (models.py:102-107): m + z sqrt(v + likelihood variance) with the injected draw z_y."""
+    spec, model, om = _predict_case(gpu_device)
+    rng = np.random.default_rng(6)
+    S, N = 5, 19
+    Xs = _f32(rng.standard_normal((N, 8)))
+    zs = _layer_noise(spec, (S, N), rng)
+    z_y = rng.standard_normal((S, N, 1)).astype(np.float32)
+    y = model.predict_y_samples(_t(Xs, gpu_device), S, zs=[_t(z, gpu_device) for z in zs], z_y=_t(z_y, gpu_device))
+    _, means, covs, _, _ = om.propagate(np.tile(Xs[None], [S, 1, 1]), zs=zs)
+    mo, vo = om.likelihood.predict_mean_and_var(means[-1], covs[-1])              # :105
+    ref = mo + z_y * vo ** 0.5
+    np.testing.assert_allclose(_np(y), ref, rtol=2e-3, atol=3e-3)
+    # and with in-library draws: finite, right shape, spread consistent with the predictive variance
+    y2 = model.predict_y_samples(_t(Xs, gpu_device), 400)
+    assert y2.shape == (400, N, 1) and torch.isfinite(y2).all()
+    assert 0.3 < float(y2.std(0).mean()) / float(np.sqrt(vo.mean() + means[-1].var(0).mean())) < 3.0
+
+
+# ------------------------------------------------------------------------------------------
+# (d, e) conditional branches: diagonal q_sqrt (:72-73), white=False (:63-65), public gauss_kl, var-exp
+# ------------------------------------------------------------------------------------------
+def _cond_case(seed, M, D, R, S, N):
+    rng = np.random.default_rng(seed)
+    Z = _f32(rng.standard_normal((M, D)))
+    ls = _f32((0.8 + 0.4 * rng.random(D)) * np.sqrt(D))
+    f = _f32(rng.standard_normal((M, R)))
+    X = _f32(rng.standard_normal((S, N, D)))
+    z = _f32(rng.standard_normal((S, N, R)))
+    return rng, Z, ls, f, X, z
+
+
+@pytest.mark.parametrize("M,D,R", [(48, 3, 2), (128, 8, 5)])
+def test_diagonal_q_sqrt_matches_oracle(gpu_device, M, D, R):
+    """q_sqrt of shape [M, R] = per-inducing-point standard deviations (temp_workaround.py:72-73)."""
+    from dgps_with_iwvi_amd import features, kernels
+    from dgps_with_iwvi_amd.temp_workaround import independent_multisample_sample_conditional as cond
+    rng, Z, ls, f, X, z = _cond_case(M + R, M, D, R, 4, 11)
+    q_diag = _f32(0.2 + rng.random((M, R)))
+    k = kernels.RBF(D, variance=1.2, lengthscales=ls).to(gpu_device)
+    s, m, v = cond(_t(X, gpu_device), features.InducingPoints(Z).to(gpu_device), k, _t(f, gpu_device),
+                   q_sqrt=_t(q_diag, gpu_device), white=True, z=_t(z, gpu_device))
+    so, mo, vo = O.independent_multisample_sample_conditional(X, Z, O.RBF(D, float(np.float32(1.2)), ls), f,
+                                                              q_sqrt=q_diag, white=True, z=z)
+    np.testing.assert_allclose(_np(m), mo, rtol=2e-3, atol=1e-3)
+    np.testing.assert_allclose(_np(v), vo, rtol=2e-3, atol=1e-4)
+    np.testing.assert_allclose(_np(s), so, rtol=2e-3, atol=2e-3)
+    # full covariance with the diagonal q_sqrt too (:83)
+    _, mf, cf = cond(_t(X, gpu_device), features.InducingPoints(Z).to(gpu_device), k, _t(f, gpu_device),
+                     q_sqrt=_t(q_diag, gpu_device), white=True, full_cov=True, want_sample=False)
+    _, mfo, cfo = O.independent_multisample_sample_conditional(X, Z, O.RBF(D, float(np.float32(1.2)), ls), f,
+                                                               q_sqrt=q_diag, white=True, full_cov=True)
+    np.testing.assert_allclose(_np(mf), mfo, rtol=2e-3, atol=1e-3)
+    np.testing.assert_allclose(_np(cf), cfo, rtol=2e-3, atol=1e-4)
+
+
+@pytest.mark.parametrize("M,D,R,qs", [(40, 3, 2, "full"), (96, 8, 3, "full"), (40, 3, 2, "diag"), (40, 3, 2, "none")])
+def test_unwhitened_conditional_matches_oracle(gpu_device, M, D, R, qs):
+    """white=False: "another backsubstitution in the unwhitened case" (temp_workaround.py:63-65), 2-D and 3-D inputs,
+    plain and SharedMixedMok kernels."""
+    from dgps_with_iwvi_amd import features, kernels
+    from dgps_with_iwvi_amd.temp_workaround import SharedMixedMok, multisample_sample_conditional as cond
+    rng, Z, ls, f, X, z = _cond_case(M * 3 + R, M, D, R, 3, 9)
+    if qs == "full":
+        q = _f32(np.tril(rng.standard_normal((R, M, M))) * 0.2 / np.sqrt(M) + 0.3 * np.eye(M))
+    elif qs == "diag":
+        q = _f32(0.1 + 0.3 * rng.random((M, R)))
+    else:
+        q = None
+    k = kernels.RBF(D, variance=0.9, lengthscales=ls).to(gpu_device)
+    ko = O.RBF(D, float(np.float32(0.9)), ls)
+    feat = features.InducingPoints(Z).to(gpu_device)
+    qd = None if q is None else _t(q, gpu_device)
+    s, m, v = cond(_t(X, gpu_device), feat, k, _t(f, gpu_device), q_sqrt=qd, white=False, z=_t(z, gpu_device))
+    so, mo, vo = O.multisample_sample_conditional(X, Z, ko, f, q_sqrt=q, white=False, z=z)
+    # the unwhitened mean a^T Lm^-1 f amplifies f by |Kuu^-1| (cond(Kuu) ~ 1e3..1e5 here): tolerance relative to its size
+    ms = np.abs(mo).max()
+    assert np.abs(_np(m) - mo).max() <= 2e-3 * ms, (np.abs(_np(m) - mo).max(), ms)
+    vs = np.abs(vo).max()
+    assert np.abs(_np(v) - vo).max() <= 2e-3 * vs + 1e-4, (np.abs(_np(v) - vo).max(), vs)
+    assert np.abs(_np(s) - so).max() <= 2e-3 * max(ms, np.sqrt(vs)) + 2e-3
+    # 2-D input (:157-161)
+    s2, m2, v2 = cond(_t(X[0], gpu_device), feat, k, _t(f, gpu_device), q_sqrt=qd, white=False, z=_t(z[0], gpu_device))
+    assert np.abs(_np(m2) - mo[0]).max() <= 2e-3 * ms and np.abs(_np(v2) - vo[0]).max() <= 2e-3 * vs + 1e-4
+    # SharedMixedMok branch (:123-147)
+    W = _f32(rng.standard_normal((4, R)))
+    s3, m3, v3 = cond(_t(X, gpu_device), features.MixedKernelSharedMof(feat), SharedMixedMok(k, W).to(gpu_device),
+                      _t(f, gpu_device), q_sqrt=qd, white=False, z=_t(z, gpu_device))
+    so3, mo3, vo3 = O.multisample_sample_conditional(X, Z, O.SharedMixedMok(ko, W), f, q_sqrt=q, white=False, z=z)
+    assert np.abs(_np(m3) - mo3).max() <= 2e-3 * np.abs(mo3).max()
+    assert np.abs(_np(v3) - vo3).max() <= 2e-3 * np.abs(vo3).max() + 1e-4
+
+
+@pytest.mark.parametrize("M,R", [(7, 1), (100, 3), (512, 2)])
+def test_public_gauss_kl(gpu_device, M, R):
+    """the ``gauss_kl`` wrapper (temp_workaround.py:167-188, KL branch) -> ``iwvi_gauss_kl``: full, diagonal q_sqrt."""
+    from dgps_with_iwvi.temp_workaround import gauss_kl
+    rng = np.random.default_rng(M)
+    q_mu = _f32(rng.standard_normal((M, R)))
+    q_sqrt = _f32(rng.standard_normal((R, M, M)) * 0.3 + np.eye(M))          # non-triangular: only the lower band counts
+    got = float(gauss_kl(_t(q_mu, gpu_device), _t(q_sqrt, gpu_device)).item())
+    ref = O.gauss_kl(q_mu, q_sqrt)
+    assert abs(got - ref) <= 1e-6 * abs(ref), (got, ref)
+    q_diag = _f32(0.1 + rng.random((M, R)))
+    got = float(gauss_kl(_t(q_mu, gpu_device), _t(q_diag, gpu_device)).item())
+    ref = O.gauss_kl(q_mu, np.stack([np.diag(q_diag[:, r]) for r in range(R)]))
+    assert abs(got - ref) <= 1e-6 * abs(ref), (got, ref)
+    with pytest.raises(NotImplementedError):
+        gauss_kl(_t(q_mu, gpu_device), None)                                   # SGHMC branch: out of scope
+
+
+def test_gaussian_variational_expectations_callable(gpu_device):
+    """``likelihood.variational_expectations(Fmu, Fvar, Y)`` as the reference calls it (models.py:66,134)."""
+    from dgps_with_iwvi import likelihoods
+    rng = np.random.default_rng(0)
+    Fmu, Fvar, Y = rng.standard_normal((6, 5, 2)), rng.random((6, 5, 2)), rng.standard_normal((6, 5, 2))
+    lik = likelihoods.Gaussian(0.37)
+    got = lik.variational_expectations(_t(Fmu, gpu_device), _t(Fvar, gpu_device), _t(Y, gpu_device))
+    ref = O.Gaussian(float(np.float32(0.37))).variational_expectations(_f32(Fmu), _f32(Fvar), _f32(Y))
+    np.testing.assert_allclose(_np(got), ref, rtol=1e-5, atol=1e-5)
+    assert got.shape == (6, 5, 2)
+
+
+# ------------------------------------------------------------------------------------------
+# an inner GPLayer with a PLAIN kernel: joint draws over the K samples (temp_workaround.py:149-155)
+# ------------------------------------------------------------------------------------------
+def test_inner_plain_kernel_layer_samples_jointly_over_K(gpu_device):
+    """under DGP_IWVI a non-final GPLayer whose kernel is not a SharedMixedMok goes through
+    independent_multisample_sample_conditional(full_cov=True): its K samples per point are drawn from the [K, K]
+    covariance.  The model detects it and follows the literal layer-by-layer path; ELBO vs the oracle on injected noise."""
+    from dgps_with_iwvi_amd import features, kernels, likelihoods
+    from dgps_with_iwvi_amd.layers import Encoder, GPLayer, LatentVariableLayer
+    from dgps_with_iwvi_amd.models import DGP_IWVI
+    rng = np.random.default_rng(7)
+    B, K, Dx, M, R = 9, 5, 3, 24, 2
+    X, Y = _f32(rng.standard_normal((B, Dx))), _f32(rng.standard_normal((B, 1)))
+    enc_o = O.Encoder(1, Dx + 1, [20, 20], rng)
+    enc_o.bs[-1] = np.array([0.0, 4.0])       # q_sqrt = softplus(raw - 3) ~ 1.3: the K inputs of a point are well separated,
+    #                                            so its [K, K] block is comfortably positive definite in float32 too
+    Z1, Z2 = _f32(rng.standard_normal((M, Dx + 1))), _f32(rng.standard_normal((M, R)))
+    p1 = (_f32(rng.standard_normal((M, R))), _f32(np.tril(rng.standard_normal((R, M, M))) * 0.05 + 0.6 * np.eye(M)))
+    p2 = (_f32(rng.standard_normal((M, 1))), _f32(np.tril(rng.standard_normal((1, M, M))) * 0.05 + 0.8 * np.eye(M)))
+    ls1, ls2 = _f32(np.r_[np.full(Dx, 2.0), 0.5]), _f32(np.full(R, 1.5))
+    # oracle
+    lo = [O.LatentVariableLayer(1, encoder=enc_o), O.GPLayer(O.RBF(Dx + 1, 1.0, ls1), Z1, R), O.GPLayer(O.RBF(R, 1.0, ls2), Z2, 1)]
+    lo[1].q_mu, lo[1].q_sqrt = p1
+    lo[2].q_mu, lo[2].q_sqrt = p2
+    om = O.DGP_IWVI(X, Y, lo, O.Gaussian(float(np.float32(0.05))), num_samples=K, num_data=100)
+    z_lv = _f32(rng.standard_normal((B, K, 1)))
+    z_in = _f32(rng.standard_normal((B, R, K, 1)))                             # full-cov noise layout [S, R, N, 1]
+    ref = om.build_likelihood([z_lv, z_in, None])
+    # device
+    enc = Encoder(1, Dx + 1, [20, 20])
+    enc.Ws, enc.bs = [_t(w, gpu_device) for w in enc_o.Ws], [_t(b, gpu_device) for b in enc_o.bs]
+    l1 = GPLayer(kernels.RBF(Dx + 1, lengthscales=ls1), features.InducingPoints(Z1), R)
+    l2 = GPLayer(kernels.RBF(R, lengthscales=ls2), features.InducingPoints(Z2), 1)
+    l1.q_mu, l1.q_sqrt = _t(p1[0], gpu_device), _t(p1[1], gpu_device)
+    l2.q_mu, l2.q_sqrt = _t(p2[0], gpu_device), _t(p2[1], gpu_device)
+    m = DGP_IWVI(X, Y, [LatentVariableLayer(1, encoder=enc), l1, l2], likelihoods.Gaussian(0.05), num_samples=K).to(gpu_device)
+    m.num_data = 100
+    assert m._joint_over_samples()
+    got = m.compute_log_likelihood([_t(z_lv, gpu_device), _t(z_in, gpu_device), None])
+    assert abs(got - ref) <= 2e-4 * abs(ref), (got, ref)
+    # the marginal-sampling shortcut would be a different estimator: the benchmark family (mixed inner layers) is not flagged
+    from dgps_with_iwvi_amd import synthetic
+    assert not synthetic.build_model(synthetic.make_spec(L=3, M=32, B=8, K=4, with_lv=True), gpu_device)._joint_over_samples()
+    from dgps_with_iwvi_amd.backward import iw_elbo_and_gradients
+    with pytest.raises(NotImplementedError):
+        iw_elbo_and_gradients(m)
+
+
+def test_mvn_sample_large_block(gpu_device):
+    """``iwvi_mvn_sample`` beyond its LDS size (N > 192: global scratch) against NumPy's Cholesky, and the rounding-tolerant
+    rule on a singular block (X tiled over K: rank 1)."""
+    from dgps_with_iwvi_amd import _abi
+    rng = np.random.default_rng(0)
+    for S, N, R in ((2, 257, 2), (3, 40, 1)):
+        G = rng.standard_normal((S, R, N, N + 5))
+        cov = (G @ G.transpose(0, 1, 3, 2) / N + 0.1 * np.eye(N)).astype(np.float32)
+        mean = rng.standard_normal((S, N, R)).astype(np.float32)
+        z = rng.standard_normal((S, R, N)).astype(np.float32)
+        out = torch.empty(S, N, R, device=gpu_device)
+        nws = _abi.lib().iwvi_mvn_sample_ws_bytes(S, N, R)
+        assert (nws > 0) == (N > 192)
+        ws = torch.empty(max(nws, 1), dtype=torch.uint8, device=gpu_device)
+        _abi.check(_abi.lib().iwvi_mvn_sample(_abi.ptr(_t(mean, gpu_device)), _abi.ptr(_t(cov, gpu_device)), _abi.ptr(_t(z, gpu_device)),
+                                              _abi.ptr(out), S, N, R, 0.0, _abi.ptr(ws), _abi.stream_ptr()))
+        ref = mean.astype(np.float64) + np.einsum("srij,srj->sir", np.linalg.cholesky(cov.astype(np.float64)), z.astype(np.float64))
+        np.testing.assert_allclose(_np(out), ref, rtol=1e-3, atol=1e-3)
+    rank1 = np.ones((1, 1, 4, 4), np.float32) * 2.25                              # pivots 2.25, 0, 0, 0 -> L = 1.5 e_1 1^T
+    out = torch.empty(1, 4, 1, device=gpu_device)
+    zz = torch.tensor([[[2.0, 7.0, -3.0, 5.0]]], device=gpu_device)
+    _abi.check(_abi.lib().iwvi_mvn_sample(_abi.ptr(torch.zeros(1, 4, 1, device=gpu_device)), _abi.ptr(_t(rank1, gpu_device)),
+                                          _abi.ptr(zz), _abi.ptr(out), 1, 4, 1, 0.0, None, _abi.stream_ptr()))
+    assert torch.equal(out.reshape(-1), torch.full((4,), 3.0, device=gpu_device))     # perfectly correlated: one draw for all
+
+
+# ------------------------------------------------------------------------------------------
+# (g) multi-layer models at M = 256 / 512 against the oracle (small B*K)
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("L,M,K,B,lv", [(3, 256, 4, 12, False), (2, 512, 3, 10, True), (3, 512, 2, 6, False), (5, 256, 2, 5, False)])
+def test_wide_multilayer_models_match_oracle(gpu_device, L, M, K, B, lv):
+    """BASELINE.json configs[3] / [4] widths (M = 256, 512; up to 5 layers) as whole MODELS: ELBO, per-point bound,
+    per-layer mean / sample and final moments vs the float64 oracle."""
+    from dgps_with_iwvi_amd import synthetic
+    spec = synthetic.make_spec(L=L, M=M, B=B, K=K, with_lv=lv, seed=M + L, n_data=2048)
+    zs = synthetic.make_noise(spec, seed=8)
+    model = synthetic.build_model(spec, gpu_device)
+    zd = [_t(z, gpu_device) for z in zs]
+    elbo = model.compute_log_likelihood(zd)
+    om = build_oracle(spec)
+    ref = om.build_likelihood(oracle_noise(spec, zs))
+    assert abs(elbo - ref) <= 1e-4 * abs(ref), (elbo, ref)
+    L_NK, _, means_o, covs_o, samples_o = om.log_weights(oracle_noise(spec, zs))
+    mx = L_NK.max(1)
+    logp_o = mx + np.log(np.exp(L_NK - mx[:, None]).sum(1)) - np.log(K)
+    np.testing.assert_allclose(_np(model.E_log_p_Y(zd)), logp_o, rtol=2e-4, atol=2e-2)
+    fmean, fvar, _, _, samples, means, covs = model._forward_iw(zd)
+    for i in range(len(spec["layers"]) - 1):
+        np.testing.assert_allclose(_np(means[i]), means_o[i], rtol=2e-3, atol=1e-3)
+        np.testing.assert_allclose(_np(samples[i]), samples_o[i], rtol=2e-3, atol=2e-3)
+    np.testing.assert_allclose(_np(fmean), means_o[-1], rtol=2e-3, atol=2e-3)
+    vo = np.diagonal(covs_o[-1], axis1=-2, axis2=-1).transpose(0, 2, 1)
+    np.testing.assert_allclose(_np(fvar), vo, rtol=5e-3, atol=2e-4)
