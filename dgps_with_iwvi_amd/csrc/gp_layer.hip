@@ -65,7 +65,7 @@ __global__ __launch_bounds__(256) void k_fullcov(const float* __restrict__ F, co
 // (correct, latency-bound: only the 2-D predict path with a consumed inner-layer sample gets there).
 // The block is a float32 difference k - a.a + u.u: for (near-)singular blocks -- X tiled over K gives rank-1 blocks,
 // a "zero" inner layer gives pure rounding noise -- it is indefinite by rounding where the float64 reference's is barely
-// positive.  So the factorisation is the rounding-tolerant PSD form: a non-positive pivot zeroes its column (no component
+// positive.  So the factorisation is the rounding-tolerant PSD form: a pivot <= 1e-6 C_jj zeroes its column (no component
 // along that direction) and every entry is clamped to |L_ij| <= sqrt(C_ii), the bound any PSD factor obeys, which keeps
 // a tiny pivot from amplifying rounding noise.  On a well-conditioned block this is the plain Cholesky factor.
 constexpr int MVN_LDS_N = 192;
@@ -90,13 +90,15 @@ __global__ __launch_bounds__(256) void k_mvn_sample(const float* __restrict__ me
     for (int j = 0; j < N; ++j) {
         __syncthreads();
         const float d = Lm[(size_t)j * N + j];
-        const float inv = d > 0.f ? rsqrtf(d) : 0.f;
+        // a pivot below 1e-6 of its original diagonal entry is float32 cancellation noise (~16 ulp), not signal
+        const bool live = d > 1e-6f * bound[j] * bound[j];
+        const float inv = live ? rsqrtf(d) : 0.f;
         __syncthreads();
         for (int i = j + 1 + tid; i < N; i += 256) {
             const float b = bound[i];
             Lm[(size_t)i * N + j] = fminf(fmaxf(Lm[(size_t)i * N + j] * inv, -b), b);
         }
-        if (tid == 0) Lm[(size_t)j * N + j] = d > 0.f ? fminf(d * inv, bound[j]) : 0.f;
+        if (tid == 0) Lm[(size_t)j * N + j] = live ? fminf(d * inv, bound[j]) : 0.f;
         __syncthreads();
         const long long n = N - j - 1;
         for (long long idx = tid; idx < n * n; idx += 256) {

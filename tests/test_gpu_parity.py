@@ -206,8 +206,9 @@ def test_conditional_argument_errors(gpu_device):
         cond(X, feat, k, f, full_output_cov=True, white=True)
     with pytest.raises(ValueError):
         cond(X, feat, k, f, q_sqrt=torch.zeros(1, 1, 4, 4, device=gpu_device), white=True)
-    with pytest.raises(NotImplementedError):
-        cond(X, feat, k, f, white=False)
+    with pytest.raises(ValueError):                              # a precomputed state holds whitened operands
+        cond(X, feat, k, f, white=False, precomputed=True)
+    cond(X, feat, k, f, white=False)                             # white=False itself is implemented (:63-65)
     # diagonal q_sqrt [M, R] (:72-73) and q_sqrt None are accepted
     s, m, v = cond(X, feat, k, f, q_sqrt=torch.ones(4, 1, device=gpu_device), white=True,
                    z=torch.zeros(2, 3, 1, device=gpu_device))

@@ -391,16 +391,17 @@ def test_mvn_sample_large_block(gpu_device):
         nws = _abi.lib().iwvi_mvn_sample_ws_bytes(S, N, R)
         assert (nws > 0) == (N > 192)
         ws = torch.empty(max(nws, 1), dtype=torch.uint8, device=gpu_device)
-        _abi.check(_abi.lib().iwvi_mvn_sample(_abi.ptr(_t(mean, gpu_device)), _abi.ptr(_t(cov, gpu_device)), _abi.ptr(_t(z, gpu_device)),
+        md, cd, zd = _t(mean, gpu_device), _t(cov, gpu_device), _t(z, gpu_device)      # named: alive until the launch has run
+        _abi.check(_abi.lib().iwvi_mvn_sample(_abi.ptr(md), _abi.ptr(cd), _abi.ptr(zd),
                                               _abi.ptr(out), S, N, R, 0.0, _abi.ptr(ws), _abi.stream_ptr()))
         ref = mean.astype(np.float64) + np.einsum("srij,srj->sir", np.linalg.cholesky(cov.astype(np.float64)), z.astype(np.float64))
         np.testing.assert_allclose(_np(out), ref, rtol=1e-3, atol=1e-3)
     rank1 = np.ones((1, 1, 4, 4), np.float32) * 2.25                              # pivots 2.25, 0, 0, 0 -> L = 1.5 e_1 1^T
     out = torch.empty(1, 4, 1, device=gpu_device)
     zz = torch.tensor([[[2.0, 7.0, -3.0, 5.0]]], device=gpu_device)
-    _abi.check(_abi.lib().iwvi_mvn_sample(_abi.ptr(torch.zeros(1, 4, 1, device=gpu_device)), _abi.ptr(_t(rank1, gpu_device)),
-                                          _abi.ptr(zz), _abi.ptr(out), 1, 4, 1, 0.0, None, _abi.stream_ptr()))
-    assert torch.equal(out.reshape(-1), torch.full((4,), 3.0, device=gpu_device))     # perfectly correlated: one draw for all
+    m0, c1 = torch.zeros(1, 4, 1, device=gpu_device), _t(rank1, gpu_device)
+    _abi.check(_abi.lib().iwvi_mvn_sample(_abi.ptr(m0), _abi.ptr(c1), _abi.ptr(zz), _abi.ptr(out), 1, 4, 1, 0.0, None, _abi.stream_ptr()))
+    np.testing.assert_allclose(_np(out).reshape(-1), 3.0, rtol=1e-6)                   # perfectly correlated: one draw for all
 
 
 # ------------------------------------------------------------------------------------------
