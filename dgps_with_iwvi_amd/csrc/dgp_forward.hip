@@ -50,6 +50,7 @@ typedef __attribute__((address_space(1))) f32x4* gout4;
 
 static unsigned long long* g_stamp_buf = nullptr;   // diagnostic; see iwvi_debug_set_stamps
 static long long g_stamp_wgs = 0;
+static int g_dbg_exit = 0;                           // diagnostic; see iwvi_debug_set_exit
 
 constexpr int XSTR_MAX = 37;          // largest row stride (floats) of the activation tiles: D, P <= 32, D + 2 <= 36
 constexpr int FW_MAXNS = 5;
@@ -126,6 +127,7 @@ struct FwHead {
     int layer_base;                  // index of this stack's first layer in the model (keys the noise streams)
     int x_per_sample;                // X has one row per sample (the output of a layer evaluated before this launch)
     int xstr;                        // row stride of the activation tiles: odd, >= max(D + 2 padded to 4, P) of the stack
+    int dbg_exit;                    // diagnostic only (iwvi_debug_set_exit): leave after phase N (1: at once, 2: after the prologue)
     FwLds lds;
     FwElbo e;
 };
@@ -134,8 +136,25 @@ struct FwHead {
 struct alignas(16) FwCopy { const float* src; int n; int dst; };           // n floats to LDS float offset dst; n < 0: 16-byte pieces
 struct alignas(16) FwNoise { const float* src; int dims, z_off, zero, layer; int pad[2]; };   // 32 bytes: one batched LDS read
 constexpr int FW_MAX_COPY = 6 * IWVI_MAX_STACK;
+// What the layer loop reads of a layer, 32 words, fetched through the SCALAR cache straight from the kernel-argument
+// segment (two s_load_dwordx16, no VALU): making the same values wave-uniform from the LDS copy of the table costs an
+// LDS read + v_readfirstlane per word in each of the eight waves -- ~0.5 us per layer.  The lines are requested first
+// thing in the kernel (warm_hot) so that they have arrived when the first layer starts.  Optional per-layer outputs
+// (sample / mean / var / noise / the adjoint's a, u, gmv; kl_local) stay in the LDS table and are read only when
+// FWF_ANY_OUT says there is one (never on the ELBO path).
+enum { FWF_NX_GP = 1, FWF_NX_RBF = 2, FWF_HASW = 4, FWF_HAS_MFB = 8, FWF_ANY_OUT = 16, FWF_PRE_ENC = 32, FWF_SAMPLED_KL = 64 };
+struct alignas(64) FwHot {
+    int type, D, c_off, z_off, flags;
+    int nx_c_off, nx_nsteps, nx_ls_off, nx_ls_n;
+    int M, Mp, nbk, nrb, nsteps, R, P, kern_type, mf_type, zt_off, ls_off;   // LV layer: R = Lw, nbk = n_enc, Mp = maxdim
+    float variance;
+    int pad0;
+    const float* nx_ls; const f32x4* LrTP; const f32x4* QmuP; const f32x4* LsP; const float* ZtP;   // LV: LrTP = enc_out
+};
+static_assert(sizeof(FwHot) == 128, "two scalar-cache lines per layer");
 struct FwArgs {
     FwHead h;
+    FwHot H[IWVI_MAX_STACK];
     FwLayer L[IWVI_MAX_STACK];
     FwNoise N[IWVI_MAX_STACK];
     FwCopy C[FW_MAX_COPY];
@@ -398,6 +417,14 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
     const int nvalid = (int)((g.T - t0) < (long long)NSAMP ? (g.T - t0) : (long long)NSAMP);
 
     float* sm = reinterpret_cast<float*>(fw_smem);
+    // ---- the hot layer descriptors: one word of each 64-byte line requested through the scalar cache now (all in
+    //      flight beside the header's own miss); consumed -- i.e. waited for -- just before the first barrier --------
+    unsigned hot_touch = 0;
+    {
+        const unsigned* hw = reinterpret_cast<const unsigned*>(&gk.H[0]);
+#pragma unroll
+        for (int i = 0; i < (int)(sizeof(FwHot) * IWVI_MAX_STACK / 64); ++i) hot_touch |= hw[16 * i];
+    }
     // ---- layer table: kernarg -> LDS, every dword in flight at once ------------------------------------
     {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -434,6 +461,7 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
 
     const unsigned long long step = g.rng_state ? g.rng_state[0] : 0ULL;
     FW_STAMP(0);
+    if (g.dbg_exit == 1) return;
 
     // ================= prologue: everything small -> LDS, all loads in flight at once ==================
     const unsigned ut0 = (unsigned)t0, uT = (unsigned)g.T;
@@ -475,15 +503,16 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
             xyrows[p * xs + i] = g.XY[(size_t)row_of((unsigned)p) * g.XYdim + i];
         }
     }
+    asm volatile("" :: "s"(hot_touch));                           // (the scalar-cache lines of gk.H have landed)
     __syncthreads();                                              // layer table (and rowi / pidx) visible
     FW_STAMP(56);
     // precomputed encoder outputs of the chunk's distinct data points -> the LV layer's constant block
     for (int li = 0; li < g.n_layers; ++li) {
-        if (ufirst(LT[li].type) != IWVI_LAYER_LV) continue;
-        const float* eo = ufirst(LT[li].lv.enc_out);
-        if (!eo) continue;
-        const int no = 2 * ufirst(LT[li].lv.Lw);
-        float* dst = sm + ufirst(LT[li].c_off);
+        const FwHot& Hp = gk.H[li];
+        if (Hp.type != IWVI_LAYER_LV || !(Hp.flags & FWF_PRE_ENC)) continue;
+        const float* eo = reinterpret_cast<const float*>(Hp.LrTP);
+        const int no = 2 * Hp.R;
+        float* dst = sm + Hp.c_off;
         const float rcp = 1.0f / (float)no;
         for (int i0 = (tid & ~63); i0 < npts * no; i0 += FW_THREADS) {     // a gather by LDS-DMA: nothing waits here
             const int idx = i0 + lane;
@@ -495,8 +524,8 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
     }
     // copy list: one entry per wave at a time, all DMA loads in flight together
     if (g.ls_first >= 0) {                                         // the largest piece first (36 KiB at M = 128), spread over every wave
-        const FwGp& G0 = LT[g.ls_first].gp;
-        async_copy_f32x4(reinterpret_cast<const float*>(ufirst(G0.LsP)), sm + ufirst(G0.ls_off), tri_blocks(ufirst(G0.nbk)) * BLK16, tid);
+        const FwHot& G0 = gk.H[g.ls_first];
+        async_copy_f32x4(reinterpret_cast<const float*>(G0.LsP), sm + G0.ls_off, tri_blocks(G0.nbk) * BLK16, tid);
     }
     for (int ci = wave; ci < g.ncopy; ci += FW_WAVES) {
         const FwCopy ce = uniform_words(CT[ci]);                   // one 16-byte LDS read per entry
@@ -550,32 +579,38 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
     FW_STAMP(59);
     __syncthreads();
     FW_STAMP(1);
+    if (g.dbg_exit == 2) return;
 
     int xt_for = -1;                                              // layer whose Gram operand x~ is already in `xt`
     for (int li = 0; li < g.n_layers; ++li) {
         const FwLayer& L = LT[li];
-        const FwHeadGp U = uniform_words(reinterpret_cast<const FwHeadGp&>(L));   // (gp part meaningful for GP layers only)
-        const FwLayerHead& H = U.h;
+        const FwHot& H = gk.H[li];                                // scalar loads from the (warmed) kernel-argument lines
+        const FwHot& G = H;
         const int D = H.D;
         const float* cst = sm + H.c_off;
         const float* zl = znoise + H.z_off;
-        const gout1 o_sample = (gout1)H.sample, o_mean = (gout1)H.mean, o_var = (gout1)H.var;
-        const gout1 o_noise = (gout1)H.noise_out;
+        // optional outputs: from the LDS table, and only when the launch has any
+        gout1 o_sample = nullptr, o_mean = nullptr, o_var = nullptr, o_noise = nullptr, o_gmv = nullptr, o_a = nullptr, o_u = nullptr, o_kl = nullptr;
+        if (H.flags & FWF_ANY_OUT) {
+            o_sample = (gout1)ufirst(L.sample); o_mean = (gout1)ufirst(L.mean); o_var = (gout1)ufirst(L.var);
+            o_noise = (gout1)ufirst(L.noise_out);
+            if (H.type == IWVI_LAYER_GP) { o_gmv = (gout1)ufirst(L.gmv_out); o_a = (gout1)ufirst(L.gp.a_out); o_u = (gout1)ufirst(L.gp.u_out); }
+            else o_kl = (gout1)ufirst(L.lv.kl_local);
+        }
         // a following GP layer gets its Gram operand from this layer's last phase (no phase of its own)
-        const bool nx_gp = H.nx_gp != 0, nx_rbf = H.nx_rbf != 0;
+        const bool nx_gp = (H.flags & FWF_NX_GP) != 0, nx_rbf = (H.flags & FWF_NX_RBF) != 0;
         const float* nx_cst = sm + H.nx_c_off;
         const int nx_nsteps = H.nx_nsteps;
         if (H.type == IWVI_LAYER_LV) {
             // ================= LatentVariableLayer (layers.py:72-105) =================================
             const FwLv& V = L.lv;
-            const int Lw = ufirst(V.Lw), Do = D + Lw, n_enc = ufirst(V.n_enc), sampled_kl = ufirst(V.sampled_kl);
-            const gout1 o_kl = (gout1)ufirst(V.kl_local);
-            const int mdim = up4(ufirst(V.maxdim));
+            const int Lw = H.R, Do = D + Lw, n_enc = H.nbk, sampled_kl = (H.flags & FWF_SAMPLED_KL) ? 1 : 0;
+            const int mdim = up4(H.Mp);
             float* act0 = scratch;
             float* act1 = act0 + NSAMP * mdim;
             const float* in = xyrows; int in_str = up4(g.XYdim);
             float* out = act0;
-            const bool pre_enc = ufirst(V.enc_out) != nullptr;    // encoder already evaluated by iwvi_model_precompute
+            const bool pre_enc = (H.flags & FWF_PRE_ENC) != 0;    // encoder already evaluated by iwvi_model_precompute
             if (pre_enc) { in = cst; in_str = 2 * Lw; }
             else {
                 int off = 0;
@@ -644,7 +679,6 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
             FW_STAMP(2 + li * 6 + 5);
         } else {
             // ================= GPLayer (layers.py:35-50) ==============================================
-            const FwGp& G = U.gp;
             const int nbk = G.nbk, R = G.R, P = G.P, nsteps = G.nsteps;
             f32x4* kuf = reinterpret_cast<f32x4*>(scratch);
             f32x4* at = kuf;                                       // solved in place (stage 1)
@@ -778,7 +812,7 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
             if (split5 && wave >= FW_WAVES / 2) {
                 const int c = wave - FW_WAVES / 2, bi = 4 + c, tcol = 16 * (NS - 1) + jq;
                 const f32x4* Al = reinterpret_cast<const f32x4*>(sm + G.ls_off) + lane;
-                const gout1 arow = (G.a_out && tcol < nvalid) ? (gout1)G.a_out + (size_t)(t0 + tcol) * G.Mp : (gout1)nullptr;
+                const gout1 arow = (o_a && tcol < nvalid) ? o_a + (size_t)(t0 + tcol) * G.Mp : (gout1)nullptr;
                 int* flag = counters + 4;                          // [0]: a_top is in the tile; [1]: rows of r_bot written
                 __builtin_amdgcn_s_setprio(2);                     // the split solve is the long dependent path of the phase
                 f32x4 a[4];
@@ -816,7 +850,7 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
             if (wave < nchain) {
                 const int tcol = 16 * wave + jq;                  // this lane's sample column
                 gptr4 Ap = (gptr4)G.LsP + lane;
-                const gout1 arow = (G.a_out && tcol < nvalid) ? (gout1)G.a_out + (size_t)(t0 + tcol) * G.Mp : (gout1)nullptr;
+                const gout1 arow = (o_a && tcol < nvalid) ? o_a + (size_t)(t0 + tcol) * G.Mp : (gout1)nullptr;
                 float ssq = 0.f;
                 if (G.ls_off >= 0 && nbk <= 8) {
                     const f32x4* Al = reinterpret_cast<const f32x4*>(sm + G.ls_off) + lane;      // staged in LDS
@@ -860,8 +894,8 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
                         for (int s = 0; s < 4; ++s) res = __builtin_amdgcn_mfma_f32_16x16x4f32(Dv[s], xcur[s], res, 0, 0, 0);
                         at[(bj * 4 + gq) * NSAMP + tcol] = res;
                         ssq += colsumsq4(res);
-                        if (G.a_out && tcol < nvalid)
-                            *((gout4)((gout1)G.a_out + (size_t)(t0 + tcol) * G.Mp + 16 * bj + 4 * gq)) = res;
+                        if (o_a && tcol < nvalid)
+                            *((gout4)(o_a + (size_t)(t0 + tcol) * G.Mp + 16 * bj + 4 * gq)) = res;
                         for (int b0 = 0; b0 < m; b0 += 4) {
                             f32x4 A[4], y[4];
 #pragma unroll
@@ -989,12 +1023,12 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
                                 brow = brow_n;
                                 if (--c == 0) {
                                     // row-block (r, bi) complete: add its squares, start the next one
-                                    if (G.u_out) {
+                                    if (o_u) {
 #pragma unroll
                                         for (int t = 0; t < NS; ++t) {
                                             const int j = 16 * t + jq;
                                             if (j < nvalid)
-                                                *((gout4)((gout1)G.u_out + ((size_t)r * g.T + (t0 + j)) * G.Mp + 16 * bi + 4 * gq)) = acc[t];
+                                                *((gout4)(o_u + ((size_t)r * g.T + (t0 + j)) * G.Mp + 16 * bi + 4 * gq)) = acc[t];
                                         }
                                     }
 #pragma unroll
@@ -1039,8 +1073,8 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
                 gbuf[(0 * R + r) * NSAMP + j] = mu;
                 gbuf[(1 * R + r) * NSAMP + j] = v;
                 gbuf[(2 * R + r) * NSAMP + j] = gs;
-                if (H.gmv_out && j < nvalid) {                   // what the adjoint's heads need per latent GP (csrc/backward.hip)
-                    const gout1 o = (gout1)H.gmv_out + (size_t)(t0 + j) * 3 * R;
+                if (o_gmv && j < nvalid) {                       // what the adjoint's heads need per latent GP (csrc/backward.hip)
+                    const gout1 o = o_gmv + (size_t)(t0 + j) * 3 * R;
                     o[r] = gs; o[R + r] = mu; o[2 * R + r] = v;
                 }
             }
@@ -1059,7 +1093,7 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
                     const int p = idx / NSAMP, j = idx - p * NSAMP;
                     const long long t = t0 + j;
                     float o_s, o_m, o_v;
-                    if (G.W) {
+                    if (G.flags & FWF_HASW) {
                         o_s = o_m = o_v = 0.f;
                         if (need_mv) {
                             for (int r0 = 0; r0 < R; r0 += 4) {
@@ -1083,7 +1117,7 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
                     if (G.mf_type == IWVI_MF_IDENTITY) mf = xin[j * XSTR + p];
                     else if (G.mf_type == IWVI_MF_LINEAR) {
                         mf = dot_lds(xin + j * XSTR, 1, mfA + p, P, D);
-                        if (G.mfb) mf += mfb[p];
+                        if (G.flags & FWF_HAS_MFB) mf += mfb[p];
                     }
                     xout[j * XSTR + p] = o_s + mf;
                     if (last) { obuf[p * NSAMP + j] = o_m + mf; obuf[(P + p) * NSAMP + j] = o_v; }
@@ -1098,7 +1132,7 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
                 const long long t = t0 + j;
                 const int Dm = (G.mf_type == IWVI_MF_LINEAR) ? D : 0;
                 const int npb = (P + 15) >> 4;                    // 16-row blocks of outputs: 1 or 2
-                const bool hasW = G.W != nullptr;
+                const bool hasW = (G.flags & FWF_HASW) != 0;
                 const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
                 f32x4 acc_s[2] = {zero4, zero4}, acc_m[2] = {zero4, zero4}, acc_v[2] = {zero4, zero4};
                 const float* gm = gbuf; const float* gv = gbuf + R * NSAMP; const float* gs = gbuf + 2 * R * NSAMP;
@@ -1144,7 +1178,7 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
                     }
                 }
                 // what the product does not already carry: identity mean function, or the linear one's bias
-                const bool mf_id = G.mf_type == IWVI_MF_IDENTITY, mf_b = G.mf_type == IWVI_MF_LINEAR && G.mfb;
+                const bool mf_id = G.mf_type == IWVI_MF_IDENTITY, mf_b = G.mf_type == IWVI_MF_LINEAR && (G.flags & FWF_HAS_MFB);
                 const float* mfp = mf_id ? xin + j * XSTR : (mf_b ? mfb : cst);
                 float n2 = 0.f;
 #pragma unroll
@@ -1623,9 +1657,36 @@ int dgp_forward_impl(const iwvi_layer_desc* layers, int n_layers, const float* X
         if (lds_bytes <= LDS_MAX) break;
     }
     if (ns < 1) { set_error("iwvi_dgp_forward: the layer stack needs %zu B of LDS per 16 samples (> 160 KiB)", lds_bytes); return IWVI_ERR_UNSUPPORTED; }
+    for (int i = 0; i < n_layers; ++i) {                 // the scalar-path copy of what the layer loop reads (after the LDS plan)
+        const FwLayer& L = a.L[i];
+        FwHot& H = a.H[i];
+        H = FwHot{};
+        H.type = L.type; H.D = L.D; H.c_off = L.c_off; H.z_off = L.z_off;
+        H.nx_c_off = L.nx_c_off; H.nx_nsteps = L.nx_nsteps; H.nx_ls_off = L.nx_ls_off; H.nx_ls_n = L.nx_ls_n; H.nx_ls = L.nx_ls;
+        int fl = (L.nx_gp ? FWF_NX_GP : 0) | (L.nx_rbf ? FWF_NX_RBF : 0);
+        if (L.noise_out || L.sample || L.mean || L.var || L.gmv_out) fl |= FWF_ANY_OUT;
+        if (L.type == IWVI_LAYER_GP) {
+            const FwGp& G = L.gp;
+            H.M = G.M; H.Mp = G.Mp; H.nbk = G.nbk; H.nrb = G.nrb; H.nsteps = G.nsteps; H.R = G.R; H.P = G.P;
+            H.kern_type = G.kern_type; H.mf_type = G.mf_type; H.zt_off = G.zt_off; H.ls_off = G.ls_off; H.variance = G.variance;
+            H.LrTP = G.LrTP; H.QmuP = G.QmuP; H.LsP = G.LsP; H.ZtP = G.ZtP;
+            if (G.W) fl |= FWF_HASW;
+            if (G.mfb) fl |= FWF_HAS_MFB;
+            if (G.a_out || G.u_out) fl |= FWF_ANY_OUT;
+        } else {
+            const FwLv& V = L.lv;
+            H.R = V.Lw; H.nbk = V.n_enc; H.Mp = V.maxdim;
+            H.LrTP = reinterpret_cast<const f32x4*>(V.enc_out);
+            if (V.enc_out) fl |= FWF_PRE_ENC;
+            if (V.sampled_kl) fl |= FWF_SAMPLED_KL;
+            if (V.kl_local) fl |= FWF_ANY_OUT;
+        }
+        H.flags = fl;
+    }
     const long long chunks = (T + 16 * ns - 1) / (16 * ns);
     if (chunks > 0x7fffffffLL) { set_error("iwvi_dgp_forward: T too large"); return IWVI_ERR_ARG; }
     a.h.stamps = (g_stamp_buf && chunks <= g_stamp_wgs) ? g_stamp_buf : nullptr;
+    a.h.dbg_exit = g_dbg_exit;
     switch (ns) {
         case 1: return launch_forward<1>(a, (unsigned)chunks, lds_bytes, stream);
         case 2: return launch_forward<2>(a, (unsigned)chunks, lds_bytes, stream);
@@ -1650,6 +1711,7 @@ extern "C" int iwvi_dgp_forward(const iwvi_layer_desc* layers, int n_layers, con
 /* diagnostic (not part of the drop-in surface): register a device buffer of 128 * max_workgroups 64-bit words;
  * every fused-forward launch with at most max_workgroups workgroups then stamps its phase boundaries
  * ([k] 100 MHz wall clock, [64 + k] shader clock) into it.  NULL switches stamping off. */
+extern "C" void iwvi_debug_set_exit(int phase) { iwvi::g_dbg_exit = phase; }   /* diagnostic: fused-forward launches return after phase N */
 extern "C" void iwvi_debug_set_stamps(void* buf, int64_t max_workgroups) {
     iwvi::g_stamp_buf = (unsigned long long*)buf;
     iwvi::g_stamp_wgs = buf ? max_workgroups : 0;
