@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libiwvi_hip.so")
 
 KERN_RBF, KERN_MATERN52 = 0, 1
 LAYER_GP, LAYER_LV = 0, 1
-ABI_VERSION = 5
+ABI_VERSION = 6
 GP_WANT_DENSE = 1
 MAX_STACK = 8
 MF_ZERO, MF_IDENTITY, MF_LINEAR = 0, 1, 2
@@ -81,7 +81,7 @@ class GpBwdDesc(ctypes.Structure):
                 ("d_sample", c_void_p), ("d_mean", c_void_p), ("d_var", c_void_p), ("kl_weight", c_double),
                 ("dF", c_void_p), ("dZ", c_void_p), ("dls", c_void_p), ("dvariance", c_void_p),
                 ("dq_mu", c_void_p), ("dq_sqrt", c_void_p), ("dW", c_void_p), ("dmf_A", c_void_p),
-                ("side_stream", c_void_p), ("side_stream2", c_void_p)]
+                ("side_stream", c_void_p), ("side_stream2", c_void_p), ("prepared", ctypes.c_int32)]
 
 
 class AdamTensor(ctypes.Structure):
@@ -104,6 +104,7 @@ PROTOTYPES = {
     "iwvi_chol_factor": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "iwvi_gp_layer_backward_ws_bytes": (c_size_t, [c_int64, c_int, c_int, c_int]),
     "iwvi_gp_layer_backward": (c_int, [ctypes.POINTER(GpBwdDesc), c_int64, c_void_p, c_void_p]),
+    "iwvi_gp_layer_backward_prepare": (c_int, [ctypes.POINTER(GpBwdDesc), c_int64, c_void_p, c_void_p]),
     "iwvi_iw_elbo_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, ctypes.POINTER(c_void_p),
                                       ctypes.POINTER(ctypes.c_int32), c_int, c_int64, c_int, c_float, c_double, c_int,
                                       c_void_p, c_void_p, c_void_p, ctypes.POINTER(c_void_p), ctypes.POINTER(ctypes.c_int32), c_int,

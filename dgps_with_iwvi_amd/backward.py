@@ -30,6 +30,14 @@ class GpSaved:
     __slots__ = ("F", "noise", "A", "U", "sample", "mean", "var", "T", "GMV")
 
 
+def needs_saved_u(M, T):
+    """The adjoint's streaming chain (csrc/backward.hip: k_bw_chain; M a multiple of 16 up to 128, T a multiple of 16) works
+    from a = Lm^-1 k alone; every other shape takes the GEMM path, which also reads the forward's u_r = L_r^T a."""
+    import os
+    ok = M % 16 == 0 and M <= 128 and T % 16 == 0 and not os.environ.get("IWVI_BW_UNFUSED") and not os.environ.get("IWVI_BW_OLD_CHAIN")
+    return not ok
+
+
 def _words(device):
     return torch.zeros(4, dtype=torch.int64, device=device)
 
@@ -60,12 +68,14 @@ def gp_forward_saved(layer, F, z=None, words=None, precomputed=False):
     s = GpSaved()
     s.F, s.T, s.GMV = F, T, None
     s.A = torch.empty(T, Mp, dtype=settings.float_type, device=dev)
-    s.U = torch.empty(R, T, Mp, dtype=settings.float_type, device=dev)
+    s.U = torch.empty(R, T, Mp, dtype=settings.float_type, device=dev) if needs_saved_u(layer.num_inducing, T) else None
     s.noise = torch.empty(T, R, dtype=settings.float_type, device=dev)
     s.sample, s.mean, s.var = (torch.empty(T, P, dtype=settings.float_type, device=dev) for _ in range(3))
     z2 = None if z is None else _abi.dev_tensor(z.reshape(T, R).contiguous(), "z")
     s.GMV = torch.empty(T, 3 * R, dtype=settings.float_type, device=dev)
-    outs = dict(sample=s.sample, mean=s.mean, var=s.var, a_out=s.A, u_out=s.U, noise_out=s.noise, gmv_out=s.GMV)
+    outs = dict(sample=s.sample, mean=s.mean, var=s.var, a_out=s.A, noise_out=s.noise, gmv_out=s.GMV)
+    if s.U is not None:
+        outs["u_out"] = s.U
     ld, keep = layer.fused_desc(z2, outs)
     descs = (_abi.LayerDesc * 1)(ld)
     words = _words(dev) if words is None else words
@@ -75,9 +85,49 @@ def gp_forward_saved(layer, F, z=None, words=None, precomputed=False):
     return s
 
 
+def _param_desc(layer, dense_state=None):
+    """The parameter part of an ``iwvi_gp_bwd_desc`` (all ``iwvi_gp_layer_backward_prepare`` reads) + the tensors to keep alive."""
+    M, R = layer.num_inducing, layer.num_outputs
+    kern = layer._base_kern()
+    b = _abi.GpBwdDesc()
+    Z, q_mu, q_sqrt = (_abi.dev_tensor(t.contiguous(), n) for t, n in ((layer._Z(), "Z"), (layer.q_mu, "q_mu"), (layer.q_sqrt, "q_sqrt")))
+    b.state = (dense_state or layer.state()).buf.data_ptr()
+    b.Z, b.lengthscales = Z.data_ptr(), kern.lengthscales.data_ptr()
+    b.q_mu, b.q_sqrt, b.variance = q_mu.data_ptr(), q_sqrt.data_ptr(), kern.variance
+    b.M, b.D, b.R, b.kern_type = M, Z.shape[1], R, kern.kern_type
+    return b, [Z, q_mu, q_sqrt]
+
+
+def prepare_side(model, T, stream):
+    """On ``stream``, beside the forward: the dense float64 factors of every GP layer (into its second state buffer) and the
+    parameter-only part of its adjoint (``iwvi_gp_layer_backward_prepare``: scaled inducing inputs, packed S_r = L_r L_r^T and
+    Lm^-T).  -> {layer index: (workspace, dense state)}; the caller joins ``stream`` before the first ``gp_backward``."""
+    gps = [(i, l) for i, l in enumerate(model.layers) if isinstance(l, GPLayer)]
+    dev = model.X.device
+    out = {}
+    for i, l in gps:                                             # (allocated on the caller's stream, used on both after the joins)
+        D = l._Z().shape[1]
+        ws = torch.empty(_abi.lib().iwvi_gp_layer_backward_ws_bytes(T, l.num_inducing, D, l.num_outputs), dtype=torch.uint8, device=dev)
+        out[i] = (ws, l.state_dense())
+    if stream != torch.cuda.current_stream():
+        stream.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(stream):
+        descs = []
+        for i, l in gps:
+            d = l.state_desc(state=out[i][1])
+            d.flags = _abi.GP_WANT_DENSE
+            descs.append(d)
+        precompute_states(descs)
+        for i, l in gps:
+            b, keep = _param_desc(l, out[i][1])
+            _abi.check(_abi.lib().iwvi_gp_layer_backward_prepare(ctypes.byref(b), T, out[i][0].data_ptr(), _abi.stream_ptr()))
+    return out
+
+
 def gp_backward(layer, saved, d_sample=None, d_mean=None, d_var=None, kl_weight=1.0, want_dF=True, side_stream=None, keep=None,
-                side_stream2=None):
-    """``iwvi_gp_layer_backward``: upstream gradients [T, P] -> dict(dF [T, D], dZ, dls, dvariance, dq_mu, dq_sqrt)."""
+                side_stream2=None, prepared=None):
+    """``iwvi_gp_layer_backward``: upstream gradients [T, P] -> dict(dF [T, D], dZ, dls, dvariance, dq_mu, dq_sqrt).
+    ``prepared`` = (workspace, dense state) from ``prepare_side``."""
     dev = saved.F.device
     T, D = saved.F.shape
     M, R = layer.num_inducing, layer.num_outputs
@@ -94,19 +144,19 @@ def gp_backward(layer, saved, d_sample=None, d_mean=None, d_var=None, kl_weight=
         out["dW"] = torch.empty(P, R, dtype=ft, device=dev)
     if layer.mean_function.mf_type == _abi.MF_LINEAR:
         out["dmf_A"] = torch.empty(D, P, dtype=ft, device=dev)
-    b = _abi.GpBwdDesc()
-    Z, q_mu, q_sqrt = (_abi.dev_tensor(t.contiguous(), n) for t, n in ((layer._Z(), "Z"), (layer.q_mu, "q_mu"), (layer.q_sqrt, "q_sqrt")))
-    b.state, b.Z, b.lengthscales = layer.state().buf.data_ptr(), Z.data_ptr(), kern.lengthscales.data_ptr()
-    b.q_mu, b.q_sqrt, b.variance = q_mu.data_ptr(), q_sqrt.data_ptr(), kern.variance
-    b.M, b.D, b.R, b.P, b.kern_type = M, D, R, P, kern.kern_type
+    b, keep_t = _param_desc(layer, prepared[1] if prepared else None)
+    b.P = P
+    b.prepared = 1 if prepared else 0
     mf = layer.mean_function
     b.mf_type = mf.mf_type
-    keep_t = [Z, q_mu, q_sqrt, W]
+    keep_t.append(W)
     if W is not None:
         b.W = W.data_ptr()
     if mf.mf_type == _abi.MF_LINEAR:
         b.mf_A = _abi.dev_tensor(mf.A, "mean_function.A").data_ptr()
-    b.F, b.noise, b.A, b.U = saved.F.data_ptr(), saved.noise.data_ptr(), saved.A.data_ptr(), saved.U.data_ptr()
+    b.F, b.noise, b.A = saved.F.data_ptr(), saved.noise.data_ptr(), saved.A.data_ptr()
+    if saved.U is not None:
+        b.U = saved.U.data_ptr()
     if saved.GMV is not None:
         b.GMV = saved.GMV.data_ptr()
     for name, t in (("d_sample", d_sample), ("d_mean", d_mean), ("d_var", d_var)):
@@ -117,7 +167,7 @@ def gp_backward(layer, saved, d_sample=None, d_mean=None, d_var=None, kl_weight=
     b.kl_weight = float(kl_weight)
     for k, t in out.items():
         setattr(b, k, t.data_ptr())
-    ws = torch.empty(_abi.lib().iwvi_gp_layer_backward_ws_bytes(T, M, D, R), dtype=torch.uint8, device=dev)
+    ws = prepared[0] if prepared else torch.empty(_abi.lib().iwvi_gp_layer_backward_ws_bytes(T, M, D, R), dtype=torch.uint8, device=dev)
     if side_stream is not None:                                  # parameter gradients beside the next layer's adjoint
         b.side_stream = ctypes.c_void_p(side_stream.cuda_stream)
         if side_stream2 is not None:
@@ -191,9 +241,16 @@ def iw_elbo_and_gradients(model, zs=None, mode_vi=None, exchange=None, K_total=N
                                   "2 latent-variable layers (%d in this model)" % n_lv)
     has_lv = any(isinstance(l, LatentVariableLayer) for l in layers)
     XY = model._xy_minibatch() if has_lv else None
-    # forward: one factorisation launch (dense factors, encoders) + ONE fused layer launch that also leaves what the
-    # adjoints need in HBM (a = Lm^-1 k, u_r = L_r^T a, the draws, every layer's output rows)
-    model.precompute(with_encoders=True, dense=True)
+    # beside the forward, on its own stream: dense float64 factors + the parameter-only part of every layer's adjoint
+    cur = torch.cuda.current_stream()
+    import os
+    if os.environ.get("IWVI_BW_SINGLE_STREAM"):                  # diagnostic: everything on the caller's stream
+        overlap = False
+    prep_stream = _side_stream(dev, 2) if overlap else cur
+    prepared = prepare_side(model, T, prep_stream)
+    # forward: one factorisation launch (packed operands, encoders) + ONE fused layer launch that also leaves what the
+    # adjoints need in HBM (a = Lm^-1 k, the draws, every layer's output rows)
+    model.precompute(with_encoders=True)
     zflat = [None if z is None else z.reshape(T, -1) for z in zs]
     _, outs, _ = model._fused_forward(T, K, B, (T,), zs=zflat, sampled_kl=not mode_vi, want_layers=True, want_logw=False,
                                       want_saved=True)
@@ -208,7 +265,7 @@ def iw_elbo_and_gradients(model, zs=None, mode_vi=None, exchange=None, K_total=N
             saved.append(("lv", layer._enc_out, o["noise_out"], o["kl_local"], D_in))
         else:
             s = GpSaved()
-            s.F, s.T, s.A, s.U, s.noise, s.GMV = F, T, o["a_out"], o["u_out"], o["noise_out"], o["gmv_out"]
+            s.F, s.T, s.A, s.U, s.noise, s.GMV = F, T, o["a_out"], o.get("u_out"), o["noise_out"], o["gmv_out"]
             s.sample, s.mean, s.var = o["sample"], o["mean"], o["var"]
             saved.append(("gp", s))
         F = o["sample"]
@@ -239,7 +296,8 @@ def iw_elbo_and_gradients(model, zs=None, mode_vi=None, exchange=None, K_total=N
         glob_p, glob_n, len(glob), _abi.ptr(lse_g), int(K_total or K),
         ctypes.c_void_p(sums.data_ptr()), ctypes.c_void_p(ws.data_ptr()), _abi.stream_ptr()))
     grads = {"lik_var": sums[1]}
-    cur = torch.cuda.current_stream()
+    if prep_stream != cur:
+        cur.wait_stream(prep_stream)                             # dense factors and packed adjoint operands are ready
     side = _side_stream(dev) if overlap else None
     side2 = _side_stream(dev, 1) if overlap else None
     held = []
@@ -251,7 +309,7 @@ def iw_elbo_and_gradients(model, zs=None, mode_vi=None, exchange=None, K_total=N
             last = i == len(layers) - 1
             g = gp_backward(layer, s[1], d_sample=None if last else dF, d_mean=d_mean if last else None,
                             d_var=d_var if last else None, kl_weight=kl_weight, want_dF=i > 0,
-                            side_stream=side if i > 0 else None, keep=held,
+                            side_stream=side if i > 0 else None, keep=held, prepared=prepared.get(i),
                             # two concurrent chains only in the window where it was measured to pay (configs[2]: -4 %); smaller jobs are
                             # host-bound (+8 % at configs[1]), larger ones fill the GPU on their own (+3 % at configs[3])
                             side_stream2=side2 if (1 << 20) <= T * layer.num_inducing <= (1 << 23) else None)

@@ -878,6 +878,413 @@ static int launch_mid(hipStream_t st, const MidArgs& a) {
     return rc == IWVI_OK ? 1 : rc;
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// The per-sample chain, streaming form (M a multiple of 16 up to 128, T a multiple of 16): the structure of the fused
+// forward kernel applied to the adjoint.  Two identities remove the saved u_r = L_r^T a altogether:
+//     sum_r 2 dv_r L_r u_r = sum_r 2 dv_r S_r a,   S_r = L_r L_r^T            (this kernel: da)
+//     dL_r = tril(A^T diag(2 dv_r) U_r) = tril(G_r L_r),   G_r = A^T diag(2 dv_r) A   (a weighted Gram of A: split-K SYRK + k_gl_tril)
+// so the forward keeps only a (T x M floats instead of (R + 1) T x M), and the adjoint's largest product reads its A
+// operand -- the packed 16x16 blocks of S_r, prepared once per evaluation by k_pack_bw -- straight from L2 in MFMA
+// fragment order while the chunk's a tile sits in LDS in the forward's B-operand layout:
+//   phase 0  heads, a rows HBM -> LDS tile [(bk*4 + g) * NSAMP + sample] (float4 = 4 consecutive m of one sample); a workgroup
+//            (8 waves) owns 16 NS samples, NS chosen like the forward's so that every CU gets one workgroup
+//   phase 1  da(bi) = sum_r 2dv_r o [sum_bk S_r(bi, bk) a(bk)] - 2 (sum_r dv_r) a(bi) + sum_r q_mu_r(bi) dmu_r
+//            one wave per output row-block: R * nbk packed blocks streamed back to back, 4 NS MFMAs each
+//   phase 2  dk(bi) = sum_{bk >= bi} Lm^-T(bi, bk) da(bk)      packed upper blocks of Lm^-T; row-blocks paired (bi, nbk-1-bi)
+//   phase 3  kernel adjoint c = dk o dk/dr2..., dx~, dF, Qx rows (as k_bw_mid)
+// ------------------------------------------------------------------------------------------------------------
+typedef const __attribute__((address_space(1))) f32x4* bw_gptr4;
+struct ChainArgs {
+    const float* GMV; const float* eps; const float* W; const float* mfA; const float* dFs; const float* dFm; const float* dFv;
+    float* DMU; float* DV2; float* SDV; float* dF; int P, mf_type;
+    const float* A; int Mp; const float* q_mu;
+    const float* SP;                     // packed S_r blocks, [bi][r][bk], 256 floats each
+    const float* LinvTP;                 // packed upper blocks of Lm^-T, row-block major (tri_upper_off)
+    float* DK;
+    const float* F; const float* Zt; const float* invls; float* C; float* Qx;
+    long long T; int M, D, R, nbk; float variance; int kern_type; int dbg_exit;
+    int dsz;                             // floats of the da tile's LDS region (it also stages the heads' and the kernel adjoint's inputs)
+    // this workgroup's share of the thin sums over samples, each job [workgroups][len] at its own base (summed by k_reduce_multi):
+    float* p_qmu;                        // [M][R]      sum_j a[m][j] dmu[j][r]                      -> dq_mu
+    float* p_ctf;                        // [M][D + 1]  sum_j c[j][m] [F[j][d] | 1]                  -> dZ~ terms
+    float* p_q;                          // [D + 2]     sum_j (dx~ o x | sum_r dv_r | sum_m k dk)   -> dls, dvariance terms
+    float* p_w;                          // 3 [P][R]    dFs^T G | dFm^T MU | dFv^T V                 -> dW        (or NULL)
+    float* p_a;                          // 2 [D][P]    F^T dFs | F^T dFm                            -> dmf_A     (or NULL)
+};
+template <int NS, int DM>               // 16 NS samples per workgroup (8 waves);  D <= DM
+__global__ __launch_bounds__(512) void k_bw_chain(ChainArgs a) {
+    constexpr int NSAMP = 16 * NS;
+    extern __shared__ __attribute__((aligned(16))) float csm[];
+    const int M = a.M, LDT = M + 4, nbk = a.nbk, R = a.R, D = a.D, P = a.P;
+    float* tileA = csm;                                      // a tile (B-operand layout), later dk sample-major [NSAMP][LDT]
+    float* tileD = tileA + NSAMP * LDT;                         // da tile (B-operand layout)
+    float* qmu_s = tileD + a.dsz;                            // [M][R]
+    float* dmu_s = qmu_s + M * R;                            // [NSAMP][R]
+    float* dv2_s = dmu_s + NSAMP * R;                        // [NSAMP][R]
+    float* sdv_s = dv2_s + NSAMP * R;                        // [NSAMP]
+    float* dfi_s = sdv_s + NSAMP;                            // [NSAMP][D]
+    float* fr = dfi_s + NSAMP * D;                           // [NSAMP][DM]  raw input rows (zero beyond D)
+    float* il = fr + NSAMP * DM;                             // [DM]         1 / lengthscales
+    float* qx_s = il + DM;                                   // [NSAMP][D + 2]  per-sample rows of the column sums
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, gq = lane >> 4, jq = lane & 15;
+    const long long t0 = (long long)blockIdx.x * NSAMP;
+    f32x4* tA4 = reinterpret_cast<f32x4*>(tileA);
+    f32x4* tD4 = reinterpret_cast<f32x4*>(tileD);
+
+    // ---- phase 0: a rows -> LDS (B-operand layout), q_mu -> LDS; the heads' inputs (rows of the upstream gradients, of the
+    //      forward's variances and draws, W, mfA) staged in the not-yet-used da tile with coalesced loads, then the heads from
+    //      LDS by all threads (a thread-per-sample loop over global memory is a chain of ~R*P dependent round trips) --------
+    float* ups_s = tileD;                                    // [3][NSAMP][P]: dFs | dFm | dFv rows (0 where absent)
+    float* W_s = ups_s + 3 * NSAMP * P;                         // [P][R]
+    float* gmv_s = W_s + P * R;                              // [NSAMP][3R]: (g | mu | v) of the latent GPs
+    float* eps_s = gmv_s + NSAMP * 3 * R;                    // [NSAMP][R]
+    float* mfA_s = eps_s + NSAMP * R;                           // [D][P]
+    {
+        const int q4 = M >> 2;                               // float4 per row
+        for (int idx = tid; idx < NSAMP * q4; idx += 512) {
+            const int j = idx / q4, q = idx - j * q4;
+            tA4[q * NSAMP + j] = *reinterpret_cast<const f32x4*>(a.A + (size_t)(t0 + j) * a.Mp + 4 * q);
+        }
+        for (int idx = tid; idx < M * R; idx += 512) qmu_s[idx] = a.q_mu[idx];
+        const float* up[3] = {a.dFs, a.dFm, a.dFv};
+#pragma unroll
+        for (int u = 0; u < 3; ++u)
+            for (int idx = tid; idx < NSAMP * P; idx += 512) ups_s[u * NSAMP * P + idx] = up[u] ? up[u][(size_t)t0 * P + idx] : 0.f;
+        for (int idx = tid; idx < P * R; idx += 512) W_s[idx] = a.W ? a.W[idx] : ((idx / R) == (idx % R) ? 1.f : 0.f);
+        for (int idx = tid; idx < NSAMP * 3 * R; idx += 512) gmv_s[idx] = a.GMV[(size_t)t0 * 3 * R + idx];
+        for (int idx = tid; idx < NSAMP * R; idx += 512) eps_s[idx] = a.eps ? a.eps[(size_t)t0 * R + idx] : 0.f;
+        for (int idx = tid; idx < NSAMP * DM; idx += 512) { const int j = idx / DM, d = idx - j * DM; fr[idx] = d < D ? a.F[(size_t)(t0 + j) * D + d] : 0.f; }
+        if (tid < DM) il[tid] = tid < D ? a.invls[tid] : 0.f;
+        if (a.mf_type == IWVI_MF_LINEAR) for (int idx = tid; idx < D * P; idx += 512) mfA_s[idx] = a.mfA[idx];
+    }
+    __syncthreads();
+    for (int idx = tid; idx < NSAMP * R; idx += 512) {       // heads: one thread per (sample, latent GP)
+        const int j = idx / R, r = idx - j * R;
+        float dg = 0.f, dm = 0.f, dvv = 0.f;
+        for (int p = 0; p < P; ++p) {
+            const float w = W_s[p * R + r];
+            dg = fmaf(w, ups_s[j * P + p], dg);
+            dm = fmaf(w, ups_s[NSAMP * P + j * P + p], dm);
+            dvv = fmaf(w * w, ups_s[2 * NSAMP * P + j * P + p], dvv);
+        }
+        const float v = gmv_s[j * 3 * R + 2 * R + r];
+        float dv = dvv;
+        if (v > 0.f) dv += dg * eps_s[idx] * 0.5f / sqrtf(v); else dv = 0.f;
+        dmu_s[idx] = dg + dm; dv2_s[idx] = 2.f * dv;
+        a.DV2[(size_t)t0 * R + idx] = 2.f * dv;             // (the G_r product's per-sample weights)
+    }
+    for (int idx = tid; idx < NSAMP * D; idx += 512) {       // the mean function's share of dF
+        const int j = idx / D, d = idx - j * D;
+        float acc = 0.f;
+        if (a.mf_type == IWVI_MF_LINEAR) {
+            for (int p = 0; p < P; ++p) acc = fmaf(mfA_s[d * P + p], ups_s[j * P + p] + ups_s[NSAMP * P + j * P + p], acc);
+        } else if (a.mf_type == IWVI_MF_IDENTITY) acc = ups_s[j * P + d] + ups_s[NSAMP * P + j * P + d];
+        dfi_s[idx] = acc;
+    }
+    __syncthreads();
+    // this workgroup's share of the thin sums whose operands are at hand now (fixed summation order: sample index)
+    {
+        float* pq = a.p_qmu + (size_t)blockIdx.x * M * R;
+        for (int idx = tid; idx < M * R; idx += 512) {       // dq_mu share: sum_j a[m][j] dmu[j][r]
+            const int m = idx / R, r = idx - m * R;
+            const float* ap = tileA + (size_t)(m >> 2) * NSAMP * 4 + (m & 3);
+            float acc = 0.f;
+#pragma unroll 16
+            for (int j = 0; j < NSAMP; ++j) acc = fmaf(ap[4 * j], dmu_s[j * R + r], acc);
+            pq[idx] = acc;
+        }
+        if (a.p_w) {                                         // dW shares: dFs^T G | dFm^T MU | dFv^T V
+            float* pw = a.p_w + (size_t)blockIdx.x * 3 * P * R;
+            for (int idx = tid; idx < 3 * P * R; idx += 512) {
+                const int u = idx / (P * R), pr = idx - u * P * R, p_ = pr / R, r = pr - p_ * R;
+                float acc = 0.f;
+#pragma unroll 16
+                for (int j = 0; j < NSAMP; ++j) acc = fmaf(ups_s[u * NSAMP * P + j * P + p_], gmv_s[j * 3 * R + u * R + r], acc);
+                pw[idx] = acc;
+            }
+        }
+        if (a.p_a) {                                         // dmf_A shares: F^T dFs | F^T dFm
+            float* pa = a.p_a + (size_t)blockIdx.x * 2 * D * P;
+            for (int idx = tid; idx < 2 * D * P; idx += 512) {
+                const int u = idx / (D * P), dp = idx - u * D * P, d = dp / P, p_ = dp - d * P;
+                float acc = 0.f;
+#pragma unroll 16
+                for (int j = 0; j < NSAMP; ++j) acc = fmaf(fr[j * DM + d], ups_s[u * NSAMP * P + j * P + p_], acc);
+                pa[idx] = acc;
+            }
+        }
+    }
+    if (tid < NSAMP) {                                       // sum_r dv_r per sample, in index order
+        float sdv = 0.f;
+        for (int r = 0; r < R; ++r) sdv += 0.5f * dv2_s[tid * R + r];
+        sdv_s[tid] = sdv;
+    }
+    __syncthreads();
+    if (a.dbg_exit == 1) return;
+
+    // ---- phase 1: da row-blocks bi = wave, wave + 4 -------------------------------------------------------------------
+    for (int bi = wave; bi < nbk; bi += 8) {
+        bw_gptr4 Pb = (bw_gptr4)a.SP + (size_t)bi * R * nbk * 64 + lane;      // this row-block's R * nbk blocks, contiguous
+        const int nblocks = R * nbk;
+        f32x4 tot[NS], acc[NS];
+#pragma unroll
+        for (int t = 0; t < NS; ++t) { tot[t] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        f32x4 a_nx = Pb[0], a_n2 = Pb[(size_t)(1 < nblocks ? 1 : 0) * 64];
+        int bk = 0, r = 0;
+        for (int q = 0; q < nblocks; ++q) {
+            const f32x4 a_cur = a_nx;
+            a_nx = a_n2;
+            a_n2 = Pb[(size_t)(q + 2 < nblocks ? q + 2 : nblocks - 1) * 64];
+            f32x4 b[NS];
+#pragma unroll
+            for (int t = 0; t < NS; ++t) b[t] = tA4[(bk * 4 + gq) * NSAMP + 16 * t + jq];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+#pragma unroll
+                for (int t = 0; t < NS; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[s], b[t][s], acc[t], 0, 0, 0);
+            }
+            if (++bk == nbk) {                               // S_r a done for this row-block: weight by 2 dv_r per sample
+#pragma unroll
+                for (int t = 0; t < NS; ++t) {
+                    const float w = dv2_s[(16 * t + jq) * R + r];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { tot[t][e] = fmaf(w, acc[t][e], tot[t][e]); acc[t][e] = 0.f; }
+                }
+                bk = 0; ++r;
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < NS; ++t) {
+            const int j = 16 * t + jq;
+            const f32x4 av = tA4[(bi * 4 + gq) * NSAMP + j];
+            const float m2 = -2.f * sdv_s[j];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float v = fmaf(m2, av[e], tot[t][e]);
+                const int m = 16 * bi + 4 * gq + e;
+                for (int rr = 0; rr < R; ++rr) v = fmaf(dmu_s[j * R + rr], qmu_s[m * R + rr], v);
+                tot[t][e] = v;
+            }
+            tD4[(bi * 4 + gq) * NSAMP + j] = tot[t];
+        }
+    }
+    __syncthreads();
+    if (a.dbg_exit == 2) return;
+
+    // ---- phase 2: dk(bi) = sum_{bk >= bi} Lm^-T(bi, bk) da(bk); row-blocks paired so that every wave streams nbk + 1 blocks
+    for (int pass = 0; pass < 2; ++pass) {
+        const int bi = pass == 0 ? wave : nbk - 1 - wave;
+        if (wave >= 4 || bi < 0 || bi >= nbk) continue;         // (waves 4-7 sit this short phase out)
+        if (pass == 0 ? (wave > nbk - 1 - wave) : (nbk - 1 - wave <= wave)) continue;      // each row-block exactly once
+        bw_gptr4 Pb = (bw_gptr4)a.LinvTP + (size_t)tri_upper_off(nbk, bi) * 64 + lane;
+        const int nblocks = nbk - bi;
+        f32x4 acc[NS];
+#pragma unroll
+        for (int t = 0; t < NS; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        f32x4 a_nx = Pb[0];
+        for (int q = 0; q < nblocks; ++q) {
+            const f32x4 a_cur = a_nx;
+            a_nx = Pb[(size_t)(q + 1 < nblocks ? q + 1 : q) * 64];
+            const int bk = bi + q;
+            f32x4 b[NS];
+#pragma unroll
+            for (int t = 0; t < NS; ++t) b[t] = tD4[(bk * 4 + gq) * NSAMP + 16 * t + jq];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+#pragma unroll
+                for (int t = 0; t < NS; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[s], b[t][s], acc[t], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < NS; ++t) {
+            const int j = 16 * t + jq;
+            *reinterpret_cast<f32x4*>(&tileA[j * LDT + 16 * bi + 4 * gq]) = acc[t];       // sample-major for the kernel adjoint
+            *reinterpret_cast<f32x4*>(a.DK + (size_t)(t0 + j) * M + 16 * bi + 4 * gq) = acc[t];
+        }
+    }
+    __syncthreads();
+    if (a.dbg_exit == 3) return;
+
+    // ---- phase 3: kernel adjoint (direct differences), 16 lanes per sample, 16 samples per round.  The scaled inducing inputs
+    //      and the chunk's input rows are staged in the (now free) da tile, padded to DM columns: per-element global loads in the
+    //      inner loops were a chain of dependent L1 round trips (50-70 us of this kernel) ------------------------------------
+    float* tile = tileA;
+    float* zs = tileD;                                       // [M][DM]   (zero beyond D)
+    for (int idx = tid; idx < M * DM; idx += 512) { const int m = idx / DM, d = idx - m * DM; zs[idx] = d < D ? a.Zt[m * D + d] : 0.f; }
+    __syncthreads();
+    const int sub = tid & 15;
+    auto gsum = [](float v) { for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64); return v; };
+    for (int round = 0; round < (NSAMP + 31) / 32; ++round) {
+        const int j = 32 * round + (tid >> 4);
+        if (j >= NSAMP) break;                                // (uniform over each 16-lane group)
+        const long long t = t0 + j;
+        float xt[DM], cz[DM];
+#pragma unroll
+        for (int d = 0; d < DM; ++d) { xt[d] = fr[j * DM + d] * il[d]; cz[d] = 0.f; }
+        float sc = 0.f, skd = 0.f;
+        for (int m0 = 0; m0 < M; m0 += 64) {
+            const int mb = m0 + 4 * sub;
+            if (mb < M) {
+                const f32x4 dk = *reinterpret_cast<const f32x4*>(&tile[j * LDT + mb]);
+                f32x4 c;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float d2 = 0.f, z[DM];
+#pragma unroll
+                    for (int d = 0; d < DM; ++d) { z[d] = zs[(mb + e) * DM + d]; const float q = xt[d] - z[d]; d2 = fmaf(q, q, d2); }
+                    float kv, kg;
+                    kern_and_grad<float>(d2, a.kern_type, a.variance, kv, kg);
+                    const float kd = kv * dk[e];
+                    c[e] = kg * dk[e];
+                    sc += c[e]; skd += kd;
+#pragma unroll
+                    for (int d = 0; d < DM; ++d) cz[d] = fmaf(c[e], z[d], cz[d]);
+                }
+                *reinterpret_cast<f32x4*>(&tile[j * LDT + mb]) = c;       // c over dk (same thread, same slot): the C^T F sums below
+            }
+        }
+        sc = gsum(sc); skd = gsum(skd);
+        const int Wq = D + 2;
+#pragma unroll
+        for (int d = 0; d < DM; ++d) {
+            if (d < D) {
+                const float czd = gsum(cz[d]);
+                if (sub == 0) {
+                    const float dxt = 2.f * xt[d] * sc - 2.f * czd;
+                    if (a.dF) a.dF[t * D + d] = fmaf(dxt, il[d], dfi_s[j * D + d]);
+                    qx_s[j * Wq + d] = dxt * fr[j * DM + d];
+                }
+            }
+        }
+        if (sub == 0) { qx_s[j * Wq + D] = sdv_s[j]; qx_s[j * Wq + D + 1] = skd; }
+    }
+    __syncthreads();
+    // ---- phase 4: this workgroup's share of C^T [F | 1] and of the column sums of Qx (fixed order: sample index) -----------
+    {
+        const int W1 = D + 1;
+        float* pc = a.p_ctf + (size_t)blockIdx.x * M * W1;
+        for (int idx = tid; idx < M * W1; idx += 512) {
+            const int m = idx / W1, d = idx - m * W1;
+            float acc = 0.f;
+            if (d < D) {
+#pragma unroll 16
+                for (int j = 0; j < NSAMP; ++j) acc = fmaf(tile[j * LDT + m], fr[j * DM + d], acc);
+            } else {
+#pragma unroll 16
+                for (int j = 0; j < NSAMP; ++j) acc += tile[j * LDT + m];
+            }
+            pc[idx] = acc;
+        }
+        const int Wq = D + 2;
+        if (tid < Wq) {
+            float acc = 0.f;
+            for (int j = 0; j < NSAMP; ++j) acc += qx_s[j * Wq + tid];
+            a.p_q[(size_t)blockIdx.x * Wq + tid] = acc;
+        }
+    }
+}
+// operands of k_bw_chain, once per evaluation: packed S_r = L_r L_r^T blocks [bi][r][bk] and the packed upper blocks of Lm^-T.
+// One workgroup per 16x16 block, one thread per entry (M^3 R flops in all: negligible, latency-bound, off the critical path).
+__global__ __launch_bounds__(256) void k_pack_bw(const float* __restrict__ q_sqrt, const double* __restrict__ Linv64, int Mp, int M, int R, int nbk,
+                                                 float* __restrict__ SP, float* __restrict__ LinvTP) {
+    __shared__ float Ls[2][16][129];                         // the 16 rows of L_r of row-block bi / bk, columns 0 .. 16 min(bi, bk) + 15
+    const int i = threadIdx.x >> 4, k = threadIdx.x & 15;
+    const int off = (16 * (k >> 2) + i) * 4 + (k & 3);       // A-fragment order: lane 16g + i holds G[i][4g + s]
+    int b = blockIdx.x;
+    const int nS = R * nbk * nbk;
+    if (b < nS) {
+        const int bi = b / (R * nbk), r = (b / nbk) % R, bk = b % nbk;
+        const int bm = bi < bk ? bi : bk, ncol = 16 * bm + 16;
+        const float* Lr = q_sqrt + (size_t)r * M * M;
+        for (int idx = threadIdx.x; idx < 16 * ncol; idx += 256) {
+            const int rr = idx / ncol, c = idx - rr * ncol;
+            Ls[0][rr][c] = (c <= 16 * bi + rr) ? Lr[(size_t)(16 * bi + rr) * M + c] : 0.f;     // tril: zero above the diagonal
+            Ls[1][rr][c] = (c <= 16 * bk + rr) ? Lr[(size_t)(16 * bk + rr) * M + c] : 0.f;
+        }
+        __syncthreads();
+        float acc = 0.f;
+        for (int j = 0; j < ncol; ++j) acc = fmaf(Ls[0][i][j], Ls[1][k][j], acc);
+        SP[(size_t)b * 256 + off] = acc;
+        return;
+    }
+    b -= nS;                                                  // upper block (bi, bk >= bi) of Lm^-T: entry [i][k] = Lm^-1[16bk + k][16bi + i]
+    int bi = 0;
+    while (b >= nbk - bi) { b -= nbk - bi; ++bi; }
+    const int bk = bi + b;
+    LinvTP[((size_t)tri_upper_off(nbk, bi) + (bk - bi)) * 256 + off] = (float)Linv64[(size_t)(16 * bk + k) * Mp + 16 * bi + i];
+}
+static int chain_ns(long long T) {                          // samples per workgroup / 16: as the forward's, then down to a divisor of T
+    int ns = (int)((T + 16 * 256 - 1) / (16 * 256));
+    if (ns > 5) ns = 5;
+    if (ns < 1) ns = 1;
+    while (ns > 1 && T % (16 * ns)) --ns;
+    return ns;
+}
+static bool chain_ok(int M, int Mp, long long T) {
+    return Mp == M && M <= 128 && (T % 16) == 0 && !getenv("IWVI_BW_UNFUSED") && !getenv("IWVI_BW_OLD_CHAIN");
+}
+template <int NS>
+static int launch_chain_ns(hipStream_t st, ChainArgs a) {
+    constexpr int NSAMP = 16 * NS;
+    const int DM = a.D <= 8 ? 8 : (a.D <= 16 ? 16 : 32);
+    int dsz = NSAMP * a.M;
+    const int heads = 3 * NSAMP * a.P + a.P * a.R + 4 * NSAMP * a.R + a.D * a.P, adj = a.M * DM;
+    if (heads > dsz) dsz = heads;
+    if (adj > dsz) dsz = adj;
+    a.dsz = (dsz + 3) & ~3;
+    const size_t lds = sizeof(float) * ((size_t)NSAMP * (a.M + 4) + (size_t)a.dsz + (size_t)a.M * a.R + (size_t)NSAMP * (2 * a.R + 1) + (size_t)NSAMP * a.D
+                                        + (size_t)NSAMP * DM + DM + (size_t)NSAMP * (a.D + 2));
+    static bool done = false;
+    if (!done) {
+        const size_t most = sizeof(float) * ((size_t)NSAMP * 132 + (size_t)(NSAMP * 128 > 3 * NSAMP * IWVI_MAX_P + IWVI_MAX_P * IWVI_MAX_R + 2 * NSAMP * IWVI_MAX_R + IWVI_MAX_D * IWVI_MAX_P
+                                                                            ? NSAMP * 128 : 3 * NSAMP * IWVI_MAX_P + IWVI_MAX_P * IWVI_MAX_R + 2 * NSAMP * IWVI_MAX_R + IWVI_MAX_D * IWVI_MAX_P)
+                                             + 128 * 32 + 32 + 128 * IWVI_MAX_R + NSAMP * (4 * IWVI_MAX_R + 1) + NSAMP * IWVI_MAX_D + NSAMP * 32 + 32 + NSAMP * (IWVI_MAX_D + 2));
+        const void* fns[] = {(const void*)k_bw_chain<NS, 8>, (const void*)k_bw_chain<NS, 16>, (const void*)k_bw_chain<NS, 32>};
+        for (const void* f : fns)
+            if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(most < 160 * 1024 ? most : 160 * 1024)) != hipSuccess) { set_error("hipFuncSetAttribute(k_bw_chain)"); return IWVI_ERR_LAUNCH; }
+        done = true;
+    }
+    if (lds > 160 * 1024) { set_error("k_bw_chain: %zu B of LDS", lds); return IWVI_ERR_UNSUPPORTED; }
+    const dim3 grid((unsigned)(a.T / NSAMP)), block(512);
+    if (a.D <= 8) hipLaunchKernelGGL((k_bw_chain<NS, 8>), grid, block, lds, st, a);
+    else if (a.D <= 16) hipLaunchKernelGGL((k_bw_chain<NS, 16>), grid, block, lds, st, a);
+    else hipLaunchKernelGGL((k_bw_chain<NS, 32>), grid, block, lds, st, a);
+    return check_launch("k_bw_chain");
+}
+static int launch_chain(hipStream_t st, const ChainArgs& a) {
+    switch (chain_ns(a.T)) {
+        case 1: return launch_chain_ns<1>(st, a);
+        case 2: return launch_chain_ns<2>(st, a);
+        case 3: return launch_chain_ns<3>(st, a);
+        case 4: return launch_chain_ns<4>(st, a);
+        default: return launch_chain_ns<5>(st, a);
+    }
+}
+// dq_sqrt[r] = tril(sym(G_r) L_r) + add_coef * (L_r - diag(1 / L_ii)),  G_r given by its lower triangle (the reduced split-K SYRK):
+// 16x16 output tile per workgroup, operands through LDS, k from the tile's first column (L_r is lower triangular).
+__global__ __launch_bounds__(256) void k_gl_tril(const float* __restrict__ G, const float* __restrict__ Lq, float* __restrict__ out, int M, double add_coef) {
+    __shared__ float As[16][17], Bs[16][17];
+    const int r = blockIdx.z;
+    const float* Gr = G + (size_t)r * M * M; const float* Lr = Lq + (size_t)r * M * M; float* o = out + (size_t)r * M * M;
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int i0 = blockIdx.y * 16, j0 = blockIdx.x * 16, i = i0 + ty, j = j0 + tx;
+    if (j0 > i0 + 15) { if (i < M && j < M) o[(size_t)i * M + j] = 0.f; return; }
+    float s = 0.f;
+    for (int k0 = j0; k0 < M; k0 += 16) {
+        const int ka = k0 + tx, kb = k0 + ty;
+        As[ty][tx] = (i < M && ka < M) ? (ka <= i ? Gr[(size_t)i * M + ka] : Gr[(size_t)ka * M + i]) : 0.f;     // symmetric read
+        Bs[ty][tx] = (kb < M && j < M && kb >= j) ? Lr[(size_t)kb * M + j] : 0.f;
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 16; ++k) s = fmaf(As[ty][k], Bs[k][tx], s);
+        __syncthreads();
+    }
+    if (i >= M || j >= M) return;
+    if (j > i) { o[(size_t)i * M + j] = 0.f; return; }
+    const double v = (double)Lr[(size_t)i * M + j];
+    o[(size_t)i * M + j] = (float)((double)s + add_coef * (v - (i == j ? 1.0 / v : 0.0)));
+}
+
 // Thin sums over samples: part[blk][m][n] = sum_{t in chunk} X[t*ldx + m] * Y(t, n), n < N + ones, N <= 64; the extra
 // column (ones) is the plain column sum.  Thread = column m, rows in a fixed order; chunks summed by k_reduce_parts.
 constexpr int THIN_ROWS = 64;
@@ -1053,6 +1460,7 @@ struct BwdWs {
     float *DMU, *DV2, *SDV, *DA, *DK, *Qx, *part, *LinvF, *Zt, *invls, *CtF1, *Qsum;
     double *Lbar, *T1, *T2, *S, *dZt_uu, *dvar_m;
     float *GMV, *lin;                   // [T, 3R];  3 [P, R] + 2 [D, P] partial results
+    float *SP, *LinvTP, *G;             // k_bw_chain's packed operands; G_r = A^T diag(2 dv_r) A [R, M, M]
     size_t part_floats, bytes;
 };
 static BwdWs bwd_layout(char* base, long long T, int M, int D, int R) {
@@ -1074,6 +1482,12 @@ static BwdWs bwd_layout(char* base, long long T, int M, int D, int R) {
     w.S = (double*)take(sizeof(double) * M * M); w.dZt_uu = (double*)take(sizeof(double) * M * D); w.dvar_m = (double*)take(sizeof(double) * M);
     w.GMV = (float*)take(sizeof(float) * T * 3 * R);
     w.lin = (float*)take(sizeof(float) * (3 * IWVI_MAX_P * IWVI_MAX_R + 2 * IWVI_MAX_D * IWVI_MAX_P));
+    {
+        const int Mp = round_up(M, 16), nbk = Mp / 16;
+        w.SP = (float*)take(sizeof(float) * (size_t)R * nbk * nbk * 256);
+        w.LinvTP = (float*)take(sizeof(float) * (size_t)tri_blocks(nbk) * 256);
+        w.G = (float*)take(sizeof(float) * (size_t)R * M * M);
+    }
     w.bytes = o;
     return w;
 }
@@ -1159,15 +1573,18 @@ struct LvBwdArgs {
     const float* mu; const float* sigma; int ld_enc, raw; const float* eps; const float* dFn; int ld, col0;
     const float* w; int Lw; long long B; int K, sampled; float* d_out;
 };
-__global__ void k_lv_bwd(LvBwdArgs a) {
-    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(256) void k_lv_bwd(LvBwdArgs a) {
+    // one wave per (point, latent dim), lanes over its K samples (a thread per point walking K samples is a chain of K
+    // dependent global round trips); lane partials combined by a fixed shuffle tree: deterministic
+    const int lane = threadIdx.x & 63;
+    const long long idx = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (idx >= a.B * a.Lw) return;
     const long long b = idx / a.Lw; const int l = (int)(idx - b * a.Lw);
     const float mu = a.mu[b * a.ld_enc + l];
     float sg = a.sigma[b * a.ld_enc + l];
     if (a.raw) sg = softplus_f(sg - 3.f);
     float dmu = 0.f, dsg = 0.f;
-    for (int k = 0; k < a.K; ++k) {
+    for (int k = lane; k < a.K; k += 64) {
         const long long t = b * a.K + k;
         const float e = a.eps[t * a.Lw + l], W = fmaf(e, sg, mu);
         const float dfw = a.dFn ? a.dFn[t * a.ld + a.col0 + l] : 0.f;
@@ -1175,8 +1592,11 @@ __global__ void k_lv_bwd(LvBwdArgs a) {
         if (a.sampled) { const float dW = dfw + dkl * W; dmu += dW; dsg += dW * e - dkl / sg; }
         else { dmu += dfw + dkl * mu; dsg += dfw * e + dkl * (sg - 1.f / sg); }
     }
-    a.d_out[b * 2 * a.Lw + l] = dmu;
-    a.d_out[b * 2 * a.Lw + a.Lw + l] = dsg * (1.f - __expf(-sg));      // sigma = softplus(raw - 3): d sigma / d raw = 1 - exp(-sigma)
+    for (int o = 32; o > 0; o >>= 1) { dmu += __shfl_xor(dmu, o, 64); dsg += __shfl_xor(dsg, o, 64); }
+    if (lane == 0) {
+        a.d_out[b * 2 * a.Lw + l] = dmu;
+        a.d_out[b * 2 * a.Lw + a.Lw + l] = dsg * (1.f - __expf(-sg));      // sigma = softplus(raw - 3): d sigma / d raw = 1 - exp(-sigma)
+    }
 }
 
 // Encoder MLP (layers.py:137-152), one thread per row: activations of every layer -> acts, then deltas (d / d pre-activation)
@@ -1185,8 +1605,10 @@ struct EncBwdArgs {
     const float* d_out;
     float* part; int woff[IWVI_MAX_ENC], boff[IWVI_MAX_ENC], ptot;     // part[workgroup][ptot]: this workgroup's share of (dW_l | db_l)
 };
-constexpr int ER = 32, ELD = 65;        // rows per workgroup, row stride of an activation tile in LDS
-// 32 rows per workgroup, activations and deltas in LDS, threads over (row, unit)
+constexpr int ER = 8, ELD = 65;         // rows per workgroup, row stride of an activation tile in LDS
+constexpr int EW_MAX = IWVI_MAX_ENC * (64 * 64 + 64);   // LDS copy of the weights and biases (widths <= 64)
+// 8 rows per workgroup (128 workgroups at B = 1024: the phase is latency-bound), activations, deltas AND the weights in LDS
+// (weights read from global memory inside the dot-product loops cost an L1 round trip per term), threads over (row, unit)
 __global__ __launch_bounds__(256) void k_enc_bwd(EncBwdArgs a) {
     extern __shared__ float esm[];
     const int tid = threadIdx.x;
@@ -1196,6 +1618,13 @@ __global__ __launch_bounds__(256) void k_enc_bwd(EncBwdArgs a) {
     float* cur = esm + (size_t)(a.n + 1) * ER * ELD;     // d / d layer output
     float* dl = cur + ER * ELD;                          // d / d pre-activation
     float* prev = dl + ER * ELD;
+    float* wl = prev + ER * ELD;                         // weights | biases of every layer, laid out like a workgroup's share of the
+    //                                                      parameter gradients: W_l at woff[l], b_l at boff[l] (ptot floats in all)
+    for (int l = 0; l < a.n; ++l) {
+        const int nw = a.dims[l] * a.dims[l + 1], nb = a.dims[l + 1];
+        for (int idx = tid; idx < nw; idx += 256) wl[a.woff[l] + idx] = a.W[l][idx];
+        for (int idx = tid; idx < nb; idx += 256) wl[a.boff[l] + idx] = a.b[l] ? a.b[l][idx] : 0.f;
+    }
     for (int idx = tid; idx < nrows * a.dims[0]; idx += 256) {
         const int r = idx / a.dims[0], i = idx - r * a.dims[0];
         const float v = a.XY[(row0 + r) * a.dims[0] + i];
@@ -1207,8 +1636,8 @@ __global__ __launch_bounds__(256) void k_enc_bwd(EncBwdArgs a) {
         const float* in = acts + (size_t)l * ER * ELD; float* out = acts + (size_t)(l + 1) * ER * ELD;
         for (int idx = tid; idx < nrows * dout; idx += 256) {
             const int r = idx / dout, o = idx - r * dout;
-            float acc = a.b[l] ? a.b[l][o] : 0.f;
-            for (int i = 0; i < din; ++i) acc = fmaf(in[r * ELD + i], a.W[l][i * dout + o], acc);
+            float acc = wl[a.boff[l] + o];
+            for (int i = 0; i < din; ++i) acc = fmaf(in[r * ELD + i], wl[a.woff[l] + i * dout + o], acc);
             if (l < a.n - 1) acc = tanhf(acc);
             if (din == dout) acc += in[r * ELD + o];
             out[r * ELD + o] = acc;
@@ -1246,7 +1675,7 @@ __global__ __launch_bounds__(256) void k_enc_bwd(EncBwdArgs a) {
         for (int idx = tid; idx < nrows * din; idx += 256) {
             const int r = idx / din, i = idx - r * din;
             float acc = skip ? cur[r * ELD + i] : 0.f;
-            for (int o = 0; o < dout; ++o) acc = fmaf(dl[r * ELD + o], a.W[l][i * dout + o], acc);
+            for (int o = 0; o < dout; ++o) acc = fmaf(dl[r * ELD + o], wl[a.woff[l] + i * dout + o], acc);
             prev[r * ELD + i] = acc;
         }
         __syncthreads();
@@ -1257,11 +1686,22 @@ __global__ __launch_bounds__(256) void k_enc_bwd(EncBwdArgs a) {
 
 // every encoder parameter = sum over the workgroups' shares (fixed order), scattered to its tensor
 struct EncReduceArgs { const float* part; int nblk, ptot, n; int off[2 * IWVI_MAX_ENC], len[2 * IWVI_MAX_ENC]; float* dst[2 * IWVI_MAX_ENC]; };
-__global__ void k_enc_reduce(EncReduceArgs a) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= a.ptot) return;
+__global__ __launch_bounds__(256) void k_enc_reduce(EncReduceArgs a) {
+    // 64 outputs per workgroup; the shares of an output are summed by 4 threads (contiguous quarters, in order), then combined
+    // in a fixed order (as k_reduce_parts): deterministic, and four times shorter than one serial pass over the workgroups
+    __shared__ double red[4][64];
+    const int o = threadIdx.x & 63, gq = threadIdx.x >> 6;
+    const int idx = blockIdx.x * 64 + o;
     double s = 0.0;
-    for (int b = 0; b < a.nblk; ++b) s += (double)a.part[(size_t)b * a.ptot + idx];
+    if (idx < a.ptot) {
+        const int per = (a.nblk + 3) / 4, k0 = gq * per, k1 = (k0 + per < a.nblk) ? k0 + per : a.nblk;
+#pragma unroll 8
+        for (int b = k0; b < k1; ++b) s += (double)a.part[(size_t)b * a.ptot + idx];
+    }
+    red[gq][o] = s;
+    __syncthreads();
+    if (gq != 0 || idx >= a.ptot) return;
+    s = ((red[0][o] + red[1][o]) + red[2][o]) + red[3][o];
     for (int j = 0; j < a.n; ++j)
         if (idx >= a.off[j] && idx < a.off[j] + a.len[j]) { if (a.dst[j]) a.dst[j][idx - a.off[j]] = (float)s; return; }
 }
@@ -1454,10 +1894,34 @@ extern "C" size_t iwvi_gp_layer_backward_ws_bytes(int64_t T, int M, int D, int R
     return bwd_layout(nullptr, T, M, D, R).bytes;
 }
 
+// What the adjoint of a layer needs besides the forward's outputs: scaled inducing inputs, a float32 Lm^-1, and for the
+// streaming chain the packed S_r / Lm^-T operands.  Depends only on the parameters and the dense factors, so a caller may
+// queue it early on another stream (beside the forward) and pass desc.prepared = 1 to iwvi_gp_layer_backward.
+extern "C" int iwvi_gp_layer_backward_prepare(const iwvi_gp_bwd_desc* dp, int64_t T, void* ws_, void* stream_) {
+    if (!dp || !ws_ || T <= 0) { set_error("iwvi_gp_layer_backward_prepare: bad argument"); return IWVI_ERR_ARG; }
+    const iwvi_gp_bwd_desc& d = *dp;
+    if (!d.state || !d.Z || !d.lengthscales || !d.q_sqrt || d.M <= 0 || d.M > IWVI_MAX_M || d.D <= 0 || d.D > IWVI_MAX_D || d.R <= 0 || d.R > IWVI_MAX_R) {
+        set_error("iwvi_gp_layer_backward_prepare: null input or size out of range"); return IWVI_ERR_ARG;
+    }
+    hipStream_t st = (hipStream_t)stream_;
+    const int M = d.M, D = d.D, R = d.R;
+    const StateLayout sl = state_layout(M, R);
+    const int Mp = sl.Mp;
+    const double* Linv64 = (const double*)((const char*)d.state + sl.off_Linv);
+    BwdWs w = bwd_layout((char*)ws_, T, M, D, R);
+    const int n = M * M > M * D ? M * M : M * D;
+    hipLaunchKernelGGL(k_prep, dim3((n + 255) / 256), dim3(256), 0, st, d.Z, d.lengthscales, Linv64, Mp, w.Zt, w.invls, w.LinvF, M, D);
+    if (chain_ok(M, Mp, T)) {
+        const int nbk = Mp / 16;
+        hipLaunchKernelGGL(k_pack_bw, dim3((unsigned)(R * nbk * nbk + tri_blocks(nbk))), dim3(256), 0, st, d.q_sqrt, Linv64, Mp, M, R, nbk, w.SP, w.LinvTP);
+    }
+    return check_launch("iwvi_gp_layer_backward_prepare");
+}
+
 extern "C" int iwvi_gp_layer_backward(const iwvi_gp_bwd_desc* dp, int64_t T, void* ws_, void* stream_) {
     if (!dp || !ws_ || T <= 0) { set_error("iwvi_gp_layer_backward: bad argument"); return IWVI_ERR_ARG; }
     const iwvi_gp_bwd_desc& d = *dp;
-    if (!d.state || !d.Z || !d.lengthscales || !d.q_mu || !d.q_sqrt || !d.F || !d.A || !d.U) { set_error("iwvi_gp_layer_backward: null input"); return IWVI_ERR_ARG; }
+    if (!d.state || !d.Z || !d.lengthscales || !d.q_mu || !d.q_sqrt || !d.F || !d.A) { set_error("iwvi_gp_layer_backward: null input"); return IWVI_ERR_ARG; }
     if (d.M <= 0 || d.M > IWVI_MAX_M || d.D <= 0 || d.D > IWVI_MAX_D || d.R <= 0 || d.R > IWVI_MAX_R || d.P <= 0 || d.P > IWVI_MAX_P || T >= (1LL << 31) / (d.M > d.D ? d.M : d.D)) {
         set_error("iwvi_gp_layer_backward: size out of range"); return IWVI_ERR_ARG;
     }
@@ -1474,14 +1938,42 @@ extern "C" int iwvi_gp_layer_backward(const iwvi_gp_bwd_desc* dp, int64_t T, voi
     const double* Linv64 = (const double*)((const char*)d.state + sl.off_Linv);
     BwdWs w = bwd_layout((char*)ws_, T, M, D, R);
     int rc;
-    {
-        const int n = M * M > M * D ? M * M : M * D;
-        hipLaunchKernelGGL(k_prep, dim3((n + 255) / 256), dim3(256), 0, st, d.Z, d.lengthscales, Linv64, Mp, w.Zt, w.invls, w.LinvF, M, D);
-    }
+    if (!d.prepared && (rc = iwvi_gp_layer_backward_prepare(dp, T, ws_, stream_)) != IWVI_OK) return rc;
     const float* gmv = d.GMV ? d.GMV : w.GMV;
+    // deferred reductions of this layer: every product over samples parks its partial sums in its own slice of the workspace
+    const size_t partA = (size_t)((T + splitk_chunk(T) - 1) / splitk_chunk(T) + 2) * M * M;
+    const bool two_q = d.side_stream && d.side_stream2 && d.side_stream2 != d.side_stream;
+    ReduceQueue rqA(w.part, two_q ? partA : 0), rqB(w.part + (two_q ? partA : 0), w.part_floats - (two_q ? partA : 0));
+    float* s[3] = {nullptr, nullptr, nullptr}; float* a12[2] = {nullptr, nullptr};
+    const bool lin_on = (d.dW && d.W) || (d.dmf_A && d.mf_type == IWVI_MF_LINEAR);
+    // streaming chain (no saved u_r): M a multiple of 16 up to 128, T a multiple of 64, the forward's gmv block at hand
+    const bool chain = d.GMV && chain_ok(M, Mp, T);
+    if (!chain && !d.U) { set_error("iwvi_gp_layer_backward: this shape (M=%d, T=%lld) takes the GEMM path, which needs the forward's u_out", M, (long long)T); return IWVI_ERR_ARG; }
+    if (chain) {
+        const int nbk = Mp / 16;
+        ChainArgs ca{d.GMV, d.noise, d.W, d.mf_A, d.d_sample, d.d_mean, d.d_var, w.DMU, w.DV2, w.SDV, d.dF, d.P, d.mf_type,
+                     d.A, Mp, d.q_mu, w.SP, w.LinvTP, w.DK, d.F, w.Zt, w.invls, w.DA, w.Qx, (long long)T, M, D, R, nbk, d.variance, d.kern_type,
+                     getenv("IWVI_CHAIN_EXIT") ? atoi(getenv("IWVI_CHAIN_EXIT")) : 0};
+        // the thin sums over samples ride in the chain kernel: one partial per workgroup and job, summed with the rest of chain B
+        const int S = (int)(T / (16 * chain_ns(T))), P = d.P;
+        auto job = [&](int Mj, int Nj, float* out, const float* add, double add_coef) -> float* {
+            float* pp = rqB.take((size_t)S * Mj * Nj);
+            if (!pp) return nullptr;
+            ReduceArgs r{pp, S, Mj, Nj, out, nullptr, (long long)Nj, 1.0, 0.0, 0, 0, add, add_coef, 0};
+            return rqB.push(r, 1) ? pp : nullptr;
+        };
+        // (- kl_weight * dKL/dq_mu = - kl_weight * q_mu rides in the reduction; temp_workaround.py:186-188)
+        ca.p_qmu = job(M, R, d.dq_mu ? d.dq_mu : w.DMU, d.dq_mu ? d.q_mu : nullptr, -d.kl_weight);
+        ca.p_ctf = job(M, D + 1, w.CtF1, nullptr, 0.0);
+        ca.p_q = job(D + 2, 1, w.Qsum, nullptr, 0.0);
+        if (d.dW && d.W) { ca.p_w = job(3 * P, R, w.lin, nullptr, 0.0); for (int i = 0; i < 3; ++i) s[i] = w.lin + (size_t)i * P * R; if (!ca.p_w) ca.p_qmu = nullptr; }
+        if (d.dmf_A && d.mf_type == IWVI_MF_LINEAR) { ca.p_a = job(2 * D, P, w.lin + 3 * IWVI_MAX_P * IWVI_MAX_R, nullptr, 0.0); for (int i = 0; i < 2; ++i) a12[i] = w.lin + 3 * IWVI_MAX_P * IWVI_MAX_R + (size_t)i * D * P; if (!ca.p_a) ca.p_qmu = nullptr; }
+        if (!ca.p_qmu || !ca.p_ctf || !ca.p_q) { set_error("backward: workspace too small for the chain kernel's partial sums"); return IWVI_ERR_ARG; }
+        if ((rc = launch_chain(st, ca)) != IWVI_OK) return rc;
+    }
     MidArgs ma{d.GMV, d.noise, d.W, d.mf_A, d.d_sample, d.d_mean, d.d_var, w.DMU, w.DV2, w.SDV, d.dF, d.P, d.mf_type,
                d.U, d.A, Mp, d.q_sqrt, d.q_mu, w.LinvF, w.DK, d.F, w.Zt, w.invls, w.DA, w.Qx, (long long)T, M, D, R, d.variance, d.kern_type};
-    const int fused = launch_mid(st, ma);                  // heads + DA + dK + kernel adjoint in one launch where the shapes allow
+    const int fused = chain ? 1 : launch_mid(st, ma);      // heads + DA + dK + kernel adjoint in one launch where the shapes allow
     if (fused < 0) return fused;
     if (!fused) {
         HeadArgs h{d.A, d.U, d.noise, d.W, d.mf_A, d.d_sample, d.d_mean, d.d_var, w.DMU, w.DV2, w.SDV, d.dF, T, M, Mp, D, R, d.P, d.mf_type, d.variance,
@@ -1534,9 +2026,6 @@ extern "C" int iwvi_gp_layer_backward(const iwvi_gp_bwd_desc* dp, int64_t T, voi
         }
         (void)hipEventDestroy(ev);                         // (released once the recorded work has passed it)
     }
-    const size_t partA = (size_t)((T + splitk_chunk(T) - 1) / splitk_chunk(T) + 2) * M * M;
-    const bool two_q = d.side_stream && d.side_stream2 && d.side_stream2 != d.side_stream;
-    ReduceQueue rqA(w.part, two_q ? partA : 0), rqB(w.part + (two_q ? partA : 0), w.part_floats - (two_q ? partA : 0));
     // ---- chain A: dLm = -tril(DK^T A)  (float64, for the adjoint of the factorisation), then S = Lm^-T Phi(Lm^T Lbar) Lm^-1
     const bool two = stB != stA;
     auto chol_adjoint = [&](hipStream_t s_) {
@@ -1562,9 +2051,16 @@ extern "C" int iwvi_gp_layer_backward(const iwvi_gp_bwd_desc* dp, int64_t T, voi
     st = stB;
     // dq_mu = A^T DMU
     // (- kl_weight * dKL/dq_mu = - kl_weight * q_mu rides in the reduction; temp_workaround.py:186-188)
-    if (d.dq_mu && (rc = thin(st, d.A, Mp, M, w.DMU, R, R, 0, T, w.part, w.part_floats, d.dq_mu, 0, &rqB, d.q_mu, -d.kl_weight)) != IWVI_OK) return rc;
+    if (!chain && d.dq_mu && (rc = thin(st, d.A, Mp, M, w.DMU, R, R, 0, T, w.part, w.part_floats, d.dq_mu, 0, &rqB, d.q_mu, -d.kl_weight)) != IWVI_OK) return rc;
+    // streaming path: dL_r = tril(G_r L_r) with G_r = A^T diag(2 dv_r) A (lower tiles of a split-K SYRK, all r in one batched launch)
+    if (d.dq_sqrt && chain) {
+        GemmArgs q{};
+        q.A = d.A; q.a_sm = 1; q.a_sk = Mp; q.B = d.A; q.b_sk = Mp; q.b_sn = 1;
+        q.scale = w.DV2; q.s_stride = R; q.scale_on_k = 1; q.M = M; q.N = M; q.K = (int)T; q.tri_out = 1;
+        if ((rc = gemm(st, q, w.part, w.part_floats, w.G, nullptr, M, 1.0, 0.0, 1, R, 0, 1, (long long)M * M, &rqB)) != IWVI_OK) return rc;
+    }
     // dL_r = tril(A^T diag(2 dv_r) U_r), all r in one batched launch
-    if (d.dq_sqrt) {
+    if (d.dq_sqrt && !chain) {
         GemmArgs q{};
         q.A = d.A; q.a_sm = 1; q.a_sk = Mp; q.B = d.U; q.b_sk = Mp; q.b_sn = 1;
         q.scale = w.DV2; q.s_stride = R; q.scale_on_k = 1; q.M = M; q.N = M; q.K = (int)T; q.tri_out = 1;
@@ -1572,12 +2068,10 @@ extern "C" int iwvi_gp_layer_backward(const iwvi_gp_bwd_desc* dp, int64_t T, voi
         if ((rc = gemm(st, q, w.part, w.part_floats, d.dq_sqrt, nullptr, M, 1.0, 0.0, 1, R, (long long)T * Mp, 1, (long long)M * M, &rqB, d.q_sqrt, -d.kl_weight, 1)) != IWVI_OK) return rc;
     }
     // sums over samples: C^T [F | 1]  and the column sums of Qx = (dx~ o x | sum_r dv_r | sum_m k dk)
-    if ((rc = thin(st, w.DA, M, M, d.F, D, D, 1, T, w.part, w.part_floats, w.CtF1, 0, &rqB)) != IWVI_OK) return rc;
-    if ((rc = thin(st, w.Qx, D + 2, D + 2, nullptr, 0, 0, 1, T, w.part, w.part_floats, w.Qsum, 0, &rqB)) != IWVI_OK) return rc;
+    if (!chain && (rc = thin(st, w.DA, M, M, d.F, D, D, 1, T, w.part, w.part_floats, w.CtF1, 0, &rqB)) != IWVI_OK) return rc;
+    if (!chain && (rc = thin(st, w.Qx, D + 2, D + 2, nullptr, 0, 0, 1, T, w.part, w.part_floats, w.Qsum, 0, &rqB)) != IWVI_OK) return rc;
     // mixing matrix and linear mean function (trainable when the reference runs with fix_linear=False, build_models.py:224-227)
-    const bool lin_on = (d.dW && d.W) || (d.dmf_A && d.mf_type == IWVI_MF_LINEAR);
-    float* s[3] = {nullptr, nullptr, nullptr}; float* a12[2] = {nullptr, nullptr};
-    if (lin_on) {
+    if (lin_on && !chain) {
         const int P = d.P;
         const float* ups[3] = {d.d_sample, d.d_mean, d.d_var};
         if (d.dW && d.W) for (int i = 0; i < 3; ++i) if (ups[i]) {
@@ -1590,6 +2084,10 @@ extern "C" int iwvi_gp_layer_backward(const iwvi_gp_bwd_desc* dp, int64_t T, voi
         }
     }
     if ((rc = rqB.flush(st)) != IWVI_OK) return rc;
+    if (d.dq_sqrt && chain) {                              // (- kl_weight * dKL/dL_r = - kl_weight * (L_r - diag(1 / L_ii)) rides along)
+        hipLaunchKernelGGL(k_gl_tril, dim3((M + 15) / 16, (M + 15) / 16, R), dim3(256), 0, st, (const float*)w.G, d.q_sqrt, d.dq_sqrt, M, -d.kl_weight);
+        if ((rc = check_launch("k_gl_tril")) != IWVI_OK) return rc;
+    }
     if (!two && (rc = chol_adjoint(st)) != IWVI_OK) return rc;     // one stream: after the single reduction, as before
     if (lin_on) {
         const int P = d.P;
@@ -1645,7 +2143,7 @@ extern "C" int iwvi_lv_layer_backward(const float* mu, const float* sigma, int l
         set_error("iwvi_lv_layer_backward: bad argument"); return IWVI_ERR_ARG;
     }
     LvBwdArgs a{mu, sigma, ld_enc, sigma_is_raw, noise, dF_next, ld_next, col0, w, latent_dim, B, K, sampled_kl, d_enc_out};
-    hipLaunchKernelGGL(k_lv_bwd, dim3((unsigned)((B * latent_dim + 63) / 64)), dim3(64), 0, (hipStream_t)stream_, a);
+    hipLaunchKernelGGL(k_lv_bwd, dim3((unsigned)((B * latent_dim + 3) / 4)), dim3(256), 0, (hipStream_t)stream_, a);
     return check_launch("k_lv_bwd");
 }
 
@@ -1679,12 +2177,13 @@ extern "C" int iwvi_encoder_backward(const float* XY, int64_t rows, const float*
     a.ptot = off;
     const int nblk = (int)((rows + ER - 1) / ER);
     r.part = a.part; r.nblk = nblk; r.ptot = off; r.n = 2 * n_enc;
-    const size_t elds = sizeof(float) * (size_t)(n_enc + 4) * ER * ELD;
+    size_t elds = sizeof(float) * (size_t)(n_enc + 4) * ER * ELD;
+    for (int l = 0; l < n_enc; ++l) elds += sizeof(float) * (size_t)(dims[l] * dims[l + 1] + dims[l + 1]);
     int rc;
     {   // once per process: allow the largest encoder (hipFuncSetAttribute is not a stream operation)
         static bool done = false;
         if (!done) {
-            const size_t most = sizeof(float) * (size_t)(IWVI_MAX_ENC + 4) * ER * ELD;
+            const size_t most = sizeof(float) * ((size_t)(IWVI_MAX_ENC + 4) * ER * ELD + EW_MAX);
             hipError_t e = hipFuncSetAttribute((const void*)k_enc_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)most);
             if (e != hipSuccess) { set_error("hipFuncSetAttribute(%zu B LDS): %s", most, hipGetErrorString(e)); return IWVI_ERR_LAUNCH; }
             done = true;
@@ -1692,7 +2191,7 @@ extern "C" int iwvi_encoder_backward(const float* XY, int64_t rows, const float*
     }
     hipLaunchKernelGGL(k_enc_bwd, dim3((unsigned)nblk), dim3(256), elds, st, a);
     if ((rc = check_launch("k_enc_bwd")) != IWVI_OK) return rc;
-    hipLaunchKernelGGL(k_enc_reduce, dim3((off + 255) / 256), dim3(256), 0, st, r);
+    hipLaunchKernelGGL(k_enc_reduce, dim3((off + 63) / 64), dim3(256), 0, st, r);
     return check_launch("k_enc_reduce");
 }
 

@@ -70,14 +70,23 @@ class GPLayer:
             self._state = GpState(self.num_inducing, self.num_outputs, dev)
         return self._state
 
-    def state_desc(self):
-        """``iwvi_gp_desc`` of this layer's current parameters (for a batched precompute)."""
+    def state_dense(self):
+        """A second factorisation buffer that holds the DENSE float64 Lm, Lm^-1 for the adjoint (backward.py): it is filled
+        on a side stream beside the forward, which reads the first one."""
+        dev = self.q_mu.device
+        st = getattr(self, "_state_dense", None)
+        if st is None or st.buf.device != dev or (st.M, st.R) != (self.num_inducing, self.num_outputs):
+            st = self._state_dense = GpState(self.num_inducing, self.num_outputs, dev)
+        return st
+
+    def state_desc(self, state=None):
+        """``iwvi_gp_desc`` of this layer's current parameters (for a batched precompute); ``state``: the buffer to fill."""
         q_mu = _abi.dev_tensor(self.q_mu.contiguous(), "q_mu")
         q_sqrt = _abi.dev_tensor(self.q_sqrt.contiguous(), "q_sqrt")
         if q_sqrt.shape != (self.num_outputs, self.num_inducing, self.num_inducing):
             raise ValueError("q_sqrt must be [R, M, M], got %s" % (tuple(q_sqrt.shape),))
-        return self.state().desc(_abi.dev_tensor(self._Z(), "Z"), self._base_kern(), q_mu, q_sqrt,
-                                 settings.jitter_level)
+        return (state or self.state()).desc(_abi.dev_tensor(self._Z(), "Z"), self._base_kern(), q_mu, q_sqrt,
+                                            settings.jitter_level)
 
     def precompute(self):
         precompute_states([self.state_desc()])

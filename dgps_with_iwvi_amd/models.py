@@ -175,7 +175,9 @@ class DGP_VI:
                     if want_saved:                               # what the adjoint of this layer needs (backward.py)
                         Mp = layer.state().Mp
                         o["a_out"] = torch.empty(T, Mp, dtype=settings.float_type, device=dev)
-                        o["u_out"] = torch.empty(R, T, Mp, dtype=settings.float_type, device=dev)
+                        from .backward import needs_saved_u
+                        if needs_saved_u(layer.num_inducing, T):     # only the GEMM path of the adjoint reads u_r = L_r^T a
+                            o["u_out"] = torch.empty(R, T, Mp, dtype=settings.float_type, device=dev)
                         o["noise_out"] = torch.empty(T, R, dtype=settings.float_type, device=dev)
                         o["gmv_out"] = torch.empty(T, 3 * R, dtype=settings.float_type, device=dev)
                 d, k = layer.fused_desc(z2, o)

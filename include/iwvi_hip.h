@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define IWVI_ABI_VERSION 5
+#define IWVI_ABI_VERSION 6
 
 enum {
     IWVI_OK = 0,
@@ -260,7 +260,9 @@ int iwvi_dgp_forward(const iwvi_layer_desc* layers_host, int n_layers,
  *   state                  as precomputed WITH IWVI_GP_WANT_DENSE (the dense float64 Lm and Lm^-1 are read)
  *   F [T, D]               the layer's input rows (per sample)
  *   noise [T, R]           the draws the forward used (needed when d_sample is given)
- *   A [T, Mp], U [R, T, Mp]  a = Lm^-1 k and u_r = L_r^T a as the forward wrote them (a_out / u_out)
+ *   A [T, Mp], U [R, T, Mp]  a = Lm^-1 k and u_r = L_r^T a as the forward wrote them (a_out / u_out).  U may be NULL when
+ *                          M is a multiple of 16 up to 128, T a multiple of 16 and GMV is given: that shape takes the streaming
+ *                          chain, which works from a alone (sum_r 2dv_r L_r u_r = sum_r 2dv_r (L_r L_r^T) a, dL_r = tril(G_r L_r))
  *   GMV [T, 3R]            optional, the forward's gmv_out
  *   d_sample/d_mean/d_var [T, P]  upstream gradients, any may be NULL (= 0)
  *   kl_weight              the objective contains -kl_weight * KL[q(u)||p(u)] of this layer (1 for the ELBO)
@@ -285,8 +287,13 @@ typedef struct iwvi_gp_bwd_desc {
                                      * below; the caller joins the two streams before reading the parameter gradients */
     void* side_stream2;             /* optional second side stream: the parameter branch then runs as two concurrent chains
                                      * (Cholesky adjoint | the other sums over samples); join both */
+    int32_t prepared;               /* nonzero: iwvi_gp_layer_backward_prepare has already run on this (desc, ws) */
 } iwvi_gp_bwd_desc;
 size_t iwvi_gp_layer_backward_ws_bytes(int64_t T, int M, int D, int R);
+/* the parameter-only part of the adjoint (scaled inducing inputs, float32 Lm^-1, the streaming chain's packed operands
+ * S_r = L_r L_r^T and Lm^-T): reads state (dense factors), Z, lengthscales, q_sqrt, M / D / R of the descriptor only, so it can
+ * be queued on another stream beside the forward; then set desc.prepared.  Called implicitly otherwise. */
+int iwvi_gp_layer_backward_prepare(const iwvi_gp_bwd_desc* desc, int64_t T, void* ws, void* stream);
 int iwvi_gp_layer_backward(const iwvi_gp_bwd_desc* desc, int64_t T, void* ws, void* stream);
 
 /* Adjoint of the ELBO tail (models.py:134-150) for the IW tiling (sample t = b*K + k):
