@@ -346,7 +346,7 @@ __global__ __launch_bounds__(256) void k_reduce_parts(ReduceArgs r) {
     const size_t MN = (size_t)r.M * r.N;
     const float* part = r.part + (size_t)b * r.S * MN;
     double s = 0.0;
-    if (idx < r.M * r.N) {
+    if (idx < r.M * r.N && !(r.tri && (idx % r.N) > (idx / r.N))) {      // (discarded upper entries are not read: they may be unwritten)
         const int per = (r.S + 3) / 4, k0 = gq * per, k1 = (k0 + per < r.S) ? k0 + per : r.S;
 #pragma unroll 8
         for (int k = k0; k < k1; ++k) s += (double)part[(size_t)k * MN + idx];
@@ -378,7 +378,7 @@ __global__ __launch_bounds__(256) void k_reduce_multi(ReduceJobs q) {
     const size_t MN = (size_t)r.M * r.N;
     const float* part = r.part + (size_t)b * r.S * MN;
     double s = 0.0;
-    if (idx < r.M * r.N) {
+    if (idx < r.M * r.N && !(r.tri && (idx % r.N) > (idx / r.N))) {      // (discarded upper entries are not read: they may be unwritten)
         const int per = (r.S + 3) / 4, k0 = gq * per, k1 = (k0 + per < r.S) ? k0 + per : r.S;
 #pragma unroll 8
         for (int k = k0; k < k1; ++k) s += (double)part[(size_t)k * MN + idx];
@@ -910,14 +910,20 @@ struct ChainArgs {
     float* p_q;                          // [D + 2]     sum_j (dx~ o x | sum_r dv_r | sum_m k dk)   -> dls, dvariance terms
     float* p_w;                          // 3 [P][R]    dFs^T G | dFm^T MU | dFv^T V                 -> dW        (or NULL)
     float* p_a;                          // 2 [D][P]    F^T dFs | F^T dFm                            -> dmf_A     (or NULL)
+    // this workgroup's share of the two M x M products over samples (lower 16x16 blocks only, dense [M][M] addressing):
+    float* p_lm;                         // [S][M][M]      sum_j dk[m][j] a[n][j]                    -> dLm = -tril(.)   (reduced with alpha = -1)
+    float* p_g;                          // [R][S][M][M]   sum_j 2dv_r[j] a[m][j] a[n][j]            -> G_r (dL_r = tril(G_r L_r))
+    int S;                               // workgroups of the launch (stride of a batch in p_g)
 };
 template <int NS, int DM>               // 16 NS samples per workgroup (8 waves);  D <= DM
 __global__ __launch_bounds__(512) void k_bw_chain(ChainArgs a) {
     constexpr int NSAMP = 16 * NS;
     extern __shared__ __attribute__((aligned(16))) float csm[];
-    const int M = a.M, LDT = M + 4, nbk = a.nbk, R = a.R, D = a.D, P = a.P;
-    float* tileA = csm;                                      // a tile (B-operand layout), later dk sample-major [NSAMP][LDT]
-    float* tileD = tileA + NSAMP * LDT;                         // da tile (B-operand layout)
+    const int M = a.M, nbk = a.nbk, R = a.R, D = a.D, P = a.P;
+    // three tiles in the forward's B-operand layout, float4 [(bk*4 + g) * NSAMP + sample] = 4 consecutive m of one sample:
+    float* tileA = csm;                                      // a (kept to the end: the products over samples read it)
+    float* tileK = tileA + NSAMP * M;                        // dk, then c = dk o dk/dd2 (kernel adjoint)
+    float* tileD = tileK + NSAMP * M;                        // da; also stages the heads' inputs before and the scaled inducing inputs after
     float* qmu_s = tileD + a.dsz;                            // [M][R]
     float* dmu_s = qmu_s + M * R;                            // [NSAMP][R]
     float* dv2_s = dmu_s + NSAMP * R;                        // [NSAMP][R]
@@ -930,6 +936,7 @@ __global__ __launch_bounds__(512) void k_bw_chain(ChainArgs a) {
     const long long t0 = (long long)blockIdx.x * NSAMP;
     f32x4* tA4 = reinterpret_cast<f32x4*>(tileA);
     f32x4* tD4 = reinterpret_cast<f32x4*>(tileD);
+    f32x4* tK4 = reinterpret_cast<f32x4*>(tileK);
 
     // ---- phase 0: a rows -> LDS (B-operand layout), q_mu -> LDS; the heads' inputs (rows of the upstream gradients, of the
     //      forward's variances and draws, W, mfA) staged in the not-yet-used da tile with coalesced loads, then the heads from
@@ -1098,17 +1105,56 @@ __global__ __launch_bounds__(512) void k_bw_chain(ChainArgs a) {
 #pragma unroll
         for (int t = 0; t < NS; ++t) {
             const int j = 16 * t + jq;
-            *reinterpret_cast<f32x4*>(&tileA[j * LDT + 16 * bi + 4 * gq]) = acc[t];       // sample-major for the kernel adjoint
-            *reinterpret_cast<f32x4*>(a.DK + (size_t)(t0 + j) * M + 16 * bi + 4 * gq) = acc[t];
+            tK4[(bi * 4 + gq) * NSAMP + j] = acc[t];
+            if (a.DK) *reinterpret_cast<f32x4*>(a.DK + (size_t)(t0 + j) * M + 16 * bi + 4 * gq) = acc[t];   // (only for the split-K GEMM path of dLm)
         }
     }
     __syncthreads();
     if (a.dbg_exit == 3) return;
 
+    // ---- phase 5 (before the kernel adjoint overwrites dk): this workgroup's share of the two products over samples,
+    //      P_lm(bi, bk) = sum_j dk(bi)[., j] a(bk)[., j]^T and P_g[r](bi, bk) = sum_j 2dv_r[j] a(bi)[., j] a(bk)[., j]^T, lower blocks.
+    //      The contraction runs over the chunk's samples (4 per MFMA step), so both operands are read TRANSPOSED from the tiles
+    //      (scalar LDS reads); the A side of a (row-block, product) pair -- NSAMP / 4 registers, for G_r scaled by 2dv_r -- is
+    //      read once and reused for every bk <= bi.  Waves: row-block pair (w & 3, nbk-1-(w & 3)) x half of the 1 + R products.
+    {
+        const int pr = wave & 3, half = wave >> 2;
+        const int nit = R + 1, i_lo = half == 0 ? 0 : (nit + 1) / 2, i_hi = half == 0 ? (nit + 1) / 2 : nit;   // item 0 = dLm, 1 + r = G_r
+        for (int pass = 0; pass < 2 && a.p_lm; ++pass) {
+            const int bi = pass == 0 ? pr : nbk - 1 - pr;
+            if (bi < 0 || bi >= nbk) continue;
+            if (pass == 0 ? (pr > nbk - 1 - pr) : (nbk - 1 - pr <= pr)) continue;
+            for (int it = i_lo; it < i_hi; ++it) {
+                if (it > 0 && !a.p_g) continue;              // (G_r not asked for)
+                const float* src = it == 0 ? tileK : tileA;
+                float av[4 * NS];
+#pragma unroll
+                for (int q = 0; q < 4 * NS; ++q) {           // A[i = jq][k = sample 4q + gq] = src[row 16bi + jq][sample]
+                    const int smp = 4 * q + gq;
+                    float v = src[((size_t)(bi * 4 + (jq >> 2)) * NSAMP + smp) * 4 + (jq & 3)];
+                    if (it > 0) v *= dv2_s[smp * R + (it - 1)];
+                    av[q] = v;
+                }
+                float* outp = it == 0 ? a.p_lm + (size_t)blockIdx.x * M * M
+                                      : a.p_g + ((size_t)(it - 1) * a.S + blockIdx.x) * M * M;
+                for (int bk = 0; bk <= bi; ++bk) {
+                    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int q = 0; q < 4 * NS; ++q) {       // B[k = sample 4q + gq][j = jq] = a[row 16bk + jq][sample]
+                        const float bv = tileA[((size_t)(bk * 4 + (jq >> 2)) * NSAMP + 4 * q + gq) * 4 + (jq & 3)];
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q], bv, acc, 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) outp[(size_t)(16 * bi + 4 * gq + e) * M + 16 * bk + jq] = acc[e];
+                }
+            }
+        }
+    }
+    __syncthreads();                                         // phase 3 rewrites the dk tile
+
     // ---- phase 3: kernel adjoint (direct differences), 16 lanes per sample, 16 samples per round.  The scaled inducing inputs
     //      and the chunk's input rows are staged in the (now free) da tile, padded to DM columns: per-element global loads in the
     //      inner loops were a chain of dependent L1 round trips (50-70 us of this kernel) ------------------------------------
-    float* tile = tileA;
     float* zs = tileD;                                       // [M][DM]   (zero beyond D)
     for (int idx = tid; idx < M * DM; idx += 512) { const int m = idx / DM, d = idx - m * DM; zs[idx] = d < D ? a.Zt[m * D + d] : 0.f; }
     __syncthreads();
@@ -1125,7 +1171,7 @@ __global__ __launch_bounds__(512) void k_bw_chain(ChainArgs a) {
         for (int m0 = 0; m0 < M; m0 += 64) {
             const int mb = m0 + 4 * sub;
             if (mb < M) {
-                const f32x4 dk = *reinterpret_cast<const f32x4*>(&tile[j * LDT + mb]);
+                const f32x4 dk = tK4[(mb >> 2) * NSAMP + j];
                 f32x4 c;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -1140,7 +1186,7 @@ __global__ __launch_bounds__(512) void k_bw_chain(ChainArgs a) {
 #pragma unroll
                     for (int d = 0; d < DM; ++d) cz[d] = fmaf(c[e], z[d], cz[d]);
                 }
-                *reinterpret_cast<f32x4*>(&tile[j * LDT + mb]) = c;       // c over dk (same thread, same slot): the C^T F sums below
+                tK4[(mb >> 2) * NSAMP + j] = c;                          // c over dk (same thread, same slot): the C^T F sums below
             }
         }
         sc = gsum(sc); skd = gsum(skd);
@@ -1168,10 +1214,10 @@ __global__ __launch_bounds__(512) void k_bw_chain(ChainArgs a) {
             float acc = 0.f;
             if (d < D) {
 #pragma unroll 16
-                for (int j = 0; j < NSAMP; ++j) acc = fmaf(tile[j * LDT + m], fr[j * DM + d], acc);
+                for (int j = 0; j < NSAMP; ++j) acc = fmaf(tileK[((size_t)(m >> 2) * NSAMP + j) * 4 + (m & 3)], fr[j * DM + d], acc);
             } else {
 #pragma unroll 16
-                for (int j = 0; j < NSAMP; ++j) acc += tile[j * LDT + m];
+                for (int j = 0; j < NSAMP; ++j) acc += tileK[((size_t)(m >> 2) * NSAMP + j) * 4 + (m & 3)];
             }
             pc[idx] = acc;
         }
@@ -1223,6 +1269,10 @@ static int chain_ns(long long T) {                          // samples per workg
 static bool chain_ok(int M, int Mp, long long T) {
     return Mp == M && M <= 128 && (T % 16) == 0 && !getenv("IWVI_BW_UNFUSED") && !getenv("IWVI_BW_OLD_CHAIN");
 }
+// the two M x M products over samples inside the chain kernel: only while the number of per-workgroup shares stays moderate
+static bool chain_products_ok(int M, long long T) {
+    return chain_ok(M, round_up(M, 16), T) && T / (16 * chain_ns(T)) <= 1024 && !getenv("IWVI_BW_GEMM_PRODUCTS");
+}
 template <int NS>
 static int launch_chain_ns(hipStream_t st, ChainArgs a) {
     constexpr int NSAMP = 16 * NS;
@@ -1232,11 +1282,11 @@ static int launch_chain_ns(hipStream_t st, ChainArgs a) {
     if (heads > dsz) dsz = heads;
     if (adj > dsz) dsz = adj;
     a.dsz = (dsz + 3) & ~3;
-    const size_t lds = sizeof(float) * ((size_t)NSAMP * (a.M + 4) + (size_t)a.dsz + (size_t)a.M * a.R + (size_t)NSAMP * (2 * a.R + 1) + (size_t)NSAMP * a.D
+    const size_t lds = sizeof(float) * ((size_t)2 * NSAMP * a.M + (size_t)a.dsz + (size_t)a.M * a.R + (size_t)NSAMP * (2 * a.R + 1) + (size_t)NSAMP * a.D
                                         + (size_t)NSAMP * DM + DM + (size_t)NSAMP * (a.D + 2));
     static bool done = false;
     if (!done) {
-        const size_t most = sizeof(float) * ((size_t)NSAMP * 132 + (size_t)(NSAMP * 128 > 3 * NSAMP * IWVI_MAX_P + IWVI_MAX_P * IWVI_MAX_R + 2 * NSAMP * IWVI_MAX_R + IWVI_MAX_D * IWVI_MAX_P
+        const size_t most = sizeof(float) * ((size_t)NSAMP * 256 + (size_t)(NSAMP * 128 > 3 * NSAMP * IWVI_MAX_P + IWVI_MAX_P * IWVI_MAX_R + 2 * NSAMP * IWVI_MAX_R + IWVI_MAX_D * IWVI_MAX_P
                                                                             ? NSAMP * 128 : 3 * NSAMP * IWVI_MAX_P + IWVI_MAX_P * IWVI_MAX_R + 2 * NSAMP * IWVI_MAX_R + IWVI_MAX_D * IWVI_MAX_P)
                                              + 128 * 32 + 32 + 128 * IWVI_MAX_R + NSAMP * (4 * IWVI_MAX_R + 1) + NSAMP * IWVI_MAX_D + NSAMP * 32 + 32 + NSAMP * (IWVI_MAX_D + 2));
         const void* fns[] = {(const void*)k_bw_chain<NS, 8>, (const void*)k_bw_chain<NS, 16>, (const void*)k_bw_chain<NS, 32>};
@@ -1471,6 +1521,10 @@ static BwdWs bwd_layout(char* base, long long T, int M, int D, int R) {
     w.DA = (float*)take(sizeof(float) * T * M); w.DK = (float*)take(sizeof(float) * T * M);
     w.Qx = (float*)take(sizeof(float) * T * (D + 2));
     w.part_floats = (size_t)nsplit * M * M * (R + 1);          // dLm + the R batched dL_r, parked together
+    if (chain_products_ok(M, T)) {                               // the chain kernel's per-workgroup shares of dLm and G_r instead
+        const size_t need = (size_t)(T / (16 * chain_ns(T))) * M * M * (R + 1);
+        if (need > w.part_floats) w.part_floats = need;
+    }
     {   // thin reductions: ceil(T / THIN_ROWS) chunks of at most [max(M, 34)][33]
         const size_t thin = (size_t)((T + (long long)THIN_ROWS * thin_chunks(T) - 1) / ((long long)THIN_ROWS * thin_chunks(T))) * (M > 34 ? M : 34) * 33;
         w.part_floats += 8 * thin + 1024;                      // + up to 8 thin products
@@ -1941,7 +1995,9 @@ extern "C" int iwvi_gp_layer_backward(const iwvi_gp_bwd_desc* dp, int64_t T, voi
     if (!d.prepared && (rc = iwvi_gp_layer_backward_prepare(dp, T, ws_, stream_)) != IWVI_OK) return rc;
     const float* gmv = d.GMV ? d.GMV : w.GMV;
     // deferred reductions of this layer: every product over samples parks its partial sums in its own slice of the workspace
-    const size_t partA = (size_t)((T + splitk_chunk(T) - 1) / splitk_chunk(T) + 2) * M * M;
+    const bool prod = d.GMV && chain_products_ok(M, T);    // dLm and G_r shares come out of the chain kernel
+    size_t partA = (size_t)((T + splitk_chunk(T) - 1) / splitk_chunk(T) + 2) * M * M;
+    if (prod && (size_t)(T / (16 * chain_ns(T))) * M * M > partA) partA = (size_t)(T / (16 * chain_ns(T))) * M * M;
     const bool two_q = d.side_stream && d.side_stream2 && d.side_stream2 != d.side_stream;
     ReduceQueue rqA(w.part, two_q ? partA : 0), rqB(w.part + (two_q ? partA : 0), w.part_floats - (two_q ? partA : 0));
     float* s[3] = {nullptr, nullptr, nullptr}; float* a12[2] = {nullptr, nullptr};
@@ -1969,6 +2025,19 @@ extern "C" int iwvi_gp_layer_backward(const iwvi_gp_bwd_desc* dp, int64_t T, voi
         if (d.dW && d.W) { ca.p_w = job(3 * P, R, w.lin, nullptr, 0.0); for (int i = 0; i < 3; ++i) s[i] = w.lin + (size_t)i * P * R; if (!ca.p_w) ca.p_qmu = nullptr; }
         if (d.dmf_A && d.mf_type == IWVI_MF_LINEAR) { ca.p_a = job(2 * D, P, w.lin + 3 * IWVI_MAX_P * IWVI_MAX_R, nullptr, 0.0); for (int i = 0; i < 2; ++i) a12[i] = w.lin + 3 * IWVI_MAX_P * IWVI_MAX_R + (size_t)i * D * P; if (!ca.p_a) ca.p_qmu = nullptr; }
         if (!ca.p_qmu || !ca.p_ctf || !ca.p_q) { set_error("backward: workspace too small for the chain kernel's partial sums"); return IWVI_ERR_ARG; }
+        ca.S = S;
+        if (prod) {                                        // dLm and G_r shares too: no DK / A round trip, no split-K launches
+            ReduceQueue& qa = two_q ? rqA : rqB;
+            ca.p_lm = qa.take((size_t)S * M * M);
+            ReduceArgs rl{ca.p_lm, S, M, M, nullptr, w.Lbar, (long long)M, -1.0, 0.0, 1, 0, nullptr, 0.0, 0};
+            if (!ca.p_lm || !qa.push(rl, 1)) { set_error("backward: workspace too small for the chain kernel's dLm shares"); return IWVI_ERR_ARG; }
+            if (d.dq_sqrt) {
+                ca.p_g = rqB.take((size_t)R * S * M * M);
+                ReduceArgs rg{ca.p_g, S, M, M, w.G, nullptr, (long long)M, 1.0, 0.0, 1, (long long)M * M, nullptr, 0.0, 0};
+                if (!ca.p_g || !rqB.push(rg, R)) { set_error("backward: workspace too small for the chain kernel's G_r shares"); return IWVI_ERR_ARG; }
+            }
+            ca.DK = nullptr;
+        }
         if ((rc = launch_chain(st, ca)) != IWVI_OK) return rc;
     }
     MidArgs ma{d.GMV, d.noise, d.W, d.mf_A, d.d_sample, d.d_mean, d.d_var, w.DMU, w.DV2, w.SDV, d.dF, d.P, d.mf_type,
@@ -2039,7 +2108,7 @@ extern "C" int iwvi_gp_layer_backward(const iwvi_gp_bwd_desc* dp, int64_t T, voi
     {
         GemmArgs q{};
         q.A = w.DK; q.a_sm = 1; q.a_sk = M; q.B = d.A; q.b_sk = Mp; q.b_sn = 1; q.M = M; q.N = M; q.K = (int)T; q.tri_out = 1;
-        if ((rc = gemm(stA, q, w.part, w.part_floats, nullptr, w.Lbar, M, -1.0, 0.0, 1, 1, 0, 0, 0, two ? &rqA : &rqB)) != IWVI_OK) return rc;
+        if (!(chain && prod) && (rc = gemm(stA, q, w.part, w.part_floats, nullptr, w.Lbar, M, -1.0, 0.0, 1, 1, 0, 0, 0, two ? &rqA : &rqB)) != IWVI_OK) return rc;
         if (two) {                                         // its own reduction and the float64 chain, concurrently with chain B
             if ((rc = rqA.flush(stA)) != IWVI_OK || (rc = chol_adjoint(stA)) != IWVI_OK) return rc;
             if (hipEventCreateWithFlags(&evA, hipEventDisableTiming) != hipSuccess || hipEventRecord(evA, stA) != hipSuccess) {
@@ -2053,7 +2122,7 @@ extern "C" int iwvi_gp_layer_backward(const iwvi_gp_bwd_desc* dp, int64_t T, voi
     // (- kl_weight * dKL/dq_mu = - kl_weight * q_mu rides in the reduction; temp_workaround.py:186-188)
     if (!chain && d.dq_mu && (rc = thin(st, d.A, Mp, M, w.DMU, R, R, 0, T, w.part, w.part_floats, d.dq_mu, 0, &rqB, d.q_mu, -d.kl_weight)) != IWVI_OK) return rc;
     // streaming path: dL_r = tril(G_r L_r) with G_r = A^T diag(2 dv_r) A (lower tiles of a split-K SYRK, all r in one batched launch)
-    if (d.dq_sqrt && chain) {
+    if (d.dq_sqrt && chain && !prod) {
         GemmArgs q{};
         q.A = d.A; q.a_sm = 1; q.a_sk = Mp; q.B = d.A; q.b_sk = Mp; q.b_sn = 1;
         q.scale = w.DV2; q.s_stride = R; q.scale_on_k = 1; q.M = M; q.N = M; q.K = (int)T; q.tri_out = 1;
