@@ -100,10 +100,25 @@ def training_leg(model, samples, iters=20):
             return (time.perf_counter() - t0) / iters * 1e3
 
         grad_ms = timed(lambda: backward.iw_elbo_and_gradients(model))
-        tr = Trainer(model)
-        step_ms = timed(tr.step)
-        return {"value_and_gradient_ms": grad_ms, "gradient_samples_per_s": samples / grad_ms * 1e3, "train_step_ms": step_ms,
-                "note": "layer-by-layer adjoint kernels, first version (DESIGN.md section 5b); runs after the timed region and changes the model's parameters"}
+        # the same evaluation replayed from a hipGraph (what a training loop with use_graph=True runs)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            backward.iw_elbo_and_gradients(model)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):
+                keep = backward.iw_elbo_and_gradients(model)
+        torch.cuda.current_stream().wait_stream(side)
+        grad_graph_ms = timed(g.replay)
+        step_ms = timed(Trainer(model).step)
+        step_graph_ms = timed(Trainer(model, use_graph=True).step)
+        return {"value_and_gradient_ms": grad_graph_ms, "value_and_gradient_eager_ms": grad_ms,
+                "gradient_samples_per_s": samples / grad_graph_ms * 1e3,
+                "train_step_ms": step_graph_ms, "train_step_eager_ms": step_ms,
+                "note": "value + gradient: one hipGraph replay of backward.iw_elbo_and_gradients (fused forward that keeps a, streaming adjoint chain "
+                        "per layer, Cholesky adjoint; DESIGN.md section 5b); train step: training.Trainer(use_graph=True).step = NatGrad op + Adam op, "
+                        "each one graph replay, trained scalars and Adam's step count on the device; runs after the timed region and changes the "
+                        "model's parameters"}
     except Exception as e:                                   # never let the informational leg take the bench line down
         return {"error": "%s: %s" % (type(e).__name__, e)}
 

@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libiwvi_hip.so")
 
 KERN_RBF, KERN_MATERN52 = 0, 1
 LAYER_GP, LAYER_LV = 0, 1
-ABI_VERSION = 6
+ABI_VERSION = 7
 GP_WANT_DENSE = 1
 MAX_STACK = 8
 MF_ZERO, MF_IDENTITY, MF_LINEAR = 0, 1, 2
@@ -33,7 +33,8 @@ class GpDesc(ctypes.Structure):
     _fields_ = [("Z", c_void_p), ("lengthscales", c_void_p), ("q_mu", c_void_p),
                 ("q_sqrt", c_void_p), ("state", c_void_p), ("variance", c_float),
                 ("jitter", c_double), ("M", ctypes.c_int32), ("D", ctypes.c_int32),
-                ("R", ctypes.c_int32), ("kern_type", ctypes.c_int32), ("flags", ctypes.c_int32)]
+                ("R", ctypes.c_int32), ("kern_type", ctypes.c_int32), ("flags", ctypes.c_int32),
+                ("variance_dev", c_void_p)]
 
 
 class EncDesc(ctypes.Structure):
@@ -58,7 +59,7 @@ class LayerDesc(ctypes.Structure):
                 ("enc_out", c_void_p),
                 ("noise", c_void_p), ("zero_noise", ctypes.c_int32), ("noise_out", c_void_p),
                 ("sample", c_void_p), ("mean", c_void_p), ("var", c_void_p), ("kl_local", c_void_p),
-                ("a_out", c_void_p), ("u_out", c_void_p), ("gmv_out", c_void_p)]
+                ("a_out", c_void_p), ("u_out", c_void_p), ("gmv_out", c_void_p), ("variance_dev", c_void_p)]
 
 
 class ElboDesc(ctypes.Structure):
@@ -68,7 +69,7 @@ class ElboDesc(ctypes.Structure):
                 ("n_glob", ctypes.c_int32), ("scale", c_double), ("K_total", ctypes.c_int32),
                 ("mode_vi", ctypes.c_int32), ("out_lse_ms", c_void_p), ("out_logp", c_void_p),
                 ("out_elbo", c_void_p), ("ws", c_void_p), ("lw_init", c_void_p), ("noise_layer_base", ctypes.c_int32),
-                ("x_per_sample", ctypes.c_int32)]
+                ("x_per_sample", ctypes.c_int32), ("lik_variance_dev", c_void_p)]
 
 
 class GpBwdDesc(ctypes.Structure):
@@ -81,7 +82,8 @@ class GpBwdDesc(ctypes.Structure):
                 ("d_sample", c_void_p), ("d_mean", c_void_p), ("d_var", c_void_p), ("kl_weight", c_double),
                 ("dF", c_void_p), ("dZ", c_void_p), ("dls", c_void_p), ("dvariance", c_void_p),
                 ("dq_mu", c_void_p), ("dq_sqrt", c_void_p), ("dW", c_void_p), ("dmf_A", c_void_p),
-                ("side_stream", c_void_p), ("side_stream2", c_void_p), ("prepared", ctypes.c_int32)]
+                ("side_stream", c_void_p), ("side_stream2", c_void_p), ("prepared", ctypes.c_int32),
+                ("variance_dev", c_void_p)]
 
 
 class AdamTensor(ctypes.Structure):
@@ -109,6 +111,10 @@ PROTOTYPES = {
                                       ctypes.POINTER(ctypes.c_int32), c_int, c_int64, c_int, c_float, c_double, c_int,
                                       c_void_p, c_void_p, c_void_p, ctypes.POINTER(c_void_p), ctypes.POINTER(ctypes.c_int32), c_int,
                                       c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+    "iwvi_iw_elbo_backward_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_int, ctypes.POINTER(c_void_p),
+                                          ctypes.POINTER(ctypes.c_int32), c_int, c_int64, c_int, c_float, c_void_p, c_double, c_int,
+                                          c_void_p, c_void_p, c_void_p, ctypes.POINTER(c_void_p), ctypes.POINTER(ctypes.c_int32), c_int,
+                                          c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "iwvi_lv_layer_backward": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p,
                                        c_int, c_int64, c_int, c_int, c_void_p, c_void_p]),
     "iwvi_encoder_backward_ws_bytes": (c_size_t, [c_int64, ctypes.POINTER(ctypes.c_int32), c_int]),
@@ -120,6 +126,7 @@ PROTOTYPES = {
     "iwvi_natgrad_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_double, c_void_p, c_void_p]),
     "iwvi_adam_step": (c_int, [ctypes.POINTER(AdamTensor), c_int, c_double, c_double, c_double, c_double, c_int64,
                                c_int, c_int, c_void_p]),
+    "iwvi_adam_step_dev": (c_int, [ctypes.POINTER(AdamTensor), c_int, c_double, c_double, c_double, c_double, c_void_p, c_int, c_void_p]),
     "iwvi_gp_layer_forward": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_float,
                                       c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
                                       c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),

@@ -19,7 +19,9 @@ _SIDE = {}
 def _side_stream(device, which=0):
     """Two extra HIP streams per device: a layer's parameter-gradient branch runs there (as two concurrent chains) beside the
     adjoint of the layer below."""
-    key = (device.type, device.index, which)
+    # one set per CALLER stream: side streams that took part in a hipGraph capture on one stream are not reused for work
+    # forked from another (HIP then reports "capturing stream has unjoined work" for the later capture)
+    key = (device.type, device.index, which, torch.cuda.current_stream(device).cuda_stream)
     if key not in _SIDE:
         _SIDE[key] = torch.cuda.Stream(device=device)
     return _SIDE[key]
@@ -93,7 +95,8 @@ def _param_desc(layer, dense_state=None):
     Z, q_mu, q_sqrt = (_abi.dev_tensor(t.contiguous(), n) for t, n in ((layer._Z(), "Z"), (layer.q_mu, "q_mu"), (layer.q_sqrt, "q_sqrt")))
     b.state = (dense_state or layer.state()).buf.data_ptr()
     b.Z, b.lengthscales = Z.data_ptr(), kern.lengthscales.data_ptr()
-    b.q_mu, b.q_sqrt, b.variance = q_mu.data_ptr(), q_sqrt.data_ptr(), kern.variance
+    b.q_mu, b.q_sqrt = q_mu.data_ptr(), q_sqrt.data_ptr()
+    b.variance, b.variance_dev = kern.desc_variance()
     b.M, b.D, b.R, b.kern_type = M, Z.shape[1], R, kern.kern_type
     return b, [Z, q_mu, q_sqrt]
 
@@ -290,9 +293,10 @@ def iw_elbo_and_gradients(model, zs=None, mode_vi=None, exchange=None, K_total=N
             raise ValueError("the K-sharded exchange is for the importance-weighted bound")
         _, _, ms = model._reduce(fin.mean, fin.var, Y, kls, [], B, K, stride_b=K, stride_k=1, mode_vi=False, want_ms=True)
         lse_g = _abi.dev_tensor(exchange(ms).to(ft).contiguous(), "lse_global")
-    _abi.check(_abi.lib().iwvi_iw_elbo_backward(
+    lik_host, lik_dev = model.likelihood.desc_variance()
+    _abi.check(_abi.lib().iwvi_iw_elbo_backward_dev(
         _abi.ptr(fin.mean), _abi.ptr(fin.var), _abi.ptr(Y), Dy, klp, kld, len(kls), B, K,
-        float(model.likelihood.variance), scale, 1 if mode_vi else 0, _abi.ptr(w), _abi.ptr(d_mean), _abi.ptr(d_var),
+        lik_host, lik_dev, scale, 1 if mode_vi else 0, _abi.ptr(w), _abi.ptr(d_mean), _abi.ptr(d_var),
         glob_p, glob_n, len(glob), _abi.ptr(lse_g), int(K_total or K),
         ctypes.c_void_p(sums.data_ptr()), ctypes.c_void_p(ws.data_ptr()), _abi.stream_ptr()))
     grads = {"lik_var": sums[1]}

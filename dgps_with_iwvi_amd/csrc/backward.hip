@@ -472,6 +472,7 @@ struct HeadArgs {
     const float* dFs; const float* dFm; const float* dFv;
     float* DMU; float* DV2; float* SDV; float* dF;
     long long T; int M, Mp, D, R, P, mf_type; float variance;
+    const float* var_dev;               // optional device scalar read instead of `variance`
     const float* q_mu; float* GMV;      // optional [T, 3R] = (g_r | mu_r | v_r) per sample, for the mixing matrix's gradient
     const float* gmv_in;                // optional: the same block as the forward left it (then A and U are not read here)
 };
@@ -502,7 +503,7 @@ __global__ __launch_bounds__(256) void k_bw_heads(HeadArgs h) {
             for (int m = lane; m < h.M; m += 64) mu = fmaf(a[m], h.q_mu[m * h.R + r], mu);
             mu = wave_sum(mu);
             if (lane == 0) {
-                const float vr = fmaxf(h.variance - aa + uu, 0.f);
+                const float vr = fmaxf((h.var_dev ? *h.var_dev : h.variance) - aa + uu, 0.f);
                 float* o = h.GMV + t * 3 * h.R;
                 o[r] = mu + (h.eps ? h.eps[t * h.R + r] : 0.f) * sqrtf(vr); o[h.R + r] = mu; o[2 * h.R + r] = vr;
             }
@@ -520,7 +521,7 @@ __global__ __launch_bounds__(256) void k_bw_heads(HeadArgs h) {
             if (h.dFm) dm = h.dFm[t * h.P + r];
             if (h.dFv) dvv = h.dFv[t * h.P + r];
         }
-        const float v = h.gmv_in ? h.gmv_in[t * 3 * h.R + 2 * h.R + r] : h.variance - aa + uu;
+        const float v = h.gmv_in ? h.gmv_in[t * 3 * h.R + 2 * h.R + r] : (h.var_dev ? *h.var_dev : h.variance) - aa + uu;
         float dv = dvv;
         if (v > 0.f) { if (h.eps) dv += dg * h.eps[t * h.R + r] * 0.5f / sqrtf(v); } else dv = 0.f;   // the forward clamps v at 0
         if (lane == r) { mine_dv = dv; mine_dmu = dg + dm; }
@@ -567,7 +568,7 @@ __device__ __forceinline__ void kern_and_grad(T d2, int type, T var, T& k, T& g)
 // dx~ = 2 x~ sum_m c_m - 2 sum_m c_m z~_m, dF += dx~ * invls, and the per-sample row of column-sum inputs
 // Qx[t] = (dx~ o x [D] | sum_r dv_r | sum_m k dk).
 struct KernArgs { const float* F; const float* Zt; const float* invls; const float* DK; float* C; const float* SDV; float* dF; float* Qx;
-                  long long T; int M, D; float variance; int kern_type; };
+                  long long T; int M, D; float variance; int kern_type; const float* var_dev; };
 template <int DM>                       // D <= DM: the per-dimension arrays stay in registers
 __global__ __launch_bounds__(256) void k_bw_kernel(KernArgs a) {
     // 16 lanes per sample (16 samples per workgroup): lane `sub` takes columns m0 + 4 sub .. + 3 of every 64-column step
@@ -595,7 +596,7 @@ __global__ __launch_bounds__(256) void k_bw_kernel(KernArgs a) {
 #pragma unroll
             for (int d = 0; d < DM; ++d) { z[d] = d < a.D ? a.Zt[m * a.D + d] : 0.f; const float q = xt[d] - z[d]; d2 = fmaf(q, q, d2); }
             float kv, kg;
-            kern_and_grad<float>(d2, a.kern_type, a.variance, kv, kg);
+            kern_and_grad<float>(d2, a.kern_type, a.var_dev ? *a.var_dev : a.variance, kv, kg);
             const float kd = (mb + e < a.M) ? kv * dk[e] : 0.f;
             c[e] = (mb + e < a.M) ? kg * dk[e] : 0.f;
             sc += c[e]; skd += kd;
@@ -637,7 +638,7 @@ struct MidArgs {
     const float* U; const float* A; int Mp; const float* q_sqrt; const float* q_mu;
     const float* LinvF; float* DK;
     const float* F; const float* Zt; const float* invls; float* C; float* Qx;
-    long long T; int M, D, R; float variance; int kern_type;
+    long long T; int M, D, R; float variance; int kern_type; const float* var_dev;
 };
 template <int NP, int DM>                // M = 64 NP;  D <= DM
 __global__ __launch_bounds__(256) void k_bw_mid(MidArgs a) {
@@ -820,7 +821,7 @@ __global__ __launch_bounds__(256) void k_bw_mid(MidArgs a) {
 #pragma unroll
                 for (int d = 0; d < DM; ++d) { z[d] = d < D ? a.Zt[(mb + e) * D + d] : 0.f; const float q = xt[d] - z[d]; d2 = fmaf(q, q, d2); }
                 float kv, kg;
-                kern_and_grad<float>(d2, a.kern_type, a.variance, kv, kg);
+                kern_and_grad<float>(d2, a.kern_type, a.var_dev ? *a.var_dev : a.variance, kv, kg);
                 const float kd = kv * dk[e];
                 c[e] = kg * dk[e];
                 sc += c[e]; skd += kd;
@@ -903,6 +904,7 @@ struct ChainArgs {
     float* DK;
     const float* F; const float* Zt; const float* invls; float* C; float* Qx;
     long long T; int M, D, R, nbk; float variance; int kern_type; int dbg_exit;
+    const float* var_dev;                // optional device scalar read instead of `variance`
     int dsz;                             // floats of the da tile's LDS region (it also stages the heads' and the kernel adjoint's inputs)
     // this workgroup's share of the thin sums over samples, each job [workgroups][len] at its own base (summed by k_reduce_multi):
     float* p_qmu;                        // [M][R]      sum_j a[m][j] dmu[j][r]                      -> dq_mu
@@ -1179,7 +1181,7 @@ __global__ __launch_bounds__(512) void k_bw_chain(ChainArgs a) {
 #pragma unroll
                     for (int d = 0; d < DM; ++d) { z[d] = zs[(mb + e) * DM + d]; const float q = xt[d] - z[d]; d2 = fmaf(q, q, d2); }
                     float kv, kg;
-                    kern_and_grad<float>(d2, a.kern_type, a.variance, kv, kg);
+                    kern_and_grad<float>(d2, a.kern_type, a.var_dev ? *a.var_dev : a.variance, kv, kg);
                     const float kd = kv * dk[e];
                     c[e] = kg * dk[e];
                     sc += c[e]; skd += kd;
@@ -1448,7 +1450,8 @@ __global__ void k_prep(const float* Z, const float* ls, const double* Linv64, in
     if (idx < M * M) { const int i = idx / M, j = idx - i * M; LinvF[idx] = j <= i ? (float)Linv64[(size_t)i * Mp + j] : 0.f; }
 }
 // row m of K_uu: dZ~_uu[m, :] = 4 sum_n Sbar_mn dK_mn/dd2 (z~_m - z~_n),  dvar_m = sum_n Sbar_mn K_mn / s2,  Sbar = (S + S^T)/2
-__global__ __launch_bounds__(256) void k_kuu_bwd(const float* Zt, const double* S, int M, int D, double variance, int kern_type, double* dZt_uu, double* dvar_m) {
+__global__ __launch_bounds__(256) void k_kuu_bwd(const float* Zt, const double* S, int M, int D, double variance_, const float* var_dev, int kern_type, double* dZt_uu, double* dvar_m) {
+    const double variance = var_dev ? (double)*var_dev : variance_;
     __shared__ double red[256];
     const int m = blockIdx.x, tid = threadIdx.x;
     double acc[IWVI_MAX_D + 1];
@@ -1474,7 +1477,7 @@ struct FinalArgsB {
     const float* Z; const float* ls; const float* q_mu; const float* q_sqrt; const float* Zt; const float* invls;
     const float* colsumC; const float* CtF; const float* sums; const float* dinvls_x; const double* dZt_uu; const double* dvar_m;
     float* dZ; float* dls; float* dvariance; float* dq_mu; float* dq_sqrt;
-    int M, D, R; double kl_weight, variance;
+    int M, D, R; double kl_weight, variance; const float* var_dev;
 };
 // workgroup d < D: dZ[:, d] and dls[d]; workgroup D: dvariance.  One wave each, lanes over m, fixed reduction tree.
 __global__ __launch_bounds__(64) void k_bw_final(FinalArgsB f) {
@@ -1494,7 +1497,7 @@ __global__ __launch_bounds__(64) void k_bw_final(FinalArgsB f) {
     } else if (f.dvariance) {
         double s = 0.0;
         for (int m = lane; m < f.M; m += 64) s += f.dvar_m[m];
-        s = wsum(s) + (double)f.sums[0] + (double)f.sums[1] / f.variance;     // + sum_t sum_r dv_r  +  sum k dk / s2
+        s = wsum(s) + (double)f.sums[0] + (double)f.sums[1] / (f.var_dev ? (double)*f.var_dev : f.variance);     // + sum_t sum_r dv_r  +  sum k dk / s2
         if (lane == 0) f.dvariance[0] = (float)s;
     }
 }
@@ -1553,7 +1556,7 @@ static BwdWs bwd_layout(char* base, long long T, int M, int D, int R) {
 struct ElboBwdArgs {
     const float* fmean; const float* fvar; const float* Y; int Dy;
     const float* kl[IWVI_MAX_KL]; int kl_dims[IWVI_MAX_KL]; int n_kl;
-    long long B; int K; float lik_var; double scale; int mode_vi;
+    long long B; int K; float lik_var; const float* lik_var_dev; double scale; int mode_vi;
     const float* lse_global; int K_total;   // K-sharded: logsumexp over ALL the job's samples of each point (after the exchange)
     float* w; float* d_mean; float* d_var; double* part;   // part[0..B) = lse - log K, part[B..2B) = d lik_var share
 };
@@ -1561,7 +1564,7 @@ __global__ __launch_bounds__(256) void k_elbo_bwd(ElboBwdArgs a) {      // one w
     const int lane = threadIdx.x & 63;
     const long long b = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (b >= a.B) return;
-    const float s = a.lik_var, c0 = -0.5f * logf(6.283185307179586f * s);
+    const float s = a.lik_var_dev ? *a.lik_var_dev : a.lik_var, c0 = -0.5f * logf(6.283185307179586f * s);
     auto logw = [&](long long t) {
         float l = 0.f;
         for (int j = 0; j < a.Dy; ++j) {
@@ -1796,13 +1799,23 @@ static void dmm(hipStream_t st, const double* A, long long a_si, long long a_sk,
 }
 // X = L^-1 for n <= TRI_SMALL in ONE workgroup, 16x16 blocks of X in LDS: the diagonal blocks by substitution (a lane per
 // column), then block diagonal d = 1, 2, ...: X(i, i-d) = -X(i, i) * sum_{k=i-d}^{i-1} L(i, k) X(k, i-d); one barrier per d.
-constexpr int TRI_SMALL = 160;
+constexpr int TRI_SMALL = 128;     // (two copies of the lower blocks in LDS: 2 * 36 * 2 KiB + scratch at n = 128)
 __global__ __launch_bounds__(256) void k_tri_inv_small(const double* L, double* X, int n) {
     extern __shared__ double xs[];                       // lower-triangular blocks, row-block major: block (i, j) at tri(i) + j
     const int nb = (n + 15) / 16, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     auto blk = [&](int i, int j) { return xs + (size_t)(i * (i + 1) / 2 + j) * 256; };
-    auto Lel = [&](int r, int c) { return (r < n && c < n) ? L[(size_t)r * n + c] : (r == c ? 1.0 : 0.0); };   // identity padding
-    double* scratch = xs + (size_t)(nb * (nb + 1) / 2) * 256 + wave * 256;
+    // L's lower blocks staged in LDS first (same block layout, identity padding): element reads from global memory inside the
+    // substitution loops were a chain of dependent L2 round trips (~100 us for n = 128)
+    double* ls = xs + (size_t)(nb * (nb + 1) / 2) * 256;
+    for (int idx = tid; idx < (nb * (nb + 1) / 2) * 256; idx += 256) {
+        const int b = idx >> 8, e = idx & 255;
+        int bi = 0; while ((bi + 1) * (bi + 2) / 2 <= b) ++bi;
+        const int bj = b - bi * (bi + 1) / 2, r = 16 * bi + (e >> 4), c = 16 * bj + (e & 15);
+        ls[idx] = (r < n && c < n) ? L[(size_t)r * n + c] : (r == c ? 1.0 : 0.0);
+    }
+    __syncthreads();
+    auto Lel = [&](int r, int c) { return ls[(size_t)((r >> 4) * ((r >> 4) + 1) / 2 + (c >> 4)) * 256 + (r & 15) * 16 + (c & 15)]; };
+    double* scratch = ls + (size_t)(nb * (nb + 1) / 2) * 256 + wave * 256;
     for (int i = wave; i < nb; i += 4) {
         if (lane < 16) {
             double x[16];
@@ -1875,11 +1888,11 @@ __global__ __launch_bounds__(64) void k_tri_inv(const double* L, double* X, int 
 static int tri_inverse(hipStream_t st, const double* L, double* X, int n) {
     if (n <= TRI_SMALL) {
         const int nb = (n + 15) / 16;
-        const size_t lds = sizeof(double) * ((size_t)(nb * (nb + 1) / 2) * 256 + 4 * 256);
+        const size_t lds = sizeof(double) * ((size_t)(nb * (nb + 1) / 2) * 512 + 4 * 256);
         static bool done = false;
         if (!done) {
             const int nbm = (TRI_SMALL + 15) / 16;
-            const size_t most = sizeof(double) * ((size_t)(nbm * (nbm + 1) / 2) * 256 + 4 * 256);
+            const size_t most = sizeof(double) * ((size_t)(nbm * (nbm + 1) / 2) * 512 + 4 * 256);
             hipError_t e = hipFuncSetAttribute((const void*)k_tri_inv_small, hipFuncAttributeMaxDynamicSharedMemorySize, (int)most);
             if (e != hipSuccess) { set_error("hipFuncSetAttribute(%zu B LDS): %s", most, hipGetErrorString(e)); return IWVI_ERR_LAUNCH; }
             done = true;
@@ -1918,9 +1931,19 @@ __global__ void k_symmetrise(double* Q, int n) {       // Q <- (Q + Q^T) / 2, on
 // Adam on GPflow's unconstrained variables.  transform 1 = positive: p = softplus(x) + 1e-6 (gpflow.transforms.Log1pe)
 struct AdamTensor { float* p; const float* g; float* x; float* m; float* v; long long n; int transform; };
 constexpr int ADAM_MAX = 48;
-struct AdamArgs { AdamTensor t[ADAM_MAX]; int n; float lr_t, b1, b2, eps, sign; int init; };
+struct AdamArgs { AdamTensor t[ADAM_MAX]; int n; float lr_t, b1, b2, eps, sign; int init; const long long* t_dev; float lr; };
 __global__ void k_adam(AdamArgs a) {
     const AdamTensor& T = a.t[blockIdx.y];
+    float lr_t = a.lr_t;                                     // (a local: writing to the by-value argument block would copy all of it to scratch)
+    if (a.t_dev) {                                           // bias correction from the device-resident step count (this step = *t_dev + 1):
+        __shared__ float lr_sh;                              // two float64 pow() per workgroup, not per thread
+        if (threadIdx.x == 0) {
+            const double t = (double)(*a.t_dev + 1);
+            lr_sh = (float)((double)a.lr * sqrt(1.0 - pow((double)a.b2, t)) / (1.0 - pow((double)a.b1, t)));
+        }
+        __syncthreads();
+        lr_t = lr_sh;
+    }
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < T.n; i += (long long)gridDim.x * blockDim.x) {
         if (a.init) {
             const float p = T.p[i];
@@ -1933,11 +1956,12 @@ __global__ void k_adam(AdamArgs a) {
         if (T.transform == 1) g *= 1.f - __expf(-(T.p[i] - 1e-6f));          // d softplus(x) / dx = sigmoid(x)
         const float m = a.b1 * T.m[i] + (1.f - a.b1) * g;
         const float v = a.b2 * T.v[i] + (1.f - a.b2) * g * g;
-        x -= a.lr_t * m / (sqrtf(v) + a.eps);
+        x -= lr_t * m / (sqrtf(v) + a.eps);
         T.m[i] = m; T.v[i] = v; T.x[i] = x;
         T.p[i] = (T.transform == 1) ? (x > 20.f ? x : log1pf(__expf(x))) + 1e-6f : x;
     }
 }
+__global__ void k_inc_i64(long long* p) { if (threadIdx.x == 0 && blockIdx.x == 0) *p += 1; }
 
 }  // namespace iwvi
 
@@ -2009,7 +2033,7 @@ extern "C" int iwvi_gp_layer_backward(const iwvi_gp_bwd_desc* dp, int64_t T, voi
         const int nbk = Mp / 16;
         ChainArgs ca{d.GMV, d.noise, d.W, d.mf_A, d.d_sample, d.d_mean, d.d_var, w.DMU, w.DV2, w.SDV, d.dF, d.P, d.mf_type,
                      d.A, Mp, d.q_mu, w.SP, w.LinvTP, w.DK, d.F, w.Zt, w.invls, w.DA, w.Qx, (long long)T, M, D, R, nbk, d.variance, d.kern_type,
-                     getenv("IWVI_CHAIN_EXIT") ? atoi(getenv("IWVI_CHAIN_EXIT")) : 0};
+                     getenv("IWVI_CHAIN_EXIT") ? atoi(getenv("IWVI_CHAIN_EXIT")) : 0, d.variance_dev};
         // the thin sums over samples ride in the chain kernel: one partial per workgroup and job, summed with the rest of chain B
         const int S = (int)(T / (16 * chain_ns(T))), P = d.P;
         auto job = [&](int Mj, int Nj, float* out, const float* add, double add_coef) -> float* {
@@ -2041,11 +2065,11 @@ extern "C" int iwvi_gp_layer_backward(const iwvi_gp_bwd_desc* dp, int64_t T, voi
         if ((rc = launch_chain(st, ca)) != IWVI_OK) return rc;
     }
     MidArgs ma{d.GMV, d.noise, d.W, d.mf_A, d.d_sample, d.d_mean, d.d_var, w.DMU, w.DV2, w.SDV, d.dF, d.P, d.mf_type,
-               d.U, d.A, Mp, d.q_sqrt, d.q_mu, w.LinvF, w.DK, d.F, w.Zt, w.invls, w.DA, w.Qx, (long long)T, M, D, R, d.variance, d.kern_type};
+               d.U, d.A, Mp, d.q_sqrt, d.q_mu, w.LinvF, w.DK, d.F, w.Zt, w.invls, w.DA, w.Qx, (long long)T, M, D, R, d.variance, d.kern_type, d.variance_dev};
     const int fused = chain ? 1 : launch_mid(st, ma);      // heads + DA + dK + kernel adjoint in one launch where the shapes allow
     if (fused < 0) return fused;
     if (!fused) {
-        HeadArgs h{d.A, d.U, d.noise, d.W, d.mf_A, d.d_sample, d.d_mean, d.d_var, w.DMU, w.DV2, w.SDV, d.dF, T, M, Mp, D, R, d.P, d.mf_type, d.variance,
+        HeadArgs h{d.A, d.U, d.noise, d.W, d.mf_A, d.d_sample, d.d_mean, d.d_var, w.DMU, w.DV2, w.SDV, d.dF, T, M, Mp, D, R, d.P, d.mf_type, d.variance, d.variance_dev,
                    d.q_mu, (d.dW && d.W && !d.GMV) ? w.GMV : nullptr, d.GMV};
         hipLaunchKernelGGL(k_bw_heads, dim3((unsigned)((T + 3) / 4)), dim3(256), 0, st, h);
         if ((rc = check_launch("k_bw_heads")) != IWVI_OK) return rc;
@@ -2068,7 +2092,7 @@ extern "C" int iwvi_gp_layer_backward(const iwvi_gp_bwd_desc* dp, int64_t T, voi
             if ((rc = gemm_rows(st, q)) != IWVI_OK) return rc;
         }
         // C = -1/2 K o DK (over DA), dx~, dF, per-sample rows of the column sums
-        KernArgs ka{d.F, w.Zt, w.invls, w.DK, w.DA, w.SDV, d.dF, w.Qx, T, M, D, d.variance, d.kern_type};
+        KernArgs ka{d.F, w.Zt, w.invls, w.DK, w.DA, w.SDV, d.dF, w.Qx, T, M, D, d.variance, d.kern_type, d.variance_dev};
         {
             const dim3 grid((unsigned)((T + 15) / 16)), block(256);
             if (D <= 4) hipLaunchKernelGGL(k_bw_kernel<4>, grid, block, 0, st, ka);
@@ -2102,7 +2126,7 @@ extern "C" int iwvi_gp_layer_backward(const iwvi_gp_bwd_desc* dp, int64_t T, voi
         hipLaunchKernelGGL(k_dmm, grid, block, 0, s_, Lm64, 1LL, (long long)Mp, (const double*)w.Lbar, (long long)M, 1LL, w.T1, M, M, 1);
         hipLaunchKernelGGL(k_dmm, grid, block, 0, s_, Linv64, 1LL, (long long)Mp, (const double*)w.T1, (long long)M, 1LL, w.T2, M, M, 0);
         hipLaunchKernelGGL(k_dmm, grid, block, 0, s_, (const double*)w.T2, (long long)M, 1LL, Linv64, (long long)Mp, 1LL, w.S, M, M, 0);
-        hipLaunchKernelGGL(k_kuu_bwd, dim3(M), dim3(256), 0, s_, w.Zt, (const double*)w.S, M, D, (double)d.variance, d.kern_type, w.dZt_uu, w.dvar_m);
+        hipLaunchKernelGGL(k_kuu_bwd, dim3(M), dim3(256), 0, s_, w.Zt, (const double*)w.S, M, D, (double)d.variance, d.variance_dev, d.kern_type, w.dZt_uu, w.dvar_m);
         return check_launch("cholesky adjoint");
     };
     {
@@ -2169,7 +2193,7 @@ extern "C" int iwvi_gp_layer_backward(const iwvi_gp_bwd_desc* dp, int64_t T, voi
         (void)hipEventDestroy(evA);
     }
     FinalArgsB f{d.Z, d.lengthscales, d.q_mu, d.q_sqrt, w.Zt, w.invls, w.CtF1, w.CtF1, w.Qsum + D, w.Qsum, w.dZt_uu, w.dvar_m,
-                 d.dZ, d.dls, d.dvariance, d.dq_mu, d.dq_sqrt, M, D, R, d.kl_weight, (double)d.variance};
+                 d.dZ, d.dls, d.dvariance, d.dq_mu, d.dq_sqrt, M, D, R, d.kl_weight, (double)d.variance, d.variance_dev};
     hipLaunchKernelGGL(k_bw_final, dim3(D + 1), dim3(64), 0, st, f);
     return check_launch("k_bw_final");
 }
@@ -2179,8 +2203,18 @@ extern "C" int iwvi_iw_elbo_backward(const float* fmean, const float* fvar, cons
                                      int64_t B, int K, float lik_variance, double scale, int mode_vi,
                                      float* out_w, float* d_mean, float* d_var,
                                      const double* const* kl_global, const int32_t* kl_global_counts, int n_glob,
-                                     const float* lse_global, int K_total,
-                                     double* out_sums /* [3]: sum_n (lse - log K), d/d lik_variance, the bound */, double* ws, void* stream_) {
+                                     const float* lse_global, int K_total, double* out_sums, double* ws, void* stream_) {
+    return iwvi_iw_elbo_backward_dev(fmean, fvar, Y, Dy, kl_local, kl_dims, n_local, B, K, lik_variance, nullptr, scale, mode_vi, out_w, d_mean, d_var,
+                                     kl_global, kl_global_counts, n_glob, lse_global, K_total, out_sums, ws, stream_);
+}
+
+extern "C" int iwvi_iw_elbo_backward_dev(const float* fmean, const float* fvar, const float* Y, int Dy,
+                                         const float* const* kl_local, const int32_t* kl_dims, int n_local,
+                                         int64_t B, int K, float lik_variance, const float* lik_variance_dev, double scale, int mode_vi,
+                                         float* out_w, float* d_mean, float* d_var,
+                                         const double* const* kl_global, const int32_t* kl_global_counts, int n_glob,
+                                         const float* lse_global, int K_total,
+                                         double* out_sums /* [3]: sum_n (lse - log K), d/d lik_variance, the bound */, double* ws, void* stream_) {
     if (!fmean || !fvar || !Y || !out_sums || !ws || Dy <= 0 || B <= 0 || K <= 0 || n_local < 0 || n_local > IWVI_MAX_KL || !(lik_variance > 0.f) ||
         n_glob < 0 || n_glob > IWVI_MAX_LAYERS) {
         set_error("iwvi_iw_elbo_backward: bad argument"); return IWVI_ERR_ARG;
@@ -2193,7 +2227,7 @@ extern "C" int iwvi_iw_elbo_backward(const float* fmean, const float* fvar, cons
         a.kl[i] = kl_local[i]; a.kl_dims[i] = kl_dims[i];
     }
     if (lse_global && (mode_vi || K_total < K)) { set_error("iwvi_iw_elbo_backward: lse_global needs the IW bound and K_total >= K"); return IWVI_ERR_ARG; }
-    a.B = B; a.K = K; a.lik_var = lik_variance; a.scale = scale; a.mode_vi = mode_vi; a.lse_global = lse_global; a.K_total = K_total; a.w = out_w; a.d_mean = d_mean; a.d_var = d_var; a.part = ws;
+    a.B = B; a.K = K; a.lik_var = lik_variance; a.lik_var_dev = lik_variance_dev; a.scale = scale; a.mode_vi = mode_vi; a.lse_global = lse_global; a.K_total = K_total; a.w = out_w; a.d_mean = d_mean; a.d_var = d_var; a.part = ws;
     hipLaunchKernelGGL(k_elbo_bwd, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, st, a);
     ElboFinishArgs fa{};
     fa.part = ws; fa.n = B; fa.scale = scale; fa.n_glob = n_glob; fa.out = out_sums;
@@ -2337,4 +2371,23 @@ extern "C" int iwvi_adam_step(const iwvi_adam_tensor* tensors, int n_tensors, do
     long long blocks = (nmax + 255) / 256; if (blocks > 1024) blocks = 1024;
     hipLaunchKernelGGL(k_adam, dim3((unsigned)blocks, n_tensors), dim3(256), 0, (hipStream_t)stream_, a);
     return check_launch("k_adam");
+}
+
+extern "C" int iwvi_adam_step_dev(const iwvi_adam_tensor* tensors, int n_tensors, double lr, double beta1, double beta2,
+                                  double eps, int64_t* t_dev, int maximise, void* stream_) {
+    if (!tensors || n_tensors <= 0 || n_tensors > ADAM_MAX || !t_dev) { set_error("iwvi_adam_step_dev: bad argument (at most %d tensors)", ADAM_MAX); return IWVI_ERR_ARG; }
+    AdamArgs a{};
+    long long nmax = 1;
+    for (int i = 0; i < n_tensors; ++i) {
+        const iwvi_adam_tensor& s = tensors[i];
+        if (!s.param || !s.x || !s.m || !s.v || !s.grad || s.n <= 0 || (s.transform != 0 && s.transform != 1)) { set_error("iwvi_adam_step_dev: bad tensor %d", i); return IWVI_ERR_ARG; }
+        a.t[i] = AdamTensor{s.param, s.grad, s.x, s.m, s.v, (long long)s.n, s.transform};
+        if (s.n > nmax) nmax = s.n;
+    }
+    a.n = n_tensors; a.init = 0; a.lr = (float)lr; a.t_dev = (const long long*)t_dev;
+    a.b1 = (float)beta1; a.b2 = (float)beta2; a.eps = (float)eps; a.sign = maximise ? -1.f : 1.f;
+    long long blocks = (nmax + 255) / 256; if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(k_adam, dim3((unsigned)blocks, n_tensors), dim3(256), 0, (hipStream_t)stream_, a);
+    hipLaunchKernelGGL(k_inc_i64, dim3(1), dim3(64), 0, (hipStream_t)stream_, (long long*)t_dev);
+    return check_launch("k_adam (device step count)");
 }

@@ -118,6 +118,8 @@ struct FwHead {
     long long T;
     unsigned row_div, row_mod;       // T < 2^31 is enforced by the host
     float lik_variance;
+    const float* lik_var_dev;        // optional device scalars, read instead of lik_variance / a layer's variance
+    const float* var_dev[IWVI_MAX_STACK];
     unsigned long long seed; unsigned long long* rng_state;
     float* out_logw;
     unsigned long long* stamps;      // diagnostic only (iwvi_debug_set_stamps): 128 words per workgroup
@@ -680,6 +682,8 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
         } else {
             // ================= GPLayer (layers.py:35-50) ==============================================
             const int nbk = G.nbk, R = G.R, P = G.P, nsteps = G.nsteps;
+            const float* vdev = g.var_dev[li];
+            const float g_variance = vdev ? *vdev : G.variance;
             f32x4* kuf = reinterpret_cast<f32x4*>(scratch);
             f32x4* at = kuf;                                       // solved in place (stage 1)
             float* usq = scratch + (size_t)G.Mp * NSAMP;           // [wave][r][NSAMP]
@@ -741,7 +745,7 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
                     }
                     // RBF: sum = c^2 r^2 -> exponent -r^2 c / 2 + log2 var;  Matern52: sum = 4 r^2 -> r^2
                     const float sc = rbf ? -0.5f / 1.4426950408889634f : 0.25f;
-                    const float of = rbf ? __log2f(G.variance) : 0.f;
+                    const float of = rbf ? __log2f(g_variance) : 0.f;
 #pragma unroll
                     for (int t = 0; t < NS; ++t)
 #pragma unroll
@@ -763,7 +767,7 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
                     for (int t = 0; t < NS; ++t) {
                         f32x4 k;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) k[e] = (mrow + e < G.M) ? kern_from_acc(acc[t][e], G.kern_type, G.variance) : 0.f;
+                        for (int e = 0; e < 4; ++e) k[e] = (mrow + e < G.M) ? kern_from_acc(acc[t][e], G.kern_type, g_variance) : 0.f;
                         kuf[(bi * 4 + gq) * NSAMP + 16 * t + jq] = k;
                     }
                 }
@@ -1066,7 +1070,7 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
 #pragma unroll
                 for (int w = 0; w < FW_WAVES; ++w) u2 += usq[(w * R + r) * NSAMP + j];   // fixed order: bit-reproducible
                 const float mu = meanp[r * NSAMP + j];
-                const float v = fmaxf(G.variance - (asq[j] + asq[NSAMP + j]) + u2, 0.f);
+                const float v = fmaxf(g_variance - (asq[j] + asq[NSAMP + j]) + u2, 0.f);
                 const float z = (j < nvalid) ? zl[r * NSAMP + j] : 0.f;
                 if (o_noise && j < nvalid) o_noise[(t0 + j) * R + r] = z;
                 const float gs = fmaf(z, sqrtf(v), mu);
@@ -1244,8 +1248,9 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
                            (NSAMP % g.e.K) == 0;
     if (g.out_logw && tid < nvalid) {
         const int Dy = g.Dy;
-        const float c0 = -0.5f * 1.8378770664093453f - 0.5f * logf(g.lik_variance);
-        const float inv2s = 0.5f / g.lik_variance;
+        const float likv = g.lik_var_dev ? *g.lik_var_dev : g.lik_variance;
+        const float c0 = -0.5f * 1.8378770664093453f - 0.5f * logf(likv);
+        const float inv2s = 0.5f / likv;
         float acc = 0.f;
         for (int d = 0; d < Dy; ++d) {
             const float df = g.Y[(size_t)rowi[tid] * Dy + d] - obuf[d * NSAMP + tid];
@@ -1578,6 +1583,7 @@ int dgp_forward_impl(const iwvi_layer_desc* layers, int n_layers, const float* X
             G.W = d.W; G.mfA = d.mf_A; G.mfb = d.mf_b; G.a_out = d.a_out; G.u_out = d.u_out;
             G.M = d.M; G.Mp = s.Mp; G.nbk = s.nbk; G.nrb = s.nrb; G.nsteps = round_up(D + 2, 4) / 4;
             G.R = d.R; G.P = d.P; G.kern_type = d.kern_type; G.mf_type = d.mf_type; G.variance = d.variance;
+            a.h.var_dev[i] = d.variance_dev;
             plan_stage2(G);
             if (d.R > maxR) maxR = d.R;
             if (d.P > maxP) maxP = d.P;
@@ -1630,6 +1636,7 @@ int dgp_forward_impl(const iwvi_layer_desc* layers, int n_layers, const float* X
         }
         E.ms = elbo->out_lse_ms; E.logp = elbo->out_logp; E.elbo = elbo->out_elbo; E.ws = elbo->ws;
         a.h.lw_init = elbo->lw_init; a.h.layer_base = elbo->noise_layer_base; a.h.x_per_sample = elbo->x_per_sample;
+        a.h.lik_var_dev = elbo->lik_variance_dev;
     }
     {   // activation row stride: room for the widest layer input + 2 (x~), padded to a multiple of 4, and the widest output; odd
         int wmax = Dx + 2, dcur = Dx;

@@ -33,7 +33,7 @@ struct PreLayer {
     const float* Z; const float* ls; const float* q_mu; const float* q_sqrt;
     double* Lm; double* Linv; float* LsP; float* LrTP; float* QmuP; float* ZtP; float* cst; double* kl;
     double* ws;
-    double jitter; float variance;
+    double jitter; float variance; const float* variance_dev;
     int M, D, R, Mp, nbk, nrb, kern_type, flags;
 };
 // an Encoder MLP (layers.py:137-152) evaluated for every row of the minibatch in the same launch: it does not
@@ -351,7 +351,9 @@ __device__ __forceinline__ double inv_get(const double* blk, const double* dinv,
 }
 
 template <bool IN_LDS>
-__device__ void role_factor(const PreLayer& L, int stop_after, unsigned long long* stamps) {
+__device__ void role_factor(const PreLayer& Lin, int stop_after, unsigned long long* stamps) {
+    PreLayer L = Lin;
+    if (L.variance_dev) L.variance = *L.variance_dev;        // a device-resident (trained) kernel variance
     PRE_STAMP(0);
     const int tid = threadIdx.x, nthreads = blockDim.x;
     const int M = L.M, D = L.D, Mp = L.Mp;
@@ -822,7 +824,7 @@ extern "C" int iwvi_model_precompute(const iwvi_gp_desc* layers, int n_layers, c
             L.cst = (float*)(st + s.off_cst);
             L.kl = (double*)(st + s.off_kl);
             L.ws = (double*)(st + s.off_ws);
-            L.jitter = d.jitter; L.variance = d.variance;
+            L.jitter = d.jitter; L.variance = d.variance; L.variance_dev = d.variance_dev;
             L.M = d.M; L.D = d.D; L.R = d.R; L.Mp = s.Mp; L.nbk = s.nbk; L.nrb = s.nrb; L.kern_type = d.kern_type; L.flags = d.flags;
             size_t la = factor_lds_bytes(s.Mp);
             if (la > lds) lds = la;

@@ -18,7 +18,42 @@ def _as_param(x, shape=None, device=None):
     return t.contiguous().clone()
 
 
-class Stationary:
+class DeviceScalarVariance:
+    """``variance`` as a host float that may be BOUND to a 1-element device tensor (``bind_device_variance``): a trainer then
+    updates it on the device, every kernel launch reads it there (``*_desc.variance_dev``), and the host copy is refreshed
+    lazily, only when somebody reads ``.variance`` -- no device-to-host copy per training step, and a captured hipGraph of a
+    step stays valid while the value changes."""
+    _var_dev = None
+    _var_stale = False
+
+    @property
+    def variance(self):
+        if self._var_dev is not None and self._var_stale:
+            self._var_host = float(self._var_dev.item())
+            self._var_stale = False
+        return self._var_host
+
+    @variance.setter
+    def variance(self, v):
+        self._var_host = float(v)
+        if self._var_dev is not None:
+            self._var_dev.fill_(self._var_host)
+        self._var_stale = False
+
+    def bind_device_variance(self, t):
+        """``t``: 1-element float32 device tensor holding the current value; updated in place by the owner."""
+        self._var_dev = t
+        self._var_stale = False
+
+    def mark_device_variance_changed(self):
+        self._var_stale = self._var_dev is not None
+
+    def desc_variance(self):
+        """(by-value float for a descriptor -- possibly stale when bound --, device pointer or None)."""
+        return self._var_host, (None if self._var_dev is None else self._var_dev.data_ptr())
+
+
+class Stationary(DeviceScalarVariance):
     kern_type = None
 
     def __init__(self, input_dim, variance=1.0, lengthscales=1.0, ARD=False, active_dims=None, name=None):

@@ -111,7 +111,8 @@ class GPLayer:
         mf = self.mean_function
         d.type, d.state = _abi.LAYER_GP, self.state().buf.data_ptr()
         d.M, d.D, d.R, d.P = M, D, R, P
-        d.kern_type, d.mf_type, d.variance = kern.kern_type, mf.mf_type, kern.variance
+        d.kern_type, d.mf_type = kern.kern_type, mf.mf_type
+        d.variance, d.variance_dev = kern.desc_variance()
         keep = [W]
         if W is not None:
             d.W = W.data_ptr()

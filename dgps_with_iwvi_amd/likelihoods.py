@@ -4,9 +4,10 @@ reference's callable form on explicit moments (``iwvi_gaussian_var_exp``)."""
 import torch
 
 from . import _abi, settings
+from .kernels import DeviceScalarVariance
 
 
-class Gaussian:
+class Gaussian(DeviceScalarVariance):
     def __init__(self, variance=1.0, name=None):
         self.variance = float(variance)
         self.name = name

@@ -69,7 +69,12 @@ class DGP_VI:
             self._mb_pos = 0
         idx = self._mb_perm[self._mb_pos:self._mb_pos + b]
         self._mb_pos += b
-        self.X, self.Y = self._X_all[idx].contiguous(), self._Y_all[idx].contiguous()
+        if self.X.shape[0] == b and self.X.data_ptr() != self._X_all.data_ptr():
+            # same buffers every step (a captured hipGraph of the step keeps reading them)
+            torch.index_select(self._X_all, 0, idx, out=self.X)
+            torch.index_select(self._Y_all, 0, idx, out=self.Y)
+        else:
+            self.X, self.Y = self._X_all[idx].contiguous(), self._Y_all[idx].contiguous()
         self._mb_serial += 1         # the caching allocator reuses addresses: pointers alone cannot key the per-minibatch caches
 
     def to(self, device):
@@ -227,6 +232,7 @@ class DGP_VI:
             ed.scale = float(self.num_data) / float(B)                     # models.py:80-81, :144-145
             ed.K_total, ed.mode_vi = elbo.get("K_total") or K, 1 if elbo["mode_vi"] else 0
             ed.out_lse_ms = None if ms is None else ms.data_ptr()
+            ed.lik_variance_dev = self.likelihood.desc_variance()[1]
             ws = torch.empty((T + 15) // 16, dtype=torch.float64, device=dev)
             ed.out_logp, ed.out_elbo, ed.ws = logp.data_ptr(), val.data_ptr(), ws.data_ptr()
             if stack_from:
@@ -235,7 +241,8 @@ class DGP_VI:
             red = (val[0], logp, ms)
         _abi.check(_abi.lib().iwvi_dgp_forward(
             descs, n, _abi.ptr(X), X.shape[1], _abi.ptr(XY), 0 if XY is None else XY.shape[1],
-            _abi.ptr(Y) if want_logw else None, Y.shape[1], T, row_div, row_mod, self.likelihood.variance,
+            _abi.ptr(Y) if want_logw else None, Y.shape[1], T, row_div, row_mod,
+            self.likelihood.desc_variance()[0] if (ed is not None or not want_logw) else self.likelihood.variance,
             settings.seed, ctypes.c_void_p(words.data_ptr() + 8), _abi.ptr(logw),
             None if ed is None else ctypes.byref(ed), _abi.stream_ptr()))
         return logw, outs, red
@@ -251,7 +258,13 @@ class DGP_VI:
         """[x_b, y_b] rows of the current minibatch (models.py:53 / :116 before tiling), cached per minibatch."""
         key = self._mb_key()
         if getattr(self, "_xy_key", None) != key:
-            self._xy_cache, self._xy_key = torch.cat([self.X, self.Y], -1).contiguous(), key
+            cur = getattr(self, "_xy_cache", None)
+            shape = (self.X.shape[0], self.X.shape[1] + self.Y.shape[1])
+            if cur is not None and tuple(cur.shape) == shape and cur.device == self.X.device:
+                torch.cat([self.X, self.Y], -1, out=cur)          # same buffer every minibatch (graph capture)
+            else:
+                self._xy_cache = torch.cat([self.X, self.Y], -1).contiguous()
+            self._xy_key = key
         return self._xy_cache
 
     def _global_kls(self):

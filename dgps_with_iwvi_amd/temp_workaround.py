@@ -97,7 +97,9 @@ class GpState:
         d = _abi.GpDesc()
         d.Z, d.lengthscales = Z.data_ptr(), kern.lengthscales.data_ptr()
         d.q_mu, d.q_sqrt, d.state = q_mu.data_ptr(), q_sqrt.data_ptr(), self.buf.data_ptr()
-        d.variance, d.jitter = kern.variance, float(jitter)
+        d.variance, vdev = kern.desc_variance()
+        d.variance_dev = vdev
+        d.jitter = float(jitter)
         d.M, d.D, d.R, d.kern_type, d.flags = M, D, R, kern.kern_type, 0
         self._keep = (Z, q_mu, q_sqrt, kern.lengthscales)     # keep operands alive until the launch ran
         self._redo_dense = d

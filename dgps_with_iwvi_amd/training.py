@@ -25,7 +25,8 @@ def staircase_decay(base, step, rate, every=1000):
 
 class Trainer:
     def __init__(self, model, lr=5e-3, gamma=1e-2, lr_decay=0.98, gamma_decay=0.98, fix_linear=True,
-                 beta1=0.9, beta2=0.999, epsilon=1e-8, group=None, shard_weight=None, shard="n", num_data_total=None):
+                 beta1=0.9, beta2=0.999, epsilon=1e-8, group=None, shard_weight=None, shard="n", num_data_total=None,
+                 use_graph=False, check_finite=True):
         """``group`` / ``shard_weight``: data-parallel training over the ranks of a torch.distributed group (each rank's
         model holds its own minibatch rows, N-shard): gradients are merged by ``sharding.allreduce_gradients`` with
         weight B_rank / B_job (default: from the all-reduced local batch sizes) before either update, so every rank
@@ -34,7 +35,14 @@ class Trainer:
         ``model.num_data`` is set to ``num_data_total`` -- by default the sum of the ranks' row counts
         (``sharding.resolve_n_shard``).
         ``shard="k"``: every rank holds all the points and its own share of the importance samples instead
-        (``sharding.k_shard_gradients``: one all-gather of the per-point pairs + one gradient all-reduce)."""
+        (``sharding.k_shard_gradients``: one all-gather of the per-point pairs + one gradient all-reduce).
+
+        The two trained host scalars of the reference -- the final layer's kernel variance and the likelihood variance -- live
+        in 1-element device tensors that Adam updates in place and every kernel reads when it runs (``variance_dev`` of the
+        descriptors); the model's host copies are refreshed lazily when read.  ``use_graph=True`` (single GPU, noise drawn on the
+        device): each of the two ops of a step is captured once into a hipGraph and replayed -- no host work per launch, no
+        device-to-host copy per step; the graphs are re-captured when the staircase decay changes lr / gamma.  ``check_finite``:
+        eager mode only, one small D2H per step that raises when the bound or the final layer's q(u) went non-finite."""
         self.model = model
         self.group, self.shard_weight, self.shard = group, shard_weight, shard
         if shard == "n" and (group is not None or num_data_total is not None):
@@ -48,7 +56,12 @@ class Trainer:
         self.betas, self.epsilon = (beta1, beta2), epsilon
         self.global_step = 0
         self.adam_t = 0
+        self.use_graph, self.check_finite = bool(use_graph), bool(check_finite)
+        if self.use_graph and group is not None:
+            raise ValueError("use_graph captures a single-GPU step; sharded training launches its collectives eagerly")
+        self._graphs = {}                                      # op name -> (decay epoch, CUDAGraph, elbo tensor)
         dev = model.X.device
+        self._t_dev = torch.zeros(1, dtype=torch.int64, device=dev)     # Adam's step count, on the device
         ft = settings.float_type
         self.final = model.layers[-1]
         if not isinstance(self.final, GPLayer):
@@ -69,7 +82,8 @@ class Trainer:
             if i == n - 1:
                 t = torch.full((1,), k.variance, dtype=ft, device=dev)
                 self._entries.append(("l%d.var" % i, t, 1))
-                self._scalars.append((t, lambda v, k=k: setattr(k, "variance", v)))
+                k.bind_device_variance(t)                      # kernels read it on the device from now on
+                self._scalars.append((t, k))
             else:
                 self._entries.append(("l%d.q_mu" % i, l.q_mu, 0))
                 self._entries.append(("l%d.q_sqrt" % i, l.q_sqrt, 0))
@@ -80,7 +94,8 @@ class Trainer:
                     self._entries.append(("l%d.mfA" % i, l.mean_function.A, 0))
         t = torch.full((1,), model.likelihood.variance, dtype=ft, device=dev)
         self._entries.append(("lik_var", t, 1))
-        self._scalars.append((t, lambda v: setattr(model.likelihood, "variance", v)))
+        model.likelihood.bind_device_variance(t)
+        self._scalars.append((t, model.likelihood))
         for name, t, _ in self._entries:
             _abi.dev_tensor(t, name)
         self._state = [tuple(torch.empty_like(t) for _ in range(3)) for _, t, _ in self._entries]
@@ -101,13 +116,17 @@ class Trainer:
                     raise ValueError("gradient %s has %d entries, parameter has %d" % (name, g.numel(), p.numel()))
                 keep.append(g)
                 a.grad = g.data_ptr()
-        _abi.check(_abi.lib().iwvi_adam_step(arr, n, lr, self.betas[0], self.betas[1], self.epsilon,
-                                            max(self.adam_t, 1), 1, 1 if init else 0, _abi.stream_ptr()))
+        if init:
+            _abi.check(_abi.lib().iwvi_adam_step(arr, n, lr, self.betas[0], self.betas[1], self.epsilon, 1, 1, 1, _abi.stream_ptr()))
+        else:                                                  # the step count lives on the device (graph replay)
+            _abi.check(_abi.lib().iwvi_adam_step_dev(arr, n, lr, self.betas[0], self.betas[1], self.epsilon,
+                                                    self._t_dev.data_ptr(), 1, _abi.stream_ptr()))
         return keep
 
-    def _gradients(self, zs):
+    def _gradients(self, zs, advance=True):
         from .sharding import allreduce_gradients, k_shard_gradients
-        self.model.next_minibatch()                              # gpflow.Minibatch: a new batch per session.run (models.py:21-26)
+        if advance:
+            self.model.next_minibatch()                          # gpflow.Minibatch: a new batch per session.run (models.py:21-26)
         if self.shard == "k":
             return k_shard_gradients(self.model, zs, group=self.group)
         elbo, g = iw_elbo_and_gradients(self.model, zs)
@@ -115,9 +134,9 @@ class Trainer:
         g = allreduce_gradients(g, weight=self.shard_weight, group=self.group)
         return g.pop("__elbo__")[0], g
 
-    def natgrad_op(self, zs=None):
+    def natgrad_op(self, zs=None, _advance=True):
         """``op_ng``: one ELBO + gradient evaluation, natural-gradient step on the final layer's q(u)."""
-        elbo, g = self._gradients(zs)
+        elbo, g = self._gradients(zs, _advance)
         i = len(self.model.layers) - 1
         f = self.final
         gamma = staircase_decay(self.gamma, self.global_step, self.gamma_decay)
@@ -127,31 +146,71 @@ class Trainer:
                                                f.num_inducing, f.num_outputs, gamma, self._ng_ws.data_ptr(), _abi.stream_ptr()))
         return elbo
 
-    def adam_op(self, zs=None):
+    def adam_op(self, zs=None, _advance=True):
         """``op_adam``: one ELBO + gradient evaluation, Adam step on everything but the final layer's q(u)."""
-        elbo, g = self._gradients(zs)
-        self.adam_t += 1
+        elbo, g = self._gradients(zs, _advance)
         self._adam_call(g, lr=staircase_decay(self.lr, self.global_step, self.lr_decay))
-        if self._scalars:                                      # host copies of the scalar parameters (one small D2H)
-            # the same transfer carries a health word: the bound and the final layer's q(u) must be finite (a natural-gradient
-            # step that leaves -2 theta_2 indefinite makes TensorFlow's Cholesky raise in the reference; here it would go on as NaN)
-            ok = (torch.isfinite(elbo) & torch.isfinite(self.final.q_sqrt).all() & torch.isfinite(self.final.q_mu).all()).to(settings.float_type)
-            vals = torch.cat([t for t, _ in self._scalars] + [ok.reshape(1)]).tolist()
-            if vals[-1] != 1.0:
+        for _, owner in self._scalars:                         # host copies are refreshed lazily, when somebody reads them
+            owner.mark_device_variance_changed()
+        if self.check_finite and not self._capturing:
+            # one small D2H: the bound and the final layer's q(u) must be finite (a natural-gradient step that leaves
+            # -2 theta_2 indefinite makes TensorFlow's Cholesky raise in the reference; here it would go on as NaN)
+            ok = torch.isfinite(elbo) & torch.isfinite(self.final.q_sqrt).all() & torch.isfinite(self.final.q_mu).all()
+            if not bool(ok.item()):
                 raise FloatingPointError("training step %d: non-finite bound or final-layer q(u) (the natural-gradient step left the "
                                          "precision matrix indefinite: lower gamma)" % self.global_step)
-            for (_, setter), v in zip(self._scalars, vals[:-1]):
-                setter(float(v))
+        return elbo
+
+    _capturing = False
+
+    def _replay(self, name, op):
+        """Capture ``op`` (one evaluation + its update) into a hipGraph on first use -- and again whenever the staircase decay
+        moves lr / gamma, which enter the update kernels by value -- then replay it."""
+        epoch = self.global_step // 1000
+        ent = self._graphs.get(name)
+        if ent is not None and ent[0] == epoch:
+            ent[1].replay()
+            return ent[2]
+        first = ent is None
+        self._capturing = True
+        try:
+            side = torch.cuda.Stream(device=self.model.X.device)
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                if first:
+                    eager = op()                               # this call's evaluation, launched eagerly (it also warms the allocator pools)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):
+                    elbo = op()                                # recorded, not executed
+            torch.cuda.current_stream().wait_stream(side)
+        finally:
+            self._capturing = False
+        self._graphs[name] = (epoch, g, elbo)
+        if first:
+            return eager
+        g.replay()                                             # re-capture after a decay step: this call's evaluation
         return elbo
 
     def step(self, zs_ng=None, zs_adam=None):
         """``model.train_op`` (build_models.py:297-300); returns the ELBO seen by the Adam op."""
         self.global_step += 1
+        if self.use_graph:
+            if zs_ng is not None or zs_adam is not None:
+                raise ValueError("use_graph draws the noise on the device (captured graphs cannot take per-step host arguments)")
+            self.model.next_minibatch()                        # outside the graph: an in-place gather into the model's X / Y buffers
+            self._replay("ng", lambda: self.natgrad_op(None, _advance=False))
+            self.model.next_minibatch()
+            return self._replay("adam", lambda: self.adam_op(None, _advance=False))
         self.natgrad_op(zs_ng)
         return self.adam_op(zs_adam)
 
+    def sync_scalars(self):
+        """Refresh the host copies of the device-resident scalars now (otherwise: lazily, on first read)."""
+        return [owner.variance for _, owner in self._scalars]
+
     # -- checkpoint / resume (reference: gpflow Saver of the whole session, run_conditional_density_estimation.py:95-125) --
     def state_dict(self):
+        self.adam_t = int(self._t_dev.item())                  # Adam's step count lives on the device
         out = {"global_step": np.int64(self.global_step), "adam_t": np.int64(self.adam_t)}
         for (name, _, _), (x, m, v) in zip(self._entries, self._state):
             out["x." + name], out["m." + name], out["v." + name] = (a.detach().cpu().numpy() for a in (x, m, v))
@@ -161,6 +220,8 @@ class Trainer:
         """After the model's parameters have been restored in place: the optimiser's own state and the step counters.
         The host scalars' device masters are refreshed from the model."""
         self.global_step, self.adam_t = int(state["global_step"]), int(state["adam_t"])
+        self._t_dev.fill_(self.adam_t)
+        self._graphs = {}
         for (name, _, _), (x, m, v) in zip(self._entries, self._state):
             for key, dst in (("x.", x), ("m.", m), ("v.", v)):
                 dst.copy_(torch.as_tensor(np.asarray(state[key + name]), dtype=dst.dtype, device=dst.device).reshape(dst.shape))

@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdio.h>
+#include <string.h>
 #include <stdlib.h>
 #include "iwvi_hip.h"
 
@@ -44,6 +45,7 @@ int main(void) {
     if (!dZ || !dls || !dqm || !dqs || !dF || !dn || !dW || !dA) { fprintf(stderr, "upload failed\n"); return 2; }
 
     iwvi_gp_desc g;
+    memset(&g, 0, sizeof(g));                              /* optional fields (variance_dev) = NULL */
     g.Z = dZ; g.lengthscales = dls; g.q_mu = dqm; g.q_sqrt = dqs; g.state = state;
     g.variance = 1.3f; g.jitter = 1e-6; g.M = M; g.D = D; g.R = R; g.kern_type = IWVI_KERN_RBF; g.flags = 0;
     IW(iwvi_gp_precompute(&g, 1, NULL));

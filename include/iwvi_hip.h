@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define IWVI_ABI_VERSION 6
+#define IWVI_ABI_VERSION 7
 
 enum {
     IWVI_OK = 0,
@@ -89,6 +89,8 @@ typedef struct iwvi_gp_desc {
     int32_t M, D, R;
     int32_t kern_type;         /* IWVI_KERN_*                                    */
     int32_t flags;             /* IWVI_GP_WANT_DENSE or 0                        */
+    const float* variance_dev; /* optional DEVICE scalar: read instead of `variance` when the launch runs (a trained
+                                * kernel variance that lives on the device keeps a captured hipGraph valid across steps) */
 } iwvi_gp_desc;
 
 size_t iwvi_gp_state_bytes(int M, int R);
@@ -223,6 +225,7 @@ typedef struct iwvi_layer_desc {
     float* kl_local;
     float* a_out; float* u_out;     /* GP, optional (what the adjoint needs): A [T, Mp], L_r^T A [R, T, Mp] */
     float* gmv_out;                 /* GP, optional: [T, 3R] = (sample | mean | variance) of the R latent GPs before mixing */
+    const float* variance_dev;      /* GP, optional device scalar read instead of `variance` (see iwvi_gp_desc) */
 } iwvi_layer_desc;
 
 /* Optional tail of the same launch: the last workgroup to finish performs models.py:138-150 on out_logw
@@ -244,6 +247,7 @@ typedef struct iwvi_elbo_desc {
     const float* lw_init;
     int32_t noise_layer_base;
     int32_t x_per_sample;
+    const float* lik_variance_dev;  /* optional device scalar read instead of iwvi_dgp_forward's lik_variance argument */
 } iwvi_elbo_desc;
 
 int iwvi_dgp_forward(const iwvi_layer_desc* layers_host, int n_layers,
@@ -288,6 +292,7 @@ typedef struct iwvi_gp_bwd_desc {
     void* side_stream2;             /* optional second side stream: the parameter branch then runs as two concurrent chains
                                      * (Cholesky adjoint | the other sums over samples); join both */
     int32_t prepared;               /* nonzero: iwvi_gp_layer_backward_prepare has already run on this (desc, ws) */
+    const float* variance_dev;      /* optional device scalar read instead of `variance` (see iwvi_gp_desc) */
 } iwvi_gp_bwd_desc;
 size_t iwvi_gp_layer_backward_ws_bytes(int64_t T, int M, int D, int R);
 /* the parameter-only part of the adjoint (scaled inducing inputs, float32 Lm^-1, the streaming chain's packed operands
@@ -311,6 +316,14 @@ int iwvi_iw_elbo_backward(const float* fmean, const float* fvar, const float* Y,
                           const double* const* kl_global, const int32_t* kl_global_counts, int n_glob,
                           const float* lse_global, int K_total,
                           double* out_sums, double* ws, void* stream);
+/* the same with the likelihood variance read from device memory when the launch runs (lik_variance_dev != NULL) */
+int iwvi_iw_elbo_backward_dev(const float* fmean, const float* fvar, const float* Y, int Dy,
+                              const float* const* kl_local, const int32_t* kl_dims, int n_local,
+                              int64_t B, int K, float lik_variance, const float* lik_variance_dev, double scale, int mode_vi,
+                              float* out_w, float* d_mean, float* d_var,
+                              const double* const* kl_global, const int32_t* kl_global_counts, int n_glob,
+                              const float* lse_global, int K_total,
+                              double* out_sums, double* ws, void* stream);
 
 /* Adjoint of the LatentVariableLayer (layers.py:83-103): mu, sigma [B, latent_dim] (the encoder's outputs per data
  * row), noise [T, latent_dim] (the draws), dF_next [T, ld_next] = gradient w.r.t. the layer's output rows (columns
@@ -349,6 +362,10 @@ typedef struct iwvi_adam_tensor {
 } iwvi_adam_tensor;
 int iwvi_adam_step(const iwvi_adam_tensor* tensors_host, int n_tensors, double lr, double beta1, double beta2,
                    double eps, int64_t t, int maximise, int init, void* stream);
+/* the same with the step count on the device: the launch uses *t_dev + 1 and then stores it back (one tiny extra launch),
+ * so a captured hipGraph of a training step stays valid from step to step */
+int iwvi_adam_step_dev(const iwvi_adam_tensor* tensors_host, int n_tensors, double lr, double beta1, double beta2,
+                       double eps, int64_t* t_dev, int maximise, void* stream);
 
 /* models.py:138-150 on precomputed log-weights: logw row of (point b, sample k) = b*stride_b + k*stride_k;
  * arguments as iwvi_iw_elbo_reduce. */

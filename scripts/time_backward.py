@@ -62,8 +62,14 @@ def main():
         print("graph capture failed: %s: %s" % (type(e).__name__, e))
     tr = Trainer(model)
     step = timed(lambda: tr.step(), a.iters)
-    print("config %d: forward (fused, eager) %.3f ms | value+gradient %.3f ms (%.2e samples/s) | training step %.3f ms"
-          % (a.config, fwd, grad, T / grad * 1e3, step))
+    step_g = float("nan")
+    try:
+        trg = Trainer(model, use_graph=True)
+        step_g = timed(lambda: trg.step(), a.iters)
+    except Exception as e:
+        print("graph-mode trainer failed: %s: %s" % (type(e).__name__, e))
+    print("config %d: forward (fused, eager) %.3f ms | value+gradient %.3f ms (%.2e samples/s) | training step %.3f ms eager, %.3f ms as two hipGraph replays"
+          % (a.config, fwd, grad, T / grad * 1e3, step, step_g))
 
 
 if __name__ == "__main__":
