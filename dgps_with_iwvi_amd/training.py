@@ -217,15 +217,14 @@ class Trainer:
         return out
 
     def load_state_dict(self, state):
-        """After the model's parameters have been restored in place: the optimiser's own state and the step counters.
-        The host scalars' device masters are refreshed from the model."""
+        """After the model's parameters have been restored in place (that also restores the device masters of the trained
+        scalars, which are bound to the model's ``variance`` attributes): the optimiser's own state and the step counters."""
         self.global_step, self.adam_t = int(state["global_step"]), int(state["adam_t"])
         self._t_dev.fill_(self.adam_t)
         self._graphs = {}
         for (name, _, _), (x, m, v) in zip(self._entries, self._state):
             for key, dst in (("x.", x), ("m.", m), ("v.", v)):
                 dst.copy_(torch.as_tensor(np.asarray(state[key + name]), dtype=dst.dtype, device=dst.device).reshape(dst.shape))
-        for (name, p, _), (x, _, _) in zip(self._entries, self._state):
-            if p.numel() == 1 and name.endswith(("var", "lik_var")):
-                p.copy_(torch.nn.functional.softplus(x) + 1e-6)          # the master of a host scalar, from its unconstrained value
+        # (the device masters of the trained scalars already hold the checkpoint's exact values: restoring the model's
+        # ``variance`` attributes writes through to the bound device tensors; recomputing them from x would be 1 ulp off)
         return self

@@ -110,3 +110,33 @@ def test_overlapped_exchange_slot_reuse(gpu_device):
                 np.testing.assert_allclose(g.cpu().numpy(), ref, rtol=2e-6)
     finally:
         dist.destroy_process_group()
+
+
+def test_trainer_n_shard_ranks_built_from_local_rows(gpu_device, tmp_path):
+    """every rank constructs its model from its own rows (local num_data, models.py:18) and uneven minibatches
+    (30 + 18 points).  Trainer(group=...) must scale the data term by the JOB's num_data and weigh the ranks by B_rank / B_job: the
+    merged gradient of the two HIP ranks equals the single-process gradient of the whole minibatch on the same injected noise."""
+    from dgps_with_iwvi_amd import backward, synthetic
+    port = _free_port()
+    out = str(tmp_path / "grad_rank%d.npz")
+    worker = os.path.join(ROOT, "tests", "helpers", "nshard_trainer_worker.py")
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, worker, out, "30", "18"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=ROOT))
+    for p in procs:
+        so, se = p.communicate(timeout=600)
+        assert p.returncode == 0, se[-3000:]
+    spec = synthetic.make_spec(L=2, M=32, B=48, K=4, with_lv=True, seed=61, n_data=48)
+    zs = synthetic.make_noise(spec, seed=62)
+    model = synthetic.build_model(spec, gpu_device)
+    elbo, ref = backward.iw_elbo_and_gradients(model, [torch.as_tensor(z, dtype=torch.float32, device=gpu_device) for z in zs])
+    r0, r1 = np.load(out % 0), np.load(out % 1)
+    assert abs(float(r0["weight"]) - 30 / 48) < 1e-12 and abs(float(r1["weight"]) - 18 / 48) < 1e-12
+    assert float(r0["elbo"]) == float(r1["elbo"])                # every rank holds the same merged value
+    assert abs(float(r0["elbo"]) - float(elbo)) <= 1e-5 * abs(float(elbo))
+    for k, v in ref.items():
+        a, b = r0[k], v.detach().double().cpu().numpy().reshape(r0[k].shape)
+        assert np.array_equal(a, r1[k]), k
+        assert np.abs(a - b).max() <= 2e-4 * max(np.abs(b).max(), 1e-6), (k, np.abs(a - b).max(), np.abs(b).max())

@@ -210,6 +210,63 @@ def test_checkpoint_resume_continues_the_same_trajectory(gpu_device, tmp_path):
     assert a.likelihood.variance == c.likelihood.variance
 
 
+def test_checkpoint_resume_with_minibatches_device_noise_and_trainable_linear_parts(gpu_device, tmp_path):
+    """the session state a tf.train.Saver would restore besides the variables -- the shuffled minibatch iterator
+    (gpflow.Minibatch(seed=0), models.py:25-26), the device noise counters, the Linear mean function's A (trainable with
+    fix_linear=False) -- travels in the checkpoint: minibatch_size = 16 of 64 rows, noise drawn on the device, fix_linear=False;
+    3 steps, save, restore into a fresh model + trainer, 3 more steps == 6 uninterrupted steps, bit for bit."""
+    from dgps_with_iwvi_amd import synthetic, build_models, settings
+    from dgps_with_iwvi_amd.models import DGP_IWVI
+    from dgps_with_iwvi_amd.training import Trainer
+    spec = synthetic.make_spec(L=2, M=32, B=64, K=4, with_lv=True, seed=29)
+
+    def fresh():
+        settings.set_seed(11)
+        m = synthetic.build_model(spec, gpu_device)
+        m2 = DGP_IWVI(spec["X"], spec["Y"], m.layers, m.likelihood, num_samples=4, minibatch_size=16).to(gpu_device)
+        return m2, Trainer(m2, fix_linear=False)
+
+    a, ta = fresh()
+    for _ in range(6):
+        ta.step()
+    b, tb = fresh()
+    for _ in range(3):
+        tb.step()
+    path = str(tmp_path / "ckpt_mb.npz")
+    build_models.save_checkpoint(b, path, tb)
+    c, tc = fresh()
+    tc.step()                                                    # disturb the fresh state: everything must come from the file
+    build_models.load_checkpoint(c, path, tc)
+    assert tc.global_step == 3 and torch.equal(c.X, b.X)         # the restored model looks at the same minibatch
+    for _ in range(3):
+        tc.step()
+    for (name, pa, _), (_, pc, _) in zip(ta._entries, tc._entries):
+        assert torch.equal(pa, pc), name
+    assert torch.equal(a.layers[1].mean_function.A, c.layers[1].mean_function.A)
+    assert torch.equal(a.layers[-1].q_sqrt, c.layers[-1].q_sqrt) and a.likelihood.variance == c.likelihood.variance
+    assert int(a._words()[1]) == int(c._words()[1])
+
+
+def test_graph_mode_training_step_equals_the_eager_one(gpu_device):
+    """Trainer(use_graph=True): each op of a step replayed from a hipGraph, trained scalars and Adam's step count on the
+    device -- the trajectory equals the eager trainer's bit for bit (same kernels, same device noise counters)."""
+    from dgps_with_iwvi_amd import synthetic, settings
+    from dgps_with_iwvi_amd.training import Trainer
+    spec = synthetic.make_spec(L=2, M=32, B=64, K=5, with_lv=True, seed=31)
+    out = []
+    for use_graph in (False, True):
+        settings.set_seed(3)
+        model = synthetic.build_model(spec, gpu_device)
+        tr = Trainer(model, use_graph=use_graph, check_finite=False)
+        vals = [float(tr.step()) for _ in range(6)]
+        out.append((vals, [p.clone() for _, p, _ in tr._entries], model.likelihood.variance, model.layers[-1].q_sqrt.clone()))
+    assert out[0][0] == out[1][0], (out[0][0], out[1][0])
+    for pa, pb in zip(out[0][1], out[1][1]):
+        assert torch.equal(pa, pb)
+    assert out[0][2] == out[1][2] and torch.equal(out[0][3], out[1][3])
+    assert out[0][2] != spec["lik_var"]                          # the likelihood variance did move (and was read back lazily)
+
+
 def test_a_diverged_natural_gradient_step_is_reported(gpu_device):
     """gamma far too large: -2 theta_2 turns indefinite, the Cholesky inside the step produces NaN; the trainer says so (the
     reference's TensorFlow Cholesky would raise at the same point) instead of training on."""
