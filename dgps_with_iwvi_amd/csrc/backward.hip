@@ -1792,9 +1792,45 @@ __global__ __launch_bounds__(256) void k_dmm2(DmmArgs a) {               // 16x1
     if (a.post == 1) s = (j > i) ? 0.0 : (j == i ? 0.5 * s : s);
     a.C[i * a.ldc + j] = s;
 }
+// The same product on v_mfma_f64_16x16x4_f64: one WAVE per 16x16 output tile (lane l feeds A[l & 15][4kk + (l >> 4)] and
+// B[4kk + (l >> 4)][l & 15]; accumulator register e of lane l is C[(l >> 4) + 4e][l & 15]).  The operands of 8 k-steps are
+// requested together (one L2 round trip per 32 of K), so a 128^3 product is ~2 us of latency instead of the LDS kernel's 8
+// barriers-and-loads rounds per tile (10-13 us); used where I, J are multiples of 16 and K of 4, J > 1.
+using bw_f64x4 = __attribute__((ext_vector_type(4))) double;
+__global__ __launch_bounds__(64) void k_dmm_mfma(DmmArgs a) {
+    const int lane = threadIdx.x, r = lane & 15, g = lane >> 4;
+    const int i0 = blockIdx.y * 16, j0 = blockIdx.x * 16;
+    bw_f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+    const double* Ap = a.A + (long long)(i0 + r) * a.a_si + (long long)g * a.a_sk;
+    const double* Bp = a.B + (long long)g * a.b_sk + (long long)(j0 + r) * a.b_sj;
+    for (int k0 = 0; k0 < a.K; k0 += 32) {
+        double av[8], bv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int k = k0 + 4 * u;
+            const bool in = k + g < a.K;
+            av[u] = in ? Ap[(long long)k * a.a_sk] : 0.0;
+            bv[u] = in ? Bp[(long long)k * a.b_sk] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[u], acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int i = i0 + g + 4 * e, j = j0 + r;
+        double s = acc[e] * a.alpha;
+        if (a.E) s += a.beta * a.E[(long long)i * a.lde + j];
+        if (a.post == 1) s = (j > i) ? 0.0 : (j == i ? 0.5 * s : s);
+        a.C[(long long)i * a.ldc + j] = s;
+    }
+}
 static void dmm(hipStream_t st, const double* A, long long a_si, long long a_sk, const double* B, long long b_sk, long long b_sj,
                 double* C, long long ldc, int I, int J, int K, double alpha = 1.0, const double* E = nullptr, long long lde = 0, double beta = 0.0, int post = 0) {
     DmmArgs a{A, a_si, a_sk, B, b_sk, b_sj, C, ldc, I, J, K, alpha, E, lde, beta, post};
+    if (I % 16 == 0 && J % 16 == 0 && K % 4 == 0 && !getenv("IWVI_DMM_LDS")) {
+        hipLaunchKernelGGL(k_dmm_mfma, dim3(J / 16, I / 16), dim3(64), 0, st, a);
+        return;
+    }
     hipLaunchKernelGGL(k_dmm2, dim3((J + 15) / 16, (I + 15) / 16), dim3(256), 0, st, a);
 }
 // X = L^-1 for n <= TRI_SMALL in ONE workgroup, 16x16 blocks of X in LDS: the diagonal blocks by substitution (a lane per
@@ -2123,9 +2159,10 @@ extern "C" int iwvi_gp_layer_backward(const iwvi_gp_bwd_desc* dp, int64_t T, voi
     const bool two = stB != stA;
     auto chol_adjoint = [&](hipStream_t s_) {
         const dim3 grid((M + 15) / 16, (M + 15) / 16), block(256);
-        hipLaunchKernelGGL(k_dmm, grid, block, 0, s_, Lm64, 1LL, (long long)Mp, (const double*)w.Lbar, (long long)M, 1LL, w.T1, M, M, 1);
-        hipLaunchKernelGGL(k_dmm, grid, block, 0, s_, Linv64, 1LL, (long long)Mp, (const double*)w.T1, (long long)M, 1LL, w.T2, M, M, 0);
-        hipLaunchKernelGGL(k_dmm, grid, block, 0, s_, (const double*)w.T2, (long long)M, 1LL, Linv64, (long long)Mp, 1LL, w.S, M, M, 0);
+        (void)grid; (void)block;
+        dmm(s_, Lm64, 1, Mp, (const double*)w.Lbar, M, 1, w.T1, M, M, M, M, 1.0, nullptr, 0, 0.0, 1);      // T1 = Phi(Lm^T Lbar)
+        dmm(s_, Linv64, 1, Mp, (const double*)w.T1, M, 1, w.T2, M, M, M, M);                                // T2 = Lm^-T T1
+        dmm(s_, (const double*)w.T2, M, 1, Linv64, Mp, 1, w.S, M, M, M, M);                                 // S  = T2 Lm^-1
         hipLaunchKernelGGL(k_kuu_bwd, dim3(M), dim3(256), 0, s_, w.Zt, (const double*)w.S, M, D, (double)d.variance, d.variance_dev, d.kern_type, w.dZt_uu, w.dvar_m);
         return check_launch("cholesky adjoint");
     };
