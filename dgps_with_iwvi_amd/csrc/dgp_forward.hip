@@ -54,6 +54,12 @@ static int g_dbg_exit = 0;                           // diagnostic; see iwvi_deb
 
 constexpr int XSTR_MAX = 37;          // largest row stride (floats) of the activation tiles: D, P <= 32, D + 2 <= 36
 constexpr int FW_MAXNS = 5;
+// From this many 16-row blocks (M > 240) stage 1 runs super-block by super-block with the packed inverses of the 128 x 128
+// diagonal super-blocks (csrc/precompute.hip writes that operand stream under the same condition).  Below it the column-at-a-time
+// substitution stays: it is the more accurate form when K_uu is ill-conditioned (an explicit 128-row inverse in float32 amplifies
+// rounding by cond(L_II); the 1-D, M = 160 case of tests/test_gpu_random_sweep.py sits at the edge of its 5e-3 tolerance), and
+// with at most 15 block columns its idle-wave loss is small.
+constexpr int FW_SB_MIN_NBK = 16;
 
 constexpr int FW_THREADS = 512;
 constexpr int FW_WAVES = FW_THREADS / 64;
@@ -808,6 +814,93 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
             // five sub-tiles, M = 128, solve stream staged: the fifth solve is split over waves 4-7 (see solve4)
             const bool split5 = (NS == FW_MAXNS) && nbk == 8 && G.ls_off >= 0;
             const int nchain = split5 ? NS - 1 : NS;
+            if (nbk >= FW_SB_MIN_NBK) {
+                // ---- M >= 256: super-block solve.  Per super-block I (8 block rows): r_I = k_I - L(I, <I) a_<I (dense product,
+                // one block row per wave, in place), then a_I = (L_II)^-1 r_I (triangular product with the packed inverse of
+                // the 128 x 128 diagonal super-block; every wave reads r_I, barrier, writes a_I in place).  No wave carries a
+                // dependent chain, all eight are busy; the operand stream (csrc/precompute.hip) comes from L2 in job order.
+                {
+                    f32x4* uz = reinterpret_cast<f32x4*>(usq);
+                    for (int i = tid; i < (FW_WAVES * R * NSAMP) / 4; i += FW_THREADS) uz[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+                gptr4 Ap = (gptr4)G.LsP + lane;
+                const int nsb = (nbk + 7) >> 3;
+                float ssq[NS];
+#pragma unroll
+                for (int t = 0; t < NS; ++t) ssq[t] = 0.f;
+                int off = 0;
+                for (int I = 0; I < nsb; ++I) {
+                    const int r0 = 8 * I, nr = (nbk - r0 < 8) ? nbk - r0 : 8;
+                    const bool mine = wave < nr;
+                    const int bi = r0 + wave;
+                    f32x4 acc[NS];
+                    if (mine && r0 > 0) {
+#pragma unroll
+                        for (int t = 0; t < NS; ++t) acc[t] = kuf[(bi * 4 + gq) * NSAMP + 16 * t + jq];
+                        gptr4 P = Ap + (size_t)(off + wave * r0) * 64;
+                        f32x4 a_nx = P[0], a_n2 = P[(size_t)(1 < r0 ? 1 : 0) * 64];
+                        for (int bj = 0; bj < r0; ++bj) {
+                            const f32x4 a_cur = a_nx;
+                            a_nx = a_n2;
+                            a_n2 = P[(size_t)(bj + 2 < r0 ? bj + 2 : r0 - 1) * 64];
+                            f32x4 b[NS];
+#pragma unroll
+                            for (int t = 0; t < NS; ++t) b[t] = at[(bj * 4 + gq) * NSAMP + 16 * t + jq];
+#pragma unroll
+                            for (int s = 0; s < 4; ++s) {
+#pragma unroll
+                                for (int t = 0; t < NS; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[s], b[t][s], acc[t], 0, 0, 0);
+                            }
+                        }
+#pragma unroll
+                        for (int t = 0; t < NS; ++t) at[(bi * 4 + gq) * NSAMP + 16 * t + jq] = acc[t];      // r(bi), in place of k(bi)
+                    }
+                    if (r0 > 0) __syncthreads();                  // r_I complete
+                    if (mine) {
+                        gptr4 P = Ap + (size_t)(off + nr * r0 + wave * (wave + 1) / 2) * 64;
+#pragma unroll
+                        for (int t = 0; t < NS; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+                        f32x4 a_nx = P[0];
+                        for (int q = 0; q <= wave; ++q) {
+                            const f32x4 a_cur = a_nx;
+                            a_nx = P[(size_t)(q + 1 <= wave ? q + 1 : q) * 64];
+                            f32x4 b[NS];
+#pragma unroll
+                            for (int t = 0; t < NS; ++t) b[t] = at[((r0 + q) * 4 + gq) * NSAMP + 16 * t + jq];
+#pragma unroll
+                            for (int s = 0; s < 4; ++s) {
+#pragma unroll
+                                for (int t = 0; t < NS; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[s], b[t][s], acc[t], 0, 0, 0);
+                            }
+                        }
+                    }
+                    __syncthreads();                              // every row of the super-block has read r_I
+                    if (mine) {
+#pragma unroll
+                        for (int t = 0; t < NS; ++t) {
+                            const int tcol = 16 * t + jq;
+                            at[(bi * 4 + gq) * NSAMP + tcol] = acc[t];
+                            ssq[t] += colsumsq4(acc[t]);
+                            if (o_a && tcol < nvalid) *((gout4)(o_a + (size_t)(t0 + tcol) * G.Mp + 16 * bi + 4 * gq)) = acc[t];
+                        }
+                    }
+                    __syncthreads();                              // a_I visible (next super-block's product, stage 2)
+                    off += nr * r0 + nr * (nr + 1) / 2;
+                }
+                // |a|^2: every wave's share to its own slot, summed in a fixed order
+#pragma unroll
+                for (int t = 0; t < NS; ++t) {
+                    const float sq = xgroup_sum_mfma(ssq[t]);
+                    if (gq == 0) asq[(2 + wave) * NSAMP + 16 * t + jq] = sq;
+                }
+                __syncthreads();
+                if (tid < NSAMP) {
+                    float sq = 0.f;
+#pragma unroll
+                    for (int w = 0; w < FW_WAVES; ++w) sq += asq[(2 + w) * NSAMP + tid];
+                    asq[tid] = sq; asq[NSAMP + tid] = 0.f;
+                }
+            } else {
             if (wave >= NS) {
                 // the waves without a sub-tile of their own clear every |u|^2 slot first (stage 2 fills only some)
                 f32x4* uz = reinterpret_cast<f32x4*>(usq);
@@ -931,6 +1024,7 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
                 ssq = xgroup_sum_mfma(ssq);
                 if (gq < 2) asq[gq * NSAMP + tcol] = gq == 0 ? ssq : 0.f;   // slot 0 carries it; slot 1 is for a split solve
             }
+            }                                                     // (nbk <= 8)
             if (g.stamps && lane == 0 && li == 1) g.stamps[(size_t)blockIdx.x * 128 + 118 + wave] = clock64();
             __syncthreads();
             FW_STAMP(2 + li * 6 + 2);
@@ -1438,7 +1532,11 @@ static size_t fw_plan_lds(FwArgs& a, int nsamp, int maxR, int maxP, bool stage_z
     l.lw = o; o += nsamp;
     l.rowi = o; o += nsamp;
     l.pidx = o; o += nsamp;
-    l.asq = o; o += 2 * nsamp;
+    {
+        bool big = false;                                   // a layer with M > 128: one |a|^2 slot per wave besides the two
+        for (int i = 0; i < a.h.n_layers; ++i) if (a.L[i].type == IWVI_LAYER_GP && a.L[i].gp.nbk >= FW_SB_MIN_NBK) big = true;
+        l.asq = o; o += (big ? 2 + FW_WAVES : 2) * nsamp;
+    }
     l.meanp = o; o += maxR * nsamp;
     l.gbuf = o; o += 3 * maxR * nsamp;
     l.obuf = o; o += 2 * maxP * nsamp;

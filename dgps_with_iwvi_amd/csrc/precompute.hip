@@ -307,12 +307,16 @@ struct NoTail { __device__ void operator()(int, int) const {} };
 struct NoPost { __device__ void operator()(int, int, int) const {} };
 
 // X = L^-1 in place: off-diagonal blocks of blk become blocks of X, diagonal blocks of X live in dinv.
+// s_lo .. s_hi: the doubling steps to run (group sizes 2 s_lo .. s_hi); s_lo == 1 also inverts the diagonal blocks.  Stopping at
+// s_hi = 8 leaves the inverses of the 128 x 128 diagonal SUPER-blocks (the blocks outside them still hold L).
 __device__ __forceinline__ void invert_blocks(double* blk, double* dinv, double* tbuf, const double* rinv, int nbk,
-                              int tid, int nthreads) {
+                              int tid, int nthreads, int s_lo = 1, int s_hi = 1 << 30) {
     const int lane = tid & 63, wave = tid >> 6, nw = nthreads >> 6;
-    for (int b = wave; b < nbk; b += nw) diag_inverse(blk + boff(b, b), rinv + NB * b, dinv + (size_t)b * BLK, lane);
-    __syncthreads();
-    for (int s = 1; s < nbk; s *= 2) {
+    if (s_lo == 1) {
+        for (int b = wave; b < nbk; b += nw) diag_inverse(blk + boff(b, b), rinv + NB * b, dinv + (size_t)b * BLK, lane);
+        __syncthreads();
+    }
+    for (int s = s_lo; s < nbk && s < s_hi; s *= 2) {
         // stage 1: T_ij = sum_{k=j..aend-1} L_ik X_kj   (i in the B half, j in the A half of a 2s group)
         for (int o = wave; o < nbk * nbk; o += nw) {
             const int i = o / nbk, j = o - i * nbk;
@@ -516,13 +520,53 @@ __device__ void role_factor(const PreLayer& Lin, int stop_after, unsigned long l
     if (stop_after == 3 || stop_after > 30) return;
     PRE_STAMP(4);
     PRE_STAMP(5);
-    if (L.flags & IWVI_GP_WANT_DENSE) {
+    const bool dense = (L.flags & IWVI_GP_WANT_DENSE) != 0;
+    if (dense) {
         for (int idx = tid; idx < Mp * Mp; idx += nthreads) {
             const int i = idx / Mp, k = idx - i * Mp;
             L.Lm[idx] = (k <= i) ? blk_get(blk, i, k) : 0.0;
         }
         __syncthreads();
-        invert_blocks(blk, dinv, tbuf, rinv, nbk, tid, nthreads);
+    }
+    if (nbk >= 16) {                                              // (== FW_SB_MIN_NBK of csrc/dgp_forward.hip)
+        // M > 240: the layer kernel's solve a = Lm^-1 k runs super-block by super-block (8 block rows = 128 rows at a time):
+        //   r_I = k_I - L(I, <I) a_<I   (a dense product, every wave busy)      a_I = (L_II)^-1 r_I   (a triangular product)
+        // so that nothing in it is a dependent chain of one wave.  Its operand stream REPLACES the column-major substitution
+        // stream in LsP (same number of blocks): per super-block I, row by row, [-L(bi, 0 .. 8I-1)], then row by row
+        // [(L_II)^-1 (bi, 8I .. bi)].  The super-block inverses are the first three doubling steps of the dense inversion.
+        invert_blocks(blk, dinv, tbuf, rinv, nbk, tid, nthreads, 1, 8);
+        float4* dst = reinterpret_cast<float4*>(L.LsP);
+        const bool full = (M == Mp);
+        const int nsb = (nbk + 7) / 8;
+        int off = 0;                                              // blocks written so far
+        for (int I = 0; I < nsb; ++I) {
+            const int r0 = 8 * I, nr = (nbk - r0 < 8) ? nbk - r0 : 8;
+            const int nx = nr * r0, ny = nr * (nr + 1) / 2;
+            for (int it = tid; it < (nx + ny) * 64; it += nthreads) {
+                const int b = it >> 6, ln = it & 63, ii = ln & 15, k0 = 4 * (ln >> 4);
+                int bi, bk; bool inv;
+                if (b < nx) { bi = r0 + b / r0; bk = b - (b / r0) * r0; inv = false; }
+                else { int q = b - nx, w = 0; while ((w + 1) * (w + 2) / 2 <= q) ++w; bi = r0 + w; bk = r0 + q - w * (w + 1) / 2; inv = true; }
+                float v[4];
+#pragma unroll
+                for (int sgm = 0; sgm < 4; ++sgm) {
+                    const int i = 16 * bi + ii, k = 16 * bk + k0 + sgm;
+                    double x;
+                    if (!inv) x = -blk[boff(bi, bk) + ii * BLD + k0 + sgm];
+                    else x = (k <= i) ? inv_get(blk, dinv, i, k) : 0.0;
+                    float f = (float)x;
+                    if (!full && (i >= M || k >= M)) f = (inv && i == k) ? 1.f : 0.f;      // padded rows solve to 0 against k = 0
+                    v[sgm] = f;
+                }
+                dst[(size_t)off * 64 + it] = make_float4(v[0], v[1], v[2], v[3]);
+            }
+            off += nx + ny;
+        }
+        __syncthreads();
+    }
+    if (dense) {
+        if (nbk >= 16) invert_blocks(blk, dinv, tbuf, rinv, nbk, tid, nthreads, 8);     // the remaining doubling steps
+        else invert_blocks(blk, dinv, tbuf, rinv, nbk, tid, nthreads);
         for (int idx = tid; idx < Mp * Mp; idx += nthreads) {
             const int i = idx / Mp, k = idx - i * Mp;
             L.Linv[idx] = (k <= i) ? inv_get(blk, dinv, i, k) : 0.0;
