@@ -14,10 +14,11 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libiwvi_hip.so")
 
 KERN_RBF, KERN_MATERN52 = 0, 1
 LAYER_GP, LAYER_LV = 0, 1
-ABI_VERSION = 7
+ABI_VERSION = 8
 GP_WANT_DENSE = 1
 MAX_STACK = 8
 MF_ZERO, MF_IDENTITY, MF_LINEAR = 0, 1, 2
+ACT_TANH, ACT_RELU, ACT_SIGMOID, ACT_SOFTPLUS, ACT_IDENTITY = 0, 1, 2, 3, 4
 MAX_LAYERS, MAX_R, MAX_P, MAX_D, MAX_M, MAX_KL, MAX_ENC = 8, 32, 32, 32, 512, 4, 8
 
 c_void_p, c_int, c_int64, c_float, c_double, c_size_t = (
@@ -44,7 +45,7 @@ class EncDesc(ctypes.Structure):
                 ("n_enc", ctypes.c_int32), ("latent_dim", ctypes.c_int32), ("out", c_void_p),
                 ("X", c_void_p), ("Dx", ctypes.c_int32), ("K", ctypes.c_int32), ("sampled_kl", ctypes.c_int32),
                 ("layer_index", ctypes.c_int32), ("seed", ctypes.c_uint64), ("rng_state", c_void_p),
-                ("sample_X", c_void_p), ("sample_kl", c_void_p), ("sample_z", c_void_p)]
+                ("sample_X", c_void_p), ("sample_kl", c_void_p), ("sample_z", c_void_p), ("act", ctypes.c_int32)]
 
 
 class LayerDesc(ctypes.Structure):
@@ -59,7 +60,8 @@ class LayerDesc(ctypes.Structure):
                 ("enc_out", c_void_p),
                 ("noise", c_void_p), ("zero_noise", ctypes.c_int32), ("noise_out", c_void_p),
                 ("sample", c_void_p), ("mean", c_void_p), ("var", c_void_p), ("kl_local", c_void_p),
-                ("a_out", c_void_p), ("u_out", c_void_p), ("gmv_out", c_void_p), ("variance_dev", c_void_p)]
+                ("a_out", c_void_p), ("u_out", c_void_p), ("gmv_out", c_void_p), ("variance_dev", c_void_p),
+                ("enc_act", ctypes.c_int32)]
 
 
 class ElboDesc(ctypes.Structure):
@@ -118,6 +120,9 @@ PROTOTYPES = {
     "iwvi_lv_layer_backward": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p,
                                        c_int, c_int64, c_int, c_int, c_void_p, c_void_p]),
     "iwvi_encoder_backward_ws_bytes": (c_size_t, [c_int64, ctypes.POINTER(ctypes.c_int32), c_int]),
+    "iwvi_encoder_backward_act": (c_int, [c_void_p, c_int64, ctypes.POINTER(c_void_p), ctypes.POINTER(c_void_p),
+                                          ctypes.POINTER(ctypes.c_int32), c_int, c_int, c_void_p,
+                                          ctypes.POINTER(c_void_p), ctypes.POINTER(c_void_p), c_void_p, c_void_p]),
     "iwvi_encoder_backward": (c_int, [c_void_p, c_int64, ctypes.POINTER(c_void_p), ctypes.POINTER(c_void_p),
                                       ctypes.POINTER(ctypes.c_int32), c_int, c_void_p,
                                       ctypes.POINTER(c_void_p), ctypes.POINTER(c_void_p), c_void_p, c_void_p]),
@@ -135,6 +140,10 @@ PROTOTYPES = {
                                       c_int64, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "iwvi_mvn_sample_ws_bytes": (c_size_t, [c_int64, c_int, c_int]),
     "iwvi_mvn_sample": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_float, c_void_p, c_void_p]),
+    "iwvi_lv_layer_forward_act": (c_int, [c_void_p, c_void_p, c_void_p, ctypes.POINTER(c_void_p),
+                                          ctypes.POINTER(c_void_p), ctypes.POINTER(ctypes.c_int32), c_int, c_int,
+                                          c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                          c_int64, c_void_p]),
     "iwvi_lv_layer_forward": (c_int, [c_void_p, c_void_p, c_void_p, ctypes.POINTER(c_void_p),
                                       ctypes.POINTER(c_void_p), ctypes.POINTER(ctypes.c_int32), c_int,
                                       c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,

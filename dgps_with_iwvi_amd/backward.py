@@ -198,8 +198,8 @@ def lv_backward(layer, XY, enc_out, eps, dF_next, col0, w, B, K, sampled_kl=True
     dWp, dbp = _abi.ptr_array(dW), _abi.ptr_array(db)
     ws = torch.empty(_abi.lib().iwvi_encoder_backward_ws_bytes(B, dims, n), dtype=torch.uint8, device=dev)
     XY = _abi.dev_tensor(XY.contiguous(), "encoder input")
-    _abi.check(_abi.lib().iwvi_encoder_backward(_abi.ptr(XY), B, Wp, bp, dims, n, _abi.ptr(d_enc), dWp, dbp,
-                                               ws.data_ptr(), _abi.stream_ptr()))
+    _abi.check(_abi.lib().iwvi_encoder_backward_act(_abi.ptr(XY), B, Wp, bp, dims, n, layer.encoder.act, _abi.ptr(d_enc), dWp, dbp,
+                                                   ws.data_ptr(), _abi.stream_ptr()))
     return dW, db
 
 

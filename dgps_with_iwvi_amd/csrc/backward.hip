@@ -1659,7 +1659,7 @@ __global__ __launch_bounds__(256) void k_lv_bwd(LvBwdArgs a) {
 // Encoder MLP (layers.py:137-152), one thread per row: activations of every layer -> acts, then deltas (d / d pre-activation)
 struct EncBwdArgs {
     const float* XY; long long rows; const float* W[IWVI_MAX_ENC]; const float* b[IWVI_MAX_ENC]; int dims[IWVI_MAX_ENC + 1]; int n;
-    const float* d_out;
+    const float* d_out; int act;
     float* part; int woff[IWVI_MAX_ENC], boff[IWVI_MAX_ENC], ptot;     // part[workgroup][ptot]: this workgroup's share of (dW_l | db_l)
 };
 constexpr int ER = 8, ELD = 65;         // rows per workgroup, row stride of an activation tile in LDS
@@ -1695,7 +1695,7 @@ __global__ __launch_bounds__(256) void k_enc_bwd(EncBwdArgs a) {
             const int r = idx / dout, o = idx - r * dout;
             float acc = wl[a.boff[l] + o];
             for (int i = 0; i < din; ++i) acc = fmaf(in[r * ELD + i], wl[a.woff[l] + i * dout + o], acc);
-            if (l < a.n - 1) acc = tanhf(acc);
+            if (l < a.n - 1) acc = enc_act(acc, a.act);
             if (din == dout) acc += in[r * ELD + o];
             out[r * ELD + o] = acc;
         }
@@ -1711,7 +1711,7 @@ __global__ __launch_bounds__(256) void k_enc_bwd(EncBwdArgs a) {
         for (int idx = tid; idx < nrows * dout; idx += 256) {
             const int r = idx / dout, o = idx - r * dout;
             float v = cur[r * ELD + o];
-            if (l < a.n - 1) { const float act = out[r * ELD + o] - (skip ? in[r * ELD + o] : 0.f); v *= 1.f - act * act; }
+            if (l < a.n - 1) { const float av = out[r * ELD + o] - (skip ? in[r * ELD + o] : 0.f); v *= enc_act_grad(av, a.act); }
             dl[r * ELD + o] = v;
         }
         __syncthreads();
@@ -2300,12 +2300,19 @@ extern "C" size_t iwvi_encoder_backward_ws_bytes(int64_t rows, const int32_t* di
 extern "C" int iwvi_encoder_backward(const float* XY, int64_t rows, const float* const* enc_W, const float* const* enc_b,
                                      const int32_t* dims, int n_enc, const float* d_out,
                                      float* const* dW, float* const* db, void* ws_, void* stream_) {
+    return iwvi_encoder_backward_act(XY, rows, enc_W, enc_b, dims, n_enc, IWVI_ACT_TANH, d_out, dW, db, ws_, stream_);
+}
+
+extern "C" int iwvi_encoder_backward_act(const float* XY, int64_t rows, const float* const* enc_W, const float* const* enc_b,
+                                         const int32_t* dims, int n_enc, int act, const float* d_out,
+                                         float* const* dW, float* const* db, void* ws_, void* stream_) {
+    if (act < IWVI_ACT_TANH || act > IWVI_ACT_IDENTITY) { set_error("iwvi_encoder_backward: unknown activation %d", act); return IWVI_ERR_UNSUPPORTED; }
     if (!XY || !enc_W || !dims || !d_out || !dW || !ws_ || rows <= 0 || n_enc <= 0 || n_enc > IWVI_MAX_ENC) { set_error("iwvi_encoder_backward: bad argument"); return IWVI_ERR_ARG; }
     for (int l = 0; l <= n_enc; ++l) if (dims[l] <= 0 || dims[l] > 64) { set_error("iwvi_encoder_backward: encoder width %d out of range (1..64)", dims[l]); return IWVI_ERR_ARG; }
     hipStream_t st = (hipStream_t)stream_;
     EncBwdArgs a{};
     EncReduceArgs r{};
-    a.XY = XY; a.rows = rows; a.n = n_enc; a.d_out = d_out; a.part = (float*)ws_;
+    a.XY = XY; a.rows = rows; a.n = n_enc; a.d_out = d_out; a.act = act; a.part = (float*)ws_;
     int off = 0;
     for (int l = 0; l <= n_enc; ++l) a.dims[l] = dims[l];
     for (int l = 0; l < n_enc; ++l) {

@@ -83,7 +83,7 @@ struct FwLv {
     const float* enc_out;             // precomputed encoder output [data rows, 2*Lw] (iwvi_model_precompute), or NULL
     float* kl_local;
     int dims[IWVI_MAX_ENC + 1];
-    int n_enc, Lw, sampled_kl, wtotal, maxdim;
+    int n_enc, Lw, sampled_kl, wtotal, maxdim, act;
 };
 // leading fields of a layer descriptor; nx_*: the following layer when that is a GP layer (its Gram operand is
 // produced by this layer's last phase)
@@ -619,6 +619,7 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
             const float* in = xyrows; int in_str = up4(g.XYdim);
             float* out = act0;
             const bool pre_enc = (H.flags & FWF_PRE_ENC) != 0;    // encoder already evaluated by iwvi_model_precompute
+            const int enc_actv = pre_enc ? 0 : ufirst(V.act);
             if (pre_enc) { in = cst; in_str = 2 * Lw; }
             else {
                 int off = 0;
@@ -630,7 +631,7 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
                         float acc = b[o];
 #pragma unroll 8
                         for (int i = 0; i < din; ++i) acc = fmaf(in[p * in_str + i], W[i * dout + o], acc);
-                        if (l < n_enc - 1) acc = tanhf(acc);                         // layers.py:143-144
+                        if (l < n_enc - 1) acc = enc_act(acc, enc_actv);             // layers.py:143-144
                         if (din == dout) acc += in[p * in_str + o];                  // layers.py:146-147
                         out[p * mdim + o] = acc;
                     }
@@ -1706,7 +1707,8 @@ int dgp_forward_impl(const iwvi_layer_desc* layers, int n_layers, const float* X
                     V.W[k] = d.enc_W[k]; V.b[k] = d.enc_b ? d.enc_b[k] : nullptr;
                     V.wtotal += d.enc_dims[k] * d.enc_dims[k + 1] + d.enc_dims[k + 1];
                 }
-                V.n_enc = d.n_enc;
+                V.n_enc = d.n_enc; V.act = d.enc_act;
+                if (d.enc_act < IWVI_ACT_TANH || d.enc_act > IWVI_ACT_IDENTITY) { set_error("iwvi_lv_layer_forward: unknown activation %d", d.enc_act); return IWVI_ERR_UNSUPPORTED; }
                 a.h.XY = XY;
             }
             if (D + d.latent_dim > maxP) maxP = D + d.latent_dim;

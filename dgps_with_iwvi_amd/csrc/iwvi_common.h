@@ -99,5 +99,24 @@ __device__ __forceinline__ void draw_normal4(unsigned long long seed, unsigned l
     box_muller4(c, v);
 }
 __device__ __forceinline__ float softplus_f(float x) { return x > 20.f ? x : log1pf(__expf(x)); }
+// Encoder activation (layers.py:109,143-144: activation_func, default tf.nn.tanh) and its derivative from the OUTPUT a = act(x)
+__device__ __forceinline__ float enc_act(float x, int act) {
+    switch (act) {
+        case IWVI_ACT_RELU: return fmaxf(x, 0.f);
+        case IWVI_ACT_SIGMOID: return 1.f / (1.f + __expf(-x));
+        case IWVI_ACT_SOFTPLUS: return softplus_f(x);
+        case IWVI_ACT_IDENTITY: return x;
+        default: return tanhf(x);
+    }
+}
+__device__ __forceinline__ float enc_act_grad(float a, int act) {
+    switch (act) {
+        case IWVI_ACT_RELU: return a > 0.f ? 1.f : 0.f;
+        case IWVI_ACT_SIGMOID: return a * (1.f - a);
+        case IWVI_ACT_SOFTPLUS: return 1.f - __expf(-a);
+        case IWVI_ACT_IDENTITY: return 1.f;
+        default: return 1.f - a * a;
+    }
+}
 
 }  // namespace iwvi

@@ -207,12 +207,20 @@ extern "C" int iwvi_lv_layer_forward(const float* F, const float* XY, const floa
                                      const int32_t* dims, int n_enc, int D, int Lw, int sampled_kl,
                                      float* sample, float* mean, float* cov, float* kl,
                                      int64_t T, void* stream_) {
+    return iwvi_lv_layer_forward_act(F, XY, noise, enc_W, enc_b, dims, n_enc, IWVI_ACT_TANH, D, Lw, sampled_kl, sample, mean, cov, kl, T, stream_);
+}
+
+extern "C" int iwvi_lv_layer_forward_act(const float* F, const float* XY, const float* noise,
+                                         const float* const* enc_W, const float* const* enc_b,
+                                         const int32_t* dims, int n_enc, int act, int D, int Lw, int sampled_kl,
+                                         float* sample, float* mean, float* cov, float* kl,
+                                         int64_t T, void* stream_) {
     if (T <= 0) return IWVI_OK;
     if (!F) { set_error("iwvi_lv_layer_forward: null input"); return IWVI_ERR_ARG; }
     if (D <= 0 || D > IWVI_MAX_D || Lw <= 0) { set_error("iwvi_lv_layer_forward: bad D=%d (1..32) or latent_dim=%d", D, Lw); return IWVI_ERR_ARG; }
     iwvi_layer_desc d{};
     d.type = IWVI_LAYER_LV; d.D = D; d.latent_dim = Lw; d.sampled_kl = sampled_kl;
-    if (XY) { d.enc_W = enc_W; d.enc_b = enc_b; d.enc_dims = dims; d.n_enc = n_enc;
+    if (XY) { d.enc_W = enc_W; d.enc_b = enc_b; d.enc_dims = dims; d.n_enc = n_enc; d.enc_act = act;
               if (!enc_W || !dims) { set_error("iwvi_lv_layer_forward: encoder inputs without an encoder"); return IWVI_ERR_ARG; } }
     d.noise = noise; d.zero_noise = 1; d.sample = sample; d.mean = mean; d.var = cov; d.kl_local = kl;
     return dgp_forward_impl(&d, 1, F, D, XY, XY ? dims[0] : 0, nullptr, 0, T, 1, T, 1.f, 0, nullptr, nullptr, nullptr,

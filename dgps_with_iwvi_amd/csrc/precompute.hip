@@ -40,7 +40,7 @@ struct PreLayer {
 // depend on the factorisation, so it rides on otherwise idle CUs instead of the critical path of the layer kernel
 struct PreEnc {
     const float* XY; float* out; const float* W[IWVI_MAX_ENC]; const float* b[IWVI_MAX_ENC];
-    long long rows; int dims[IWVI_MAX_ENC + 1]; int n_enc, Lw, blk0, nblk;
+    long long rows; int dims[IWVI_MAX_ENC + 1]; int n_enc, Lw, blk0, nblk, act;
     // sampling tail (sample_X != nullptr): see iwvi_enc_desc
     const float* X; int Dx, K, sampled_kl, layer_index;
     unsigned long long seed; const unsigned long long* rng_state;
@@ -685,7 +685,7 @@ __device__ void role_encoder(const PreEnc& E, int blk) {
             const int r = idx / dout, o = idx - r * dout;
             float acc = b[o];
             for (int i = 0; i < din; ++i) acc = fmaf(in[r * mdim + i], W[i * dout + o], acc);
-            if (l < E.n_enc - 1) acc = tanhf(acc);                         // layers.py:143-144
+            if (l < E.n_enc - 1) acc = enc_act(acc, E.act);                // layers.py:143-144
             if (din == dout) acc += in[r * mdim + o];                       // layers.py:146-147
             out[r * mdim + o] = acc;
         }
@@ -893,7 +893,8 @@ extern "C" int iwvi_model_precompute(const iwvi_gp_desc* layers, int n_layers, c
                     E.W[k] = d.enc_W[k]; E.b[k] = d.enc_b ? d.enc_b[k] : nullptr;
                     w += (size_t)d.dims[k] * d.dims[k + 1] + d.dims[k + 1];
                 }
-                E.XY = d.XY; E.out = d.out; E.rows = d.rows; E.n_enc = d.n_enc; E.Lw = d.latent_dim;
+                E.XY = d.XY; E.out = d.out; E.rows = d.rows; E.n_enc = d.n_enc; E.Lw = d.latent_dim; E.act = d.act;
+                if (d.act < IWVI_ACT_TANH || d.act > IWVI_ACT_IDENTITY) { set_error("iwvi_model_precompute: unknown activation %d", d.act); return IWVI_ERR_UNSUPPORTED; }
                 E.sample_X = d.sample_X; E.sample_kl = d.sample_kl; E.sample_z = d.sample_z;
                 if (d.sample_X) {
                     if (!d.X || !d.sample_kl || d.Dx <= 0 || d.Dx + d.latent_dim > IWVI_MAX_D || d.K <= 0) { set_error("iwvi_model_precompute: bad sampling tail of encoder %d", e); return IWVI_ERR_ARG; }

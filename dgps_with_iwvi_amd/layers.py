@@ -146,13 +146,29 @@ class GPLayer:
         return samples, mean, cov, kl
 
 
+def _activation_code(activation_func):
+    """``Encoder(activation_func=...)`` (reference layers.py:109,119: default ``tf.nn.tanh``) -> IWVI_ACT_*.  Accepts None, a
+    name, or the torch callable of one of the activations the kernels implement."""
+    if activation_func is None:
+        return _abi.ACT_TANH
+    names = {"tanh": _abi.ACT_TANH, "relu": _abi.ACT_RELU, "sigmoid": _abi.ACT_SIGMOID, "softplus": _abi.ACT_SOFTPLUS,
+             "identity": _abi.ACT_IDENTITY, "linear": _abi.ACT_IDENTITY}
+    if isinstance(activation_func, str):
+        key = activation_func.lower()
+    else:
+        key = getattr(activation_func, "__name__", type(activation_func).__name__).lower()
+    if key in names:
+        return names[key]
+    raise NotImplementedError("Encoder activation %r: the HIP kernels implement %s" % (activation_func, sorted(set(names))))
+
+
 class Encoder:
-    """tanh MLP [input_dim, *network_dims, 2*latent_dim] with skip connections (reference :108-152).
-    Evaluated inside ``iwvi_lv_layer_forward``; ``__call__`` runs that kernel in encoder-only mode."""
+    """MLP [input_dim, *network_dims, 2*latent_dim] with skip connections (reference :108-152), hidden activation
+    ``activation_func`` (default tanh like the reference; also relu / sigmoid / softplus / identity, by name or as the torch
+    callable).  Evaluated inside ``iwvi_lv_layer_forward``; ``__call__`` runs that kernel in encoder-only mode."""
 
     def __init__(self, latent_dim, input_dim, network_dims, activation_func=None, name=None):
-        if activation_func is not None:
-            raise NotImplementedError("only the default tanh activation is implemented in the HIP kernel")
+        self.act = _activation_code(activation_func)
         self.latent_dim = latent_dim
         self.layer_dims = [input_dim, *network_dims, latent_dim * 2]
         if len(self.layer_dims) - 1 > _abi.MAX_ENC:
@@ -186,8 +202,8 @@ class Encoder:
         mean = torch.empty(T, 1 + Lw, dtype=settings.float_type, device=Z.device)
         cov = torch.empty(T, 1 + Lw, dtype=settings.float_type, device=Z.device)
         Wp, bp, dims, n, keep = self.abi_args()
-        _abi.check(_abi.lib().iwvi_lv_layer_forward(
-            _abi.ptr(dummy), _abi.ptr(Z.reshape(T, -1)), None, Wp, bp, dims, n, 1, Lw, 0,
+        _abi.check(_abi.lib().iwvi_lv_layer_forward_act(
+            _abi.ptr(dummy), _abi.ptr(Z.reshape(T, -1)), None, Wp, bp, dims, n, self.act, 1, Lw, 0,
             None, _abi.ptr(mean), _abi.ptr(cov), None, T, _abi.stream_ptr()))
         return mean[:, 1:].reshape(*lead, Lw), cov[:, 1:].sqrt().reshape(*lead, Lw)
 
@@ -202,6 +218,10 @@ class LatentVariableLayer:
             encoder = Encoder(latent_dim, XY_dim, [20, 20])
         self.encoder = encoder
         self.name = name
+        # the reference's placeholders_with_default (layers.py:60-64): in prior mode (no recognition inputs) q_mu / q_sqrt may be
+        # FED, e.g. for plotting; None = the defaults 0 / 1.  Tensors broadcastable to [..., latent_dim].
+        self.q_mu_placeholder = None
+        self.q_sqrt_placeholder = None
 
     def to(self, device):
         self.encoder.to(device)
@@ -223,7 +243,7 @@ class LatentVariableLayer:
         Wp, bp, dims, n, k2 = self.encoder.abi_args()
         e = _abi.EncDesc()
         e.XY, e.rows, e.enc_W, e.enc_b, e.dims, e.n_enc = XY.data_ptr(), rows, Wp, bp, dims, n
-        e.latent_dim, e.out = self.latent_dim, self._enc_out.data_ptr()
+        e.latent_dim, e.out, e.act = self.latent_dim, self._enc_out.data_ptr(), self.encoder.act
         keep = [XY, Wp, bp, dims, k2]
         if sample is not None:
             X = _abi.dev_tensor(sample["X"].contiguous(), "X")
@@ -256,7 +276,7 @@ class LatentVariableLayer:
             keep.append(enc_out)
         elif use_encoder:
             Wp, bp, dims, n, k2 = self.encoder.abi_args()
-            d.enc_W, d.enc_b, d.enc_dims, d.n_enc = Wp, bp, dims, n
+            d.enc_W, d.enc_b, d.enc_dims, d.n_enc, d.enc_act = Wp, bp, dims, n, self.encoder.act
             keep += [Wp, bp, dims, k2]
         if z is not None:
             d.noise = _abi.dev_tensor(z, "z").data_ptr()
@@ -284,10 +304,38 @@ class LatentVariableLayer:
         z2 = draw_normal((T, Lw), dev) if z is None else _abi.dev_tensor(z.reshape(T, Lw).contiguous(), "z")
         outs = [torch.empty(T, D + Lw, dtype=settings.float_type, device=dev) for _ in range(3)]
         kl = torch.empty(T, Lw, dtype=settings.float_type, device=dev)
+        if XY is None and (self.q_mu_placeholder is not None or self.q_sqrt_placeholder is not None):
+            return self._propagate_fed(F.reshape(T, D), z2, outs, kl, lead, is_sampled_local_regularizer)
         Wp, bp, dims, n, keep = self.encoder.abi_args()
-        _abi.check(_abi.lib().iwvi_lv_layer_forward(
-            _abi.ptr(F.reshape(T, D)), _abi.ptr(XY), _abi.ptr(z2), Wp, bp, dims, n, D, Lw,
+        _abi.check(_abi.lib().iwvi_lv_layer_forward_act(
+            _abi.ptr(F.reshape(T, D)), _abi.ptr(XY), _abi.ptr(z2), Wp, bp, dims, n, self.encoder.act, D, Lw,
             1 if is_sampled_local_regularizer else 0,
             _abi.ptr(outs[0]), _abi.ptr(outs[1]), _abi.ptr(outs[2]), _abi.ptr(kl), T, _abi.stream_ptr()))
+        s, m, c = (o.view(*lead, D + Lw) for o in outs)
+        return s, m, c, kl.view(*lead, Lw)
+
+    def _propagate_fed(self, F2, z2, outs, kl, lead, sampled):
+        """Prior mode with FED q_mu / q_sqrt (the reference's placeholders, layers.py:60-64,78-81): the values travel as a
+        precomputed "encoder output" [T, 2*latent_dim] = (q_mu | raw) with q_sqrt = softplus(raw - 3), through the same kernel."""
+        T, D = F2.shape
+        Lw, dev = self.latent_dim, F2.device
+        ft = settings.float_type
+        mu = torch.zeros(T, Lw, dtype=ft, device=dev) if self.q_mu_placeholder is None else \
+            torch.as_tensor(self.q_mu_placeholder, dtype=ft, device=dev).expand(*lead, Lw).reshape(T, Lw)
+        sg = torch.ones(T, Lw, dtype=ft, device=dev) if self.q_sqrt_placeholder is None else \
+            torch.as_tensor(self.q_sqrt_placeholder, dtype=ft, device=dev).expand(*lead, Lw).reshape(T, Lw)
+        if bool((sg <= 0).any()):
+            raise ValueError("q_sqrt_placeholder must be positive")
+        sg64 = sg.double()
+        raw = torch.where(sg64 > 20.0, sg64, torch.log(torch.expm1(sg64))) + 3.0          # softplus^-1, float64 then rounded once
+        enc_out = torch.cat([mu, raw.to(ft)], -1).contiguous()
+        d = _abi.LayerDesc()
+        d.type, d.D, d.latent_dim, d.sampled_kl = _abi.LAYER_LV, D, Lw, 1 if sampled else 0
+        d.enc_out = enc_out.data_ptr()
+        d.noise, d.zero_noise = z2.data_ptr(), 1
+        d.sample, d.mean, d.var, d.kl_local = (t.data_ptr() for t in (*outs, kl))
+        descs = (_abi.LayerDesc * 1)(d)
+        _abi.check(_abi.lib().iwvi_dgp_forward(descs, 1, _abi.ptr(F2), D, None, 0, None, 0, T, 1, T, 1.0, 0, None, None, None,
+                                              _abi.stream_ptr()))
         s, m, c = (o.view(*lead, D + Lw) for o in outs)
         return s, m, c, kl.view(*lead, Lw)

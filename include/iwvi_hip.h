@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define IWVI_ABI_VERSION 7
+#define IWVI_ABI_VERSION 8
 
 enum {
     IWVI_OK = 0,
@@ -38,6 +38,9 @@ enum {
 
 /* stationary kernels of gpflow.kernels used on the path (temp_workaround.py:39,44,45) */
 enum { IWVI_KERN_RBF = 0, IWVI_KERN_MATERN52 = 1 };
+
+/* Encoder(activation_func=...) (layers.py:109,119,143-144; the reference's default is tf.nn.tanh) */
+enum { IWVI_ACT_TANH = 0, IWVI_ACT_RELU = 1, IWVI_ACT_SIGMOID = 2, IWVI_ACT_SOFTPLUS = 3, IWVI_ACT_IDENTITY = 4 };
 
 /* gpflow.mean_functions used by GPLayer.propagate (layers.py:46-48) */
 enum { IWVI_MF_ZERO = 0, IWVI_MF_IDENTITY = 1, IWVI_MF_LINEAR = 2 };
@@ -120,6 +123,7 @@ typedef struct iwvi_enc_desc {
     float* sample_X;                     /* [rows * K, Dx + latent_dim] = concat(X tiled, W)          (layers.py:89) */
     float* sample_kl;                    /* [rows * K] local regulariser summed over the latent dims  (:98-103)      */
     float* sample_z;                     /* optional [rows * K, latent_dim]: the draws                               */
+    int32_t act;                         /* IWVI_ACT_* of the hidden layers (0 = tanh)                                */
 } iwvi_enc_desc;
 int iwvi_model_precompute(const iwvi_gp_desc* layers_host, int n_layers,
                           const iwvi_enc_desc* encs_host, int n_encs, void* stream);
@@ -226,6 +230,7 @@ typedef struct iwvi_layer_desc {
     float* a_out; float* u_out;     /* GP, optional (what the adjoint needs): A [T, Mp], L_r^T A [R, T, Mp] */
     float* gmv_out;                 /* GP, optional: [T, 3R] = (sample | mean | variance) of the R latent GPs before mixing */
     const float* variance_dev;      /* GP, optional device scalar read instead of `variance` (see iwvi_gp_desc) */
+    int32_t enc_act;                /* LV: IWVI_ACT_* of the encoder's hidden layers (0 = tanh) */
 } iwvi_layer_desc;
 
 /* Optional tail of the same launch: the last workgroup to finish performs models.py:138-150 on out_logw
@@ -340,6 +345,10 @@ size_t iwvi_encoder_backward_ws_bytes(int64_t rows, const int32_t* dims, int n_e
 int iwvi_encoder_backward(const float* XY, int64_t rows, const float* const* enc_W, const float* const* enc_b,
                           const int32_t* dims, int n_enc, const float* d_out,
                           float* const* dW, float* const* db, void* ws, void* stream);
+/* the same for an encoder whose hidden layers use activation IWVI_ACT_* */
+int iwvi_encoder_backward_act(const float* XY, int64_t rows, const float* const* enc_W, const float* const* enc_b,
+                              const int32_t* dims, int n_enc, int act, const float* d_out,
+                              float* const* dW, float* const* db, void* ws, void* stream);
 
 /* Test log-likelihood of experiments/run_conditional_density_estimation.py:148-169, batched over the test points:
  * samples: S predictive draws per point (element (s, n) at samples[s*sample_stride + n*point_stride]); y [N].
@@ -390,6 +399,13 @@ int iwvi_lv_layer_forward(const float* F, const float* XY, const float* noise,
                           int D, int Lw, int sampled_kl,
                           float* sample, float* mean, float* cov, float* kl,
                           int64_t T, void* stream);
+/* the same for an encoder whose hidden layers use activation IWVI_ACT_* (Encoder(activation_func=...), layers.py:109) */
+int iwvi_lv_layer_forward_act(const float* F, const float* XY, const float* noise,
+                              const float* const* enc_W_host, const float* const* enc_b_host,
+                              const int32_t* dims_host, int n_enc, int act,
+                              int D, int Lw, int sampled_kl,
+                              float* sample, float* mean, float* cov, float* kl,
+                              int64_t T, void* stream);
 
 /* ------------------------------------------------------------------------
  * The IW-ELBO reduction (models.py:133-150): Gaussian variational expectations

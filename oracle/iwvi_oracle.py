@@ -329,7 +329,8 @@ class GPLayer:
 class Encoder:
     """layers.py:108-152 -- tanh MLP with skip connections on equal dims."""
 
-    def __init__(self, latent_dim, input_dim, network_dims, rng=None):
+    def __init__(self, latent_dim, input_dim, network_dims, rng=None, activation_func=None):
+        self.activation_func = np.tanh if activation_func is None else activation_func   # :119 (default tf.nn.tanh)
         self.latent_dim = latent_dim
         self.layer_dims = [input_dim, *network_dims, latent_dim * 2]
         rng = np.random.default_rng(0) if rng is None else rng
@@ -347,7 +348,7 @@ class Encoder:
             Z0 = Z
             Z = np.matmul(Z, W) + b                                  # :141
             if i < n - 1:
-                Z = np.tanh(Z)                                       # :143-144
+                Z = self.activation_func(Z)                          # :143-144
             if dout == din:
                 Z = Z + Z0                                           # :146-147
         means, raw = np.split(Z, 2, axis=-1)                         # :149
@@ -368,9 +369,10 @@ class LatentVariableLayer:
     def propagate(self, F, inference_amorization_inputs=None,
                   is_sampled_local_regularizer=False, z=None, **kwargs):
         F = np.asarray(F, np.float64)
-        if inference_amorization_inputs is None:                     # :73-81 prior
+        if inference_amorization_inputs is None:                     # :73-81 prior; the placeholders (:60-64) may be fed
             shape = F.shape[:-1] + (self.latent_dim,)
-            q_mu, q_sqrt = np.zeros(shape), np.ones(shape)
+            q_mu = np.broadcast_to(np.asarray(getattr(self, "q_mu_placeholder", 0.0), np.float64), shape) * np.ones(shape)
+            q_sqrt = np.broadcast_to(np.asarray(getattr(self, "q_sqrt_placeholder", 1.0), np.float64), shape) * np.ones(shape)
         else:
             q_mu, q_sqrt = self.encoder(inference_amorization_inputs)  # :83
         zz = np.zeros_like(q_mu) if z is None else np.asarray(z, np.float64)

@@ -431,3 +431,76 @@ def test_wide_multilayer_models_match_oracle(gpu_device, L, M, K, B, lv):
     np.testing.assert_allclose(_np(fmean), means_o[-1], rtol=2e-3, atol=2e-3)
     vo = np.diagonal(covs_o[-1], axis1=-2, axis2=-1).transpose(0, 2, 1)
     np.testing.assert_allclose(_np(fvar), vo, rtol=5e-3, atol=2e-4)
+
+
+# ------------------------------------------------------------------------------------------
+# Encoder(activation_func=...) (layers.py:109,119) and the LV layer's fed placeholders (layers.py:60-64)
+# ------------------------------------------------------------------------------------------
+_ACTS = {"relu": lambda x: np.maximum(x, 0.0), "sigmoid": lambda x: 1.0 / (1.0 + np.exp(-x)),
+         "softplus": lambda x: np.logaddexp(0.0, x), "tanh": np.tanh}
+
+
+@pytest.mark.parametrize("act", ["relu", "sigmoid", "softplus"])
+def test_encoder_activation_forward_and_gradient(gpu_device, act):
+    """A non-default ``activation_func``: (1) encoder and LV-layer outputs vs the oracle with the same activation, through all
+    three places the MLP runs (standalone layer kernel, the precompute launch, inside the fused forward); (2) the IW-ELBO of a
+    model built on it vs the oracle; (3) its encoder gradients vs central finite differences of that ELBO (fixed noise)."""
+    from dgps_with_iwvi_amd import synthetic
+    from dgps_with_iwvi_amd.backward import iw_elbo_and_gradients
+    from dgps_with_iwvi_amd.layers import Encoder, LatentVariableLayer
+    torch_act = {"relu": torch.relu, "sigmoid": torch.sigmoid, "softplus": "softplus"}[act]
+    spec = synthetic.make_spec(L=2, M=32, B=24, K=4, with_lv=True, seed=71, n_data=300)
+    zs = synthetic.make_noise(spec, seed=72)
+    zd = [_t(z, gpu_device) for z in zs]
+    model = synthetic.build_model(spec, gpu_device)
+    lvs = spec["layers"][0]
+    enc = Encoder(lvs["latent_dim"], lvs["dims"][0], lvs["dims"][1:-1], activation_func=torch_act)
+    enc.Ws, enc.bs = [_t(w, gpu_device) for w in lvs["enc_W"]], [_t(b, gpu_device) for b in lvs["enc_b"]]
+    model.layers[0] = LatentVariableLayer(lvs["latent_dim"], encoder=enc)
+    om = build_oracle(spec)
+    om.layers[0].encoder.activation_func = _ACTS[act]
+    XY = np.concatenate([spec["X"][:24], spec["Y"][:24]], -1)
+    qm, qs = enc(_t(XY, gpu_device))
+    qmo, qso = om.layers[0].encoder(XY)
+    np.testing.assert_allclose(_np(qm), qmo, rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(_np(qs), qso, rtol=1e-4, atol=1e-6)
+    ref = om.build_likelihood(oracle_noise(spec, zs))
+    got = model.compute_log_likelihood(zd)                       # encoder inside the precompute launch
+    assert abs(got - ref) <= 1e-4 * abs(ref), (got, ref)
+    elbo, g = iw_elbo_and_gradients(model, zd)
+    assert abs(float(elbo) - ref) <= 1e-4 * abs(ref)
+    rng = np.random.default_rng(0)
+    for j, W in enumerate(enc.Ws):                               # directional derivative along a random direction, per weight matrix
+        dirn = torch.as_tensor(rng.standard_normal(tuple(W.shape)), dtype=torch.float32, device=gpu_device)
+        eps = 2e-3 if act == "relu" else 1e-2                   # (relu has kinks: a large step crosses some of them)
+        W.add_(eps * dirn); up = model.compute_log_likelihood(zd)
+        W.sub_(2 * eps * dirn); dn = model.compute_log_likelihood(zd)
+        W.add_(eps * dirn)
+        fd = (up - dn) / (2 * eps)
+        an = float((g["l0.encW%d" % j] * dirn).sum())
+        assert abs(fd - an) <= 3e-2 * max(abs(fd), abs(an), 1.0), (act, j, fd, an)
+    with pytest.raises(NotImplementedError):
+        Encoder(1, 3, [4], activation_func=torch.erf)
+
+
+def test_latent_variable_layer_fed_placeholders(gpu_device):
+    """Prior mode with q_mu / q_sqrt FED through the layer's placeholders (the reference's placeholder_with_default,
+    layers.py:60-64,78-81) vs the oracle; unset placeholders give the prior N(0, 1)."""
+    from dgps_with_iwvi_amd.layers import LatentVariableLayer
+    rng = np.random.default_rng(5)
+    F = _f32(rng.standard_normal((7, 3, 4)))
+    z = _f32(rng.standard_normal((7, 3, 2)))
+    lv = LatentVariableLayer(2, XY_dim=5).to(gpu_device)
+    lo = O.LatentVariableLayer(2, XY_dim=5)
+    for q_mu, q_sqrt in ((np.array([[0.5, -1.0]]), np.array([[0.3, 2.0]])), (_f32(rng.standard_normal((7, 3, 2))), None), (None, np.float64(0.05))):
+        lv.q_mu_placeholder = None if q_mu is None else _t(q_mu, gpu_device)
+        lv.q_sqrt_placeholder = None if q_sqrt is None else _t(q_sqrt, gpu_device)
+        if q_mu is None: lo.__dict__.pop("q_mu_placeholder", None)
+        else: lo.q_mu_placeholder = _f32(q_mu)
+        if q_sqrt is None: lo.__dict__.pop("q_sqrt_placeholder", None)
+        else: lo.q_sqrt_placeholder = _f32(q_sqrt)
+        for sampled in (True, False):
+            s, m, c, kl = lv.propagate(_t(F, gpu_device), None, sampled, z=_t(z, gpu_device))
+            so, mo, co, klo = lo.propagate(F, None, sampled, z=z)
+            for a, b in ((s, so), (m, mo), (c, co), (kl, klo)):
+                np.testing.assert_allclose(_np(a), b, rtol=1e-5, atol=1e-5)
