@@ -108,6 +108,7 @@ PROTOTYPES = {
     "iwvi_chol_factor": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "iwvi_gp_layer_backward_ws_bytes": (c_size_t, [c_int64, c_int, c_int, c_int]),
     "iwvi_gp_layer_backward": (c_int, [ctypes.POINTER(GpBwdDesc), c_int64, c_void_p, c_void_p]),
+    "iwvi_gp_layer_backward_needs_u": (c_int, [c_int64, c_int, c_int, c_int, c_int]),
     "iwvi_gp_layer_backward_prepare": (c_int, [ctypes.POINTER(GpBwdDesc), c_int64, c_void_p, c_void_p]),
     "iwvi_iw_elbo_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, ctypes.POINTER(c_void_p),
                                       ctypes.POINTER(ctypes.c_int32), c_int, c_int64, c_int, c_float, c_double, c_int,

@@ -32,12 +32,13 @@ class GpSaved:
     __slots__ = ("F", "noise", "A", "U", "sample", "mean", "var", "T", "GMV")
 
 
-def needs_saved_u(M, T):
-    """The adjoint's streaming chain (csrc/backward.hip: k_bw_chain; M a multiple of 16 up to 128, T a multiple of 16) works
-    from a = Lm^-1 k alone; every other shape takes the GEMM path, which also reads the forward's u_r = L_r^T a."""
-    import os
-    ok = M % 16 == 0 and M <= 128 and T % 16 == 0 and not os.environ.get("IWVI_BW_UNFUSED") and not os.environ.get("IWVI_BW_OLD_CHAIN")
-    return not ok
+def needs_saved_u(layer, T):
+    """The adjoint's streaming chain (csrc/backward.hip: k_bw_chain; M <= 256, M and T multiples of 16, its tiles within the LDS) works
+    from a = Lm^-1 k alone; every other shape takes the GEMM path, which also reads the forward's u_r = L_r^T a.  The library
+    decides (``iwvi_gp_layer_backward_needs_u``)."""
+    R = layer.num_outputs
+    P = layer.kern.W.shape[0] if isinstance(layer.kern, SharedMixedMok) else R
+    return bool(_abi.lib().iwvi_gp_layer_backward_needs_u(int(T), layer.num_inducing, layer._Z().shape[1], R, P))
 
 
 def _words(device):
@@ -70,7 +71,7 @@ def gp_forward_saved(layer, F, z=None, words=None, precomputed=False):
     s = GpSaved()
     s.F, s.T, s.GMV = F, T, None
     s.A = torch.empty(T, Mp, dtype=settings.float_type, device=dev)
-    s.U = torch.empty(R, T, Mp, dtype=settings.float_type, device=dev) if needs_saved_u(layer.num_inducing, T) else None
+    s.U = torch.empty(R, T, Mp, dtype=settings.float_type, device=dev) if needs_saved_u(layer, T) else None
     s.noise = torch.empty(T, R, dtype=settings.float_type, device=dev)
     s.sample, s.mean, s.var = (torch.empty(T, P, dtype=settings.float_type, device=dev) for _ in range(3))
     z2 = None if z is None else _abi.dev_tensor(z.reshape(T, R).contiguous(), "z")
@@ -98,6 +99,7 @@ def _param_desc(layer, dense_state=None):
     b.q_mu, b.q_sqrt = q_mu.data_ptr(), q_sqrt.data_ptr()
     b.variance, b.variance_dev = kern.desc_variance()
     b.M, b.D, b.R, b.kern_type = M, Z.shape[1], R, kern.kern_type
+    b.P = layer.kern.W.shape[0] if isinstance(layer.kern, SharedMixedMok) else R
     return b, [Z, q_mu, q_sqrt]
 
 

@@ -1081,10 +1081,11 @@ __global__ __launch_bounds__(512) void k_bw_chain(ChainArgs a) {
     if (a.dbg_exit == 2) return;
 
     // ---- phase 2: dk(bi) = sum_{bk >= bi} Lm^-T(bi, bk) da(bk); row-blocks paired so that every wave streams nbk + 1 blocks
+    const int npair = (nbk + 1) / 2, nw2 = nbk <= 8 ? 4 : 8;         // (nbk <= 8: four pairs at most, waves 4-7 sit this short phase out)
+    for (int p_ = wave; p_ < npair && wave < nw2; p_ += nw2)
     for (int pass = 0; pass < 2; ++pass) {
-        const int bi = pass == 0 ? wave : nbk - 1 - wave;
-        if (wave >= 4 || bi < 0 || bi >= nbk) continue;         // (waves 4-7 sit this short phase out)
-        if (pass == 0 ? (wave > nbk - 1 - wave) : (nbk - 1 - wave <= wave)) continue;      // each row-block exactly once
+        const int bi = pass == 0 ? p_ : nbk - 1 - p_;
+        if (pass == 1 && bi <= p_) continue;                    // (the middle row-block of an odd nbk: once)
         bw_gptr4 Pb = (bw_gptr4)a.LinvTP + (size_t)tri_upper_off(nbk, bi) * 64 + lane;
         const int nblocks = nbk - bi;
         f32x4 acc[NS];
@@ -1235,7 +1236,7 @@ __global__ __launch_bounds__(512) void k_bw_chain(ChainArgs a) {
 // One workgroup per 16x16 block, one thread per entry (M^3 R flops in all: negligible, latency-bound, off the critical path).
 __global__ __launch_bounds__(256) void k_pack_bw(const float* __restrict__ q_sqrt, const double* __restrict__ Linv64, int Mp, int M, int R, int nbk,
                                                  float* __restrict__ SP, float* __restrict__ LinvTP) {
-    __shared__ float Ls[2][16][129];                         // the 16 rows of L_r of row-block bi / bk, columns 0 .. 16 min(bi, bk) + 15
+    __shared__ float Ls[2][16][129];                         // the 16 rows of L_r of row-block bi / bk, 128 columns at a time
     const int i = threadIdx.x >> 4, k = threadIdx.x & 15;
     const int off = (16 * (k >> 2) + i) * 4 + (k & 3);       // A-fragment order: lane 16g + i holds G[i][4g + s]
     int b = blockIdx.x;
@@ -1244,14 +1245,18 @@ __global__ __launch_bounds__(256) void k_pack_bw(const float* __restrict__ q_sqr
         const int bi = b / (R * nbk), r = (b / nbk) % R, bk = b % nbk;
         const int bm = bi < bk ? bi : bk, ncol = 16 * bm + 16;
         const float* Lr = q_sqrt + (size_t)r * M * M;
-        for (int idx = threadIdx.x; idx < 16 * ncol; idx += 256) {
-            const int rr = idx / ncol, c = idx - rr * ncol;
-            Ls[0][rr][c] = (c <= 16 * bi + rr) ? Lr[(size_t)(16 * bi + rr) * M + c] : 0.f;     // tril: zero above the diagonal
-            Ls[1][rr][c] = (c <= 16 * bk + rr) ? Lr[(size_t)(16 * bk + rr) * M + c] : 0.f;
-        }
-        __syncthreads();
         float acc = 0.f;
-        for (int j = 0; j < ncol; ++j) acc = fmaf(Ls[0][i][j], Ls[1][k][j], acc);
+        for (int c0 = 0; c0 < ncol; c0 += 128) {
+            const int nc = ncol - c0 < 128 ? ncol - c0 : 128;
+            if (c0) __syncthreads();
+            for (int idx = threadIdx.x; idx < 16 * nc; idx += 256) {
+                const int rr = idx / nc, c = c0 + idx - rr * nc;
+                Ls[0][rr][c - c0] = (c <= 16 * bi + rr) ? Lr[(size_t)(16 * bi + rr) * M + c] : 0.f;     // tril: zero above the diagonal
+                Ls[1][rr][c - c0] = (c <= 16 * bk + rr) ? Lr[(size_t)(16 * bk + rr) * M + c] : 0.f;
+            }
+            __syncthreads();
+            for (int j = 0; j < nc; ++j) acc = fmaf(Ls[0][i][j], Ls[1][k][j], acc);
+        }
         SP[(size_t)b * 256 + off] = acc;
         return;
     }
@@ -1261,19 +1266,35 @@ __global__ __launch_bounds__(256) void k_pack_bw(const float* __restrict__ q_sqr
     const int bk = bi + b;
     LinvTP[((size_t)tri_upper_off(nbk, bi) + (bk - bi)) * 256 + off] = (float)Linv64[(size_t)(16 * bk + k) * Mp + 16 * bi + i];
 }
-static int chain_ns(long long T) {                          // samples per workgroup / 16: as the forward's, then down to a divisor of T
+static int chain_ns(long long T, int M = 128) {             // samples per workgroup / 16: as the forward's, then down to a divisor of T
     int ns = (int)((T + 16 * 256 - 1) / (16 * 256));
-    if (ns > 5) ns = 5;
+    const int cap = M <= 128 ? 5 : (M <= 256 ? 2 : 1);      // three [M x 16 NS] float tiles in 160 KB of LDS
+    if (ns > cap) ns = cap;
     if (ns < 1) ns = 1;
     while (ns > 1 && T % (16 * ns)) --ns;
     return ns;
 }
 static bool chain_ok(int M, int Mp, long long T) {
-    return Mp == M && M <= 128 && (T % 16) == 0 && !getenv("IWVI_BW_UNFUSED") && !getenv("IWVI_BW_OLD_CHAIN");
+    // M <= 256: at M = 512 only 16 samples fit a workgroup's three tiles, so every packed S_r block (R * 32 * 32 KiB per layer)
+    // would be fetched from L2 for 4 MFMAs -- measured 383 ms per value + gradient at configs[4] against 359 ms on the GEMM path
+    return Mp == M && M <= 256 && (T % 16) == 0 && !getenv("IWVI_BW_UNFUSED") && !getenv("IWVI_BW_OLD_CHAIN") &&
+           !(M > 128 && getenv("IWVI_BW_CHAIN_SMALL_M_ONLY"));
 }
+// LDS bytes of k_bw_chain for a layer shape (the one formula: launch, path selection and iwvi_gp_layer_backward_needs_u use it)
+static size_t chain_lds_bytes(long long T, int M, int D, int R, int P) {
+    const int NSAMP = 16 * chain_ns(T, M), DM = D <= 8 ? 8 : (D <= 16 ? 16 : 32);
+    int dsz = NSAMP * M;
+    const int heads = 3 * NSAMP * P + P * R + 4 * NSAMP * R + D * P, adj = M * DM;
+    if (heads > dsz) dsz = heads;
+    if (adj > dsz) dsz = adj;
+    dsz = (dsz + 3) & ~3;
+    return sizeof(float) * ((size_t)2 * NSAMP * M + (size_t)dsz + (size_t)M * R + (size_t)NSAMP * (2 * R + 1) + (size_t)NSAMP * D
+                            + (size_t)NSAMP * DM + DM + (size_t)NSAMP * (D + 2));
+}
+static bool chain_fits(long long T, int M, int Mp, int D, int R, int P) { return chain_ok(M, Mp, T) && chain_lds_bytes(T, M, D, R, P) <= 160 * 1024; }
 // the two M x M products over samples inside the chain kernel: only while the number of per-workgroup shares stays moderate
 static bool chain_products_ok(int M, long long T) {
-    return chain_ok(M, round_up(M, 16), T) && T / (16 * chain_ns(T)) <= 1024 && !getenv("IWVI_BW_GEMM_PRODUCTS");
+    return chain_ok(M, round_up(M, 16), T) && M <= 128 && T / (16 * chain_ns(T, M)) <= 1024 && !getenv("IWVI_BW_GEMM_PRODUCTS");
 }
 template <int NS>
 static int launch_chain_ns(hipStream_t st, ChainArgs a) {
@@ -1288,12 +1309,10 @@ static int launch_chain_ns(hipStream_t st, ChainArgs a) {
                                         + (size_t)NSAMP * DM + DM + (size_t)NSAMP * (a.D + 2));
     static bool done = false;
     if (!done) {
-        const size_t most = sizeof(float) * ((size_t)NSAMP * 256 + (size_t)(NSAMP * 128 > 3 * NSAMP * IWVI_MAX_P + IWVI_MAX_P * IWVI_MAX_R + 2 * NSAMP * IWVI_MAX_R + IWVI_MAX_D * IWVI_MAX_P
-                                                                            ? NSAMP * 128 : 3 * NSAMP * IWVI_MAX_P + IWVI_MAX_P * IWVI_MAX_R + 2 * NSAMP * IWVI_MAX_R + IWVI_MAX_D * IWVI_MAX_P)
-                                             + 128 * 32 + 32 + 128 * IWVI_MAX_R + NSAMP * (4 * IWVI_MAX_R + 1) + NSAMP * IWVI_MAX_D + NSAMP * 32 + 32 + NSAMP * (IWVI_MAX_D + 2));
+        const size_t most = 160 * 1024;
         const void* fns[] = {(const void*)k_bw_chain<NS, 8>, (const void*)k_bw_chain<NS, 16>, (const void*)k_bw_chain<NS, 32>};
         for (const void* f : fns)
-            if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(most < 160 * 1024 ? most : 160 * 1024)) != hipSuccess) { set_error("hipFuncSetAttribute(k_bw_chain)"); return IWVI_ERR_LAUNCH; }
+            if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)most) != hipSuccess) { set_error("hipFuncSetAttribute(k_bw_chain)"); return IWVI_ERR_LAUNCH; }
         done = true;
     }
     if (lds > 160 * 1024) { set_error("k_bw_chain: %zu B of LDS", lds); return IWVI_ERR_UNSUPPORTED; }
@@ -1304,7 +1323,7 @@ static int launch_chain_ns(hipStream_t st, ChainArgs a) {
     return check_launch("k_bw_chain");
 }
 static int launch_chain(hipStream_t st, const ChainArgs& a) {
-    switch (chain_ns(a.T)) {
+    switch (chain_ns(a.T, a.M)) {
         case 1: return launch_chain_ns<1>(st, a);
         case 2: return launch_chain_ns<2>(st, a);
         case 3: return launch_chain_ns<3>(st, a);
@@ -1525,8 +1544,12 @@ static BwdWs bwd_layout(char* base, long long T, int M, int D, int R) {
     w.Qx = (float*)take(sizeof(float) * T * (D + 2));
     w.part_floats = (size_t)nsplit * M * M * (R + 1);          // dLm + the R batched dL_r, parked together
     if (chain_products_ok(M, T)) {                               // the chain kernel's per-workgroup shares of dLm and G_r instead
-        const size_t need = (size_t)(T / (16 * chain_ns(T))) * M * M * (R + 1);
+        const size_t need = (size_t)(T / (16 * chain_ns(T, M))) * M * M * (R + 1);
         if (need > w.part_floats) w.part_floats = need;
+    }
+    if (chain_ok(M, round_up(M, 16), T)) {                        // + its per-workgroup shares of the thin sums
+        const size_t S = (size_t)(T / (16 * chain_ns(T, M)));
+        w.part_floats += S * ((size_t)M * (R + D + 1) + D + 2 + 3 * (size_t)IWVI_MAX_P * R + 2 * (size_t)D * IWVI_MAX_P) + 64 * 8;
     }
     {   // thin reductions: ceil(T / THIN_ROWS) chunks of at most [max(M, 34)][33]
         const size_t thin = (size_t)((T + (long long)THIN_ROWS * thin_chunks(T) - 1) / ((long long)THIN_ROWS * thin_chunks(T))) * (M > 34 ? M : 34) * 33;
@@ -2003,6 +2026,11 @@ __global__ void k_inc_i64(long long* p) { if (threadIdx.x == 0 && blockIdx.x == 
 
 using namespace iwvi;
 
+extern "C" int iwvi_gp_layer_backward_needs_u(int64_t T, int M, int D, int R, int P) {
+    if (T <= 0 || M <= 0 || D <= 0 || R <= 0 || P <= 0) return 1;
+    return chain_fits(T, M, round_up(M, 16), D, R, P) ? 0 : 1;
+}
+
 extern "C" size_t iwvi_gp_layer_backward_ws_bytes(int64_t T, int M, int D, int R) {
     if (T <= 0 || M <= 0 || D <= 0 || R <= 0) return 0;
     return bwd_layout(nullptr, T, M, D, R).bytes;
@@ -2025,7 +2053,7 @@ extern "C" int iwvi_gp_layer_backward_prepare(const iwvi_gp_bwd_desc* dp, int64_
     BwdWs w = bwd_layout((char*)ws_, T, M, D, R);
     const int n = M * M > M * D ? M * M : M * D;
     hipLaunchKernelGGL(k_prep, dim3((n + 255) / 256), dim3(256), 0, st, d.Z, d.lengthscales, Linv64, Mp, w.Zt, w.invls, w.LinvF, M, D);
-    if (chain_ok(M, Mp, T)) {
+    if (chain_fits(T, M, Mp, D, R, d.P > 0 ? d.P : R)) {
         const int nbk = Mp / 16;
         hipLaunchKernelGGL(k_pack_bw, dim3((unsigned)(R * nbk * nbk + tri_blocks(nbk))), dim3(256), 0, st, d.q_sqrt, Linv64, Mp, M, R, nbk, w.SP, w.LinvTP);
     }
@@ -2057,13 +2085,13 @@ extern "C" int iwvi_gp_layer_backward(const iwvi_gp_bwd_desc* dp, int64_t T, voi
     // deferred reductions of this layer: every product over samples parks its partial sums in its own slice of the workspace
     const bool prod = d.GMV && chain_products_ok(M, T);    // dLm and G_r shares come out of the chain kernel
     size_t partA = (size_t)((T + splitk_chunk(T) - 1) / splitk_chunk(T) + 2) * M * M;
-    if (prod && (size_t)(T / (16 * chain_ns(T))) * M * M > partA) partA = (size_t)(T / (16 * chain_ns(T))) * M * M;
+    if (prod && (size_t)(T / (16 * chain_ns(T, M))) * M * M > partA) partA = (size_t)(T / (16 * chain_ns(T, M))) * M * M;
     const bool two_q = d.side_stream && d.side_stream2 && d.side_stream2 != d.side_stream;
     ReduceQueue rqA(w.part, two_q ? partA : 0), rqB(w.part + (two_q ? partA : 0), w.part_floats - (two_q ? partA : 0));
     float* s[3] = {nullptr, nullptr, nullptr}; float* a12[2] = {nullptr, nullptr};
     const bool lin_on = (d.dW && d.W) || (d.dmf_A && d.mf_type == IWVI_MF_LINEAR);
     // streaming chain (no saved u_r): M a multiple of 16 up to 128, T a multiple of 64, the forward's gmv block at hand
-    const bool chain = d.GMV && chain_ok(M, Mp, T);
+    const bool chain = d.GMV && chain_fits(T, M, Mp, D, R, d.P);
     if (!chain && !d.U) { set_error("iwvi_gp_layer_backward: this shape (M=%d, T=%lld) takes the GEMM path, which needs the forward's u_out", M, (long long)T); return IWVI_ERR_ARG; }
     if (chain) {
         const int nbk = Mp / 16;
@@ -2071,7 +2099,7 @@ extern "C" int iwvi_gp_layer_backward(const iwvi_gp_bwd_desc* dp, int64_t T, voi
                      d.A, Mp, d.q_mu, w.SP, w.LinvTP, w.DK, d.F, w.Zt, w.invls, w.DA, w.Qx, (long long)T, M, D, R, nbk, d.variance, d.kern_type,
                      getenv("IWVI_CHAIN_EXIT") ? atoi(getenv("IWVI_CHAIN_EXIT")) : 0, d.variance_dev};
         // the thin sums over samples ride in the chain kernel: one partial per workgroup and job, summed with the rest of chain B
-        const int S = (int)(T / (16 * chain_ns(T))), P = d.P;
+        const int S = (int)(T / (16 * chain_ns(T, M))), P = d.P;
         auto job = [&](int Mj, int Nj, float* out, const float* add, double add_coef) -> float* {
             float* pp = rqB.take((size_t)S * Mj * Nj);
             if (!pp) return nullptr;

@@ -181,7 +181,7 @@ class DGP_VI:
                         Mp = layer.state().Mp
                         o["a_out"] = torch.empty(T, Mp, dtype=settings.float_type, device=dev)
                         from .backward import needs_saved_u
-                        if needs_saved_u(layer.num_inducing, T):     # only the GEMM path of the adjoint reads u_r = L_r^T a
+                        if needs_saved_u(layer, T):     # only the GEMM path of the adjoint reads u_r = L_r^T a
                             o["u_out"] = torch.empty(R, T, Mp, dtype=settings.float_type, device=dev)
                         o["noise_out"] = torch.empty(T, R, dtype=settings.float_type, device=dev)
                         o["gmv_out"] = torch.empty(T, 3 * R, dtype=settings.float_type, device=dev)

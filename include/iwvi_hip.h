@@ -270,7 +270,7 @@ int iwvi_dgp_forward(const iwvi_layer_desc* layers_host, int n_layers,
  *   F [T, D]               the layer's input rows (per sample)
  *   noise [T, R]           the draws the forward used (needed when d_sample is given)
  *   A [T, Mp], U [R, T, Mp]  a = Lm^-1 k and u_r = L_r^T a as the forward wrote them (a_out / u_out).  U may be NULL when
- *                          M is a multiple of 16 up to 128, T a multiple of 16 and GMV is given: that shape takes the streaming
+ *                          M is a multiple of 16 up to 256, T a multiple of 16 and GMV is given: that shape takes the streaming
  *                          chain, which works from a alone (sum_r 2dv_r L_r u_r = sum_r 2dv_r (L_r L_r^T) a, dL_r = tril(G_r L_r))
  *   GMV [T, 3R]            optional, the forward's gmv_out
  *   d_sample/d_mean/d_var [T, P]  upstream gradients, any may be NULL (= 0)
@@ -300,6 +300,9 @@ typedef struct iwvi_gp_bwd_desc {
     const float* variance_dev;      /* optional device scalar read instead of `variance` (see iwvi_gp_desc) */
 } iwvi_gp_bwd_desc;
 size_t iwvi_gp_layer_backward_ws_bytes(int64_t T, int M, int D, int R);
+/* 1 if the adjoint of this layer shape takes the GEMM path and therefore needs the forward's u_out, 0 if the streaming chain
+ * (which works from a_out alone) will run */
+int iwvi_gp_layer_backward_needs_u(int64_t T, int M, int D, int R, int P);
 /* the parameter-only part of the adjoint (scaled inducing inputs, float32 Lm^-1, the streaming chain's packed operands
  * S_r = L_r L_r^T and Lm^-T): reads state (dense factors), Z, lengthscales, q_sqrt, M / D / R of the descriptor only, so it can
  * be queued on another stream beside the forward; then set desc.prepared.  Called implicitly otherwise. */
