@@ -394,11 +394,12 @@ def main():
 
     # HBM bytes per launch of the dominant kernel from the committed PMC profile of this very workload (the counters
     # need their own rocprofv3 passes and cannot be read live); null for any other workload
-    traffic, traffic_src = None, None
+    traffic, traffic_src, pmc = None, None, {}
     try:
         tj = json.load(open(os.path.join(ROOT, "profiles", "traffic_latest.json")))
         if args.config == 2 and world == 1:
             traffic, traffic_src = tj["hbm_bytes"], tj["source"]
+            pmc = {k: tj[k] for k in ("mfma_busy_frac", "mfma_issued_tflops", "kernel_avg_us_rocprof") if k in tj}
     except Exception:
         pass
     if rank == 0:
@@ -420,7 +421,7 @@ def main():
             "roofline": {"bound": "mfma", "kernel": "k_dgp_forward (all layers fused, one launch per ELBO evaluation)", "achieved": achieved / 1e12,
                          "peak": PEAK_MFMA_F32 / 1e12, "unit": "TFLOP/s", "frac": achieved / PEAK_MFMA_F32,
                          "traffic": traffic, "traffic_source": traffic_src, "launch_ms": dom_ms,
-                         "flops_per_launch": dom_flops},
+                         "flops_per_launch": dom_flops, **pmc},
         }
         res["model_frac_of_mfma_peak"] = res["value"] / world * tot_flops / PEAK_MFMA_F32
         if med is not None:
