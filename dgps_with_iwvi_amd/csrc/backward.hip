@@ -1866,11 +1866,21 @@ __global__ __launch_bounds__(256) void k_tri_inv_small(const double* L, double* 
     // L's lower blocks staged in LDS first (same block layout, identity padding): element reads from global memory inside the
     // substitution loops were a chain of dependent L2 round trips (~100 us for n = 128)
     double* ls = xs + (size_t)(nb * (nb + 1) / 2) * 256;
-    for (int idx = tid; idx < (nb * (nb + 1) / 2) * 256; idx += 256) {
-        const int b = idx >> 8, e = idx & 255;
-        int bi = 0; while ((bi + 1) * (bi + 2) / 2 <= b) ++bi;
-        const int bj = b - bi * (bi + 1) / 2, r = 16 * bi + (e >> 4), c = 16 * bj + (e & 15);
-        ls[idx] = (r < n && c < n) ? L[(size_t)r * n + c] : (r == c ? 1.0 : 0.0);
+    {   // one element of every block per thread, eight blocks' loads in flight at a time (one load per iteration is a chain of
+        // ~36 L2 round trips: most of this kernel's 66 us before)
+        const int nblk = nb * (nb + 1) / 2, er = tid >> 4, ec = tid & 15;
+        for (int b0 = 0; b0 < nblk; b0 += 8) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int b = (b0 + u < nblk) ? b0 + u : nblk - 1;
+                int bi = 0; while ((bi + 1) * (bi + 2) / 2 <= b) ++bi;
+                const int bj = b - bi * (bi + 1) / 2, r = 16 * bi + er, c = 16 * bj + ec;
+                v[u] = (r < n && c < n) ? L[(size_t)r * n + c] : (r == c ? 1.0 : 0.0);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) if (b0 + u < nblk) ls[(size_t)(b0 + u) * 256 + tid] = v[u];
+        }
     }
     __syncthreads();
     auto Lel = [&](int r, int c) { return ls[(size_t)((r >> 4) * ((r >> 4) + 1) / 2 + (c >> 4)) * 256 + (r & 15) * 16 + (c & 15)]; };
@@ -1891,32 +1901,31 @@ __global__ __launch_bounds__(256) void k_tri_inv_small(const double* L, double* 
         }
     }
     __syncthreads();
+    // off-diagonal blocks by v_mfma_f64_16x16x4_f64 (lane l feeds A[l & 15][4kk + (l >> 4)] and B[4kk + (l >> 4)][l & 15]; accumulator
+    // register e of lane l is C[(l >> 4) + 4e][l & 15]): a 16^3 block product is 4 MFMAs instead of a serial 16 x 4 fma loop per lane
+    // (the block diagonals late in the sweep were chains of ~100 dependent LDS round trips per block: 66 us at n = 128)
+    auto lblk = [&](int i, int j) { return ls + (size_t)(i * (i + 1) / 2 + j) * 256; };
+    const int mr = lane & 15, mg = lane >> 4;
     for (int d = 1; d < nb; ++d) {
         for (int i = d + wave; i < nb; i += 4) {
             const int j = i - d;
-            // T = sum_k L(i, k) X(k, j), k = j .. i-1   (4 outputs per lane: rows 4*(lane/16)+v, column lane%16)
-            double t[4] = {0.0, 0.0, 0.0, 0.0};
-            const int c = lane & 15, r0 = 4 * (lane >> 4);
+            // T = sum_k L(i, k) X(k, j), k = j .. i-1
+            bw_f64x4 t = {0.0, 0.0, 0.0, 0.0};
             for (int k = j; k < i; ++k) {
-                const double* xk = blk(k, j);
-                for (int q = 0; q < 16; ++q) {
-                    const double xv = xk[q * 16 + c];
+                const double* A = lblk(i, k); const double* B = blk(k, j);
 #pragma unroll
-                    for (int v = 0; v < 4; ++v) t[v] = fma(Lel(16 * i + r0 + v, 16 * k + q), xv, t[v]);
-                }
+                for (int kk = 0; kk < 4; ++kk) t = __builtin_amdgcn_mfma_f64_16x16x4f64(A[mr * 16 + 4 * kk + mg], B[(4 * kk + mg) * 16 + mr], t, 0, 0, 0);
             }
 #pragma unroll
-            for (int v = 0; v < 4; ++v) scratch[(r0 + v) * 16 + c] = t[v];
+            for (int e = 0; e < 4; ++e) scratch[(mg + 4 * e) * 16 + mr] = t[e];
             __builtin_amdgcn_wave_barrier();
-            double o[4] = {0.0, 0.0, 0.0, 0.0};
+            // X(i, j) = -X(i, i) T
+            bw_f64x4 o = {0.0, 0.0, 0.0, 0.0};
             const double* xi = blk(i, i);
-            for (int q = 0; q < 16; ++q) {
-                const double tv = scratch[q * 16 + c];
 #pragma unroll
-                for (int v = 0; v < 4; ++v) o[v] = fma(-xi[(r0 + v) * 16 + q], tv, o[v]);
-            }
+            for (int kk = 0; kk < 4; ++kk) o = __builtin_amdgcn_mfma_f64_16x16x4f64(-xi[mr * 16 + 4 * kk + mg], scratch[(4 * kk + mg) * 16 + mr], o, 0, 0, 0);
 #pragma unroll
-            for (int v = 0; v < 4; ++v) blk(i, j)[(r0 + v) * 16 + c] = o[v];
+            for (int e = 0; e < 4; ++e) blk(i, j)[(mg + 4 * e) * 16 + mr] = o[e];
             __builtin_amdgcn_wave_barrier();
         }
         __syncthreads();
