@@ -73,6 +73,23 @@ def test_bench_single_rank_line_has_the_contract_fields(gpu_device):
     assert r["bound"] == "mfma" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
 
 
+@pytest.mark.parametrize("shard", ["k", "n"])
+def test_bench_exchange_path_on_a_real_rccl_communicator(gpu_device, shard):
+    """The multi-GPU code path of bench.py -- per-slot hipGraphs, OverlappedExchange on a side stream, iwvi_lse_merge_steps /
+    all-reduce -- on a 1-rank **RCCL** ("nccl") communicator (IWVI_BENCH_FORCE_XCH=1): what an 8-GPU launch runs, minus the peers."""
+    port = _free_port()
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+               IWVI_BENCH_FORCE_XCH="1", IWVI_BENCH_BACKEND="nccl", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "50", "--warmup", "5", "--shard", shard, "--check",
+           "--no-cpu-baseline", "--no-train-leg", "--median-iters", "0"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, cwd=ROOT, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    res = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
+    assert "one exchange per replay" in res["config"]["launch"] and res["n_ranks_seen"] == 1
+    assert res["check"]["all_steps_equal"] and res["check"]["rel_diff"] <= 2e-6, res["check"]
+    assert np.isfinite(res["elbo"]) and res["value"] > 1e7      # (a sanity floor: > 10 M samples/s through the exchange path)
+
+
 def test_overlapped_exchange_slot_reuse(gpu_device):
     """depth-2 staging ring, 7 submits of 3 evaluations each on a 1-rank RCCL communicator: every exchanged slot returns
     the ELBOs of exactly the evaluations written into it (no slot is overwritten while its exchange is still reading it)."""
