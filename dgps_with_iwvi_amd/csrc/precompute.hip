@@ -47,7 +47,7 @@ struct PreEnc {
     float* sample_X; float* sample_kl; float* sample_z;
 };
 constexpr int PRE_MAX_ENC = 2;
-struct PreArgs { PreLayer L[IWVI_MAX_LAYERS]; int n; int stop_after; unsigned long long* stamps; PreEnc E[PRE_MAX_ENC]; int n_enc; };
+struct PreArgs { PreLayer L[IWVI_MAX_LAYERS]; int n; int stop_after; int stamp_p; unsigned long long* stamps; PreEnc E[PRE_MAX_ENC]; int n_enc; };
 
 static unsigned long long* g_pre_stamps = nullptr;   // diagnostic; see iwvi_debug_set_pre_stamps
 #define PRE_STAMP(k) do { if (stamps && threadIdx.x == 0) stamps[(size_t)blockIdx.x * 16 + (k)] = wall_clock64(); } while (0)
@@ -248,19 +248,20 @@ __device__ __forceinline__ void blk_store(double* C, const f64x4& v, int lane) {
 // Two barriers per step; no trailing update ever sits on the critical path.
 template <class GEN, class POST, class TAIL>
 __device__ __forceinline__ void chol_blocks(double* blk, int nbk, double* rinv, double* xT, int tid, int nthreads, GEN gen, POST post, TAIL tail,
-                                            unsigned long long* stamps = nullptr) {
+                                            unsigned long long* stamps = nullptr, int stamp_p = 1) {
     const int lane = tid & 63, wave = tid >> 6, nw = nthreads >> 6;
     gen(0, nbk < 2 ? 1 : 2, wave, nw);
     __syncthreads();
+    PRE_STAMP(7);
     for (int p = 0; p < nbk; ++p) {
         const int m = nbk - 1 - p;                       // block rows below the diagonal block
         const int win = m < 2 ? m : 2;                   // of which the factoring wave carries this many
-        if (p == 1) PRE_STAMP(10);
+        if (p == stamp_p) PRE_STAMP(10);
         if (wave == 0) {
             __builtin_amdgcn_s_setprio(3);               // the serial pass is the critical path: its LDS traffic goes first
-            diag_factor_window(blk, p, win, xT + (size_t)p * BLK, rinv + NB * p, lane, (stamps && p == 1) ? stamps + (size_t)blockIdx.x * 16 : nullptr);
+            diag_factor_window(blk, p, win, xT + (size_t)p * BLK, rinv + NB * p, lane, (stamps && p == stamp_p) ? stamps + (size_t)blockIdx.x * 16 : nullptr);
             __builtin_amdgcn_s_setprio(0);
-            if (p == 1) PRE_STAMP(11);
+            if (p == stamp_p) PRE_STAMP(11);
         } else if ((wave & 3) != 0 || nw < 8) {
             // the workers: every wave that does not share wave 0's SIMD (waves 4, 8, .. would slow the serial pass down)
             const int w = (nw < 8) ? wave - 1 : wave - 1 - (wave >> 2), nwo = (nw < 8) ? nw - 1 : nw - (nw >> 2);
@@ -281,7 +282,7 @@ __device__ __forceinline__ void chol_blocks(double* blk, int nbk, double* rinv, 
             if (p == nbk - 1) tail(w * 64 + lane, nwo * 64);     // work nobody waits for, beside the last (otherwise idle) pass
         }
         __syncthreads();
-        if (p == 1) PRE_STAMP(12);
+        if (p == stamp_p) PRE_STAMP(12);
         // block rows below: finish column p (rows beyond the window) and bring column p+1 up to date with it
         for (int b = wave; b < m; b += nw) {
             const int bi = p + 1 + b;
@@ -297,7 +298,7 @@ __device__ __forceinline__ void chol_blocks(double* blk, int nbk, double* rinv, 
             blk_store(C, acc, lane);
         }
         if (m > 0) __syncthreads();
-        if (p == 1) PRE_STAMP(13);
+        if (p == stamp_p) PRE_STAMP(13);
     }
     post(nbk - 1, tid, nthreads);                        // the last column (everyone)
     __syncthreads();
@@ -355,7 +356,7 @@ __device__ __forceinline__ double inv_get(const double* blk, const double* dinv,
 }
 
 template <bool IN_LDS>
-__device__ void role_factor(const PreLayer& Lin, int stop_after, unsigned long long* stamps) {
+__device__ void role_factor(const PreLayer& Lin, int stop_after, unsigned long long* stamps, int stamp_p) {
     PreLayer L = Lin;
     if (L.variance_dev) L.variance = *L.variance_dev;        // a device-resident (trained) kernel variance
     PRE_STAMP(0);
@@ -515,7 +516,7 @@ __device__ void role_factor(const PreLayer& Lin, int stop_after, unsigned long l
             dst[it] = make_float4(v[0], v[1], v[2], v[3]);
         }
     };
-    chol_blocks(blk, nbk, rinv, dinv, tid, nthreads, gen, post, tail, stamps);
+    chol_blocks(blk, nbk, rinv, dinv, tid, nthreads, gen, post, tail, stamps, stamp_p);
     PRE_STAMP(3);
     if (stop_after == 3 || stop_after > 30) return;
     PRE_STAMP(4);
@@ -738,7 +739,7 @@ __global__ __launch_bounds__(1024) void k_precompute(PreArgs args) {
     const PreLayer& L = args.L[blockIdx.x];
     const int role = blockIdx.y;
     if (role == 0) {
-        if (L.Mp <= 128) role_factor<true>(L, args.stop_after, args.stamps); else role_factor<false>(L, args.stop_after, args.stamps);
+        if (L.Mp <= 128) role_factor<true>(L, args.stop_after, args.stamps, args.stamp_p); else role_factor<false>(L, args.stop_after, args.stamps, args.stamp_p);
     } else if (role <= L.R) {
         role_pack_r(L, role - 1, reinterpret_cast<double*>(smem_raw));
     }
@@ -843,6 +844,7 @@ extern "C" int iwvi_model_precompute(const iwvi_gp_desc* layers, int n_layers, c
         a.n = n_layers - base < IWVI_MAX_LAYERS ? n_layers - base : IWVI_MAX_LAYERS;
         { const char* e = getenv("IWVI_DEBUG_STOP"); a.stop_after = e ? atoi(e) : 0; }
         a.stamps = g_pre_stamps;
+        { const char* e = g_pre_stamps ? getenv("IWVI_PRE_STAMP_P") : nullptr; a.stamp_p = e ? atoi(e) : 1; }
         size_t lds = 1024 * sizeof(double);
         int max_roles = 0;
         for (int l = 0; l < a.n; ++l) {
