@@ -130,9 +130,10 @@ def prepare_side(model, T, stream):
 
 
 def gp_backward(layer, saved, d_sample=None, d_mean=None, d_var=None, kl_weight=1.0, want_dF=True, side_stream=None, keep=None,
-                side_stream2=None, prepared=None):
+                side_stream2=None, prepared=None, q_only=False):
     """``iwvi_gp_layer_backward``: upstream gradients [T, P] -> dict(dF [T, D], dZ, dls, dvariance, dq_mu, dq_sqrt).
-    ``prepared`` = (workspace, dense state) from ``prepare_side``."""
+    ``prepared`` = (workspace, dense state) from ``prepare_side``.  ``q_only``: dict(dq_mu, dq_sqrt) alone -- the library then
+    skips everything those two do not need (no prepared operands, no dense factors)."""
     dev = saved.F.device
     T, D = saved.F.shape
     M, R = layer.num_inducing, layer.num_outputs
@@ -140,15 +141,16 @@ def gp_backward(layer, saved, d_sample=None, d_mean=None, d_var=None, kl_weight=
     W = _abi.dev_tensor(layer.kern.W, "W") if isinstance(layer.kern, SharedMixedMok) else None
     P = W.shape[0] if W is not None else R
     ft = settings.float_type
-    out = dict(dZ=torch.empty(M, D, dtype=ft, device=dev), dls=torch.empty(D, dtype=ft, device=dev),
-               dvariance=torch.empty(1, dtype=ft, device=dev), dq_mu=torch.empty(M, R, dtype=ft, device=dev),
-               dq_sqrt=torch.empty(R, M, M, dtype=ft, device=dev))
-    if want_dF:
-        out["dF"] = torch.empty(T, D, dtype=ft, device=dev)
-    if W is not None:
-        out["dW"] = torch.empty(P, R, dtype=ft, device=dev)
-    if layer.mean_function.mf_type == _abi.MF_LINEAR:
-        out["dmf_A"] = torch.empty(D, P, dtype=ft, device=dev)
+    out = dict(dq_mu=torch.empty(M, R, dtype=ft, device=dev), dq_sqrt=torch.empty(R, M, M, dtype=ft, device=dev))
+    if not q_only:
+        out.update(dZ=torch.empty(M, D, dtype=ft, device=dev), dls=torch.empty(D, dtype=ft, device=dev),
+                   dvariance=torch.empty(1, dtype=ft, device=dev))
+        if want_dF:
+            out["dF"] = torch.empty(T, D, dtype=ft, device=dev)
+        if W is not None:
+            out["dW"] = torch.empty(P, R, dtype=ft, device=dev)
+        if layer.mean_function.mf_type == _abi.MF_LINEAR:
+            out["dmf_A"] = torch.empty(D, P, dtype=ft, device=dev)
     b, keep_t = _param_desc(layer, prepared[1] if prepared else None)
     b.P = P
     b.prepared = 1 if prepared else 0
@@ -205,8 +207,11 @@ def lv_backward(layer, XY, enc_out, eps, dF_next, col0, w, B, K, sampled_kl=True
     return dW, db
 
 
-def iw_elbo_and_gradients(model, zs=None, mode_vi=None, exchange=None, K_total=None, kl_weight=1.0, overlap=True):
-    """``mode_vi`` (default: the model is a DGP_VI, not a DGP_IWVI): the bound of models.py:49-86 instead -- analytic
+def iw_elbo_and_gradients(model, zs=None, mode_vi=None, exchange=None, K_total=None, kl_weight=1.0, overlap=True, wrt="all"):
+    """``wrt="final_q"``: only the final layer's 'l<i>.q_mu' / 'l<i>.q_sqrt' (all that the natural-gradient op of
+    build_models.py:288-295 uses): same forward and bound, and of the adjoints only the final layer's two sums over samples.
+
+    ``mode_vi`` (default: the model is a DGP_VI, not a DGP_IWVI): the bound of models.py:49-86 instead -- analytic
     local KL, mean over the S samples; ``zs`` then in that model's layout [S*N, dim] (S-major tiling, models.py:50).
 
     K-sharded training (``sharding.k_shard_gradients``): ``exchange(ms [B, 2]) -> lse [B]`` turns this rank's per-point
@@ -251,8 +256,13 @@ def iw_elbo_and_gradients(model, zs=None, mode_vi=None, exchange=None, K_total=N
     import os
     if os.environ.get("IWVI_BW_SINGLE_STREAM"):                  # diagnostic: everything on the caller's stream
         overlap = False
-    prep_stream = _side_stream(dev, 2) if overlap else cur
-    prepared = prepare_side(model, T, prep_stream)
+    if wrt not in ("all", "final_q"):
+        raise ValueError("wrt is 'all' or 'final_q'")
+    final_q = wrt == "final_q"
+    if final_q and needs_saved_u(layers[-1], T):                 # (shapes off the streaming chain: the full adjoint gives the same two entries)
+        final_q = False
+    prep_stream = _side_stream(dev, 2) if (overlap and not final_q) else cur
+    prepared = {} if final_q else prepare_side(model, T, prep_stream)
     # forward: one factorisation launch (packed operands, encoders) + ONE fused layer launch that also leaves what the
     # adjoints need in HBM (a = Lm^-1 k, the draws, every layer's output rows)
     model.precompute(with_encoders=True)
@@ -302,12 +312,16 @@ def iw_elbo_and_gradients(model, zs=None, mode_vi=None, exchange=None, K_total=N
         glob_p, glob_n, len(glob), _abi.ptr(lse_g), int(K_total or K),
         ctypes.c_void_p(sums.data_ptr()), ctypes.c_void_p(ws.data_ptr()), _abi.stream_ptr()))
     grads = {"lik_var": sums[1]}
+    elbo = sums[2]                                               # scale * sum_n(...) - sum of the global KLs, formed on the device
+    if final_q:
+        i = len(layers) - 1
+        g = gp_backward(layers[i], fin, d_mean=d_mean, d_var=d_var, kl_weight=kl_weight, q_only=True)
+        return elbo, {"l%d.q_mu" % i: g["dq_mu"], "l%d.q_sqrt" % i: g["dq_sqrt"]}
     if prep_stream != cur:
         cur.wait_stream(prep_stream)                             # dense factors and packed adjoint operands are ready
     side = _side_stream(dev) if overlap else None
     side2 = _side_stream(dev, 1) if overlap else None
     held = []
-    elbo = sums[2]                                               # scale * sum_n(...) - sum of the global KLs, formed on the device
     dF = None
     for i in range(len(layers) - 1, -1, -1):
         layer, s = layers[i], saved[i]
@@ -334,6 +348,9 @@ def iw_elbo_and_gradients(model, zs=None, mode_vi=None, exchange=None, K_total=N
         cur.wait_stream(side)                                    # join: the parameter gradients are complete on the caller's stream
         cur.wait_stream(side2)
     del held
+    if wrt == "final_q":                                         # (a shape off the streaming chain: formed by the full adjoint above)
+        i = len(layers) - 1
+        grads = {k: grads[k] for k in ("l%d.q_mu" % i, "l%d.q_sqrt" % i)}
     return elbo, grads
 
 

@@ -916,6 +916,7 @@ struct ChainArgs {
     float* p_lm;                         // [S][M][M]      sum_j dk[m][j] a[n][j]                    -> dLm = -tril(.)   (reduced with alpha = -1)
     float* p_g;                          // [R][S][M][M]   sum_j 2dv_r[j] a[m][j] a[n][j]            -> G_r (dL_r = tril(G_r L_r))
     int S;                               // workgroups of the launch (stride of a batch in p_g)
+    int q_only;                          // only dq_mu / dq_sqrt are wanted (the natural-gradient op): heads, dq_mu shares, G_r shares
 };
 template <int NS, int DM>               // 16 NS samples per workgroup (8 waves);  D <= DM
 __global__ __launch_bounds__(512) void k_bw_chain(ChainArgs a) {
@@ -1030,9 +1031,10 @@ __global__ __launch_bounds__(512) void k_bw_chain(ChainArgs a) {
     }
     __syncthreads();
     if (a.dbg_exit == 1) return;
+    if (a.q_only && !a.p_g) return;                          // (G_r then comes from the split-K GEMM over the saved a rows)
 
     // ---- phase 1: da row-blocks bi = wave, wave + 4 -------------------------------------------------------------------
-    for (int bi = wave; bi < nbk; bi += 8) {
+    for (int bi = wave; bi < nbk && !a.q_only; bi += 8) {
         bw_gptr4 Pb = (bw_gptr4)a.SP + (size_t)bi * R * nbk * 64 + lane;      // this row-block's R * nbk blocks, contiguous
         const int nblocks = R * nbk;
         f32x4 tot[NS], acc[NS];
@@ -1082,7 +1084,7 @@ __global__ __launch_bounds__(512) void k_bw_chain(ChainArgs a) {
 
     // ---- phase 2: dk(bi) = sum_{bk >= bi} Lm^-T(bi, bk) da(bk); row-blocks paired so that every wave streams nbk + 1 blocks
     const int npair = (nbk + 1) / 2, nw2 = nbk <= 8 ? 4 : 8;         // (nbk <= 8: four pairs at most, waves 4-7 sit this short phase out)
-    for (int p_ = wave; p_ < npair && wave < nw2; p_ += nw2)
+    for (int p_ = wave; p_ < npair && wave < nw2 && !a.q_only; p_ += nw2)
     for (int pass = 0; pass < 2; ++pass) {
         const int bi = pass == 0 ? p_ : nbk - 1 - p_;
         if (pass == 1 && bi <= p_) continue;                    // (the middle row-block of an odd nbk: once)
@@ -1122,8 +1124,9 @@ __global__ __launch_bounds__(512) void k_bw_chain(ChainArgs a) {
     //      read once and reused for every bk <= bi.  Waves: row-block pair (w & 3, nbk-1-(w & 3)) x half of the 1 + R products.
     {
         const int pr = wave & 3, half = wave >> 2;
-        const int nit = R + 1, i_lo = half == 0 ? 0 : (nit + 1) / 2, i_hi = half == 0 ? (nit + 1) / 2 : nit;   // item 0 = dLm, 1 + r = G_r
-        for (int pass = 0; pass < 2 && a.p_lm; ++pass) {
+        const int it0 = a.p_lm ? 0 : 1, nit = R + 1 - it0;                                                     // item 0 = dLm, 1 + r = G_r
+        const int i_lo = it0 + (half == 0 ? 0 : (nit + 1) / 2), i_hi = it0 + (half == 0 ? (nit + 1) / 2 : nit);
+        for (int pass = 0; pass < 2 && (a.p_lm || a.p_g); ++pass) {
             const int bi = pass == 0 ? pr : nbk - 1 - pr;
             if (bi < 0 || bi >= nbk) continue;
             if (pass == 0 ? (pr > nbk - 1 - pr) : (nbk - 1 - pr <= pr)) continue;
@@ -1153,6 +1156,7 @@ __global__ __launch_bounds__(512) void k_bw_chain(ChainArgs a) {
             }
         }
     }
+    if (a.q_only) return;
     __syncthreads();                                         // phase 3 rewrites the dk tile
 
     // ---- phase 3: kernel adjoint (direct differences), 16 lanes per sample, 16 samples per round.  The scaled inducing inputs
@@ -2089,7 +2093,11 @@ extern "C" int iwvi_gp_layer_backward(const iwvi_gp_bwd_desc* dp, int64_t T, voi
     const double* Linv64 = (const double*)((const char*)d.state + sl.off_Linv);
     BwdWs w = bwd_layout((char*)ws_, T, M, D, R);
     int rc;
-    if (!d.prepared && (rc = iwvi_gp_layer_backward_prepare(dp, T, ws_, stream_)) != IWVI_OK) return rc;
+    // Only dq_mu / dq_sqrt asked for (the natural-gradient op, build_models.py:288-295, moves nothing else): on the streaming chain's
+    // shapes that is the heads + two sums over samples -- no da / dk, no kernel adjoint, no adjoint of the factorisation, and
+    // nothing of iwvi_gp_layer_backward_prepare (the state may then be the packed one: the dense factors are not read).
+    const bool q_only = !d.dZ && !d.dls && !d.dvariance && !d.dF && !d.dW && !d.dmf_A && d.GMV && chain_fits(T, M, Mp, D, R, d.P);
+    if (!q_only && !d.prepared && (rc = iwvi_gp_layer_backward_prepare(dp, T, ws_, stream_)) != IWVI_OK) return rc;
     const float* gmv = d.GMV ? d.GMV : w.GMV;
     // deferred reductions of this layer: every product over samples parks its partial sums in its own slice of the workspace
     const bool prod = d.GMV && chain_products_ok(M, T);    // dLm and G_r shares come out of the chain kernel
@@ -2117,17 +2125,19 @@ extern "C" int iwvi_gp_layer_backward(const iwvi_gp_bwd_desc* dp, int64_t T, voi
         };
         // (- kl_weight * dKL/dq_mu = - kl_weight * q_mu rides in the reduction; temp_workaround.py:186-188)
         ca.p_qmu = job(M, R, d.dq_mu ? d.dq_mu : w.DMU, d.dq_mu ? d.q_mu : nullptr, -d.kl_weight);
-        ca.p_ctf = job(M, D + 1, w.CtF1, nullptr, 0.0);
-        ca.p_q = job(D + 2, 1, w.Qsum, nullptr, 0.0);
+        ca.q_only = q_only ? 1 : 0;
+        if (!q_only) { ca.p_ctf = job(M, D + 1, w.CtF1, nullptr, 0.0); ca.p_q = job(D + 2, 1, w.Qsum, nullptr, 0.0); }
         if (d.dW && d.W) { ca.p_w = job(3 * P, R, w.lin, nullptr, 0.0); for (int i = 0; i < 3; ++i) s[i] = w.lin + (size_t)i * P * R; if (!ca.p_w) ca.p_qmu = nullptr; }
         if (d.dmf_A && d.mf_type == IWVI_MF_LINEAR) { ca.p_a = job(2 * D, P, w.lin + 3 * IWVI_MAX_P * IWVI_MAX_R, nullptr, 0.0); for (int i = 0; i < 2; ++i) a12[i] = w.lin + 3 * IWVI_MAX_P * IWVI_MAX_R + (size_t)i * D * P; if (!ca.p_a) ca.p_qmu = nullptr; }
-        if (!ca.p_qmu || !ca.p_ctf || !ca.p_q) { set_error("backward: workspace too small for the chain kernel's partial sums"); return IWVI_ERR_ARG; }
+        if (!ca.p_qmu || (!q_only && (!ca.p_ctf || !ca.p_q))) { set_error("backward: workspace too small for the chain kernel's partial sums"); return IWVI_ERR_ARG; }
         ca.S = S;
         if (prod) {                                        // dLm and G_r shares too: no DK / A round trip, no split-K launches
             ReduceQueue& qa = two_q ? rqA : rqB;
-            ca.p_lm = qa.take((size_t)S * M * M);
-            ReduceArgs rl{ca.p_lm, S, M, M, nullptr, w.Lbar, (long long)M, -1.0, 0.0, 1, 0, nullptr, 0.0, 0};
-            if (!ca.p_lm || !qa.push(rl, 1)) { set_error("backward: workspace too small for the chain kernel's dLm shares"); return IWVI_ERR_ARG; }
+            if (!q_only) {
+                ca.p_lm = qa.take((size_t)S * M * M);
+                ReduceArgs rl{ca.p_lm, S, M, M, nullptr, w.Lbar, (long long)M, -1.0, 0.0, 1, 0, nullptr, 0.0, 0};
+                if (!ca.p_lm || !qa.push(rl, 1)) { set_error("backward: workspace too small for the chain kernel's dLm shares"); return IWVI_ERR_ARG; }
+            }
             if (d.dq_sqrt) {
                 ca.p_g = rqB.take((size_t)R * S * M * M);
                 ReduceArgs rg{ca.p_g, S, M, M, w.G, nullptr, (long long)M, 1.0, 0.0, 1, (long long)M * M, nullptr, 0.0, 0};
@@ -2136,6 +2146,20 @@ extern "C" int iwvi_gp_layer_backward(const iwvi_gp_bwd_desc* dp, int64_t T, voi
             ca.DK = nullptr;
         }
         if ((rc = launch_chain(st, ca)) != IWVI_OK) return rc;
+        if (q_only) {                                      // the two reductions (+ G_r by split-K GEMM where the chain does not form it), then dL_r
+            if (d.dq_sqrt && !prod) {
+                GemmArgs q{};
+                q.A = d.A; q.a_sm = 1; q.a_sk = Mp; q.B = d.A; q.b_sk = Mp; q.b_sn = 1;
+                q.scale = w.DV2; q.s_stride = R; q.scale_on_k = 1; q.M = M; q.N = M; q.K = (int)T; q.tri_out = 1;
+                if ((rc = gemm(st, q, w.part, w.part_floats, w.G, nullptr, M, 1.0, 0.0, 1, R, 0, 1, (long long)M * M, &rqB)) != IWVI_OK) return rc;
+            }
+            if ((rc = rqB.flush(st)) != IWVI_OK) return rc;
+            if (d.dq_sqrt) {
+                hipLaunchKernelGGL(k_gl_tril, dim3((M + 15) / 16, (M + 15) / 16, R), dim3(256), 0, st, (const float*)w.G, d.q_sqrt, d.dq_sqrt, M, -d.kl_weight);
+                if ((rc = check_launch("k_gl_tril")) != IWVI_OK) return rc;
+            }
+            return IWVI_OK;
+        }
     }
     MidArgs ma{d.GMV, d.noise, d.W, d.mf_A, d.d_sample, d.d_mean, d.d_var, w.DMU, w.DV2, w.SDV, d.dF, d.P, d.mf_type,
                d.U, d.A, Mp, d.q_sqrt, d.q_mu, w.LinvF, w.DK, d.F, w.Zt, w.invls, w.DA, w.Qx, (long long)T, M, D, R, d.variance, d.kern_type, d.variance_dev};

@@ -222,7 +222,7 @@ def lse_from_pairs(ms_all):
     return m + torch.log((ms_all[..., 1] * torch.exp(ms_all[..., 0] - m)).sum(0))
 
 
-def k_shard_gradients(model, zs=None, K_total=None, group=None):
+def k_shard_gradients(model, zs=None, K_total=None, group=None, wrt="all"):
     """(Every rank must draw its own noise: give each a different ``settings.set_seed`` -- the kernels key their Philox
     streams by (seed, step, layer, sample, quad), so equal seeds would duplicate the samples across ranks.)
 
@@ -241,6 +241,6 @@ def k_shard_gradients(model, zs=None, K_total=None, group=None):
         dist.all_gather_into_tensor(gathered.view(-1), ms.contiguous().view(-1), group=group)
         return lse_from_pairs(gathered)
 
-    elbo, g = iw_elbo_and_gradients(model, zs, exchange=exchange, K_total=K_total, kl_weight=1.0 / world)
+    elbo, g = iw_elbo_and_gradients(model, zs, exchange=exchange, K_total=K_total, kl_weight=1.0 / world, wrt=wrt)
     g = allreduce_gradients(g, weight=1.0, group=group)             # a sum: the shares add up
     return elbo, g

@@ -123,20 +123,21 @@ class Trainer:
                                                     self._t_dev.data_ptr(), 1, _abi.stream_ptr()))
         return keep
 
-    def _gradients(self, zs, advance=True):
+    def _gradients(self, zs, advance=True, wrt="all"):
         from .sharding import allreduce_gradients, k_shard_gradients
         if advance:
             self.model.next_minibatch()                          # gpflow.Minibatch: a new batch per session.run (models.py:21-26)
         if self.shard == "k":
-            return k_shard_gradients(self.model, zs, group=self.group)
-        elbo, g = iw_elbo_and_gradients(self.model, zs)
+            return k_shard_gradients(self.model, zs, group=self.group, wrt=wrt)
+        elbo, g = iw_elbo_and_gradients(self.model, zs, wrt=wrt)
         g["__elbo__"] = elbo.reshape(1)                          # rides in the same bucket: the job's bound
         g = allreduce_gradients(g, weight=self.shard_weight, group=self.group)
         return g.pop("__elbo__")[0], g
 
     def natgrad_op(self, zs=None, _advance=True):
-        """``op_ng``: one ELBO + gradient evaluation, natural-gradient step on the final layer's q(u)."""
-        elbo, g = self._gradients(zs, _advance)
+        """``op_ng``: one ELBO + gradient evaluation, natural-gradient step on the final layer's q(u).  Only that layer's
+        (q_mu, q_sqrt) gradients are formed (``wrt="final_q"``): the op reads nothing else."""
+        elbo, g = self._gradients(zs, _advance, wrt="final_q")
         i = len(self.model.layers) - 1
         f = self.final
         gamma = staircase_decay(self.gamma, self.global_step, self.gamma_decay)

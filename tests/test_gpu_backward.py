@@ -165,6 +165,27 @@ def test_iw_elbo_gradients_match_oracle(gpu_device, L, M, K, B, lv):
     torch.cuda.synchronize()
     for k in runs[0]:
         assert torch.equal(runs[0][k], runs[1][k]) and torch.equal(runs[0][k], runs[2][k]), k
+    # wrt="final_q" (what the natural-gradient op asks for): the same bound and the same two entries, bit for bit
+    e_q, g_q = backward.iw_elbo_and_gradients(model, zd, wrt="final_q")
+    assert sorted(g_q) == ["l%d.q_mu" % (L - 1 + int(lv)), "l%d.q_sqrt" % (L - 1 + int(lv))]
+    assert float(e_q) == float(backward.iw_elbo_and_gradients(model, zd)[0])
+    for k in g_q:
+        assert torch.equal(g_q[k], runs[0][k]), k
+
+
+@pytest.mark.parametrize("cfg", [1, 2, 3])
+def test_final_q_gradients_at_full_size_equal_the_full_adjoints(gpu_device, cfg):
+    """BASELINE.json configs[1..3] at full size: in-chain G_r shares (configs[1], [2]), split-K GEMM for G_r (configs[3], M = 256)."""
+    from bench import CONFIGS
+    from dgps_with_iwvi_amd import synthetic, backward
+    spec = synthetic.make_spec(seed=0, parity=True, n_data=8192, **CONFIGS[cfg])
+    model = synthetic.build_model(spec, gpu_device)
+    zd = [torch.as_tensor(np.asarray(z, dtype=np.float32), device=gpu_device) for z in synthetic.make_noise(spec, seed=4)]
+    e, g = backward.iw_elbo_and_gradients(model, zd)
+    e_q, g_q = backward.iw_elbo_and_gradients(model, zd, wrt="final_q")
+    assert float(e) == float(e_q) and len(g_q) == 2
+    for k in g_q:
+        assert torch.equal(g_q[k], g[k]), k
 
 
 @pytest.mark.parametrize("dims,rows", [([9, 20, 20, 2], 100), ([5, 48, 48, 40, 4], 333), ([3, 64, 2], 64)])
