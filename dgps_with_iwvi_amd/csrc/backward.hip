@@ -1987,18 +1987,6 @@ __global__ void k_d2f(const double* src, float* dst, long long ld, int rows, int
     const int i = idx / cols, j = idx - i * cols;
     dst[i * ld + j] = (tril && j > i) ? 0.f : (float)src[idx];
 }
-__global__ void k_axpby(const double* x, double a, const double* y, double b, double* out, int n) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = a * x[i] + b * y[i];
-}
-__global__ void k_symmetrise(double* Q, int n) {       // Q <- (Q + Q^T) / 2, one thread per (i >= j)
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= n * n) return;
-    const int i = idx / n, j = idx - i * n;
-    if (j > i) return;
-    const double v = 0.5 * (Q[(size_t)i * n + j] + Q[(size_t)j * n + i]);
-    Q[(size_t)i * n + j] = v; Q[(size_t)j * n + i] = v;
-}
 
 // Adam on GPflow's unconstrained variables.  transform 1 = positive: p = softplus(x) + 1e-6 (gpflow.transforms.Log1pe)
 struct AdamTensor { float* p; const float* g; float* x; float* m; float* v; long long n; int transform; };
@@ -2412,6 +2400,21 @@ extern "C" size_t iwvi_natgrad_ws_bytes(int M) {
 //   eta = (m, S + m m^T), theta = (S^-1 m, -1/2 S^-1);  theta <- theta - gamma dLoss/d eta;  back through
 //   natural_to_meanvarsqrt (cholesky(-2 theta_2), its inverse, S = X^T X, mu = S theta_1, cholesky(S)).
 // dq_mu / dq_sqrt are gradients of the objective that is MAXIMISED (the ELBO): loss = -ELBO.
+//
+// The same update without S^-1, with one factorisation instead of two.  With S = L L^T, Lbar = dLoss/dL, mbar = dLoss/dm:
+//   dLoss/dS = L^-T sym(Phi) L^-1,  Phi = Phi(L^T Lbar)  (lower triangle, diagonal halved; sym(A) = (A + A^T) / 2)
+//   -2 theta_2' = S^-1 + 2 gamma dLoss/dS = L^-T Q L^-1,          Q = I + gamma (Phi + Phi^T)
+//   S' = (-2 theta_2')^-1 = L Q^-1 L^T = (L W)(L W)^T             with Q^-1 = W W^T, W lower  =>  L' = chol(S') = L W
+//   theta_1' = L^-T (Q y - gamma L^T mbar), y = L^-1 m            =>  mu' = S' theta_1' = m - gamma L' (L'^T mbar)
+// Q^-1 = W W^T with W lower is Q = V V^T with V = W^-T UPPER: the Cholesky factorisation of Q with rows and columns reversed
+// (J Q J = C C^T, C lower, V = J C J), so W[k][j] = (C^-1)[M-1-j][M-1-k].  Every step is the reference's arithmetic regrouped
+// (float64 throughout); an indefinite -2 theta_2' shows up as an indefinite Q (congruent) and ends in NaN as before.
+__global__ void k_ng_q(const double* __restrict__ Phi, double gamma, double* __restrict__ Qrev, int M) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= M * M) return;
+    const int i = idx / M, j = idx - i * M, ri = M - 1 - i, rj = M - 1 - j;
+    Qrev[idx] = (i == j ? 1.0 : 0.0) + gamma * (Phi[(size_t)ri * M + rj] + Phi[(size_t)rj * M + ri]);
+}
 extern "C" int iwvi_natgrad_step(float* q_mu, float* q_sqrt, const float* dq_mu, const float* dq_sqrt,
                                  int M, int R, double gamma, void* ws_, void* stream_) {
     if (!q_mu || !q_sqrt || !dq_mu || !dq_sqrt || !ws_ || M <= 0 || M > IWVI_MAX_M || R <= 0 || R > IWVI_MAX_R) { set_error("iwvi_natgrad_step: bad argument"); return IWVI_ERR_ARG; }
@@ -2419,8 +2422,9 @@ extern "C" int iwvi_natgrad_step(float* q_mu, float* q_sqrt, const float* dq_mu,
     char* base = (char*)ws_; size_t o = 0;
     auto mat = [&]() { double* p = (double*)(base + o); o += align256(sizeof(double) * (size_t)M * M); return p; };
     auto vec = [&]() { double* p = (double*)(base + o); o += align256(sizeof(double) * M); return p; };
-    double *L = mat(), *Lbar = mat(), *Linv = mat(), *T1 = mat(), *T2 = mat(), *Sbar = mat(), *Sinv = mat(), *Pn = mat();
-    double *m = vec(), *mbar = vec(), *th1 = vec(), *tmp = vec();
+    double *L = mat(), *Lbar = mat(), *Phi = mat(), *Qrev = mat(), *C = mat(), *Cinv = mat(), *Lnew = mat(), *unused = mat();
+    double *m = vec(), *mbar = vec(), *t = vec(), *mnew = vec();
+    (void)unused;
     void* cws = base + o;
     const int nb = (M * M + 255) / 256;
     int rc;
@@ -2429,28 +2433,17 @@ extern "C" int iwvi_natgrad_step(float* q_mu, float* q_sqrt, const float* dq_mu,
         hipLaunchKernelGGL(k_f2d, dim3(nb), dim3(256), 0, st, dq_sqrt + (size_t)r * M * M, (long long)M, Lbar, M, M, -1.0, 1);
         hipLaunchKernelGGL(k_f2d, dim3((M + 255) / 256), dim3(256), 0, st, (const float*)(q_mu + r), (long long)R, m, M, 1, 1.0, 0);
         hipLaunchKernelGGL(k_f2d, dim3((M + 255) / 256), dim3(256), 0, st, dq_mu + r, (long long)R, mbar, M, 1, -1.0, 0);
-        if ((rc = tri_inverse(st, L, Linv, M)) != IWVI_OK) return rc;
-        // dLoss/dS (symmetric) from dLoss/dL: Sbar = sym(L^-T Phi(L^T Lbar) L^-1)
-        dmm(st, L, 1, M, Lbar, M, 1, T1, M, M, M, M, 1.0, nullptr, 0, 0.0, 1);
-        dmm(st, Linv, 1, M, T1, M, 1, T2, M, M, M, M);
-        dmm(st, T2, M, 1, Linv, M, 1, Sbar, M, M, M, M);
-        hipLaunchKernelGGL(k_symmetrise, dim3(nb), dim3(256), 0, st, Sbar, M);
-        // g1 = mbar - 2 Sbar m  (d/d eta_1),  g2 = Sbar  (d/d eta_2)
-        dmm(st, Sbar, M, 1, m, 1, 1, tmp, 1, M, 1, M, -2.0, mbar, 1, 1.0);
-        // theta_1 = S^-1 m, theta_2 = -1/2 S^-1, S^-1 = L^-T L^-1
-        dmm(st, Linv, 1, M, Linv, M, 1, Sinv, M, M, M, M);
-        dmm(st, Sinv, M, 1, m, 1, 1, th1, 1, M, 1, M);
-        // theta_1' = theta_1 - gamma g1 (into mbar);  -2 theta_2' = S^-1 + 2 gamma Sbar (into Pn)
-        hipLaunchKernelGGL(k_axpby, dim3((M + 255) / 256), dim3(256), 0, st, (const double*)th1, 1.0, (const double*)tmp, -gamma, mbar, M);
-        hipLaunchKernelGGL(k_axpby, dim3(nb), dim3(256), 0, st, (const double*)Sinv, 1.0, (const double*)Sbar, 2.0 * gamma, Pn, M * M);
-        // natural_to_meanvarsqrt
-        if ((rc = iwvi_chol_factor(Pn, T1, M, cws, stream_)) != IWVI_OK) return rc;
-        if ((rc = tri_inverse(st, T1, T2, M)) != IWVI_OK) return rc;
-        dmm(st, T2, 1, M, T2, M, 1, Sbar, M, M, M, M);                                   // S' = X^T X
-        dmm(st, Sbar, M, 1, mbar, 1, 1, m, 1, M, 1, M);                                  // mu' = S' theta_1'
-        if ((rc = iwvi_chol_factor(Sbar, L, M, cws, stream_)) != IWVI_OK) return rc;
-        hipLaunchKernelGGL(k_d2f, dim3(nb), dim3(256), 0, st, (const double*)L, q_sqrt + (size_t)r * M * M, (long long)M, M, M, 1);
-        hipLaunchKernelGGL(k_d2f, dim3((M + 255) / 256), dim3(256), 0, st, (const double*)m, q_mu + r, (long long)R, M, 1, 0);
+        dmm(st, L, 1, M, Lbar, M, 1, Phi, M, M, M, M, 1.0, nullptr, 0, 0.0, 1);          // Phi(L^T Lbar)
+        hipLaunchKernelGGL(k_ng_q, dim3(nb), dim3(256), 0, st, (const double*)Phi, gamma, Qrev, M);
+        if ((rc = iwvi_chol_factor(Qrev, C, M, cws, stream_)) != IWVI_OK) return rc;
+        if ((rc = tri_inverse(st, C, Cinv, M)) != IWVI_OK) return rc;
+        // L' = L W,  W[k][j] = Cinv[M-1-j][M-1-k]
+        dmm(st, L, M, 1, Cinv + (size_t)(M - 1) * M + (M - 1), -1, -(long long)M, Lnew, M, M, M, M);
+        // mu' = m - gamma L' (L'^T mbar)
+        dmm(st, Lnew, 1, M, mbar, 1, 1, t, 1, M, 1, M);
+        dmm(st, Lnew, M, 1, t, 1, 1, mnew, 1, M, 1, M, -gamma, m, 1, 1.0);
+        hipLaunchKernelGGL(k_d2f, dim3(nb), dim3(256), 0, st, (const double*)Lnew, q_sqrt + (size_t)r * M * M, (long long)M, M, M, 1);
+        hipLaunchKernelGGL(k_d2f, dim3((M + 255) / 256), dim3(256), 0, st, (const double*)mnew, q_mu + r, (long long)R, M, 1, 0);
         if ((rc = check_launch("iwvi_natgrad_step")) != IWVI_OK) return rc;
     }
     return IWVI_OK;
