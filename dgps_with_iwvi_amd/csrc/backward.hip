@@ -917,6 +917,7 @@ struct ChainArgs {
     float* p_g;                          // [R][S][M][M]   sum_j 2dv_r[j] a[m][j] a[n][j]            -> G_r (dL_r = tril(G_r L_r))
     int S;                               // workgroups of the launch (stride of a batch in p_g)
     int q_only;                          // only dq_mu / dq_sqrt are wanted (the natural-gradient op): heads, dq_mu shares, G_r shares
+    const float* ZtP; const float* cst; int nsteps;   // the state's K_uf operand (A-fragment order), its constant block (1/ls | centre | extent), k-steps
 };
 template <int NS, int DM>               // 16 NS samples per workgroup (8 waves);  D <= DM
 __global__ __launch_bounds__(512) void k_bw_chain(ChainArgs a) {
@@ -1156,10 +1157,143 @@ __global__ __launch_bounds__(512) void k_bw_chain(ChainArgs a) {
             }
         }
     }
-    if (a.q_only) return;
+    if (a.q_only || a.dbg_exit == 4) return;
     __syncthreads();                                         // phase 3 rewrites the dk tile
 
-    // ---- phase 3: kernel adjoint (direct differences), 16 lanes per sample, 16 samples per round.  The scaled inducing inputs
+    // ---- phases 3 + 4 for the RBF kernel, on the matrix cores.  dK/dd2 = -K/2, so the adjoint needs K(z_m, x_j) itself: it is
+    //      REBUILT exactly as the forward builds it (x~ rows, then exp2 of one small MFMA product with the state's Z~ operand --
+    //      or the differenced form when the inducing cloud is wide, csrc/dgp_forward.hip "Gram form"), in the dk tile's layout, so
+    //      c = -K dk / 2 is one multiply per entry.  sum_m c[m] z~[m][d] (-> dx~) and sum_j c[j][m] [F | 1] (-> dZ~ shares) are
+    //      MFMA products over the tile.  Before: ~3 D + 10 VALU instructions per (sample, inducing point), 27 + 5 us of the
+    //      117 us of this kernel at configs[2]'s first layer.
+    if (a.kern_type == IWVI_KERN_RBF) {
+        const int nsteps = a.nsteps, XS = 4 * nsteps;
+        float* xt = tileD;                                   // [NSAMP][XS]  x~ = ((x/ls - centre) | -|.|^2/2 | 1 | 0..)
+        float* zs = xt + NSAMP * XS;                         // [M][DM]      z/ls (zero beyond D)
+        float* red = zs + M * DM;                            // [2][8][NSAMP] per-wave shares of sum_m c and sum_m K dk
+        const float* cst = a.cst;
+        for (int idx = tid; idx < M * DM; idx += 512) { const int m = idx / DM, d = idx - m * DM; zs[idx] = d < D ? a.Zt[m * D + d] : 0.f; }
+        if (tid < NSAMP) {
+            float n2 = 0.f;
+            for (int d = 0; d < D; ++d) { const float v = fmaf(fr[tid * DM + d], cst[d], -cst[32 + d]); xt[tid * XS + d] = v; n2 = fmaf(v, v, n2); }
+            xt[tid * XS + D] = -0.5f * n2; xt[tid * XS + D + 1] = 1.f;
+            for (int d = D + 2; d < XS; ++d) xt[tid * XS + d] = 0.f;
+        }
+        __syncthreads();
+        const bool gram_mfma = __float_as_int(cst[64]) <= __float_as_int(4.0f);
+        float sc[NS], skd[NS];
+#pragma unroll
+        for (int t = 0; t < NS; ++t) { sc[t] = 0.f; skd[t] = 0.f; }
+        for (int bi = wave; bi < nbk; bi += 8) {
+            f32x4 acc[NS];
+#pragma unroll
+            for (int t = 0; t < NS; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (gram_mfma) {
+                const float* zp = a.ZtP + (size_t)bi * nsteps * 64 + lane;
+                for (int s_ = 0; s_ < nsteps; ++s_) {
+                    const float av = zp[s_ * 64];
+#pragma unroll
+                    for (int t = 0; t < NS; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, xt[(16 * t + jq) * XS + 4 * s_ + gq], acc[t], 0, 0, 0);
+                }
+            } else {
+                const float sx = 1.4426950408889634f;
+                for (int d = 0; d < D; ++d) {
+                    const f32x4 z4 = *reinterpret_cast<const f32x4*>(a.ZtP + ((size_t)bi * nsteps + (d >> 2)) * 64 + 16 * (d & 3) + 4 * gq);
+#pragma unroll
+                    for (int t = 0; t < NS; ++t) {
+                        const float xv = sx * xt[(16 * t + jq) * XS + d];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { const float df = xv - z4[e]; acc[t][e] = fmaf(df, df, acc[t][e]); }
+                    }
+                }
+                const float of = __log2f(a.var_dev ? *a.var_dev : a.variance);
+#pragma unroll
+                for (int t = 0; t < NS; ++t)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[t][e] = fmaf(acc[t][e], -0.5f / 1.4426950408889634f, of);
+            }
+#pragma unroll
+            for (int t = 0; t < NS; ++t) {
+                const int slot = (bi * 4 + gq) * NSAMP + 16 * t + jq;
+                const f32x4 dk = tK4[slot];
+                f32x4 c;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float kd = __builtin_amdgcn_exp2f(acc[t][e]) * dk[e];     // (log2 of the variance is folded into Z~)
+                    c[e] = -0.5f * kd;
+                    sc[t] += c[e]; skd[t] += kd;
+                }
+                tK4[slot] = c;                                       // c over dk (same lane, same slot)
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < NS; ++t) {
+            sc[t] += __shfl_xor(sc[t], 16, 64); sc[t] += __shfl_xor(sc[t], 32, 64);
+            skd[t] += __shfl_xor(skd[t], 16, 64); skd[t] += __shfl_xor(skd[t], 32, 64);
+            if (gq == 0) { red[wave * NSAMP + 16 * t + jq] = sc[t]; red[(8 + wave) * NSAMP + 16 * t + jq] = skd[t]; }
+        }
+        __syncthreads();
+        const int Wq = D + 2, ndb = (D + 15) >> 4;
+        for (int job = wave; job < NS * ndb; job += 8) {     // CZ[d][j] = sum_m z~[m][d] c[j][m]: a 16 x 16 block per (sub-tile, 16 dims)
+            const int t = job / ndb, db = job - t * ndb, dcol = 16 * db + jq;
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            for (int bk = 0; bk < nbk; ++bk) {
+                const f32x4 b = tK4[(bk * 4 + gq) * NSAMP + 16 * t + jq];
+#pragma unroll
+                for (int s_ = 0; s_ < 4; ++s_) {
+                    const float av = dcol < DM ? zs[(16 * bk + 4 * gq + s_) * DM + dcol] : 0.f;
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b[s_], acc, 0, 0, 0);
+                }
+            }
+            const int j = 16 * t + jq;
+            float scj = 0.f;
+#pragma unroll
+            for (int w_ = 0; w_ < 8; ++w_) scj += red[w_ * NSAMP + j];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int d = 16 * db + 4 * gq + e;
+                if (d < D) {
+                    const float x_ = fr[j * DM + d], dxt = 2.f * (x_ * il[d]) * scj - 2.f * acc[e];
+                    if (a.dF) a.dF[(t0 + j) * D + d] = fmaf(dxt, il[d], dfi_s[j * D + d]);
+                    qx_s[j * Wq + d] = dxt * x_;
+                }
+            }
+        }
+        if (tid < NSAMP) {
+            float s_ = 0.f;
+#pragma unroll
+            for (int w_ = 0; w_ < 8; ++w_) s_ += red[(8 + w_) * NSAMP + tid];
+            qx_s[tid * Wq + D] = sdv_s[tid]; qx_s[tid * Wq + D + 1] = s_;
+        }
+        __syncthreads();
+        if (a.dbg_exit == 5) return;
+        {   // this workgroup's share of C^T [F | 1]: P[m][col] = sum_j c[j][m] [F | 1][j][col], a 16 x 16 block per (row-block, 16 columns)
+            const int W1 = D + 1, ncb = (W1 + 15) >> 4;
+            float* pc = a.p_ctf + (size_t)blockIdx.x * M * W1;
+            for (int job = wave; job < nbk * ncb; job += 8) {
+                const int bi = job / ncb, cb = job - bi * ncb, col = 16 * cb + jq;
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int q = 0; q < 4 * NS; ++q) {
+                    const int smp = 4 * q + gq;
+                    const float av = tileK[((size_t)(bi * 4 + (jq >> 2)) * NSAMP + smp) * 4 + (jq & 3)];
+                    const float bv = col < D ? fr[smp * DM + col] : (col == D ? 1.f : 0.f);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
+                }
+                if (col < W1) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) pc[(size_t)(16 * bi + 4 * gq + e) * W1 + col] = acc[e];
+                }
+            }
+            if (tid < Wq) {
+                float acc = 0.f;
+                for (int j = 0; j < NSAMP; ++j) acc += qx_s[j * Wq + tid];
+                a.p_q[(size_t)blockIdx.x * Wq + tid] = acc;
+            }
+        }
+        return;
+    }
+    // ---- phase 3 (Matern-5/2): kernel adjoint (direct differences), 16 lanes per sample, 16 samples per round.  The scaled inducing inputs
     //      and the chunk's input rows are staged in the (now free) da tile, padded to DM columns: per-element global loads in the
     //      inner loops were a chain of dependent L1 round trips (50-70 us of this kernel) ------------------------------------
     float* zs = tileD;                                       // [M][DM]   (zero beyond D)
@@ -1212,6 +1346,7 @@ __global__ __launch_bounds__(512) void k_bw_chain(ChainArgs a) {
         if (sub == 0) { qx_s[j * Wq + D] = sdv_s[j]; qx_s[j * Wq + D + 1] = skd; }
     }
     __syncthreads();
+    if (a.dbg_exit == 5) return;
     // ---- phase 4: this workgroup's share of C^T [F | 1] and of the column sums of Qx (fixed order: sample index) -----------
     {
         const int W1 = D + 1;
@@ -1284,14 +1419,18 @@ static bool chain_ok(int M, int Mp, long long T) {
     return Mp == M && M <= 256 && (T % 16) == 0 && !getenv("IWVI_BW_UNFUSED") && !getenv("IWVI_BW_OLD_CHAIN") &&
            !(M > 128 && getenv("IWVI_BW_CHAIN_SMALL_M_ONLY"));
 }
+// floats of the da tile's region: the tile itself, or what is staged there before (heads) / after it (kernel adjoint: x~ rows, z~, shares)
+static int chain_dsz(int NSAMP, int M, int D, int R, int P, int DM) {
+    int dsz = NSAMP * M;
+    const int heads = 3 * NSAMP * P + P * R + 4 * NSAMP * R + D * P, adj = NSAMP * round_up(D + 2, 4) + M * DM + 16 * NSAMP;
+    if (heads > dsz) dsz = heads;
+    if (adj > dsz) dsz = adj;
+    return (dsz + 3) & ~3;
+}
 // LDS bytes of k_bw_chain for a layer shape (the one formula: launch, path selection and iwvi_gp_layer_backward_needs_u use it)
 static size_t chain_lds_bytes(long long T, int M, int D, int R, int P) {
     const int NSAMP = 16 * chain_ns(T, M), DM = D <= 8 ? 8 : (D <= 16 ? 16 : 32);
-    int dsz = NSAMP * M;
-    const int heads = 3 * NSAMP * P + P * R + 4 * NSAMP * R + D * P, adj = M * DM;
-    if (heads > dsz) dsz = heads;
-    if (adj > dsz) dsz = adj;
-    dsz = (dsz + 3) & ~3;
+    const int dsz = chain_dsz(NSAMP, M, D, R, P, DM);
     return sizeof(float) * ((size_t)2 * NSAMP * M + (size_t)dsz + (size_t)M * R + (size_t)NSAMP * (2 * R + 1) + (size_t)NSAMP * D
                             + (size_t)NSAMP * DM + DM + (size_t)NSAMP * (D + 2));
 }
@@ -1304,11 +1443,7 @@ template <int NS>
 static int launch_chain_ns(hipStream_t st, ChainArgs a) {
     constexpr int NSAMP = 16 * NS;
     const int DM = a.D <= 8 ? 8 : (a.D <= 16 ? 16 : 32);
-    int dsz = NSAMP * a.M;
-    const int heads = 3 * NSAMP * a.P + a.P * a.R + 4 * NSAMP * a.R + a.D * a.P, adj = a.M * DM;
-    if (heads > dsz) dsz = heads;
-    if (adj > dsz) dsz = adj;
-    a.dsz = (dsz + 3) & ~3;
+    a.dsz = chain_dsz(NSAMP, a.M, a.D, a.R, a.P, DM);
     const size_t lds = sizeof(float) * ((size_t)2 * NSAMP * a.M + (size_t)a.dsz + (size_t)a.M * a.R + (size_t)NSAMP * (2 * a.R + 1) + (size_t)NSAMP * a.D
                                         + (size_t)NSAMP * DM + DM + (size_t)NSAMP * (a.D + 2));
     static bool done = false;
@@ -2114,6 +2249,7 @@ extern "C" int iwvi_gp_layer_backward(const iwvi_gp_bwd_desc* dp, int64_t T, voi
         // (- kl_weight * dKL/dq_mu = - kl_weight * q_mu rides in the reduction; temp_workaround.py:186-188)
         ca.p_qmu = job(M, R, d.dq_mu ? d.dq_mu : w.DMU, d.dq_mu ? d.q_mu : nullptr, -d.kl_weight);
         ca.q_only = q_only ? 1 : 0;
+        ca.ZtP = (const float*)((const char*)d.state + sl.off_ZtP); ca.cst = (const float*)((const char*)d.state + sl.off_cst); ca.nsteps = round_up(D + 2, 4) / 4;
         if (!q_only) { ca.p_ctf = job(M, D + 1, w.CtF1, nullptr, 0.0); ca.p_q = job(D + 2, 1, w.Qsum, nullptr, 0.0); }
         if (d.dW && d.W) { ca.p_w = job(3 * P, R, w.lin, nullptr, 0.0); for (int i = 0; i < 3; ++i) s[i] = w.lin + (size_t)i * P * R; if (!ca.p_w) ca.p_qmu = nullptr; }
         if (d.dmf_A && d.mf_type == IWVI_MF_LINEAR) { ca.p_a = job(2 * D, P, w.lin + 3 * IWVI_MAX_P * IWVI_MAX_R, nullptr, 0.0); for (int i = 0; i < 2; ++i) a12[i] = w.lin + 3 * IWVI_MAX_P * IWVI_MAX_R + (size_t)i * D * P; if (!ca.p_a) ca.p_qmu = nullptr; }
