@@ -887,7 +887,7 @@ static int launch_mid(hipStream_t st, const MidArgs& a) {
 // so the forward keeps only a (T x M floats instead of (R + 1) T x M), and the adjoint's largest product reads its A
 // operand -- the packed 16x16 blocks of S_r, prepared once per evaluation by k_pack_bw -- straight from L2 in MFMA
 // fragment order while the chunk's a tile sits in LDS in the forward's B-operand layout:
-//   phase 0  heads, a rows HBM -> LDS tile [(bk*4 + g) * NSAMP + sample] (float4 = 4 consecutive m of one sample); a workgroup
+//   phase 0  heads, a rows HBM -> LDS tile [(bk*4 + g) * (NSAMP + 4) + sample] (float4 = 4 consecutive m of one sample); a workgroup
 //            (8 waves) owns 16 NS samples, NS chosen like the forward's so that every CU gets one workgroup
 //   phase 1  da(bi) = sum_r 2dv_r o [sum_bk S_r(bi, bk) a(bk)] - 2 (sum_r dv_r) a(bi) + sum_r q_mu_r(bi) dmu_r
 //            one wave per output row-block: R * nbk packed blocks streamed back to back, 4 NS MFMAs each
@@ -895,6 +895,17 @@ static int launch_mid(hipStream_t st, const MidArgs& a) {
 //   phase 3  kernel adjoint c = dk o dk/dr2..., dx~, dF, Qx rows (as k_bw_mid)
 // ------------------------------------------------------------------------------------------------------------
 typedef const __attribute__((address_space(1))) f32x4* bw_gptr4;
+// asynchronous global -> LDS copy of n floats by a 512-thread workgroup (LDS-DMA: no VGPR round trip; complete after the issuing
+// wave's s_waitcnt vmcnt(0) and a barrier).  One wave-instruction moves 64 consecutive floats; dst + i0 is wave-uniform.
+__device__ __forceinline__ void bw_async_copy(const float* __restrict__ src, float* lds_dst, int n, int tid) {
+    const int lane = tid & 63;
+    for (int i0 = (tid & ~63); i0 < n; i0 += 512) {
+        const int i = i0 + lane;
+        if (i < n)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + i),
+                                             (__attribute__((address_space(3))) void*)(lds_dst + i0), 4, 0, 0);
+    }
+}
 struct ChainArgs {
     const float* GMV; const float* eps; const float* W; const float* mfA; const float* dFs; const float* dFm; const float* dFv;
     float* DMU; float* DV2; float* SDV; float* dF; int P, mf_type;
@@ -922,12 +933,14 @@ struct ChainArgs {
 template <int NS, int DM>               // 16 NS samples per workgroup (8 waves);  D <= DM
 __global__ __launch_bounds__(512) void k_bw_chain(ChainArgs a) {
     constexpr int NSAMP = 16 * NS;
+    constexpr int TS = NSAMP + 4;        // float4 per tile row: NSAMP samples + 4 of padding, so that the TRANSPOSED scalar reads of a tile
+                                         // (products over samples: lanes 4 rows x 4 samples x 4 entries) spread over all 32 banks
     extern __shared__ __attribute__((aligned(16))) float csm[];
     const int M = a.M, nbk = a.nbk, R = a.R, D = a.D, P = a.P;
-    // three tiles in the forward's B-operand layout, float4 [(bk*4 + g) * NSAMP + sample] = 4 consecutive m of one sample:
+    // three tiles in the forward's B-operand layout, float4 [(bk*4 + g) * TS + sample] = 4 consecutive m of one sample:
     float* tileA = csm;                                      // a (kept to the end: the products over samples read it)
-    float* tileK = tileA + NSAMP * M;                        // dk, then c = dk o dk/dd2 (kernel adjoint)
-    float* tileD = tileK + NSAMP * M;                        // da; also stages the heads' inputs before and the scaled inducing inputs after
+    float* tileK = tileA + TS * M;                        // dk, then c = dk o dk/dd2 (kernel adjoint)
+    float* tileD = tileK + TS * M;                        // da; also stages the heads' inputs before and the scaled inducing inputs after
     float* qmu_s = tileD + a.dsz;                            // [M][R]
     float* dmu_s = qmu_s + M * R;                            // [NSAMP][R]
     float* dv2_s = dmu_s + NSAMP * R;                        // [NSAMP][R]
@@ -951,24 +964,51 @@ __global__ __launch_bounds__(512) void k_bw_chain(ChainArgs a) {
     float* eps_s = gmv_s + NSAMP * 3 * R;                    // [NSAMP][R]
     float* mfA_s = eps_s + NSAMP * R;                           // [D][P]
     {
+        // every input of the chunk in ONE round trip: the contiguous pieces by LDS-DMA (no register staging, nothing waits), the two
+        // that change layout (a rows -> B-operand order, F rows -> DM-padded) through registers with all their loads issued first.
+        // (Before: one loop per piece, each ending in s_waitcnt vmcnt(0) -- a dozen dependent round trips, most of this phase.)
         const int q4 = M >> 2;                               // float4 per row
-        for (int idx = tid; idx < NSAMP * q4; idx += 512) {
-            const int j = idx / q4, q = idx - j * q4;
-            tA4[q * NSAMP + j] = *reinterpret_cast<const f32x4*>(a.A + (size_t)(t0 + j) * a.Mp + 4 * q);
-        }
-        for (int idx = tid; idx < M * R; idx += 512) qmu_s[idx] = a.q_mu[idx];
+        constexpr int AB = 8;                                // a-row float4 per thread and batch
         const float* up[3] = {a.dFs, a.dFm, a.dFv};
+        bw_async_copy(a.q_mu, qmu_s, M * R, tid);
 #pragma unroll
-        for (int u = 0; u < 3; ++u)
-            for (int idx = tid; idx < NSAMP * P; idx += 512) ups_s[u * NSAMP * P + idx] = up[u] ? up[u][(size_t)t0 * P + idx] : 0.f;
-        for (int idx = tid; idx < P * R; idx += 512) W_s[idx] = a.W ? a.W[idx] : ((idx / R) == (idx % R) ? 1.f : 0.f);
-        for (int idx = tid; idx < NSAMP * 3 * R; idx += 512) gmv_s[idx] = a.GMV[(size_t)t0 * 3 * R + idx];
-        for (int idx = tid; idx < NSAMP * R; idx += 512) eps_s[idx] = a.eps ? a.eps[(size_t)t0 * R + idx] : 0.f;
-        for (int idx = tid; idx < NSAMP * DM; idx += 512) { const int j = idx / DM, d = idx - j * DM; fr[idx] = d < D ? a.F[(size_t)(t0 + j) * D + d] : 0.f; }
-        if (tid < DM) il[tid] = tid < D ? a.invls[tid] : 0.f;
-        if (a.mf_type == IWVI_MF_LINEAR) for (int idx = tid; idx < D * P; idx += 512) mfA_s[idx] = a.mfA[idx];
+        for (int u = 0; u < 3; ++u) if (up[u]) bw_async_copy(up[u] + (size_t)t0 * P, ups_s + u * NSAMP * P, NSAMP * P, tid);
+        if (a.W) bw_async_copy(a.W, W_s, P * R, tid);
+        bw_async_copy(a.GMV + (size_t)t0 * 3 * R, gmv_s, NSAMP * 3 * R, tid);
+        if (a.eps) bw_async_copy(a.eps + (size_t)t0 * R, eps_s, NSAMP * R, tid);
+        if (a.mf_type == IWVI_MF_LINEAR) bw_async_copy(a.mfA, mfA_s, D * P, tid);
+        float fv[(5 * 16 * DM + 511) / 512];
+#pragma unroll
+        for (int u = 0; u < (5 * 16 * DM + 511) / 512; ++u) {
+            const int idx = tid + 512 * u, j = idx / DM, d = idx - j * DM;
+            fv[u] = (idx < NSAMP * DM && d < D) ? a.F[(size_t)(t0 + j) * D + d] : 0.f;
+        }
+        const float ilv = (tid < D) ? a.invls[tid] : 0.f;
+        for (int b0 = 0; b0 < NSAMP * q4; b0 += AB * 512) {
+            f32x4 av[AB];
+#pragma unroll
+            for (int u = 0; u < AB; ++u) {
+                const int idx = b0 + tid + 512 * u, j = idx / q4, q = idx - j * q4;
+                if (idx < NSAMP * q4) av[u] = *reinterpret_cast<const f32x4*>(a.A + (size_t)(t0 + j) * a.Mp + 4 * q);
+            }
+#pragma unroll
+            for (int u = 0; u < AB; ++u) {
+                const int idx = b0 + tid + 512 * u, j = idx / q4, q = idx - j * q4;
+                if (idx < NSAMP * q4) tA4[q * TS + j] = av[u];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < (5 * 16 * DM + 511) / 512; ++u) if (tid + 512 * u < NSAMP * DM) fr[tid + 512 * u] = fv[u];
+        if (tid < DM) il[tid] = ilv;
+        // the pieces a caller may leave out
+#pragma unroll
+        for (int u = 0; u < 3; ++u) if (!up[u]) for (int idx = tid; idx < NSAMP * P; idx += 512) ups_s[u * NSAMP * P + idx] = 0.f;
+        if (!a.W) for (int idx = tid; idx < P * R; idx += 512) W_s[idx] = ((idx / R) == (idx % R) ? 1.f : 0.f);
+        if (!a.eps) for (int idx = tid; idx < NSAMP * R; idx += 512) eps_s[idx] = 0.f;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the LDS-DMA copies of this wave have landed
     }
     __syncthreads();
+    if (a.dbg_exit == 10) return;
     for (int idx = tid; idx < NSAMP * R; idx += 512) {       // heads: one thread per (sample, latent GP)
         const int j = idx / R, r = idx - j * R;
         float dg = 0.f, dm = 0.f, dvv = 0.f;
@@ -993,35 +1033,41 @@ __global__ __launch_bounds__(512) void k_bw_chain(ChainArgs a) {
         dfi_s[idx] = acc;
     }
     __syncthreads();
-    // this workgroup's share of the thin sums whose operands are at hand now (fixed summation order: sample index)
+    if (a.dbg_exit == 11) return;
+    // this workgroup's share of the thin sums whose operands are at hand now (fixed summation order).  dq_mu's share
+    // sum_j a[m][j] dmu[j][r] is an M x 16 MFMA product over the chunk's samples (a read transposed, one row-block per wave);
+    // the two small ones (dW, dmf_A) run beside it on different threads.
     {
         float* pq = a.p_qmu + (size_t)blockIdx.x * M * R;
-        for (int idx = tid; idx < M * R; idx += 512) {       // dq_mu share: sum_j a[m][j] dmu[j][r]
-            const int m = idx / R, r = idx - m * R;
-            const float* ap = tileA + (size_t)(m >> 2) * NSAMP * 4 + (m & 3);
-            float acc = 0.f;
-#pragma unroll 16
-            for (int j = 0; j < NSAMP; ++j) acc = fmaf(ap[4 * j], dmu_s[j * R + r], acc);
-            pq[idx] = acc;
-        }
-        if (a.p_w) {                                         // dW shares: dFs^T G | dFm^T MU | dFv^T V
-            float* pw = a.p_w + (size_t)blockIdx.x * 3 * P * R;
-            for (int idx = tid; idx < 3 * P * R; idx += 512) {
-                const int u = idx / (P * R), pr = idx - u * P * R, p_ = pr / R, r = pr - p_ * R;
-                float acc = 0.f;
-#pragma unroll 16
-                for (int j = 0; j < NSAMP; ++j) acc = fmaf(ups_s[u * NSAMP * P + j * P + p_], gmv_s[j * 3 * R + u * R + r], acc);
-                pw[idx] = acc;
+        const int nrb = (R + 15) >> 4;
+        for (int job = wave; job < nbk * nrb; job += 8) {
+            const int bi = job / nrb, rb = job - bi * nrb, rcol = 16 * rb + jq;
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int q = 0; q < 4 * NS; ++q) {
+                const int smp = 4 * q + gq;
+                const float av = tileA[((size_t)(bi * 4 + (jq >> 2)) * TS + smp) * 4 + (jq & 3)];
+                const float bv = rcol < R ? dmu_s[smp * R + rcol] : 0.f;
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
+            }
+            if (rcol < R) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) pq[(size_t)(16 * bi + 4 * gq + e) * R + rcol] = acc[e];
             }
         }
-        if (a.p_a) {                                         // dmf_A shares: F^T dFs | F^T dFm
-            float* pa = a.p_a + (size_t)blockIdx.x * 2 * D * P;
-            for (int idx = tid; idx < 2 * D * P; idx += 512) {
-                const int u = idx / (D * P), dp = idx - u * D * P, d = dp / P, p_ = dp - d * P;
-                float acc = 0.f;
+        const int n_w = a.p_w ? 3 * P * R : 0, n_a = a.p_a ? 2 * D * P : 0;
+        for (int idx = tid; idx < n_w + n_a; idx += 512) {
+            float acc = 0.f;
+            if (idx < n_w) {                                     // dW shares: dFs^T G | dFm^T MU | dFv^T V
+                const int u = idx / (P * R), pr = idx - u * P * R, p_ = pr / R, r = pr - p_ * R;
+#pragma unroll 16
+                for (int j = 0; j < NSAMP; ++j) acc = fmaf(ups_s[u * NSAMP * P + j * P + p_], gmv_s[j * 3 * R + u * R + r], acc);
+                a.p_w[(size_t)blockIdx.x * 3 * P * R + idx] = acc;
+            } else {                                             // dmf_A shares: F^T dFs | F^T dFm
+                const int i2 = idx - n_w, u = i2 / (D * P), dp = i2 - u * D * P, d = dp / P, p_ = dp - d * P;
 #pragma unroll 16
                 for (int j = 0; j < NSAMP; ++j) acc = fmaf(fr[j * DM + d], ups_s[u * NSAMP * P + j * P + p_], acc);
-                pa[idx] = acc;
+                a.p_a[(size_t)blockIdx.x * 2 * D * P + i2] = acc;
             }
         }
     }
@@ -1049,7 +1095,7 @@ __global__ __launch_bounds__(512) void k_bw_chain(ChainArgs a) {
             a_n2 = Pb[(size_t)(q + 2 < nblocks ? q + 2 : nblocks - 1) * 64];
             f32x4 b[NS];
 #pragma unroll
-            for (int t = 0; t < NS; ++t) b[t] = tA4[(bk * 4 + gq) * NSAMP + 16 * t + jq];
+            for (int t = 0; t < NS; ++t) b[t] = tA4[(bk * 4 + gq) * TS + 16 * t + jq];
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
 #pragma unroll
@@ -1068,7 +1114,7 @@ __global__ __launch_bounds__(512) void k_bw_chain(ChainArgs a) {
 #pragma unroll
         for (int t = 0; t < NS; ++t) {
             const int j = 16 * t + jq;
-            const f32x4 av = tA4[(bi * 4 + gq) * NSAMP + j];
+            const f32x4 av = tA4[(bi * 4 + gq) * TS + j];
             const float m2 = -2.f * sdv_s[j];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -1077,7 +1123,7 @@ __global__ __launch_bounds__(512) void k_bw_chain(ChainArgs a) {
                 for (int rr = 0; rr < R; ++rr) v = fmaf(dmu_s[j * R + rr], qmu_s[m * R + rr], v);
                 tot[t][e] = v;
             }
-            tD4[(bi * 4 + gq) * NSAMP + j] = tot[t];
+            tD4[(bi * 4 + gq) * TS + j] = tot[t];
         }
     }
     __syncthreads();
@@ -1101,7 +1147,7 @@ __global__ __launch_bounds__(512) void k_bw_chain(ChainArgs a) {
             const int bk = bi + q;
             f32x4 b[NS];
 #pragma unroll
-            for (int t = 0; t < NS; ++t) b[t] = tD4[(bk * 4 + gq) * NSAMP + 16 * t + jq];
+            for (int t = 0; t < NS; ++t) b[t] = tD4[(bk * 4 + gq) * TS + 16 * t + jq];
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
 #pragma unroll
@@ -1111,7 +1157,7 @@ __global__ __launch_bounds__(512) void k_bw_chain(ChainArgs a) {
 #pragma unroll
         for (int t = 0; t < NS; ++t) {
             const int j = 16 * t + jq;
-            tK4[(bi * 4 + gq) * NSAMP + j] = acc[t];
+            tK4[(bi * 4 + gq) * TS + j] = acc[t];
             if (a.DK) *reinterpret_cast<f32x4*>(a.DK + (size_t)(t0 + j) * M + 16 * bi + 4 * gq) = acc[t];   // (only for the split-K GEMM path of dLm)
         }
     }
@@ -1138,7 +1184,7 @@ __global__ __launch_bounds__(512) void k_bw_chain(ChainArgs a) {
 #pragma unroll
                 for (int q = 0; q < 4 * NS; ++q) {           // A[i = jq][k = sample 4q + gq] = src[row 16bi + jq][sample]
                     const int smp = 4 * q + gq;
-                    float v = src[((size_t)(bi * 4 + (jq >> 2)) * NSAMP + smp) * 4 + (jq & 3)];
+                    float v = src[((size_t)(bi * 4 + (jq >> 2)) * TS + smp) * 4 + (jq & 3)];
                     if (it > 0) v *= dv2_s[smp * R + (it - 1)];
                     av[q] = v;
                 }
@@ -1148,7 +1194,7 @@ __global__ __launch_bounds__(512) void k_bw_chain(ChainArgs a) {
                     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                     for (int q = 0; q < 4 * NS; ++q) {       // B[k = sample 4q + gq][j = jq] = a[row 16bk + jq][sample]
-                        const float bv = tileA[((size_t)(bk * 4 + (jq >> 2)) * NSAMP + 4 * q + gq) * 4 + (jq & 3)];
+                        const float bv = tileA[((size_t)(bk * 4 + (jq >> 2)) * TS + 4 * q + gq) * 4 + (jq & 3)];
                         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q], bv, acc, 0, 0, 0);
                     }
 #pragma unroll
@@ -1214,7 +1260,7 @@ __global__ __launch_bounds__(512) void k_bw_chain(ChainArgs a) {
             }
 #pragma unroll
             for (int t = 0; t < NS; ++t) {
-                const int slot = (bi * 4 + gq) * NSAMP + 16 * t + jq;
+                const int slot = (bi * 4 + gq) * TS + 16 * t + jq;
                 const f32x4 dk = tK4[slot];
                 f32x4 c;
 #pragma unroll
@@ -1238,7 +1284,7 @@ __global__ __launch_bounds__(512) void k_bw_chain(ChainArgs a) {
             const int t = job / ndb, db = job - t * ndb, dcol = 16 * db + jq;
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
             for (int bk = 0; bk < nbk; ++bk) {
-                const f32x4 b = tK4[(bk * 4 + gq) * NSAMP + 16 * t + jq];
+                const f32x4 b = tK4[(bk * 4 + gq) * TS + 16 * t + jq];
 #pragma unroll
                 for (int s_ = 0; s_ < 4; ++s_) {
                     const float av = dcol < DM ? zs[(16 * bk + 4 * gq + s_) * DM + dcol] : 0.f;
@@ -1276,7 +1322,7 @@ __global__ __launch_bounds__(512) void k_bw_chain(ChainArgs a) {
 #pragma unroll
                 for (int q = 0; q < 4 * NS; ++q) {
                     const int smp = 4 * q + gq;
-                    const float av = tileK[((size_t)(bi * 4 + (jq >> 2)) * NSAMP + smp) * 4 + (jq & 3)];
+                    const float av = tileK[((size_t)(bi * 4 + (jq >> 2)) * TS + smp) * 4 + (jq & 3)];
                     const float bv = col < D ? fr[smp * DM + col] : (col == D ? 1.f : 0.f);
                     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
                 }
@@ -1312,7 +1358,7 @@ __global__ __launch_bounds__(512) void k_bw_chain(ChainArgs a) {
         for (int m0 = 0; m0 < M; m0 += 64) {
             const int mb = m0 + 4 * sub;
             if (mb < M) {
-                const f32x4 dk = tK4[(mb >> 2) * NSAMP + j];
+                const f32x4 dk = tK4[(mb >> 2) * TS + j];
                 f32x4 c;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -1327,7 +1373,7 @@ __global__ __launch_bounds__(512) void k_bw_chain(ChainArgs a) {
 #pragma unroll
                     for (int d = 0; d < DM; ++d) cz[d] = fmaf(c[e], z[d], cz[d]);
                 }
-                tK4[(mb >> 2) * NSAMP + j] = c;                          // c over dk (same thread, same slot): the C^T F sums below
+                tK4[(mb >> 2) * TS + j] = c;                          // c over dk (same thread, same slot): the C^T F sums below
             }
         }
         sc = gsum(sc); skd = gsum(skd);
@@ -1356,10 +1402,10 @@ __global__ __launch_bounds__(512) void k_bw_chain(ChainArgs a) {
             float acc = 0.f;
             if (d < D) {
 #pragma unroll 16
-                for (int j = 0; j < NSAMP; ++j) acc = fmaf(tileK[((size_t)(m >> 2) * NSAMP + j) * 4 + (m & 3)], fr[j * DM + d], acc);
+                for (int j = 0; j < NSAMP; ++j) acc = fmaf(tileK[((size_t)(m >> 2) * TS + j) * 4 + (m & 3)], fr[j * DM + d], acc);
             } else {
 #pragma unroll 16
-                for (int j = 0; j < NSAMP; ++j) acc += tileK[((size_t)(m >> 2) * NSAMP + j) * 4 + (m & 3)];
+                for (int j = 0; j < NSAMP; ++j) acc += tileK[((size_t)(m >> 2) * TS + j) * 4 + (m & 3)];
             }
             pc[idx] = acc;
         }
@@ -1421,7 +1467,7 @@ static bool chain_ok(int M, int Mp, long long T) {
 }
 // floats of the da tile's region: the tile itself, or what is staged there before (heads) / after it (kernel adjoint: x~ rows, z~, shares)
 static int chain_dsz(int NSAMP, int M, int D, int R, int P, int DM) {
-    int dsz = NSAMP * M;
+    int dsz = (NSAMP + 4) * M;                               // (tile rows are padded by 4 float4: k_bw_chain's TS)
     const int heads = 3 * NSAMP * P + P * R + 4 * NSAMP * R + D * P, adj = NSAMP * round_up(D + 2, 4) + M * DM + 16 * NSAMP;
     if (heads > dsz) dsz = heads;
     if (adj > dsz) dsz = adj;
@@ -1431,7 +1477,7 @@ static int chain_dsz(int NSAMP, int M, int D, int R, int P, int DM) {
 static size_t chain_lds_bytes(long long T, int M, int D, int R, int P) {
     const int NSAMP = 16 * chain_ns(T, M), DM = D <= 8 ? 8 : (D <= 16 ? 16 : 32);
     const int dsz = chain_dsz(NSAMP, M, D, R, P, DM);
-    return sizeof(float) * ((size_t)2 * NSAMP * M + (size_t)dsz + (size_t)M * R + (size_t)NSAMP * (2 * R + 1) + (size_t)NSAMP * D
+    return sizeof(float) * ((size_t)2 * (NSAMP + 4) * M + (size_t)dsz + (size_t)M * R + (size_t)NSAMP * (2 * R + 1) + (size_t)NSAMP * D
                             + (size_t)NSAMP * DM + DM + (size_t)NSAMP * (D + 2));
 }
 static bool chain_fits(long long T, int M, int Mp, int D, int R, int P) { return chain_ok(M, Mp, T) && chain_lds_bytes(T, M, D, R, P) <= 160 * 1024; }
@@ -1444,7 +1490,7 @@ static int launch_chain_ns(hipStream_t st, ChainArgs a) {
     constexpr int NSAMP = 16 * NS;
     const int DM = a.D <= 8 ? 8 : (a.D <= 16 ? 16 : 32);
     a.dsz = chain_dsz(NSAMP, a.M, a.D, a.R, a.P, DM);
-    const size_t lds = sizeof(float) * ((size_t)2 * NSAMP * a.M + (size_t)a.dsz + (size_t)a.M * a.R + (size_t)NSAMP * (2 * a.R + 1) + (size_t)NSAMP * a.D
+    const size_t lds = sizeof(float) * ((size_t)2 * (NSAMP + 4) * a.M + (size_t)a.dsz + (size_t)a.M * a.R + (size_t)NSAMP * (2 * a.R + 1) + (size_t)NSAMP * a.D
                                         + (size_t)NSAMP * DM + DM + (size_t)NSAMP * (a.D + 2));
     static bool done = false;
     if (!done) {
