@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libiwvi_hip.so")
 
 KERN_RBF, KERN_MATERN52 = 0, 1
 LAYER_GP, LAYER_LV = 0, 1
-ABI_VERSION = 8
+ABI_VERSION = 9
 GP_WANT_DENSE = 1
 MAX_STACK = 8
 MF_ZERO, MF_IDENTITY, MF_LINEAR = 0, 1, 2
@@ -85,7 +85,7 @@ class GpBwdDesc(ctypes.Structure):
                 ("dF", c_void_p), ("dZ", c_void_p), ("dls", c_void_p), ("dvariance", c_void_p),
                 ("dq_mu", c_void_p), ("dq_sqrt", c_void_p), ("dW", c_void_p), ("dmf_A", c_void_p),
                 ("side_stream", c_void_p), ("side_stream2", c_void_p), ("prepared", ctypes.c_int32),
-                ("variance_dev", c_void_p)]
+                ("variance_dev", c_void_p), ("phase", ctypes.c_int32)]
 
 
 class AdamTensor(ctypes.Structure):

@@ -130,10 +130,13 @@ def prepare_side(model, T, stream):
 
 
 def gp_backward(layer, saved, d_sample=None, d_mean=None, d_var=None, kl_weight=1.0, want_dF=True, side_stream=None, keep=None,
-                side_stream2=None, prepared=None, q_only=False):
+                side_stream2=None, prepared=None, q_only=False, defer_params=False):
     """``iwvi_gp_layer_backward``: upstream gradients [T, P] -> dict(dF [T, D], dZ, dls, dvariance, dq_mu, dq_sqrt).
     ``prepared`` = (workspace, dense state) from ``prepare_side``.  ``q_only``: dict(dq_mu, dq_sqrt) alone -- the library then
-    skips everything those two do not need (no prepared operands, no dense factors)."""
+    skips everything those two do not need (no prepared operands, no dense factors).
+    ``defer_params`` (with side streams): only the per-sample chain is queued now (``desc.phase = 1``: dF is on its way); the
+    dict carries ``"_finish"``, a callable that queues the parameter branch (``phase = 2``) on the side streams -- the caller runs
+    it after queueing whatever should FOLLOW the chain on the same hardware queue of a captured graph (the next layer's chain)."""
     dev = saved.F.device
     T, D = saved.F.shape
     M, R = layer.num_inducing, layer.num_outputs
@@ -180,6 +183,18 @@ def gp_backward(layer, saved, d_sample=None, d_mean=None, d_var=None, kl_weight=
         if side_stream2 is not None:
             b.side_stream2 = ctypes.c_void_p(side_stream2.cuda_stream)
         keep.append((ws, out, keep_t))                           # alive until the caller has joined the streams
+    if defer_params and side_stream is not None and not q_only:
+        b.phase = 1
+        _abi.check(_abi.lib().iwvi_gp_layer_backward(ctypes.byref(b), T, ws.data_ptr(), _abi.stream_ptr()))
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+
+        def finish():
+            side_stream.wait_event(ev)
+            b.phase = 2                                          # (same descriptor: the workspace layout depends on the two side streams)
+            _abi.check(_abi.lib().iwvi_gp_layer_backward(ctypes.byref(b), T, ws.data_ptr(), ctypes.c_void_p(side_stream.cuda_stream)))
+        out["_finish"] = finish
+        return out
     _abi.check(_abi.lib().iwvi_gp_layer_backward(ctypes.byref(b), T, ws.data_ptr(), _abi.stream_ptr()))
     return out
 
@@ -320,33 +335,41 @@ def iw_elbo_and_gradients(model, zs=None, mode_vi=None, exchange=None, K_total=N
     if prep_stream != cur:
         cur.wait_stream(prep_stream)                             # dense factors and packed adjoint operands are ready
     side = _side_stream(dev) if overlap else None
-    side2 = _side_stream(dev, 1) if overlap else None
     held = []
     dF = None
+    pending = None                                               # the parameter branch of the layer above, queued once this layer's chain is
+    # the LAST branch to be queued (the lowest GP layer that has one) runs as two chains: the adjoint of the factorisation on the side
+    # stream, every other sum on the caller's own stream -- nothing else is left to run there (0.364 -> 0.350 ms at configs[2])
+    deferred = [j for j, l in enumerate(layers) if isinstance(l, GPLayer) and j > 0]
+    last_deferred = min(deferred) if (deferred and overlap) else -1
     for i in range(len(layers) - 1, -1, -1):
         layer, s = layers[i], saved[i]
         if s[0] == "gp":
             last = i == len(layers) - 1
             g = gp_backward(layer, s[1], d_sample=None if last else dF, d_mean=d_mean if last else None,
                             d_var=d_var if last else None, kl_weight=kl_weight, want_dF=i > 0,
-                            side_stream=side if i > 0 else None, keep=held, prepared=prepared.get(i),
-                            # two concurrent chains only in the window where it was measured to pay (configs[2]: -4 %); smaller jobs are
-                            # host-bound (+8 % at configs[1]), larger ones fill the GPU on their own (+3 % at configs[3])
-                            side_stream2=side2 if (1 << 20) <= T * layer.num_inducing <= (1 << 23) else None)
+                            side_stream=side if i > 0 else None, keep=held, prepared=prepared.get(i), defer_params=True,
+                            # (one side stream: with the chains of consecutive layers back to back on the caller's stream -- defer_params --
+                            # a second one for the Cholesky-adjoint chain no longer pays: 0.400 -> 0.369 ms at configs[2] without it)
+                            side_stream2=cur if i == last_deferred else None)
             for k_out, k_name in (("dZ", "Z"), ("dls", "ls"), ("dvariance", "var"), ("dq_mu", "q_mu"), ("dq_sqrt", "q_sqrt"),
                                   ("dW", "W"), ("dmf_A", "mfA")):
                 if k_out in g:
                     grads["l%d.%s" % (i, k_name)] = g[k_out]
             dF = g.get("dF")
+            if pending is not None:
+                pending()
+            pending = g.pop("_finish", None)
         else:
             _, enc_out, eps, _, D_in = s
             dW, db = lv_backward(layer, XY, enc_out, eps, dF, D_in, w, B, K, not mode_vi)
             for j, (a, b) in enumerate(zip(dW, db)):
                 grads["l%d.encW%d" % (i, j)], grads["l%d.encb%d" % (i, j)] = a, b
             dF = None if (dF is None or i == 0) else dF[:, :D_in].contiguous()
+    if pending is not None:
+        pending()
     if side is not None:
         cur.wait_stream(side)                                    # join: the parameter gradients are complete on the caller's stream
-        cur.wait_stream(side2)
     del held
     if wrt == "final_q":                                         # (a shape off the streaming chain: formed by the full adjoint above)
         i = len(layers) - 1

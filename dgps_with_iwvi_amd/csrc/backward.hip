@@ -2266,7 +2266,13 @@ extern "C" int iwvi_gp_layer_backward(const iwvi_gp_bwd_desc* dp, int64_t T, voi
     // shapes that is the heads + two sums over samples -- no da / dk, no kernel adjoint, no adjoint of the factorisation, and
     // nothing of iwvi_gp_layer_backward_prepare (the state may then be the packed one: the dense factors are not read).
     const bool q_only = !d.dZ && !d.dls && !d.dvariance && !d.dF && !d.dW && !d.dmf_A && d.GMV && chain_fits(T, M, Mp, D, R, d.P);
-    if (!q_only && !d.prepared && (rc = iwvi_gp_layer_backward_prepare(dp, T, ws_, stream_)) != IWVI_OK) return rc;
+    // desc.phase splits the call at the point where dF is queued: 1 = the per-sample chain only, 2 = the parameter branch only (same
+    // descriptor, same workspace; the caller orders 2 after 1 -- on any stream -- and may queue other work in between: a captured
+    // graph then keeps the layers' chains on one hardware queue).  Shapes off the streaming chain do everything in phase 1.
+    const int phase = (q_only || !(d.GMV && chain_fits(T, M, Mp, D, R, d.P))) ? (d.phase == 2 ? -1 : 0) : d.phase;
+    if (phase == -1) return IWVI_OK;
+    if (phase < 0 || phase > 2) { set_error("iwvi_gp_layer_backward: phase %d", d.phase); return IWVI_ERR_ARG; }
+    if (phase != 2 && !q_only && !d.prepared && (rc = iwvi_gp_layer_backward_prepare(dp, T, ws_, stream_)) != IWVI_OK) return rc;
     const float* gmv = d.GMV ? d.GMV : w.GMV;
     // deferred reductions of this layer: every product over samples parks its partial sums in its own slice of the workspace
     const bool prod = d.GMV && chain_products_ok(M, T);    // dLm and G_r shares come out of the chain kernel
@@ -2315,7 +2321,8 @@ extern "C" int iwvi_gp_layer_backward(const iwvi_gp_bwd_desc* dp, int64_t T, voi
             }
             ca.DK = nullptr;
         }
-        if ((rc = launch_chain(st, ca)) != IWVI_OK) return rc;
+        if (phase != 2 && (rc = launch_chain(st, ca)) != IWVI_OK) return rc;
+        if (phase == 1) return IWVI_OK;
         if (q_only) {                                      // the two reductions (+ G_r by split-K GEMM where the chain does not form it), then dL_r
             if (d.dq_sqrt && !prod) {
                 GemmArgs q{};
@@ -2380,8 +2387,9 @@ extern "C" int iwvi_gp_layer_backward(const iwvi_gp_bwd_desc* dp, int64_t T, voi
         stA = (hipStream_t)d.side_stream;
         stB = d.side_stream2 ? (hipStream_t)d.side_stream2 : stA;
         hipEvent_t ev;
+        // (a stream never waits on its own event: in phase 2 the caller's stream IS the first side stream)
         if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess || hipEventRecord(ev, st) != hipSuccess ||
-            hipStreamWaitEvent(stA, ev, 0) != hipSuccess || (stB != stA && hipStreamWaitEvent(stB, ev, 0) != hipSuccess)) {
+            (stA != st && hipStreamWaitEvent(stA, ev, 0) != hipSuccess) || (stB != stA && stB != st && hipStreamWaitEvent(stB, ev, 0) != hipSuccess)) {
             set_error("iwvi_gp_layer_backward: stream fork failed"); return IWVI_ERR_LAUNCH;
         }
         (void)hipEventDestroy(ev);                         // (released once the recorded work has passed it)

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define IWVI_ABI_VERSION 8
+#define IWVI_ABI_VERSION 9
 
 enum {
     IWVI_OK = 0,
@@ -298,6 +298,11 @@ typedef struct iwvi_gp_bwd_desc {
                                      * (Cholesky adjoint | the other sums over samples); join both */
     int32_t prepared;               /* nonzero: iwvi_gp_layer_backward_prepare has already run on this (desc, ws) */
     const float* variance_dev;      /* optional device scalar read instead of `variance` (see iwvi_gp_desc) */
+    int32_t phase;                  /* 0: the whole adjoint.  1: only the per-sample chain (dF and the partial sums are queued);
+                                     * 2: only the parameter branch of a call made with phase 1 on the same descriptor and
+                                     * workspace.  The caller orders 2 after 1 and may queue other work in between (so that, in a
+                                     * captured graph, the next layer's chain follows this one's on the same hardware queue).
+                                     * Shapes off the streaming chain do everything in phase 1; phase 2 is then a no-op. */
 } iwvi_gp_bwd_desc;
 size_t iwvi_gp_layer_backward_ws_bytes(int64_t T, int M, int D, int R);
 /* 1 if the adjoint of this layer shape takes the GEMM path and therefore needs the forward's u_out, 0 if the streaming chain
