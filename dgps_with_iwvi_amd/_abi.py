@@ -16,6 +16,7 @@ KERN_RBF, KERN_MATERN52 = 0, 1
 LAYER_GP, LAYER_LV = 0, 1
 ABI_VERSION = 9
 GP_WANT_DENSE = 1
+ADAM_GRAD_F64 = 16
 MAX_STACK = 8
 MF_ZERO, MF_IDENTITY, MF_LINEAR = 0, 1, 2
 ACT_TANH, ACT_RELU, ACT_SIGMOID, ACT_SOFTPLUS, ACT_IDENTITY = 0, 1, 2, 3, 4

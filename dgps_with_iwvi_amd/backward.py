@@ -350,7 +350,8 @@ def iw_elbo_and_gradients(model, zs=None, mode_vi=None, exchange=None, K_total=N
                             d_var=d_var if last else None, kl_weight=kl_weight, want_dF=i > 0,
                             side_stream=side if i > 0 else None, keep=held, prepared=prepared.get(i), defer_params=True,
                             # (one side stream: with the chains of consecutive layers back to back on the caller's stream -- defer_params --
-                            # a second one for the Cholesky-adjoint chain no longer pays: 0.400 -> 0.369 ms at configs[2] without it)
+                            # a second one for the Cholesky-adjoint chain no longer pays: 0.400 -> 0.369 ms at configs[2] without it; alternating
+                            # the layers' branches between two side streams: 0.356 -> 0.379 ms)
                             side_stream2=cur if i == last_deferred else None)
             for k_out, k_name in (("dZ", "Z"), ("dls", "ls"), ("dvariance", "var"), ("dq_mu", "q_mu"), ("dq_sqrt", "q_sqrt"),
                                   ("dW", "W"), ("dmf_A", "mfA")):

@@ -1655,26 +1655,36 @@ __global__ void k_prep(const float* Z, const float* ls, const double* Linv64, in
 }
 // row m of K_uu: dZ~_uu[m, :] = 4 sum_n Sbar_mn dK_mn/dd2 (z~_m - z~_n),  dvar_m = sum_n Sbar_mn K_mn / s2,  Sbar = (S + S^T)/2
 __global__ __launch_bounds__(256) void k_kuu_bwd(const float* Zt, const double* S, int M, int D, double variance_, const float* var_dev, int kern_type, double* dZt_uu, double* dvar_m) {
+    // one WAVE per row m (lanes over n, fixed-order shuffle reductions; no LDS, no barriers, no dynamically indexed arrays)
     const double variance = var_dev ? (double)*var_dev : variance_;
-    __shared__ double red[256];
-    const int m = blockIdx.x, tid = threadIdx.x;
-    double acc[IWVI_MAX_D + 1];
-    for (int d = 0; d <= D; ++d) acc[d] = 0.0;
-    for (int n = tid; n < M; n += 256) {
-        double d2 = 0.0;
-        for (int d = 0; d < D; ++d) { const double e = (double)Zt[m * D + d] - (double)Zt[n * D + d]; d2 += e * e; }
-        double k, g;
-        kern_and_grad<double>(d2, kern_type, variance, k, g);
-        const double sb = 0.5 * (S[(size_t)m * M + n] + S[(size_t)n * M + m]);
-        for (int d = 0; d < D; ++d) acc[d] += 4.0 * sb * g * ((double)Zt[m * D + d] - (double)Zt[n * D + d]);   // both (m, n) and (n, m)
-        acc[D] += sb * k / variance;
+    const int lane = threadIdx.x & 63, m = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= M) return;
+    constexpr int NI = (IWVI_MAX_M + 63) / 64;
+    auto wsum = [](double v) { for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64); return v; };
+    double w[NI], kv = 0.0;
+#pragma unroll
+    for (int it = 0; it < NI; ++it) {
+        const int n = lane + 64 * it;
+        w[it] = 0.0;
+        if (n < M) {
+            double d2 = 0.0;
+            for (int d = 0; d < D; ++d) { const double e = (double)Zt[m * D + d] - (double)Zt[n * D + d]; d2 += e * e; }
+            double k, g;
+            kern_and_grad<double>(d2, kern_type, variance, k, g);
+            const double sb = 0.5 * (S[(size_t)m * M + n] + S[(size_t)n * M + m]);
+            w[it] = 4.0 * sb * g;                                  // both (m, n) and (n, m)
+            kv += sb * k / variance;
+        }
     }
-    for (int d = 0; d <= D; ++d) {
-        red[tid] = acc[d];
-        __syncthreads();
-        for (int o = 128; o > 0; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
-        if (tid == 0) { if (d < D) dZt_uu[m * D + d] = red[0]; else dvar_m[m] = red[0]; }
-        __syncthreads();
+    kv = wsum(kv);
+    if (lane == 0) dvar_m[m] = kv;
+    for (int d = 0; d < D; ++d) {
+        const double zm = (double)Zt[m * D + d];
+        double acc = 0.0;
+#pragma unroll
+        for (int it = 0; it < NI; ++it) { const int n = lane + 64 * it; if (n < M) acc += w[it] * (zm - (double)Zt[n * D + d]); }
+        acc = wsum(acc);
+        if (lane == 0) dZt_uu[m * D + d] = acc;
     }
 }
 struct FinalArgsB {
@@ -2001,8 +2011,8 @@ __global__ __launch_bounds__(256) void k_dmm2(DmmArgs a) {               // 16x1
     a.C[i * a.ldc + j] = s;
 }
 // The same product on v_mfma_f64_16x16x4_f64: one WAVE per 16x16 output tile (lane l feeds A[l & 15][4kk + (l >> 4)] and
-// B[4kk + (l >> 4)][l & 15]; accumulator register e of lane l is C[(l >> 4) + 4e][l & 15]).  The operands of 8 k-steps are
-// requested together (one L2 round trip per 32 of K), so a 128^3 product is ~2 us of latency instead of the LDS kernel's 8
+// B[4kk + (l >> 4)][l & 15]; accumulator register e of lane l is C[(l >> 4) + 4e][l & 15]).  The operands of 32 k-steps are
+// requested together (one L2 round trip per 128 of K), so a 128^3 product is ~2 us of latency instead of the LDS kernel's 8
 // barriers-and-loads rounds per tile (10-13 us); used where I, J are multiples of 16 and K of 4, J > 1.
 using bw_f64x4 = __attribute__((ext_vector_type(4))) double;
 __global__ __launch_bounds__(64) void k_dmm_mfma(DmmArgs a) {
@@ -2011,17 +2021,17 @@ __global__ __launch_bounds__(64) void k_dmm_mfma(DmmArgs a) {
     bw_f64x4 acc = {0.0, 0.0, 0.0, 0.0};
     const double* Ap = a.A + (long long)(i0 + r) * a.a_si + (long long)g * a.a_sk;
     const double* Bp = a.B + (long long)g * a.b_sk + (long long)(j0 + r) * a.b_sj;
-    for (int k0 = 0; k0 < a.K; k0 += 32) {
-        double av[8], bv[8];
+    for (int k0 = 0; k0 < a.K; k0 += 128) {                   // 32 k-steps' operands requested together: ONE L2 round trip per 128 of K
+        double av[32], bv[32];                               // (8 at a time was four dependent round trips for a 128^3 product: 7 us of latency)
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < 32; ++u) {
             const int k = k0 + 4 * u;
             const bool in = k + g < a.K;
             av[u] = in ? Ap[(long long)k * a.a_sk] : 0.0;
             bv[u] = in ? Bp[(long long)k * a.b_sk] : 0.0;
         }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[u], acc, 0, 0, 0);
+        for (int u = 0; u < 32; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[u], acc, 0, 0, 0);
     }
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -2170,7 +2180,7 @@ __global__ void k_d2f(const double* src, float* dst, long long ld, int rows, int
 }
 
 // Adam on GPflow's unconstrained variables.  transform 1 = positive: p = softplus(x) + 1e-6 (gpflow.transforms.Log1pe)
-struct AdamTensor { float* p; const float* g; float* x; float* m; float* v; long long n; int transform; };
+struct AdamTensor { float* p; const float* g; float* x; float* m; float* v; long long n; int transform; int g64; };
 constexpr int ADAM_MAX = 48;
 struct AdamArgs { AdamTensor t[ADAM_MAX]; int n; float lr_t, b1, b2, eps, sign; int init; const long long* t_dev; float lr; };
 __global__ void k_adam(AdamArgs a) {
@@ -2193,7 +2203,7 @@ __global__ void k_adam(AdamArgs a) {
             T.x[i] = x; T.m[i] = 0.f; T.v[i] = 0.f;
             continue;
         }
-        float x = T.x[i], g = a.sign * T.g[i];
+        float x = T.x[i], g = a.sign * (T.g64 ? (float)reinterpret_cast<const double*>(T.g)[i] : T.g[i]);
         if (T.transform == 1) g *= 1.f - __expf(-(T.p[i] - 1e-6f));          // d softplus(x) / dx = sigmoid(x)
         const float m = a.b1 * T.m[i] + (1.f - a.b1) * g;
         const float v = a.b2 * T.v[i] + (1.f - a.b2) * g * g;
@@ -2402,7 +2412,7 @@ extern "C" int iwvi_gp_layer_backward(const iwvi_gp_bwd_desc* dp, int64_t T, voi
         dmm(s_, Lm64, 1, Mp, (const double*)w.Lbar, M, 1, w.T1, M, M, M, M, 1.0, nullptr, 0, 0.0, 1);      // T1 = Phi(Lm^T Lbar)
         dmm(s_, Linv64, 1, Mp, (const double*)w.T1, M, 1, w.T2, M, M, M, M);                                // T2 = Lm^-T T1
         dmm(s_, (const double*)w.T2, M, 1, Linv64, Mp, 1, w.S, M, M, M, M);                                 // S  = T2 Lm^-1
-        hipLaunchKernelGGL(k_kuu_bwd, dim3(M), dim3(256), 0, s_, w.Zt, (const double*)w.S, M, D, (double)d.variance, d.variance_dev, d.kern_type, w.dZt_uu, w.dvar_m);
+        hipLaunchKernelGGL(k_kuu_bwd, dim3((M + 3) / 4), dim3(256), 0, s_, w.Zt, (const double*)w.S, M, D, (double)d.variance, d.variance_dev, d.kern_type, w.dZt_uu, w.dvar_m);
         return check_launch("cholesky adjoint");
     };
     {
@@ -2649,8 +2659,8 @@ extern "C" int iwvi_adam_step(const iwvi_adam_tensor* tensors, int n_tensors, do
     long long nmax = 1;
     for (int i = 0; i < n_tensors; ++i) {
         const iwvi_adam_tensor& s = tensors[i];
-        if (!s.param || !s.x || !s.m || !s.v || (!init && !s.grad) || s.n <= 0 || (s.transform != 0 && s.transform != 1)) { set_error("iwvi_adam_step: bad tensor %d", i); return IWVI_ERR_ARG; }
-        a.t[i] = AdamTensor{s.param, s.grad, s.x, s.m, s.v, (long long)s.n, s.transform};
+        if (!s.param || !s.x || !s.m || !s.v || (!init && !s.grad) || s.n <= 0 || ((s.transform & ~IWVI_ADAM_GRAD_F64) != 0 && (s.transform & ~IWVI_ADAM_GRAD_F64) != 1)) { set_error("iwvi_adam_step: bad tensor %d", i); return IWVI_ERR_ARG; }
+        a.t[i] = AdamTensor{s.param, s.grad, s.x, s.m, s.v, (long long)s.n, s.transform & ~IWVI_ADAM_GRAD_F64, (s.transform & IWVI_ADAM_GRAD_F64) ? 1 : 0};
         if (s.n > nmax) nmax = s.n;
     }
     a.n = n_tensors; a.init = init;
@@ -2668,8 +2678,8 @@ extern "C" int iwvi_adam_step_dev(const iwvi_adam_tensor* tensors, int n_tensors
     long long nmax = 1;
     for (int i = 0; i < n_tensors; ++i) {
         const iwvi_adam_tensor& s = tensors[i];
-        if (!s.param || !s.x || !s.m || !s.v || !s.grad || s.n <= 0 || (s.transform != 0 && s.transform != 1)) { set_error("iwvi_adam_step_dev: bad tensor %d", i); return IWVI_ERR_ARG; }
-        a.t[i] = AdamTensor{s.param, s.grad, s.x, s.m, s.v, (long long)s.n, s.transform};
+        if (!s.param || !s.x || !s.m || !s.v || !s.grad || s.n <= 0 || ((s.transform & ~IWVI_ADAM_GRAD_F64) != 0 && (s.transform & ~IWVI_ADAM_GRAD_F64) != 1)) { set_error("iwvi_adam_step_dev: bad tensor %d", i); return IWVI_ERR_ARG; }
+        a.t[i] = AdamTensor{s.param, s.grad, s.x, s.m, s.v, (long long)s.n, s.transform & ~IWVI_ADAM_GRAD_F64, (s.transform & IWVI_ADAM_GRAD_F64) ? 1 : 0};
         if (s.n > nmax) nmax = s.n;
     }
     a.n = n_tensors; a.init = 0; a.lr = (float)lr; a.t_dev = (const long long*)t_dev;

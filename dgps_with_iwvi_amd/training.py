@@ -111,7 +111,12 @@ class Trainer:
             a = arr[i]
             a.param, a.x, a.m, a.v, a.n, a.transform = p.data_ptr(), x.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), tr
             if not init:
-                g = _abi.dev_tensor(grads[name].reshape(-1).to(settings.float_type).contiguous(), "grad " + name)
+                g = grads[name].reshape(-1)
+                if g.dtype == torch.float64:                     # (the head kernel's float64 sums: read as they are, no conversion launch)
+                    a.transform = tr | _abi.ADAM_GRAD_F64
+                else:
+                    g = g.to(settings.float_type)
+                g = _abi.dev_tensor(g.contiguous(), "grad " + name, g.dtype)
                 if g.numel() != p.numel():
                     raise ValueError("gradient %s has %d entries, parameter has %d" % (name, g.numel(), p.numel()))
                 keep.append(g)

@@ -373,11 +373,13 @@ int iwvi_kde_loglik(const float* samples, int64_t sample_stride, int64_t point_s
  * iwvi_natgrad_step: GPflow NatGradOptimizer (natural parameterisation) on a whitened (q_mu [M, R], q_sqrt [R, M, M]),
  * in place, float64 inside; dq_mu / dq_sqrt = gradients of the ELBO (the objective that is maximised).
  * iwvi_adam_step: TensorFlow AdamOptimizer on GPflow's unconstrained variables; transform 0 = identity,
- * 1 = positive (param = softplus(x) + 1e-6); x/m/v are the optimiser's state (same length as param);
+ * 1 = positive (param = softplus(x) + 1e-6), | IWVI_ADAM_GRAD_F64: `grad` points to doubles (the likelihood-variance
+ * gradient leaves iwvi_iw_elbo_backward in float64); x/m/v are the optimiser's state (same length as param);
  * init != 0 fills them from the current parameter values instead of stepping; t = 1-based step count. */
 size_t iwvi_natgrad_ws_bytes(int M);
 int iwvi_natgrad_step(float* q_mu, float* q_sqrt, const float* dq_mu, const float* dq_sqrt,
                       int M, int R, double gamma, void* ws, void* stream);
+#define IWVI_ADAM_GRAD_F64 16
 typedef struct iwvi_adam_tensor {
     float* param; const float* grad; float* x; float* m; float* v; int64_t n; int32_t transform;
 } iwvi_adam_tensor;
