@@ -789,6 +789,196 @@ __global__ __launch_bounds__(1024) void k_chol_only(const double* A, double* Lou
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// The natural-gradient step of one latent GP (iwvi_natgrad_step; algebra in csrc/backward.hip) in ONE workgroup, everything in
+// LDS, for Mp <= 128 -- instead of 14 launches (conversions, three products, factorisation and triangular inverse in L2):
+//   1  Qrev = J (I + gamma sym(Phi(L^T Lbar))) J, lower blocks, straight from the float32 inputs (f64 MFMA block products)
+//   2  Qrev = C C^T              chol_blocks (the factorisation of the precompute launch)
+//   3  C^-1                      invert_blocks
+//   4  mu' = m - gamma L z,      z = J C^-T C^-1 J (L^T mbar)        (four matrix-vector products)
+//   5  L' = L W,                 W[k][j] = C^-1[M-1-j][M-1-k]         (block products, held in registers until every wave has read L)
+// blockIdx.x = latent GP r.  Lbar = -dq_sqrt, mbar = -dq_mu (the ELBO is maximised).
+using f32x4g = __attribute__((ext_vector_type(4))) float;
+__global__ __launch_bounds__(1024) void k_natgrad_small(float* q_mu, float* q_sqrt, const float* __restrict__ dq_mu, const float* __restrict__ dq_sqrt,
+                                                        int M, int R, double gamma, int stop) {
+    const int tid = threadIdx.x, nthreads = blockDim.x, lane = tid & 63, wave = tid >> 6, nw = nthreads >> 6;
+    const int r = blockIdx.x, Mp = round_up(M, NB);
+    const WsLayout w = ws_layout(Mp);
+    const int nbk = w.nbk, ntri = nbk * (nbk + 1) / 2;
+    double* sm = reinterpret_cast<double*>(smem_raw);
+    double* rinv = sm;
+    double* blk = sm + Mp + w.blk;
+    double* dinv = sm + Mp + w.dinv;
+    double* tbuf = sm + Mp + w.tbuf;
+    double* va = sm + Mp + w.total;                          // four vectors of Mp doubles
+    double* vb = va + Mp; double* vc = vb + Mp; double* vd = vc + Mp;
+    double* ypart = vd + Mp;                                 // [16 waves][128] partial vectors of the first product
+    float* Lf = q_sqrt + (size_t)r * M * M;
+    const float* Gf = dq_sqrt + (size_t)r * M * M;
+    const int ri = lane & 15, g = lane >> 4;
+    auto tri_decode = [](int o, int& bi, int& bj) { bi = 0; while ((bi + 1) * (bi + 2) / 2 <= o) ++bi; bj = o - bi * (bi + 1) / 2; };
+
+    // ---- 1: Qrev(bi, bj)[i][j] = delta - gamma * sum_k L[k][p] dq[k][q],  p = M-1-(16bj+j), q = M-1-(16bi+i)   (p >= q on and below the diagonal)
+    for (int o = wave; o < ntri; o += nw) {
+        int bi, bj; tri_decode(o, bi, bj);
+        const int ig = NB * bi + ri, jg = NB * bj + ri;      // this lane's A row (i) and B column (j)
+        const int q = M - 1 - ig, p = M - 1 - jg;
+        int k0 = M - 1 - (NB * bj + NB - 1); if (k0 < 0) k0 = 0; k0 &= ~3;
+        f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+        for (int kb = k0; kb < M; kb += 64) {                // 16 k-steps' operands per round trip (32 would not fit 128 VGPRs)
+            double av[16], bv[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int k = kb + 4 * u + g;
+                av[u] = (k < M && q >= 0 && k >= q) ? (double)Gf[(size_t)k * M + q] : 0.0;     // A[i][k] = dq[k][q]
+                bv[u] = (k < M && p >= 0 && k >= p) ? (double)Lf[(size_t)k * M + p] : 0.0;     // B[k][j] = L[k][p]
+            }
+#pragma unroll
+            for (int u = 0; u < 16; ++u) if (kb + 4 * u < M) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[u], acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {                        // acc[e] = C[g + 4e][ri]
+            const int i = NB * bi + g + 4 * e, j = NB * bj + ri;
+            double v = (i == j) ? 1.0 : 0.0;
+            if (i < M && j < M) v -= gamma * acc[e];
+            blk[boff(bi, bj) + (g + 4 * e) * BLD + ri] = v;
+        }
+    }
+    // the vectors' inputs meanwhile
+    if (tid < Mp) { va[tid] = tid < M ? (double)q_mu[(size_t)tid * R + r] : 0.0; vb[tid] = tid < M ? -(double)dq_mu[(size_t)tid * R + r] : 0.0; }
+    __syncthreads();
+    if (stop == 1) return;
+    // ---- 2, 3
+    chol_blocks(blk, nbk, rinv, dinv, tid, nthreads, NoGen(), NoPost(), NoTail());
+    if (stop == 2) return;
+    invert_blocks(blk, dinv, tbuf, rinv, nbk, tid, nthreads);
+    if (stop == 3) return;
+    // ---- 4: y1 = L^T mbar (reversed into vc), y2 = C^-1 vc (vd), y3 = C^-T y2 (reversed into vb), mu' = m - gamma L vb.
+    //      A wave per output entry (8 each), lanes over the contraction index, every load of a wave's entries in flight together:
+    //      a thread per entry walking its row was a chain of 128 dependent global / LDS round trips per product.
+    auto wsum = [](double v) { for (int o_ = 32; o_ > 0; o_ >>= 1) v += __shfl_xor(v, o_, 64); return v; };
+    constexpr int NPW = 128 / 16;                            // entries per wave (Mp <= 128, 16 waves)
+    {   // y1[p] = sum_{k >= p} L[k][p] mbar[k]: lanes over p (rows of L read coalesced), wave w takes the rows k = w, w + 16, ..;
+        double p0 = 0.0, p1 = 0.0;
+        float l0[NPW], l1[NPW];
+#pragma unroll
+        for (int u = 0; u < NPW; ++u) {
+            const int k = wave + nw * u;
+            l0[u] = (k < M && lane <= k) ? Lf[(size_t)k * M + lane] : 0.f;
+            l1[u] = (k < M && lane + 64 <= k) ? Lf[(size_t)k * M + lane + 64] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < NPW; ++u) {
+            const int k = wave + nw * u;
+            const double mk = k < M ? vb[k] : 0.0;
+            p0 = fma((double)l0[u], mk, p0); p1 = fma((double)l1[u], mk, p1);
+        }
+        ypart[wave * 128 + lane] = p0; ypart[wave * 128 + 64 + lane] = p1;
+        __syncthreads();
+        if (tid < Mp) {
+            double v = 0.0;
+#pragma unroll
+            for (int w_ = 0; w_ < 16; ++w_) v += ypart[w_ * 128 + tid];
+            if (tid < M) vc[M - 1 - tid] = v; else vc[tid] = 0.0;
+        }
+    }
+    __syncthreads();
+    {
+        double part[NPW];
+#pragma unroll
+        for (int u = 0; u < NPW; ++u) {                      // y2[i] = sum_{k <= i} Cinv[i][k] vc[k]
+            const int i_ = wave + nw * u;
+            double a_ = 0.0;
+            for (int k = lane; k < M; k += 64) if (i_ < M && k <= i_) a_ = fma(inv_get(blk, dinv, i_, k), vc[k], a_);
+            part[u] = a_;
+        }
+#pragma unroll
+        for (int u = 0; u < NPW; ++u) { const int i_ = wave + nw * u; const double v = wsum(part[u]); if (lane == 0 && i_ < Mp) vd[i_] = v; }
+    }
+    __syncthreads();
+    {
+        double part[NPW];
+#pragma unroll
+        for (int u = 0; u < NPW; ++u) {                      // y3[k] = sum_{i >= k} Cinv[i][k] y2[i]
+            const int k_ = wave + nw * u;
+            double a_ = 0.0;
+            for (int i = lane; i < M; i += 64) if (k_ < M && i >= k_) a_ = fma(inv_get(blk, dinv, i, k_), vd[i], a_);
+            part[u] = a_;
+        }
+#pragma unroll
+        for (int u = 0; u < NPW; ++u) { const int k_ = wave + nw * u; const double v = wsum(part[u]); if (lane == 0 && k_ < M) vb[M - 1 - k_] = v; }   // (mbar is no longer needed)
+    }
+    __syncthreads();
+    {
+        double part[NPW];
+#pragma unroll
+        for (int u = 0; u < NPW; ++u) {                      // (L z)[i] = sum_{k <= i} L[i][k] z[k]
+            const int i_ = wave + nw * u;
+            double a_ = 0.0;
+            for (int k = lane; k < M; k += 64) if (i_ < M && k <= i_) a_ = fma((double)Lf[(size_t)i_ * M + k], vb[k], a_);
+            part[u] = a_;
+        }
+#pragma unroll
+        for (int u = 0; u < NPW; ++u) { const int i_ = wave + nw * u; const double v = wsum(part[u]); if (lane == 0 && i_ < M) vd[i_] = va[i_] - gamma * v; }   // mu' (y2 is no longer needed)
+    }
+    if (stop == 4) return;
+    // ---- 5: L'(bi, bj)[i][j] = sum_{k = 16bj .. 16bi+15} L[16bi+i][k] W[k][16bj+j]
+    f64x4 outv[3];
+    for (int t = 0; t < 3; ++t) {
+        const int o = wave + t * nw;
+        outv[t] = f64x4{0.0, 0.0, 0.0, 0.0};
+        if (o >= ntri) continue;
+        int bi, bj; tri_decode(o, bi, bj);
+        const int ig = NB * bi + ri, jg = NB * bj + ri, k0 = NB * bj;
+        f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+        // k order of a 16-deep chunk c: MFMA step s contracts k = kb + 16c + 4g + s (g = lane >> 4), so that a lane's four A entries
+        // are ONE 16-byte load of its row of L (16 rows x 64 B per wave-load instead of 16 rows x 4 B)
+        const bool al16 = (M & 3) == 0;
+        for (int kb = k0; kb < NB * bi + NB; kb += 64) {
+            double av[16], bv[16];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int kq = kb + 16 * c + 4 * g;              // this lane's four consecutive k
+                float a4[4] = {0.f, 0.f, 0.f, 0.f};
+                if (ig < M && kq < NB * bi + NB && kq < M) {
+                    if (al16) { const f32x4g v = *reinterpret_cast<const f32x4g*>(Lf + (size_t)ig * M + kq); a4[0] = v[0]; a4[1] = v[1]; a4[2] = v[2]; a4[3] = v[3]; }
+                    else { for (int s_ = 0; s_ < 4; ++s_) if (kq + s_ < M) a4[s_] = Lf[(size_t)ig * M + kq + s_]; }
+                }
+#pragma unroll
+                for (int s_ = 0; s_ < 4; ++s_) {
+                    const int k = kq + s_;
+                    const bool in = k < NB * bi + NB && k < M;
+                    av[4 * c + s_] = (in && k <= ig) ? (double)a4[s_] : 0.0;                                        // A[i][k] = L[i][k]
+                    bv[4 * c + s_] = (in && jg < M && k >= jg) ? inv_get(blk, dinv, M - 1 - jg, M - 1 - k) : 0.0;     // B[k][j] = W[k][j]
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 16; ++u) if (kb + 16 * (u >> 2) < NB * bi + NB) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[u], acc, 0, 0, 0);
+        }
+        outv[t] = acc;
+    }
+    __syncthreads();                                         // every read of the old L is done
+    for (int t = 0; t < 3; ++t) {
+        const int o = wave + t * nw;
+        if (o >= ntri) continue;
+        int bi, bj; tri_decode(o, bi, bj);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int i = NB * bi + g + 4 * e, j = NB * bj + ri;
+            if (i < M && j < M) Lf[(size_t)i * M + j] = (j <= i) ? (float)outv[t][e] : 0.f;
+        }
+    }
+    for (int idx = tid; idx < M * M; idx += nthreads) {      // (blocks above the diagonal: zero, as tril() leaves them)
+        const int i = idx / M, j = idx - i * M;
+        if ((j >> 4) > (i >> 4)) Lf[idx] = 0.f;
+    }
+    __syncthreads();
+    if (tid < M) q_mu[(size_t)tid * R + r] = (float)vd[tid];
+}
+
+// host side: 0 if the shape is not covered (the caller then takes the multi-launch path)
+int natgrad_small(float* q_mu, float* q_sqrt, const float* dq_mu, const float* dq_sqrt, int M, int R, double gamma, hipStream_t st);
+
 static int ensure_lds_attr(const void* fn, size_t bytes) {
     // remember the largest size configured per kernel: hipFuncSetAttribute is not a stream operation and
     // must stay out of the steady state (and out of hipGraph capture)
@@ -811,6 +1001,17 @@ static size_t factor_lds_bytes(int Mp) {
     size_t d = (size_t)Mp;                                   // rinv
     if (Mp <= 128) d += ws_layout(Mp).total;                 // blocks + dinv + tbuf resident in LDS
     return d * sizeof(double) + ((size_t)Mp * ZLD + Mp + 32) * sizeof(float) + ((size_t)Mp + 1024) * sizeof(double) + 8;
+}
+
+int natgrad_small(float* q_mu, float* q_sqrt, const float* dq_mu, const float* dq_sqrt, int M, int R, double gamma, hipStream_t st) {
+    const int Mp = round_up(M, NB);
+    if (Mp > 128 || getenv("IWVI_NATGRAD_UNFUSED")) return 0;
+    const size_t lds = sizeof(double) * ((size_t)Mp + ws_layout(Mp).total + 4 * (size_t)Mp + 16 * 128);
+    int rc;
+    if ((rc = ensure_lds_attr((const void*)k_natgrad_small, lds)) != IWVI_OK) return rc;
+    hipLaunchKernelGGL(k_natgrad_small, dim3(R), dim3(1024), lds, st, q_mu, q_sqrt, dq_mu, dq_sqrt, M, R, gamma, getenv("IWVI_NG_STOP") ? atoi(getenv("IWVI_NG_STOP")) : 0);
+    rc = check_launch("k_natgrad_small");
+    return rc == IWVI_OK ? 1 : rc;
 }
 
 }  // namespace iwvi

@@ -18,7 +18,7 @@ def _t(a, dev):
     return torch.as_tensor(np.asarray(a, dtype=np.float32), device=dev)
 
 
-@pytest.mark.parametrize("M,R", [(8, 1), (40, 2), (128, 1), (200, 1)])      # 200: the wave-per-column triangular inverse (M > 160)
+@pytest.mark.parametrize("M,R", [(8, 1), (40, 2), (100, 3), (128, 1), (200, 1)])      # M <= 128: one fused workgroup per latent GP; 200: the multi-launch path
 def test_natgrad_step_matches_oracle(gpu_device, M, R):
     import ctypes
     from dgps_with_iwvi_amd import _abi
@@ -35,6 +35,16 @@ def test_natgrad_step_matches_oracle(gpu_device, M, R):
     np.testing.assert_allclose(d_mu.cpu().numpy(), ref_mu, rtol=2e-5, atol=2e-6)
     np.testing.assert_allclose(d_sqrt.cpu().numpy(), ref_sqrt, rtol=2e-5, atol=2e-6)
     assert float(torch.triu(d_sqrt, 1).abs().max()) == 0.0
+    if M <= 128:                                                 # the multi-launch path (kept for M > 128) on the same inputs
+        e_mu, e_sqrt = _t(q_mu, gpu_device), _t(q_sqrt, gpu_device)
+        os.environ["IWVI_NATGRAD_UNFUSED"] = "1"
+        try:
+            _abi.check(_abi.lib().iwvi_natgrad_step(_abi.ptr(e_mu), _abi.ptr(e_sqrt), _abi.ptr(dg_mu), _abi.ptr(dg_sqrt), M, R, 0.05,
+                                                   ws.data_ptr(), _abi.stream_ptr()))
+        finally:
+            del os.environ["IWVI_NATGRAD_UNFUSED"]
+        np.testing.assert_allclose(e_mu.cpu().numpy(), d_mu.cpu().numpy(), rtol=2e-6, atol=2e-7)
+        np.testing.assert_allclose(e_sqrt.cpu().numpy(), d_sqrt.cpu().numpy(), rtol=2e-6, atol=2e-7)
 
 
 def test_adam_steps_match_oracle(gpu_device):
