@@ -274,8 +274,6 @@ def iw_elbo_and_gradients(model, zs=None, mode_vi=None, exchange=None, K_total=N
     if wrt not in ("all", "final_q"):
         raise ValueError("wrt is 'all' or 'final_q'")
     final_q = wrt == "final_q"
-    if final_q and needs_saved_u(layers[-1], T):                 # (shapes off the streaming chain: the full adjoint gives the same two entries)
-        final_q = False
     prep_stream = _side_stream(dev, 2) if (overlap and not final_q) else cur
     prepared = {} if final_q else prepare_side(model, T, prep_stream)
     # forward: one factorisation launch (packed operands, encoders) + ONE fused layer launch that also leaves what the
@@ -372,9 +370,6 @@ def iw_elbo_and_gradients(model, zs=None, mode_vi=None, exchange=None, K_total=N
     if side is not None:
         cur.wait_stream(side)                                    # join: the parameter gradients are complete on the caller's stream
     del held
-    if wrt == "final_q":                                         # (a shape off the streaming chain: formed by the full adjoint above)
-        i = len(layers) - 1
-        grads = {k: grads[k] for k in ("l%d.q_mu" % i, "l%d.q_sqrt" % i)}
     return elbo, grads
 
 

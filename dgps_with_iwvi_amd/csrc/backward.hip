@@ -2275,14 +2275,15 @@ extern "C" int iwvi_gp_layer_backward(const iwvi_gp_bwd_desc* dp, int64_t T, voi
     // Only dq_mu / dq_sqrt asked for (the natural-gradient op, build_models.py:288-295, moves nothing else): on the streaming chain's
     // shapes that is the heads + two sums over samples -- no da / dk, no kernel adjoint, no adjoint of the factorisation, and
     // nothing of iwvi_gp_layer_backward_prepare (the state may then be the packed one: the dense factors are not read).
-    const bool q_only = !d.dZ && !d.dls && !d.dvariance && !d.dF && !d.dW && !d.dmf_A && d.GMV && chain_fits(T, M, Mp, D, R, d.P);
+    const bool q_any = !d.dZ && !d.dls && !d.dvariance && !d.dF && !d.dW && !d.dmf_A;
+    const bool q_only = q_any && d.GMV && chain_fits(T, M, Mp, D, R, d.P);
     // desc.phase splits the call at the point where dF is queued: 1 = the per-sample chain only, 2 = the parameter branch only (same
     // descriptor, same workspace; the caller orders 2 after 1 -- on any stream -- and may queue other work in between: a captured
     // graph then keeps the layers' chains on one hardware queue).  Shapes off the streaming chain do everything in phase 1.
     const int phase = (q_only || !(d.GMV && chain_fits(T, M, Mp, D, R, d.P))) ? (d.phase == 2 ? -1 : 0) : d.phase;
     if (phase == -1) return IWVI_OK;
     if (phase < 0 || phase > 2) { set_error("iwvi_gp_layer_backward: phase %d", d.phase); return IWVI_ERR_ARG; }
-    if (phase != 2 && !q_only && !d.prepared && (rc = iwvi_gp_layer_backward_prepare(dp, T, ws_, stream_)) != IWVI_OK) return rc;
+    if (phase != 2 && !q_any && !d.prepared && (rc = iwvi_gp_layer_backward_prepare(dp, T, ws_, stream_)) != IWVI_OK) return rc;
     const float* gmv = d.GMV ? d.GMV : w.GMV;
     // deferred reductions of this layer: every product over samples parks its partial sums in its own slice of the workspace
     const bool prod = d.GMV && chain_products_ok(M, T);    // dLm and G_r shares come out of the chain kernel
@@ -2347,6 +2348,22 @@ extern "C" int iwvi_gp_layer_backward(const iwvi_gp_bwd_desc* dp, int64_t T, voi
             }
             return IWVI_OK;
         }
+    }
+    if (q_any && !chain) {
+        // the same two gradients on the GEMM path (shapes off the streaming chain, e.g. M = 512): heads, dq_mu = A^T DMU, dL_r = tril(A^T
+        // diag(2 dv_r) U_r) -- nothing of the kernel adjoint, the triangular solves or the adjoint of the factorisation
+        HeadArgs h{d.A, d.U, d.noise, d.W, d.mf_A, d.d_sample, d.d_mean, d.d_var, w.DMU, w.DV2, w.SDV, nullptr, T, M, Mp, D, R, d.P, d.mf_type, d.variance, d.variance_dev,
+                   d.q_mu, nullptr, d.GMV};
+        hipLaunchKernelGGL(k_bw_heads, dim3((unsigned)((T + 3) / 4)), dim3(256), 0, st, h);
+        if ((rc = check_launch("k_bw_heads")) != IWVI_OK) return rc;
+        if (d.dq_mu && (rc = thin(st, d.A, Mp, M, w.DMU, R, R, 0, T, w.part, w.part_floats, d.dq_mu, 0, &rqB, d.q_mu, -d.kl_weight)) != IWVI_OK) return rc;
+        if (d.dq_sqrt) {
+            GemmArgs q{};
+            q.A = d.A; q.a_sm = 1; q.a_sk = Mp; q.B = d.U; q.b_sk = Mp; q.b_sn = 1;
+            q.scale = w.DV2; q.s_stride = R; q.scale_on_k = 1; q.M = M; q.N = M; q.K = (int)T; q.tri_out = 1;
+            if ((rc = gemm(st, q, w.part, w.part_floats, d.dq_sqrt, nullptr, M, 1.0, 0.0, 1, R, (long long)T * Mp, 1, (long long)M * M, &rqB, d.q_sqrt, -d.kl_weight, 1)) != IWVI_OK) return rc;
+        }
+        return rqB.flush(st);
     }
     MidArgs ma{d.GMV, d.noise, d.W, d.mf_A, d.d_sample, d.d_mean, d.d_var, w.DMU, w.DV2, w.SDV, d.dF, d.P, d.mf_type,
                d.U, d.A, Mp, d.q_sqrt, d.q_mu, w.LinvF, w.DK, d.F, w.Zt, w.invls, w.DA, w.Qx, (long long)T, M, D, R, d.variance, d.kern_type, d.variance_dev};

@@ -313,9 +313,9 @@ int iwvi_gp_layer_backward_needs_u(int64_t T, int M, int D, int R, int P);
  * be queued on another stream beside the forward; then set desc.prepared.  Called implicitly otherwise. */
 int iwvi_gp_layer_backward_prepare(const iwvi_gp_bwd_desc* desc, int64_t T, void* ws, void* stream);
 /* Outputs left NULL are not formed.  With ONLY dq_mu / dq_sqrt given (what the natural-gradient op of build_models.py:288-295 reads)
- * and a shape on the streaming chain (iwvi_gp_layer_backward_needs_u == 0, GMV given) the call reduces to the heads and the two sums
- * over samples behind those gradients: no prepare step, no dense factors in `state`, no adjoint of the factorisation; the values are
- * bit-identical to the full call's. */
+ * the call reduces to the heads and the two sums over samples behind those gradients (on either path: the streaming chain, or the
+ * GEMMs over a_out / u_out): no prepare step, no dense factors in `state`, no kernel adjoint, no adjoint of the factorisation; the
+ * values are bit-identical to the full call's. */
 int iwvi_gp_layer_backward(const iwvi_gp_bwd_desc* desc, int64_t T, void* ws, void* stream);
 
 /* Adjoint of the ELBO tail (models.py:134-150) for the IW tiling (sample t = b*K + k):

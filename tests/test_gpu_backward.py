@@ -173,12 +173,13 @@ def test_iw_elbo_gradients_match_oracle(gpu_device, L, M, K, B, lv):
         assert torch.equal(g_q[k], runs[0][k]), k
 
 
-@pytest.mark.parametrize("cfg", [1, 2, 3])
+@pytest.mark.parametrize("cfg", [1, 2, 3, dict(L=2, M=512, K=16, B=64, with_lv=True), dict(L=3, M=200, K=7, B=9, with_lv=False)])
 def test_final_q_gradients_at_full_size_equal_the_full_adjoints(gpu_device, cfg):
-    """BASELINE.json configs[1..3] at full size: in-chain G_r shares (configs[1], [2]), split-K GEMM for G_r (configs[3], M = 256)."""
+    """BASELINE.json configs[1..3] at full size: in-chain G_r shares (configs[1], [2]), split-K GEMM for G_r (configs[3], M = 256); and two
+    shapes off the streaming chain (M = 512; ragged M, T), where the two gradients come from the GEMMs over a_out / u_out."""
     from bench import CONFIGS
     from dgps_with_iwvi_amd import synthetic, backward
-    spec = synthetic.make_spec(seed=0, parity=True, n_data=8192, **CONFIGS[cfg])
+    spec = synthetic.make_spec(seed=0, parity=True, n_data=8192, **(CONFIGS[cfg] if isinstance(cfg, int) else cfg))
     model = synthetic.build_model(spec, gpu_device)
     zd = [torch.as_tensor(np.asarray(z, dtype=np.float32), device=gpu_device) for z in synthetic.make_noise(spec, seed=4)]
     e, g = backward.iw_elbo_and_gradients(model, zd)
