@@ -102,7 +102,9 @@ def attach_train_op(model, ARGS):
             from .training import Trainer
             state["t"] = Trainer(model, lr=getattr(ARGS, "lr", 5e-3), gamma=getattr(ARGS, "gamma", 1e-2),
                                  lr_decay=getattr(ARGS, "lr_decay", 0.98), gamma_decay=getattr(ARGS, "gamma_decay", 0.98),
-                                 fix_linear=getattr(ARGS, "fix_linear", True))
+                                 fix_linear=getattr(ARGS, "fix_linear", True),
+                                 # every op of a step replayed from a hipGraph (the reference's session.run of a prebuilt graph, in effect)
+                                 use_graph=bool(getattr(ARGS, "use_graph", True)))
         return state["t"]
 
     model.trainer = trainer

@@ -26,7 +26,7 @@ def staircase_decay(base, step, rate, every=1000):
 class Trainer:
     def __init__(self, model, lr=5e-3, gamma=1e-2, lr_decay=0.98, gamma_decay=0.98, fix_linear=True,
                  beta1=0.9, beta2=0.999, epsilon=1e-8, group=None, shard_weight=None, shard="n", num_data_total=None,
-                 use_graph=False, check_finite=True):
+                 use_graph=False, check_finite=True, check_every=100):
         """``group`` / ``shard_weight``: data-parallel training over the ranks of a torch.distributed group (each rank's
         model holds its own minibatch rows, N-shard): gradients are merged by ``sharding.allreduce_gradients`` with
         weight B_rank / B_job (default: from the all-reduced local batch sizes) before either update, so every rank
@@ -42,7 +42,8 @@ class Trainer:
         descriptors); the model's host copies are refreshed lazily when read.  ``use_graph=True`` (single GPU, noise drawn on the
         device): each of the two ops of a step is captured once into a hipGraph and replayed -- no host work per launch, no
         device-to-host copy per step; the graphs are re-captured when the staircase decay changes lr / gamma.  ``check_finite``:
-        eager mode only, one small D2H per step that raises when the bound or the final layer's q(u) went non-finite."""
+        one small D2H that raises when the bound or the final layer's q(u) went non-finite (the reference's Cholesky raises) -- every
+        step in eager mode, every ``check_every`` steps in graph mode."""
         self.model = model
         self.group, self.shard_weight, self.shard = group, shard_weight, shard
         if shard == "n" and (group is not None or num_data_total is not None):
@@ -56,7 +57,7 @@ class Trainer:
         self.betas, self.epsilon = (beta1, beta2), epsilon
         self.global_step = 0
         self.adam_t = 0
-        self.use_graph, self.check_finite = bool(use_graph), bool(check_finite)
+        self.use_graph, self.check_finite, self.check_every = bool(use_graph), bool(check_finite), max(1, int(check_every))
         if self.use_graph and group is not None:
             raise ValueError("use_graph captures a single-GPU step; sharded training launches its collectives eagerly")
         self._graphs = {}                                      # op name -> (decay epoch, CUDAGraph, elbo tensor)
@@ -158,14 +159,17 @@ class Trainer:
         self._adam_call(g, lr=staircase_decay(self.lr, self.global_step, self.lr_decay))
         for _, owner in self._scalars:                         # host copies are refreshed lazily, when somebody reads them
             owner.mark_device_variance_changed()
-        if self.check_finite and not self._capturing:
-            # one small D2H: the bound and the final layer's q(u) must be finite (a natural-gradient step that leaves
-            # -2 theta_2 indefinite makes TensorFlow's Cholesky raise in the reference; here it would go on as NaN)
-            ok = torch.isfinite(elbo) & torch.isfinite(self.final.q_sqrt).all() & torch.isfinite(self.final.q_mu).all()
-            if not bool(ok.item()):
-                raise FloatingPointError("training step %d: non-finite bound or final-layer q(u) (the natural-gradient step left the "
-                                         "precision matrix indefinite: lower gamma)" % self.global_step)
+        if self.check_finite and not self._capturing and not self.use_graph:
+            self._raise_if_not_finite(elbo)
         return elbo
+
+    def _raise_if_not_finite(self, elbo):
+        # one small D2H: the bound and the final layer's q(u) must be finite (a natural-gradient step that leaves
+        # -2 theta_2 indefinite makes TensorFlow's Cholesky raise in the reference; here it would go on as NaN)
+        ok = torch.isfinite(elbo) & torch.isfinite(self.final.q_sqrt).all() & torch.isfinite(self.final.q_mu).all()
+        if not bool(ok.item()):
+            raise FloatingPointError("training step %d: non-finite bound or final-layer q(u) (the natural-gradient step left the "
+                                     "precision matrix indefinite: lower gamma)" % self.global_step)
 
     _capturing = False
 
@@ -206,7 +210,10 @@ class Trainer:
             self.model.next_minibatch()                        # outside the graph: an in-place gather into the model's X / Y buffers
             self._replay("ng", lambda: self.natgrad_op(None, _advance=False))
             self.model.next_minibatch()
-            return self._replay("adam", lambda: self.adam_op(None, _advance=False))
+            elbo = self._replay("adam", lambda: self.adam_op(None, _advance=False))
+            if self.check_finite and self.global_step % self.check_every == 0:
+                self._raise_if_not_finite(elbo)
+            return elbo
         self.natgrad_op(zs_ng)
         return self.adam_op(zs_adam)
 

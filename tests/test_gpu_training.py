@@ -288,3 +288,10 @@ def test_a_diverged_natural_gradient_step_is_reported(gpu_device):
     with pytest.raises(FloatingPointError):
         for _ in range(3):
             tr.step()
+    # graph mode: the same check, every ``check_every`` steps
+    model = synthetic.build_model(spec, gpu_device)
+    tr = Trainer(model, gamma=1e6, use_graph=True, check_every=4)
+    with pytest.raises(FloatingPointError):
+        for _ in range(8):
+            tr.step()
+    assert tr.global_step == 4
