@@ -277,6 +277,28 @@ def test_graph_mode_training_step_equals_the_eager_one(gpu_device):
     assert out[0][2] != spec["lik_var"]                          # the likelihood variance did move (and was read back lazily)
 
 
+def test_graph_mode_follows_the_staircase_decay(gpu_device):
+    """lr / gamma enter the captured update kernels by value: crossing a decay boundary (every 1000 steps, build_models.py:276-282)
+    re-captures the two graphs, and the trajectory stays the eager one's bit for bit."""
+    from dgps_with_iwvi_amd import synthetic, settings
+    from dgps_with_iwvi_amd.training import Trainer
+    spec = synthetic.make_spec(L=2, M=16, B=16, K=2, with_lv=True, seed=5)
+    out = []
+    for use_graph in (False, True):
+        settings.set_seed(9)
+        model = synthetic.build_model(spec, gpu_device)
+        tr = Trainer(model, use_graph=use_graph, check_finite=False, lr=1e-3, gamma=1e-3)
+        tr.global_step = 996                                   # (the decay epoch is global_step // 1000)
+        vals = [float(tr.step()) for _ in range(8)]
+        out.append((vals, [p.clone() for _, p, _ in tr._entries], model.layers[-1].q_sqrt.clone()))
+        if use_graph:
+            assert tr._graphs["adam"][0] == 1 and tr._graphs["ng"][0] == 1      # re-captured for epoch 1
+    assert out[0][0] == out[1][0], (out[0][0], out[1][0])
+    for pa, pb in zip(out[0][1], out[1][1]):
+        assert torch.equal(pa, pb)
+    assert torch.equal(out[0][2], out[1][2])
+
+
 def test_a_diverged_natural_gradient_step_is_reported(gpu_device):
     """gamma far too large: -2 theta_2 turns indefinite, the Cholesky inside the step produces NaN; the trainer says so (the
     reference's TensorFlow Cholesky would raise at the same point) instead of training on."""
