@@ -928,19 +928,20 @@ struct ChainArgs {
     float* p_g;                          // [R][S][M][M]   sum_j 2dv_r[j] a[m][j] a[n][j]            -> G_r (dL_r = tril(G_r L_r))
     int S;                               // workgroups of the launch (stride of a batch in p_g)
     int q_only;                          // only dq_mu / dq_sqrt are wanted (the natural-gradient op): heads, dq_mu shares, G_r shares
+    int ts;                              // float4 per tile row (16 NS, + 4 of padding where it fits)
     const float* ZtP; const float* cst; int nsteps;   // the state's K_uf operand (A-fragment order), its constant block (1/ls | centre | extent), k-steps
 };
 template <int NS, int DM>               // 16 NS samples per workgroup (8 waves);  D <= DM
 __global__ __launch_bounds__(512) void k_bw_chain(ChainArgs a) {
     constexpr int NSAMP = 16 * NS;
-    constexpr int TS = NSAMP + 4;        // float4 per tile row: NSAMP samples + 4 of padding, so that the TRANSPOSED scalar reads of a tile
-                                         // (products over samples: lanes 4 rows x 4 samples x 4 entries) spread over all 32 banks
+    const int TS = a.ts;                 // float4 per tile row: NSAMP samples (+ 4 of padding where the LDS allows it, so that the TRANSPOSED
+                                         // scalar reads of a tile -- products over samples: lanes 4 rows x 4 samples x 4 entries -- spread over all banks)
     extern __shared__ __attribute__((aligned(16))) float csm[];
     const int M = a.M, nbk = a.nbk, R = a.R, D = a.D, P = a.P;
-    // three tiles in the forward's B-operand layout, float4 [(bk*4 + g) * TS + sample] = 4 consecutive m of one sample:
+    // two tiles in the forward's B-operand layout, float4 [(bk*4 + g) * TS + sample] = 4 consecutive m of one sample:
     float* tileA = csm;                                      // a (kept to the end: the products over samples read it)
-    float* tileK = tileA + TS * M;                        // dk, then c = dk o dk/dd2 (kernel adjoint)
-    float* tileD = tileK + TS * M;                        // da; also stages the heads' inputs before and the scaled inducing inputs after
+    float* tileK = tileA + TS * M;                        // da, then dk (in place: phase 2), then c = dk o dk/dd2 (kernel adjoint)
+    float* tileD = tileK + TS * M;                        // staging: the heads' inputs before, the kernel adjoint's operands after
     float* qmu_s = tileD + a.dsz;                            // [M][R]
     float* dmu_s = qmu_s + M * R;                            // [NSAMP][R]
     float* dv2_s = dmu_s + NSAMP * R;                        // [NSAMP][R]
@@ -952,7 +953,6 @@ __global__ __launch_bounds__(512) void k_bw_chain(ChainArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, gq = lane >> 4, jq = lane & 15;
     const long long t0 = (long long)blockIdx.x * NSAMP;
     f32x4* tA4 = reinterpret_cast<f32x4*>(tileA);
-    f32x4* tD4 = reinterpret_cast<f32x4*>(tileD);
     f32x4* tK4 = reinterpret_cast<f32x4*>(tileK);
 
     // ---- phase 0: a rows -> LDS (B-operand layout), q_mu -> LDS; the heads' inputs (rows of the upstream gradients, of the
@@ -1123,23 +1123,26 @@ __global__ __launch_bounds__(512) void k_bw_chain(ChainArgs a) {
                 for (int rr = 0; rr < R; ++rr) v = fmaf(dmu_s[j * R + rr], qmu_s[m * R + rr], v);
                 tot[t][e] = v;
             }
-            tD4[(bi * 4 + gq) * TS + j] = tot[t];
+            tK4[(bi * 4 + gq) * TS + j] = tot[t];
         }
     }
     __syncthreads();
     if (a.dbg_exit == 2) return;
 
     // ---- phase 2: dk(bi) = sum_{bk >= bi} Lm^-T(bi, bk) da(bk); row-blocks paired so that every wave streams nbk + 1 blocks
+    //      IN PLACE over da: every wave holds its (at most two) result row-blocks in registers until all have read da.
     const int npair = (nbk + 1) / 2, nw2 = nbk <= 8 ? 4 : 8;         // (nbk <= 8: four pairs at most, waves 4-7 sit this short phase out)
-    for (int p_ = wave; p_ < npair && wave < nw2 && !a.q_only; p_ += nw2)
+    f32x4 res[2][NS];
+    int rbi[2] = {-1, -1};
+    if (wave < nw2 && wave < npair && !a.q_only)
     for (int pass = 0; pass < 2; ++pass) {
+        const int p_ = wave;
         const int bi = pass == 0 ? p_ : nbk - 1 - p_;
         if (pass == 1 && bi <= p_) continue;                    // (the middle row-block of an odd nbk: once)
         bw_gptr4 Pb = (bw_gptr4)a.LinvTP + (size_t)tri_upper_off(nbk, bi) * 64 + lane;
         const int nblocks = nbk - bi;
-        f32x4 acc[NS];
 #pragma unroll
-        for (int t = 0; t < NS; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < NS; ++t) res[pass][t] = f32x4{0.f, 0.f, 0.f, 0.f};
         f32x4 a_nx = Pb[0];
         for (int q = 0; q < nblocks; ++q) {
             const f32x4 a_cur = a_nx;
@@ -1147,18 +1150,25 @@ __global__ __launch_bounds__(512) void k_bw_chain(ChainArgs a) {
             const int bk = bi + q;
             f32x4 b[NS];
 #pragma unroll
-            for (int t = 0; t < NS; ++t) b[t] = tD4[(bk * 4 + gq) * TS + 16 * t + jq];
+            for (int t = 0; t < NS; ++t) b[t] = tK4[(bk * 4 + gq) * TS + 16 * t + jq];
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
 #pragma unroll
-                for (int t = 0; t < NS; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[s], b[t][s], acc[t], 0, 0, 0);
+                for (int t = 0; t < NS; ++t) res[pass][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[s], b[t][s], res[pass][t], 0, 0, 0);
             }
         }
+        rbi[pass] = bi;
+    }
+    __syncthreads();                                         // every read of da is done
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        if (rbi[pass] < 0) continue;
+        const int bi = rbi[pass];
 #pragma unroll
         for (int t = 0; t < NS; ++t) {
             const int j = 16 * t + jq;
-            tK4[(bi * 4 + gq) * TS + j] = acc[t];
-            if (a.DK) *reinterpret_cast<f32x4*>(a.DK + (size_t)(t0 + j) * M + 16 * bi + 4 * gq) = acc[t];   // (only for the split-K GEMM path of dLm)
+            tK4[(bi * 4 + gq) * TS + j] = res[pass][t];
+            if (a.DK) *reinterpret_cast<f32x4*>(a.DK + (size_t)(t0 + j) * M + 16 * bi + 4 * gq) = res[pass][t];   // (only for the split-K GEMM path of dLm)
         }
     }
     __syncthreads();
@@ -1451,34 +1461,48 @@ __global__ __launch_bounds__(256) void k_pack_bw(const float* __restrict__ q_sqr
     const int bk = bi + b;
     LinvTP[((size_t)tri_upper_off(nbk, bi) + (bk - bi)) * 256 + off] = (float)Linv64[(size_t)(16 * bk + k) * Mp + 16 * bi + i];
 }
-static int chain_ns(long long T, int M = 128) {             // samples per workgroup / 16: as the forward's, then down to a divisor of T
+static int chain_ns_cap(long long T, int cap) {             // samples per workgroup / 16: as the forward's (every CU a workgroup), then down to a divisor of T
     int ns = (int)((T + 16 * 256 - 1) / (16 * 256));
-    const int cap = M <= 128 ? 5 : (M <= 256 ? 2 : 1);      // three [M x 16 NS] float tiles in 160 KB of LDS
     if (ns > cap) ns = cap;
     if (ns < 1) ns = 1;
     while (ns > 1 && T % (16 * ns)) --ns;
     return ns;
 }
+// the conservative choice (two [M x 16 NS] float tiles + staging in 160 KB of LDS for any D, R, P): what the workspace is sized for
+static int chain_ns(long long T, int M = 128) { return chain_ns_cap(T, M <= 128 ? 5 : (M <= 256 ? 2 : 1)); }
 static bool chain_ok(int M, int Mp, long long T) {
-    // M <= 256: at M = 512 only 16 samples fit a workgroup's three tiles, so every packed S_r block (R * 32 * 32 KiB per layer)
+    // M <= 256: at M = 512 only 16 samples fit a workgroup's tiles, so every packed S_r block (R * 32 * 32 KiB per layer)
     // would be fetched from L2 for 4 MFMAs -- measured 383 ms per value + gradient at configs[4] against 359 ms on the GEMM path
     return Mp == M && M <= 256 && (T % 16) == 0 && !getenv("IWVI_BW_UNFUSED") && !getenv("IWVI_BW_OLD_CHAIN") &&
            !(M > 128 && getenv("IWVI_BW_CHAIN_SMALL_M_ONLY"));
 }
-// floats of the da tile's region: the tile itself, or what is staged there before (heads) / after it (kernel adjoint: x~ rows, z~, shares)
+// floats of the staging region beside the two tiles: what is staged there before (heads) / after (kernel adjoint: x~ rows, z~, shares)
 static int chain_dsz(int NSAMP, int M, int D, int R, int P, int DM) {
-    int dsz = (NSAMP + 4) * M;                               // (tile rows are padded by 4 float4: k_bw_chain's TS)
     const int heads = 3 * NSAMP * P + P * R + 4 * NSAMP * R + D * P, adj = NSAMP * round_up(D + 2, 4) + M * DM + 16 * NSAMP;
-    if (heads > dsz) dsz = heads;
-    if (adj > dsz) dsz = adj;
-    return (dsz + 3) & ~3;
+    return ((heads > adj ? heads : adj) + 3) & ~3;
 }
-// LDS bytes of k_bw_chain for a layer shape (the one formula: launch, path selection and iwvi_gp_layer_backward_needs_u use it)
-static size_t chain_lds_bytes(long long T, int M, int D, int R, int P) {
-    const int NSAMP = 16 * chain_ns(T, M), DM = D <= 8 ? 8 : (D <= 16 ? 16 : 32);
-    const int dsz = chain_dsz(NSAMP, M, D, R, P, DM);
-    return sizeof(float) * ((size_t)2 * (NSAMP + 4) * M + (size_t)dsz + (size_t)M * R + (size_t)NSAMP * (2 * R + 1) + (size_t)NSAMP * D
+// LDS bytes of k_bw_chain for a layer shape and a tile row stride ts (float4)
+static size_t chain_lds_bytes_ts(int NSAMP, int ts, int M, int D, int R, int P) {
+    const int DM = D <= 8 ? 8 : (D <= 16 ? 16 : 32);
+    return sizeof(float) * ((size_t)2 * ts * M + (size_t)chain_dsz(NSAMP, M, D, R, P, DM) + (size_t)M * R + (size_t)NSAMP * (2 * R + 1) + (size_t)NSAMP * D
                             + (size_t)NSAMP * DM + DM + (size_t)NSAMP * (D + 2));
+}
+// the padded row stride where it fits, else the plain one
+static int chain_ts(int NSAMP, int M, int D, int R, int P) { return chain_lds_bytes_ts(NSAMP, NSAMP + 4, M, D, R, P) <= 160 * 1024 ? NSAMP + 4 : NSAMP; }
+// samples per workgroup / 16 for a layer shape: 128 < M <= 256 takes 64 samples where the shape's tiles and staging fit (every packed
+// S_r block fetched from L2 then feeds 16 MFMAs instead of 8), else the conservative choice.  Never fewer workgroups than chain_ns()
+// implies more partial sums: the workspace (sized with chain_ns) covers both.
+static int chain_ns_shape(long long T, int M, int D, int R, int P) {
+    const int base = chain_ns(T, M);
+    if (M > 128 && M <= 256 && !getenv("IWVI_BW_CHAIN_NS2")) {
+        const int ns4 = chain_ns_cap(T, 4);
+        if (ns4 > base && chain_lds_bytes_ts(16 * ns4, 16 * ns4, M, D, R, P) <= 160 * 1024) return ns4;
+    }
+    return base;
+}
+static size_t chain_lds_bytes(long long T, int M, int D, int R, int P) {
+    const int NSAMP = 16 * chain_ns_shape(T, M, D, R, P);
+    return chain_lds_bytes_ts(NSAMP, chain_ts(NSAMP, M, D, R, P), M, D, R, P);
 }
 static bool chain_fits(long long T, int M, int Mp, int D, int R, int P) { return chain_ok(M, Mp, T) && chain_lds_bytes(T, M, D, R, P) <= 160 * 1024; }
 // the two M x M products over samples inside the chain kernel: only while the number of per-workgroup shares stays moderate
@@ -1490,8 +1514,8 @@ static int launch_chain_ns(hipStream_t st, ChainArgs a) {
     constexpr int NSAMP = 16 * NS;
     const int DM = a.D <= 8 ? 8 : (a.D <= 16 ? 16 : 32);
     a.dsz = chain_dsz(NSAMP, a.M, a.D, a.R, a.P, DM);
-    const size_t lds = sizeof(float) * ((size_t)2 * (NSAMP + 4) * a.M + (size_t)a.dsz + (size_t)a.M * a.R + (size_t)NSAMP * (2 * a.R + 1) + (size_t)NSAMP * a.D
-                                        + (size_t)NSAMP * DM + DM + (size_t)NSAMP * (a.D + 2));
+    a.ts = chain_ts(NSAMP, a.M, a.D, a.R, a.P);
+    const size_t lds = chain_lds_bytes_ts(NSAMP, a.ts, a.M, a.D, a.R, a.P);
     static bool done = false;
     if (!done) {
         const size_t most = 160 * 1024;
@@ -1508,7 +1532,7 @@ static int launch_chain_ns(hipStream_t st, ChainArgs a) {
     return check_launch("k_bw_chain");
 }
 static int launch_chain(hipStream_t st, const ChainArgs& a) {
-    switch (chain_ns(a.T, a.M)) {
+    switch (chain_ns_shape(a.T, a.M, a.D, a.R, a.P)) {
         case 1: return launch_chain_ns<1>(st, a);
         case 2: return launch_chain_ns<2>(st, a);
         case 3: return launch_chain_ns<3>(st, a);
@@ -2302,7 +2326,7 @@ extern "C" int iwvi_gp_layer_backward(const iwvi_gp_bwd_desc* dp, int64_t T, voi
                      d.A, Mp, d.q_mu, w.SP, w.LinvTP, w.DK, d.F, w.Zt, w.invls, w.DA, w.Qx, (long long)T, M, D, R, nbk, d.variance, d.kern_type,
                      getenv("IWVI_CHAIN_EXIT") ? atoi(getenv("IWVI_CHAIN_EXIT")) : 0, d.variance_dev};
         // the thin sums over samples ride in the chain kernel: one partial per workgroup and job, summed with the rest of chain B
-        const int S = (int)(T / (16 * chain_ns(T, M))), P = d.P;
+        const int S = (int)(T / (16 * chain_ns_shape(T, M, D, R, d.P))), P = d.P;
         auto job = [&](int Mj, int Nj, float* out, const float* add, double add_coef) -> float* {
             float* pp = rqB.take((size_t)S * Mj * Nj);
             if (!pp) return nullptr;
