@@ -33,7 +33,7 @@ class GpSaved:
 
 
 def needs_saved_u(layer, T):
-    """The adjoint's streaming chain (csrc/backward.hip: k_bw_chain; M <= 256, M and T multiples of 16, its tiles within the LDS) works
+    """The adjoint's streaming chain (csrc/backward.hip: k_bw_chain; M <= 512, M and T multiples of 16 -- T of 32 beyond M = 256 --, its tiles within the LDS) works
     from a = Lm^-1 k alone; every other shape takes the GEMM path, which also reads the forward's u_r = L_r^T a.  The library
     decides (``iwvi_gp_layer_backward_needs_u``)."""
     R = layer.num_outputs

@@ -929,6 +929,7 @@ struct ChainArgs {
     int S;                               // workgroups of the launch (stride of a batch in p_g)
     int q_only;                          // only dq_mu / dq_sqrt are wanted (the natural-gradient op): heads, dq_mu shares, G_r shares
     int ts;                              // float4 per tile row (16 NS, + 4 of padding where it fits)
+    int z_lds;                           // the scaled inducing inputs are staged in LDS for the kernel adjoint (M <= 256; beyond: read from L2)
     const float* ZtP; const float* cst; int nsteps;   // the state's K_uf operand (A-fragment order), its constant block (1/ls | centre | extent), k-steps
 };
 template <int NS, int DM>               // 16 NS samples per workgroup (8 waves);  D <= DM
@@ -1132,43 +1133,49 @@ __global__ __launch_bounds__(512) void k_bw_chain(ChainArgs a) {
     // ---- phase 2: dk(bi) = sum_{bk >= bi} Lm^-T(bi, bk) da(bk); row-blocks paired so that every wave streams nbk + 1 blocks
     //      IN PLACE over da: every wave holds its (at most two) result row-blocks in registers until all have read da.
     const int npair = (nbk + 1) / 2, nw2 = nbk <= 8 ? 4 : 8;         // (nbk <= 8: four pairs at most, waves 4-7 sit this short phase out)
-    f32x4 res[2][NS];
-    int rbi[2] = {-1, -1};
-    if (wave < nw2 && wave < npair && !a.q_only)
-    for (int pass = 0; pass < 2; ++pass) {
-        const int p_ = wave;
-        const int bi = pass == 0 ? p_ : nbk - 1 - p_;
-        if (pass == 1 && bi <= p_) continue;                    // (the middle row-block of an odd nbk: once)
-        bw_gptr4 Pb = (bw_gptr4)a.LinvTP + (size_t)tri_upper_off(nbk, bi) * 64 + lane;
-        const int nblocks = nbk - bi;
+    f32x4 res[4][NS];                                        // (nbk <= 32: two pairs = four row-blocks per wave at most)
+    int rbi[4] = {-1, -1, -1, -1};
+    if (wave < nw2 && !a.q_only)
 #pragma unroll
-        for (int t = 0; t < NS; ++t) res[pass][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-        f32x4 a_nx = Pb[0];
-        for (int q = 0; q < nblocks; ++q) {
-            const f32x4 a_cur = a_nx;
-            a_nx = Pb[(size_t)(q + 1 < nblocks ? q + 1 : q) * 64];
-            const int bk = bi + q;
-            f32x4 b[NS];
+    for (int pp = 0; pp < 2; ++pp) {
+        const int p_ = wave + nw2 * pp;
+        if (p_ >= npair) continue;
 #pragma unroll
-            for (int t = 0; t < NS; ++t) b[t] = tK4[(bk * 4 + gq) * TS + 16 * t + jq];
+        for (int pass = 0; pass < 2; ++pass) {
+            const int bi = pass == 0 ? p_ : nbk - 1 - p_;
+            if (pass == 1 && bi <= p_) continue;                // (the middle row-block of an odd nbk: once)
+            const int slot = 2 * pp + pass;
+            bw_gptr4 Pb = (bw_gptr4)a.LinvTP + (size_t)tri_upper_off(nbk, bi) * 64 + lane;
+            const int nblocks = nbk - bi;
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
+            for (int t = 0; t < NS; ++t) res[slot][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+            f32x4 a_nx = Pb[0];
+            for (int q = 0; q < nblocks; ++q) {
+                const f32x4 a_cur = a_nx;
+                a_nx = Pb[(size_t)(q + 1 < nblocks ? q + 1 : q) * 64];
+                const int bk = bi + q;
+                f32x4 b[NS];
 #pragma unroll
-                for (int t = 0; t < NS; ++t) res[pass][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[s], b[t][s], res[pass][t], 0, 0, 0);
+                for (int t = 0; t < NS; ++t) b[t] = tK4[(bk * 4 + gq) * TS + 16 * t + jq];
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+#pragma unroll
+                    for (int t = 0; t < NS; ++t) res[slot][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[s], b[t][s], res[slot][t], 0, 0, 0);
+                }
             }
+            rbi[slot] = bi;
         }
-        rbi[pass] = bi;
     }
     __syncthreads();                                         // every read of da is done
 #pragma unroll
-    for (int pass = 0; pass < 2; ++pass) {
-        if (rbi[pass] < 0) continue;
-        const int bi = rbi[pass];
+    for (int slot = 0; slot < 4; ++slot) {
+        if (rbi[slot] < 0) continue;
+        const int bi = rbi[slot];
 #pragma unroll
         for (int t = 0; t < NS; ++t) {
             const int j = 16 * t + jq;
-            tK4[(bi * 4 + gq) * TS + j] = res[pass][t];
-            if (a.DK) *reinterpret_cast<f32x4*>(a.DK + (size_t)(t0 + j) * M + 16 * bi + 4 * gq) = res[pass][t];   // (only for the split-K GEMM path of dLm)
+            tK4[(bi * 4 + gq) * TS + j] = res[slot][t];
+            if (a.DK) *reinterpret_cast<f32x4*>(a.DK + (size_t)(t0 + j) * M + 16 * bi + 4 * gq) = res[slot][t];   // (only for the split-K GEMM path of dLm)
         }
     }
     __syncthreads();
@@ -1225,10 +1232,11 @@ __global__ __launch_bounds__(512) void k_bw_chain(ChainArgs a) {
     if (a.kern_type == IWVI_KERN_RBF) {
         const int nsteps = a.nsteps, XS = 4 * nsteps;
         float* xt = tileD;                                   // [NSAMP][XS]  x~ = ((x/ls - centre) | -|.|^2/2 | 1 | 0..)
-        float* zs = xt + NSAMP * XS;                         // [M][DM]      z/ls (zero beyond D)
-        float* red = zs + M * DM;                            // [2][8][NSAMP] per-wave shares of sum_m c and sum_m K dk
+        float* zs = xt + NSAMP * XS;                         // [M][DM]      z/ls (zero beyond D); M > 256: not staged, read from L2
+        const bool z_lds = a.z_lds != 0;
+        float* red = zs + (z_lds ? M * DM : 0);              // [2][8][NSAMP] per-wave shares of sum_m c and sum_m K dk
         const float* cst = a.cst;
-        for (int idx = tid; idx < M * DM; idx += 512) { const int m = idx / DM, d = idx - m * DM; zs[idx] = d < D ? a.Zt[m * D + d] : 0.f; }
+        if (z_lds) for (int idx = tid; idx < M * DM; idx += 512) { const int m = idx / DM, d = idx - m * DM; zs[idx] = d < D ? a.Zt[m * D + d] : 0.f; }
         if (tid < NSAMP) {
             float n2 = 0.f;
             for (int d = 0; d < D; ++d) { const float v = fmaf(fr[tid * DM + d], cst[d], -cst[32 + d]); xt[tid * XS + d] = v; n2 = fmaf(v, v, n2); }
@@ -1297,7 +1305,8 @@ __global__ __launch_bounds__(512) void k_bw_chain(ChainArgs a) {
                 const f32x4 b = tK4[(bk * 4 + gq) * TS + 16 * t + jq];
 #pragma unroll
                 for (int s_ = 0; s_ < 4; ++s_) {
-                    const float av = dcol < DM ? zs[(16 * bk + 4 * gq + s_) * DM + dcol] : 0.f;
+                    const int m_ = 16 * bk + 4 * gq + s_;
+                    const float av = z_lds ? (dcol < DM ? zs[m_ * DM + dcol] : 0.f) : (dcol < D ? a.Zt[m_ * D + dcol] : 0.f);
                     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b[s_], acc, 0, 0, 0);
                 }
             }
@@ -1352,8 +1361,9 @@ __global__ __launch_bounds__(512) void k_bw_chain(ChainArgs a) {
     // ---- phase 3 (Matern-5/2): kernel adjoint (direct differences), 16 lanes per sample, 16 samples per round.  The scaled inducing inputs
     //      and the chunk's input rows are staged in the (now free) da tile, padded to DM columns: per-element global loads in the
     //      inner loops were a chain of dependent L1 round trips (50-70 us of this kernel) ------------------------------------
-    float* zs = tileD;                                       // [M][DM]   (zero beyond D)
-    for (int idx = tid; idx < M * DM; idx += 512) { const int m = idx / DM, d = idx - m * DM; zs[idx] = d < D ? a.Zt[m * D + d] : 0.f; }
+    float* zs = tileD;                                       // [M][DM]   (zero beyond D); M > 256: read from L2 instead
+    const bool z_lds = a.z_lds != 0;
+    if (z_lds) for (int idx = tid; idx < M * DM; idx += 512) { const int m = idx / DM, d = idx - m * DM; zs[idx] = d < D ? a.Zt[m * D + d] : 0.f; }
     __syncthreads();
     const int sub = tid & 15;
     auto gsum = [](float v) { for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64); return v; };
@@ -1374,7 +1384,7 @@ __global__ __launch_bounds__(512) void k_bw_chain(ChainArgs a) {
                 for (int e = 0; e < 4; ++e) {
                     float d2 = 0.f, z[DM];
 #pragma unroll
-                    for (int d = 0; d < DM; ++d) { z[d] = zs[(mb + e) * DM + d]; const float q = xt[d] - z[d]; d2 = fmaf(q, q, d2); }
+                    for (int d = 0; d < DM; ++d) { z[d] = z_lds ? zs[(mb + e) * DM + d] : (d < D ? a.Zt[(mb + e) * D + d] : 0.f); const float q = xt[d] - z[d]; d2 = fmaf(q, q, d2); }
                     float kv, kg;
                     kern_and_grad<float>(d2, a.kern_type, a.var_dev ? *a.var_dev : a.variance, kv, kg);
                     const float kd = kv * dk[e];
@@ -1469,22 +1479,24 @@ static int chain_ns_cap(long long T, int cap) {             // samples per workg
     return ns;
 }
 // the conservative choice (two [M x 16 NS] float tiles + staging in 160 KB of LDS for any D, R, P): what the workspace is sized for
-static int chain_ns(long long T, int M = 128) { return chain_ns_cap(T, M <= 128 ? 5 : (M <= 256 ? 2 : 1)); }
+static int chain_ns(long long T, int M = 128) { return chain_ns_cap(T, M <= 128 ? 5 : 2); }
 static bool chain_ok(int M, int Mp, long long T) {
-    // M <= 256: at M = 512 only 16 samples fit a workgroup's tiles, so every packed S_r block (R * 32 * 32 KiB per layer)
-    // would be fetched from L2 for 4 MFMAs -- measured 383 ms per value + gradient at configs[4] against 359 ms on the GEMM path
-    return Mp == M && M <= 256 && (T % 16) == 0 && !getenv("IWVI_BW_UNFUSED") && !getenv("IWVI_BW_OLD_CHAIN") &&
-           !(M > 128 && getenv("IWVI_BW_CHAIN_SMALL_M_ONLY"));
+    // M > 256: only with 32 samples per workgroup (two [M x 32] tiles; the scaled inducing inputs then stay in L2) -- at 16 every packed
+    // S_r block (R * 32 * 32 KiB per layer) would be fetched from L2 for 4 MFMAs: measured 383 ms per value + gradient at configs[4]
+    // against 359 ms on the GEMM path
+    return Mp == M && M <= 512 && (T % 16) == 0 && (M <= 256 || chain_ns(T, M) >= 2) && !getenv("IWVI_BW_UNFUSED") && !getenv("IWVI_BW_OLD_CHAIN") &&
+           !(M > 128 && getenv("IWVI_BW_CHAIN_SMALL_M_ONLY")) && !(M > 256 && getenv("IWVI_BW_CHAIN_M256_ONLY"));
 }
 // floats of the staging region beside the two tiles: what is staged there before (heads) / after (kernel adjoint: x~ rows, z~, shares)
-static int chain_dsz(int NSAMP, int M, int D, int R, int P, int DM) {
-    const int heads = 3 * NSAMP * P + P * R + 4 * NSAMP * R + D * P, adj = NSAMP * round_up(D + 2, 4) + M * DM + 16 * NSAMP;
+static bool chain_z_lds(int M) { return M <= 256; }
+static int chain_dsz(int NSAMP, int M, int D, int R, int P, int DM, bool z_lds = true) {
+    const int heads = 3 * NSAMP * P + P * R + 4 * NSAMP * R + D * P, adj = NSAMP * round_up(D + 2, 4) + (z_lds ? M * DM : 0) + 16 * NSAMP;
     return ((heads > adj ? heads : adj) + 3) & ~3;
 }
 // LDS bytes of k_bw_chain for a layer shape and a tile row stride ts (float4)
 static size_t chain_lds_bytes_ts(int NSAMP, int ts, int M, int D, int R, int P) {
     const int DM = D <= 8 ? 8 : (D <= 16 ? 16 : 32);
-    return sizeof(float) * ((size_t)2 * ts * M + (size_t)chain_dsz(NSAMP, M, D, R, P, DM) + (size_t)M * R + (size_t)NSAMP * (2 * R + 1) + (size_t)NSAMP * D
+    return sizeof(float) * ((size_t)2 * ts * M + (size_t)chain_dsz(NSAMP, M, D, R, P, DM, M <= 256) + (size_t)M * R + (size_t)NSAMP * (2 * R + 1) + (size_t)NSAMP * D
                             + (size_t)NSAMP * DM + DM + (size_t)NSAMP * (D + 2));
 }
 // the padded row stride where it fits, else the plain one
@@ -1513,7 +1525,8 @@ template <int NS>
 static int launch_chain_ns(hipStream_t st, ChainArgs a) {
     constexpr int NSAMP = 16 * NS;
     const int DM = a.D <= 8 ? 8 : (a.D <= 16 ? 16 : 32);
-    a.dsz = chain_dsz(NSAMP, a.M, a.D, a.R, a.P, DM);
+    a.z_lds = chain_z_lds(a.M) ? 1 : 0;
+    a.dsz = chain_dsz(NSAMP, a.M, a.D, a.R, a.P, DM, a.M <= 256);
     a.ts = chain_ts(NSAMP, a.M, a.D, a.R, a.P);
     const size_t lds = chain_lds_bytes_ts(NSAMP, a.ts, a.M, a.D, a.R, a.P);
     static bool done = false;

@@ -270,7 +270,8 @@ int iwvi_dgp_forward(const iwvi_layer_desc* layers_host, int n_layers,
  *   F [T, D]               the layer's input rows (per sample)
  *   noise [T, R]           the draws the forward used (needed when d_sample is given)
  *   A [T, Mp], U [R, T, Mp]  a = Lm^-1 k and u_r = L_r^T a as the forward wrote them (a_out / u_out).  U may be NULL when
- *                          M is a multiple of 16 up to 256, T a multiple of 16 and GMV is given: that shape takes the streaming
+ *                          iwvi_gp_layer_backward_needs_u says 0 (M a multiple of 16 up to 512, T a multiple of 16 -- of 32 beyond
+ *                          M = 256 --, the tiles within the LDS) and GMV is given: that shape takes the streaming
  *                          chain, which works from a alone (sum_r 2dv_r L_r u_r = sum_r 2dv_r (L_r L_r^T) a, dL_r = tril(G_r L_r))
  *   GMV [T, 3R]            optional, the forward's gmv_out
  *   d_sample/d_mean/d_var [T, P]  upstream gradients, any may be NULL (= 0)
