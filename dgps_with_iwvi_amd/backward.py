@@ -103,19 +103,34 @@ def _param_desc(layer, dense_state=None):
     return b, [Z, q_mu, q_sqrt]
 
 
-def prepare_side(model, T, stream):
-    """On ``stream``, beside the forward: the dense float64 factors of every GP layer (into its second state buffer) and the
-    parameter-only part of its adjoint (``iwvi_gp_layer_backward_prepare``: scaled inducing inputs, packed S_r = L_r L_r^T and
-    Lm^-T).  -> {layer index: (workspace, dense state)}; the caller joins ``stream`` before the first ``gp_backward``."""
-    gps = [(i, l) for i, l in enumerate(model.layers) if isinstance(l, GPLayer)]
+def prepare_alloc(model, T):
+    """Workspace + dense state per GP layer -> {layer index: (workspace, dense state)} (allocated on the caller's stream BEFORE the
+    forward is queued: ``prepare_side`` may then run on another stream ordered only after this point)."""
     dev = model.X.device
     out = {}
-    for i, l in gps:                                             # (allocated on the caller's stream, used on both after the joins)
-        D = l._Z().shape[1]
-        ws = torch.empty(_abi.lib().iwvi_gp_layer_backward_ws_bytes(T, l.num_inducing, D, l.num_outputs), dtype=torch.uint8, device=dev)
-        out[i] = (ws, l.state_dense())
+    for i, l in enumerate(model.layers):
+        if isinstance(l, GPLayer):
+            D = l._Z().shape[1]
+            ws = torch.empty(_abi.lib().iwvi_gp_layer_backward_ws_bytes(T, l.num_inducing, D, l.num_outputs), dtype=torch.uint8, device=dev)
+            out[i] = (ws, l.state_dense())
+    return out
+
+
+def prepare_side(model, T, stream, out=None, after=None):
+    """On ``stream``, beside the forward: the dense float64 factors of every GP layer (into its second state buffer) and the
+    parameter-only part of its adjoint (``iwvi_gp_layer_backward_prepare``: scaled inducing inputs, packed S_r = L_r L_r^T and
+    Lm^-T).  -> {layer index: (workspace, dense state)}; the caller joins ``stream`` before the first ``gp_backward``.
+    ``out`` = ``prepare_alloc``'s result, ``after`` = an event recorded on the caller's stream right after it: the side work then
+    depends on nothing queued later -- the caller can queue its own precompute + forward FIRST, so that in a captured graph they
+    continue the caller's hardware queue (the first successor captured does; the other pays ~10 us of cross-queue dispatch)."""
+    gps = [(i, l) for i, l in enumerate(model.layers) if isinstance(l, GPLayer)]
+    if out is None:
+        out = prepare_alloc(model, T)
     if stream != torch.cuda.current_stream():
-        stream.wait_stream(torch.cuda.current_stream())
+        if after is not None:
+            stream.wait_event(after)
+        else:
+            stream.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(stream):
         descs = []
         for i, l in gps:
@@ -275,6 +290,8 @@ def iw_elbo_and_gradients(model, zs=None, mode_vi=None, exchange=None, K_total=N
         raise ValueError("wrt is 'all' or 'final_q'")
     final_q = wrt == "final_q"
     prep_stream = _side_stream(dev, 2) if (overlap and not final_q) else cur
+    # (queued BEFORE the caller's own precompute: queued after it -- ordered by an event only -- the dense factorisation lands beside the
+    # layer kernel instead, whose workgroups then wait for its two CUs: 0.355 -> 0.382 ms at configs[2])
     prepared = {} if final_q else prepare_side(model, T, prep_stream)
     # forward: one factorisation launch (packed operands, encoders) + ONE fused layer launch that also leaves what the
     # adjoints need in HBM (a = Lm^-1 k, the draws, every layer's output rows)
