@@ -77,6 +77,7 @@ struct alignas(16) FwGp {             // copied LDS -> registers in 16-byte piec
     unsigned char jr[FW_WAVES], jbi[FW_WAVES];   // first job of wave w: latent GP jr[w], row-block jbi[w]
     unsigned short nblk[FW_WAVES];
     signed char mean_wave[2];
+    signed char s16;                  // stage 2 runs on the split-f16 images: nblk counts 2-KiB slabs, LrTP / QmuP point to them
 };
 struct FwLv {
     const float* W[IWVI_MAX_ENC]; const float* b[IWVI_MAX_ENC];
@@ -150,7 +151,8 @@ constexpr int FW_MAX_COPY = 6 * IWVI_MAX_STACK;
 // thing in the kernel (warm_hot) so that they have arrived when the first layer starts.  Optional per-layer outputs
 // (sample / mean / var / noise / the adjoint's a, u, gmv; kl_local) stay in the LDS table and are read only when
 // FWF_ANY_OUT says there is one (never on the ELBO path).
-enum { FWF_NX_GP = 1, FWF_NX_RBF = 2, FWF_HASW = 4, FWF_HAS_MFB = 8, FWF_ANY_OUT = 16, FWF_PRE_ENC = 32, FWF_SAMPLED_KL = 64 };
+enum { FWF_NX_GP = 1, FWF_NX_RBF = 2, FWF_HASW = 4, FWF_HAS_MFB = 8, FWF_ANY_OUT = 16, FWF_PRE_ENC = 32, FWF_SAMPLED_KL = 64,
+       FWF_S16 = 128 };      // stage 2 on split-f16 operands (LrTP / QmuP then point to the state's slab images; iwvi_common.h: s16_*)
 struct alignas(64) FwHot {
     int type, D, c_off, z_off, flags;
     int nx_c_off, nx_nsteps, nx_ls_off, nx_ls_n;
@@ -414,7 +416,7 @@ __device__ __forceinline__ void lds_wait_ge(int* flag, int v) {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
-template <int NS>
+template <int NS, bool S16>           // S16: stage 2 of every GP layer on split-f16 operands (iwvi_common.h: s16_*)
 __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
     constexpr int NSAMP = 16 * NS;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -785,7 +787,9 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
             const int s2_nblocks = ufirst((int)L.gp.nblk[wave]);   // runs are dealt to waves by load, not in order
             const int s2_mw0 = ufirst((int)L.gp.mean_wave[0]), s2_mw1 = ufirst((int)L.gp.mean_wave[1]);
             const int s2_r0 = ufirst((int)L.gp.jr[wave]), s2_bi0 = ufirst((int)L.gp.jbi[wave]);
-            gptr4 s2_P = (gptr4)G.LrTP + ((size_t)s2_r0 * ntri + tri_upper_off(nbk, s2_bi0)) * 64 + lane;
+            constexpr bool s16 = S16;
+            gptr4 s2_P = s16 ? (gptr4)G.LrTP + ((size_t)s2_r0 * s16_slabs_total(nbk) + s16_slab_off(nbk, s2_bi0)) * 128 + lane
+                             : (gptr4)G.LrTP + ((size_t)s2_r0 * ntri + tri_upper_off(nbk, s2_bi0)) * 64 + lane;
             // the NEXT GP layer's forward-substitution stream is fetched into registers now and parked in the staging
             // buffer once this layer's stage 2 is over (the buffer is busy until the solve below ends; an LDS-DMA left
             // pending across stage 2 would make every LDS read there wait for all outstanding loads)
@@ -799,7 +803,7 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
             }
             f32x4 ring[4];
             ring[0] = ring[1] = ring[2] = ring[3] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (s2_nblocks > 0) {
+            if (s2_nblocks > 0 && !s16) {
                 ring[0] = s2_P[0];
                 ring[1] = s2_P[(size_t)(1 < s2_nblocks ? 1 : s2_nblocks - 1) * 64];
                 ring[2] = s2_P[(size_t)(2 < s2_nblocks ? 2 : s2_nblocks - 1) * 64];
@@ -1029,6 +1033,133 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
             if (g.stamps && lane == 0 && li == 1) g.stamps[(size_t)blockIdx.x * 128 + 118 + wave] = clock64();
             __syncthreads();
             FW_STAMP(2 + li * 6 + 2);
+            // ---- stage 2 on split-f16 operands (iwvi_common.h: s16_*): the a tile is rewritten IN PLACE as two f16 planes
+            //      (h1 = f16(a 2^ea), h2 = f16(a 2^ea - h1); 16-B vectors [(kc*4 + g) * NSAMP + sample] = a[32 kc + 8 g .. + 7]), then every
+            //      16 x 32 slab of L_r^T (two planes from L2) takes three v_mfma_f32_16x16x32_f16 per sub-tile -- h1 h1' + h1 h2' + h2 h1' --
+            //      instead of eight fp32 MFMAs at twice their cycles (scripts/ubench/stage2_split16.hip: 281 vs 1436 clocks per slab).
+            if constexpr (S16) {
+                using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
+                const int nvec = nbk * 2 * NSAMP;                 // vectors per plane
+                // this wave's first slabs: requested now, so that the conversion below covers their L2 round trip
+                f32x4 ring2[4];
+                ring2[0] = ring2[1] = ring2[2] = ring2[3] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (s2_nblocks > 0) {
+#pragma unroll
+                    for (int u = 0; u < 3; ++u) {
+                        const size_t o_ = (size_t)(u < s2_nblocks ? u : s2_nblocks - 1) * 128;
+                        ring[u] = s2_P[o_]; ring2[u] = s2_P[o_ + 64];
+                    }
+                }
+                // In-place conversion: the eight values a[32 kc + 8 g .. + 7] of a sample are the two float4 rows 8 kc + 2 g and 8 kc + 2 g + 1
+                // of the fp32 tile; their h1 vector goes back to the first, their h2 vector to the second (planes interleaved row by row):
+                // every item reads and writes its own two slots -- no hazard, no temporaries, every thread busy.
+                {
+                    const float sa = cst[IWVI_CST_SA];
+                    for (int v = tid; v < nvec; v += FW_THREADS) {
+                        const int j = v % NSAMP, kg = v / NSAMP;          // kg = 4 kc + g
+                        const int row = (2 * kg) * NSAMP + j;
+                        const f32x4 x0 = at[row], x1 = at[row + NSAMP];
+                        f16x8 h1, h2;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float a0 = x0[e] * sa, a1 = x1[e] * sa;
+                            h1[e] = (_Float16)a0; h2[e] = (_Float16)(a0 - (float)h1[e]);
+                            h1[4 + e] = (_Float16)a1; h2[4 + e] = (_Float16)(a1 - (float)h1[4 + e]);
+                        }
+                        at[row] = __builtin_bit_cast(f32x4, h1); at[row + NSAMP] = __builtin_bit_cast(f32x4, h2);
+                    }
+                }
+                __syncthreads();
+                if (wave >= FW_WAVES / 2) __builtin_amdgcn_s_setprio(1);
+                const f32x4* p1 = at + (size_t)(2 * gq) * NSAMP + jq;   // h1 vector of chunk kc, sub-tile t: p1[kc * 8 * NSAMP + 16 t]; h2: the next row
+                const f32x4* p2 = p1 + NSAMP;
+                // (a) q_mu^T row-blocks assigned to this wave
+                for (int rb = 0; rb < G.nrb; ++rb) {
+                    if ((rb == 0 ? s2_mw0 : s2_mw1) != wave) continue;
+                    gptr4 P = (gptr4)G.QmuP + (size_t)rb * (nbk >> 1) * 128 + lane;
+                    f32x4 acc[NS];
+#pragma unroll
+                    for (int t = 0; t < NS; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    for (int kc = 0; kc < (nbk >> 1); ++kc) {
+                        const f16x8 a1 = __builtin_bit_cast(f16x8, P[(size_t)kc * 128]), a2 = __builtin_bit_cast(f16x8, P[(size_t)kc * 128 + 64]);
+#pragma unroll
+                        for (int t = 0; t < NS; ++t) {
+                            const f16x8 b1 = __builtin_bit_cast(f16x8, p1[kc * 8 * NSAMP + 16 * t]), b2 = __builtin_bit_cast(f16x8, p2[kc * 8 * NSAMP + 16 * t]);
+                            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b1, acc[t], 0, 0, 0);
+                            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b2, acc[t], 0, 0, 0);
+                            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2, b1, acc[t], 0, 0, 0);
+                        }
+                    }
+                    const float fm = cst[IWVI_CST_FMEAN];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int r = 16 * rb + 4 * gq + e;
+                        if (r < R) {
+#pragma unroll
+                            for (int t = 0; t < NS; ++t) meanp[r * NSAMP + 16 * t + jq] = acc[t][e] * fm;
+                        }
+                    }
+                }
+                // (b) this wave's contiguous run of (r, bi) row-block jobs: one linear stream of slabs
+                const int nsl = s2_nblocks;
+                if (nsl > 0) {
+                    int r = s2_r0, bi = s2_bi0;
+                    gptr4 P = s2_P;
+                    f32x4 acc[NS];
+                    float ssq[NS];
+#pragma unroll
+                    for (int t = 0; t < NS; ++t) { acc[t] = f32x4{0.f, 0.f, 0.f, 0.f}; ssq[t] = 0.f; }
+                    int kc = (bi & ~1) >> 1, c = s16_slabs(nbk, bi);
+                    for (int q0 = 0; q0 < nsl; q0 += 4) {
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const int q = q0 + u;
+                            if (q < nsl) {
+                                const size_t nx = (size_t)(q + 3 < nsl ? q + 3 : nsl - 1) * 128;
+                                ring[(u + 3) & 3] = P[nx]; ring2[(u + 3) & 3] = P[nx + 64];
+                                const f16x8 a1 = __builtin_bit_cast(f16x8, ring[u]), a2 = __builtin_bit_cast(f16x8, ring2[u]);
+                                f32x4 b1[NS], b2[NS];
+#pragma unroll
+                                for (int t = 0; t < NS; ++t) { b1[t] = p1[kc * 8 * NSAMP + 16 * t]; b2[t] = p2[kc * 8 * NSAMP + 16 * t]; }
+#pragma unroll
+                                for (int t = 0; t < NS; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, __builtin_bit_cast(f16x8, b1[t]), acc[t], 0, 0, 0);
+#pragma unroll
+                                for (int t = 0; t < NS; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, __builtin_bit_cast(f16x8, b2[t]), acc[t], 0, 0, 0);
+#pragma unroll
+                                for (int t = 0; t < NS; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2, __builtin_bit_cast(f16x8, b1[t]), acc[t], 0, 0, 0);
+                                ++kc;
+                                if (--c == 0) {
+                                    // row-block (r, bi) complete: back to the scale of u, add its squares, start the next one
+                                    const float fr = cst[IWVI_CST_FR + r];
+#pragma unroll
+                                    for (int t = 0; t < NS; ++t) acc[t] *= fr;
+                                    if (o_u) {
+#pragma unroll
+                                        for (int t = 0; t < NS; ++t) {
+                                            const int j = 16 * t + jq;
+                                            if (j < nvalid)
+                                                *((gout4)(o_u + ((size_t)r * g.T + (t0 + j)) * G.Mp + 16 * bi + 4 * gq)) = acc[t];
+                                        }
+                                    }
+#pragma unroll
+                                    for (int t = 0; t < NS; ++t) { ssq[t] += colsumsq4(acc[t]); acc[t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+                                    ++bi;
+                                    if (bi == nbk || q == nsl - 1) {
+#pragma unroll
+                                        for (int t = 0; t < NS; ++t) {
+                                            const float sq = xgroup_sum_mfma(ssq[t]);
+                                            if (gq == 0) usq[(wave * R + r) * NSAMP + 16 * t + jq] = sq;
+                                            ssq[t] = 0.f;
+                                        }
+                                        if (bi == nbk) { bi = 0; ++r; }
+                                    }
+                                    c = s16_slabs(nbk, bi); kc = (bi & ~1) >> 1;
+                                }
+                            }
+                        }
+                    }
+                }
+            } else
             // ---- stage 2: u block (r, bi) = sum_{bk >= bi} LrT(bi, bk) a(bk), only |u|^2 kept; mean = q_mu^T a ----
             {
                 if (wave >= FW_WAVES / 2) __builtin_amdgcn_s_setprio(1);   // the second-dispatched half loses issue arbitration otherwise
@@ -1446,15 +1577,15 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
     }
 }
 
-template <int NS>
+template <int NS, bool S16>
 static int launch_forward(const FwArgs& a, unsigned grid, size_t lds_bytes, hipStream_t stream) {
     static size_t attr_set = 0;
     if (lds_bytes > attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_dgp_forward<NS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        hipError_t e = hipFuncSetAttribute((const void*)k_dgp_forward<NS, S16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) { set_error("hipFuncSetAttribute(k_dgp_forward, %zu B): %s", lds_bytes, hipGetErrorString(e)); return IWVI_ERR_LAUNCH; }
         attr_set = lds_bytes;
     }
-    hipLaunchKernelGGL(k_dgp_forward<NS>, dim3(grid), dim3(FW_THREADS), lds_bytes, stream, a);
+    hipLaunchKernelGGL((k_dgp_forward<NS, S16>), dim3(grid), dim3(FW_THREADS), lds_bytes, stream, a);
     return check_launch("k_dgp_forward");
 }
 
@@ -1465,15 +1596,16 @@ static void plan_stage2(FwGp& G) {
     // cost model: a job (r, bi) streams nbk - bi packed blocks, a q_mu^T row-block nbk; the two waves w and
     // w + FW_WAVES/2 share a SIMD (and its MFMA pipe), so the quantity to level is the load per SIMD pair
     const int nbk = G.nbk, R = G.R, njobs = R * nbk, W = FW_WAVES, nm = G.nrb < 2 ? G.nrb : 2;
+    const int mean_cost = G.s16 ? nbk / 2 : nbk;                       // (split-f16: costs in slabs of two blocks)
     std::vector<int> pref(njobs + 1, 0);
-    for (int j = 0; j < njobs; ++j) pref[j + 1] = pref[j] + (nbk - (j % nbk));
+    for (int j = 0; j < njobs; ++j) pref[j + 1] = pref[j] + (G.s16 ? s16_slabs(nbk, j % nbk) : nbk - (j % nbk));
     struct Eval { int maxpair, sq, maxseg; bool operator<(const Eval& o) const {
         return maxpair != o.maxpair ? maxpair < o.maxpair : (sq != o.sq ? sq < o.sq : maxseg < o.maxseg); } };
     int load[FW_WAVES], order[FW_WAVES];
     auto loads = [&](const int* b) {
         for (int k = 0; k < W; ++k) { load[k] = pref[b[k + 1]] - pref[b[k]]; order[k] = k; }
         std::sort(order, order + W, [&](int x, int y) { return load[x] != load[y] ? load[x] < load[y] : x < y; });
-        for (int i = 0; i < nm; ++i) load[order[i]] += nbk;            // q_mu^T row-blocks ride on the lightest runs
+        for (int i = 0; i < nm; ++i) load[order[i]] += mean_cost;      // q_mu^T row-blocks ride on the lightest runs
         std::sort(order, order + W, [&](int x, int y) { return load[x] != load[y] ? load[x] > load[y] : x < y; });
     };
     auto evaluate = [&](const int* b) {
@@ -1655,6 +1787,9 @@ int dgp_forward_impl(const iwvi_layer_desc* layers, int n_layers, const float* X
     a.h.seed = seed; a.h.rng_state = (unsigned long long*)rng_state; a.h.out_logw = out_logw;
     int D = Dx, maxR = 1, maxP = 1;
     bool need_rng = false;
+    // stage 2 on split-f16 operands (one kernel variant for the launch): every GP layer must have an even number of 16-row blocks
+    bool s16_all = !getenv("IWVI_FW_F32_STAGE2");
+    for (int i = 0; i < n_layers; ++i) if (layers[i].type == IWVI_LAYER_GP && ((round_up(layers[i].M, 16) / 16) & 1)) s16_all = false;
     for (int i = 0; i < n_layers; ++i) {
         const iwvi_layer_desc& d = layers[i];
         FwLayer& L = a.L[i];
@@ -1683,6 +1818,8 @@ int dgp_forward_impl(const iwvi_layer_desc* layers, int n_layers, const float* X
             G.M = d.M; G.Mp = s.Mp; G.nbk = s.nbk; G.nrb = s.nrb; G.nsteps = round_up(D + 2, 4) / 4;
             G.R = d.R; G.P = d.P; G.kern_type = d.kern_type; G.mf_type = d.mf_type; G.variance = d.variance;
             a.h.var_dev[i] = d.variance_dev;
+            G.s16 = s16_all ? 1 : 0;
+            if (G.s16) { G.LrTP = (const f32x4*)(st + s.off_LrT16); G.QmuP = (const f32x4*)(st + s.off_Qmu16); }
             plan_stage2(G);
             if (d.R > maxR) maxR = d.R;
             if (d.P > maxP) maxP = d.P;
@@ -1778,6 +1915,7 @@ int dgp_forward_impl(const iwvi_layer_desc* layers, int n_layers, const float* X
             H.kern_type = G.kern_type; H.mf_type = G.mf_type; H.zt_off = G.zt_off; H.ls_off = G.ls_off; H.variance = G.variance;
             H.LrTP = G.LrTP; H.QmuP = G.QmuP; H.LsP = G.LsP; H.ZtP = G.ZtP;
             if (G.W) fl |= FWF_HASW;
+            if (G.s16) fl |= FWF_S16;
             if (G.mfb) fl |= FWF_HAS_MFB;
             if (G.a_out || G.u_out) fl |= FWF_ANY_OUT;
         } else {
@@ -1794,12 +1932,19 @@ int dgp_forward_impl(const iwvi_layer_desc* layers, int n_layers, const float* X
     if (chunks > 0x7fffffffLL) { set_error("iwvi_dgp_forward: T too large"); return IWVI_ERR_ARG; }
     a.h.stamps = (g_stamp_buf && chunks <= g_stamp_wgs) ? g_stamp_buf : nullptr;
     a.h.dbg_exit = g_dbg_exit;
+    if (s16_all) switch (ns) {
+        case 1: return launch_forward<1, true>(a, (unsigned)chunks, lds_bytes, stream);
+        case 2: return launch_forward<2, true>(a, (unsigned)chunks, lds_bytes, stream);
+        case 3: return launch_forward<3, true>(a, (unsigned)chunks, lds_bytes, stream);
+        case 4: return launch_forward<4, true>(a, (unsigned)chunks, lds_bytes, stream);
+        default: return launch_forward<5, true>(a, (unsigned)chunks, lds_bytes, stream);
+    }
     switch (ns) {
-        case 1: return launch_forward<1>(a, (unsigned)chunks, lds_bytes, stream);
-        case 2: return launch_forward<2>(a, (unsigned)chunks, lds_bytes, stream);
-        case 3: return launch_forward<3>(a, (unsigned)chunks, lds_bytes, stream);
-        case 4: return launch_forward<4>(a, (unsigned)chunks, lds_bytes, stream);
-        default: return launch_forward<5>(a, (unsigned)chunks, lds_bytes, stream);
+        case 1: return launch_forward<1, false>(a, (unsigned)chunks, lds_bytes, stream);
+        case 2: return launch_forward<2, false>(a, (unsigned)chunks, lds_bytes, stream);
+        case 3: return launch_forward<3, false>(a, (unsigned)chunks, lds_bytes, stream);
+        case 4: return launch_forward<4, false>(a, (unsigned)chunks, lds_bytes, stream);
+        default: return launch_forward<5, false>(a, (unsigned)chunks, lds_bytes, stream);
     }
 }
 

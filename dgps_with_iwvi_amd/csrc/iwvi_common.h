@@ -23,7 +23,8 @@ __host__ __device__ static inline int round_up(int x, int m) { return (x + m - 1
 // accumulator registers of lane (g, j) hold for rows 16c + 4g .. +3 (C/D map: col = lane & 15,
 // row = 4*(lane >> 4) + reg), so a result tile is the next product's B operand without any shuffle.
 constexpr int BLK16 = 256;                       // floats per packed 16x16 block
-constexpr int IWVI_CST_FLOATS = 68;              // invls[32] | zc[32] | zmax2 = max_m |Z_m/l - zc|^2 | pad[3]
+constexpr int IWVI_CST_FLOATS = 104;             // invls[32] | zc[32] | zmax2 = max_m |Z_m/l - zc|^2 | 2^ea | 2^-(ea+eq) | pad | 2^-(ea+e_r) [32]
+constexpr int IWVI_CST_SA = 65, IWVI_CST_FMEAN = 66, IWVI_CST_FR = 72;   // split-f16 scales (see s16_* below)
 
 // triangular block storage, row-block major:
 //   solve stream LsP (column-block major): column bj = [Lm(bj,bj)^-1, -Lm(bj+1,bj), .., -Lm(nbk-1,bj)],
@@ -34,9 +35,21 @@ __host__ __device__ static inline int tri_upper_off(int nbk, int bi) { return bi
 __host__ __device__ static inline int tri_blocks(int nbk) { return nbk * (nbk + 1) / 2; }
 
 // ---- per-layer state layout (see include/iwvi_hip.h) ----------------------------------------
+// ---- split-f16 operands (x = h1 + h2, h1 = f16(x), h2 = f16(x - h1): 22 mantissa bits; h1 h1' + h1 h2' + h2 h1' on
+// v_mfma_f32_16x16x32_f16 reproduces the fp32 product to ~2^-22) ------------------------------------------------
+// A 16 x 32 SLAB of a matrix G (rows = output rows, 32 consecutive k starting at an EVEN 16-block) is 2 planes x 64 lanes x 16 B:
+// lane l = 16 g + i holds G[i][8 g + j], j = 0..7, as eight f16 (plane 0: h1, plane 1: h2).  Row-block bi of the upper-triangular
+// L_r^T starts at block column bi & ~1 (the block below the diagonal is stored as zeros), so it has s16_slabs(nbk, bi) slabs; the
+// B operand (the a tile in LDS as 16-B vectors of eight f16: rows 8 kc + 2 g (h1) and 8 kc + 2 g + 1 (h2) hold a[32 kc + 8 g .. + 7]) needs no realignment.
+// Values are pre-multiplied by a power of two per matrix (L_r: max -> [2^13, 2^14); a: 2^ea with sigma -> <= 2^10) and the
+// accumulators scaled back (IWVI_CST_FR + r); only even nbk takes this path.
+__host__ __device__ static inline int s16_slabs(int nbk, int bi) { return (nbk - (bi & ~1) + 1) / 2; }
+__host__ __device__ static inline int s16_slab_off(int nbk, int bi) { int o = 0; for (int b = 0; b < bi; ++b) o += s16_slabs(nbk, b); return o; }
+__host__ __device__ static inline int s16_slabs_total(int nbk) { return s16_slab_off(nbk, nbk); }
+
 struct StateLayout {
     int Mp, nbk, nrb, nsteps;
-    size_t off_Lm, off_Linv, off_LsP, off_LrTP, off_QmuP, off_ZtP, off_cst, off_kl, off_ws, bytes;
+    size_t off_Lm, off_Linv, off_LsP, off_LrTP, off_QmuP, off_ZtP, off_cst, off_kl, off_ws, off_LrT16, off_Qmu16, bytes;
 };
 static inline size_t align256(size_t x) { return (x + 255) & ~size_t(255); }
 // ZtP is sized for the largest input dimension (IWVI_MAX_D) so that the layout depends on (M, R) only
@@ -61,6 +74,9 @@ static inline StateLayout state_layout(int M, int R) {
         const size_t blocks = nbk * (nbk + 1) / 2 + nbk + (nbk * nbk + 3) / 4;
         s.off_ws = o; o = align256(o + sizeof(double) * blocks * 16 * 17);
     }
+    // split-f16 images of L_r^T and q_mu^T for v_mfma_f32_16x16x32_f16 (s16_*): 2-KiB slabs (16 rows x 32 k, two f16 planes)
+    s.off_LrT16 = o; o = align256(o + (size_t)R * s16_slabs_total(s.nbk) * 2048);
+    s.off_Qmu16 = o; o = align256(o + (size_t)s.nrb * ((s.nbk + 1) / 2) * 2048);
     s.bytes = o;
     return s;
 }

@@ -33,6 +33,7 @@ struct PreLayer {
     const float* Z; const float* ls; const float* q_mu; const float* q_sqrt;
     double* Lm; double* Linv; float* LsP; float* LrTP; float* QmuP; float* ZtP; float* cst; double* kl;
     double* ws;
+    unsigned short* LrT16; unsigned short* Qmu16;   // split-f16 images (iwvi_common.h: s16_*)
     double jitter; float variance; const float* variance_dev;
     int M, D, R, Mp, nbk, nrb, kern_type, flags;
 };
@@ -387,6 +388,7 @@ __device__ void role_factor(const PreLayer& Lin, int stop_after, unsigned long l
         zs[m * ZLD + d] = v;
     }
     if (tid < 32) L.cst[tid] = (tid < D) ? (float)(1.0 / (double)L.ls[tid]) : 0.f;
+    if (tid == 32) L.cst[IWVI_CST_SA] = ldexpf(1.f, 10 - (int)ceilf(0.5f * log2f(fmaxf(L.variance, 1e-30f))));   // 2^ea: the split-f16 scale of a = Lm^-1 k (|a| <= sigma)
     __syncthreads();
     // centre: K_uf is formed as exp2(x~ . z~) with |x|^2 + |z|^2 - 2 x.z expanded (like gpflow's
     // square_dist); subtracting a common centre leaves r^2 unchanged and keeps the expansion well scaled
@@ -635,6 +637,66 @@ __device__ void role_pack_r(const PreLayer& L, int r, double* red) {
     }
     const double tot = block_sum(acc, red);
     if (threadIdx.x == 0) L.kl[r] = 0.5 * (tot - (double)M);
+    // ---- the split-f16 image of L_r^T (and, role 1, of q_mu^T) with its power-of-two scale ----------------------------------
+    if (nbk & 1) return;
+    const float var = L.variance_dev ? *L.variance_dev : L.variance;
+    const int ea = 10 - (int)ceilf(0.5f * log2f(fmaxf(var, 1e-30f)));          // |a| <= sigma  ->  |a| 2^ea <= 2^10
+    double mx = 0.0;
+    for (int idx = threadIdx.x; idx < M * M; idx += blockDim.x) { const int k = idx / M, i = idx - k * M; if (k >= i) mx = fmax(mx, fabs((double)q[idx])); }
+    __syncthreads();
+    red[threadIdx.x] = mx;
+    __syncthreads();
+    for (int s_ = blockDim.x / 2; s_ > 0; s_ >>= 1) { if ((int)threadIdx.x < s_) red[threadIdx.x] = fmax(red[threadIdx.x], red[threadIdx.x + s_]); __syncthreads(); }
+    mx = red[0];
+    __syncthreads();
+    const int er = mx > 0.0 ? 13 - (int)floor(log2(mx)) : 0;                  // max |L_r| 2^er in [2^13, 2^14)
+    const float sr = ldexpf(1.f, er);
+    if (threadIdx.x == 0) L.cst[IWVI_CST_FR + r] = ldexpf(1.f, -(ea + er));
+    {
+        const int nst = s16_slabs_total(nbk);
+        unsigned short* dst = L.LrT16 + (size_t)r * nst * 1024;                 // 1024 halves per slab (2 planes x 512)
+        for (int v = threadIdx.x; v < nst * 64; v += blockDim.x) {            // one lane-vector (8 k) of a slab per thread-iteration
+            const int sl = v >> 6, lane = v & 63;
+            int bi = 0, o = 0;
+            while (o + s16_slabs(nbk, bi) <= sl) { o += s16_slabs(nbk, bi); ++bi; }
+            const int kc = ((bi & ~1) >> 1) + (sl - o);                       // 32-chunk of k
+            const int i = 16 * bi + (lane & 15), k0 = 32 * kc + 8 * (lane >> 4);
+            _Float16 h1[8], h2[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int k = k0 + e;
+                float x = 0.f;
+                if (i < M && k < M && k >= i) x = q[(size_t)k * M + i] * sr;  // (L_r^T)[i][k] = L_r[k][i]
+                h1[e] = (_Float16)x; h2[e] = (_Float16)(x - (float)h1[e]);
+            }
+            *reinterpret_cast<float4*>(dst + (size_t)sl * 1024 + lane * 8) = *reinterpret_cast<const float4*>(h1);
+            *reinterpret_cast<float4*>(dst + (size_t)sl * 1024 + 512 + lane * 8) = *reinterpret_cast<const float4*>(h2);
+        }
+    }
+    if (r == 0) {
+        double mq = 0.0;
+        for (int idx = threadIdx.x; idx < M * R; idx += blockDim.x) mq = fmax(mq, fabs((double)L.q_mu[idx]));
+        red[threadIdx.x] = mq;
+        __syncthreads();
+        for (int s_ = blockDim.x / 2; s_ > 0; s_ >>= 1) { if ((int)threadIdx.x < s_) red[threadIdx.x] = fmax(red[threadIdx.x], red[threadIdx.x + s_]); __syncthreads(); }
+        mq = red[0];
+        const int eq = mq > 0.0 ? 13 - (int)floor(log2(mq)) : 0;
+        const float sq = ldexpf(1.f, eq);
+        if (threadIdx.x == 0) L.cst[IWVI_CST_FMEAN] = ldexpf(1.f, -(ea + eq));
+        const int nkc = nbk / 2;
+        for (int v = threadIdx.x; v < L.nrb * nkc * 64; v += blockDim.x) {
+            const int sl = v >> 6, lane = v & 63, rb = sl / nkc, kc = sl - rb * nkc;
+            const int rr = 16 * rb + (lane & 15), k0 = 32 * kc + 8 * (lane >> 4);
+            _Float16 h1[8], h2[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float x = (rr < R && k0 + e < M) ? L.q_mu[(size_t)(k0 + e) * R + rr] * sq : 0.f;
+                h1[e] = (_Float16)x; h2[e] = (_Float16)(x - (float)h1[e]);
+            }
+            *reinterpret_cast<float4*>(L.Qmu16 + (size_t)sl * 1024 + lane * 8) = *reinterpret_cast<const float4*>(h1);
+            *reinterpret_cast<float4*>(L.Qmu16 + (size_t)sl * 1024 + 512 + lane * 8) = *reinterpret_cast<const float4*>(h2);
+        }
+    }
 }
 
 // standalone whitened KL (iwvi_gauss_kl): sum over all R
@@ -1071,6 +1133,7 @@ extern "C" int iwvi_model_precompute(const iwvi_gp_desc* layers, int n_layers, c
             L.Lm = (double*)(st + s.off_Lm); L.Linv = (double*)(st + s.off_Linv);
             L.LsP = (float*)(st + s.off_LsP); L.LrTP = (float*)(st + s.off_LrTP);
             L.QmuP = (float*)(st + s.off_QmuP); L.ZtP = (float*)(st + s.off_ZtP);
+            L.LrT16 = (unsigned short*)(st + s.off_LrT16); L.Qmu16 = (unsigned short*)(st + s.off_Qmu16);
             L.cst = (float*)(st + s.off_cst);
             L.kl = (double*)(st + s.off_kl);
             L.ws = (double*)(st + s.off_ws);
