@@ -1,0 +1,63 @@
+"""Stage 2 of the layer kernel on split-f16 operands (iwvi_common.h: s16_*; x = h1 + h2, three v_mfma_f32_16x16x32_f16 per 16 x 32
+slab) against the fp32-MFMA stage 2 (IWVI_FW_F32_STAGE2=1) and the float64 oracle: same accuracy, across operand scales that would
+leave f16's range without the per-matrix power-of-two scaling."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle.from_spec import build_oracle, oracle_noise
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(model, zd, f32):
+    if f32:
+        os.environ["IWVI_FW_F32_STAGE2"] = "1"
+    try:
+        fmean, fvar, _, _, samples, means, covs = model._forward_iw(zd)
+        elbo = float(model.compute_log_likelihood(zd))
+    finally:
+        os.environ.pop("IWVI_FW_F32_STAGE2", None)
+    torch.cuda.synchronize()
+    return elbo, [m.double().cpu().numpy() for m in means], [c.double().cpu().numpy() for c in covs]
+
+
+@pytest.mark.parametrize("M,q_scale,var_scale", [(128, 1.0, 1.0), (128, 1e-5, 1.0), (64, 30.0, 1.0), (128, 1.0, 1e-6), (128, 1.0, 1e4), (256, 1e-3, 0.25)])
+def test_split_f16_stage2_is_as_accurate_as_fp32(gpu_device, M, q_scale, var_scale):
+    from dgps_with_iwvi_amd import synthetic
+    spec = synthetic.make_spec(L=2, M=M, B=24, K=5, with_lv=True, seed=11)
+    for lay in spec["layers"]:
+        if "q_sqrt" in lay:
+            lay["q_sqrt"] = (np.asarray(lay["q_sqrt"]) * q_scale).astype(np.float32)
+            lay["var"] = float(lay["var"]) * var_scale
+    zs = synthetic.make_noise(spec, seed=12)
+    zd = [torch.as_tensor(z, dtype=torch.float32, device=gpu_device) for z in zs]
+    model = synthetic.build_model(spec, gpu_device)
+    e16, m16, v16 = _run(model, zd, f32=False)
+    e32, m32, v32 = _run(model, zd, f32=True)
+    om = build_oracle(spec)
+    ref = om.build_likelihood(oracle_noise(spec, zs))
+    # both paths agree with each other far inside the tolerance they are held to against float64
+    assert abs(e16 - e32) <= 2e-5 * abs(ref) + 1e-3, (e16, e32, ref)
+    assert abs(e16 - ref) <= max(2.0 * abs(e32 - ref), 1e-5 * abs(ref)) + 1e-3, (e16, e32, ref)
+    for a, b in zip(m16 + v16, m32 + v32):
+        scale = max(np.abs(b).max(), 1e-30)
+        assert np.abs(a - b).max() <= 2e-5 * scale, (np.abs(a - b).max(), scale)
+
+
+def test_an_odd_block_count_takes_the_fp32_stage2(gpu_device):
+    """M = 48 (three 16-row blocks): the launch falls back to the fp32-MFMA variant (slabs pair blocks from an even boundary)."""
+    from dgps_with_iwvi_amd import synthetic
+    spec = synthetic.make_spec(L=2, M=48, B=8, K=3, with_lv=False, seed=3)
+    zs = synthetic.make_noise(spec, seed=4)
+    zd = [torch.as_tensor(z, dtype=torch.float32, device=gpu_device) for z in zs]
+    model = synthetic.build_model(spec, gpu_device)
+    a = float(model.compute_log_likelihood(zd))
+    os.environ["IWVI_FW_F32_STAGE2"] = "1"
+    try:
+        b = float(model.compute_log_likelihood(zd))
+    finally:
+        os.environ.pop("IWVI_FW_F32_STAGE2", None)
+    assert a == b
