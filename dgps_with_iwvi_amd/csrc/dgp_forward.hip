@@ -803,6 +803,12 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
             }
             f32x4 ring[4];
             ring[0] = ring[1] = ring[2] = ring[3] = f32x4{0.f, 0.f, 0.f, 0.f};
+            f32x4 ring2e[2];                                      // split-f16: second plane of the two slabs requested ahead of stage 1
+            ring2e[0] = ring2e[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (s2_nblocks > 0 && s16) {
+                const size_t o1 = (size_t)(1 < s2_nblocks ? 1 : s2_nblocks - 1) * 128;
+                ring[0] = s2_P[0]; ring2e[0] = s2_P[64]; ring[1] = s2_P[o1]; ring2e[1] = s2_P[o1 + 64];
+            }
             if (s2_nblocks > 0 && !s16) {
                 ring[0] = s2_P[0];
                 ring[1] = s2_P[(size_t)(1 < s2_nblocks ? 1 : s2_nblocks - 1) * 64];
@@ -1043,12 +1049,10 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
                 // this wave's first slabs: requested now, so that the conversion below covers their L2 round trip
                 f32x4 ring2[4];
                 ring2[0] = ring2[1] = ring2[2] = ring2[3] = f32x4{0.f, 0.f, 0.f, 0.f};
+                ring2[0] = ring2e[0]; ring2[1] = ring2e[1];       // (slabs 0 and 1 were requested ahead of stage 1)
                 if (s2_nblocks > 0) {
-#pragma unroll
-                    for (int u = 0; u < 3; ++u) {
-                        const size_t o_ = (size_t)(u < s2_nblocks ? u : s2_nblocks - 1) * 128;
-                        ring[u] = s2_P[o_]; ring2[u] = s2_P[o_ + 64];
-                    }
+                    const size_t o_ = (size_t)(2 < s2_nblocks ? 2 : s2_nblocks - 1) * 128;
+                    ring[2] = s2_P[o_]; ring2[2] = s2_P[o_ + 64];
                 }
                 // In-place conversion: the eight values a[32 kc + 8 g .. + 7] of a sample are the two float4 rows 8 kc + 2 g and 8 kc + 2 g + 1
                 // of the fp32 tile; their h1 vector goes back to the first, their h2 vector to the second (planes interleaved row by row):
@@ -1070,7 +1074,7 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
                     }
                 }
                 __syncthreads();
-                if (wave >= FW_WAVES / 2) __builtin_amdgcn_s_setprio(1);
+                if (g.stamps && lane == 0 && li == 1) g.stamps[(size_t)blockIdx.x * 128 + 100 + wave] = clock64();
                 const f32x4* p1 = at + (size_t)(2 * gq) * NSAMP + jq;   // h1 vector of chunk kc, sub-tile t: p1[kc * 8 * NSAMP + 16 t]; h2: the next row
                 const f32x4* p2 = p1 + NSAMP;
                 // (a) q_mu^T row-blocks assigned to this wave
@@ -1110,6 +1114,11 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
 #pragma unroll
                     for (int t = 0; t < NS; ++t) { acc[t] = f32x4{0.f, 0.f, 0.f, 0.f}; ssq[t] = 0.f; }
                     int kc = (bi & ~1) >> 1, c = s16_slabs(nbk, bi);
+                    // B vectors: h1 of the NEXT slab is requested while this slab's last five MFMAs (on h2) issue, h2 of this slab at its
+                    // top, under the ten MFMAs on h1 -- each read has a burst of MFMAs to land behind, at 40 registers for both planes
+                    f32x4 b1[NS], b2[NS];
+#pragma unroll
+                    for (int t = 0; t < NS; ++t) b1[t] = p1[kc * 8 * NSAMP + 16 * t];
                     for (int q0 = 0; q0 < nsl; q0 += 4) {
 #pragma unroll
                         for (int u = 0; u < 4; ++u) {
@@ -1118,15 +1127,19 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
                                 const size_t nx = (size_t)(q + 3 < nsl ? q + 3 : nsl - 1) * 128;
                                 ring[(u + 3) & 3] = P[nx]; ring2[(u + 3) & 3] = P[nx + 64];
                                 const f16x8 a1 = __builtin_bit_cast(f16x8, ring[u]), a2 = __builtin_bit_cast(f16x8, ring2[u]);
-                                f32x4 b1[NS], b2[NS];
 #pragma unroll
-                                for (int t = 0; t < NS; ++t) { b1[t] = p1[kc * 8 * NSAMP + 16 * t]; b2[t] = p2[kc * 8 * NSAMP + 16 * t]; }
+                                for (int t = 0; t < NS; ++t) b2[t] = p2[kc * 8 * NSAMP + 16 * t];
 #pragma unroll
                                 for (int t = 0; t < NS; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, __builtin_bit_cast(f16x8, b1[t]), acc[t], 0, 0, 0);
 #pragma unroll
-                                for (int t = 0; t < NS; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, __builtin_bit_cast(f16x8, b2[t]), acc[t], 0, 0, 0);
-#pragma unroll
                                 for (int t = 0; t < NS; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2, __builtin_bit_cast(f16x8, b1[t]), acc[t], 0, 0, 0);
+                                // where the next slab's B vectors live: next chunk of this job, else the first chunk of the next job (a select, not a branch)
+                                const int bi_n = bi + 1 == nbk ? 0 : bi + 1;
+                                const int kc_n = (c > 1) ? kc + 1 : ((bi_n & ~1) >> 1);
+#pragma unroll
+                                for (int t = 0; t < NS; ++t) b1[t] = p1[kc_n * 8 * NSAMP + 16 * t];
+#pragma unroll
+                                for (int t = 0; t < NS; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, __builtin_bit_cast(f16x8, b2[t]), acc[t], 0, 0, 0);
                                 ++kc;
                                 if (--c == 0) {
                                     // row-block (r, bi) complete: back to the scale of u, add its squares, start the next one
@@ -1599,7 +1612,10 @@ static void plan_stage2(FwGp& G) {
     const int mean_cost = G.s16 ? nbk / 2 : nbk;                       // (split-f16: costs in slabs of two blocks)
     std::vector<int> pref(njobs + 1, 0);
     for (int j = 0; j < njobs; ++j) pref[j + 1] = pref[j] + (G.s16 ? s16_slabs(nbk, j % nbk) : nbk - (j % nbk));
-    struct Eval { int maxpair, sq, maxseg; bool operator<(const Eval& o) const {
+    // (split-f16: the loop is no longer bound by the SIMD's MFMA pipe but by each wave's own LDS reads: level the waves first)
+    const bool per_wave = G.s16 != 0;
+    struct Eval { int maxpair, sq, maxseg; bool pw; bool operator<(const Eval& o) const {
+        if (pw && maxseg != o.maxseg) return maxseg < o.maxseg;
         return maxpair != o.maxpair ? maxpair < o.maxpair : (sq != o.sq ? sq < o.sq : maxseg < o.maxseg); } };
     int load[FW_WAVES], order[FW_WAVES];
     auto loads = [&](const int* b) {
@@ -1610,7 +1626,7 @@ static void plan_stage2(FwGp& G) {
     };
     auto evaluate = [&](const int* b) {
         loads(b);
-        Eval e{0, 0, load[order[0]]};
+        Eval e{0, 0, load[order[0]], per_wave};
         for (int i = 0; i < W / 2; ++i) { const int p = load[order[i]] + load[order[W - 1 - i]]; e.maxpair = p > e.maxpair ? p : e.maxpair; e.sq += p * p; }
         return e;
     };
