@@ -409,6 +409,11 @@ def main():
             "value": total / elapsed, "unit": "samples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            # what "f32" means on this path: float32 data and accumulation, float64 factorisation (K_uu, Cholesky); the operands of
+            # stage 2 (u_r = L_r^T a, mean = q_mu^T a) enter the matrix cores as x = h1 + h2, two f16 planes = 22 mantissa bits, with
+            # power-of-two scales -- as accurate as the fp32 MFMA it replaces (tests/test_gpu_split16.py; IWVI_FW_F32_STAGE2=1 switches back)
+            "dtype_note": ("fp32 data and accumulate, fp64 factorisation; stage-2 matrix operands as split f16 (h1 + h2, 22 mantissa bits) "
+                           "unless IWVI_FW_F32_STAGE2=1" if not os.environ.get("IWVI_FW_F32_STAGE2") else "fp32 MFMA stage 2 (IWVI_FW_F32_STAGE2=1)"),
             "config": {"workload": "BASELINE.json configs[%d]: %s; Dx=8, Dy=1, inner layers G5 (R=5, P=8), RBF-ARD, "
                                    "per-step Gram+Cholesky included, noise drawn on device" % (args.config, spec["name"]),
                        "global_batch": B * (world if args.shard == "n" else 1),
