@@ -423,6 +423,9 @@ def main():
             "elbo": final_elbo,
             "n_ranks_seen": (dist.get_world_size() if dist is not None else 1),
             "host_enqueue_ms_per_step": t_enqueued / args.steps * 1e3,
+            # (achieved = algorithmic fp32-equivalent FLOP / s; peak = the fp32-MFMA peak, as for the path's dtype.  Stage 2 issues its
+            #  products as three f16 MFMAs per eight fp32 ones, so at M >= 256, where stage 2 dominates, frac can pass 1: the path then beats
+            #  what any pure-fp32-MFMA kernel could do -- it is not a claim about the f16 peak, 2.5 PFLOP/s.)
             "roofline": {"bound": "mfma", "kernel": "k_dgp_forward (all layers fused, one launch per ELBO evaluation)", "achieved": achieved / 1e12,
                          "peak": PEAK_MFMA_F32 / 1e12, "unit": "TFLOP/s", "frac": achieved / PEAK_MFMA_F32,
                          "traffic": traffic, "traffic_source": traffic_src, "launch_ms": dom_ms,
