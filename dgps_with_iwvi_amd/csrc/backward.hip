@@ -929,6 +929,7 @@ struct ChainArgs {
     int S;                               // workgroups of the launch (stride of a batch in p_g)
     int q_only;                          // only dq_mu / dq_sqrt are wanted (the natural-gradient op): heads, dq_mu shares, G_r shares
     int ts;                              // float4 per tile row (16 NS, + 4 of padding where it fits)
+    const float* SP16; const float* spf; int s16;   // phase 1 on split-f16 operands (a third tile holds a as two f16 planes)
     int z_lds;                           // the scaled inducing inputs are staged in LDS for the kernel adjoint (M <= 256; beyond: read from L2)
     const float* ZtP; const float* cst; int nsteps;   // the state's K_uf operand (A-fragment order), its constant block (1/ls | centre | extent), k-steps
 };
@@ -942,7 +943,8 @@ __global__ __launch_bounds__(512) void k_bw_chain(ChainArgs a) {
     // two tiles in the forward's B-operand layout, float4 [(bk*4 + g) * TS + sample] = 4 consecutive m of one sample:
     float* tileA = csm;                                      // a (kept to the end: the products over samples read it)
     float* tileK = tileA + TS * M;                        // da, then dk (in place: phase 2), then c = dk o dk/dd2 (kernel adjoint)
-    float* tileD = tileK + TS * M;                        // staging: the heads' inputs before, the kernel adjoint's operands after
+    float* tileH = tileK + TS * M;                        // (s16) a as two f16 planes, rows interleaved: float4 row 8kc + 2g = h1, + 1 = h2 of a[32kc + 8g .. + 7]
+    float* tileD = tileH + (a.s16 ? TS * M : 0);          // staging: the heads' inputs before, the kernel adjoint's operands after
     float* qmu_s = tileD + a.dsz;                            // [M][R]
     float* dmu_s = qmu_s + M * R;                            // [NSAMP][R]
     float* dv2_s = dmu_s + NSAMP * R;                        // [NSAMP][R]
@@ -1009,6 +1011,25 @@ __global__ __launch_bounds__(512) void k_bw_chain(ChainArgs a) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the LDS-DMA copies of this wave have landed
     }
     __syncthreads();
+    if (a.s16 && !a.q_only) {                                // the a tile once more as split f16 (scaled by 2^ea): phase 1's B operand
+        using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
+        const float sa = a.cst[IWVI_CST_SA];
+        f32x4* tH4 = reinterpret_cast<f32x4*>(tileH);
+        const int nvec = nbk * 2 * NSAMP;
+        for (int v = tid; v < nvec; v += 512) {
+            const int j = v % NSAMP, kg = v / NSAMP, row = (2 * kg) * TS + j;
+            const f32x4 x0 = tA4[row], x1 = tA4[row + TS];
+            f16x8 h1, h2;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float a0 = x0[e] * sa, a1 = x1[e] * sa;
+                h1[e] = (_Float16)a0; h2[e] = (_Float16)(a0 - (float)h1[e]);
+                h1[4 + e] = (_Float16)a1; h2[4 + e] = (_Float16)(a1 - (float)h1[4 + e]);
+            }
+            tH4[row] = __builtin_bit_cast(f32x4, h1); tH4[row + TS] = __builtin_bit_cast(f32x4, h2);
+        }
+        // (made visible by the barrier that ends the heads)
+    }
     if (a.dbg_exit == 10) return;
     for (int idx = tid; idx < NSAMP * R; idx += 512) {       // heads: one thread per (sample, latent GP)
         const int j = idx / R, r = idx - j * R;
@@ -1081,6 +1102,72 @@ __global__ __launch_bounds__(512) void k_bw_chain(ChainArgs a) {
     if (a.dbg_exit == 1) return;
     if (a.q_only && !a.p_g) return;                          // (G_r then comes from the split-K GEMM over the saved a rows)
 
+    // ---- phase 1 on split-f16 operands: S_r (bi, :) as nbk / 2 slabs per latent GP, three v_mfma_f32_16x16x32_f16 per slab and sub-tile
+    if (a.s16 && !a.q_only) {
+        using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
+        const f32x4* tH4 = reinterpret_cast<const f32x4*>(tileH);
+        const int nkc = nbk >> 1;
+        for (int bi = wave; bi < nbk; bi += 8) {
+            bw_gptr4 Pb = (bw_gptr4)a.SP16 + (size_t)bi * R * nkc * 128 + lane;
+            const int nsl = R * nkc;
+            f32x4 tot[NS], acc[NS];
+#pragma unroll
+            for (int t = 0; t < NS; ++t) { tot[t] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+            f32x4 r1[4], r2[4];
+#pragma unroll
+            for (int u = 0; u < 3; ++u) { const size_t o_ = (size_t)(u < nsl ? u : nsl - 1) * 128; r1[u] = Pb[o_]; r2[u] = Pb[o_ + 64]; }
+            int kc = 0, r = 0;
+            f32x4 b1[NS], b2[NS];
+#pragma unroll
+            for (int t = 0; t < NS; ++t) b1[t] = tH4[(2 * gq) * TS + 16 * t + jq];
+            for (int q0 = 0; q0 < nsl; q0 += 4) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int q = q0 + u;
+                    if (q < nsl) {
+                        const size_t nx = (size_t)(q + 3 < nsl ? q + 3 : nsl - 1) * 128;
+                        r1[(u + 3) & 3] = Pb[nx]; r2[(u + 3) & 3] = Pb[nx + 64];
+                        const f16x8 a1 = __builtin_bit_cast(f16x8, r1[u]), a2 = __builtin_bit_cast(f16x8, r2[u]);
+#pragma unroll
+                        for (int t = 0; t < NS; ++t) b2[t] = tH4[(8 * kc + 2 * gq + 1) * TS + 16 * t + jq];
+#pragma unroll
+                        for (int t = 0; t < NS; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, __builtin_bit_cast(f16x8, b1[t]), acc[t], 0, 0, 0);
+#pragma unroll
+                        for (int t = 0; t < NS; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2, __builtin_bit_cast(f16x8, b1[t]), acc[t], 0, 0, 0);
+                        const int kc_n = kc + 1 == nkc ? 0 : kc + 1;
+#pragma unroll
+                        for (int t = 0; t < NS; ++t) b1[t] = tH4[(8 * kc_n + 2 * gq) * TS + 16 * t + jq];
+#pragma unroll
+                        for (int t = 0; t < NS; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, __builtin_bit_cast(f16x8, b2[t]), acc[t], 0, 0, 0);
+                        if (++kc == nkc) {                   // S_r a done for this row-block: back to its scale, weight by 2 dv_r per sample
+                            const float fr = a.spf[r];
+#pragma unroll
+                            for (int t = 0; t < NS; ++t) {
+                                const float w = dv2_s[(16 * t + jq) * R + r] * fr;
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) { tot[t][e] = fmaf(w, acc[t][e], tot[t][e]); acc[t][e] = 0.f; }
+                            }
+                            kc = 0; ++r;
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < NS; ++t) {
+                const int j = 16 * t + jq;
+                const f32x4 av = tA4[(bi * 4 + gq) * TS + j];
+                const float m2 = -2.f * sdv_s[j];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float v = fmaf(m2, av[e], tot[t][e]);
+                    const int m = 16 * bi + 4 * gq + e;
+                    for (int rr = 0; rr < R; ++rr) v = fmaf(dmu_s[j * R + rr], qmu_s[m * R + rr], v);
+                    tot[t][e] = v;
+                }
+                tK4[(bi * 4 + gq) * TS + j] = tot[t];
+            }
+        }
+    } else
     // ---- phase 1: da row-blocks bi = wave, wave + 4 -------------------------------------------------------------------
     for (int bi = wave; bi < nbk && !a.q_only; bi += 8) {
         bw_gptr4 Pb = (bw_gptr4)a.SP + (size_t)bi * R * nbk * 64 + lane;      // this row-block's R * nbk blocks, contiguous
@@ -1439,8 +1526,12 @@ __global__ __launch_bounds__(512) void k_bw_chain(ChainArgs a) {
 }
 // operands of k_bw_chain, once per evaluation: packed S_r = L_r L_r^T blocks [bi][r][bk] and the packed upper blocks of Lm^-T.
 // One workgroup per 16x16 block, one thread per entry (M^3 R flops in all: negligible, latency-bound, off the critical path).
+// SP16 (or NULL): the split-f16 image of the same S_r blocks for v_mfma_f32_16x16x32_f16 (iwvi_common.h: s16_*): slab (bi, r, kc) = the
+// blocks bk = 2kc, 2kc + 1, two planes of 64 lanes x 8 halves; scaled by 2^es_r with M max|L_r|^2 2^es_r <= 2^14 (max|L_r| from the scales
+// the factorisation launch left in the state's constant block); spf[r] = 2^-(es_r + ea), what an accumulated row-block is multiplied by.
 __global__ __launch_bounds__(256) void k_pack_bw(const float* __restrict__ q_sqrt, const double* __restrict__ Linv64, int Mp, int M, int R, int nbk,
-                                                 float* __restrict__ SP, float* __restrict__ LinvTP) {
+                                                 float* __restrict__ SP, float* __restrict__ LinvTP,
+                                                 unsigned short* __restrict__ SP16, const float* __restrict__ cst, float* __restrict__ spf) {
     __shared__ float Ls[2][16][129];                         // the 16 rows of L_r of row-block bi / bk, 128 columns at a time
     const int i = threadIdx.x >> 4, k = threadIdx.x & 15;
     const int off = (16 * (k >> 2) + i) * 4 + (k & 3);       // A-fragment order: lane 16g + i holds G[i][4g + s]
@@ -1463,6 +1554,16 @@ __global__ __launch_bounds__(256) void k_pack_bw(const float* __restrict__ q_sqr
             for (int j = 0; j < nc; ++j) acc = fmaf(Ls[0][i][j], Ls[1][k][j], acc);
         }
         SP[(size_t)b * 256 + off] = acc;
+        if (SP16) {
+            const float max_l = 16384.f * cst[IWVI_CST_FR + r] * cst[IWVI_CST_SA];          // max|L_r| < 2^(14 - e_r)
+            const int es = 14 - (int)ceilf(log2f(fmaxf((float)M * max_l * max_l, 1e-30f)));
+            const float x = acc * ldexpf(1.f, es);
+            const _Float16 h1 = (_Float16)x, h2 = (_Float16)(x - (float)h1);
+            const int kc = bk >> 1, k32 = 16 * (bk & 1) + k, ln = 16 * (k32 >> 3) + i, jj = k32 & 7;
+            _Float16* dst = reinterpret_cast<_Float16*>(SP16) + ((size_t)(bi * R + r) * (nbk >> 1) + kc) * 1024;
+            dst[ln * 8 + jj] = h1; dst[512 + ln * 8 + jj] = h2;
+            if (bi == 0 && bk == 0 && threadIdx.x == 0) spf[r] = ldexpf(1.f, -es) / cst[IWVI_CST_SA];
+        }
         return;
     }
     b -= nS;                                                  // upper block (bi, bk >= bi) of Lm^-T: entry [i][k] = Lm^-1[16bk + k][16bi + i]
@@ -1480,6 +1581,8 @@ static int chain_ns_cap(long long T, int cap) {             // samples per workg
 }
 // the conservative choice (two [M x 16 NS] float tiles + staging in 160 KB of LDS for any D, R, P): what the workspace is sized for
 static int chain_ns(long long T, int M = 128) { return chain_ns_cap(T, M <= 128 ? 5 : 2); }
+// phase 1 of the chain on split-f16 operands: an even number of 16-row blocks (the state then carries the scales), M <= 256 (a third tile)
+static bool chain_s16(int M, int Mp) { return Mp == M && ((Mp / 16) & 1) == 0 && M <= 256 && !getenv("IWVI_BW_F32_CHAIN"); }
 static bool chain_ok(int M, int Mp, long long T) {
     // M > 256: only with 32 samples per workgroup (two [M x 32] tiles; the scaled inducing inputs then stay in L2) -- at 16 every packed
     // S_r block (R * 32 * 32 KiB per layer) would be fetched from L2 for 4 MFMAs: measured 383 ms per value + gradient at configs[4]
@@ -1496,7 +1599,7 @@ static int chain_dsz(int NSAMP, int M, int D, int R, int P, int DM, bool z_lds =
 // LDS bytes of k_bw_chain for a layer shape and a tile row stride ts (float4)
 static size_t chain_lds_bytes_ts(int NSAMP, int ts, int M, int D, int R, int P) {
     const int DM = D <= 8 ? 8 : (D <= 16 ? 16 : 32);
-    return sizeof(float) * ((size_t)2 * ts * M + (size_t)chain_dsz(NSAMP, M, D, R, P, DM, M <= 256) + (size_t)M * R + (size_t)NSAMP * (2 * R + 1) + (size_t)NSAMP * D
+    return sizeof(float) * ((size_t)(chain_s16(M, round_up(M, 16)) ? 3 : 2) * ts * M + (size_t)chain_dsz(NSAMP, M, D, R, P, DM, M <= 256) + (size_t)M * R + (size_t)NSAMP * (2 * R + 1) + (size_t)NSAMP * D
                             + (size_t)NSAMP * DM + DM + (size_t)NSAMP * (D + 2));
 }
 // the padded row stride where it fits, else the plain one
@@ -1526,6 +1629,7 @@ static int launch_chain_ns(hipStream_t st, ChainArgs a) {
     constexpr int NSAMP = 16 * NS;
     const int DM = a.D <= 8 ? 8 : (a.D <= 16 ? 16 : 32);
     a.z_lds = chain_z_lds(a.M) ? 1 : 0;
+    a.s16 = chain_s16(a.M, a.Mp) ? 1 : 0;
     a.dsz = chain_dsz(NSAMP, a.M, a.D, a.R, a.P, DM, a.M <= 256);
     a.ts = chain_ts(NSAMP, a.M, a.D, a.R, a.P);
     const size_t lds = chain_lds_bytes_ts(NSAMP, a.ts, a.M, a.D, a.R, a.P);
@@ -1765,6 +1869,7 @@ struct BwdWs {
     double *Lbar, *T1, *T2, *S, *dZt_uu, *dvar_m;
     float *GMV, *lin;                   // [T, 3R];  3 [P, R] + 2 [D, P] partial results
     float *SP, *LinvTP, *G;             // k_bw_chain's packed operands; G_r = A^T diag(2 dv_r) A [R, M, M]
+    unsigned short* SP16; float* spf;   // split-f16 image of S_r and its per-r factors (even nbk)
     size_t part_floats, bytes;
 };
 static BwdWs bwd_layout(char* base, long long T, int M, int D, int R) {
@@ -1797,6 +1902,7 @@ static BwdWs bwd_layout(char* base, long long T, int M, int D, int R) {
     {
         const int Mp = round_up(M, 16), nbk = Mp / 16;
         w.SP = (float*)take(sizeof(float) * (size_t)R * nbk * nbk * 256);
+        w.SP16 = (unsigned short*)take((size_t)R * nbk * ((nbk + 1) / 2) * 2048); w.spf = (float*)take(sizeof(float) * IWVI_MAX_R);
         w.LinvTP = (float*)take(sizeof(float) * (size_t)tri_blocks(nbk) * 256);
         w.G = (float*)take(sizeof(float) * (size_t)R * M * M);
     }
@@ -2284,7 +2390,9 @@ extern "C" int iwvi_gp_layer_backward_prepare(const iwvi_gp_bwd_desc* dp, int64_
     hipLaunchKernelGGL(k_prep, dim3((n + 255) / 256), dim3(256), 0, st, d.Z, d.lengthscales, Linv64, Mp, w.Zt, w.invls, w.LinvF, M, D);
     if (chain_fits(T, M, Mp, D, R, d.P > 0 ? d.P : R)) {
         const int nbk = Mp / 16;
-        hipLaunchKernelGGL(k_pack_bw, dim3((unsigned)(R * nbk * nbk + tri_blocks(nbk))), dim3(256), 0, st, d.q_sqrt, Linv64, Mp, M, R, nbk, w.SP, w.LinvTP);
+        const bool s16 = chain_s16(M, Mp);
+        hipLaunchKernelGGL(k_pack_bw, dim3((unsigned)(R * nbk * nbk + tri_blocks(nbk))), dim3(256), 0, st, d.q_sqrt, Linv64, Mp, M, R, nbk, w.SP, w.LinvTP,
+                           s16 ? w.SP16 : (unsigned short*)nullptr, (const float*)((const char*)d.state + sl.off_cst), w.spf);
     }
     return check_launch("iwvi_gp_layer_backward_prepare");
 }
@@ -2349,6 +2457,7 @@ extern "C" int iwvi_gp_layer_backward(const iwvi_gp_bwd_desc* dp, int64_t T, voi
         // (- kl_weight * dKL/dq_mu = - kl_weight * q_mu rides in the reduction; temp_workaround.py:186-188)
         ca.p_qmu = job(M, R, d.dq_mu ? d.dq_mu : w.DMU, d.dq_mu ? d.q_mu : nullptr, -d.kl_weight);
         ca.q_only = q_only ? 1 : 0;
+        ca.SP16 = (const float*)w.SP16; ca.spf = w.spf;
         ca.ZtP = (const float*)((const char*)d.state + sl.off_ZtP); ca.cst = (const float*)((const char*)d.state + sl.off_cst); ca.nsteps = round_up(D + 2, 4) / 4;
         if (!q_only) { ca.p_ctf = job(M, D + 1, w.CtF1, nullptr, 0.0); ca.p_q = job(D + 2, 1, w.Qsum, nullptr, 0.0); }
         if (d.dW && d.W) { ca.p_w = job(3 * P, R, w.lin, nullptr, 0.0); for (int i = 0; i < 3; ++i) s[i] = w.lin + (size_t)i * P * R; if (!ca.p_w) ca.p_qmu = nullptr; }
