@@ -1580,14 +1580,16 @@ static int chain_ns_cap(long long T, int cap) {             // samples per workg
     return ns;
 }
 // the conservative choice (two [M x 16 NS] float tiles + staging in 160 KB of LDS for any D, R, P): what the workspace is sized for
-static int chain_ns(long long T, int M = 128) { return chain_ns_cap(T, M <= 128 ? 5 : 2); }
-// phase 1 of the chain on split-f16 operands: an even number of 16-row blocks (the state then carries the scales), M <= 256 (a third tile)
-static bool chain_s16(int M, int Mp) { return Mp == M && ((Mp / 16) & 1) == 0 && M <= 256 && !getenv("IWVI_BW_F32_CHAIN"); }
+// phase 1 of the chain on split-f16 operands: an even number of 16-row blocks (the state then carries the scales); a third tile holds
+// the a planes, so beyond M = 256 only 16 samples fit a workgroup -- still faster than the fp32 phase 1 at 32 (configs[4]: 277 -> 240 ms per
+// value + gradient; IWVI_BW_S16_SMALL_M=1 keeps the fp32 phase 1 there)
+static bool chain_s16(int M, int Mp) { return Mp == M && ((Mp / 16) & 1) == 0 && (M <= 256 || !getenv("IWVI_BW_S16_SMALL_M")) && !getenv("IWVI_BW_F32_CHAIN"); }
+static int chain_ns(long long T, int M = 128) { return chain_ns_cap(T, M <= 128 ? 5 : ((M > 256 && chain_s16(M, M)) ? 1 : 2)); }
 static bool chain_ok(int M, int Mp, long long T) {
     // M > 256: only with 32 samples per workgroup (two [M x 32] tiles; the scaled inducing inputs then stay in L2) -- at 16 every packed
     // S_r block (R * 32 * 32 KiB per layer) would be fetched from L2 for 4 MFMAs: measured 383 ms per value + gradient at configs[4]
     // against 359 ms on the GEMM path
-    return Mp == M && M <= 512 && (T % 16) == 0 && (M <= 256 || chain_ns(T, M) >= 2) && !getenv("IWVI_BW_UNFUSED") && !getenv("IWVI_BW_OLD_CHAIN") &&
+    return Mp == M && M <= 512 && (T % 16) == 0 && (M <= 256 || chain_ns(T, M) >= 2 || chain_s16(M, Mp)) && !getenv("IWVI_BW_UNFUSED") && !getenv("IWVI_BW_OLD_CHAIN") &&
            !(M > 128 && getenv("IWVI_BW_CHAIN_SMALL_M_ONLY")) && !(M > 256 && getenv("IWVI_BW_CHAIN_M256_ONLY"));
 }
 // floats of the staging region beside the two tiles: what is staged there before (heads) / after (kernel adjoint: x~ rows, z~, shares)
