@@ -322,9 +322,22 @@ __device__ __forceinline__ void xt_subtile(const float* xr, float* xo, const flo
 // right-hand-side block r_i in registers.  Column bj: a_bj = Dinv_bj r_bj (4 dependent MFMAs), then the NBK-1-bj
 // updates r_i += (-L(i,bj)) a_bj are independent accumulator chains interleaved at the MFMA issue rate; the next
 // column's packed blocks are loaded while this one computes.
-template <int NS, int NBK, class AP>
+// Split-f16 form of the off-diagonal updates (H16: every layer with an even nbk <= 8): the packed block holds, per lane,
+// [h1 x 4 | h2 x 4] of 2^est (-L(bi,bj)) (csrc/precompute.hip: post()), the freshly solved a_bj is split the same way after scaling
+// by sb = 2^est, and r_bi += h1 h1' + h1 h2' + h2 h1' on v_mfma_f32_16x16x16_f16 -- three MFMAs of 16 clocks for four of 32.
+// r therefore lives in units of U = 2^(2 est): the Gram tile is written times U and the stream's Dinv blocks are packed
+// times 1/U (both exact), so a itself, |a|^2 and everything behind stage 1 are as in the fp32 form.  The diagonal solves stay fp32.
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void split_b16(const f32x4 a, float sb, f16x4& b1, f16x4& b2) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { const float x = a[e] * sb; const _Float16 h = (_Float16)x; b1[e] = h; b2[e] = (_Float16)(x - (float)h); }
+}
+struct A16 { f16x4 h1, h2; };
+__device__ __forceinline__ A16 as_a16(const f32x4 A) { A16 o; __builtin_memcpy(&o, &A, 16); return o; }
+
+template <int NS, int NBK, bool H16, class AP>
 __device__ __forceinline__ float stage1_unrolled(AP Ap, const f32x4* kuf, f32x4* at, int tcol, int gq,
-                                                 gout1 a_out_row /* or nullptr */) {
+                                                 gout1 a_out_row /* or nullptr */, float sb) {
     constexpr int NSAMP = 16 * NS;
     f32x4 r[NBK], A[NBK];
 #pragma unroll
@@ -342,11 +355,22 @@ __device__ __forceinline__ float stage1_unrolled(AP Ap, const f32x4* kuf, f32x4*
         f32x4 res = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int s = 0; s < 4; ++s) res = __builtin_amdgcn_mfma_f32_16x16x4f32(A[0][s], r[bj][s], res, 0, 0, 0);
+        if constexpr (H16) {
+            f16x4 b1, b2;
+            split_b16(res, sb, b1, b2);
+#pragma unroll
+            for (int bi = bj + 1; bi < NBK; ++bi) r[bi] = __builtin_amdgcn_mfma_f32_16x16x16f16(as_a16(A[bi - bj]).h1, b1, r[bi], 0, 0, 0);
+#pragma unroll
+            for (int bi = bj + 1; bi < NBK; ++bi) r[bi] = __builtin_amdgcn_mfma_f32_16x16x16f16(as_a16(A[bi - bj]).h2, b1, r[bi], 0, 0, 0);
+#pragma unroll
+            for (int bi = bj + 1; bi < NBK; ++bi) r[bi] = __builtin_amdgcn_mfma_f32_16x16x16f16(as_a16(A[bi - bj]).h1, b2, r[bi], 0, 0, 0);
+        } else {
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
 #pragma unroll
             for (int bi = bj + 1; bi < NBK; ++bi)
                 r[bi] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[bi - bj][s], res[s], r[bi], 0, 0, 0);
+        }
         }
         at[(bj * 4 + gq) * NSAMP + tcol] = res;
         ssq += colsumsq4(res);
@@ -366,8 +390,8 @@ __device__ __forceinline__ float stage1_unrolled(AP Ap, const f32x4* kuf, f32x4*
 // with two LDS hand-offs (a flag after a_top, an arrival count after r_bot).  Every SIMD then carries ~200 MFMAs
 // instead of 288 / 144 / 144 / 144.  solve4<R0>: the 4 x 4 block system of rows and columns R0 .. R0+3; r[] in
 // registers; results go to the `at` tile (and a_out); returns this lane's share of |a|^2.
-template <int NS, int R0>
-__device__ __forceinline__ float solve4(const f32x4* Al, f32x4 (&r)[4], f32x4* at, int tcol, int gq, gout1 a_out_row) {
+template <int NS, int R0, bool H16>
+__device__ __forceinline__ float solve4(const f32x4* Al, f32x4 (&r)[4], f32x4* at, int tcol, int gq, gout1 a_out_row, float sb) {
     constexpr int NSAMP = 16 * NS;
     float ssq = 0.f;
 #pragma unroll
@@ -380,10 +404,21 @@ __device__ __forceinline__ float solve4(const f32x4* Al, f32x4 (&r)[4], f32x4* a
         f32x4 res = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int s = 0; s < 4; ++s) res = __builtin_amdgcn_mfma_f32_16x16x4f32(Dv[s], r[c][s], res, 0, 0, 0);
+        if constexpr (H16) {
+            f16x4 b1, b2;
+            split_b16(res, sb, b1, b2);
+#pragma unroll
+            for (int i = c + 1; i < 4; ++i) r[i] = __builtin_amdgcn_mfma_f32_16x16x16f16(as_a16(An[i - c - 1]).h1, b1, r[i], 0, 0, 0);
+#pragma unroll
+            for (int i = c + 1; i < 4; ++i) r[i] = __builtin_amdgcn_mfma_f32_16x16x16f16(as_a16(An[i - c - 1]).h2, b1, r[i], 0, 0, 0);
+#pragma unroll
+            for (int i = c + 1; i < 4; ++i) r[i] = __builtin_amdgcn_mfma_f32_16x16x16f16(as_a16(An[i - c - 1]).h1, b2, r[i], 0, 0, 0);
+        } else {
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
 #pragma unroll
             for (int i = c + 1; i < 4; ++i) r[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(An[i - c - 1][s], res[s], r[i], 0, 0, 0);
+        }
         }
         at[(bj * 4 + gq) * NSAMP + tcol] = res;
         ssq += colsumsq4(res);
@@ -393,12 +428,27 @@ __device__ __forceinline__ float solve4(const f32x4* Al, f32x4 (&r)[4], f32x4* a
 }
 // r_bi = k_bi - sum_{j<4} L(bi,j) a_j for one block row bi >= 4 (a_j from registers or from the `at` tile), two
 // accumulators so that the 16 MFMAs are two chains of 8
-template <int NS>
-__device__ __forceinline__ f32x4 row_minus_L21(const f32x4* Al, const f32x4 (&a)[4], f32x4 k, int bi) {
+template <int NS, bool H16>
+__device__ __forceinline__ f32x4 row_minus_L21(const f32x4* Al, const f32x4 (&a)[4], f32x4 k, int bi, float sb) {
     f32x4 r0 = k, r1 = {0.f, 0.f, 0.f, 0.f};
     f32x4 A[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) A[j] = Al[(size_t)(tri_upper_off(8, j) + bi - j) * 64];
+    if constexpr (H16) {
+        f16x4 b1[4], b2[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) split_b16(a[j], sb, b1[j], b2[j]);
+#pragma unroll
+        for (int j = 0; j < 4; j += 2) {
+            r0 = __builtin_amdgcn_mfma_f32_16x16x16f16(as_a16(A[j]).h1, b1[j], r0, 0, 0, 0);
+            r1 = __builtin_amdgcn_mfma_f32_16x16x16f16(as_a16(A[j + 1]).h1, b1[j + 1], r1, 0, 0, 0);
+            r0 = __builtin_amdgcn_mfma_f32_16x16x16f16(as_a16(A[j]).h2, b1[j], r0, 0, 0, 0);
+            r1 = __builtin_amdgcn_mfma_f32_16x16x16f16(as_a16(A[j + 1]).h2, b1[j + 1], r1, 0, 0, 0);
+            r0 = __builtin_amdgcn_mfma_f32_16x16x16f16(as_a16(A[j]).h1, b2[j], r0, 0, 0, 0);
+            r1 = __builtin_amdgcn_mfma_f32_16x16x16f16(as_a16(A[j + 1]).h1, b2[j + 1], r1, 0, 0, 0);
+        }
+        return r0 + r1;
+    }
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
         r0 = __builtin_amdgcn_mfma_f32_16x16x4f32(A[0][s], a[0][s], r0, 0, 0, 0);
@@ -697,6 +747,8 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
             f32x4* at = kuf;                                       // solved in place (stage 1)
             float* usq = scratch + (size_t)G.Mp * NSAMP;           // [wave][r][NSAMP]
             const bool rbf = G.kern_type == IWVI_KERN_RBF;
+            // split-f16 solve (even nbk <= 8; see split_b16): the Gram tile in units of U (1 otherwise), a_bj scaled by sb for the updates
+            const float st1_u = cst[IWVI_CST_U], st1_sb = cst[IWVI_CST_SB];
             const float* invls = cst; const float* zc = cst + 32;
             const float* Wm = cst + gpc_W(); const float* mfA = cst + gpc_A(P, R); const float* mfb = cst + gpc_b(D, P, R);
             // Gram form: the expanded |x|^2 + |z|^2 - 2 x.z (one small MFMA product) has an absolute error of
@@ -769,6 +821,7 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
                         f32x4 k;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) k[e] = (mrow + e < G.M) ? __builtin_amdgcn_exp2f(acc[t][e]) : 0.f;   // log2(var) folded in
+                        k *= st1_u;
                         kuf[(bi * 4 + gq) * NSAMP + 16 * t + jq] = k;
                     }
                 } else {
@@ -777,6 +830,7 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
                         f32x4 k;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) k[e] = (mrow + e < G.M) ? kern_from_acc(acc[t][e], G.kern_type, g_variance) : 0.f;
+                        k *= st1_u;
                         kuf[(bi * 4 + gq) * NSAMP + 16 * t + jq] = k;
                     }
                 }
@@ -928,7 +982,7 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
                 if (c == 0) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) a[i] = kuf[(i * 4 + gq) * NSAMP + tcol];
-                    ssq = solve4<NS, 0>(Al, a, at, tcol, gq, arow);          // leaves a_top in a[] (and in the tile)
+                    ssq = solve4<NS, 0, true>(Al, a, at, tcol, gq, arow, st1_sb);          // leaves a_top in a[] (and in the tile)
 #pragma unroll
                     for (int i = 0; i < 4; ++i) a[i] = at[(i * 4 + gq) * NSAMP + tcol];
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -938,7 +992,7 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) a[i] = at[(i * 4 + gq) * NSAMP + tcol];
                 }
-                const f32x4 rb = row_minus_L21<NS>(Al, a, kuf[(bi * 4 + gq) * NSAMP + tcol], bi);
+                const f32x4 rb = row_minus_L21<NS, true>(Al, a, kuf[(bi * 4 + gq) * NSAMP + tcol], bi, st1_sb);
                 at[(bi * 4 + gq) * NSAMP + tcol] = rb;
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                 if (lane == 0) __hip_atomic_fetch_add(flag + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -948,7 +1002,7 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
                     f32x4 r[4];
 #pragma unroll
                     for (int i = 0; i < 4; ++i) r[i] = at[((4 + i) * 4 + gq) * NSAMP + tcol];
-                    ssq_b = solve4<NS, 4>(Al, r, at, tcol, gq, arow);
+                    ssq_b = solve4<NS, 4, true>(Al, r, at, tcol, gq, arow, st1_sb);
                 }
                 // |a|^2 of these columns: the top half from wave 4 (slot 0), the bottom half from wave 5 (slot 1)
                 if (c == 0) { ssq = xgroup_sum_mfma(ssq); if (gq == 0) asq[tcol] = ssq; }
@@ -963,25 +1017,25 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
                 if (G.ls_off >= 0 && nbk <= 8) {
                     const f32x4* Al = reinterpret_cast<const f32x4*>(sm + G.ls_off) + lane;      // staged in LDS
                     switch (nbk) {
-                        case 1: ssq = stage1_unrolled<NS, 1>(Al, kuf, at, tcol, gq, arow); break;
-                        case 2: ssq = stage1_unrolled<NS, 2>(Al, kuf, at, tcol, gq, arow); break;
-                        case 3: ssq = stage1_unrolled<NS, 3>(Al, kuf, at, tcol, gq, arow); break;
-                        case 4: ssq = stage1_unrolled<NS, 4>(Al, kuf, at, tcol, gq, arow); break;
-                        case 5: ssq = stage1_unrolled<NS, 5>(Al, kuf, at, tcol, gq, arow); break;
-                        case 6: ssq = stage1_unrolled<NS, 6>(Al, kuf, at, tcol, gq, arow); break;
-                        case 7: ssq = stage1_unrolled<NS, 7>(Al, kuf, at, tcol, gq, arow); break;
-                        default: ssq = stage1_unrolled<NS, 8>(Al, kuf, at, tcol, gq, arow); break;
+                        case 1: ssq = stage1_unrolled<NS, 1, false>(Al, kuf, at, tcol, gq, arow, st1_sb); break;
+                        case 2: ssq = stage1_unrolled<NS, 2, true>(Al, kuf, at, tcol, gq, arow, st1_sb); break;
+                        case 3: ssq = stage1_unrolled<NS, 3, false>(Al, kuf, at, tcol, gq, arow, st1_sb); break;
+                        case 4: ssq = stage1_unrolled<NS, 4, true>(Al, kuf, at, tcol, gq, arow, st1_sb); break;
+                        case 5: ssq = stage1_unrolled<NS, 5, false>(Al, kuf, at, tcol, gq, arow, st1_sb); break;
+                        case 6: ssq = stage1_unrolled<NS, 6, true>(Al, kuf, at, tcol, gq, arow, st1_sb); break;
+                        case 7: ssq = stage1_unrolled<NS, 7, false>(Al, kuf, at, tcol, gq, arow, st1_sb); break;
+                        default: ssq = stage1_unrolled<NS, 8, true>(Al, kuf, at, tcol, gq, arow, st1_sb); break;
                     }
                 } else
                 switch (nbk) {
-                    case 1: ssq = stage1_unrolled<NS, 1>(Ap, kuf, at, tcol, gq, arow); break;
-                    case 2: ssq = stage1_unrolled<NS, 2>(Ap, kuf, at, tcol, gq, arow); break;
-                    case 3: ssq = stage1_unrolled<NS, 3>(Ap, kuf, at, tcol, gq, arow); break;
-                    case 4: ssq = stage1_unrolled<NS, 4>(Ap, kuf, at, tcol, gq, arow); break;
-                    case 5: ssq = stage1_unrolled<NS, 5>(Ap, kuf, at, tcol, gq, arow); break;
-                    case 6: ssq = stage1_unrolled<NS, 6>(Ap, kuf, at, tcol, gq, arow); break;
-                    case 7: ssq = stage1_unrolled<NS, 7>(Ap, kuf, at, tcol, gq, arow); break;
-                    case 8: ssq = stage1_unrolled<NS, 8>(Ap, kuf, at, tcol, gq, arow); break;
+                    case 1: ssq = stage1_unrolled<NS, 1, false>(Ap, kuf, at, tcol, gq, arow, st1_sb); break;
+                    case 2: ssq = stage1_unrolled<NS, 2, true>(Ap, kuf, at, tcol, gq, arow, st1_sb); break;
+                    case 3: ssq = stage1_unrolled<NS, 3, false>(Ap, kuf, at, tcol, gq, arow, st1_sb); break;
+                    case 4: ssq = stage1_unrolled<NS, 4, true>(Ap, kuf, at, tcol, gq, arow, st1_sb); break;
+                    case 5: ssq = stage1_unrolled<NS, 5, false>(Ap, kuf, at, tcol, gq, arow, st1_sb); break;
+                    case 6: ssq = stage1_unrolled<NS, 6, true>(Ap, kuf, at, tcol, gq, arow, st1_sb); break;
+                    case 7: ssq = stage1_unrolled<NS, 7, false>(Ap, kuf, at, tcol, gq, arow, st1_sb); break;
+                    case 8: ssq = stage1_unrolled<NS, 8, true>(Ap, kuf, at, tcol, gq, arow, st1_sb); break;
                     default: {
                         // generic column-at-a-time form (M > 128): right-hand sides in the LDS tile, the packed factor
                         // streamed from L2.  Column bj: a_bj = Dinv_bj r_bj (4 dependent MFMAs), then the updates of the

@@ -25,6 +25,10 @@ __host__ __device__ static inline int round_up(int x, int m) { return (x + m - 1
 constexpr int BLK16 = 256;                       // floats per packed 16x16 block
 constexpr int IWVI_CST_FLOATS = 104;             // invls[32] | zc[32] | zmax2 = max_m |Z_m/l - zc|^2 | 2^ea | 2^-(ea+eq) | pad | 2^-(ea+e_r) [32]
 constexpr int IWVI_CST_SA = 65, IWVI_CST_FMEAN = 66, IWVI_CST_FR = 72;   // split-f16 scales (see s16_* below)
+// stage 1 with split-f16 off-diagonal updates (M <= 128, even block count; csrc/dgp_forward.hip: split_b16): the right-hand sides run in
+// units of U = 2^(2 est), sigma 2^est -> 2^7.  [U] = U (1 when the layer's solve is fp32): the Gram tile is written times U and the LsP
+// stream's Dinv blocks are packed times 1/U;  [SB] = 2^est: a_j -> the B operand of the updates, whose A blocks are 2^est (-L) in two halves
+constexpr int IWVI_CST_U = 67, IWVI_CST_SB = 68;
 
 // triangular block storage, row-block major:
 //   solve stream LsP (column-block major): column bj = [Lm(bj,bj)^-1, -Lm(bj+1,bj), .., -Lm(nbk-1,bj)],

@@ -282,7 +282,7 @@ __device__ __forceinline__ void chol_blocks(double* blk, int nbk, double* rinv, 
             int wg = w;                                  // generation starts with the workers the catch-up left idle
             if (p > 0 && m < nwo) { wg = w - m; if (wg < 0) wg += nwo; }
             if (p + 2 < nbk) gen(p + 2, p + 3, wg, nwo);
-            if (p > 0) post(p - 1, w * 64 + lane, nwo * 64);
+            if (p > 0) for (int it = w * 64 + lane; it < (nbk - p + 1) * 64; it += nwo * 64) post(p - 1, it >> 6, it & 63);
             if (p == nbk - 1) tail(w * 64 + lane, nwo * 64);     // work nobody waits for, beside the last (otherwise idle) pass
         }
         __syncthreads();
@@ -304,12 +304,12 @@ __device__ __forceinline__ void chol_blocks(double* blk, int nbk, double* rinv, 
         if (m > 0) __syncthreads();
         if (p == stamp_p) PRE_STAMP(13);
     }
-    post(nbk - 1, tid, nthreads);                        // the last column (everyone)
+    if (tid < 64) post(nbk - 1, 0, tid);                 // the last column: its diagonal block
     __syncthreads();
 }
 struct NoGen { __device__ void operator()(int, int, int, int) const {} };
 struct NoTail { __device__ void operator()(int, int) const {} };
-struct NoPost { __device__ void operator()(int, int, int) const {} };
+struct NoPost { __device__ void operator()(int, int, int) const {} };   // (column, block of it, lane)
 
 // X = L^-1 in place: off-diagonal blocks of blk become blocks of X, diagonal blocks of X live in dinv.
 // s_lo .. s_hi: the doubling steps to run (group sizes 2 s_lo .. s_hi); s_lo == 1 also inverts the diagonal blocks.  Stopping at
@@ -388,7 +388,13 @@ __device__ void role_factor(const PreLayer& Lin, int stop_after, unsigned long l
         zs[m * ZLD + d] = v;
     }
     if (tid < 32) L.cst[tid] = (tid < D) ? (float)(1.0 / (double)L.ls[tid]) : 0.f;
-    if (tid == 32) L.cst[IWVI_CST_SA] = ldexpf(1.f, 10 - (int)ceilf(0.5f * log2f(fmaxf(L.variance, 1e-30f))));   // 2^ea: the split-f16 scale of a = Lm^-1 k (|a| <= sigma)
+    const int lg_sigma = (int)ceilf(0.5f * log2f(fmaxf(L.variance, 1e-30f)));
+    const bool st1_16 = (L.nbk <= 8) && ((L.nbk & 1) == 0);  // this layer's solve takes split-f16 off-diagonal updates (iwvi_common.h: IWVI_CST_U)
+    const int est = st1_16 ? 7 - lg_sigma : 0;
+    const float st1_iu = ldexpf(1.f, -2 * est), st1_sc = ldexpf(1.f, est);
+    if (tid == 32) L.cst[IWVI_CST_SA] = ldexpf(1.f, 10 - lg_sigma);   // 2^ea: the split-f16 scale of a = Lm^-1 k (|a| <= sigma)
+    if (tid == 33) L.cst[IWVI_CST_U] = ldexpf(1.f, 2 * est);
+    if (tid == 34) L.cst[IWVI_CST_SB] = ldexpf(1.f, est);
     __syncthreads();
     // centre: K_uf is formed as exp2(x~ . z~) with |x|^2 + |z|^2 - 2 x.z expanded (like gpflow's
     // square_dist); subtracting a common centre leaves r^2 unchanged and keeps the expansion well scaled
@@ -488,14 +494,13 @@ __device__ void role_factor(const PreLayer& Lin, int stop_after, unsigned long l
     if (stop_after == 2) return;
     // post-processing of a finished block column bj, run by the waves that do not factor: the packed float32 solve
     // stream of the column (its first block is the inverse of the diagonal block, from the factoring wave), column-block major: [L(bj,bj)^-1, -L(bj+1,bj), .., -L(nbk-1,bj)]; identity padding -> 0
-    auto post = [&](int bj, int t, int nt) {
+    auto post = [&](int bj, int b, int ln) {
         // one item = one lane's four consecutive floats of a packed block (one 16-byte store): lane (g, ii) holds
-        // G[ii][4g .. 4g+3]; item 0..63 of block 0 is the diagonal block's inverse, then the blocks below it
+        // G[ii][4g .. 4g+3]; block 0 of the column is the diagonal block's inverse, then the blocks below it
         float4* dst = reinterpret_cast<float4*>(L.LsP + (size_t)tri_upper_off(nbk, bj) * BLK16);
-        const int nblk = nbk - bj;                               // diagonal block + the blocks below it
         const bool full = (M == Mp);
-        for (int it = t; it < nblk * 64; it += nt) {
-            const int b = it >> 6, ln = it & 63;
+        {
+            const int it = b * 64 + ln;
             const int ii = ln & 15, k0 = 4 * (ln >> 4);
             float v[4];
             if (b == 0) {                                        // L(bj,bj)^-1 = transpose of the factoring wave's L^-T
@@ -518,7 +523,17 @@ __device__ void role_factor(const PreLayer& Lin, int stop_after, unsigned long l
                     v[sgm] = f;
                 }
             }
-            dst[it] = make_float4(v[0], v[1], v[2], v[3]);
+            float4 o = make_float4(v[0], v[1], v[2], v[3]);
+            if (st1_16) {                                        // split-f16 solve (iwvi_common.h: IWVI_CST_U): Dinv times 1/U, the other
+                if (b == 0) { o.x *= st1_iu; o.y *= st1_iu; o.z *= st1_iu; o.w *= st1_iu; }   // blocks as [h1 x 4 | h2 x 4] of 2^est (-L(bi, bj))
+                else {
+                    _Float16 h[8];
+#pragma unroll
+                    for (int sgm = 0; sgm < 4; ++sgm) { const float x = v[sgm] * st1_sc; h[sgm] = (_Float16)x; h[4 + sgm] = (_Float16)(x - (float)h[sgm]); }
+                    o = *reinterpret_cast<const float4*>(h);
+                }
+            }
+            dst[it] = o;
         }
     };
     chol_blocks(blk, nbk, rinv, dinv, tid, nthreads, gen, post, tail, stamps, stamp_p);

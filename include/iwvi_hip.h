@@ -69,7 +69,10 @@ const char* iwvi_last_error(void);
  *   double  Lm   [Mp*Mp]   lower Cholesky factor of Kuu   (written only with IWVI_GP_WANT_DENSE)
  *   double  Linv [Mp*Mp]   Lm^-1                          (written only with IWVI_GP_WANT_DENSE)
  *   float   LsP  [ntri*256]        forward-substitution stream of matrix_triangular_solve (:51): row-block bi =
- *                                  [-Lm(bi,0) .. -Lm(bi,bi-1), Lm(bi,bi)^-1], packed
+ *                                  [-Lm(bi,0) .. -Lm(bi,bi-1), Lm(bi,bi)^-1], packed.  Layers with an even nbk <= 8 hold
+ *                                  the off-diagonal blocks as split-f16 halves (16 B per lane: h1 x 4 | h2 x 4 of
+ *                                  2^est (-Lm(bi,bj))) and the inverse diagonal blocks times 2^(-2 est): the state is an
+ *                                  opaque operand image of the fused kernels, not an interchange format
  *   float   LrTP [R*ntri*256]      tril(q_sqrt[r])^T, upper-triangular blocks, packed
  *   float   QmuP [ceil(R/16)*nbk*256]  q_mu^T, packed  (mean = A^T q_mu, :68)
  *   float   ZtP  [nbk*9*64]        K_uf operand: augmented, centred, scaled inducing inputs

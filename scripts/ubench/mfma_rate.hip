@@ -38,6 +38,30 @@ __global__ __launch_bounds__(512) void k32(float* out, int iters, unsigned long 
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
     if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
 }
+using f16x4 = __attribute__((ext_vector_type(4))) _Float16;
+using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
+template <int NACC, int K32>
+__global__ __launch_bounds__(512) void kh(float* out, int iters, unsigned long long* cyc) {
+    f32x4 acc[NACC];
+    for (int t = 0; t < NACC; ++t) acc[t] = f32x4{0, 0, 0, 0};
+    f16x4 a4, b4; f16x8 a8, b8;
+    for (int e = 0; e < 4; ++e) { a4[e] = (_Float16)(threadIdx.x * 1e-3f); b4[e] = (_Float16)(1.0f + e); }
+    for (int e = 0; e < 8; ++e) { a8[e] = (_Float16)(threadIdx.x * 1e-3f); b8[e] = (_Float16)(1.0f + e); }
+    unsigned long long t0 = clock64();
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int t = 0; t < NACC; ++t) {
+                if constexpr (K32) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a8, b8, acc[t], 0, 0, 0);
+                else acc[t] = __builtin_amdgcn_mfma_f32_16x16x16f16(a4, b4, acc[t], 0, 0, 0);
+            }
+    }
+    unsigned long long t1 = clock64();
+    float s = 0; for (int t = 0; t < NACC; ++t) s += acc[t][0] + acc[t][3];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+    if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
+}
 template <class K>
 void run(const char* name, K kern, int threads, int nacc, int flop_per_mfma) {
     float* out; unsigned long long* cyc;
@@ -61,5 +85,8 @@ int main() {
     run("16x16x4 f32, 1 acc", k16<1>, 256, 1, 2048); run("16x16x4 f32, 2 acc", k16<2>, 256, 2, 2048);
     run("32x32x2 f32, 2 acc", k32<2>, 256, 2, 4096); run("32x32x2 f32, 2 acc", k32<2>, 512, 2, 4096);
     run("32x32x2 f32, 1 acc", k32<1>, 256, 1, 4096);
+    run("16x16x16 f16, 5 acc", kh<5, 0>, 256, 5, 8192); run("16x16x16 f16, 1 acc (dependent)", kh<1, 0>, 256, 1, 8192);
+    run("16x16x32 f16, 5 acc", kh<5, 1>, 256, 5, 16384); run("16x16x32 f16, 1 acc (dependent)", kh<1, 1>, 256, 1, 16384);
+    run("16x16x32 f16, 2 acc", kh<2, 1>, 256, 2, 16384); run("16x16x16 f16, 2 acc", kh<2, 0>, 256, 2, 8192);
     return 0;
 }

@@ -1,6 +1,8 @@
 """Stage 2 of the layer kernel on split-f16 operands (iwvi_common.h: s16_*; x = h1 + h2, three v_mfma_f32_16x16x32_f16 per 16 x 32
 slab) against the fp32-MFMA stage 2 (IWVI_FW_F32_STAGE2=1) and the float64 oracle: same accuracy, across operand scales that would
-leave f16's range without the per-matrix power-of-two scaling."""
+leave f16's range without the per-matrix power-of-two scaling.  (Stage 1's off-diagonal updates are split f16 in BOTH variants for an
+even block count <= 8 -- csrc/dgp_forward.hip: split_b16 -- so for that part the float64 oracle is the reference here, at kernel variances
+from 1e-6 to 1e4 times the spec's.)"""
 import os
 
 import numpy as np
