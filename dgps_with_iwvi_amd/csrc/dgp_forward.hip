@@ -335,7 +335,9 @@ __device__ __forceinline__ void split_b16(const f32x4 a, float sb, f16x4& b1, f1
 struct A16 { f16x4 h1, h2; };
 __device__ __forceinline__ A16 as_a16(const f32x4 A) { A16 o; __builtin_memcpy(&o, &A, 16); return o; }
 
-template <int NS, int NBK, bool H16, class AP>
+// P16 (an S16 launch): a goes to the tile as the two f16 planes stage 2 reads (its scale 2^ea = sb for these layers), i.e. the halves
+// b1 / b2 just formed: lane (gq, jq) owns 8 bytes of the h1 vector and 8 of the h2 vector of (chunk bj / 2, group 2 (bj & 1) + gq / 2).
+template <int NS, int NBK, bool H16, bool P16, class AP>
 __device__ __forceinline__ float stage1_unrolled(AP Ap, const f32x4* kuf, f32x4* at, int tcol, int gq,
                                                  gout1 a_out_row /* or nullptr */, float sb) {
     constexpr int NSAMP = 16 * NS;
@@ -358,6 +360,10 @@ __device__ __forceinline__ float stage1_unrolled(AP Ap, const f32x4* kuf, f32x4*
         if constexpr (H16) {
             f16x4 b1, b2;
             split_b16(res, sb, b1, b2);
+            if constexpr (P16) {
+                char* pl = reinterpret_cast<char*>(at) + ((size_t)((4 * bj + 2 * (gq >> 1)) * NSAMP + tcol)) * 16 + 8 * (gq & 1);
+                *reinterpret_cast<f16x4*>(pl) = b1; *reinterpret_cast<f16x4*>(pl + NSAMP * 16) = b2;
+            }
 #pragma unroll
             for (int bi = bj + 1; bi < NBK; ++bi) r[bi] = __builtin_amdgcn_mfma_f32_16x16x16f16(as_a16(A[bi - bj]).h1, b1, r[bi], 0, 0, 0);
 #pragma unroll
@@ -372,7 +378,7 @@ __device__ __forceinline__ float stage1_unrolled(AP Ap, const f32x4* kuf, f32x4*
                 r[bi] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[bi - bj][s], res[s], r[bi], 0, 0, 0);
         }
         }
-        at[(bj * 4 + gq) * NSAMP + tcol] = res;
+        if constexpr (!P16) at[(bj * 4 + gq) * NSAMP + tcol] = res;
         ssq += colsumsq4(res);
         if (a_out_row) *((gout4)(a_out_row + 16 * bj + 4 * gq)) = res;
 #pragma unroll
@@ -390,7 +396,7 @@ __device__ __forceinline__ float stage1_unrolled(AP Ap, const f32x4* kuf, f32x4*
 // with two LDS hand-offs (a flag after a_top, an arrival count after r_bot).  Every SIMD then carries ~200 MFMAs
 // instead of 288 / 144 / 144 / 144.  solve4<R0>: the 4 x 4 block system of rows and columns R0 .. R0+3; r[] in
 // registers; results go to the `at` tile (and a_out); returns this lane's share of |a|^2.
-template <int NS, int R0, bool H16>
+template <int NS, int R0, bool H16, bool P16>
 __device__ __forceinline__ float solve4(const f32x4* Al, f32x4 (&r)[4], f32x4* at, int tcol, int gq, gout1 a_out_row, float sb) {
     constexpr int NSAMP = 16 * NS;
     float ssq = 0.f;
@@ -407,6 +413,10 @@ __device__ __forceinline__ float solve4(const f32x4* Al, f32x4 (&r)[4], f32x4* a
         if constexpr (H16) {
             f16x4 b1, b2;
             split_b16(res, sb, b1, b2);
+            if constexpr (P16) {
+                char* pl = reinterpret_cast<char*>(at) + ((size_t)((4 * bj + 2 * (gq >> 1)) * NSAMP + tcol)) * 16 + 8 * (gq & 1);
+                *reinterpret_cast<f16x4*>(pl) = b1; *reinterpret_cast<f16x4*>(pl + NSAMP * 16) = b2;
+            }
 #pragma unroll
             for (int i = c + 1; i < 4; ++i) r[i] = __builtin_amdgcn_mfma_f32_16x16x16f16(as_a16(An[i - c - 1]).h1, b1, r[i], 0, 0, 0);
 #pragma unroll
@@ -420,7 +430,7 @@ __device__ __forceinline__ float solve4(const f32x4* Al, f32x4 (&r)[4], f32x4* a
             for (int i = c + 1; i < 4; ++i) r[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(An[i - c - 1][s], res[s], r[i], 0, 0, 0);
         }
         }
-        at[(bj * 4 + gq) * NSAMP + tcol] = res;
+        if constexpr (!P16) at[(bj * 4 + gq) * NSAMP + tcol] = res;
         ssq += colsumsq4(res);
         if (a_out_row) *((gout4)(a_out_row + 16 * bj + 4 * gq)) = res;
     }
@@ -428,16 +438,32 @@ __device__ __forceinline__ float solve4(const f32x4* Al, f32x4 (&r)[4], f32x4* a
 }
 // r_bi = k_bi - sum_{j<4} L(bi,j) a_j for one block row bi >= 4 (a_j from registers or from the `at` tile), two
 // accumulators so that the 16 MFMAs are two chains of 8
-template <int NS, bool H16>
-__device__ __forceinline__ f32x4 row_minus_L21(const f32x4* Al, const f32x4 (&a)[4], f32x4 k, int bi, float sb) {
+// (P16: a_j is read from the tile's f16 planes, where solve4 put it; see stage1_unrolled)
+template <int NS, bool H16, bool P16>
+__device__ __forceinline__ f32x4 row_minus_L21(const f32x4* Al, const f32x4* at, int tcol, int gq, f32x4 k, int bi, float sb) {
+    constexpr int NSAMP = 16 * NS;
     f32x4 r0 = k, r1 = {0.f, 0.f, 0.f, 0.f};
     f32x4 A[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) A[j] = Al[(size_t)(tri_upper_off(8, j) + bi - j) * 64];
+    f32x4 a[4];
+    if constexpr (!P16) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a[i] = at[(i * 4 + gq) * NSAMP + tcol];
+    }
     if constexpr (H16) {
         f16x4 b1[4], b2[4];
+        if constexpr (P16) {
+            const char* pl = reinterpret_cast<const char*>(at) + ((size_t)((2 * (gq >> 1)) * NSAMP + tcol)) * 16 + 8 * (gq & 1);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) split_b16(a[j], sb, b1[j], b2[j]);
+            for (int j = 0; j < 4; ++j) {
+                b1[j] = *reinterpret_cast<const f16x4*>(pl + (size_t)(4 * j) * NSAMP * 16);
+                b2[j] = *reinterpret_cast<const f16x4*>(pl + (size_t)(4 * j + 1) * NSAMP * 16);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) split_b16(a[j], sb, b1[j], b2[j]);
+        }
 #pragma unroll
         for (int j = 0; j < 4; j += 2) {
             r0 = __builtin_amdgcn_mfma_f32_16x16x16f16(as_a16(A[j]).h1, b1[j], r0, 0, 0, 0);
@@ -977,22 +1003,18 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
                 const gout1 arow = (o_a && tcol < nvalid) ? o_a + (size_t)(t0 + tcol) * G.Mp : (gout1)nullptr;
                 int* flag = counters + 4;                          // [0]: a_top is in the tile; [1]: rows of r_bot written
                 __builtin_amdgcn_s_setprio(2);                     // the split solve is the long dependent path of the phase
-                f32x4 a[4];
                 float ssq = 0.f;
                 if (c == 0) {
+                    f32x4 a[4];
 #pragma unroll
                     for (int i = 0; i < 4; ++i) a[i] = kuf[(i * 4 + gq) * NSAMP + tcol];
-                    ssq = solve4<NS, 0, true>(Al, a, at, tcol, gq, arow, st1_sb);          // leaves a_top in a[] (and in the tile)
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) a[i] = at[(i * 4 + gq) * NSAMP + tcol];
+                    ssq = solve4<NS, 0, true, S16>(Al, a, at, tcol, gq, arow, st1_sb);     // a_top into the tile
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                     if (lane == 0) __hip_atomic_store(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 } else {
                     lds_wait_ge(flag, 1);
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) a[i] = at[(i * 4 + gq) * NSAMP + tcol];
                 }
-                const f32x4 rb = row_minus_L21<NS, true>(Al, a, kuf[(bi * 4 + gq) * NSAMP + tcol], bi, st1_sb);
+                const f32x4 rb = row_minus_L21<NS, true, S16>(Al, at, tcol, gq, kuf[(bi * 4 + gq) * NSAMP + tcol], bi, st1_sb);
                 at[(bi * 4 + gq) * NSAMP + tcol] = rb;
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                 if (lane == 0) __hip_atomic_fetch_add(flag + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -1002,7 +1024,7 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
                     f32x4 r[4];
 #pragma unroll
                     for (int i = 0; i < 4; ++i) r[i] = at[((4 + i) * 4 + gq) * NSAMP + tcol];
-                    ssq_b = solve4<NS, 4, true>(Al, r, at, tcol, gq, arow, st1_sb);
+                    ssq_b = solve4<NS, 4, true, S16>(Al, r, at, tcol, gq, arow, st1_sb);
                 }
                 // |a|^2 of these columns: the top half from wave 4 (slot 0), the bottom half from wave 5 (slot 1)
                 if (c == 0) { ssq = xgroup_sum_mfma(ssq); if (gq == 0) asq[tcol] = ssq; }
@@ -1017,25 +1039,25 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
                 if (G.ls_off >= 0 && nbk <= 8) {
                     const f32x4* Al = reinterpret_cast<const f32x4*>(sm + G.ls_off) + lane;      // staged in LDS
                     switch (nbk) {
-                        case 1: ssq = stage1_unrolled<NS, 1, false>(Al, kuf, at, tcol, gq, arow, st1_sb); break;
-                        case 2: ssq = stage1_unrolled<NS, 2, true>(Al, kuf, at, tcol, gq, arow, st1_sb); break;
-                        case 3: ssq = stage1_unrolled<NS, 3, false>(Al, kuf, at, tcol, gq, arow, st1_sb); break;
-                        case 4: ssq = stage1_unrolled<NS, 4, true>(Al, kuf, at, tcol, gq, arow, st1_sb); break;
-                        case 5: ssq = stage1_unrolled<NS, 5, false>(Al, kuf, at, tcol, gq, arow, st1_sb); break;
-                        case 6: ssq = stage1_unrolled<NS, 6, true>(Al, kuf, at, tcol, gq, arow, st1_sb); break;
-                        case 7: ssq = stage1_unrolled<NS, 7, false>(Al, kuf, at, tcol, gq, arow, st1_sb); break;
-                        default: ssq = stage1_unrolled<NS, 8, true>(Al, kuf, at, tcol, gq, arow, st1_sb); break;
+                        case 1: ssq = stage1_unrolled<NS, 1, false, false>(Al, kuf, at, tcol, gq, arow, st1_sb); break;
+                        case 2: ssq = stage1_unrolled<NS, 2, true, S16>(Al, kuf, at, tcol, gq, arow, st1_sb); break;
+                        case 3: ssq = stage1_unrolled<NS, 3, false, false>(Al, kuf, at, tcol, gq, arow, st1_sb); break;
+                        case 4: ssq = stage1_unrolled<NS, 4, true, S16>(Al, kuf, at, tcol, gq, arow, st1_sb); break;
+                        case 5: ssq = stage1_unrolled<NS, 5, false, false>(Al, kuf, at, tcol, gq, arow, st1_sb); break;
+                        case 6: ssq = stage1_unrolled<NS, 6, true, S16>(Al, kuf, at, tcol, gq, arow, st1_sb); break;
+                        case 7: ssq = stage1_unrolled<NS, 7, false, false>(Al, kuf, at, tcol, gq, arow, st1_sb); break;
+                        default: ssq = stage1_unrolled<NS, 8, true, S16>(Al, kuf, at, tcol, gq, arow, st1_sb); break;
                     }
                 } else
                 switch (nbk) {
-                    case 1: ssq = stage1_unrolled<NS, 1, false>(Ap, kuf, at, tcol, gq, arow, st1_sb); break;
-                    case 2: ssq = stage1_unrolled<NS, 2, true>(Ap, kuf, at, tcol, gq, arow, st1_sb); break;
-                    case 3: ssq = stage1_unrolled<NS, 3, false>(Ap, kuf, at, tcol, gq, arow, st1_sb); break;
-                    case 4: ssq = stage1_unrolled<NS, 4, true>(Ap, kuf, at, tcol, gq, arow, st1_sb); break;
-                    case 5: ssq = stage1_unrolled<NS, 5, false>(Ap, kuf, at, tcol, gq, arow, st1_sb); break;
-                    case 6: ssq = stage1_unrolled<NS, 6, true>(Ap, kuf, at, tcol, gq, arow, st1_sb); break;
-                    case 7: ssq = stage1_unrolled<NS, 7, false>(Ap, kuf, at, tcol, gq, arow, st1_sb); break;
-                    case 8: ssq = stage1_unrolled<NS, 8, true>(Ap, kuf, at, tcol, gq, arow, st1_sb); break;
+                    case 1: ssq = stage1_unrolled<NS, 1, false, false>(Ap, kuf, at, tcol, gq, arow, st1_sb); break;
+                    case 2: ssq = stage1_unrolled<NS, 2, true, S16>(Ap, kuf, at, tcol, gq, arow, st1_sb); break;
+                    case 3: ssq = stage1_unrolled<NS, 3, false, false>(Ap, kuf, at, tcol, gq, arow, st1_sb); break;
+                    case 4: ssq = stage1_unrolled<NS, 4, true, S16>(Ap, kuf, at, tcol, gq, arow, st1_sb); break;
+                    case 5: ssq = stage1_unrolled<NS, 5, false, false>(Ap, kuf, at, tcol, gq, arow, st1_sb); break;
+                    case 6: ssq = stage1_unrolled<NS, 6, true, S16>(Ap, kuf, at, tcol, gq, arow, st1_sb); break;
+                    case 7: ssq = stage1_unrolled<NS, 7, false, false>(Ap, kuf, at, tcol, gq, arow, st1_sb); break;
+                    case 8: ssq = stage1_unrolled<NS, 8, true, S16>(Ap, kuf, at, tcol, gq, arow, st1_sb); break;
                     default: {
                         // generic column-at-a-time form (M > 128): right-hand sides in the LDS tile, the packed factor
                         // streamed from L2.  Column bj: a_bj = Dinv_bj r_bj (4 dependent MFMAs), then the updates of the
@@ -1111,7 +1133,7 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
                 // In-place conversion: the eight values a[32 kc + 8 g .. + 7] of a sample are the two float4 rows 8 kc + 2 g and 8 kc + 2 g + 1
                 // of the fp32 tile; their h1 vector goes back to the first, their h2 vector to the second (planes interleaved row by row):
                 // every item reads and writes its own two slots -- no hazard, no temporaries, every thread busy.
-                {
+                if (nbk > 8) {                                    // (nbk <= 8: stage 1 wrote the planes itself -- stage1_unrolled, P16)
                     const float sa = cst[IWVI_CST_SA];
                     for (int v = tid; v < nvec; v += FW_THREADS) {
                         const int j = v % NSAMP, kg = v / NSAMP;          // kg = 4 kc + g
@@ -1126,8 +1148,8 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
                         }
                         at[row] = __builtin_bit_cast(f32x4, h1); at[row + NSAMP] = __builtin_bit_cast(f32x4, h2);
                     }
+                    __syncthreads();
                 }
-                __syncthreads();
                 if (g.stamps && lane == 0 && li == 1) g.stamps[(size_t)blockIdx.x * 128 + 100 + wave] = clock64();
                 const f32x4* p1 = at + (size_t)(2 * gq) * NSAMP + jq;   // h1 vector of chunk kc, sub-tile t: p1[kc * 8 * NSAMP + 16 t]; h2: the next row
                 const f32x4* p2 = p1 + NSAMP;

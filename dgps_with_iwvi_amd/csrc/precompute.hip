@@ -392,7 +392,7 @@ __device__ void role_factor(const PreLayer& Lin, int stop_after, unsigned long l
     const bool st1_16 = (L.nbk <= 8) && ((L.nbk & 1) == 0);  // this layer's solve takes split-f16 off-diagonal updates (iwvi_common.h: IWVI_CST_U)
     const int est = st1_16 ? 7 - lg_sigma : 0;
     const float st1_iu = ldexpf(1.f, -2 * est), st1_sc = ldexpf(1.f, est);
-    if (tid == 32) L.cst[IWVI_CST_SA] = ldexpf(1.f, 10 - lg_sigma);   // 2^ea: the split-f16 scale of a = Lm^-1 k (|a| <= sigma)
+    if (tid == 32) L.cst[IWVI_CST_SA] = ldexpf(1.f, (st1_16 ? 7 : 10) - lg_sigma);   // 2^ea: the split-f16 scale of a = Lm^-1 k (|a| <= sigma); = 2^est when stage 1 writes the planes itself
     if (tid == 33) L.cst[IWVI_CST_U] = ldexpf(1.f, 2 * est);
     if (tid == 34) L.cst[IWVI_CST_SB] = ldexpf(1.f, est);
     __syncthreads();
@@ -655,7 +655,7 @@ __device__ void role_pack_r(const PreLayer& L, int r, double* red) {
     // ---- the split-f16 image of L_r^T (and, role 1, of q_mu^T) with its power-of-two scale ----------------------------------
     if (nbk & 1) return;
     const float var = L.variance_dev ? *L.variance_dev : L.variance;
-    const int ea = 10 - (int)ceilf(0.5f * log2f(fmaxf(var, 1e-30f)));          // |a| <= sigma  ->  |a| 2^ea <= 2^10
+    const int ea = ((L.nbk <= 8 && (L.nbk & 1) == 0) ? 7 : 10) - (int)ceilf(0.5f * log2f(fmaxf(var, 1e-30f)));   // |a| <= sigma  ->  |a| 2^ea <= 2^10 (2^7 = 2^est where stage 1 writes the planes: role_factor)
     double mx = 0.0;
     for (int idx = threadIdx.x; idx < M * M; idx += blockDim.x) { const int k = idx / M, i = idx - k * M; if (k >= i) mx = fmax(mx, fabs((double)q[idx])); }
     __syncthreads();
