@@ -871,8 +871,8 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
             gptr4 s2_P = s16 ? (gptr4)G.LrTP + ((size_t)s2_r0 * s16_slabs_total(nbk) + s16_slab_off(nbk, s2_bi0)) * 128 + lane
                              : (gptr4)G.LrTP + ((size_t)s2_r0 * ntri + tri_upper_off(nbk, s2_bi0)) * 64 + lane;
             // the NEXT GP layer's forward-substitution stream is fetched into registers now and parked in the staging
-            // buffer once this layer's stage 2 is over (the buffer is busy until the solve below ends; an LDS-DMA left
-            // pending across stage 2 would make every LDS read there wait for all outstanding loads)
+            // buffer once this layer's solve is over (the buffer is busy until then; an LDS-DMA left pending across
+            // stage 2 would make every LDS read there wait for all outstanding loads)
             constexpr int LSN = (36 * 64 + FW_THREADS - 1) / FW_THREADS;   // tri_blocks(8) packed blocks of 64 float4
             f32x4 lsn[LSN];
             const int lsn4 = H.nx_ls_off >= 0 ? H.nx_ls_n >> 2 : 0;
@@ -1115,6 +1115,10 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
             if (g.stamps && lane == 0 && li == 1) g.stamps[(size_t)blockIdx.x * 128 + 118 + wave] = clock64();
             __syncthreads();
             FW_STAMP(2 + li * 6 + 2);
+            // the solve is over: the next GP layer's stream leaves its registers for the staging buffer (free from here on)
+#pragma unroll
+            for (int i = 0; i < LSN; ++i)
+                if (tid + i * FW_THREADS < lsn4) reinterpret_cast<f32x4*>(sm + H.nx_ls_off)[tid + i * FW_THREADS] = lsn[i];
             // ---- stage 2 on split-f16 operands (iwvi_common.h: s16_*): the a tile is rewritten IN PLACE as two f16 planes
             //      (h1 = f16(a 2^ea), h2 = f16(a 2^ea - h1); 16-B vectors [(kc*4 + g) * NSAMP + sample] = a[32 kc + 8 g .. + 7]), then every
             //      16 x 32 slab of L_r^T (two planes from L2) takes three v_mfma_f32_16x16x32_f16 per sub-tile -- h1 h1' + h1 h2' + h2 h1' --
@@ -1123,12 +1127,17 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
                 using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
                 const int nvec = nbk * 2 * NSAMP;                 // vectors per plane
                 // this wave's first slabs: requested now, so that the conversion below covers their L2 round trip
-                f32x4 ring2[4];
-                ring2[0] = ring2[1] = ring2[2] = ring2[3] = f32x4{0.f, 0.f, 0.f, 0.f};
-                ring2[0] = ring2e[0]; ring2[1] = ring2e[1];       // (slabs 0 and 1 were requested ahead of stage 1)
-                if (s2_nblocks > 0) {
-                    const size_t o_ = (size_t)(2 < s2_nblocks ? 2 : s2_nblocks - 1) * 128;
-                    ring[2] = s2_P[o_]; ring2[2] = s2_P[o_ + 64];
+                // the slab stream pairs the row-blocks 2p and 2p+1 (same chunks of k, same B vectors): one STEP = [slab(2p, kc) h1 | h2 |
+                // slab(2p+1, kc) h1 | h2], 4 KiB.  Step 0 was requested ahead of stage 1, step 1 is requested here, behind the solve.
+                const int nstp = s2_nblocks >> 1;
+                f32x4 A[3][4];
+#pragma unroll
+                for (int i = 0; i < 3; ++i) A[i][0] = A[i][1] = A[i][2] = A[i][3] = f32x4{0.f, 0.f, 0.f, 0.f};
+                A[0][0] = ring[0]; A[0][1] = ring2e[0]; A[0][2] = ring[1]; A[0][3] = ring2e[1];
+                if (nstp > 0) {
+                    const size_t o_ = (size_t)(1 < nstp ? 1 : nstp - 1) * 256;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) A[1][i] = s2_P[o_ + 64 * i];
                 }
                 // In-place conversion: the eight values a[32 kc + 8 g .. + 7] of a sample are the two float4 rows 8 kc + 2 g and 8 kc + 2 g + 1
                 // of the fp32 tile; their h1 vector goes back to the first, their h2 vector to the second (planes interleaved row by row):
@@ -1180,69 +1189,79 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
                         }
                     }
                 }
-                // (b) this wave's contiguous run of (r, bi) row-block jobs: one linear stream of slabs
-                const int nsl = s2_nblocks;
-                if (nsl > 0) {
-                    int r = s2_r0, bi = s2_bi0;
+                // (b) this wave's contiguous run of (r, p) jobs -- row-blocks 2p and 2p+1 of L_r^T, nbk/2 - p steps -- as one linear stream
+                if (nstp > 0) {
+                    int r = s2_r0, bp = s2_bi0 >> 1;
                     gptr4 P = s2_P;
-                    f32x4 acc[NS];
+                    f32x4 acc0[NS], acc1[NS];
                     float ssq[NS];
 #pragma unroll
-                    for (int t = 0; t < NS; ++t) { acc[t] = f32x4{0.f, 0.f, 0.f, 0.f}; ssq[t] = 0.f; }
-                    int kc = (bi & ~1) >> 1, c = s16_slabs(nbk, bi);
-                    // B vectors: h1 of the NEXT slab is requested while this slab's last five MFMAs (on h2) issue, h2 of this slab at its
-                    // top, under the ten MFMAs on h1 -- each read has a burst of MFMAs to land behind, at 40 registers for both planes
+                    for (int t = 0; t < NS; ++t) { acc0[t] = acc1[t] = f32x4{0.f, 0.f, 0.f, 0.f}; ssq[t] = 0.f; }
+                    const int nkc = nbk >> 1;
+                    int kc = bp, c = nkc - bp;
+                    // B vectors serve both row-blocks: h1 of the NEXT step is requested while this step's last ten MFMAs (on h2) issue, h2 of
+                    // this step at its top, under the twenty MFMAs on h1 -- half the LDS reads per MFMA of one row-block per job
                     f32x4 b1[NS], b2[NS];
 #pragma unroll
                     for (int t = 0; t < NS; ++t) b1[t] = p1[kc * 8 * NSAMP + 16 * t];
-                    for (int q0 = 0; q0 < nsl; q0 += 4) {
+                    for (int q0 = 0; q0 < nstp; q0 += 3) {
 #pragma unroll
-                        for (int u = 0; u < 4; ++u) {
+                        for (int u = 0; u < 3; ++u) {
                             const int q = q0 + u;
-                            if (q < nsl) {
-                                const size_t nx = (size_t)(q + 3 < nsl ? q + 3 : nsl - 1) * 128;
-                                ring[(u + 3) & 3] = P[nx]; ring2[(u + 3) & 3] = P[nx + 64];
-                                const f16x8 a1 = __builtin_bit_cast(f16x8, ring[u]), a2 = __builtin_bit_cast(f16x8, ring2[u]);
+                            if (q < nstp) {
+                                const size_t nx = (size_t)(q + 2 < nstp ? q + 2 : nstp - 1) * 256;
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) A[(u + 2) % 3][i] = P[nx + 64 * i];
+                                const f16x8 a10 = __builtin_bit_cast(f16x8, A[u][0]), a20 = __builtin_bit_cast(f16x8, A[u][1]);
+                                const f16x8 a11 = __builtin_bit_cast(f16x8, A[u][2]), a21 = __builtin_bit_cast(f16x8, A[u][3]);
 #pragma unroll
                                 for (int t = 0; t < NS; ++t) b2[t] = p2[kc * 8 * NSAMP + 16 * t];
 #pragma unroll
-                                for (int t = 0; t < NS; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, __builtin_bit_cast(f16x8, b1[t]), acc[t], 0, 0, 0);
+                                for (int t = 0; t < NS; ++t) acc0[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a10, __builtin_bit_cast(f16x8, b1[t]), acc0[t], 0, 0, 0);
 #pragma unroll
-                                for (int t = 0; t < NS; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2, __builtin_bit_cast(f16x8, b1[t]), acc[t], 0, 0, 0);
-                                // where the next slab's B vectors live: next chunk of this job, else the first chunk of the next job (a select, not a branch)
-                                const int bi_n = bi + 1 == nbk ? 0 : bi + 1;
-                                const int kc_n = (c > 1) ? kc + 1 : ((bi_n & ~1) >> 1);
+                                for (int t = 0; t < NS; ++t) acc1[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a11, __builtin_bit_cast(f16x8, b1[t]), acc1[t], 0, 0, 0);
+#pragma unroll
+                                for (int t = 0; t < NS; ++t) acc0[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a20, __builtin_bit_cast(f16x8, b1[t]), acc0[t], 0, 0, 0);
+#pragma unroll
+                                for (int t = 0; t < NS; ++t) acc1[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a21, __builtin_bit_cast(f16x8, b1[t]), acc1[t], 0, 0, 0);
+                                // where the next step's B vectors live: next chunk of this job, else the first chunk of the next job (a select, not a branch)
+                                const int bp_n = bp + 1 == nkc ? 0 : bp + 1;
+                                const int kc_n = (c > 1) ? kc + 1 : bp_n;
 #pragma unroll
                                 for (int t = 0; t < NS; ++t) b1[t] = p1[kc_n * 8 * NSAMP + 16 * t];
 #pragma unroll
-                                for (int t = 0; t < NS; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, __builtin_bit_cast(f16x8, b2[t]), acc[t], 0, 0, 0);
+                                for (int t = 0; t < NS; ++t) acc0[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a10, __builtin_bit_cast(f16x8, b2[t]), acc0[t], 0, 0, 0);
+#pragma unroll
+                                for (int t = 0; t < NS; ++t) acc1[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a11, __builtin_bit_cast(f16x8, b2[t]), acc1[t], 0, 0, 0);
                                 ++kc;
                                 if (--c == 0) {
-                                    // row-block (r, bi) complete: back to the scale of u, add its squares, start the next one
+                                    // row-blocks (r, 2p) and (r, 2p+1) complete: back to the scale of u, add their squares, start the next pair
                                     const float fr = cst[IWVI_CST_FR + r];
 #pragma unroll
-                                    for (int t = 0; t < NS; ++t) acc[t] *= fr;
+                                    for (int t = 0; t < NS; ++t) { acc0[t] *= fr; acc1[t] *= fr; }
                                     if (o_u) {
 #pragma unroll
                                         for (int t = 0; t < NS; ++t) {
                                             const int j = 16 * t + jq;
-                                            if (j < nvalid)
-                                                *((gout4)(o_u + ((size_t)r * g.T + (t0 + j)) * G.Mp + 16 * bi + 4 * gq)) = acc[t];
+                                            if (j < nvalid) {
+                                                gout1 ur = o_u + ((size_t)r * g.T + (t0 + j)) * G.Mp + 32 * bp + 4 * gq;
+                                                *((gout4)ur) = acc0[t]; *((gout4)(ur + 16)) = acc1[t];
+                                            }
                                         }
                                     }
 #pragma unroll
-                                    for (int t = 0; t < NS; ++t) { ssq[t] += colsumsq4(acc[t]); acc[t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-                                    ++bi;
-                                    if (bi == nbk || q == nsl - 1) {
+                                    for (int t = 0; t < NS; ++t) { ssq[t] += colsumsq4(acc0[t]) + colsumsq4(acc1[t]); acc0[t] = acc1[t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+                                    ++bp;
+                                    if (bp == nkc || q == nstp - 1) {
 #pragma unroll
                                         for (int t = 0; t < NS; ++t) {
                                             const float sq = xgroup_sum_mfma(ssq[t]);
                                             if (gq == 0) usq[(wave * R + r) * NSAMP + 16 * t + jq] = sq;
                                             ssq[t] = 0.f;
                                         }
-                                        if (bi == nbk) { bi = 0; ++r; }
+                                        if (bp == nkc) { bp = 0; ++r; }
                                     }
-                                    c = s16_slabs(nbk, bi); kc = (bi & ~1) >> 1;
+                                    c = nkc - bp; kc = bp;
                                 }
                             }
                         }
@@ -1372,9 +1391,7 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
             }
             __builtin_amdgcn_s_setprio(0);
             if (g.stamps && lane == 0 && li == 1) g.stamps[(size_t)blockIdx.x * 128 + 110 + wave] = clock64();
-#pragma unroll
-            for (int i = 0; i < LSN; ++i)
-                if (tid + i * FW_THREADS < lsn4) reinterpret_cast<f32x4*>(sm + H.nx_ls_off)[tid + i * FW_THREADS] = lsn[i];
+
             __syncthreads();
             FW_STAMP(2 + li * 6 + 3);
 
@@ -1684,10 +1701,11 @@ static int launch_forward(const FwArgs& a, unsigned grid, size_t lds_bytes, hipS
 static void plan_stage2(FwGp& G) {
     // cost model: a job (r, bi) streams nbk - bi packed blocks, a q_mu^T row-block nbk; the two waves w and
     // w + FW_WAVES/2 share a SIMD (and its MFMA pipe), so the quantity to level is the load per SIMD pair
-    const int nbk = G.nbk, R = G.R, njobs = R * nbk, W = FW_WAVES, nm = G.nrb < 2 ? G.nrb : 2;
-    const int mean_cost = G.s16 ? nbk / 2 : nbk;                       // (split-f16: costs in slabs of two blocks)
+    // split-f16: a job is a PAIR of row-blocks (r, 2p), (r, 2p+1) -- they share their B vectors -- and costs are counted in slabs
+    const int nbk = G.nbk, R = G.R, npr = G.s16 ? nbk / 2 : nbk, njobs = R * npr, W = FW_WAVES, nm = G.nrb < 2 ? G.nrb : 2;
+    const int mean_cost = G.s16 ? nbk / 2 : nbk;
     std::vector<int> pref(njobs + 1, 0);
-    for (int j = 0; j < njobs; ++j) pref[j + 1] = pref[j] + (G.s16 ? s16_slabs(nbk, j % nbk) : nbk - (j % nbk));
+    for (int j = 0; j < njobs; ++j) pref[j + 1] = pref[j] + (G.s16 ? 2 * (npr - j % npr) : nbk - (j % nbk));
     // (split-f16: the loop is no longer bound by the SIMD's MFMA pipe but by each wave's own LDS reads: level the waves first)
     const bool per_wave = G.s16 != 0;
     struct Eval { int maxpair, sq, maxseg; bool pw; bool operator<(const Eval& o) const {
@@ -1739,8 +1757,8 @@ static void plan_stage2(FwGp& G) {
         for (int i = 0; i < nm; ++i) G.mean_wave[i] = (signed char)run_wave[ord2[i]];
     }
     for (int k = 0; k < W; ++k) {
-        G.jr[run_wave[k]] = (unsigned char)(b[k] / nbk);
-        G.jbi[run_wave[k]] = (unsigned char)(b[k] % nbk);
+        G.jr[run_wave[k]] = (unsigned char)(b[k] / npr);
+        G.jbi[run_wave[k]] = (unsigned char)(G.s16 ? 2 * (b[k] % npr) : b[k] % npr);
         G.nblk[run_wave[k]] = (unsigned short)(pref[b[k + 1]] - pref[b[k]]);
     }
 }

@@ -684,8 +684,10 @@ __device__ void role_pack_r(const PreLayer& L, int r, double* red) {
                 if (i < M && k < M && k >= i) x = q[(size_t)k * M + i] * sr;  // (L_r^T)[i][k] = L_r[k][i]
                 h1[e] = (_Float16)x; h2[e] = (_Float16)(x - (float)h1[e]);
             }
-            *reinterpret_cast<float4*>(dst + (size_t)sl * 1024 + lane * 8) = *reinterpret_cast<const float4*>(h1);
-            *reinterpret_cast<float4*>(dst + (size_t)sl * 1024 + 512 + lane * 8) = *reinterpret_cast<const float4*>(h2);
+            // the slabs of row-blocks 2p and 2p+1 are interleaved chunk by chunk (they are multiplied as one step: same B vectors)
+            const int slp = ((bi & 1) ? o - s16_slabs(nbk, bi) : o) + 2 * (sl - o) + (bi & 1);
+            *reinterpret_cast<float4*>(dst + (size_t)slp * 1024 + lane * 8) = *reinterpret_cast<const float4*>(h1);
+            *reinterpret_cast<float4*>(dst + (size_t)slp * 1024 + 512 + lane * 8) = *reinterpret_cast<const float4*>(h2);
         }
     }
     if (r == 0) {
