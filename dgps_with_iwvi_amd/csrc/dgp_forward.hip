@@ -19,8 +19,8 @@
 //   stage 1 a = Lm^-1 k by blocked right-looking forward substitution (matrix_triangular_solve, :51): one wave
 //           per 16-sample sub-tile streams the packed factor (staged in LDS one layer ahead); a_j = Dinv_j r_j, then
 //           r_i -= L_ij a_j for all i > j (independent MFMA chains); the B operand is the result tile just computed,
-//           still in registers (accumulator layout == B layout).  With five sub-tiles on four SIMDs the fifth solve
-//           is cut once into a 2 x 2 block system and spread over four waves (solve4)            -> LDS at, |a|^2
+//           still in registers (accumulator layout == B layout).  Even block counts <= 8: the updates
+//           run on split-f16 operands (split_b16) and a is written as the f16 planes stage 2 reads        -> LDS at, |a|^2
 //   stage 2 u_r = tril(q_sqrt_r)^T a (upper blocks) -> |u_r|^2 only (never stored); mean = q_mu^T a
 //           a wave owns one 16-row block of the output for ALL NS sub-tiles: each 1-KiB packed A block is
 //           loaded once (coalesced, L2 -> registers, prefetched three blocks ahead, across job boundaries) and
@@ -387,111 +387,6 @@ __device__ __forceinline__ float stage1_unrolled(AP Ap, const f32x4* kuf, f32x4*
     return ssq;
 }
 
-// ---- the fifth sub-tile of an 80-sample chunk (M = 128: an 8 x 8 block system) ---------------------------------
-// Five single-wave solves on four SIMDs leave one SIMD with two of them while the others idle half of stage 1.  The
-// fifth solve is therefore cut ONCE, as a 2 x 2 system of 4 x 4 block systems:
-//     a_top = L11^-1 k_top          (solve4<0>, the wave on SIMD 0)
-//     r_bot = k_bot - L21 a_top     (one block row per wave, four waves, one per SIMD: the only parallel part)
-//     a_bot = L22^-1 r_bot          (solve4<4>, the wave on SIMD 1)
-// with two LDS hand-offs (a flag after a_top, an arrival count after r_bot).  Every SIMD then carries ~200 MFMAs
-// instead of 288 / 144 / 144 / 144.  solve4<R0>: the 4 x 4 block system of rows and columns R0 .. R0+3; r[] in
-// registers; results go to the `at` tile (and a_out); returns this lane's share of |a|^2.
-template <int NS, int R0, bool H16, bool P16>
-__device__ __forceinline__ float solve4(const f32x4* Al, f32x4 (&r)[4], f32x4* at, int tcol, int gq, gout1 a_out_row, float sb) {
-    constexpr int NSAMP = 16 * NS;
-    float ssq = 0.f;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        const int bj = R0 + c, col = tri_upper_off(8, bj);       // packed column bj: [Dinv(bj), -L(bj+1,bj), ..]
-        const f32x4 Dv = Al[(size_t)col * 64];
-        f32x4 An[3];
-#pragma unroll
-        for (int i = c + 1; i < 4; ++i) An[i - c - 1] = Al[(size_t)(col + i - c) * 64];
-        f32x4 res = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int s = 0; s < 4; ++s) res = __builtin_amdgcn_mfma_f32_16x16x4f32(Dv[s], r[c][s], res, 0, 0, 0);
-        if constexpr (H16) {
-            f16x4 b1, b2;
-            split_b16(res, sb, b1, b2);
-            if constexpr (P16) {
-                char* pl = reinterpret_cast<char*>(at) + ((size_t)((4 * bj + 2 * (gq >> 1)) * NSAMP + tcol)) * 16 + 8 * (gq & 1);
-                *reinterpret_cast<f16x4*>(pl) = b1; *reinterpret_cast<f16x4*>(pl + NSAMP * 16) = b2;
-            }
-#pragma unroll
-            for (int i = c + 1; i < 4; ++i) r[i] = __builtin_amdgcn_mfma_f32_16x16x16f16(as_a16(An[i - c - 1]).h1, b1, r[i], 0, 0, 0);
-#pragma unroll
-            for (int i = c + 1; i < 4; ++i) r[i] = __builtin_amdgcn_mfma_f32_16x16x16f16(as_a16(An[i - c - 1]).h2, b1, r[i], 0, 0, 0);
-#pragma unroll
-            for (int i = c + 1; i < 4; ++i) r[i] = __builtin_amdgcn_mfma_f32_16x16x16f16(as_a16(An[i - c - 1]).h1, b2, r[i], 0, 0, 0);
-        } else {
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-#pragma unroll
-            for (int i = c + 1; i < 4; ++i) r[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(An[i - c - 1][s], res[s], r[i], 0, 0, 0);
-        }
-        }
-        if constexpr (!P16) at[(bj * 4 + gq) * NSAMP + tcol] = res;
-        ssq += colsumsq4(res);
-        if (a_out_row) *((gout4)(a_out_row + 16 * bj + 4 * gq)) = res;
-    }
-    return ssq;
-}
-// r_bi = k_bi - sum_{j<4} L(bi,j) a_j for one block row bi >= 4 (a_j from registers or from the `at` tile), two
-// accumulators so that the 16 MFMAs are two chains of 8
-// (P16: a_j is read from the tile's f16 planes, where solve4 put it; see stage1_unrolled)
-template <int NS, bool H16, bool P16>
-__device__ __forceinline__ f32x4 row_minus_L21(const f32x4* Al, const f32x4* at, int tcol, int gq, f32x4 k, int bi, float sb) {
-    constexpr int NSAMP = 16 * NS;
-    f32x4 r0 = k, r1 = {0.f, 0.f, 0.f, 0.f};
-    f32x4 A[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) A[j] = Al[(size_t)(tri_upper_off(8, j) + bi - j) * 64];
-    f32x4 a[4];
-    if constexpr (!P16) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) a[i] = at[(i * 4 + gq) * NSAMP + tcol];
-    }
-    if constexpr (H16) {
-        f16x4 b1[4], b2[4];
-        if constexpr (P16) {
-            const char* pl = reinterpret_cast<const char*>(at) + ((size_t)((2 * (gq >> 1)) * NSAMP + tcol)) * 16 + 8 * (gq & 1);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                b1[j] = *reinterpret_cast<const f16x4*>(pl + (size_t)(4 * j) * NSAMP * 16);
-                b2[j] = *reinterpret_cast<const f16x4*>(pl + (size_t)(4 * j + 1) * NSAMP * 16);
-            }
-        } else {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) split_b16(a[j], sb, b1[j], b2[j]);
-        }
-#pragma unroll
-        for (int j = 0; j < 4; j += 2) {
-            r0 = __builtin_amdgcn_mfma_f32_16x16x16f16(as_a16(A[j]).h1, b1[j], r0, 0, 0, 0);
-            r1 = __builtin_amdgcn_mfma_f32_16x16x16f16(as_a16(A[j + 1]).h1, b1[j + 1], r1, 0, 0, 0);
-            r0 = __builtin_amdgcn_mfma_f32_16x16x16f16(as_a16(A[j]).h2, b1[j], r0, 0, 0, 0);
-            r1 = __builtin_amdgcn_mfma_f32_16x16x16f16(as_a16(A[j + 1]).h2, b1[j + 1], r1, 0, 0, 0);
-            r0 = __builtin_amdgcn_mfma_f32_16x16x16f16(as_a16(A[j]).h1, b2[j], r0, 0, 0, 0);
-            r1 = __builtin_amdgcn_mfma_f32_16x16x16f16(as_a16(A[j + 1]).h1, b2[j + 1], r1, 0, 0, 0);
-        }
-        return r0 + r1;
-    }
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        r0 = __builtin_amdgcn_mfma_f32_16x16x4f32(A[0][s], a[0][s], r0, 0, 0, 0);
-        r1 = __builtin_amdgcn_mfma_f32_16x16x4f32(A[1][s], a[1][s], r1, 0, 0, 0);
-    }
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        r0 = __builtin_amdgcn_mfma_f32_16x16x4f32(A[2][s], a[2][s], r0, 0, 0, 0);
-        r1 = __builtin_amdgcn_mfma_f32_16x16x4f32(A[3][s], a[3][s], r1, 0, 0, 0);
-    }
-    return r0 + r1;
-}
-__device__ __forceinline__ void lds_wait_ge(int* flag, int v) {
-    while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < v) __builtin_amdgcn_s_sleep(2);
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-}
-
 template <int NS, bool S16>           // S16: stage 2 of every GP layer on split-f16 operands (iwvi_common.h: s16_*)
 __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
     constexpr int NSAMP = 16 * NS;
@@ -792,7 +687,6 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
             FW_STAMP(2 + li * 6 + 0);
 
             // ---- Gram: kuf block bi = kernel(Z_bi, x), written in B-operand order ---------------------------
-            if (tid < 2) counters[4 + tid] = 0;                    // hand-off words of the split fifth solve (stage 1)
             for (int bi = wave; bi < nbk; bi += FW_WAVES) {
                 f32x4 acc[NS];
 #pragma unroll
@@ -902,9 +796,8 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
             // r_bi += (-L(bi,bj)) a_bj for every bi > bj: independent MFMA chains, B operand = a_bj in registers.
             // r lives in the `at` tile (first touched from the Gram tile); the freshly updated r_{bj+1} is handed
             // to the next column in registers, so the dependent chain never waits for LDS.
-            // five sub-tiles, M = 128, solve stream staged: the fifth solve is split over waves 4-7 (see solve4)
-            const bool split5 = (NS == FW_MAXNS) && nbk == 8 && G.ls_off >= 0;
-            const int nchain = split5 ? NS - 1 : NS;
+            // (five sub-tiles on four SIMDs: two solves share SIMD 0.  Cutting the fifth solve into a 2 x 2 block system over four waves paid
+            // while its updates were fp32 MFMAs; with the split-f16 updates the hand-offs cost what the cut saves: measured equal, removed.)
             if (nbk >= FW_SB_MIN_NBK) {
                 // ---- M >= 256: super-block solve.  Per super-block I (8 block rows): r_I = k_I - L(I, <I) a_<I (dense product,
                 // one block row per wave, in place), then a_I = (L_II)^-1 r_I (triangular product with the packed inverse of
@@ -997,41 +890,7 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
                 f32x4* uz = reinterpret_cast<f32x4*>(usq);
                 for (int i = (wave - NS) * 64 + lane; i < (FW_WAVES * R * NSAMP) / 4; i += (FW_WAVES - NS) * 64) uz[i] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
-            if (split5 && wave >= FW_WAVES / 2) {
-                const int c = wave - FW_WAVES / 2, bi = 4 + c, tcol = 16 * (NS - 1) + jq;
-                const f32x4* Al = reinterpret_cast<const f32x4*>(sm + G.ls_off) + lane;
-                const gout1 arow = (o_a && tcol < nvalid) ? o_a + (size_t)(t0 + tcol) * G.Mp : (gout1)nullptr;
-                int* flag = counters + 4;                          // [0]: a_top is in the tile; [1]: rows of r_bot written
-                __builtin_amdgcn_s_setprio(2);                     // the split solve is the long dependent path of the phase
-                float ssq = 0.f;
-                if (c == 0) {
-                    f32x4 a[4];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) a[i] = kuf[(i * 4 + gq) * NSAMP + tcol];
-                    ssq = solve4<NS, 0, true, S16>(Al, a, at, tcol, gq, arow, st1_sb);     // a_top into the tile
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                    if (lane == 0) __hip_atomic_store(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                } else {
-                    lds_wait_ge(flag, 1);
-                }
-                const f32x4 rb = row_minus_L21<NS, true, S16>(Al, at, tcol, gq, kuf[(bi * 4 + gq) * NSAMP + tcol], bi, st1_sb);
-                at[(bi * 4 + gq) * NSAMP + tcol] = rb;
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                if (lane == 0) __hip_atomic_fetch_add(flag + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                float ssq_b = 0.f;
-                if (c == 1) {
-                    lds_wait_ge(flag + 1, 4);
-                    f32x4 r[4];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) r[i] = at[((4 + i) * 4 + gq) * NSAMP + tcol];
-                    ssq_b = solve4<NS, 4, true, S16>(Al, r, at, tcol, gq, arow, st1_sb);
-                }
-                // |a|^2 of these columns: the top half from wave 4 (slot 0), the bottom half from wave 5 (slot 1)
-                if (c == 0) { ssq = xgroup_sum_mfma(ssq); if (gq == 0) asq[tcol] = ssq; }
-                if (c == 1) { ssq_b = xgroup_sum_mfma(ssq_b); if (gq == 0) asq[NSAMP + tcol] = ssq_b; }
-                __builtin_amdgcn_s_setprio(0);
-            }
-            if (wave < nchain) {
+            if (wave < NS) {
                 const int tcol = 16 * wave + jq;                  // this lane's sample column
                 gptr4 Ap = (gptr4)G.LsP + lane;
                 const gout1 arow = (o_a && tcol < nvalid) ? o_a + (size_t)(t0 + tcol) * G.Mp : (gout1)nullptr;
@@ -1109,7 +968,7 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
                     }
                 }
                 ssq = xgroup_sum_mfma(ssq);
-                if (gq < 2) asq[gq * NSAMP + tcol] = gq == 0 ? ssq : 0.f;   // slot 0 carries it; slot 1 is for a split solve
+                if (gq < 2) asq[gq * NSAMP + tcol] = gq == 0 ? ssq : 0.f;   // slot 0 carries it; the variance reads two slots (the super-block solve fills both)
             }
             }                                                     // (nbk <= 8)
             if (g.stamps && lane == 0 && li == 1) g.stamps[(size_t)blockIdx.x * 128 + 118 + wave] = clock64();
