@@ -43,7 +43,8 @@ __host__ __device__ static inline int tri_blocks(int nbk) { return nbk * (nbk + 
 // v_mfma_f32_16x16x32_f16 reproduces the fp32 product to ~2^-22) ------------------------------------------------
 // A 16 x 32 SLAB of a matrix G (rows = output rows, 32 consecutive k starting at an EVEN 16-block) is 2 planes x 64 lanes x 16 B:
 // lane l = 16 g + i holds G[i][8 g + j], j = 0..7, as eight f16 (plane 0: h1, plane 1: h2).  Row-block bi of the upper-triangular
-// L_r^T starts at block column bi & ~1 (the block below the diagonal is stored as zeros), so it has s16_slabs(nbk, bi) slabs; the
+// L_r^T starts at block column bi & ~1 (the block below the diagonal is stored as zeros), so it has s16_slabs(nbk, bi) slabs -- those of
+// row-blocks 2p and 2p+1 (same count) are INTERLEAVED chunk by chunk from s16_slab_off(nbk, 2p) on: the forward multiplies them as one step --; the
 // B operand (the a tile in LDS as 16-B vectors of eight f16: rows 8 kc + 2 g (h1) and 8 kc + 2 g + 1 (h2) hold a[32 kc + 8 g .. + 7]) needs no realignment.
 // Values are pre-multiplied by a power of two per matrix (L_r: max -> [2^13, 2^14); a: 2^ea with sigma -> <= 2^10) and the
 // accumulators scaled back (IWVI_CST_FR + r); only even nbk takes this path.
