@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libiwvi_hip.so")
 
 KERN_RBF, KERN_MATERN52 = 0, 1
 LAYER_GP, LAYER_LV = 0, 1
-ABI_VERSION = 9
+ABI_VERSION = 10
 GP_WANT_DENSE = 1
 ADAM_GRAD_F64 = 16
 MAX_STACK = 8
@@ -111,6 +111,7 @@ PROTOTYPES = {
     "iwvi_gp_layer_backward": (c_int, [ctypes.POINTER(GpBwdDesc), c_int64, c_void_p, c_void_p]),
     "iwvi_gp_layer_backward_needs_u": (c_int, [c_int64, c_int, c_int, c_int, c_int]),
     "iwvi_gp_layer_backward_prepare": (c_int, [ctypes.POINTER(GpBwdDesc), c_int64, c_void_p, c_void_p]),
+    "iwvi_gp_layers_backward_prepare": (c_int, [ctypes.POINTER(GpBwdDesc), c_int, c_int64, ctypes.POINTER(c_void_p), c_void_p]),
     "iwvi_iw_elbo_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, ctypes.POINTER(c_void_p),
                                       ctypes.POINTER(ctypes.c_int32), c_int, c_int64, c_int, c_float, c_double, c_int,
                                       c_void_p, c_void_p, c_void_p, ctypes.POINTER(c_void_p), ctypes.POINTER(ctypes.c_int32), c_int,

@@ -138,9 +138,20 @@ def prepare_side(model, T, stream, out=None, after=None):
             d.flags = _abi.GP_WANT_DENSE
             descs.append(d)
         precompute_states(descs)
-        for i, l in gps:
-            b, keep = _param_desc(l, out[i][1])
-            _abi.check(_abi.lib().iwvi_gp_layer_backward_prepare(ctypes.byref(b), T, out[i][0].data_ptr(), _abi.stream_ptr()))
+        if 1 < len(gps) <= _abi.MAX_STACK:                       # every layer's operands in one launch
+            arr = (_abi.GpBwdDesc * len(gps))()
+            wsp = (ctypes.c_void_p * len(gps))()
+            keeps = []
+            for k, (i, l) in enumerate(gps):
+                b, keep = _param_desc(l, out[i][1])
+                arr[k] = b
+                wsp[k] = out[i][0].data_ptr()
+                keeps.append(keep)
+            _abi.check(_abi.lib().iwvi_gp_layers_backward_prepare(arr, len(gps), T, wsp, _abi.stream_ptr()))
+        else:
+            for i, l in gps:
+                b, keep = _param_desc(l, out[i][1])
+                _abi.check(_abi.lib().iwvi_gp_layer_backward_prepare(ctypes.byref(b), T, out[i][0].data_ptr(), _abi.stream_ptr()))
     return out
 
 
@@ -204,10 +215,14 @@ def gp_backward(layer, saved, d_sample=None, d_mean=None, d_var=None, kl_weight=
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream())
 
-        def finish():
-            side_stream.wait_event(ev)
+        def finish(stream=None):
+            # ``stream``: queue the branch there instead (the caller's own stream, once nothing else is left to queue on it)
+            st = side_stream if stream is None else stream
+            if st != torch.cuda.current_stream() or stream is None:
+                st.wait_event(ev)
             b.phase = 2                                          # (same descriptor: the workspace layout depends on the two side streams)
-            _abi.check(_abi.lib().iwvi_gp_layer_backward(ctypes.byref(b), T, ws.data_ptr(), ctypes.c_void_p(side_stream.cuda_stream)))
+            b.side_stream = ctypes.c_void_p(st.cuda_stream)
+            _abi.check(_abi.lib().iwvi_gp_layer_backward(ctypes.byref(b), T, ws.data_ptr(), ctypes.c_void_p(st.cuda_stream)))
         out["_finish"] = finish
         return out
     _abi.check(_abi.lib().iwvi_gp_layer_backward(ctypes.byref(b), T, ws.data_ptr(), _abi.stream_ptr()))
@@ -357,6 +372,14 @@ def iw_elbo_and_gradients(model, zs=None, mode_vi=None, exchange=None, K_total=N
     # stream, every other sum on the caller's own stream -- nothing else is left to run there (0.364 -> 0.350 ms at configs[2])
     deferred = [j for j, l in enumerate(layers) if isinstance(l, GPLayer) and j > 0]
     last_deferred = min(deferred) if (deferred and overlap) else -1
+    # With two or more branches: a chain kernel fills every CU, so the branch of the layer above the lowest one does not get to run beside
+    # the lowest layer's chain anyway -- on the side stream it ends up IN FRONT of the lowest layer's branch, one after the other.  It is
+    # therefore queued on the caller's stream behind everything else there, and the lowest layer's branch runs whole on the side stream:
+    # the two branches then run side by side (configs[2]: 0.331 -> 0.307 ms per value + gradient).  IWVI_BW_BRANCH_ORDER=old: both on the side stream.
+    # (M <= 128 only: at M = 256 the branches are GEMM-sized and do overlap the chains -- configs[3]: 8.88 ms this way round, 9.09 ms the other)
+    on_cur = sorted(deferred)[1] if (len(deferred) >= 2 and overlap and os.environ.get("IWVI_BW_BRANCH_ORDER") != "old"
+                                     and layers[sorted(deferred)[1]].num_inducing <= 128) else -1
+    finish_on_cur = None
     for i in range(len(layers) - 1, -1, -1):
         layer, s = layers[i], saved[i]
         if s[0] == "gp":
@@ -367,12 +390,18 @@ def iw_elbo_and_gradients(model, zs=None, mode_vi=None, exchange=None, K_total=N
                             # (one side stream: with the chains of consecutive layers back to back on the caller's stream -- defer_params --
                             # a second one for the Cholesky-adjoint chain no longer pays: 0.400 -> 0.369 ms at configs[2] without it; alternating
                             # the layers' branches between two side streams: 0.356 -> 0.379 ms)
-                            side_stream2=cur if i == last_deferred else None)
+                            side_stream2=cur if (i == last_deferred and on_cur < 0) else None)
             for k_out, k_name in (("dZ", "Z"), ("dls", "ls"), ("dvariance", "var"), ("dq_mu", "q_mu"), ("dq_sqrt", "q_sqrt"),
                                   ("dW", "W"), ("dmf_A", "mfA")):
                 if k_out in g:
                     grads["l%d.%s" % (i, k_name)] = g[k_out]
             dF = g.get("dF")
+            if i == on_cur:
+                finish_on_cur = g.pop("_finish", None)
+                if pending is not None:
+                    pending()
+                pending = None
+                continue
             if pending is not None:
                 pending()
             pending = g.pop("_finish", None)
@@ -384,6 +413,8 @@ def iw_elbo_and_gradients(model, zs=None, mode_vi=None, exchange=None, K_total=N
             dF = None if (dF is None or i == 0) else dF[:, :D_in].contiguous()
     if pending is not None:
         pending()
+    if finish_on_cur is not None:
+        finish_on_cur(cur)
     if side is not None:
         cur.wait_stream(side)                                    # join: the parameter gradients are complete on the caller's stream
     del held

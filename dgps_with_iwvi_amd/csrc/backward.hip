@@ -1529,13 +1529,12 @@ __global__ __launch_bounds__(512) void k_bw_chain(ChainArgs a) {
 // SP16 (or NULL): the split-f16 image of the same S_r blocks for v_mfma_f32_16x16x32_f16 (iwvi_common.h: s16_*): slab (bi, r, kc) = the
 // blocks bk = 2kc, 2kc + 1, two planes of 64 lanes x 8 halves; scaled by 2^es_r with M max|L_r|^2 2^es_r <= 2^14 (max|L_r| from the scales
 // the factorisation launch left in the state's constant block); spf[r] = 2^-(es_r + ea), what an accumulated row-block is multiplied by.
-__global__ __launch_bounds__(256) void k_pack_bw(const float* __restrict__ q_sqrt, const double* __restrict__ Linv64, int Mp, int M, int R, int nbk,
-                                                 float* __restrict__ SP, float* __restrict__ LinvTP,
-                                                 unsigned short* __restrict__ SP16, const float* __restrict__ cst, float* __restrict__ spf) {
+__device__ __forceinline__ void pack_bw_body(int b, const float* __restrict__ q_sqrt, const double* __restrict__ Linv64, int Mp, int M, int R, int nbk,
+                                             float* __restrict__ SP, float* __restrict__ LinvTP,
+                                             unsigned short* __restrict__ SP16, const float* __restrict__ cst, float* __restrict__ spf) {
     __shared__ float Ls[2][16][129];                         // the 16 rows of L_r of row-block bi / bk, 128 columns at a time
     const int i = threadIdx.x >> 4, k = threadIdx.x & 15;
     const int off = (16 * (k >> 2) + i) * 4 + (k & 3);       // A-fragment order: lane 16g + i holds G[i][4g + s]
-    int b = blockIdx.x;
     const int nS = R * nbk * nbk;
     if (b < nS) {
         const int bi = b / (R * nbk), r = (b / nbk) % R, bk = b % nbk;
@@ -1571,6 +1570,11 @@ __global__ __launch_bounds__(256) void k_pack_bw(const float* __restrict__ q_sqr
     while (b >= nbk - bi) { b -= nbk - bi; ++bi; }
     const int bk = bi + b;
     LinvTP[((size_t)tri_upper_off(nbk, bi) + (bk - bi)) * 256 + off] = (float)Linv64[(size_t)(16 * bk + k) * Mp + 16 * bi + i];
+}
+__global__ __launch_bounds__(256) void k_pack_bw(const float* __restrict__ q_sqrt, const double* __restrict__ Linv64, int Mp, int M, int R, int nbk,
+                                                 float* __restrict__ SP, float* __restrict__ LinvTP,
+                                                 unsigned short* __restrict__ SP16, const float* __restrict__ cst, float* __restrict__ spf) {
+    pack_bw_body((int)blockIdx.x, q_sqrt, Linv64, Mp, M, R, nbk, SP, LinvTP, SP16, cst, spf);
 }
 static int chain_ns_cap(long long T, int cap) {             // samples per workgroup / 16: as the forward's (every CU a workgroup), then down to a divisor of T
     int ns = (int)((T + 16 * 256 - 1) / (16 * 256));
@@ -1790,11 +1794,32 @@ __global__ __launch_bounds__(256) void k_dmm(const double* A, long long a_si, lo
     if (post == 1) s = (j > i) ? 0.0 : (j == i ? 0.5 * s : s);
     C[(size_t)i * ldc + j] = s;
 }
-__global__ void k_prep(const float* Z, const float* ls, const double* Linv64, int Mp, float* Zt, float* invls, float* LinvF, int M, int D) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void prep_body(int bid, const float* Z, const float* ls, const double* Linv64, int Mp, float* Zt, float* invls, float* LinvF, int M, int D) {
+    const int idx = bid * 256 + threadIdx.x;
     if (idx < D) invls[idx] = 1.f / ls[idx];
     if (idx < M * D) Zt[idx] = Z[idx] / ls[idx % D];
     if (idx < M * M) { const int i = idx / M, j = idx - i * M; LinvF[idx] = j <= i ? (float)Linv64[(size_t)i * Mp + j] : 0.f; }
+}
+__global__ __launch_bounds__(256) void k_prep(const float* Z, const float* ls, const double* Linv64, int Mp, float* Zt, float* invls, float* LinvF, int M, int D) {
+    prep_body((int)blockIdx.x, Z, ls, Linv64, Mp, Zt, invls, LinvF, M, D);
+}
+// the parameter-only operands of EVERY layer's adjoint in one launch (iwvi_gp_layers_backward_prepare): the four small launches of a
+// two-layer model queue up behind the layer kernel, which holds every CU -- as one they are over before the ELBO tail's adjoint is
+struct PrepOne {
+    const float* Z; const float* ls; const double* Linv64; const float* q_sqrt; const float* cst;
+    float* Zt; float* invls; float* LinvF; float* SP; float* LinvTP; unsigned short* SP16; float* spf;
+    int Mp, M, D, R, nbk, nprep, npack, pad_;
+};
+struct PrepAll { PrepOne L[IWVI_MAX_STACK]; int n; };
+__global__ __launch_bounds__(256) void k_prepare_all(const PrepAll a) {
+    int b = (int)blockIdx.x;
+    for (int li = 0; li < a.n; ++li) {
+        const PrepOne& L = a.L[li];
+        if (b < L.nprep) { prep_body(b, L.Z, L.ls, L.Linv64, L.Mp, L.Zt, L.invls, L.LinvF, L.M, L.D); return; }
+        b -= L.nprep;
+        if (b < L.npack) { pack_bw_body(b, L.q_sqrt, L.Linv64, L.Mp, L.M, L.R, L.nbk, L.SP, L.LinvTP, L.SP16, L.cst, L.spf); return; }
+        b -= L.npack;
+    }
 }
 // row m of K_uu: dZ~_uu[m, :] = 4 sum_n Sbar_mn dK_mn/dd2 (z~_m - z~_n),  dvar_m = sum_n Sbar_mn K_mn / s2,  Sbar = (S + S^T)/2
 __global__ __launch_bounds__(256) void k_kuu_bwd(const float* Zt, const double* S, int M, int D, double variance_, const float* var_dev, int kern_type, double* dZt_uu, double* dvar_m) {
@@ -2397,6 +2422,35 @@ extern "C" int iwvi_gp_layer_backward_prepare(const iwvi_gp_bwd_desc* dp, int64_
                            s16 ? w.SP16 : (unsigned short*)nullptr, (const float*)((const char*)d.state + sl.off_cst), w.spf);
     }
     return check_launch("iwvi_gp_layer_backward_prepare");
+}
+
+extern "C" int iwvi_gp_layers_backward_prepare(const iwvi_gp_bwd_desc* descs, int n, int64_t T, void* const* ws, void* stream_) {
+    if (!descs || !ws || n <= 0 || n > IWVI_MAX_STACK || T <= 0) { set_error("iwvi_gp_layers_backward_prepare: bad argument"); return IWVI_ERR_ARG; }
+    PrepAll a{};
+    a.n = n;
+    unsigned grid = 0;
+    for (int i = 0; i < n; ++i) {
+        const iwvi_gp_bwd_desc& d = descs[i];
+        if (!ws[i] || !d.state || !d.Z || !d.lengthscales || !d.q_sqrt || d.M <= 0 || d.M > IWVI_MAX_M || d.D <= 0 || d.D > IWVI_MAX_D || d.R <= 0 || d.R > IWVI_MAX_R) {
+            set_error("iwvi_gp_layers_backward_prepare: layer %d: null input or size out of range", i); return IWVI_ERR_ARG;
+        }
+        const int M = d.M, D = d.D, R = d.R;
+        const StateLayout sl = state_layout(M, R);
+        BwdWs w = bwd_layout((char*)ws[i], T, M, D, R);
+        PrepOne& L = a.L[i];
+        L.Z = d.Z; L.ls = d.lengthscales; L.Linv64 = (const double*)((const char*)d.state + sl.off_Linv); L.q_sqrt = d.q_sqrt;
+        L.cst = (const float*)((const char*)d.state + sl.off_cst);
+        L.Zt = w.Zt; L.invls = w.invls; L.LinvF = w.LinvF; L.SP = w.SP; L.LinvTP = w.LinvTP; L.spf = w.spf;
+        L.Mp = sl.Mp; L.M = M; L.D = D; L.R = R; L.nbk = sl.Mp / 16;
+        const int nn = M * M > M * D ? M * M : M * D;
+        L.nprep = (nn + 255) / 256;
+        const bool chain = chain_fits(T, M, sl.Mp, D, R, d.P > 0 ? d.P : R);
+        L.npack = chain ? R * L.nbk * L.nbk + tri_blocks(L.nbk) : 0;
+        L.SP16 = (chain && chain_s16(M, sl.Mp)) ? w.SP16 : (unsigned short*)nullptr;
+        grid += (unsigned)(L.nprep + L.npack);
+    }
+    hipLaunchKernelGGL(k_prepare_all, dim3(grid), dim3(256), 0, (hipStream_t)stream_, a);
+    return check_launch("iwvi_gp_layers_backward_prepare");
 }
 
 extern "C" int iwvi_gp_layer_backward(const iwvi_gp_bwd_desc* dp, int64_t T, void* ws_, void* stream_) {

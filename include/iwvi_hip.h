@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define IWVI_ABI_VERSION 9
+#define IWVI_ABI_VERSION 10
 
 enum {
     IWVI_OK = 0,
@@ -316,6 +316,9 @@ int iwvi_gp_layer_backward_needs_u(int64_t T, int M, int D, int R, int P);
  * S_r = L_r L_r^T and Lm^-T): reads state (dense factors), Z, lengthscales, q_sqrt, M / D / R of the descriptor only, so it can
  * be queued on another stream beside the forward; then set desc.prepared.  Called implicitly otherwise. */
 int iwvi_gp_layer_backward_prepare(const iwvi_gp_bwd_desc* desc, int64_t T, void* ws, void* stream);
+/* The same for n layers (n <= IWVI_MAX_STACK) in ONE launch: descs[i] with its workspace ws[i].  (The prepare steps of a model are
+ * queued beside the layer kernel, which holds every CU; as separate launches they run one after the other once it retires.) */
+int iwvi_gp_layers_backward_prepare(const iwvi_gp_bwd_desc* descs, int n, int64_t T, void* const* ws, void* stream);
 /* Outputs left NULL are not formed.  With ONLY dq_mu / dq_sqrt given (what the natural-gradient op of build_models.py:288-295 reads)
  * the call reduces to the heads and the two sums over samples behind those gradients (on either path: the streaming chain, or the
  * GEMMs over a_out / u_out): no prepare step, no dense factors in `state`, no kernel adjoint, no adjoint of the factorisation; the
