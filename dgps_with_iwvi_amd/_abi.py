@@ -14,8 +14,9 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libiwvi_hip.so")
 
 KERN_RBF, KERN_MATERN52 = 0, 1
 LAYER_GP, LAYER_LV = 0, 1
-ABI_VERSION = 10
+ABI_VERSION = 11
 GP_WANT_DENSE = 1
+GP_WANT_LM = 2
 ADAM_GRAD_F64 = 16
 MAX_STACK = 8
 MF_ZERO, MF_IDENTITY, MF_LINEAR = 0, 1, 2
@@ -102,6 +103,7 @@ PROTOTYPES = {
     "iwvi_gp_state_bytes": (c_size_t, [c_int, c_int]),
     "iwvi_gp_state_offsets": (c_int, [c_int, c_int, ctypes.POINTER(c_size_t)]),
     "iwvi_gp_precompute": (c_int, [ctypes.POINTER(GpDesc), c_int, c_void_p]),
+    "iwvi_gp_dense_inverse": (c_int, [ctypes.POINTER(GpDesc), c_int, c_void_p]),
     "iwvi_model_precompute": (c_int, [ctypes.POINTER(GpDesc), c_int, ctypes.POINTER(EncDesc), c_int, c_void_p]),
     "iwvi_rbf_gram_sym": (c_int, [c_void_p, c_void_p, c_float, c_double, c_int, c_int, c_int,
                                   c_void_p, c_void_p]),

@@ -116,6 +116,38 @@ def prepare_alloc(model, T):
     return out
 
 
+def prepare_inline(model, T):
+    """The adjoint's operands from the forward's OWN factorisation, on the caller's stream: ``model.precompute(dense="lm")`` (one
+    factorisation for both passes, the dense factor written too), ``iwvi_gp_dense_inverse`` (Lm^-1 on nbk CUs per layer) and the
+    parameter-only part of every layer's adjoint in one launch.  No second factorisation, no second state buffer, nothing to join:
+    the dense factorisation of ``prepare_side`` holds one CU per layer for twice as long as the fast one, and two workgroups of the
+    layer kernel -- which needs every CU -- wait for it.  -> {layer index: (workspace, state)} like ``prepare_side``; the caller must
+    NOT run ``model.precompute`` again."""
+    dev = model.X.device
+    gps = [(i, l) for i, l in enumerate(model.layers) if isinstance(l, GPLayer)]
+    out = {}
+    for i, l in gps:
+        D = l._Z().shape[1]
+        ws = torch.empty(_abi.lib().iwvi_gp_layer_backward_ws_bytes(T, l.num_inducing, D, l.num_outputs), dtype=torch.uint8, device=dev)
+        out[i] = (ws, l.state())
+    model.precompute(with_encoders=True, dense="lm")
+    if len(gps) <= _abi.MAX_STACK:
+        arr = (_abi.GpBwdDesc * len(gps))()
+        wsp = (ctypes.c_void_p * len(gps))()
+        keeps = []
+        for k, (i, l) in enumerate(gps):
+            b, keep = _param_desc(l, out[i][1])
+            arr[k] = b
+            wsp[k] = out[i][0].data_ptr()
+            keeps.append(keep)
+        _abi.check(_abi.lib().iwvi_gp_layers_backward_prepare(arr, len(gps), T, wsp, _abi.stream_ptr()))
+    else:
+        for i, l in gps:
+            b, keep = _param_desc(l, out[i][1])
+            _abi.check(_abi.lib().iwvi_gp_layer_backward_prepare(ctypes.byref(b), T, out[i][0].data_ptr(), _abi.stream_ptr()))
+    return out
+
+
 def prepare_side(model, T, stream, out=None, after=None):
     """On ``stream``, beside the forward: the dense float64 factors of every GP layer (into its second state buffer) and the
     parameter-only part of its adjoint (``iwvi_gp_layer_backward_prepare``: scaled inducing inputs, packed S_r = L_r L_r^T and
@@ -307,10 +339,19 @@ def iw_elbo_and_gradients(model, zs=None, mode_vi=None, exchange=None, K_total=N
     prep_stream = _side_stream(dev, 2) if (overlap and not final_q) else cur
     # (queued BEFORE the caller's own precompute: queued after it -- ordered by an event only -- the dense factorisation lands beside the
     # layer kernel instead, whose workgroups then wait for its two CUs: 0.355 -> 0.382 ms at configs[2])
-    prepared = {} if final_q else prepare_side(model, T, prep_stream)
-    # forward: one factorisation launch (packed operands, encoders) + ONE fused layer launch that also leaves what the
-    # adjoints need in HBM (a = Lm^-1 k, the draws, every layer's output rows)
-    model.precompute(with_encoders=True)
+    n_gp = sum(isinstance(l, GPLayer) for l in layers)
+    inline = (not final_q) and n_gp <= _abi.MAX_STACK and os.environ.get("IWVI_BW_PREPARE") == "inline"
+    if inline:
+        # IWVI_BW_PREPARE=inline: one factorisation for both passes (prepare_inline).  Measured, not the default: the inversion launch sits
+        # in front of the layer kernel (17 us at M = 128) where the side stream's dense factorisation costs the layer kernel 7 us and a
+        # join 10 -- configs[2] 0.318 vs 0.309 ms per value + gradient, configs[3] 8.98 vs 8.90 ms
+        prepared = prepare_inline(model, T)
+        prep_stream = cur
+    else:
+        prepared = {} if final_q else prepare_side(model, T, prep_stream)
+        # forward: one factorisation launch (packed operands, encoders) + ONE fused layer launch that also leaves what the
+        # adjoints need in HBM (a = Lm^-1 k, the draws, every layer's output rows)
+        model.precompute(with_encoders=True)
     zflat = [None if z is None else z.reshape(T, -1) for z in zs]
     _, outs, _ = model._fused_forward(T, K, B, (T,), zs=zflat, sampled_kl=not mode_vi, want_layers=True, want_logw=False,
                                       want_saved=True)

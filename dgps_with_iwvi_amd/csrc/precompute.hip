@@ -542,7 +542,7 @@ __device__ void role_factor(const PreLayer& Lin, int stop_after, unsigned long l
     PRE_STAMP(4);
     PRE_STAMP(5);
     const bool dense = (L.flags & IWVI_GP_WANT_DENSE) != 0;
-    if (dense) {
+    if (dense || (L.flags & IWVI_GP_WANT_LM)) {                  // (WANT_LM: the factor only; iwvi_gp_dense_inverse forms Lm^-1 on many CUs)
         for (int idx = tid; idx < Mp * Mp; idx += nthreads) {
             const int i = idx / Mp, k = idx - i * Mp;
             L.Lm[idx] = (k <= i) ? blk_get(blk, i, k) : 0.0;
@@ -1200,6 +1200,134 @@ extern "C" int iwvi_model_precompute(const iwvi_gp_desc* layers, int n_layers, c
         if ((rc = check_launch("k_precompute")) != IWVI_OK) return rc;
     }
     return IWVI_OK;
+}
+
+// ---- Lm^-1 from the dense Lm, one workgroup (4 waves) per 16-column block J of the inverse: X_J = D_J^-1, then block row by block row
+// X_bi = -D_bi^-1 sum_{J <= bk < bi} L(bi, bk) X_bk (float64 MFMA products, the sum dealt to the four waves).  nbk workgroups per layer
+// instead of the factorising workgroup's recursive doubling (17 of the 54 us of a dense factorisation at M = 128 on ONE CU, during which
+// that CU is lost to the layer kernel): 5-6 us at M = 128.
+namespace iwvi {
+struct LinvOne { const double* Lm; double* Linv; int Mp, nbk, first; int pad_; };
+struct LinvAll { LinvOne L[IWVI_MAX_STACK]; int n; };
+__global__ __launch_bounds__(256) void k_linv(const LinvAll a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char linv_smem[];
+    int li = 0;
+    while (li + 1 < a.n && (int)blockIdx.x >= a.L[li + 1].first) ++li;
+    const LinvOne& L = a.L[li];
+    const int J = (int)blockIdx.x - L.first, nbk = L.nbk, Mp = L.Mp, nb = nbk - J;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double* X = reinterpret_cast<double*>(linv_smem);            // [nb][BLK]: the finished blocks of this block column
+    double* Dv = X + (size_t)nb * BLK;                          // [nb][BLK]: the diagonal blocks, then their inverses
+    double* part = Dv + (size_t)nb * BLK;                       // [4][BLK]: the waves' partial sums
+    double* rinv = part + 4 * BLK;                              // [nb][16]: reciprocal pivots
+    // nbk <= 8: the lower blocks L(J + t, J + u), u <= t, go to LDS in ONE round trip (all loads of a thread issued before its first store:
+    // a load-store loop pays a global round trip per block, 30 us for the 36 blocks of J = 0): the diagonal ones to Dv (inverted in place
+    // below), the others to the packed triangle Ls[t (t - 1) / 2 + u] -- read from the dense factor inside the loop, every step would
+    // wait for a round trip of its own
+    double* Ls = rinv + (size_t)nb * 16;
+    const bool staged = nbk <= 8;
+    {
+        const int rr = tid >> 4, cc = tid & 15;
+        if (staged) {
+            constexpr int MAXB = 36;
+            const int ntot = nb * (nb + 1) / 2;
+            double v[MAXB];
+#pragma unroll
+            for (int q = 0; q < MAXB; ++q) {
+                int t = 0;
+                while ((t + 1) * (t + 2) / 2 <= q) ++t;              // (compile-time: q is an unrolled constant)
+                const int u = q - t * (t + 1) / 2;
+                v[q] = (q < ntot) ? L.Lm[(size_t)(16 * (J + t) + rr) * Mp + 16 * (J + u) + cc] : 0.0;
+            }
+#pragma unroll
+            for (int q = 0; q < MAXB; ++q) {
+                int t = 0;
+                while ((t + 1) * (t + 2) / 2 <= q) ++t;
+                const int u = q - t * (t + 1) / 2;
+                if (q < ntot) {
+                    if (u == t) { Dv[(size_t)t * BLK + rr * BLD + cc] = v[q]; if (rr == cc) rinv[t * 16 + rr] = 1.0 / v[q]; }
+                    else Ls[(size_t)(t * (t - 1) / 2 + u) * BLK + rr * BLD + cc] = v[q];
+                }
+            }
+        } else {
+            for (int b0 = 0; b0 < nb; b0 += 8) {                     // diagonal blocks only, eight round trips in flight
+                double v[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { const int bi = J + (b0 + e < nb ? b0 + e : nb - 1); v[e] = L.Lm[(size_t)(16 * bi + rr) * Mp + 16 * bi + cc]; }
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    if (b0 + e < nb) { Dv[(size_t)(b0 + e) * BLK + rr * BLD + cc] = v[e]; if (rr == cc) rinv[(b0 + e) * 16 + rr] = 1.0 / v[e]; }
+            }
+        }
+    }
+    __syncthreads();
+    for (int b = wave; b < nb; b += 4) diag_inverse(Dv + (size_t)b * BLK, rinv + b * 16, b == 0 ? X : Dv + (size_t)b * BLK, lane);
+    __syncthreads();
+    const int r = lane & 15, g = lane >> 4;
+    for (int t = 1; t < nb; ++t) {
+        const int bi = J + t;
+        f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+        for (int bk = J + wave; bk < bi; bk += 4) {             // acc += L(bi, bk) X_bk
+            const double* B = X + (size_t)(bk - J) * BLK;
+            if (staged) blk_mma<false>(acc, Ls + (size_t)(t * (t - 1) / 2 + (bk - J)) * BLK, B, lane, 1.0);
+            else {                                              // (the A operand straight from the dense factor)
+                const double* Ag = L.Lm + (size_t)(16 * bi + r) * Mp + 16 * bk;
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Ag[4 * kk + g], B[(4 * kk + g) * BLD + r], acc, 0, 0, 0);
+            }
+        }
+        blk_store(part + wave * BLK, acc, lane);
+        __syncthreads();
+        {   // the four partial sums, one entry per thread
+            const int rr = tid >> 4, cc = tid & 15, o = rr * BLD + cc;
+            part[o] = (part[o] + part[BLK + o]) + (part[2 * BLK + o] + part[3 * BLK + o]);
+        }
+        __syncthreads();
+        if (wave == 0) {
+            f64x4 x = {0.0, 0.0, 0.0, 0.0};
+            blk_mma<false>(x, Dv + (size_t)t * BLK, part, lane, -1.0);
+            blk_store(X + (size_t)t * BLK, x, lane);
+        }
+        __syncthreads();
+    }
+    // block column J of the dense inverse (zeros above the diagonal block)
+    for (int idx = tid; idx < nbk * 256; idx += 256) {
+        const int bi = idx >> 8, rr = (idx >> 4) & 15, cc = idx & 15;
+        double v = 0.0;
+        if (bi >= J) v = X[(size_t)(bi - J) * BLK + rr * BLD + cc];
+        if (bi == J && cc > rr) v = 0.0;
+        L.Linv[(size_t)(16 * bi + rr) * Mp + 16 * J + cc] = v;
+    }
+}
+}  // namespace iwvi
+
+extern "C" int iwvi_gp_dense_inverse(const iwvi_gp_desc* layers, int n_layers, void* stream_) {
+    using namespace iwvi;
+    if (!layers || n_layers <= 0 || n_layers > IWVI_MAX_STACK) { set_error("iwvi_gp_dense_inverse: bad argument"); return IWVI_ERR_ARG; }
+    LinvAll a{};
+    a.n = n_layers;
+    int grid = 0;
+    for (int i = 0; i < n_layers; ++i) {
+        const iwvi_gp_desc& d = layers[i];
+        if (!d.state || d.M <= 0 || d.M > IWVI_MAX_M || d.R <= 0 || d.R > IWVI_MAX_R) { set_error("iwvi_gp_dense_inverse: layer %d: null state or size out of range", i); return IWVI_ERR_ARG; }
+        const StateLayout s = state_layout(d.M, d.R);
+        a.L[i].Lm = (const double*)((const char*)d.state + s.off_Lm);
+        a.L[i].Linv = (double*)((char*)d.state + s.off_Linv);
+        a.L[i].Mp = s.Mp; a.L[i].nbk = s.nbk; a.L[i].first = grid;
+        grid += s.nbk;
+    }
+    size_t lds = 0;
+    for (int i = 0; i < n_layers; ++i) {
+        const int nb = a.L[i].nbk;
+        const size_t need = sizeof(double) * ((size_t)(2 * nb + 4 + (nb <= 8 ? nb * (nb - 1) / 2 : 0)) * BLK + (size_t)nb * 16);
+        if (need > lds) lds = need;
+    }
+    if (lds > 64 * 1024) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_linv), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) { set_error("iwvi_gp_dense_inverse: %zu B of LDS: %s", lds, hipGetErrorString(e)); return IWVI_ERR_LAUNCH; }
+    }
+    hipLaunchKernelGGL(k_linv, dim3(grid), dim3(256), lds, (hipStream_t)stream_, a);
+    return check_launch("iwvi_gp_dense_inverse");
 }
 
 extern "C" int iwvi_rbf_gram_sym(const float* Z, const float* ls, float variance, double jitter,

@@ -113,9 +113,12 @@ class DGP_VI:
                     l._enc_key = self._mb_key()
         descs = [l.state_desc() for l in self.layers if isinstance(l, GPLayer)]
         if dense:                                                    # the adjoints read the dense float64 Lm, Lm^-1
-            for d in descs:
-                d.flags = _abi.GP_WANT_DENSE
+            for d in descs:                                          # ("lm": the factor only; Lm^-1 by iwvi_gp_dense_inverse)
+                d.flags = _abi.GP_WANT_LM if dense == "lm" else _abi.GP_WANT_DENSE
         precompute_states(descs, encs)
+        if dense == "lm" and descs:
+            arr = (_abi.GpDesc * len(descs))(*descs)
+            _abi.check(_abi.lib().iwvi_gp_dense_inverse(arr, len(descs), _abi.stream_ptr()))
 
     def propagate(self, X, full_cov=False, inference_amorization_inputs=None,
                   is_sampled_local_regularizer=False, zs=None, _precomputed=False, _kl_parts=False, _last_sample=True):

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define IWVI_ABI_VERSION 10
+#define IWVI_ABI_VERSION 11
 
 enum {
     IWVI_OK = 0,
@@ -83,6 +83,7 @@ const char* iwvi_last_error(void);
  * iwvi_gp_state_bytes() returns the size; offsets via iwvi_gp_state_offsets().
  * ---------------------------------------------------------------------- */
 #define IWVI_GP_WANT_DENSE 1   /* iwvi_gp_desc.flags: also write the dense float64 Lm and Lm^-1 */
+#define IWVI_GP_WANT_LM    2   /* iwvi_gp_desc.flags: also write the dense float64 Lm (Lm^-1 then by iwvi_gp_dense_inverse)  */
 
 typedef struct iwvi_gp_desc {
     const float* Z;            /* [M, D]  inducing inputs                        */
@@ -94,7 +95,7 @@ typedef struct iwvi_gp_desc {
     double jitter;             /* gpflow settings.numerics.jitter_level          */
     int32_t M, D, R;
     int32_t kern_type;         /* IWVI_KERN_*                                    */
-    int32_t flags;             /* IWVI_GP_WANT_DENSE or 0                        */
+    int32_t flags;             /* IWVI_GP_WANT_DENSE, IWVI_GP_WANT_LM or 0       */
     const float* variance_dev; /* optional DEVICE scalar: read instead of `variance` when the launch runs (a trained
                                 * kernel variance that lives on the device keeps a captured hipGraph valid across steps) */
 } iwvi_gp_desc;
@@ -106,6 +107,10 @@ int iwvi_gp_state_offsets(int M, int R, size_t out_host[8]);
 /* factorise up to IWVI_MAX_LAYERS layers per launch: grid (layer, role) -- role 0 Gram + Cholesky +
  * triangular inverse + packing, roles 1..R tril(q_sqrt[r])^T packing + KL share */
 int iwvi_gp_precompute(const iwvi_gp_desc* layers_host, int n_layers, void* stream);
+/* Lm^-1 (dense float64) from the dense Lm of states precomputed with IWVI_GP_WANT_LM (or _DENSE): one workgroup per 16-column block of
+ * the inverse, n_layers <= IWVI_MAX_STACK in one launch.  The adjoint's route to the dense factors: one factorisation serves the
+ * forward and the backward, and the inversion does not sit on the factorising workgroup's CU. */
+int iwvi_gp_dense_inverse(const iwvi_gp_desc* layers_host, int n_layers, void* stream);
 
 /* The same launch can also evaluate the Encoder MLP of a LatentVariableLayer (layers.py:137-152) for every row of
  * the minibatch: it does not depend on the factorisation, so it runs on otherwise idle CUs, off the critical

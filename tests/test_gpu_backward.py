@@ -332,3 +332,50 @@ def test_full_size_gradient_agrees_with_central_differences_of_the_forward(gpu_d
             p.add_(eps * d)
         fd = (fp - fm) / (2 * eps)
         assert abs(fd - gd) <= 0.02 * abs(gd) + noise / eps, (name, fd, gd, eps)       # measured: 3e-5 .. 9e-3 relative
+
+
+@pytest.mark.parametrize("M,R", [(128, 5), (40, 2), (256, 1), (512, 1)])
+def test_dense_inverse_launch_equals_the_factorising_kernels_inverse(gpu_device, M, R):  # (R: the layer's own; the inverse does not depend on it)
+    """``iwvi_gp_dense_inverse`` (Lm^-1 from the dense Lm of an ``IWVI_GP_WANT_LM`` state, one workgroup per 16-column block) against
+    the inverse the factorising workgroup writes with ``IWVI_GP_WANT_DENSE``, and against float64 LAPACK on the same Lm."""
+    import ctypes
+    from dgps_with_iwvi_amd import _abi, synthetic
+    from dgps_with_iwvi_amd.layers import GPLayer
+    from dgps_with_iwvi_amd.temp_workaround import GpState, precompute_states
+    spec = synthetic.make_spec(L=1, M=M, B=4, K=2, with_lv=False, seed=5)
+    model = synthetic.build_model(spec, gpu_device)
+    layer = [l for l in model.layers if isinstance(l, GPLayer)][0]
+    Mp = (M + 15) // 16 * 16
+    st_a, st_b = GpState(layer.num_inducing, layer.num_outputs, gpu_device), GpState(layer.num_inducing, layer.num_outputs, gpu_device)
+    da, db = layer.state_desc(state=st_a), layer.state_desc(state=st_b)
+    da.flags, db.flags = _abi.GP_WANT_DENSE, _abi.GP_WANT_LM
+    precompute_states([da]); precompute_states([db])
+    arr = (_abi.GpDesc * 1)(db)
+    _abi.check(_abi.lib().iwvi_gp_dense_inverse(arr, 1, _abi.stream_ptr()))
+    torch.cuda.synchronize()
+    Lm_a, Li_a = (st_a.view(n, torch.float64, Mp * Mp).reshape(Mp, Mp) for n in ("Lm", "Linv"))
+    Lm_b, Li_b = (st_b.view(n, torch.float64, Mp * Mp).reshape(Mp, Mp) for n in ("Lm", "Linv"))
+    assert torch.equal(Lm_a, Lm_b)
+    ref = torch.linalg.inv(Lm_b.cpu()).numpy()
+    scale = np.abs(ref).max()
+    assert np.abs(Li_b.cpu().numpy() - ref).max() <= 1e-9 * scale * max(1.0, np.linalg.cond(Lm_b.cpu().numpy()) * 1e-6)
+    assert np.abs(Li_b.cpu().numpy() - Li_a.cpu().numpy()).max() <= 1e-9 * scale * max(1.0, np.linalg.cond(Lm_b.cpu().numpy()) * 1e-6)
+    assert float(torch.triu(Li_b, 1).abs().max()) == 0.0
+
+
+def test_inline_prepare_route_gives_the_default_routes_gradients(gpu_device, monkeypatch):
+    """IWVI_BW_PREPARE=inline (one factorisation for both passes + iwvi_gp_dense_inverse) against the default (a second, dense
+    factorisation on a side stream): same bound; gradients to float32 rounding of two float64 inverses that differ in the last bits."""
+    from dgps_with_iwvi_amd import backward, synthetic
+    spec = synthetic.make_spec(L=2, M=128, B=16, K=5, with_lv=True, seed=21)
+    zs = synthetic.make_noise(spec, seed=3)
+    model = synthetic.build_model(spec, gpu_device)
+    zd = [torch.as_tensor(np.asarray(z, dtype=np.float32), device=gpu_device) for z in zs]
+    e0, g0 = backward.iw_elbo_and_gradients(model, zd)
+    monkeypatch.setenv("IWVI_BW_PREPARE", "inline")
+    e1, g1 = backward.iw_elbo_and_gradients(model, zd)
+    torch.cuda.synchronize()
+    assert float(e0) == float(e1)
+    for k in g0:
+        a, b = g0[k].double().cpu().numpy(), g1[k].double().cpu().numpy()
+        assert np.abs(a - b).max() <= 1e-4 * max(np.abs(a).max(), 1e-30), k
