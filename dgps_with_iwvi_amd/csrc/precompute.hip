@@ -282,7 +282,14 @@ __device__ __forceinline__ void chol_blocks(double* blk, int nbk, double* rinv, 
             int wg = w;                                  // generation starts with the workers the catch-up left idle
             if (p > 0 && m < nwo) { wg = w - m; if (wg < 0) wg += nwo; }
             if (p + 2 < nbk) gen(p + 2, p + 3, wg, nwo);
-            if (p > 0) for (int it = w * 64 + lane; it < (nbk - p + 1) * 64; it += nwo * 64) post(p - 1, it >> 6, it & 63);
+            // packing column p-1: dealt to the workers that do NOT generate in this step, the idle ones first (rotated index wg: [0, ng)
+            // generate, then the idle waves, the catch-up waves last) -- generating a block costs ten times a catch-up product, and the
+            // barrier of an early pass waits for the generating waves
+            if (p > 0) {
+                const int ng = (p + 2 < nbk) ? nbk - p - 2 : 0;
+                const int rel = ng < nwo ? wg - ng : w, nrel = ng < nwo ? nwo - ng : nwo;
+                if (rel >= 0) for (int it = rel * 64 + lane; it < (nbk - p + 1) * 64; it += nrel * 64) post(p - 1, it >> 6, it & 63);
+            }
             if (p == nbk - 1) tail(w * 64 + lane, nwo * 64);     // work nobody waits for, beside the last (otherwise idle) pass
         }
         __syncthreads();
