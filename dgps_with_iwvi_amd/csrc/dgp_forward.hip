@@ -924,6 +924,9 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
                         // A blocks requested one group ahead -- so the phase is bound by MFMA issue, not by the latency of
                         // one dependent chain per block.  (Clamped indices: a short last group recomputes its last row,
                         // nothing of it is written back.)
+                    int tcol_g = tcol;                              // opaque copy: this rarely taken path's tile addresses are formed here, not
+                    asm volatile("" : "+v"(tcol_g));                // hoisted to the top of the kernel where they cost a live (spilled) register
+                    const int tcol = tcol_g;
                     f32x4 xcur = kuf[gq * NSAMP + tcol];             // r_0
                     for (int bj = 0; bj < nbk; ++bj) {
                         const size_t col = (size_t)tri_upper_off(nbk, bj);
