@@ -1326,7 +1326,9 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
                     }
                 }
             } else if (wave < NS) {
-                const int j = 16 * wave + jq;
+                int j_ = 16 * wave + jq;                          // opaque copy: the row addresses below are formed here, per layer, instead of
+                asm volatile("" : "+v"(j_));                      // living (spilled, in the narrow variants) across the whole layer loop
+                const int j = j_;
                 const long long t = t0 + j;
                 const int Dm = (G.mf_type == IWVI_MF_LINEAR) ? D : 0;
                 const int npb = (P + 15) >> 4;                    // 16-row blocks of outputs: 1 or 2
