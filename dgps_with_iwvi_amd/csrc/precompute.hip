@@ -388,12 +388,18 @@ __device__ void role_factor(const PreLayer& Lin, int stop_after, unsigned long l
     double* znd = reinterpret_cast<double*>(zcs + 32);   // the same squared norms in float64 (Gram)
 
     // scaled inducing inputs, float32-rounded (the values the K_uf Gram also sees)
+    // (1024 threads: thread (pr = tid >> 5, d = tid & 31) loads exactly the rows m = pr, pr + 32, .. of column d -- the 32 partial sums of
+    // the column means below are formed right here, in the same order, without waiting for the tile)
+    const bool fused_sum = nthreads == 1024;
+    double colpart = 0.0;
     for (int idx = tid; idx < Mp * 32; idx += nthreads) {
         const int m = idx >> 5, d = idx & 31;
         float v = 0.f;
         if (m < M && d < D) v = (float)((double)L.Z[(size_t)m * D + d] / (double)L.ls[d]);
         zs[m * ZLD + d] = v;
+        if (m < M) colpart += (double)v;
     }
+    if (fused_sum) (znd + Mp)[(tid >> 5) * 32 + (tid & 31)] = colpart;
     if (tid < 32) L.cst[tid] = (tid < D) ? (float)(1.0 / (double)L.ls[tid]) : 0.f;
     const int lg_sigma = (int)ceilf(0.5f * log2f(fmaxf(L.variance, 1e-30f)));
     const bool st1_16 = (L.nbk <= 8) && ((L.nbk & 1) == 0);  // this layer's solve takes split-f16 off-diagonal updates (iwvi_common.h: IWVI_CST_U)
@@ -408,12 +414,14 @@ __device__ void role_factor(const PreLayer& Lin, int stop_after, unsigned long l
     {   // column means of zs: 32 partial sums per column, then one thread per column adds them in a fixed order
         double* partd = znd + Mp;                                    // [32][32] partial sums
         const int d = tid & 31, pr = tid >> 5;                       // 32 parts (1024 threads)
-        if (pr < 32) {
-            double acc = 0.0;
-            for (int m = pr; m < M; m += 32) acc += (double)zs[m * ZLD + d];
-            partd[pr * 32 + d] = acc;
+        if (!fused_sum) {
+            if (pr < 32) {
+                double acc = 0.0;
+                for (int m = pr; m < M; m += 32) acc += (double)zs[m * ZLD + d];
+                partd[pr * 32 + d] = acc;
+            }
+            __syncthreads();
         }
-        __syncthreads();
         if (tid < 32) {
             double acc = 0.0;
             for (int q = 0; q < 32; ++q) acc += partd[q * 32 + tid];
