@@ -46,7 +46,10 @@ class Trainer:
         step in eager mode, every ``check_every`` steps in graph mode."""
         self.model = model
         self.group, self.shard_weight, self.shard = group, shard_weight, shard
-        if shard == "n" and (group is not None or num_data_total is not None):
+        import torch.distributed as dist
+        # group=None means the DEFAULT group once torch.distributed is up: what counts is the number of ranks
+        self.world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+        if shard == "n" and (self.world > 1 or group is not None or num_data_total is not None):
             from .sharding import resolve_n_shard
             _, w = resolve_n_shard(model, group, num_data_total)
             if self.shard_weight is None:
@@ -58,7 +61,7 @@ class Trainer:
         self.global_step = 0
         self.adam_t = 0
         self.use_graph, self.check_finite, self.check_every = bool(use_graph), bool(check_finite), max(1, int(check_every))
-        if self.use_graph and group is not None:
+        if self.use_graph and self.world > 1:
             raise ValueError("use_graph captures a single-GPU step; sharded training launches its collectives eagerly")
         self._graphs = {}                                      # op name -> (decay epoch, CUDAGraph, elbo tensor)
         dev = model.X.device
@@ -172,6 +175,13 @@ class Trainer:
                                      "precision matrix indefinite: lower gamma)" % self.global_step)
 
     _capturing = False
+    _cap_stream = None
+
+    def _capture_stream(self):
+        """ONE capture stream per trainer (backward keeps per-stream side streams: a fresh stream per re-capture leaks them)."""
+        if self._cap_stream is None:
+            self._cap_stream = torch.cuda.Stream(device=self.model.X.device)
+        return self._cap_stream
 
     def _replay(self, name, op):
         """Capture ``op`` (one evaluation + its update) into a hipGraph on first use -- and again whenever the staircase decay
@@ -184,7 +194,7 @@ class Trainer:
         first = ent is None
         self._capturing = True
         try:
-            side = torch.cuda.Stream(device=self.model.X.device)
+            side = self._capture_stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
                 if first:
@@ -207,15 +217,26 @@ class Trainer:
         if self.use_graph:
             if zs_ng is not None or zs_adam is not None:
                 raise ValueError("use_graph draws the noise on the device (captured graphs cannot take per-step host arguments)")
-            self.model.next_minibatch()                        # outside the graph: an in-place gather into the model's X / Y buffers
+            self._advance_outside_graph()
             self._replay("ng", lambda: self.natgrad_op(None, _advance=False))
-            self.model.next_minibatch()
+            self._advance_outside_graph()
             elbo = self._replay("adam", lambda: self.adam_op(None, _advance=False))
+            for _, owner in self._scalars:                     # a replay runs no host code: flag the host copies here
+                owner.mark_device_variance_changed()
             if self.check_finite and self.global_step % self.check_every == 0:
                 self._raise_if_not_finite(elbo)
             return elbo
         self.natgrad_op(zs_ng)
         return self.adam_op(zs_adam)
+
+    def _advance_outside_graph(self):
+        """Everything of a minibatch change that is host-driven runs here, never inside the captured op: the in-place
+        gather into the model's X / Y buffers AND the [x, y] rows the encoders read (``_xy_minibatch`` re-runs its
+        ``cat`` only when the minibatch key moved -- inside the captured op the key is unchanged, so the cat would
+        not be recorded and every replay would read the first step's rows)."""
+        self.model.next_minibatch()
+        if any(isinstance(l, LatentVariableLayer) for l in self.model.layers):
+            self.model._xy_minibatch()
 
     def sync_scalars(self):
         """Refresh the host copies of the device-resident scalars now (otherwise: lazily, on first read)."""

@@ -317,3 +317,72 @@ def test_a_diverged_natural_gradient_step_is_reported(gpu_device):
         for _ in range(8):
             tr.step()
     assert tr.global_step == 4
+
+
+def _minibatched_lv_model(spec, dev, mb):
+    """A latent-variable model over ALL the spec's rows, stepping through shuffled minibatches of ``mb`` rows."""
+    from dgps_with_iwvi_amd import synthetic
+    from dgps_with_iwvi_amd.models import DGP_IWVI
+    m = synthetic.build_model(spec, dev)
+    return DGP_IWVI(spec["X"], spec["Y"], m.layers, m.likelihood, num_samples=spec["K"], minibatch_size=mb).to(dev)
+
+
+def test_graph_mode_with_minibatches_feeds_the_encoder_fresh_rows(gpu_device):
+    """minibatch_size < N with a latent-variable layer: the encoder's [x, y] rows are refreshed OUTSIDE the captured op
+    at every minibatch change (a cat keyed by the minibatch serial is not recorded into the graph when the key did not
+    move inside it) -- the graph-mode trajectory is the eager one bit for bit over several different minibatches."""
+    from dgps_with_iwvi_amd import synthetic, settings
+    from dgps_with_iwvi_amd.training import Trainer
+    spec = synthetic.make_spec(L=2, M=32, B=96, K=4, with_lv=True, seed=37, n_data=96)
+    out = []
+    for use_graph in (False, True):
+        settings.set_seed(11)
+        model = _minibatched_lv_model(spec, gpu_device, 16)
+        tr = Trainer(model, use_graph=use_graph, check_finite=False)
+        vals = [float(tr.step()) for _ in range(7)]             # 14 minibatches: more than one epoch of 6
+        out.append((vals, [p.clone() for _, p, _ in tr._entries], model._xy_minibatch().clone(), model.X.clone(), model.Y.clone()))
+    assert out[0][0] == out[1][0], (out[0][0], out[1][0])
+    for pa, pb in zip(out[0][1], out[1][1]):
+        assert torch.equal(pa, pb)
+    # and the cached rows ARE the current minibatch's
+    for o in out:
+        assert torch.equal(o[2], torch.cat([o[3], o[4]], -1))
+
+
+def test_graph_mode_host_scalars_follow_the_device_values(gpu_device):
+    """Reading ``likelihood.variance`` / the final ``kern.variance`` in the middle of a graph-mode run must not freeze the
+    host copy: every later read returns the device value of THAT moment (replays run no host code, so ``step()`` flags
+    the copies stale itself)."""
+    from dgps_with_iwvi_amd import synthetic, settings
+    from dgps_with_iwvi_amd.training import Trainer
+    spec = synthetic.make_spec(L=2, M=32, B=32, K=4, with_lv=True, seed=41)
+    settings.set_seed(5)
+    model = synthetic.build_model(spec, gpu_device)
+    tr = Trainer(model, use_graph=True, check_finite=False)
+    kern = model.layers[-1]._base_kern()
+    seen = []
+    for _ in range(5):
+        tr.step()
+        lv, kv = model.likelihood.variance, kern.variance        # a mid-training read (evaluation, checkpoint)
+        assert lv == float(tr._scalars[-1][0].item()) and kv == float(tr._scalars[0][0].item())
+        seen.append((lv, kv))
+    assert len(set(seen)) == 5, seen                             # the values moved at every step and were seen moving
+
+
+def test_trainer_counts_ranks_not_group_arguments(gpu_device):
+    """``group=None`` is the default group once torch.distributed is initialised: the N-shard bookkeeping and the
+    use_graph guard follow the WORLD SIZE (1 rank: plain single-GPU training, graph capture allowed)."""
+    import torch.distributed as dist
+    from dgps_with_iwvi_amd import synthetic
+    from dgps_with_iwvi_amd.training import Trainer
+    spec = synthetic.make_spec(L=1, M=16, B=16, K=2, seed=1)
+    model = synthetic.build_model(spec, gpu_device)
+    assert Trainer(model, use_graph=True).world == 1
+    if not dist.is_initialized():
+        import tempfile
+        f = tempfile.NamedTemporaryFile(delete=False)
+        dist.init_process_group("gloo", init_method="file://" + f.name, rank=0, world_size=1)
+        try:
+            assert Trainer(model, use_graph=True).world == 1     # 1 rank: still a single-GPU step
+        finally:
+            dist.destroy_process_group()
