@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libiwvi_hip.so")
 
 KERN_RBF, KERN_MATERN52 = 0, 1
 LAYER_GP, LAYER_LV = 0, 1
-ABI_VERSION = 11
+ABI_VERSION = 12
 GP_WANT_DENSE = 1
 GP_WANT_LM = 2
 ADAM_GRAD_F64 = 16
@@ -156,6 +156,11 @@ PROTOTYPES = {
     "iwvi_dgp_forward": (c_int, [ctypes.POINTER(LayerDesc), c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int,
                                  c_int64, c_int64, c_int64, c_float, ctypes.c_uint64, c_void_p, c_void_p,
                                  ctypes.POINTER(ElboDesc), c_void_p]),
+    "iwvi_fused_ws_bytes": (c_size_t, []),
+    "iwvi_dgp_forward_fused": (c_int, [ctypes.POINTER(GpDesc), c_int, c_void_p,
+                                       ctypes.POINTER(LayerDesc), c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int,
+                                       c_int64, c_int64, c_int64, c_float, ctypes.c_uint64, c_void_p, c_void_p,
+                                       ctypes.POINTER(ElboDesc), c_void_p]),
     "iwvi_logw_reduce": (c_int, [c_void_p, c_int64, c_int, c_int64, c_int64, ctypes.POINTER(c_void_p),
                                  ctypes.POINTER(ctypes.c_int32), c_int, c_double, c_int, c_int,
                                  c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),

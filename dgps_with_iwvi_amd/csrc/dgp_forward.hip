@@ -33,9 +33,11 @@
 // Every partial sum goes to its own LDS slot / workspace word and is added in a fixed order: results are
 // bit-reproducible.
 #include "iwvi_common.h"
+#include "precompute_dev.h"
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <type_traits>
 #include <vector>
 
 namespace iwvi {
@@ -131,6 +133,8 @@ struct FwHead {
     float* out_logw;
     unsigned long long* stamps;      // diagnostic only (iwvi_debug_set_stamps): 128 words per workgroup
     int ncopy;
+    int ncopy_indep;                 // the first ncopy_indep entries of the copy list read nothing another workgroup of this launch writes
+    int nchunks;                     // chunks of 16 * NS samples (== workgroups, except in the merged launch)
     int ls_first;                    // first GP layer whose solve stream is staged in LDS (fetched in the prologue), or -1
     const float* lw_init;            // optional [T]: local regularisers of layers evaluated before this launch (summed per sample)
     int layer_base;                  // index of this stack's first layer in the model (keys the noise streams)
@@ -162,8 +166,25 @@ struct alignas(64) FwHot {
     const float* nx_ls; const f32x4* LrTP; const f32x4* QmuP; const f32x4* LsP; const float* ZtP;   // LV: LrTP = enc_out
 };
 static_assert(sizeof(FwHot) == 128, "two scalar-cache lines per layer");
+// ---- the merged launch (template parameter FZ): the precompute roles and the layer stack in ONE launch ----------------------
+// Workgroups take a role by ticket (an agent-scope counter, so the order of dispatch decides nothing but speed): the first n_gp to start
+// factorise a GP layer each (role_factor), the others own a chunk of samples; chunk c < n_pack first packs tril(q_sqrt_r)^T for one
+// (layer, r).  A chunk's front -- table, inputs, noise, latent-variable layer, x~, K_uf Gram -- needs nothing of the factorisation
+// but the scaled inducing inputs (counter `early`, ~3 us into the launch) and runs beside it; stage 1 of the first GP layer waits for
+// `done`.  All counters are monotonic and counted per generation (`gen` = launches completed on this buffer): nothing is reset per
+// launch, and the words are zeroed once, when the buffer is allocated.  Every wait depends only on workgroups with a smaller ticket,
+// which have started: no deadlock under any dispatch order.  Spins are bounded; a give-up poisons the result with NaN.
+struct FzSync { unsigned gen, role, early, pack, done, timeout; unsigned cols[IWVI_MAX_STACK]; unsigned pad[50]; };
+static_assert(sizeof(FzSync) == 256, "sync block");
+struct FzArgs {
+    int enabled, n_gp, n_pack, n_reg, n_ticket, first_gp;
+    int pack_off[IWVI_MAX_STACK + 1];      // pack job j: GP layer l with pack_off[l] <= j < pack_off[l + 1], latent GP j - pack_off[l]
+    FzSync* sync;
+    PreLayer P[IWVI_MAX_STACK];            // the GP layers of the stack, in stack order
+};
 struct FwArgs {
     FwHead h;
+    FzArgs z;
     FwHot H[IWVI_MAX_STACK];
     FwLayer L[IWVI_MAX_STACK];
     FwNoise N[IWVI_MAX_STACK];
@@ -387,17 +408,192 @@ __device__ __forceinline__ float stage1_unrolled(AP Ap, const f32x4* kuf, f32x4*
     return ssq;
 }
 
-template <int NS, bool S16>           // S16: stage 2 of every GP layer on split-f16 operands (iwvi_common.h: s16_*)
+// prologue copy list, entries [c_lo, c_hi): one entry per wave at a time, all DMA loads in flight together
+__device__ __forceinline__ void fw_copy_entries(const FwCopy* CT, float* sm, int c_lo, int c_hi, int wave, int lane) {
+    for (int ci = c_lo + wave; ci < c_hi; ci += FW_WAVES) {
+        const FwCopy ce = uniform_words(CT[ci]);                   // one 16-byte LDS read per entry
+        const float* src = ce.src;
+        const int n = ce.n;
+        float* dst = sm + ce.dst;
+        const int wl = lane;                                       // this wave alone moves the entry
+        if (!src) { for (int i = wl; i < n; i += 64) dst[i] = 0.f; }           // absent operand (e.g. no encoder bias)
+        else if (n < 0) { for (int i0 = 0; i0 < (-n >> 2); i0 += 64) if (i0 + wl < (-n >> 2))
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 4 * (i0 + wl)),
+                                                 (__attribute__((address_space(3))) void*)(dst + 4 * i0), 16, 0, 0); }
+        else { for (int i0 = 0; i0 < n; i0 += 64) if (i0 + wl < n)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + i0 + wl),
+                                                 (__attribute__((address_space(3))) void*)(dst + i0), 4, 0, 0); }
+    }
+}
+
+// ---- one ticket per workgroup: the last arriver advances the noise stream (every workgroup has read the step counter by
+//      then) and, if asked, finishes the IW-ELBO reduction of models.py:138-150.  Every workgroup of the launch arrives exactly
+//      once, whatever its role (merged launch: the factorising workgroups too -- the last arriver then also closes the generation).
+template <int NS, bool FZ>
+__device__ __forceinline__ void fw_arrive(const FwArgs& gk, float* sm, int tid, int chunk_id) {
+    constexpr int NSAMP = 16 * NS;
+    const FwHead& g = gk.h;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int* counters = reinterpret_cast<int*>(sm + g.lds.cnt);
+    const bool local_lse = g.e.enabled && g.e.ws && !g.e.mode_vi && g.e.stride_k == 1 && g.e.stride_b == g.e.K &&
+                           (NSAMP % g.e.K) == 0;
+    if (g.rng_state) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's stores have left
+        __syncthreads();
+        if (tid == 0) {
+            const unsigned long long tk = __hip_atomic_fetch_add(&g.rng_state[1], 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int last = (tk == (unsigned long long)gridDim.x - 1);
+            if (last) {
+                __hip_atomic_store(&g.rng_state[1], 0ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_fetch_add(&g.rng_state[0], 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if constexpr (FZ) __hip_atomic_fetch_add(&gk.z.sync->gen, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            counters[2] = last;
+        }
+        __syncthreads();
+        if (g.e.enabled && counters[2]) {
+            const FwElbo& E = g.e;
+            double acc = 0.0;
+            if (local_lse) {
+                for (int i = tid; i < g.nchunks; i += FW_THREADS)
+                    acc += __hip_atomic_load(E.ws + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                const int K = E.K;
+                for (long long b = tid; b < E.B; b += FW_THREADS) {
+                    const float* row = g.out_logw + b * E.stride_b;
+                    float m = -INFINITY, ssum = 0.f, lsum = 0.f;
+                    for (int k0 = 0; k0 < K; k0 += 8) {
+                        float Lv[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u)                                    // 8 independent write-through-coherent loads
+                            Lv[u] = (k0 + u < K) ? __hip_atomic_load(row + (k0 + u) * E.stride_k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : -INFINITY;
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            if (k0 + u < K) {
+                                lsum += Lv[u];
+                                if (Lv[u] > m) { ssum = ssum * __expf(m - Lv[u]) + 1.f; m = Lv[u]; }
+                                else ssum += __expf(Lv[u] - m);
+                            }
+                        }
+                    }
+                    float lp;
+                    if (E.mode_vi) lp = lsum / (float)K;                               // models.py:84
+                    else {
+                        lp = m + logf(ssum) - logf((float)E.K_total);                  // models.py:148
+                        if (E.ms) { E.ms[2 * b] = m; E.ms[2 * b + 1] = ssum; }
+                    }
+                    if (E.logp) E.logp[b] = lp;
+                    acc += (double)lp;
+                }
+            }
+            // deterministic block sum: lanes by shuffles, then the 8 wave partials in a fixed order
+            for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+            double* wsum = reinterpret_cast<double*>(sm + g.lds.xa);
+            if (lane == 0) wsum[wave] = acc;
+            __syncthreads();
+            if (tid == 0 && E.elbo) {
+                double tot = 0.0, kl = 0.0;
+                if constexpr (FZ) { if (chunk_id < 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }   // (a factorising workgroup has not acquired the KL shares yet)
+                for (int w = 0; w < FW_WAVES; ++w) tot += wsum[w];
+                for (int i = 0; i < E.n_glob; ++i)
+                    for (int c = 0; c < E.klg_n[i]; ++c) kl += E.klg[i][c];
+                double val = tot * E.scale - kl;                                       // models.py:150
+                if constexpr (FZ) {                                                    // a wait of this launch gave up: say so, loudly
+                    if (__hip_atomic_load(&gk.z.sync->timeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) val = __builtin_nan("");
+                }
+                *E.elbo = val;
+            }
+        }
+    }
+}
+
+// ---- merged launch: waits and coherent reads --------------------------------------------------------------------------------
+// ONE lane polls ONE word with relaxed agent-scope loads (sc1: no cache maintenance per poll); wrap-safe compare; bounded.
+__device__ __forceinline__ void fz_wait_ge(unsigned* word, unsigned target, unsigned* tmo) {
+    for (unsigned spins = 0;; ++spins) {
+        if ((int)(__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) >= 0) return;
+        __builtin_amdgcn_s_sleep(2);
+        if (spins > (1u << 22)) { __hip_atomic_store(tmo, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return; }
+    }
+}
+// the same, returning the value seen (a counter that keeps growing: the caller takes everything that is there)
+__device__ __forceinline__ unsigned fz_wait_ge_val(unsigned* word, unsigned target, unsigned* tmo) {
+    for (unsigned spins = 0;; ++spins) {
+        const unsigned v = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((int)(v - target) >= 0) return v;
+        __builtin_amdgcn_s_sleep(2);
+        if (spins > (1u << 22)) { __hip_atomic_store(tmo, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return target + (1u << 20); }
+    }
+}
+// a packed operand stream another workgroup of this launch has just stored write-through: every 16-byte vector is read with an sc1
+// load to registers (served behind this CU's L1, which may hold last evaluation's lines) -- no acquire on the critical path
+struct Sc1Stream {
+    __amdgpu_buffer_rsrc_t r; unsigned off;
+    __device__ __forceinline__ Sc1Stream(const void* base, unsigned bytes, unsigned lane_off)
+        : r(__builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000)), off(lane_off) {}
+    __device__ __forceinline__ f32x4 operator[](size_t i) const {
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, off + (unsigned)i * 16u, 0, 16));
+    }
+};
+
+template <int NS, bool S16, bool FZ = false>   // S16: stage 2 of every GP layer on split-f16 operands (iwvi_common.h: s16_*); FZ: merged launch
 __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
     constexpr int NSAMP = 16 * NS;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int gq = lane >> 4, jq = lane & 15;
     const FwHead& g = gk.h;                                       // scalar path (first kernarg lines)
     const int XSTR = g.xstr;
-    const long long t0 = (long long)blockIdx.x * NSAMP;
+    float* sm = reinterpret_cast<float*>(fw_smem);
+    int fz_chunk = 0;
+    unsigned fz_gen = 0;
+    if constexpr (FZ) {
+        // ---- role by ticket: whoever starts first factorises (nothing below ever waits for a workgroup that has not started) ----
+        const FzArgs& z = gk.z;
+        int* rw = reinterpret_cast<int*>(sm + g.lds.cnt);
+        if (tid == 0) {
+            const unsigned g0 = __hip_atomic_load(&z.sync->gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned t = __hip_atomic_fetch_add(&z.sync->role, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - g0 * (unsigned)z.n_ticket;
+            rw[4] = (int)t; rw[5] = (int)g0;
+        }
+        __syncthreads();
+        const int tk = ufirst(rw[4]);
+        fz_gen = (unsigned)ufirst(rw[5]);
+        __syncthreads();                                          // (the roles below use the LDS from its start)
+        if (g.stamps && tid == 0) g.stamps[(size_t)blockIdx.x * 128 + 127] = 1000 + tk;   // (diagnostic: who played which role)
+        if (tk < z.n_gp) {
+            const PreLayer Lc = z.P[tk];                          // (by value: a reference into the kernel arguments would force them into scratch)
+            // (diagnostic stamps land in this workgroup's 128-word row, words 0 .. 15: PRE_STAMP indexes 16 words per block)
+            role_factor<true, true>(Lc, 0, g.stamps ? g.stamps + (size_t)blockIdx.x * 112 : nullptr, 1, FzPub{&z.sync->early, &z.sync->done, &z.sync->cols[tk]});
+            __syncthreads();
+            fw_arrive<NS, FZ>(gk, sm, tid, -1);
+            return;
+        }
+        fz_chunk = tk - z.n_gp;
+        if (fz_chunk < z.n_pack) {
+            // tril(q_sqrt_r)^T packing + KL shares (csrc/precompute_dev.h: role_pack_r): the first chunks carry one (layer, r) each;
+            // plain stores, published by ONE agent-scope release of this workgroup
+            unsigned njobs = 0;
+            for (int j = fz_chunk; j < z.n_pack; j += z.n_reg) {
+                int l = 0;
+                while (j >= z.pack_off[l + 1]) ++l;
+                const PreLayer Lc = z.P[l];
+                role_pack_r(Lc, j - z.pack_off[l], reinterpret_cast<double*>(fw_smem));
+                __syncthreads();
+                ++njobs;
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (keep: the compiler may drop the fence's own wait)
+                __hip_atomic_fetch_add(&z.sync->pack, njobs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
+    const int chunk_id = FZ ? fz_chunk : (int)blockIdx.x;
+    const long long t0 = (long long)chunk_id * NSAMP;
     const int nvalid = (int)((g.T - t0) < (long long)NSAMP ? (g.T - t0) : (long long)NSAMP);
 
-    float* sm = reinterpret_cast<float*>(fw_smem);
     // ---- the hot layer descriptors: one word of each 64-byte line requested through the scalar cache now (all in
     //      flight beside the header's own miss); consumed -- i.e. waited for -- just before the first barrier --------
     unsigned hot_touch = 0;
@@ -508,20 +704,7 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
         const FwHot& G0 = gk.H[g.ls_first];
         async_copy_f32x4(reinterpret_cast<const float*>(G0.LsP), sm + G0.ls_off, tri_blocks(G0.nbk) * BLK16, tid);
     }
-    for (int ci = wave; ci < g.ncopy; ci += FW_WAVES) {
-        const FwCopy ce = uniform_words(CT[ci]);                   // one 16-byte LDS read per entry
-        const float* src = ce.src;
-        const int n = ce.n;
-        float* dst = sm + ce.dst;
-        const int wl = lane;                                       // this wave alone moves the entry
-        if (!src) { for (int i = wl; i < n; i += 64) dst[i] = 0.f; }           // absent operand (e.g. no encoder bias)
-        else if (n < 0) { for (int i0 = 0; i0 < (-n >> 2); i0 += 64) if (i0 + wl < (-n >> 2))
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 4 * (i0 + wl)),
-                                                 (__attribute__((address_space(3))) void*)(dst + 4 * i0), 16, 0, 0); }
-        else { for (int i0 = 0; i0 < n; i0 += 64) if (i0 + wl < n)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + i0 + wl),
-                                                 (__attribute__((address_space(3))) void*)(dst + i0), 4, 0, 0); }
-    }
+    fw_copy_entries(CT, sm, 0, FZ ? g.ncopy_indep : g.ncopy, wave, lane);                // (merged launch: what the factorising workgroups write comes last, below)
     // noise of every layer -> znoise[z_off + r * NSAMP + j].  Injected [T, dims]: a gather by LDS-DMA (the source is per
     // lane).  Drawn here: 4 normals per Philox call, the (layer, 4-component group, sample) items of all layers laid end
     // to end over the workgroup's threads (one item per thread while they fit), overlapping the copies above.
@@ -555,6 +738,17 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
         }
     }
     FW_STAMP(57);
+    if constexpr (FZ) {
+        // the GP layers' constant blocks and Gram operands Z~ are written by the factorising workgroups of THIS launch (~3 us into it):
+        // one lane waits for all of them, one agent-scope acquire covers the workgroup, then the copies are plain LDS-DMA loads
+        if (wave == 0) {
+            if (lane == 0) fz_wait_ge(&gk.z.sync->early, (fz_gen + 1u) * (unsigned)gk.z.n_gp, &gk.z.sync->timeout);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();
+        fw_copy_entries(CT, sm, g.ncopy_indep, g.ncopy, wave, lane);
+    }
     FW_STAMP(58);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     FW_STAMP(59);
@@ -755,6 +949,51 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
                     }
                 }
             }
+            if constexpr (FZ) {
+                if (li == gk.z.first_gp) {
+                    // ---- merged launch: from here on the layers need the factorisation.  The pack roles finished long ago (one acquire,
+                    // in the shadow of the wait); `done` is polled by one lane and everything it guards is read by sc1 loads.
+                    FW_STAMP(60);
+                    if (wave == 0) {
+                        if (lane == 0) fz_wait_ge(&gk.z.sync->pack, (fz_gen + 1u) * (unsigned)gk.z.n_pack, &gk.z.sync->timeout);
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                        // this layer's solve stream goes to the LDS staging buffer COLUMN BY COLUMN, as the factorising workgroup
+                        // publishes it (a column is final one pass after its diagonal block): when the last one arrives, only that
+                        // one is left to fetch -- the stream's 36 KiB never sit on the critical path.  sc1 loads to registers, then LDS.
+                        if (G.ls_off >= 0 && nbk <= 8) {
+                            const Sc1Stream src(G.LsP, (unsigned)(tri_blocks(nbk) * BLK16 * 4), (unsigned)lane * 16u);
+                            f32x4* dstl = reinterpret_cast<f32x4*>(sm + G.ls_off) + lane;
+                            const unsigned cbase = fz_gen * (unsigned)nbk;
+                            unsigned* cw = &gk.z.sync->cols[0];                // (the first GP layer is factorised under ticket 0)
+                            for (int j = 0; j < nbk;) {
+                                unsigned have = 0;
+                                if (lane == 0) have = fz_wait_ge_val(cw, cbase + (unsigned)j + 1u, &gk.z.sync->timeout) - cbase;
+                                int upto = __builtin_amdgcn_readfirstlane((int)have);
+                                upto = upto > nbk ? nbk : upto;
+                                const int b1 = tri_upper_off(nbk, upto);
+                                for (int b = tri_upper_off(nbk, j); b < b1; b += 8) {
+                                    f32x4 v[8];
+#pragma unroll
+                                    for (int u = 0; u < 8; ++u) v[u] = src[(size_t)(b + u < b1 ? b + u : b1 - 1) * 64];
+#pragma unroll
+                                    for (int u = 0; u < 8; ++u) if (b + u < b1) dstl[(size_t)(b + u) * 64] = v[u];
+                                }
+                                j = upto;
+                            }
+                        }
+                        if (lane == 0) fz_wait_ge(&gk.z.sync->done, (fz_gen + 1u) * (unsigned)gk.z.n_gp, &gk.z.sync->timeout);
+                        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                    }
+                    __syncthreads();
+                    FW_STAMP(61);
+                    // the split-f16 scales the pack roles wrote into every GP layer's constant block (cst[64 .. 104)), now that they exist
+                    for (int i = tid; i < g.n_layers * 40; i += FW_THREADS) {
+                        const int l = i / 40, o = 64 + (i - l * 40);
+                        if (gk.H[l].type == IWVI_LAYER_GP) sm[gk.H[l].c_off + o] = ((gptr1)LT[l].gp.cst)[o];
+                    }
+                    // (visible behind the barrier that ends the Gram phase, below)
+                }
+            }
             // stage 2's first operands are requested here, in the shadow of the Gram phase's barrier (nothing in them
             // depends on the Gram or the solve), so that its MFMAs start right behind the barrier that ends stage 1
             const int ntri = tri_blocks(nbk);
@@ -773,7 +1012,10 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
 #pragma unroll
             for (int i = 0; i < LSN; ++i) {
                 lsn[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (tid + i * FW_THREADS < lsn4) lsn[i] = ((gptr4)H.nx_ls)[tid + i * FW_THREADS];
+                if (tid + i * FW_THREADS < lsn4) {
+                    if constexpr (FZ) lsn[i] = Sc1Stream(H.nx_ls, (unsigned)H.nx_ls_n * 4u, 0u)[tid + i * FW_THREADS];
+                    else lsn[i] = ((gptr4)H.nx_ls)[tid + i * FW_THREADS];
+                }
             }
             f32x4 ring[4];
             ring[0] = ring[1] = ring[2] = ring[3] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -892,7 +1134,9 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
             }
             if (wave < NS) {
                 const int tcol = 16 * wave + jq;                  // this lane's sample column
-                gptr4 Ap = (gptr4)G.LsP + lane;
+                using ApT = typename std::conditional<FZ, Sc1Stream, gptr4>::type;
+                ApT Ap = [&]() { if constexpr (FZ) return Sc1Stream(G.LsP, (unsigned)(tri_blocks(nbk) * BLK16 * 4), (unsigned)lane * 16u);
+                                 else return (gptr4)G.LsP + lane; }();
                 const gout1 arow = (o_a && tcol < nvalid) ? o_a + (size_t)(t0 + tcol) * G.Mp : (gout1)nullptr;
                 float ssq = 0.f;
                 if (G.ls_off >= 0 && nbk <= 8) {
@@ -1478,84 +1722,21 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
         if (tid == 0) {
             double part = 0.0;
             for (int p = 0; p < npl; ++p) part += (double)xt[p];                       // fixed order
-            __hip_atomic_store(E.ws + blockIdx.x, part, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(E.ws + chunk_id, part, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
-    // ---- one ticket per workgroup: the last arriver advances the noise stream (every workgroup has read the
-    //      step counter by then) and, if asked, finishes the IW-ELBO reduction of models.py:138-150 ----------
-    if (g.rng_state) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's stores have left
-        __syncthreads();
-        if (tid == 0) {
-            const unsigned long long tk = __hip_atomic_fetch_add(&g.rng_state[1], 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const int last = (tk == (unsigned long long)gridDim.x - 1);
-            if (last) {
-                __hip_atomic_store(&g.rng_state[1], 0ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_fetch_add(&g.rng_state[0], 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            counters[2] = last;
-        }
-        __syncthreads();
-        if (g.e.enabled && counters[2]) {
-            const FwElbo& E = g.e;
-            double acc = 0.0;
-            if (local_lse) {
-                for (int i = tid; i < (int)gridDim.x; i += FW_THREADS)
-                    acc += __hip_atomic_load(E.ws + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            } else {
-                const int K = E.K;
-                for (long long b = tid; b < E.B; b += FW_THREADS) {
-                    const float* row = g.out_logw + b * E.stride_b;
-                    float m = -INFINITY, ssum = 0.f, lsum = 0.f;
-                    for (int k0 = 0; k0 < K; k0 += 8) {
-                        float Lv[8];
-#pragma unroll
-                        for (int u = 0; u < 8; ++u)                                    // 8 independent write-through-coherent loads
-                            Lv[u] = (k0 + u < K) ? __hip_atomic_load(row + (k0 + u) * E.stride_k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : -INFINITY;
-#pragma unroll
-                        for (int u = 0; u < 8; ++u) {
-                            if (k0 + u < K) {
-                                lsum += Lv[u];
-                                if (Lv[u] > m) { ssum = ssum * __expf(m - Lv[u]) + 1.f; m = Lv[u]; }
-                                else ssum += __expf(Lv[u] - m);
-                            }
-                        }
-                    }
-                    float lp;
-                    if (E.mode_vi) lp = lsum / (float)K;                               // models.py:84
-                    else {
-                        lp = m + logf(ssum) - logf((float)E.K_total);                  // models.py:148
-                        if (E.ms) { E.ms[2 * b] = m; E.ms[2 * b + 1] = ssum; }
-                    }
-                    if (E.logp) E.logp[b] = lp;
-                    acc += (double)lp;
-                }
-            }
-            // deterministic block sum: lanes by shuffles, then the 8 wave partials in a fixed order
-            for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
-            double* wsum = reinterpret_cast<double*>(sm + g.lds.xa);
-            if (lane == 0) wsum[wave] = acc;
-            __syncthreads();
-            if (tid == 0 && E.elbo) {
-                double tot = 0.0, kl = 0.0;
-                for (int w = 0; w < FW_WAVES; ++w) tot += wsum[w];
-                for (int i = 0; i < E.n_glob; ++i)
-                    for (int c = 0; c < E.klg_n[i]; ++c) kl += E.klg[i][c];
-                *E.elbo = tot * E.scale - kl;                                          // models.py:150
-            }
-        }
-    }
+    fw_arrive<NS, FZ>(gk, sm, tid, chunk_id);
 }
 
-template <int NS, bool S16>
+template <int NS, bool S16, bool FZ = false>
 static int launch_forward(const FwArgs& a, unsigned grid, size_t lds_bytes, hipStream_t stream) {
     static size_t attr_set = 0;
     if (lds_bytes > attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_dgp_forward<NS, S16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        hipError_t e = hipFuncSetAttribute((const void*)k_dgp_forward<NS, S16, FZ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) { set_error("hipFuncSetAttribute(k_dgp_forward, %zu B): %s", lds_bytes, hipGetErrorString(e)); return IWVI_ERR_LAUNCH; }
         attr_set = lds_bytes;
     }
-    hipLaunchKernelGGL((k_dgp_forward<NS, S16>), dim3(grid), dim3(FW_THREADS), lds_bytes, stream, a);
+    hipLaunchKernelGGL((k_dgp_forward<NS, S16, FZ>), dim3(grid), dim3(FW_THREADS), lds_bytes, stream, a);
     return check_launch("k_dgp_forward");
 }
 
@@ -1629,8 +1810,9 @@ static void plan_stage2(FwGp& G) {
 
 // LDS image for a chunk of nsamp samples; fills the per-layer offsets of `a`.  stage_zt: keep every GP layer's
 // Gram operand Z~ in LDS for the whole launch.
-static size_t fw_plan_lds(FwArgs& a, int nsamp, int maxR, int maxP, bool stage_zt, bool stage_ls) {
+static size_t fw_plan_lds(FwArgs& a, int nsamp, int maxR, int maxP, bool stage_zt, bool stage_ls, bool fz = false) {
     int scratch = 0, zdims = 0, o = 0, ls_max = 0;
+    bool seen_gp = false;
     FwLds& l = a.h.lds;
     l.ltab = o; o += up4((int)((sizeof(FwArgs) - offsetof(FwArgs, L)) / 4));
     l.xa = o; o += up4(nsamp * a.h.xstr);
@@ -1657,7 +1839,10 @@ static size_t fw_plan_lds(FwArgs& a, int nsamp, int maxR, int maxP, bool stage_z
             G.zt_off = -1;
             if (stage_zt) { G.zt_off = o; o += G.nbk * G.nsteps * 64; }
             G.ls_off = -1;
+            // (merged launch: the first GP layer's stream does not exist yet when the prologue runs -- it is staged column by column
+            // while the factorisation runs; the later layers' streams are staged as ever, one layer ahead)
             if (stage_ls && G.nbk <= 8 && tri_blocks(G.nbk) * BLK16 > ls_max) ls_max = tri_blocks(G.nbk) * BLK16;
+            seen_gp = true;
             zdims += G.R;
             const int need = gp_scratch_floats(G.Mp, G.nbk, G.R, nsamp);
             if (need > scratch) scratch = need;
@@ -1679,8 +1864,12 @@ static size_t fw_plan_lds(FwArgs& a, int nsamp, int maxR, int maxP, bool stage_z
     }
     int ls_first = -1;
     if (ls_max > 0) {                                   // one staging buffer, reused layer after layer
-        for (int i = 0; i < a.h.n_layers; ++i)
-            if (a.L[i].type == IWVI_LAYER_GP && a.L[i].gp.nbk <= 8) { a.L[i].gp.ls_off = o; if (ls_first < 0) ls_first = i; }
+        bool first_gp = true;
+        for (int i = 0; i < a.h.n_layers; ++i) {
+            if (a.L[i].type != IWVI_LAYER_GP) continue;
+            if (a.L[i].gp.nbk <= 8) { a.L[i].gp.ls_off = o; if (ls_first < 0 && !fz) ls_first = i; }
+            first_gp = false;
+        }
         o += ls_max;
     }
     l.znoise = o;
@@ -1713,6 +1902,8 @@ static size_t fw_plan_lds(FwArgs& a, int nsamp, int maxR, int maxP, bool stage_z
             break;
         }
     }
+    // the copy list in two parts: first what no workgroup of a merged launch writes (mixing matrices, mean functions, encoder weights),
+    // then the GP layers' constant blocks and Gram operands (ncopy_indep separates them; an ordinary launch issues all of it at once)
     for (int i = 0; i < a.h.n_layers; ++i) {
         FwLayer& L = a.L[i];
         FwNoise& nz = a.N[i];
@@ -1720,13 +1911,11 @@ static size_t fw_plan_lds(FwArgs& a, int nsamp, int maxR, int maxP, bool stage_z
         if (L.type == IWVI_LAYER_GP) {
             const FwGp& G = L.gp;
             nz.dims = G.R;
-            add_copy(G.cst, IWVI_CST_FLOATS, L.c_off, true);                           // invls[32] | zc[32] | zmax2
             add_copy(G.W, G.P * G.R, L.c_off + gpc_W(), true);
             if (G.mf_type == IWVI_MF_LINEAR) {
                 add_copy(G.mfA, L.D * G.P, L.c_off + gpc_A(G.P, G.R), true);
                 add_copy(G.mfb, G.P, L.c_off + gpc_b(L.D, G.P, G.R), true);
             }
-            if (G.zt_off >= 0) add_copy(G.ZtP, G.nbk * G.nsteps * 64, G.zt_off, true);
         } else {
             const FwLv& V = L.lv;
             nz.dims = V.Lw;
@@ -1740,15 +1929,28 @@ static size_t fw_plan_lds(FwArgs& a, int nsamp, int maxR, int maxP, bool stage_z
             }
         }
     }
+    a.h.ncopy_indep = a.h.ncopy;
+    for (int i = 0; i < a.h.n_layers; ++i) {
+        FwLayer& L = a.L[i];
+        if (L.type != IWVI_LAYER_GP) continue;
+        const FwGp& G = L.gp;
+        add_copy(G.cst, IWVI_CST_FLOATS, L.c_off, true);                               // invls[32] | zc[32] | zmax2 | scales
+        if (G.zt_off >= 0) add_copy(G.ZtP, G.nbk * G.nsteps * 64, G.zt_off, true);
+    }
     l.cnt = o; o += 12;
     l.scratch = o; o += up4(scratch);
     l.total = o;
     return (size_t)o * sizeof(float);
 }
 
-int dgp_forward_impl(const iwvi_layer_desc* layers, int n_layers, const float* X, int Dx, const float* XY, int XYdim,
-                     const float* Y, int Dy, int64_t T, int64_t row_div, int64_t row_mod, float lik_variance,
-                     uint64_t seed, uint64_t* rng_state, float* out_logw, const iwvi_elbo_desc* elbo, hipStream_t stream) {
+// `fz` (merged launch): the iwvi_gp_desc of every GP layer of the stack, in stack order, + the sync block.  FZ_FALLBACK = this stack /
+// shape is not covered by the merged launch (the caller runs the precompute launch, then calls again without `fz`).
+struct FzHost { const iwvi_gp_desc* gp; int n_gp; void* ws; };
+constexpr int FZ_FALLBACK = 1;
+static int dgp_forward_fz(const iwvi_layer_desc* layers, int n_layers, const float* X, int Dx, const float* XY, int XYdim,
+                          const float* Y, int Dy, int64_t T, int64_t row_div, int64_t row_mod, float lik_variance,
+                          uint64_t seed, uint64_t* rng_state, float* out_logw, const iwvi_elbo_desc* elbo, hipStream_t stream,
+                          const FzHost* fz) {
     if (T <= 0) return IWVI_OK;                         // empty batch: nothing to do
     if (!layers || n_layers <= 0 || n_layers > IWVI_MAX_STACK) { set_error("iwvi_dgp_forward: %d layers (1..%d supported)", n_layers, IWVI_MAX_STACK); return IWVI_ERR_ARG; }
     if (!X || Dx <= 0 || Dx > IWVI_MAX_D) { set_error("iwvi_dgp_forward: null X or Dx=%d out of range (1..%d)", Dx, IWVI_MAX_D); return IWVI_ERR_ARG; }
@@ -1859,6 +2061,31 @@ int dgp_forward_impl(const iwvi_layer_desc* layers, int n_layers, const float* X
         a.h.xstr = round_up(wmax, 4) + 1;
         if (a.h.xstr > XSTR_MAX) a.h.xstr = XSTR_MAX;
     }
+    // ---- merged launch: is this stack covered?  (every GP layer factorises in LDS -- M <= 128 --, no dense factors asked for, encoders
+    //      evaluated inside the layer kernel, the arrival ticket present)
+    bool use_fz = false;
+    if (fz) {
+        if (T > 0 && (!fz->gp || fz->n_gp <= 0 || !fz->ws)) { set_error("iwvi_dgp_forward_fused: null GP descriptors / workspace"); return IWVI_ERR_ARG; }
+        use_fz = rng_state != nullptr && !g_dbg_exit;
+        int k = 0;
+        FzArgs& z = a.z;
+        z.pack_off[0] = 0;
+        for (int i = 0; i < n_layers && use_fz; ++i) {
+            if (layers[i].type == IWVI_LAYER_LV) { if (layers[i].enc_out) use_fz = false; continue; }
+            if (k >= fz->n_gp || fz->gp[k].state != layers[i].state || fz->gp[k].M != layers[i].M || fz->gp[k].R != layers[i].R) {
+                set_error("iwvi_dgp_forward_fused: GP descriptor %d does not describe layer %d of the stack", k, i); return IWVI_ERR_ARG;
+            }
+            const int rc = fill_pre_layer(fz->gp[k], i, z.P[k]);
+            if (rc != IWVI_OK) return rc;
+            if (z.P[k].Mp > 128 || z.P[k].flags != 0) use_fz = false;
+            if (k == 0) z.first_gp = i;
+            z.pack_off[k + 1] = z.pack_off[k] + fz->gp[k].R;
+            ++k;
+        }
+        if (use_fz && k != fz->n_gp) { set_error("iwvi_dgp_forward_fused: %d GP descriptors for a stack with %d GP layers", fz->n_gp, k); return IWVI_ERR_ARG; }
+        if (!use_fz) return FZ_FALLBACK;
+        z.enabled = 1; z.n_gp = k; z.n_pack = z.pack_off[k]; z.sync = reinterpret_cast<FzSync*>(fz->ws);
+    }
     // chunk size: 16*NS samples per workgroup, NS no larger than what gives every CU a workgroup, then the
     // largest that fits the LDS (with Z~ staged if that fits too)
     const size_t LDS_MAX = 160 * 1024;
@@ -1867,11 +2094,11 @@ int dgp_forward_impl(const iwvi_layer_desc* layers, int n_layers, const float* X
     if (ns < 1) ns = 1;
     size_t lds_bytes = 0;
     for (; ns >= 1; --ns) {
-        lds_bytes = fw_plan_lds(a, 16 * ns, maxR, maxP, true, true);
+        lds_bytes = fw_plan_lds(a, 16 * ns, maxR, maxP, true, true, use_fz);
         if (lds_bytes <= LDS_MAX) break;
-        lds_bytes = fw_plan_lds(a, 16 * ns, maxR, maxP, true, false);
+        lds_bytes = fw_plan_lds(a, 16 * ns, maxR, maxP, true, false, use_fz);
         if (lds_bytes <= LDS_MAX) break;
-        lds_bytes = fw_plan_lds(a, 16 * ns, maxR, maxP, false, false);
+        lds_bytes = fw_plan_lds(a, 16 * ns, maxR, maxP, false, false, use_fz);
         if (lds_bytes <= LDS_MAX) break;
     }
     if (ns < 1) { set_error("iwvi_dgp_forward: the layer stack needs %zu B of LDS per 16 samples (> 160 KiB)", lds_bytes); return IWVI_ERR_UNSUPPORTED; }
@@ -1904,22 +2131,60 @@ int dgp_forward_impl(const iwvi_layer_desc* layers, int n_layers, const float* X
     }
     const long long chunks = (T + 16 * ns - 1) / (16 * ns);
     if (chunks > 0x7fffffffLL) { set_error("iwvi_dgp_forward: T too large"); return IWVI_ERR_ARG; }
-    a.h.stamps = (g_stamp_buf && chunks <= g_stamp_wgs) ? g_stamp_buf : nullptr;
+    a.h.nchunks = (int)chunks;
+    a.h.stamps = (g_stamp_buf && chunks + IWVI_MAX_STACK <= g_stamp_wgs) ? g_stamp_buf : nullptr;
     a.h.dbg_exit = g_dbg_exit;
+    if (use_fz) {
+        FzArgs& z = a.z;
+        z.n_reg = (int)chunks;
+        z.n_ticket = z.n_gp + (int)chunks;
+        for (int k = 0; k < z.n_gp; ++k) { const size_t la = factor_lds_bytes(z.P[k].Mp); if (la > lds_bytes) lds_bytes = la; }
+        const unsigned grid = (unsigned)z.n_ticket;
+        if (s16_all) switch (ns) {
+#ifndef IWVI_DEV_ONLY5   /* development builds: only the 80-sample variants (make DEV5=1) */
+            case 1: return launch_forward<1, true, true>(a, grid, lds_bytes, stream);
+            case 2: return launch_forward<2, true, true>(a, grid, lds_bytes, stream);
+            case 3: return launch_forward<3, true, true>(a, grid, lds_bytes, stream);
+            case 4: return launch_forward<4, true, true>(a, grid, lds_bytes, stream);
+#endif
+            default: return launch_forward<5, true, true>(a, grid, lds_bytes, stream);
+        }
+        switch (ns) {
+#ifndef IWVI_DEV_ONLY5   /* development builds: only the 80-sample variants (make DEV5=1) */
+            case 1: return launch_forward<1, false, true>(a, grid, lds_bytes, stream);
+            case 2: return launch_forward<2, false, true>(a, grid, lds_bytes, stream);
+            case 3: return launch_forward<3, false, true>(a, grid, lds_bytes, stream);
+            case 4: return launch_forward<4, false, true>(a, grid, lds_bytes, stream);
+#endif
+            default: return launch_forward<5, false, true>(a, grid, lds_bytes, stream);
+        }
+    }
     if (s16_all) switch (ns) {
+#ifndef IWVI_DEV_ONLY5   /* development builds: only the 80-sample variants (make DEV5=1) */
         case 1: return launch_forward<1, true>(a, (unsigned)chunks, lds_bytes, stream);
         case 2: return launch_forward<2, true>(a, (unsigned)chunks, lds_bytes, stream);
         case 3: return launch_forward<3, true>(a, (unsigned)chunks, lds_bytes, stream);
         case 4: return launch_forward<4, true>(a, (unsigned)chunks, lds_bytes, stream);
+#endif
         default: return launch_forward<5, true>(a, (unsigned)chunks, lds_bytes, stream);
     }
     switch (ns) {
+#ifndef IWVI_DEV_ONLY5   /* development builds: only the 80-sample variants (make DEV5=1) */
         case 1: return launch_forward<1, false>(a, (unsigned)chunks, lds_bytes, stream);
         case 2: return launch_forward<2, false>(a, (unsigned)chunks, lds_bytes, stream);
         case 3: return launch_forward<3, false>(a, (unsigned)chunks, lds_bytes, stream);
         case 4: return launch_forward<4, false>(a, (unsigned)chunks, lds_bytes, stream);
+#endif
         default: return launch_forward<5, false>(a, (unsigned)chunks, lds_bytes, stream);
     }
+}
+
+// (the entry the other translation units call: csrc/gp_layer.hip, csrc/lv_elbo.hip)
+int dgp_forward_impl(const iwvi_layer_desc* layers, int n_layers, const float* X, int Dx, const float* XY, int XYdim,
+                     const float* Y, int Dy, int64_t T, int64_t row_div, int64_t row_mod, float lik_variance,
+                     uint64_t seed, uint64_t* rng_state, float* out_logw, const iwvi_elbo_desc* elbo, hipStream_t stream) {
+    return dgp_forward_fz(layers, n_layers, X, Dx, XY, XYdim, Y, Dy, T, row_div, row_mod, lik_variance, seed, rng_state, out_logw,
+                          elbo, stream, nullptr);
 }
 
 }  // namespace iwvi
@@ -1930,6 +2195,23 @@ extern "C" int iwvi_dgp_forward(const iwvi_layer_desc* layers, int n_layers, con
                                 const float* XY, int XYdim, const float* Y, int Dy, int64_t T, int64_t row_div,
                                 int64_t row_mod, float lik_variance, uint64_t seed, uint64_t* rng_state,
                                 float* out_logw, const iwvi_elbo_desc* elbo, void* stream) {
+    return dgp_forward_impl(layers, n_layers, X, Dx, XY, XYdim, Y, Dy, T, row_div, row_mod, lik_variance, seed,
+                            rng_state, out_logw, elbo, (hipStream_t)stream);
+}
+
+extern "C" size_t iwvi_fused_ws_bytes(void) { return sizeof(iwvi::FzSync); }
+
+extern "C" int iwvi_dgp_forward_fused(const iwvi_gp_desc* gp, int n_gp, void* fused_ws,
+                                      const iwvi_layer_desc* layers, int n_layers, const float* X, int Dx,
+                                      const float* XY, int XYdim, const float* Y, int Dy, int64_t T, int64_t row_div,
+                                      int64_t row_mod, float lik_variance, uint64_t seed, uint64_t* rng_state,
+                                      float* out_logw, const iwvi_elbo_desc* elbo, void* stream) {
+    const FzHost fz{gp, n_gp, fused_ws};
+    int rc = dgp_forward_fz(layers, n_layers, X, Dx, XY, XYdim, Y, Dy, T, row_div, row_mod, lik_variance, seed,
+                            rng_state, out_logw, elbo, (hipStream_t)stream, &fz);
+    if (rc != FZ_FALLBACK) return rc;
+    // not covered by the merged launch (M > 128, dense factors, precomputed encoder outputs, no ticket word): the two launches
+    if ((rc = iwvi_model_precompute(gp, n_gp, nullptr, 0, stream)) != IWVI_OK) return rc;
     return dgp_forward_impl(layers, n_layers, X, Dx, XY, XYdim, Y, Dy, T, row_div, row_mod, lik_variance, seed,
                             rng_state, out_logw, elbo, (hipStream_t)stream);
 }

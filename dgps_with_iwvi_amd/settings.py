@@ -4,6 +4,7 @@ float_type is fixed: per-sample arithmetic is float32 on the MFMA pipe, the indu
 factorisation (Gram, Cholesky, inverse) is float64 (DESIGN.md, "Precision").
 """
 import contextlib
+import os
 
 import torch
 
@@ -11,6 +12,9 @@ float_type = torch.float32
 jitter_level = 1e-6          # gpflow.settings.numerics.jitter_level default
 seed = 0                     # Philox key of the on-device N(0,1) stream (iwvi_fill_normal)
 _offset = 0                  # Philox counter; advanced by every draw
+# One launch per bound evaluation (iwvi_dgp_forward_fused: the factorisations run in workgroups of the layer stack's own launch);
+# False: the two launches iwvi_model_precompute + iwvi_dgp_forward.  Same results bit for bit.
+merged_launch = os.environ.get("IWVI_MERGED_LAUNCH", "0") != "0"      # (the environment variable only sets this default)
 
 
 def default_device():
