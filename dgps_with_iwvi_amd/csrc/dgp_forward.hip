@@ -174,14 +174,23 @@ static_assert(sizeof(FwHot) == 128, "two scalar-cache lines per layer");
 // `done`.  All counters are monotonic and counted per generation (`gen` = launches completed on this buffer): nothing is reset per
 // launch, and the words are zeroed once, when the buffer is allocated.  Every wait depends only on workgroups with a smaller ticket,
 // which have started: no deadlock under any dispatch order.  Spins are bounded; a give-up poisons the result with NaN.
-struct FzSync { unsigned gen, role, early, pack, done, timeout; unsigned cols[IWVI_MAX_STACK]; unsigned pad[50]; };
+struct FzSync { unsigned gen, role, early, pack, done, timeout; unsigned cols[IWVI_MAX_STACK]; unsigned snap[IWVI_MAX_STACK]; unsigned pad[42]; };
 static_assert(sizeof(FzSync) == 256, "sync block");
 struct FzArgs {
     int enabled, n_gp, n_pack, n_reg, n_ticket, first_gp;
+    int nchunks_reg;                       // chunks owned by chunk workgroups (resume mode: the last n_gp chunks belong to the factorising ones)
     int pack_off[IWVI_MAX_STACK + 1];      // pack job j: GP layer l with pack_off[l] <= j < pack_off[l + 1], latent GP j - pack_off[l]
     FzSync* sync;
+    // resume mode (more workgroups than CUs otherwise): a factorising workgroup also owns a chunk.  Its front is computed by a HELPER --
+    // the chunk workgroup with ticket help_t0 + k, which has ~12 us of idle time before the factorisation ends anyway -- up to the
+    // first GP layer's Gram, and what is particular to the chunk is left in HBM ("snapshot": the activation tiles with x~, regulariser
+    // sums, row indices, every layer's noise: ~16 KB), to be picked up by factorising workgroup k when it is done.
+    int resume, help_t0, snap_a0, snap_a1, snap_b0, snap_b1;   // LDS float ranges of a snapshot: [xa .. asq) and the noise of every layer
+    unsigned snap_stride;                  // bytes per snapshot slot
+    unsigned char* snap;
     PreLayer P[IWVI_MAX_STACK];            // the GP layers of the stack, in stack order
 };
+constexpr size_t FZ_SNAP_BYTES = 32 * 1024;
 struct FwArgs {
     FwHead h;
     FzArgs z;
@@ -544,8 +553,18 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
     const FwHead& g = gk.h;                                       // scalar path (first kernarg lines)
     const int XSTR = g.xstr;
     float* sm = reinterpret_cast<float*>(fw_smem);
-    int fz_chunk = 0;
+    int fz_chunk = 0, fz_mode = 0, fz_slot = 0, fz_own = 0;       // fz_mode: 0 chunk, 1 helper (first pass: another chunk's front), 2 resume
     unsigned fz_gen = 0;
+    if constexpr (FZ) {
+        // every 64-byte line of the header, the role arguments and the hot descriptors requested through the scalar cache at once: read
+        // field by field where they are used, a cold kernel-argument segment costs a memory round trip per line, one after the other
+        // (6.6 us between the ticket and the first stamp of the forward part before this)
+        unsigned warm = 0;
+        const unsigned* kw = reinterpret_cast<const unsigned*>(&gk);
+#pragma unroll
+        for (int i = 0; i < (int)(offsetof(FwArgs, L) / 64); ++i) warm |= kw[16 * i];
+        asm volatile("" :: "s"(warm));
+    }
     if constexpr (FZ) {
         // ---- role by ticket: whoever starts first factorises (nothing below ever waits for a workgroup that has not started) ----
         const FzArgs& z = gk.z;
@@ -559,38 +578,49 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
         const int tk = ufirst(rw[4]);
         fz_gen = (unsigned)ufirst(rw[5]);
         __syncthreads();                                          // (the roles below use the LDS from its start)
-        if (g.stamps && tid == 0) g.stamps[(size_t)blockIdx.x * 128 + 127] = 1000 + tk;   // (diagnostic: who played which role)
+        if (g.stamps && tid == 0) {                               // (diagnostic: who played which role, where, and when it came to life)
+            g.stamps[(size_t)blockIdx.x * 128 + 50] = 1000 + tk;
+            g.stamps[(size_t)blockIdx.x * 128 + 51] = __builtin_amdgcn_s_getreg(6164) & 15;   // HW_REG_XCC_ID
+            g.stamps[(size_t)blockIdx.x * 128 + 52] = wall_clock64();
+        }
         if (tk < z.n_gp) {
             const PreLayer Lc = z.P[tk];                          // (by value: a reference into the kernel arguments would force them into scratch)
             // (diagnostic stamps land in this workgroup's 128-word row, words 0 .. 15: PRE_STAMP indexes 16 words per block)
             role_factor<true, true>(Lc, 0, g.stamps ? g.stamps + (size_t)blockIdx.x * 112 : nullptr, 1, FzPub{&z.sync->early, &z.sync->done, &z.sync->cols[tk]});
             __syncthreads();
-            fw_arrive<NS, FZ>(gk, sm, tid, -1);
-            return;
-        }
-        fz_chunk = tk - z.n_gp;
-        if (fz_chunk < z.n_pack) {
-            // tril(q_sqrt_r)^T packing + KL shares (csrc/precompute_dev.h: role_pack_r): the first chunks carry one (layer, r) each;
-            // plain stores, published by ONE agent-scope release of this workgroup
-            unsigned njobs = 0;
-            for (int j = fz_chunk; j < z.n_pack; j += z.n_reg) {
-                int l = 0;
-                while (j >= z.pack_off[l + 1]) ++l;
-                const PreLayer Lc = z.P[l];
-                role_pack_r(Lc, j - z.pack_off[l], reinterpret_cast<double*>(fw_smem));
-                __syncthreads();
-                ++njobs;
+            if (!z.resume) {
+                fw_arrive<NS, FZ>(gk, sm, tid, -1);
+                return;
             }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (tid == 0) {
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (keep: the compiler may drop the fence's own wait)
-                __hip_atomic_fetch_add(&z.sync->pack, njobs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            fz_mode = 2; fz_slot = tk; fz_chunk = z.nchunks_reg + tk;      // carries on with the chunk its helper has prepared
+        } else {
+            fz_chunk = tk - z.n_gp;
+            if (fz_chunk < z.n_pack) {
+                // tril(q_sqrt_r)^T packing + KL shares (csrc/precompute_dev.h: role_pack_r): the first chunks carry one (layer, r) each
+                unsigned njobs = 0;
+                if (g.stamps && tid == 0) g.stamps[(size_t)blockIdx.x * 128 + 53] = wall_clock64();
+                for (int j = fz_chunk; j < z.n_pack; j += z.n_reg) {
+                    int l = 0;
+                    while (j >= z.pack_off[l + 1]) ++l;
+                    const PreLayer Lc = z.P[l];
+                    role_pack_r<true>(Lc, j - z.pack_off[l], reinterpret_cast<double*>(fw_smem));
+                    __syncthreads();
+                    ++njobs;
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // write-through stores, drained by every wave: no release fence
+                __syncthreads();                                  // (a buffer_wbl2 behind ~80 KB of freshly written images took 5-8 us)
+                if (tid == 0) __hip_atomic_fetch_add(&z.sync->pack, njobs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (g.stamps && tid == 0) g.stamps[(size_t)blockIdx.x * 128 + 54] = wall_clock64();
+            }
+            if (z.resume && tk >= z.help_t0 && tk < z.help_t0 + z.n_gp) {
+                fz_mode = 1; fz_slot = tk - z.help_t0; fz_own = fz_chunk; fz_chunk = z.nchunks_reg + fz_slot;   // first the other chunk's front
             }
         }
     }
-    const int chunk_id = FZ ? fz_chunk : (int)blockIdx.x;
+    int chunk_id = FZ ? fz_chunk : (int)blockIdx.x;
+fz_restart: ;                                                    // (merged launch, helper: a second pass with its own chunk)
+    const bool fz_resume = FZ && fz_mode == 2;
+    bool fz_acq = false;                                          // the pack roles' images are already acquired (a late arrival)
     const long long t0 = (long long)chunk_id * NSAMP;
     const int nvalid = (int)((g.T - t0) < (long long)NSAMP ? (g.T - t0) : (long long)NSAMP);
 
@@ -660,6 +690,7 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
         if (wide_mod) { if (r >= (unsigned)g.row_mod) r -= (unsigned)g.row_mod; } else r %= (unsigned)g.row_mod;
         return r;
     };
+    if (!fz_resume) {                                             // (a resumed chunk: all of this comes with the snapshot, below)
     if (tid < NSAMP) {
         const unsigned dp = point_of(tid);
         rowi[tid] = (int)row_of(dp);
@@ -680,9 +711,11 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
             xyrows[p * xs + i] = g.XY[(size_t)row_of((unsigned)p) * g.XYdim + i];
         }
     }
+    }
     asm volatile("" :: "s"(hot_touch));                           // (the scalar-cache lines of gk.H have landed)
     __syncthreads();                                              // layer table (and rowi / pidx) visible
     FW_STAMP(56);
+    if (!fz_resume) {
     // precomputed encoder outputs of the chunk's distinct data points -> the LV layer's constant block
     for (int li = 0; li < g.n_layers; ++li) {
         const FwHot& Hp = gk.H[li];
@@ -742,12 +775,47 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
         // the GP layers' constant blocks and Gram operands Z~ are written by the factorising workgroups of THIS launch (~3 us into it):
         // one lane waits for all of them, one agent-scope acquire covers the workgroup, then the copies are plain LDS-DMA loads
         if (wave == 0) {
-            if (lane == 0) fz_wait_ge(&gk.z.sync->early, (fz_gen + 1u) * (unsigned)gk.z.n_gp, &gk.z.sync->timeout);
+            int packed = 0;
+            if (lane == 0) {
+                fz_wait_ge(&gk.z.sync->early, (fz_gen + 1u) * (unsigned)gk.z.n_gp, &gk.z.sync->timeout);
+                packed = (int)(__hip_atomic_load(&gk.z.sync->pack, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - (fz_gen + 1u) * (unsigned)gk.z.n_pack) >= 0;
+                counters[6] = packed;                             // (a workgroup that comes late finds the pack roles done: this acquire covers them)
+            }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __syncthreads();
+        fz_acq = counters[6] != 0;
         fw_copy_entries(CT, sm, g.ncopy_indep, g.ncopy, wave, lane);
+    }
+    } else {
+        if constexpr (FZ) {
+            // ---- resume: the chunk's front was computed by its helper.  What is the same for every chunk (constant blocks, weights, Z~)
+            //      is copied as ever -- the factorisations are over, one acquire covers them and the pack roles --, what is particular
+            //      to the chunk comes back from HBM (sc1 loads to registers, all in flight, then LDS)
+            const FzArgs& z = gk.z;
+            if (wave == 0) {
+                if (lane == 0) {
+                    fz_wait_ge(&z.sync->snap[fz_slot], fz_gen + 1u, &z.sync->timeout);
+                    fz_wait_ge(&z.sync->pack, (fz_gen + 1u) * (unsigned)z.n_pack, &z.sync->timeout);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __syncthreads();
+            fw_copy_entries(CT, sm, 0, g.ncopy, wave, lane);
+            const Sc1Stream src(z.snap + (size_t)fz_slot * z.snap_stride, (unsigned)z.snap_stride, 0u);
+            f32x4* dl = reinterpret_cast<f32x4*>(sm);
+            const int nA = (z.snap_a1 - z.snap_a0) >> 2, nB = (z.snap_b1 - z.snap_b0) >> 2;
+            for (int v0 = tid; v0 < nA + nB; v0 += 4 * FW_THREADS) {
+                f32x4 r[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { const int v = v0 + u * FW_THREADS; r[u] = src[(size_t)(v < nA + nB ? v : nA + nB - 1)]; }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { const int v = v0 + u * FW_THREADS; if (v < nA + nB) dl[v < nA ? (z.snap_a0 >> 2) + v : (z.snap_b0 >> 2) + (v - nA)] = r[u]; }
+            }
+            fz_acq = true;                                        // (the pack roles are acquired: no second fence at the wait)
+        }
     }
     FW_STAMP(58);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -758,6 +826,9 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
 
     int xt_for = -1;                                              // layer whose Gram operand x~ is already in `xt`
     for (int li = 0; li < g.n_layers; ++li) {
+        if constexpr (FZ) {
+            if (fz_resume && li < gk.z.first_gp) { float* tmp = xin; xin = xout; xout = tmp; continue; }   // (the helper ran these layers)
+        }
         const FwLayer& L = LT[li];
         const FwHot& H = gk.H[li];                                // scalar loads from the (warmed) kernel-argument lines
         const FwHot& G = H;
@@ -871,7 +942,9 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
             // else difference the coordinates directly (error ~eps * r^2)
             const bool gram_mfma = __float_as_int(cst[64]) <= __float_as_int(4.0f);   // zmax2 >= 0: int compare is exact
 
+            const bool fz_skip_front = FZ && fz_resume && li == gk.z.first_gp;   // (resume: x~ came with the snapshot)
             // ---- x~ (only when the layer before did not already leave it in `xt`) -------------------------
+            if (fz_skip_front) xt_for = li;
             if (xt_for != li) {
                 if (wave < NS) xt_subtile(xin + (16 * wave + jq) * XSTR, xt + (16 * wave + jq) * XSTR, invls, zc, D, nsteps, rbf, gq);
                 __syncthreads();
@@ -879,6 +952,29 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
             // (the layer's forward-substitution stream is already on its way to LDS: prologue for the first GP
             // layer, the previous GP layer's stage 2 for the others)
             FW_STAMP(2 + li * 6 + 0);
+            if constexpr (FZ) {
+                if (fz_mode == 1 && li == gk.z.first_gp) {
+                    // ---- helper: this chunk belongs to a factorising workgroup.  What its layers need from here on that is particular to
+                    //      the chunk -- the activation tiles with x~, the regulariser sums, the row indices, the noise of every layer --
+                    //      is left in HBM (write-through; ~16 KB), counted in, and this workgroup starts over with its own chunk
+                    const FzArgs& z = gk.z;
+                    if (xt_for == li) __syncthreads();            // (x~ from the layer before: complete behind its barrier; own phase: synced above)
+                    if (g.stamps && tid == 0) g.stamps[(size_t)blockIdx.x * 128 + 53] = wall_clock64();
+                    const f32x4* sl = reinterpret_cast<const f32x4*>(sm);
+                    f32x4* dg = reinterpret_cast<f32x4*>(z.snap + (size_t)fz_slot * z.snap_stride);
+                    const int nA = (z.snap_a1 - z.snap_a0) >> 2, nB = (z.snap_b1 - z.snap_b0) >> 2;
+                    for (int v = tid; v < nA + nB; v += FW_THREADS) {
+                        const f32x4 x = sl[v < nA ? (z.snap_a0 >> 2) + v : (z.snap_b0 >> 2) + (v - nA)];
+                        asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(dg + v), "v"(x) : "memory");
+                    }
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __syncthreads();
+                    if (tid == 0) __hip_atomic_fetch_add(&z.sync->snap[fz_slot], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (g.stamps && tid == 0) g.stamps[(size_t)blockIdx.x * 128 + 54] = wall_clock64();
+                    fz_mode = 0; chunk_id = fz_own;
+                    goto fz_restart;
+                }
+            }
 
             // ---- Gram: kuf block bi = kernel(Z_bi, x), written in B-operand order ---------------------------
             for (int bi = wave; bi < nbk; bi += FW_WAVES) {
@@ -955,8 +1051,10 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
                     // in the shadow of the wait); `done` is polled by one lane and everything it guards is read by sc1 loads.
                     FW_STAMP(60);
                     if (wave == 0) {
-                        if (lane == 0) fz_wait_ge(&gk.z.sync->pack, (fz_gen + 1u) * (unsigned)gk.z.n_pack, &gk.z.sync->timeout);
-                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                        if (!fz_acq) {
+                            if (lane == 0) fz_wait_ge(&gk.z.sync->pack, (fz_gen + 1u) * (unsigned)gk.z.n_pack, &gk.z.sync->timeout);
+                            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                        }
                         // this layer's solve stream goes to the LDS staging buffer COLUMN BY COLUMN, as the factorising workgroup
                         // publishes it (a column is final one pass after its diagonal block): when the last one arrives, only that
                         // one is left to fetch -- the stream's 36 KiB never sit on the critical path.  sc1 loads to registers, then LDS.
@@ -965,11 +1063,12 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
                             f32x4* dstl = reinterpret_cast<f32x4*>(sm + G.ls_off) + lane;
                             const unsigned cbase = fz_gen * (unsigned)nbk;
                             unsigned* cw = &gk.z.sync->cols[0];                // (the first GP layer is factorised under ticket 0)
-                            for (int j = 0; j < nbk;) {
+                            int j = 0;
+                            while (j < nbk) {
                                 unsigned have = 0;
                                 if (lane == 0) have = fz_wait_ge_val(cw, cbase + (unsigned)j + 1u, &gk.z.sync->timeout) - cbase;
                                 int upto = __builtin_amdgcn_readfirstlane((int)have);
-                                upto = upto > nbk ? nbk : upto;
+                                if (upto >= nbk) break;                       // everything is there: what is left goes faster with every wave (below)
                                 const int b1 = tri_upper_off(nbk, upto);
                                 for (int b = tri_upper_off(nbk, j); b < b1; b += 8) {
                                     f32x4 v[8];
@@ -980,12 +1079,27 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
                                 }
                                 j = upto;
                             }
+                            if (lane == 0) counters[7] = j;
                         }
                         if (lane == 0) fz_wait_ge(&gk.z.sync->done, (fz_gen + 1u) * (unsigned)gk.z.n_gp, &gk.z.sync->timeout);
                         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
                     }
                     __syncthreads();
                     FW_STAMP(61);
+                    if (G.ls_off >= 0 && nbk <= 8) {
+                        // the columns not yet staged (the last two of a workgroup that kept up; all of them for one that arrived after the
+                        // factorisation -- a resumed chunk, a helper's own chunk): all waves, every load in flight at once
+                        const int b0 = tri_upper_off(nbk, counters[7]), nv = (tri_blocks(nbk) - b0) * 64;
+                        const Sc1Stream src(G.LsP, (unsigned)(tri_blocks(nbk) * BLK16 * 4), 0u);
+                        f32x4* dstl = reinterpret_cast<f32x4*>(sm + G.ls_off);
+                        for (int v0 = tid; v0 < nv; v0 += 5 * FW_THREADS) {
+                            f32x4 r[5];
+#pragma unroll
+                            for (int u = 0; u < 5; ++u) { const int v = v0 + u * FW_THREADS; r[u] = src[(size_t)(b0 * 64 + (v < nv ? v : nv - 1))]; }
+#pragma unroll
+                            for (int u = 0; u < 5; ++u) { const int v = v0 + u * FW_THREADS; if (v < nv) dstl[b0 * 64 + v] = r[u]; }
+                        }
+                    }
                     // the split-f16 scales the pack roles wrote into every GP layer's constant block (cst[64 .. 104)), now that they exist
                     for (int i = tid; i < g.n_layers * 40; i += FW_THREADS) {
                         const int l = i / 40, o = 64 + (i - l * 40);
@@ -1940,6 +2054,7 @@ static size_t fw_plan_lds(FwArgs& a, int nsamp, int maxR, int maxP, bool stage_z
     l.cnt = o; o += 12;
     l.scratch = o; o += up4(scratch);
     l.total = o;
+    a.z.snap_a0 = l.xa; a.z.snap_a1 = l.asq; a.z.snap_b0 = l.znoise; a.z.snap_b1 = l.znoise + up4(zdims * nsamp);
     return (size_t)o * sizeof(float);
 }
 
@@ -2136,8 +2251,18 @@ static int dgp_forward_fz(const iwvi_layer_desc* layers, int n_layers, const flo
     a.h.dbg_exit = g_dbg_exit;
     if (use_fz) {
         FzArgs& z = a.z;
-        z.n_reg = (int)chunks;
-        z.n_ticket = z.n_gp + (int)chunks;
+        static int n_cu = 0;
+        if (!n_cu) { int dev = 0; (void)hipGetDevice(&dev); if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) n_cu = 256; }
+        // more workgroups than CUs (one workgroup per CU at these LDS sizes): the factorising workgroups own chunks too (resume mode) --
+        // a chunk workgroup left without a CU would only start when a factorising one retires, and pay its whole front behind it
+        z.resume = (chunks + z.n_gp > n_cu && chunks >= 2 * z.n_gp + z.n_pack && (size_t)(z.snap_a1 - z.snap_a0 + z.snap_b1 - z.snap_b0) * 4 <= FZ_SNAP_BYTES &&
+                    !getenv("IWVI_FZ_NO_RESUME")) ? 1 : 0;
+        z.snap = reinterpret_cast<unsigned char*>(fz->ws) + sizeof(FzSync);
+        z.snap_stride = (unsigned)FZ_SNAP_BYTES;
+        z.help_t0 = z.n_gp + z.n_pack;
+        z.n_reg = (int)chunks - (z.resume ? z.n_gp : 0);
+        z.nchunks_reg = z.n_reg;
+        z.n_ticket = z.resume ? (int)chunks : z.n_gp + (int)chunks;
         for (int k = 0; k < z.n_gp; ++k) { const size_t la = factor_lds_bytes(z.P[k].Mp); if (la > lds_bytes) lds_bytes = la; }
         const unsigned grid = (unsigned)z.n_ticket;
         if (s16_all) switch (ns) {
@@ -2199,7 +2324,7 @@ extern "C" int iwvi_dgp_forward(const iwvi_layer_desc* layers, int n_layers, con
                             rng_state, out_logw, elbo, (hipStream_t)stream);
 }
 
-extern "C" size_t iwvi_fused_ws_bytes(void) { return sizeof(iwvi::FzSync); }
+extern "C" size_t iwvi_fused_ws_bytes(void) { return sizeof(iwvi::FzSync) + (size_t)IWVI_MAX_STACK * iwvi::FZ_SNAP_BYTES; }
 
 extern "C" int iwvi_dgp_forward_fused(const iwvi_gp_desc* gp, int n_gp, void* fused_ws,
                                       const iwvi_layer_desc* layers, int n_layers, const float* X, int Dx,

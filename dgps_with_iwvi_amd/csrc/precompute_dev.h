@@ -690,9 +690,33 @@ __device__ __forceinline__ double block_sum_vt(double* red) {
 //   kl[r] = 1/2 (|q_mu[:,r]|^2 - M - sum log L_ii^2 + |tril L|^2).
 // One float4 of the packed image per thread-iteration, one 16-byte store.  The KL share is accumulated by PACK_VT virtual threads
 // (a workgroup of fewer threads plays several of them in turn), so its rounding does not depend on the launch geometry.
+template <bool WT = false>        // WT: write-through stores (merged launch: the images are read by other workgroups of the SAME launch)
 __device__ __forceinline__ void role_pack_r(const PreLayer& L, int r, double* red) {
     const int nbk = L.nbk, M = L.M, R = L.R;
     const float* q = L.q_sqrt + (size_t)r * M * M;
+    if (L.Mp <= 128) {
+        // q_sqrt[r] -> LDS first, every thread's loads in flight at once (behind the reduction slots; both launches give a layer
+        // with Mp <= 128 the factorisation's ~158 KB of LDS): the loops below read each value once or twice through dependent
+        // addresses -- from global memory that was a chain of round trips (8 us with 1024 threads, 24 us with 512)
+        float* qs = reinterpret_cast<float*>(red + PACK_VT);
+        const int n = M * M;
+        if ((n & 3) == 0) {
+            const float4* q4 = reinterpret_cast<const float4*>(q);
+            float4* s4 = reinterpret_cast<float4*>(qs);
+            const int n4 = n >> 2, nt = (int)blockDim.x;
+            for (int i0 = threadIdx.x; i0 < n4; i0 += 8 * nt) {
+                float4 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { const int i = i0 + u * nt; v[u] = q4[i < n4 ? i : n4 - 1]; }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { const int i = i0 + u * nt; if (i < n4) s4[i] = v[u]; }
+            }
+        } else {
+            for (int i = threadIdx.x; i < n; i += blockDim.x) qs[i] = q[i];
+        }
+        __syncthreads();
+        q = qs;
+    }
     float4* dstm = reinterpret_cast<float4*>(L.LrTP + (size_t)r * tri_blocks(nbk) * BLK16);
     const int nvec = nbk * nbk * 64;
     for (int vt = threadIdx.x; vt < PACK_VT; vt += blockDim.x) {
@@ -713,7 +737,7 @@ __device__ __forceinline__ void role_pack_r(const PreLayer& L, int r, double* re
             acc += (double)x * (double)x;
             if (k == i && i < M) acc -= log((double)x * (double)x);
         }
-        dstm[(size_t)(tri_upper_off(nbk, bi) + (bk - bi)) * 64 + lane] = make_float4(o[0], o[1], o[2], o[3]);
+        st_pub4<WT>(dstm + (size_t)(tri_upper_off(nbk, bi) + (bk - bi)) * 64 + lane, make_float4(o[0], o[1], o[2], o[3]));
     }
     for (int m = vt; m < M; m += PACK_VT) {
         const double v = L.q_mu[(size_t)m * R + r];
@@ -730,17 +754,21 @@ __device__ __forceinline__ void role_pack_r(const PreLayer& L, int r, double* re
             float o[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = (rr < R && k0 + e < M) ? L.q_mu[(size_t)(k0 + e) * R + rr] : 0.f;
-            dq[v4] = make_float4(o[0], o[1], o[2], o[3]);
+            st_pub4<WT>(dq + v4, make_float4(o[0], o[1], o[2], o[3]));
         }
     }
     const double tot = block_sum_vt(red);
-    if (threadIdx.x == 0) L.kl[r] = 0.5 * (tot - (double)M);
+    if (threadIdx.x == 0) {
+        if constexpr (WT) __hip_atomic_store(L.kl + r, 0.5 * (tot - (double)M), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else L.kl[r] = 0.5 * (tot - (double)M);
+    }
     // ---- the split-f16 image of L_r^T (and, role 1, of q_mu^T) with its power-of-two scale ----------------------------------
     if (nbk & 1) return;
     const float var = L.variance_dev ? *L.variance_dev : L.variance;
     const int ea = ((L.nbk <= 8 && (L.nbk & 1) == 0) ? 7 : 10) - (int)ceilf(0.5f * log2f(fmaxf(var, 1e-30f)));   // |a| <= sigma  ->  |a| 2^ea <= 2^10 (2^7 = 2^est where stage 1 writes the planes: role_factor)
-    double mx = 0.0;
-    for (int idx = threadIdx.x; idx < M * M; idx += blockDim.x) { const int k = idx / M, i = idx - k * M; if (k >= i) mx = fmax(mx, fabs((double)q[idx])); }
+    double mx = 0.0;                                             // (a wave per row, lanes along it: no division per element; max is order-free)
+    for (int k = threadIdx.x >> 6; k < M; k += (int)(blockDim.x >> 6))
+        for (int i = threadIdx.x & 63; i <= k; i += 64) mx = fmax(mx, fabs((double)q[(size_t)k * M + i]));
     __syncthreads();
     red[threadIdx.x] = mx;
     __syncthreads();
@@ -749,7 +777,7 @@ __device__ __forceinline__ void role_pack_r(const PreLayer& L, int r, double* re
     __syncthreads();
     const int er = mx > 0.0 ? 13 - (int)floor(log2(mx)) : 0;                  // max |L_r| 2^er in [2^13, 2^14)
     const float sr = ldexpf(1.f, er);
-    if (threadIdx.x == 0) L.cst[IWVI_CST_FR + r] = ldexpf(1.f, -(ea + er));
+    if (threadIdx.x == 0) st_pub<WT>(L.cst + IWVI_CST_FR + r, ldexpf(1.f, -(ea + er)));
     {
         const int nst = s16_slabs_total(nbk);
         unsigned short* dst = L.LrT16 + (size_t)r * nst * 1024;                 // 1024 halves per slab (2 planes x 512)
@@ -769,8 +797,8 @@ __device__ __forceinline__ void role_pack_r(const PreLayer& L, int r, double* re
             }
             // the slabs of row-blocks 2p and 2p+1 are interleaved chunk by chunk (they are multiplied as one step: same B vectors)
             const int slp = ((bi & 1) ? o - s16_slabs(nbk, bi) : o) + 2 * (sl - o) + (bi & 1);
-            *reinterpret_cast<float4*>(dst + (size_t)slp * 1024 + lane * 8) = *reinterpret_cast<const float4*>(h1);
-            *reinterpret_cast<float4*>(dst + (size_t)slp * 1024 + 512 + lane * 8) = *reinterpret_cast<const float4*>(h2);
+            st_pub4<WT>(reinterpret_cast<float4*>(dst + (size_t)slp * 1024 + lane * 8), *reinterpret_cast<const float4*>(h1));
+            st_pub4<WT>(reinterpret_cast<float4*>(dst + (size_t)slp * 1024 + 512 + lane * 8), *reinterpret_cast<const float4*>(h2));
         }
     }
     if (r == 0) {
@@ -782,7 +810,7 @@ __device__ __forceinline__ void role_pack_r(const PreLayer& L, int r, double* re
         mq = red[0];
         const int eq = mq > 0.0 ? 13 - (int)floor(log2(mq)) : 0;
         const float sq = ldexpf(1.f, eq);
-        if (threadIdx.x == 0) L.cst[IWVI_CST_FMEAN] = ldexpf(1.f, -(ea + eq));
+        if (threadIdx.x == 0) st_pub<WT>(L.cst + IWVI_CST_FMEAN, ldexpf(1.f, -(ea + eq)));
         const int nkc = nbk / 2;
         for (int v = threadIdx.x; v < L.nrb * nkc * 64; v += blockDim.x) {
             const int sl = v >> 6, lane = v & 63, rb = sl / nkc, kc = sl - rb * nkc;
@@ -793,8 +821,8 @@ __device__ __forceinline__ void role_pack_r(const PreLayer& L, int r, double* re
                 const float x = (rr < R && k0 + e < M) ? L.q_mu[(size_t)(k0 + e) * R + rr] * sq : 0.f;
                 h1[e] = (_Float16)x; h2[e] = (_Float16)(x - (float)h1[e]);
             }
-            *reinterpret_cast<float4*>(L.Qmu16 + (size_t)sl * 1024 + lane * 8) = *reinterpret_cast<const float4*>(h1);
-            *reinterpret_cast<float4*>(L.Qmu16 + (size_t)sl * 1024 + 512 + lane * 8) = *reinterpret_cast<const float4*>(h2);
+            st_pub4<WT>(reinterpret_cast<float4*>(L.Qmu16 + (size_t)sl * 1024 + lane * 8), *reinterpret_cast<const float4*>(h1));
+            st_pub4<WT>(reinterpret_cast<float4*>(L.Qmu16 + (size_t)sl * 1024 + 512 + lane * 8), *reinterpret_cast<const float4*>(h2));
         }
     }
 }
