@@ -14,9 +14,11 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libiwvi_hip.so")
 
 KERN_RBF, KERN_MATERN52 = 0, 1
 LAYER_GP, LAYER_LV = 0, 1
-ABI_VERSION = 12
+ABI_VERSION = 13
 GP_WANT_DENSE = 1
 GP_WANT_LM = 2
+LAYER_F32_STAGE2 = 1        # iwvi_layer_desc.flags
+BW_F32_CHAIN = 1            # iwvi_gp_bwd_desc.flags
 ADAM_GRAD_F64 = 16
 MAX_STACK = 8
 MF_ZERO, MF_IDENTITY, MF_LINEAR = 0, 1, 2
@@ -63,7 +65,7 @@ class LayerDesc(ctypes.Structure):
                 ("noise", c_void_p), ("zero_noise", ctypes.c_int32), ("noise_out", c_void_p),
                 ("sample", c_void_p), ("mean", c_void_p), ("var", c_void_p), ("kl_local", c_void_p),
                 ("a_out", c_void_p), ("u_out", c_void_p), ("gmv_out", c_void_p), ("variance_dev", c_void_p),
-                ("enc_act", ctypes.c_int32)]
+                ("enc_act", ctypes.c_int32), ("flags", ctypes.c_int32)]
 
 
 class ElboDesc(ctypes.Structure):
@@ -87,7 +89,7 @@ class GpBwdDesc(ctypes.Structure):
                 ("dF", c_void_p), ("dZ", c_void_p), ("dls", c_void_p), ("dvariance", c_void_p),
                 ("dq_mu", c_void_p), ("dq_sqrt", c_void_p), ("dW", c_void_p), ("dmf_A", c_void_p),
                 ("side_stream", c_void_p), ("side_stream2", c_void_p), ("prepared", ctypes.c_int32),
-                ("variance_dev", c_void_p), ("phase", ctypes.c_int32)]
+                ("variance_dev", c_void_p), ("phase", ctypes.c_int32), ("flags", ctypes.c_int32)]
 
 
 class AdamTensor(ctypes.Structure):
@@ -99,6 +101,7 @@ class AdamTensor(ctypes.Structure):
 # name -> (restype, argtypes); every symbol include/iwvi_hip.h declares
 PROTOTYPES = {
     "iwvi_version": (c_int, []),
+    "iwvi_debug_set_option": (c_int, [ctypes.c_char_p, c_int]),
     "iwvi_last_error": (ctypes.c_char_p, []),
     "iwvi_gp_state_bytes": (c_size_t, [c_int, c_int]),
     "iwvi_gp_state_offsets": (c_int, [c_int, c_int, ctypes.POINTER(c_size_t)]),
@@ -181,6 +184,16 @@ PROTOTYPES = {
     "iwvi_fill_normal_dev": (c_int, [c_void_p, c_int64, ctypes.c_uint64, c_void_p, c_void_p]),
 }
 
+DEBUG_OPTIONS = ("IWVI_BW_SMALL_TILES", "IWVI_BW_UNFUSED", "IWVI_BW_FUSED", "IWVI_BW_S16_SMALL_M", "IWVI_BW_OLD_CHAIN",
+                 "IWVI_BW_CHAIN_SMALL_M_ONLY", "IWVI_BW_CHAIN_M256_ONLY", "IWVI_BW_CHAIN_NS2", "IWVI_BW_GEMM_PRODUCTS", "IWVI_DMM_LDS",
+                 "IWVI_CHAIN_EXIT", "IWVI_FZ_NO_RESUME", "IWVI_NATGRAD_UNFUSED", "IWVI_NG_STOP", "IWVI_DEBUG_STOP", "IWVI_PRE_STAMP_P")
+
+
+def set_debug_option(name, value):
+    """``iwvi_debug_set_option``: a development route switch of the library (process-wide; 0 = default route)."""
+    check(lib().iwvi_debug_set_option(name.encode(), int(value)))
+
+
 _lib = None
 
 
@@ -198,6 +211,13 @@ def lib():
             fn.restype, fn.argtypes = res, args
         if handle.iwvi_version() != ABI_VERSION:
             raise IwviError("libiwvi_hip.so ABI version %d != %d (rebuild: make -C dgps_with_iwvi_amd/csrc)" % (handle.iwvi_version(), ABI_VERSION))
+        # development route switches: the C library never reads the environment; IWVI_* variables seen HERE become its options
+        for name in DEBUG_OPTIONS:
+            if os.environ.get(name):
+                try:
+                    handle.iwvi_debug_set_option(name.encode(), int(os.environ[name]))
+                except ValueError:
+                    handle.iwvi_debug_set_option(name.encode(), 1)
         _lib = handle
     return _lib
 

@@ -100,6 +100,7 @@ def _param_desc(layer, dense_state=None):
     b.variance, b.variance_dev = kern.desc_variance()
     b.M, b.D, b.R, b.kern_type = M, Z.shape[1], R, kern.kern_type
     b.P = layer.kern.W.shape[0] if isinstance(layer.kern, SharedMixedMok) else R
+    b.flags = _abi.BW_F32_CHAIN if settings.bw_f32_chain else 0     # per call, not per process (include/iwvi_hip.h)
     return b, [Z, q_mu, q_sqrt]
 
 

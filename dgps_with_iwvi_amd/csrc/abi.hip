@@ -2,6 +2,7 @@
 #include "iwvi_common.h"
 #include <cstdarg>
 #include <cstdio>
+#include <cstring>
 
 namespace iwvi {
 
@@ -23,7 +24,26 @@ int check_launch(const char* what) {
     return IWVI_OK;
 }
 
+// ---- development route switches: set through iwvi_debug_set_option only (the library does not read the environment) -------------
+static const char* const g_opt_names[] = {
+    "IWVI_BW_SMALL_TILES", "IWVI_BW_UNFUSED", "IWVI_BW_FUSED", "IWVI_BW_S16_SMALL_M", "IWVI_BW_OLD_CHAIN", "IWVI_BW_CHAIN_SMALL_M_ONLY",
+    "IWVI_BW_CHAIN_M256_ONLY", "IWVI_BW_CHAIN_NS2", "IWVI_BW_GEMM_PRODUCTS", "IWVI_DMM_LDS", "IWVI_CHAIN_EXIT", "IWVI_FZ_NO_RESUME",
+    "IWVI_NATGRAD_UNFUSED", "IWVI_NG_STOP", "IWVI_DEBUG_STOP", "IWVI_PRE_STAMP_P"};
+constexpr int N_OPTS = (int)(sizeof(g_opt_names) / sizeof(g_opt_names[0]));
+static int g_opt_values[N_OPTS] = {0};
+static int opt_index(const char* name) {
+    for (int i = 0; i < N_OPTS; ++i) if (!strcmp(name, g_opt_names[i])) return i;
+    return -1;
+}
+int dbg_opt(const char* name) { const int i = opt_index(name); return i < 0 ? 0 : g_opt_values[i]; }
+
 }  // namespace iwvi
 
+extern "C" int iwvi_debug_set_option(const char* name, int value) {
+    const int i = name ? iwvi::opt_index(name) : -1;
+    if (i < 0) { iwvi::set_error("iwvi_debug_set_option: unknown option %s", name ? name : "(null)"); return IWVI_ERR_ARG; }
+    iwvi::g_opt_values[i] = value;
+    return IWVI_OK;
+}
 extern "C" int iwvi_version(void) { return IWVI_ABI_VERSION; }
 extern "C" const char* iwvi_last_error(void) { return iwvi::g_err; }

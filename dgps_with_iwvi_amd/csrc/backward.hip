@@ -304,7 +304,7 @@ __global__ __launch_bounds__(256) void k_gemm_big(GemmArgs g) {
 }
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 static bool use_big_tiles(const GemmArgs& g) {
-    if (g.M % BT || g.N % BT || getenv("IWVI_BW_SMALL_TILES")) return false;
+    if (g.M % BT || g.N % BT || dbg_opt("IWVI_BW_SMALL_TILES")) return false;
     return (long long)(g.M / BT) * (g.N / BT) * g.nsplit * g.nbatch >= 512;
 }
 // launch on the fast path if the shapes allow it; returns false otherwise (caller falls back to k_gemm)
@@ -855,10 +855,10 @@ static void launch_mid_d(hipStream_t st, const MidArgs& a, dim3 grid, size_t lds
 // returns 1 if the fused kernel was launched, 0 if the shapes do not allow it, < 0 on error
 static int launch_mid(hipStream_t st, const MidArgs& a) {
     const int M = a.M;
-    if (!a.GMV || M % 64 || M > 256 || M == 192 || a.T % 64 || a.Mp != M || getenv("IWVI_BW_UNFUSED")) return 0;
+    if (!a.GMV || M % 64 || M > 256 || M == 192 || a.T % 64 || a.Mp != M || dbg_opt("IWVI_BW_UNFUSED")) return 0;
     // measured (configs[1] / [2] / [3]): -3.5 % of the whole evaluation at M = 128, T = 20480; +7 % at T = 5120 (80 workgroups
     // for 256 CUs) and +10 % at M = 256 (105 KB of LDS: one workgroup per CU) -- so only where it wins, unless forced
-    if (!getenv("IWVI_BW_FUSED") && (M > 128 || a.T < 16384)) return 0;
+    if (!dbg_opt("IWVI_BW_FUSED") && (M > 128 || a.T < 16384)) return 0;
     if (!aligned16(a.U) || !aligned16(a.q_sqrt) || !aligned16(a.LinvF) || !aligned16(a.C)) return 0;
     const size_t lds = sizeof(float) * ((size_t)64 * (M + 4) + 4 * OPB + (size_t)64 * (2 * a.R + 1) + (size_t)64 * a.D);
     static bool done = false;
@@ -1587,14 +1587,18 @@ static int chain_ns_cap(long long T, int cap) {             // samples per workg
 // phase 1 of the chain on split-f16 operands: an even number of 16-row blocks (the state then carries the scales); a third tile holds
 // the a planes, so beyond M = 256 only 16 samples fit a workgroup -- still faster than the fp32 phase 1 at 32 (configs[4]: 277 -> 240 ms per
 // value + gradient; IWVI_BW_S16_SMALL_M=1 keeps the fp32 phase 1 there)
-static bool chain_s16(int M, int Mp) { return Mp == M && ((Mp / 16) & 1) == 0 && (M <= 256 || !getenv("IWVI_BW_S16_SMALL_M")) && !getenv("IWVI_BW_F32_CHAIN"); }
+// IWVI_BW_F32_CHAIN of the descriptor being served by this thread's current call (set at the entry points that take a descriptor;
+// the sizing functions, which take none, see the default -- the split-f16 chain needs the larger workspace)
+static thread_local bool t_bw_f32_chain = false;
+struct BwFlagScope { bool old; explicit BwFlagScope(int flags) : old(t_bw_f32_chain) { t_bw_f32_chain = (flags & IWVI_BW_F32_CHAIN) != 0; } ~BwFlagScope() { t_bw_f32_chain = old; } };
+static bool chain_s16(int M, int Mp) { return Mp == M && ((Mp / 16) & 1) == 0 && (M <= 256 || !dbg_opt("IWVI_BW_S16_SMALL_M")) && !t_bw_f32_chain; }
 static int chain_ns(long long T, int M = 128) { return chain_ns_cap(T, M <= 128 ? 5 : ((M > 256 && chain_s16(M, M)) ? 1 : 2)); }
 static bool chain_ok(int M, int Mp, long long T) {
     // M > 256: only with 32 samples per workgroup (two [M x 32] tiles; the scaled inducing inputs then stay in L2) -- at 16 every packed
     // S_r block (R * 32 * 32 KiB per layer) would be fetched from L2 for 4 MFMAs: measured 383 ms per value + gradient at configs[4]
     // against 359 ms on the GEMM path
-    return Mp == M && M <= 512 && (T % 16) == 0 && (M <= 256 || chain_ns(T, M) >= 2 || chain_s16(M, Mp)) && !getenv("IWVI_BW_UNFUSED") && !getenv("IWVI_BW_OLD_CHAIN") &&
-           !(M > 128 && getenv("IWVI_BW_CHAIN_SMALL_M_ONLY")) && !(M > 256 && getenv("IWVI_BW_CHAIN_M256_ONLY"));
+    return Mp == M && M <= 512 && (T % 16) == 0 && (M <= 256 || chain_ns(T, M) >= 2 || chain_s16(M, Mp)) && !dbg_opt("IWVI_BW_UNFUSED") && !dbg_opt("IWVI_BW_OLD_CHAIN") &&
+           !(M > 128 && dbg_opt("IWVI_BW_CHAIN_SMALL_M_ONLY")) && !(M > 256 && dbg_opt("IWVI_BW_CHAIN_M256_ONLY"));
 }
 // floats of the staging region beside the two tiles: what is staged there before (heads) / after (kernel adjoint: x~ rows, z~, shares)
 static bool chain_z_lds(int M) { return M <= 256; }
@@ -1615,7 +1619,7 @@ static int chain_ts(int NSAMP, int M, int D, int R, int P) { return chain_lds_by
 // implies more partial sums: the workspace (sized with chain_ns) covers both.
 static int chain_ns_shape(long long T, int M, int D, int R, int P) {
     const int base = chain_ns(T, M);
-    if (M > 128 && M <= 256 && !getenv("IWVI_BW_CHAIN_NS2")) {
+    if (M > 128 && M <= 256 && !dbg_opt("IWVI_BW_CHAIN_NS2")) {
         const int ns4 = chain_ns_cap(T, 4);
         if (ns4 > base && chain_lds_bytes_ts(16 * ns4, 16 * ns4, M, D, R, P) <= 160 * 1024) return ns4;
     }
@@ -1628,7 +1632,7 @@ static size_t chain_lds_bytes(long long T, int M, int D, int R, int P) {
 static bool chain_fits(long long T, int M, int Mp, int D, int R, int P) { return chain_ok(M, Mp, T) && chain_lds_bytes(T, M, D, R, P) <= 160 * 1024; }
 // the two M x M products over samples inside the chain kernel: only while the number of per-workgroup shares stays moderate
 static bool chain_products_ok(int M, long long T) {
-    return chain_ok(M, round_up(M, 16), T) && M <= 128 && T / (16 * chain_ns(T, M)) <= 1024 && !getenv("IWVI_BW_GEMM_PRODUCTS");
+    return chain_ok(M, round_up(M, 16), T) && M <= 128 && T / (16 * chain_ns(T, M)) <= 1024 && !dbg_opt("IWVI_BW_GEMM_PRODUCTS");
 }
 template <int NS>
 static int launch_chain_ns(hipStream_t st, ChainArgs a) {
@@ -2215,7 +2219,7 @@ __global__ __launch_bounds__(64) void k_dmm_mfma(DmmArgs a) {
 static void dmm(hipStream_t st, const double* A, long long a_si, long long a_sk, const double* B, long long b_sk, long long b_sj,
                 double* C, long long ldc, int I, int J, int K, double alpha = 1.0, const double* E = nullptr, long long lde = 0, double beta = 0.0, int post = 0) {
     DmmArgs a{A, a_si, a_sk, B, b_sk, b_sj, C, ldc, I, J, K, alpha, E, lde, beta, post};
-    if (I % 16 == 0 && J % 16 == 0 && K % 4 == 0 && !getenv("IWVI_DMM_LDS")) {
+    if (I % 16 == 0 && J % 16 == 0 && K % 4 == 0 && !dbg_opt("IWVI_DMM_LDS")) {
         hipLaunchKernelGGL(k_dmm_mfma, dim3(J / 16, I / 16), dim3(64), 0, st, a);
         return;
     }
@@ -2404,6 +2408,7 @@ extern "C" size_t iwvi_gp_layer_backward_ws_bytes(int64_t T, int M, int D, int R
 extern "C" int iwvi_gp_layer_backward_prepare(const iwvi_gp_bwd_desc* dp, int64_t T, void* ws_, void* stream_) {
     if (!dp || !ws_ || T <= 0) { set_error("iwvi_gp_layer_backward_prepare: bad argument"); return IWVI_ERR_ARG; }
     const iwvi_gp_bwd_desc& d = *dp;
+    const BwFlagScope flag_scope(d.flags);
     if (!d.state || !d.Z || !d.lengthscales || !d.q_sqrt || d.M <= 0 || d.M > IWVI_MAX_M || d.D <= 0 || d.D > IWVI_MAX_D || d.R <= 0 || d.R > IWVI_MAX_R) {
         set_error("iwvi_gp_layer_backward_prepare: null input or size out of range"); return IWVI_ERR_ARG;
     }
@@ -2429,6 +2434,7 @@ extern "C" int iwvi_gp_layers_backward_prepare(const iwvi_gp_bwd_desc* descs, in
     PrepAll a{};
     a.n = n;
     unsigned grid = 0;
+    const BwFlagScope flag_scope(descs[0].flags);                  // (one launch for all layers: the first descriptor's mode)
     for (int i = 0; i < n; ++i) {
         const iwvi_gp_bwd_desc& d = descs[i];
         if (!ws[i] || !d.state || !d.Z || !d.lengthscales || !d.q_sqrt || d.M <= 0 || d.M > IWVI_MAX_M || d.D <= 0 || d.D > IWVI_MAX_D || d.R <= 0 || d.R > IWVI_MAX_R) {
@@ -2456,6 +2462,7 @@ extern "C" int iwvi_gp_layers_backward_prepare(const iwvi_gp_bwd_desc* descs, in
 extern "C" int iwvi_gp_layer_backward(const iwvi_gp_bwd_desc* dp, int64_t T, void* ws_, void* stream_) {
     if (!dp || !ws_ || T <= 0) { set_error("iwvi_gp_layer_backward: bad argument"); return IWVI_ERR_ARG; }
     const iwvi_gp_bwd_desc& d = *dp;
+    const BwFlagScope flag_scope(d.flags);
     if (!d.state || !d.Z || !d.lengthscales || !d.q_mu || !d.q_sqrt || !d.F || !d.A) { set_error("iwvi_gp_layer_backward: null input"); return IWVI_ERR_ARG; }
     if (d.M <= 0 || d.M > IWVI_MAX_M || d.D <= 0 || d.D > IWVI_MAX_D || d.R <= 0 || d.R > IWVI_MAX_R || d.P <= 0 || d.P > IWVI_MAX_P || T >= (1LL << 31) / (d.M > d.D ? d.M : d.D)) {
         set_error("iwvi_gp_layer_backward: size out of range"); return IWVI_ERR_ARG;
@@ -2501,7 +2508,7 @@ extern "C" int iwvi_gp_layer_backward(const iwvi_gp_bwd_desc* dp, int64_t T, voi
         const int nbk = Mp / 16;
         ChainArgs ca{d.GMV, d.noise, d.W, d.mf_A, d.d_sample, d.d_mean, d.d_var, w.DMU, w.DV2, w.SDV, d.dF, d.P, d.mf_type,
                      d.A, Mp, d.q_mu, w.SP, w.LinvTP, w.DK, d.F, w.Zt, w.invls, w.DA, w.Qx, (long long)T, M, D, R, nbk, d.variance, d.kern_type,
-                     getenv("IWVI_CHAIN_EXIT") ? atoi(getenv("IWVI_CHAIN_EXIT")) : 0, d.variance_dev};
+                     dbg_opt("IWVI_CHAIN_EXIT"), d.variance_dev};
         // the thin sums over samples ride in the chain kernel: one partial per workgroup and job, summed with the rest of chain B
         const int S = (int)(T / (16 * chain_ns_shape(T, M, D, R, d.P))), P = d.P;
         auto job = [&](int Mj, int Nj, float* out, const float* add, double add_coef) -> float* {

@@ -2079,7 +2079,8 @@ static int dgp_forward_fz(const iwvi_layer_desc* layers, int n_layers, const flo
     int D = Dx, maxR = 1, maxP = 1;
     bool need_rng = false;
     // stage 2 on split-f16 operands (one kernel variant for the launch): every GP layer must have an even number of 16-row blocks
-    bool s16_all = !getenv("IWVI_FW_F32_STAGE2");
+    bool s16_all = true;                                         // ... and none asks for the fp32 variant (IWVI_LAYER_F32_STAGE2: per call, not per process)
+    for (int i = 0; i < n_layers; ++i) if (layers[i].type == IWVI_LAYER_GP && (layers[i].flags & IWVI_LAYER_F32_STAGE2)) s16_all = false;
     for (int i = 0; i < n_layers; ++i) if (layers[i].type == IWVI_LAYER_GP && ((round_up(layers[i].M, 16) / 16) & 1)) s16_all = false;
     for (int i = 0; i < n_layers; ++i) {
         const iwvi_layer_desc& d = layers[i];
@@ -2256,7 +2257,7 @@ static int dgp_forward_fz(const iwvi_layer_desc* layers, int n_layers, const flo
         // more workgroups than CUs (one workgroup per CU at these LDS sizes): the factorising workgroups own chunks too (resume mode) --
         // a chunk workgroup left without a CU would only start when a factorising one retires, and pay its whole front behind it
         z.resume = (chunks + z.n_gp > n_cu && chunks >= 2 * z.n_gp + z.n_pack && (size_t)(z.snap_a1 - z.snap_a0 + z.snap_b1 - z.snap_b0) * 4 <= FZ_SNAP_BYTES &&
-                    !getenv("IWVI_FZ_NO_RESUME")) ? 1 : 0;
+                    !dbg_opt("IWVI_FZ_NO_RESUME")) ? 1 : 0;
         z.snap = reinterpret_cast<unsigned char*>(fz->ws) + sizeof(FzSync);
         z.snap_stride = (unsigned)FZ_SNAP_BYTES;
         z.help_t0 = z.n_gp + z.n_pack;

@@ -405,11 +405,11 @@ static int ensure_lds_attr(const void* fn, size_t bytes) {
 
 int natgrad_small(float* q_mu, float* q_sqrt, const float* dq_mu, const float* dq_sqrt, int M, int R, double gamma, hipStream_t st) {
     const int Mp = round_up(M, NB);
-    if (Mp > 128 || getenv("IWVI_NATGRAD_UNFUSED")) return 0;
+    if (Mp > 128 || dbg_opt("IWVI_NATGRAD_UNFUSED")) return 0;
     const size_t lds = sizeof(double) * ((size_t)Mp + ws_layout(Mp).total + 4 * (size_t)Mp + 16 * 128);
     int rc;
     if ((rc = ensure_lds_attr((const void*)k_natgrad_small, lds)) != IWVI_OK) return rc;
-    hipLaunchKernelGGL(k_natgrad_small, dim3(R), dim3(1024), lds, st, q_mu, q_sqrt, dq_mu, dq_sqrt, M, R, gamma, getenv("IWVI_NG_STOP") ? atoi(getenv("IWVI_NG_STOP")) : 0);
+    hipLaunchKernelGGL(k_natgrad_small, dim3(R), dim3(1024), lds, st, q_mu, q_sqrt, dq_mu, dq_sqrt, M, R, gamma, dbg_opt("IWVI_NG_STOP"));
     rc = check_launch("k_natgrad_small");
     return rc == IWVI_OK ? 1 : rc;
 }
@@ -443,9 +443,9 @@ extern "C" int iwvi_model_precompute(const iwvi_gp_desc* layers, int n_layers, c
     for (int base = 0; base < n_layers; base += IWVI_MAX_LAYERS) {
         PreArgs a{};
         a.n = n_layers - base < IWVI_MAX_LAYERS ? n_layers - base : IWVI_MAX_LAYERS;
-        { const char* e = getenv("IWVI_DEBUG_STOP"); a.stop_after = e ? atoi(e) : 0; }
+        a.stop_after = dbg_opt("IWVI_DEBUG_STOP");
         a.stamps = g_pre_stamps;
-        { const char* e = g_pre_stamps ? getenv("IWVI_PRE_STAMP_P") : nullptr; a.stamp_p = e ? atoi(e) : 1; }
+        a.stamp_p = (g_pre_stamps && dbg_opt("IWVI_PRE_STAMP_P")) ? dbg_opt("IWVI_PRE_STAMP_P") : 1;
         size_t lds = 1024 * sizeof(double);
         int max_roles = 0;
         for (int l = 0; l < a.n; ++l) {

@@ -113,6 +113,7 @@ class GPLayer:
         d.M, d.D, d.R, d.P = M, D, R, P
         d.kern_type, d.mf_type = kern.kern_type, mf.mf_type
         d.variance, d.variance_dev = kern.desc_variance()
+        d.flags = _abi.LAYER_F32_STAGE2 if settings.fw_f32_stage2 else 0
         keep = [W]
         if W is not None:
             d.W = W.data_ptr()

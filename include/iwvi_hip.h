@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define IWVI_ABI_VERSION 12
+#define IWVI_ABI_VERSION 13
 
 enum {
     IWVI_OK = 0,
@@ -239,7 +239,14 @@ typedef struct iwvi_layer_desc {
     float* gmv_out;                 /* GP, optional: [T, 3R] = (sample | mean | variance) of the R latent GPs before mixing */
     const float* variance_dev;      /* GP, optional device scalar read instead of `variance` (see iwvi_gp_desc) */
     int32_t enc_act;                /* LV: IWVI_ACT_* of the encoder's hidden layers (0 = tanh) */
+    int32_t flags;                  /* GP: IWVI_LAYER_* bits below (0 = the default arithmetic) */
 } iwvi_layer_desc;
+/* Arithmetic of the R * M^2 contraction u_r = tril(q_sqrt_r)^T a (temp_workaround.py:78) and of mean = q_mu^T a (:68), per CALL
+ * (no process-wide mode: two threads may differ).  Default: split-f16 operands (x = h1 + h2, three v_mfma_f32_16x16x32_f16 per slab,
+ * fp32 accumulate, per-matrix power-of-two scales; 22 operand mantissa bits -- DESIGN.md section 4) whenever every GP layer of the
+ * launch has an even number of 16-row blocks.  IWVI_LAYER_F32_STAGE2 on ANY GP layer of a launch makes the whole launch take the
+ * fp32-MFMA variant (v_mfma_f32_16x16x4_f32). */
+#define IWVI_LAYER_F32_STAGE2 1
 
 /* Optional tail of the same launch: the last workgroup to finish performs models.py:138-150 on out_logw
  * (logsumexp over K minus log K, or the mean over S of :84; sum over points * scale; minus the global KLs),
@@ -332,7 +339,10 @@ typedef struct iwvi_gp_bwd_desc {
                                      * workspace.  The caller orders 2 after 1 and may queue other work in between (so that, in a
                                      * captured graph, the next layer's chain follows this one's on the same hardware queue).
                                      * Shapes off the streaming chain do everything in phase 1; phase 2 is then a no-op. */
+    int32_t flags;                  /* IWVI_BW_* bits below (0 = the default arithmetic) */
 } iwvi_gp_bwd_desc;
+/* IWVI_BW_F32_CHAIN: the adjoint chain's S_r products on fp32 MFMAs instead of split-f16 operands (per call, like IWVI_LAYER_F32_STAGE2). */
+#define IWVI_BW_F32_CHAIN 1
 size_t iwvi_gp_layer_backward_ws_bytes(int64_t T, int M, int D, int R);
 /* 1 if the adjoint of this layer shape takes the GEMM path and therefore needs the forward's u_out, 0 if the streaming chain
  * (which works from a_out alone) will run */
@@ -516,6 +526,11 @@ int iwvi_fill_normal(float* out, int64_t n, uint64_t seed, uint64_t offset, void
  * by ceil(n/4) by its last block), state[1] = internal ticket; zero both once. Lets a captured hipGraph
  * draw fresh noise on every replay. */
 int iwvi_fill_normal_dev(float* out, int64_t n, uint64_t seed, uint64_t* state, void* stream);
+
+/* Diagnostic / development route switches (NOT part of the drop-in surface, like iwvi_debug_set_stamps): the library itself never reads
+ * the environment.  name = one of the IWVI_* route names listed in csrc/abi.hip (e.g. "IWVI_BW_UNFUSED", "IWVI_NATGRAD_UNFUSED"),
+ * value 0 = default route.  Returns 0, or IWVI_ERR_ARG for an unknown name.  Process-wide; not for concurrent use with launches. */
+int iwvi_debug_set_option(const char* name, int value);
 
 #ifdef __cplusplus
 }

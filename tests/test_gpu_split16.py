@@ -1,10 +1,8 @@
 """Stage 2 of the layer kernel on split-f16 operands (iwvi_common.h: s16_*; x = h1 + h2, three v_mfma_f32_16x16x32_f16 per 16 x 32
-slab) against the fp32-MFMA stage 2 (IWVI_FW_F32_STAGE2=1) and the float64 oracle: same accuracy, across operand scales that would
+slab) against the fp32-MFMA stage 2 (iwvi_layer_desc.flags & IWVI_LAYER_F32_STAGE2, per call: ``settings.fw_f32_stage2``) and the float64 oracle: same accuracy, across operand scales that would
 leave f16's range without the per-matrix power-of-two scaling.  (Stage 1's off-diagonal updates are split f16 in BOTH variants for an
 even block count <= 8 -- csrc/dgp_forward.hip: split_b16 -- so for that part the float64 oracle is the reference here, at kernel variances
 from 1e-6 to 1e4 times the spec's.)"""
-import os
-
 import numpy as np
 import pytest
 import torch
@@ -15,13 +13,13 @@ pytestmark = pytest.mark.gpu
 
 
 def _run(model, zd, f32):
-    if f32:
-        os.environ["IWVI_FW_F32_STAGE2"] = "1"
+    from dgps_with_iwvi_amd import settings
+    old, settings.fw_f32_stage2 = settings.fw_f32_stage2, bool(f32)      # a descriptor flag of each call, not a process-wide mode
     try:
         fmean, fvar, _, _, samples, means, covs = model._forward_iw(zd)
         elbo = float(model.compute_log_likelihood(zd))
     finally:
-        os.environ.pop("IWVI_FW_F32_STAGE2", None)
+        settings.fw_f32_stage2 = old
     torch.cuda.synchronize()
     return elbo, [m.double().cpu().numpy() for m in means], [c.double().cpu().numpy() for c in covs]
 
@@ -56,10 +54,11 @@ def test_an_odd_block_count_takes_the_fp32_stage2(gpu_device):
     zs = synthetic.make_noise(spec, seed=4)
     zd = [torch.as_tensor(z, dtype=torch.float32, device=gpu_device) for z in zs]
     model = synthetic.build_model(spec, gpu_device)
+    from dgps_with_iwvi_amd import settings
     a = float(model.compute_log_likelihood(zd))
-    os.environ["IWVI_FW_F32_STAGE2"] = "1"
+    old, settings.fw_f32_stage2 = settings.fw_f32_stage2, True
     try:
         b = float(model.compute_log_likelihood(zd))
     finally:
-        os.environ.pop("IWVI_FW_F32_STAGE2", None)
+        settings.fw_f32_stage2 = old
     assert a == b

@@ -37,12 +37,12 @@ def test_natgrad_step_matches_oracle(gpu_device, M, R):
     assert float(torch.triu(d_sqrt, 1).abs().max()) == 0.0
     if M <= 128:                                                 # the multi-launch path (kept for M > 128) on the same inputs
         e_mu, e_sqrt = _t(q_mu, gpu_device), _t(q_sqrt, gpu_device)
-        os.environ["IWVI_NATGRAD_UNFUSED"] = "1"
+        _abi.set_debug_option("IWVI_NATGRAD_UNFUSED", 1)         # (a route switch of the library: iwvi_debug_set_option, not the environment)
         try:
             _abi.check(_abi.lib().iwvi_natgrad_step(_abi.ptr(e_mu), _abi.ptr(e_sqrt), _abi.ptr(dg_mu), _abi.ptr(dg_sqrt), M, R, 0.05,
                                                    ws.data_ptr(), _abi.stream_ptr()))
         finally:
-            del os.environ["IWVI_NATGRAD_UNFUSED"]
+            _abi.set_debug_option("IWVI_NATGRAD_UNFUSED", 0)
         np.testing.assert_allclose(e_mu.cpu().numpy(), d_mu.cpu().numpy(), rtol=2e-6, atol=2e-7)
         np.testing.assert_allclose(e_sqrt.cpu().numpy(), d_sqrt.cpu().numpy(), rtol=2e-6, atol=2e-7)
 
