@@ -37,12 +37,33 @@ CONFIGS = {   # BASELINE.json configs[1..4]
     4: dict(L=5, M=512, K=100, B=8192, with_lv=False),
 }
 PEAK_MFMA_F32 = 157.3e12     # MI355X_MICROARCH.md: dense f32-input MFMA peak
+PEAK_MFMA_F16 = 2.5e15       # dense f16-input MFMA peak (never the 2:1-sparsity figure)
+PEAK_HBM = 8.0e12            # bytes / s
 
 
 def f_alg_layer(M, D, R, P):
     """Algorithmic FLOPs per sample of one GP layer: Gram + triangular
     Lm^-1 k + R triangular L_r^T a + mean + reductions + mixing/mean function."""
     return (2 * M * D + 3 * M) + M * M + R * M * M + 2 * M * R + (2 * M + 2 * R * M) + 6 * R * P + 2 * D * P
+
+
+def f_alg_split(spec, f32_stage2=False):
+    """The same algorithmic FLOPs per sample split by the matrix instruction that executes them: (fp32-MFMA part, split-f16 part).
+    Split-f16 (x = h1 + h2; csrc/dgp_forward.hip): stage 2 (R M^2 + 2 M R) when EVERY GP layer has an even number of 16-row blocks,
+    and the off-diagonal updates of stage 1 (M^2 - 16 M) of a layer with an even block count <= 8.  A split-f16 product costs three
+    f16 MFMA FLOPs per algorithmic FLOP, so its ceiling is PEAK_MFMA_F16 / 3."""
+    gps = [l for l in spec["layers"] if l["type"] == "gp"]
+    nbks = [(l["Z"].shape[0] + 15) // 16 for l in gps]
+    s16_all = (not f32_stage2) and all(n % 2 == 0 for n in nbks)
+    tot, _ = f_alg_model(spec)
+    f16 = 0.0
+    for l, nbk in zip(gps, nbks):
+        M, R = l["Z"].shape[0], l["q_mu"].shape[1]
+        if s16_all:
+            f16 += R * M * M + 2 * M * R
+        if nbk % 2 == 0 and nbk <= 8:
+            f16 += M * M - 16 * M
+    return tot - f16, f16
 
 
 def f_alg_model(spec):
@@ -158,6 +179,31 @@ def cpu_baseline(spec, seconds=12.0, dtype=torch.float64):
                        "covariance), %d threads of %d, median" % (iters, spec["B"], spec["K"],
                                                                   "float64" if dtype == torch.float64 else "float32", nt, ncpu),
                 ms_per_step=med * 1e3)
+
+
+def roofline_object(achieved, flops, launch_ms, spec, traffic, traffic_src, pmc):
+    from dgps_with_iwvi_amd import settings
+    f32p, f16p = f_alg_split(spec, settings.fw_f32_stage2)
+    mix_peak = (f32p + f16p) / (f32p / PEAK_MFMA_F32 + f16p / (PEAK_MFMA_F16 / 3.0))
+    hbm_frac = None if traffic is None else traffic / (launch_ms * 1e-3) / PEAK_HBM
+    busy = pmc.get("mfma_busy_frac")
+    if busy is None:
+        bound, why = "mfma", "no counters for this workload: the kernel's arithmetic is matrix products"
+    elif busy >= 0.5:
+        bound, why = "mfma", "matrix pipe busy %.2f of the kernel" % busy
+    elif hbm_frac is not None and hbm_frac >= 0.5:
+        bound, why = "hbm", "HBM traffic at %.2f of peak" % hbm_frac
+    else:
+        bound, why = "latency/issue", ("matrix pipe busy %.2f of the kernel, HBM at %.3f of peak: dependent chains (triangular solves), barriers and "
+                                       "launch / drain, not a throughput limit" % (busy, hbm_frac or 0.0))
+    return {"bound": bound, "bound_from": why,
+            "kernel": "k_dgp_forward (all layers fused, one launch per ELBO evaluation)",
+            "achieved": achieved / 1e12, "peak": mix_peak / 1e12, "unit": "TFLOP/s", "frac": achieved / mix_peak,
+            "peak_basis": "instruction mix: %.0f%% of the algorithmic FLOPs on fp32 MFMAs (157.3 TF), %.0f%% as split f16 (2.5 PF / 3)" % (
+                100 * f32p / (f32p + f16p), 100 * f16p / (f32p + f16p)),
+            "frac_fp32_equivalent": achieved / PEAK_MFMA_F32,
+            "traffic": traffic, "traffic_source": traffic_src, "hbm_frac": hbm_frac, "launch_ms": launch_ms,
+            "flops_per_launch": flops, **pmc}
 
 
 def main():
@@ -392,6 +438,35 @@ def main():
     dom_ms = float(np.median([a.elapsed_time(b) for a, b in evs])) / NREP
     achieved = dom_flops / (dom_ms * 1e-3)
 
+    # ---- the same evaluation with the fp32-MFMA stage 2 (iwvi_layer_desc.flags & IWVI_LAYER_F32_STAGE2: a per-call flag), so that the
+    #      pure-fp32 figure is observed in the same run, next to the split-f16 default
+    fp32_path = None
+    if world == 1 and not settings.fw_f32_stage2:
+        settings.fw_f32_stage2 = True
+        try:
+            s4 = torch.cuda.Stream(device=dev)
+            s4.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s4):
+                model._build_likelihood()
+                g4 = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g4, stream=s4, capture_error_mode="thread_local"):
+                    for _ in range(10):
+                        keep4 = model._build_likelihood()
+            torch.cuda.current_stream().wait_stream(s4)
+            torch.cuda.synchronize()
+            g4.replay()
+            torch.cuda.synchronize()
+            t4 = time.perf_counter()
+            for _ in range(max(2, args.steps // 10)):
+                g4.replay()
+            torch.cuda.synchronize()
+            ms4 = (time.perf_counter() - t4) / (max(2, args.steps // 10) * 10) * 1e3
+            fp32_path = {"ms_per_step": ms4, "samples_per_s": B * K / ms4 * 1e3,
+                         "model_frac_of_fp32_mfma_peak": B * K / ms4 * 1e3 * tot_flops / PEAK_MFMA_F32,
+                         "how": "IWVI_LAYER_F32_STAGE2 on every GP layer (v_mfma_f32_16x16x4_f32 in stage 2), hipGraph of 10 evaluations"}
+        finally:
+            settings.fw_f32_stage2 = False
+
     # HBM bytes per launch of the dominant kernel from the committed PMC profile of this very workload (the counters
     # need their own rocprofv3 passes and cannot be read live); null for any other workload
     traffic, traffic_src, pmc = None, None, {}
@@ -399,7 +474,8 @@ def main():
         tj = json.load(open(os.path.join(ROOT, "profiles", "traffic_latest.json")))
         if args.config == 2 and world == 1:
             traffic, traffic_src = tj["hbm_bytes"], tj["source"]
-            pmc = {k: tj[k] for k in ("mfma_busy_frac", "mfma_issued_tflops", "kernel_avg_us_rocprof") if k in tj}
+            pmc = {k: tj[k] for k in ("mfma_busy_frac", "mfma_issued_f32_tflops", "mfma_issued_f16_tflops", "mfma_pipe_frac",
+                                      "kernel_avg_us_rocprof", "pmc_profile_of_commit") if k in tj}
     except Exception:
         pass
     if rank == 0:
@@ -408,12 +484,12 @@ def main():
             "metric": "IW-ELBO samples/sec (KxN) at L=2, M=128, K=20",
             "value": total / elapsed, "unit": "samples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32" if settings.fw_f32_stage2 else "f32 (split-f16 operands in stage 2)", "data": "synthetic",
             # what "f32" means on this path: float32 data and accumulation, float64 factorisation (K_uu, Cholesky); the operands of
             # stage 2 (u_r = L_r^T a, mean = q_mu^T a) enter the matrix cores as x = h1 + h2, two f16 planes = 22 mantissa bits, with
             # power-of-two scales -- as accurate as the fp32 MFMA it replaces (tests/test_gpu_split16.py; IWVI_FW_F32_STAGE2=1 switches back)
             "dtype_note": ("fp32 data and accumulate, fp64 factorisation; stage-2 matrix operands as split f16 (h1 + h2, 22 mantissa bits) "
-                           "unless IWVI_FW_F32_STAGE2=1" if not os.environ.get("IWVI_FW_F32_STAGE2") else "fp32 MFMA stage 2 (IWVI_FW_F32_STAGE2=1)"),
+                           "unless IWVI_LAYER_F32_STAGE2 is set on a layer (see fp32_path)" if not settings.fw_f32_stage2 else "fp32 MFMA stage 2 (IWVI_LAYER_F32_STAGE2)"),
             "config": {"workload": "BASELINE.json configs[%d]: %s; Dx=8, Dy=1, inner layers G5 (R=5, P=8), RBF-ARD, "
                                    "per-step Gram+Cholesky included, noise drawn on device" % (args.config, spec["name"]),
                        "global_batch": B * (world if args.shard == "n" else 1),
@@ -423,15 +499,18 @@ def main():
             "elbo": final_elbo,
             "n_ranks_seen": (dist.get_world_size() if dist is not None else 1),
             "host_enqueue_ms_per_step": t_enqueued / args.steps * 1e3,
-            # (achieved = algorithmic fp32-equivalent FLOP / s; peak = the fp32-MFMA peak, as for the path's dtype.  Stage 2 issues its
-            #  products as three f16 MFMAs per eight fp32 ones, so at M >= 256, where stage 2 dominates, frac can pass 1: the path then beats
-            #  what any pure-fp32-MFMA kernel could do -- it is not a claim about the f16 peak, 2.5 PFLOP/s.)
-            "roofline": {"bound": "mfma", "kernel": "k_dgp_forward (all layers fused, one launch per ELBO evaluation)", "achieved": achieved / 1e12,
-                         "peak": PEAK_MFMA_F32 / 1e12, "unit": "TFLOP/s", "frac": achieved / PEAK_MFMA_F32,
-                         "traffic": traffic, "traffic_source": traffic_src, "launch_ms": dom_ms,
-                         "flops_per_launch": dom_flops, **pmc},
+            # achieved = algorithmic FLOP / s of the dominant kernel.  peak = the ceiling of THIS instruction mix: the fp32-MFMA part of the
+            # algorithm at the fp32-MFMA peak, the split-f16 part (three f16 MFMA FLOPs per algorithmic FLOP) at a third of the f16 peak --
+            # so frac <= 1 whatever the shape.  frac_fp32_equivalent (algorithmic / fp32-MFMA peak) is last round's number; it passes 1
+            # where stage 2 dominates (M >= 256) and is kept only for comparison.  bound: from the counters of the committed profile.
+            "roofline": roofline_object(achieved, dom_flops, dom_ms, spec, traffic, traffic_src, pmc),
         }
-        res["model_frac_of_mfma_peak"] = res["value"] / world * tot_flops / PEAK_MFMA_F32
+        f32p, f16p = f_alg_split(spec, settings.fw_f32_stage2)
+        mix_peak = (f32p + f16p) / (f32p / PEAK_MFMA_F32 + f16p / (PEAK_MFMA_F16 / 3.0))
+        res["model_frac_of_mfma_peak"] = res["value"] / world * tot_flops / mix_peak          # the WHOLE step (both launches) against the mix ceiling
+        res["model_frac_of_fp32_mfma_peak"] = res["value"] / world * tot_flops / PEAK_MFMA_F32
+        if fp32_path is not None:
+            res["fp32_path"] = fp32_path
         if med is not None:
             res.update({"ms_per_step_median": med["ms_per_step_median"], "median_protocol": med})
         if check is not None:
