@@ -86,10 +86,11 @@ class Step:
     Noise is drawn inside the forward kernel from its counter-based stream; the step counter lives on the
     device and is advanced by the launch itself, so every graph replay sees fresh noise."""
 
-    def __init__(self, model, spec, dev, shard, world, exchange=None):
+    def __init__(self, model, spec, dev, shard, world, exchange=None, K_total=None):
         self.model, self.dev, self.shard, self.world = model, dev, shard, world
         self.exchange = (world > 1) if exchange is None else exchange
         self.B, self.K = spec["B"], spec["K"]
+        self.K_total = K_total if K_total is not None else self.K * self.world
         self.out = torch.zeros(1, dtype=torch.float64, device=dev)
 
     def run(self, out=None, zs=None):
@@ -97,7 +98,7 @@ class Step:
         ``zs``: injected noise (the --check leg), None = drawn on the device."""
         m = self.model
         if self.shard == "k" and self.exchange:
-            self.ms, self.glob = m.lse_partials(zs, K_total=self.K * self.world, out=out)
+            self.ms, self.glob = m.lse_partials(zs, K_total=self.K_total, out=out)
             return self.ms
         self.out = m._build_likelihood(zs, out=out)
         return self.out
@@ -213,6 +214,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS))
     ap.add_argument("--shard", choices=["k", "n"], default="k")
+    ap.add_argument("--split-k", action="store_true",
+                    help="strong scaling of the K-shard: the CONFIG's K importance samples are divided over the ranks "
+                         "(sharding.split_samples: 50 over 8 -> 7,7,6,6,6,6,6,6 -- BASELINE.json configs[3]/[4] 'K-sharded across 8') "
+                         "instead of every rank drawing K of its own (weak scaling, the default)")
+    ap.add_argument("--batch", type=int, default=None, help="override the config's minibatch size (plumbing tests; not a BASELINE workload)")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -249,17 +255,26 @@ def main():
     _abi.lib()                                                   # fail loudly if the extension is missing
     if world > 1:
         settings.set_seed(settings.seed + 7919 * rank)           # every rank its own Philox key: the job's K_total samples are distinct
-    cfg = CONFIGS[args.config]
+    cfg = dict(CONFIGS[args.config])
+    if args.batch:
+        cfg["B"] = int(args.batch)
+    if args.split_k and args.shard != "k":
+        raise SystemExit("--split-k divides the importance samples: it needs --shard k")
+    from dgps_with_iwvi_amd.sharding import split_samples
+    # importance samples of THIS rank / of the job: weak K-shard: K each, K * world in all; --split-k: the config's K divided
+    K_parts = split_samples(cfg["K"], world) if args.split_k else [cfg["K"]] * world
+    K_local = K_parts[rank]
+    K_job = cfg["K"] if (args.split_k or args.shard != "k") else cfg["K"] * world
     # parity=True: random q_mu / dense lower-triangular q_sqrt (a trained-like state).  The reference's
     # initial values (q_mu = 0, q_sqrt = 1e-5 I) would feed the MFMAs mostly zeros and flatter the clock.
     spec = synthetic.make_spec(seed=0, parity=True, n_data=65536, **cfg)
     if args.shard == "n" and world > 1:                          # each rank owns different points
         lo = (rank * cfg["B"]) % (spec["n_data"] - cfg["B"] + 1)
         spec = dict(spec, X=spec["X"][lo:], Y=spec["Y"][lo:])
-    model = synthetic.build_model(spec, dev)
+    model = synthetic.build_model(spec, dev, num_samples=K_local)
     model.lv_in_precompute = os.environ.get("IWVI_BENCH_LV_PRE", "0") == "1"   # leading LV layer inside the precompute launch
-    step = Step(model, spec, dev, args.shard, world, exchange=(world > 1 or force_xch))
-    B, K = cfg["B"], cfg["K"]
+    step = Step(model, spec, dev, args.shard, world, exchange=(world > 1 or force_xch), K_total=K_job)
+    B, K = cfg["B"], K_local
     # ---- capture -----------------------------------------------------------------------------
     # steps per graph replay: every step is the complete evaluation (fresh noise from the device counter); several
     # per replay only spares the host-side launch between them.  Multi-GPU runs exchange the replay's evaluations in
@@ -275,7 +290,7 @@ def main():
     if world > 1 or force_xch:
         # multi-GPU: the evaluations of one graph replay are exchanged in one collective on a side stream
         from dgps_with_iwvi_amd.sharding import OverlappedExchange
-        xch = OverlappedExchange(args.shard, world, B, K * world, float(spec["n_data"]) / B, dev, steps=spg)
+        xch = OverlappedExchange(args.shard, world, B, K_job, float(spec["n_data"]) / B, dev, steps=spg)
     graph = None
     step.run()
     torch.cuda.synchronize()
@@ -354,12 +369,13 @@ def main():
     # ---- --check: the sharded path against the unsharded job on injected noise (multi-rank correctness, no timing) ----------
     check = None
     if args.check:
-        Kt = K * (world if args.shard == "k" else 1)
+        Kt = K_job
         Bt = B * (world if args.shard == "n" else 1)
         job_spec = synthetic.make_spec(seed=0, parity=True, n_data=65536, **dict(cfg, K=Kt, B=Bt))
         zjob = synthetic.make_noise(job_spec, seed=123, K=Kt, B=Bt)
         if args.shard == "k":
-            zloc = [z[:, rank * K:(rank + 1) * K] for z in zjob]
+            k0 = sum(K_parts[:rank])
+            zloc = [z[:, k0:k0 + K_local] for z in zjob]
         else:
             zloc = [z[rank * B:(rank + 1) * B] for z in zjob]
         zloc = [torch.as_tensor(np.ascontiguousarray(z), dtype=torch.float32, device=dev) for z in zloc]
@@ -479,22 +495,23 @@ def main():
     except Exception:
         pass
     if rank == 0:
-        total = float(B) * K * world * args.steps
+        total = float(B) * (K_job if args.shard == "k" else K * world) * args.steps      # the job's samples per step x steps
         res = {
             "metric": "IW-ELBO samples/sec (KxN) at L=2, M=128, K=20",
             "value": total / elapsed, "unit": "samples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32" if settings.fw_f32_stage2 else "f32 (split-f16 operands in stage 2)", "data": "synthetic",
+            "scaling": "strong" if args.split_k else "weak", "vs_baseline": None, "dtype": "f32" if settings.fw_f32_stage2 else "f32 (split-f16 operands in stage 2)", "data": "synthetic",
             # what "f32" means on this path: float32 data and accumulation, float64 factorisation (K_uu, Cholesky); the operands of
             # stage 2 (u_r = L_r^T a, mean = q_mu^T a) enter the matrix cores as x = h1 + h2, two f16 planes = 22 mantissa bits, with
             # power-of-two scales -- as accurate as the fp32 MFMA it replaces (tests/test_gpu_split16.py; IWVI_FW_F32_STAGE2=1 switches back)
             "dtype_note": ("fp32 data and accumulate, fp64 factorisation; stage-2 matrix operands as split f16 (h1 + h2, 22 mantissa bits) "
                            "unless IWVI_LAYER_F32_STAGE2 is set on a layer (see fp32_path)" if not settings.fw_f32_stage2 else "fp32 MFMA stage 2 (IWVI_LAYER_F32_STAGE2)"),
             "config": {"workload": "BASELINE.json configs[%d]: %s; Dx=8, Dy=1, inner layers G5 (R=5, P=8), RBF-ARD, "
-                                   "per-step Gram+Cholesky included, noise drawn on device" % (args.config, spec["name"]),
+                                   "per-step Gram+Cholesky included, noise drawn on device%s" % (
+                                       args.config, spec["name"], "" if not args.batch else " -- batch overridden (--batch %d): a plumbing run, not the BASELINE workload" % args.batch),
                        "global_batch": B * (world if args.shard == "n" else 1),
-                       "K_total": K * (world if args.shard == "k" else 1),
-                       "sharding": ("none" if world == 1 else args.shard + "-shard"),
+                       "K_total": K_job, "K_per_rank": K_parts,
+                       "sharding": ("none" if world == 1 else args.shard + "-shard" + (" (the config's K split over the ranks)" if args.split_k else "")),
                        "launch": "eager" if graph is None else ("hipGraph replay, %d steps per replay" % spg) + ("" if xch is None else ", one exchange per replay")},
             "elbo": final_elbo,
             "n_ranks_seen": (dist.get_world_size() if dist is not None else 1),
