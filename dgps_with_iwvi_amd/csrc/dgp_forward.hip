@@ -603,7 +603,7 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
                     int l = 0;
                     while (j >= z.pack_off[l + 1]) ++l;
                     const PreLayer Lc = z.P[l];
-                    role_pack_r<true>(Lc, j - z.pack_off[l], reinterpret_cast<double*>(fw_smem));
+                    role_pack_r<true>(Lc, j - z.pack_off[l], reinterpret_cast<double*>(fw_smem), g.stamps ? g.stamps + (size_t)blockIdx.x * 128 + 30 : nullptr);
                     __syncthreads();
                     ++njobs;
                 }

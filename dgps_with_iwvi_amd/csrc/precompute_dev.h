@@ -32,6 +32,10 @@ template <bool WT>
 __device__ __forceinline__ void st_pub(float* p, float v) {
     if constexpr (WT) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else *p = v;
 }
+// eight f16 values as one 16-byte vector IN REGISTERS (an _Float16 array read back through reinterpret_cast lives in scratch memory: the
+// pack role's split-f16 image loop was two scratch round trips per vector -- 8.5 of its 24 us at 512 threads)
+typedef _Float16 pk_f16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ float4 as_f4(const pk_f16x8 h) { return __builtin_bit_cast(float4, h); }
 template <bool WT>
 __device__ __forceinline__ void st_pub4(float4* p, const float4 v) {
     if constexpr (WT) {
@@ -579,10 +583,10 @@ __device__ __forceinline__ void role_factor(const PreLayer& Lin, int stop_after,
             if (st1_16) {                                        // split-f16 solve (iwvi_common.h: IWVI_CST_U): Dinv times 1/U, the other
                 if (b == 0) { o.x *= st1_iu; o.y *= st1_iu; o.z *= st1_iu; o.w *= st1_iu; }   // blocks as [h1 x 4 | h2 x 4] of 2^est (-L(bi, bj))
                 else {
-                    _Float16 h[8];
+                    pk_f16x8 h;
 #pragma unroll
-                    for (int sgm = 0; sgm < 4; ++sgm) { const float x = v[sgm] * st1_sc; h[sgm] = (_Float16)x; h[4 + sgm] = (_Float16)(x - (float)h[sgm]); }
-                    o = *reinterpret_cast<const float4*>(h);
+                    for (int sgm = 0; sgm < 4; ++sgm) { const float x = v[sgm] * st1_sc; const _Float16 hh = (_Float16)x; h[sgm] = hh; h[4 + sgm] = (_Float16)(x - (float)hh); }
+                    o = as_f4(h);
                 }
             }
             st_pub4<FZ>(dst + it, o);
@@ -690,8 +694,142 @@ __device__ __forceinline__ double block_sum_vt(double* red) {
 //   kl[r] = 1/2 (|q_mu[:,r]|^2 - M - sum log L_ii^2 + |tril L|^2).
 // One float4 of the packed image per thread-iteration, one 16-byte store.  The KL share is accumulated by PACK_VT virtual threads
 // (a workgroup of fewer threads plays several of them in turn), so its rounding does not depend on the launch geometry.
+#define PACK_STAMP(k) do { if (st && threadIdx.x == 0) st[k] = wall_clock64(); } while (0)
+// the role's work on q_sqrt[r] read through `q`: an LDS pointer when the matrix was staged (Mp <= 128), a global one otherwise -- a pointer
+// that could be either makes every access a FLAT load with a full wait behind it (the role's loops were chains of those)
+template <bool WT, class QP>
+__device__ __forceinline__ void role_pack_body(const PreLayer& L, int r, double* red, const QP q, const bool lg_in_lds, unsigned long long* st) {
+    const int nbk = L.nbk, M = L.M, R = L.R;
+    PACK_STAMP(1);
+    float4* dstm = reinterpret_cast<float4*>(L.LrTP + (size_t)r * tri_blocks(nbk) * BLK16);
+    const int nvec = nbk * nbk * 64;
+    // log L_ii^2 of the M diagonal entries, one per thread, up front: inside the accumulation loop below four lanes of a wave reach a
+    // diagonal entry at a time and the whole wave then runs the float64 log four times over (5 us of the role).  Same values, subtracted
+    // at the same point of the same accumulator: the KL share is unchanged bit for bit.
+    double* lg = red + PACK_VT + (lg_in_lds ? (M * M + 1) / 2 : 0);        // behind the staged q_sqrt (doubles)
+    const bool lg_ok = lg_in_lds;
+    if (lg_ok) {
+        for (int i = threadIdx.x; i < M; i += blockDim.x) { const double x = (double)q[(size_t)i * M + i]; lg[i] = log(x * x); }
+        __syncthreads();
+    }
+    for (int vt = threadIdx.x; vt < PACK_VT; vt += blockDim.x) {
+    double acc = 0.0;
+    for (int v4 = vt; v4 < nvec; v4 += PACK_VT) {
+        const int b = v4 >> 6, bi = b / nbk, bk = b - bi * nbk;
+        if (bi > bk) continue;
+        const int lane = v4 & 63;
+        const int i = 16 * bi + (lane & 15);
+        const int k0 = 16 * bk + 4 * (lane >> 4);
+        float o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int k = k0 + e;                      // (L_r^T)[i][k] = L_r[k][i], non-zero for k >= i
+            float x = 0.f;
+            if (i < M && k < M && k >= i) x = q[(size_t)k * M + i];
+            o[e] = x;
+            acc += (double)x * (double)x;
+            if (k == i && i < M) acc -= lg_ok ? lg[i] : log((double)x * (double)x);
+        }
+        st_pub4<WT>(dstm + (size_t)(tri_upper_off(nbk, bi) + (bk - bi)) * 64 + lane, make_float4(o[0], o[1], o[2], o[3]));
+    }
+    for (int m = vt; m < M; m += PACK_VT) {
+        const double v = L.q_mu[(size_t)m * R + r];
+        acc += v * v;
+    }
+    red[vt] = acc;
+    }
+    if (r == 0) {
+        // q_mu^T as MFMA A blocks [nrb][nbk]: row = latent GP (padded to 16), k = inducing point
+        float4* dq = reinterpret_cast<float4*>(L.QmuP);
+        for (int v4 = threadIdx.x; v4 < L.nrb * nbk * 64; v4 += blockDim.x) {
+            const int b = v4 >> 6, rb = b / nbk, bk = b - rb * nbk, lane = v4 & 63;
+            const int rr = 16 * rb + (lane & 15), k0 = 16 * bk + 4 * (lane >> 4);
+            float o[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (rr < R && k0 + e < M) ? L.q_mu[(size_t)(k0 + e) * R + rr] : 0.f;
+            st_pub4<WT>(dq + v4, make_float4(o[0], o[1], o[2], o[3]));
+        }
+    }
+    PACK_STAMP(2);
+    const double tot = block_sum_vt(red);
+    PACK_STAMP(3);
+    if (threadIdx.x == 0) {
+        if constexpr (WT) __hip_atomic_store(L.kl + r, 0.5 * (tot - (double)M), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else L.kl[r] = 0.5 * (tot - (double)M);
+    }
+    // ---- the split-f16 image of L_r^T (and, role 1, of q_mu^T) with its power-of-two scale ----------------------------------
+    if (nbk & 1) return;
+    const float var = L.variance_dev ? *L.variance_dev : L.variance;
+    const int ea = ((L.nbk <= 8 && (L.nbk & 1) == 0) ? 7 : 10) - (int)ceilf(0.5f * log2f(fmaxf(var, 1e-30f)));   // |a| <= sigma  ->  |a| 2^ea <= 2^10 (2^7 = 2^est where stage 1 writes the planes: role_factor)
+    double mx = 0.0;                                             // (a wave per row, lanes along it: no division per element; max is order-free)
+    for (int k = threadIdx.x >> 6; k < M; k += (int)(blockDim.x >> 6))
+        for (int i = threadIdx.x & 63; i <= k; i += 64) mx = fmax(mx, fabs((double)q[(size_t)k * M + i]));
+    __syncthreads();
+    red[threadIdx.x] = mx;
+    __syncthreads();
+    for (int s_ = blockDim.x / 2; s_ > 0; s_ >>= 1) { if ((int)threadIdx.x < s_) red[threadIdx.x] = fmax(red[threadIdx.x], red[threadIdx.x + s_]); __syncthreads(); }
+    mx = red[0];
+    __syncthreads();
+    PACK_STAMP(4);
+    const int er = mx > 0.0 ? 13 - ilogb(mx) : 0;                             // max |L_r| 2^er in [2^13, 2^14)  (ilogb == floor(log2) exactly, without a float64 log in every thread)
+    const float sr = ldexpf(1.f, er);
+    if (threadIdx.x == 0) st_pub<WT>(L.cst + IWVI_CST_FR + r, ldexpf(1.f, -(ea + er)));
+    {
+        const int nst = s16_slabs_total(nbk);
+        unsigned short* dst = L.LrT16 + (size_t)r * nst * 1024;                 // 1024 halves per slab (2 planes x 512)
+        for (int v = threadIdx.x; v < nst * 64; v += blockDim.x) {            // one lane-vector (8 k) of a slab per thread-iteration
+            const int sl = v >> 6, lane = v & 63;
+            int bi = 0, o = 0;
+            while (o + s16_slabs(nbk, bi) <= sl) { o += s16_slabs(nbk, bi); ++bi; }
+            const int kc = ((bi & ~1) >> 1) + (sl - o);                       // 32-chunk of k
+            const int i = 16 * bi + (lane & 15), k0 = 32 * kc + 8 * (lane >> 4);
+            pk_f16x8 h1, h2;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int k = k0 + e;
+                float x = 0.f;
+                if (i < M && k < M && k >= i) x = q[(size_t)k * M + i] * sr;  // (L_r^T)[i][k] = L_r[k][i]
+                const _Float16 hh = (_Float16)x;
+                h1[e] = hh; h2[e] = (_Float16)(x - (float)hh);
+            }
+            // the slabs of row-blocks 2p and 2p+1 are interleaved chunk by chunk (they are multiplied as one step: same B vectors)
+            const int slp = ((bi & 1) ? o - s16_slabs(nbk, bi) : o) + 2 * (sl - o) + (bi & 1);
+            st_pub4<WT>(reinterpret_cast<float4*>(dst + (size_t)slp * 1024 + lane * 8), as_f4(h1));
+            st_pub4<WT>(reinterpret_cast<float4*>(dst + (size_t)slp * 1024 + 512 + lane * 8), as_f4(h2));
+        }
+    }
+    PACK_STAMP(5);
+    if (r == 0) {
+        double mq = 0.0;
+        for (int idx = threadIdx.x; idx < M * R; idx += blockDim.x) mq = fmax(mq, fabs((double)L.q_mu[idx]));
+        red[threadIdx.x] = mq;
+        __syncthreads();
+        for (int s_ = blockDim.x / 2; s_ > 0; s_ >>= 1) { if ((int)threadIdx.x < s_) red[threadIdx.x] = fmax(red[threadIdx.x], red[threadIdx.x + s_]); __syncthreads(); }
+        mq = red[0];
+        const int eq = mq > 0.0 ? 13 - ilogb(mq) : 0;
+        const float sq = ldexpf(1.f, eq);
+        if (threadIdx.x == 0) st_pub<WT>(L.cst + IWVI_CST_FMEAN, ldexpf(1.f, -(ea + eq)));
+        const int nkc = nbk / 2;
+        for (int v = threadIdx.x; v < L.nrb * nkc * 64; v += blockDim.x) {
+            const int sl = v >> 6, lane = v & 63, rb = sl / nkc, kc = sl - rb * nkc;
+            const int rr = 16 * rb + (lane & 15), k0 = 32 * kc + 8 * (lane >> 4);
+            pk_f16x8 h1, h2;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float x = (rr < R && k0 + e < M) ? L.q_mu[(size_t)(k0 + e) * R + rr] * sq : 0.f;
+                const _Float16 hh = (_Float16)x;
+                h1[e] = hh; h2[e] = (_Float16)(x - (float)hh);
+            }
+            st_pub4<WT>(reinterpret_cast<float4*>(L.Qmu16 + (size_t)sl * 1024 + lane * 8), as_f4(h1));
+            st_pub4<WT>(reinterpret_cast<float4*>(L.Qmu16 + (size_t)sl * 1024 + 512 + lane * 8), as_f4(h2));
+        }
+    }
+}
+
+
 template <bool WT = false>        // WT: write-through stores (merged launch: the images are read by other workgroups of the SAME launch)
-__device__ __forceinline__ void role_pack_r(const PreLayer& L, int r, double* red) {
+__device__ __forceinline__ void role_pack_r(const PreLayer& L, int r, double* red, unsigned long long* st = nullptr) {
+    PACK_STAMP(0);
     const int nbk = L.nbk, M = L.M, R = L.R;
     const float* q = L.q_sqrt + (size_t)r * M * M;
     if (L.Mp <= 128) {
@@ -715,118 +853,13 @@ __device__ __forceinline__ void role_pack_r(const PreLayer& L, int r, double* re
             for (int i = threadIdx.x; i < n; i += blockDim.x) qs[i] = q[i];
         }
         __syncthreads();
-        q = qs;
+        typedef const __attribute__((address_space(3))) float* lds_cf;
+        role_pack_body<WT>(L, r, red, (lds_cf)qs, true, st);
+        return;
     }
-    float4* dstm = reinterpret_cast<float4*>(L.LrTP + (size_t)r * tri_blocks(nbk) * BLK16);
-    const int nvec = nbk * nbk * 64;
-    for (int vt = threadIdx.x; vt < PACK_VT; vt += blockDim.x) {
-    double acc = 0.0;
-    for (int v4 = vt; v4 < nvec; v4 += PACK_VT) {
-        const int b = v4 >> 6, bi = b / nbk, bk = b - bi * nbk;
-        if (bi > bk) continue;
-        const int lane = v4 & 63;
-        const int i = 16 * bi + (lane & 15);
-        const int k0 = 16 * bk + 4 * (lane >> 4);
-        float o[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int k = k0 + e;                      // (L_r^T)[i][k] = L_r[k][i], non-zero for k >= i
-            float x = 0.f;
-            if (i < M && k < M && k >= i) x = q[(size_t)k * M + i];
-            o[e] = x;
-            acc += (double)x * (double)x;
-            if (k == i && i < M) acc -= log((double)x * (double)x);
-        }
-        st_pub4<WT>(dstm + (size_t)(tri_upper_off(nbk, bi) + (bk - bi)) * 64 + lane, make_float4(o[0], o[1], o[2], o[3]));
-    }
-    for (int m = vt; m < M; m += PACK_VT) {
-        const double v = L.q_mu[(size_t)m * R + r];
-        acc += v * v;
-    }
-    red[vt] = acc;
-    }
-    if (r == 0) {
-        // q_mu^T as MFMA A blocks [nrb][nbk]: row = latent GP (padded to 16), k = inducing point
-        float4* dq = reinterpret_cast<float4*>(L.QmuP);
-        for (int v4 = threadIdx.x; v4 < L.nrb * nbk * 64; v4 += blockDim.x) {
-            const int b = v4 >> 6, rb = b / nbk, bk = b - rb * nbk, lane = v4 & 63;
-            const int rr = 16 * rb + (lane & 15), k0 = 16 * bk + 4 * (lane >> 4);
-            float o[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = (rr < R && k0 + e < M) ? L.q_mu[(size_t)(k0 + e) * R + rr] : 0.f;
-            st_pub4<WT>(dq + v4, make_float4(o[0], o[1], o[2], o[3]));
-        }
-    }
-    const double tot = block_sum_vt(red);
-    if (threadIdx.x == 0) {
-        if constexpr (WT) __hip_atomic_store(L.kl + r, 0.5 * (tot - (double)M), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        else L.kl[r] = 0.5 * (tot - (double)M);
-    }
-    // ---- the split-f16 image of L_r^T (and, role 1, of q_mu^T) with its power-of-two scale ----------------------------------
-    if (nbk & 1) return;
-    const float var = L.variance_dev ? *L.variance_dev : L.variance;
-    const int ea = ((L.nbk <= 8 && (L.nbk & 1) == 0) ? 7 : 10) - (int)ceilf(0.5f * log2f(fmaxf(var, 1e-30f)));   // |a| <= sigma  ->  |a| 2^ea <= 2^10 (2^7 = 2^est where stage 1 writes the planes: role_factor)
-    double mx = 0.0;                                             // (a wave per row, lanes along it: no division per element; max is order-free)
-    for (int k = threadIdx.x >> 6; k < M; k += (int)(blockDim.x >> 6))
-        for (int i = threadIdx.x & 63; i <= k; i += 64) mx = fmax(mx, fabs((double)q[(size_t)k * M + i]));
-    __syncthreads();
-    red[threadIdx.x] = mx;
-    __syncthreads();
-    for (int s_ = blockDim.x / 2; s_ > 0; s_ >>= 1) { if ((int)threadIdx.x < s_) red[threadIdx.x] = fmax(red[threadIdx.x], red[threadIdx.x + s_]); __syncthreads(); }
-    mx = red[0];
-    __syncthreads();
-    const int er = mx > 0.0 ? 13 - (int)floor(log2(mx)) : 0;                  // max |L_r| 2^er in [2^13, 2^14)
-    const float sr = ldexpf(1.f, er);
-    if (threadIdx.x == 0) st_pub<WT>(L.cst + IWVI_CST_FR + r, ldexpf(1.f, -(ea + er)));
-    {
-        const int nst = s16_slabs_total(nbk);
-        unsigned short* dst = L.LrT16 + (size_t)r * nst * 1024;                 // 1024 halves per slab (2 planes x 512)
-        for (int v = threadIdx.x; v < nst * 64; v += blockDim.x) {            // one lane-vector (8 k) of a slab per thread-iteration
-            const int sl = v >> 6, lane = v & 63;
-            int bi = 0, o = 0;
-            while (o + s16_slabs(nbk, bi) <= sl) { o += s16_slabs(nbk, bi); ++bi; }
-            const int kc = ((bi & ~1) >> 1) + (sl - o);                       // 32-chunk of k
-            const int i = 16 * bi + (lane & 15), k0 = 32 * kc + 8 * (lane >> 4);
-            _Float16 h1[8], h2[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int k = k0 + e;
-                float x = 0.f;
-                if (i < M && k < M && k >= i) x = q[(size_t)k * M + i] * sr;  // (L_r^T)[i][k] = L_r[k][i]
-                h1[e] = (_Float16)x; h2[e] = (_Float16)(x - (float)h1[e]);
-            }
-            // the slabs of row-blocks 2p and 2p+1 are interleaved chunk by chunk (they are multiplied as one step: same B vectors)
-            const int slp = ((bi & 1) ? o - s16_slabs(nbk, bi) : o) + 2 * (sl - o) + (bi & 1);
-            st_pub4<WT>(reinterpret_cast<float4*>(dst + (size_t)slp * 1024 + lane * 8), *reinterpret_cast<const float4*>(h1));
-            st_pub4<WT>(reinterpret_cast<float4*>(dst + (size_t)slp * 1024 + 512 + lane * 8), *reinterpret_cast<const float4*>(h2));
-        }
-    }
-    if (r == 0) {
-        double mq = 0.0;
-        for (int idx = threadIdx.x; idx < M * R; idx += blockDim.x) mq = fmax(mq, fabs((double)L.q_mu[idx]));
-        red[threadIdx.x] = mq;
-        __syncthreads();
-        for (int s_ = blockDim.x / 2; s_ > 0; s_ >>= 1) { if ((int)threadIdx.x < s_) red[threadIdx.x] = fmax(red[threadIdx.x], red[threadIdx.x + s_]); __syncthreads(); }
-        mq = red[0];
-        const int eq = mq > 0.0 ? 13 - (int)floor(log2(mq)) : 0;
-        const float sq = ldexpf(1.f, eq);
-        if (threadIdx.x == 0) st_pub<WT>(L.cst + IWVI_CST_FMEAN, ldexpf(1.f, -(ea + eq)));
-        const int nkc = nbk / 2;
-        for (int v = threadIdx.x; v < L.nrb * nkc * 64; v += blockDim.x) {
-            const int sl = v >> 6, lane = v & 63, rb = sl / nkc, kc = sl - rb * nkc;
-            const int rr = 16 * rb + (lane & 15), k0 = 32 * kc + 8 * (lane >> 4);
-            _Float16 h1[8], h2[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float x = (rr < R && k0 + e < M) ? L.q_mu[(size_t)(k0 + e) * R + rr] * sq : 0.f;
-                h1[e] = (_Float16)x; h2[e] = (_Float16)(x - (float)h1[e]);
-            }
-            st_pub4<WT>(reinterpret_cast<float4*>(L.Qmu16 + (size_t)sl * 1024 + lane * 8), *reinterpret_cast<const float4*>(h1));
-            st_pub4<WT>(reinterpret_cast<float4*>(L.Qmu16 + (size_t)sl * 1024 + 512 + lane * 8), *reinterpret_cast<const float4*>(h2));
-        }
-    }
+    typedef const __attribute__((address_space(1))) float* glb_cf;
+    role_pack_body<WT>(L, r, red, (glb_cf)q, false, st);
 }
-
 
 // ---- host side, shared by the two launch functions ----------------------------------------------------------
 static inline size_t factor_lds_bytes(int Mp) {

@@ -67,6 +67,8 @@ show("log-weights written", col(63))
 n_pack = sum(l["q_mu"].shape[1] for l in spec["layers"] if l["type"] == "gp")
 for r in full[(role >= n_gp) & (role < n_gp + n_pack)]:
     print("ticket %d (pack job): came to life %.2f | pack %.2f -> %.2f | chunk start %.2f | log-weights %.2f us" % (r[50] - 1000, us(r[52]), us(r[53]), us(r[54]), us(r[0]), us(r[63])))
+    p_ = [(r[30 + k] - r[30]) * 1e-2 for k in range(6)]
+    print("      inside: q_sqrt in LDS +%.2f | fp32 image + KL terms +%.2f | tree +%.2f | max +%.2f | S16 image +%.2f us" % tuple(p_[1:]))
 for r in full[(role >= n_gp + n_pack) & (role < n_gp + n_pack + n_gp)]:
     print("ticket %d (helper): other chunk's x~ done %.2f, in HBM %.2f | own chunk: start %.2f | prologue done %.2f | front done %.2f | factorisation seen %.2f | log-weights %.2f us" % (
         r[50] - 1000, us(r[53]), us(r[54]), us(r[0]), us(r[1]), us(r[60]), us(r[61]), us(r[63])))
