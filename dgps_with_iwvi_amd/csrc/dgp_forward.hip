@@ -586,7 +586,8 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
         if (tk < z.n_gp) {
             const PreLayer Lc = z.P[tk];                          // (by value: a reference into the kernel arguments would force them into scratch)
             // (diagnostic stamps land in this workgroup's 128-word row, words 0 .. 15: PRE_STAMP indexes 16 words per block)
-            role_factor<true, true>(Lc, 0, g.stamps ? g.stamps + (size_t)blockIdx.x * 112 : nullptr, 1, FzPub{&z.sync->early, &z.sync->done, &z.sync->cols[tk]});
+            role_factor<true, true>(Lc, 0, g.stamps ? g.stamps + (size_t)blockIdx.x * 112 : nullptr, 1, FzPub{&z.sync->early, &z.sync->done, &z.sync->cols[tk],
+                                          z.resume ? &z.sync->snap[tk] : nullptr, fz_gen + 1u, &z.sync->pack, (fz_gen + 1u) * (unsigned)z.n_pack, &z.sync->timeout});
             __syncthreads();
             if (!z.resume) {
                 fw_arrive<NS, FZ>(gk, sm, tid, -1);
@@ -619,6 +620,11 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
     }
     int chunk_id = FZ ? fz_chunk : (int)blockIdx.x;
 fz_restart: ;                                                    // (merged launch, helper: a second pass with its own chunk)
+    int tid_pass = threadIdx.x;
+    if constexpr (FZ) asm volatile("" : "+v"(tid_pass));           // opaque per pass: nothing derived from the thread id is hoisted out of
+    {                                                             // the helper's two-pass loop (hoisted, it stays live through stage 1 / 2: spills)
+    const int tid = tid_pass, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int gq = lane >> 4, jq = lane & 15;
     const bool fz_resume = FZ && fz_mode == 2;
     bool fz_acq = false;                                          // the pack roles' images are already acquired (a late arrival)
     const long long t0 = (long long)chunk_id * NSAMP;
@@ -794,15 +800,8 @@ fz_restart: ;                                                    // (merged laun
             //      is copied as ever -- the factorisations are over, one acquire covers them and the pack roles --, what is particular
             //      to the chunk comes back from HBM (sc1 loads to registers, all in flight, then LDS)
             const FzArgs& z = gk.z;
-            if (wave == 0) {
-                if (lane == 0) {
-                    fz_wait_ge(&z.sync->snap[fz_slot], fz_gen + 1u, &z.sync->timeout);
-                    fz_wait_ge(&z.sync->pack, (fz_gen + 1u) * (unsigned)z.n_pack, &z.sync->timeout);
-                }
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
-            __syncthreads();
+            // (the snapshot's and the pack roles' counters were polled and the acquire issued beside the factorisation's last diagonal
+            //  pass -- role_factor, FzPub::wait1 / wait2 -- so nothing but the loads themselves stands between `done` and the Gram)
             fw_copy_entries(CT, sm, 0, g.ncopy, wave, lane);
             const Sc1Stream src(z.snap + (size_t)fz_slot * z.snap_stride, (unsigned)z.snap_stride, 0u);
             f32x4* dl = reinterpret_cast<f32x4*>(sm);
@@ -1840,6 +1839,7 @@ fz_restart: ;                                                    // (merged laun
         }
     }
     fw_arrive<NS, FZ>(gk, sm, tid, chunk_id);
+    }
 }
 
 template <int NS, bool S16, bool FZ = false>

@@ -27,7 +27,9 @@ struct PreLayer {
 //   early  += 1  once cst[0 .. 72) and Z~ are written: all the K_uf Gram needs (readers: acquire, then plain loads)
 //   cols   += 1  per packed column of the solve stream LsP, in order (readers stage the stream in LDS column by column, sc1 loads)
 //   done   += 1  once the solve stream LsP is complete (readers: sc1 loads to registers, no acquire on the critical path)
-struct FzPub { unsigned* early; unsigned* done; unsigned* cols; };   // cols += 1 per packed column of LsP (in order)
+struct FzPub { unsigned* early; unsigned* done; unsigned* cols;      // cols += 1 per packed column of LsP (in order)
+               // resume mode: words this workgroup's own chunk will wait for, polled (bounded) + ONE agent acquire beside the last diagonal pass
+               unsigned* wait1; unsigned target1; unsigned* wait2; unsigned target2; unsigned* tmo; };
 template <bool WT>
 __device__ __forceinline__ void st_pub(float* p, float v) {
     if constexpr (WT) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else *p = v;
@@ -395,7 +397,7 @@ __device__ __forceinline__ double inv_get(const double* blk, const double* dinv,
 }
 
 template <bool IN_LDS, bool FZ = false>
-__device__ __forceinline__ void role_factor(const PreLayer& Lin, int stop_after, unsigned long long* stamps, int stamp_p, const FzPub pub = FzPub{nullptr, nullptr, nullptr}) {
+__device__ __forceinline__ void role_factor(const PreLayer& Lin, int stop_after, unsigned long long* stamps, int stamp_p, const FzPub pub = FzPub{nullptr, nullptr, nullptr, nullptr, 0u, nullptr, 0u, nullptr}) {
     PreLayer L = Lin;
     if (L.variance_dev) L.variance = *L.variance_dev;        // a device-resident (trained) kernel variance
     PRE_STAMP(0);
@@ -418,16 +420,23 @@ __device__ __forceinline__ void role_factor(const PreLayer& Lin, int stop_after,
     // scaled inducing inputs, float32-rounded (the values the K_uf Gram also sees)
     // (1024 threads: thread (pr = tid >> 5, d = tid & 31) loads exactly the rows m = pr, pr + 32, .. of column d -- the 32 partial sums of
     // the column means below are formed right here, in the same order, without waiting for the tile)
-    const bool fused_sum = nthreads == 1024;
-    double colpart = 0.0;
+    // (512 threads: thread (pr = tid >> 5 < 16, d) loads the rows m = pr, pr + 16, ..: two of the 32 partial sums, alternately)
+    const bool fused_sum = nthreads == 1024 || nthreads == 512;
+    const bool two_parts = nthreads == 512;
+    double colpart = 0.0, colpart2 = 0.0;
+    int odd = 0;
     for (int idx = tid; idx < Mp * 32; idx += nthreads) {
         const int m = idx >> 5, d = idx & 31;
         float v = 0.f;
         if (m < M && d < D) v = (float)((double)L.Z[(size_t)m * D + d] / (double)L.ls[d]);
         zs[m * ZLD + d] = v;
-        if (m < M) colpart += (double)v;
+        if (m < M) { if (two_parts && odd) colpart2 += (double)v; else colpart += (double)v; }
+        odd ^= 1;
     }
-    if (fused_sum) (znd + Mp)[(tid >> 5) * 32 + (tid & 31)] = colpart;
+    if (fused_sum) {
+        (znd + Mp)[(tid >> 5) * 32 + (tid & 31)] = colpart;
+        if (two_parts) (znd + Mp)[((tid >> 5) + 16) * 32 + (tid & 31)] = colpart2;
+    }
     if (tid < 32) st_pub<FZ>(L.cst + tid, (tid < D) ? (float)(1.0 / (double)L.ls[tid]) : 0.f);
     const int lg_sigma = (int)ceilf(0.5f * log2f(fmaxf(L.variance, 1e-30f)));
     const bool st1_16 = (L.nbk <= 8) && ((L.nbk & 1) == 0);  // this layer's solve takes split-f16 off-diagonal updates (iwvi_common.h: IWVI_CST_U)
@@ -533,17 +542,23 @@ __device__ __forceinline__ void role_factor(const PreLayer& Lin, int stop_after,
         const double c = 1.4426950408889634;
         const double l2v = log2((double)L.variance);
         const float rns = 1.0f / (float)nsteps;
-        for (int idx = t; idx < nbk * nsteps * 64; idx += nt) {
-            const int lane = idx & 63, wb = idx >> 6;
+        for (int i4 = t; i4 < nbk * nsteps * 16; i4 += nt) {        // four consecutive lanes' entries per thread: one 16-byte store
+            const int idx0 = 4 * i4, lane0 = idx0 & 63, wb = idx0 >> 6;
             const int bi = (int)(((float)wb + 0.5f) * rns), s = wb - bi * nsteps;   // exact for these small integers
-            const int m = 16 * bi + (lane & 15), f = 4 * s + (lane >> 4);
-            float v = 0.f;
-            if (m < M) {
-                if (f < D) v = rbf ? (float)(c * (double)zs[m * ZLD + f]) : -2.f * zs[m * ZLD + f];
-                else if (f == D) v = rbf ? (float)c : 1.f;
-                else if (f == D + 1) v = rbf ? (float)(-0.5 * c * znd[m] + l2v) : zn[m];
-            } else if (f == D + 1 && rbf) v = -1.0e30f;              // padding rows: k = exp2(-huge) = 0
-            st_pub<FZ>(L.ZtP + idx, v);
+            const int f = 4 * s + (lane0 >> 4);
+            float v4[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int m = 16 * bi + ((lane0 + e) & 15);
+                float v = 0.f;
+                if (m < M) {
+                    if (f < D) v = rbf ? (float)(c * (double)zs[m * ZLD + f]) : -2.f * zs[m * ZLD + f];
+                    else if (f == D) v = rbf ? (float)c : 1.f;
+                    else if (f == D + 1) v = rbf ? (float)(-0.5 * c * znd[m] + l2v) : zn[m];
+                } else if (f == D + 1 && rbf) v = -1.0e30f;          // padding rows: k = exp2(-huge) = 0
+                v4[e] = v;
+            }
+            st_pub4<FZ>(reinterpret_cast<float4*>(L.ZtP + idx0), make_float4(v4[0], v4[1], v4[2], v4[3]));
         }
     };
     PRE_STAMP(2);
@@ -598,7 +613,21 @@ __device__ __forceinline__ void role_factor(const PreLayer& Lin, int stop_after,
         auto pubcol = [&](int c) {                                   // one lane of a worker wave, never the serial wave
             if (tid == 64) __hip_atomic_fetch_add(c == 0 ? pub.early : pub.cols, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         };
-        chol_blocks(blk, nbk, rinv, dinv, tid, nthreads, gen, post, NoTail(), stamps, stamp_p, pubcol);
+        auto ftail = [&](int t, int) {                               // beside the last diagonal pass (worker waves are idle there)
+            if (pub.wait1 && t < 64) {
+                if (t == 0) {
+                    unsigned* w[2] = {pub.wait1, pub.wait2}; const unsigned tg[2] = {pub.target1, pub.target2};
+                    for (int k = 0; k < 2; ++k)
+                        for (unsigned spins = 0; w[k] && (int)(__hip_atomic_load(w[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - tg[k]) < 0; ++spins) {
+                            __builtin_amdgcn_s_sleep(2);
+                            if (spins > (1u << 22)) { __hip_atomic_store(pub.tmo, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                        }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+        };
+        chol_blocks(blk, nbk, rinv, dinv, tid, nthreads, gen, post, ftail, stamps, stamp_p, pubcol);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (tid == 0) {
