@@ -106,7 +106,7 @@ struct FwLayer {
 struct FwHeadGp { FwLayerHead h; FwGp gp; };      // how a GP layer's descriptor starts: one batched LDS read
 static_assert(offsetof(FwLayer, gp) == sizeof(FwLayerHead) && offsetof(FwHeadGp, gp) == sizeof(FwLayerHead), "layer head layout");
 // LDS carve, float offsets (all multiples of 4)
-struct FwLds { int ltab, xa, xb, xt, lw, rowi, pidx, asq, meanp, gbuf, obuf, znoise, xyrows, cnt, scratch, total; };
+struct FwLds { int ltab, xa, xb, xt, lw, rowi, pidx, asq, meanp, gbuf, obuf, znoise, xyrows, yrows, cnt, scratch, total; };
 
 // Kernel arguments.  The header is read through the scalar cache; the layer table is copied to LDS with
 // vector loads first thing (one round trip for all of it): read line by line through the scalar cache, a
@@ -721,6 +721,23 @@ fz_restart: ;                                                    // (merged laun
     asm volatile("" :: "s"(hot_touch));                           // (the scalar-cache lines of gk.H have landed)
     __syncthreads();                                              // layer table (and rowi / pidx) visible
     FW_STAMP(56);
+    // the chunk's targets y (a gather through rowi by LDS-DMA: no register, nothing waits here) and the likelihood variance: read in the
+    // tail, where a global round trip had nothing left to hide behind
+    if (g.out_logw) {
+        float* yrows = sm + g.lds.yrows;
+        const int Dy_ = g.Dy;
+        for (int i0 = (tid & ~63); i0 < NSAMP * Dy_; i0 += FW_THREADS) {
+            const int idx = i0 + lane, d = idx / NSAMP, j = idx - d * NSAMP;
+            if (idx < NSAMP * Dy_ && j < nvalid)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g.Y + (size_t)(fz_resume ? (int)row_of(point_of(j)) : rowi[j]) * Dy_ + d),   // (a resumed chunk's rowi arrives later, with its snapshot)
+                                                 (__attribute__((address_space(3))) void*)(yrows + i0), 4, 0, 0);
+        }
+        if (tid == 0) {
+            float lv = g.lik_variance;
+            if (g.lik_var_dev) lv = *((gptr1)g.lik_var_dev);
+            sm[g.lds.cnt + 8] = lv;
+        }
+    }
     if (!fz_resume) {
     // precomputed encoder outputs of the chunk's distinct data points -> the LV layer's constant block
     for (int li = 0; li < g.n_layers; ++li) {
@@ -927,7 +944,8 @@ fz_restart: ;                                                    // (merged laun
             // ================= GPLayer (layers.py:35-50) ==============================================
             const int nbk = G.nbk, R = G.R, P = G.P, nsteps = G.nsteps;
             const float* vdev = g.var_dev[li];
-            const float g_variance = vdev ? *vdev : G.variance;
+            float g_variance = G.variance;                        // (a select between a device pointer and the argument's own address is a FLAT load)
+            if (vdev) g_variance = *((gptr1)vdev);
             f32x4* kuf = reinterpret_cast<f32x4*>(scratch);
             f32x4* at = kuf;                                       // solved in place (stage 1)
             float* usq = scratch + (size_t)G.Mp * NSAMP;           // [wave][r][NSAMP]
@@ -1801,12 +1819,13 @@ fz_restart: ;                                                    // (merged laun
                            (NSAMP % g.e.K) == 0;
     if (g.out_logw && tid < nvalid) {
         const int Dy = g.Dy;
-        const float likv = g.lik_var_dev ? *g.lik_var_dev : g.lik_variance;
+        const float likv = sm[g.lds.cnt + 8];                      // (prologue)
         const float c0 = -0.5f * 1.8378770664093453f - 0.5f * logf(likv);
         const float inv2s = 0.5f / likv;
+        const float* yrows = sm + g.lds.yrows;
         float acc = 0.f;
         for (int d = 0; d < Dy; ++d) {
-            const float df = g.Y[(size_t)rowi[tid] * Dy + d] - obuf[d * NSAMP + tid];
+            const float df = yrows[d * NSAMP + tid] - obuf[d * NSAMP + tid];
             acc += c0 - (df * df + obuf[(Dy + d) * NSAMP + tid]) * inv2s;
         }
         const float lwv = acc - lw[tid];
@@ -1944,6 +1963,7 @@ static size_t fw_plan_lds(FwArgs& a, int nsamp, int maxR, int maxP, bool stage_z
     l.gbuf = o; o += 3 * maxR * nsamp;
     l.obuf = o; o += 2 * maxP * nsamp;
     l.xyrows = o; o += a.h.XY ? nsamp * up4(a.h.XYdim) : 0;
+    l.yrows = o; o += a.h.Y ? up4(nsamp * a.h.Dy) : 0;   // the chunk's targets, gathered in the prologue (the tail then waits for no global load)
     for (int i = 0; i < a.h.n_layers; ++i) {
         FwLayer& L = a.L[i];
         L.c_off = o;
