@@ -148,3 +148,39 @@ def test_merged_launch_replays_from_a_graph(gpu_device):
     settings.merged_launch = old_merged
     words = m2._fz_ws().view(torch.int32)
     assert int(words[0]) == 2 * n + 1 and int(words[5]) == 0       # gen = launches completed; no wait ever gave up
+
+
+def test_merged_launch_sees_parameter_updates_between_evaluations(gpu_device):
+    """Every evaluation rewrites the factorisation state in place, and workgroups of the SAME launch read it on other CUs (other XCDs):
+    a hand-off that served last evaluation's lines from a cache would go unnoticed while the parameters stand still.  Here Z, the
+    lengthscales, q_mu, q_sqrt and the kernel variance move between evaluations (as under training); every evaluation must equal the two
+    launches' bit for bit -- also at the full configs[2] grid, where the factorising workgroups resume chunks from snapshots."""
+    from dgps_with_iwvi_amd import synthetic
+    for B in (64, 1024):
+        spec = synthetic.make_spec(L=2, M=128, B=B, K=20, R=5, with_lv=True, seed=17)
+        zs = [torch.as_tensor(z, dtype=torch.float32, device=gpu_device) for z in synthetic.make_noise(spec, seed=18)]
+
+        def run():
+            m = _model(spec, gpu_device)
+            gen = torch.Generator(device="cpu").manual_seed(5)
+            out = []
+            for it in range(6):
+                out.append(m._elbo_parts(zs)[0].clone())
+                out.append(m._elbo_parts(None)[1].clone())
+                for l in m.layers:                                   # an in-place parameter step, the same in both runs
+                    if not hasattr(l, "q_sqrt"):
+                        for w in l.encoder.Ws:
+                            w.mul_(1.0 + 0.01 * float(torch.randn((), generator=gen)))
+                        continue
+                    l.q_mu.add_(0.05 * torch.randn(l.q_mu.shape, generator=gen).to(gpu_device))
+                    l.q_sqrt.mul_(1.0 + 0.02 * float(torch.randn((), generator=gen)))
+                    l._Z().add_(0.02 * torch.randn(l._Z().shape, generator=gen).to(gpu_device))
+                    k = l._base_kern()
+                    k.lengthscales.mul_(1.0 + 0.02 * float(torch.randn((), generator=gen)))
+                    k.variance = k.variance * (1.0 + 0.03 * float(torch.randn((), generator=gen)))
+            return out
+
+        a, b = _both(run)
+        for i, (x, y) in enumerate(zip(a, b)):
+            assert torch.equal(x, y), (B, i, x.flatten()[:3], y.flatten()[:3])
+        assert not torch.equal(a[0], a[2])                           # the parameters did move
