@@ -176,8 +176,9 @@ def _kgrad_worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def test_k_sharded_gradient_shares_sum_to_the_unsharded_gradient():
-    world, port = 2, _free_port()
+@pytest.mark.parametrize("world", [2, 3])
+def test_k_sharded_gradient_shares_sum_to_the_unsharded_gradient(world):
+    port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     procs = [ctx.Process(target=_kgrad_worker, args=(r, world, port, q)) for r in range(world)]
@@ -207,9 +208,9 @@ def test_data_parallel_gradient_equals_unsharded():
     assert res[0][2] == res[1][2]
 
 
-@pytest.mark.parametrize("mode", ["k", "n"])
-def test_sharded_elbo_equals_unsharded(mode):
-    world, port = 2, _free_port()
+@pytest.mark.parametrize("mode,world", [("k", 2), ("n", 2), ("k", 4), ("n", 3)])     # K = 7 over 4 ranks: 2, 2, 2, 1 samples
+def test_sharded_elbo_equals_unsharded(mode, world):
+    port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     procs = [ctx.Process(target=_worker, args=(r, world, port, mode, q)) for r in range(world)]
@@ -221,7 +222,7 @@ def test_sharded_elbo_equals_unsharded(mode):
         assert p.exitcode == 0
     for rank, got, ref in res:
         assert abs(got - ref) <= 1e-9 * abs(ref), (mode, rank, got, ref)
-    assert res[0][1] == res[1][1]                                    # every rank holds the same answer
+    assert all(r[1] == res[0][1] for r in res)                       # every rank holds the same answer
 
 
 def test_split_helpers():
