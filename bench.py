@@ -141,7 +141,9 @@ def training_leg(model, samples, iters=20):
                         "per layer, Cholesky adjoint; DESIGN.md section 5b); train step: training.Trainer(use_graph=True).step = NatGrad op + Adam op, "
                         "each one graph replay, trained scalars and Adam's step count on the device; runs after the timed region and changes the "
                         "model's parameters"}
-    except Exception as e:                                   # never let the informational leg take the bench line down
+    except Exception as e:                                   # the informational leg must not take the headline line down -- but it fails LOUDLY:
+        import traceback                                     # the traceback goes to stderr and the JSON carries the error text
+        traceback.print_exc()
         return {"error": "%s: %s" % (type(e).__name__, e)}
 
 
