@@ -115,11 +115,14 @@ def training_leg(model, samples, iters=20):
         def timed(fn):
             fn(); fn()
             torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(iters):
-                fn()
-            torch.cuda.synchronize()
-            return (time.perf_counter() - t0) / iters * 1e3
+            reps = []
+            for _ in range(5):                               # median of five batches: one host stall inside a 20-iteration batch
+                t0 = time.perf_counter()                     # otherwise shows up as a 2x slower step
+                for _ in range(iters):
+                    fn()
+                torch.cuda.synchronize()
+                reps.append((time.perf_counter() - t0) / iters * 1e3)
+            return float(np.median(reps))
 
         grad_ms = timed(lambda: backward.iw_elbo_and_gradients(model))
         # the same evaluation replayed from a hipGraph (what a training loop with use_graph=True runs)

@@ -292,7 +292,7 @@ def test_lv_layer_in_the_precompute_launch(gpu_device, L, M, K, B):
     zd = [None] + [_t(z, gpu_device) for z in zs[1:]]
     logp = model.E_log_p_Y(zd)
     z0 = _np(model.layers[0]._smp_z).reshape(B, K, -1)
-    assert abs(z0.mean()) < 5.0 / np.sqrt(z0.size) and abs(z0.std() - 1) < 0.05
+    assert abs(z0.mean()) < 5.0 / np.sqrt(z0.size) and abs(z0.std() - 1) < 5.0 / np.sqrt(2 * z0.size)       # five sigma of each statistic
     elbo = model.compute_log_likelihood(zd)                      # the step counter moved on: new LV draws
     z1 = _np(model.layers[0]._smp_z).reshape(B, K, -1)
     assert np.abs(z1 - z0).max() > 0.1
