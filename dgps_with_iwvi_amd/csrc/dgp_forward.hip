@@ -136,6 +136,12 @@ struct FwHead {
     int ncopy_indep;                 // the first ncopy_indep entries of the copy list read nothing another workgroup of this launch writes
     int nchunks;                     // chunks of 16 * NS samples (== workgroups, except in the merged launch)
     int ls_first;                    // first GP layer whose solve stream is staged in LDS (fetched in the prologue), or -1
+    int n_early;                     // the last n_early waves issue the prologue's big copies (first solve stream, every Z~ image) before anything else
+    unsigned zt_mask;                // GP layers whose Z~ image those waves copy (bit = layer); 0 when n_early == 0: the copy list carries them
+    int nz_cnt[IWVI_MAX_STACK], nz_zoff[IWVI_MAX_STACK], nz_dims[IWVI_MAX_STACK];   // the noise plan of a stack that draws all of its noise: items, slot,
+    unsigned nz_zero_mask;           // components per layer + which layers' noise is zero -- in the header: scalar loads, no table walk in LDS
+    int noise_drawn, noise_any_src;  // prologue: (layer, 4-component group, sample) items drawn in the kernel; any layer with injected noise
+    unsigned pre_enc_mask;           // LV layers whose encoder output was evaluated before this launch (bit = layer): the prologue gathers their rows
     const float* lw_init;            // optional [T]: local regularisers of layers evaluated before this launch (summed per sample)
     int layer_base;                  // index of this stack's first layer in the model (keys the noise streams)
     int x_per_sample;                // X has one row per sample (the output of a layer evaluated before this launch)
@@ -418,21 +424,41 @@ __device__ __forceinline__ float stage1_unrolled(AP Ap, const f32x4* kuf, f32x4*
 }
 
 // prologue copy list, entries [c_lo, c_hi): one entry per wave at a time, all DMA loads in flight together
-__device__ __forceinline__ void fw_copy_entries(const FwCopy* CT, float* sm, int c_lo, int c_hi, int wave, int lane) {
-    for (int ci = c_lo + wave; ci < c_hi; ci += FW_WAVES) {
-        const FwCopy ce = uniform_words(CT[ci]);                   // one 16-byte LDS read per entry
-        const float* src = ce.src;
-        const int n = ce.n;
-        float* dst = sm + ce.dst;
-        const int wl = lane;                                       // this wave alone moves the entry
-        if (!src) { for (int i = wl; i < n; i += 64) dst[i] = 0.f; }           // absent operand (e.g. no encoder bias)
-        else if (n < 0) { for (int i0 = 0; i0 < (-n >> 2); i0 += 64) if (i0 + wl < (-n >> 2))
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 4 * (i0 + wl)),
+// The compiler orders every LDS access behind every pending LDS-DMA (an `s_waitcnt vmcnt(0)` in front of each ds_read / ds_write that follows a
+// global_load_lds): an entry read from the LDS table between two copies makes the second wait until the first has landed.  So: this wave's
+// entries first (and the zero fills, which are LDS stores), then the copies back to back.
+constexpr int FW_COPY_PER_WAVE = FW_MAX_COPY / FW_WAVES;
+__device__ __forceinline__ void fw_copy_load(const FwCopy* CT, float* sm, int c_lo, int c_hi, int wave, int lane, FwCopy (&ce)[FW_COPY_PER_WAVE],
+                                             int nwaves = FW_WAVES) {
+#pragma unroll
+    for (int k = 0; k < FW_COPY_PER_WAVE; ++k) {
+        const int ci = c_lo + wave + k * nwaves;
+        ce[k].src = nullptr; ce[k].n = 0; ce[k].dst = 0;
+        if (ci < c_hi) {
+            ce[k] = uniform_words(CT[ci]);                         // one 16-byte LDS read per entry
+            if (!ce[k].src) { float* dst = sm + ce[k].dst; for (int i = lane; i < ce[k].n; i += 64) dst[i] = 0.f; }   // absent operand (e.g. no encoder bias)
+        }
+    }
+}
+__device__ __forceinline__ void fw_copy_issue(float* sm, int lane, const FwCopy (&ce)[FW_COPY_PER_WAVE]) {
+#pragma unroll
+    for (int k = 0; k < FW_COPY_PER_WAVE; ++k) {
+        const float* src = ce[k].src;
+        if (!src) continue;
+        const int n = ce[k].n;
+        float* dst = sm + ce[k].dst;
+        if (n < 0) { for (int i0 = 0; i0 < (-n >> 2); i0 += 64) if (i0 + lane < (-n >> 2))
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 4 * (i0 + lane)),
                                                  (__attribute__((address_space(3))) void*)(dst + 4 * i0), 16, 0, 0); }
-        else { for (int i0 = 0; i0 < n; i0 += 64) if (i0 + wl < n)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + i0 + wl),
+        else { for (int i0 = 0; i0 < n; i0 += 64) if (i0 + lane < n)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + i0 + lane),
                                                  (__attribute__((address_space(3))) void*)(dst + i0), 4, 0, 0); }
     }
+}
+__device__ __forceinline__ void fw_copy_entries(const FwCopy* CT, float* sm, int c_lo, int c_hi, int wave, int lane) {
+    FwCopy ce[FW_COPY_PER_WAVE];
+    fw_copy_load(CT, sm, c_lo, c_hi, wave, lane, ce);
+    fw_copy_issue(sm, lane, ce);
 }
 
 // ---- one ticket per workgroup: the last arriver advances the noise stream (every workgroup has read the step counter by
@@ -637,9 +663,15 @@ fz_restart: ;                                                    // (merged laun
         const unsigned* hw = reinterpret_cast<const unsigned*>(&gk.H[0]);
 #pragma unroll
         for (int i = 0; i < (int)(sizeof(FwHot) * IWVI_MAX_STACK / 64); ++i) hot_touch |= hw[16 * i];
+        hot_touch |= (unsigned)g.nz_cnt[0] | (unsigned)g.nz_zoff[0] | (unsigned)g.nz_dims[0] | g.nz_zero_mask;   // (the noise plan's lines of the header)
     }
+    // ---- the last n_early waves (those that draw no noise below) issue every copy of the prologue; the others fetch the layer table and the
+    //      chunk's rows (below: "the prologue's copies")
+    const int n_early = FZ ? 0 : g.n_early;
+    const bool early_wave = wave >= FW_WAVES - n_early;
+    const int ethreads = (FW_WAVES - n_early) * 64;               // threads that run the small loads in front of the first barrier
     // ---- layer table: kernarg -> LDS, every dword in flight at once ------------------------------------
-    {
+    if (!early_wave) {
 #if defined(__HIP_DEVICE_COMPILE__)
         const uint32_t* ka = (const uint32_t*)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(FwArgs, L) / 4;
 #else
@@ -648,11 +680,11 @@ fz_restart: ;                                                    // (merged laun
         uint32_t* dst = reinterpret_cast<uint32_t*>(sm + g.lds.ltab);
         // layers | noise plan | copy list are contiguous in FwArgs; copy only what is in use
         const int nl = g.n_layers * (int)(sizeof(FwLayer) / 4);
-        for (int i = tid; i < nl; i += FW_THREADS) dst[i] = ka[i];
+        for (int i = tid; i < nl; i += ethreads) dst[i] = ka[i];
         constexpr int offN = (int)((offsetof(FwArgs, N) - offsetof(FwArgs, L)) / 4), offC = (int)((offsetof(FwArgs, C) - offsetof(FwArgs, L)) / 4);
         const int nn = g.n_layers * (int)(sizeof(FwNoise) / 4), nc = g.ncopy * (int)(sizeof(FwCopy) / 4);
-        for (int i = tid; i < nn; i += FW_THREADS) dst[offN + i] = ka[offN + i];
-        for (int i = tid; i < nc; i += FW_THREADS) dst[offC + i] = ka[offC + i];
+        for (int i = tid; i < nn; i += ethreads) dst[offN + i] = ka[offN + i];
+        for (int i = tid; i < nc; i += ethreads) dst[offC + i] = ka[offC + i];
     }
     const FwLayer* LT = reinterpret_cast<const FwLayer*>(sm + g.lds.ltab);
     const FwNoise* NT = reinterpret_cast<const FwNoise*>(sm + g.lds.ltab + (offsetof(FwArgs, N) - offsetof(FwArgs, L)) / 4);
@@ -672,7 +704,9 @@ fz_restart: ;                                                    // (merged laun
     int* counters = reinterpret_cast<int*>(sm + g.lds.cnt);
     float* scratch = sm + g.lds.scratch;
 
-    const unsigned long long step = g.rng_state ? g.rng_state[0] : 0ULL;
+    // (through the scalar cache: a vector load here would make every wave wait for vmcnt(0), the early waves for their copies; the counter
+    //  only moves when the last workgroup of a launch arrives, after every workgroup of that launch has read it)
+    const unsigned long long step = g.rng_state ? *((const __attribute__((address_space(4))) unsigned long long*)g.rng_state) : 0ULL;
     FW_STAMP(0);
     if (g.dbg_exit == 1) return;
 
@@ -696,7 +730,38 @@ fz_restart: ;                                                    // (merged laun
         if (wide_mod) { if (r >= (unsigned)g.row_mod) r -= (unsigned)g.row_mod; } else r %= (unsigned)g.row_mod;
         return r;
     };
-    if (!fz_resume) {                                             // (a resumed chunk: all of this comes with the snapshot, below)
+    // ---- the prologue's big copies (the first solve stream: 36 KiB at M = 128; every layer's Z~ image: 8 KiB each), first thing, by the waves
+    //      that draw no noise.  These operands were written by the launch before this one: every XCD's first read of a line goes past its L2,
+    //      and a CU takes in ~25 KB per us of such copies -- issued behind the first barrier by every wave, between its table reads and its
+    //      draws, they were 2.5 us of this kernel.  Now they land while the other waves fetch the table and draw.  The issuing waves touch no
+    //      LDS in front of the first barrier (the compiler would make them wait for the copies there) and wait at their first table read behind
+    //      it.  (Measured and rejected: the small copies and the row gathers issued here as well, entries read from the kernel arguments
+    //      -- these waves then reach the first barrier at 2.0-2.3 us instead of 1.0, in either order; the small copies given to the drawing
+    //      waves -- they queue behind the big ones in the CU's address unit, 0.6 us per wave.)
+    if (early_wave) {
+        const int dw = FW_WAVES - 1 - wave, dth = n_early * 64;
+        if (g.ls_first >= 0) {
+            const FwHot& G0 = gk.H[g.ls_first];
+            const float* lsrc = reinterpret_cast<const float*>(G0.LsP);
+            float* ldst = sm + G0.ls_off;
+            const int n4 = (tri_blocks(G0.nbk) * BLK16) >> 2;
+            for (int i0 = dw * 64; i0 < n4; i0 += dth)
+                if (i0 + lane < n4)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(lsrc + 4 * (i0 + lane)),
+                                                     (__attribute__((address_space(3))) void*)(ldst + 4 * i0), 16, 0, 0);
+        }
+        for (unsigned zm = g.zt_mask; zm; zm &= zm - 1) {
+            const FwHot& Hz = gk.H[__builtin_ctz(zm)];
+            const float* zsrc = Hz.ZtP;
+            float* zdst = sm + Hz.zt_off;
+            const int n4 = Hz.nbk * Hz.nsteps * 16;
+            for (int i0 = dw * 64; i0 < n4; i0 += dth)
+                if (i0 + lane < n4)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(zsrc + 4 * (i0 + lane)),
+                                                     (__attribute__((address_space(3))) void*)(zdst + 4 * i0), 16, 0, 0);
+        }
+    }
+    if (!fz_resume && !early_wave) {                              // (a resumed chunk: all of this comes with the snapshot, below)
     if (tid < NSAMP) {
         const unsigned dp = point_of(tid);
         rowi[tid] = (int)row_of(dp);
@@ -704,7 +769,7 @@ fz_restart: ;                                                    // (merged laun
         lw[tid] = (g.lw_init && tid < nvalid) ? g.lw_init[t0 + tid] : 0.f;
     }
     // the chunk's rows of X (models.py:113 / :50 tiling done here) and of the encoder input
-    for (int idx = tid; idx < NSAMP * g.Dx; idx += FW_THREADS) {
+    for (int idx = tid; idx < NSAMP * g.Dx; idx += ethreads) {
         const int d = idx / NSAMP, j = idx - d * NSAMP;            // (compile-time divisor)
         const unsigned row = g.x_per_sample ? ut0 + (unsigned)(j < nvalid ? j : nvalid - 1) : row_of(point_of(j));
         xin[j * XSTR + d] = (j < nvalid) ? g.X[(size_t)row * g.Dx + d] : 0.f;
@@ -712,42 +777,94 @@ fz_restart: ;                                                    // (merged laun
     if (g.XY) {
         const int xs = up4(g.XYdim);
         const float rcp = 1.0f / (float)g.XYdim;
-        for (int idx = tid; idx < npts * g.XYdim; idx += FW_THREADS) {
+        for (int idx = tid; idx < npts * g.XYdim; idx += ethreads) {
             const int p = div_small(idx, rcp), i = idx - p * g.XYdim;
             xyrows[p * xs + i] = g.XY[(size_t)row_of((unsigned)p) * g.XYdim + i];
         }
     }
     }
     asm volatile("" :: "s"(hot_touch));                           // (the scalar-cache lines of gk.H have landed)
-    __syncthreads();                                              // layer table (and rowi / pidx) visible
+    // layer table (and rowi / pidx) visible.  Not __syncthreads(): its release half waits for vmcnt(0), i.e. for the early waves' copies --
+    // this wave's LDS stores are what the others need, and those are done at lgkmcnt(0)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
     FW_STAMP(56);
-    // the chunk's targets y (a gather through rowi by LDS-DMA: no register, nothing waits here) and the likelihood variance: read in the
-    // tail, where a global round trip had nothing left to hide behind
-    if (g.out_logw) {
+    // ---- everything small -> LDS, the duties split over the waves: each of these steps is a short chain of dependent latencies (a table
+    //      read, an address, a copy), and one wave running all of them one after the other was 3.4 us of this kernel.  The first
+    //      `noise_drawn` threads draw the noise (one Philox item each), from wave 0 up; the copies go to the waves that draw nothing, from
+    //      the last wave down (to every wave when fewer than two are free).  In a wave that does both, whatever reads LDS comes first and
+    //      the copies follow back to back: the compiler puts `s_waitcnt vmcnt(0)` in front of every ds_read / ds_write that follows a
+    //      global_load_lds, so a table entry read between two copies makes the second wait until the first has landed.
+    const int ncopy0 = FZ ? g.ncopy_indep : g.ncopy;              // (merged launch: what the factorising workgroups write comes last, below)
+    const int draw_waves = g.noise_any_src ? FW_WAVES : ((g.noise_drawn + 63) >> 6 < FW_WAVES ? (g.noise_drawn + 63) >> 6 : FW_WAVES);
+    const int ndma = n_early > 0 ? n_early : FW_WAVES;            // (the host has checked that the copy list fits those waves)
+    const int dwave = FW_WAVES - 1 - wave;                        // the copies' wave index: 0 = the last wave
+    const bool dma_wave = dwave < ndma, late_big = n_early == 0;  // (without early waves the big copies are issued here too, by every wave)
+    const int dthreads = ndma * 64;
+    FwCopy ce0[FW_COPY_PER_WAVE];                                 // this wave's entries of the copy list
+    // noise of every layer -> znoise[z_off + r * NSAMP + j]: 4 normals per Philox call, the (layer, 4-component group, sample) items of all
+    // layers laid end to end over the workgroup's threads.  A thread's first item is looked up now (table reads), drawn in registers after
+    // this wave's copies are issued and stored last; further items (more than one per thread: rare) follow
+    int it_li = -1, it_k = 0, it_dims = 0, it_zoff = 0, it_zero = 0;
+    if (!fz_resume) {
+    if (wave < draw_waves && !g.noise_any_src) {                  // the plan from the header: no LDS round trip per layer
+        int base = 0, cnts[IWVI_MAX_STACK], zoffs[IWVI_MAX_STACK], dms[IWVI_MAX_STACK];
+#pragma unroll
+        for (int li = 0; li < IWVI_MAX_STACK; ++li) { cnts[li] = g.nz_cnt[li]; zoffs[li] = g.nz_zoff[li]; dms[li] = g.nz_dims[li]; }   // (three wide scalar loads, one wait)
+        const unsigned zmask = g.nz_zero_mask;
+#pragma unroll
+        for (int li = 0; li < IWVI_MAX_STACK; ++li) {              // (layers beyond the stack: 0 items)
+            int k = tid - base;
+            if (k < 0) k += FW_THREADS;
+            if (it_li < 0 && k < cnts[li]) { it_li = li; it_k = k; it_dims = dms[li]; it_zoff = zoffs[li]; it_zero = (int)(zmask >> li & 1u); }
+            base = (base + cnts[li]) & (FW_THREADS - 1);
+        }
+    } else if (wave < draw_waves) {
+        int base = 0;                                              // first thread of the current layer's items
+        for (int li = 0; li < g.n_layers; ++li) {
+            const FwNoise nz = uniform_words(NT[li]);              // one LDS round trip per layer
+            if (nz.src) {                                          // injected [T, dims]: a gather by LDS-DMA (the source is per lane)
+                float* zdst = znoise + nz.z_off;
+                for (int i0 = (tid & ~63); i0 < nz.dims * NSAMP; i0 += FW_THREADS) {
+                    const int i = i0 + lane, r = i / NSAMP, j = i - r * NSAMP;
+                    if (i < nz.dims * NSAMP && j < nvalid)
+                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(nz.src + (size_t)(t0 + j) * nz.dims + r),
+                                                         (__attribute__((address_space(3))) void*)(zdst + i0), 4, 0, 0);
+                }
+                continue;
+            }
+            const int cnt = ((nz.dims + 3) >> 2) * NSAMP;
+            int k = tid - base;
+            if (k < 0) k += FW_THREADS;
+            if (it_li < 0 && k < cnt) { it_li = li; it_k = k; it_dims = nz.dims; it_zoff = nz.z_off; it_zero = nz.zero; }
+            base = (base + cnt) & (FW_THREADS - 1);
+        }
+    }
+    FW_STAMP(40);
+    if (dma_wave) fw_copy_load(CT, sm, 0, ncopy0, dwave, lane, ce0, ndma);
+    }
+    // the chunk's targets y (a gather by LDS-DMA: no register, nothing waits here)
+    if (g.out_logw && dma_wave) {
         float* yrows = sm + g.lds.yrows;
         const int Dy_ = g.Dy;
-        for (int i0 = (tid & ~63); i0 < NSAMP * Dy_; i0 += FW_THREADS) {
+        for (int i0 = dwave * 64; i0 < NSAMP * Dy_; i0 += dthreads) {
             const int idx = i0 + lane, d = idx / NSAMP, j = idx - d * NSAMP;
             if (idx < NSAMP * Dy_ && j < nvalid)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g.Y + (size_t)(fz_resume ? (int)row_of(point_of(j)) : rowi[j]) * Dy_ + d),   // (a resumed chunk's rowi arrives later, with its snapshot)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g.Y + (size_t)row_of(point_of(j)) * Dy_ + d),   // (= rowi[j], without the LDS read)
                                                  (__attribute__((address_space(3))) void*)(yrows + i0), 4, 0, 0);
-        }
-        if (tid == 0) {
-            float lv = g.lik_variance;
-            if (g.lik_var_dev) lv = *((gptr1)g.lik_var_dev);
-            sm[g.lds.cnt + 8] = lv;
         }
     }
     if (!fz_resume) {
+    if (dma_wave) {
     // precomputed encoder outputs of the chunk's distinct data points -> the LV layer's constant block
-    for (int li = 0; li < g.n_layers; ++li) {
-        const FwHot& Hp = gk.H[li];
-        if (Hp.type != IWVI_LAYER_LV || !(Hp.flags & FWF_PRE_ENC)) continue;
+    for (unsigned pm = g.pre_enc_mask; pm; pm &= pm - 1) {         // (no walk over the layer table: each step of it is a scalar-cache round trip)
+        const FwHot& Hp = gk.H[__builtin_ctz(pm)];
         const float* eo = reinterpret_cast<const float*>(Hp.LrTP);
         const int no = 2 * Hp.R;
         float* dst = sm + Hp.c_off;
         const float rcp = 1.0f / (float)no;
-        for (int i0 = (tid & ~63); i0 < npts * no; i0 += FW_THREADS) {     // a gather by LDS-DMA: nothing waits here
+        for (int i0 = dwave * 64; i0 < npts * no; i0 += dthreads) {        // a gather by LDS-DMA: nothing waits here
             const int idx = i0 + lane;
             const int p = div_small(idx < npts * no ? idx : 0, rcp), o = idx - p * no;
             if (idx < npts * no)
@@ -755,42 +872,51 @@ fz_restart: ;                                                    // (merged laun
                                                  (__attribute__((address_space(3))) void*)(dst + i0), 4, 0, 0);
         }
     }
-    // copy list: one entry per wave at a time, all DMA loads in flight together
-    if (g.ls_first >= 0) {                                         // the largest piece first (36 KiB at M = 128), spread over every wave
+    fw_copy_issue(sm, lane, ce0);                                 // copy list: all DMA loads in flight together
+    if (g.ls_first >= 0 && late_big) {                             // the largest piece (36 KiB at M = 128), 1 KiB per wave-instruction
         const FwHot& G0 = gk.H[g.ls_first];
-        async_copy_f32x4(reinterpret_cast<const float*>(G0.LsP), sm + G0.ls_off, tri_blocks(G0.nbk) * BLK16, tid);
+        const float* lsrc = reinterpret_cast<const float*>(G0.LsP);
+        float* ldst = sm + G0.ls_off;
+        const int n4 = (tri_blocks(G0.nbk) * BLK16) >> 2;
+        for (int i0 = dwave * 64; i0 < n4; i0 += dthreads) {
+            const int i = i0 + lane;
+            if (i < n4)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(lsrc + 4 * i),
+                                                 (__attribute__((address_space(3))) void*)(ldst + 4 * i0), 16, 0, 0);
+        }
     }
-    fw_copy_entries(CT, sm, 0, FZ ? g.ncopy_indep : g.ncopy, wave, lane);                // (merged launch: what the factorising workgroups write comes last, below)
-    // noise of every layer -> znoise[z_off + r * NSAMP + j].  Injected [T, dims]: a gather by LDS-DMA (the source is per
-    // lane).  Drawn here: 4 normals per Philox call, the (layer, 4-component group, sample) items of all layers laid end
-    // to end over the workgroup's threads (one item per thread while they fit), overlapping the copies above.
-    {
-        int base = 0;                                              // first thread of the current layer's items
-        for (int li = 0; li < g.n_layers; ++li) {
-            const FwNoise nz = uniform_words(NT[li]);              // one LDS round trip per layer
-            const int dims = nz.dims;
-            float* zdst = znoise + nz.z_off;
-            if (nz.src) {
-                for (int i0 = (tid & ~63); i0 < dims * NSAMP; i0 += FW_THREADS) {
-                    const int i = i0 + lane, r = i / NSAMP, j = i - r * NSAMP;
-                    if (i < dims * NSAMP && j < nvalid)
-                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(nz.src + (size_t)(t0 + j) * dims + r),
-                                                         (__attribute__((address_space(3))) void*)(zdst + i0), 4, 0, 0);
-                }
-                continue;
-            }
-            const int cnt = ((dims + 3) >> 2) * NSAMP;
-            int k = tid - base;
-            if (k < 0) k += FW_THREADS;
-            for (; k < cnt; k += FW_THREADS) {
-                const int q = k / NSAMP, j = k - q * NSAMP;
-                float v[4] = {0.f, 0.f, 0.f, 0.f};
-                if (!nz.zero && j < nvalid) draw_normal4(g.seed, step, g.layer_base + li, t0 + j, q, v);
+    }
+    if (wave < draw_waves) {
+        const int q0 = it_k / NSAMP, j0 = it_k - q0 * NSAMP;
+        float v0[4] = {0.f, 0.f, 0.f, 0.f};
+        if (it_li >= 0 && !it_zero && j0 < nvalid) draw_normal4(g.seed, step, g.layer_base + it_li, t0 + j0, q0, v0);
+        if (it_li >= 0) {
+            float* zdst = znoise + it_zoff;
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (4 * q + e < dims) zdst[(4 * q + e) * NSAMP + j] = v[e];
+            for (int e = 0; e < 4; ++e)
+                if (4 * q0 + e < it_dims) zdst[(4 * q0 + e) * NSAMP + j0] = v0[e];
+        }
+        if (g.noise_drawn > FW_THREADS) {                          // more items than threads: the rest, as they come
+            int base = 0;
+            for (int li = 0; li < g.n_layers; ++li) {
+                const FwNoise nz = uniform_words(NT[li]);
+                if (nz.src) continue;
+                const int dims = nz.dims;
+                float* zdst = znoise + nz.z_off;
+                const int cnt = ((dims + 3) >> 2) * NSAMP;
+                int k = tid - base;
+                if (k < 0) k += FW_THREADS;
+                for (; k < cnt; k += FW_THREADS) {
+                    if (li == it_li && k == it_k) continue;
+                    const int q = k / NSAMP, j = k - q * NSAMP;
+                    float v[4] = {0.f, 0.f, 0.f, 0.f};
+                    if (!nz.zero && j < nvalid) draw_normal4(g.seed, step, g.layer_base + li, t0 + j, q, v);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (4 * q + e < dims) zdst[(4 * q + e) * NSAMP + j] = v[e];
+                }
+                base = (base + cnt) & (FW_THREADS - 1);
             }
-            base = (base + cnt) & (FW_THREADS - 1);
         }
     }
     FW_STAMP(57);
@@ -834,6 +960,13 @@ fz_restart: ;                                                    // (merged laun
         }
     }
     FW_STAMP(58);
+    // the likelihood variance -> LDS (read in the tail, where a global round trip had nothing left to hide behind): by the last wave, whose
+    // copies are all issued -- a scalar load would sit in front of every later lgkmcnt(0) of the wave that issued it, for its whole round trip
+    if (tid == FW_THREADS - 1) {
+        float lv = g.lik_variance;
+        if (g.lik_var_dev) lv = *((gptr1)g.lik_var_dev);
+        sm[g.lds.cnt + 8] = lv;
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     FW_STAMP(59);
     __syncthreads();
@@ -2036,6 +2169,27 @@ static size_t fw_plan_lds(FwArgs& a, int nsamp, int maxR, int maxP, bool stage_z
             break;
         }
     }
+    // who copies the big operands: the waves that draw no noise, when there are at least two of them (kernel: n_early)
+    a.h.noise_drawn = 0; a.h.noise_any_src = 0;
+    for (int i = 0; i < a.h.n_layers; ++i) {
+        const FwLayer& L = a.L[i];
+        const int dims = (L.type == IWVI_LAYER_GP) ? L.gp.R : L.lv.Lw;
+        if (L.noise) a.h.noise_any_src = 1;
+        else a.h.noise_drawn += ((dims + 3) >> 2) * nsamp;
+    }
+    a.h.nz_zero_mask = 0;
+    for (int i = 0; i < IWVI_MAX_STACK; ++i) {
+        const bool in = i < a.h.n_layers;
+        const FwLayer& L = a.L[in ? i : 0];
+        const int dims = (L.type == IWVI_LAYER_GP) ? L.gp.R : L.lv.Lw;
+        a.h.nz_cnt[i] = in ? ((dims + 3) >> 2) * nsamp : 0; a.h.nz_dims[i] = in ? dims : 0; a.h.nz_zoff[i] = in ? L.z_off : 0;
+        if (in && L.zero_noise) a.h.nz_zero_mask |= 1u << i;
+    }
+    {
+        const int draw_waves = a.h.noise_any_src ? FW_WAVES : std::min(FW_WAVES, (a.h.noise_drawn + 63) / 64);
+        a.h.n_early = (!fz && FW_WAVES - draw_waves >= 2) ? FW_WAVES - draw_waves : 0;
+    }
+    a.h.zt_mask = 0;
     // the copy list in two parts: first what no workgroup of a merged launch writes (mixing matrices, mean functions, encoder weights),
     // then the GP layers' constant blocks and Gram operands (ncopy_indep separates them; an ordinary launch issues all of it at once)
     for (int i = 0; i < a.h.n_layers; ++i) {
@@ -2069,7 +2223,15 @@ static size_t fw_plan_lds(FwArgs& a, int nsamp, int maxR, int maxP, bool stage_z
         if (L.type != IWVI_LAYER_GP) continue;
         const FwGp& G = L.gp;
         add_copy(G.cst, IWVI_CST_FLOATS, L.c_off, true);                               // invls[32] | zc[32] | zmax2 | scales
-        if (G.zt_off >= 0) add_copy(G.ZtP, G.nbk * G.nsteps * 64, G.zt_off, true);
+        if (G.zt_off >= 0) {
+            if (a.h.n_early > 0 && (((uintptr_t)G.ZtP) % 16 == 0)) a.h.zt_mask |= 1u << i;
+            else add_copy(G.ZtP, G.nbk * G.nsteps * 64, G.zt_off, true);
+        }
+    }
+    if (a.h.n_early > 0 && a.h.ncopy > a.h.n_early * (FW_MAX_COPY / FW_WAVES)) {          // (the small copies would not fit those waves' registers:
+        for (int i = 0; i < a.h.n_layers; ++i)                                            //  every wave copies, as in a merged launch)
+            if (a.h.zt_mask >> i & 1) add_copy(a.L[i].gp.ZtP, a.L[i].gp.nbk * a.L[i].gp.nsteps * 64, a.L[i].gp.zt_off, true);
+        a.h.n_early = 0; a.h.zt_mask = 0;
     }
     l.cnt = o; o += 12;
     l.scratch = o; o += up4(scratch);
@@ -2264,6 +2426,7 @@ static int dgp_forward_fz(const iwvi_layer_desc* layers, int n_layers, const flo
             if (V.kl_local) fl |= FWF_ANY_OUT;
         }
         H.flags = fl;
+        if (fl & FWF_PRE_ENC) a.h.pre_enc_mask |= 1u << i;
     }
     const long long chunks = (T + 16 * ns - 1) / (16 * ns);
     if (chunks > 0x7fffffffLL) { set_error("iwvi_dgp_forward: T too large"); return IWVI_ERR_ARG; }

@@ -38,7 +38,7 @@ for li, l in enumerate(spec["layers"]):
     for k, n in enumerate(ph):
         if n: names[2 + li * 6 + k] = "L%d %s" % (li, n)
 names[63] = "end"
-for k, n in ((56, "p.ltab+x"), (57, "p.dma-issued"), (58, "p.philox"), (59, "p.vmcnt0")):
+for k, n in ((56, "p.ltab+x"), (40, "p.item-found"), (57, "p.noise-drawn"), (58, "p.(merged)"), (59, "p.vmcnt0")):
     print("%-14s at med %6.2f us after start" % (n, np.median(s[:, k] - s[:, 0]) * 10e-3))
 prev = None
 for k in sorted(names):
