@@ -119,6 +119,7 @@ struct FwElbo {
     double scale;
     const double* klg[FW_MAX_GLOB]; int klg_n[FW_MAX_GLOB];
     float* ms; float* logp; double* elbo; double* ws;
+    int fast;                        // one packed atomic per workgroup carries its partial sum AND its ticket (fw_arrive); decided by the host
 };
 struct FwHead {
     int n_layers;
@@ -464,6 +465,55 @@ __device__ __forceinline__ void fw_copy_entries(const FwCopy* CT, float* sm, int
 // ---- one ticket per workgroup: the last arriver advances the noise stream (every workgroup has read the step counter by
 //      then) and, if asked, finishes the IW-ELBO reduction of models.py:138-150.  Every workgroup of the launch arrives exactly
 //      once, whatever its role (merged launch: the factorising workgroups too -- the last arriver then also closes the generation).
+// The packed arrival (FwElbo::fast; the headline shape): the workgroup's partial sum of the per-point log p travels IN the ticket -- one
+// 64-bit atomic add of  fixed(part) << 18 | overflow << 9 | 1  on rng_state[1]: bits 0-8 count the arrivals, bits 18-63 accumulate the
+// partial sums in units of 2^-20 (integer adds commute: the total does not depend on the order of arrival).  The workgroup whose add returns
+// the count grid-1 holds the complete sum in the returned value and finishes models.py:150 at once.  Before this the end of a launch was
+// three dependent round trips behind the last workgroup's arithmetic -- its partial's write-through store drained, the ticket, the loads of
+// all partials by the last arriver -- and a fourth for the global KL terms (now summed in the prologue): ~4 us of every evaluation.
+// A partial too large for its share of the 46-bit field (|part| >= 2^17: every workgroup's share, so that no total can overflow) is stored
+// exactly, tagged with the evaluation's number and drained BEFORE the add, which then carries 0 and counts in bits 9-17; the last arriver
+// adds those partials from memory (a cold path: one more round trip, only when it happens).
+constexpr double FX_UNIT = 1048576.0;                              // 2^20 units per 1.0
+constexpr double FX_PART_MAX = 137438953472.0;                     // 2^37 units = 2^17: a workgroup's share (<= 511 arrivals, 46-bit field)
+template <int NS, bool FZ>
+__device__ __forceinline__ void fw_arrive_fast(const FwArgs& gk, float* sm, int tid, int chunk_id, double part, unsigned long long step) {
+    const FwHead& g = gk.h;
+    if (tid != 0) return;
+    const FwElbo& E = g.e;
+    const double sc = part * FX_UNIT;
+    const bool ovf = !(fabs(sc) < FX_PART_MAX);                    // (a NaN partial goes the exact way too)
+    const long long fx = ovf ? 0LL : __double2ll_rn(sc);
+    if (ovf && chunk_id >= 0) {
+        __hip_atomic_store(E.ws + chunk_id, part, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(reinterpret_cast<unsigned long long*>(E.ws) + g.nchunks + chunk_id, step + 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    const unsigned long long add = ((unsigned long long)fx << 18) + (ovf ? 512ULL : 0ULL) + 1ULL;
+    const unsigned long long old = __hip_atomic_fetch_add(&g.rng_state[1], add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if ((unsigned)(old & 511ULL) != gridDim.x - 1) return;
+    __hip_atomic_store(&g.rng_state[1], 0ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_fetch_add(&g.rng_state[0], 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if constexpr (FZ) __hip_atomic_fetch_add(&gk.z.sync->gen, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    double tot = (double)(((long long)old >> 18) + fx) * (1.0 / FX_UNIT);                 // (arithmetic shift: the field's sign)
+    if ((unsigned)(old >> 9 & 511ULL) + (ovf ? 1u : 0u)) {
+        for (int c = 0; c < g.nchunks; ++c)
+            if (__hip_atomic_load(reinterpret_cast<unsigned long long*>(E.ws) + g.nchunks + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == step + 1ULL)
+                tot += __hip_atomic_load(E.ws + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    double kl = 0.0;
+    if constexpr (FZ) {                                            // (the KL shares are written by workgroups of this launch)
+        if (chunk_id < 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        for (int i = 0; i < E.n_glob; ++i)
+            for (int c = 0; c < E.klg_n[i]; ++c) kl += E.klg[i][c];
+    } else kl = *reinterpret_cast<const double*>(sm + g.lds.cnt + 10);                   // (summed in the prologue)
+    double val = tot * E.scale - kl;                                                       // models.py:150
+    if constexpr (FZ) {
+        if (__hip_atomic_load(&gk.z.sync->timeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) val = __builtin_nan("");
+    }
+    *E.elbo = val;
+}
+
 template <int NS, bool FZ>
 __device__ __forceinline__ void fw_arrive(const FwArgs& gk, float* sm, int tid, int chunk_id) {
     constexpr int NSAMP = 16 * NS;
@@ -616,7 +666,8 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
                                           z.resume ? &z.sync->snap[tk] : nullptr, fz_gen + 1u, &z.sync->pack, (fz_gen + 1u) * (unsigned)z.n_pack, &z.sync->timeout});
             __syncthreads();
             if (!z.resume) {
-                fw_arrive<NS, FZ>(gk, sm, tid, -1);
+                if (g.e.fast) fw_arrive_fast<NS, FZ>(gk, sm, tid, -1, 0.0, g.rng_state ? *((const __attribute__((address_space(4))) unsigned long long*)g.rng_state) : 0ULL);
+                else fw_arrive<NS, FZ>(gk, sm, tid, -1);
                 return;
             }
             fz_mode = 2; fz_slot = tk; fz_chunk = z.nchunks_reg + tk;      // carries on with the chunk its helper has prepared
@@ -966,6 +1017,13 @@ fz_restart: ;                                                    // (merged laun
         float lv = g.lik_variance;
         if (g.lik_var_dev) lv = *((gptr1)g.lik_var_dev);
         sm[g.lds.cnt + 8] = lv;
+    }
+    if (!FZ && g.e.fast && tid == FW_THREADS - 2) {               // the global KL terms (models.py:150), for whichever workgroup arrives last
+        const FwElbo& E = g.e;
+        double kl = 0.0;
+        for (int i = 0; i < E.n_glob; ++i)
+            for (int c = 0; c < E.klg_n[i]; ++c) kl += E.klg[i][c];
+        *reinterpret_cast<double*>(sm + g.lds.cnt + 10) = kl;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     FW_STAMP(59);
@@ -1987,11 +2045,22 @@ fz_restart: ;                                                    // (merged laun
         if (tid == 0) {
             double part = 0.0;
             for (int p = 0; p < npl; ++p) part += (double)xt[p];                       // fixed order
-            __hip_atomic_store(E.ws + chunk_id, part, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (E.fast) { fw_arrive_fast<NS, FZ>(gk, sm, tid, chunk_id, part, step); }
+            else __hip_atomic_store(E.ws + chunk_id, part, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+        if (E.fast) return;                                                            // (uniform)
     }
     fw_arrive<NS, FZ>(gk, sm, tid, chunk_id);
     }
+}
+
+// the packed arrival (fw_arrive_fast) applies when every point's K samples sit in one chunk (the kernel's local_lse), the launch finishes the
+// ELBO itself, its arrivals fit the 9-bit count and the scratch holds a tagged slot per chunk for the exact (overflow) path
+static void fw_decide_fast(FwArgs& a, unsigned grid, int nsamp, int64_t T) {
+    const FwElbo& E = a.h.e;
+    const int64_t ws_len = (T + 15) / 16;
+    a.h.e.fast = (E.enabled && E.ws && E.elbo && !E.mode_vi && E.stride_k == 1 && E.stride_b == E.K && E.K > 0 && (nsamp % E.K) == 0 &&
+                  a.h.rng_state && grid <= 511u && 2 * (int64_t)a.h.nchunks <= ws_len && !dbg_opt("IWVI_FW_SLOW_TAIL")) ? 1 : 0;
 }
 
 template <int NS, bool S16, bool FZ = false>
@@ -2449,6 +2518,7 @@ static int dgp_forward_fz(const iwvi_layer_desc* layers, int n_layers, const flo
         z.n_ticket = z.resume ? (int)chunks : z.n_gp + (int)chunks;
         for (int k = 0; k < z.n_gp; ++k) { const size_t la = factor_lds_bytes(z.P[k].Mp); if (la > lds_bytes) lds_bytes = la; }
         const unsigned grid = (unsigned)z.n_ticket;
+        fw_decide_fast(a, grid, 16 * ns, T);
         if (s16_all) switch (ns) {
 #ifndef IWVI_DEV_ONLY5   /* development builds: only the 80-sample variants (make DEV5=1) */
             case 1: return launch_forward<1, true, true>(a, grid, lds_bytes, stream);
@@ -2468,6 +2538,7 @@ static int dgp_forward_fz(const iwvi_layer_desc* layers, int n_layers, const flo
             default: return launch_forward<5, false, true>(a, grid, lds_bytes, stream);
         }
     }
+    fw_decide_fast(a, (unsigned)chunks, 16 * ns, T);
     if (s16_all) switch (ns) {
 #ifndef IWVI_DEV_ONLY5   /* development builds: only the 80-sample variants (make DEV5=1) */
         case 1: return launch_forward<1, true>(a, (unsigned)chunks, lds_bytes, stream);

@@ -258,8 +258,11 @@ typedef struct iwvi_elbo_desc {
     const double* const* kl_global; const int32_t* kl_global_counts; int32_t n_glob;
     double scale; int32_t K_total, mode_vi;
     float* out_lse_ms; float* out_logp; double* out_elbo;
-    double* ws;                     /* optional scratch, ceil(T/16) doubles: one partial sum per workgroup when every
-                                     * point's K samples sit in one chunk; NULL -> the last workgroup reads all of out_logw */
+    double* ws;                     /* optional scratch, ceil(T/16) doubles, used when every point's K samples sit in one chunk (NULL -> the
+                                     * last workgroup reads all of out_logw): one partial sum per workgroup; with out_elbo given and at
+                                     * most 511 workgroups the partial sums travel in the workgroups' tickets instead (a 64-bit atomic on
+                                     * rng_state[1]) and ws only holds, tagged with the evaluation's number, the partial sums too large
+                                     * for that fixed-point field.  Contents are scratch either way */
     /* when the leading LatentVariableLayer was evaluated by iwvi_model_precompute (iwvi_enc_desc.sample_X): its local
      * regulariser per sample [T] (subtracted from the log-weights like models.py:141-142), and the position of this
      * stack's first layer in the model, so that its noise streams do not collide with that layer's; x_per_sample:
