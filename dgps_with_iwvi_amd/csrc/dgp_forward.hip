@@ -119,6 +119,7 @@ struct FwElbo {
     double scale;
     const double* klg[FW_MAX_GLOB]; int klg_n[FW_MAX_GLOB];
     float* ms; float* logp; double* elbo; double* ws;
+    int kl_total;                    // entries of all klg arrays together
     int fast;                        // one packed atomic per workgroup carries its partial sum AND its ticket (fw_arrive); decided by the host
 };
 struct FwHead {
@@ -142,6 +143,7 @@ struct FwHead {
     int nz_cnt[IWVI_MAX_STACK], nz_zoff[IWVI_MAX_STACK], nz_dims[IWVI_MAX_STACK];   // the noise plan of a stack that draws all of its noise: items, slot,
     unsigned nz_zero_mask;           // components per layer + which layers' noise is zero -- in the header: scalar loads, no table walk in LDS
     int noise_drawn, noise_any_src;  // prologue: (layer, 4-component group, sample) items drawn in the kernel; any layer with injected noise
+    unsigned var_dev_mask;           // layers whose kernel variance is a device scalar (var_dev[layer]); the prologue fetches them into LDS
     unsigned pre_enc_mask;           // LV layers whose encoder output was evaluated before this launch (bit = layer): the prologue gathers their rows
     const float* lw_init;            // optional [T]: local regularisers of layers evaluated before this launch (summed per sample)
     int layer_base;                  // index of this stack's first layer in the model (keys the noise streams)
@@ -479,19 +481,38 @@ constexpr double FX_PART_MAX = 137438953472.0;                     // 2^37 units
 template <int NS, bool FZ>
 __device__ __forceinline__ void fw_arrive_fast(const FwArgs& gk, float* sm, int tid, int chunk_id, double part, unsigned long long step) {
     const FwHead& g = gk.h;
-    if (tid != 0) return;
+    if (tid >= 64) return;
     const FwElbo& E = g.e;
+    // the global KL terms (models.py:150): entry `lane` of the klg arrays laid end to end, requested by EVERY workgroup just before its
+    // ticket -- whichever arrives last has them back together with the ticket's answer (one round trip, not two)
+    double kl_lane = 0.0;
+    if (!FZ && tid < E.kl_total) {
+        int idx = tid;
+        const double* src = nullptr;
+        for (int i = 0; i < E.n_glob; ++i) {
+            if (!src && idx < E.klg_n[i]) src = E.klg[i] + idx;
+            idx -= E.klg_n[i];
+        }
+        if (src) kl_lane = *((const __attribute__((address_space(1))) double*)src);
+    }
+    part = readlane_d(part, 0);
     const double sc = part * FX_UNIT;
     const bool ovf = !(fabs(sc) < FX_PART_MAX);                    // (a NaN partial goes the exact way too)
     const long long fx = ovf ? 0LL : __double2ll_rn(sc);
-    if (ovf && chunk_id >= 0) {
+    if (ovf && chunk_id >= 0 && tid == 0) {
         __hip_atomic_store(E.ws + chunk_id, part, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(reinterpret_cast<unsigned long long*>(E.ws) + g.nchunks + chunk_id, step + 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     const unsigned long long add = ((unsigned long long)fx << 18) + (ovf ? 512ULL : 0ULL) + 1ULL;
-    const unsigned long long old = __hip_atomic_fetch_add(&g.rng_state[1], add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned long long old = 0ULL;
+    if (tid == 0) old = __hip_atomic_fetch_add(&g.rng_state[1], add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    old = (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)old) |
+          ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(old >> 32)) << 32);
     if ((unsigned)(old & 511ULL) != gridDim.x - 1) return;
+    double kl_sum = 0.0;                                           // (in the arrays' order, like the loop it replaces)
+    if constexpr (!FZ) { for (int k = 0; k < E.kl_total; ++k) kl_sum += readlane_d(kl_lane, k); }
+    if (tid != 0) return;
     __hip_atomic_store(&g.rng_state[1], 0ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_fetch_add(&g.rng_state[0], 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if constexpr (FZ) __hip_atomic_fetch_add(&gk.z.sync->gen, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -506,7 +527,7 @@ __device__ __forceinline__ void fw_arrive_fast(const FwArgs& gk, float* sm, int 
         if (chunk_id < 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         for (int i = 0; i < E.n_glob; ++i)
             for (int c = 0; c < E.klg_n[i]; ++c) kl += E.klg[i][c];
-    } else kl = *reinterpret_cast<const double*>(sm + g.lds.cnt + 10);                   // (summed in the prologue)
+    } else kl = kl_sum;
     double val = tot * E.scale - kl;                                                       // models.py:150
     if constexpr (FZ) {
         if (__hip_atomic_load(&gk.z.sync->timeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) val = __builtin_nan("");
@@ -788,7 +809,7 @@ fz_restart: ;                                                    // (merged laun
     //      LDS in front of the first barrier (the compiler would make them wait for the copies there) and wait at their first table read behind
     //      it.  (Measured and rejected: the small copies and the row gathers issued here as well, entries read from the kernel arguments
     //      -- these waves then reach the first barrier at 2.0-2.3 us instead of 1.0, in either order; the small copies given to the drawing
-    //      waves -- they queue behind the big ones in the CU's address unit, 0.6 us per wave.)
+    //      waves -- in front of their draws they queue behind the big ones in the CU's address unit, 0.6 us per wave; behind their draws: no change.)
     if (early_wave) {
         const int dw = FW_WAVES - 1 - wave, dth = n_early * 64;
         if (g.ls_first >= 0) {
@@ -1011,19 +1032,13 @@ fz_restart: ;                                                    // (merged laun
         }
     }
     FW_STAMP(58);
-    // the likelihood variance -> LDS (read in the tail, where a global round trip had nothing left to hide behind): by the last wave, whose
-    // copies are all issued -- a scalar load would sit in front of every later lgkmcnt(0) of the wave that issued it, for its whole round trip
-    if (tid == FW_THREADS - 1) {
-        float lv = g.lik_variance;
-        if (g.lik_var_dev) lv = *((gptr1)g.lik_var_dev);
-        sm[g.lds.cnt + 8] = lv;
-    }
-    if (!FZ && g.e.fast && tid == FW_THREADS - 2) {               // the global KL terms (models.py:150), for whichever workgroup arrives last
-        const FwElbo& E = g.e;
-        double kl = 0.0;
-        for (int i = 0; i < E.n_glob; ++i)
-            for (int c = 0; c < E.klg_n[i]; ++c) kl += E.klg[i][c];
-        *reinterpret_cast<double*>(sm + g.lds.cnt + 10) = kl;
+    // the launch's device scalars -> LDS (likelihood variance: read in the tail; kernel variances: read at the top of a layer -- a global round
+    // trip has nothing to hide behind in either place): one per lane of the last wave, whose copies are all issued.  (A scalar load would sit
+    // in front of every later lgkmcnt(0) of its wave for its whole round trip; requested at the top of the kernel instead, the address
+    // arithmetic kept this wave from the first barrier: +0.3 us for everybody.)
+    if (wave == FW_WAVES - 1) {
+        if (lane == 63) { float lv = g.lik_variance; if (g.lik_var_dev) lv = *((gptr1)g.lik_var_dev); sm[g.lds.cnt + 8] = lv; }
+        if (lane >= 48 && lane < 48 + IWVI_MAX_STACK && (g.var_dev_mask >> (lane - 48) & 1u)) sm[g.lds.cnt + 12 + (lane - 48)] = *((gptr1)g.var_dev[lane - 48]);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     FW_STAMP(59);
@@ -1037,7 +1052,18 @@ fz_restart: ;                                                    // (merged laun
             if (fz_resume && li < gk.z.first_gp) { float* tmp = xin; xin = xout; xout = tmp; continue; }   // (the helper ran these layers)
         }
         const FwLayer& L = LT[li];
-        const FwHot& H = gk.H[li];                                // scalar loads from the (warmed) kernel-argument lines
+        // the layer's 32 hot words: ONE pair of wide scalar loads from the (warmed) kernel-argument lines, then opaque registers.  Read through
+        // a reference, every field was re-loaded next to each use (the compiler rematerialises loads of the kernel arguments instead of
+        // keeping them) -- nine dependent scalar-cache round trips at the top of a layer, ~0.5 us per layer boundary
+        FwHot Hv;
+        {
+            uint32_t hw_[sizeof(FwHot) / 4];
+            __builtin_memcpy(hw_, &gk.H[li], sizeof(FwHot));
+#pragma unroll
+            for (int i = 0; i < (int)(sizeof(FwHot) / 4); ++i) asm volatile("" : "+s"(hw_[i]));
+            __builtin_memcpy(&Hv, hw_, sizeof(FwHot));
+        }
+        const FwHot& H = Hv;
         const FwHot& G = H;
         const int D = H.D;
         const float* cst = sm + H.c_off;
@@ -1134,9 +1160,8 @@ fz_restart: ;                                                    // (merged laun
         } else {
             // ================= GPLayer (layers.py:35-50) ==============================================
             const int nbk = G.nbk, R = G.R, P = G.P, nsteps = G.nsteps;
-            const float* vdev = g.var_dev[li];
-            float g_variance = G.variance;                        // (a select between a device pointer and the argument's own address is a FLAT load)
-            if (vdev) g_variance = *((gptr1)vdev);
+            float g_variance = G.variance;
+            if (g.var_dev_mask >> li & 1u) g_variance = sm[g.lds.cnt + 12 + li];          // (a device scalar: fetched in the prologue)
             f32x4* kuf = reinterpret_cast<f32x4*>(scratch);
             f32x4* at = kuf;                                       // solved in place (stage 1)
             float* usq = scratch + (size_t)G.Mp * NSAMP;           // [wave][r][NSAMP]
@@ -2042,13 +2067,12 @@ fz_restart: ;                                                    // (merged laun
             xt[tid] = lp;
         }
         __syncthreads();
+        double part = 0.0;
         if (tid == 0) {
-            double part = 0.0;
             for (int p = 0; p < npl; ++p) part += (double)xt[p];                       // fixed order
-            if (E.fast) { fw_arrive_fast<NS, FZ>(gk, sm, tid, chunk_id, part, step); }
-            else __hip_atomic_store(E.ws + chunk_id, part, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (!E.fast) __hip_atomic_store(E.ws + chunk_id, part, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        if (E.fast) return;                                                            // (uniform)
+        if (E.fast) { fw_arrive_fast<NS, FZ>(gk, sm, tid, chunk_id, part, step); return; }   // (uniform)
     }
     fw_arrive<NS, FZ>(gk, sm, tid, chunk_id);
     }
@@ -2060,7 +2084,7 @@ static void fw_decide_fast(FwArgs& a, unsigned grid, int nsamp, int64_t T) {
     const FwElbo& E = a.h.e;
     const int64_t ws_len = (T + 15) / 16;
     a.h.e.fast = (E.enabled && E.ws && E.elbo && !E.mode_vi && E.stride_k == 1 && E.stride_b == E.K && E.K > 0 && (nsamp % E.K) == 0 &&
-                  a.h.rng_state && grid <= 511u && 2 * (int64_t)a.h.nchunks <= ws_len && !dbg_opt("IWVI_FW_SLOW_TAIL")) ? 1 : 0;
+                  a.h.rng_state && grid <= 511u && 2 * (int64_t)a.h.nchunks <= ws_len && E.kl_total <= 64 && !dbg_opt("IWVI_FW_SLOW_TAIL")) ? 1 : 0;
 }
 
 template <int NS, bool S16, bool FZ = false>
@@ -2302,7 +2326,7 @@ static size_t fw_plan_lds(FwArgs& a, int nsamp, int maxR, int maxP, bool stage_z
             if (a.h.zt_mask >> i & 1) add_copy(a.L[i].gp.ZtP, a.L[i].gp.nbk * a.L[i].gp.nsteps * 64, a.L[i].gp.zt_off, true);
         a.h.n_early = 0; a.h.zt_mask = 0;
     }
-    l.cnt = o; o += 12;
+    l.cnt = o; o += 24;                                  // 12 counters / scalars, then one kernel variance per layer (device scalars, fetched in the prologue)
     l.scratch = o; o += up4(scratch);
     l.total = o;
     a.z.snap_a0 = l.xa; a.z.snap_a1 = l.asq; a.z.snap_b0 = l.znoise; a.z.snap_b1 = l.znoise + up4(zdims * nsamp);
@@ -2361,6 +2385,7 @@ static int dgp_forward_fz(const iwvi_layer_desc* layers, int n_layers, const flo
             G.M = d.M; G.Mp = s.Mp; G.nbk = s.nbk; G.nrb = s.nrb; G.nsteps = round_up(D + 2, 4) / 4;
             G.R = d.R; G.P = d.P; G.kern_type = d.kern_type; G.mf_type = d.mf_type; G.variance = d.variance;
             a.h.var_dev[i] = d.variance_dev;
+            if (d.variance_dev) a.h.var_dev_mask |= 1u << i;
             G.s16 = s16_all ? 1 : 0;
             if (G.s16) { G.LrTP = (const f32x4*)(st + s.off_LrT16); G.QmuP = (const f32x4*)(st + s.off_Qmu16); }
             plan_stage2(G);
@@ -2413,6 +2438,7 @@ static int dgp_forward_fz(const iwvi_layer_desc* layers, int n_layers, const flo
             E.klg[i] = elbo->kl_global[i];
             E.klg_n[i] = elbo->kl_global_counts ? elbo->kl_global_counts[i] : 1;
             if (E.klg_n[i] <= 0 || E.klg_n[i] > IWVI_MAX_R) { set_error("iwvi_dgp_forward: bad global KL count %d", E.klg_n[i]); return IWVI_ERR_ARG; }
+            E.kl_total += E.klg_n[i];
         }
         E.ms = elbo->out_lse_ms; E.logp = elbo->out_logp; E.elbo = elbo->out_elbo; E.ws = elbo->ws;
         a.h.lw_init = elbo->lw_init; a.h.layer_base = elbo->noise_layer_base; a.h.x_per_sample = elbo->x_per_sample;
