@@ -113,15 +113,32 @@ struct FwLds { int ltab, xa, xb, xt, lw, rowi, pidx, asq, meanp, gbuf, obuf, zno
 // cold 3-KiB kernarg segment costs a memory round trip per 64 bytes, serialised by the control flow.
 constexpr int FW_MAX_GLOB = 16;
 // optional tail: the last workgroup to finish performs models.py:138-150 on the log-weights
-struct FwElbo {
+struct FwElboHot {                   // what the end of the kernel reads: 24 words, fetched as ONE block of scalar loads (k_dgp_forward: tail)
     int enabled, K, K_total, mode_vi, n_glob;
-    long long B, stride_b, stride_k;
-    double scale;
-    const double* klg[FW_MAX_GLOB]; int klg_n[FW_MAX_GLOB];
-    float* ms; float* logp; double* elbo; double* ws;
     int kl_total;                    // entries of all klg arrays together
     int fast;                        // one packed atomic per workgroup carries its partial sum AND its ticket (fw_arrive); decided by the host
+    int pad0;
+    long long B, stride_b, stride_k;
+    double scale;
+    float* ms; float* logp; double* elbo; double* ws;
 };
+static_assert(sizeof(FwElboHot) == 96, "one s_load_dwordx16 + one s_load_dwordx8");
+struct FwElbo : FwElboHot {
+    const double* klg[FW_MAX_GLOB]; int klg_n[FW_MAX_GLOB];
+};
+// a block of kernel-argument words as registers the compiler cannot rematerialise: it treats kernel-argument loads as free to repeat and
+// re-loads a field next to each use -- one dependent scalar-cache round trip per field on whatever path reads them
+template <class T>
+__device__ __forceinline__ T opaque_block(const T& src) {
+    static_assert(sizeof(T) % 4 == 0, "whole words");
+    uint32_t w[sizeof(T) / 4];
+    __builtin_memcpy(w, &src, sizeof(T));
+#pragma unroll
+    for (int i = 0; i < (int)(sizeof(T) / 4); ++i) asm volatile("" : "+s"(w[i]));
+    T v;
+    __builtin_memcpy(&v, w, sizeof(T));
+    return v;
+}
 struct FwHead {
     int n_layers;
     const float* X; const float* XY; const float* Y;
@@ -479,19 +496,28 @@ __device__ __forceinline__ void fw_copy_entries(const FwCopy* CT, float* sm, int
 constexpr double FX_UNIT = 1048576.0;                              // 2^20 units per 1.0
 constexpr double FX_PART_MAX = 137438953472.0;                     // 2^37 units = 2^17: a workgroup's share (<= 511 arrivals, 46-bit field)
 template <int NS, bool FZ>
-__device__ __forceinline__ void fw_arrive_fast(const FwArgs& gk, float* sm, int tid, int chunk_id, double part, unsigned long long step) {
-    const FwHead& g = gk.h;
+__device__ __forceinline__ void fw_arrive_fast(const FwArgs& gk, const FwElboHot& E, unsigned long long* rng, int nchunks, int tid, int chunk_id,
+                                               double part, unsigned long long step) {
     if (tid >= 64) return;
-    const FwElbo& E = g.e;
     // the global KL terms (models.py:150): entry `lane` of the klg arrays laid end to end, requested by EVERY workgroup just before its
-    // ticket -- whichever arrives last has them back together with the ticket's answer (one round trip, not two)
+    // ticket -- whichever arrives last has them back together with the ticket's answer (one round trip, not two).  The first four arrays'
+    // pointers and counts as one batch of scalar loads; further arrays (a stack of more than four GP layers) one by one
     double kl_lane = 0.0;
     if (!FZ && tid < E.kl_total) {
+        struct KlHead { const double* p[4]; int n[4]; };
+        const KlHead kh = opaque_block(KlHead{{gk.h.e.klg[0], gk.h.e.klg[1], gk.h.e.klg[2], gk.h.e.klg[3]},
+                                               {gk.h.e.klg_n[0], gk.h.e.klg_n[1], gk.h.e.klg_n[2], gk.h.e.klg_n[3]}});
         int idx = tid;
         const double* src = nullptr;
-        for (int i = 0; i < E.n_glob; ++i) {
-            if (!src && idx < E.klg_n[i]) src = E.klg[i] + idx;
-            idx -= E.klg_n[i];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int n = i < E.n_glob ? kh.n[i] : 0;
+            if (!src && idx < n) src = kh.p[i] + idx;
+            idx -= n;
+        }
+        for (int i = 4; i < E.n_glob; ++i) {
+            if (!src && idx < gk.h.e.klg_n[i]) src = gk.h.e.klg[i] + idx;
+            idx -= gk.h.e.klg_n[i];
         }
         if (src) kl_lane = *((const __attribute__((address_space(1))) double*)src);
     }
@@ -501,32 +527,32 @@ __device__ __forceinline__ void fw_arrive_fast(const FwArgs& gk, float* sm, int 
     const long long fx = ovf ? 0LL : __double2ll_rn(sc);
     if (ovf && chunk_id >= 0 && tid == 0) {
         __hip_atomic_store(E.ws + chunk_id, part, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(reinterpret_cast<unsigned long long*>(E.ws) + g.nchunks + chunk_id, step + 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(reinterpret_cast<unsigned long long*>(E.ws) + nchunks + chunk_id, step + 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     const unsigned long long add = ((unsigned long long)fx << 18) + (ovf ? 512ULL : 0ULL) + 1ULL;
     unsigned long long old = 0ULL;
-    if (tid == 0) old = __hip_atomic_fetch_add(&g.rng_state[1], add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0) old = __hip_atomic_fetch_add(&rng[1], add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     old = (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)old) |
           ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(old >> 32)) << 32);
     if ((unsigned)(old & 511ULL) != gridDim.x - 1) return;
     double kl_sum = 0.0;                                           // (in the arrays' order, like the loop it replaces)
     if constexpr (!FZ) { for (int k = 0; k < E.kl_total; ++k) kl_sum += readlane_d(kl_lane, k); }
     if (tid != 0) return;
-    __hip_atomic_store(&g.rng_state[1], 0ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_fetch_add(&g.rng_state[0], 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&rng[1], 0ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_fetch_add(&rng[0], 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if constexpr (FZ) __hip_atomic_fetch_add(&gk.z.sync->gen, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     double tot = (double)(((long long)old >> 18) + fx) * (1.0 / FX_UNIT);                 // (arithmetic shift: the field's sign)
     if ((unsigned)(old >> 9 & 511ULL) + (ovf ? 1u : 0u)) {
-        for (int c = 0; c < g.nchunks; ++c)
-            if (__hip_atomic_load(reinterpret_cast<unsigned long long*>(E.ws) + g.nchunks + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == step + 1ULL)
+        for (int c = 0; c < nchunks; ++c)
+            if (__hip_atomic_load(reinterpret_cast<unsigned long long*>(E.ws) + nchunks + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == step + 1ULL)
                 tot += __hip_atomic_load(E.ws + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     double kl = 0.0;
     if constexpr (FZ) {                                            // (the KL shares are written by workgroups of this launch)
         if (chunk_id < 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         for (int i = 0; i < E.n_glob; ++i)
-            for (int c = 0; c < E.klg_n[i]; ++c) kl += E.klg[i][c];
+            for (int c = 0; c < gk.h.e.klg_n[i]; ++c) kl += gk.h.e.klg[i][c];
     } else kl = kl_sum;
     double val = tot * E.scale - kl;                                                       // models.py:150
     if constexpr (FZ) {
@@ -661,6 +687,18 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
 #pragma unroll
         for (int i = 0; i < (int)(offsetof(FwArgs, L) / 64); ++i) warm |= kw[16 * i];
         asm volatile("" :: "s"(warm));
+    } else {
+        // the same for the header and the hot layer descriptors, FIRST thing and waited for at once: the header's fields are read all over
+        // the prologue, and the first reads of lines that had not arrived yet were cold round trips one behind the other (the branch on
+        // n_early alone cost one) -- one cold round trip for everything, scalar-cache hits from then on
+        unsigned warm = 0;
+        const unsigned* kw = reinterpret_cast<const unsigned*>(&gk);
+#pragma unroll
+        for (int i = 0; i < (int)((sizeof(FwHead) + 63) / 64); ++i) warm |= kw[16 * i];
+        const unsigned* hw = reinterpret_cast<const unsigned*>(&gk.H[0]);
+#pragma unroll
+        for (int i = 0; i < (int)(sizeof(FwHot) * IWVI_MAX_STACK / 64); ++i) warm |= hw[16 * i];
+        asm volatile("" :: "s"(warm));
     }
     if constexpr (FZ) {
         // ---- role by ticket: whoever starts first factorises (nothing below ever waits for a workgroup that has not started) ----
@@ -687,7 +725,8 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
                                           z.resume ? &z.sync->snap[tk] : nullptr, fz_gen + 1u, &z.sync->pack, (fz_gen + 1u) * (unsigned)z.n_pack, &z.sync->timeout});
             __syncthreads();
             if (!z.resume) {
-                if (g.e.fast) fw_arrive_fast<NS, FZ>(gk, sm, tid, -1, 0.0, g.rng_state ? *((const __attribute__((address_space(4))) unsigned long long*)g.rng_state) : 0ULL);
+                if (g.e.fast) fw_arrive_fast<NS, FZ>(gk, static_cast<const FwElboHot&>(g.e), g.rng_state, g.nchunks, tid, -1, 0.0,
+                                                      g.rng_state ? *((const __attribute__((address_space(4))) unsigned long long*)g.rng_state) : 0ULL);
                 else fw_arrive<NS, FZ>(gk, sm, tid, -1);
                 return;
             }
@@ -728,15 +767,6 @@ fz_restart: ;                                                    // (merged laun
     const long long t0 = (long long)chunk_id * NSAMP;
     const int nvalid = (int)((g.T - t0) < (long long)NSAMP ? (g.T - t0) : (long long)NSAMP);
 
-    // ---- the hot layer descriptors: one word of each 64-byte line requested through the scalar cache now (all in
-    //      flight beside the header's own miss); consumed -- i.e. waited for -- just before the first barrier --------
-    unsigned hot_touch = 0;
-    {
-        const unsigned* hw = reinterpret_cast<const unsigned*>(&gk.H[0]);
-#pragma unroll
-        for (int i = 0; i < (int)(sizeof(FwHot) * IWVI_MAX_STACK / 64); ++i) hot_touch |= hw[16 * i];
-        hot_touch |= (unsigned)g.nz_cnt[0] | (unsigned)g.nz_zoff[0] | (unsigned)g.nz_dims[0] | g.nz_zero_mask;   // (the noise plan's lines of the header)
-    }
     // ---- the last n_early waves (those that draw no noise below) issue every copy of the prologue; the others fetch the layer table and the
     //      chunk's rows (below: "the prologue's copies")
     const int n_early = FZ ? 0 : g.n_early;
@@ -855,7 +885,6 @@ fz_restart: ;                                                    // (merged laun
         }
     }
     }
-    asm volatile("" :: "s"(hot_touch));                           // (the scalar-cache lines of gk.H have landed)
     // layer table (and rowi / pidx) visible.  Not __syncthreads(): its release half waits for vmcnt(0), i.e. for the early waves' copies --
     // this wave's LDS stores are what the others need, and those are done at lgkmcnt(0)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1055,14 +1084,7 @@ fz_restart: ;                                                    // (merged laun
         // the layer's 32 hot words: ONE pair of wide scalar loads from the (warmed) kernel-argument lines, then opaque registers.  Read through
         // a reference, every field was re-loaded next to each use (the compiler rematerialises loads of the kernel arguments instead of
         // keeping them) -- nine dependent scalar-cache round trips at the top of a layer, ~0.5 us per layer boundary
-        FwHot Hv;
-        {
-            uint32_t hw_[sizeof(FwHot) / 4];
-            __builtin_memcpy(hw_, &gk.H[li], sizeof(FwHot));
-#pragma unroll
-            for (int i = 0; i < (int)(sizeof(FwHot) / 4); ++i) asm volatile("" : "+s"(hw_[i]));
-            __builtin_memcpy(&Hv, hw_, sizeof(FwHot));
-        }
+        const FwHot Hv = opaque_block(gk.H[li]);
         const FwHot& H = Hv;
         const FwHot& G = H;
         const int D = H.D;
@@ -2031,14 +2053,19 @@ fz_restart: ;                                                    // (merged laun
     //      regularisers (:140-142) ----------------------------------------------------------------------
     // chunk-local reduction: with the IW tiling and K | NSAMP every data point's K samples sit in one chunk, so
     // logsumexp_k happens here from LDS and only one partial sum per workgroup crosses workgroups
-    const bool local_lse = g.e.enabled && g.e.ws && !g.e.mode_vi && g.e.stride_k == 1 && g.e.stride_b == g.e.K &&
-                           (NSAMP % g.e.K) == 0;
-    if (g.out_logw && tid < nvalid) {
-        const int Dy = g.Dy;
-        const float likv = sm[g.lds.cnt + 8];                      // (prologue)
+    // (what this tail reads of the kernel arguments, requested together: read where they are used, each field was its own scalar-cache round
+    //  trip on the one path every workgroup ends with -- fourteen of them, one after the other)
+    const FwElboHot Eh = opaque_block(static_cast<const FwElboHot&>(g.e));
+    struct TailHot { float* out_logw; unsigned long long* rng; int Dy, yrows, cnt, nchunks; };
+    const TailHot th = opaque_block(TailHot{g.out_logw, g.rng_state, g.Dy, g.lds.yrows, g.lds.cnt, g.nchunks});
+    const bool local_lse = Eh.enabled && Eh.ws && !Eh.mode_vi && Eh.stride_k == 1 && Eh.stride_b == Eh.K &&
+                           (NSAMP % Eh.K) == 0;
+    if (th.out_logw && tid < nvalid) {
+        const int Dy = th.Dy;
+        const float likv = sm[th.cnt + 8];                         // (prologue)
         const float c0 = -0.5f * 1.8378770664093453f - 0.5f * logf(likv);
         const float inv2s = 0.5f / likv;
-        const float* yrows = sm + g.lds.yrows;
+        const float* yrows = sm + th.yrows;
         float acc = 0.f;
         for (int d = 0; d < Dy; ++d) {
             const float df = yrows[d * NSAMP + tid] - obuf[d * NSAMP + tid];
@@ -2046,12 +2073,12 @@ fz_restart: ;                                                    // (merged laun
         }
         const float lwv = acc - lw[tid];
         // write-through (sc1) store: the last workgroup may read every log-weight without an acquire fence
-        __hip_atomic_store(g.out_logw + t0 + tid, lwv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(th.out_logw + t0 + tid, lwv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         lw[tid] = lwv;
     }
     FW_STAMP(63);
     if (local_lse) {
-        const FwElbo& E = g.e;
+        const FwElboHot& E = Eh;
         const int K = E.K, npl = nvalid / K;                      // complete points of this chunk
         __syncthreads();
         float lp = 0.f;
@@ -2072,7 +2099,7 @@ fz_restart: ;                                                    // (merged laun
             for (int p = 0; p < npl; ++p) part += (double)xt[p];                       // fixed order
             if (!E.fast) __hip_atomic_store(E.ws + chunk_id, part, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        if (E.fast) { fw_arrive_fast<NS, FZ>(gk, sm, tid, chunk_id, part, step); return; }   // (uniform)
+        if (E.fast) { fw_arrive_fast<NS, FZ>(gk, Eh, th.rng, th.nchunks, tid, chunk_id, part, step); return; }   // (uniform)
     }
     fw_arrive<NS, FZ>(gk, sm, tid, chunk_id);
     }
