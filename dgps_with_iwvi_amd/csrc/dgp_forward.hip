@@ -2307,7 +2307,7 @@ static size_t fw_plan_lds(FwArgs& a, int nsamp, int maxR, int maxP, bool stage_z
     }
     {
         const int draw_waves = a.h.noise_any_src ? FW_WAVES : std::min(FW_WAVES, (a.h.noise_drawn + 63) / 64);
-        a.h.n_early = (!fz && FW_WAVES - draw_waves >= 2) ? FW_WAVES - draw_waves : 0;
+        a.h.n_early = (!fz && FW_WAVES - draw_waves >= 2) ? std::min(FW_WAVES - draw_waves, FW_WAVES / 2) : 0;   // (at least half of the waves fetch the table and the rows)
     }
     a.h.zt_mask = 0;
     // the copy list in two parts: first what no workgroup of a merged launch writes (mixing matrices, mean functions, encoder weights),
