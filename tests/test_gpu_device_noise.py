@@ -31,12 +31,17 @@ def _forward_with_readback(model, spec):
     return red[0], red[1], outs
 
 
-@pytest.mark.parametrize("L,M,K,B,lv", [(2, 128, 20, 48, True),      # configs[2]'s stack at a batch the oracle finishes in seconds
-                                        (2, 128, 5, 64, False),      # configs[1]'s
-                                        (3, 64, 7, 33, True)])       # ragged chunk, three GP layers
-def test_device_drawn_noise_read_back_matches_oracle(gpu_device, L, M, K, B, lv):
+# (the prologue of the launch splits its duties by how many waves the noise items fill -- csrc/dgp_forward.hip, n_early: 5 of 8 waves at
+#  configs[2] -> three waves issue the big copies first thing; R = 2 without an LV layer: 2 waves draw, the cap of four early waves; R = 13 in two
+#  inner layers: more items than threads, every wave draws and copies, the second round of draws)
+@pytest.mark.parametrize("L,M,K,B,lv,R", [(2, 128, 20, 48, True, 5),     # configs[2]'s stack at a batch the oracle finishes in seconds
+                                          (2, 128, 5, 64, False, 5),     # configs[1]'s
+                                          (3, 64, 7, 33, True, 5),       # ragged chunk, three GP layers
+                                          (2, 32, 10, 24, False, 2),
+                                          (3, 32, 5, 32, True, 13)])
+def test_device_drawn_noise_read_back_matches_oracle(gpu_device, L, M, K, B, lv, R):
     from dgps_with_iwvi_amd import settings, synthetic
-    spec = synthetic.make_spec(L=L, M=M, B=B, K=K, with_lv=lv, seed=L * 10 + K)
+    spec = synthetic.make_spec(L=L, M=M, B=B, K=K, with_lv=lv, R=R, seed=L * 10 + K)
     settings.set_seed(1234)
     model = synthetic.build_model(spec, gpu_device)
     elbo, logp, outs = _forward_with_readback(model, spec)
