@@ -193,16 +193,19 @@ def roofline_object(achieved, flops, launch_ms, spec, traffic, traffic_src, pmc)
     mix_peak = (f32p + f16p) / (f32p / PEAK_MFMA_F32 + f16p / (PEAK_MFMA_F16 / 3.0))
     hbm_frac = None if traffic is None else traffic / (launch_ms * 1e-3) / PEAK_HBM
     busy = pmc.get("mfma_busy_frac")
+    # `bound` names the roofline `achieved` / `peak` are priced against (the contract's "hbm" | "mfma": this kernel's arithmetic is matrix
+    # products and its HBM traffic is ~1 % of the peak, so the matrix-core ceiling of its instruction mix); `limiter` says, from the
+    # counters, what the kernel actually waits for -- which today is neither
     if busy is None:
-        bound, why = "mfma", "no counters for this workload: the kernel's arithmetic is matrix products"
+        limiter, why = "unknown", "no counters for this workload: the kernel's arithmetic is matrix products"
     elif busy >= 0.5:
-        bound, why = "mfma", "matrix pipe busy %.2f of the kernel" % busy
+        limiter, why = "mfma", "matrix pipe busy %.2f of the kernel" % busy
     elif hbm_frac is not None and hbm_frac >= 0.5:
-        bound, why = "hbm", "HBM traffic at %.2f of peak" % hbm_frac
+        limiter, why = "hbm", "HBM traffic at %.2f of peak" % hbm_frac
     else:
-        bound, why = "latency/issue", ("matrix pipe busy %.2f of the kernel, HBM at %.3f of peak: dependent chains (triangular solves), barriers and "
-                                       "launch / drain, not a throughput limit" % (busy, hbm_frac or 0.0))
-    return {"bound": bound, "bound_from": why,
+        limiter, why = "latency/issue", ("matrix pipe busy %.2f of the kernel, HBM at %.3f of peak: dependent chains (triangular solves), barriers and "
+                                         "launch / drain, not a throughput limit" % (busy, hbm_frac or 0.0))
+    return {"bound": "mfma", "limiter": limiter, "bound_from": why,
             "kernel": "k_dgp_forward (all layers fused, one launch per ELBO evaluation)",
             "achieved": achieved / 1e12, "peak": mix_peak / 1e12, "unit": "TFLOP/s", "frac": achieved / mix_peak,
             "peak_basis": "instruction mix: %.0f%% of the algorithmic FLOPs on fp32 MFMAs (157.3 TF), %.0f%% as split f16 (2.5 PF / 3)" % (
