@@ -207,7 +207,8 @@ int iwvi_mvn_sample(const float* mean, const float* cov, const float* z, float* 
  *   kl_local   LV only, optional [T, latent_dim]: log q(W) - log p(W) (sampled_kl) or the analytic KL
  * rng_state: 2 device words {step counter, ticket}, zeroed once by the caller; the launch reads the step
  *   and its last workgroup advances it, so a replayed hipGraph draws fresh noise.  May be NULL when every
- *   layer has explicit noise.
+ *   layer has explicit noise.  The ticket word is the launch's arrival counter (every workgroup adds to it once,
+ *   the last one leaves it at 0): two launches that may overlap in time need their own rng_state.
  * Y / out_logw may be NULL (propagate only).  out_logw [T] = sum_d var_exp - sum local regularisers.
  * ---------------------------------------------------------------------- */
 enum { IWVI_LAYER_GP = 0, IWVI_LAYER_LV = 1 };
