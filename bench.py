@@ -449,6 +449,17 @@ def main():
         med = {"ms_per_step_median": float(np.median(ts)), "p10": float(np.percentile(ts, 10)), "p90": float(np.percentile(ts, 90)),
                "iters": int(args.median_iters), "warmup": 10,
                "how": "hipEvents around single-evaluation hipGraph replays (one precompute + one fused forward each), back to back"}
+        if graph is not None and xch is None:
+            # ... and of the timed region's own unit: hipEvents around whole replays of the timed graph (spg evaluations each), per evaluation
+            evs_r = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(15)]
+            for a, b in evs_r:
+                a.record()
+                graph.replay()
+                b.record()
+            torch.cuda.synchronize()
+            tr = np.array([a.elapsed_time(b) for a, b in evs_r]) / spg
+            med.update({"ms_per_step_median_of_replays": float(np.median(tr)), "replays_p10": float(np.percentile(tr, 10)),
+                        "replays_p90": float(np.percentile(tr, 90)), "evaluations_per_replay": int(spg)})
 
     # ---- dominant kernel: the fused forward (all layers), HIP events around a graph of back-to-back launches
     tot_flops, _ = f_alg_model(spec)
