@@ -200,7 +200,9 @@ static_assert(sizeof(FwHot) == 128, "two scalar-cache lines per layer");
 // `done`.  All counters are monotonic and counted per generation (`gen` = launches completed on this buffer): nothing is reset per
 // launch, and the words are zeroed once, when the buffer is allocated.  Every wait depends only on workgroups with a smaller ticket,
 // which have started: no deadlock under any dispatch order.  Spins are bounded; a give-up poisons the result with NaN.
-struct FzSync { unsigned gen, role, early, pack, done, timeout; unsigned cols[IWVI_MAX_STACK]; unsigned snap[IWVI_MAX_STACK]; unsigned pad[42]; };
+struct FzSync { unsigned gen, role, early, pack, done, timeout; unsigned cols[IWVI_MAX_STACK]; unsigned snap[IWVI_MAX_STACK];
+                unsigned started;   // (IWVI_FZ_EXT) workgroups of k_precompute_pub that have a CU, ever
+                unsigned pad[41]; };
 static_assert(sizeof(FzSync) == 256, "sync block");
 struct FzArgs {
     int enabled, n_gp, n_pack, n_reg, n_ticket, first_gp;
@@ -213,6 +215,7 @@ struct FzArgs {
     // sums, row indices, every layer's noise: ~16 KB), to be picked up by factorising workgroup k when it is done.
     int resume, help_t0, snap_a0, snap_a1, snap_b0, snap_b1;   // LDS float ranges of a snapshot: [xa .. asq) and the noise of every layer
     unsigned snap_stride;                  // bytes per snapshot slot
+    int ext;                               // (experiment, IWVI_FZ_EXT) the roles run in ANOTHER launch, k_precompute_pub, on a second stream: every workgroup here is a chunk workgroup
     unsigned char* snap;
     PreLayer P[IWVI_MAX_STACK];            // the GP layers of the stack, in stack order
 };
@@ -706,7 +709,11 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
         int* rw = reinterpret_cast<int*>(sm + g.lds.cnt);
         if (tid == 0) {
             const unsigned g0 = __hip_atomic_load(&z.sync->gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const unsigned t = __hip_atomic_fetch_add(&z.sync->role, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - g0 * (unsigned)z.n_ticket;
+            unsigned t = __hip_atomic_fetch_add(&z.sync->role, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - g0 * (unsigned)z.n_ticket;
+            // (IWVI_FZ_EXT: no role is played here.  Tickets 0 .. n_reg-1 are ordinary chunks -- shifted past the factor tickets so that the
+            //  code below files them as chunk workgroups --; the LAST tickets belong to the workgroups that found no CU until the
+            //  factorisation launch's workgroups retired: they resume the chunks whose fronts the helpers have prepared)
+            if (z.ext) t = (t < (unsigned)z.n_reg || !z.resume) ? t + (unsigned)z.n_gp : (t - (unsigned)z.n_reg) | 0x40000000u;
             rw[4] = (int)t; rw[5] = (int)g0;
         }
         __syncthreads();
@@ -718,7 +725,18 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
             g.stamps[(size_t)blockIdx.x * 128 + 51] = __builtin_amdgcn_s_getreg(6164) & 15;   // HW_REG_XCC_ID
             g.stamps[(size_t)blockIdx.x * 128 + 52] = wall_clock64();
         }
-        if (tk < z.n_gp) {
+        if (z.ext && (tk & 0x40000000)) {
+            // a late workgroup of the EXT experiment: resume slot tk.  What role_factor's tail does for a factorising workgroup: wait for the
+            // helper's snapshot and the pack roles, ONE acquire
+            fz_mode = 2; fz_slot = tk & 0xffff; fz_chunk = z.nchunks_reg + fz_slot;
+            if (tid == 0) {
+                fz_wait_ge(&z.sync->snap[fz_slot], fz_gen + 1u, &z.sync->timeout);
+                fz_wait_ge(&z.sync->pack, (fz_gen + 1u) * (unsigned)z.n_pack, &z.sync->timeout);
+                fz_wait_ge(&z.sync->early, (fz_gen + 1u) * (unsigned)z.n_gp, &z.sync->timeout);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            __syncthreads();
+        } else if (tk < z.n_gp) {
             const PreLayer Lc = z.P[tk];                          // (by value: a reference into the kernel arguments would force them into scratch)
             // (diagnostic stamps land in this workgroup's 128-word row, words 0 .. 15: PRE_STAMP indexes 16 words per block)
             role_factor<true, true>(Lc, 0, g.stamps ? g.stamps + (size_t)blockIdx.x * 112 : nullptr, 1, FzPub{&z.sync->early, &z.sync->done, &z.sync->cols[tk],
@@ -733,7 +751,7 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
             fz_mode = 2; fz_slot = tk; fz_chunk = z.nchunks_reg + tk;      // carries on with the chunk its helper has prepared
         } else {
             fz_chunk = tk - z.n_gp;
-            if (fz_chunk < z.n_pack) {
+            if (fz_chunk < z.n_pack && !z.ext) {
                 // tril(q_sqrt_r)^T packing + KL shares (csrc/precompute_dev.h: role_pack_r): the first chunks carry one (layer, r) each
                 unsigned njobs = 0;
                 if (g.stamps && tid == 0) g.stamps[(size_t)blockIdx.x * 128 + 53] = wall_clock64();
@@ -2563,12 +2581,14 @@ static int dgp_forward_fz(const iwvi_layer_desc* layers, int n_layers, const flo
         // a chunk workgroup left without a CU would only start when a factorising one retires, and pay its whole front behind it
         z.resume = (chunks + z.n_gp > n_cu && chunks >= 2 * z.n_gp + z.n_pack && (size_t)(z.snap_a1 - z.snap_a0 + z.snap_b1 - z.snap_b0) * 4 <= FZ_SNAP_BYTES &&
                     !dbg_opt("IWVI_FZ_NO_RESUME")) ? 1 : 0;
+        z.ext = dbg_opt("IWVI_FZ_EXT") ? 1 : 0;
+        if (z.ext && dbg_opt("IWVI_FZ_EXT") == 2) z.resume = 0;    // (2: without the late workgroups' resume)
         z.snap = reinterpret_cast<unsigned char*>(fz->ws) + sizeof(FzSync);
         z.snap_stride = (unsigned)FZ_SNAP_BYTES;
         z.help_t0 = z.n_gp + z.n_pack;
         z.n_reg = (int)chunks - (z.resume ? z.n_gp : 0);
         z.nchunks_reg = z.n_reg;
-        z.n_ticket = z.resume ? (int)chunks : z.n_gp + (int)chunks;
+        z.n_ticket = (z.resume || z.ext) ? (int)chunks : z.n_gp + (int)chunks;
         for (int k = 0; k < z.n_gp; ++k) { const size_t la = factor_lds_bytes(z.P[k].Mp); if (la > lds_bytes) lds_bytes = la; }
         const unsigned grid = (unsigned)z.n_ticket;
         fw_decide_fast(a, grid, 16 * ns, T);
@@ -2630,6 +2650,59 @@ extern "C" int iwvi_dgp_forward(const iwvi_layer_desc* layers, int n_layers, con
                                 float* out_logw, const iwvi_elbo_desc* elbo, void* stream) {
     return dgp_forward_impl(layers, n_layers, X, Dx, XY, XYdim, Y, Dy, T, row_div, row_mod, lik_variance, seed,
                             rng_state, out_logw, elbo, (hipStream_t)stream);
+}
+
+// ---- experiment (IWVI_FZ_EXT): the merged launch's roles as a launch of their own, 1024 threads per workgroup like k_precompute, publishing
+//      through the same counters -- run on a second stream BESIDE a k_dgp_forward<.., FZ> launch whose workgroups are all chunk workgroups
+struct PubArgs { PreLayer P[IWVI_MAX_STACK]; int n_gp; FzSync* sync; };
+__global__ __launch_bounds__(1024) void k_precompute_pub(PubArgs a) {
+    const int l = blockIdx.x, role = blockIdx.y, tid = threadIdx.x;
+    if (tid == 0) __hip_atomic_fetch_add(&a.sync->started, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (this workgroup has its CU: see k_fz_gate)
+    if (l >= a.n_gp) return;
+    const PreLayer Lc = a.P[l];
+    if (role == 0) {
+        role_factor<true, true>(Lc, 0, nullptr, 1, FzPub{&a.sync->early, &a.sync->done, &a.sync->cols[l], nullptr, 0u, nullptr, 0u, &a.sync->timeout});
+    } else if (role <= Lc.R) {
+        role_pack_r<true>(Lc, role - 1, reinterpret_cast<double*>(smem_raw));
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) __hip_atomic_fetch_add(&a.sync->pack, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+// one workgroup in front of the layer launch on ITS stream: leaves once every workgroup of this evaluation's k_precompute_pub has a CU, so
+// that the layer launch's 256 workgroups cannot take the CUs the factorisation needs (inside a captured graph nothing else orders the two)
+__global__ void k_fz_gate(FzSync* s, unsigned nblocks) {
+    if (threadIdx.x == 0) {
+        const unsigned g0 = __hip_atomic_load(&s->gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        fz_wait_ge(&s->started, (g0 + 1u) * nblocks, &s->timeout);
+    }
+}
+static int pub_blocks(const iwvi_gp_desc* gp, int n_gp) { int maxR = 1; for (int k = 0; k < n_gp; ++k) maxR = std::max(maxR, (int)gp[k].R); return n_gp * (1 + maxR); }
+extern "C" int iwvi_fz_gate(const iwvi_gp_desc* gp, int n_gp, void* fused_ws, void* stream) {
+    if (!gp || n_gp <= 0 || !fused_ws) { set_error("iwvi_fz_gate: bad arguments"); return IWVI_ERR_ARG; }
+    hipLaunchKernelGGL(k_fz_gate, dim3(1), dim3(64), 0, (hipStream_t)stream, reinterpret_cast<FzSync*>(fused_ws), (unsigned)pub_blocks(gp, n_gp));
+    return check_launch("k_fz_gate");
+}
+extern "C" int iwvi_gp_precompute_pub(const iwvi_gp_desc* gp, int n_gp, void* fused_ws, void* stream) {
+    if (!gp || n_gp <= 0 || n_gp > IWVI_MAX_STACK || !fused_ws) { set_error("iwvi_gp_precompute_pub: bad arguments"); return IWVI_ERR_ARG; }
+    PubArgs a{};
+    int maxR = 1;
+    size_t lds = 0;
+    for (int k = 0; k < n_gp; ++k) {
+        const int rc = fill_pre_layer(gp[k], k, a.P[k]);
+        if (rc != IWVI_OK) return rc;
+        if (a.P[k].Mp > 128 || a.P[k].flags != 0) { set_error("iwvi_gp_precompute_pub: layer %d is not covered (M > 128 or dense factors)", k); return IWVI_ERR_UNSUPPORTED; }
+        maxR = std::max(maxR, a.P[k].R);
+        lds = std::max(lds, factor_lds_bytes(a.P[k].Mp));
+    }
+    a.n_gp = n_gp; a.sync = reinterpret_cast<FzSync*>(fused_ws);
+    static size_t attr_set = 0;
+    if (lds > attr_set) {
+        if (hipFuncSetAttribute((const void*)k_precompute_pub, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) { set_error("iwvi_gp_precompute_pub: LDS attribute"); return IWVI_ERR_LAUNCH; }
+        attr_set = lds;
+    }
+    hipLaunchKernelGGL(k_precompute_pub, dim3(n_gp, 1 + maxR), dim3(1024), lds, (hipStream_t)stream, a);
+    return check_launch("k_precompute_pub");
 }
 
 extern "C" size_t iwvi_fused_ws_bytes(void) { return sizeof(iwvi::FzSync) + (size_t)IWVI_MAX_STACK * iwvi::FZ_SNAP_BYTES; }

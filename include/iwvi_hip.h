@@ -299,6 +299,14 @@ int iwvi_dgp_forward_fused(const iwvi_gp_desc* gp_host, int n_gp, void* fused_ws
                            int64_t T, int64_t row_div, int64_t row_mod, float lik_variance,
                            uint64_t seed, uint64_t* rng_state, float* out_logw,
                            const iwvi_elbo_desc* elbo /* or NULL */, void* stream);
+/* Experiment (development route IWVI_FZ_EXT of iwvi_debug_set_option; scripts/time_ext_precompute.py): the merged launch's roles as a
+ * launch of their own -- the 1024-thread factorisation of iwvi_gp_precompute publishing through the counters in `fused_ws` -- to be
+ * queued on a SECOND stream beside an iwvi_dgp_forward_fused call made with IWVI_FZ_EXT set, whose workgroups then only wait for it.
+ * The caller orders this call after the previous evaluation's layer launch (it overwrites the operands that launch reads). */
+int iwvi_gp_precompute_pub(const iwvi_gp_desc* gp_host, int n_gp, void* fused_ws, void* stream);
+/* ... and the one-workgroup gate queued in front of that iwvi_dgp_forward_fused call on ITS stream: it leaves when every workgroup of this
+ * evaluation's iwvi_gp_precompute_pub launch has a CU (inside a captured graph nothing else orders the two launches' dispatch). */
+int iwvi_fz_gate(const iwvi_gp_desc* gp_host, int n_gp, void* fused_ws, void* stream);
 
 /* ----------------------------------------------------------------------
  * Backward pass (the reference gets these from TensorFlow's autodiff of the graph of
