@@ -56,3 +56,30 @@ def test_partials_beyond_the_fixed_point_range_take_the_exact_path(gpu_device, w
     fast, slow = _both_tails(spec, zs, gpu_device)
     assert np.isfinite(fast) and abs(fast) > 2.0 ** 17
     assert abs(fast - slow) <= 1e-12 * abs(slow) + 64 * 2.0 ** -21, (fast, slow)
+
+
+def test_two_models_on_two_streams_do_not_interfere(gpu_device):
+    """Two evaluations in flight (bench.py: ``two_in_flight``): two models with the same parameters, each with its own operand state, noise
+    stream and arrival word, evaluated concurrently on two streams give the values they give one after the other -- nothing in the
+    library is shared between launches except what the caller passes in."""
+    from dgps_with_iwvi_amd import settings, synthetic
+    spec = synthetic.make_spec(L=2, M=128, B=512, K=20, with_lv=True, seed=4, n_data=4096)
+
+    def build():
+        settings.set_seed(0)
+        return synthetic.build_model(spec, gpu_device)
+
+    ref = build()
+    serial = [float(ref._build_likelihood()) for _ in range(6)]          # device-drawn noise: evaluation i of a fresh model, for every model
+    a, b = build(), build()
+    sa, sb = torch.cuda.Stream(device=gpu_device), torch.cuda.Stream(device=gpu_device)
+    outs = {"a": [], "b": []}
+    torch.cuda.synchronize()
+    for _ in range(6):
+        with torch.cuda.stream(sa):
+            outs["a"].append(a._build_likelihood())
+        with torch.cuda.stream(sb):
+            outs["b"].append(b._build_likelihood())
+    torch.cuda.synchronize()
+    assert [float(v) for v in outs["a"]] == serial
+    assert [float(v) for v in outs["b"]] == serial
