@@ -159,13 +159,6 @@ PROTOTYPES = {
     "iwvi_dgp_forward": (c_int, [ctypes.POINTER(LayerDesc), c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int,
                                  c_int64, c_int64, c_int64, c_float, ctypes.c_uint64, c_void_p, c_void_p,
                                  ctypes.POINTER(ElboDesc), c_void_p]),
-    "iwvi_fused_ws_bytes": (c_size_t, []),
-    "iwvi_gp_precompute_pub": (c_int, [ctypes.POINTER(GpDesc), c_int, c_void_p, c_void_p]),
-    "iwvi_fz_gate": (c_int, [ctypes.POINTER(GpDesc), c_int, c_void_p, c_void_p]),
-    "iwvi_dgp_forward_fused": (c_int, [ctypes.POINTER(GpDesc), c_int, c_void_p,
-                                       ctypes.POINTER(LayerDesc), c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int,
-                                       c_int64, c_int64, c_int64, c_float, ctypes.c_uint64, c_void_p, c_void_p,
-                                       ctypes.POINTER(ElboDesc), c_void_p]),
     "iwvi_logw_reduce": (c_int, [c_void_p, c_int64, c_int, c_int64, c_int64, ctypes.POINTER(c_void_p),
                                  ctypes.POINTER(ctypes.c_int32), c_int, c_double, c_int, c_int,
                                  c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
@@ -188,7 +181,7 @@ PROTOTYPES = {
 
 DEBUG_OPTIONS = ("IWVI_BW_SMALL_TILES", "IWVI_BW_UNFUSED", "IWVI_BW_FUSED", "IWVI_BW_S16_SMALL_M", "IWVI_BW_OLD_CHAIN",
                  "IWVI_BW_CHAIN_SMALL_M_ONLY", "IWVI_BW_CHAIN_M256_ONLY", "IWVI_BW_CHAIN_NS2", "IWVI_BW_GEMM_PRODUCTS", "IWVI_DMM_LDS",
-                 "IWVI_CHAIN_EXIT", "IWVI_FZ_NO_RESUME", "IWVI_FZ_EXT", "IWVI_FW_SLOW_TAIL", "IWVI_NATGRAD_UNFUSED", "IWVI_NG_STOP", "IWVI_DEBUG_STOP", "IWVI_PRE_STAMP_P")
+                 "IWVI_CHAIN_EXIT", "IWVI_FW_SLOW_TAIL", "IWVI_NATGRAD_UNFUSED", "IWVI_NG_STOP", "IWVI_DEBUG_STOP", "IWVI_PRE_STAMP_P")
 
 
 def set_debug_option(name, value):

@@ -152,8 +152,7 @@ struct FwHead {
     float* out_logw;
     unsigned long long* stamps;      // diagnostic only (iwvi_debug_set_stamps): 128 words per workgroup
     int ncopy;
-    int ncopy_indep;                 // the first ncopy_indep entries of the copy list read nothing another workgroup of this launch writes
-    int nchunks;                     // chunks of 16 * NS samples (== workgroups, except in the merged launch)
+    int nchunks;                     // chunks of 16 * NS samples (== workgroups)
     int ls_first;                    // first GP layer whose solve stream is staged in LDS (fetched in the prologue), or -1
     int n_early;                     // the last n_early waves issue the prologue's big copies (first solve stream, every Z~ image) before anything else
     unsigned zt_mask;                // GP layers whose Z~ image those waves copy (bit = layer); 0 when n_early == 0: the copy list carries them
@@ -192,37 +191,8 @@ struct alignas(64) FwHot {
     const float* nx_ls; const f32x4* LrTP; const f32x4* QmuP; const f32x4* LsP; const float* ZtP;   // LV: LrTP = enc_out
 };
 static_assert(sizeof(FwHot) == 128, "two scalar-cache lines per layer");
-// ---- the merged launch (template parameter FZ): the precompute roles and the layer stack in ONE launch ----------------------
-// Workgroups take a role by ticket (an agent-scope counter, so the order of dispatch decides nothing but speed): the first n_gp to start
-// factorise a GP layer each (role_factor), the others own a chunk of samples; chunk c < n_pack first packs tril(q_sqrt_r)^T for one
-// (layer, r).  A chunk's front -- table, inputs, noise, latent-variable layer, x~, K_uf Gram -- needs nothing of the factorisation
-// but the scaled inducing inputs (counter `early`, ~3 us into the launch) and runs beside it; stage 1 of the first GP layer waits for
-// `done`.  All counters are monotonic and counted per generation (`gen` = launches completed on this buffer): nothing is reset per
-// launch, and the words are zeroed once, when the buffer is allocated.  Every wait depends only on workgroups with a smaller ticket,
-// which have started: no deadlock under any dispatch order.  Spins are bounded; a give-up poisons the result with NaN.
-struct FzSync { unsigned gen, role, early, pack, done, timeout; unsigned cols[IWVI_MAX_STACK]; unsigned snap[IWVI_MAX_STACK];
-                unsigned started;   // (IWVI_FZ_EXT) workgroups of k_precompute_pub that have a CU, ever
-                unsigned pad[41]; };
-static_assert(sizeof(FzSync) == 256, "sync block");
-struct FzArgs {
-    int enabled, n_gp, n_pack, n_reg, n_ticket, first_gp;
-    int nchunks_reg;                       // chunks owned by chunk workgroups (resume mode: the last n_gp chunks belong to the factorising ones)
-    int pack_off[IWVI_MAX_STACK + 1];      // pack job j: GP layer l with pack_off[l] <= j < pack_off[l + 1], latent GP j - pack_off[l]
-    FzSync* sync;
-    // resume mode (more workgroups than CUs otherwise): a factorising workgroup also owns a chunk.  Its front is computed by a HELPER --
-    // the chunk workgroup with ticket help_t0 + k, which has ~12 us of idle time before the factorisation ends anyway -- up to the
-    // first GP layer's Gram, and what is particular to the chunk is left in HBM ("snapshot": the activation tiles with x~, regulariser
-    // sums, row indices, every layer's noise: ~16 KB), to be picked up by factorising workgroup k when it is done.
-    int resume, help_t0, snap_a0, snap_a1, snap_b0, snap_b1;   // LDS float ranges of a snapshot: [xa .. asq) and the noise of every layer
-    unsigned snap_stride;                  // bytes per snapshot slot
-    int ext;                               // (experiment, IWVI_FZ_EXT) the roles run in ANOTHER launch, k_precompute_pub, on a second stream: every workgroup here is a chunk workgroup
-    unsigned char* snap;
-    PreLayer P[IWVI_MAX_STACK];            // the GP layers of the stack, in stack order
-};
-constexpr size_t FZ_SNAP_BYTES = 32 * 1024;
 struct FwArgs {
     FwHead h;
-    FzArgs z;
     FwHot H[IWVI_MAX_STACK];
     FwLayer L[IWVI_MAX_STACK];
     FwNoise N[IWVI_MAX_STACK];
@@ -486,7 +456,7 @@ __device__ __forceinline__ void fw_copy_entries(const FwCopy* CT, float* sm, int
 
 // ---- one ticket per workgroup: the last arriver advances the noise stream (every workgroup has read the step counter by
 //      then) and, if asked, finishes the IW-ELBO reduction of models.py:138-150.  Every workgroup of the launch arrives exactly
-//      once, whatever its role (merged launch: the factorising workgroups too -- the last arriver then also closes the generation).
+//      once.
 // The packed arrival (FwElbo::fast; the headline shape): the workgroup's partial sum of the per-point log p travels IN the ticket -- one
 // 64-bit atomic add of  fixed(part) << 18 | overflow << 9 | 1  on rng_state[1]: bits 0-8 count the arrivals, bits 18-63 accumulate the
 // partial sums in units of 2^-20 (integer adds commute: the total does not depend on the order of arrival).  The workgroup whose add returns
@@ -498,7 +468,7 @@ __device__ __forceinline__ void fw_copy_entries(const FwCopy* CT, float* sm, int
 // adds those partials from memory (a cold path: one more round trip, only when it happens).
 constexpr double FX_UNIT = 1048576.0;                              // 2^20 units per 1.0
 constexpr double FX_PART_MAX = 137438953472.0;                     // 2^37 units = 2^17: a workgroup's share (<= 511 arrivals, 46-bit field)
-template <int NS, bool FZ>
+template <int NS>
 __device__ __forceinline__ void fw_arrive_fast(const FwArgs& gk, const FwElboHot& E, unsigned long long* rng, int nchunks, int tid, int chunk_id,
                                                double part, unsigned long long step) {
     if (tid >= 64) return;
@@ -506,7 +476,7 @@ __device__ __forceinline__ void fw_arrive_fast(const FwArgs& gk, const FwElboHot
     // ticket -- whichever arrives last has them back together with the ticket's answer (one round trip, not two).  The first four arrays'
     // pointers and counts as one batch of scalar loads; further arrays (a stack of more than four GP layers) one by one
     double kl_lane = 0.0;
-    if (!FZ && tid < E.kl_total) {
+    if (tid < E.kl_total) {
         struct KlHead { const double* p[4]; int n[4]; };
         const KlHead kh = opaque_block(KlHead{{gk.h.e.klg[0], gk.h.e.klg[1], gk.h.e.klg[2], gk.h.e.klg[3]},
                                                {gk.h.e.klg_n[0], gk.h.e.klg_n[1], gk.h.e.klg_n[2], gk.h.e.klg_n[3]}});
@@ -540,31 +510,21 @@ __device__ __forceinline__ void fw_arrive_fast(const FwArgs& gk, const FwElboHot
           ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(old >> 32)) << 32);
     if ((unsigned)(old & 511ULL) != gridDim.x - 1) return;
     double kl_sum = 0.0;                                           // (in the arrays' order, like the loop it replaces)
-    if constexpr (!FZ) { for (int k = 0; k < E.kl_total; ++k) kl_sum += readlane_d(kl_lane, k); }
+    for (int k = 0; k < E.kl_total; ++k) kl_sum += readlane_d(kl_lane, k);
     if (tid != 0) return;
     __hip_atomic_store(&rng[1], 0ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_fetch_add(&rng[0], 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if constexpr (FZ) __hip_atomic_fetch_add(&gk.z.sync->gen, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     double tot = (double)(((long long)old >> 18) + fx) * (1.0 / FX_UNIT);                 // (arithmetic shift: the field's sign)
     if ((unsigned)(old >> 9 & 511ULL) + (ovf ? 1u : 0u)) {
         for (int c = 0; c < nchunks; ++c)
             if (__hip_atomic_load(reinterpret_cast<unsigned long long*>(E.ws) + nchunks + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == step + 1ULL)
                 tot += __hip_atomic_load(E.ws + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    double kl = 0.0;
-    if constexpr (FZ) {                                            // (the KL shares are written by workgroups of this launch)
-        if (chunk_id < 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        for (int i = 0; i < E.n_glob; ++i)
-            for (int c = 0; c < gk.h.e.klg_n[i]; ++c) kl += gk.h.e.klg[i][c];
-    } else kl = kl_sum;
-    double val = tot * E.scale - kl;                                                       // models.py:150
-    if constexpr (FZ) {
-        if (__hip_atomic_load(&gk.z.sync->timeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) val = __builtin_nan("");
-    }
+    const double val = tot * E.scale - kl_sum;                                                 // models.py:150
     *E.elbo = val;
 }
 
-template <int NS, bool FZ>
+template <int NS>
 __device__ __forceinline__ void fw_arrive(const FwArgs& gk, float* sm, int tid, int chunk_id) {
     constexpr int NSAMP = 16 * NS;
     const FwHead& g = gk.h;
@@ -581,7 +541,6 @@ __device__ __forceinline__ void fw_arrive(const FwArgs& gk, float* sm, int tid, 
             if (last) {
                 __hip_atomic_store(&g.rng_state[1], 0ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_fetch_add(&g.rng_state[0], 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if constexpr (FZ) __hip_atomic_fetch_add(&gk.z.sync->gen, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             counters[2] = last;
         }
@@ -628,50 +587,17 @@ __device__ __forceinline__ void fw_arrive(const FwArgs& gk, float* sm, int tid, 
             __syncthreads();
             if (tid == 0 && E.elbo) {
                 double tot = 0.0, kl = 0.0;
-                if constexpr (FZ) { if (chunk_id < 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }   // (a factorising workgroup has not acquired the KL shares yet)
                 for (int w = 0; w < FW_WAVES; ++w) tot += wsum[w];
                 for (int i = 0; i < E.n_glob; ++i)
                     for (int c = 0; c < E.klg_n[i]; ++c) kl += E.klg[i][c];
-                double val = tot * E.scale - kl;                                       // models.py:150
-                if constexpr (FZ) {                                                    // a wait of this launch gave up: say so, loudly
-                    if (__hip_atomic_load(&gk.z.sync->timeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) val = __builtin_nan("");
-                }
+                const double val = tot * E.scale - kl;                                 // models.py:150
                 *E.elbo = val;
             }
         }
     }
 }
 
-// ---- merged launch: waits and coherent reads --------------------------------------------------------------------------------
-// ONE lane polls ONE word with relaxed agent-scope loads (sc1: no cache maintenance per poll); wrap-safe compare; bounded.
-__device__ __forceinline__ void fz_wait_ge(unsigned* word, unsigned target, unsigned* tmo) {
-    for (unsigned spins = 0;; ++spins) {
-        if ((int)(__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) >= 0) return;
-        __builtin_amdgcn_s_sleep(2);
-        if (spins > (1u << 22)) { __hip_atomic_store(tmo, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return; }
-    }
-}
-// the same, returning the value seen (a counter that keeps growing: the caller takes everything that is there)
-__device__ __forceinline__ unsigned fz_wait_ge_val(unsigned* word, unsigned target, unsigned* tmo) {
-    for (unsigned spins = 0;; ++spins) {
-        const unsigned v = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if ((int)(v - target) >= 0) return v;
-        __builtin_amdgcn_s_sleep(2);
-        if (spins > (1u << 22)) { __hip_atomic_store(tmo, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return target + (1u << 20); }
-    }
-}
-// a packed operand stream another workgroup of this launch has just stored write-through: every 16-byte vector is read with an sc1
-// load to registers (served behind this CU's L1, which may hold last evaluation's lines) -- no acquire on the critical path
-struct Sc1Stream {
-    __amdgpu_buffer_rsrc_t r; unsigned off;
-    __device__ __forceinline__ Sc1Stream(const void* base, unsigned bytes, unsigned lane_off)
-        : r(__builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000)), off(lane_off) {}
-    __device__ __forceinline__ f32x4 operator[](size_t i) const {
-        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, off + (unsigned)i * 16u, 0, 16));
-    }
-};
-
-template <int NS, bool S16, bool FZ = false>   // S16: stage 2 of every GP layer on split-f16 operands (iwvi_common.h: s16_*); FZ: merged launch
+template <int NS, bool S16>   // S16: stage 2 of every GP layer on split-f16 operands (iwvi_common.h: s16_*)
 __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
     constexpr int NSAMP = 16 * NS;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -679,19 +605,8 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
     const FwHead& g = gk.h;                                       // scalar path (first kernarg lines)
     const int XSTR = g.xstr;
     float* sm = reinterpret_cast<float*>(fw_smem);
-    int fz_chunk = 0, fz_mode = 0, fz_slot = 0, fz_own = 0;       // fz_mode: 0 chunk, 1 helper (first pass: another chunk's front), 2 resume
-    unsigned fz_gen = 0;
-    if constexpr (FZ) {
-        // every 64-byte line of the header, the role arguments and the hot descriptors requested through the scalar cache at once: read
-        // field by field where they are used, a cold kernel-argument segment costs a memory round trip per line, one after the other
-        // (6.6 us between the ticket and the first stamp of the forward part before this)
-        unsigned warm = 0;
-        const unsigned* kw = reinterpret_cast<const unsigned*>(&gk);
-#pragma unroll
-        for (int i = 0; i < (int)(offsetof(FwArgs, L) / 64); ++i) warm |= kw[16 * i];
-        asm volatile("" :: "s"(warm));
-    } else {
-        // the same for the header and the hot layer descriptors, FIRST thing and waited for at once: the header's fields are read all over
+    {
+        // the header and the hot layer descriptors, FIRST thing and waited for at once: the header's fields are read all over
         // the prologue, and the first reads of lines that had not arrived yet were cold round trips one behind the other (the branch on
         // n_early alone cost one) -- one cold round trip for everything, scalar-cache hits from then on
         unsigned warm = 0;
@@ -703,91 +618,13 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
         for (int i = 0; i < (int)(sizeof(FwHot) * IWVI_MAX_STACK / 64); ++i) warm |= hw[16 * i];
         asm volatile("" :: "s"(warm));
     }
-    if constexpr (FZ) {
-        // ---- role by ticket: whoever starts first factorises (nothing below ever waits for a workgroup that has not started) ----
-        const FzArgs& z = gk.z;
-        int* rw = reinterpret_cast<int*>(sm + g.lds.cnt);
-        if (tid == 0) {
-            const unsigned g0 = __hip_atomic_load(&z.sync->gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            unsigned t = __hip_atomic_fetch_add(&z.sync->role, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - g0 * (unsigned)z.n_ticket;
-            // (IWVI_FZ_EXT: no role is played here.  Tickets 0 .. n_reg-1 are ordinary chunks -- shifted past the factor tickets so that the
-            //  code below files them as chunk workgroups --; the LAST tickets belong to the workgroups that found no CU until the
-            //  factorisation launch's workgroups retired: they resume the chunks whose fronts the helpers have prepared)
-            if (z.ext) t = (t < (unsigned)z.n_reg || !z.resume) ? t + (unsigned)z.n_gp : (t - (unsigned)z.n_reg) | 0x40000000u;
-            rw[4] = (int)t; rw[5] = (int)g0;
-        }
-        __syncthreads();
-        const int tk = ufirst(rw[4]);
-        fz_gen = (unsigned)ufirst(rw[5]);
-        __syncthreads();                                          // (the roles below use the LDS from its start)
-        if (g.stamps && tid == 0) {                               // (diagnostic: who played which role, where, and when it came to life)
-            g.stamps[(size_t)blockIdx.x * 128 + 50] = 1000 + tk;
-            g.stamps[(size_t)blockIdx.x * 128 + 51] = __builtin_amdgcn_s_getreg(6164) & 15;   // HW_REG_XCC_ID
-            g.stamps[(size_t)blockIdx.x * 128 + 52] = wall_clock64();
-        }
-        if (z.ext && (tk & 0x40000000)) {
-            // a late workgroup of the EXT experiment: resume slot tk.  What role_factor's tail does for a factorising workgroup: wait for the
-            // helper's snapshot and the pack roles, ONE acquire
-            fz_mode = 2; fz_slot = tk & 0xffff; fz_chunk = z.nchunks_reg + fz_slot;
-            if (tid == 0) {
-                fz_wait_ge(&z.sync->snap[fz_slot], fz_gen + 1u, &z.sync->timeout);
-                fz_wait_ge(&z.sync->pack, (fz_gen + 1u) * (unsigned)z.n_pack, &z.sync->timeout);
-                fz_wait_ge(&z.sync->early, (fz_gen + 1u) * (unsigned)z.n_gp, &z.sync->timeout);
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            __syncthreads();
-        } else if (tk < z.n_gp) {
-            const PreLayer Lc = z.P[tk];                          // (by value: a reference into the kernel arguments would force them into scratch)
-            // (diagnostic stamps land in this workgroup's 128-word row, words 0 .. 15: PRE_STAMP indexes 16 words per block)
-            role_factor<true, true>(Lc, 0, g.stamps ? g.stamps + (size_t)blockIdx.x * 112 : nullptr, 1, FzPub{&z.sync->early, &z.sync->done, &z.sync->cols[tk],
-                                          z.resume ? &z.sync->snap[tk] : nullptr, fz_gen + 1u, &z.sync->pack, (fz_gen + 1u) * (unsigned)z.n_pack, &z.sync->timeout});
-            __syncthreads();
-            if (!z.resume) {
-                if (g.e.fast) fw_arrive_fast<NS, FZ>(gk, static_cast<const FwElboHot&>(g.e), g.rng_state, g.nchunks, tid, -1, 0.0,
-                                                      g.rng_state ? *((const __attribute__((address_space(4))) unsigned long long*)g.rng_state) : 0ULL);
-                else fw_arrive<NS, FZ>(gk, sm, tid, -1);
-                return;
-            }
-            fz_mode = 2; fz_slot = tk; fz_chunk = z.nchunks_reg + tk;      // carries on with the chunk its helper has prepared
-        } else {
-            fz_chunk = tk - z.n_gp;
-            if (fz_chunk < z.n_pack && !z.ext) {
-                // tril(q_sqrt_r)^T packing + KL shares (csrc/precompute_dev.h: role_pack_r): the first chunks carry one (layer, r) each
-                unsigned njobs = 0;
-                if (g.stamps && tid == 0) g.stamps[(size_t)blockIdx.x * 128 + 53] = wall_clock64();
-                for (int j = fz_chunk; j < z.n_pack; j += z.n_reg) {
-                    int l = 0;
-                    while (j >= z.pack_off[l + 1]) ++l;
-                    const PreLayer Lc = z.P[l];
-                    role_pack_r<true>(Lc, j - z.pack_off[l], reinterpret_cast<double*>(fw_smem), g.stamps ? g.stamps + (size_t)blockIdx.x * 128 + 30 : nullptr);
-                    __syncthreads();
-                    ++njobs;
-                }
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // write-through stores, drained by every wave: no release fence
-                __syncthreads();                                  // (a buffer_wbl2 behind ~80 KB of freshly written images took 5-8 us)
-                if (tid == 0) __hip_atomic_fetch_add(&z.sync->pack, njobs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (g.stamps && tid == 0) g.stamps[(size_t)blockIdx.x * 128 + 54] = wall_clock64();
-            }
-            if (z.resume && tk >= z.help_t0 && tk < z.help_t0 + z.n_gp) {
-                fz_mode = 1; fz_slot = tk - z.help_t0; fz_own = fz_chunk; fz_chunk = z.nchunks_reg + fz_slot;   // first the other chunk's front
-            }
-        }
-    }
-    int chunk_id = FZ ? fz_chunk : (int)blockIdx.x;
-fz_restart: ;                                                    // (merged launch, helper: a second pass with its own chunk)
-    int tid_pass = threadIdx.x;
-    if constexpr (FZ) asm volatile("" : "+v"(tid_pass));           // opaque per pass: nothing derived from the thread id is hoisted out of
-    {                                                             // the helper's two-pass loop (hoisted, it stays live through stage 1 / 2: spills)
-    const int tid = tid_pass, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int gq = lane >> 4, jq = lane & 15;
-    const bool fz_resume = FZ && fz_mode == 2;
-    bool fz_acq = false;                                          // the pack roles' images are already acquired (a late arrival)
+    const int chunk_id = (int)blockIdx.x;
     const long long t0 = (long long)chunk_id * NSAMP;
     const int nvalid = (int)((g.T - t0) < (long long)NSAMP ? (g.T - t0) : (long long)NSAMP);
 
     // ---- the last n_early waves (those that draw no noise below) issue every copy of the prologue; the others fetch the layer table and the
     //      chunk's rows (below: "the prologue's copies")
-    const int n_early = FZ ? 0 : g.n_early;
+    const int n_early = g.n_early;
     const bool early_wave = wave >= FW_WAVES - n_early;
     const int ethreads = (FW_WAVES - n_early) * 64;               // threads that run the small loads in front of the first barrier
     // ---- layer table: kernarg -> LDS, every dword in flight at once ------------------------------------
@@ -821,7 +658,6 @@ fz_restart: ;                                                    // (merged laun
     float* obuf = sm + g.lds.obuf;
     float* znoise = sm + g.lds.znoise;
     float* xyrows = sm + g.lds.xyrows;
-    int* counters = reinterpret_cast<int*>(sm + g.lds.cnt);
     float* scratch = sm + g.lds.scratch;
 
     // (through the scalar cache: a vector load here would make every wave wait for vmcnt(0), the early waves for their copies; the counter
@@ -881,7 +717,7 @@ fz_restart: ;                                                    // (merged laun
                                                      (__attribute__((address_space(3))) void*)(zdst + 4 * i0), 16, 0, 0);
         }
     }
-    if (!fz_resume && !early_wave) {                              // (a resumed chunk: all of this comes with the snapshot, below)
+    if (!early_wave) {
     if (tid < NSAMP) {
         const unsigned dp = point_of(tid);
         rowi[tid] = (int)row_of(dp);
@@ -915,7 +751,7 @@ fz_restart: ;                                                    // (merged laun
     //      the last wave down (to every wave when fewer than two are free).  In a wave that does both, whatever reads LDS comes first and
     //      the copies follow back to back: the compiler puts `s_waitcnt vmcnt(0)` in front of every ds_read / ds_write that follows a
     //      global_load_lds, so a table entry read between two copies makes the second wait until the first has landed.
-    const int ncopy0 = FZ ? g.ncopy_indep : g.ncopy;              // (merged launch: what the factorising workgroups write comes last, below)
+    const int ncopy0 = g.ncopy;
     const int draw_waves = g.noise_any_src ? FW_WAVES : ((g.noise_drawn + 63) >> 6 < FW_WAVES ? (g.noise_drawn + 63) >> 6 : FW_WAVES);
     const int ndma = n_early > 0 ? n_early : FW_WAVES;            // (the host has checked that the copy list fits those waves)
     const int dwave = FW_WAVES - 1 - wave;                        // the copies' wave index: 0 = the last wave
@@ -926,7 +762,7 @@ fz_restart: ;                                                    // (merged laun
     // layers laid end to end over the workgroup's threads.  A thread's first item is looked up now (table reads), drawn in registers after
     // this wave's copies are issued and stored last; further items (more than one per thread: rare) follow
     int it_li = -1, it_k = 0, it_dims = 0, it_zoff = 0, it_zero = 0;
-    if (!fz_resume) {
+    {
     if (wave < draw_waves && !g.noise_any_src) {                  // the plan from the header: no LDS round trip per layer
         int base = 0, cnts[IWVI_MAX_STACK], zoffs[IWVI_MAX_STACK], dms[IWVI_MAX_STACK];
 #pragma unroll
@@ -974,7 +810,7 @@ fz_restart: ;                                                    // (merged laun
                                                  (__attribute__((address_space(3))) void*)(yrows + i0), 4, 0, 0);
         }
     }
-    if (!fz_resume) {
+    {
     if (dma_wave) {
     // precomputed encoder outputs of the chunk's distinct data points -> the LV layer's constant block
     for (unsigned pm = g.pre_enc_mask; pm; pm &= pm - 1) {         // (no walk over the layer table: each step of it is a scalar-cache round trip)
@@ -1039,44 +875,6 @@ fz_restart: ;                                                    // (merged laun
         }
     }
     FW_STAMP(57);
-    if constexpr (FZ) {
-        // the GP layers' constant blocks and Gram operands Z~ are written by the factorising workgroups of THIS launch (~3 us into it):
-        // one lane waits for all of them, one agent-scope acquire covers the workgroup, then the copies are plain LDS-DMA loads
-        if (wave == 0) {
-            int packed = 0;
-            if (lane == 0) {
-                fz_wait_ge(&gk.z.sync->early, (fz_gen + 1u) * (unsigned)gk.z.n_gp, &gk.z.sync->timeout);
-                packed = (int)(__hip_atomic_load(&gk.z.sync->pack, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - (fz_gen + 1u) * (unsigned)gk.z.n_pack) >= 0;
-                counters[6] = packed;                             // (a workgroup that comes late finds the pack roles done: this acquire covers them)
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        __syncthreads();
-        fz_acq = counters[6] != 0;
-        fw_copy_entries(CT, sm, g.ncopy_indep, g.ncopy, wave, lane);
-    }
-    } else {
-        if constexpr (FZ) {
-            // ---- resume: the chunk's front was computed by its helper.  What is the same for every chunk (constant blocks, weights, Z~)
-            //      is copied as ever -- the factorisations are over, one acquire covers them and the pack roles --, what is particular
-            //      to the chunk comes back from HBM (sc1 loads to registers, all in flight, then LDS)
-            const FzArgs& z = gk.z;
-            // (the snapshot's and the pack roles' counters were polled and the acquire issued beside the factorisation's last diagonal
-            //  pass -- role_factor, FzPub::wait1 / wait2 -- so nothing but the loads themselves stands between `done` and the Gram)
-            fw_copy_entries(CT, sm, 0, g.ncopy, wave, lane);
-            const Sc1Stream src(z.snap + (size_t)fz_slot * z.snap_stride, (unsigned)z.snap_stride, 0u);
-            f32x4* dl = reinterpret_cast<f32x4*>(sm);
-            const int nA = (z.snap_a1 - z.snap_a0) >> 2, nB = (z.snap_b1 - z.snap_b0) >> 2;
-            for (int v0 = tid; v0 < nA + nB; v0 += 4 * FW_THREADS) {
-                f32x4 r[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) { const int v = v0 + u * FW_THREADS; r[u] = src[(size_t)(v < nA + nB ? v : nA + nB - 1)]; }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) { const int v = v0 + u * FW_THREADS; if (v < nA + nB) dl[v < nA ? (z.snap_a0 >> 2) + v : (z.snap_b0 >> 2) + (v - nA)] = r[u]; }
-            }
-            fz_acq = true;                                        // (the pack roles are acquired: no second fence at the wait)
-        }
     }
     FW_STAMP(58);
     // the launch's device scalars -> LDS (likelihood variance: read in the tail; kernel variances: read at the top of a layer -- a global round
@@ -1095,9 +893,6 @@ fz_restart: ;                                                    // (merged laun
 
     int xt_for = -1;                                              // layer whose Gram operand x~ is already in `xt`
     for (int li = 0; li < g.n_layers; ++li) {
-        if constexpr (FZ) {
-            if (fz_resume && li < gk.z.first_gp) { float* tmp = xin; xin = xout; xout = tmp; continue; }   // (the helper ran these layers)
-        }
         const FwLayer& L = LT[li];
         // the layer's 32 hot words: ONE pair of wide scalar loads from the (warmed) kernel-argument lines, then opaque registers.  Read through
         // a reference, every field was re-loaded next to each use (the compiler rematerialises loads of the kernel arguments instead of
@@ -1215,9 +1010,7 @@ fz_restart: ;                                                    // (merged laun
             // else difference the coordinates directly (error ~eps * r^2)
             const bool gram_mfma = __float_as_int(cst[64]) <= __float_as_int(4.0f);   // zmax2 >= 0: int compare is exact
 
-            const bool fz_skip_front = FZ && fz_resume && li == gk.z.first_gp;   // (resume: x~ came with the snapshot)
             // ---- x~ (only when the layer before did not already leave it in `xt`) -------------------------
-            if (fz_skip_front) xt_for = li;
             if (xt_for != li) {
                 if (wave < NS) xt_subtile(xin + (16 * wave + jq) * XSTR, xt + (16 * wave + jq) * XSTR, invls, zc, D, nsteps, rbf, gq);
                 __syncthreads();
@@ -1225,30 +1018,6 @@ fz_restart: ;                                                    // (merged laun
             // (the layer's forward-substitution stream is already on its way to LDS: prologue for the first GP
             // layer, the previous GP layer's stage 2 for the others)
             FW_STAMP(2 + li * 6 + 0);
-            if constexpr (FZ) {
-                if (fz_mode == 1 && li == gk.z.first_gp) {
-                    // ---- helper: this chunk belongs to a factorising workgroup.  What its layers need from here on that is particular to
-                    //      the chunk -- the activation tiles with x~, the regulariser sums, the row indices, the noise of every layer --
-                    //      is left in HBM (write-through; ~16 KB), counted in, and this workgroup starts over with its own chunk
-                    const FzArgs& z = gk.z;
-                    if (xt_for == li) __syncthreads();            // (x~ from the layer before: complete behind its barrier; own phase: synced above)
-                    if (g.stamps && tid == 0) g.stamps[(size_t)blockIdx.x * 128 + 53] = wall_clock64();
-                    const f32x4* sl = reinterpret_cast<const f32x4*>(sm);
-                    f32x4* dg = reinterpret_cast<f32x4*>(z.snap + (size_t)fz_slot * z.snap_stride);
-                    const int nA = (z.snap_a1 - z.snap_a0) >> 2, nB = (z.snap_b1 - z.snap_b0) >> 2;
-                    for (int v = tid; v < nA + nB; v += FW_THREADS) {
-                        const f32x4 x = sl[v < nA ? (z.snap_a0 >> 2) + v : (z.snap_b0 >> 2) + (v - nA)];
-                        asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(dg + v), "v"(x) : "memory");
-                    }
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    __syncthreads();
-                    if (tid == 0) __hip_atomic_fetch_add(&z.sync->snap[fz_slot], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (g.stamps && tid == 0) g.stamps[(size_t)blockIdx.x * 128 + 54] = wall_clock64();
-                    fz_mode = 0; chunk_id = fz_own;
-                    goto fz_restart;
-                }
-            }
-
             // ---- Gram: kuf block bi = kernel(Z_bi, x), written in B-operand order ---------------------------
             for (int bi = wave; bi < nbk; bi += FW_WAVES) {
                 f32x4 acc[NS];
@@ -1318,69 +1087,6 @@ fz_restart: ;                                                    // (merged laun
                     }
                 }
             }
-            if constexpr (FZ) {
-                if (li == gk.z.first_gp) {
-                    // ---- merged launch: from here on the layers need the factorisation.  The pack roles finished long ago (one acquire,
-                    // in the shadow of the wait); `done` is polled by one lane and everything it guards is read by sc1 loads.
-                    FW_STAMP(60);
-                    if (wave == 0) {
-                        if (!fz_acq) {
-                            if (lane == 0) fz_wait_ge(&gk.z.sync->pack, (fz_gen + 1u) * (unsigned)gk.z.n_pack, &gk.z.sync->timeout);
-                            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                        }
-                        // this layer's solve stream goes to the LDS staging buffer COLUMN BY COLUMN, as the factorising workgroup
-                        // publishes it (a column is final one pass after its diagonal block): when the last one arrives, only that
-                        // one is left to fetch -- the stream's 36 KiB never sit on the critical path.  sc1 loads to registers, then LDS.
-                        if (G.ls_off >= 0 && nbk <= 8) {
-                            const Sc1Stream src(G.LsP, (unsigned)(tri_blocks(nbk) * BLK16 * 4), (unsigned)lane * 16u);
-                            f32x4* dstl = reinterpret_cast<f32x4*>(sm + G.ls_off) + lane;
-                            const unsigned cbase = fz_gen * (unsigned)nbk;
-                            unsigned* cw = &gk.z.sync->cols[0];                // (the first GP layer is factorised under ticket 0)
-                            int j = 0;
-                            while (j < nbk) {
-                                unsigned have = 0;
-                                if (lane == 0) have = fz_wait_ge_val(cw, cbase + (unsigned)j + 1u, &gk.z.sync->timeout) - cbase;
-                                int upto = __builtin_amdgcn_readfirstlane((int)have);
-                                if (upto >= nbk) break;                       // everything is there: what is left goes faster with every wave (below)
-                                const int b1 = tri_upper_off(nbk, upto);
-                                for (int b = tri_upper_off(nbk, j); b < b1; b += 8) {
-                                    f32x4 v[8];
-#pragma unroll
-                                    for (int u = 0; u < 8; ++u) v[u] = src[(size_t)(b + u < b1 ? b + u : b1 - 1) * 64];
-#pragma unroll
-                                    for (int u = 0; u < 8; ++u) if (b + u < b1) dstl[(size_t)(b + u) * 64] = v[u];
-                                }
-                                j = upto;
-                            }
-                            if (lane == 0) counters[7] = j;
-                        }
-                        if (lane == 0) fz_wait_ge(&gk.z.sync->done, (fz_gen + 1u) * (unsigned)gk.z.n_gp, &gk.z.sync->timeout);
-                        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-                    }
-                    __syncthreads();
-                    FW_STAMP(61);
-                    if (G.ls_off >= 0 && nbk <= 8) {
-                        // the columns not yet staged (the last two of a workgroup that kept up; all of them for one that arrived after the
-                        // factorisation -- a resumed chunk, a helper's own chunk): all waves, every load in flight at once
-                        const int b0 = tri_upper_off(nbk, counters[7]), nv = (tri_blocks(nbk) - b0) * 64;
-                        const Sc1Stream src(G.LsP, (unsigned)(tri_blocks(nbk) * BLK16 * 4), 0u);
-                        f32x4* dstl = reinterpret_cast<f32x4*>(sm + G.ls_off);
-                        for (int v0 = tid; v0 < nv; v0 += 5 * FW_THREADS) {
-                            f32x4 r[5];
-#pragma unroll
-                            for (int u = 0; u < 5; ++u) { const int v = v0 + u * FW_THREADS; r[u] = src[(size_t)(b0 * 64 + (v < nv ? v : nv - 1))]; }
-#pragma unroll
-                            for (int u = 0; u < 5; ++u) { const int v = v0 + u * FW_THREADS; if (v < nv) dstl[b0 * 64 + v] = r[u]; }
-                        }
-                    }
-                    // the split-f16 scales the pack roles wrote into every GP layer's constant block (cst[64 .. 104)), now that they exist
-                    for (int i = tid; i < g.n_layers * 40; i += FW_THREADS) {
-                        const int l = i / 40, o = 64 + (i - l * 40);
-                        if (gk.H[l].type == IWVI_LAYER_GP) sm[gk.H[l].c_off + o] = ((gptr1)LT[l].gp.cst)[o];
-                    }
-                    // (visible behind the barrier that ends the Gram phase, below)
-                }
-            }
             // stage 2's first operands are requested here, in the shadow of the Gram phase's barrier (nothing in them
             // depends on the Gram or the solve), so that its MFMAs start right behind the barrier that ends stage 1
             const int ntri = tri_blocks(nbk);
@@ -1400,8 +1106,7 @@ fz_restart: ;                                                    // (merged laun
             for (int i = 0; i < LSN; ++i) {
                 lsn[i] = f32x4{0.f, 0.f, 0.f, 0.f};
                 if (tid + i * FW_THREADS < lsn4) {
-                    if constexpr (FZ) lsn[i] = Sc1Stream(H.nx_ls, (unsigned)H.nx_ls_n * 4u, 0u)[tid + i * FW_THREADS];
-                    else lsn[i] = ((gptr4)H.nx_ls)[tid + i * FW_THREADS];
+                    lsn[i] = ((gptr4)H.nx_ls)[tid + i * FW_THREADS];
                 }
             }
             f32x4 ring[4];
@@ -1521,9 +1226,7 @@ fz_restart: ;                                                    // (merged laun
             }
             if (wave < NS) {
                 const int tcol = 16 * wave + jq;                  // this lane's sample column
-                using ApT = typename std::conditional<FZ, Sc1Stream, gptr4>::type;
-                ApT Ap = [&]() { if constexpr (FZ) return Sc1Stream(G.LsP, (unsigned)(tri_blocks(nbk) * BLK16 * 4), (unsigned)lane * 16u);
-                                 else return (gptr4)G.LsP + lane; }();
+                const gptr4 Ap = (gptr4)G.LsP + lane;
                 const gout1 arow = (o_a && tcol < nvalid) ? o_a + (size_t)(t0 + tcol) * G.Mp : (gout1)nullptr;
                 float ssq = 0.f;
                 if (G.ls_off >= 0 && nbk <= 8) {
@@ -2117,10 +1820,9 @@ fz_restart: ;                                                    // (merged laun
             for (int p = 0; p < npl; ++p) part += (double)xt[p];                       // fixed order
             if (!E.fast) __hip_atomic_store(E.ws + chunk_id, part, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        if (E.fast) { fw_arrive_fast<NS, FZ>(gk, Eh, th.rng, th.nchunks, tid, chunk_id, part, step); return; }   // (uniform)
+        if (E.fast) { fw_arrive_fast<NS>(gk, Eh, th.rng, th.nchunks, tid, chunk_id, part, step); return; }   // (uniform)
     }
-    fw_arrive<NS, FZ>(gk, sm, tid, chunk_id);
-    }
+    fw_arrive<NS>(gk, sm, tid, chunk_id);
 }
 
 // the packed arrival (fw_arrive_fast) applies when every point's K samples sit in one chunk (the kernel's local_lse), the launch finishes the
@@ -2132,15 +1834,15 @@ static void fw_decide_fast(FwArgs& a, unsigned grid, int nsamp, int64_t T) {
                   a.h.rng_state && grid <= 511u && 2 * (int64_t)a.h.nchunks <= ws_len && E.kl_total <= 64 && !dbg_opt("IWVI_FW_SLOW_TAIL")) ? 1 : 0;
 }
 
-template <int NS, bool S16, bool FZ = false>
+template <int NS, bool S16>
 static int launch_forward(const FwArgs& a, unsigned grid, size_t lds_bytes, hipStream_t stream) {
     static size_t attr_set = 0;
     if (lds_bytes > attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_dgp_forward<NS, S16, FZ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        hipError_t e = hipFuncSetAttribute((const void*)k_dgp_forward<NS, S16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) { set_error("hipFuncSetAttribute(k_dgp_forward, %zu B): %s", lds_bytes, hipGetErrorString(e)); return IWVI_ERR_LAUNCH; }
         attr_set = lds_bytes;
     }
-    hipLaunchKernelGGL((k_dgp_forward<NS, S16, FZ>), dim3(grid), dim3(FW_THREADS), lds_bytes, stream, a);
+    hipLaunchKernelGGL((k_dgp_forward<NS, S16>), dim3(grid), dim3(FW_THREADS), lds_bytes, stream, a);
     return check_launch("k_dgp_forward");
 }
 
@@ -2214,9 +1916,8 @@ static void plan_stage2(FwGp& G) {
 
 // LDS image for a chunk of nsamp samples; fills the per-layer offsets of `a`.  stage_zt: keep every GP layer's
 // Gram operand Z~ in LDS for the whole launch.
-static size_t fw_plan_lds(FwArgs& a, int nsamp, int maxR, int maxP, bool stage_zt, bool stage_ls, bool fz = false) {
+static size_t fw_plan_lds(FwArgs& a, int nsamp, int maxR, int maxP, bool stage_zt, bool stage_ls) {
     int scratch = 0, zdims = 0, o = 0, ls_max = 0;
-    bool seen_gp = false;
     FwLds& l = a.h.lds;
     l.ltab = o; o += up4((int)((sizeof(FwArgs) - offsetof(FwArgs, L)) / 4));
     l.xa = o; o += up4(nsamp * a.h.xstr);
@@ -2244,10 +1945,7 @@ static size_t fw_plan_lds(FwArgs& a, int nsamp, int maxR, int maxP, bool stage_z
             G.zt_off = -1;
             if (stage_zt) { G.zt_off = o; o += G.nbk * G.nsteps * 64; }
             G.ls_off = -1;
-            // (merged launch: the first GP layer's stream does not exist yet when the prologue runs -- it is staged column by column
-            // while the factorisation runs; the later layers' streams are staged as ever, one layer ahead)
             if (stage_ls && G.nbk <= 8 && tri_blocks(G.nbk) * BLK16 > ls_max) ls_max = tri_blocks(G.nbk) * BLK16;
-            seen_gp = true;
             zdims += G.R;
             const int need = gp_scratch_floats(G.Mp, G.nbk, G.R, nsamp);
             if (need > scratch) scratch = need;
@@ -2269,11 +1967,9 @@ static size_t fw_plan_lds(FwArgs& a, int nsamp, int maxR, int maxP, bool stage_z
     }
     int ls_first = -1;
     if (ls_max > 0) {                                   // one staging buffer, reused layer after layer
-        bool first_gp = true;
         for (int i = 0; i < a.h.n_layers; ++i) {
             if (a.L[i].type != IWVI_LAYER_GP) continue;
-            if (a.L[i].gp.nbk <= 8) { a.L[i].gp.ls_off = o; if (ls_first < 0 && !fz) ls_first = i; }
-            first_gp = false;
+            if (a.L[i].gp.nbk <= 8) { a.L[i].gp.ls_off = o; if (ls_first < 0) ls_first = i; }
         }
         o += ls_max;
     }
@@ -2325,11 +2021,10 @@ static size_t fw_plan_lds(FwArgs& a, int nsamp, int maxR, int maxP, bool stage_z
     }
     {
         const int draw_waves = a.h.noise_any_src ? FW_WAVES : std::min(FW_WAVES, (a.h.noise_drawn + 63) / 64);
-        a.h.n_early = (!fz && FW_WAVES - draw_waves >= 2) ? std::min(FW_WAVES - draw_waves, FW_WAVES / 2) : 0;   // (at least half of the waves fetch the table and the rows)
+        a.h.n_early = (FW_WAVES - draw_waves >= 2) ? std::min(FW_WAVES - draw_waves, FW_WAVES / 2) : 0;   // (at least half of the waves fetch the table and the rows)
     }
     a.h.zt_mask = 0;
-    // the copy list in two parts: first what no workgroup of a merged launch writes (mixing matrices, mean functions, encoder weights),
-    // then the GP layers' constant blocks and Gram operands (ncopy_indep separates them; an ordinary launch issues all of it at once)
+    // the copy list: mixing matrices, mean functions, encoder weights, then the GP layers' constant blocks and Gram operands
     for (int i = 0; i < a.h.n_layers; ++i) {
         FwLayer& L = a.L[i];
         FwNoise& nz = a.N[i];
@@ -2355,7 +2050,6 @@ static size_t fw_plan_lds(FwArgs& a, int nsamp, int maxR, int maxP, bool stage_z
             }
         }
     }
-    a.h.ncopy_indep = a.h.ncopy;
     for (int i = 0; i < a.h.n_layers; ++i) {
         FwLayer& L = a.L[i];
         if (L.type != IWVI_LAYER_GP) continue;
@@ -2367,25 +2061,19 @@ static size_t fw_plan_lds(FwArgs& a, int nsamp, int maxR, int maxP, bool stage_z
         }
     }
     if (a.h.n_early > 0 && a.h.ncopy > a.h.n_early * (FW_MAX_COPY / FW_WAVES)) {          // (the small copies would not fit those waves' registers:
-        for (int i = 0; i < a.h.n_layers; ++i)                                            //  every wave copies, as in a merged launch)
+        for (int i = 0; i < a.h.n_layers; ++i)                                            //  every wave copies)
             if (a.h.zt_mask >> i & 1) add_copy(a.L[i].gp.ZtP, a.L[i].gp.nbk * a.L[i].gp.nsteps * 64, a.L[i].gp.zt_off, true);
         a.h.n_early = 0; a.h.zt_mask = 0;
     }
     l.cnt = o; o += 24;                                  // 12 counters / scalars, then one kernel variance per layer (device scalars, fetched in the prologue)
     l.scratch = o; o += up4(scratch);
     l.total = o;
-    a.z.snap_a0 = l.xa; a.z.snap_a1 = l.asq; a.z.snap_b0 = l.znoise; a.z.snap_b1 = l.znoise + up4(zdims * nsamp);
     return (size_t)o * sizeof(float);
 }
 
-// `fz` (merged launch): the iwvi_gp_desc of every GP layer of the stack, in stack order, + the sync block.  FZ_FALLBACK = this stack /
-// shape is not covered by the merged launch (the caller runs the precompute launch, then calls again without `fz`).
-struct FzHost { const iwvi_gp_desc* gp; int n_gp; void* ws; };
-constexpr int FZ_FALLBACK = 1;
-static int dgp_forward_fz(const iwvi_layer_desc* layers, int n_layers, const float* X, int Dx, const float* XY, int XYdim,
+int dgp_forward_impl(const iwvi_layer_desc* layers, int n_layers, const float* X, int Dx, const float* XY, int XYdim,
                           const float* Y, int Dy, int64_t T, int64_t row_div, int64_t row_mod, float lik_variance,
-                          uint64_t seed, uint64_t* rng_state, float* out_logw, const iwvi_elbo_desc* elbo, hipStream_t stream,
-                          const FzHost* fz) {
+                          uint64_t seed, uint64_t* rng_state, float* out_logw, const iwvi_elbo_desc* elbo, hipStream_t stream) {
     if (T <= 0) return IWVI_OK;                         // empty batch: nothing to do
     if (!layers || n_layers <= 0 || n_layers > IWVI_MAX_STACK) { set_error("iwvi_dgp_forward: %d layers (1..%d supported)", n_layers, IWVI_MAX_STACK); return IWVI_ERR_ARG; }
     if (!X || Dx <= 0 || Dx > IWVI_MAX_D) { set_error("iwvi_dgp_forward: null X or Dx=%d out of range (1..%d)", Dx, IWVI_MAX_D); return IWVI_ERR_ARG; }
@@ -2499,31 +2187,6 @@ static int dgp_forward_fz(const iwvi_layer_desc* layers, int n_layers, const flo
         a.h.xstr = round_up(wmax, 4) + 1;
         if (a.h.xstr > XSTR_MAX) a.h.xstr = XSTR_MAX;
     }
-    // ---- merged launch: is this stack covered?  (every GP layer factorises in LDS -- M <= 128 --, no dense factors asked for, encoders
-    //      evaluated inside the layer kernel, the arrival ticket present)
-    bool use_fz = false;
-    if (fz) {
-        if (T > 0 && (!fz->gp || fz->n_gp <= 0 || !fz->ws)) { set_error("iwvi_dgp_forward_fused: null GP descriptors / workspace"); return IWVI_ERR_ARG; }
-        use_fz = rng_state != nullptr && !g_dbg_exit;
-        int k = 0;
-        FzArgs& z = a.z;
-        z.pack_off[0] = 0;
-        for (int i = 0; i < n_layers && use_fz; ++i) {
-            if (layers[i].type == IWVI_LAYER_LV) { if (layers[i].enc_out) use_fz = false; continue; }
-            if (k >= fz->n_gp || fz->gp[k].state != layers[i].state || fz->gp[k].M != layers[i].M || fz->gp[k].R != layers[i].R) {
-                set_error("iwvi_dgp_forward_fused: GP descriptor %d does not describe layer %d of the stack", k, i); return IWVI_ERR_ARG;
-            }
-            const int rc = fill_pre_layer(fz->gp[k], i, z.P[k]);
-            if (rc != IWVI_OK) return rc;
-            if (z.P[k].Mp > 128 || z.P[k].flags != 0) use_fz = false;
-            if (k == 0) z.first_gp = i;
-            z.pack_off[k + 1] = z.pack_off[k] + fz->gp[k].R;
-            ++k;
-        }
-        if (use_fz && k != fz->n_gp) { set_error("iwvi_dgp_forward_fused: %d GP descriptors for a stack with %d GP layers", fz->n_gp, k); return IWVI_ERR_ARG; }
-        if (!use_fz) return FZ_FALLBACK;
-        z.enabled = 1; z.n_gp = k; z.n_pack = z.pack_off[k]; z.sync = reinterpret_cast<FzSync*>(fz->ws);
-    }
     // chunk size: 16*NS samples per workgroup, NS no larger than what gives every CU a workgroup, then the
     // largest that fits the LDS (with Z~ staged if that fits too)
     const size_t LDS_MAX = 160 * 1024;
@@ -2532,11 +2195,11 @@ static int dgp_forward_fz(const iwvi_layer_desc* layers, int n_layers, const flo
     if (ns < 1) ns = 1;
     size_t lds_bytes = 0;
     for (; ns >= 1; --ns) {
-        lds_bytes = fw_plan_lds(a, 16 * ns, maxR, maxP, true, true, use_fz);
+        lds_bytes = fw_plan_lds(a, 16 * ns, maxR, maxP, true, true);
         if (lds_bytes <= LDS_MAX) break;
-        lds_bytes = fw_plan_lds(a, 16 * ns, maxR, maxP, true, false, use_fz);
+        lds_bytes = fw_plan_lds(a, 16 * ns, maxR, maxP, true, false);
         if (lds_bytes <= LDS_MAX) break;
-        lds_bytes = fw_plan_lds(a, 16 * ns, maxR, maxP, false, false, use_fz);
+        lds_bytes = fw_plan_lds(a, 16 * ns, maxR, maxP, false, false);
         if (lds_bytes <= LDS_MAX) break;
     }
     if (ns < 1) { set_error("iwvi_dgp_forward: the layer stack needs %zu B of LDS per 16 samples (> 160 KiB)", lds_bytes); return IWVI_ERR_UNSUPPORTED; }
@@ -2573,44 +2236,6 @@ static int dgp_forward_fz(const iwvi_layer_desc* layers, int n_layers, const flo
     a.h.nchunks = (int)chunks;
     a.h.stamps = (g_stamp_buf && chunks + IWVI_MAX_STACK <= g_stamp_wgs) ? g_stamp_buf : nullptr;
     a.h.dbg_exit = g_dbg_exit;
-    if (use_fz) {
-        FzArgs& z = a.z;
-        static int n_cu = 0;
-        if (!n_cu) { int dev = 0; (void)hipGetDevice(&dev); if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) n_cu = 256; }
-        // more workgroups than CUs (one workgroup per CU at these LDS sizes): the factorising workgroups own chunks too (resume mode) --
-        // a chunk workgroup left without a CU would only start when a factorising one retires, and pay its whole front behind it
-        z.resume = (chunks + z.n_gp > n_cu && chunks >= 2 * z.n_gp + z.n_pack && (size_t)(z.snap_a1 - z.snap_a0 + z.snap_b1 - z.snap_b0) * 4 <= FZ_SNAP_BYTES &&
-                    !dbg_opt("IWVI_FZ_NO_RESUME")) ? 1 : 0;
-        z.ext = dbg_opt("IWVI_FZ_EXT") ? 1 : 0;
-        if (z.ext && dbg_opt("IWVI_FZ_EXT") == 2) z.resume = 0;    // (2: without the late workgroups' resume)
-        z.snap = reinterpret_cast<unsigned char*>(fz->ws) + sizeof(FzSync);
-        z.snap_stride = (unsigned)FZ_SNAP_BYTES;
-        z.help_t0 = z.n_gp + z.n_pack;
-        z.n_reg = (int)chunks - (z.resume ? z.n_gp : 0);
-        z.nchunks_reg = z.n_reg;
-        z.n_ticket = (z.resume || z.ext) ? (int)chunks : z.n_gp + (int)chunks;
-        for (int k = 0; k < z.n_gp; ++k) { const size_t la = factor_lds_bytes(z.P[k].Mp); if (la > lds_bytes) lds_bytes = la; }
-        const unsigned grid = (unsigned)z.n_ticket;
-        fw_decide_fast(a, grid, 16 * ns, T);
-        if (s16_all) switch (ns) {
-#ifndef IWVI_DEV_ONLY5   /* development builds: only the 80-sample variants (make DEV5=1) */
-            case 1: return launch_forward<1, true, true>(a, grid, lds_bytes, stream);
-            case 2: return launch_forward<2, true, true>(a, grid, lds_bytes, stream);
-            case 3: return launch_forward<3, true, true>(a, grid, lds_bytes, stream);
-            case 4: return launch_forward<4, true, true>(a, grid, lds_bytes, stream);
-#endif
-            default: return launch_forward<5, true, true>(a, grid, lds_bytes, stream);
-        }
-        switch (ns) {
-#ifndef IWVI_DEV_ONLY5   /* development builds: only the 80-sample variants (make DEV5=1) */
-            case 1: return launch_forward<1, false, true>(a, grid, lds_bytes, stream);
-            case 2: return launch_forward<2, false, true>(a, grid, lds_bytes, stream);
-            case 3: return launch_forward<3, false, true>(a, grid, lds_bytes, stream);
-            case 4: return launch_forward<4, false, true>(a, grid, lds_bytes, stream);
-#endif
-            default: return launch_forward<5, false, true>(a, grid, lds_bytes, stream);
-        }
-    }
     fw_decide_fast(a, (unsigned)chunks, 16 * ns, T);
     if (s16_all) switch (ns) {
 #ifndef IWVI_DEV_ONLY5   /* development builds: only the 80-sample variants (make DEV5=1) */
@@ -2632,14 +2257,6 @@ static int dgp_forward_fz(const iwvi_layer_desc* layers, int n_layers, const flo
     }
 }
 
-// (the entry the other translation units call: csrc/gp_layer.hip, csrc/lv_elbo.hip)
-int dgp_forward_impl(const iwvi_layer_desc* layers, int n_layers, const float* X, int Dx, const float* XY, int XYdim,
-                     const float* Y, int Dy, int64_t T, int64_t row_div, int64_t row_mod, float lik_variance,
-                     uint64_t seed, uint64_t* rng_state, float* out_logw, const iwvi_elbo_desc* elbo, hipStream_t stream) {
-    return dgp_forward_fz(layers, n_layers, X, Dx, XY, XYdim, Y, Dy, T, row_div, row_mod, lik_variance, seed, rng_state, out_logw,
-                          elbo, stream, nullptr);
-}
-
 }  // namespace iwvi
 
 using namespace iwvi;
@@ -2648,76 +2265,6 @@ extern "C" int iwvi_dgp_forward(const iwvi_layer_desc* layers, int n_layers, con
                                 const float* XY, int XYdim, const float* Y, int Dy, int64_t T, int64_t row_div,
                                 int64_t row_mod, float lik_variance, uint64_t seed, uint64_t* rng_state,
                                 float* out_logw, const iwvi_elbo_desc* elbo, void* stream) {
-    return dgp_forward_impl(layers, n_layers, X, Dx, XY, XYdim, Y, Dy, T, row_div, row_mod, lik_variance, seed,
-                            rng_state, out_logw, elbo, (hipStream_t)stream);
-}
-
-// ---- experiment (IWVI_FZ_EXT): the merged launch's roles as a launch of their own, 1024 threads per workgroup like k_precompute, publishing
-//      through the same counters -- run on a second stream BESIDE a k_dgp_forward<.., FZ> launch whose workgroups are all chunk workgroups
-struct PubArgs { PreLayer P[IWVI_MAX_STACK]; int n_gp; FzSync* sync; };
-__global__ __launch_bounds__(1024) void k_precompute_pub(PubArgs a) {
-    const int l = blockIdx.x, role = blockIdx.y, tid = threadIdx.x;
-    if (tid == 0) __hip_atomic_fetch_add(&a.sync->started, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (this workgroup has its CU: see k_fz_gate)
-    if (l >= a.n_gp) return;
-    const PreLayer Lc = a.P[l];
-    if (role == 0) {
-        role_factor<true, true>(Lc, 0, nullptr, 1, FzPub{&a.sync->early, &a.sync->done, &a.sync->cols[l], nullptr, 0u, nullptr, 0u, &a.sync->timeout});
-    } else if (role <= Lc.R) {
-        role_pack_r<true>(Lc, role - 1, reinterpret_cast<double*>(smem_raw));
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (tid == 0) __hip_atomic_fetch_add(&a.sync->pack, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-}
-// one workgroup in front of the layer launch on ITS stream: leaves once every workgroup of this evaluation's k_precompute_pub has a CU, so
-// that the layer launch's 256 workgroups cannot take the CUs the factorisation needs (inside a captured graph nothing else orders the two)
-__global__ void k_fz_gate(FzSync* s, unsigned nblocks) {
-    if (threadIdx.x == 0) {
-        const unsigned g0 = __hip_atomic_load(&s->gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        fz_wait_ge(&s->started, (g0 + 1u) * nblocks, &s->timeout);
-    }
-}
-static int pub_blocks(const iwvi_gp_desc* gp, int n_gp) { int maxR = 1; for (int k = 0; k < n_gp; ++k) maxR = std::max(maxR, (int)gp[k].R); return n_gp * (1 + maxR); }
-extern "C" int iwvi_fz_gate(const iwvi_gp_desc* gp, int n_gp, void* fused_ws, void* stream) {
-    if (!gp || n_gp <= 0 || !fused_ws) { set_error("iwvi_fz_gate: bad arguments"); return IWVI_ERR_ARG; }
-    hipLaunchKernelGGL(k_fz_gate, dim3(1), dim3(64), 0, (hipStream_t)stream, reinterpret_cast<FzSync*>(fused_ws), (unsigned)pub_blocks(gp, n_gp));
-    return check_launch("k_fz_gate");
-}
-extern "C" int iwvi_gp_precompute_pub(const iwvi_gp_desc* gp, int n_gp, void* fused_ws, void* stream) {
-    if (!gp || n_gp <= 0 || n_gp > IWVI_MAX_STACK || !fused_ws) { set_error("iwvi_gp_precompute_pub: bad arguments"); return IWVI_ERR_ARG; }
-    PubArgs a{};
-    int maxR = 1;
-    size_t lds = 0;
-    for (int k = 0; k < n_gp; ++k) {
-        const int rc = fill_pre_layer(gp[k], k, a.P[k]);
-        if (rc != IWVI_OK) return rc;
-        if (a.P[k].Mp > 128 || a.P[k].flags != 0) { set_error("iwvi_gp_precompute_pub: layer %d is not covered (M > 128 or dense factors)", k); return IWVI_ERR_UNSUPPORTED; }
-        maxR = std::max(maxR, a.P[k].R);
-        lds = std::max(lds, factor_lds_bytes(a.P[k].Mp));
-    }
-    a.n_gp = n_gp; a.sync = reinterpret_cast<FzSync*>(fused_ws);
-    static size_t attr_set = 0;
-    if (lds > attr_set) {
-        if (hipFuncSetAttribute((const void*)k_precompute_pub, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) { set_error("iwvi_gp_precompute_pub: LDS attribute"); return IWVI_ERR_LAUNCH; }
-        attr_set = lds;
-    }
-    hipLaunchKernelGGL(k_precompute_pub, dim3(n_gp, 1 + maxR), dim3(1024), lds, (hipStream_t)stream, a);
-    return check_launch("k_precompute_pub");
-}
-
-extern "C" size_t iwvi_fused_ws_bytes(void) { return sizeof(iwvi::FzSync) + (size_t)IWVI_MAX_STACK * iwvi::FZ_SNAP_BYTES; }
-
-extern "C" int iwvi_dgp_forward_fused(const iwvi_gp_desc* gp, int n_gp, void* fused_ws,
-                                      const iwvi_layer_desc* layers, int n_layers, const float* X, int Dx,
-                                      const float* XY, int XYdim, const float* Y, int Dy, int64_t T, int64_t row_div,
-                                      int64_t row_mod, float lik_variance, uint64_t seed, uint64_t* rng_state,
-                                      float* out_logw, const iwvi_elbo_desc* elbo, void* stream) {
-    const FzHost fz{gp, n_gp, fused_ws};
-    int rc = dgp_forward_fz(layers, n_layers, X, Dx, XY, XYdim, Y, Dy, T, row_div, row_mod, lik_variance, seed,
-                            rng_state, out_logw, elbo, (hipStream_t)stream, &fz);
-    if (rc != FZ_FALLBACK) return rc;
-    // not covered by the merged launch (M > 128, dense factors, precomputed encoder outputs, no ticket word): the two launches
-    if ((rc = iwvi_model_precompute(gp, n_gp, nullptr, 0, stream)) != IWVI_OK) return rc;
     return dgp_forward_impl(layers, n_layers, X, Dx, XY, XYdim, Y, Dy, T, row_div, row_mod, lik_variance, seed,
                             rng_state, out_logw, elbo, (hipStream_t)stream);
 }

@@ -21,30 +21,12 @@ struct PreLayer {
 };
 #define PRE_STAMP(k) do { if (stamps && threadIdx.x == 0) stamps[(size_t)blockIdx.x * 16 + (k)] = wall_clock64(); } while (0)
 
-// ---- the merged launch (csrc/dgp_forward.hip, FZ): role_factor runs in a workgroup of the SAME launch as its readers, on another CU,
-// possibly another XCD (private L2s).  Everything it hands over is stored WRITE-THROUGH (sc1) and counted in after every storing
-// wave's vmcnt(0) + the workgroup barrier (MI355X_MICROARCH.md, inter-workgroup visibility: sc1 payload, drained, one agent-scope add):
-//   early  += 1  once cst[0 .. 72) and Z~ are written: all the K_uf Gram needs (readers: acquire, then plain loads)
-//   cols   += 1  per packed column of the solve stream LsP, in order (readers stage the stream in LDS column by column, sc1 loads)
-//   done   += 1  once the solve stream LsP is complete (readers: sc1 loads to registers, no acquire on the critical path)
-struct FzPub { unsigned* early; unsigned* done; unsigned* cols;      // cols += 1 per packed column of LsP (in order)
-               // resume mode: words this workgroup's own chunk will wait for, polled (bounded) + ONE agent acquire beside the last diagonal pass
-               unsigned* wait1; unsigned target1; unsigned* wait2; unsigned target2; unsigned* tmo; };
-template <bool WT>
-__device__ __forceinline__ void st_pub(float* p, float v) {
-    if constexpr (WT) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else *p = v;
-}
 // eight f16 values as one 16-byte vector IN REGISTERS (an _Float16 array read back through reinterpret_cast lives in scratch memory: the
 // pack role's split-f16 image loop was two scratch round trips per vector -- 8.5 of its 24 us at 512 threads)
 typedef _Float16 pk_f16x8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ float4 as_f4(const pk_f16x8 h) { return __builtin_bit_cast(float4, h); }
-template <bool WT>
-__device__ __forceinline__ void st_pub4(float4* p, const float4 v) {
-    if constexpr (WT) {
-        using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
-        asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(p), "v"(__builtin_bit_cast(u32x4, v)) : "memory");   // (s_nop: the data registers may be rewritten right behind a wide store)
-    } else *p = v;
-}
+__device__ __forceinline__ void st_pub(float* p, float v) { *p = v; }
+__device__ __forceinline__ void st_pub4(float4* p, const float4 v) { *p = v; }
 
 // exp(-x) for x >= 0 in float64, ~2e-16 relative: n = rint(-x log2 e), t = -x - n ln2 (two-term), degree-12 Taylor
 // on |t| <= ln2/2 (remainder < 3e-17), scaled by 2^n with v_ldexp_f64.  About 22 fp64 instructions
@@ -271,19 +253,12 @@ __device__ __forceinline__ void blk_store(double* C, const f64x4& v, int lane) {
 //   step p, B  one wave per block row i > p: L(i,p) = A(i,p) L_pp^-T for the rows beyond the pass's window, then
 //              C(i,p+1) -= L(i,p) L(p+1,p)^T  -- after which column p+1 is ready for its diagonal pass.
 // Two barriers per step; no trailing update ever sits on the critical path.
-struct NoPub { __device__ void operator()(int) const {} };
-// pub(c): called by every thread behind a barrier.  c == 0: the matrix's first two block columns are generated (the caller's own
-// stores issued before the call have been drained by every wave); c >= 2: the packed column c - 2 of the solve stream is complete --
-// stored beside pass c - 1, drained by its storing waves at the top of pass c (a drain right behind the stores would wait ~1.5 us
-// for the write-through, on the critical path of every pass).  Merged launch: one lane counts them in.
-template <class GEN, class POST, class TAIL, class PUB = NoPub>
+template <class GEN, class POST, class TAIL>
 __device__ __forceinline__ void chol_blocks(double* blk, int nbk, double* rinv, double* xT, int tid, int nthreads, GEN gen, POST post, TAIL tail,
-                                            unsigned long long* stamps = nullptr, int stamp_p = 1, PUB pub = PUB()) {
+                                            unsigned long long* stamps = nullptr, int stamp_p = 1) {
     const int lane = tid & 63, wave = tid >> 6, nw = nthreads >> 6;
     gen(0, nbk < 2 ? 1 : 2, wave, nw);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // (merged launch: the caller's write-through stores of Z~ / cst, issued before this call)
     __syncthreads();
-    pub(0);                                              // ... are counted in here, off the critical path
     PRE_STAMP(7);
     for (int p = 0; p < nbk; ++p) {
         const int m = nbk - 1 - p;                       // block rows below the diagonal block
@@ -297,7 +272,6 @@ __device__ __forceinline__ void chol_blocks(double* blk, int nbk, double* rinv, 
         } else if ((wave & 3) != 0 || nw < 8) {
             // the workers: every wave that does not share wave 0's SIMD (waves 4, 8, .. would slow the serial pass down)
             const int w = (nw < 8) ? wave - 1 : wave - 1 - (wave >> 2), nwo = (nw < 8) ? nw - 1 : nw - (nw >> 2);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the packed column this wave stored beside the LAST pass has long left (see pub)
             // column p+1 catches up with the factored columns k < p
             if (p > 0) {
                 for (int b = w; b < m; b += nwo) {
@@ -339,7 +313,6 @@ __device__ __forceinline__ void chol_blocks(double* blk, int nbk, double* rinv, 
         }
         if (m > 0) __syncthreads();
         if (p == stamp_p) PRE_STAMP(13);
-        if (p > 1) pub(p);                               // column p - 2: packed beside the previous pass, drained at the top of this one
     }
     if (tid < 64) post(nbk - 1, 0, tid);                 // the last column: its diagonal block
     __syncthreads();
@@ -396,8 +369,8 @@ __device__ __forceinline__ double inv_get(const double* blk, const double* dinv,
     return (bi == bk) ? dinv[(size_t)bi * BLK + (i & 15) * BLD + (k & 15)] : blk[boff(bi, bk) + (i & 15) * BLD + (k & 15)];
 }
 
-template <bool IN_LDS, bool FZ = false>
-__device__ __forceinline__ void role_factor(const PreLayer& Lin, int stop_after, unsigned long long* stamps, int stamp_p, const FzPub pub = FzPub{nullptr, nullptr, nullptr, nullptr, 0u, nullptr, 0u, nullptr}) {
+template <bool IN_LDS>
+__device__ __forceinline__ void role_factor(const PreLayer& Lin, int stop_after, unsigned long long* stamps, int stamp_p) {
     PreLayer L = Lin;
     if (L.variance_dev) L.variance = *L.variance_dev;        // a device-resident (trained) kernel variance
     PRE_STAMP(0);
@@ -437,14 +410,14 @@ __device__ __forceinline__ void role_factor(const PreLayer& Lin, int stop_after,
         (znd + Mp)[(tid >> 5) * 32 + (tid & 31)] = colpart;
         if (two_parts) (znd + Mp)[((tid >> 5) + 16) * 32 + (tid & 31)] = colpart2;
     }
-    if (tid < 32) st_pub<FZ>(L.cst + tid, (tid < D) ? (float)(1.0 / (double)L.ls[tid]) : 0.f);
+    if (tid < 32) st_pub(L.cst + tid, (tid < D) ? (float)(1.0 / (double)L.ls[tid]) : 0.f);
     const int lg_sigma = (int)ceilf(0.5f * log2f(fmaxf(L.variance, 1e-30f)));
     const bool st1_16 = (L.nbk <= 8) && ((L.nbk & 1) == 0);  // this layer's solve takes split-f16 off-diagonal updates (iwvi_common.h: IWVI_CST_U)
     const int est = st1_16 ? 7 - lg_sigma : 0;
     const float st1_iu = ldexpf(1.f, -2 * est), st1_sc = ldexpf(1.f, est);
-    if (tid == 32) st_pub<FZ>(L.cst + IWVI_CST_SA, ldexpf(1.f, (st1_16 ? 7 : 10) - lg_sigma));   // 2^ea: the split-f16 scale of a = Lm^-1 k (|a| <= sigma); = 2^est when stage 1 writes the planes itself
-    if (tid == 33) st_pub<FZ>(L.cst + IWVI_CST_U, ldexpf(1.f, 2 * est));
-    if (tid == 34) st_pub<FZ>(L.cst + IWVI_CST_SB, ldexpf(1.f, est));
+    if (tid == 32) st_pub(L.cst + IWVI_CST_SA, ldexpf(1.f, (st1_16 ? 7 : 10) - lg_sigma));   // 2^ea: the split-f16 scale of a = Lm^-1 k (|a| <= sigma); = 2^est when stage 1 writes the planes itself
+    if (tid == 33) st_pub(L.cst + IWVI_CST_U, ldexpf(1.f, 2 * est));
+    if (tid == 34) st_pub(L.cst + IWVI_CST_SB, ldexpf(1.f, est));
     __syncthreads();
     // centre: K_uf is formed as exp2(x~ . z~) with |x|^2 + |z|^2 - 2 x.z expanded (like gpflow's
     // square_dist); subtracting a common centre leaves r^2 unchanged and keeps the expansion well scaled
@@ -464,7 +437,7 @@ __device__ __forceinline__ void role_factor(const PreLayer& Lin, int stop_after,
             for (int q = 0; q < 32; ++q) acc += partd[q * 32 + tid];
             const float c = (tid < D) ? (float)(acc / (double)M) : 0.f;
             zcs[tid] = c;
-            st_pub<FZ>(L.cst + 32 + tid, c);
+            st_pub(L.cst + 32 + tid, c);
         }
     }
     __syncthreads();
@@ -534,7 +507,7 @@ __device__ __forceinline__ void role_factor(const PreLayer& Lin, int stop_after,
             float mx = 0.f;                                          // the layer kernel picks its Gram form by it
             for (int m = t; m < M; m += 64) mx = fmaxf(mx, zn[m]);
             for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
-            if (t == 0) st_pub<FZ>(L.cst + 64, mx);
+            if (t == 0) st_pub(L.cst + 64, mx);
         }
         // Gram operand of K_uf in A-fragment order
         const int nsteps = round_up(D + 2, 4) / 4;
@@ -558,7 +531,7 @@ __device__ __forceinline__ void role_factor(const PreLayer& Lin, int stop_after,
                 } else if (f == D + 1 && rbf) v = -1.0e30f;          // padding rows: k = exp2(-huge) = 0
                 v4[e] = v;
             }
-            st_pub4<FZ>(reinterpret_cast<float4*>(L.ZtP + idx0), make_float4(v4[0], v4[1], v4[2], v4[3]));
+            st_pub4(reinterpret_cast<float4*>(L.ZtP + idx0), make_float4(v4[0], v4[1], v4[2], v4[3]));
         }
     };
     PRE_STAMP(2);
@@ -604,39 +577,9 @@ __device__ __forceinline__ void role_factor(const PreLayer& Lin, int stop_after,
                     o = as_f4(h);
                 }
             }
-            st_pub4<FZ>(dst + it, o);
+            st_pub4(dst + it, o);
         }
     };
-    if constexpr (FZ) {
-        // the merged launch: Z~ and zmax2 NOW (not beside the last diagonal pass) -- the other workgroups' Gram phases wait for them
-        tail(tid, nthreads);                                         // (write-through stores: drained and counted in inside chol_blocks)
-        auto pubcol = [&](int c) {                                   // one lane of a worker wave, never the serial wave
-            if (tid == 64) __hip_atomic_fetch_add(c == 0 ? pub.early : pub.cols, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        };
-        auto ftail = [&](int t, int) {                               // beside the last diagonal pass (worker waves are idle there)
-            if (pub.wait1 && t < 64) {
-                if (t == 0) {
-                    unsigned* w[2] = {pub.wait1, pub.wait2}; const unsigned tg[2] = {pub.target1, pub.target2};
-                    for (int k = 0; k < 2; ++k)
-                        for (unsigned spins = 0; w[k] && (int)(__hip_atomic_load(w[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - tg[k]) < 0; ++spins) {
-                            __builtin_amdgcn_s_sleep(2);
-                            if (spins > (1u << 22)) { __hip_atomic_store(pub.tmo, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
-                        }
-                }
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
-        };
-        chol_blocks(blk, nbk, rinv, dinv, tid, nthreads, gen, post, ftail, stamps, stamp_p, pubcol);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (tid == 0) {
-            __hip_atomic_fetch_add(pub.cols, (unsigned)(nbk < 2 ? nbk : 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // the last two columns
-            __hip_atomic_fetch_add(pub.done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        PRE_STAMP(3);
-        return;
-    }
     chol_blocks(blk, nbk, rinv, dinv, tid, nthreads, gen, post, tail, stamps, stamp_p);
     PRE_STAMP(3);
     if (stop_after == 3 || stop_after > 30) return;
@@ -726,7 +669,7 @@ __device__ __forceinline__ double block_sum_vt(double* red) {
 #define PACK_STAMP(k) do { if (st && threadIdx.x == 0) st[k] = wall_clock64(); } while (0)
 // the role's work on q_sqrt[r] read through `q`: an LDS pointer when the matrix was staged (Mp <= 128), a global one otherwise -- a pointer
 // that could be either makes every access a FLAT load with a full wait behind it (the role's loops were chains of those)
-template <bool WT, class QP>
+template <class QP>
 __device__ __forceinline__ void role_pack_body(const PreLayer& L, int r, double* red, const QP q, const bool lg_in_lds, unsigned long long* st) {
     const int nbk = L.nbk, M = L.M, R = L.R;
     PACK_STAMP(1);
@@ -759,7 +702,7 @@ __device__ __forceinline__ void role_pack_body(const PreLayer& L, int r, double*
             acc += (double)x * (double)x;
             if (k == i && i < M) acc -= lg_ok ? lg[i] : log((double)x * (double)x);
         }
-        st_pub4<WT>(dstm + (size_t)(tri_upper_off(nbk, bi) + (bk - bi)) * 64 + lane, make_float4(o[0], o[1], o[2], o[3]));
+        st_pub4(dstm + (size_t)(tri_upper_off(nbk, bi) + (bk - bi)) * 64 + lane, make_float4(o[0], o[1], o[2], o[3]));
     }
     for (int m = vt; m < M; m += PACK_VT) {
         const double v = L.q_mu[(size_t)m * R + r];
@@ -776,15 +719,14 @@ __device__ __forceinline__ void role_pack_body(const PreLayer& L, int r, double*
             float o[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = (rr < R && k0 + e < M) ? L.q_mu[(size_t)(k0 + e) * R + rr] : 0.f;
-            st_pub4<WT>(dq + v4, make_float4(o[0], o[1], o[2], o[3]));
+            st_pub4(dq + v4, make_float4(o[0], o[1], o[2], o[3]));
         }
     }
     PACK_STAMP(2);
     const double tot = block_sum_vt(red);
     PACK_STAMP(3);
     if (threadIdx.x == 0) {
-        if constexpr (WT) __hip_atomic_store(L.kl + r, 0.5 * (tot - (double)M), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        else L.kl[r] = 0.5 * (tot - (double)M);
+        L.kl[r] = 0.5 * (tot - (double)M);
     }
     // ---- the split-f16 image of L_r^T (and, role 1, of q_mu^T) with its power-of-two scale ----------------------------------
     if (nbk & 1) return;
@@ -802,7 +744,7 @@ __device__ __forceinline__ void role_pack_body(const PreLayer& L, int r, double*
     PACK_STAMP(4);
     const int er = mx > 0.0 ? 13 - ilogb(mx) : 0;                             // max |L_r| 2^er in [2^13, 2^14)  (ilogb == floor(log2) exactly, without a float64 log in every thread)
     const float sr = ldexpf(1.f, er);
-    if (threadIdx.x == 0) st_pub<WT>(L.cst + IWVI_CST_FR + r, ldexpf(1.f, -(ea + er)));
+    if (threadIdx.x == 0) st_pub(L.cst + IWVI_CST_FR + r, ldexpf(1.f, -(ea + er)));
     {
         const int nst = s16_slabs_total(nbk);
         unsigned short* dst = L.LrT16 + (size_t)r * nst * 1024;                 // 1024 halves per slab (2 planes x 512)
@@ -823,8 +765,8 @@ __device__ __forceinline__ void role_pack_body(const PreLayer& L, int r, double*
             }
             // the slabs of row-blocks 2p and 2p+1 are interleaved chunk by chunk (they are multiplied as one step: same B vectors)
             const int slp = ((bi & 1) ? o - s16_slabs(nbk, bi) : o) + 2 * (sl - o) + (bi & 1);
-            st_pub4<WT>(reinterpret_cast<float4*>(dst + (size_t)slp * 1024 + lane * 8), as_f4(h1));
-            st_pub4<WT>(reinterpret_cast<float4*>(dst + (size_t)slp * 1024 + 512 + lane * 8), as_f4(h2));
+            st_pub4(reinterpret_cast<float4*>(dst + (size_t)slp * 1024 + lane * 8), as_f4(h1));
+            st_pub4(reinterpret_cast<float4*>(dst + (size_t)slp * 1024 + 512 + lane * 8), as_f4(h2));
         }
     }
     PACK_STAMP(5);
@@ -837,7 +779,7 @@ __device__ __forceinline__ void role_pack_body(const PreLayer& L, int r, double*
         mq = red[0];
         const int eq = mq > 0.0 ? 13 - ilogb(mq) : 0;
         const float sq = ldexpf(1.f, eq);
-        if (threadIdx.x == 0) st_pub<WT>(L.cst + IWVI_CST_FMEAN, ldexpf(1.f, -(ea + eq)));
+        if (threadIdx.x == 0) st_pub(L.cst + IWVI_CST_FMEAN, ldexpf(1.f, -(ea + eq)));
         const int nkc = nbk / 2;
         for (int v = threadIdx.x; v < L.nrb * nkc * 64; v += blockDim.x) {
             const int sl = v >> 6, lane = v & 63, rb = sl / nkc, kc = sl - rb * nkc;
@@ -849,14 +791,13 @@ __device__ __forceinline__ void role_pack_body(const PreLayer& L, int r, double*
                 const _Float16 hh = (_Float16)x;
                 h1[e] = hh; h2[e] = (_Float16)(x - (float)hh);
             }
-            st_pub4<WT>(reinterpret_cast<float4*>(L.Qmu16 + (size_t)sl * 1024 + lane * 8), as_f4(h1));
-            st_pub4<WT>(reinterpret_cast<float4*>(L.Qmu16 + (size_t)sl * 1024 + 512 + lane * 8), as_f4(h2));
+            st_pub4(reinterpret_cast<float4*>(L.Qmu16 + (size_t)sl * 1024 + lane * 8), as_f4(h1));
+            st_pub4(reinterpret_cast<float4*>(L.Qmu16 + (size_t)sl * 1024 + 512 + lane * 8), as_f4(h2));
         }
     }
 }
 
 
-template <bool WT = false>        // WT: write-through stores (merged launch: the images are read by other workgroups of the SAME launch)
 __device__ __forceinline__ void role_pack_r(const PreLayer& L, int r, double* red, unsigned long long* st = nullptr) {
     PACK_STAMP(0);
     const int nbk = L.nbk, M = L.M, R = L.R;
@@ -883,11 +824,11 @@ __device__ __forceinline__ void role_pack_r(const PreLayer& L, int r, double* re
         }
         __syncthreads();
         typedef const __attribute__((address_space(3))) float* lds_cf;
-        role_pack_body<WT>(L, r, red, (lds_cf)qs, true, st);
+        role_pack_body(L, r, red, (lds_cf)qs, true, st);
         return;
     }
     typedef const __attribute__((address_space(1))) float* glb_cf;
-    role_pack_body<WT>(L, r, red, (glb_cf)q, false, st);
+    role_pack_body(L, r, red, (glb_cf)q, false, st);
 }
 
 // ---- host side, shared by the two launch functions ----------------------------------------------------------

@@ -4,12 +4,10 @@ with the same constructor / method signatures, running on the HIP kernels behind
 ``DGP_IWVI._build_likelihood`` is the north-star function; ``E_log_p_Y`` (the name used in the older
 doubly-stochastic DGP code and in BASELINE.json) is an alias for its per-point log-weight stage.
 
-One ELBO evaluation is ONE launch (``iwvi_dgp_forward_fused``, ``settings.merged_launch``): workgroups take a role by ticket -- the
-first to start factorise a GP layer each (Gram + Cholesky + operand packing), the others carry a chunk of samples through
-the tiling of X/Y over K, every layer, the Gaussian variational expectation and the local regularisers in LDS, their
-factorisation-independent front running beside the Cholesky; the last workgroup to finish does the log-sum-exp over K, the
-scaled sum and subtracts the global KLs.  ``merged_launch = False`` (and any stack the merged launch does not cover: M > 128)
-runs the same work as two launches, ``iwvi_model_precompute`` + ``iwvi_dgp_forward``, with bit-identical results.
+One ELBO evaluation is TWO launches: ``iwvi_model_precompute`` (per GP layer: Gram + float64 Cholesky + operand packing; the
+encoders of the latent-variable layers) and ``iwvi_dgp_forward``, whose workgroups each carry a chunk of samples through the
+tiling of X/Y over K, every layer, the Gaussian variational expectation and the local regularisers in LDS; the last workgroup
+to finish does the log-sum-exp over K, the scaled sum and subtracts the global KLs.
 
 Differences from the reference, all documented in DESIGN.md:
   * ``zs`` (one N(0,1) array or None per layer) injects the noise tf.random_normal draws in-graph; None
@@ -146,24 +144,14 @@ class DGP_VI:
         return samples[1:], means, covs, kls, kl_types
 
     # -- fused forward ------------------------------------------------------------------------
-    def _fz_ws(self):
-        """The merged launch's generation-counted sync words (``iwvi_fused_ws_bytes``): zeroed once, one block per model."""
-        dev = self.X.device
-        ws = getattr(self, "_fz_words", None)
-        if ws is None or ws.device != dev:
-            ws = self._fz_words = torch.zeros(_abi.lib().iwvi_fused_ws_bytes(), dtype=torch.uint8, device=dev)
-        return ws
-
     def _fused_forward(self, T, row_div, row_mod, lead, zs=None, sampled_kl=True, want_layers=False,
-                       want_logw=True, use_encoder=True, elbo=None, stack_from=0, want_saved=False, merged=False):
+                       want_logw=True, use_encoder=True, elbo=None, stack_from=0, want_saved=False):
         """``iwvi_dgp_forward`` over the current minibatch: every layer + log-weights in one launch.
         Row t of the flattened batch reads data row (t // row_div) % row_mod.  ``elbo`` = dict(B, K, stride_b,
         stride_k, mode_vi, want_ms, K_total): also run the reduction of models.py:138-150 in the tail of the
         launch.  Returns (logw [T] or None, per-layer dict lists when ``want_layers``, (elbo, logp, ms) or None).
         ``stack_from=1`` (needs ``elbo``): layer 0 was evaluated by ``precompute(sample_first=...)``; the launch
-        starts from its samples [T, Dx+Lw] and its per-sample regulariser.
-        ``merged``: the call IS the precompute too (``iwvi_dgp_forward_fused``: the factorisations run in workgroups of this
-        same launch, the encoders inside the layer kernel) -- do not call ``precompute`` before it."""
+        starts from its samples [T, Dx+Lw] and its per-sample regulariser."""
         dev = self.X.device
         layers = self.layers[stack_from:]
         n = len(layers)
@@ -214,7 +202,7 @@ class DGP_VI:
                     if want_saved:
                         o["noise_out"] = torch.empty(T, Lw, dtype=settings.float_type, device=dev)
                 # encoder output of THIS minibatch from the last precompute launch, if there is one
-                eo = layer._enc_out if (use_encoder and not merged and getattr(layer, "_enc_key", None) == self._mb_key()) else None
+                eo = layer._enc_out if (use_encoder and getattr(layer, "_enc_key", None) == self._mb_key()) else None
                 d, k = layer.fused_desc(D, z2, o, sampled_kl=sampled_kl, use_encoder=use_encoder, enc_out=eo)
                 D += Lw
             else:
@@ -259,12 +247,7 @@ class DGP_VI:
                 self.likelihood.desc_variance()[0] if (ed is not None or not want_logw) else self.likelihood.variance,
                 settings.seed, ctypes.c_void_p(words.data_ptr() + 8), _abi.ptr(logw),
                 None if ed is None else ctypes.byref(ed), _abi.stream_ptr())
-        if merged:
-            gps = [l.state_desc() for l in layers if isinstance(l, GPLayer)]
-            gp_arr = (_abi.GpDesc * max(len(gps), 1))(*gps)
-            _abi.check(_abi.lib().iwvi_dgp_forward_fused(gp_arr, len(gps), _abi.ptr(self._fz_ws()), *args))
-        else:
-            _abi.check(_abi.lib().iwvi_dgp_forward(*args))
+        _abi.check(_abi.lib().iwvi_dgp_forward(*args))
         return logw, outs, red
 
     def _mb_key(self):
@@ -333,12 +316,10 @@ class DGP_VI:
     def _build_likelihood(self, zs=None):
         """The VI bound, reference models.py:49-86 (2-D [S*N, D] tiling, mean over S)."""
         S, N = self.num_samples, self.X.shape[0]
-        merged = settings.merged_launch
-        if not merged:
-            self.precompute(with_encoders=True)
+        self.precompute(with_encoders=True)
         # tile(X, [S, 1]) (:50-53): row t = s*N + n reads data row t % N; analytic local KL (:58-61)
         _, _, red = self._fused_forward(S * N, 1, N, (S * N,), zs=zs, sampled_kl=False,
-                                        elbo=dict(B=N, K=S, stride_b=1, stride_k=N, mode_vi=True), merged=merged)
+                                        elbo=dict(B=N, K=S, stride_b=1, stride_k=N, mode_vi=True))
         return red[0]
 
     def compute_log_likelihood(self, zs=None):
@@ -427,8 +408,6 @@ class DGP_IWVI(DGP_VI):
             self.precompute(with_encoders=True, sample_first=dict(K=K, sampled_kl=True, want_z=self.keep_lv_noise))
             return self._fused_forward(B * K, K, B, (B, K), zs=None if zs is None else zs[1:], sampled_kl=True,
                                        elbo=el, stack_from=1)[2]
-        if settings.merged_launch:                                   # one launch: factorisations + layer stack + reduction
-            return self._fused_forward(B * K, K, B, (B, K), zs=zs, sampled_kl=True, elbo=el, merged=True)[2]
         self.precompute(with_encoders=True)
         return self._fused_forward(B * K, K, B, (B, K), zs=zs, sampled_kl=True, elbo=el)[2]
 

@@ -12,14 +12,11 @@ float_type = torch.float32
 jitter_level = 1e-6          # gpflow.settings.numerics.jitter_level default
 seed = 0                     # Philox key of the on-device N(0,1) stream (iwvi_fill_normal)
 _offset = 0                  # Philox counter; advanced by every draw
-# One launch per bound evaluation (iwvi_dgp_forward_fused: the factorisations run in workgroups of the layer stack's own launch);
-# False: the two launches iwvi_model_precompute + iwvi_dgp_forward.  Same results bit for bit.
 # Arithmetic of the R * M^2 contraction (stage 2 of the layer kernel) and of the adjoint chain's S_r products: split-f16 operands on
 # v_mfma_f32_16x16x32_f16 (default; 22 operand mantissa bits) or fp32 MFMAs.  Passed PER CALL in the descriptors
 # (iwvi_layer_desc.flags / iwvi_gp_bwd_desc.flags); the environment variables only set these defaults.
 fw_f32_stage2 = bool(os.environ.get("IWVI_FW_F32_STAGE2"))
 bw_f32_chain = bool(os.environ.get("IWVI_BW_F32_CHAIN"))
-merged_launch = os.environ.get("IWVI_MERGED_LAUNCH", "0") != "0"      # (the environment variable only sets this default)
 
 
 def default_device():

@@ -280,34 +280,6 @@ int iwvi_dgp_forward(const iwvi_layer_desc* layers_host, int n_layers,
                      uint64_t seed, uint64_t* rng_state, float* out_logw,
                      const iwvi_elbo_desc* elbo /* or NULL */, void* stream);
 
-/* ONE launch per IW-ELBO evaluation: iwvi_gp_precompute of the stack's GP layers AND iwvi_dgp_forward, merged.  The factorisation
- * (temp_workaround.py:39,48) is a 25 us serial chain on one CU per layer; here it runs in workgroups of the SAME launch as the
- * layer stack, whose factorisation-independent front (input tiling, noise, latent-variable layer and encoder, K_uf Gram:
- * models.py:113-116, layers.py:72-105, temp_workaround.py:44) runs beside it on the other CUs; the stack's first triangular
- * solve (:51) waits for a device-side counter.  Roles are taken by ticket, every wait is bounded (a give-up poisons the ELBO with
- * NaN), nothing depends on dispatch order.  Results are bit-identical to the two launches.
- *   gp_host[n_gp]   iwvi_gp_desc of the stack's GP layers, in stack order (states as in `layers`)
- *   fused_ws        iwvi_fused_ws_bytes() bytes, zeroed ONCE by the caller (not per call), one per model: the launch keeps
- *                   generation-counted words there.  Calls that share a workspace must be ordered on one stream.
- *   everything else as iwvi_dgp_forward; rng_state must be given (its ticket word closes the launch).
- * Stacks the merged launch does not cover (a layer with M > 128, IWVI_GP_WANT_* flags, enc_out given) run as the two launches:
- * the call is always equivalent to iwvi_gp_precompute + iwvi_dgp_forward. */
-size_t iwvi_fused_ws_bytes(void);
-int iwvi_dgp_forward_fused(const iwvi_gp_desc* gp_host, int n_gp, void* fused_ws,
-                           const iwvi_layer_desc* layers_host, int n_layers,
-                           const float* X, int Dx, const float* XY, int XYdim, const float* Y, int Dy,
-                           int64_t T, int64_t row_div, int64_t row_mod, float lik_variance,
-                           uint64_t seed, uint64_t* rng_state, float* out_logw,
-                           const iwvi_elbo_desc* elbo /* or NULL */, void* stream);
-/* Experiment (development route IWVI_FZ_EXT of iwvi_debug_set_option; scripts/time_ext_precompute.py): the merged launch's roles as a
- * launch of their own -- the 1024-thread factorisation of iwvi_gp_precompute publishing through the counters in `fused_ws` -- to be
- * queued on a SECOND stream beside an iwvi_dgp_forward_fused call made with IWVI_FZ_EXT set, whose workgroups then only wait for it.
- * The caller orders this call after the previous evaluation's layer launch (it overwrites the operands that launch reads). */
-int iwvi_gp_precompute_pub(const iwvi_gp_desc* gp_host, int n_gp, void* fused_ws, void* stream);
-/* ... and the one-workgroup gate queued in front of that iwvi_dgp_forward_fused call on ITS stream: it leaves when every workgroup of this
- * evaluation's iwvi_gp_precompute_pub launch has a CU (inside a captured graph nothing else orders the two launches' dispatch). */
-int iwvi_fz_gate(const iwvi_gp_desc* gp_host, int n_gp, void* fused_ws, void* stream);
-
 /* ----------------------------------------------------------------------
  * Backward pass (the reference gets these from TensorFlow's autodiff of the graph of
  * models.py:112-150, experiments/build_models.py:284-304).  Layer by layer; RBF and Matern-5/2 kernels.
