@@ -463,11 +463,17 @@ __device__ __forceinline__ void fw_copy_entries(const FwCopy* CT, float* sm, int
 // the count grid-1 holds the complete sum in the returned value and finishes models.py:150 at once.  Before this the end of a launch was
 // three dependent round trips behind the last workgroup's arithmetic -- its partial's write-through store drained, the ticket, the loads of
 // all partials by the last arriver -- and a fourth for the global KL terms (now summed in the prologue): ~4 us of every evaluation.
-// A partial too large for its share of the 46-bit field (|part| >= 2^17: every workgroup's share, so that no total can overflow) is stored
+// A partial too large for its share of the 46-bit SIGNED field (+-2^45 units; |part| >= 2^16: with at most 511 arrivals the sum of the
+// shares stays below 2^45) is stored
 // exactly, tagged with the evaluation's number and drained BEFORE the add, which then carries 0 and counts in bits 9-17; the last arriver
 // adds those partials from memory (a cold path: one more round trip, only when it happens).
 constexpr double FX_UNIT = 1048576.0;                              // 2^20 units per 1.0
-constexpr double FX_PART_MAX = 137438953472.0;                     // 2^37 units = 2^17: a workgroup's share (<= 511 arrivals, 46-bit field)
+constexpr double FX_PART_MAX = 68719476736.0;                      // 2^36 units = 2^16: a workgroup's share (511 * 2^36 < 2^45, the signed field's range)
+// tag of an exactly stored partial: the evaluation's number mixed with the address of the model's arrival word -- the scratch `ws` is
+// whatever the caller's allocator recycled, and a block last used by ANOTHER model at the same step count must not match
+__device__ __forceinline__ unsigned long long fx_tag(const unsigned long long* rng, unsigned long long step) {
+    return (step + 1ULL) ^ ((unsigned long long)(uintptr_t)rng * 0x9E3779B97F4A7C15ULL);
+}
 template <int NS>
 __device__ __forceinline__ void fw_arrive_fast(const FwArgs& gk, const FwElboHot& E, unsigned long long* rng, int nchunks, int tid, int chunk_id,
                                                double part, unsigned long long step) {
@@ -500,7 +506,7 @@ __device__ __forceinline__ void fw_arrive_fast(const FwArgs& gk, const FwElboHot
     const long long fx = ovf ? 0LL : __double2ll_rn(sc);
     if (ovf && chunk_id >= 0 && tid == 0) {
         __hip_atomic_store(E.ws + chunk_id, part, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(reinterpret_cast<unsigned long long*>(E.ws) + nchunks + chunk_id, step + 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(reinterpret_cast<unsigned long long*>(E.ws) + nchunks + chunk_id, fx_tag(rng, step), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     const unsigned long long add = ((unsigned long long)fx << 18) + (ovf ? 512ULL : 0ULL) + 1ULL;
@@ -517,7 +523,7 @@ __device__ __forceinline__ void fw_arrive_fast(const FwArgs& gk, const FwElboHot
     double tot = (double)(((long long)old >> 18) + fx) * (1.0 / FX_UNIT);                 // (arithmetic shift: the field's sign)
     if ((unsigned)(old >> 9 & 511ULL) + (ovf ? 1u : 0u)) {
         for (int c = 0; c < nchunks; ++c)
-            if (__hip_atomic_load(reinterpret_cast<unsigned long long*>(E.ws) + nchunks + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == step + 1ULL)
+            if (__hip_atomic_load(reinterpret_cast<unsigned long long*>(E.ws) + nchunks + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == fx_tag(rng, step))
                 tot += __hip_atomic_load(E.ws + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     const double val = tot * E.scale - kl_sum;                                                 // models.py:150

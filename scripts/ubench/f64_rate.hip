@@ -41,7 +41,9 @@ static void run(const char* name, K kern, int per_iter, double* out, long long* 
         hipLaunchKernelGGL(kern, dim3(1), dim3(threads), 0, 0, out, clk, n); (void)hipDeviceSynchronize();
         hipLaunchKernelGGL(kern, dim3(1), dim3(threads), 0, 0, out, clk, n); (void)hipDeviceSynchronize();
         (void)hipMemcpy(h.data(), clk, 128, hipMemcpyDeviceToHost);
-        printf("%-40s %4d threads: %7.2f ticks per group\n", name, threads, (double)h[0] / (n * per_iter));
+        printf("%-40s %4d threads: %7.2f ticks per group (wave 0)", name, threads, (double)h[0] / (n * per_iter));
+        if (threads == 1024) printf("   waves 4 / 8 / 12 (its SIMD): %.2f %.2f %.2f", (double)h[4] / (n * per_iter), (double)h[8] / (n * per_iter), (double)h[12] / (n * per_iter));
+        printf("\n");
     }
 }
 

@@ -58,6 +58,19 @@ def test_partials_beyond_the_fixed_point_range_take_the_exact_path(gpu_device, w
     assert abs(fast - slow) <= 1e-12 * abs(slow) + 64 * 2.0 ** -21, (fast, slow)
 
 
+def test_many_large_partials_of_one_sign_do_not_overflow_the_field(gpu_device):
+    """510 arrivals whose partial sums share a sign and mostly lie between 2^16 and 2^17 (oracle, float64: 315 of them; their sum is
+    1.1 * 2^25, beyond the signed 46-bit field's +-2^25): a workgroup's share of the field is 2^16, so those go the exact way and the
+    packed total cannot wrap."""
+    from dgps_with_iwvi_amd import synthetic
+    spec = synthetic.make_spec(L=1, M=32, B=2040, K=20, with_lv=False, seed=21, n_data=2040)
+    spec["lik_var"] = 6e-5
+    zs = synthetic.make_noise(spec, seed=22)
+    fast, slow = _both_tails(spec, zs, gpu_device)
+    assert np.isfinite(fast) and abs(fast) > 2.0 ** 25
+    assert abs(fast - slow) <= 1e-12 * abs(slow) + 512 * 2.0 ** -21, (fast, slow)
+
+
 def test_two_models_on_two_streams_do_not_interfere(gpu_device):
     """Two evaluations in flight (bench.py: ``two_in_flight``): two models with the same parameters, each with its own operand state, noise
     stream and arrival word, evaluated concurrently on two streams give the values they give one after the other -- nothing in the
