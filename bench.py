@@ -16,19 +16,19 @@ Multi-GPU (weak scaling, per-GPU work fixed):
       and a merge kernel give the global log-sum-exp and ELBO (SURVEY.md section 8 row E, mode i);
   --shard n: every rank owns B different points and all K samples; one scalar all-reduce per step.
 """
-import os
-os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")   # kernel arguments in device memory (read before HIP initialises)
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
-import numpy as np
-import torch
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+import dgps_with_iwvi_amd  # noqa: F401,E402  (first: the package sets HIP_FORCE_DEV_KERNARG=1 before HIP initialises -- the product's own environment)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
 
 CONFIGS = {   # BASELINE.json configs[1..4]
     1: dict(L=2, M=128, K=5, B=1024, with_lv=False),
@@ -159,6 +159,10 @@ def cpu_baseline(spec, seconds=12.0, dtype=torch.float64):
     from dgps_with_iwvi_amd import synthetic
     from oracle.ref_torch_cpu import CpuDGP
     ncpu = os.cpu_count() or 1
+    try:
+        torch.set_num_interop_threads(1)                     # (one op at a time: the op sequence is a chain)
+    except RuntimeError:
+        pass
     zs = synthetic.make_noise(spec, seed=1)
     m = CpuDGP(spec, dtype)
     best = None
@@ -179,7 +183,24 @@ def cpu_baseline(spec, seconds=12.0, dtype=torch.float64):
         m.elbo(zs)
         times.append(time.perf_counter() - t0)
     med = float(np.median(times))
-    return dict(value=spec["B"] * spec["K"] / med, unit="samples/s", cores=nt, kind="port",
+    # FLOPs the restatement EXECUTES per sample (dense einsum 2 R M^2 per inner layer, M^2 solve, Gram; the final layer's full K x K
+    # covariance: SURVEY.md section 8d, "for information") and the bytes of the [S, R, M, N] intermediate it writes and re-reads
+    K = spec["K"]
+    f_exec, lta_bytes = 0.0, 0.0
+    for l in spec["layers"]:
+        if l["type"] != "gp":
+            continue
+        M, D = l["Z"].shape
+        R = l["q_mu"].shape[1]
+        f_exec += 2 * M * D + M * M + 2 * R * M * M + 2 * M * R + (4 * R * M * K if l["W"] is None else 2 * R * M)
+        lta_bytes += 3.0 * R * M * (8 if dtype == torch.float64 else 4)
+    gflops = f_exec * spec["B"] * K / med / 1e9
+    return dict(value=spec["B"] * spec["K"] / med, unit="samples/s", cores=nt, kind="port", executed_gflops=gflops,
+                executed_flop_per_sample=f_exec, lta_gbytes_per_s=lta_bytes * spec["B"] * K / med / 1e9,
+                threads_note="best of {all, 1/2, 1/4, 32, 16, 8, 4} hardware threads.  Where the time goes (torch profiler, 8 threads, float64): "
+                             "36 % the element-wise square of the permuted [S, R, M, N] intermediate (a strided pass over 13 M values), 27 % the "
+                             "einsum GEMM, 8 % adds, 5 % copies of permuted views -- a chain of ~150 separately parallelised ops, so beyond a few "
+                             "threads per op the fork / join and the strided passes, not the FLOPs (see executed_gflops), set the time",
                 sample="%d full IW-ELBO evaluations of the same workload (B=%d, K=%d), %s torch-CPU/MKL "
                        "restatement of the reference op sequence (materialised Kmn, A, LTA, full K x K final "
                        "covariance), %d threads of %d, median" % (iters, spec["B"], spec["K"],
@@ -215,6 +236,24 @@ def roofline_object(achieved, flops, launch_ms, spec, traffic, traffic_src, pmc)
             "flops_per_launch": flops, **pmc}
 
 
+def no_dev_kernarg_leg(args):
+    """The same timed loop in a FRESH process with HIP_FORCE_DEV_KERNARG=0 (kernel arguments in host-visible memory: the runtime's
+    default when the package has not been imported before HIP initialises), started before this process touches the GPU."""
+    env = dict(os.environ, HIP_FORCE_DEV_KERNARG="0", IWVI_BENCH_CHILD="1")
+    cmd = [sys.executable, os.path.abspath(__file__), "--steps", str(args.steps), "--warmup", str(args.warmup), "--config", str(args.config),
+           "--no-cpu-baseline", "--no-train-leg", "--median-iters", "0", "--no-kernarg-leg"]
+    try:
+        p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+        line = [l for l in p.stdout.splitlines() if l.startswith("{")]
+        if p.returncode != 0 or not line:
+            return {"error": "child exited %d: %s" % (p.returncode, p.stderr[-300:])}
+        r = json.loads(line[0])
+        return {"ms_per_step": r["ms_per_step"], "value": r["value"], "forward_launch_ms": r["roofline"]["launch_ms"],
+                "how": "same command in a fresh process with HIP_FORCE_DEV_KERNARG=0"}
+    except Exception as e:
+        return {"error": "%s: %s" % (type(e).__name__, e)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -235,11 +274,19 @@ def main():
                     help="after the timed region: one evaluation on INJECTED job-wide noise through the very same sharded path "
                          "(graph-free), and on rank 0 the unsharded evaluation of the whole job on the same noise; both go into the JSON")
     ap.add_argument("--median-iters", type=int, default=60, help="hipEvent-timed single-evaluation replays for ms_per_step_median")
+    ap.add_argument("--no-kernarg-leg", action="store_true", help="skip the (informational) HIP_FORCE_DEV_KERNARG=0 child run")
+    ap.add_argument("--xch-every", type=int, default=0,
+                    help="multi-GPU: evaluations per exchange (default: one exchange per graph replay of up to 25 evaluations; 1 = one "
+                         "exchange per evaluation, what a training loop pays)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    kernarg_leg = None
+    if world == 1 and not args.no_kernarg_leg and not args.no_train_leg and os.environ.get("IWVI_BENCH_CHILD") != "1" \
+            and os.environ.get("HIP_FORCE_DEV_KERNARG") == "1":
+        kernarg_leg = no_dev_kernarg_leg(args)                   # (before this process's first GPU call)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm device (the HIP path has no CPU fallback)")
     local %= torch.cuda.device_count()                           # (several ranks on one device only in plumbing tests)
@@ -291,6 +338,8 @@ def main():
     spg = 1
     if not args.no_graph:
         cap = int(os.environ.get("IWVI_BENCH_SPG", "25"))
+        if args.xch_every > 0 and (world > 1 or force_xch):
+            cap = args.xch_every
         spg = max(d for d in range(1, cap + 1) if args.steps % d == 0)      # the timed region is exactly --steps evaluations
         if spg < min(8, args.steps) and world == 1 and not force_xch:
             spg = min(cap, args.steps)                                        # awkward --steps: full replays + a remainder launched singly
@@ -298,7 +347,7 @@ def main():
     if world > 1 or force_xch:
         # multi-GPU: the evaluations of one graph replay are exchanged in one collective on a side stream
         from dgps_with_iwvi_amd.sharding import OverlappedExchange
-        xch = OverlappedExchange(args.shard, world, B, K_job, float(spec["n_data"]) / B, dev, steps=spg)
+        xch = OverlappedExchange(args.shard, world, B, K_job, float(spec["n_data"]) / B, dev, steps=spg, timed=True)
     graph = None
     step.run()
     torch.cuda.synchronize()
@@ -392,6 +441,7 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     final_elbo = float((xch.finish()[-1] if xch is not None else step.out.reshape(1)).item())
+    exchange_ms = xch.exchange_ms() if xch is not None else None
 
     # ---- --check: the sharded path against the unsharded job on injected noise (multi-rank correctness, no timing) ----------
     check = None
@@ -601,6 +651,9 @@ def main():
                        "launch": "eager" if graph is None else ("hipGraph replay, %d steps per replay" % spg) + ("" if xch is None else ", one exchange per replay")},
             "elbo": final_elbo,
             "n_ranks_seen": (dist.get_world_size() if dist is not None else 1),
+            # side-stream time of one exchange (collective + merge kernel, from events; overlapped with the next replay) and how many
+            # evaluations it carries
+            "exchange_ms": exchange_ms, "evaluations_per_exchange": (spg if xch is not None else None),
             "host_enqueue_ms_per_step": t_enqueued / args.steps * 1e3,
             # achieved = algorithmic FLOP / s of the dominant kernel.  peak = the ceiling of THIS instruction mix: the fp32-MFMA part of the
             # algorithm at the fp32-MFMA peak, the split-f16 part (three f16 MFMA FLOPs per algorithmic FLOP) at a third of the f16 peak --
@@ -616,6 +669,10 @@ def main():
             res["fp32_path"] = fp32_path
         if two_in_flight is not None:
             res["two_in_flight"] = two_in_flight
+        if kernarg_leg is not None:
+            res["no_dev_kernarg"] = kernarg_leg
+        res["environment"] = {"HIP_FORCE_DEV_KERNARG": os.environ.get("HIP_FORCE_DEV_KERNARG"),
+                              "set_by": "dgps_with_iwvi_amd/__init__.py (setdefault at import, before HIP initialises)"}
         if med is not None:
             res.update({"ms_per_step_median": med["ms_per_step_median"], "median_protocol": med})
         if check is not None:

@@ -96,7 +96,7 @@ class OverlappedExchange:
     Before a slot is overwritten the main stream waits for the exchange that last read it (``before_step``).
     Everything the per-call path touches (buffers, events, the merge's argument block) is created once."""
 
-    def __init__(self, mode, world, B, K_total, scale, device, depth=2, group=None, steps=1):
+    def __init__(self, mode, world, B, K_total, scale, device, depth=2, group=None, steps=1, timed=False):
         assert mode in ("k", "n")
         self.mode, self.world, self.B, self.K_total, self.scale, self.group = mode, world, B, K_total, float(scale), group
         self.steps = steps
@@ -111,6 +111,10 @@ class OverlappedExchange:
         self.gathered = torch.empty((world,) + shape, dtype=dtype, device=device) if mode == "k" else None
         self.result = torch.zeros(steps, dtype=torch.float64, device=device)     # the last exchanged slot's ELBOs
         self._glob_key, self._glob_args = None, None
+        # timed: events around each exchange on the communication stream (collective + merge), read back by exchange_ms()
+        self.timed = bool(timed)
+        self._t = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(depth)] if timed else None
+        self._t_ms = []
 
     def slot(self):
         return self.i % self.depth
@@ -142,9 +146,13 @@ class OverlappedExchange:
         self.i += 1
         main = torch.cuda.current_stream()
         self.ready[slot].record(main)
+        if self.timed and self.used[slot]:                       # (this slot's previous exchange has completed: before_step waited for it)
+            self._collect(slot)
         self.used[slot] = True
         with torch.cuda.stream(self.comm):
             self.comm.wait_event(self.ready[slot])
+            if self.timed:
+                self._t[slot][0].record(self.comm)
             if self.mode == "k":
                 dist.all_gather_into_tensor(self.gathered.view(-1), self.stage[slot].view(-1), group=self.group)
                 arr, counts, n = self._merge_args(global_kls)
@@ -153,7 +161,28 @@ class OverlappedExchange:
             else:
                 dist.all_reduce(self.stage[slot], op=dist.ReduceOp.SUM, group=self.group)
                 self.result.copy_(self.stage[slot], non_blocking=True)     # sums over ranks; finish() divides
+            if self.timed:
+                self._t[slot][1].record(self.comm)
             self.done[slot].record(self.comm)
+
+    def _collect(self, slot):
+        a, b = self._t[slot]
+        if b.query():                                            # (still running: skipped, the next use of the slot has another)
+            self._t_ms.append(a.elapsed_time(b))
+
+    def exchange_ms(self):
+        """Median side-stream time of one exchange (collective + merge kernel) over the timed submits so far; None if not timed."""
+        if not self.timed:
+            return None
+        torch.cuda.current_stream().wait_stream(self.comm)
+        torch.cuda.synchronize()
+        for slot in range(self.depth):
+            if self.used[slot]:
+                self._collect(slot)
+        if not self._t_ms:
+            return None
+        v = sorted(self._t_ms)
+        return float(v[len(v) // 2])
 
     def finish(self):
         """Wait for the exchanges; returns the last slot's per-evaluation ELBOs [steps]."""

@@ -60,6 +60,14 @@ def test_bench_two_ranks_on_one_gpu_merges_to_the_unsharded_elbo(gpu_device, sha
     # float32 logsumexp merged in a different order than the single-rank reduction
     assert c["rel_diff"] <= 2e-6, c
     assert np.isfinite(res["value"]) and res["value"] > 0 and np.isfinite(res["elbo"])
+    assert res["exchange_ms"] is not None and 0.0 < res["exchange_ms"] < 50.0 and res["evaluations_per_exchange"] == 8
+
+
+def test_bench_two_ranks_one_exchange_per_evaluation(gpu_device):
+    """--xch-every 1: every evaluation is exchanged on its own (what a training loop pays), same merged value."""
+    res = _run_bench(2, "k", extra=("--xch-every", "1"))
+    assert res["evaluations_per_exchange"] == 1 and res["exchange_ms"] is not None and res["exchange_ms"] > 0.0
+    assert res["check"]["all_steps_equal"] and res["check"]["rel_diff"] <= 2e-6, res["check"]
 
 
 def test_bench_single_rank_line_has_the_contract_fields(gpu_device):
