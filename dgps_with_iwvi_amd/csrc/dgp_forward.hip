@@ -603,7 +603,9 @@ __device__ __forceinline__ void fw_arrive(const FwArgs& gk, float* sm, int tid, 
     }
 }
 
-template <int NS, bool S16>   // S16: stage 2 of every GP layer on split-f16 operands (iwvi_common.h: s16_*)
+// S16: stage 2 of every GP layer on split-f16 operands (iwvi_common.h: s16_*); BIG: some GP layer has more than 8 block rows (M > 128) --
+// the launch variants for M <= 128 do not carry the column-at-a-time / super-block solves and the in-place plane conversion
+template <int NS, bool S16, bool BIG>
 __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
     constexpr int NSAMP = 16 * NS;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1138,7 +1140,7 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
             // to the next column in registers, so the dependent chain never waits for LDS.
             // (five sub-tiles on four SIMDs: two solves share SIMD 0.  Cutting the fifth solve into a 2 x 2 block system over four waves paid
             // while its updates were fp32 MFMAs; with the split-f16 updates the hand-offs cost what the cut saves: measured equal, removed.)
-            if (nbk >= FW_SB_MIN_NBK) {
+            if (BIG && nbk >= FW_SB_MIN_NBK) {
                 // ---- M >= 256: super-block solve.  Per super-block I (8 block rows): r_I = k_I - L(I, <I) a_<I (dense product,
                 // one block row per wave, in place), then a_I = (L_II)^-1 r_I (triangular product with the packed inverse of
                 // the 128 x 128 diagonal super-block; every wave reads r_I, barrier, writes a_I in place).  No wave carries a
@@ -1257,7 +1259,7 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
                     case 6: ssq = stage1_unrolled<NS, 6, true, S16>(Ap, kuf, at, tcol, gq, arow, st1_sb); break;
                     case 7: ssq = stage1_unrolled<NS, 7, false, false>(Ap, kuf, at, tcol, gq, arow, st1_sb); break;
                     case 8: ssq = stage1_unrolled<NS, 8, true, S16>(Ap, kuf, at, tcol, gq, arow, st1_sb); break;
-                    default: {
+                    default: if constexpr (BIG) {
                         // generic column-at-a-time form (M > 128): right-hand sides in the LDS tile, the packed factor
                         // streamed from L2.  Column bj: a_bj = Dinv_bj r_bj (4 dependent MFMAs), then the updates of the
                         // rows below it four block rows at a time -- four independent accumulator chains in flight, their
@@ -1344,7 +1346,7 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
                 // In-place conversion: the eight values a[32 kc + 8 g .. + 7] of a sample are the two float4 rows 8 kc + 2 g and 8 kc + 2 g + 1
                 // of the fp32 tile; their h1 vector goes back to the first, their h2 vector to the second (planes interleaved row by row):
                 // every item reads and writes its own two slots -- no hazard, no temporaries, every thread busy.
-                if (nbk > 8) {                                    // (nbk <= 8: stage 1 wrote the planes itself -- stage1_unrolled, P16)
+                if (BIG && nbk > 8) {                             // (nbk <= 8: stage 1 wrote the planes itself -- stage1_unrolled, P16)
                     const float sa = cst[IWVI_CST_SA];
                     for (int v = tid; v < nvec; v += FW_THREADS) {
                         const int j = v % NSAMP, kg = v / NSAMP;          // kg = 4 kc + g
@@ -1840,15 +1842,15 @@ static void fw_decide_fast(FwArgs& a, unsigned grid, int nsamp, int64_t T) {
                   a.h.rng_state && grid <= 511u && 2 * (int64_t)a.h.nchunks <= ws_len && E.kl_total <= 64 && !dbg_opt("IWVI_FW_SLOW_TAIL")) ? 1 : 0;
 }
 
-template <int NS, bool S16>
+template <int NS, bool S16, bool BIG>
 static int launch_forward(const FwArgs& a, unsigned grid, size_t lds_bytes, hipStream_t stream) {
     static size_t attr_set = 0;
     if (lds_bytes > attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_dgp_forward<NS, S16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        hipError_t e = hipFuncSetAttribute((const void*)k_dgp_forward<NS, S16, BIG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) { set_error("hipFuncSetAttribute(k_dgp_forward, %zu B): %s", lds_bytes, hipGetErrorString(e)); return IWVI_ERR_LAUNCH; }
         attr_set = lds_bytes;
     }
-    hipLaunchKernelGGL((k_dgp_forward<NS, S16>), dim3(grid), dim3(FW_THREADS), lds_bytes, stream, a);
+    hipLaunchKernelGGL((k_dgp_forward<NS, S16, BIG>), dim3(grid), dim3(FW_THREADS), lds_bytes, stream, a);
     return check_launch("k_dgp_forward");
 }
 
@@ -2243,24 +2245,22 @@ int dgp_forward_impl(const iwvi_layer_desc* layers, int n_layers, const float* X
     a.h.stamps = (g_stamp_buf && chunks + IWVI_MAX_STACK <= g_stamp_wgs) ? g_stamp_buf : nullptr;
     a.h.dbg_exit = g_dbg_exit;
     fw_decide_fast(a, (unsigned)chunks, 16 * ns, T);
-    if (s16_all) switch (ns) {
-#ifndef IWVI_DEV_ONLY5   /* development builds: only the 80-sample variants (make DEV5=1) */
-        case 1: return launch_forward<1, true>(a, (unsigned)chunks, lds_bytes, stream);
-        case 2: return launch_forward<2, true>(a, (unsigned)chunks, lds_bytes, stream);
-        case 3: return launch_forward<3, true>(a, (unsigned)chunks, lds_bytes, stream);
-        case 4: return launch_forward<4, true>(a, (unsigned)chunks, lds_bytes, stream);
-#endif
-        default: return launch_forward<5, true>(a, (unsigned)chunks, lds_bytes, stream);
-    }
+    bool big = false;                                    // a layer with M > 128: the variants that carry the generic / super-block solves
+    for (int i = 0; i < n_layers; ++i) if (a.L[i].type == IWVI_LAYER_GP && a.L[i].gp.nbk > 8) big = true;
+#define FW_LAUNCH(NS_) (s16_all ? (big ? launch_forward<NS_, true, true>(a, (unsigned)chunks, lds_bytes, stream)      \
+                                      : launch_forward<NS_, true, false>(a, (unsigned)chunks, lds_bytes, stream))     \
+                                : (big ? launch_forward<NS_, false, true>(a, (unsigned)chunks, lds_bytes, stream)     \
+                                      : launch_forward<NS_, false, false>(a, (unsigned)chunks, lds_bytes, stream)))
     switch (ns) {
 #ifndef IWVI_DEV_ONLY5   /* development builds: only the 80-sample variants (make DEV5=1) */
-        case 1: return launch_forward<1, false>(a, (unsigned)chunks, lds_bytes, stream);
-        case 2: return launch_forward<2, false>(a, (unsigned)chunks, lds_bytes, stream);
-        case 3: return launch_forward<3, false>(a, (unsigned)chunks, lds_bytes, stream);
-        case 4: return launch_forward<4, false>(a, (unsigned)chunks, lds_bytes, stream);
+        case 1: return FW_LAUNCH(1);
+        case 2: return FW_LAUNCH(2);
+        case 3: return FW_LAUNCH(3);
+        case 4: return FW_LAUNCH(4);
 #endif
-        default: return launch_forward<5, false>(a, (unsigned)chunks, lds_bytes, stream);
+        default: return FW_LAUNCH(5);
     }
+#undef FW_LAUNCH
 }
 
 }  // namespace iwvi
