@@ -50,7 +50,8 @@ def f_alg_layer(M, D, R, P):
 def f_alg_split(spec, f32_stage2=False):
     """The same algorithmic FLOPs per sample split by the matrix instruction that executes them: (fp32-MFMA part, split-f16 part).
     Split-f16 (x = h1 + h2; csrc/dgp_forward.hip): stage 2 (R M^2 + 2 M R) when EVERY GP layer has an even number of 16-row blocks,
-    and the off-diagonal updates of stage 1 (M^2 - 16 M) of a layer with an even block count <= 8.  A split-f16 product costs three
+    the off-diagonal updates of stage 1 (M^2 - 16 M) of a layer with an even block count <= 8, and (round 4) the dense part of the
+    super-block solve of a layer with M > 240 in such a launch.  A split-f16 product costs three
     f16 MFMA FLOPs per algorithmic FLOP, so its ceiling is PEAK_MFMA_F16 / 3."""
     gps = [l for l in spec["layers"] if l["type"] == "gp"]
     nbks = [(l["Z"].shape[0] + 15) // 16 for l in gps]
@@ -63,6 +64,8 @@ def f_alg_split(spec, f32_stage2=False):
             f16 += R * M * M + 2 * M * R
         if nbk % 2 == 0 and nbk <= 8:
             f16 += M * M - 16 * M
+        if s16_all and nbk >= 16:                                # the dense part of the super-block solve: the blocks -L(I, <I), 512 FLOP per block and sample
+            f16 += 512.0 * sum(min(8, nbk - 8 * I) * 8 * I for I in range((nbk + 7) // 8))
     return tot - f16, f16
 
 
@@ -234,6 +237,82 @@ def roofline_object(achieved, flops, launch_ms, spec, traffic, traffic_src, pmc)
             "frac_fp32_equivalent": achieved / PEAK_MFMA_F32,
             "traffic": traffic, "traffic_source": traffic_src, "hbm_frac": hbm_frac, "launch_ms": launch_ms,
             "flops_per_launch": flops, **pmc}
+
+
+def gemm_phase_mfma_util(model, spec, B, K):
+    """MFMA utilisation INSIDE the batched conditional GEMM phases of the layer kernel (north_star: ">= 40 % MFMA utilisation on the
+    batched conditional GEMMs", temp_workaround.py:51 and :68,78): per GP layer, the matrix instructions a workgroup issues in stage 1
+    (a = Lm^-1 k) and stage 2 (u_r = L_r^T a, mean = q_mu^T a) x their issue cycles on one SIMD, over 4 SIMDs x the phase's duration in
+    shader clocks (in-kernel stamps, median over the workgroups of one stamped launch).  Issue cycles per instruction
+    (MI355X_MICROARCH.md / scripts/ubench/mfma_rate.hip): v_mfma_f32_16x16x4_f32 32, v_mfma_f32_16x16x16_f16 16, v_mfma_f32_16x16x32_f16 16."""
+    import ctypes
+    from dgps_with_iwvi_amd import _abi, settings
+    lib = _abi.lib()
+    lib.iwvi_debug_set_stamps.restype = None
+    lib.iwvi_debug_set_stamps.argtypes = [ctypes.c_void_p, ctypes.c_int64]
+    dev = model.X.device
+    T = B * K
+    gps = [(i, l) for i, l in enumerate(spec["layers"]) if l["type"] == "gp"]
+    nbks = [(l["Z"].shape[0] + 15) // 16 for _, l in gps]
+    s16 = (not settings.fw_f32_stage2) and all(n % 2 == 0 for n in nbks)
+    ns = min(5, max(1, (T + 16 * 256 - 1) // (16 * 256)))
+    nwg = (T + 16 * ns - 1) // (16 * ns)
+    if nwg + 16 > 32768:
+        return None
+    buf = torch.zeros(32768 * 128, dtype=torch.int64, device=dev)
+    el = dict(B=B, K=K, stride_b=K, stride_k=1, mode_vi=False)
+    model.precompute(with_encoders=True)
+    for _ in range(2):
+        model._fused_forward(T, K, B, (B, K), elbo=el)
+    torch.cuda.synchronize()
+    lib.iwvi_debug_set_stamps(buf.data_ptr(), 32768)
+    model._fused_forward(T, K, B, (B, K), elbo=el)
+    torch.cuda.synchronize()
+    lib.iwvi_debug_set_stamps(None, 0)
+    full = buf.view(32768, 128).cpu().numpy()
+    full = full[full[:, 0] > 0]
+    if len(full) == 0:
+        return None
+    nsamp_wg = int(round(T / len(full) / 16.0))                   # sub-tiles per workgroup the launch actually used
+    NS = max(1, min(5, nsamp_wg))
+    cyc = full[:, 64:].astype(np.float64)
+    per_layer, tot_issue, tot_win = [], 0.0, 0.0
+    tri = lambda n: n * (n + 1) // 2
+    for (li, l), nbk in zip(gps, nbks):
+        R = l["q_mu"].shape[1]
+        nrb = (R + 15) // 16
+        # stage 1 (csrc/dgp_forward.hip): nbk <= 8: per sub-tile nbk diagonal solves (4 fp32 MFMAs) + the blocks below them (3 f16 MFMAs
+        # of K = 16 when nbk is even, else 4 fp32); 8 < nbk < 16: every block 4 fp32; nbk >= 16: the super-block stream (inverse blocks fp32)
+        if nbk <= 8:
+            off = tri(nbk) - nbk
+            i1 = NS * (nbk * 4 * 32 + off * (3 * 16 if nbk % 2 == 0 else 4 * 32))
+        elif nbk < 16:
+            i1 = NS * tri(nbk) * 4 * 32
+        else:
+            dense, inv = 0, 0                                      # blocks of -L(I, <I) / of the inverse diagonal super-blocks
+            for I in range((nbk + 7) // 8):
+                r0, nr = 8 * I, min(8, nbk - 8 * I)
+                dense += nr * r0
+                inv += nr * (nr + 1) // 2
+            # S16 launches: the dense part as 16 x 32 slabs of split f16 (3 MFMAs of 16 clocks per pair of blocks)
+            i1 = NS * (inv * 4 * 32 + (dense // 2 * 3 * 16 if s16 else dense * 4 * 32))
+        if s16:                                                    # pairs of row-blocks: (nkc - p) steps of 6 MFMAs per sub-tile; q_mu^T: 3 per slab
+            nkc = nbk // 2
+            i2 = NS * (R * sum(nkc - p for p in range(nkc)) * 6 + nrb * nkc * 3) * 16
+        else:
+            i2 = NS * (R * tri(nbk) + nrb * nbk) * 4 * 32
+        w1 = float(np.median(cyc[:, 2 + li * 6 + 2] - cyc[:, 2 + li * 6 + 1]))
+        w2 = float(np.median(cyc[:, 2 + li * 6 + 3] - cyc[:, 2 + li * 6 + 2]))
+        per_layer.append({"layer": li, "M": int(l["Z"].shape[0]), "R": int(R),
+                          "stage1": {"mfma_issue_clk": i1, "window_clk": w1, "util": i1 / (4.0 * w1) if w1 > 0 else None},
+                          "stage2": {"mfma_issue_clk": i2, "window_clk": w2, "util": i2 / (4.0 * w2) if w2 > 0 else None}})
+        tot_issue += i1 + i2
+        tot_win += w1 + w2
+    return {"value": tot_issue / (4.0 * tot_win) if tot_win > 0 else None, "per_layer": per_layer, "subtiles_per_workgroup": NS,
+            "split_f16_stage2": bool(s16),
+            "how": "sum over the GP layers of (MFMA instructions of stage 1 + stage 2 per workgroup x issue cycles) / (4 SIMDs x the two phases' "
+                   "median duration in shader clocks, from the in-kernel stamps of one launch); the phases include their operand fetches "
+                   "and the VALU work between the MFMAs, not the barriers that end them"}
 
 
 def no_dev_kernarg_leg(args):
@@ -541,6 +620,12 @@ def main():
     torch.cuda.synchronize()
     dom_ms = float(np.median([a.elapsed_time(b) for a, b in evs])) / NREP
     achieved = dom_flops / (dom_ms * 1e-3)
+    gemm_util = None
+    if world == 1:
+        try:
+            gemm_util = gemm_phase_mfma_util(model, spec, B, K)
+        except Exception as e:                                   # (diagnostic stamps: must not take the headline line down)
+            gemm_util = {"error": "%s: %s" % (type(e).__name__, e)}
 
     # ---- the same evaluation with the fp32-MFMA stage 2 (iwvi_layer_desc.flags & IWVI_LAYER_F32_STAGE2: a per-call flag), so that the
     #      pure-fp32 figure is observed in the same run, next to the split-f16 default
@@ -661,6 +746,8 @@ def main():
             # where stage 2 dominates (M >= 256) and is kept only for comparison.  bound: from the counters of the committed profile.
             "roofline": roofline_object(achieved, dom_flops, dom_ms, spec, traffic, traffic_src, pmc),
         }
+        if gemm_util is not None:
+            res["roofline"]["gemm_phase_mfma_util"] = gemm_util
         f32p, f16p = f_alg_split(spec, settings.fw_f32_stage2)
         mix_peak = (f32p + f16p) / (f32p / PEAK_MFMA_F32 + f16p / (PEAK_MFMA_F16 / 3.0))
         res["model_frac_of_mfma_peak"] = res["value"] / world * tot_flops / mix_peak          # the WHOLE step (both launches) against the mix ceiling

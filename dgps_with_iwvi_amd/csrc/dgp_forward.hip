@@ -187,7 +187,7 @@ struct alignas(64) FwHot {
     int nx_c_off, nx_nsteps, nx_ls_off, nx_ls_n;
     int M, Mp, nbk, nrb, nsteps, R, P, kern_type, mf_type, zt_off, ls_off;   // LV layer: R = Lw, nbk = n_enc, Mp = maxdim
     float variance;
-    int pad0;
+    int ls16_off;                        // M > 240: the split-f16 slabs of the super-block solve, in 16-byte units behind LsP (iwvi_common.h: sb16_slabs)
     const float* nx_ls; const f32x4* LrTP; const f32x4* QmuP; const f32x4* LsP; const float* ZtP;   // LV: LrTP = enc_out
 };
 static_assert(sizeof(FwHot) == 128, "two scalar-cache lines per layer");
@@ -1145,6 +1145,11 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
                 // one block row per wave, in place), then a_I = (L_II)^-1 r_I (triangular product with the packed inverse of
                 // the 128 x 128 diagonal super-block; every wave reads r_I, barrier, writes a_I in place).  No wave carries a
                 // dependent chain, all eight are busy; the operand stream (csrc/precompute.hip) comes from L2 in job order.
+                // S16 launches (round 4): the dense product runs on split-f16 operands like stage 2 -- the slabs of 2^ea (-L(bi, <8I)) from
+                // the state (k_pack_ls16), the solved a_<I read as the f16 planes stage 2 reads -- three v_mfma_f32_16x16x32_f16 (16 clocks
+                // each) per 16 x 32 slab instead of eight fp32 MFMAs of 32: 47 % of this stage's blocks at M = 256, 73 % at M = 512 (the
+                // products with the inverse diagonal super-blocks stay fp32: an error there is amplified by cond(L_II)).  a_I is written
+                // straight as its two f16 planes (each block's planes live in the block's own four tile rows), so stage 2 converts nothing.
                 {
                     f32x4* uz = reinterpret_cast<f32x4*>(usq);
                     for (int i = tid; i < (FW_WAVES * R * NSAMP) / 4; i += FW_THREADS) uz[i] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -1154,13 +1159,40 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
                 float ssq[NS];
 #pragma unroll
                 for (int t = 0; t < NS; ++t) ssq[t] = 0.f;
-                int off = 0;
+                int off = 0, off16 = 0;
+                const float sa_sb = cst[IWVI_CST_SA];
                 for (int I = 0; I < nsb; ++I) {
                     const int r0 = 8 * I, nr = (nbk - r0 < 8) ? nbk - r0 : 8;
                     const bool mine = wave < nr;
                     const int bi = r0 + wave;
                     f32x4 acc[NS];
-                    if (mine && r0 > 0) {
+                    if (S16 && mine && r0 > 0) {
+                        using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
+                        const int nst = r0 >> 1;                  // slabs of this block row
+                        gptr4 P16 = (gptr4)G.LsP + G.ls16_off + (size_t)(off16 + wave * nst) * 128 + lane;
+                        const f32x4* p1 = at + (size_t)(2 * gq) * NSAMP + jq;   // h1 vector of chunk kc, sub-tile t: p1[kc * 8 * NSAMP + 16 t]; h2: the next row
+                        const f32x4* p2 = p1 + NSAMP;
+#pragma unroll
+                        for (int t = 0; t < NS; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+                        f32x4 A1 = P16[0], A2 = P16[64];
+                        for (int kc = 0; kc < nst; ++kc) {
+                            const f16x8 a1 = __builtin_bit_cast(f16x8, A1), a2 = __builtin_bit_cast(f16x8, A2);
+                            const size_t nx = (size_t)(kc + 1 < nst ? kc + 1 : kc) * 128;
+                            A1 = P16[nx]; A2 = P16[nx + 64];
+                            f32x4 b1[NS], b2[NS];
+#pragma unroll
+                            for (int t = 0; t < NS; ++t) { b1[t] = p1[kc * 8 * NSAMP + 16 * t]; b2[t] = p2[kc * 8 * NSAMP + 16 * t]; }
+#pragma unroll
+                            for (int t = 0; t < NS; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, __builtin_bit_cast(f16x8, b1[t]), acc[t], 0, 0, 0);
+#pragma unroll
+                            for (int t = 0; t < NS; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2, __builtin_bit_cast(f16x8, b1[t]), acc[t], 0, 0, 0);
+#pragma unroll
+                            for (int t = 0; t < NS; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, __builtin_bit_cast(f16x8, b2[t]), acc[t], 0, 0, 0);
+                        }
+                        const float inv_u = 1.0f / (sa_sb * sa_sb);   // both operands carry 2^ea (exact powers of two)
+#pragma unroll
+                        for (int t = 0; t < NS; ++t) at[(bi * 4 + gq) * NSAMP + 16 * t + jq] = kuf[(bi * 4 + gq) * NSAMP + 16 * t + jq] + acc[t] * inv_u;
+                    } else if (mine && r0 > 0) {
 #pragma unroll
                         for (int t = 0; t < NS; ++t) acc[t] = kuf[(bi * 4 + gq) * NSAMP + 16 * t + jq];
                         gptr4 P = Ap + (size_t)(off + wave * r0) * 64;
@@ -1205,13 +1237,19 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
 #pragma unroll
                         for (int t = 0; t < NS; ++t) {
                             const int tcol = 16 * t + jq;
-                            at[(bi * 4 + gq) * NSAMP + tcol] = acc[t];
+                            if constexpr (S16) {                  // the two f16 planes of 2^ea a (lane (gq, jq): 8 bytes of each vector)
+                                f16x4 h1, h2;
+                                split_b16(acc[t], sa_sb, h1, h2);
+                                char* pl = reinterpret_cast<char*>(at) + ((size_t)((4 * bi + 2 * (gq >> 1)) * NSAMP + tcol)) * 16 + 8 * (gq & 1);
+                                *reinterpret_cast<f16x4*>(pl) = h1; *reinterpret_cast<f16x4*>(pl + NSAMP * 16) = h2;
+                            } else at[(bi * 4 + gq) * NSAMP + tcol] = acc[t];
                             ssq[t] += colsumsq4(acc[t]);
                             if (o_a && tcol < nvalid) *((gout4)(o_a + (size_t)(t0 + tcol) * G.Mp + 16 * bi + 4 * gq)) = acc[t];
                         }
                     }
                     __syncthreads();                              // a_I visible (next super-block's product, stage 2)
                     off += nr * r0 + nr * (nr + 1) / 2;
+                    off16 += nr * (r0 >> 1);
                 }
                 // |a|^2: every wave's share to its own slot, summed in a fixed order
 #pragma unroll
@@ -1346,7 +1384,7 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
                 // In-place conversion: the eight values a[32 kc + 8 g .. + 7] of a sample are the two float4 rows 8 kc + 2 g and 8 kc + 2 g + 1
                 // of the fp32 tile; their h1 vector goes back to the first, their h2 vector to the second (planes interleaved row by row):
                 // every item reads and writes its own two slots -- no hazard, no temporaries, every thread busy.
-                if (BIG && nbk > 8) {                             // (nbk <= 8: stage 1 wrote the planes itself -- stage1_unrolled, P16)
+                if (BIG && nbk > 8 && nbk < FW_SB_MIN_NBK) {      // (nbk <= 8 and the super-block solve write the planes themselves)
                     const float sa = cst[IWVI_CST_SA];
                     for (int v = tid; v < nvec; v += FW_THREADS) {
                         const int j = v % NSAMP, kg = v / NSAMP;          // kg = 4 kc + g
@@ -2224,6 +2262,7 @@ int dgp_forward_impl(const iwvi_layer_desc* layers, int n_layers, const float* X
             H.M = G.M; H.Mp = G.Mp; H.nbk = G.nbk; H.nrb = G.nrb; H.nsteps = G.nsteps; H.R = G.R; H.P = G.P;
             H.kern_type = G.kern_type; H.mf_type = G.mf_type; H.zt_off = G.zt_off; H.ls_off = G.ls_off; H.variance = G.variance;
             H.LrTP = G.LrTP; H.QmuP = G.QmuP; H.LsP = G.LsP; H.ZtP = G.ZtP;
+            { const StateLayout sl = state_layout(G.M, G.R); H.ls16_off = (int)(((long long)sl.off_Ls16 - (long long)sl.off_LsP) / 16); }
             if (G.W) fl |= FWF_HASW;
             if (G.s16) fl |= FWF_S16;
             if (G.mfb) fl |= FWF_HAS_MFB;

@@ -54,9 +54,18 @@ __host__ __device__ static inline int s16_slabs(int nbk, int bi) { return (nbk -
 __host__ __device__ static inline int s16_slab_off(int nbk, int bi) { int o = 0; for (int b = 0; b < bi; ++b) o += s16_slabs(nbk, b); return o; }
 __host__ __device__ static inline int s16_slabs_total(int nbk) { return s16_slab_off(nbk, nbk); }
 
+// M > 240 (nbk >= 16): the solve runs super-block by super-block (8 block rows each; csrc/dgp_forward.hip), and the dense part of it --
+// r_I = k_I - L(I, <I) a_<I -- takes split-f16 operands when the launch does (S16): the blocks -L(bi, 0 .. 8I-1) of a block row as
+// 2-KiB slabs (16 rows x 32 k, planes h1 | h2 of 2^ea (-L), lane 16 g + i holds G[i][8 g .. 8 g + 7]), 4 I slabs per row, rows in order,
+// super-blocks I = 1 .. in order (k_pack_ls16, csrc/precompute.hip)
+__host__ __device__ static inline int sb16_slabs(int nbk) {
+    int n = 0;
+    for (int I = 1; 8 * I < nbk; ++I) { const int nr = nbk - 8 * I < 8 ? nbk - 8 * I : 8; n += nr * 4 * I; }
+    return nbk >= 16 ? n : 0;
+}
 struct StateLayout {
     int Mp, nbk, nrb, nsteps;
-    size_t off_Lm, off_Linv, off_LsP, off_LrTP, off_QmuP, off_ZtP, off_cst, off_kl, off_ws, off_LrT16, off_Qmu16, bytes;
+    size_t off_Lm, off_Linv, off_LsP, off_LrTP, off_QmuP, off_ZtP, off_cst, off_kl, off_ws, off_LrT16, off_Qmu16, off_Ls16, bytes;
 };
 static inline size_t align256(size_t x) { return (x + 255) & ~size_t(255); }
 // ZtP is sized for the largest input dimension (IWVI_MAX_D) so that the layout depends on (M, R) only
@@ -84,6 +93,7 @@ static inline StateLayout state_layout(int M, int R) {
     // split-f16 images of L_r^T and q_mu^T for v_mfma_f32_16x16x32_f16 (s16_*): 2-KiB slabs (16 rows x 32 k, two f16 planes)
     s.off_LrT16 = o; o = align256(o + (size_t)R * s16_slabs_total(s.nbk) * 2048);
     s.off_Qmu16 = o; o = align256(o + (size_t)s.nrb * ((s.nbk + 1) / 2) * 2048);
+    s.off_Ls16 = o;  o = align256(o + (size_t)sb16_slabs(s.nbk) * 2048);
     s.bytes = o;
     return s;
 }

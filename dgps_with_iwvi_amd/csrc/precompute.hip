@@ -151,6 +151,43 @@ __global__ __launch_bounds__(1024) void k_precompute(PreArgs args) {
     }
 }
 
+// The split-f16 slabs of the super-block solve's dense part (iwvi_common.h: sb16_slabs), for every layer with M > 240, from the factor
+// the launch before left in the layer's workspace (block storage; the blocks between different super-blocks still hold L there) or, for a
+// state precomputed with IWVI_GP_WANT_DENSE / _LM, from its dense Lm.  A launch of its own: k_precompute is not touched by it
+// (at 128 VGPRs with spills, a source change anywhere in that kernel moves the M <= 128 path by +-1 us: profiles/r04_precompute_notes.txt).
+struct Ls16One { const double* blk; const double* Lm; unsigned short* dst; const float* variance_dev; float variance; int nbk, Mp, M, first; };
+struct Ls16All { Ls16One L[IWVI_MAX_LAYERS]; int n; };
+__global__ __launch_bounds__(256) void k_pack_ls16(const Ls16All a) {
+    int li = 0;
+    while (li + 1 < a.n && (int)blockIdx.x >= a.L[li + 1].first) ++li;
+    const Ls16One& L = a.L[li];
+    const int nbk = L.nbk;
+    int s = ((int)blockIdx.x - L.first) * 4 + (threadIdx.x >> 6);           // slab of this wave
+    if (s >= sb16_slabs(nbk)) return;
+    const int lane = threadIdx.x & 63;
+    int I = 1;
+    for (;; ++I) { const int nr = nbk - 8 * I < 8 ? nbk - 8 * I : 8, cnt = nr * 4 * I; if (s < cnt) break; s -= cnt; }
+    const int row = s / (4 * I), kc = s - row * 4 * I;                      // block row 8 I + row, blocks 2 kc, 2 kc + 1
+    const int bi = 8 * I + row;
+    const float var = L.variance_dev ? *L.variance_dev : L.variance;
+    const float sc = ldexpf(1.f, 10 - (int)ceilf(0.5f * log2f(fmaxf(var, 1e-30f))));   // 2^ea of a layer with M > 128 (role_factor: IWVI_CST_SA)
+    const int i = lane & 15, g = lane >> 4;
+    pk_f16x8 h1, h2;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int k = 32 * kc + 8 * g + e, bk = k >> 4;
+        const int r = 16 * bi + i;
+        double v = L.Lm ? L.Lm[(size_t)r * L.Mp + k] : L.blk[boff(bi, bk) + i * BLD + (k & 15)];
+        if (r >= L.M || k >= L.M) v = 0.0;                                   // identity padding: nothing below the diagonal
+        const float x = -(float)v * sc;
+        const _Float16 hh = (_Float16)x;
+        h1[e] = hh; h2[e] = (_Float16)(x - (float)hh);
+    }
+    unsigned short* dst = L.dst + ((size_t)blockIdx.x - L.first) * 4 * 1024 + (size_t)(threadIdx.x >> 6) * 1024;
+    *reinterpret_cast<float4*>(dst + lane * 8) = as_f4(h1);
+    *reinterpret_cast<float4*>(dst + 512 + lane * 8) = as_f4(h2);
+}
+
 __global__ __launch_bounds__(256) void k_gauss_kl(const float* q_mu, const float* q_sqrt, int M, int R,
                                                    double* kl) {
     role_kl_only(q_mu, q_sqrt, M, R, kl, reinterpret_cast<double*>(smem_raw));
@@ -494,6 +531,26 @@ extern "C" int iwvi_model_precompute(const iwvi_gp_desc* layers, int n_layers, c
         if ((rc = ensure_lds_attr((const void*)k_precompute, lds)) != IWVI_OK) return rc;
         hipLaunchKernelGGL(k_precompute, dim3(a.n + enc_blocks, max_roles), dim3(1024), lds, stream, a);
         if ((rc = check_launch("k_precompute")) != IWVI_OK) return rc;
+        {   // layers with M > 240: the split-f16 operands of the super-block solve's dense part
+            Ls16All q{};
+            int grid = 0;
+            for (int l = 0; l < a.n; ++l) {
+                const PreLayer& L = a.L[l];
+                if (L.nbk < 16) continue;
+                const StateLayout sl = state_layout(L.M, L.R);
+                Ls16One& o = q.L[q.n++];
+                o.blk = L.ws + ws_layout(L.Mp).blk;
+                o.Lm = (L.flags & (IWVI_GP_WANT_DENSE | IWVI_GP_WANT_LM)) ? L.Lm : nullptr;
+                o.dst = reinterpret_cast<unsigned short*>(reinterpret_cast<char*>(L.Lm) - sl.off_Lm + sl.off_Ls16);
+                o.variance = L.variance; o.variance_dev = L.variance_dev;
+                o.nbk = L.nbk; o.Mp = L.Mp; o.M = L.M; o.first = grid;
+                grid += (sb16_slabs(L.nbk) + 3) / 4;
+            }
+            if (q.n > 0) {
+                hipLaunchKernelGGL(k_pack_ls16, dim3(grid), dim3(256), 0, stream, q);
+                if ((rc = check_launch("k_pack_ls16")) != IWVI_OK) return rc;
+            }
+        }
     }
     return IWVI_OK;
 }

@@ -42,9 +42,19 @@ def test_split_f16_stage2_is_as_accurate_as_fp32(gpu_device, M, q_scale, var_sca
     # both paths agree with each other far inside the tolerance they are held to against float64
     assert abs(e16 - e32) <= 2e-5 * abs(ref) + 1e-3, (e16, e32, ref)
     assert abs(e16 - ref) <= max(2.0 * abs(e32 - ref), 1e-5 * abs(ref)) + 1e-3, (e16, e32, ref)
+    # M > 240: the split-f16 launch also runs the dense part of the super-block solve on split operands (csrc/dgp_forward.hip, round 4), so
+    # the two modes differ in stage 1 too -- each sits ~7e-5 from the float64 means there (profiles/r04_split16_error.txt)
+    tol = 2e-5 if M <= 128 else 8e-5
     for a, b in zip(m16 + v16, m32 + v32):
         scale = max(np.abs(b).max(), 1e-30)
-        assert np.abs(a - b).max() <= 2e-5 * scale, (np.abs(a - b).max(), scale)
+        assert np.abs(a - b).max() <= tol * scale, (np.abs(a - b).max(), scale)
+    # ... and both against the float64 oracle's per-layer means, at the tolerance DESIGN.md states (rtol 2e-3 + atol 1e-3), the split form
+    # no more than twice as far as the fp32 one
+    means_o = om.log_weights(oracle_noise(spec, zs))[2]
+    for k, mo in enumerate(means_o):
+        d16, d32 = np.abs(m16[k] - mo).max(), np.abs(m32[k] - mo).max()
+        assert d16 <= 1e-3 + 2e-3 * np.abs(mo).max() and d32 <= 1e-3 + 2e-3 * np.abs(mo).max(), (k, d16, d32)
+        assert d16 <= 2.0 * d32 + 5e-5, (k, d16, d32)
 
 
 def test_an_odd_block_count_takes_the_fp32_stage2(gpu_device):
