@@ -1160,16 +1160,19 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
 #pragma unroll
                 for (int t = 0; t < NS; ++t) ssq[t] = 0.f;
                 int off = 0, off16 = 0;
+                // block row of a wave within a super-block: waves w and w + 4 share a SIMD, and row q of the inverse part costs q + 1 blocks --
+                // rows (i, 7 - i) per SIMD level it (9 blocks each instead of 6 / 8 / 10 / 12)
+                const int rw = wave < 4 ? wave : 11 - wave;
                 const float sa_sb = cst[IWVI_CST_SA];
                 for (int I = 0; I < nsb; ++I) {
                     const int r0 = 8 * I, nr = (nbk - r0 < 8) ? nbk - r0 : 8;
-                    const bool mine = wave < nr;
-                    const int bi = r0 + wave;
+                    const bool mine = rw < nr;
+                    const int bi = r0 + rw;
                     f32x4 acc[NS];
                     if (S16 && mine && r0 > 0) {
                         using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
                         const int nst = r0 >> 1;                  // slabs of this block row
-                        gptr4 P16 = (gptr4)G.LsP + G.ls16_off + (size_t)(off16 + wave * nst) * 128 + lane;
+                        gptr4 P16 = (gptr4)G.LsP + G.ls16_off + (size_t)(off16 + rw * nst) * 128 + lane;
                         const f32x4* p1 = at + (size_t)(2 * gq) * NSAMP + jq;   // h1 vector of chunk kc, sub-tile t: p1[kc * 8 * NSAMP + 16 t]; h2: the next row
                         const f32x4* p2 = p1 + NSAMP;
 #pragma unroll
@@ -1195,7 +1198,7 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
                     } else if (mine && r0 > 0) {
 #pragma unroll
                         for (int t = 0; t < NS; ++t) acc[t] = kuf[(bi * 4 + gq) * NSAMP + 16 * t + jq];
-                        gptr4 P = Ap + (size_t)(off + wave * r0) * 64;
+                        gptr4 P = Ap + (size_t)(off + rw * r0) * 64;
                         f32x4 a_nx = P[0], a_n2 = P[(size_t)(1 < r0 ? 1 : 0) * 64];
                         for (int bj = 0; bj < r0; ++bj) {
                             const f32x4 a_cur = a_nx;
@@ -1215,13 +1218,13 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
                     }
                     if (r0 > 0) __syncthreads();                  // r_I complete
                     if (mine) {
-                        gptr4 P = Ap + (size_t)(off + nr * r0 + wave * (wave + 1) / 2) * 64;
+                        gptr4 P = Ap + (size_t)(off + nr * r0 + rw * (rw + 1) / 2) * 64;
 #pragma unroll
                         for (int t = 0; t < NS; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
                         f32x4 a_nx = P[0];
-                        for (int q = 0; q <= wave; ++q) {
+                        for (int q = 0; q <= rw; ++q) {
                             const f32x4 a_cur = a_nx;
-                            a_nx = P[(size_t)(q + 1 <= wave ? q + 1 : q) * 64];
+                            a_nx = P[(size_t)(q + 1 <= rw ? q + 1 : q) * 64];
                             f32x4 b[NS];
 #pragma unroll
                             for (int t = 0; t < NS; ++t) b[t] = at[((r0 + q) * 4 + gq) * NSAMP + 16 * t + jq];
