@@ -68,7 +68,7 @@ if len(sys.argv) > 2 and sys.argv[2] == "--latest":
         d, der = out["kernels"][k], out["kernels"][k]["derived"]
         import subprocess
         try:
-            commit = subprocess.check_output(["git", "rev-parse", "--short", "HEAD"], stderr=subprocess.DEVNULL).decode().strip()
+            commit = subprocess.check_output(["git", "log", "-1", "--format=%h", "--", "dgps_with_iwvi_amd/csrc"], stderr=subprocess.DEVNULL).decode().strip()   # the kernels' last commit (tests/test_profiles_fresh.py)
         except Exception:
             commit = None
         lat = {"kernel": k.replace("iwvi::", ""), "config": "BASELINE.json configs[2]",
