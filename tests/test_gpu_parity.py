@@ -138,6 +138,9 @@ def _oracle_layer(c, D, R, mixing, mf, full_cov=False, z=None):
     (256, 8, 5, 8, True, "linear", 4, 50),      # config 4 layer
     (512, 8, 2, 8, True, "linear", 2, 40),      # config 5 width (one workgroup per CU)
     (40, 17, 2, 2, False, "zero", 3, 7),        # D > 16 instantiation
+    (250, 8, 2, 2, False, "zero", 3, 40),       # super-block solve (M > 240) with padded inducing rows, split-f16 dense part
+    (270, 5, 1, 1, False, "linear", 2, 30),     # 17 block rows: odd, so the fp32 variant; a one-row last super-block
+    (384, 8, 3, 8, True, "linear", 2, 24),      # three super-blocks
 ])
 def test_gp_layer_forward(gpu_device, M, D, R, P, mixing, mf, S, N):
     c = _layer_case(M + D + R, M, D, R, P, mixing, mf, S, N)
@@ -155,6 +158,21 @@ def test_gp_layer_forward(gpu_device, M, D, R, P, mixing, mf, S, N):
     # with z = 0 the sample is exactly the mean
     s0, m0, _, _ = _run_layer(c, gpu_device, D, R, mixing, mf, z=torch.zeros(S, N, R, device=gpu_device))
     assert torch.equal(s0, m0)
+
+
+def test_super_block_operands_from_a_dense_state(gpu_device):
+    """M > 240: the split-f16 slabs of the solve's dense part are packed from the factorisation's workspace -- or, for a state
+    precomputed with IWVI_GP_WANT_DENSE (whose workspace then holds the full inverse), from its dense Lm: the same numbers."""
+    from dgps_with_iwvi_amd import synthetic
+    spec = synthetic.make_spec(L=2, M=256, B=40, K=6, with_lv=False, seed=5)
+    zs = [_t(z, gpu_device).reshape(40 * 6, -1) for z in synthetic.make_noise(spec, seed=6)]
+    model = synthetic.build_model(spec, gpu_device)
+    out = []
+    for dense in (False, True):
+        model.precompute(with_encoders=True, dense=dense)
+        logw, _, _ = model._fused_forward(40 * 6, 6, 40, (40, 6), zs=zs)
+        out.append(logw.clone())
+    assert torch.equal(out[0], out[1])
 
 
 def test_gp_layer_2d_equals_3d_flat(gpu_device):
