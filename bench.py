@@ -107,7 +107,7 @@ class Step:
         return self.out
 
 
-def training_leg(model, samples, iters=20):
+def training_leg(model, samples, iters=20, flops_forward=None):
     """Informational, outside the timed region of the headline metric: the same workload through the backward pass
      -- one IW-ELBO value + gradient evaluation, and one training step of the reference
     (NatGrad op + Adam op = two gradient evaluations, experiments/build_models.py:297-300), eager launches."""
@@ -140,7 +140,28 @@ def training_leg(model, samples, iters=20):
         grad_graph_ms = timed(g.replay)
         step_ms = timed(Trainer(model).step)
         step_graph_ms = timed(Trainer(model, use_graph=True).step)
-        return {"value_and_gradient_ms": grad_graph_ms, "value_and_gradient_eager_ms": grad_ms,
+        roof = None
+        if flops_forward:
+            # algorithmic FLOPs of one value + gradient evaluation: the forward's + two adjoint products per forward
+            # product (d operand A, d operand B) = 3 x; priced against the fp32-MFMA peak (the adjoint's products over samples and its
+            # Cholesky adjoint are fp32 / fp64 MFMA work; only phase 1 of the chain kernel runs split f16) -- fp32-equivalent, like
+            # roofline.frac_fp32_equivalent of the forward
+            f = 3.0 * flops_forward
+            ach = f / (grad_graph_ms * 1e-3)
+            roof = {"bound": "mfma", "kernel": "one value + gradient evaluation = one hipGraph replay (~30 launches; dominant: k_bw_chain per GP layer)",
+                    "achieved": ach / 1e12, "peak": PEAK_MFMA_F32 / 1e12, "unit": "TFLOP/s", "frac": ach / PEAK_MFMA_F32,
+                    "flops_per_evaluation": f, "traffic": None,
+                    "limiter": "launch-bound chains: ~30 dependent launches and 3 cross-queue joins per evaluation (DESIGN.md section 6)"}
+            try:
+                bj = json.load(open(os.path.join(ROOT, "profiles", "backward_latest.json")))
+                roof["kernels_of_the_committed_profile"] = bj["kernels"][:6]
+                roof["pmc_profile_of_commit"] = bj.get("pmc_profile_of_commit")
+                roof["traffic"] = sum((k.get("hbm_read_bytes") or 0.0) + (k.get("hbm_write_bytes") or 0.0) for k in bj["kernels"]
+                                      if (k.get("calls") or 0) > 0 and k.get("hbm_read_bytes") is not None) or None
+                roof["traffic_note"] = "sum over the profile's kernels of their per-dispatch HBM bytes (one dispatch of each per evaluation, two of the chain kernel's variants)"
+            except Exception:
+                pass
+        return {"roofline": roof, "value_and_gradient_ms": grad_graph_ms, "value_and_gradient_eager_ms": grad_ms,
                 "gradient_samples_per_s": samples / grad_graph_ms * 1e3,
                 "train_step_ms": step_graph_ms, "train_step_eager_ms": step_ms,
                 "note": "value + gradient: one hipGraph replay of backward.iw_elbo_and_gradients (fused forward that keeps a, streaming adjoint chain "
@@ -772,7 +793,7 @@ def main():
                 res["cpu_baseline_fp32"] = {"error": "%s: %s" % (type(e).__name__, e)}
             res["gpu_over_cpu"] = res["value"] / res["cpu_baseline"]["value"]
         if world == 1 and not args.no_train_leg:
-            res["training_step"] = training_leg(model, B * K)
+            res["training_step"] = training_leg(model, B * K, flops_forward=tot_flops * B * K)
         print(json.dumps(res))
     if dist is not None:
         dist.destroy_process_group()

@@ -81,6 +81,25 @@ if len(sys.argv) > 2 and sys.argv[2] == "--latest":
                "kernel_avg_us_rocprof": d.get("avg_ns", 0.0) / 1e3, "pmc_profile_of_commit": commit}
         lat["hbm_bytes"] = (lat["hbm_read_bytes"] or 0.0) + (lat["hbm_write_bytes"] or 0.0)
         json.dump(lat, open(os.path.join("profiles", "traffic_latest.json"), "w"), indent=1)
+# the value + gradient evaluation (scripts/profile_backward.sh): its dominant kernels' entries, quoted by bench.py's training_step.roofline
+if len(sys.argv) > 2 and sys.argv[2] == "--backward":
+    import subprocess
+    try:
+        commit = subprocess.check_output(["git", "log", "-1", "--format=%h", "--", "dgps_with_iwvi_amd/csrc"], stderr=subprocess.DEVNULL).decode().strip()
+    except Exception:
+        commit = None
+    tot = sum(d.get("avg_ns", 0.0) * d.get("calls", 0) for d in out["kernels"].values())
+    rows = []
+    for k, d in sorted(out["kernels"].items(), key=lambda kv: -kv[1].get("avg_ns", 0.0) * kv[1].get("calls", 0)):
+        der = d.get("derived", {})
+        rows.append({"kernel": k.replace("iwvi::", ""), "calls": d.get("calls"), "avg_us": d.get("avg_ns", 0.0) / 1e3,
+                     "share_of_kernel_time": d.get("avg_ns", 0.0) * d.get("calls", 0) / max(tot, 1.0),
+                     "mfma_busy_frac": der.get("mfma_busy_frac(SQ_VALU_MFMA_BUSY_CYCLES/(1024*GRBM_GUI_ACTIVE/8))"),
+                     "mfma_pipe_frac": der.get("mfma_pipe_frac(f32/157.3T+f16/2.5P+f64/78.6T)"),
+                     "hbm_read_bytes": der.get("hbm_read_bytes(FETCH_SIZE*1024*2)"), "hbm_write_bytes": der.get("hbm_write_bytes(WRITE_SIZE*1024)")})
+    json.dump({"config": "BASELINE.json configs[2], one value + gradient evaluation (scripts/time_backward.py --only-gradient)",
+               "source": "profiles/%s_summary.json" % tag, "pmc_profile_of_commit": commit, "kernels": rows[:12]},
+              open(os.path.join("profiles", "backward_latest.json"), "w"), indent=1)
 with open(os.path.join("profiles", tag + "_summary.json"), "w") as fh:
     json.dump(out, fh, indent=1, sort_keys=True)
 for f in glob.glob(os.path.join(root, "trace", "**", "*kernel_stats.csv"), recursive=True):

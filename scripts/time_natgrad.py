@@ -1,18 +1,38 @@
-"""Kernel-level view of one NatGrad step (iwvi_natgrad_step) at M = 128, R = 1 (development aid; run under scripts/prof_any.sh)."""
+"""Kernel-level view of one NatGrad step (iwvi_natgrad_step) at M = 128, R = 1: hipGraph replays of 20 steps, and the same with the
+kernel leaving after step 1 .. 4 (IWVI_NG_STOP: the update is then incomplete -- timing only).  Development aid."""
 import os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from dgps_with_iwvi_amd import _abi
 dev = torch.device("cuda:0")
 M, R = 128, 1
 g = torch.Generator().manual_seed(0)
-q_mu = torch.randn(M, R, generator=g).to(dev)
-q_sqrt = (torch.tril(torch.randn(R, M, M, generator=g)) * 0.05 + torch.eye(M)).to(dev)
+q_mu0 = torch.randn(M, R, generator=g).to(dev)
+q_sqrt0 = (torch.tril(torch.randn(R, M, M, generator=g)) * 0.05 + torch.eye(M)).to(dev)
 dq_mu = (torch.randn(M, R, generator=g) * 1e-2).to(dev)
 dq_sqrt = (torch.tril(torch.randn(R, M, M, generator=g)) * 1e-2).to(dev)
 ws = torch.empty(_abi.lib().iwvi_natgrad_ws_bytes(M), dtype=torch.uint8, device=dev)
-def step():
-    _abi.check(_abi.lib().iwvi_natgrad_step(_abi.ptr(q_mu), _abi.ptr(q_sqrt), _abi.ptr(dq_mu), _abi.ptr(dq_sqrt), M, R, 1e-3, ws.data_ptr(), _abi.stream_ptr()))
-for _ in range(3): step()
-torch.cuda.synchronize(); t0 = time.perf_counter()
-for _ in range(50): step()
-torch.cuda.synchronize(); print("natgrad step: %.1f us eager" % ((time.perf_counter() - t0) / 50 * 1e6))
+names = {0: "whole step", 1: "1 Q build", 2: "+ 2 factorisation", 3: "+ 3 inverse", 4: "+ 4 vectors"}
+prev = 0.0
+for stop in (1, 2, 3, 4, 0):
+    _abi.set_debug_option("IWVI_NG_STOP", stop)
+    q_mu, q_sqrt = q_mu0.clone(), q_sqrt0.clone()
+    def step():
+        _abi.check(_abi.lib().iwvi_natgrad_step(_abi.ptr(q_mu), _abi.ptr(q_sqrt), _abi.ptr(dq_mu), _abi.ptr(dq_sqrt), M, R, 1e-6, ws.data_ptr(), _abi.stream_ptr()))
+    s = torch.cuda.Stream(device=dev)
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        step()
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr, stream=s, capture_error_mode="thread_local"):
+            for _ in range(20):
+                step()
+    torch.cuda.current_stream().wait_stream(s)
+    torch.cuda.synchronize()
+    for _ in range(3): gr.replay()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(10): gr.replay()
+    torch.cuda.synchronize()
+    us = (time.perf_counter() - t0) / 200 * 1e6
+    print("%-20s %6.1f us per launch%s" % (names[stop], us, "" if stop in (0, 1) else "   (+%.1f)" % (us - prev)))
+    prev = us
+_abi.set_debug_option("IWVI_NG_STOP", 0)
