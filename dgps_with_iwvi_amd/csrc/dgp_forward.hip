@@ -605,7 +605,9 @@ __device__ __forceinline__ void fw_arrive(const FwArgs& gk, float* sm, int tid, 
 
 // S16: stage 2 of every GP layer on split-f16 operands (iwvi_common.h: s16_*); BIG: some GP layer has more than 8 block rows (M > 128) --
 // the launch variants for M <= 128 do not carry the column-at-a-time / super-block solves and the in-place plane conversion
-template <int NS, bool S16, bool BIG>
+// LEAN (the bound's own evaluation: every GP layer RBF, every latent-variable layer's encoder evaluated by the precompute launch, all noise drawn in
+// the kernel, no per-layer output asked for, the packed arrival): none of those alternatives is compiled into the variant
+template <int NS, bool S16, bool BIG, bool LEAN = false>
 __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
     constexpr int NSAMP = 16 * NS;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -628,7 +630,7 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
     }
     const int chunk_id = (int)blockIdx.x;
     const long long t0 = (long long)chunk_id * NSAMP;
-    const int nvalid = (int)((g.T - t0) < (long long)NSAMP ? (g.T - t0) : (long long)NSAMP);
+    const int nvalid = LEAN ? NSAMP : (int)((g.T - t0) < (long long)NSAMP ? (g.T - t0) : (long long)NSAMP);   // (LEAN: T is a multiple of the chunk)
 
     // ---- the last n_early waves (those that draw no noise below) issue every copy of the prologue; the others fetch the layer table and the
     //      chunk's rows (below: "the prologue's copies")
@@ -672,7 +674,7 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
     //  only moves when the last workgroup of a launch arrives, after every workgroup of that launch has read it)
     const unsigned long long step = g.rng_state ? *((const __attribute__((address_space(4))) unsigned long long*)g.rng_state) : 0ULL;
     FW_STAMP(0);
-    if (g.dbg_exit == 1) return;
+    if (!LEAN && g.dbg_exit == 1) return;
 
     // ================= prologue: everything small -> LDS, all loads in flight at once ==================
     const unsigned ut0 = (unsigned)t0, uT = (unsigned)g.T;
@@ -730,12 +732,12 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
         const unsigned dp = point_of(tid);
         rowi[tid] = (int)row_of(dp);
         pidx[tid] = (int)dp;
-        lw[tid] = (g.lw_init && tid < nvalid) ? g.lw_init[t0 + tid] : 0.f;
+        lw[tid] = (!LEAN && g.lw_init && tid < nvalid) ? g.lw_init[t0 + tid] : 0.f;
     }
     // the chunk's rows of X (models.py:113 / :50 tiling done here) and of the encoder input
     for (int idx = tid; idx < NSAMP * g.Dx; idx += ethreads) {
         const int d = idx / NSAMP, j = idx - d * NSAMP;            // (compile-time divisor)
-        const unsigned row = g.x_per_sample ? ut0 + (unsigned)(j < nvalid ? j : nvalid - 1) : row_of(point_of(j));
+        const unsigned row = (!LEAN && g.x_per_sample) ? ut0 + (unsigned)(j < nvalid ? j : nvalid - 1) : row_of(point_of(j));
         xin[j * XSTR + d] = (j < nvalid) ? g.X[(size_t)row * g.Dx + d] : 0.f;
     }
     if (g.XY) {
@@ -760,7 +762,8 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
     //      the copies follow back to back: the compiler puts `s_waitcnt vmcnt(0)` in front of every ds_read / ds_write that follows a
     //      global_load_lds, so a table entry read between two copies makes the second wait until the first has landed.
     const int ncopy0 = g.ncopy;
-    const int draw_waves = g.noise_any_src ? FW_WAVES : ((g.noise_drawn + 63) >> 6 < FW_WAVES ? (g.noise_drawn + 63) >> 6 : FW_WAVES);
+    const bool noise_any_src = !LEAN && g.noise_any_src;
+    const int draw_waves = noise_any_src ? FW_WAVES : ((g.noise_drawn + 63) >> 6 < FW_WAVES ? (g.noise_drawn + 63) >> 6 : FW_WAVES);
     const int ndma = n_early > 0 ? n_early : FW_WAVES;            // (the host has checked that the copy list fits those waves)
     const int dwave = FW_WAVES - 1 - wave;                        // the copies' wave index: 0 = the last wave
     const bool dma_wave = dwave < ndma, late_big = n_early == 0;  // (without early waves the big copies are issued here too, by every wave)
@@ -771,7 +774,7 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
     // this wave's copies are issued and stored last; further items (more than one per thread: rare) follow
     int it_li = -1, it_k = 0, it_dims = 0, it_zoff = 0, it_zero = 0;
     {
-    if (wave < draw_waves && !g.noise_any_src) {                  // the plan from the header: no LDS round trip per layer
+    if (wave < draw_waves && !noise_any_src) {                  // the plan from the header: no LDS round trip per layer
         int base = 0, cnts[IWVI_MAX_STACK], zoffs[IWVI_MAX_STACK], dms[IWVI_MAX_STACK];
 #pragma unroll
         for (int li = 0; li < IWVI_MAX_STACK; ++li) { cnts[li] = g.nz_cnt[li]; zoffs[li] = g.nz_zoff[li]; dms[li] = g.nz_dims[li]; }   // (three wide scalar loads, one wait)
@@ -897,7 +900,7 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
     FW_STAMP(59);
     __syncthreads();
     FW_STAMP(1);
-    if (g.dbg_exit == 2) return;
+    if (!LEAN && g.dbg_exit == 2) return;
 
     int xt_for = -1;                                              // layer whose Gram operand x~ is already in `xt`
     for (int li = 0; li < g.n_layers; ++li) {
@@ -913,16 +916,16 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
         const float* zl = znoise + H.z_off;
         // optional outputs: from the LDS table, and only when the launch has any
         gout1 o_sample = nullptr, o_mean = nullptr, o_var = nullptr, o_noise = nullptr, o_gmv = nullptr, o_a = nullptr, o_u = nullptr, o_kl = nullptr;
-        if (H.flags & FWF_ANY_OUT) {
+        if (!LEAN && (H.flags & FWF_ANY_OUT)) {
             o_sample = (gout1)ufirst(L.sample); o_mean = (gout1)ufirst(L.mean); o_var = (gout1)ufirst(L.var);
             o_noise = (gout1)ufirst(L.noise_out);
             if (H.type == IWVI_LAYER_GP) { o_gmv = (gout1)ufirst(L.gmv_out); o_a = (gout1)ufirst(L.gp.a_out); o_u = (gout1)ufirst(L.gp.u_out); }
             else o_kl = (gout1)ufirst(L.lv.kl_local);
         }
         // a following GP layer gets its Gram operand from this layer's last phase (no phase of its own)
-        const bool nx_gp = (H.flags & FWF_NX_GP) != 0, nx_rbf = (H.flags & FWF_NX_RBF) != 0;
+        const bool nx_gp = (H.flags & FWF_NX_GP) != 0, nx_rbf = LEAN || (H.flags & FWF_NX_RBF) != 0;
         const float* nx_cst = sm + H.nx_c_off;
-        const int nx_nsteps = H.nx_nsteps;
+        const int nx_nsteps = LEAN ? 3 : H.nx_nsteps;
         if (H.type == IWVI_LAYER_LV) {
             // ================= LatentVariableLayer (layers.py:72-105) =================================
             const FwLv& V = L.lv;
@@ -932,7 +935,7 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
             float* act1 = act0 + NSAMP * mdim;
             const float* in = xyrows; int in_str = up4(g.XYdim);
             float* out = act0;
-            const bool pre_enc = (H.flags & FWF_PRE_ENC) != 0;    // encoder already evaluated by iwvi_model_precompute
+            const bool pre_enc = LEAN || (H.flags & FWF_PRE_ENC) != 0;    // encoder already evaluated by iwvi_model_precompute
             const int enc_actv = pre_enc ? 0 : ufirst(V.act);
             if (pre_enc) { in = cst; in_str = 2 * Lw; }
             else {
@@ -1002,13 +1005,13 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
             FW_STAMP(2 + li * 6 + 5);
         } else {
             // ================= GPLayer (layers.py:35-50) ==============================================
-            const int nbk = G.nbk, R = G.R, P = G.P, nsteps = G.nsteps;
+            const int nbk = LEAN ? 8 : G.nbk, R = G.R, P = G.P, nsteps = LEAN ? 3 : G.nsteps;   // (LEAN: M = 128, D <= 10 -- see launch)
             float g_variance = G.variance;
             if (g.var_dev_mask >> li & 1u) g_variance = sm[g.lds.cnt + 12 + li];          // (a device scalar: fetched in the prologue)
             f32x4* kuf = reinterpret_cast<f32x4*>(scratch);
             f32x4* at = kuf;                                       // solved in place (stage 1)
             float* usq = scratch + (size_t)G.Mp * NSAMP;           // [wave][r][NSAMP]
-            const bool rbf = G.kern_type == IWVI_KERN_RBF;
+            const bool rbf = LEAN || G.kern_type == IWVI_KERN_RBF;
             // split-f16 solve (even nbk <= 8; see split_b16): the Gram tile in units of U (1 otherwise), a_bj scaled by sb for the updates
             const float st1_u = cst[IWVI_CST_U], st1_sb = cst[IWVI_CST_SB];
             const float* invls = cst; const float* zc = cst + 32;
@@ -1032,7 +1035,7 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
 #pragma unroll
                 for (int t = 0; t < NS; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
                 if (gram_mfma) {
-                    if (G.zt_off >= 0) {
+                    if (LEAN || G.zt_off >= 0) {
                         const float* zp = sm + G.zt_off + (size_t)bi * nsteps * 64 + lane;      // staged in LDS
                         for (int s = 0; s < nsteps; ++s) {
                             const float a = zp[s * 64];
@@ -1055,7 +1058,7 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
                     const float sx = rbf ? 1.4426950408889634f : -2.f;
                     for (int d = 0; d < D; ++d) {
                         const size_t zi = ((size_t)bi * nsteps + (d >> 2)) * 64 + 16 * (d & 3) + 4 * gq;
-                        const f32x4 z4 = (G.zt_off >= 0) ? *reinterpret_cast<const f32x4*>(sm + G.zt_off + zi)
+                        const f32x4 z4 = (LEAN || G.zt_off >= 0) ? *reinterpret_cast<const f32x4*>(sm + G.zt_off + zi)
                                                          : *((gptr4)(G.ZtP + zi));
 #pragma unroll
                         for (int t = 0; t < NS; ++t) {
@@ -1080,7 +1083,7 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
                     for (int t = 0; t < NS; ++t) {
                         f32x4 k;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) k[e] = (mrow + e < G.M) ? __builtin_amdgcn_exp2f(acc[t][e]) : 0.f;   // log2(var) folded in
+                        for (int e = 0; e < 4; ++e) k[e] = (LEAN || mrow + e < G.M) ? __builtin_amdgcn_exp2f(acc[t][e]) : 0.f;   // log2(var) folded in
                         k *= st1_u;
                         kuf[(bi * 4 + gq) * NSAMP + 16 * t + jq] = k;
                     }
@@ -1278,6 +1281,9 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
                 const gptr4 Ap = (gptr4)G.LsP + lane;
                 const gout1 arow = (o_a && tcol < nvalid) ? o_a + (size_t)(t0 + tcol) * G.Mp : (gout1)nullptr;
                 float ssq = 0.f;
+                if constexpr (LEAN) {
+                    ssq = stage1_unrolled<NS, 8, true, S16>(reinterpret_cast<const f32x4*>(sm + G.ls_off) + lane, kuf, at, tcol, gq, arow, st1_sb);
+                } else
                 if (G.ls_off >= 0 && nbk <= 8) {
                     const f32x4* Al = reinterpret_cast<const f32x4*>(sm + G.ls_off) + lane;      // staged in LDS
                     switch (nbk) {
@@ -1828,8 +1834,8 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
     const FwElboHot Eh = opaque_block(static_cast<const FwElboHot&>(g.e));
     struct TailHot { float* out_logw; unsigned long long* rng; int Dy, yrows, cnt, nchunks; };
     const TailHot th = opaque_block(TailHot{g.out_logw, g.rng_state, g.Dy, g.lds.yrows, g.lds.cnt, g.nchunks});
-    const bool local_lse = Eh.enabled && Eh.ws && !Eh.mode_vi && Eh.stride_k == 1 && Eh.stride_b == Eh.K &&
-                           (NSAMP % Eh.K) == 0;
+    const bool local_lse = LEAN || (Eh.enabled && Eh.ws && !Eh.mode_vi && Eh.stride_k == 1 && Eh.stride_b == Eh.K &&
+                                    (NSAMP % Eh.K) == 0);
     if (th.out_logw && tid < nvalid) {
         const int Dy = th.Dy;
         const float likv = sm[th.cnt + 8];                         // (prologue)
@@ -1867,11 +1873,11 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
         double part = 0.0;
         if (tid == 0) {
             for (int p = 0; p < npl; ++p) part += (double)xt[p];                       // fixed order
-            if (!E.fast) __hip_atomic_store(E.ws + chunk_id, part, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (!LEAN && !E.fast) __hip_atomic_store(E.ws + chunk_id, part, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        if (E.fast) { fw_arrive_fast<NS>(gk, Eh, th.rng, th.nchunks, tid, chunk_id, part, step); return; }   // (uniform)
+        if (LEAN || E.fast) { fw_arrive_fast<NS>(gk, Eh, th.rng, th.nchunks, tid, chunk_id, part, step); return; }   // (uniform)
     }
-    fw_arrive<NS>(gk, sm, tid, chunk_id);
+    if constexpr (!LEAN) fw_arrive<NS>(gk, sm, tid, chunk_id);
 }
 
 // the packed arrival (fw_arrive_fast) applies when every point's K samples sit in one chunk (the kernel's local_lse), the launch finishes the
@@ -1883,15 +1889,15 @@ static void fw_decide_fast(FwArgs& a, unsigned grid, int nsamp, int64_t T) {
                   a.h.rng_state && grid <= 511u && 2 * (int64_t)a.h.nchunks <= ws_len && E.kl_total <= 64 && !dbg_opt("IWVI_FW_SLOW_TAIL")) ? 1 : 0;
 }
 
-template <int NS, bool S16, bool BIG>
+template <int NS, bool S16, bool BIG, bool LEAN = false>
 static int launch_forward(const FwArgs& a, unsigned grid, size_t lds_bytes, hipStream_t stream) {
     static size_t attr_set = 0;
     if (lds_bytes > attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_dgp_forward<NS, S16, BIG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        hipError_t e = hipFuncSetAttribute((const void*)k_dgp_forward<NS, S16, BIG, LEAN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) { set_error("hipFuncSetAttribute(k_dgp_forward, %zu B): %s", lds_bytes, hipGetErrorString(e)); return IWVI_ERR_LAUNCH; }
         attr_set = lds_bytes;
     }
-    hipLaunchKernelGGL((k_dgp_forward<NS, S16, BIG>), dim3(grid), dim3(FW_THREADS), lds_bytes, stream, a);
+    hipLaunchKernelGGL((k_dgp_forward<NS, S16, BIG, LEAN>), dim3(grid), dim3(FW_THREADS), lds_bytes, stream, a);
     return check_launch("k_dgp_forward");
 }
 
@@ -2293,6 +2299,19 @@ int dgp_forward_impl(const iwvi_layer_desc* layers, int n_layers, const float* X
                                       : launch_forward<NS_, true, false>(a, (unsigned)chunks, lds_bytes, stream))     \
                                 : (big ? launch_forward<NS_, false, true>(a, (unsigned)chunks, lds_bytes, stream)     \
                                       : launch_forward<NS_, false, false>(a, (unsigned)chunks, lds_bytes, stream)))
+    {   // the bound's own evaluation at the headline chunk size (k_dgp_forward: LEAN)
+        bool lean = ns == 5 && s16_all && !big && a.h.e.fast && !a.h.noise_any_src && a.h.out_logw && !a.h.lw_init && !a.h.x_per_sample && !g_dbg_exit && T % (16 * 5) == 0;
+        for (int i = 0; i < n_layers && lean; ++i) {
+            const FwLayer& L = a.L[i];
+            if (a.H[i].flags & FWF_ANY_OUT) lean = false;
+            if (L.type == IWVI_LAYER_GP) {
+                const FwGp& G = L.gp;                              // the shape the variant is compiled for: M = 128 (8 blocks), D <= 10, operands staged in LDS
+                if (G.kern_type != IWVI_KERN_RBF || G.M != 128 || G.nbk != 8 || G.nsteps != 3 || G.ls_off < 0 || G.zt_off < 0) lean = false;
+            }
+            else if (!L.lv.enc_out) lean = false;
+        }
+        if (lean) return launch_forward<5, true, false, true>(a, (unsigned)chunks, lds_bytes, stream);
+    }
     switch (ns) {
 #ifndef IWVI_DEV_ONLY5   /* development builds: only the 80-sample variants (make DEV5=1) */
         case 1: return FW_LAUNCH(1);
