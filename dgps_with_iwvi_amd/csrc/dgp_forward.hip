@@ -353,9 +353,11 @@ __device__ __forceinline__ void xt_subtile(const float* xr, float* xo, const flo
 // column's packed blocks are loaded while this one computes.
 // Split-f16 form of the off-diagonal updates (H16: every layer with an even nbk <= 8): the packed block holds, per lane,
 // [h1 x 4 | h2 x 4] of 2^est (-L(bi,bj)) (csrc/precompute.hip: post()), the freshly solved a_bj is split the same way after scaling
-// by sb = 2^est, and r_bi += h1 h1' + h1 h2' + h2 h1' on v_mfma_f32_16x16x16_f16 -- three MFMAs of 16 clocks for four of 32.
+// by sb = 2^est, and r_bi += (h1 + h2)(h1' + h2')' on v_mfma_f32_16x16x32_f16 (see the loop) -- two MFMAs of 16 clocks for four of 32.
 // r therefore lives in units of U = 2^(2 est): the Gram tile is written times U and the stream's Dinv blocks are packed
-// times 1/U (both exact), so a itself, |a|^2 and everything behind stage 1 are as in the fp32 form.  The diagonal solves stay fp32.
+// times 1/U (both exact), so a itself, |a|^2 and everything behind stage 1 are as in the fp32 form.  The diagonal solves stay fp32
+// (measured, round 4: Dinv as f16 pairs against r / 2 -- two MFMAs of 16 clocks for four of 32 -- left the evaluation where it was,
+// 57.8 us: the two solve waves that share a SIMD then wait on each other's vector instructions instead).
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void split_b16(const f32x4 a, float sb, f16x4& b1, f16x4& b2) {
 #pragma unroll
@@ -393,12 +395,15 @@ __device__ __forceinline__ float stage1_unrolled(AP Ap, const f32x4* kuf, f32x4*
                 char* pl = reinterpret_cast<char*>(at) + ((size_t)((4 * bj + 2 * (gq >> 1)) * NSAMP + tcol)) * 16 + 8 * (gq & 1);
                 *reinterpret_cast<f16x4*>(pl) = b1; *reinterpret_cast<f16x4*>(pl + NSAMP * 16) = b2;
             }
+            // the lane's 16 bytes [h1 x 4 | h2 x 4] ARE an A operand of v_mfma_f32_16x16x32_f16 (k-slots 8 gq + e <-> h1, 8 gq + 4 + e <-> h2 of
+            // k = 4 gq + e): against B = [b1 | b1] one instruction gives h1 b1' + h2 b1', against [b2 | b2] the other two terms -- the whole
+            // product in two MFMAs of 16 clocks (the K = 16 form took three for three of the four terms)
+            using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
+            const f16x8 bb1 = __builtin_shufflevector(b1, b1, 0, 1, 2, 3, 4, 5, 6, 7), bb2 = __builtin_shufflevector(b2, b2, 0, 1, 2, 3, 4, 5, 6, 7);
 #pragma unroll
-            for (int bi = bj + 1; bi < NBK; ++bi) r[bi] = __builtin_amdgcn_mfma_f32_16x16x16f16(as_a16(A[bi - bj]).h1, b1, r[bi], 0, 0, 0);
+            for (int bi = bj + 1; bi < NBK; ++bi) r[bi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, A[bi - bj]), bb1, r[bi], 0, 0, 0);
 #pragma unroll
-            for (int bi = bj + 1; bi < NBK; ++bi) r[bi] = __builtin_amdgcn_mfma_f32_16x16x16f16(as_a16(A[bi - bj]).h2, b1, r[bi], 0, 0, 0);
-#pragma unroll
-            for (int bi = bj + 1; bi < NBK; ++bi) r[bi] = __builtin_amdgcn_mfma_f32_16x16x16f16(as_a16(A[bi - bj]).h1, b2, r[bi], 0, 0, 0);
+            for (int bi = bj + 1; bi < NBK; ++bi) r[bi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, A[bi - bj]), bb2, r[bi], 0, 0, 0);
         } else {
 #pragma unroll
         for (int s = 0; s < 4; ++s) {

@@ -20,11 +20,12 @@ lib.iwvi_debug_set_stamps.argtypes = [ctypes.c_void_p, ctypes.c_int64]
 NW = 32768
 buf = torch.zeros(NW * 128, dtype=torch.int64, device=dev)
 m.precompute(with_encoders=True)
+el = dict(B=B, K=K, stride_b=K, stride_k=1, mode_vi=False)   # the bound's own evaluation: the variant bench.py times
 for _ in range(3):
-    m._fused_forward(B * K, K, B, (B, K))
+    m._fused_forward(B * K, K, B, (B, K), elbo=el)
 torch.cuda.synchronize()
 lib.iwvi_debug_set_stamps(buf.data_ptr(), NW)
-m._fused_forward(B * K, K, B, (B, K))
+m._fused_forward(B * K, K, B, (B, K), elbo=el)
 torch.cuda.synchronize()
 lib.iwvi_debug_set_stamps(None, 0)
 full = buf.view(NW, 128).cpu().numpy()
