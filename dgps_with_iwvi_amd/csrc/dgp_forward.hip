@@ -254,6 +254,15 @@ __device__ __forceinline__ float colsumsq4(const f32x4& v) {
     s = fmaf(v[1], v[1], s); s = fmaf(v[2], v[2], s); s = fmaf(v[3], v[3], s);
     return s;
 }
+// the same over two blocks at once, as packed fp32 pairs (v_pk_mul_f32 / v_pk_fma_f32 on the accumulators' own register pairs)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float colsumsq8(const f32x4& a, const f32x4& b) {
+    const f32x2 a0 = __builtin_shufflevector(a, a, 0, 1), a1 = __builtin_shufflevector(a, a, 2, 3);
+    const f32x2 b0 = __builtin_shufflevector(b, b, 0, 1), b1 = __builtin_shufflevector(b, b, 2, 3);
+    f32x2 p = a0 * a0;
+    p = __builtin_elementwise_fma(a1, a1, p); p = __builtin_elementwise_fma(b0, b0, p); p = __builtin_elementwise_fma(b1, b1, p);
+    return p[0] + p[1];
+}
 __device__ __forceinline__ float xgroup_sum(float s) {
     s += __shfl_xor(s, 16);
     s += __shfl_xor(s, 32);
@@ -1425,14 +1434,29 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
                     f32x4 acc[NS];
 #pragma unroll
                     for (int t = 0; t < NS; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-                    for (int kc = 0; kc < (nbk >> 1); ++kc) {
-                        const f16x8 a1 = __builtin_bit_cast(f16x8, P[(size_t)kc * 128]), a2 = __builtin_bit_cast(f16x8, P[(size_t)kc * 128 + 64]);
+                    // the slabs of four chunks are requested together (one L2 round trip per group, not one per slab)
+                    for (int kc0 = 0; kc0 < (nbk >> 1); kc0 += 4) {
+                        f32x4 Q[4][2];
 #pragma unroll
-                        for (int t = 0; t < NS; ++t) {
-                            const f16x8 b1 = __builtin_bit_cast(f16x8, p1[kc * 8 * NSAMP + 16 * t]), b2 = __builtin_bit_cast(f16x8, p2[kc * 8 * NSAMP + 16 * t]);
-                            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b1, acc[t], 0, 0, 0);
-                            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b2, acc[t], 0, 0, 0);
-                            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2, b1, acc[t], 0, 0, 0);
+                        for (int u = 0; u < 4; ++u) {
+                            const size_t kq = (size_t)(kc0 + u < (nbk >> 1) ? kc0 + u : (nbk >> 1) - 1) * 128;
+                            Q[u][0] = P[kq]; Q[u][1] = P[kq + 64];
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const int kc = kc0 + u;
+                            if (kc < (nbk >> 1)) {
+                                const f16x8 a1 = __builtin_bit_cast(f16x8, Q[u][0]), a2 = __builtin_bit_cast(f16x8, Q[u][1]);
+                                f32x4 b1[NS], b2[NS];
+#pragma unroll
+                                for (int t = 0; t < NS; ++t) { b1[t] = p1[kc * 8 * NSAMP + 16 * t]; b2[t] = p2[kc * 8 * NSAMP + 16 * t]; }
+#pragma unroll
+                                for (int t = 0; t < NS; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, __builtin_bit_cast(f16x8, b1[t]), acc[t], 0, 0, 0);
+#pragma unroll
+                                for (int t = 0; t < NS; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, __builtin_bit_cast(f16x8, b2[t]), acc[t], 0, 0, 0);
+#pragma unroll
+                                for (int t = 0; t < NS; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2, __builtin_bit_cast(f16x8, b1[t]), acc[t], 0, 0, 0);
+                            }
                         }
                     }
                     const float fm = cst[IWVI_CST_FMEAN];
@@ -1455,6 +1479,7 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
                     for (int t = 0; t < NS; ++t) { acc0[t] = acc1[t] = f32x4{0.f, 0.f, 0.f, 0.f}; ssq[t] = 0.f; }
                     const int nkc = nbk >> 1;
                     int kc = bp, c = nkc - bp;
+                    bool fresh = true;
                     // B vectors serve both row-blocks: h1 of the NEXT step is requested while this step's last ten MFMAs (on h2) issue, h2 of
                     // this step at its top, under the twenty MFMAs on h1 -- half the LDS reads per MFMA of one row-block per job
                     f32x4 b1[NS], b2[NS];
@@ -1465,6 +1490,9 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
                         for (int u = 0; u < 3; ++u) {
                             const int q = q0 + u;
                             if (q < nstp) {
+#ifdef IWVI_S2_STEP_STAMPS
+                                if (g.stamps && lane == 0 && li == 1) g.stamps[(size_t)(1024 + blockIdx.x * 8 + wave) * 128 + q] = clock64();
+#endif
                                 const size_t nx = (size_t)(q + 2 < nstp ? q + 2 : nstp - 1) * 256;
 #pragma unroll
                                 for (int i = 0; i < 4; ++i) A[(u + 2) % 3][i] = P[nx + 64 * i];
@@ -1472,10 +1500,19 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
                                 const f16x8 a11 = __builtin_bit_cast(f16x8, A[u][2]), a21 = __builtin_bit_cast(f16x8, A[u][3]);
 #pragma unroll
                                 for (int t = 0; t < NS; ++t) b2[t] = p2[kc * 8 * NSAMP + 16 * t];
+                                if (fresh) {                       // first step of a job: accumulate onto the constant 0 (no registers to clear between jobs)
+                                    const f32x4 Z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                                    for (int t = 0; t < NS; ++t) acc0[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a10, __builtin_bit_cast(f16x8, b1[t]), Z, 0, 0, 0);
+#pragma unroll
+                                    for (int t = 0; t < NS; ++t) acc1[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a11, __builtin_bit_cast(f16x8, b1[t]), Z, 0, 0, 0);
+                                } else {
 #pragma unroll
                                 for (int t = 0; t < NS; ++t) acc0[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a10, __builtin_bit_cast(f16x8, b1[t]), acc0[t], 0, 0, 0);
 #pragma unroll
                                 for (int t = 0; t < NS; ++t) acc1[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a11, __builtin_bit_cast(f16x8, b1[t]), acc1[t], 0, 0, 0);
+                                }
+                                fresh = false;
 #pragma unroll
                                 for (int t = 0; t < NS; ++t) acc0[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a20, __builtin_bit_cast(f16x8, b1[t]), acc0[t], 0, 0, 0);
 #pragma unroll
@@ -1491,27 +1528,29 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
                                 for (int t = 0; t < NS; ++t) acc1[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a11, __builtin_bit_cast(f16x8, b2[t]), acc1[t], 0, 0, 0);
                                 ++kc;
                                 if (--c == 0) {
-                                    // row-blocks (r, 2p) and (r, 2p+1) complete: back to the scale of u, add their squares, start the next pair
+                                    // row-blocks (r, 2p) and (r, 2p+1) complete: add their squares, start the next pair.  The squares are summed at the
+                                    // scale of the operands and taken back to the scale of u once per r (fr is a power of two: the same bits as scaling
+                                    // every accumulator first -- 40 multiplies per job); only the saved u needs the accumulators themselves scaled
                                     const float fr = cst[IWVI_CST_FR + r];
-#pragma unroll
-                                    for (int t = 0; t < NS; ++t) { acc0[t] *= fr; acc1[t] *= fr; }
                                     if (o_u) {
 #pragma unroll
                                         for (int t = 0; t < NS; ++t) {
                                             const int j = 16 * t + jq;
                                             if (j < nvalid) {
                                                 gout1 ur = o_u + ((size_t)r * g.T + (t0 + j)) * G.Mp + 32 * bp + 4 * gq;
-                                                *((gout4)ur) = acc0[t]; *((gout4)(ur + 16)) = acc1[t];
+                                                *((gout4)ur) = acc0[t] * fr; *((gout4)(ur + 16)) = acc1[t] * fr;
                                             }
                                         }
                                     }
 #pragma unroll
-                                    for (int t = 0; t < NS; ++t) { ssq[t] += colsumsq4(acc0[t]) + colsumsq4(acc1[t]); acc0[t] = acc1[t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+                                    for (int t = 0; t < NS; ++t) ssq[t] += colsumsq8(acc0[t], acc1[t]);
+                                    fresh = true;
                                     ++bp;
                                     if (bp == nkc || q == nstp - 1) {
+                                        const float fr2 = fr * fr;
 #pragma unroll
                                         for (int t = 0; t < NS; ++t) {
-                                            const float sq = xgroup_sum_mfma(ssq[t]);
+                                            const float sq = xgroup_sum_mfma(ssq[t]) * fr2;
                                             if (gq == 0) usq[(wave * R + r) * NSAMP + 16 * t + jq] = sq;
                                             ssq[t] = 0.f;
                                         }
