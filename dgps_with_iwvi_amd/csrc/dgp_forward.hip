@@ -80,6 +80,9 @@ struct alignas(16) FwGp {             // copied LDS -> registers in 16-byte piec
     unsigned short nblk[FW_WAVES];
     signed char mean_wave[2];
     signed char s16;                  // stage 2 runs on the split-f16 images: nblk counts 2-KiB slabs, LrTP / QmuP point to them
+    // the same schedule as ONE 8-byte record per wave (one LDS read at the top of the layer instead of five and a loop over row-blocks):
+    // low word = offset of the run in LrTP, 16-byte units; high word = nblk | jr << 16 | jbi << 24 | (wave takes q_mu^T row-block 0 / 1) << 30 / 31
+    unsigned long long s2w[FW_WAVES];
 };
 struct FwLv {
     const float* W[IWVI_MAX_ENC]; const float* b[IWVI_MAX_ENC];
@@ -278,6 +281,11 @@ extern __shared__ __attribute__((aligned(16))) unsigned char fw_smem[];
         g.stamps[(size_t)blockIdx.x * 128 + (k)] = wall_clock64(); \
         g.stamps[(size_t)blockIdx.x * 128 + 64 + (k)] = clock64(); } } while (0)
 
+#ifdef IWVI_S2_STEP_STAMPS   /* development: per-wave clock stamps of layer 1 into the unused rows of the stamp buffer (scripts/s2_steps.py) */
+#define DBG_WSTAMP(slot) do { if (g.stamps && lane == 0 && li == 1) g.stamps[(size_t)(1024 + blockIdx.x * 8 + wave) * 128 + (slot)] = clock64(); } while (0)
+#else
+#define DBG_WSTAMP(slot) do { } while (0)
+#endif
 // wave-uniform copies of values that were read from the LDS copy of the layer table
 __device__ __forceinline__ int ufirst(int v) { return __builtin_amdgcn_readfirstlane(v); }
 template <class T>
@@ -1020,6 +1028,7 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
         } else {
             // ================= GPLayer (layers.py:35-50) ==============================================
             const int nbk = LEAN ? 8 : G.nbk, R = G.R, P = G.P, nsteps = LEAN ? 3 : G.nsteps;   // (LEAN: M = 128, D <= 10 -- see launch)
+            const unsigned long long s2_rec = L.gp.s2w[wave];    // stage 2's run of this wave (used behind the Gram: the read is long back by then)
             float g_variance = G.variance;
             if (g.var_dev_mask >> li & 1u) g_variance = sm[g.lds.cnt + 12 + li];          // (a device scalar: fetched in the prologue)
             f32x4* kuf = reinterpret_cast<f32x4*>(scratch);
@@ -1044,6 +1053,7 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
             // layer, the previous GP layer's stage 2 for the others)
             FW_STAMP(2 + li * 6 + 0);
             // ---- Gram: kuf block bi = kernel(Z_bi, x), written in B-operand order ---------------------------
+            DBG_WSTAMP(32);
             for (int bi = wave; bi < nbk; bi += FW_WAVES) {
                 f32x4 acc[NS];
 #pragma unroll
@@ -1112,15 +1122,15 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
                     }
                 }
             }
+            DBG_WSTAMP(33);
             // stage 2's first operands are requested here, in the shadow of the Gram phase's barrier (nothing in them
             // depends on the Gram or the solve), so that its MFMAs start right behind the barrier that ends stage 1
-            const int ntri = tri_blocks(nbk);
-            const int s2_nblocks = ufirst((int)L.gp.nblk[wave]);   // runs are dealt to waves by load, not in order
-            const int s2_mw0 = ufirst((int)L.gp.mean_wave[0]), s2_mw1 = ufirst((int)L.gp.mean_wave[1]);
-            const int s2_r0 = ufirst((int)L.gp.jr[wave]), s2_bi0 = ufirst((int)L.gp.jbi[wave]);
+            // (this wave's run: the record read at the top of the layer -- runs are dealt to waves by load, not in order)
+            const unsigned s2_lo = (unsigned)ufirst((int)(unsigned)s2_rec), s2_hi = (unsigned)ufirst((int)(unsigned)(s2_rec >> 32));
+            const int s2_nblocks = (int)(s2_hi & 0xffffu), s2_r0 = (int)(s2_hi >> 16 & 0xffu), s2_bi0 = (int)(s2_hi >> 24 & 63u);
+            const int s2_mw0 = (s2_hi >> 30 & 1u) ? wave : -1, s2_mw1 = (s2_hi >> 31) ? wave : -1;
             constexpr bool s16 = S16;
-            gptr4 s2_P = s16 ? (gptr4)G.LrTP + ((size_t)s2_r0 * s16_slabs_total(nbk) + s16_slab_off(nbk, s2_bi0)) * 128 + lane
-                             : (gptr4)G.LrTP + ((size_t)s2_r0 * ntri + tri_upper_off(nbk, s2_bi0)) * 64 + lane;
+            gptr4 s2_P = (gptr4)G.LrTP + (size_t)s2_lo + lane;
             // the NEXT GP layer's forward-substitution stream is fetched into registers now and parked in the staging
             // buffer once this layer's solve is over (the buffer is busy until then; an LDS-DMA left pending across
             // stage 2 would make every LDS read there wait for all outstanding loads)
@@ -1138,6 +1148,10 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
             ring[0] = ring[1] = ring[2] = ring[3] = f32x4{0.f, 0.f, 0.f, 0.f};
             f32x4 ring2e[2];                                      // split-f16: second plane of the two slabs requested ahead of stage 1
             ring2e[0] = ring2e[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+            f32x4 Qpre[4][2];                                     // split-f16, M <= 128: the q_mu^T slabs, requested during stage 1 by a wave that is idle there
+            bool q_pre = false;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) Qpre[u][0] = Qpre[u][1] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (s2_nblocks > 0 && s16) {
                 const size_t o1 = (size_t)(1 < s2_nblocks ? 1 : s2_nblocks - 1) * 128;
                 ring[0] = s2_P[0]; ring2e[0] = s2_P[64]; ring[1] = s2_P[o1]; ring2e[1] = s2_P[o1 + 64];
@@ -1147,7 +1161,9 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
                 ring[1] = s2_P[(size_t)(1 < s2_nblocks ? 1 : s2_nblocks - 1) * 64];
                 ring[2] = s2_P[(size_t)(2 < s2_nblocks ? 2 : s2_nblocks - 1) * 64];
             }
+            DBG_WSTAMP(34);
             __syncthreads();                                      // (the staged solve stream was complete before this layer began)
+            DBG_WSTAMP(35);
             FW_STAMP(2 + li * 6 + 1);
 
             // ---- stage 1: a = Lm^-1 k, right-looking blocked forward substitution, one wave per sub-tile ------
@@ -1289,6 +1305,19 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
                 // the waves without a sub-tile of their own clear every |u|^2 slot first (stage 2 fills only some)
                 f32x4* uz = reinterpret_cast<f32x4*>(usq);
                 for (int i = (wave - NS) * 64 + lane; i < (FW_WAVES * R * NSAMP) / 4; i += (FW_WAVES - NS) * 64) uz[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+                // ... and the one that multiplies by q_mu^T in stage 2 (plan_stage2 puts it here when it can) requests those slabs now: their first
+                // read of an evaluation comes from HBM (written by the precompute launch), 5000 clocks of that wave when requested in stage 2
+                if constexpr (S16) {
+                    if (s2_mw0 == wave && nbk <= 8) {
+                        gptr4 Pq = (gptr4)G.QmuP + lane;
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const size_t kq = (size_t)(u < (nbk >> 1) ? u : (nbk >> 1) - 1) * 128;
+                            Qpre[u][0] = Pq[kq]; Qpre[u][1] = Pq[kq + 64];
+                        }
+                        q_pre = true;
+                    }
+                }
             }
             if (wave < NS) {
                 const int tcol = 16 * wave + jq;                  // this lane's sample column
@@ -1428,6 +1457,7 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
                 const f32x4* p1 = at + (size_t)(2 * gq) * NSAMP + jq;   // h1 vector of chunk kc, sub-tile t: p1[kc * 8 * NSAMP + 16 t]; h2: the next row
                 const f32x4* p2 = p1 + NSAMP;
                 // (a) q_mu^T row-blocks assigned to this wave
+                DBG_WSTAMP(36);
                 for (int rb = 0; rb < G.nrb; ++rb) {
                     if ((rb == 0 ? s2_mw0 : s2_mw1) != wave) continue;
                     gptr4 P = (gptr4)G.QmuP + (size_t)rb * (nbk >> 1) * 128 + lane;
@@ -1437,10 +1467,15 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
                     // the slabs of four chunks are requested together (one L2 round trip per group, not one per slab)
                     for (int kc0 = 0; kc0 < (nbk >> 1); kc0 += 4) {
                         f32x4 Q[4][2];
+                        if (q_pre && rb == 0) {                   // (on their way since stage 1; kc0 = 0 is the only group then)
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) { Q[u][0] = Qpre[u][0]; Q[u][1] = Qpre[u][1]; }
+                        } else {
 #pragma unroll
                         for (int u = 0; u < 4; ++u) {
                             const size_t kq = (size_t)(kc0 + u < (nbk >> 1) ? kc0 + u : (nbk >> 1) - 1) * 128;
                             Q[u][0] = P[kq]; Q[u][1] = P[kq + 64];
+                        }
                         }
 #pragma unroll
                         for (int u = 0; u < 4; ++u) {
@@ -1470,6 +1505,7 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
                     }
                 }
                 // (b) this wave's contiguous run of (r, p) jobs -- row-blocks 2p and 2p+1 of L_r^T, nbk/2 - p steps -- as one linear stream
+                DBG_WSTAMP(37);
                 if (nstp > 0) {
                     int r = s2_r0, bp = s2_bi0 >> 1;
                     gptr4 P = s2_P;
@@ -1548,11 +1584,12 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
                                     ++bp;
                                     if (bp == nkc || q == nstp - 1) {
                                         const float fr2 = fr * fr;
+                                        float sq[NS];              // (the sums first, then one predicated block of stores: the MFMAs issue back to back)
 #pragma unroll
-                                        for (int t = 0; t < NS; ++t) {
-                                            const float sq = xgroup_sum_mfma(ssq[t]) * fr2;
-                                            if (gq == 0) usq[(wave * R + r) * NSAMP + 16 * t + jq] = sq;
-                                            ssq[t] = 0.f;
+                                        for (int t = 0; t < NS; ++t) { sq[t] = xgroup_sum_mfma(ssq[t]) * fr2; ssq[t] = 0.f; }
+                                        if (gq == 0) {
+#pragma unroll
+                                            for (int t = 0; t < NS; ++t) usq[(wave * R + r) * NSAMP + 16 * t + jq] = sq[t];
                                         }
                                         if (bp == nkc) { bp = 0; ++r; }
                                     }
@@ -2006,10 +2043,29 @@ static void plan_stage2(FwGp& G) {
         std::sort(ord2, ord2 + W, [&](int x, int y) { return seg[x] != seg[y] ? seg[x] < seg[y] : x < y; });
         for (int i = 0; i < nm; ++i) G.mean_wave[i] = (signed char)run_wave[ord2[i]];
     }
+    // the first q_mu^T row-block on a wave above W/2: at the headline chunk (5 sub-tiles) those waves carry no solve in stage 1 and request
+    // its slabs there.  Exchanging the SIMD pairs (0, W/2) and (1, W/2 + 1) changes no pair's load.
+    if (G.mean_wave[0] == W / 2) {
+        for (int k = 0; k < W; ++k) {
+            const int w = run_wave[k];
+            run_wave[k] = w == 0 ? 1 : w == 1 ? 0 : w == W / 2 ? W / 2 + 1 : w == W / 2 + 1 ? W / 2 : w;
+        }
+        for (int i = 0; i < nm; ++i) {
+            const int w = G.mean_wave[i];
+            G.mean_wave[i] = (signed char)(w == 0 ? 1 : w == 1 ? 0 : w == W / 2 ? W / 2 + 1 : w == W / 2 + 1 ? W / 2 : w);
+        }
+    }
     for (int k = 0; k < W; ++k) {
         G.jr[run_wave[k]] = (unsigned char)(b[k] / npr);
         G.jbi[run_wave[k]] = (unsigned char)(G.s16 ? 2 * (b[k] % npr) : b[k] % npr);
         G.nblk[run_wave[k]] = (unsigned short)(pref[b[k + 1]] - pref[b[k]]);
+    }
+    for (int w = 0; w < W; ++w) {
+        const unsigned long long off = G.s16 ? ((unsigned long long)G.jr[w] * s16_slabs_total(nbk) + s16_slab_off(nbk, G.jbi[w])) * 128
+                                             : ((unsigned long long)G.jr[w] * tri_blocks(nbk) + tri_upper_off(nbk, G.jbi[w])) * 64;
+        const unsigned hi = (unsigned)G.nblk[w] | (unsigned)G.jr[w] << 16 | (unsigned)(G.jbi[w] & 63) << 24
+                          | (G.mean_wave[0] == w ? 1u << 30 : 0u) | (G.mean_wave[1] == w ? 1u << 31 : 0u);
+        G.s2w[w] = (unsigned long long)hi << 32 | (off & 0xffffffffull);
     }
 }
 

@@ -30,5 +30,5 @@ for wg in (0, 100, 200):
     print("WG", wg, "wave start", (full[wg, 100:108] - base), "end", (full[wg, 110:118] - base))
     for w in range(8):
         row = full[1024 + wg * 8 + w]
-        st = row[row > 0] - base
-        print("  wave", w, "steps at", st.tolist(), "deltas", np.diff(st).tolist())
+        st = row[:32][row[:32] > 0] - base
+        print("  wave", w, "steps at", st.tolist(), "deltas", np.diff(st).tolist(), "| gram start/end, prefetch issued, barrier passed:", (row[32:36] - row[32]).tolist(), "| mean job", int(row[37] - row[36]))
