@@ -1728,6 +1728,7 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
             FW_STAMP(2 + li * 6 + 3);
 
             // ---- epilogue (i): per (sample, latent GP): variance, sample (temp_workaround.py:59,85,89-91) ----
+            DBG_WSTAMP(40);
             for (int idx = tid; idx < NSAMP * R; idx += FW_THREADS) {
                 const int r = idx / NSAMP, j = idx - r * NSAMP;
                 float u2 = 0.f;
@@ -1746,15 +1747,18 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
                     o[r] = gs; o[R + r] = mu; o[2 * R + r] = v;
                 }
             }
+            DBG_WSTAMP(41);
             __syncthreads();
+            DBG_WSTAMP(42);
             FW_STAMP(2 + li * 6 + 4);
             // ---- epilogue (ii): mixing (:142-145) + linear mean function (layers.py:46-48); ahead of another GP layer
             //      as ONE small MFMA product out[p][j] = sum_k A[p][k] B[k][j],  A = [W | mfA^T],  B = [f_r(j) ; x_d(j)]:
             //      wave t owns sample sub-tile t; the result lands as 4 outputs p = 4gq .. 4gq+3 of sample 16t + jq
             //      per lane, from which the next GP layer's x~ row is formed on the spot.
             const bool last = (li == g.n_layers - 1);
-            const bool need_mv = last || o_mean || o_var;         // inner layers only hand their sample on
+            const bool need_mv_any = last || o_mean || o_var;     // inner layers only hand their sample on
             if (!nx_gp) {
+                const bool need_mv = need_mv_any;
                 // nothing downstream needs an x~ row (last layer, or an LV layer next): a handful of outputs per
                 // sample, one thread per (output, sample), dot products straight from LDS
                 for (int idx = tid; idx < NSAMP * P; idx += FW_THREADS) {
@@ -1801,7 +1805,10 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
                 const int j = j_;
                 const long long t = t0 + j;
                 const int Dm = (G.mf_type == IWVI_MF_LINEAR) ? D : 0;
-                const int npb = (P + 15) >> 4;                    // 16-row blocks of outputs: 1 or 2
+                // (LEAN: the next layer's D = P <= 10 and nothing but the sample is handed on -- compile-time, or every step below is a handful of
+                //  wave-uniform branches)
+                const int npb = LEAN ? 1 : (P + 15) >> 4;         // 16-row blocks of outputs: 1 or 2
+                const bool need_mv = LEAN ? false : need_mv_any;
                 const bool hasW = (G.flags & FWF_HASW) != 0;
                 const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
                 f32x4 acc_s[2] = {zero4, zero4}, acc_m[2] = {zero4, zero4}, acc_v[2] = {zero4, zero4};
@@ -1811,42 +1818,68 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
                 // the A entry of a padded k or p is zero)
                 const int p_lo = jq, p_hi = 16 + jq;              // A operand rows of the two output blocks (lane i = jq)
                 const int pc_lo = p_lo < P ? p_lo : P - 1, pc_hi = p_hi < P ? p_hi : P - 1;
-                for (int k0 = 0; k0 < R; k0 += 4) {
-                    const int k = k0 + gq, kc = k < R ? k : R - 1;
-                    const float bs = gs[kc * NSAMP + j];
-                    float a_lo = hasW ? Wm[pc_lo * R + kc] : (pc_lo == kc ? 1.f : 0.f);
-                    a_lo = (k < R && p_lo < P) ? a_lo : 0.f;
-                    acc_s[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_lo, bs, acc_s[0], 0, 0, 0);
-                    float a_hi = 0.f;
-                    if (npb > 1) {
-                        a_hi = hasW ? Wm[pc_hi * R + kc] : (pc_hi == kc ? 1.f : 0.f);
-                        a_hi = (k < R && p_hi < P) ? a_hi : 0.f;
-                        acc_s[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_hi, bs, acc_s[1], 0, 0, 0);
-                    }
-                    if (need_mv) {
-                        const float bm = gm[kc * NSAMP + j], bv = gv[kc * NSAMP + j];
-                        acc_m[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_lo, bm, acc_m[0], 0, 0, 0);
-                        acc_v[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_lo * a_lo, bv, acc_v[0], 0, 0, 0);
+                // (K steps in groups of four, a group's operands requested together: one LDS round trip per group instead of one per step --
+                //  the steps accumulate in the same order)
+                for (int k0 = 0; k0 < R; k0 += 16) {
+                    float bs[4], al[4], ah[4], bm[4], bv[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int k = k0 + 4 * u + gq, kc = k < R ? k : R - 1;
+                        bs[u] = gs[kc * NSAMP + j];
+                        float wv = Wm[pc_lo * R + kc];                // (unconditional -- the block is reserved with or without a mixing matrix -- and
+                        asm volatile("" : "+v"(wv));                  //  kept so: moved under `hasW` it is a branch and an LDS wait per step)
+                        const float a = hasW ? wv : (pc_lo == kc ? 1.f : 0.f);
+                        al[u] = (k < R && p_lo < P) ? a : 0.f;
+                        ah[u] = 0.f;
                         if (npb > 1) {
-                            acc_m[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_hi, bm, acc_m[1], 0, 0, 0);
-                            acc_v[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_hi * a_hi, bv, acc_v[1], 0, 0, 0);
+                            const float a2 = hasW ? Wm[pc_hi * R + kc] : (pc_hi == kc ? 1.f : 0.f);
+                            ah[u] = (k < R && p_hi < P) ? a2 : 0.f;
+                        }
+                        bm[u] = bv[u] = 0.f;
+                        if (need_mv) { bm[u] = gm[kc * NSAMP + j]; bv[u] = gv[kc * NSAMP + j]; }
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        {                                             // (a step beyond R has an A of zeros: no guard, no branch)
+                            acc_s[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(al[u], bs[u], acc_s[0], 0, 0, 0);
+                            if (npb > 1) acc_s[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ah[u], bs[u], acc_s[1], 0, 0, 0);
+                            if (need_mv) {
+                                acc_m[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(al[u], bm[u], acc_m[0], 0, 0, 0);
+                                acc_v[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(al[u] * al[u], bv[u], acc_v[0], 0, 0, 0);
+                                if (npb > 1) {
+                                    acc_m[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ah[u], bm[u], acc_m[1], 0, 0, 0);
+                                    acc_v[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ah[u] * ah[u], bv[u], acc_v[1], 0, 0, 0);
+                                }
+                            }
                         }
                     }
                 }
-                for (int d0 = 0; d0 < Dm; d0 += 4) {             // linear mean function rows: sample and mean alike
-                    const int d = d0 + gq, dc = d < Dm ? d : Dm - 1;
-                    const float bx = xin[j * XSTR + dc];
-                    float a_lo = mfA[dc * P + pc_lo];
-                    a_lo = (d < Dm && p_lo < P) ? a_lo : 0.f;
-                    acc_s[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_lo, bx, acc_s[0], 0, 0, 0);
-                    if (need_mv) acc_m[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_lo, bx, acc_m[0], 0, 0, 0);
-                    if (npb > 1) {
-                        float a_hi = mfA[dc * P + pc_hi];
-                        a_hi = (d < Dm && p_hi < P) ? a_hi : 0.f;
-                        acc_s[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_hi, bx, acc_s[1], 0, 0, 0);
-                        if (need_mv) acc_m[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_hi, bx, acc_m[1], 0, 0, 0);
+                DBG_WSTAMP(43);
+                for (int d0 = 0; d0 < Dm; d0 += 16) {            // linear mean function rows: sample and mean alike
+                    float bx[4], al[4], ah[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int d = d0 + 4 * u + gq, dc = d < Dm ? d : Dm - 1;
+                        bx[u] = xin[j * XSTR + dc];
+                        float a = mfA[dc * P + pc_lo];
+                        asm volatile("" : "+v"(a));
+                        al[u] = (d < Dm && p_lo < P) ? a : 0.f;
+                        ah[u] = 0.f;
+                        if (npb > 1) { const float a2 = mfA[dc * P + pc_hi]; ah[u] = (d < Dm && p_hi < P) ? a2 : 0.f; }
+                    }
+#pragma unroll
+                    for (int u = 0; u < (LEAN ? 3 : 4); ++u) {        // (LEAN: D <= 10)
+                        {
+                            acc_s[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(al[u], bx[u], acc_s[0], 0, 0, 0);
+                            if (need_mv) acc_m[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(al[u], bx[u], acc_m[0], 0, 0, 0);
+                            if (npb > 1) {
+                                acc_s[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ah[u], bx[u], acc_s[1], 0, 0, 0);
+                                if (need_mv) acc_m[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ah[u], bx[u], acc_m[1], 0, 0, 0);
+                            }
+                        }
                     }
                 }
+                DBG_WSTAMP(44);
                 // what the product does not already carry: identity mean function, or the linear one's bias
                 const bool mf_id = G.mf_type == IWVI_MF_IDENTITY, mf_b = G.mf_type == IWVI_MF_LINEAR && (G.flags & FWF_HAS_MFB);
                 const float* mfp = mf_id ? xin + j * XSTR : (mf_b ? mfb : cst);
@@ -1873,7 +1906,7 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
                                 if (p0 + e < P) { xt[j * XSTR + p0 + e] = v; n2 = fmaf(v, v, n2); }
                             }
                         }
-                        if (last) {
+                        if (!LEAN && last) {                       // (not reached for the last layer -- nothing follows it --: kept for o_mean / o_var)
 #pragma unroll
                             for (int e = 0; e < 4; ++e)
                                 if (p0 + e < P) { obuf[(p0 + e) * NSAMP + j] = acc_m[pb][e] + mfv[e]; obuf[(P + p0 + e) * NSAMP + j] = acc_v[pb][e]; }
@@ -1890,6 +1923,7 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
                         }
                     }
                 }
+                DBG_WSTAMP(45);
                 if (nx_gp) {
                     n2 = xgroup_sum_mfma(n2);
                     if (gq == 0) {
@@ -1900,7 +1934,9 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
                 }
             }
             if (nx_gp) xt_for = li + 1;
+            DBG_WSTAMP(46);
             __syncthreads();
+            DBG_WSTAMP(47);
             FW_STAMP(2 + li * 6 + 5);
         }
         float* tmp = xin; xin = xout; xout = tmp;

@@ -31,4 +31,4 @@ for wg in (0, 100, 200):
     for w in range(8):
         row = full[1024 + wg * 8 + w]
         st = row[:32][row[:32] > 0] - base
-        print("  wave", w, "steps at", st.tolist(), "deltas", np.diff(st).tolist(), "| gram start/end, prefetch issued, barrier passed:", (row[32:36] - row[32]).tolist(), "| mean job", int(row[37] - row[36]))
+        print("  wave", w, "steps at", st.tolist(), "deltas", np.diff(st).tolist(), "| gram start/end, prefetch issued, barrier passed:", (row[32:36] - row[32]).tolist(), "| mean job", int(row[37] - row[36]), "| epi: i start, i end, barrier, k loop, d loop, outputs, end, barrier", (row[40:48] - row[40]).tolist())
