@@ -266,6 +266,26 @@ __device__ __forceinline__ float colsumsq8(const f32x4& a, const f32x4& b) {
     p = __builtin_elementwise_fma(a1, a1, p); p = __builtin_elementwise_fma(b0, b0, p); p = __builtin_elementwise_fma(b1, b1, p);
     return p[0] + p[1];
 }
+// max / sum over the 32 lanes of a half-wave, every lane gets the result: four DPP steps inside each row of 16 (quad swaps, half-row mirror,
+// row mirror), then one swizzle that exchanges the two rows (lane ^ 16 within 32)
+__device__ __forceinline__ float dpp_f(float v, int ctrl_sel) {
+    int x = __float_as_int(v), r;
+    switch (ctrl_sel) {
+        case 0: r = __builtin_amdgcn_update_dpp(x, x, 0xB1, 0xF, 0xF, false); break;    // quad_perm [1,0,3,2]
+        case 1: r = __builtin_amdgcn_update_dpp(x, x, 0x4E, 0xF, 0xF, false); break;    // quad_perm [2,3,0,1]
+        case 2: r = __builtin_amdgcn_update_dpp(x, x, 0x141, 0xF, 0xF, false); break;   // row_half_mirror
+        default: r = __builtin_amdgcn_update_dpp(x, x, 0x140, 0xF, 0xF, false); break;  // row_mirror
+    }
+    return __int_as_float(r);
+}
+__device__ __forceinline__ float halfwave_all_max(float v) {
+    v = fmaxf(v, dpp_f(v, 0)); v = fmaxf(v, dpp_f(v, 1)); v = fmaxf(v, dpp_f(v, 2)); v = fmaxf(v, dpp_f(v, 3));
+    return fmaxf(v, __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), 0x401F)));
+}
+__device__ __forceinline__ float halfwave_all_sum(float v) {
+    v += dpp_f(v, 0); v += dpp_f(v, 1); v += dpp_f(v, 2); v += dpp_f(v, 3);
+    return v + __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), 0x401F));
+}
 __device__ __forceinline__ float xgroup_sum(float s) {
     s += __shfl_xor(s, 16);
     s += __shfl_xor(s, 32);
@@ -1953,6 +1973,56 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
     const TailHot th = opaque_block(TailHot{g.out_logw, g.rng_state, g.Dy, g.lds.yrows, g.lds.cnt, g.nchunks});
     const bool local_lse = LEAN || (Eh.enabled && Eh.ws && !Eh.mode_vi && Eh.stride_k == 1 && Eh.stride_b == Eh.K &&
                                     (NSAMP % Eh.K) == 0);
+    if constexpr (LEAN) {
+        // LEAN (5 <= K <= 32, K | 80): one half-wave per data point -- lane e < K of half-wave p holds sample p K + e, its log-weight goes
+        // straight into the point's logsumexp by cross-lane steps (DPP within 16 lanes, one swizzle across): no LDS round trip per term, one
+        // barrier instead of two.  (Before: 80 threads wrote log-weights to LDS, a barrier, ONE thread per point read its K terms twice:
+        // 2.4 us of every workgroup in front of its arrival.)  The sum over k is a tree here: fixed order, not the serial one.
+        const FwElboHot& E = Eh;
+        const int K = E.K, npl = NSAMP / K;
+        const int p = tid >> 5, e = tid & 31;
+        if (p < npl) {                                             // (whole waves: two points per wave)
+            const bool act = e < K;
+            const int j = p * K + (act ? e : 0);
+            const int Dy = th.Dy;
+            const float likv = sm[th.cnt + 8];                     // (prologue)
+            const float c0 = -0.5f * 1.8378770664093453f - 0.5f * logf(likv);
+            const float inv2s = 0.5f / likv;
+            const float* yrows = sm + th.yrows;
+            float acc = 0.f;
+            for (int d = 0; d < Dy; ++d) {
+                const float df = yrows[d * NSAMP + j] - obuf[d * NSAMP + j];
+                acc += c0 - (df * df + obuf[(Dy + d) * NSAMP + j]) * inv2s;
+            }
+            const float lwv = acc - lw[j];
+            if (act) __hip_atomic_store(th.out_logw + t0 + j, lwv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            FW_STAMP(61);
+            const float m = halfwave_all_max(act ? lwv : -INFINITY);
+            const float ssum = halfwave_all_sum(act ? __expf(lwv - m) : 0.f);
+            if (e == 0) {
+                const float lp = m + logf(ssum) - logf((float)E.K_total);                  // models.py:148
+                const long long b = t0 / K + p;
+                if (E.ms) { E.ms[2 * b] = m; E.ms[2 * b + 1] = ssum; }
+                if (E.logp) E.logp[b] = lp;
+                xt[p] = lp;
+            }
+        }
+        __syncthreads();
+        double part = 0.0;
+        if (tid == 0) {
+            for (int p0 = 0; p0 < npl; p0 += 8) {                                      // fixed order; eight terms requested together
+                float v[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] = xt[p0 + q < npl ? p0 + q : npl - 1];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) part += (p0 + q < npl) ? (double)v[q] : 0.0;
+            }
+        }
+        FW_STAMP(62);
+        fw_arrive_fast<NS>(gk, Eh, th.rng, th.nchunks, tid, chunk_id, part, step);
+        FW_STAMP(63);
+        return;
+    }
     if (th.out_logw && tid < nvalid) {
         const int Dy = th.Dy;
         const float likv = sm[th.cnt + 8];                         // (prologue)
@@ -1969,17 +2039,29 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
         __hip_atomic_store(th.out_logw + t0 + tid, lwv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         lw[tid] = lwv;
     }
-    FW_STAMP(63);
+    FW_STAMP(61);
     if (local_lse) {
         const FwElboHot& E = Eh;
         const int K = E.K, npl = nvalid / K;                      // complete points of this chunk
         __syncthreads();
         float lp = 0.f;
         if (tid < npl) {
-            float m = -INFINITY;
-            for (int k = 0; k < K; ++k) m = fmaxf(m, lw[tid * K + k]);
-            float ssum = 0.f;
-            for (int k = 0; k < K; ++k) ssum += __expf(lw[tid * K + k] - m);
+            // (32 log-weights at a time, requested together with clamped indices: a loop of run-time length pays one LDS round trip per
+            //  term, twice -- 2 us of every workgroup at K = 20, in front of its arrival.  Same order of the sums.)
+            float m = -INFINITY, ssum = 0.f;
+            const float* lwp = lw + tid * K;
+            if (K <= 32) {
+                float v[32];
+#pragma unroll
+                for (int e = 0; e < 32; ++e) v[e] = lwp[e < K ? e : K - 1];
+#pragma unroll
+                for (int e = 0; e < 32; ++e) m = fmaxf(m, v[e]);                       // (the clamped repeats change no maximum)
+#pragma unroll
+                for (int e = 0; e < 32; ++e) { const float t = __expf(v[e] - m); ssum += (e < K) ? t : 0.f; }
+            } else {
+                for (int k = 0; k < K; ++k) m = fmaxf(m, lwp[k]);
+                for (int k = 0; k < K; ++k) ssum += __expf(lwp[k] - m);
+            }
             lp = m + logf(ssum) - logf((float)E.K_total);                              // models.py:148
             const long long b = t0 / K + tid;
             if (E.ms) { E.ms[2 * b] = m; E.ms[2 * b + 1] = ssum; }
@@ -1989,12 +2071,19 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
         __syncthreads();
         double part = 0.0;
         if (tid == 0) {
-            for (int p = 0; p < npl; ++p) part += (double)xt[p];                       // fixed order
+            for (int p0 = 0; p0 < npl; p0 += 8) {                                      // fixed order; eight terms requested together
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = xt[p0 + e < npl ? p0 + e : npl - 1];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) part += (p0 + e < npl) ? (double)v[e] : 0.0;
+            }
             if (!LEAN && !E.fast) __hip_atomic_store(E.ws + chunk_id, part, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        if (LEAN || E.fast) { fw_arrive_fast<NS>(gk, Eh, th.rng, th.nchunks, tid, chunk_id, part, step); return; }   // (uniform)
+        FW_STAMP(62);
+        if (LEAN || E.fast) { fw_arrive_fast<NS>(gk, Eh, th.rng, th.nchunks, tid, chunk_id, part, step); FW_STAMP(63); return; }   // (uniform)
     }
-    if constexpr (!LEAN) fw_arrive<NS>(gk, sm, tid, chunk_id);
+    if constexpr (!LEAN) { fw_arrive<NS>(gk, sm, tid, chunk_id); FW_STAMP(63); }
 }
 
 // the packed arrival (fw_arrive_fast) applies when every point's K samples sit in one chunk (the kernel's local_lse), the launch finishes the
@@ -2436,7 +2525,8 @@ int dgp_forward_impl(const iwvi_layer_desc* layers, int n_layers, const float* X
                                 : (big ? launch_forward<NS_, false, true>(a, (unsigned)chunks, lds_bytes, stream)     \
                                       : launch_forward<NS_, false, false>(a, (unsigned)chunks, lds_bytes, stream)))
     {   // the bound's own evaluation at the headline chunk size (k_dgp_forward: LEAN)
-        bool lean = ns == 5 && s16_all && !big && a.h.e.fast && !a.h.noise_any_src && a.h.out_logw && !a.h.lw_init && !a.h.x_per_sample && !g_dbg_exit && T % (16 * 5) == 0;
+        bool lean = ns == 5 && s16_all && !big && a.h.e.fast && !a.h.noise_any_src && a.h.out_logw && !a.h.lw_init && !a.h.x_per_sample && !g_dbg_exit && T % (16 * 5) == 0 &&
+                    a.h.e.K >= 5 && a.h.e.K <= 32;       // (its tail: one half-wave per data point)
         for (int i = 0; i < n_layers && lean; ++i) {
             const FwLayer& L = a.L[i];
             if (a.H[i].flags & FWF_ANY_OUT) lean = false;

@@ -8,7 +8,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bench import CONFIGS
 from dgps_with_iwvi_amd import _abi, synthetic
 
-ap = argparse.ArgumentParser(); ap.add_argument("--config", type=int, default=2); args = ap.parse_args()
+ap = argparse.ArgumentParser(); ap.add_argument("--config", type=int, default=2)
+ap.add_argument("--sustained", type=int, default=0, help="replay a graph of 20 evaluations this many times right before the stamped launch (the clocks of a busy device)")
+args = ap.parse_args()
 dev = torch.device("cuda:0")
 cfg = CONFIGS[args.config]
 spec = synthetic.make_spec(seed=0, parity=True, n_data=65536, **cfg)
@@ -24,8 +26,23 @@ el = dict(B=B, K=K, stride_b=K, stride_k=1, mode_vi=False)   # the bound's own e
 for _ in range(3):
     m._fused_forward(B * K, K, B, (B, K), elbo=el)
 torch.cuda.synchronize()
-lib.iwvi_debug_set_stamps(buf.data_ptr(), NW)
-m._fused_forward(B * K, K, B, (B, K), elbo=el)
+if args.sustained:
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr, stream=side):
+            for _ in range(20):
+                m.precompute(with_encoders=True)
+                m._fused_forward(B * K, K, B, (B, K), elbo=el)
+        for _ in range(args.sustained):
+            gr.replay()
+        lib.iwvi_debug_set_stamps(buf.data_ptr(), NW)
+        m._fused_forward(B * K, K, B, (B, K), elbo=el)
+    torch.cuda.synchronize()
+    lib.iwvi_debug_set_stamps(None, 0)
+lib.iwvi_debug_set_stamps(buf.data_ptr(), NW) if not args.sustained else None
+if not args.sustained:
+    m._fused_forward(B * K, K, B, (B, K), elbo=el)
 torch.cuda.synchronize()
 lib.iwvi_debug_set_stamps(None, 0)
 full = buf.view(NW, 128).cpu().numpy()
@@ -38,7 +55,7 @@ for li, l in enumerate(spec["layers"]):
     ph = ["", "lv.mlp", "", "", "", "lv.out"] if l["type"] == "lv" else ["gp.xt", "gp.gram", "gp.stage1", "gp.stage2", "gp.epi1", "gp.epi2"]
     for k, n in enumerate(ph):
         if n: names[2 + li * 6 + k] = "L%d %s" % (li, n)
-names[63] = "end"
+names[61] = "logw"; names[62] = "tail.lse"; names[63] = "tail.arrive"
 for k, n in ((56, "p.ltab+x"), (40, "p.item-found"), (57, "p.noise-drawn"), (58, "p.(merged)"), (59, "p.vmcnt0")):
     print("%-14s at med %6.2f us after start" % (n, np.median(s[:, k] - s[:, 0]) * 10e-3))
 prev = None
