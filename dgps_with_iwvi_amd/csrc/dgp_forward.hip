@@ -1168,10 +1168,12 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
             ring[0] = ring[1] = ring[2] = ring[3] = f32x4{0.f, 0.f, 0.f, 0.f};
             f32x4 ring2e[2];                                      // split-f16: second plane of the two slabs requested ahead of stage 1
             ring2e[0] = ring2e[1] = f32x4{0.f, 0.f, 0.f, 0.f};
-            f32x4 Qpre[4][2];                                     // split-f16, M <= 128: the q_mu^T slabs, requested during stage 1 by a wave that is idle there
+            // split-f16, M <= 128: the q_mu^T slabs, requested during stage 1 by a wave that is idle there.  (Not in the BIG variants: eight more
+            // registers live across the super-block solve cost configs[3] a third of its stage 1 in spills -- 28100 -> 37500 clocks.)
+            f32x4 Qpre[BIG ? 1 : 4][2];
             bool q_pre = false;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) Qpre[u][0] = Qpre[u][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int u = 0; u < (BIG ? 1 : 4); ++u) Qpre[u][0] = Qpre[u][1] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (s2_nblocks > 0 && s16) {
                 const size_t o1 = (size_t)(1 < s2_nblocks ? 1 : s2_nblocks - 1) * 128;
                 ring[0] = s2_P[0]; ring2e[0] = s2_P[64]; ring[1] = s2_P[o1]; ring2e[1] = s2_P[o1 + 64];
@@ -1327,7 +1329,7 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
                 for (int i = (wave - NS) * 64 + lane; i < (FW_WAVES * R * NSAMP) / 4; i += (FW_WAVES - NS) * 64) uz[i] = f32x4{0.f, 0.f, 0.f, 0.f};
                 // ... and the one that multiplies by q_mu^T in stage 2 (plan_stage2 puts it here when it can) requests those slabs now: their first
                 // read of an evaluation comes from HBM (written by the precompute launch), 5000 clocks of that wave when requested in stage 2
-                if constexpr (S16) {
+                if constexpr (S16 && !BIG) {
                     if (s2_mw0 == wave && nbk <= 8) {
                         gptr4 Pq = (gptr4)G.QmuP + lane;
 #pragma unroll
@@ -1484,21 +1486,23 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
                     f32x4 acc[NS];
 #pragma unroll
                     for (int t = 0; t < NS; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-                    // the slabs of four chunks are requested together (one L2 round trip per group, not one per slab)
-                    for (int kc0 = 0; kc0 < (nbk >> 1); kc0 += 4) {
-                        f32x4 Q[4][2];
-                        if (q_pre && rb == 0) {                   // (on their way since stage 1; kc0 = 0 is the only group then)
+                    // the slabs of four chunks are requested together (one L2 round trip per group, not one per slab; the BIG variants of more than three sub-tiles: one chunk at a
+                    // time -- they have no registers to spare, see BIG_ZERO below)
+                    constexpr int QG = (BIG && NS > 3) ? 1 : 4;
+                    for (int kc0 = 0; kc0 < (nbk >> 1); kc0 += QG) {
+                        f32x4 Q[QG][2];
+                        if (!BIG && q_pre && rb == 0) {           // (on their way since stage 1; kc0 = 0 is the only group then)
 #pragma unroll
-                            for (int u = 0; u < 4; ++u) { Q[u][0] = Qpre[u][0]; Q[u][1] = Qpre[u][1]; }
+                            for (int u = 0; u < QG; ++u) { Q[u][0] = Qpre[u][0]; Q[u][1] = Qpre[u][1]; }
                         } else {
 #pragma unroll
-                        for (int u = 0; u < 4; ++u) {
+                        for (int u = 0; u < QG; ++u) {
                             const size_t kq = (size_t)(kc0 + u < (nbk >> 1) ? kc0 + u : (nbk >> 1) - 1) * 128;
                             Q[u][0] = P[kq]; Q[u][1] = P[kq + 64];
                         }
                         }
 #pragma unroll
-                        for (int u = 0; u < 4; ++u) {
+                        for (int u = 0; u < QG; ++u) {
                             const int kc = kc0 + u;
                             if (kc < (nbk >> 1)) {
                                 const f16x8 a1 = __builtin_bit_cast(f16x8, Q[u][0]), a2 = __builtin_bit_cast(f16x8, Q[u][1]);
@@ -1536,6 +1540,9 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
                     const int nkc = nbk >> 1;
                     int kc = bp, c = nkc - bp;
                     bool fresh = true;
+                    // (the BIG variant of five sub-tiles clears its accumulators between jobs instead: the second copy of a step's first ten MFMAs
+                    //  put it into scratch -- configs[3]: stage 1 28100 -> 37500 clocks)
+                    constexpr bool BIG_ZERO = BIG && NS > 3;
                     // B vectors serve both row-blocks: h1 of the NEXT step is requested while this step's last ten MFMAs (on h2) issue, h2 of
                     // this step at its top, under the twenty MFMAs on h1 -- half the LDS reads per MFMA of one row-block per job
                     f32x4 b1[NS], b2[NS];
@@ -1556,7 +1563,7 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
                                 const f16x8 a11 = __builtin_bit_cast(f16x8, A[u][2]), a21 = __builtin_bit_cast(f16x8, A[u][3]);
 #pragma unroll
                                 for (int t = 0; t < NS; ++t) b2[t] = p2[kc * 8 * NSAMP + 16 * t];
-                                if (fresh) {                       // first step of a job: accumulate onto the constant 0 (no registers to clear between jobs)
+                                if (!BIG_ZERO && fresh) {          // first step of a job: accumulate onto the constant 0 (no registers to clear between jobs)
                                     const f32x4 Z = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                                     for (int t = 0; t < NS; ++t) acc0[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a10, __builtin_bit_cast(f16x8, b1[t]), Z, 0, 0, 0);
@@ -1600,6 +1607,10 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
                                     }
 #pragma unroll
                                     for (int t = 0; t < NS; ++t) ssq[t] += colsumsq8(acc0[t], acc1[t]);
+                                    if constexpr (BIG_ZERO) {
+#pragma unroll
+                                        for (int t = 0; t < NS; ++t) acc0[t] = acc1[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+                                    }
                                     fresh = true;
                                     ++bp;
                                     if (bp == nkc || q == nstp - 1) {
