@@ -53,6 +53,7 @@ typedef __attribute__((address_space(1))) f32x4* gout4;
 static unsigned long long* g_stamp_buf = nullptr;   // diagnostic; see iwvi_debug_set_stamps
 static long long g_stamp_wgs = 0;
 static int g_dbg_exit = 0;                           // diagnostic; see iwvi_debug_set_exit
+static int g_last_variant = 0;                       // diagnostic; see iwvi_debug_last_forward_variant
 
 constexpr int XSTR_MAX = 37;          // largest row stride (floats) of the activation tiles: D, P <= 32, D + 2 <= 36
 constexpr int FW_MAXNS = 5;
@@ -2547,8 +2548,9 @@ int dgp_forward_impl(const iwvi_layer_desc* layers, int n_layers, const float* X
             }
             else if (!L.lv.enc_out) lean = false;
         }
-        if (lean) return launch_forward<5, true, false, true>(a, (unsigned)chunks, lds_bytes, stream);
+        if (lean && !dbg_opt("IWVI_FW_NO_LEAN")) { g_last_variant = 5 | 1 << 8 | 1 << 10; return launch_forward<5, true, false, true>(a, (unsigned)chunks, lds_bytes, stream); }
     }
+    g_last_variant = ns | (s16_all ? 1 << 8 : 0) | (big ? 1 << 9 : 0);
     switch (ns) {
 #ifndef IWVI_DEV_ONLY5   /* development builds: only the 80-sample variants (make DEV5=1) */
         case 1: return FW_LAUNCH(1);
@@ -2576,6 +2578,8 @@ extern "C" int iwvi_dgp_forward(const iwvi_layer_desc* layers, int n_layers, con
 /* diagnostic (not part of the drop-in surface): register a device buffer of 128 * max_workgroups 64-bit words;
  * every fused-forward launch with at most max_workgroups workgroups then stamps its phase boundaries
  * ([k] 100 MHz wall clock, [64 + k] shader clock) into it.  NULL switches stamping off. */
+/* diagnostic: the k_dgp_forward variant of the last launch -- sub-tiles per workgroup | S16 << 8 | BIG << 9 | LEAN << 10 (tests/test_gpu_lean_variant.py) */
+extern "C" int iwvi_debug_last_forward_variant(void) { return iwvi::g_last_variant; }
 extern "C" void iwvi_debug_set_exit(int phase) { iwvi::g_dbg_exit = phase; }   /* diagnostic: fused-forward launches return after phase N */
 extern "C" void iwvi_debug_set_stamps(void* buf, int64_t max_workgroups) {
     iwvi::g_stamp_buf = (unsigned long long*)buf;
