@@ -302,11 +302,11 @@ def gemm_phase_mfma_util(model, spec, B, K):
     for (li, l), nbk in zip(gps, nbks):
         R = l["q_mu"].shape[1]
         nrb = (R + 15) // 16
-        # stage 1 (csrc/dgp_forward.hip): nbk <= 8: per sub-tile nbk diagonal solves (4 fp32 MFMAs) + the blocks below them (3 f16 MFMAs
-        # of K = 16 when nbk is even, else 4 fp32); 8 < nbk < 16: every block 4 fp32; nbk >= 16: the super-block stream (inverse blocks fp32)
+        # stage 1 (csrc/dgp_forward.hip): nbk <= 8: per sub-tile nbk diagonal solves (4 fp32 MFMAs) + the blocks below them (2 f16 MFMAs
+        # of K = 32 when nbk is even, else 4 fp32); 8 < nbk < 16: every block 4 fp32; nbk >= 16: the super-block stream (inverse blocks fp32)
         if nbk <= 8:
             off = tri(nbk) - nbk
-            i1 = NS * (nbk * 4 * 32 + off * (3 * 16 if nbk % 2 == 0 else 4 * 32))
+            i1 = NS * (nbk * 4 * 32 + off * (2 * 16 if nbk % 2 == 0 else 4 * 32))
         elif nbk < 16:
             i1 = NS * tri(nbk) * 4 * 32
         else:

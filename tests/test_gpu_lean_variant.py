@@ -1,0 +1,90 @@
+"""The variant of ``k_dgp_forward`` that bench.py times (LEAN, csrc/dgp_forward.hip): the bound's own evaluation of an all-RBF M = 128 stack
+at 80 samples per workgroup -- compile-time shapes, no per-layer outputs, the half-wave-per-point tail.  It cannot return the draws it made,
+so it is pinned to the general variant: the SAME evaluation (same seed, same device-resident step) through both, and the general variant is
+what the oracle suites cover (tests/test_gpu_device_noise.py reads its draws back, tests/test_gpu_parity.py injects them).  The two differ
+in the order of one sum (the logsumexp over k is a tree in LEAN), nothing else."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+LEAN_BIT, S16_BIT = 1 << 10, 1 << 8
+
+
+def _last_variant():
+    from dgps_with_iwvi_amd import _abi
+    f = _abi.lib().iwvi_debug_last_forward_variant
+    f.restype, f.argtypes = ctypes.c_int, []
+    return int(f())
+
+
+def _evaluate(model, spec, force_general):
+    """One IW-ELBO evaluation from step 0 of the model's noise stream -> (elbo, logp [B], log-weights [B, K], variant bits)."""
+    from dgps_with_iwvi_amd import _abi
+    B, K = spec["B"], spec["K"]
+    model._words().zero_()                                       # the device-resident counter: both evaluations draw the same numbers
+    model.precompute(with_encoders=True)
+    _abi.set_debug_option("IWVI_FW_NO_LEAN", 1 if force_general else 0)
+    try:
+        logw, _, red = model._fused_forward(B * K, K, B, (B, K), zs=None, sampled_kl=True,
+                                            elbo=dict(B=B, K=K, stride_b=K, stride_k=1, mode_vi=False))
+        torch.cuda.synchronize()
+        variant = _last_variant()
+    finally:
+        _abi.set_debug_option("IWVI_FW_NO_LEAN", 0)
+    return float(red[0]), red[1].double().cpu().numpy(), logw.double().cpu().numpy().reshape(B, K), variant
+
+
+# (K must divide 80 and lie in 5..32 for the variant's tail; T = B K a multiple of 80 and large enough for 80-sample workgroups)
+@pytest.mark.parametrize("K,B,with_lv", [(20, 1024, True),       # BASELINE.json configs[2]: the bench line
+                                         (10, 2048, True),
+                                         (16, 1280, False),
+                                         (5, 4096, True)])
+def test_lean_variant_equals_the_general_variant_on_the_same_draws(gpu_device, K, B, with_lv):
+    from dgps_with_iwvi_amd import settings, synthetic
+    spec = synthetic.make_spec(L=2, M=128, B=B, K=K, with_lv=with_lv, seed=K, n_data=65536)
+    settings.set_seed(99)
+    model = synthetic.build_model(spec, gpu_device)
+    e_lean, lp_lean, lw_lean, v_lean = _evaluate(model, spec, force_general=False)
+    e_gen, lp_gen, lw_gen, v_gen = _evaluate(model, spec, force_general=True)
+    assert v_lean & LEAN_BIT and (v_lean & 0xff) == 5, "the bench shape must take the LEAN variant (%#x)" % v_lean
+    assert not (v_gen & LEAN_BIT) and v_gen & S16_BIT
+    assert np.isfinite(lw_lean).all()
+    # per-sample log-weights: the same arithmetic in both -- identical bits
+    np.testing.assert_array_equal(lw_lean, lw_gen)
+    # per-point logsumexp: tree against serial sum of K float32 terms
+    np.testing.assert_allclose(lp_lean, lp_gen, rtol=0, atol=4e-6 * max(1.0, np.abs(lp_gen).max()))
+    assert abs(e_lean - e_gen) <= 2e-7 * abs(e_gen), (e_lean, e_gen)
+    # and the draws move on: the next evaluation is another sample of the bound
+    logw2, _, red2 = model._fused_forward(B * K, K, B, (B, K), zs=None, sampled_kl=True,
+                                          elbo=dict(B=B, K=K, stride_b=K, stride_k=1, mode_vi=False))
+    assert float(red2[0]) != e_lean
+
+
+@pytest.mark.parametrize("why,kw", [("M = 64", dict(L=2, M=64, B=1024, K=20, with_lv=True)),
+                                    ("K = 40 (tail needs K <= 32)", dict(L=2, M=128, B=512, K=40, with_lv=True)),
+                                    ("a ragged last workgroup", dict(L=2, M=128, B=1023, K=20, with_lv=True))])
+def test_shapes_outside_the_variant_take_the_general_one(gpu_device, why, kw):
+    from dgps_with_iwvi_amd import settings, synthetic
+    spec = synthetic.make_spec(seed=3, n_data=65536, **kw)
+    settings.set_seed(5)
+    model = synthetic.build_model(spec, gpu_device)
+    e, lp, lw, v = _evaluate(model, spec, force_general=False)
+    assert not (v & LEAN_BIT), why
+    assert np.isfinite(e) and np.isfinite(lw).all()
+
+
+def test_requested_layer_outputs_take_the_general_variant(gpu_device):
+    from dgps_with_iwvi_amd import settings, synthetic
+    spec = synthetic.make_spec(L=2, M=128, B=1024, K=20, with_lv=True, seed=0, n_data=65536)
+    settings.set_seed(5)
+    model = synthetic.build_model(spec, gpu_device)
+    B, K = spec["B"], spec["K"]
+    model.precompute(with_encoders=True)
+    model._fused_forward(B * K, K, B, (B, K), zs=None, sampled_kl=True, want_layers=True,
+                         elbo=dict(B=B, K=K, stride_b=K, stride_k=1, mode_vi=False))
+    torch.cuda.synchronize()
+    assert not (_last_variant() & LEAN_BIT)
