@@ -2392,14 +2392,22 @@ __global__ void k_inc_i64(long long* p) { if (threadIdx.x == 0 && blockIdx.x == 
 
 using namespace iwvi;
 
+// The two sizing entries take no descriptor, so they answer for BOTH arithmetic modes a later call may ask for through its descriptor's
+// flags (IWVI_BW_F32_CHAIN): u is needed when either mode's adjoint reads it, the workspace is the larger of the two layouts.
 extern "C" int iwvi_gp_layer_backward_needs_u(int64_t T, int M, int D, int R, int P) {
     if (T <= 0 || M <= 0 || D <= 0 || R <= 0 || P <= 0) return 1;
-    return chain_fits(T, M, round_up(M, 16), D, R, P) ? 0 : 1;
+    bool fits_s16, fits_f32;
+    { const BwFlagScope sc(0); fits_s16 = chain_fits(T, M, round_up(M, 16), D, R, P); }
+    { const BwFlagScope sc(IWVI_BW_F32_CHAIN); fits_f32 = chain_fits(T, M, round_up(M, 16), D, R, P); }
+    return (fits_s16 && fits_f32) ? 0 : 1;
 }
 
 extern "C" size_t iwvi_gp_layer_backward_ws_bytes(int64_t T, int M, int D, int R) {
     if (T <= 0 || M <= 0 || D <= 0 || R <= 0) return 0;
-    return bwd_layout(nullptr, T, M, D, R).bytes;
+    size_t b_s16, b_f32;
+    { const BwFlagScope sc(0); b_s16 = bwd_layout(nullptr, T, M, D, R).bytes; }
+    { const BwFlagScope sc(IWVI_BW_F32_CHAIN); b_f32 = bwd_layout(nullptr, T, M, D, R).bytes; }
+    return b_s16 > b_f32 ? b_s16 : b_f32;
 }
 
 // What the adjoint of a layer needs besides the forward's outputs: scaled inducing inputs, a float32 Lm^-1, and for the
@@ -2434,7 +2442,9 @@ extern "C" int iwvi_gp_layers_backward_prepare(const iwvi_gp_bwd_desc* descs, in
     PrepAll a{};
     a.n = n;
     unsigned grid = 0;
-    const BwFlagScope flag_scope(descs[0].flags);                  // (one launch for all layers: the first descriptor's mode)
+    for (int i = 1; i < n; ++i)                                    // (one launch for all layers: one arithmetic mode)
+        if ((descs[i].flags ^ descs[0].flags) & IWVI_BW_F32_CHAIN) { set_error("iwvi_gp_layers_backward_prepare: layer %d asks for another arithmetic mode (IWVI_BW_F32_CHAIN) than layer 0", i); return IWVI_ERR_ARG; }
+    const BwFlagScope flag_scope(descs[0].flags);
     for (int i = 0; i < n; ++i) {
         const iwvi_gp_bwd_desc& d = descs[i];
         if (!ws[i] || !d.state || !d.Z || !d.lengthscales || !d.q_sqrt || d.M <= 0 || d.M > IWVI_MAX_M || d.D <= 0 || d.D > IWVI_MAX_D || d.R <= 0 || d.R > IWVI_MAX_R) {

@@ -327,16 +327,19 @@ typedef struct iwvi_gp_bwd_desc {
 } iwvi_gp_bwd_desc;
 /* IWVI_BW_F32_CHAIN: the adjoint chain's S_r products on fp32 MFMAs instead of split-f16 operands (per call, like IWVI_LAYER_F32_STAGE2). */
 #define IWVI_BW_F32_CHAIN 1
+/* (both sizing entries answer for either arithmetic mode a later call may select through desc.flags: the larger workspace; u is needed
+ * when either mode's adjoint reads it) */
 size_t iwvi_gp_layer_backward_ws_bytes(int64_t T, int M, int D, int R);
-/* 1 if the adjoint of this layer shape takes the GEMM path and therefore needs the forward's u_out, 0 if the streaming chain
- * (which works from a_out alone) will run */
+/* 1 if the adjoint of this layer shape takes the GEMM path (in either arithmetic mode) and therefore needs the forward's u_out, 0 if the
+ * streaming chain (which works from a_out alone) will run */
 int iwvi_gp_layer_backward_needs_u(int64_t T, int M, int D, int R, int P);
 /* the parameter-only part of the adjoint (scaled inducing inputs, float32 Lm^-1, the streaming chain's packed operands
  * S_r = L_r L_r^T and Lm^-T): reads state (dense factors), Z, lengthscales, q_sqrt, M / D / R of the descriptor only, so it can
  * be queued on another stream beside the forward; then set desc.prepared.  Called implicitly otherwise. */
 int iwvi_gp_layer_backward_prepare(const iwvi_gp_bwd_desc* desc, int64_t T, void* ws, void* stream);
-/* The same for n layers (n <= IWVI_MAX_STACK) in ONE launch: descs[i] with its workspace ws[i].  (The prepare steps of a model are
- * queued beside the layer kernel, which holds every CU; as separate launches they run one after the other once it retires.) */
+/* The same for n layers (n <= IWVI_MAX_STACK) in ONE launch: descs[i] with its workspace ws[i]; every descriptor must ask for the same
+ * arithmetic mode (flags & IWVI_BW_F32_CHAIN), else IWVI_ERR_ARG.  (The prepare steps of a model are queued beside the layer kernel,
+ * which holds every CU; as separate launches they run one after the other once it retires.) */
 int iwvi_gp_layers_backward_prepare(const iwvi_gp_bwd_desc* descs, int n, int64_t T, void* const* ws, void* stream);
 /* Outputs left NULL are not formed.  With ONLY dq_mu / dq_sqrt given (what the natural-gradient op of build_models.py:288-295 reads)
  * the call reduces to the heads and the two sums over samples behind those gradients (on either path: the streaming chain, or the

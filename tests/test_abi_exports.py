@@ -68,3 +68,17 @@ def test_training_entry_points_refuse_bad_arguments_without_touching_the_gpu():
     dims = (ctypes.c_int32 * 3)(9, 20, 2)
     assert lib.iwvi_encoder_backward_ws_bytes(0, dims, 2) == 0 and lib.iwvi_encoder_backward_ws_bytes(64, dims, 2) > 0
     assert lib.iwvi_encoder_backward(None, 64, None, None, dims, 2, None, None, None, None, None) == -1
+
+
+def test_backward_sizing_entries_answer_for_both_arithmetic_modes():
+    """``iwvi_gp_layer_backward_needs_u`` / ``_ws_bytes`` take no descriptor, the arithmetic mode is chosen per call (desc.flags &
+    IWVI_BW_F32_CHAIN): they must cover whichever mode the later call asks for.  M = 512 at a small batch: the split-f16 chain runs from
+    a_out alone, the fp32 chain does not fit and the GEMM path reads u -- the forward must be told to keep it.  Host logic only."""
+    from dgps_with_iwvi_amd import _abi
+    if not os.path.exists(_abi.LIB_PATH):
+        pytest.skip("libiwvi_hip.so not built (run __graft_entry__.build())")
+    lib = _abi.lib()
+    assert lib.iwvi_gp_layer_backward_needs_u(1024, 512, 8, 5, 5) == 1
+    assert lib.iwvi_gp_layer_backward_needs_u(20480, 128, 9, 5, 8) == 0            # configs[2]: the chain in either mode
+    assert lib.iwvi_gp_layer_backward_needs_u(20480, 120, 9, 5, 8) == 1            # M not a multiple of 16: GEMM path
+    assert lib.iwvi_gp_layer_backward_ws_bytes(1024, 512, 8, 5) >= lib.iwvi_gp_layer_backward_ws_bytes(1024, 256, 8, 5) > 0
