@@ -1130,8 +1130,14 @@ __global__ __launch_bounds__(512) void k_bw_chain(ChainArgs a) {
                         const f16x8 a1 = __builtin_bit_cast(f16x8, r1[u]), a2 = __builtin_bit_cast(f16x8, r2[u]);
 #pragma unroll
                         for (int t = 0; t < NS; ++t) b2[t] = tH4[(8 * kc + 2 * gq + 1) * TS + 16 * t + jq];
+                        if (kc == 0) {                       // first slab of a latent GP: onto the constant 0 (nothing cleared between them)
+                            const f32x4 Z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                            for (int t = 0; t < NS; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, __builtin_bit_cast(f16x8, b1[t]), Z, 0, 0, 0);
+                        } else {
 #pragma unroll
                         for (int t = 0; t < NS; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, __builtin_bit_cast(f16x8, b1[t]), acc[t], 0, 0, 0);
+                        }
 #pragma unroll
                         for (int t = 0; t < NS; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2, __builtin_bit_cast(f16x8, b1[t]), acc[t], 0, 0, 0);
                         const int kc_n = kc + 1 == nkc ? 0 : kc + 1;
@@ -1145,27 +1151,35 @@ __global__ __launch_bounds__(512) void k_bw_chain(ChainArgs a) {
                             for (int t = 0; t < NS; ++t) {
                                 const float w = dv2_s[(16 * t + jq) * R + r] * fr;
 #pragma unroll
-                                for (int e = 0; e < 4; ++e) { tot[t][e] = fmaf(w, acc[t][e], tot[t][e]); acc[t][e] = 0.f; }
+                                for (int e = 0; e < 4; ++e) tot[t][e] = fmaf(w, acc[t][e], tot[t][e]);
                             }
                             kc = 0; ++r;
                         }
                     }
                 }
             }
+            // (+ q_mu dmu: per latent GP the 4 + NS operands read once -- per element it was 2 R LDS reads for R multiply-adds; same order)
 #pragma unroll
             for (int t = 0; t < NS; ++t) {
                 const int j = 16 * t + jq;
                 const f32x4 av = tA4[(bi * 4 + gq) * TS + j];
                 const float m2 = -2.f * sdv_s[j];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float v = fmaf(m2, av[e], tot[t][e]);
-                    const int m = 16 * bi + 4 * gq + e;
-                    for (int rr = 0; rr < R; ++rr) v = fmaf(dmu_s[j * R + rr], qmu_s[m * R + rr], v);
-                    tot[t][e] = v;
-                }
-                tK4[(bi * 4 + gq) * TS + j] = tot[t];
+                for (int e = 0; e < 4; ++e) tot[t][e] = fmaf(m2, av[e], tot[t][e]);
             }
+            for (int rr = 0; rr < R; ++rr) {
+                float qm[4], dm[NS];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) qm[e] = qmu_s[(16 * bi + 4 * gq + e) * R + rr];
+#pragma unroll
+                for (int t = 0; t < NS; ++t) dm[t] = dmu_s[(16 * t + jq) * R + rr];
+#pragma unroll
+                for (int t = 0; t < NS; ++t)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) tot[t][e] = fmaf(dm[t], qm[e], tot[t][e]);
+            }
+#pragma unroll
+            for (int t = 0; t < NS; ++t) tK4[(bi * 4 + gq) * TS + 16 * t + jq] = tot[t];
         }
     } else
     // ---- phase 1: da row-blocks bi = wave, wave + 4 -------------------------------------------------------------------
@@ -1205,30 +1219,40 @@ __global__ __launch_bounds__(512) void k_bw_chain(ChainArgs a) {
             const f32x4 av = tA4[(bi * 4 + gq) * TS + j];
             const float m2 = -2.f * sdv_s[j];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float v = fmaf(m2, av[e], tot[t][e]);
-                const int m = 16 * bi + 4 * gq + e;
-                for (int rr = 0; rr < R; ++rr) v = fmaf(dmu_s[j * R + rr], qmu_s[m * R + rr], v);
-                tot[t][e] = v;
-            }
-            tK4[(bi * 4 + gq) * TS + j] = tot[t];
+            for (int e = 0; e < 4; ++e) tot[t][e] = fmaf(m2, av[e], tot[t][e]);
         }
+        for (int rr = 0; rr < R; ++rr) {
+            float qm[4], dm[NS];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) qm[e] = qmu_s[(16 * bi + 4 * gq + e) * R + rr];
+#pragma unroll
+            for (int t = 0; t < NS; ++t) dm[t] = dmu_s[(16 * t + jq) * R + rr];
+#pragma unroll
+            for (int t = 0; t < NS; ++t)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) tot[t][e] = fmaf(dm[t], qm[e], tot[t][e]);
+        }
+#pragma unroll
+        for (int t = 0; t < NS; ++t) tK4[(bi * 4 + gq) * TS + 16 * t + jq] = tot[t];
     }
     __syncthreads();
     if (a.dbg_exit == 2) return;
 
     // ---- phase 2: dk(bi) = sum_{bk >= bi} Lm^-T(bi, bk) da(bk); row-blocks paired so that every wave streams nbk + 1 blocks
     //      IN PLACE over da: every wave holds its (at most two) result row-blocks in registers until all have read da.
-    const int npair = (nbk + 1) / 2, nw2 = nbk <= 8 ? 4 : 8;         // (nbk <= 8: four pairs at most, waves 4-7 sit this short phase out)
+    const int npair = (nbk + 1) / 2;
+    const bool split8 = nbk <= 8;                            // (four pairs at most: a pair's two row-blocks go to the waves w and w + 4 -- one SIMD, nbk + 1
+                                                             //  blocks between them as before, but two waves to hide each other's operand latency)
     f32x4 res[4][NS];                                        // (nbk <= 32: two pairs = four row-blocks per wave at most)
     int rbi[4] = {-1, -1, -1, -1};
-    if (wave < nw2 && !a.q_only)
+    if (!a.q_only)
 #pragma unroll
     for (int pp = 0; pp < 2; ++pp) {
-        const int p_ = wave + nw2 * pp;
+        const int p_ = split8 ? (wave & 3) + 4 * pp : wave + 8 * pp;
         if (p_ >= npair) continue;
 #pragma unroll
         for (int pass = 0; pass < 2; ++pass) {
+            if (split8 && pass != (wave >> 2)) continue;
             const int bi = pass == 0 ? p_ : nbk - 1 - p_;
             if (pass == 1 && bi <= p_) continue;                // (the middle row-block of an odd nbk: once)
             const int slot = 2 * pp + pass;
@@ -1294,6 +1318,8 @@ __global__ __launch_bounds__(512) void k_bw_chain(ChainArgs a) {
                 }
                 float* outp = it == 0 ? a.p_lm + (size_t)blockIdx.x * M * M
                                       : a.p_g + ((size_t)(it - 1) * a.S + blockIdx.x) * M * M;
+                // (measured and rejected, round 4: two column blocks at a time with even / odd k-steps on their own accumulators -- four
+                //  independent MFMA chains instead of one of 20 dependent ones -- 35.5 -> 40 us for the two launches of configs[2])
                 for (int bk = 0; bk <= bi; ++bk) {
                     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll

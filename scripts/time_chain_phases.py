@@ -14,7 +14,7 @@ dev = torch.device("cuda:0")
 spec = synthetic.make_spec(seed=0, parity=True, n_data=65536, **cfg)
 settings.set_seed(1)
 m = synthetic.build_model(spec, dev)
-names = {0: "whole", 10: "inputs in LDS", 11: "heads", 1: "phase 1: da", 2: "phase 2: dk", 3: "thin sums", 4: "products over samples", 5: "kernel adjoint"}
+names = {0: "whole", 10: "inputs in LDS", 11: "heads", 1: "thin sums (dq_mu, dW)", 2: "phase 1: da", 3: "phase 2: dk", 4: "products over samples", 5: "kernel adjoint"}
 base = None
 for ex in (10, 11, 1, 2, 3, 4, 5, 0):
     _abi.set_debug_option("IWVI_CHAIN_EXIT", ex)
