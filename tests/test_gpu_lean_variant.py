@@ -2,7 +2,8 @@
 at 80 samples per workgroup -- compile-time shapes, no per-layer outputs, the half-wave-per-point tail.  It cannot return the draws it made,
 so it is pinned to the general variant: the SAME evaluation (same seed, same device-resident step) through both, and the general variant is
 what the oracle suites cover (tests/test_gpu_device_noise.py reads its draws back, tests/test_gpu_parity.py injects them).  The two differ
-in the order of one sum (the logsumexp over k is a tree in LEAN), nothing else."""
+in the order of one sum (the logsumexp over k is a tree in LEAN), nothing else.  The last test closes the loop at the bench shape itself:
+the LEAN evaluation of BASELINE.json configs[2] at full size against the float64 oracle, on the draws read back from the same noise step."""
 import ctypes
 
 import numpy as np
@@ -88,3 +89,32 @@ def test_requested_layer_outputs_take_the_general_variant(gpu_device):
                          elbo=dict(B=B, K=K, stride_b=K, stride_k=1, mode_vi=False))
     torch.cuda.synchronize()
     assert not (_last_variant() & LEAN_BIT)
+
+
+def test_lean_variant_against_the_oracle_at_the_bench_shape(gpu_device):
+    """BASELINE.json configs[2] at full size: the LEAN evaluation's bound and per-point terms against the float64 oracle, fed the draws the
+    general variant reads back from the SAME noise step (the two variants' log-weights are identical bits, see above).  Tolerances of the
+    device-noise suite: ELBO relative 1e-4, per-point logsumexp rtol 2e-4 + atol 2e-2."""
+    from dgps_with_iwvi_amd import settings, synthetic
+    from oracle.from_spec import build_oracle, oracle_noise
+    spec = synthetic.make_spec(L=2, M=128, B=1024, K=20, with_lv=True, seed=20, n_data=65536)
+    B, K = spec["B"], spec["K"]
+    settings.set_seed(4321)
+    model = synthetic.build_model(spec, gpu_device)
+    e_lean, lp_lean, lw_lean, v_lean = _evaluate(model, spec, force_general=False)
+    assert v_lean & LEAN_BIT
+    model._words().zero_()                                       # the same noise step once more, through the variant that returns its draws
+    model.precompute(with_encoders=True)
+    lw_gen, outs, red = model._fused_forward(B * K, K, B, (B, K), zs=None, sampled_kl=True, want_layers=True, want_saved=True,
+                                             elbo=dict(B=B, K=K, stride_b=K, stride_k=1, mode_vi=False))
+    torch.cuda.synchronize()
+    assert not (_last_variant() & LEAN_BIT)
+    np.testing.assert_array_equal(lw_lean, lw_gen.double().cpu().numpy().reshape(B, K))
+    zs = [o["noise_out"].double().cpu().numpy().reshape(B, K, -1) for o in outs]
+    om = build_oracle(spec)
+    ref = om.build_likelihood(oracle_noise(spec, zs))
+    assert abs(e_lean - ref) <= 1e-4 * abs(ref), (e_lean, ref)
+    L_NK = om.log_weights(oracle_noise(spec, zs))[0]
+    m_o = L_NK.max(1)
+    np.testing.assert_allclose(lp_lean, m_o + np.log(np.exp(L_NK - m_o[:, None]).sum(1)) - np.log(K), rtol=2e-4, atol=2e-2)
+    np.testing.assert_allclose(lw_lean, L_NK, rtol=2e-4, atol=2e-2)
