@@ -650,9 +650,13 @@ __device__ __forceinline__ void fw_arrive(const FwArgs& gk, float* sm, int tid, 
 // the launch variants for M <= 128 do not carry the column-at-a-time / super-block solves and the in-place plane conversion
 // LEAN (the bound's own evaluation: every GP layer RBF, every latent-variable layer's encoder evaluated by the precompute launch, all noise drawn in
 // the kernel, no per-layer output asked for, the packed arrival): none of those alternatives is compiled into the variant
-template <int NS, bool S16, bool BIG, bool LEAN = false>
+template <int NS, bool S16, bool BIG, int LEAN_MODE = 0>
 __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
     constexpr int NSAMP = 16 * NS;
+    constexpr bool SHP = LEAN_MODE != 0;     // the headline stack's shapes and sources compiled in (all RBF, M = 128, D <= 10, operands staged, encoders
+                                             // precomputed, noise drawn here, whole chunks): mode 1 and mode 2
+    constexpr bool LEAN = LEAN_MODE == 1;    // ... and the bound's own evaluation: no per-layer outputs, the packed arrival, the half-wave tail.
+                                             // Mode 2 keeps the outputs and the general tail: the forward of a value + gradient evaluation
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int gq = lane >> 4, jq = lane & 15;
     const FwHead& g = gk.h;                                       // scalar path (first kernarg lines)
@@ -673,7 +677,7 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
     }
     const int chunk_id = (int)blockIdx.x;
     const long long t0 = (long long)chunk_id * NSAMP;
-    const int nvalid = LEAN ? NSAMP : (int)((g.T - t0) < (long long)NSAMP ? (g.T - t0) : (long long)NSAMP);   // (LEAN: T is a multiple of the chunk)
+    const int nvalid = SHP ? NSAMP : (int)((g.T - t0) < (long long)NSAMP ? (g.T - t0) : (long long)NSAMP);   // (LEAN: T is a multiple of the chunk)
 
     // ---- the last n_early waves (those that draw no noise below) issue every copy of the prologue; the others fetch the layer table and the
     //      chunk's rows (below: "the prologue's copies")
@@ -717,7 +721,7 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
     //  only moves when the last workgroup of a launch arrives, after every workgroup of that launch has read it)
     const unsigned long long step = g.rng_state ? *((const __attribute__((address_space(4))) unsigned long long*)g.rng_state) : 0ULL;
     FW_STAMP(0);
-    if (!LEAN && g.dbg_exit == 1) return;
+    if (!SHP && g.dbg_exit == 1) return;
 
     // ================= prologue: everything small -> LDS, all loads in flight at once ==================
     const unsigned ut0 = (unsigned)t0, uT = (unsigned)g.T;
@@ -775,12 +779,12 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
         const unsigned dp = point_of(tid);
         rowi[tid] = (int)row_of(dp);
         pidx[tid] = (int)dp;
-        lw[tid] = (!LEAN && g.lw_init && tid < nvalid) ? g.lw_init[t0 + tid] : 0.f;
+        lw[tid] = (!SHP && g.lw_init && tid < nvalid) ? g.lw_init[t0 + tid] : 0.f;
     }
     // the chunk's rows of X (models.py:113 / :50 tiling done here) and of the encoder input
     for (int idx = tid; idx < NSAMP * g.Dx; idx += ethreads) {
         const int d = idx / NSAMP, j = idx - d * NSAMP;            // (compile-time divisor)
-        const unsigned row = (!LEAN && g.x_per_sample) ? ut0 + (unsigned)(j < nvalid ? j : nvalid - 1) : row_of(point_of(j));
+        const unsigned row = (!SHP && g.x_per_sample) ? ut0 + (unsigned)(j < nvalid ? j : nvalid - 1) : row_of(point_of(j));
         xin[j * XSTR + d] = (j < nvalid) ? g.X[(size_t)row * g.Dx + d] : 0.f;
     }
     if (g.XY) {
@@ -805,7 +809,7 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
     //      the copies follow back to back: the compiler puts `s_waitcnt vmcnt(0)` in front of every ds_read / ds_write that follows a
     //      global_load_lds, so a table entry read between two copies makes the second wait until the first has landed.
     const int ncopy0 = g.ncopy;
-    const bool noise_any_src = !LEAN && g.noise_any_src;
+    const bool noise_any_src = !SHP && g.noise_any_src;
     const int draw_waves = noise_any_src ? FW_WAVES : ((g.noise_drawn + 63) >> 6 < FW_WAVES ? (g.noise_drawn + 63) >> 6 : FW_WAVES);
     const int ndma = n_early > 0 ? n_early : FW_WAVES;            // (the host has checked that the copy list fits those waves)
     const int dwave = FW_WAVES - 1 - wave;                        // the copies' wave index: 0 = the last wave
@@ -943,7 +947,7 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
     FW_STAMP(59);
     __syncthreads();
     FW_STAMP(1);
-    if (!LEAN && g.dbg_exit == 2) return;
+    if (!SHP && g.dbg_exit == 2) return;
 
     int xt_for = -1;                                              // layer whose Gram operand x~ is already in `xt`
     for (int li = 0; li < g.n_layers; ++li) {
@@ -966,9 +970,9 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
             else o_kl = (gout1)ufirst(L.lv.kl_local);
         }
         // a following GP layer gets its Gram operand from this layer's last phase (no phase of its own)
-        const bool nx_gp = (H.flags & FWF_NX_GP) != 0, nx_rbf = LEAN || (H.flags & FWF_NX_RBF) != 0;
+        const bool nx_gp = (H.flags & FWF_NX_GP) != 0, nx_rbf = SHP || (H.flags & FWF_NX_RBF) != 0;
         const float* nx_cst = sm + H.nx_c_off;
-        const int nx_nsteps = LEAN ? 3 : H.nx_nsteps;
+        const int nx_nsteps = SHP ? 3 : H.nx_nsteps;
         if (H.type == IWVI_LAYER_LV) {
             // ================= LatentVariableLayer (layers.py:72-105) =================================
             const FwLv& V = L.lv;
@@ -978,7 +982,7 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
             float* act1 = act0 + NSAMP * mdim;
             const float* in = xyrows; int in_str = up4(g.XYdim);
             float* out = act0;
-            const bool pre_enc = LEAN || (H.flags & FWF_PRE_ENC) != 0;    // encoder already evaluated by iwvi_model_precompute
+            const bool pre_enc = SHP || (H.flags & FWF_PRE_ENC) != 0;    // encoder already evaluated by iwvi_model_precompute
             const int enc_actv = pre_enc ? 0 : ufirst(V.act);
             if (pre_enc) { in = cst; in_str = 2 * Lw; }
             else {
@@ -1048,14 +1052,14 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
             FW_STAMP(2 + li * 6 + 5);
         } else {
             // ================= GPLayer (layers.py:35-50) ==============================================
-            const int nbk = LEAN ? 8 : G.nbk, R = G.R, P = G.P, nsteps = LEAN ? 3 : G.nsteps;   // (LEAN: M = 128, D <= 10 -- see launch)
+            const int nbk = SHP ? 8 : G.nbk, R = G.R, P = G.P, nsteps = SHP ? 3 : G.nsteps;   // (LEAN: M = 128, D <= 10 -- see launch)
             const unsigned long long s2_rec = L.gp.s2w[wave];    // stage 2's run of this wave (used behind the Gram: the read is long back by then)
             float g_variance = G.variance;
             if (g.var_dev_mask >> li & 1u) g_variance = sm[g.lds.cnt + 12 + li];          // (a device scalar: fetched in the prologue)
             f32x4* kuf = reinterpret_cast<f32x4*>(scratch);
             f32x4* at = kuf;                                       // solved in place (stage 1)
             float* usq = scratch + (size_t)G.Mp * NSAMP;           // [wave][r][NSAMP]
-            const bool rbf = LEAN || G.kern_type == IWVI_KERN_RBF;
+            const bool rbf = SHP || G.kern_type == IWVI_KERN_RBF;
             // split-f16 solve (even nbk <= 8; see split_b16): the Gram tile in units of U (1 otherwise), a_bj scaled by sb for the updates
             const float st1_u = cst[IWVI_CST_U], st1_sb = cst[IWVI_CST_SB];
             const float* invls = cst; const float* zc = cst + 32;
@@ -1080,7 +1084,7 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
 #pragma unroll
                 for (int t = 0; t < NS; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
                 if (gram_mfma) {
-                    if (LEAN || G.zt_off >= 0) {
+                    if (SHP || G.zt_off >= 0) {
                         const float* zp = sm + G.zt_off + (size_t)bi * nsteps * 64 + lane;      // staged in LDS
                         for (int s = 0; s < nsteps; ++s) {
                             const float a = zp[s * 64];
@@ -1103,7 +1107,7 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
                     const float sx = rbf ? 1.4426950408889634f : -2.f;
                     for (int d = 0; d < D; ++d) {
                         const size_t zi = ((size_t)bi * nsteps + (d >> 2)) * 64 + 16 * (d & 3) + 4 * gq;
-                        const f32x4 z4 = (LEAN || G.zt_off >= 0) ? *reinterpret_cast<const f32x4*>(sm + G.zt_off + zi)
+                        const f32x4 z4 = (SHP || G.zt_off >= 0) ? *reinterpret_cast<const f32x4*>(sm + G.zt_off + zi)
                                                          : *((gptr4)(G.ZtP + zi));
 #pragma unroll
                         for (int t = 0; t < NS; ++t) {
@@ -1128,7 +1132,7 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
                     for (int t = 0; t < NS; ++t) {
                         f32x4 k;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) k[e] = (LEAN || mrow + e < G.M) ? __builtin_amdgcn_exp2f(acc[t][e]) : 0.f;   // log2(var) folded in
+                        for (int e = 0; e < 4; ++e) k[e] = (SHP || mrow + e < G.M) ? __builtin_amdgcn_exp2f(acc[t][e]) : 0.f;   // log2(var) folded in
                         k *= st1_u;
                         kuf[(bi * 4 + gq) * NSAMP + 16 * t + jq] = k;
                     }
@@ -1347,7 +1351,7 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
                 const gptr4 Ap = (gptr4)G.LsP + lane;
                 const gout1 arow = (o_a && tcol < nvalid) ? o_a + (size_t)(t0 + tcol) * G.Mp : (gout1)nullptr;
                 float ssq = 0.f;
-                if constexpr (LEAN) {
+                if constexpr (SHP) {
                     ssq = stage1_unrolled<NS, 8, true, S16>(reinterpret_cast<const f32x4*>(sm + G.ls_off) + lane, kuf, at, tcol, gq, arow, st1_sb);
                 } else
                 if (G.ls_off >= 0 && nbk <= 8) {
@@ -1839,7 +1843,7 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
                 const int Dm = (G.mf_type == IWVI_MF_LINEAR) ? D : 0;
                 // (LEAN: the next layer's D = P <= 10 and nothing but the sample is handed on -- compile-time, or every step below is a handful of
                 //  wave-uniform branches)
-                const int npb = LEAN ? 1 : (P + 15) >> 4;         // 16-row blocks of outputs: 1 or 2
+                const int npb = SHP ? 1 : (P + 15) >> 4;         // 16-row blocks of outputs: 1 or 2
                 const bool need_mv = LEAN ? false : need_mv_any;
                 const bool hasW = (G.flags & FWF_HASW) != 0;
                 const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
@@ -1900,7 +1904,7 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
                         if (npb > 1) { const float a2 = mfA[dc * P + pc_hi]; ah[u] = (d < Dm && p_hi < P) ? a2 : 0.f; }
                     }
 #pragma unroll
-                    for (int u = 0; u < (LEAN ? 3 : 4); ++u) {        // (LEAN: D <= 10)
+                    for (int u = 0; u < (SHP ? 3 : 4); ++u) {         // (compiled-in shapes: D <= 10)
                         {
                             acc_s[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(al[u], bx[u], acc_s[0], 0, 0, 0);
                             if (need_mv) acc_m[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(al[u], bx[u], acc_m[0], 0, 0, 0);
@@ -2107,15 +2111,15 @@ static void fw_decide_fast(FwArgs& a, unsigned grid, int nsamp, int64_t T) {
                   a.h.rng_state && grid <= 511u && 2 * (int64_t)a.h.nchunks <= ws_len && E.kl_total <= 64 && !dbg_opt("IWVI_FW_SLOW_TAIL")) ? 1 : 0;
 }
 
-template <int NS, bool S16, bool BIG, bool LEAN = false>
+template <int NS, bool S16, bool BIG, int LEAN_MODE = 0>
 static int launch_forward(const FwArgs& a, unsigned grid, size_t lds_bytes, hipStream_t stream) {
     static size_t attr_set = 0;
     if (lds_bytes > attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_dgp_forward<NS, S16, BIG, LEAN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        hipError_t e = hipFuncSetAttribute((const void*)k_dgp_forward<NS, S16, BIG, LEAN_MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) { set_error("hipFuncSetAttribute(k_dgp_forward, %zu B): %s", lds_bytes, hipGetErrorString(e)); return IWVI_ERR_LAUNCH; }
         attr_set = lds_bytes;
     }
-    hipLaunchKernelGGL((k_dgp_forward<NS, S16, BIG, LEAN>), dim3(grid), dim3(FW_THREADS), lds_bytes, stream, a);
+    hipLaunchKernelGGL((k_dgp_forward<NS, S16, BIG, LEAN_MODE>), dim3(grid), dim3(FW_THREADS), lds_bytes, stream, a);
     return check_launch("k_dgp_forward");
 }
 
@@ -2536,19 +2540,25 @@ int dgp_forward_impl(const iwvi_layer_desc* layers, int n_layers, const float* X
                                       : launch_forward<NS_, true, false>(a, (unsigned)chunks, lds_bytes, stream))     \
                                 : (big ? launch_forward<NS_, false, true>(a, (unsigned)chunks, lds_bytes, stream)     \
                                       : launch_forward<NS_, false, false>(a, (unsigned)chunks, lds_bytes, stream)))
-    {   // the bound's own evaluation at the headline chunk size (k_dgp_forward: LEAN)
-        bool lean = ns == 5 && s16_all && !big && a.h.e.fast && !a.h.noise_any_src && a.h.out_logw && !a.h.lw_init && !a.h.x_per_sample && !g_dbg_exit && T % (16 * 5) == 0 &&
-                    a.h.e.K >= 5 && a.h.e.K <= 32;       // (its tail: one half-wave per data point)
-        for (int i = 0; i < n_layers && lean; ++i) {
+    {   // the headline stack at the headline chunk size: the variants with its shapes and sources compiled in (k_dgp_forward: SHP / LEAN)
+        bool shp = ns == 5 && s16_all && !big && !a.h.noise_any_src && !a.h.lw_init && !a.h.x_per_sample && !g_dbg_exit && T % (16 * 5) == 0;
+        for (int i = 0; i < n_layers && shp; ++i) {
             const FwLayer& L = a.L[i];
-            if (a.H[i].flags & FWF_ANY_OUT) lean = false;
             if (L.type == IWVI_LAYER_GP) {
-                const FwGp& G = L.gp;                              // the shape the variant is compiled for: M = 128 (8 blocks), D <= 10, operands staged in LDS
-                if (G.kern_type != IWVI_KERN_RBF || G.M != 128 || G.nbk != 8 || G.nsteps != 3 || G.ls_off < 0 || G.zt_off < 0) lean = false;
+                const FwGp& G = L.gp;                              // M = 128 (8 blocks), D <= 10, operands staged in LDS
+                if (G.kern_type != IWVI_KERN_RBF || G.M != 128 || G.nbk != 8 || G.nsteps != 3 || G.ls_off < 0 || G.zt_off < 0) shp = false;
             }
-            else if (!L.lv.enc_out) lean = false;
+            else if (!L.lv.enc_out) shp = false;
         }
-        if (lean && !dbg_opt("IWVI_FW_NO_LEAN")) { g_last_variant = 5 | 1 << 8 | 1 << 10; return launch_forward<5, true, false, true>(a, (unsigned)chunks, lds_bytes, stream); }
+        // mode 1: the bound's own evaluation (no per-layer output, the packed arrival; its tail: one half-wave per data point)
+        bool lean = shp && a.h.e.fast && a.h.out_logw && a.h.e.K >= 5 && a.h.e.K <= 32;
+        for (int i = 0; i < n_layers && lean; ++i) if (a.H[i].flags & FWF_ANY_OUT) lean = false;
+        if (shp && !dbg_opt("IWVI_FW_NO_LEAN")) {
+            if (lean) { g_last_variant = 5 | 1 << 8 | 1 << 10; return launch_forward<5, true, false, 1>(a, (unsigned)chunks, lds_bytes, stream); }
+            // mode 2: the same stack with outputs and the general tail (the forward of a value + gradient evaluation, predictions, read-backs)
+            g_last_variant = 5 | 1 << 8 | 1 << 11;
+            return launch_forward<5, true, false, 2>(a, (unsigned)chunks, lds_bytes, stream);
+        }
     }
     g_last_variant = ns | (s16_all ? 1 << 8 : 0) | (big ? 1 << 9 : 0);
     switch (ns) {
@@ -2578,7 +2588,7 @@ extern "C" int iwvi_dgp_forward(const iwvi_layer_desc* layers, int n_layers, con
 /* diagnostic (not part of the drop-in surface): register a device buffer of 128 * max_workgroups 64-bit words;
  * every fused-forward launch with at most max_workgroups workgroups then stamps its phase boundaries
  * ([k] 100 MHz wall clock, [64 + k] shader clock) into it.  NULL switches stamping off. */
-/* diagnostic: the k_dgp_forward variant of the last launch -- sub-tiles per workgroup | S16 << 8 | BIG << 9 | LEAN << 10 (tests/test_gpu_lean_variant.py) */
+/* diagnostic: the k_dgp_forward variant of the last launch -- sub-tiles per workgroup | S16 << 8 | BIG << 9 | LEAN << 10 | (shapes compiled in, outputs kept) << 11 (tests/test_gpu_lean_variant.py) */
 extern "C" int iwvi_debug_last_forward_variant(void) { return iwvi::g_last_variant; }
 extern "C" void iwvi_debug_set_exit(int phase) { iwvi::g_dbg_exit = phase; }   /* diagnostic: fused-forward launches return after phase N */
 extern "C" void iwvi_debug_set_stamps(void* buf, int64_t max_workgroups) {

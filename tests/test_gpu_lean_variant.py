@@ -12,7 +12,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-LEAN_BIT, S16_BIT = 1 << 10, 1 << 8
+LEAN_BIT, S16_BIT, SHAPES_BIT = 1 << 10, 1 << 8, 1 << 11      # (bit 11: the variant with the same shapes compiled in that keeps outputs and the general tail)
 
 
 def _last_variant():
@@ -52,7 +52,7 @@ def test_lean_variant_equals_the_general_variant_on_the_same_draws(gpu_device, K
     e_lean, lp_lean, lw_lean, v_lean = _evaluate(model, spec, force_general=False)
     e_gen, lp_gen, lw_gen, v_gen = _evaluate(model, spec, force_general=True)
     assert v_lean & LEAN_BIT and (v_lean & 0xff) == 5, "the bench shape must take the LEAN variant (%#x)" % v_lean
-    assert not (v_gen & LEAN_BIT) and v_gen & S16_BIT
+    assert not (v_gen & (LEAN_BIT | SHAPES_BIT)) and v_gen & S16_BIT       # (IWVI_FW_NO_LEAN: the fully general variant)
     assert np.isfinite(lw_lean).all()
     # per-sample log-weights: the same arithmetic in both -- identical bits
     np.testing.assert_array_equal(lw_lean, lw_gen)
@@ -78,7 +78,7 @@ def test_shapes_outside_the_variant_take_the_general_one(gpu_device, why, kw):
     assert np.isfinite(e) and np.isfinite(lw).all()
 
 
-def test_requested_layer_outputs_take_the_general_variant(gpu_device):
+def test_requested_layer_outputs_take_the_variant_that_keeps_them(gpu_device):
     from dgps_with_iwvi_amd import settings, synthetic
     spec = synthetic.make_spec(L=2, M=128, B=1024, K=20, with_lv=True, seed=0, n_data=65536)
     settings.set_seed(5)
@@ -88,7 +88,7 @@ def test_requested_layer_outputs_take_the_general_variant(gpu_device):
     model._fused_forward(B * K, K, B, (B, K), zs=None, sampled_kl=True, want_layers=True,
                          elbo=dict(B=B, K=K, stride_b=K, stride_k=1, mode_vi=False))
     torch.cuda.synchronize()
-    assert not (_last_variant() & LEAN_BIT)
+    assert not (_last_variant() & LEAN_BIT) and (_last_variant() & SHAPES_BIT)
 
 
 def test_lean_variant_against_the_oracle_at_the_bench_shape(gpu_device):
