@@ -118,3 +118,33 @@ def test_lean_variant_against_the_oracle_at_the_bench_shape(gpu_device):
     m_o = L_NK.max(1)
     np.testing.assert_allclose(lp_lean, m_o + np.log(np.exp(L_NK - m_o[:, None]).sum(1)) - np.log(K), rtol=2e-4, atol=2e-2)
     np.testing.assert_allclose(lw_lean, L_NK, rtol=2e-4, atol=2e-2)
+
+
+def test_the_variant_that_keeps_outputs_equals_the_general_variant(gpu_device):
+    """Mode 2 (shapes compiled in, per-layer outputs and the general tail kept: the forward of a value + gradient evaluation) against the fully
+    general variant on the same draws: every per-layer output, every saved operand of the adjoint and the log-weights, bit for bit."""
+    from dgps_with_iwvi_amd import _abi, settings, synthetic
+    spec = synthetic.make_spec(L=2, M=128, B=1024, K=20, with_lv=True, seed=7, n_data=65536)
+    B, K = spec["B"], spec["K"]
+    settings.set_seed(11)
+    model = synthetic.build_model(spec, gpu_device)
+    got = []
+    for force_general in (False, True):
+        model._words().zero_()
+        model.precompute(with_encoders=True)
+        _abi.set_debug_option("IWVI_FW_NO_LEAN", 1 if force_general else 0)
+        try:
+            lw, outs, red = model._fused_forward(B * K, K, B, (B, K), zs=None, sampled_kl=True, want_layers=True, want_saved=True,
+                                                 elbo=dict(B=B, K=K, stride_b=K, stride_k=1, mode_vi=False))
+            torch.cuda.synchronize()
+            v = _last_variant()
+        finally:
+            _abi.set_debug_option("IWVI_FW_NO_LEAN", 0)
+        assert bool(v & SHAPES_BIT) == (not force_general) and not (v & LEAN_BIT)
+        got.append((lw.clone(), [{k: t.clone() for k, t in o.items()} for o in outs], float(red[0])))
+    (lw_a, outs_a, e_a), (lw_b, outs_b, e_b) = got
+    assert torch.equal(lw_a, lw_b) and e_a == e_b
+    for oa, ob in zip(outs_a, outs_b):
+        assert oa.keys() == ob.keys()
+        for k in oa:
+            assert torch.equal(oa[k], ob[k]), k
