@@ -2882,7 +2882,7 @@ extern "C" int iwvi_natgrad_step(float* q_mu, float* q_sqrt, const float* dq_mu,
     if (!q_mu || !q_sqrt || !dq_mu || !dq_sqrt || !ws_ || M <= 0 || M > IWVI_MAX_M || R <= 0 || R > IWVI_MAX_R) { set_error("iwvi_natgrad_step: bad argument"); return IWVI_ERR_ARG; }
     hipStream_t st = (hipStream_t)stream_;
     {   // M <= 128: the whole step in one workgroup per latent GP (csrc/precompute.hip: k_natgrad_small)
-        const int rcs = natgrad_small(q_mu, q_sqrt, dq_mu, dq_sqrt, M, R, gamma, st);
+        const int rcs = natgrad_small(q_mu, q_sqrt, dq_mu, dq_sqrt, M, R, gamma, st, ws_, iwvi_natgrad_ws_bytes(M));
         if (rcs != 0) return rcs == 1 ? IWVI_OK : rcs;
     }
     char* base = (char*)ws_; size_t o = 0;

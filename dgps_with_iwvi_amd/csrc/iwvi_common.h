@@ -13,7 +13,7 @@ int check_launch(const char* what);
 // development route switch (csrc/abi.hip; set by iwvi_debug_set_option, 0 by default): the library never reads the environment
 int dbg_opt(const char* name);
 // the natural-gradient step in one workgroup per latent GP (csrc/precompute.hip); 1 = launched, 0 = shape not covered, < 0 = error
-int natgrad_small(float* q_mu, float* q_sqrt, const float* dq_mu, const float* dq_sqrt, int M, int R, double gamma, hipStream_t st);
+int natgrad_small(float* q_mu, float* q_sqrt, const float* dq_mu, const float* dq_sqrt, int M, int R, double gamma, hipStream_t st, void* ws, size_t ws_bytes);
 
 __host__ __device__ static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 

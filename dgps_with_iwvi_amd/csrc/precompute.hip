@@ -242,8 +242,42 @@ __global__ __launch_bounds__(1024) void k_chol_only(const double* A, double* Lou
 //   5  L' = L W,                 W[k][j] = C^-1[M-1-j][M-1-k]         (block products, held in registers until every wave has read L)
 // blockIdx.x = latent GP r.  Lbar = -dq_sqrt, mbar = -dq_mu (the ELBO is maximised).
 using f32x4g = __attribute__((ext_vector_type(4))) float;
+// one 16 x 16 block (bi, bj) of Qrev by one wave, written to block storage at `dst` (LDS or global): 16 x 16 x M on the float64 matrix cores
+__device__ __forceinline__ void ng_q_block(const float* __restrict__ Lf, const float* __restrict__ Gf, int M, double gamma, int bi, int bj, int lane, double* dst) {
+    const int ri = lane & 15, g = lane >> 4;
+    const int ig = NB * bi + ri, jg = NB * bj + ri;          // this lane's A row (i) and B column (j)
+    const int q = M - 1 - ig, p = M - 1 - jg;
+    int k0 = M - 1 - (NB * bj + NB - 1); if (k0 < 0) k0 = 0; k0 &= ~3;
+    f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+    for (int kb = k0; kb < M; kb += 64) {                    // 16 k-steps' operands per round trip (32 would not fit 128 VGPRs)
+        double av[16], bv[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int k = kb + 4 * u + g;
+            av[u] = (k < M && q >= 0 && k >= q) ? (double)Gf[(size_t)k * M + q] : 0.0;     // A[i][k] = dq[k][q]
+            bv[u] = (k < M && p >= 0 && k >= p) ? (double)Lf[(size_t)k * M + p] : 0.0;     // B[k][j] = L[k][p]
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) if (kb + 4 * u < M) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[u], acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {                            // acc[e] = C[g + 4e][ri]
+        const int i = NB * bi + g + 4 * e, j = NB * bj + ri;
+        double v = (i == j) ? 1.0 : 0.0;
+        if (i < M && j < M) v -= gamma * acc[e];
+        dst[(g + 4 * e) * BLD + ri] = v;
+    }
+}
+// step 1 on many CUs (one wave per block, grid (blocks, R)): in the one-workgroup kernel it is 36 x 32 float64 MFMAs of 64 clocks on
+// four SIMDs -- 20 of its 91 us.  The blocks go to the step's workspace in block storage; k_natgrad_small copies them into LDS.
+__global__ __launch_bounds__(64) void k_ng_qbuild(const float* __restrict__ q_sqrt, const float* __restrict__ dq_sqrt, int M, double gamma, double* __restrict__ qws, int ntri) {
+    const int o = blockIdx.x, r = blockIdx.y;
+    int bi = 0; while ((bi + 1) * (bi + 2) / 2 <= o) ++bi;
+    const int bj = o - bi * (bi + 1) / 2;
+    ng_q_block(q_sqrt + (size_t)r * M * M, dq_sqrt + (size_t)r * M * M, M, gamma, bi, bj, threadIdx.x, qws + (size_t)r * ntri * BLK + boff(bi, bj));
+}
 __global__ __launch_bounds__(1024) void k_natgrad_small(float* q_mu, float* q_sqrt, const float* __restrict__ dq_mu, const float* __restrict__ dq_sqrt,
-                                                        int M, int R, double gamma, int stop) {
+                                                        int M, int R, double gamma, int stop, const double* __restrict__ qws) {
     const int tid = threadIdx.x, nthreads = blockDim.x, lane = tid & 63, wave = tid >> 6, nw = nthreads >> 6;
     const int r = blockIdx.x, Mp = round_up(M, NB);
     const WsLayout w = ws_layout(Mp);
@@ -262,30 +296,13 @@ __global__ __launch_bounds__(1024) void k_natgrad_small(float* q_mu, float* q_sq
     auto tri_decode = [](int o, int& bi, int& bj) { bi = 0; while ((bi + 1) * (bi + 2) / 2 <= o) ++bi; bj = o - bi * (bi + 1) / 2; };
 
     // ---- 1: Qrev(bi, bj)[i][j] = delta - gamma * sum_k L[k][p] dq[k][q],  p = M-1-(16bj+j), q = M-1-(16bi+i)   (p >= q on and below the diagonal)
+    if (qws) {                                                // formed by k_ng_qbuild on many CUs: copy the lower blocks (same storage order)
+        const double* src = qws + (size_t)r * ntri * BLK;
+        for (int i = tid; i < ntri * BLK; i += nthreads) blk[i] = src[i];
+    } else
     for (int o = wave; o < ntri; o += nw) {
         int bi, bj; tri_decode(o, bi, bj);
-        const int ig = NB * bi + ri, jg = NB * bj + ri;      // this lane's A row (i) and B column (j)
-        const int q = M - 1 - ig, p = M - 1 - jg;
-        int k0 = M - 1 - (NB * bj + NB - 1); if (k0 < 0) k0 = 0; k0 &= ~3;
-        f64x4 acc = {0.0, 0.0, 0.0, 0.0};
-        for (int kb = k0; kb < M; kb += 64) {                // 16 k-steps' operands per round trip (32 would not fit 128 VGPRs)
-            double av[16], bv[16];
-#pragma unroll
-            for (int u = 0; u < 16; ++u) {
-                const int k = kb + 4 * u + g;
-                av[u] = (k < M && q >= 0 && k >= q) ? (double)Gf[(size_t)k * M + q] : 0.0;     // A[i][k] = dq[k][q]
-                bv[u] = (k < M && p >= 0 && k >= p) ? (double)Lf[(size_t)k * M + p] : 0.0;     // B[k][j] = L[k][p]
-            }
-#pragma unroll
-            for (int u = 0; u < 16; ++u) if (kb + 4 * u < M) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[u], acc, 0, 0, 0);
-        }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {                        // acc[e] = C[g + 4e][ri]
-            const int i = NB * bi + g + 4 * e, j = NB * bj + ri;
-            double v = (i == j) ? 1.0 : 0.0;
-            if (i < M && j < M) v -= gamma * acc[e];
-            blk[boff(bi, bj) + (g + 4 * e) * BLD + ri] = v;
-        }
+        ng_q_block(Lf, Gf, M, gamma, bi, bj, lane, blk + boff(bi, bj));
     }
     // the vectors' inputs meanwhile
     if (tid < Mp) { va[tid] = tid < M ? (double)q_mu[(size_t)tid * R + r] : 0.0; vb[tid] = tid < M ? -(double)dq_mu[(size_t)tid * R + r] : 0.0; }
@@ -420,7 +437,7 @@ __global__ __launch_bounds__(1024) void k_natgrad_small(float* q_mu, float* q_sq
 }
 
 // host side: 0 if the shape is not covered (the caller then takes the multi-launch path)
-int natgrad_small(float* q_mu, float* q_sqrt, const float* dq_mu, const float* dq_sqrt, int M, int R, double gamma, hipStream_t st);
+int natgrad_small(float* q_mu, float* q_sqrt, const float* dq_mu, const float* dq_sqrt, int M, int R, double gamma, hipStream_t st, void* ws, size_t ws_bytes);
 
 static int ensure_lds_attr(const void* fn, size_t bytes) {
     // remember the largest size configured per kernel: hipFuncSetAttribute is not a stream operation and
@@ -440,13 +457,21 @@ static int ensure_lds_attr(const void* fn, size_t bytes) {
 }
 
 
-int natgrad_small(float* q_mu, float* q_sqrt, const float* dq_mu, const float* dq_sqrt, int M, int R, double gamma, hipStream_t st) {
+int natgrad_small(float* q_mu, float* q_sqrt, const float* dq_mu, const float* dq_sqrt, int M, int R, double gamma, hipStream_t st, void* ws, size_t ws_bytes) {
     const int Mp = round_up(M, NB);
     if (Mp > 128 || dbg_opt("IWVI_NATGRAD_UNFUSED")) return 0;
     const size_t lds = sizeof(double) * ((size_t)Mp + ws_layout(Mp).total + 4 * (size_t)Mp + 16 * 128);
     int rc;
     if ((rc = ensure_lds_attr((const void*)k_natgrad_small, lds)) != IWVI_OK) return rc;
-    hipLaunchKernelGGL(k_natgrad_small, dim3(R), dim3(1024), lds, st, q_mu, q_sqrt, dq_mu, dq_sqrt, M, R, gamma, dbg_opt("IWVI_NG_STOP"));
+    // step 1 (Qrev) on many CUs first, when the workspace holds the R block images
+    const int nbk = Mp / NB, ntri = nbk * (nbk + 1) / 2;
+    double* qws = nullptr;
+    if (ws && (size_t)R * ntri * BLK * sizeof(double) <= ws_bytes && !dbg_opt("IWVI_NG_STOP")) {
+        qws = (double*)ws;
+        hipLaunchKernelGGL(k_ng_qbuild, dim3(ntri, R), dim3(64), 0, st, (const float*)q_sqrt, dq_sqrt, M, gamma, qws, ntri);
+        if ((rc = check_launch("k_ng_qbuild")) != IWVI_OK) return rc;
+    }
+    hipLaunchKernelGGL(k_natgrad_small, dim3(R), dim3(1024), lds, st, q_mu, q_sqrt, dq_mu, dq_sqrt, M, R, gamma, dbg_opt("IWVI_NG_STOP"), (const double*)qws);
     rc = check_launch("k_natgrad_small");
     return rc == IWVI_OK ? 1 : rc;
 }
