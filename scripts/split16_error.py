@@ -32,3 +32,27 @@ for name, cfg in CASES:
         dv = float(np.abs(fvar.double().cpu().numpy() - vo).max())
         print("%-32s %-10s %12.3e %12.3e %14.3e" % (name, mode, dm, dv, abs(elbo - ref) / abs(ref)))
 settings.fw_f32_stage2 = False
+
+# the ill-conditioned family: M = 160 .. 256 inducing points in a ONE-dimensional box -- K_uu numerically rank-deficient,
+# cond(Lm) >> 1e3; the super-block solve multiplies by explicit 128 x 128 inverses from M = 256 (nbk >= 16), the column-at-a-time solve runs
+# below.  Both arithmetic modes against float64; the suite's tolerance for this family is 5e-3 on the ELBO (tests/test_gpu_random_sweep.py).
+print()
+print("%-32s %-10s %12s %12s %14s" % ("1-D inputs, L=2, K=10, B=16", "stage 2", "max|d mean|", "max|d var|", "|d ELBO|/|ELBO|"))
+for M in (160, 192, 224, 256):
+    spec = synthetic.make_spec(seed=M, parity=True, n_data=4096, L=2, M=M, K=10, B=16, Dx=1, with_lv=False)
+    zs = synthetic.make_noise(spec, seed=1)
+    zd = [torch.as_tensor(z, dtype=torch.float32, device=dev) for z in zs]
+    om = build_oracle(spec)
+    ref = om.build_likelihood(oracle_noise(spec, zs))
+    _, _, means_o, covs_o, _ = om.log_weights(oracle_noise(spec, zs))
+    for mode, f32 in (("split-f16", False), ("fp32", True)):
+        settings.fw_f32_stage2 = f32
+        m = synthetic.build_model(spec, dev)
+        elbo = float(m.compute_log_likelihood(zd))
+        fmean, fvar, _, _, _, means, covs = m._forward_iw(zd)
+        dm = max(float(np.abs(mm.double().cpu().numpy() - mo).max()) for mm, mo in zip(means[:-1], means_o[:-1]))
+        dm = max(dm, float(np.abs(fmean.double().cpu().numpy() - means_o[-1]).max()))
+        vo = np.diagonal(covs_o[-1], axis1=-2, axis2=-1).transpose(0, 2, 1)
+        dv = float(np.abs(fvar.double().cpu().numpy() - vo).max())
+        print("%-32s %-10s %12.3e %12.3e %14.3e" % ("M = %d" % M, mode, dm, dv, abs(elbo - ref) / abs(ref)))
+settings.fw_f32_stage2 = False
