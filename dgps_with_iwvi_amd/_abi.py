@@ -179,9 +179,8 @@ PROTOTYPES = {
     "iwvi_fill_normal_dev": (c_int, [c_void_p, c_int64, ctypes.c_uint64, c_void_p, c_void_p]),
 }
 
-DEBUG_OPTIONS = ("IWVI_BW_SMALL_TILES", "IWVI_BW_UNFUSED", "IWVI_BW_FUSED", "IWVI_BW_S16_SMALL_M", "IWVI_BW_OLD_CHAIN",
-                 "IWVI_BW_CHAIN_SMALL_M_ONLY", "IWVI_BW_CHAIN_M256_ONLY", "IWVI_BW_CHAIN_NS2", "IWVI_BW_GEMM_PRODUCTS", "IWVI_DMM_LDS",
-                 "IWVI_CHAIN_EXIT", "IWVI_FW_SLOW_TAIL", "IWVI_NATGRAD_UNFUSED", "IWVI_NG_STOP", "IWVI_DEBUG_STOP", "IWVI_PRE_STAMP_P", "IWVI_FW_NO_LEAN")
+DEBUG_OPTIONS = ("IWVI_BW_FUSED", "IWVI_CHAIN_EXIT", "IWVI_FW_SLOW_TAIL", "IWVI_NATGRAD_UNFUSED", "IWVI_NG_STOP", "IWVI_DEBUG_STOP", "IWVI_PRE_STAMP_P",
+                 "IWVI_FW_NO_LEAN")
 
 
 def set_debug_option(name, value):

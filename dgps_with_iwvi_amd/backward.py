@@ -332,8 +332,6 @@ def iw_elbo_and_gradients(model, zs=None, mode_vi=None, exchange=None, K_total=N
     # beside the forward, on its own stream: dense float64 factors + the parameter-only part of every layer's adjoint
     cur = torch.cuda.current_stream()
     import os
-    if os.environ.get("IWVI_BW_SINGLE_STREAM"):                  # diagnostic: everything on the caller's stream
-        overlap = False
     if wrt not in ("all", "final_q"):
         raise ValueError("wrt is 'all' or 'final_q'")
     final_q = wrt == "final_q"

@@ -26,9 +26,8 @@ int check_launch(const char* what) {
 
 // ---- development route switches: set through iwvi_debug_set_option only (the library does not read the environment) -------------
 static const char* const g_opt_names[] = {
-    "IWVI_BW_SMALL_TILES", "IWVI_BW_UNFUSED", "IWVI_BW_FUSED", "IWVI_BW_S16_SMALL_M", "IWVI_BW_OLD_CHAIN", "IWVI_BW_CHAIN_SMALL_M_ONLY",
-    "IWVI_BW_CHAIN_M256_ONLY", "IWVI_BW_CHAIN_NS2", "IWVI_BW_GEMM_PRODUCTS", "IWVI_DMM_LDS", "IWVI_CHAIN_EXIT", "IWVI_FW_SLOW_TAIL",
-    "IWVI_NATGRAD_UNFUSED", "IWVI_NG_STOP", "IWVI_DEBUG_STOP", "IWVI_PRE_STAMP_P", "IWVI_FW_NO_LEAN"};
+    "IWVI_BW_FUSED", "IWVI_CHAIN_EXIT", "IWVI_FW_SLOW_TAIL", "IWVI_NATGRAD_UNFUSED", "IWVI_NG_STOP", "IWVI_DEBUG_STOP", "IWVI_PRE_STAMP_P",
+    "IWVI_FW_NO_LEAN"};
 constexpr int N_OPTS = (int)(sizeof(g_opt_names) / sizeof(g_opt_names[0]));
 static int g_opt_values[N_OPTS] = {0};
 static int opt_index(const char* name) {

@@ -304,7 +304,7 @@ __global__ __launch_bounds__(256) void k_gemm_big(GemmArgs g) {
 }
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 static bool use_big_tiles(const GemmArgs& g) {
-    if (g.M % BT || g.N % BT || dbg_opt("IWVI_BW_SMALL_TILES")) return false;
+    if (g.M % BT || g.N % BT) return false;
     return (long long)(g.M / BT) * (g.N / BT) * g.nsplit * g.nbatch >= 512;
 }
 // launch on the fast path if the shapes allow it; returns false otherwise (caller falls back to k_gemm)
@@ -855,7 +855,7 @@ static void launch_mid_d(hipStream_t st, const MidArgs& a, dim3 grid, size_t lds
 // returns 1 if the fused kernel was launched, 0 if the shapes do not allow it, < 0 on error
 static int launch_mid(hipStream_t st, const MidArgs& a) {
     const int M = a.M;
-    if (!a.GMV || M % 64 || M > 256 || M == 192 || a.T % 64 || a.Mp != M || dbg_opt("IWVI_BW_UNFUSED")) return 0;
+    if (!a.GMV || M % 64 || M > 256 || M == 192 || a.T % 64 || a.Mp != M) return 0;
     // measured (configs[1] / [2] / [3]): -3.5 % of the whole evaluation at M = 128, T = 20480; +7 % at T = 5120 (80 workgroups
     // for 256 CUs) and +10 % at M = 256 (105 KB of LDS: one workgroup per CU) -- so only where it wins, unless forced
     if (!dbg_opt("IWVI_BW_FUSED") && (M > 128 || a.T < 16384)) return 0;
@@ -1612,19 +1612,18 @@ static int chain_ns_cap(long long T, int cap) {             // samples per workg
 // the conservative choice (two [M x 16 NS] float tiles + staging in 160 KB of LDS for any D, R, P): what the workspace is sized for
 // phase 1 of the chain on split-f16 operands: an even number of 16-row blocks (the state then carries the scales); a third tile holds
 // the a planes, so beyond M = 256 only 16 samples fit a workgroup -- still faster than the fp32 phase 1 at 32 (configs[4]: 277 -> 240 ms per
-// value + gradient; IWVI_BW_S16_SMALL_M=1 keeps the fp32 phase 1 there)
+// value + gradient)
 // IWVI_BW_F32_CHAIN of the descriptor being served by this thread's current call (set at the entry points that take a descriptor;
 // the sizing functions, which take none, see the default -- the split-f16 chain needs the larger workspace)
 static thread_local bool t_bw_f32_chain = false;
 struct BwFlagScope { bool old; explicit BwFlagScope(int flags) : old(t_bw_f32_chain) { t_bw_f32_chain = (flags & IWVI_BW_F32_CHAIN) != 0; } ~BwFlagScope() { t_bw_f32_chain = old; } };
-static bool chain_s16(int M, int Mp) { return Mp == M && ((Mp / 16) & 1) == 0 && (M <= 256 || !dbg_opt("IWVI_BW_S16_SMALL_M")) && !t_bw_f32_chain; }
+static bool chain_s16(int M, int Mp) { return Mp == M && ((Mp / 16) & 1) == 0 && !t_bw_f32_chain; }
 static int chain_ns(long long T, int M = 128) { return chain_ns_cap(T, M <= 128 ? 5 : ((M > 256 && chain_s16(M, M)) ? 1 : 2)); }
 static bool chain_ok(int M, int Mp, long long T) {
     // M > 256: only with 32 samples per workgroup (two [M x 32] tiles; the scaled inducing inputs then stay in L2) -- at 16 every packed
     // S_r block (R * 32 * 32 KiB per layer) would be fetched from L2 for 4 MFMAs: measured 383 ms per value + gradient at configs[4]
     // against 359 ms on the GEMM path
-    return Mp == M && M <= 512 && (T % 16) == 0 && (M <= 256 || chain_ns(T, M) >= 2 || chain_s16(M, Mp)) && !dbg_opt("IWVI_BW_UNFUSED") && !dbg_opt("IWVI_BW_OLD_CHAIN") &&
-           !(M > 128 && dbg_opt("IWVI_BW_CHAIN_SMALL_M_ONLY")) && !(M > 256 && dbg_opt("IWVI_BW_CHAIN_M256_ONLY"));
+    return Mp == M && M <= 512 && (T % 16) == 0 && (M <= 256 || chain_ns(T, M) >= 2 || chain_s16(M, Mp));
 }
 // floats of the staging region beside the two tiles: what is staged there before (heads) / after (kernel adjoint: x~ rows, z~, shares)
 static bool chain_z_lds(int M) { return M <= 256; }
@@ -1645,7 +1644,7 @@ static int chain_ts(int NSAMP, int M, int D, int R, int P) { return chain_lds_by
 // implies more partial sums: the workspace (sized with chain_ns) covers both.
 static int chain_ns_shape(long long T, int M, int D, int R, int P) {
     const int base = chain_ns(T, M);
-    if (M > 128 && M <= 256 && !dbg_opt("IWVI_BW_CHAIN_NS2")) {
+    if (M > 128 && M <= 256) {
         const int ns4 = chain_ns_cap(T, 4);
         if (ns4 > base && chain_lds_bytes_ts(16 * ns4, 16 * ns4, M, D, R, P) <= 160 * 1024) return ns4;
     }
@@ -1658,7 +1657,7 @@ static size_t chain_lds_bytes(long long T, int M, int D, int R, int P) {
 static bool chain_fits(long long T, int M, int Mp, int D, int R, int P) { return chain_ok(M, Mp, T) && chain_lds_bytes(T, M, D, R, P) <= 160 * 1024; }
 // the two M x M products over samples inside the chain kernel: only while the number of per-workgroup shares stays moderate
 static bool chain_products_ok(int M, long long T) {
-    return chain_ok(M, round_up(M, 16), T) && M <= 128 && T / (16 * chain_ns(T, M)) <= 1024 && !dbg_opt("IWVI_BW_GEMM_PRODUCTS");
+    return chain_ok(M, round_up(M, 16), T) && M <= 128 && T / (16 * chain_ns(T, M)) <= 1024;
 }
 template <int NS>
 static int launch_chain_ns(hipStream_t st, ChainArgs a) {
@@ -2245,7 +2244,7 @@ __global__ __launch_bounds__(64) void k_dmm_mfma(DmmArgs a) {
 static void dmm(hipStream_t st, const double* A, long long a_si, long long a_sk, const double* B, long long b_sk, long long b_sj,
                 double* C, long long ldc, int I, int J, int K, double alpha = 1.0, const double* E = nullptr, long long lde = 0, double beta = 0.0, int post = 0) {
     DmmArgs a{A, a_si, a_sk, B, b_sk, b_sj, C, ldc, I, J, K, alpha, E, lde, beta, post};
-    if (I % 16 == 0 && J % 16 == 0 && K % 4 == 0 && !dbg_opt("IWVI_DMM_LDS")) {
+    if (I % 16 == 0 && J % 16 == 0 && K % 4 == 0) {
         hipLaunchKernelGGL(k_dmm_mfma, dim3(J / 16, I / 16), dim3(64), 0, st, a);
         return;
     }

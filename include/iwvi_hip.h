@@ -515,7 +515,7 @@ int iwvi_fill_normal(float* out, int64_t n, uint64_t seed, uint64_t offset, void
 int iwvi_fill_normal_dev(float* out, int64_t n, uint64_t seed, uint64_t* state, void* stream);
 
 /* Diagnostic / development route switches (NOT part of the drop-in surface, like iwvi_debug_set_stamps): the library itself never reads
- * the environment.  name = one of the IWVI_* route names listed in csrc/abi.hip (e.g. "IWVI_BW_UNFUSED", "IWVI_NATGRAD_UNFUSED"),
+ * the environment.  name = one of the IWVI_* route names listed in csrc/abi.hip (e.g. "IWVI_BW_FUSED", "IWVI_NATGRAD_UNFUSED"),
  * value 0 = default route.  Returns 0, or IWVI_ERR_ARG for an unknown name.  Process-wide; not for concurrent use with launches. */
 int iwvi_debug_set_option(const char* name, int value);
 
