@@ -80,6 +80,12 @@ def test_bench_single_rank_line_has_the_contract_fields(gpu_device):
     r = res["roofline"]
     assert r["bound"] in ("mfma", "hbm") and r["limiter"] in ("mfma", "hbm", "latency/issue", "unknown") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
     assert 0.0 < r["frac"] <= 1.0 and r["frac_fp32_equivalent"] >= r["frac"]       # the mix ceiling is never below the fp32-MFMA peak
+    # round 4: the GEMM phases' own utilisation (north_star's "MFMA utilisation on the batched conditional GEMMs" as a number) and the
+    # environment the line was measured in
+    g = r["gemm_phase_mfma_util"]
+    assert 0.0 < g["value"] <= 1.0 and len(g["per_layer"]) == 2 and all(0.0 < l["stage2"]["util"] <= 1.0 for l in g["per_layer"])
+    assert res["environment"]["HIP_FORCE_DEV_KERNARG"] == "1"
+    # (the `no_dev_kernarg` leg -- the same loop in a fresh process without device-resident kernel arguments -- belongs to the full line only)
 
 
 @pytest.mark.parametrize("shard", ["k", "n"])
