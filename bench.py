@@ -8,7 +8,9 @@ one minibatch already resident in HBM.  Default workload = BASELINE.json configs
 metric is quoted on): 2-layer DGP + LatentVariableLayer, M=128, K=20, batch=1024, Dx=8, Dy=1, R=5.
 
   python bench.py [--gpus N --steps K --warmup W] [--config 1..4] [--shard k|n]
-  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+      --gpus N > 1 with no WORLD_SIZE in the environment: this process starts the N rank processes itself (launch_ranks:
+      before anything touches the GPU), relays rank 0's JSON line and exits with the first non-zero rank's code
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...      (the same ranks from a launcher)
 
 Multi-GPU (weak scaling, per-GPU work fixed):
   --shard k (default): every rank holds the same B points and draws its own K importance samples
@@ -25,6 +27,8 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# multi-process GPU work on this image needs dmabuf IPC (RCCL's hipIpcGetMemHandle fails in the legacy mode); read when HIP initialises
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 import dgps_with_iwvi_amd  # noqa: F401,E402  (first: the package sets HIP_FORCE_DEV_KERNARG=1 before HIP initialises -- the product's own environment)
 
 import numpy as np  # noqa: E402
@@ -354,6 +358,88 @@ def no_dev_kernarg_leg(args):
         return {"error": "%s: %s" % (type(e).__name__, e)}
 
 
+def launch_ranks(args, argv):
+    """``--gpus N`` > 1 without a launcher: start the N rank processes from HERE -- a process that has not touched the GPU (no HIP
+    call so far: ``import torch`` and ``torch.cuda.device_count()`` do not initialise it on this image; nothing is re-exec'd) -- with the
+    environment contract of ``torch.distributed.run`` (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT), dmabuf IPC for RCCL
+    and device-resident kernel arguments.  Rank 0's stdout (the one JSON line) is relayed; the other ranks' stdout goes to stderr.
+    Returns the exit code: the first non-zero rank's (the others are then killed -- exactly the process groups started here), 124 on
+    ``--launch-timeout``."""
+    import signal
+    import socket
+    import threading
+    n = args.gpus
+    ndev = torch.cuda.device_count()
+    if args.rendezvous_only:
+        ndev = n
+    if n > ndev and not args.oversubscribe:
+        print("bench.py: --gpus %d but this node shows %d device(s); one rank per GPU.  (--oversubscribe --backend gloo puts several "
+              "ranks on one device: a plumbing run, never a measurement)" % (n, ndev), file=sys.stderr)
+        return 2
+    if n > ndev and args.backend == "nccl":
+        print("bench.py: RCCL cannot place two ranks on one device; --oversubscribe needs --backend gloo", file=sys.stderr)
+        return 2
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    base = dict(os.environ, WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                HSA_ENABLE_IPC_MODE_LEGACY="0", IWVI_BENCH_LAUNCHED="1", IWVI_BENCH_BACKEND=args.backend)
+    base.setdefault("HIP_FORCE_DEV_KERNARG", "1")
+    procs, out0 = [], []
+    for r in range(n):
+        env = dict(base, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *argv], env=env, cwd=ROOT, text=True,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, start_new_session=True))
+    reader = threading.Thread(target=lambda: out0.extend(procs[0].stdout.readlines()), daemon=True)
+    reader.start()
+
+    def kill_all():
+        for p in procs:
+            if p.poll() is None:
+                try:
+                    os.killpg(p.pid, signal.SIGKILL)             # (start_new_session: the rank's pid is its process group)
+                except ProcessLookupError:
+                    pass
+        for p in procs:
+            try:
+                p.wait(timeout=10)
+            except subprocess.TimeoutExpired:
+                pass
+
+    def on_signal(signum, frame):
+        kill_all()
+        sys.exit(128 + signum)
+    for sg in (signal.SIGTERM, signal.SIGINT):
+        signal.signal(sg, on_signal)
+    deadline = time.monotonic() + args.launch_timeout
+    rc = 0
+    while True:
+        codes = [p.poll() for p in procs]
+        bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+        if bad:
+            rc = bad[0][1] if bad[0][1] > 0 else 1
+            print("bench.py: rank %d exited with %d; stopping the other ranks" % bad[0], file=sys.stderr)
+            kill_all()
+            break
+        if all(c == 0 for c in codes):
+            break
+        if time.monotonic() > deadline:
+            print("bench.py: ranks still running after --launch-timeout %.0f s; stopping them" % args.launch_timeout, file=sys.stderr)
+            kill_all()
+            rc = 124
+            break
+        time.sleep(0.05)
+    reader.join(timeout=10)
+    lines = [l for l in out0 if l.startswith("{")]
+    for l in out0:
+        (sys.stdout if l.startswith("{") else sys.stderr).write(l)
+    sys.stdout.flush()
+    if rc == 0 and len(lines) != 1:
+        print("bench.py: rank 0 printed %d JSON lines (expected 1)" % len(lines), file=sys.stderr)
+        rc = 1
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -378,18 +464,45 @@ def main():
     ap.add_argument("--xch-every", type=int, default=0,
                     help="multi-GPU: evaluations per exchange (default: one exchange per graph replay of up to 25 evaluations; 1 = one "
                          "exchange per evaluation, what a training loop pays)")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default=os.environ.get("IWVI_BENCH_BACKEND", "nccl"),
+                    help='process-group backend: "nccl" IS RCCL on ROCm (the measured path); "gloo" only for plumbing runs')
+    ap.add_argument("--oversubscribe", action="store_true",
+                    help="plumbing only: allow more ranks than devices (rank r on device r %% device_count; needs --backend gloo)")
+    ap.add_argument("--rendezvous-only", action="store_true",
+                    help="plumbing only: every rank joins the process group (gloo, CPU tensors), all-reduces its rank and rank 0 prints "
+                         "{n_ranks_seen, rank_sum, env}; no GPU is touched -- checks the launcher and the rendezvous by themselves")
+    ap.add_argument("--launch-timeout", type=float, default=1800.0, help="self-launched ranks are stopped after this many seconds")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args, sys.argv[1:]))               # (this process never touches the GPU)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.rendezvous_only:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        t = torch.tensor([rank], dtype=torch.int64)
+        dist.all_reduce(t)
+        dist.barrier()
+        if rank == 0:
+            print(json.dumps({"rendezvous_only": True, "n_gpus": world, "n_ranks_seen": dist.get_world_size(), "rank_sum": int(t.item()),
+                              "self_launched": os.environ.get("IWVI_BENCH_LAUNCHED") == "1",
+                              "environment": {k: os.environ.get(k) for k in ("HSA_ENABLE_IPC_MODE_LEGACY", "HIP_FORCE_DEV_KERNARG",
+                                                                              "MASTER_ADDR", "LOCAL_WORLD_SIZE")}}))
+        dist.destroy_process_group()
+        return
     kernarg_leg = None
     if world == 1 and not args.no_kernarg_leg and not args.no_train_leg and os.environ.get("IWVI_BENCH_CHILD") != "1" \
             and os.environ.get("HIP_FORCE_DEV_KERNARG") == "1":
         kernarg_leg = no_dev_kernarg_leg(args)                   # (before this process's first GPU call)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm device (the HIP path has no CPU fallback)")
-    local %= torch.cuda.device_count()                           # (several ranks on one device only in plumbing tests)
+    if world > torch.cuda.device_count() and os.environ.get("IWVI_BENCH_BACKEND", args.backend) == "nccl":
+        raise SystemExit("bench.py: %d ranks on %d device(s): RCCL needs one device per rank" % (world, torch.cuda.device_count()))
+    local %= torch.cuda.device_count()                           # (several ranks on one device only in plumbing runs: gloo)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
@@ -398,13 +511,14 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        backend = os.environ.get("IWVI_BENCH_BACKEND", "nccl")   # "nccl" is RCCL on ROCm; "gloo" only for plumbing tests
+        backend = os.environ.get("IWVI_BENCH_BACKEND", args.backend)   # "nccl" is RCCL on ROCm; "gloo" only for plumbing tests
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
-    if args.gpus != world and rank == 0:
-        print("note: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
+    if args.gpus != world:
+        # a launcher started a different number of ranks than --gpus names: the line would carry an n_gpus the caller did not ask for
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (the launcher's rank count and --gpus must agree)" % (args.gpus, world))
 
     from dgps_with_iwvi_amd import _abi, settings, synthetic
     _abi.lib()                                                   # fail loudly if the extension is missing
@@ -438,10 +552,13 @@ def main():
     spg = 1
     if not args.no_graph:
         cap = int(os.environ.get("IWVI_BENCH_SPG", "25"))
+        if args.steps >= 12:
+            cap = min(cap, args.steps // 3)                      # never ONE replay as the whole timed region: >= 3 replays (at the driver's
+                                                                 # --steps 20: 4 replays of 5 evaluations; a replay's launch is ~7 us)
         if args.xch_every > 0 and (world > 1 or force_xch):
             cap = args.xch_every
         spg = max(d for d in range(1, cap + 1) if args.steps % d == 0)      # the timed region is exactly --steps evaluations
-        if spg < min(8, args.steps) and world == 1 and not force_xch:
+        if spg < min(4, args.steps) and world == 1 and not force_xch:
             spg = min(cap, args.steps)                                        # awkward --steps: full replays + a remainder launched singly
     xch = None
     if world > 1 or force_xch:
@@ -779,7 +896,9 @@ def main():
             res["two_in_flight"] = two_in_flight
         if kernarg_leg is not None:
             res["no_dev_kernarg"] = kernarg_leg
+        res["self_launched"] = os.environ.get("IWVI_BENCH_LAUNCHED") == "1"     # bench.py --gpus N started its own ranks (no torchrun)
         res["environment"] = {"HIP_FORCE_DEV_KERNARG": os.environ.get("HIP_FORCE_DEV_KERNARG"),
+                              "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY"),
                               "set_by": "dgps_with_iwvi_amd/__init__.py (setdefault at import, before HIP initialises)"}
         if med is not None:
             res.update({"ms_per_step_median": med["ms_per_step_median"], "median_protocol": med})

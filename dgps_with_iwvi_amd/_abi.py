@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libiwvi_hip.so")
 
 KERN_RBF, KERN_MATERN52 = 0, 1
 LAYER_GP, LAYER_LV = 0, 1
-ABI_VERSION = 13
+ABI_VERSION = 14
 GP_WANT_DENSE = 1
 GP_WANT_LM = 2
 LAYER_F32_STAGE2 = 1        # iwvi_layer_desc.flags
@@ -102,6 +102,10 @@ class AdamTensor(ctypes.Structure):
 PROTOTYPES = {
     "iwvi_version": (c_int, []),
     "iwvi_debug_set_option": (c_int, [ctypes.c_char_p, c_int]),
+    "iwvi_debug_last_forward_variant": (c_int, []),
+    "iwvi_debug_set_stamps": (None, [c_void_p, c_int64]),
+    "iwvi_debug_set_pre_stamps": (None, [c_void_p]),
+    "iwvi_debug_set_exit": (None, [c_int]),
     "iwvi_last_error": (ctypes.c_char_p, []),
     "iwvi_gp_state_bytes": (c_size_t, [c_int, c_int]),
     "iwvi_gp_state_offsets": (c_int, [c_int, c_int, ctypes.POINTER(c_size_t)]),

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define IWVI_ABI_VERSION 13
+#define IWVI_ABI_VERSION 14
 
 enum {
     IWVI_OK = 0,
@@ -518,6 +518,16 @@ int iwvi_fill_normal_dev(float* out, int64_t n, uint64_t seed, uint64_t* state, 
  * the environment.  name = one of the IWVI_* route names listed in csrc/abi.hip (e.g. "IWVI_BW_FUSED", "IWVI_NATGRAD_UNFUSED"),
  * value 0 = default route.  Returns 0, or IWVI_ERR_ARG for an unknown name.  Process-wide; not for concurrent use with launches. */
 int iwvi_debug_set_option(const char* name, int value);
+/* Which instantiation of the fused forward kernel the LAST iwvi_dgp_forward call of this process launched (tests assert that a shape
+ * takes / does not take the compiled-in-shapes variants): bits 0-7 sub-tiles per workgroup (NS), bit 8 split-f16 stage 2, bit 9 the
+ * large-M (M > 128) build, bits 10-11 LEAN mode (0 general, 1 bound-only, 2 with per-layer outputs), bit 12 a layer ran the float64
+ * stage-1 route.  0 before the first launch. */
+int iwvi_debug_last_forward_variant(void);
+/* In-kernel time stamps of the fused forward / of the precompute launch (128 64-bit words per workgroup; NULL switches them off) and an
+ * early exit of the fused forward after phase N -- timing scripts only (scripts/stamp_*.py, bench.py's gemm_phase_mfma_util). */
+void iwvi_debug_set_stamps(void* buf, int64_t max_workgroups);
+void iwvi_debug_set_pre_stamps(void* buf);
+void iwvi_debug_set_exit(int phase);
 
 #ifdef __cplusplus
 }

@@ -84,7 +84,7 @@ def test_bench_single_rank_line_has_the_contract_fields(gpu_device):
     # environment the line was measured in
     g = r["gemm_phase_mfma_util"]
     assert 0.0 < g["value"] <= 1.0 and len(g["per_layer"]) == 2 and all(0.0 < l["stage2"]["util"] <= 1.0 for l in g["per_layer"])
-    assert res["environment"]["HIP_FORCE_DEV_KERNARG"] == "1"
+    assert res["environment"]["HIP_FORCE_DEV_KERNARG"] == os.environ.get("HIP_FORCE_DEV_KERNARG", "1")   # (an inherited value wins over the package's default)
     # (the `no_dev_kernarg` leg -- the same loop in a fresh process without device-resident kernel arguments -- belongs to the full line only)
 
 
@@ -103,6 +103,49 @@ def test_bench_exchange_path_on_a_real_rccl_communicator(gpu_device, shard):
     assert "one exchange per replay" in res["config"]["launch"] and res["n_ranks_seen"] == 1
     assert res["check"]["all_steps_equal"] and res["check"]["rel_diff"] <= 2e-6, res["check"]
     assert np.isfinite(res["elbo"]) and res["value"] > 1e7      # (a sanity floor: > 10 M samples/s through the exchange path)
+
+
+def _bare_env():
+    """The caller's environment WITHOUT any launcher variable (and without the switches bench.py sets for its ranks)."""
+    drop = ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "IWVI_BENCH_BACKEND",
+            "HSA_ENABLE_IPC_MODE_LEGACY", "HIP_FORCE_DEV_KERNARG", "IWVI_BENCH_LAUNCHED")
+    return {k: v for k, v in os.environ.items() if k not in drop}
+
+
+@pytest.mark.parametrize("shard", ["k", "n"])
+def test_bench_gpus_2_starts_its_own_ranks(gpu_device, shard):
+    """``python bench.py --gpus 2 ...`` with NO launcher and NO launcher environment starts its own two rank
+    processes (before touching the GPU), sets dmabuf IPC + device kernel arguments for them, relays rank 0's single JSON line.
+    Both ranks share cuda:0 here (one-GPU lease), hence --oversubscribe --backend gloo; on a node it is `python bench.py --gpus 8`."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "1", "--batch", "64", "--steps", "8", "--warmup", "2",
+           "--shard", shard, "--check", "--no-cpu-baseline", "--no-train-leg", "--oversubscribe", "--backend", "gloo"]
+    p = subprocess.run(cmd, env=_bare_env(), capture_output=True, text=True, cwd=ROOT, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and p.stdout.strip() == lines[0], p.stdout          # stdout is exactly rank 0's line
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["n_ranks_seen"] == 2 and res["self_launched"] is True
+    assert res["config"]["K_per_rank"] == [5, 5] and res["config"]["K_total"] == (10 if shard == "k" else 5)
+    assert res["environment"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" and res["environment"]["HIP_FORCE_DEV_KERNARG"] == "1"
+    assert res["exchange_ms"] is not None and 0.0 < res["exchange_ms"] < 50.0 and res["evaluations_per_exchange"] == 8
+    assert res["check"]["all_steps_equal"] and res["check"]["rel_diff"] <= 2e-6, res["check"]
+    assert np.isfinite(res["value"]) and res["value"] > 0
+
+
+def test_bench_refuses_more_ranks_than_devices(gpu_device):
+    """--gpus N > device_count without the plumbing override is refused before any rank starts (one rank per GPU)."""
+    n = torch.cuda.device_count() + 1
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "4", "--warmup", "1"],
+                       env=_bare_env(), capture_output=True, text=True, cwd=ROOT, timeout=300)
+    assert p.returncode == 2 and "one rank per GPU" in p.stderr and not p.stdout.strip()
+
+
+def test_bench_self_launch_reports_a_failing_rank(gpu_device):
+    """A rank that dies takes the job down with a non-zero exit code instead of leaving its peers in a collective."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "1", "--batch", "64", "--steps", "4", "--warmup", "1",
+           "--shard", "n", "--split-k", "--no-cpu-baseline", "--no-train-leg", "--oversubscribe", "--backend", "gloo"]   # (--split-k needs --shard k)
+    p = subprocess.run(cmd, env=_bare_env(), capture_output=True, text=True, cwd=ROOT, timeout=600)
+    assert p.returncode != 0 and not [l for l in p.stdout.splitlines() if l.startswith("{")]
 
 
 def test_overlapped_exchange_slot_reuse(gpu_device):
