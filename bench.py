@@ -850,6 +850,9 @@ def main():
             traffic, traffic_src = tj["hbm_bytes"], tj["source"]
             pmc = {k: tj[k] for k in ("mfma_busy_frac", "mfma_issued_f32_tflops", "mfma_issued_f16_tflops", "mfma_pipe_frac",
                                       "kernel_avg_us_rocprof", "pmc_profile_of_commit") if k in tj}
+            # are the quoted counters OF the kernels this run timed?  (source hash recorded with the profile vs the tree's)
+            from dgps_with_iwvi_amd.kernel_resources import csrc_hash
+            pmc["pmc_profile_is_of_these_sources"] = (tj.get("csrc_sha256") == csrc_hash()) if tj.get("csrc_sha256") else None
     except Exception:
         pass
     if rank == 0:

@@ -11,7 +11,17 @@ import os as _os
 # reads them through the scalar cache first thing; from host-visible memory that first read is a PCIe round trip (measured: bench.py,
 # `no_dev_kernarg`).  Set here so that what a user of the package runs is what bench.py times -- it takes effect when this import
 # comes before the process's first HIP call (safest: before `import torch`); an explicit HIP_FORCE_DEV_KERNARG in the environment wins.
-_os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
+# It is a process-wide runtime switch (torch's and RCCL's kernels in this process see it too, child processes inherit it): set
+# IWVI_NO_ENV_DEFAULTS=1 to keep the package from touching the environment at all.
+if not _os.environ.get("IWVI_NO_ENV_DEFAULTS"):
+    if "HIP_FORCE_DEV_KERNARG" not in _os.environ:
+        _os.environ["HIP_FORCE_DEV_KERNARG"] = "1"
+        import sys as _sys
+        _t = _sys.modules.get("torch")
+        if _t is not None and _t.cuda.is_initialized():          # too late for this process: say so instead of silently doing nothing
+            import warnings as _w
+            _w.warn("dgps_with_iwvi_amd was imported after HIP initialised: HIP_FORCE_DEV_KERNARG=1 (device-resident kernel arguments, "
+                    "~1 us per layer launch) is not in effect; import the package before the first GPU call or export the variable")
 
 from . import settings  # noqa: F401
 from . import features, kernels, likelihoods, mean_functions  # noqa: F401

@@ -18,6 +18,8 @@ ABI_VERSION = 14
 GP_WANT_DENSE = 1
 GP_WANT_LM = 2
 LAYER_F32_STAGE2 = 1        # iwvi_layer_desc.flags
+LAYER_F64_STAGE1 = 2        # iwvi_layer_desc.flags: K_uf, Lm^-1 k, sigma^2 - |a|^2 of the layer in float64
+GP_F64_STAGE1 = 4           # iwvi_gp_desc.flags: prepare the state for it (dense float64 Lm^-1, plain z~)
 BW_F32_CHAIN = 1            # iwvi_gp_bwd_desc.flags
 ADAM_GRAD_F64 = 16
 MAX_STACK = 8
@@ -147,6 +149,11 @@ PROTOTYPES = {
     "iwvi_gp_layer_forward": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_float,
                                       c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
                                       c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
+    "iwvi_gp_layer_forward_ex": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_float,
+                                         c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
+                                         c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
+    "iwvi_gp_layer_fullcov_ex": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p,
+                                         c_int64, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "iwvi_gp_fullcov_ws_bytes": (c_size_t, [c_int64, c_int, c_int]),
     "iwvi_gp_layer_fullcov": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p,
                                       c_int64, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),

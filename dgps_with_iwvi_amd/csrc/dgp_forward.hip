@@ -81,6 +81,7 @@ struct alignas(16) FwGp {             // copied LDS -> registers in 16-byte piec
     unsigned short nblk[FW_WAVES];
     signed char mean_wave[2];
     signed char s16;                  // stage 2 runs on the split-f16 images: nblk counts 2-KiB slabs, LrTP / QmuP point to them
+    signed char f64;                  // IWVI_LAYER_F64_STAGE1 (host-side planning only: the kernel reads FWF_F64 of the hot descriptor)
     // the same schedule as ONE 8-byte record per wave (one LDS read at the top of the layer instead of five and a loop over row-blocks):
     // low word = offset of the run in LrTP, 16-byte units; high word = nblk | jr << 16 | jbi << 24 | (wave takes q_mu^T row-block 0 / 1) << 30 / 31
     unsigned long long s2w[FW_WAVES];
@@ -185,7 +186,8 @@ constexpr int FW_MAX_COPY = 6 * IWVI_MAX_STACK;
 // (sample / mean / var / noise / the adjoint's a, u, gmv; kl_local) stay in the LDS table and are read only when
 // FWF_ANY_OUT says there is one (never on the ELBO path).
 enum { FWF_NX_GP = 1, FWF_NX_RBF = 2, FWF_HASW = 4, FWF_HAS_MFB = 8, FWF_ANY_OUT = 16, FWF_PRE_ENC = 32, FWF_SAMPLED_KL = 64,
-       FWF_S16 = 128 };      // stage 2 on split-f16 operands (LrTP / QmuP then point to the state's slab images; iwvi_common.h: s16_*)
+       FWF_S16 = 128,        // stage 2 on split-f16 operands (LrTP / QmuP then point to the state's slab images; iwvi_common.h: s16_*)
+       FWF_F64 = 256 };      // this layer's K_uf, a = Lm^-1 k and sigma^2 - |a|^2 in float64 (IWVI_LAYER_F64_STAGE1; only the F64 kernel variants)
 struct alignas(64) FwHot {
     int type, D, c_off, z_off, flags;
     int nx_c_off, nx_nsteps, nx_ls_off, nx_ls_n;
@@ -212,10 +214,10 @@ __host__ __device__ static inline int gpc_b(int D, int P, int R) { return gpc_A(
 __host__ __device__ static inline int gpc_size(int D, int P, int R) { return gpc_b(D, P, R) + up4(P); }
 
 // scratch needs (floats) of a layer for a chunk of nsamp samples
-static inline int gp_scratch_floats(int Mp, int nbk, int R, int nsamp) {
+static inline int gp_scratch_floats(int Mp, int nbk, int R, int nsamp, bool f64 = false) {
     // one tile: the Gram tile is solved in place (a wave reads and overwrites only its own sample columns), plus
-    // the |u|^2 slots [wave][r]
-    return Mp * nsamp + FW_WAVES * R * nsamp;
+    // the |u|^2 slots [wave][r]; float64 route: + the float64 Gram tile and the waves' float64 shares of |a|^2
+    return Mp * nsamp + FW_WAVES * R * nsamp + (f64 ? 2 * Mp * nsamp + 2 * FW_WAVES * nsamp : 0);
 }
 static inline int lv_scratch_floats(int maxdim, int nsamp) { return 2 * nsamp * up4(maxdim); }
 
@@ -650,8 +652,116 @@ __device__ __forceinline__ void fw_arrive(const FwArgs& gk, float* sm, int tid, 
 // the launch variants for M <= 128 do not carry the column-at-a-time / super-block solves and the in-place plane conversion
 // LEAN (the bound's own evaluation: every GP layer RBF, every latent-variable layer's encoder evaluated by the precompute launch, all noise drawn in
 // the kernel, no per-layer output asked for, the packed arrival): none of those alternatives is compiled into the variant
-template <int NS, bool S16, bool BIG, int LEAN_MODE = 0>
+// ---- float64 stage-1 route (IWVI_LAYER_F64_STAGE1; only instantiated in the F64 kernel variants) ------------------------------------
+// The reference computes Kuf, A = Lm^-1 Kuf and Kdiag - sum A^2 in float64 (temp_workaround.py:44,51,59; settings.float_type).  With
+// K_uu ill-conditioned (cond(Lm) ~ 1e4: M >~ 100 inducing points in a 1-3-dimensional box) a float32 k alone moves the mean by 5e-4 and
+// the float32 substitution by 1e-2 .. 1e-1 (profiles/r04h_split16_error.txt); a rounded to float32 AFTER a float64 solve costs 7e-8.
+//   Gram     k[m][t] = var exp(-|z~_m - x~_t|^2 / 2) from the float32 z~ the factorisation saw (state: Zs) and the layer's float32 x~ rows,
+//            differenced and exponentiated in float64 (precompute_dev.h: exp_neg4), stored as the B operand of the product below:
+//            k64[(bk * 4 + g) * NSAMP + t][s] = k[16 bk + 4 g + s][t]
+//   solve    a = Lm^-1 k as a lower-triangular float64 product with the DENSE inverse (state: Linv, row-major; k_linv): wave w owns the
+//            block rows (p, nbk - 1 - p), p = w, w + 8, .. (nbk + 1 blocks per pair: level), all NS sub-tiles; per 16 x 16 block four
+//            v_mfma_f64_16x16x4_f64 per sub-tile.  A rows are fed PERMUTED (lane i supplies row 4 (i & 3) + (i >> 2)) so that the
+//            accumulator registers of lane (g, j) are rows 4 g .. 4 g + 3 of the block (the f64 C/D map is row = g + 4 reg): the
+//            float32 a tile stage 2 reads is written without a shuffle.
+//   |a|^2    per sample in float64, the waves' shares summed in a fixed order; the layer's variance leaves as dvar = var - |a|^2.
+template <int NS>
+__device__ __forceinline__ void f64_gram(const FwHot& G, const float* Zs, const float* xt, int XSTR, int D, float variance,
+                                         double* k64, int wave, int gq, int jq) {
+    constexpr int NSAMP = 16 * NS;
+    const int nbk = G.nbk, M = G.M;
+    for (int idx = wave; idx < nbk * NS; idx += FW_WAVES) {
+        const int bk = idx / NS, t = idx - bk * NS;
+        const int m0 = 16 * bk + 4 * gq;
+        const float* xr = xt + (16 * t + jq) * XSTR;
+        double r2[4] = {0.0, 0.0, 0.0, 0.0};
+        for (int d = 0; d < D; ++d) {
+            const double xd = (double)xr[d];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const double df = (double)Zs[(size_t)(m0 + e) * IWVI_MAX_D + d] - xd; r2[e] = fma(df, df, r2[e]); }
+        }
+        double kv[4];
+        if (G.kern_type == IWVI_KERN_RBF) {
+            double hx[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) hx[e] = 0.5 * r2[e];
+            exp_neg4(hx, kv);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) kv[e] *= (double)variance;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) kv[e] = kern_value(r2[e], G.kern_type, (double)variance);
+        }
+        double* dst = k64 + ((size_t)(bk * 4 + gq) * NSAMP + 16 * t + jq) * 4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dst[e] = (m0 + e < M) ? kv[e] : 0.0;          // padded inducing rows: k = 0
+    }
+}
+template <int NS>
+__device__ __forceinline__ void f64_solve(const FwHot& G, const double* Linv, const double* k64, f32x4* at, double* part64, float* asq,
+                                          float variance, gout1 o_a, long long t0, int nvalid, int tid, int wave, int gq, int jq) {
+    constexpr int NSAMP = 16 * NS;
+    using f64x4v = __attribute__((ext_vector_type(4))) double;
+    using f64x2v = __attribute__((ext_vector_type(2))) double;
+    const int nbk = G.nbk, Mp = G.Mp;
+    const int prow = 4 * (jq & 3) + (jq >> 2);                    // the row of a block this lane feeds as A operand (see above)
+    double ssq[NS];
+#pragma unroll
+    for (int t = 0; t < NS; ++t) ssq[t] = 0.0;
+    for (int p = wave; p < (nbk + 1) / 2; p += FW_WAVES) {
+        for (int half = 0; half < 2; ++half) {
+            const int bi = half == 0 ? p : nbk - 1 - p;
+            if (half == 1 && bi == p) break;                      // (odd block count: the middle row once)
+            typedef const __attribute__((address_space(1))) f64x2v* gptr2d;
+            gptr2d Ar = (gptr2d)(Linv + (size_t)(16 * bi + prow) * Mp + 4 * gq);
+            f64x4v acc[NS];
+#pragma unroll
+            for (int t = 0; t < NS; ++t) acc[t] = f64x4v{0.0, 0.0, 0.0, 0.0};
+            f64x2v a01 = Ar[0], a23 = Ar[1];
+            for (int bk = 0; bk <= bi; ++bk) {
+                const f64x2v c01 = a01, c23 = a23;
+                const int nx = bk + 1 <= bi ? bk + 1 : bk;
+                a01 = Ar[8 * nx]; a23 = Ar[8 * nx + 1];           // (16 doubles per block column)
+                const double* kb = k64 + ((size_t)(bk * 4 + gq) * NSAMP + jq) * 4;
+#pragma unroll
+                for (int t = 0; t < NS; ++t) {
+                    const f64x4v b = *reinterpret_cast<const f64x4v*>(kb + (size_t)64 * t);
+                    acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(c01[0], b[0], acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(c01[1], b[1], acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(c23[0], b[2], acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(c23[1], b[3], acc[t], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < NS; ++t) {
+                const int tcol = 16 * t + jq;
+                const f32x4 af = {(float)acc[t][0], (float)acc[t][1], (float)acc[t][2], (float)acc[t][3]};
+                at[(bi * 4 + gq) * NSAMP + tcol] = af;
+                ssq[t] = fma(acc[t][0], acc[t][0], fma(acc[t][1], acc[t][1], fma(acc[t][2], acc[t][2], fma(acc[t][3], acc[t][3], ssq[t]))));
+                if (o_a && tcol < nvalid) *((gout4)(o_a + (size_t)(t0 + tcol) * Mp + 16 * bi + 4 * gq)) = af;
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < NS; ++t) {                                // this wave's share of |a|^2 per sample (0 for a wave without rows)
+        double v = ssq[t];
+        v += __shfl_xor(v, 16);
+        v += __shfl_xor(v, 32);
+        if (gq == 0) part64[wave * NSAMP + 16 * t + jq] = v;
+    }
+    __syncthreads();
+    if (tid < NSAMP) {
+        double sq = 0.0;
+#pragma unroll
+        for (int w = 0; w < FW_WAVES; ++w) sq += part64[w * NSAMP + tid];
+        asq[tid] = (float)((double)variance - sq);                // dvar = sigma^2 - |a|^2, the cancellation in float64 (epilogue (i))
+        asq[NSAMP + tid] = 0.f;
+    }
+}
+
+template <int NS, bool S16, bool BIG, int LEAN_MODE = 0, bool F64 = false>
 __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
+    static_assert(!F64 || (!S16 && BIG && LEAN_MODE == 0), "the float64 stage-1 variants: fp32 stage 2, every solve form, no compiled-in shapes");
     constexpr int NSAMP = 16 * NS;
     constexpr bool SHP = LEAN_MODE != 0;     // the headline stack's shapes and sources compiled in (all RBF, M = 128, D <= 10, operands staged, encoders
                                              // precomputed, noise drawn here, whole chunks): mode 1 and mode 2
@@ -1079,7 +1189,24 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
             FW_STAMP(2 + li * 6 + 0);
             // ---- Gram: kuf block bi = kernel(Z_bi, x), written in B-operand order ---------------------------
             DBG_WSTAMP(32);
-            for (int bi = wave; bi < nbk; bi += FW_WAVES) {
+            // float64 stage-1 route (F64 variants, layers flagged IWVI_LAYER_F64_STAGE1): the Gram tile in float64, behind the |u|^2 slots
+            bool f64_l = false;
+            double* k64 = nullptr; double* part64 = nullptr;
+            const double* f64_Linv = nullptr;
+            if constexpr (F64) {
+                f64_l = (H.flags & FWF_F64) != 0;
+                if (f64_l) {
+                    k64 = reinterpret_cast<double*>(usq + (size_t)FW_WAVES * R * NSAMP);
+                    part64 = k64 + (size_t)G.Mp * NSAMP;
+                    const StateLayout sl = state_layout(G.M, R);
+                    const char* st = reinterpret_cast<const char*>(G.LsP) - sl.off_LsP;
+                    f64_Linv = reinterpret_cast<const double*>(st + sl.off_Linv);
+                    f64_gram<NS>(G, reinterpret_cast<const float*>(st + sl.off_Zs), xt, XSTR, D, g_variance, k64, wave, gq, jq);
+                    f32x4* uz = reinterpret_cast<f32x4*>(usq);      // (stage 2 fills only some of the |u|^2 slots)
+                    for (int i = tid; i < (FW_WAVES * R * NSAMP) / 4; i += FW_THREADS) uz[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+            }
+            for (int bi = wave; bi < (f64_l ? 0 : nbk); bi += FW_WAVES) {
                 f32x4 acc[NS];
 #pragma unroll
                 for (int t = 0; t < NS; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -1200,6 +1327,10 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
             // to the next column in registers, so the dependent chain never waits for LDS.
             // (five sub-tiles on four SIMDs: two solves share SIMD 0.  Cutting the fifth solve into a 2 x 2 block system over four waves paid
             // while its updates were fp32 MFMAs; with the split-f16 updates the hand-offs cost what the cut saves: measured equal, removed.)
+            if (F64 && f64_l) {
+                if constexpr (F64)
+                    f64_solve<NS>(G, f64_Linv, k64, at, part64, asq, g_variance, o_a, t0, nvalid, tid, wave, gq, jq);
+            } else
             if (BIG && nbk >= FW_SB_MIN_NBK) {
                 // ---- M >= 256: super-block solve.  Per super-block I (8 block rows): r_I = k_I - L(I, <I) a_<I (dense product,
                 // one block row per wave, in place), then a_I = (L_II)^-1 r_I (triangular product with the packed inverse of
@@ -1771,7 +1902,8 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
 #pragma unroll
                 for (int w = 0; w < FW_WAVES; ++w) u2 += usq[(w * R + r) * NSAMP + j];   // fixed order: bit-reproducible
                 const float mu = meanp[r * NSAMP + j];
-                const float v = fmaxf(g_variance - (asq[j] + asq[NSAMP + j]) + u2, 0.f);
+                // (float64 route: asq[j] already holds sigma^2 - |a|^2, differenced in float64)
+                const float v = (F64 && f64_l) ? fmaxf(asq[j] + u2, 0.f) : fmaxf(g_variance - (asq[j] + asq[NSAMP + j]) + u2, 0.f);
                 const float z = (j < nvalid) ? zl[r * NSAMP + j] : 0.f;
                 if (o_noise && j < nvalid) o_noise[(t0 + j) * R + r] = z;
                 const float gs = fmaf(z, sqrtf(v), mu);
@@ -2111,15 +2243,15 @@ static void fw_decide_fast(FwArgs& a, unsigned grid, int nsamp, int64_t T) {
                   a.h.rng_state && grid <= 511u && 2 * (int64_t)a.h.nchunks <= ws_len && E.kl_total <= 64 && !dbg_opt("IWVI_FW_SLOW_TAIL")) ? 1 : 0;
 }
 
-template <int NS, bool S16, bool BIG, int LEAN_MODE = 0>
+template <int NS, bool S16, bool BIG, int LEAN_MODE = 0, bool F64 = false>
 static int launch_forward(const FwArgs& a, unsigned grid, size_t lds_bytes, hipStream_t stream) {
     static size_t attr_set = 0;
     if (lds_bytes > attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_dgp_forward<NS, S16, BIG, LEAN_MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        hipError_t e = hipFuncSetAttribute((const void*)k_dgp_forward<NS, S16, BIG, LEAN_MODE, F64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) { set_error("hipFuncSetAttribute(k_dgp_forward, %zu B): %s", lds_bytes, hipGetErrorString(e)); return IWVI_ERR_LAUNCH; }
         attr_set = lds_bytes;
     }
-    hipLaunchKernelGGL((k_dgp_forward<NS, S16, BIG, LEAN_MODE>), dim3(grid), dim3(FW_THREADS), lds_bytes, stream, a);
+    hipLaunchKernelGGL((k_dgp_forward<NS, S16, BIG, LEAN_MODE, F64>), dim3(grid), dim3(FW_THREADS), lds_bytes, stream, a);
     return check_launch("k_dgp_forward");
 }
 
@@ -2243,7 +2375,7 @@ static size_t fw_plan_lds(FwArgs& a, int nsamp, int maxR, int maxP, bool stage_z
             G.ls_off = -1;
             if (stage_ls && G.nbk <= 8 && tri_blocks(G.nbk) * BLK16 > ls_max) ls_max = tri_blocks(G.nbk) * BLK16;
             zdims += G.R;
-            const int need = gp_scratch_floats(G.Mp, G.nbk, G.R, nsamp);
+            const int need = gp_scratch_floats(G.Mp, G.nbk, G.R, nsamp, G.f64 != 0);
             if (need > scratch) scratch = need;
         } else {
             o += up4(L.lv.enc_out ? nsamp * 2 * L.lv.Lw : L.lv.wtotal);
@@ -2386,6 +2518,10 @@ int dgp_forward_impl(const iwvi_layer_desc* layers, int n_layers, const float* X
     bool s16_all = true;                                         // ... and none asks for the fp32 variant (IWVI_LAYER_F32_STAGE2: per call, not per process)
     for (int i = 0; i < n_layers; ++i) if (layers[i].type == IWVI_LAYER_GP && (layers[i].flags & IWVI_LAYER_F32_STAGE2)) s16_all = false;
     for (int i = 0; i < n_layers; ++i) if (layers[i].type == IWVI_LAYER_GP && ((round_up(layers[i].M, 16) / 16) & 1)) s16_all = false;
+    // float64 stage-1 route (IWVI_LAYER_F64_STAGE1 on any GP layer): the F64 kernel variants -- fp32 stage 2, the flagged layers' Gram and solve in float64
+    bool f64_any = false;
+    for (int i = 0; i < n_layers; ++i) if (layers[i].type == IWVI_LAYER_GP && (layers[i].flags & IWVI_LAYER_F64_STAGE1)) f64_any = true;
+    if (f64_any) s16_all = false;
     for (int i = 0; i < n_layers; ++i) {
         const iwvi_layer_desc& d = layers[i];
         FwLayer& L = a.L[i];
@@ -2416,6 +2552,7 @@ int dgp_forward_impl(const iwvi_layer_desc* layers, int n_layers, const float* X
             a.h.var_dev[i] = d.variance_dev;
             if (d.variance_dev) a.h.var_dev_mask |= 1u << i;
             G.s16 = s16_all ? 1 : 0;
+            G.f64 = (d.flags & IWVI_LAYER_F64_STAGE1) ? 1 : 0;
             if (G.s16) { G.LrTP = (const f32x4*)(st + s.off_LrT16); G.QmuP = (const f32x4*)(st + s.off_Qmu16); }
             plan_stage2(G);
             if (d.R > maxR) maxR = d.R;
@@ -2515,6 +2652,7 @@ int dgp_forward_impl(const iwvi_layer_desc* layers, int n_layers, const float* X
             { const StateLayout sl = state_layout(G.M, G.R); H.ls16_off = (int)(((long long)sl.off_Ls16 - (long long)sl.off_LsP) / 16); }
             if (G.W) fl |= FWF_HASW;
             if (G.s16) fl |= FWF_S16;
+            if (G.f64) fl |= FWF_F64;
             if (G.mfb) fl |= FWF_HAS_MFB;
             if (G.a_out || G.u_out) fl |= FWF_ANY_OUT;
         } else {
@@ -2541,23 +2679,41 @@ int dgp_forward_impl(const iwvi_layer_desc* layers, int n_layers, const float* X
                                 : (big ? launch_forward<NS_, false, true>(a, (unsigned)chunks, lds_bytes, stream)     \
                                       : launch_forward<NS_, false, false>(a, (unsigned)chunks, lds_bytes, stream)))
     {   // the headline stack at the headline chunk size: the variants with its shapes and sources compiled in (k_dgp_forward: SHP / LEAN)
-        bool shp = ns == 5 && s16_all && !big && !a.h.noise_any_src && !a.h.lw_init && !a.h.x_per_sample && !g_dbg_exit && T % (16 * 5) == 0;
+        // EVERY assumption the SHP / LEAN code compiles in is a condition here (the kernel has no run-time guard of its own,
+        // and tests/test_gpu_lean_variant.py lists a shape per condition that must NOT take these variants):
+        //   nvalid = NSAMP, grid * 80 == T  <- T % 80 == 0 (whole chunks)        nbk = 8                  <- M == 128
+        //   nsteps = 3 / nx_nsteps = 3      <- D + 2 <= 12 of every GP layer      mean-function loop u < 3 <- D <= 10 (the same)
+        //   npb = 1 (one block of outputs)  <- P <= 16                            rbf, operands staged, encoders precomputed, device noise
+        bool shp = ns == 5 && s16_all && !f64_any && !big && !a.h.noise_any_src && !a.h.lw_init && !a.h.x_per_sample && !g_dbg_exit && T % (16 * 5) == 0
+                   && chunks * (16 * 5) == T;
         for (int i = 0; i < n_layers && shp; ++i) {
             const FwLayer& L = a.L[i];
             if (L.type == IWVI_LAYER_GP) {
-                const FwGp& G = L.gp;                              // M = 128 (8 blocks), D <= 10, operands staged in LDS
-                if (G.kern_type != IWVI_KERN_RBF || G.M != 128 || G.nbk != 8 || G.nsteps != 3 || G.ls_off < 0 || G.zt_off < 0) shp = false;
+                const FwGp& G = L.gp;                              // M = 128 (8 blocks), D <= 10, P <= 16, operands staged in LDS
+                if (G.kern_type != IWVI_KERN_RBF || G.M != 128 || G.nbk != 8 || G.nsteps != 3 || L.D > 10 || G.P > 16 || G.ls_off < 0 || G.zt_off < 0) shp = false;
+                if (L.nx_gp && L.nx_nsteps != 3) shp = false;
             }
             else if (!L.lv.enc_out) shp = false;
         }
-        // mode 1: the bound's own evaluation (no per-layer output, the packed arrival; its tail: one half-wave per data point)
-        bool lean = shp && a.h.e.fast && a.h.out_logw && a.h.e.K >= 5 && a.h.e.K <= 32;
+        // mode 1: the bound's own evaluation (no per-layer output, the packed arrival; its tail: one half-wave per data point, lane = sample,
+        // so a chunk must hold whole data points: K | 80 with K <= 16 samples per half-wave ... or K = 20 (4 points per chunk) -- see the tail)
+        bool lean = shp && a.h.e.fast && a.h.out_logw && a.h.e.K >= 5 && a.h.e.K <= 32 && (16 * 5) % a.h.e.K == 0;
         for (int i = 0; i < n_layers && lean; ++i) if (a.H[i].flags & FWF_ANY_OUT) lean = false;
         if (shp && !dbg_opt("IWVI_FW_NO_LEAN")) {
             if (lean) { g_last_variant = 5 | 1 << 8 | 1 << 10; return launch_forward<5, true, false, 1>(a, (unsigned)chunks, lds_bytes, stream); }
             // mode 2: the same stack with outputs and the general tail (the forward of a value + gradient evaluation, predictions, read-backs)
             g_last_variant = 5 | 1 << 8 | 1 << 11;
             return launch_forward<5, true, false, 2>(a, (unsigned)chunks, lds_bytes, stream);
+        }
+    }
+    if (f64_any) {
+        g_last_variant = ns | 1 << 9 | 1 << 12;
+        switch (ns) {
+            case 1: return launch_forward<1, false, true, 0, true>(a, (unsigned)chunks, lds_bytes, stream);
+            case 2: return launch_forward<2, false, true, 0, true>(a, (unsigned)chunks, lds_bytes, stream);
+            case 3: return launch_forward<3, false, true, 0, true>(a, (unsigned)chunks, lds_bytes, stream);
+            case 4: return launch_forward<4, false, true, 0, true>(a, (unsigned)chunks, lds_bytes, stream);
+            default: return launch_forward<5, false, true, 0, true>(a, (unsigned)chunks, lds_bytes, stream);
         }
     }
     g_last_variant = ns | (s16_all ? 1 << 8 : 0) | (big ? 1 << 9 : 0);

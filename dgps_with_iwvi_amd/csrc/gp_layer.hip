@@ -21,6 +21,7 @@ __device__ __forceinline__ float kern_value_f32(float r2, int type, float var) {
 
 constexpr int FULLCOV_ROWS = 32;
 // cov[s][r][i][j] = k(x_si, x_sj) - a_si . a_sj + u_rsi . u_rsj      (temp_workaround.py:45,56,83)
+template <bool F64>
 __global__ __launch_bounds__(256) void k_fullcov(const float* __restrict__ F, const float* __restrict__ invls,
                                                  const float* __restrict__ a, const float* __restrict__ u,
                                                  float* __restrict__ cov, long long S, int N, int D, int Mp,
@@ -37,6 +38,28 @@ __global__ __launch_bounds__(256) void k_fullcov(const float* __restrict__ F, co
     for (long long idx = (long long)i_lo * N + threadIdx.x; idx < (long long)i_hi * N; idx += blockDim.x) {
         const int i = (int)(idx / N), jx = (int)(idx - (long long)i * N);
         if (jx > i) continue;
+        if constexpr (F64) {
+            // float64 route (IWVI_LAYER_F64_STAGE1): the entry is a difference of O(sigma^2) terms -- formed and summed in float64 from the
+            // float32 a (rounded behind a float64 solve) and u rows
+            double r2 = 0.0;
+            for (int d = 0; d < D; ++d) {
+                const double df = ((double)F[((size_t)s * N + i) * D + d] - (double)F[((size_t)s * N + jx) * D + d]) * (double)invls[d];
+                r2 = fma(df, df, r2);
+            }
+            double acc;
+            if (kern_type == IWVI_KERN_MATERN52) {
+                const double s5 = 2.23606797749978969641, r = sqrt(r2 + 1e-12);
+                acc = (double)variance * (1.0 + s5 * r + (5.0 / 3.0) * r * r) * exp(-s5 * r);
+            } else acc = (double)variance * exp(-0.5 * r2);
+            const float* ai = as + (size_t)i * Mp; const float* aj = as + (size_t)jx * Mp;
+            const float* ui = us + (size_t)i * Mp; const float* uj = us + (size_t)jx * Mp;
+            double da = 0.0, du = 0.0;
+            for (int m = 0; m < Mp; ++m) { da = fma((double)ai[m], (double)aj[m], da); du = fma((double)ui[m], (double)uj[m], du); }
+            const float o = (float)(acc - da + du);
+            out[(size_t)i * N + jx] = o;
+            out[(size_t)jx * N + i] = o;
+            continue;
+        }
         float r2 = 0.f;
         for (int d = 0; d < D; ++d) {
             float df = (F[((size_t)s * N + i) * D + d] - F[((size_t)s * N + jx) * D + d]) * invls[d];
@@ -118,7 +141,7 @@ static int layer_forward_impl(const void* state, int M, int D, int R, int P, int
                               const float* F, const float* noise, const float* W,
                               int mf_type, const float* mf_A, const float* mf_b,
                               float* sample, float* mean, float* var, float* a_out, float* u_out,
-                              int64_t T, int bcast_K, hipStream_t stream) {
+                              int64_t T, int bcast_K, int layer_flags, hipStream_t stream) {
     if (T <= 0) return IWVI_OK;                         // empty batch: nothing to do
     if (!state || !F) { set_error("iwvi_gp_layer_forward: null state or input"); return IWVI_ERR_ARG; }
     if (bcast_K < 1 || T % bcast_K != 0) { set_error("iwvi_gp_layer_forward: T=%lld is not a multiple of bcast_K=%d", (long long)T, bcast_K); return IWVI_ERR_ARG; }
@@ -128,6 +151,7 @@ static int layer_forward_impl(const void* state, int M, int D, int R, int P, int
     d.mf_type = mf_type; d.variance = variance; d.W = W; d.mf_A = mf_A; d.mf_b = mf_b;
     d.noise = noise; d.sample = sample; d.mean = mean; d.var = var; d.a_out = a_out; d.u_out = u_out;
     d.zero_noise = 1;        // noise == NULL means z = 0 for this entry point (include/iwvi_hip.h)
+    d.flags = layer_flags;
     return dgp_forward_impl(&d, 1, F, D, nullptr, 0, nullptr, 0, T, bcast_K, T / bcast_K, 1.f, 0, nullptr, nullptr, nullptr, stream);
 }
 
@@ -135,12 +159,18 @@ static int layer_forward_impl(const void* state, int M, int D, int R, int P, int
 
 using namespace iwvi;
 
+extern "C" int iwvi_gp_layer_forward_ex(const void* state, int M, int D, int R, int P, int kern_type, float variance,
+                                        const float* F, const float* noise, const float* W,
+                                        int mf_type, const float* mf_A, const float* mf_b,
+                                        float* sample, float* mean, float* var, int64_t T, int bcast_K, int layer_flags, void* stream) {
+    return layer_forward_impl(state, M, D, R, P, kern_type, variance, F, noise, W, mf_type, mf_A, mf_b,
+                              sample, mean, var, nullptr, nullptr, T, bcast_K, layer_flags, (hipStream_t)stream);
+}
 extern "C" int iwvi_gp_layer_forward(const void* state, int M, int D, int R, int P, int kern_type, float variance,
                                      const float* F, const float* noise, const float* W,
                                      int mf_type, const float* mf_A, const float* mf_b,
                                      float* sample, float* mean, float* var, int64_t T, int bcast_K, void* stream) {
-    return layer_forward_impl(state, M, D, R, P, kern_type, variance, F, noise, W, mf_type, mf_A, mf_b,
-                              sample, mean, var, nullptr, nullptr, T, bcast_K, (hipStream_t)stream);
+    return iwvi_gp_layer_forward_ex(state, M, D, R, P, kern_type, variance, F, noise, W, mf_type, mf_A, mf_b, sample, mean, var, T, bcast_K, 0, stream);
 }
 
 extern "C" size_t iwvi_gp_fullcov_ws_bytes(int64_t T, int M, int R) {
@@ -153,6 +183,12 @@ extern "C" int iwvi_gp_layer_fullcov(const void* state, int M, int D, int R, int
                                      const float* F, int64_t S, int64_t N,
                                      int mf_type, const float* mf_A, const float* mf_b,
                                      float* mean, float* cov, void* ws, void* stream_) {
+    return iwvi_gp_layer_fullcov_ex(state, M, D, R, kern_type, variance, F, S, N, mf_type, mf_A, mf_b, mean, cov, ws, 0, stream_);
+}
+extern "C" int iwvi_gp_layer_fullcov_ex(const void* state, int M, int D, int R, int kern_type, float variance,
+                                        const float* F, int64_t S, int64_t N,
+                                        int mf_type, const float* mf_A, const float* mf_b,
+                                        float* mean, float* cov, void* ws, int layer_flags, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (S <= 0 || N <= 0) return IWVI_OK;
     if (!state || !F || !cov || !ws) { set_error("iwvi_gp_layer_fullcov: null pointer"); return IWVI_ERR_ARG; }
@@ -162,12 +198,17 @@ extern "C" int iwvi_gp_layer_fullcov(const void* state, int M, int D, int R, int
     float* a = (float*)ws;
     float* u = a + (size_t)T * Mp;
     int rc = layer_forward_impl(state, M, D, R, R, kern_type, variance, F, nullptr, nullptr, mf_type,
-                                mf_A, mf_b, nullptr, mean, nullptr, a, u, T, 1, stream);
+                                mf_A, mf_b, nullptr, mean, nullptr, a, u, T, 1, layer_flags, stream);
     if (rc != IWVI_OK) return rc;
     StateLayout sl = state_layout(M, R);
     const float* invls = (const float*)((const char*)state + sl.off_cst);
-    hipLaunchKernelGGL(k_fullcov, dim3((unsigned)S, (unsigned)R, (unsigned)((N + FULLCOV_ROWS - 1) / FULLCOV_ROWS)), dim3(256), 0, stream, F, invls,
-                       (const float*)a, (const float*)u, cov, (long long)S, (int)N, D, (int)Mp, R, kern_type, variance);
+    const dim3 grid((unsigned)S, (unsigned)R, (unsigned)((N + FULLCOV_ROWS - 1) / FULLCOV_ROWS));
+    if (layer_flags & IWVI_LAYER_F64_STAGE1)
+        hipLaunchKernelGGL(k_fullcov<true>, grid, dim3(256), 0, stream, F, invls,
+                           (const float*)a, (const float*)u, cov, (long long)S, (int)N, D, (int)Mp, R, kern_type, variance);
+    else
+        hipLaunchKernelGGL(k_fullcov<false>, grid, dim3(256), 0, stream, F, invls,
+                           (const float*)a, (const float*)u, cov, (long long)S, (int)N, D, (int)Mp, R, kern_type, variance);
     return check_launch("k_fullcov");
 }
 

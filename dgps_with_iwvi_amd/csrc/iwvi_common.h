@@ -65,11 +65,11 @@ __host__ __device__ static inline int sb16_slabs(int nbk) {
 }
 struct StateLayout {
     int Mp, nbk, nrb, nsteps;
-    size_t off_Lm, off_Linv, off_LsP, off_LrTP, off_QmuP, off_ZtP, off_cst, off_kl, off_ws, off_LrT16, off_Qmu16, off_Ls16, bytes;
+    size_t off_Lm, off_Linv, off_LsP, off_LrTP, off_QmuP, off_ZtP, off_cst, off_kl, off_ws, off_LrT16, off_Qmu16, off_Ls16, off_Zs, bytes;
 };
-static inline size_t align256(size_t x) { return (x + 255) & ~size_t(255); }
+__host__ __device__ static inline size_t align256(size_t x) { return (x + 255) & ~size_t(255); }
 // ZtP is sized for the largest input dimension (IWVI_MAX_D) so that the layout depends on (M, R) only
-static inline StateLayout state_layout(int M, int R) {
+__host__ __device__ static inline StateLayout state_layout(int M, int R) {
     StateLayout s;
     s.Mp = round_up(M, 16);
     s.nbk = s.Mp / 16;
@@ -94,6 +94,9 @@ static inline StateLayout state_layout(int M, int R) {
     s.off_LrT16 = o; o = align256(o + (size_t)R * s16_slabs_total(s.nbk) * 2048);
     s.off_Qmu16 = o; o = align256(o + (size_t)s.nrb * ((s.nbk + 1) / 2) * 2048);
     s.off_Ls16 = o;  o = align256(o + (size_t)sb16_slabs(s.nbk) * 2048);
+    // float64 stage-1 route (IWVI_GP_F64_STAGE1): the centred, scaled inducing inputs z~ as PLAIN float32 [Mp][IWVI_MAX_D] -- the very values
+    // the factorisation saw (ZtP holds them times log2 e, rounded again) -- written by k_f64_prep behind the precompute launch
+    s.off_Zs = o;    o = align256(o + sizeof(float) * (size_t)s.Mp * IWVI_MAX_D);
     s.bytes = o;
     return s;
 }

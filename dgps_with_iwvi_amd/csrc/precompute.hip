@@ -274,7 +274,11 @@ __global__ __launch_bounds__(64) void k_ng_qbuild(const float* __restrict__ q_sq
     const int o = blockIdx.x, r = blockIdx.y;
     int bi = 0; while ((bi + 1) * (bi + 2) / 2 <= o) ++bi;
     const int bj = o - bi * (bi + 1) / 2;
-    ng_q_block(q_sqrt + (size_t)r * M * M, dq_sqrt + (size_t)r * M * M, M, gamma, bi, bj, threadIdx.x, qws + (size_t)r * ntri * BLK + boff(bi, bj));
+    double* dst = qws + (size_t)r * ntri * BLK + boff(bi, bj);
+    ng_q_block(q_sqrt + (size_t)r * M * M, dq_sqrt + (size_t)r * M * M, M, gamma, bi, bj, threadIdx.x, dst);
+    // the block's padding column (BLD = 17 doubles per row): k_natgrad_small copies whole blocks out of this caller-allocated, never
+    // initialised workspace -- nothing reads the padding, but it should not carry whatever the allocation held
+    if (threadIdx.x < NB) for (int c = NB; c < BLD; ++c) dst[threadIdx.x * BLD + c] = 0.0;
 }
 __global__ __launch_bounds__(1024) void k_natgrad_small(float* q_mu, float* q_sqrt, const float* __restrict__ dq_mu, const float* __restrict__ dq_sqrt,
                                                         int M, int R, double gamma, int stop, const double* __restrict__ qws) {
@@ -493,6 +497,26 @@ extern "C" int iwvi_gp_state_offsets(int M, int R, size_t out[8]) {
     return IWVI_OK;
 }
 
+namespace iwvi {
+// float64 stage-1 route: z~[m][d] = fl32(fl32(Z[m][d] / l[d]) - zc[d]) -- the centred, scaled inducing inputs exactly as k_precompute
+// formed them for K_uu (precompute_dev.h: role 0; zc = the published centre, cst[32 + d]) -- as plain float32 [Mp][IWVI_MAX_D], padding 0.
+// The forward's float64 Gram differences them against x~ directly (ZtP carries log2(e) z~, rounded once more: not the same numbers).
+struct F64PrepOne { const float* Z; const float* ls; const float* cst; float* Zs; int M, Mp, D, pad_; };
+struct F64PrepAll { F64PrepOne L[IWVI_MAX_LAYERS]; int n; };
+__global__ __launch_bounds__(256) void k_f64_prep(const F64PrepAll a) {
+    const F64PrepOne& L = a.L[blockIdx.x];
+    for (int idx = threadIdx.x; idx < L.Mp * IWVI_MAX_D; idx += 256) {
+        const int m = idx / IWVI_MAX_D, d = idx - m * IWVI_MAX_D;
+        float v = 0.f;
+        if (m < L.M && d < L.D) {
+            const float zs = (float)((double)L.Z[(size_t)m * L.D + d] / (double)L.ls[d]);
+            v = zs - L.cst[32 + d];
+        }
+        L.Zs[idx] = v;
+    }
+}
+}  // namespace iwvi
+
 extern "C" int iwvi_gp_precompute(const iwvi_gp_desc* layers, int n_layers, void* stream_) {
     return iwvi_model_precompute(layers, n_layers, nullptr, 0, stream_);
 }
@@ -514,6 +538,7 @@ extern "C" int iwvi_model_precompute(const iwvi_gp_desc* layers, int n_layers, c
             const iwvi_gp_desc& d = layers[base + l];
             PreLayer& L = a.L[l];
             { const int rc = fill_pre_layer(d, base + l, L); if (rc != IWVI_OK) return rc; }
+            if (d.flags & IWVI_GP_F64_STAGE1) L.flags |= IWVI_GP_WANT_LM;      // the float64 route multiplies by the dense Lm^-1 (k_linv below)
             size_t la = factor_lds_bytes(L.Mp);
             if (la > lds) lds = la;
             if (d.R + 1 > max_roles) max_roles = d.R + 1;
@@ -574,6 +599,27 @@ extern "C" int iwvi_model_precompute(const iwvi_gp_desc* layers, int n_layers, c
             if (q.n > 0) {
                 hipLaunchKernelGGL(k_pack_ls16, dim3(grid), dim3(256), 0, stream, q);
                 if ((rc = check_launch("k_pack_ls16")) != IWVI_OK) return rc;
+            }
+        }
+        {   // layers prepared for the float64 stage-1 route (IWVI_GP_F64_STAGE1): Lm^-1 in float64 on many CUs, the plain z~ the factor saw
+            iwvi_gp_desc f64l[IWVI_MAX_LAYERS];
+            F64PrepAll fp{};
+            int nf = 0;
+            for (int l = 0; l < a.n; ++l) {
+                const iwvi_gp_desc& d = layers[base + l];
+                if (!(d.flags & IWVI_GP_F64_STAGE1)) continue;
+                const PreLayer& L = a.L[l];
+                const StateLayout sl = state_layout(L.M, L.R);
+                f64l[nf] = d;
+                F64PrepOne& o = fp.L[nf++];
+                o.Z = L.Z; o.ls = L.ls; o.cst = L.cst; o.Zs = reinterpret_cast<float*>(reinterpret_cast<char*>(L.Lm) - sl.off_Lm + sl.off_Zs);
+                o.M = L.M; o.Mp = L.Mp; o.D = L.D;
+            }
+            if (nf > 0) {
+                fp.n = nf;
+                if ((rc = iwvi_gp_dense_inverse(f64l, nf, stream_)) != IWVI_OK) return rc;
+                hipLaunchKernelGGL(k_f64_prep, dim3(nf), dim3(256), 0, stream, fp);
+                if ((rc = check_launch("k_f64_prep")) != IWVI_OK) return rc;
             }
         }
     }

@@ -46,6 +46,11 @@ class GPLayer:
         self.num_outputs = num_outputs
         self.name = name
         self._state = None
+        self.f64_stage1 = None          # None: settings.f64_stage1 decides (auto: input dimension <= 3); True / False: this layer's own choice
+
+    def uses_f64_stage1(self):
+        """Does this layer take the float64 stage-1 route (include/iwvi_hip.h: IWVI_LAYER_F64_STAGE1)?"""
+        return settings.use_f64_stage1(self._Z().shape[1], self.f64_stage1)
 
     # -- plumbing -------------------------------------------------------------------------
     def _Z(self):
@@ -85,8 +90,11 @@ class GPLayer:
         q_sqrt = _abi.dev_tensor(self.q_sqrt.contiguous(), "q_sqrt")
         if q_sqrt.shape != (self.num_outputs, self.num_inducing, self.num_inducing):
             raise ValueError("q_sqrt must be [R, M, M], got %s" % (tuple(q_sqrt.shape),))
-        return (state or self.state()).desc(_abi.dev_tensor(self._Z(), "Z"), self._base_kern(), q_mu, q_sqrt,
-                                            settings.jitter_level)
+        d = (state or self.state()).desc(_abi.dev_tensor(self._Z(), "Z"), self._base_kern(), q_mu, q_sqrt,
+                                         settings.jitter_level)
+        if self.uses_f64_stage1():
+            d.flags |= _abi.GP_F64_STAGE1        # the dense float64 Lm^-1 and the plain z~ for the forward's float64 Gram + solve
+        return d
 
     def precompute(self):
         precompute_states([self.state_desc()])
@@ -113,7 +121,7 @@ class GPLayer:
         d.M, d.D, d.R, d.P = M, D, R, P
         d.kern_type, d.mf_type = kern.kern_type, mf.mf_type
         d.variance, d.variance_dev = kern.desc_variance()
-        d.flags = _abi.LAYER_F32_STAGE2 if settings.fw_f32_stage2 else 0
+        d.flags = (_abi.LAYER_F32_STAGE2 if settings.fw_f32_stage2 else 0) | (_abi.LAYER_F64_STAGE1 if self.uses_f64_stage1() else 0)
         keep = [W]
         if W is not None:
             d.W = W.data_ptr()
@@ -140,7 +148,7 @@ class GPLayer:
         samples, mean, cov = multisample_sample_conditional(
             F, self.feature, self.kern, self.q_mu, full_cov=full_cov, q_sqrt=self.q_sqrt, white=True,
             z=z, state=self.state(), mean_function=self.mean_function,      # layers.py:46-48 fused into the kernels
-            precomputed=True, want_sample=_want_sample)
+            precomputed=True, want_sample=_want_sample, f64_stage1=self.uses_f64_stage1())
         # layers.py:44 (computed by the precompute); _kl_parts hands the model the R per-GP shares
         # so that the ELBO reduction sums them without an extra launch
         kl = self.state().kl_parts if _kl_parts else self.kl

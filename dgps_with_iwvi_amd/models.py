@@ -114,7 +114,7 @@ class DGP_VI:
         descs = [l.state_desc() for l in self.layers if isinstance(l, GPLayer)]
         if dense:                                                    # the adjoints read the dense float64 Lm, Lm^-1
             for d in descs:                                          # ("lm": the factor only; Lm^-1 by iwvi_gp_dense_inverse)
-                d.flags = _abi.GP_WANT_LM if dense == "lm" else _abi.GP_WANT_DENSE
+                d.flags |= _abi.GP_WANT_LM if dense == "lm" else _abi.GP_WANT_DENSE
         precompute_states(descs, encs)
         if dense == "lm" and descs:
             arr = (_abi.GpDesc * len(descs))(*descs)

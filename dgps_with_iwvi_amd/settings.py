@@ -16,6 +16,28 @@ _offset = 0                  # Philox counter; advanced by every draw
 # v_mfma_f32_16x16x32_f16 (default; 22 operand mantissa bits) or fp32 MFMAs.  Passed PER CALL in the descriptors
 # (iwvi_layer_desc.flags / iwvi_gp_bwd_desc.flags); the environment variables only set these defaults.
 fw_f32_stage2 = bool(os.environ.get("IWVI_FW_F32_STAGE2"))
+# float64 stage-1 route of a GP layer (iwvi_layer_desc.flags & IWVI_LAYER_F64_STAGE1 / iwvi_gp_desc.flags & IWVI_GP_F64_STAGE1): K_uf,
+# a = Lm^-1 k and sigma^2 - |a|^2 in float64 -- what the reference's float_type = float64 gives (temp_workaround.py:39-59) -- for layers whose
+# K_uu is ill-conditioned.  "auto" (default): a layer takes it when its INPUT dimension is <= f64_auto_max_dim (inducing points crowd a
+# 1-3-dimensional box: cond(Lm) ~ 1e4, float32 loses 1e-2 .. 1e-1 of the mean there; the reference's own tests and demo are 1-D) --
+# a static rule, so no launch ever waits for a condition estimate; "on" / "off" force it for every layer; GPLayer.f64_stage1 = True / False
+# overrides per layer, and models.DGP_VI.autotune_f64() sets those per-layer overrides from the measured diag(Lm) ratio.
+# The 8-dimensional BASELINE stacks never take it (tests/test_gpu_f64_route.py asserts the variant bits).
+f64_stage1 = os.environ.get("IWVI_F64_STAGE1", "auto")
+f64_auto_max_dim = 3
+
+
+def use_f64_stage1(input_dim, override=None):
+    """The rule above for one GP layer of input dimension ``input_dim`` (``override``: the layer's own True / False / None)."""
+    if override is not None:
+        return bool(override)
+    if f64_stage1 == "on":
+        return True
+    if f64_stage1 == "off":
+        return False
+    if f64_stage1 != "auto":
+        raise ValueError("settings.f64_stage1 must be 'auto', 'on' or 'off', got %r" % (f64_stage1,))
+    return int(input_dim) <= f64_auto_max_dim
 bw_f32_chain = bool(os.environ.get("IWVI_BW_F32_CHAIN"))
 
 
@@ -39,13 +61,16 @@ def set_seed(s):
 
 
 @contextlib.contextmanager
-def temp_settings(jitter=None):
+def temp_settings(jitter=None, f64_stage1=None):
     """Counterpart of ``gpflow.settings.temp_settings`` (reference tests/test_gp_layer.py:81-83)."""
     global jitter_level
-    old = jitter_level
+    old, old64 = jitter_level, globals()["f64_stage1"]
     if jitter is not None:
         jitter_level = float(jitter)
+    if f64_stage1 is not None:
+        globals()["f64_stage1"] = f64_stage1
     try:
         yield
     finally:
         jitter_level = old
+        globals()["f64_stage1"] = old64

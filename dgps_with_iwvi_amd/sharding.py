@@ -115,6 +115,7 @@ class OverlappedExchange:
         self.timed = bool(timed)
         self._t = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(depth)] if timed else None
         self._t_ms = []
+        self._t_open = [False] * depth                           # slot holds a recorded pair of events nobody has read yet
 
     def slot(self):
         return self.i % self.depth
@@ -146,8 +147,8 @@ class OverlappedExchange:
         self.i += 1
         main = torch.cuda.current_stream()
         self.ready[slot].record(main)
-        if self.timed and self.used[slot]:                       # (this slot's previous exchange has completed: before_step waited for it)
-            self._collect(slot)
+        if self.timed and self.used[slot]:                       # this slot's previous exchange: before_step only QUEUED a wait for it on the
+            self._collect(slot)                                  # device, so it may still be running -- its sample is then dropped (counted)
         self.used[slot] = True
         with torch.cuda.stream(self.comm):
             self.comm.wait_event(self.ready[slot])
@@ -163,12 +164,19 @@ class OverlappedExchange:
                 self.result.copy_(self.stage[slot], non_blocking=True)     # sums over ranks; finish() divides
             if self.timed:
                 self._t[slot][1].record(self.comm)
+                self._t_open[slot] = True
             self.done[slot].record(self.comm)
 
     def _collect(self, slot):
+        """Read a slot's pair of events ONCE (a second call before the slot is re-recorded adds nothing: no duplicate samples)."""
+        if not self._t_open[slot]:
+            return
         a, b = self._t[slot]
-        if b.query():                                            # (still running: skipped, the next use of the slot has another)
+        if b.query():
             self._t_ms.append(a.elapsed_time(b))
+        else:                                                    # still running and about to be re-recorded: this exchange is not sampled
+            self.t_dropped = getattr(self, "t_dropped", 0) + 1
+        self._t_open[slot] = False
 
     def exchange_ms(self):
         """Median side-stream time of one exchange (collective + merge kernel) over the timed submits so far; None if not timed."""

@@ -150,8 +150,12 @@ def draw_normal(shape, device):
     return out
 
 
-def _forward_diag(state, kern, D, R, F2, z2, W, mean_function, want=(True, True, True)):
-    """[T, D] -> sample/mean/var [T, P] through ``iwvi_gp_layer_forward``."""
+def _layer_flags(f64):
+    return (_abi.LAYER_F32_STAGE2 if settings.fw_f32_stage2 else 0) | (_abi.LAYER_F64_STAGE1 if f64 else 0)
+
+
+def _forward_diag(state, kern, D, R, F2, z2, W, mean_function, want=(True, True, True), f64=False):
+    """[T, D] -> sample/mean/var [T, P] through ``iwvi_gp_layer_forward_ex`` (``f64``: the float64 stage-1 route)."""
     T = F2.shape[0]
     P = W.shape[0] if W is not None else R
     dev = F2.device
@@ -163,10 +167,10 @@ def _forward_diag(state, kern, D, R, F2, z2, W, mean_function, want=(True, True,
             if tuple(mfA.shape) != (D, P):
                 raise ValueError("Linear mean function A is %s, layer needs (%d, %d)" % (tuple(mfA.shape), D, P))
             _abi.dev_tensor(mfA, "mean_function.A")
-    _abi.check(_abi.lib().iwvi_gp_layer_forward(
+    _abi.check(_abi.lib().iwvi_gp_layer_forward_ex(
         _abi.ptr(state.buf), state.M, D, R, P, kern.kern_type, kern.variance,
         _abi.ptr(F2), _abi.ptr(z2), _abi.ptr(W), mf_type, _abi.ptr(mfA), _abi.ptr(mfb),
-        _abi.ptr(outs[0]), _abi.ptr(outs[1]), _abi.ptr(outs[2]), T, 1, _abi.stream_ptr()))
+        _abi.ptr(outs[0]), _abi.ptr(outs[1]), _abi.ptr(outs[2]), T, 1, _layer_flags(f64), _abi.stream_ptr()))
     return outs
 
 
@@ -179,16 +183,18 @@ def _check_common(Xnew, full_output_cov, white, precomputed=False):
         raise ValueError("Xnew must be [N, D] or [S, N, D]")
 
 
-def _factorise(state, Z, kern, f, q_sqrt, white):
+def _factorise(state, Z, kern, f, q_sqrt, white, f64=False):
     """Fill ``state`` for q(u) = (f, q_sqrt).  white=False (reference :63-65): the extra solve with Lm^T is folded
     into the operands once -- f_w = Lm^-1 f, q_sqrt_w[r] = Lm^-1 tril(q_sqrt[r]) -- and the whitened kernels run unchanged."""
     Z = _abi.dev_tensor(Z, "Z")
     q3 = _abi.dev_tensor(_prep_q_sqrt(q_sqrt, f), "q_sqrt")
     d = state.desc(Z, kern, f, q3, settings.jitter_level)
+    if f64:
+        d.flags |= _abi.GP_F64_STAGE1
     if white:
         precompute_states([d])
         return
-    d.flags = _abi.GP_WANT_DENSE
+    d.flags |= _abi.GP_WANT_DENSE
     precompute_states([d])
     M, R = f.shape
     f_w, q_w = torch.empty_like(f), torch.empty_like(q3)
@@ -196,12 +202,15 @@ def _factorise(state, Z, kern, f, q_sqrt, white):
                                         _abi.ptr(f_w), _abi.ptr(q_w) if q_sqrt is not None else None, _abi.stream_ptr()))
     if q_sqrt is None:
         q_w.zero_()
-    precompute_states([state.desc(Z, kern, f_w, q_w, settings.jitter_level)])
+    d = state.desc(Z, kern, f_w, q_w, settings.jitter_level)
+    if f64:
+        d.flags |= _abi.GP_F64_STAGE1
+    precompute_states([d])
 
 
 def independent_multisample_sample_conditional(Xnew, feat, kern, f, *, full_cov=False, full_output_cov=False,
                                                q_sqrt=None, white=False, z=None, state=None,
-                                               mean_function=None, precomputed=False, want_sample=True):
+                                               mean_function=None, precomputed=False, want_sample=True, f64_stage1=None):
     """Multisample, single-output GP conditional (reference temp_workaround.py:12-98).
 
     :param Xnew: [S, N, D] (also accepts [N, D], the 2-D ``sample_conditional`` path of :157-161)
@@ -209,7 +218,9 @@ def independent_multisample_sample_conditional(Xnew, feat, kern, f, *, full_cov=
     :return: sample [S,N,R], mean [S,N,R], var [S,N,R] (full_cov=False) or [S,R,N,N] (full_cov=True);
              for 2-D input: [N,R], [N,R], [N,R] | [R,N,N].
     ``state``/``precomputed``/``mean_function`` are used by GPLayer to reuse the per-step factorisation
-    and to fuse the mean-function add; plain callers leave them at their defaults.  ``want_sample=False`` (full_cov
+    and to fuse the mean-function add; plain callers leave them at their defaults.  ``f64_stage1``: K_uf, Lm^-1 k and
+    Kdiag - sum A^2 (:44,51,59) in float64 like the reference's float_type (None: ``settings.f64_stage1`` decides -- by default
+    for inputs of dimension <= 3).  ``want_sample=False`` (full_cov
     only) returns None for the sample: a TF graph never evaluates an unfetched sample (models.py:89-91 fetches the
     final mean and covariance only), an eager library has to be told.
     """
@@ -223,16 +234,17 @@ def independent_multisample_sample_conditional(Xnew, feat, kern, f, *, full_cov=
     D = Xnew.shape[-1]
     if Z.shape != (M, D):
         raise ValueError("feature is %s, expected (%d, %d)" % (tuple(Z.shape), M, D))
+    f64 = settings.use_f64_stage1(D, f64_stage1)
     if state is None:
         state = GpState(M, R, Xnew.device)
     if not precomputed:
-        _factorise(state, Z, kern, f, q_sqrt, white)
+        _factorise(state, Z, kern, f, q_sqrt, white, f64)
     lead = Xnew.shape[:-1]
     F2 = Xnew.reshape(-1, D)
     T = F2.shape[0]
     if not full_cov:
         z2 = draw_normal((T, R), Xnew.device) if z is None else _abi.dev_tensor(z.reshape(T, R).contiguous(), "z")
-        s, m, v = _forward_diag(state, kern, D, R, F2, z2, None, mean_function)
+        s, m, v = _forward_diag(state, kern, D, R, F2, z2, None, mean_function, f64=f64)
         return s.view(*lead, R), m.view(*lead, R), v.view(*lead, R)
     # full covariance over the second axis (reference :45,56,83,93-96)
     S, N = (1, lead[0]) if Xnew.dim() == 2 else lead
@@ -246,9 +258,9 @@ def independent_multisample_sample_conditional(Xnew, feat, kern, f, *, full_cov=
             raise ValueError("Linear mean function A is %s, layer needs (%d, %d)" % (tuple(mfA.shape), D, R))
         if mf_type == _abi.MF_IDENTITY and D != R:
             raise ValueError("Identity mean function needs D == R")
-    _abi.check(_abi.lib().iwvi_gp_layer_fullcov(_abi.ptr(state.buf), M, D, R, kern.kern_type, kern.variance,
-                                               _abi.ptr(F2), S, N, mf_type, _abi.ptr(mfA), _abi.ptr(mfb),
-                                               _abi.ptr(mean), _abi.ptr(cov), _abi.ptr(ws), _abi.stream_ptr()))
+    _abi.check(_abi.lib().iwvi_gp_layer_fullcov_ex(_abi.ptr(state.buf), M, D, R, kern.kern_type, kern.variance,
+                                                  _abi.ptr(F2), S, N, mf_type, _abi.ptr(mfA), _abi.ptr(mfb),
+                                                  _abi.ptr(mean), _abi.ptr(cov), _abi.ptr(ws), _layer_flags(f64), _abi.stream_ptr()))
     if not want_sample:
         return (None, mean[0], cov[0]) if Xnew.dim() == 2 else (None, mean, cov)
     zz = draw_normal((S, R, N, 1), Xnew.device) if z is None else _abi.dev_tensor(z.reshape(S, R, N, 1).contiguous(), "z")
@@ -269,7 +281,7 @@ def independent_multisample_sample_conditional(Xnew, feat, kern, f, *, full_cov=
 
 def multisample_sample_conditional(Xnew, feat, kern, f, *, full_cov=False, full_output_cov=False,
                                    q_sqrt=None, white=False, z=None, state=None, mean_function=None,
-                                   precomputed=False, want_sample=True):
+                                   precomputed=False, want_sample=True, f64_stage1=None):
     """Dispatcher of reference temp_workaround.py:118-161."""
     if isinstance(kern, SharedMixedMok) and isinstance(feat, MixedKernelSharedMof):      # :123
         _check_common(Xnew, False, white, precomputed)
@@ -281,22 +293,24 @@ def multisample_sample_conditional(Xnew, feat, kern, f, *, full_cov=False, full_
         W = _abi.dev_tensor(kern.W, "W")
         if W.shape[1] != R:
             raise ValueError("W is %s but there are %d latent GPs" % (tuple(W.shape), R))
+        f64 = settings.use_f64_stage1(D, f64_stage1)
         if state is None:
             state = GpState(M, R, Xnew.device)
         if not precomputed:
-            _factorise(state, Z, base, f, q_sqrt, white)
+            _factorise(state, Z, base, f, q_sqrt, white, f64)
         lead = Xnew.shape[:-1]
         F2 = Xnew.reshape(-1, D)
         T = F2.shape[0]
         # full_cov is forced to False on this branch (reference :125-129, :134-138)
         z2 = draw_normal((T, R), Xnew.device) if z is None else _abi.dev_tensor(z.reshape(T, R).contiguous(), "z")
-        s, m, v = _forward_diag(state, base, D, R, F2, z2, W, mean_function)   # mixing fused (:142-145)
+        s, m, v = _forward_diag(state, base, D, R, F2, z2, W, mean_function, f64=f64)   # mixing fused (:142-145)
         P = W.shape[0]
         return s.view(*lead, P), m.view(*lead, P), v.view(*lead, P)
     assert not isinstance(kern, SharedMixedMok)                                          # :149
     return independent_multisample_sample_conditional(
         Xnew, feat, kern, f, full_cov=full_cov, full_output_cov=full_output_cov, q_sqrt=q_sqrt,
-        white=white, z=z, state=state, mean_function=mean_function, precomputed=precomputed, want_sample=want_sample)
+        white=white, z=z, state=state, mean_function=mean_function, precomputed=precomputed, want_sample=want_sample,
+        f64_stage1=f64_stage1)
 
 
 def gauss_kl(q_mu, q_sqrt, K=None):

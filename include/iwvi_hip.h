@@ -84,6 +84,10 @@ const char* iwvi_last_error(void);
  * ---------------------------------------------------------------------- */
 #define IWVI_GP_WANT_DENSE 1   /* iwvi_gp_desc.flags: also write the dense float64 Lm and Lm^-1 */
 #define IWVI_GP_WANT_LM    2   /* iwvi_gp_desc.flags: also write the dense float64 Lm (Lm^-1 then by iwvi_gp_dense_inverse)  */
+/* iwvi_gp_desc.flags: prepare the layer for the float64 stage-1 route of the forward (IWVI_LAYER_F64_STAGE1 below): the precompute call
+ * also leaves the dense float64 Lm and Lm^-1 (as with IWVI_GP_WANT_LM + iwvi_gp_dense_inverse, launched behind it on the same stream)
+ * and the plain float32 inducing inputs z~ the factorisation saw. */
+#define IWVI_GP_F64_STAGE1 4
 
 typedef struct iwvi_gp_desc {
     const float* Z;            /* [M, D]  inducing inputs                        */
@@ -165,6 +169,13 @@ int iwvi_gp_layer_forward(const void* state, int M, int D, int R, int P,
                           int mf_type, const float* mf_A, const float* mf_b,
                           float* sample, float* mean, float* var,
                           int64_t T, int bcast_K, void* stream);
+/* the same with iwvi_layer_desc.flags bits for the layer (IWVI_LAYER_F32_STAGE2, IWVI_LAYER_F64_STAGE1); the plain entry = flags 0 */
+int iwvi_gp_layer_forward_ex(const void* state, int M, int D, int R, int P,
+                             int kern_type, float variance,
+                             const float* F, const float* noise, const float* W,
+                             int mf_type, const float* mf_A, const float* mf_b,
+                             float* sample, float* mean, float* var,
+                             int64_t T, int bcast_K, int layer_flags, void* stream);
 
 /* Full covariance over the second axis (temp_workaround.py:45,56,83 with full_cov=True):
  *   F [S, N, D] -> mean [S, N, R] (+ the layer's mean function, layers.py:46-48: mf_type / mf_A [D, R] / mf_b [R] as
@@ -176,6 +187,12 @@ int iwvi_gp_layer_fullcov(const void* state, int M, int D, int R, int kern_type,
                           const float* F, int64_t S, int64_t N,
                           int mf_type, const float* mf_A, const float* mf_b,
                           float* mean, float* cov, void* ws, void* stream);
+/* the same with iwvi_layer_desc.flags bits.  IWVI_LAYER_F64_STAGE1: a = Lm^-1 k comes from the float64 route, and the covariance
+ * k(x_i, x_j) - a_i . a_j + u_i . u_j is differenced and accumulated in float64 before it is rounded to the float32 output. */
+int iwvi_gp_layer_fullcov_ex(const void* state, int M, int D, int R, int kern_type, float variance,
+                             const float* F, int64_t S, int64_t N,
+                             int mf_type, const float* mf_A, const float* mf_b,
+                             float* mean, float* cov, void* ws, int layer_flags, void* stream);
 
 /* The jointly Gaussian sample of the full-covariance branch (temp_workaround.py:93-96, with the intended
  * fmean_SRN1 of :95):  sample[s, n, r] = mean[s, n, r] + (chol(cov[s, r] + jitter I) z[s, r])[n].
@@ -248,6 +265,13 @@ typedef struct iwvi_layer_desc {
  * launch has an even number of 16-row blocks.  IWVI_LAYER_F32_STAGE2 on ANY GP layer of a launch makes the whole launch take the
  * fp32-MFMA variant (v_mfma_f32_16x16x4_f32). */
 #define IWVI_LAYER_F32_STAGE2 1
+/* iwvi_layer_desc.flags, per GP layer: K_uf, a = Lm^-1 k and sigma^2 - |a|^2 of THIS layer in float64 (v_mfma_f64_16x16x4_f64 against the
+ * dense float64 Lm^-1; temp_workaround.py:44,51,59 -- the reference computes all of it in float64), a rounded to float32 only behind the
+ * solve.  For ill-conditioned K_uu (many inducing points in a 1-3-dimensional box: cond(Lm) ~ 1e4, where a float32 k alone costs 5e-4 of
+ * the mean and the float32 solve 1e-2 .. 1e-1) it brings the per-layer mean / variance to ~1e-6 of the float64 reference; it costs a
+ * float64 Gram and M^2 float64 MFMA FLOPs per sample (half the fp32-MFMA rate), and the launch then runs stage 2 on fp32 MFMAs.
+ * The layer's state must have been precomputed with IWVI_GP_F64_STAGE1. */
+#define IWVI_LAYER_F64_STAGE1 2
 
 /* Optional tail of the same launch: the last workgroup to finish performs models.py:138-150 on out_logw
  * (logsumexp over K minus log K, or the mean over S of :84; sum over points * scale; minus the global KLs),

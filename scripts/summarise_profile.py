@@ -79,6 +79,12 @@ if len(sys.argv) > 2 and sys.argv[2] == "--latest":
                "mfma_issued_f16_tflops": der.get("mfma_f16_flops_per_s(MOPS*512/avg_ns)", 0.0) / 1e12,
                "mfma_pipe_frac": der.get("mfma_pipe_frac(f32/157.3T+f16/2.5P+f64/78.6T)"),
                "kernel_avg_us_rocprof": d.get("avg_ns", 0.0) / 1e3, "pmc_profile_of_commit": commit}
+        try:
+            sys.path.insert(0, os.getcwd())
+            from dgps_with_iwvi_amd.kernel_resources import csrc_hash
+            lat["csrc_sha256"] = csrc_hash()                      # the sources the profiled library was built from (git-free freshness check)
+        except Exception:
+            lat["csrc_sha256"] = None
         lat["hbm_bytes"] = (lat["hbm_read_bytes"] or 0.0) + (lat["hbm_write_bytes"] or 0.0)
         json.dump(lat, open(os.path.join("profiles", "traffic_latest.json"), "w"), indent=1)
 # the value + gradient evaluation (scripts/profile_backward.sh): its dominant kernels' entries, quoted by bench.py's training_step.roofline
