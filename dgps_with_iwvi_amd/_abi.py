@@ -153,7 +153,7 @@ PROTOTYPES = {
                                          c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
                                          c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
     "iwvi_gp_layer_fullcov_ex": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p,
-                                         c_int64, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+                                         c_int64, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "iwvi_gp_fullcov_ws_bytes": (c_size_t, [c_int64, c_int, c_int]),
     "iwvi_gp_layer_fullcov": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p,
                                       c_int64, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),

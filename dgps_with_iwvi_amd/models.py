@@ -120,6 +120,25 @@ class DGP_VI:
             arr = (_abi.GpDesc * len(descs))(*descs)
             _abi.check(_abi.lib().iwvi_gp_dense_inverse(arr, len(descs), _abi.stream_ptr()))
 
+    def autotune_f64(self, threshold=300.0):
+        """Set every GP layer's ``f64_stage1`` override from the factor itself: max / min of diag(Lm) of the CURRENT parameters (one
+        precompute with the dense factor + a read-back: a synchronisation, so it is a calibration call -- after building or loading
+        a model, every so many training steps -- not part of an evaluation).  diag(Lm) spans [sqrt(jitter), sigma] -- at most 1e3 at the default jitter and unit
+        variance.  Measured (scripts/diag_ratio.py): 14 / 28 / 85 at the BASELINE stacks (8-D, M = 128 / 256 / 512), 430 at 4-D M = 128, 820-990
+        for 1-3-D inputs at any M >= 32; the default ``threshold`` 300 separates what float32 holds at the stated tolerance from what
+        it does not (profiles/r05_f64_route_error.txt).  Returns [{layer, diag_ratio, f64_stage1}]."""
+        self.precompute()
+        rep = []
+        for i, l in enumerate(self.layers):
+            if not isinstance(l, GPLayer):
+                continue
+            d = torch.diagonal(l.state().Lm)
+            ratio = float((d.max() / d.min()).item())
+            l.f64_stage1 = bool(ratio >= threshold)
+            rep.append(dict(layer=i, diag_ratio=ratio, f64_stage1=l.f64_stage1))
+        self.precompute()                                         # (the states as an evaluation expects them: flags of the new choice)
+        return rep
+
     def propagate(self, X, full_cov=False, inference_amorization_inputs=None,
                   is_sampled_local_regularizer=False, zs=None, _precomputed=False, _kl_parts=False, _last_sample=True):
         """reference models.py:31-46 -> (samples[1:], means, covs, kls, kl_types); one launch per layer.
