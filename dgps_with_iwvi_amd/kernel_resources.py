@@ -27,12 +27,16 @@ FIELDS = ("vgpr_count", "agpr_count", "sgpr_count", "vgpr_spill_count", "sgpr_sp
 NO_SCRATCH = ("k_dgp_forward", "k_bw_chain")
 # ... except these (demangled-name substring -> bytes of scratch it is known to use; lower it when a kernel improves)
 ALLOWED_SCRATCH = {
-    # state at the start of round 5 (profiles/r05a_kernel_resources.txt): a few spilled VGPRs in variants no BASELINE config takes, in the
-    # configs[3] variant and in the value + gradient variant; none may grow.  (template arguments: NS, S16, BIG, LEAN_MODE, F64)
+    # round 5 (profiles/r05c_kernel_resources.txt): a few spilled VGPRs in variants no BASELINE config takes, in the value + gradient
+    # variant, and -- since the super-block solve keeps 2-4 operand blocks in flight per wave (worth 10 % of configs[4]) -- in the large-M
+    # variants; none may grow.  (template arguments: NS, S16, BIG, LEAN_MODE, F64)
     "k_dgp_forward<2,true,false,0,false>": 16, "k_dgp_forward<4,false,true,0,false>": 24, "k_dgp_forward<4,true,false,0,false>": 56,
-    "k_dgp_forward<4,true,true,0,false>": 16, "k_dgp_forward<5,true,false,2,false>": 12, "k_dgp_forward<5,true,true,0,false>": 20,
+    "k_dgp_forward<5,true,false,2,false>": 12,
+    "k_dgp_forward<2,true,true,0,false>": 12, "k_dgp_forward<3,true,true,0,false>": 28, "k_dgp_forward<4,true,true,0,false>": 52,
+    "k_dgp_forward<5,true,true,0,false>": 76,
     # the float64 stage-1 variants (an accuracy route, never a BASELINE workload's)
-    "k_dgp_forward<2,false,true,0,true>": 20, "k_dgp_forward<4,false,true,0,true>": 88, "k_dgp_forward<5,false,true,0,true>": 24,
+    "k_dgp_forward<1,false,true,0,true>": 24, "k_dgp_forward<2,false,true,0,true>": 68, "k_dgp_forward<3,false,true,0,true>": 32,
+    "k_dgp_forward<4,false,true,0,true>": 128, "k_dgp_forward<5,false,true,0,true>": 24,
 }
 # spill counts that may not GROW (demangled-name substring -> (max vgpr spills, max sgpr spills)); the factorisation lives with its
 # spills (LABNOTES round 4: 35-55 VGPRs, ~760 SGPRs at 1024 threads) -- the guard only keeps them from getting worse unnoticed

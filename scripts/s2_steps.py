@@ -29,6 +29,6 @@ for wg in (0, 100, 200):
     base = full[wg, 64 + 2 + 1*6 + 2]   # stage-1 end stamp cycles layer 1
     print("WG", wg, "wave start", (full[wg, 100:108] - base), "end", (full[wg, 110:118] - base))
     for w in range(8):
-        row = full[1024 + wg * 8 + w]
+        row = full[256 + wg * 8 + w]      # (configs[2]: 256 workgroups; per-wave rows start behind them)
         st = row[:32][row[:32] > 0] - base
         print("  wave", w, "steps at", st.tolist(), "deltas", np.diff(st).tolist(), "| gram start/end, prefetch issued, barrier passed:", (row[32:36] - row[32]).tolist(), "| mean job", int(row[37] - row[36]), "| epi: i start, i end, barrier, k loop, d loop, outputs, end, barrier", (row[40:48] - row[40]).tolist())
