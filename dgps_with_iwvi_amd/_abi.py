@@ -77,7 +77,8 @@ class ElboDesc(ctypes.Structure):
                 ("n_glob", ctypes.c_int32), ("scale", c_double), ("K_total", ctypes.c_int32),
                 ("mode_vi", ctypes.c_int32), ("out_lse_ms", c_void_p), ("out_logp", c_void_p),
                 ("out_elbo", c_void_p), ("ws", c_void_p), ("lw_init", c_void_p), ("noise_layer_base", ctypes.c_int32),
-                ("x_per_sample", ctypes.c_int32), ("lik_variance_dev", c_void_p)]
+                ("x_per_sample", ctypes.c_int32), ("lik_variance_dev", c_void_p),
+                ("adj_w", c_void_p), ("adj_dmean", c_void_p), ("adj_dvar", c_void_p), ("adj_sums", c_void_p)]
 
 
 class GpBwdDesc(ctypes.Structure):

@@ -285,7 +285,7 @@ def lv_backward(layer, XY, enc_out, eps, dF_next, col0, w, B, K, sampled_kl=True
     return dW, db
 
 
-def iw_elbo_and_gradients(model, zs=None, mode_vi=None, exchange=None, K_total=None, kl_weight=1.0, overlap=True, wrt="all"):
+def iw_elbo_and_gradients(model, zs=None, mode_vi=None, exchange=None, K_total=None, kl_weight=1.0, overlap=True, wrt="all", fuse_heads=True):
     """``wrt="final_q"``: only the final layer's 'l<i>.q_mu' / 'l<i>.q_sqrt' (all that the natural-gradient op of
     build_models.py:288-295 uses): same forward and bound, and of the adjoints only the final layer's two sums over samples.
 
@@ -352,8 +352,27 @@ def iw_elbo_and_gradients(model, zs=None, mode_vi=None, exchange=None, K_total=N
         # adjoints need in HBM (a = Lm^-1 k, the draws, every layer's output rows)
         model.precompute(with_encoders=True)
     zflat = [None if z is None else z.reshape(T, -1) for z in zs]
-    _, outs, _ = model._fused_forward(T, K, B, (T,), zs=zflat, sampled_kl=not mode_vi, want_layers=True, want_logw=False,
-                                      want_saved=True)
+    Dy = Y.shape[1]
+    w = torch.empty(T, dtype=ft, device=dev)
+    d_mean, d_var = torch.empty(T, Dy, dtype=ft, device=dev), torch.empty(T, Dy, dtype=ft, device=dev)
+    sums = torch.empty(3, dtype=torch.float64, device=dev)
+    # The heads of the bound's adjoint (w, d / d final mean and variance, the sums) come out of the layer launch's own tail when the
+    # bound is importance-weighted, unsharded, and every point's K samples sit in one chunk of the launch (include/iwvi_hip.h:
+    # iwvi_elbo_desc.adj_*): two launches less in front of the first chain.  The library refuses (before launching anything) when the
+    # launch's chunk does not hold whole points; the separate iwvi_iw_elbo_backward below then does it.
+    fused_heads = False
+    if (not mode_vi) and exchange is None and (K_total is None or int(K_total) == K) and fuse_heads:
+        try:
+            _, outs, _ = model._fused_forward(T, K, B, (T,), zs=zflat, sampled_kl=True, want_layers=True, want_logw=True, want_saved=True,
+                                              elbo=dict(B=B, K=K, stride_b=K, stride_k=1, mode_vi=False,
+                                                        adj=dict(w=w, d_mean=d_mean, d_var=d_var, sums=sums)))
+            fused_heads = True
+        except _abi.IwviError as e:
+            if "fused adjoint heads" not in str(e):
+                raise
+    if not fused_heads:
+        _, outs, _ = model._fused_forward(T, K, B, (T,), zs=zflat, sampled_kl=not mode_vi, want_layers=True, want_logw=False,
+                                          want_saved=True)
     # (the layer launch itself advances the device-resident noise counter: the next evaluation draws fresh noise)
     saved = []
     F = None
@@ -372,13 +391,9 @@ def iw_elbo_and_gradients(model, zs=None, mode_vi=None, exchange=None, K_total=N
     if saved[-1][0] != "gp":
         raise ValueError("the last layer must be a GPLayer")
     fin = saved[-1][1]
-    Dy = Y.shape[1]
     kls = [s[3] for s in saved if s[0] == "lv"]
     klp = _abi.ptr_array(kls)
     kld = (ctypes.c_int32 * max(len(kls), 1))(*[k.shape[1] for k in kls])
-    w = torch.empty(T, dtype=ft, device=dev)
-    d_mean, d_var = torch.empty(T, Dy, dtype=ft, device=dev), torch.empty(T, Dy, dtype=ft, device=dev)
-    sums = torch.empty(3, dtype=torch.float64, device=dev)
     glob = [_abi.dev_tensor(g.reshape(-1), "global kl", torch.float64) for g in model._global_kls()]
     glob_p = _abi.ptr_array(glob)
     glob_n = (ctypes.c_int32 * max(len(glob), 1))(*[g.numel() for g in glob])
@@ -391,11 +406,12 @@ def iw_elbo_and_gradients(model, zs=None, mode_vi=None, exchange=None, K_total=N
         _, _, ms = model._reduce(fin.mean, fin.var, Y, kls, [], B, K, stride_b=K, stride_k=1, mode_vi=False, want_ms=True)
         lse_g = _abi.dev_tensor(exchange(ms).to(ft).contiguous(), "lse_global")
     lik_host, lik_dev = model.likelihood.desc_variance()
-    _abi.check(_abi.lib().iwvi_iw_elbo_backward_dev(
-        _abi.ptr(fin.mean), _abi.ptr(fin.var), _abi.ptr(Y), Dy, klp, kld, len(kls), B, K,
-        lik_host, lik_dev, scale, 1 if mode_vi else 0, _abi.ptr(w), _abi.ptr(d_mean), _abi.ptr(d_var),
-        glob_p, glob_n, len(glob), _abi.ptr(lse_g), int(K_total or K),
-        ctypes.c_void_p(sums.data_ptr()), ctypes.c_void_p(ws.data_ptr()), _abi.stream_ptr()))
+    if not fused_heads:
+        _abi.check(_abi.lib().iwvi_iw_elbo_backward_dev(
+            _abi.ptr(fin.mean), _abi.ptr(fin.var), _abi.ptr(Y), Dy, klp, kld, len(kls), B, K,
+            lik_host, lik_dev, scale, 1 if mode_vi else 0, _abi.ptr(w), _abi.ptr(d_mean), _abi.ptr(d_var),
+            glob_p, glob_n, len(glob), _abi.ptr(lse_g), int(K_total or K),
+            ctypes.c_void_p(sums.data_ptr()), ctypes.c_void_p(ws.data_ptr()), _abi.stream_ptr()))
     grads = {"lik_var": sums[1]}
     elbo = sums[2]                                               # scale * sum_n(...) - sum of the global KLs, formed on the device
     if final_q:

@@ -145,6 +145,8 @@ struct FwElboHot {                   // what the end of the kernel reads: 24 wor
 static_assert(sizeof(FwElboHot) == 96, "one s_load_dwordx16 + one s_load_dwordx8");
 struct FwElbo : FwElboHot {
     const double* klg[FW_MAX_GLOB]; int klg_n[FW_MAX_GLOB];
+    // optional heads of the bound's adjoint (iwvi_elbo_desc.adj_*): per-sample weights and d / d final moments from the tail, the sums by the last workgroup
+    float* adj_w; float* adj_dmean; float* adj_dvar; double* adj_sums;
 };
 // a block of kernel-argument words as registers the compiler cannot rematerialise: it treats kernel-argument loads as free to repeat and
 // re-loads a field next to each use -- one dependent scalar-cache round trip per field on whatever path reads them
@@ -615,9 +617,13 @@ __device__ __forceinline__ void fw_arrive(const FwArgs& gk, float* sm, int tid, 
         if (g.e.enabled && counters[2]) {
             const FwElbo& E = g.e;
             double acc = 0.0;
+            double acc_ds = 0.0;                                   // adjoint heads: the chunks' shares of d ELBO / d lik_variance (ws[nchunks ..))
             if (local_lse) {
                 for (int i = tid; i < g.nchunks; i += FW_THREADS)
                     acc += __hip_atomic_load(E.ws + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (E.adj_sums)
+                    for (int i = tid; i < g.nchunks; i += FW_THREADS)
+                        acc_ds += __hip_atomic_load(E.ws + g.nchunks + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             } else {
                 const int K = E.K;
                 for (long long b = tid; b < E.B; b += FW_THREADS) {
@@ -648,17 +654,18 @@ __device__ __forceinline__ void fw_arrive(const FwArgs& gk, float* sm, int tid, 
                 }
             }
             // deterministic block sum: lanes by shuffles, then the 8 wave partials in a fixed order
-            for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+            for (int o = 32; o > 0; o >>= 1) { acc += __shfl_xor(acc, o); acc_ds += __shfl_xor(acc_ds, o); }
             double* wsum = reinterpret_cast<double*>(sm + g.lds.xa);
-            if (lane == 0) wsum[wave] = acc;
+            if (lane == 0) { wsum[wave] = acc; wsum[FW_WAVES + wave] = acc_ds; }
             __syncthreads();
-            if (tid == 0 && E.elbo) {
-                double tot = 0.0, kl = 0.0;
-                for (int w = 0; w < FW_WAVES; ++w) tot += wsum[w];
+            if (tid == 0 && (E.elbo || E.adj_sums)) {
+                double tot = 0.0, tds = 0.0, kl = 0.0;
+                for (int w = 0; w < FW_WAVES; ++w) { tot += wsum[w]; tds += wsum[FW_WAVES + w]; }
                 for (int i = 0; i < E.n_glob; ++i)
                     for (int c = 0; c < E.klg_n[i]; ++c) kl += E.klg[i][c];
                 const double val = tot * E.scale - kl;                                 // models.py:150
-                *E.elbo = val;
+                if (E.elbo) *E.elbo = val;
+                if (E.adj_sums) { E.adj_sums[0] = tot; E.adj_sums[1] = tds; E.adj_sums[2] = val; }
             }
         }
     }
@@ -2268,8 +2275,43 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
             if (E.ms) { E.ms[2 * b] = m; E.ms[2 * b + 1] = ssum; }
             if (E.logp) E.logp[b] = lp;
             xt[tid] = lp;
+            xt[NSAMP + tid] = m; xt[2 * NSAMP + tid] = (float)(E.scale / (double)ssum);   // (adjoint heads below)
         }
         __syncthreads();
+        if constexpr (!LEAN) {
+            const FwElbo& Ef = g.e;
+            float* const aw = ufirst(Ef.adj_w);
+            if (aw) {
+                // heads of the bound's adjoint (csrc/backward.hip: k_elbo_bwd, models.py:134-148): w = scale * softmax_k(L_nk); d / d final
+                // mean = w (y - m) / s, d / d final variance = -w / (2 s); this chunk's share of d / d lik_variance in float64
+                float* const adm = ufirst(Ef.adj_dmean); float* const adv = ufirst(Ef.adj_dvar);
+                double ds = 0.0;
+                if (tid < npl * K) {
+                    const int pnt = tid / K;
+                    const float wt = xt[2 * NSAMP + pnt] * __expf(lw[tid] - xt[NSAMP + pnt]);
+                    const int Dy = th.Dy;
+                    const float likv = sm[th.cnt + 8];
+                    const float* yrows = sm + th.yrows;
+                    aw[t0 + tid] = wt;
+                    for (int d = 0; d < Dy; ++d) {
+                        const float e = yrows[d * NSAMP + tid] - obuf[d * NSAMP + tid], v = obuf[(Dy + d) * NSAMP + tid];
+                        adm[(t0 + tid) * Dy + d] = wt * e / likv;
+                        adv[(t0 + tid) * Dy + d] = -0.5f * wt / likv;
+                        ds += (double)wt * (-0.5 / (double)likv + 0.5 * ((double)e * e + (double)v) / ((double)likv * likv));
+                    }
+                }
+                if (tid < 128) {                                   // the two waves that hold the chunk's samples (NSAMP <= 80): a fixed tree
+                    for (int o = 32; o > 0; o >>= 1) ds += __shfl_xor(ds, o);
+                    double* dsl = reinterpret_cast<double*>(xt + 3 * NSAMP + (NSAMP & 1));      // (8-byte aligned: xt is 16-byte aligned)
+                    if (lane == 0) dsl[wave] = ds;
+                }
+                __syncthreads();
+                if (tid == 0) {
+                    const double* dsl = reinterpret_cast<const double*>(xt + 3 * NSAMP + (NSAMP & 1));
+                    __hip_atomic_store(E.ws + th.nchunks + chunk_id, dsl[0] + dsl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        }
         double part = 0.0;
         if (tid == 0) {
             for (int p0 = 0; p0 < npl; p0 += 8) {                                      // fixed order; eight terms requested together
@@ -2660,6 +2702,14 @@ int dgp_forward_impl(const iwvi_layer_desc* layers, int n_layers, const float* X
             E.kl_total += E.klg_n[i];
         }
         E.ms = elbo->out_lse_ms; E.logp = elbo->out_logp; E.elbo = elbo->out_elbo; E.ws = elbo->ws;
+        E.adj_w = elbo->adj_w; E.adj_dmean = elbo->adj_dmean; E.adj_dvar = elbo->adj_dvar; E.adj_sums = elbo->adj_sums;
+        if (E.adj_w || E.adj_dmean || E.adj_dvar || E.adj_sums) {
+            if (!(E.adj_w && E.adj_dmean && E.adj_dvar && E.adj_sums)) { set_error("iwvi_dgp_forward: the adjoint heads adj_w / adj_dmean / adj_dvar / adj_sums come together"); return IWVI_ERR_ARG; }
+            if (E.mode_vi || !E.ws || E.stride_k != 1 || E.stride_b != E.K || E.K_total != E.K) {
+                set_error("iwvi_dgp_forward: the fused adjoint heads need the importance-weighted bound with contiguous samples, ws, and no sharded exchange");
+                return IWVI_ERR_UNSUPPORTED;
+            }
+        }
         a.h.lw_init = elbo->lw_init; a.h.layer_base = elbo->noise_layer_base; a.h.x_per_sample = elbo->x_per_sample;
         a.h.lik_var_dev = elbo->lik_variance_dev;
     }
@@ -2725,6 +2775,13 @@ int dgp_forward_impl(const iwvi_layer_desc* layers, int n_layers, const float* X
     a.h.stamps = (g_stamp_buf && chunks + IWVI_MAX_STACK <= g_stamp_wgs) ? g_stamp_buf : nullptr;
     a.h.dbg_exit = g_dbg_exit;
     fw_decide_fast(a, (unsigned)chunks, 16 * ns, T);
+    if (a.h.e.adj_w) {                                   // every point's K samples inside one chunk, two doubles of ws per chunk; the sums travel through ws
+        if ((16 * ns) % a.h.e.K != 0 || 2 * chunks > (T + 15) / 16) {
+            set_error("iwvi_dgp_forward: the fused adjoint heads need K (%d) to divide the chunk of %d samples", a.h.e.K, 16 * ns);
+            return IWVI_ERR_UNSUPPORTED;
+        }
+        a.h.e.fast = 0;
+    }
     bool big = false;                                    // a layer with M > 128: the variants that carry the generic / super-block solves
     for (int i = 0; i < n_layers; ++i) if (a.L[i].type == IWVI_LAYER_GP && a.L[i].gp.nbk > 8) big = true;
 #define FW_LAUNCH(NS_) (s16_all ? (big ? launch_forward<NS_, true, true>(a, (unsigned)chunks, lds_bytes, stream)      \

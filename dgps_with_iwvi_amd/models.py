@@ -257,6 +257,10 @@ class DGP_VI:
             ed.lik_variance_dev = self.likelihood.desc_variance()[1]
             ws = torch.empty((T + 15) // 16, dtype=torch.float64, device=dev)
             ed.out_logp, ed.out_elbo, ed.ws = logp.data_ptr(), val.data_ptr(), ws.data_ptr()
+            adj = elbo.get("adj")                                # heads of the bound's adjoint from the same launch (backward.py)
+            if adj is not None:
+                ed.adj_w, ed.adj_dmean, ed.adj_dvar, ed.adj_sums = (adj["w"].data_ptr(), adj["d_mean"].data_ptr(),
+                                                                    adj["d_var"].data_ptr(), adj["sums"].data_ptr())
             if stack_from:
                 ed.lw_init, ed.noise_layer_base, ed.x_per_sample = self.layers[0]._smp_kl.data_ptr(), stack_from, 1
             keep.append((glob, glob_p, glob_n, ws))

@@ -296,6 +296,15 @@ typedef struct iwvi_elbo_desc {
     int32_t noise_layer_base;
     int32_t x_per_sample;
     const float* lik_variance_dev;  /* optional device scalar read instead of iwvi_dgp_forward's lik_variance argument */
+    /* Optional: the heads of the bound's adjoint from the same launch (what iwvi_iw_elbo_backward computes from the final layer's moments --
+     * two launches less in front of the first layer adjoint of a value + gradient evaluation): adj_w [T] = d ELBO / d L_nk (scale x the
+     * softmax over the K samples of models.py:146-148), adj_dmean / adj_dvar [T, Dy] = d ELBO / d final mean / variance, adj_sums [3] =
+     * (sum_n (lse_n - log K), d ELBO / d lik_variance, the bound), written by the last workgroup.  All four or none.  Importance-weighted
+     * bound only (mode_vi = 0), every point's K samples contiguous (stride_k = 1, stride_b = K) and inside one chunk of the launch
+     * (K divides 16 x the launch's sub-tile count), ws given with room for two doubles per chunk, no K-sharded exchange (the weights of a
+     * sharded job need the job-wide logsumexp: iwvi_iw_elbo_backward's lse_global).  Otherwise the call returns IWVI_ERR_UNSUPPORTED
+     * before anything is launched -- fall back to iwvi_iw_elbo_backward. */
+    float* adj_w; float* adj_dmean; float* adj_dvar; double* adj_sums;
 } iwvi_elbo_desc;
 
 int iwvi_dgp_forward(const iwvi_layer_desc* layers_host, int n_layers,
