@@ -192,7 +192,7 @@ PROTOTYPES = {
 }
 
 DEBUG_OPTIONS = ("IWVI_BW_FUSED", "IWVI_CHAIN_EXIT", "IWVI_FW_SLOW_TAIL", "IWVI_NATGRAD_UNFUSED", "IWVI_NG_STOP", "IWVI_DEBUG_STOP", "IWVI_PRE_STAMP_P",
-                 "IWVI_FW_NO_LEAN")
+                 "IWVI_FW_NO_LEAN", "IWVI_PRE_SB_INLINE")
 
 
 def set_debug_option(name, value):

@@ -188,6 +188,97 @@ __global__ __launch_bounds__(256) void k_pack_ls16(const Ls16All a) {
     *reinterpret_cast<float4*>(dst + 512 + lane * 8) = as_f4(h2);
 }
 
+// ---- M > 240: the inverses of the 128 x 128 diagonal super-blocks of Lm, packed as the triangular part of the layer kernel's solve stream
+// (csrc/dgp_forward.hip: a_I = (L_II)^-1 r_I).  One workgroup (4 waves) per 16-column block J of a super-block, like k_linv:
+//   X_J = D_J^-1,   X_t = -D_t^-1 sum_{J <= u < t} L(t, u) X_u   (float64 MFMA products, the sum dealt to the four waves)
+// from the factor the launch before left in the layer's workspace (block storage; diagonal-block inverses transposed in `dinv`), written
+// straight in A-fragment order behind the dense part of super-block I.  In k_precompute the same inverses were three doubling steps on the
+// factorising workgroup's one CU: 53 us at M = 256 (two super-blocks), 16 workgroups here.
+struct SbInvOne { const double* ws; float* LsP; int nbk, Mp, M, first; };
+struct SbInvAll { SbInvOne L[IWVI_MAX_LAYERS]; int n; };
+__global__ __launch_bounds__(256) void k_sb_inv(const SbInvAll a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char sbinv_smem[];
+    int li = 0;
+    while (li + 1 < a.n && (int)blockIdx.x >= a.L[li + 1].first) ++li;
+    const SbInvOne& L = a.L[li];
+    const int nbk = L.nbk, wg = (int)blockIdx.x - L.first;
+    const int I = wg >> 3, J = wg & 7, r0 = 8 * I, nr = (nbk - r0 < 8) ? nbk - r0 : 8;
+    if (J >= nr) return;
+    const int nb = nr - J;                                       // blocks of this block column: rows J .. nr - 1 of the super-block
+    const WsLayout w = ws_layout(L.Mp);
+    const double* blk = L.ws + w.blk;
+    const double* dinvT = L.ws + w.dinv;                         // [nbk][BLK]: L_pp^-T of the factorisation's diagonal passes
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double* X = reinterpret_cast<double*>(sbinv_smem);           // [nb][BLK]  the finished blocks of this block column
+    double* Dv = X + (size_t)nb * BLK;                           // [nb][BLK]  D_t^-1
+    double* Ls = Dv + (size_t)nb * BLK;                          // [nb (nb - 1) / 2][BLK]  L(t, u), u < t
+    double* part = Ls + (size_t)(nb * (nb - 1) / 2) * BLK;       // [4][BLK]
+    {   // everything this column needs, one round trip: all loads of a thread issued before its first store
+        const int rr = tid >> 4, cc = tid & 15;
+        constexpr int MAXB = 36;
+        const int ntot = nb * (nb + 1) / 2;
+        double v[MAXB];
+#pragma unroll
+        for (int q = 0; q < MAXB; ++q) {
+            int t = 0;
+            while ((t + 1) * (t + 2) / 2 <= q) ++t;
+            const int u = q - t * (t + 1) / 2;
+            const int bt = r0 + J + t, bu = r0 + J + u;
+            v[q] = 0.0;
+            if (q < ntot) v[q] = (u == t) ? dinvT[(size_t)bt * BLK + cc * BLD + rr] : blk[boff(bt, bu) + rr * BLD + cc];   // (transposed: D^-1[rr][cc])
+        }
+#pragma unroll
+        for (int q = 0; q < MAXB; ++q) {
+            int t = 0;
+            while ((t + 1) * (t + 2) / 2 <= q) ++t;
+            const int u = q - t * (t + 1) / 2;
+            if (q < ntot) {
+                if (u == t) Dv[(size_t)t * BLK + rr * BLD + cc] = (cc <= rr) ? v[q] : 0.0;
+                else Ls[(size_t)(t * (t - 1) / 2 + u) * BLK + rr * BLD + cc] = v[q];
+            }
+        }
+        if (tid < 256) X[rr * BLD + cc] = 0.0;
+    }
+    __syncthreads();
+    for (int i = tid; i < BLK; i += 256) X[i] = Dv[i];            // X_0 = D_J^-1
+    __syncthreads();
+    for (int t = 1; t < nb; ++t) {
+        f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+        for (int u = wave; u < t; u += 4) blk_mma<false>(acc, Ls + (size_t)(t * (t - 1) / 2 + u) * BLK, X + (size_t)u * BLK, lane, 1.0);
+        blk_store(part + wave * BLK, acc, lane);
+        __syncthreads();
+        {
+            const int rr = tid >> 4, cc = tid & 15, o = rr * BLD + cc;
+            part[o] = (part[o] + part[BLK + o]) + (part[2 * BLK + o] + part[3 * BLK + o]);
+        }
+        __syncthreads();
+        if (wave == 0) {
+            f64x4 x = {0.0, 0.0, 0.0, 0.0};
+            blk_mma<false>(x, Dv + (size_t)t * BLK, part, lane, -1.0);
+            blk_store(X + (size_t)t * BLK, x, lane);
+        }
+        __syncthreads();
+    }
+    // packed fp32 blocks: row w = J + t of the super-block's triangle, block q = J: position nr r0 + w (w + 1) / 2 + J behind the super-block's start
+    int off = 0;
+    for (int i2 = 0; i2 < I; ++i2) { const int rr0 = 8 * i2, nn = (nbk - rr0 < 8) ? nbk - rr0 : 8; off += nn * rr0 + nn * (nn + 1) / 2; }
+    float4* dst = reinterpret_cast<float4*>(L.LsP);
+    const bool full = (L.M == L.Mp);
+    for (int it = tid; it < nb * 64; it += 256) {
+        const int t = it >> 6, ln = it & 63, ii = ln & 15, k0 = 4 * (ln >> 4);
+        const int wrow = J + t;
+        float v[4];
+#pragma unroll
+        for (int sgm = 0; sgm < 4; ++sgm) {
+            const int i = 16 * (r0 + wrow) + ii, k = 16 * (r0 + J) + k0 + sgm;
+            float f = (k <= i) ? (float)X[(size_t)t * BLK + ii * BLD + k0 + sgm] : 0.f;
+            if (!full && (i >= L.M || k >= L.M)) f = (i == k) ? 1.f : 0.f;                 // padded rows solve to 0 against k = 0
+            v[sgm] = f;
+        }
+        dst[(size_t)(off + nr * r0 + wrow * (wrow + 1) / 2 + J) * 64 + ln] = make_float4(v[0], v[1], v[2], v[3]);
+    }
+}
+
 __global__ __launch_bounds__(256) void k_gauss_kl(const float* q_mu, const float* q_sqrt, int M, int R,
                                                    double* kl) {
     role_kl_only(q_mu, q_sqrt, M, R, kl, reinterpret_cast<double*>(smem_raw));
@@ -539,6 +630,7 @@ extern "C" int iwvi_model_precompute(const iwvi_gp_desc* layers, int n_layers, c
             PreLayer& L = a.L[l];
             { const int rc = fill_pre_layer(d, base + l, L); if (rc != IWVI_OK) return rc; }
             if (d.flags & IWVI_GP_F64_STAGE1) L.flags |= IWVI_GP_WANT_LM;      // the float64 route multiplies by the dense Lm^-1 (k_linv below)
+            if (L.nbk >= 16 && !(d.flags & IWVI_GP_WANT_DENSE) && !dbg_opt("IWVI_PRE_SB_INLINE")) L.flags |= IWVI_GP_SB_EXT_;   // super-block inverses by k_sb_inv
             size_t la = factor_lds_bytes(L.Mp);
             if (la > lds) lds = la;
             if (d.R + 1 > max_roles) max_roles = d.R + 1;
@@ -581,6 +673,24 @@ extern "C" int iwvi_model_precompute(const iwvi_gp_desc* layers, int n_layers, c
         if ((rc = ensure_lds_attr((const void*)k_precompute, lds)) != IWVI_OK) return rc;
         hipLaunchKernelGGL(k_precompute, dim3(a.n + enc_blocks, max_roles), dim3(1024), lds, stream, a);
         if ((rc = check_launch("k_precompute")) != IWVI_OK) return rc;
+        {   // layers with M > 240: the inverses of the diagonal super-blocks, one workgroup per 16-column block of each
+            SbInvAll q{};
+            int grid = 0;
+            size_t lds_sb = 0;
+            for (int l = 0; l < a.n; ++l) {
+                const PreLayer& L = a.L[l];
+                if (!(L.flags & IWVI_GP_SB_EXT_)) continue;
+                SbInvOne& o = q.L[q.n++];
+                o.ws = L.ws; o.LsP = L.LsP; o.nbk = L.nbk; o.Mp = L.Mp; o.M = L.M; o.first = grid;
+                grid += 8 * ((L.nbk + 7) / 8);
+                lds_sb = sizeof(double) * (size_t)(8 + 8 + 28 + 4) * BLK;
+            }
+            if (q.n > 0) {
+                if ((rc = ensure_lds_attr((const void*)k_sb_inv, lds_sb)) != IWVI_OK) return rc;
+                hipLaunchKernelGGL(k_sb_inv, dim3(grid), dim3(256), lds_sb, stream, q);
+                if ((rc = check_launch("k_sb_inv")) != IWVI_OK) return rc;
+            }
+        }
         {   // layers with M > 240: the split-f16 operands of the super-block solve's dense part
             Ls16All q{};
             int grid = 0;

@@ -11,6 +11,7 @@ constexpr int BLD = NB + 1;       // padded row stride of a block (doubles)
 constexpr int BLK = NB * BLD;     // doubles per block
 constexpr int ZLD = 33;           // row stride of the LDS copy of Zs (floats)
 
+constexpr int IWVI_GP_SB_EXT_ = 1 << 8;   // PreLayer.flags, internal: the super-block inverses of a layer with M > 240 come from k_sb_inv (csrc/precompute.hip)
 struct PreLayer {
     const float* Z; const float* ls; const float* q_mu; const float* q_sqrt;
     double* Lm; double* Linv; float* LsP; float* LrTP; float* QmuP; float* ZtP; float* cst; double* kl;
@@ -599,7 +600,10 @@ __device__ __forceinline__ void role_factor(const PreLayer& Lin, int stop_after,
         // so that nothing in it is a dependent chain of one wave.  Its operand stream REPLACES the column-major substitution
         // stream in LsP (same number of blocks): per super-block I, row by row, [-L(bi, 0 .. 8I-1)], then row by row
         // [(L_II)^-1 (bi, 8I .. bi)].  The super-block inverses are the first three doubling steps of the dense inversion.
-        invert_blocks(blk, dinv, tbuf, rinv, nbk, tid, nthreads, 1, 8);
+        // (round 5: unless the dense inverse is asked for, the super-block inverses are formed and packed by k_sb_inv behind this launch, one
+        //  workgroup per 16-column block of each super-block -- here they were 53 us on this one CU at M = 256, 16.5 % of configs[3])
+        const bool sb_ext = (L.flags & IWVI_GP_SB_EXT_) != 0 && !dense;
+        if (!sb_ext) invert_blocks(blk, dinv, tbuf, rinv, nbk, tid, nthreads, 1, 8);
         float4* dst = reinterpret_cast<float4*>(L.LsP);
         const bool full = (M == Mp);
         const int nsb = (nbk + 7) / 8;
@@ -607,7 +611,7 @@ __device__ __forceinline__ void role_factor(const PreLayer& Lin, int stop_after,
         for (int I = 0; I < nsb; ++I) {
             const int r0 = 8 * I, nr = (nbk - r0 < 8) ? nbk - r0 : 8;
             const int nx = nr * r0, ny = nr * (nr + 1) / 2;
-            for (int it = tid; it < (nx + ny) * 64; it += nthreads) {
+            for (int it = tid; it < (sb_ext ? nx : nx + ny) * 64; it += nthreads) {
                 const int b = it >> 6, ln = it & 63, ii = ln & 15, k0 = 4 * (ln >> 4);
                 int bi, bk; bool inv;
                 if (b < nx) { bi = r0 + b / r0; bk = b - (b / r0) * r0; inv = false; }
