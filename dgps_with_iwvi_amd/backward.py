@@ -274,6 +274,16 @@ def lv_backward(layer, XY, enc_out, eps, dF_next, col0, w, B, K, sampled_kl=True
         ctypes.c_void_p(enc_out.data_ptr()), ctypes.c_void_p(enc_out.data_ptr() + 4 * Lw), 2 * Lw, 1,
         _abi.ptr(eps), _abi.ptr(dF_next), 0 if dF_next is None else dF_next.shape[1], col0,
         _abi.ptr(w), Lw, B, K, 1 if sampled_kl else 0, _abi.ptr(d_enc), _abi.stream_ptr()))
+    if layer.encoder.custom_act is not None:
+        # a user-supplied activation: the encoder is torch ops (layers.Encoder.torch_raw), so are its weight gradients -- the
+        # vector-Jacobian product of d(encoder output), which the kernel above formed
+        enc = layer.encoder
+        Ws = [t.detach().clone().requires_grad_(True) for t in enc.Ws]
+        bs = [t.detach().clone().requires_grad_(True) for t in enc.bs]
+        with torch.enable_grad():
+            raw = enc.torch_raw(_abi.dev_tensor(XY.contiguous(), "encoder input"), Ws, bs)
+            gr = torch.autograd.grad(raw, Ws + bs, grad_outputs=d_enc)
+        return list(gr[:len(Ws)]), list(gr[len(Ws):])
     Wp, bp, dims, n, keep = layer.encoder.abi_args()
     dW = [torch.empty_like(t) for t in keep[0]]
     db = [torch.empty_like(t) for t in keep[1]]

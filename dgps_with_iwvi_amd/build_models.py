@@ -75,8 +75,8 @@ def build_layers(configuration, X, M, rng=None):
 
 def build_model(ARGS, X, Y, apply_name=True, device=None):
     if ARGS.mode not in ("VI", "IWAE"):
-        raise NotImplementedError("mode %r: only the VI / IWAE forward models are built here (training ops, SGHMC "
-                                  "and the CVAE baseline are outside the hot path)" % (ARGS.mode,))
+        raise NotImplementedError("mode %r: the VI / IWAE models (with their NatGrad + Adam train_op) are built here; SGHMC "
+                                  "and the CVAE baseline are outside the scope of this port (SURVEY.md section 8)" % (ARGS.mode,))
     layers = build_layers(ARGS.configuration, X, ARGS.M)
     lik = Gaussian(ARGS.likelihood_variance)
     name = "Model" if apply_name else None

@@ -177,7 +177,18 @@ class Encoder:
     callable).  Evaluated inside ``iwvi_lv_layer_forward``; ``__call__`` runs that kernel in encoder-only mode."""
 
     def __init__(self, latent_dim, input_dim, network_dims, activation_func=None, name=None):
-        self.act = _activation_code(activation_func)
+        # A built-in activation (tanh, relu, sigmoid, softplus, identity: by name or as the torch callable) runs inside the HIP kernels.
+        # ANY other callable on torch tensors (reference layers.py:119 takes any TensorFlow op) is honoured too: the MLP is then
+        # evaluated with torch ops on the device (``torch_raw``) and handed to the kernels as a precomputed encoder output
+        # (iwvi_layer_desc.enc_out -- the route the precompute launch's encoder rows already take), its weight gradients by
+        # torch.autograd from the kernels' d(encoder output).  The user's function has to run somewhere; nothing else changes route.
+        self.custom_act = None
+        try:
+            self.act = _activation_code(activation_func)
+        except NotImplementedError:
+            if not callable(activation_func):
+                raise
+            self.act, self.custom_act = _abi.ACT_IDENTITY, activation_func
         self.latent_dim = latent_dim
         self.layer_dims = [input_dim, *network_dims, latent_dim * 2]
         if len(self.layer_dims) - 1 > _abi.MAX_ENC:
@@ -194,7 +205,27 @@ class Encoder:
         self.bs = [b.to(device) for b in self.bs]
         return self
 
+    _TORCH_ACTS = {_abi.ACT_TANH: torch.tanh, _abi.ACT_RELU: torch.relu, _abi.ACT_SIGMOID: torch.sigmoid,
+                   _abi.ACT_SOFTPLUS: torch.nn.functional.softplus, _abi.ACT_IDENTITY: (lambda x: x)}
+
+    def torch_raw(self, Z, Ws=None, bs=None):
+        """The MLP of reference layers.py:137-147 with torch ops: [rows, input_dim] -> [rows, 2*latent_dim] = (means | raw), where
+        q_sqrt = softplus(raw - 3) (:149-150) is applied by the consumer.  ``Ws`` / ``bs``: stand-ins for the weights (autograd leaves)."""
+        act = self.custom_act if self.custom_act is not None else self._TORCH_ACTS[self.act]
+        Ws, bs = (self.Ws if Ws is None else Ws), (self.bs if bs is None else bs)
+        n = len(bs)
+        for i, (W, b, din, dout) in enumerate(zip(Ws, bs, self.layer_dims[:-1], self.layer_dims[1:])):
+            Z0 = Z
+            Z = Z @ W + b                                        # :141
+            if i < n - 1:
+                Z = act(Z)                                       # :143-144
+            if dout == din:
+                Z = Z + Z0                                       # :146-147
+        return Z
+
     def abi_args(self):
+        if self.custom_act is not None:
+            raise RuntimeError("an Encoder with a custom activation is evaluated by torch_raw(), not inside the kernels")
         Ws = [_abi.dev_tensor(w, "encoder W") for w in self.Ws]
         bs = [_abi.dev_tensor(b, "encoder b") for b in self.bs]
         dims = (ctypes.c_int32 * len(self.layer_dims))(*self.layer_dims)
@@ -207,6 +238,9 @@ class Encoder:
         if Z.shape[-1] != self.layer_dims[0]:
             raise ValueError("encoder expects %d features, got %d" % (self.layer_dims[0], Z.shape[-1]))
         Lw = self.latent_dim
+        if self.custom_act is not None:
+            raw = self.torch_raw(Z.reshape(T, -1))
+            return raw[:, :Lw].reshape(*lead, Lw), torch.nn.functional.softplus(raw[:, Lw:] - 3.0).reshape(*lead, Lw)
         dummy = torch.zeros(T, 1, dtype=settings.float_type, device=Z.device)
         mean = torch.empty(T, 1 + Lw, dtype=settings.float_type, device=Z.device)
         cov = torch.empty(T, 1 + Lw, dtype=settings.float_type, device=Z.device)
@@ -249,6 +283,12 @@ class LatentVariableLayer:
         rows = XY.shape[0]
         if getattr(self, "_enc_out", None) is None or self._enc_out.shape[0] != rows or self._enc_out.device != XY.device:
             self._enc_out = torch.empty(rows, 2 * self.latent_dim, dtype=settings.float_type, device=XY.device)
+        if self.encoder.custom_act is not None:                  # a user-supplied activation: torch evaluates the MLP, same output buffer
+            if sample is not None:
+                raise NotImplementedError("the leading-LV-layer-in-the-precompute-launch route needs a built-in encoder activation")
+            with torch.no_grad():
+                self._enc_out.copy_(self.encoder.torch_raw(XY))
+            return None, (XY,)
         Wp, bp, dims, n, k2 = self.encoder.abi_args()
         e = _abi.EncDesc()
         e.XY, e.rows, e.enc_W, e.enc_b, e.dims, e.n_enc = XY.data_ptr(), rows, Wp, bp, dims, n
@@ -315,6 +355,12 @@ class LatentVariableLayer:
         kl = torch.empty(T, Lw, dtype=settings.float_type, device=dev)
         if XY is None and (self.q_mu_placeholder is not None or self.q_sqrt_placeholder is not None):
             return self._propagate_fed(F.reshape(T, D), z2, outs, kl, lead, is_sampled_local_regularizer)
+        if XY is not None and self.encoder.custom_act is not None:
+            with torch.no_grad():
+                enc_out = self.encoder.torch_raw(XY).contiguous()
+            return self._propagate_fed(F.reshape(T, D), z2, outs, kl, lead, is_sampled_local_regularizer, enc_out=enc_out)
+        if XY is None and self.encoder.custom_act is not None:   # prior mode: N(0, 1), as fed defaults
+            return self._propagate_fed(F.reshape(T, D), z2, outs, kl, lead, is_sampled_local_regularizer)
         Wp, bp, dims, n, keep = self.encoder.abi_args()
         _abi.check(_abi.lib().iwvi_lv_layer_forward_act(
             _abi.ptr(F.reshape(T, D)), _abi.ptr(XY), _abi.ptr(z2), Wp, bp, dims, n, self.encoder.act, D, Lw,
@@ -323,12 +369,14 @@ class LatentVariableLayer:
         s, m, c = (o.view(*lead, D + Lw) for o in outs)
         return s, m, c, kl.view(*lead, Lw)
 
-    def _propagate_fed(self, F2, z2, outs, kl, lead, sampled):
+    def _propagate_fed(self, F2, z2, outs, kl, lead, sampled, enc_out=None):
         """Prior mode with FED q_mu / q_sqrt (the reference's placeholders, layers.py:60-64,78-81): the values travel as a
         precomputed "encoder output" [T, 2*latent_dim] = (q_mu | raw) with q_sqrt = softplus(raw - 3), through the same kernel."""
         T, D = F2.shape
         Lw, dev = self.latent_dim, F2.device
         ft = settings.float_type
+        if enc_out is not None:                                  # (an encoder evaluated outside the kernels: custom activation)
+            return self._run_pre_encoded(F2, z2, outs, kl, lead, sampled, _abi.dev_tensor(enc_out, "enc_out"))
         mu = torch.zeros(T, Lw, dtype=ft, device=dev) if self.q_mu_placeholder is None else \
             torch.as_tensor(self.q_mu_placeholder, dtype=ft, device=dev).expand(*lead, Lw).reshape(T, Lw)
         sg = torch.ones(T, Lw, dtype=ft, device=dev) if self.q_sqrt_placeholder is None else \
@@ -338,6 +386,12 @@ class LatentVariableLayer:
         sg64 = sg.double()
         raw = torch.where(sg64 > 20.0, sg64, torch.log(torch.expm1(sg64))) + 3.0          # softplus^-1, float64 then rounded once
         enc_out = torch.cat([mu, raw.to(ft)], -1).contiguous()
+        return self._run_pre_encoded(F2, z2, outs, kl, lead, sampled, enc_out)
+
+    def _run_pre_encoded(self, F2, z2, outs, kl, lead, sampled, enc_out):
+        """The layer kernel on a precomputed "encoder output" [T, 2*latent_dim] = (q_mu | raw), q_sqrt = softplus(raw - 3)."""
+        T, D = F2.shape
+        Lw = self.latent_dim
         d = _abi.LayerDesc()
         d.type, d.D, d.latent_dim, d.sampled_kl = _abi.LAYER_LV, D, Lw, 1 if sampled else 0
         d.enc_out = enc_out.data_ptr()

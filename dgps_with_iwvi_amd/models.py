@@ -108,7 +108,8 @@ class DGP_VI:
                         smp = dict(sample_first, X=self.X, layer_index=0, seed=settings.seed,
                                    rng_state=ctypes.c_void_p(self._words().data_ptr() + 8))
                     e, k = l.enc_desc(self._xy_minibatch(), sample=smp)
-                    encs.append(e)
+                    if e is not None:                            # (None: a custom-activation encoder, already evaluated by torch ops)
+                        encs.append(e)
                     keep.append(k)
                     l._enc_key = self._mb_key()
         descs = [l.state_desc() for l in self.layers if isinstance(l, GPLayer)]
@@ -222,6 +223,10 @@ class DGP_VI:
                         o["noise_out"] = torch.empty(T, Lw, dtype=settings.float_type, device=dev)
                 # encoder output of THIS minibatch from the last precompute launch, if there is one
                 eo = layer._enc_out if (use_encoder and getattr(layer, "_enc_key", None) == self._mb_key()) else None
+                if eo is None and use_encoder and layer.encoder.custom_act is not None:      # a custom activation never runs inside the kernels
+                    layer.enc_desc(self._xy_minibatch())
+                    layer._enc_key = self._mb_key()
+                    eo = layer._enc_out
                 d, k = layer.fused_desc(D, z2, o, sampled_kl=sampled_kl, use_encoder=use_encoder, enc_out=eo)
                 D += Lw
             else:

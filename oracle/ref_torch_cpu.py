@@ -47,7 +47,7 @@ class CpuDGP:
         self.layers = []
         for l in spec["layers"]:
             if l["type"] == "lv":
-                self.layers.append(dict(type="lv", Lw=l["latent_dim"], W=[t(w) for w in l["enc_W"]],
+                self.layers.append(dict(type="lv", Lw=l["latent_dim"], act=l.get("act", torch.tanh), W=[t(w) for w in l["enc_W"]],
                                         b=[t(b) for b in l["enc_b"]], dims=l["dims"]))
             else:
                 self.layers.append(dict(type="gp", Z=t(l["Z"]), ls=t(l["ls"]), var=l["var"], q_mu=t(l["q_mu"]),
@@ -112,7 +112,7 @@ class CpuDGP:
                     H0 = H
                     H = H @ W + b
                     if i < n - 1:
-                        H = torch.tanh(H)
+                        H = L.get("act", torch.tanh)(H)                                            # layers.py:119 (default tf.nn.tanh); spec["layers"][i]["act"]
                     if W.shape[0] == W.shape[1]:
                         H = H + H0
                 mu, raw = H.split(L["Lw"], -1)

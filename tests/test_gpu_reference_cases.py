@@ -440,10 +440,12 @@ def test_wide_multilayer_models_match_oracle(gpu_device, L, M, K, B, lv):
 # Encoder(activation_func=...) (layers.py:109,119) and the LV layer's fed placeholders (layers.py:60-64)
 # ------------------------------------------------------------------------------------------
 _ACTS = {"relu": lambda x: np.maximum(x, 0.0), "sigmoid": lambda x: 1.0 / (1.0 + np.exp(-x)),
-         "softplus": lambda x: np.logaddexp(0.0, x), "tanh": np.tanh}
+         "softplus": lambda x: np.logaddexp(0.0, x), "tanh": np.tanh,
+         "custom_elu": lambda x: np.where(x > 0, x, np.expm1(np.minimum(x, 0.0))),          # (a callable the kernels do not implement)
+         "custom_sinx": lambda x: x + 0.5 * np.sin(x)}
 
 
-@pytest.mark.parametrize("act", ["relu", "sigmoid", "softplus"])
+@pytest.mark.parametrize("act", ["relu", "sigmoid", "softplus", "custom_elu", "custom_sinx"])
 def test_encoder_activation_forward_and_gradient(gpu_device, act):
     """A non-default ``activation_func``: (1) encoder and LV-layer outputs vs the oracle with the same activation, through all
     three places the MLP runs (standalone layer kernel, the precompute launch, inside the fused forward); (2) the IW-ELBO of a
@@ -451,7 +453,8 @@ def test_encoder_activation_forward_and_gradient(gpu_device, act):
     from dgps_with_iwvi_amd import synthetic
     from dgps_with_iwvi_amd.backward import iw_elbo_and_gradients
     from dgps_with_iwvi_amd.layers import Encoder, LatentVariableLayer
-    torch_act = {"relu": torch.relu, "sigmoid": torch.sigmoid, "softplus": "softplus"}[act]
+    torch_act = {"relu": torch.relu, "sigmoid": torch.sigmoid, "softplus": "softplus", "custom_elu": torch.nn.functional.elu,
+                 "custom_sinx": lambda x: x + 0.5 * torch.sin(x)}[act]                      # (custom_*: reference layers.py:119 takes ANY op)
     spec = synthetic.make_spec(L=2, M=32, B=24, K=4, with_lv=True, seed=71, n_data=300)
     zs = synthetic.make_noise(spec, seed=72)
     zd = [_t(z, gpu_device) for z in zs]
@@ -472,8 +475,19 @@ def test_encoder_activation_forward_and_gradient(gpu_device, act):
     assert abs(got - ref) <= 1e-4 * abs(ref), (got, ref)
     elbo, g = iw_elbo_and_gradients(model, zd)
     assert abs(float(elbo) - ref) <= 1e-4 * abs(ref)
+    if act.startswith("custom"):
+        # a callable the kernels do not know: its weight gradients come from torch.autograd on the kernels' d(encoder output) -- against
+        # the float64 autodiff of the restatement with the same activation
+        from oracle import grad_oracle
+        spec_a = dict(spec, layers=[dict(spec["layers"][0], act=torch_act)] + list(spec["layers"][1:]))
+        ref_v, ref_g = grad_oracle.iw_elbo_and_gradients(spec_a, zs)
+        assert abs(ref_v - ref) <= 1e-9 * abs(ref)
+        for j in range(len(enc.Ws)):
+            for nm in ("l0.encW%d" % j, "l0.encb%d" % j):
+                a, b = _np(g[nm]).reshape(ref_g[nm].shape), ref_g[nm]
+                assert np.abs(a - b).max() <= 2e-3 * max(np.abs(b).max(), 1e-3), (nm, np.abs(a - b).max(), np.abs(b).max())
     rng = np.random.default_rng(0)
-    for j, W in enumerate(enc.Ws):                               # directional derivative along a random direction, per weight matrix
+    for j, W in enumerate(enc.Ws if not act.startswith("custom") else []):   # directional derivative along a random direction, per weight matrix
         dirn = torch.as_tensor(rng.standard_normal(tuple(W.shape)), dtype=torch.float32, device=gpu_device)
         eps = 2e-3 if act == "relu" else 1e-2                   # (relu has kinks: a large step crosses some of them)
         W.add_(eps * dirn); up = model.compute_log_likelihood(zd)
@@ -482,8 +496,16 @@ def test_encoder_activation_forward_and_gradient(gpu_device, act):
         fd = (up - dn) / (2 * eps)
         an = float((g["l0.encW%d" % j] * dirn).sum())
         assert abs(fd - an) <= 3e-2 * max(abs(fd), abs(an), 1.0), (act, j, fd, an)
+    assert (enc.custom_act is not None) == act.startswith("custom")
+    # the layer-by-layer API (layers.py:72-105) with recognition inputs, against the oracle's layer
+    F = _f32(spec["X"][:24])
+    zl = _f32(np.random.default_rng(3).standard_normal((24, lvs["latent_dim"])))
+    s_, m_, c_, kl_ = model.layers[0].propagate(_t(F, gpu_device), _t(XY, gpu_device), True, z=_t(zl, gpu_device))
+    so, mo, co, klo = om.layers[0].propagate(F, XY, True, z=zl)
+    np.testing.assert_allclose(_np(s_), so, rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(_np(kl_), klo, rtol=1e-3, atol=1e-4)
     with pytest.raises(NotImplementedError):
-        Encoder(1, 3, [4], activation_func=torch.erf)
+        Encoder(1, 3, [4], activation_func="no such activation")
 
 
 def test_latent_variable_layer_fed_placeholders(gpu_device):
