@@ -2788,13 +2788,15 @@ int dgp_forward_impl(const iwvi_layer_desc* layers, int n_layers, const float* X
                                       : launch_forward<NS_, true, false>(a, (unsigned)chunks, lds_bytes, stream))     \
                                 : (big ? launch_forward<NS_, false, true>(a, (unsigned)chunks, lds_bytes, stream)     \
                                       : launch_forward<NS_, false, false>(a, (unsigned)chunks, lds_bytes, stream)))
+    bool fp32_shp = false;                               // s16_all is off only because a layer asked for the fp32-MFMA stage 2
+    for (int i = 0; i < n_layers; ++i) if (layers[i].type == IWVI_LAYER_GP && (layers[i].flags & IWVI_LAYER_F32_STAGE2)) fp32_shp = true;
     {   // the headline stack at the headline chunk size: the variants with its shapes and sources compiled in (k_dgp_forward: SHP / LEAN)
         // EVERY assumption the SHP / LEAN code compiles in is a condition here (the kernel has no run-time guard of its own,
         // and tests/test_gpu_lean_variant.py lists a shape per condition that must NOT take these variants):
         //   nvalid = NSAMP, grid * 80 == T  <- T % 80 == 0 (whole chunks)        nbk = 8                  <- M == 128
         //   nsteps = 3 / nx_nsteps = 3      <- D + 2 <= 12 of every GP layer      mean-function loop u < 3 <- D <= 10 (the same)
         //   npb = 1 (one block of outputs)  <- P <= 16                            rbf, operands staged, encoders precomputed, device noise
-        bool shp = ns == 5 && s16_all && !f64_any && !big && !a.h.noise_any_src && !a.h.lw_init && !a.h.x_per_sample && !g_dbg_exit && T % (16 * 5) == 0
+        bool shp = ns == 5 && (s16_all || fp32_shp) && !f64_any && !big && !a.h.noise_any_src && !a.h.lw_init && !a.h.x_per_sample && !g_dbg_exit && T % (16 * 5) == 0
                    && chunks * (16 * 5) == T;
         for (int i = 0; i < n_layers && shp; ++i) {
             const FwLayer& L = a.L[i];
@@ -2810,6 +2812,11 @@ int dgp_forward_impl(const iwvi_layer_desc* layers, int n_layers, const float* X
         bool lean = shp && a.h.e.fast && a.h.out_logw && a.h.e.K >= 5 && a.h.e.K <= 32 && (16 * 5) % a.h.e.K == 0;
         for (int i = 0; i < n_layers && lean; ++i) if (a.H[i].flags & FWF_ANY_OUT) lean = false;
         if (shp && !dbg_opt("IWVI_FW_NO_LEAN")) {
+            if (!s16_all) {                              // the strict-fp32 route (IWVI_LAYER_F32_STAGE2 on a layer) with the same shapes compiled in
+                if (lean) { g_last_variant = 5 | 1 << 10; return launch_forward<5, false, false, 1>(a, (unsigned)chunks, lds_bytes, stream); }
+                g_last_variant = 5 | 1 << 11;
+                return launch_forward<5, false, false, 2>(a, (unsigned)chunks, lds_bytes, stream);
+            }
             if (lean) { g_last_variant = 5 | 1 << 8 | 1 << 10; return launch_forward<5, true, false, 1>(a, (unsigned)chunks, lds_bytes, stream); }
             // mode 2: the same stack with outputs and the general tail (the forward of a value + gradient evaluation, predictions, read-backs)
             g_last_variant = 5 | 1 << 8 | 1 << 11;

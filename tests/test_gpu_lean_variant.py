@@ -65,6 +65,27 @@ def test_lean_variant_equals_the_general_variant_on_the_same_draws(gpu_device, K
     assert float(red2[0]) != e_lean
 
 
+def test_fp32_route_has_its_compiled_in_shapes_variant_too(gpu_device):
+    """``settings.fw_f32_stage2`` (IWVI_LAYER_F32_STAGE2: fp32 MFMAs in stage 2) at the bench shape: since round 5 it takes a LEAN
+    instantiation of its own (it ran the general variant: 77.7 us per evaluation against 66.4 when fp32 was the default)
+    -- same log-weights, bit for bit, as the general fp32 variant on the same draws."""
+    from dgps_with_iwvi_amd import settings, synthetic
+    spec = synthetic.make_spec(L=2, M=128, B=1024, K=20, with_lv=True, seed=20, n_data=65536)
+    settings.set_seed(77)
+    old, settings.fw_f32_stage2 = settings.fw_f32_stage2, True
+    try:
+        model = synthetic.build_model(spec, gpu_device)
+        e_lean, lp_lean, lw_lean, v_lean = _evaluate(model, spec, force_general=False)
+        e_gen, lp_gen, lw_gen, v_gen = _evaluate(model, spec, force_general=True)
+    finally:
+        settings.fw_f32_stage2 = old
+    assert v_lean & LEAN_BIT and not v_lean & S16_BIT and (v_lean & 0xff) == 5, hex(v_lean)
+    assert not v_gen & (LEAN_BIT | SHAPES_BIT | S16_BIT), hex(v_gen)
+    np.testing.assert_array_equal(lw_lean, lw_gen)
+    np.testing.assert_allclose(lp_lean, lp_gen, rtol=0, atol=4e-6 * max(1.0, np.abs(lp_gen).max()))
+    assert abs(e_lean - e_gen) <= 2e-7 * abs(e_gen), (e_lean, e_gen)
+
+
 @pytest.mark.parametrize("why,kw", [("M = 64", dict(L=2, M=64, B=1024, K=20, with_lv=True)),
                                     ("K = 40 (tail needs K <= 32)", dict(L=2, M=128, B=512, K=40, with_lv=True)),
                                     ("a ragged last workgroup", dict(L=2, M=128, B=1023, K=20, with_lv=True))])
