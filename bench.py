@@ -186,6 +186,16 @@ def cpu_baseline(spec, seconds=12.0, dtype=torch.float64):
     batched matmuls with 256 threads is slower than fewer threads, and the baseline should be the host's best."""
     from dgps_with_iwvi_amd import synthetic
     from oracle.ref_torch_cpu import CpuDGP
+    # a BOUNDED sample of the workload: the restatement materialises [S, R, M, N] intermediates (8 B x 3 R M per sample and layer) and
+    # executes ~2 R M^2 FLOP per sample -- at configs[4] one full evaluation is 10 TFLOP and tens of GB.  The first B_cpu rows of the
+    # minibatch (all K samples each), B_cpu from a ~50 GFLOP/s / 8 GB budget; configs[1] / [2] run whole (B_cpu = B)
+    K_ = spec["K"]
+    gps_ = [l for l in spec["layers"] if l["type"] == "gp"]
+    f_est = sum(2.0 * l["q_mu"].shape[1] * l["Z"].shape[0] ** 2 + l["Z"].shape[0] ** 2 for l in gps_)
+    mem_per_row = max(3.0 * l["q_mu"].shape[1] * l["Z"].shape[0] * 8 for l in gps_) * K_
+    B_cpu = int(max(8, min(spec["B"], (seconds * 0.1) * 5e10 / (f_est * K_), 8e9 / mem_per_row)))
+    if B_cpu < spec["B"]:
+        spec = dict(spec, B=B_cpu, _cut=True)
     ncpu = os.cpu_count() or 1
     try:
         torch.set_num_interop_threads(1)                     # (one op at a time: the op sequence is a chain)
@@ -229,9 +239,9 @@ def cpu_baseline(spec, seconds=12.0, dtype=torch.float64):
                              "36 % the element-wise square of the permuted [S, R, M, N] intermediate (a strided pass over 13 M values), 27 % the "
                              "einsum GEMM, 8 % adds, 5 % copies of permuted views -- a chain of ~150 separately parallelised ops, so beyond a few "
                              "threads per op the fork / join and the strided passes, not the FLOPs (see executed_gflops), set the time",
-                sample="%d full IW-ELBO evaluations of the same workload (B=%d, K=%d), %s torch-CPU/MKL "
+                sample="%d IW-ELBO evaluations of the same workload%s (B=%d, K=%d), %s torch-CPU/MKL "
                        "restatement of the reference op sequence (materialised Kmn, A, LTA, full K x K final "
-                       "covariance), %d threads of %d, median" % (iters, spec["B"], spec["K"],
+                       "covariance), %d threads of %d, median" % (iters, "" if not spec.get("_cut") else " cut to its first rows", spec["B"], spec["K"],
                                                                   "float64" if dtype == torch.float64 else "float32", nt, ncpu),
                 ms_per_step=med * 1e3)
 

@@ -373,9 +373,13 @@ def iw_elbo_and_gradients(model, zs=None, mode_vi=None, exchange=None, K_total=N
     fused_heads = False
     if (not mode_vi) and exchange is None and (K_total is None or int(K_total) == K) and fuse_heads:
         try:
+            # (wrt = "final_q", the natural-gradient op: with the heads fused, of everything the launch can leave in HBM only the final
+            #  layer's a, draws and latent moments are read -- no per-layer rows, nothing of the inner layers: ~25 MB of stores less at configs[2])
+            slim = wrt == "final_q"
             _, outs, _ = model._fused_forward(T, K, B, (T,), zs=zflat, sampled_kl=True, want_layers=True, want_logw=True, want_saved=True,
                                               elbo=dict(B=B, K=K, stride_b=K, stride_k=1, mode_vi=False,
-                                                        adj=dict(w=w, d_mean=d_mean, d_var=d_var, sums=sums)))
+                                                        adj=dict(w=w, d_mean=d_mean, d_var=d_var, sums=sums)),
+                                              outputs_for={len(layers) - 1} if slim else None, moments=not slim)
             fused_heads = True
         except _abi.IwviError as e:
             if "fused adjoint heads" not in str(e):
@@ -386,7 +390,18 @@ def iw_elbo_and_gradients(model, zs=None, mode_vi=None, exchange=None, K_total=N
     # (the layer launch itself advances the device-resident noise counter: the next evaluation draws fresh noise)
     saved = []
     F = None
+    slim_q = fused_heads and wrt == "final_q"                    # only the final layer left anything (its adjoint reads a, noise, latent moments)
     for i, (layer, o) in enumerate(zip(layers, outs)):
+        if slim_q:
+            if i < len(layers) - 1:
+                saved.append(("skipped",))
+                continue
+            s = GpSaved()
+            s.F = torch.empty(T, layer._Z().shape[1], dtype=ft, device=dev)        # (shape only: the q-only adjoint does not read the inputs)
+            s.T, s.A, s.U, s.noise, s.GMV = T, o["a_out"], o.get("u_out"), o["noise_out"], o["gmv_out"]
+            s.sample = s.mean = s.var = None
+            saved.append(("gp", s))
+            continue
         if F is None and isinstance(layer, GPLayer):                              # first layer: the tiled inputs (models.py:113)
             F = X[:, None, :].expand(B, K, X.shape[1]).reshape(T, -1).contiguous()
         if isinstance(layer, LatentVariableLayer):
@@ -401,7 +416,7 @@ def iw_elbo_and_gradients(model, zs=None, mode_vi=None, exchange=None, K_total=N
     if saved[-1][0] != "gp":
         raise ValueError("the last layer must be a GPLayer")
     fin = saved[-1][1]
-    kls = [s[3] for s in saved if s[0] == "lv"]
+    kls = [s[3] for s in saved if s[0] == "lv"]                  # (only the unfused heads read them)
     klp = _abi.ptr_array(kls)
     kld = (ctypes.c_int32 * max(len(kls), 1))(*[k.shape[1] for k in kls])
     glob = [_abi.dev_tensor(g.reshape(-1), "global kl", torch.float64) for g in model._global_kls()]

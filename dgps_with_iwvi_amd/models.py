@@ -165,13 +165,16 @@ class DGP_VI:
 
     # -- fused forward ------------------------------------------------------------------------
     def _fused_forward(self, T, row_div, row_mod, lead, zs=None, sampled_kl=True, want_layers=False,
-                       want_logw=True, use_encoder=True, elbo=None, stack_from=0, want_saved=False):
+                       want_logw=True, use_encoder=True, elbo=None, stack_from=0, want_saved=False, outputs_for=None, moments=True):
         """``iwvi_dgp_forward`` over the current minibatch: every layer + log-weights in one launch.
         Row t of the flattened batch reads data row (t // row_div) % row_mod.  ``elbo`` = dict(B, K, stride_b,
         stride_k, mode_vi, want_ms, K_total): also run the reduction of models.py:138-150 in the tail of the
         launch.  Returns (logw [T] or None, per-layer dict lists when ``want_layers``, (elbo, logp, ms) or None).
         ``stack_from=1`` (needs ``elbo``): layer 0 was evaluated by ``precompute(sample_first=...)``; the launch
-        starts from its samples [T, Dx+Lw] and its per-sample regulariser."""
+        starts from its samples [T, Dx+Lw] and its per-sample regulariser.
+        ``outputs_for`` (with ``want_layers``): only these layers (indices into the stack) get output buffers, the others write
+        nothing; ``moments=False``: no sample / mean / var rows either (only what ``want_saved`` adds) -- the natural-gradient op needs
+        the final layer's a, noise and latent moments alone."""
         dev = self.X.device
         layers = self.layers[stack_from:]
         n = len(layers)
@@ -197,9 +200,9 @@ class DGP_VI:
                 R = layer.num_outputs
                 z2 = None if z is None else _abi.dev_tensor(z.reshape(T, R).contiguous(), "z")
                 o = None
-                if want_layers:
+                if want_layers and (outputs_for is None or i in outputs_for):
                     P = layer.kern.W.shape[0] if hasattr(layer.kern, "W") else R
-                    o = {k: torch.empty(*lead, P, dtype=settings.float_type, device=dev) for k in ("sample", "mean", "var")}
+                    o = {k: torch.empty(*lead, P, dtype=settings.float_type, device=dev) for k in ("sample", "mean", "var")} if moments else {}
                     if want_saved:                               # what the adjoint of this layer needs (backward.py)
                         Mp = layer.state().Mp
                         o["a_out"] = torch.empty(T, Mp, dtype=settings.float_type, device=dev)
@@ -216,8 +219,8 @@ class DGP_VI:
                 Lw = layer.latent_dim
                 z2 = None if z is None else _abi.dev_tensor(z.reshape(T, Lw).contiguous(), "z")
                 o = None
-                if want_layers:
-                    o = {k: torch.empty(*lead, D + Lw, dtype=settings.float_type, device=dev) for k in ("sample", "mean", "var")}
+                if want_layers and (outputs_for is None or i in outputs_for):
+                    o = {k: torch.empty(*lead, D + Lw, dtype=settings.float_type, device=dev) for k in ("sample", "mean", "var")} if moments else {}
                     o["kl_local"] = torch.empty(*lead, Lw, dtype=settings.float_type, device=dev)
                     if want_saved:
                         o["noise_out"] = torch.empty(T, Lw, dtype=settings.float_type, device=dev)
