@@ -1229,10 +1229,53 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
                     for (int i = tid; i < (FW_WAVES * R * NSAMP) / 4; i += FW_THREADS) uz[i] = f32x4{0.f, 0.f, 0.f, 0.f};
                 }
             }
+            // Z~ from L2 (the large stacks: five layers' images do not fit the LDS beside a 96-KiB tile): every wave reaches this phase behind the
+            // same barrier, so a load in front of its MFMAs is a round trip all eight wait for together -- and the k-step loop had one
+            // per step (run-time trip count: load, wait, NS MFMAs; 12 round trips per wave at M = 512 = most of the phase's 5.2 us).
+            // Round 5: the first GZP k-steps of the NEXT block row are requested while this one's MFMAs issue.
+            constexpr int GZP = 3;                                // (D <= 10; the steps beyond are loaded in place)
+            float znext[GZP] = {0.f, 0.f, 0.f};
+            // (only in the variants of at most three sub-tiles -- the ones whose Z~ images do not fit: at NS = 5 the images are staged, and
+            //  the extra live registers cost configs[3] 1.4 %)
+            constexpr bool GZ_ON = BIG && NS <= 3;
+            const bool z_l2 = GZ_ON && !SHP && gram_mfma && G.zt_off < 0 && !f64_l;
+            if (GZ_ON && z_l2 && wave < nbk) {
+                gptr1 zq = (gptr1)G.ZtP + (size_t)wave * nsteps * 64 + lane;
+#pragma unroll
+                for (int u = 0; u < GZP; ++u) znext[u] = zq[(u < nsteps ? u : nsteps - 1) * 64];
+            }
             for (int bi = wave; bi < (f64_l ? 0 : nbk); bi += FW_WAVES) {
                 f32x4 acc[NS];
 #pragma unroll
                 for (int t = 0; t < NS; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (GZ_ON && z_l2) {
+                    float zc[GZP];
+#pragma unroll
+                    for (int u = 0; u < GZP; ++u) zc[u] = znext[u];
+                    FW_PIN_LOADS();
+                    {
+                        const int bn = bi + FW_WAVES < nbk ? bi + FW_WAVES : bi;
+                        gptr1 zq = (gptr1)G.ZtP + (size_t)bn * nsteps * 64 + lane;
+#pragma unroll
+                        for (int u = 0; u < GZP; ++u) znext[u] = zq[(u < nsteps ? u : nsteps - 1) * 64];
+                    }
+                    FW_PIN_LOADS();
+#pragma unroll
+                    for (int u = 0; u < GZP; ++u) {
+                        if (u < nsteps) {
+#pragma unroll
+                            for (int t = 0; t < NS; ++t)
+                                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(zc[u], xt[(16 * t + jq) * XSTR + 4 * u + gq], acc[t], 0, 0, 0);
+                        }
+                    }
+                    gptr1 zp = (gptr1)G.ZtP + (size_t)bi * nsteps * 64 + lane;
+                    for (int s = GZP; s < nsteps; ++s) {
+                        const float a = zp[s * 64];
+#pragma unroll
+                        for (int t = 0; t < NS; ++t)
+                            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, xt[(16 * t + jq) * XSTR + 4 * s + gq], acc[t], 0, 0, 0);
+                    }
+                } else
                 if (gram_mfma) {
                     if (SHP || G.zt_off >= 0) {
                         const float* zp = sm + G.zt_off + (size_t)bi * nsteps * 64 + lane;      // staged in LDS

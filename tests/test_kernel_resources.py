@@ -24,7 +24,7 @@ def test_hot_kernels_stay_within_their_register_budget():
         assert must in names, must
     by = {r["demangled"]: r for r in rows}
     assert by["k_dgp_forward<5,true,false,1,false>"]["private_segment_fixed_size"] == 0      # the headline variant: no scratch, ever
-    assert by["k_dgp_forward<3,true,true,0,false>"]["private_segment_fixed_size"] <= 28      # configs[4]: the solve's operand rings (round 5)
+    assert by["k_dgp_forward<3,true,true,0,false>"]["private_segment_fixed_size"] <= 52      # configs[4]: the solve's operand rings + the Gram's prefetch (round 5)
     assert all(r["vgpr_count"] <= 256 for r in rows if r["demangled"].startswith("k_dgp_forward"))
 
 
