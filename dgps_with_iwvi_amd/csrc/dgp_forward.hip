@@ -1419,7 +1419,7 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
                 float ssq[NS];
 #pragma unroll
                 for (int t = 0; t < NS; ++t) ssq[t] = 0.f;
-                int off = 0, off16 = 0;
+                int off = 0, off16 = 0, offt = 0;
                 // block row of a wave within a super-block: waves w and w + 4 share a SIMD, and row q of the inverse part costs q + 1 blocks --
                 // rows (i, 7 - i) per SIMD level it (9 blocks each instead of 6 / 8 / 10 / 12)
                 const int rw = wave < 4 ? wave : 11 - wave;
@@ -1430,6 +1430,10 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
                     const int bi = r0 + rw;
                     f32x4 acc[NS];
                     DBG_WSTAMP(48 + 6 * I);
+                    f32x4 Dg = {0.f, 0.f, 0.f, 0.f};              // S16: the row's own diagonal block of (L_II)^-1 (fp32), asked for ahead of the dense part
+                    if constexpr (S16) {
+                        if (mine) { Dg = Ap[(size_t)(off + nr * r0 + rw * (rw + 1) / 2 + rw) * 64]; FW_PIN_LOADS(); }
+                    }
                     if (S16 && mine && r0 > 0) {
                         using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
                         const int nst = r0 >> 1;                  // slabs of this block row
@@ -1466,7 +1470,10 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
                         }
                         const float inv_u = 1.0f / (sa_sb * sa_sb);   // both operands carry 2^ea (exact powers of two)
 #pragma unroll
-                        for (int t = 0; t < NS; ++t) at[(bi * 4 + gq) * NSAMP + 16 * t + jq] = kuf[(bi * 4 + gq) * NSAMP + 16 * t + jq] + acc[t] * inv_u;
+                        for (int t = 0; t < NS; ++t) acc[t] = kuf[(bi * 4 + gq) * NSAMP + 16 * t + jq] + acc[t] * inv_u;      // r(bi), in registers
+                    } else if (S16 && mine) {
+#pragma unroll
+                        for (int t = 0; t < NS; ++t) acc[t] = kuf[(bi * 4 + gq) * NSAMP + 16 * t + jq];                        // first super-block: r = k
                     } else if (mine && r0 > 0) {
 #pragma unroll
                         for (int t = 0; t < NS; ++t) acc[t] = kuf[(bi * 4 + gq) * NSAMP + 16 * t + jq];
@@ -1488,40 +1495,106 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
 #pragma unroll
                         for (int t = 0; t < NS; ++t) at[(bi * 4 + gq) * NSAMP + 16 * t + jq] = acc[t];      // r(bi), in place of k(bi)
                     }
-                    // the row's first blocks of the inverse super-block are requested BEFORE the barrier (nothing in them depends on r_I):
-                    // the wait for the slowest row covers their round trip; SBT blocks in flight from then on (one until round 5).
-                    // (Tried in round 5 and not kept: the short row's wave also taking the long row of its SIMD partner for the last
-                    // sub-tiles -- per-wave times level out, 3700-5400 clocks instead of 1400-5600, but the phase is as long as before: it is
-                    // bound by what one SIMD issues, not by the balance between its two waves; and the extra accumulators spill.)
-                    f32x4 Ti[SBT];
-                    gptr4 Pt = Ap + (size_t)(off + nr * r0 + rw * (rw + 1) / 2) * 64;
-                    if (mine) {
+                    // ---- a_I = (L_II)^-1 r_I.  S16 (round 5, last): only the DIAGONAL block of a row is an fp32 product -- on the row's own r(bi),
+                    // still in registers, in front of the barrier --; the blocks left of it take split-f16 operands like the dense part: the
+                    // packed image holds, per lane, [h1 x 4 | h2 x 4] of 2^lg (L_II)^-1 (k_pack_ls16; lg = ceil(log2 sigma)), every row
+                    // publishes r(bi) as [h1 x 4 | h2 x 4] of s_r r (s_r = 2^(5 - 2 lg): |r| <= sigma^2 -> <= 32) in place of k(bi), and
+                    // block (w, q) costs two v_mfma_f32_16x16x32_f16 per sub-tile (A = [h1 | h1], then [h2 | h2], against B = [h1' | h2']:
+                    // all four partial products) -- 32 clocks where the fp32 block took 128; 28 of a super-block's 36 blocks.  An error in
+                    // these products is amplified by cond(L_II) like one in r itself, which the split-f16 dense part already carries at
+                    // the same 2^-22; layers whose K_uu is ill-conditioned take the float64 route (F64).
+                    if constexpr (S16) {
+                        f32x4 Ti[SBT];
+                        using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
+                        const float s_i = 1024.0f / sa_sb, s_r = 32.0f / (s_i * s_i);        // sa_sb = 2^(10 - lg) for these layers
+                        gptr4 Pt16 = (gptr4)G.LsP + G.ls16_off + (size_t)sb16_slabs(nbk) * 128 + (size_t)(offt + rw * (rw - 1) / 2) * 64 + lane;
+                        if (mine) {
 #pragma unroll
-                        for (int u = 0; u < SBT; ++u) Ti[u] = Pt[(size_t)(u <= rw ? u : rw) * 64];
-                    }
-                    DBG_WSTAMP(49 + 6 * I);
-                    if (r0 > 0) __syncthreads();                  // r_I complete
-                    DBG_WSTAMP(50 + 6 * I);
-                    if (mine) {
+                            for (int u = 0; u < SBT; ++u) Ti[u] = Pt16[(size_t)(u < rw ? u : (rw > 0 ? rw - 1 : 0)) * 64];
+                            f32x4 rs[NS];
 #pragma unroll
-                        for (int t = 0; t < NS; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-                        for (int q0 = 0; q0 <= rw; q0 += SBT) {
+                            for (int t = 0; t < NS; ++t) {
+                                rs[t] = acc[t] * s_r;
+                                f16x4 h1, h2;
+                                split_b16(rs[t], 1.0f, h1, h2);
+                                A16 pk; pk.h1 = h1; pk.h2 = h2;
+                                f32x4 w_;
+                                __builtin_memcpy(&w_, &pk, 16);
+                                at[(bi * 4 + gq) * NSAMP + 16 * t + jq] = w_;
+                                rs[t] = rs[t] * s_i;
+                                acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+                            }
 #pragma unroll
-                            for (int u = 0; u < SBT; ++u) {
-                                const int q = q0 + u;
-                                if (q <= rw) {                    // (wave-uniform)
-                                    const f32x4 a_cur = Ti[u];
-                                    f32x4 b[NS];
+                            for (int s = 0; s < 4; ++s) {
 #pragma unroll
-                                    for (int t = 0; t < NS; ++t) b[t] = at[((r0 + q) * 4 + gq) * NSAMP + 16 * t + jq];
+                                for (int t = 0; t < NS; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(Dg[s], rs[t][s], acc[t], 0, 0, 0);
+                            }
+                        }
+                        DBG_WSTAMP(49 + 6 * I);
+                        __syncthreads();                          // r_I complete (published by every row)
+                        DBG_WSTAMP(50 + 6 * I);
+                        if (mine) {
+                            for (int q0 = 0; q0 < rw; q0 += SBT) {
 #pragma unroll
-                                    for (int s = 0; s < 4; ++s) {
+                                for (int u = 0; u < SBT; ++u) {
+                                    const int q = q0 + u;
+                                    if (q < rw) {                 // (wave-uniform)
+                                        const A16 ah = as_a16(Ti[u]);
+                                        const f16x8 a1 = __builtin_shufflevector(ah.h1, ah.h1, 0, 1, 2, 3, 4, 5, 6, 7);
+                                        const f16x8 a2 = __builtin_shufflevector(ah.h2, ah.h2, 0, 1, 2, 3, 4, 5, 6, 7);
+                                        f32x4 b[NS];
 #pragma unroll
-                                        for (int t = 0; t < NS; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[s], b[t][s], acc[t], 0, 0, 0);
+                                        for (int t = 0; t < NS; ++t) b[t] = at[((r0 + q) * 4 + gq) * NSAMP + 16 * t + jq];
+#pragma unroll
+                                        for (int t = 0; t < NS; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, __builtin_bit_cast(f16x8, b[t]), acc[t], 0, 0, 0);
+#pragma unroll
+                                        for (int t = 0; t < NS; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2, __builtin_bit_cast(f16x8, b[t]), acc[t], 0, 0, 0);
+                                        FW_PIN_LOADS();
+                                        Ti[u] = Pt16[(size_t)(q + SBT < rw ? q + SBT : rw - 1) * 64];
+                                        FW_PIN_LOADS();
                                     }
-                                    FW_PIN_LOADS();
-                                    Ti[u] = Pt[(size_t)(q + SBT <= rw ? q + SBT : rw) * 64];
-                                    FW_PIN_LOADS();
+                                }
+                            }
+                            const float un = 1.0f / (s_r * s_i);
+#pragma unroll
+                            for (int t = 0; t < NS; ++t) acc[t] = acc[t] * un;
+                        }
+                    } else {
+                        // the row's first blocks of the inverse super-block are requested BEFORE the barrier (nothing in them depends on r_I):
+                        // the wait for the slowest row covers their round trip; SBT blocks in flight from then on (one until round 5).
+                        // (Tried in round 5 and not kept: the short row's wave also taking the long row of its SIMD partner for the last
+                        // sub-tiles -- per-wave times level out, 3700-5400 clocks instead of 1400-5600, but the phase is as long as before: it is
+                        // bound by what one SIMD issues, not by the balance between its two waves; and the extra accumulators spill.)
+                        f32x4 Ti[SBT];
+                        gptr4 Pt = Ap + (size_t)(off + nr * r0 + rw * (rw + 1) / 2) * 64;
+                        if (mine) {
+#pragma unroll
+                            for (int u = 0; u < SBT; ++u) Ti[u] = Pt[(size_t)(u <= rw ? u : rw) * 64];
+                        }
+                        DBG_WSTAMP(49 + 6 * I);
+                        if (r0 > 0) __syncthreads();                  // r_I complete
+                        DBG_WSTAMP(50 + 6 * I);
+                        if (mine) {
+#pragma unroll
+                            for (int t = 0; t < NS; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+                            for (int q0 = 0; q0 <= rw; q0 += SBT) {
+#pragma unroll
+                                for (int u = 0; u < SBT; ++u) {
+                                    const int q = q0 + u;
+                                    if (q <= rw) {                    // (wave-uniform)
+                                        const f32x4 a_cur = Ti[u];
+                                        f32x4 b[NS];
+#pragma unroll
+                                        for (int t = 0; t < NS; ++t) b[t] = at[((r0 + q) * 4 + gq) * NSAMP + 16 * t + jq];
+#pragma unroll
+                                        for (int s = 0; s < 4; ++s) {
+#pragma unroll
+                                            for (int t = 0; t < NS; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[s], b[t][s], acc[t], 0, 0, 0);
+                                        }
+                                        FW_PIN_LOADS();
+                                        Ti[u] = Pt[(size_t)(q + SBT <= rw ? q + SBT : rw) * 64];
+                                        FW_PIN_LOADS();
+                                    }
                                 }
                             }
                         }
@@ -1547,6 +1620,7 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
                     __syncthreads();                              // a_I visible (next super-block's product, stage 2)
                     off += nr * r0 + nr * (nr + 1) / 2;
                     off16 += nr * (r0 >> 1);
+                    offt += nr * (nr - 1) / 2;
                 }
                 // |a|^2: every wave's share to its own slot, summed in a fixed order
 #pragma unroll

@@ -63,6 +63,14 @@ __host__ __device__ static inline int sb16_slabs(int nbk) {
     for (int I = 1; 8 * I < nbk; ++I) { const int nr = nbk - 8 * I < 8 ? nbk - 8 * I : 8; n += nr * 4 * I; }
     return nbk >= 16 ? n : 0;
 }
+// ... and the triangular part -- a_I = (L_II)^-1 r_I -- takes split-f16 operands for every block LEFT of the diagonal (round 5): behind the
+// slabs, one 1-KiB block per (super-block I, row w = 1 .. nr - 1, q < w), rows in order, lane 16 g + i holding [h1 x 4 | h2 x 4] of
+// 2^lg (L_II)^-1 [16 w + i][16 q + 4 g .. + 3] (lg = ceil(log2 sigma); saturated at the largest f16) -- k_pack_ls16 again
+__host__ __device__ static inline int sb16_tri_blocks(int nbk) {
+    int n = 0;
+    for (int I = 0; 8 * I < nbk; ++I) { const int nr = nbk - 8 * I < 8 ? nbk - 8 * I : 8; n += nr * (nr - 1) / 2; }
+    return nbk >= 16 ? n : 0;
+}
 struct StateLayout {
     int Mp, nbk, nrb, nsteps;
     size_t off_Lm, off_Linv, off_LsP, off_LrTP, off_QmuP, off_ZtP, off_cst, off_kl, off_ws, off_LrT16, off_Qmu16, off_Ls16, off_Zs, bytes;
@@ -93,7 +101,7 @@ __host__ __device__ static inline StateLayout state_layout(int M, int R) {
     // split-f16 images of L_r^T and q_mu^T for v_mfma_f32_16x16x32_f16 (s16_*): 2-KiB slabs (16 rows x 32 k, two f16 planes)
     s.off_LrT16 = o; o = align256(o + (size_t)R * s16_slabs_total(s.nbk) * 2048);
     s.off_Qmu16 = o; o = align256(o + (size_t)s.nrb * ((s.nbk + 1) / 2) * 2048);
-    s.off_Ls16 = o;  o = align256(o + (size_t)sb16_slabs(s.nbk) * 2048);
+    s.off_Ls16 = o;  o = align256(o + (size_t)sb16_slabs(s.nbk) * 2048 + (size_t)sb16_tri_blocks(s.nbk) * 1024);
     // float64 stage-1 route (IWVI_GP_F64_STAGE1): the centred, scaled inducing inputs z~ as PLAIN float32 [Mp][IWVI_MAX_D] -- the very values
     // the factorisation saw (ZtP holds them times log2 e, rounded again) -- written by k_f64_prep behind the precompute launch
     s.off_Zs = o;    o = align256(o + sizeof(float) * (size_t)s.Mp * IWVI_MAX_D);

@@ -155,7 +155,7 @@ __global__ __launch_bounds__(1024) void k_precompute(PreArgs args) {
 // the launch before left in the layer's workspace (block storage; the blocks between different super-blocks still hold L there) or, for a
 // state precomputed with IWVI_GP_WANT_DENSE / _LM, from its dense Lm.  A launch of its own: k_precompute is not touched by it
 // (at 128 VGPRs with spills, a source change anywhere in that kernel moves the M <= 128 path by +-1 us: profiles/r04_precompute_notes.txt).
-struct Ls16One { const double* blk; const double* Lm; unsigned short* dst; const float* variance_dev; float variance; int nbk, Mp, M, first; };
+struct Ls16One { const double* blk; const double* Lm; unsigned short* dst; const float* LsP; const float* variance_dev; float variance; int nbk, Mp, M, first; };
 struct Ls16All { Ls16One L[IWVI_MAX_LAYERS]; int n; };
 __global__ __launch_bounds__(256) void k_pack_ls16(const Ls16All a) {
     int li = 0;
@@ -163,8 +163,38 @@ __global__ __launch_bounds__(256) void k_pack_ls16(const Ls16All a) {
     const Ls16One& L = a.L[li];
     const int nbk = L.nbk;
     int s = ((int)blockIdx.x - L.first) * 4 + (threadIdx.x >> 6);           // slab of this wave
-    if (s >= sb16_slabs(nbk)) return;
     const int lane = threadIdx.x & 63;
+    if (s >= sb16_slabs(nbk)) {
+        // the triangular part's blocks left of the diagonal (iwvi_common.h: sb16_tri_blocks), from the fp32 blocks k_sb_inv / k_precompute
+        // packed into LsP in the launches before: same lane, same four values -- scaled by 2^lg and split
+        int tb = s - sb16_slabs(nbk);
+        if (tb >= sb16_tri_blocks(nbk)) return;
+        const int tb0 = tb;
+        int I = 0, off = 0;
+        for (;; ++I) {
+            const int r0 = 8 * I, nr = nbk - r0 < 8 ? nbk - r0 : 8, cnt = nr * (nr - 1) / 2;
+            if (tb < cnt) break;
+            tb -= cnt; off += nr * r0 + nr * (nr + 1) / 2;
+        }
+        const int r0 = 8 * I, nr = nbk - r0 < 8 ? nbk - r0 : 8;
+        int w = 1;
+        while (w * (w + 1) / 2 <= tb) ++w;
+        const int q = tb - w * (w - 1) / 2;
+        const float var = L.variance_dev ? *L.variance_dev : L.variance;
+        const float si = ldexpf(1.f, (int)ceilf(0.5f * log2f(fmaxf(var, 1e-30f))));
+        const float4 v = reinterpret_cast<const float4*>(L.LsP)[(size_t)(off + nr * r0 + w * (w + 1) / 2 + q) * 64 + lane];
+        const float x[4] = {v.x * si, v.y * si, v.z * si, v.w * si};
+        pk_f16x8 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float xc = fminf(fmaxf(x[e], -65504.f), 65504.f);
+            const _Float16 hh = (_Float16)xc;
+            o[e] = hh; o[4 + e] = (_Float16)(xc - (float)hh);
+        }
+        unsigned short* dst = L.dst + (size_t)sb16_slabs(nbk) * 1024 + (size_t)tb0 * 512;
+        *reinterpret_cast<float4*>(dst + lane * 8) = as_f4(o);
+        return;
+    }
     int I = 1;
     for (;; ++I) { const int nr = nbk - 8 * I < 8 ? nbk - 8 * I : 8, cnt = nr * 4 * I; if (s < cnt) break; s -= cnt; }
     const int row = s / (4 * I), kc = s - row * 4 * I;                      // block row 8 I + row, blocks 2 kc, 2 kc + 1
@@ -702,9 +732,10 @@ extern "C" int iwvi_model_precompute(const iwvi_gp_desc* layers, int n_layers, c
                 o.blk = L.ws + ws_layout(L.Mp).blk;
                 o.Lm = (L.flags & (IWVI_GP_WANT_DENSE | IWVI_GP_WANT_LM)) ? L.Lm : nullptr;
                 o.dst = reinterpret_cast<unsigned short*>(reinterpret_cast<char*>(L.Lm) - sl.off_Lm + sl.off_Ls16);
+                o.LsP = L.LsP;
                 o.variance = L.variance; o.variance_dev = L.variance_dev;
                 o.nbk = L.nbk; o.Mp = L.Mp; o.M = L.M; o.first = grid;
-                grid += (sb16_slabs(L.nbk) + 3) / 4;
+                grid += (sb16_slabs(L.nbk) + sb16_tri_blocks(L.nbk) + 3) / 4;
             }
             if (q.n > 0) {
                 hipLaunchKernelGGL(k_pack_ls16, dim3(grid), dim3(256), 0, stream, q);

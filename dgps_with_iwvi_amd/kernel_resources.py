@@ -32,8 +32,8 @@ ALLOWED_SCRATCH = {
     # variants; none may grow.  (template arguments: NS, S16, BIG, LEAN_MODE, F64)
     "k_dgp_forward<2,true,false,0,false>": 16, "k_dgp_forward<4,false,true,0,false>": 24, "k_dgp_forward<4,true,false,0,false>": 56,
     "k_dgp_forward<5,true,false,2,false>": 12,
-    "k_dgp_forward<2,true,true,0,false>": 68, "k_dgp_forward<3,true,true,0,false>": 52, "k_dgp_forward<2,false,true,0,false>": 24, "k_dgp_forward<4,true,true,0,false>": 52,
-    "k_dgp_forward<5,true,true,0,false>": 76,
+    "k_dgp_forward<2,true,true,0,false>": 24, "k_dgp_forward<3,true,true,0,false>": 52, "k_dgp_forward<2,false,true,0,false>": 24, "k_dgp_forward<4,true,true,0,false>": 56,
+    "k_dgp_forward<5,true,true,0,false>": 60,
     # the float64 stage-1 variants (an accuracy route, never a BASELINE workload's)
     "k_dgp_forward<1,false,true,0,true>": 24, "k_dgp_forward<2,false,true,0,true>": 88, "k_dgp_forward<3,false,true,0,true>": 32,
     "k_dgp_forward<4,false,true,0,true>": 128, "k_dgp_forward<5,false,true,0,true>": 24,
