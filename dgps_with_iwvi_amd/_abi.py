@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libiwvi_hip.so")
 
 KERN_RBF, KERN_MATERN52 = 0, 1
 LAYER_GP, LAYER_LV = 0, 1
-ABI_VERSION = 14
+ABI_VERSION = 15
 GP_WANT_DENSE = 1
 GP_WANT_LM = 2
 LAYER_F32_STAGE2 = 1        # iwvi_layer_desc.flags
@@ -138,6 +138,11 @@ PROTOTYPES = {
     "iwvi_encoder_backward_act": (c_int, [c_void_p, c_int64, ctypes.POINTER(c_void_p), ctypes.POINTER(c_void_p),
                                           ctypes.POINTER(ctypes.c_int32), c_int, c_int, c_void_p,
                                           ctypes.POINTER(c_void_p), ctypes.POINTER(c_void_p), c_void_p, c_void_p]),
+    "iwvi_lv_encoder_backward": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p,
+                                         c_int, c_int64, c_int, c_int,
+                                         c_void_p, ctypes.POINTER(c_void_p), ctypes.POINTER(c_void_p),
+                                         ctypes.POINTER(ctypes.c_int32), c_int, c_int,
+                                         ctypes.POINTER(c_void_p), ctypes.POINTER(c_void_p), c_void_p, c_void_p]),
     "iwvi_encoder_backward": (c_int, [c_void_p, c_int64, ctypes.POINTER(c_void_p), ctypes.POINTER(c_void_p),
                                       ctypes.POINTER(ctypes.c_int32), c_int, c_void_p,
                                       ctypes.POINTER(c_void_p), ctypes.POINTER(c_void_p), c_void_p, c_void_p]),
@@ -191,7 +196,7 @@ PROTOTYPES = {
     "iwvi_fill_normal_dev": (c_int, [c_void_p, c_int64, ctypes.c_uint64, c_void_p, c_void_p]),
 }
 
-DEBUG_OPTIONS = ("IWVI_BW_FUSED", "IWVI_CHAIN_EXIT", "IWVI_FW_SLOW_TAIL", "IWVI_NATGRAD_UNFUSED", "IWVI_NG_STOP", "IWVI_DEBUG_STOP", "IWVI_PRE_STAMP_P",
+DEBUG_OPTIONS = ("IWVI_BW_FUSED", "IWVI_CHAIN_EXIT", "IWVI_FW_SLOW_TAIL", "IWVI_NATGRAD_UNFUSED", "IWVI_NG_ONE_WG", "IWVI_NG_STOP", "IWVI_DEBUG_STOP", "IWVI_PRE_STAMP_P",
                  "IWVI_FW_NO_LEAN", "IWVI_PRE_SB_INLINE")
 
 

@@ -262,13 +262,27 @@ def gp_backward(layer, saved, d_sample=None, d_mean=None, d_var=None, kl_weight=
     return out
 
 
-def lv_backward(layer, XY, enc_out, eps, dF_next, col0, w, B, K, sampled_kl=True):
+def lv_backward(layer, XY, enc_out, eps, dF_next, col0, w, B, K, sampled_kl=True, fused=True):
     """``iwvi_lv_layer_backward`` + ``iwvi_encoder_backward`` -> (dW list, db list) of the layer's encoder.
     ``enc_out`` [B, 2*latent_dim] = (means | raw) as the precompute launch leaves it (``layer._enc_out``)."""
     dev = enc_out.device
     Lw = layer.latent_dim
     ft = settings.float_type
     enc_out = _abi.dev_tensor(enc_out, "enc_out")
+    if layer.encoder.custom_act is None and fused:
+        # one launch: the encoder's workgroups form the d(means | raw) of their own rows (iwvi_lv_encoder_backward)
+        Wp, bp, dims, n, keep = layer.encoder.abi_args()
+        dW = [torch.empty_like(t) for t in keep[0]]
+        db = [torch.empty_like(t) for t in keep[1]]
+        dWp, dbp = _abi.ptr_array(dW), _abi.ptr_array(db)
+        ws = torch.empty(_abi.lib().iwvi_encoder_backward_ws_bytes(B, dims, n), dtype=torch.uint8, device=dev)
+        XY = _abi.dev_tensor(XY.contiguous(), "encoder input")
+        _abi.check(_abi.lib().iwvi_lv_encoder_backward(
+            ctypes.c_void_p(enc_out.data_ptr()), ctypes.c_void_p(enc_out.data_ptr() + 4 * Lw), 2 * Lw, 1,
+            _abi.ptr(eps), _abi.ptr(dF_next), 0 if dF_next is None else dF_next.shape[1], col0,
+            _abi.ptr(w), Lw, B, K, 1 if sampled_kl else 0,
+            _abi.ptr(XY), Wp, bp, dims, n, layer.encoder.act, dWp, dbp, ws.data_ptr(), _abi.stream_ptr()))
+        return dW, db
     d_enc = torch.empty(B, 2 * Lw, dtype=ft, device=dev)
     _abi.check(_abi.lib().iwvi_lv_layer_backward(
         ctypes.c_void_p(enc_out.data_ptr()), ctypes.c_void_p(enc_out.data_ptr() + 4 * Lw), 2 * Lw, 1,

@@ -2047,13 +2047,8 @@ struct LvBwdArgs {
     const float* mu; const float* sigma; int ld_enc, raw; const float* eps; const float* dFn; int ld, col0;
     const float* w; int Lw; long long B; int K, sampled; float* d_out;
 };
-__global__ __launch_bounds__(256) void k_lv_bwd(LvBwdArgs a) {
-    // one wave per (point, latent dim), lanes over its K samples (a thread per point walking K samples is a chain of K
-    // dependent global round trips); lane partials combined by a fixed shuffle tree: deterministic
-    const int lane = threadIdx.x & 63;
-    const long long idx = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (idx >= a.B * a.Lw) return;
-    const long long b = idx / a.Lw; const int l = (int)(idx - b * a.Lw);
+// (point b, latent dim l): lanes over the K samples, partials combined by a fixed shuffle tree (deterministic) -> (d mu, d raw) in every lane
+__device__ __forceinline__ void lv_bwd_pair(const LvBwdArgs& a, long long b, int l, int lane, float& o_mu, float& o_raw) {
     const float mu = a.mu[b * a.ld_enc + l];
     float sg = a.sigma[b * a.ld_enc + l];
     if (a.raw) sg = softplus_f(sg - 3.f);
@@ -2067,9 +2062,21 @@ __global__ __launch_bounds__(256) void k_lv_bwd(LvBwdArgs a) {
         else { dmu += dfw + dkl * mu; dsg += dfw * e + dkl * (sg - 1.f / sg); }
     }
     for (int o = 32; o > 0; o >>= 1) { dmu += __shfl_xor(dmu, o, 64); dsg += __shfl_xor(dsg, o, 64); }
+    o_mu = dmu;
+    o_raw = dsg * (1.f - __expf(-sg));                          // sigma = softplus(raw - 3): d sigma / d raw = 1 - exp(-sigma)
+}
+__global__ __launch_bounds__(256) void k_lv_bwd(LvBwdArgs a) {
+    // one wave per (point, latent dim), lanes over its K samples (a thread per point walking K samples is a chain of K
+    // dependent global round trips)
+    const int lane = threadIdx.x & 63;
+    const long long idx = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (idx >= a.B * a.Lw) return;
+    const long long b = idx / a.Lw; const int l = (int)(idx - b * a.Lw);
+    float dmu, draw;
+    lv_bwd_pair(a, b, l, lane, dmu, draw);
     if (lane == 0) {
         a.d_out[b * 2 * a.Lw + l] = dmu;
-        a.d_out[b * 2 * a.Lw + a.Lw + l] = dsg * (1.f - __expf(-sg));      // sigma = softplus(raw - 3): d sigma / d raw = 1 - exp(-sigma)
+        a.d_out[b * 2 * a.Lw + a.Lw + l] = draw;
     }
 }
 
@@ -2078,6 +2085,7 @@ struct EncBwdArgs {
     const float* XY; long long rows; const float* W[IWVI_MAX_ENC]; const float* b[IWVI_MAX_ENC]; int dims[IWVI_MAX_ENC + 1]; int n;
     const float* d_out; int act;
     float* part; int woff[IWVI_MAX_ENC], boff[IWVI_MAX_ENC], ptot;     // part[workgroup][ptot]: this workgroup's share of (dW_l | db_l)
+    LvBwdArgs lv; int fused;                                           // fused: d_out rows come from the latent-variable layer's adjoint, formed here
 };
 constexpr int ER = 8, ELD = 65;         // rows per workgroup, row stride of an activation tile in LDS
 constexpr int EW_MAX = IWVI_MAX_ENC * (64 * 64 + 64);   // LDS copy of the weights and biases (widths <= 64)
@@ -2094,15 +2102,51 @@ __global__ __launch_bounds__(256) void k_enc_bwd(EncBwdArgs a) {
     float* prev = dl + ER * ELD;
     float* wl = prev + ER * ELD;                         // weights | biases of every layer, laid out like a workgroup's share of the
     //                                                      parameter gradients: W_l at woff[l], b_l at boff[l] (ptot floats in all)
-    for (int l = 0; l < a.n; ++l) {
-        const int nw = a.dims[l] * a.dims[l + 1], nb = a.dims[l + 1];
-        for (int idx = tid; idx < nw; idx += 256) wl[a.woff[l] + idx] = a.W[l][idx];
-        for (int idx = tid; idx < nb; idx += 256) wl[a.boff[l] + idx] = a.b[l] ? a.b[l][idx] : 0.f;
+    // Prologue: every global read is issued before the first value is used (round 5: layer by layer, each copy loop a round trip of its
+    // own -- weights x n, input rows, d_out: six dependent round trips in a 15 us kernel).
+    constexpr int CH = 8;                                    // parameters per thread held in registers (n ptot <= 2048: one pass)
+    float wv[CH];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+        const int idx = tid + 256 * c;
+        wv[c] = 0.f;
+        if (idx < a.ptot) {
+            int l = 0;
+            while (l + 1 < a.n && idx >= a.woff[l + 1]) ++l;
+            wv[c] = idx < a.boff[l] ? a.W[l][idx - a.woff[l]] : (a.b[l] ? a.b[l][idx - a.boff[l]] : 0.f);
+        }
     }
-    for (int idx = tid; idx < nrows * a.dims[0]; idx += 256) {
-        const int r = idx / a.dims[0], i = idx - r * a.dims[0];
-        const float v = a.XY[(row0 + r) * a.dims[0] + i];
-        acts[r * ELD + i] = v;
+    float xv[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const int idx = tid + 256 * c;
+        xv[c] = 0.f;
+        if (idx < nrows * a.dims[0]) { const int r = idx / a.dims[0], i = idx - r * a.dims[0]; xv[c] = a.XY[(row0 + r) * a.dims[0] + i]; }
+    }
+    const int dlast = a.dims[a.n];
+    if (a.fused) {
+        // d / d (means | raw) of this workgroup's rows: the latent-variable layer's adjoint (k_lv_bwd's arithmetic, same shuffle tree)
+        const int lane = tid & 63, wave = tid >> 6;
+        for (int p = wave; p < nrows * a.lv.Lw; p += 4) {
+            const int r = p / a.lv.Lw, l = p - r * a.lv.Lw;
+            float dmu, draw;
+            lv_bwd_pair(a.lv, row0 + r, l, lane, dmu, draw);
+            if (lane == 0) { cur[r * ELD + l] = dmu; cur[r * ELD + a.lv.Lw + l] = draw; }
+        }
+    } else {
+        for (int idx = tid; idx < nrows * dlast; idx += 256) { const int r = idx / dlast, o = idx - r * dlast; cur[r * ELD + o] = a.d_out[(row0 + r) * dlast + o]; }
+    }
+#pragma unroll
+    for (int c = 0; c < CH; ++c) { const int idx = tid + 256 * c; if (idx < a.ptot) wl[idx] = wv[c]; }
+    for (int idx = tid + 256 * CH; idx < a.ptot; idx += 256) {      // (wider encoders: the rest, pass by pass)
+        int l = 0;
+        while (l + 1 < a.n && idx >= a.woff[l + 1]) ++l;
+        wl[idx] = idx < a.boff[l] ? a.W[l][idx - a.woff[l]] : (a.b[l] ? a.b[l][idx - a.boff[l]] : 0.f);
+    }
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const int idx = tid + 256 * c;
+        if (idx < nrows * a.dims[0]) { const int r = idx / a.dims[0], i = idx - r * a.dims[0]; acts[r * ELD + i] = xv[c]; }
     }
     __syncthreads();
     for (int l = 0; l < a.n; ++l) {
@@ -2118,9 +2162,6 @@ __global__ __launch_bounds__(256) void k_enc_bwd(EncBwdArgs a) {
         }
         __syncthreads();
     }
-    const int dlast = a.dims[a.n];
-    for (int idx = tid; idx < nrows * dlast; idx += 256) { const int r = idx / dlast, o = idx - r * dlast; cur[r * ELD + o] = a.d_out[(row0 + r) * dlast + o]; }
-    __syncthreads();
     for (int l = a.n - 1; l >= 0; --l) {
         const int din = a.dims[l], dout = a.dims[l + 1];
         const bool skip = din == dout;
@@ -2813,16 +2854,41 @@ extern "C" int iwvi_encoder_backward(const float* XY, int64_t rows, const float*
     return iwvi_encoder_backward_act(XY, rows, enc_W, enc_b, dims, n_enc, IWVI_ACT_TANH, d_out, dW, db, ws_, stream_);
 }
 
+static int enc_bwd_impl(const float* XY, int64_t rows, const float* const* enc_W, const float* const* enc_b,
+                        const int32_t* dims, int n_enc, int act, const float* d_out, const LvBwdArgs* lv,
+                        float* const* dW, float* const* db, void* ws_, void* stream_);
 extern "C" int iwvi_encoder_backward_act(const float* XY, int64_t rows, const float* const* enc_W, const float* const* enc_b,
                                          const int32_t* dims, int n_enc, int act, const float* d_out,
                                          float* const* dW, float* const* db, void* ws_, void* stream_) {
+    if (!d_out) { set_error("iwvi_encoder_backward: bad argument"); return IWVI_ERR_ARG; }
+    return enc_bwd_impl(XY, rows, enc_W, enc_b, dims, n_enc, act, d_out, nullptr, dW, db, ws_, stream_);
+}
+// iwvi_lv_layer_backward + iwvi_encoder_backward_act as one launch (+ the reduction): the workgroup that back-propagates eight data rows
+// through the encoder forms their d(means | raw) itself
+extern "C" int iwvi_lv_encoder_backward(const float* mu, const float* sigma, int ld_enc, int sigma_is_raw, const float* noise,
+                                        const float* dF_next, int ld_next, int col0, const float* w,
+                                        int latent_dim, int64_t B, int K, int sampled_kl,
+                                        const float* XY, const float* const* enc_W, const float* const* enc_b,
+                                        const int32_t* dims, int n_enc, int act,
+                                        float* const* dW, float* const* db, void* ws_, void* stream_) {
+    if (!mu || !sigma || !noise || latent_dim <= 0 || ld_enc < latent_dim || B <= 0 || K <= 0 || (dF_next && (ld_next < col0 + latent_dim || col0 < 0))) {
+        set_error("iwvi_lv_encoder_backward: bad argument"); return IWVI_ERR_ARG;
+    }
+    if (!dims || n_enc <= 0 || n_enc > IWVI_MAX_ENC || dims[n_enc] != 2 * latent_dim) { set_error("iwvi_lv_encoder_backward: the encoder's output width must be 2 * latent_dim"); return IWVI_ERR_ARG; }
+    const LvBwdArgs lv{mu, sigma, ld_enc, sigma_is_raw, noise, dF_next, ld_next, col0, w, latent_dim, B, K, sampled_kl, nullptr};
+    return enc_bwd_impl(XY, B, enc_W, enc_b, dims, n_enc, act, nullptr, &lv, dW, db, ws_, stream_);
+}
+static int enc_bwd_impl(const float* XY, int64_t rows, const float* const* enc_W, const float* const* enc_b,
+                        const int32_t* dims, int n_enc, int act, const float* d_out, const LvBwdArgs* lv,
+                        float* const* dW, float* const* db, void* ws_, void* stream_) {
     if (act < IWVI_ACT_TANH || act > IWVI_ACT_IDENTITY) { set_error("iwvi_encoder_backward: unknown activation %d", act); return IWVI_ERR_UNSUPPORTED; }
-    if (!XY || !enc_W || !dims || !d_out || !dW || !ws_ || rows <= 0 || n_enc <= 0 || n_enc > IWVI_MAX_ENC) { set_error("iwvi_encoder_backward: bad argument"); return IWVI_ERR_ARG; }
+    if (!XY || !enc_W || !dims || (!d_out && !lv) || !dW || !ws_ || rows <= 0 || n_enc <= 0 || n_enc > IWVI_MAX_ENC) { set_error("iwvi_encoder_backward: bad argument"); return IWVI_ERR_ARG; }
     for (int l = 0; l <= n_enc; ++l) if (dims[l] <= 0 || dims[l] > 64) { set_error("iwvi_encoder_backward: encoder width %d out of range (1..64)", dims[l]); return IWVI_ERR_ARG; }
     hipStream_t st = (hipStream_t)stream_;
     EncBwdArgs a{};
     EncReduceArgs r{};
     a.XY = XY; a.rows = rows; a.n = n_enc; a.d_out = d_out; a.act = act; a.part = (float*)ws_;
+    if (lv) { a.lv = *lv; a.fused = 1; }
     int off = 0;
     for (int l = 0; l <= n_enc; ++l) a.dims[l] = dims[l];
     for (int l = 0; l < n_enc; ++l) {

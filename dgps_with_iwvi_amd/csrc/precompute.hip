@@ -224,7 +224,7 @@ __global__ __launch_bounds__(256) void k_pack_ls16(const Ls16All a) {
 // from the factor the launch before left in the layer's workspace (block storage; diagonal-block inverses transposed in `dinv`), written
 // straight in A-fragment order behind the dense part of super-block I.  In k_precompute the same inverses were three doubling steps on the
 // factorising workgroup's one CU: 53 us at M = 256 (two super-blocks), 16 workgroups here.
-struct SbInvOne { const double* ws; float* LsP; int nbk, Mp, M, first; };
+struct SbInvOne { const double* ws; float* LsP; int nbk, Mp, M, first; double* X64; };   // X64 (natural-gradient step): the inverse as float64 blocks (block storage), no LsP
 struct SbInvAll { SbInvOne L[IWVI_MAX_LAYERS]; int n; };
 __global__ __launch_bounds__(256) void k_sb_inv(const SbInvAll a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char sbinv_smem[];
@@ -288,6 +288,13 @@ __global__ __launch_bounds__(256) void k_sb_inv(const SbInvAll a) {
             blk_store(X + (size_t)t * BLK, x, lane);
         }
         __syncthreads();
+    }
+    if (L.X64) {                                                 // (one super-block: nbk <= 8)
+        for (int it = tid; it < nb * BLK; it += 256) {
+            const int t = it / BLK, e = it - t * BLK;
+            L.X64[boff(J + t, J) + e] = X[(size_t)t * BLK + e];
+        }
+        return;
     }
     // packed fp32 blocks: row w = J + t of the super-block's triangle, block q = J: position nr r0 + w (w + 1) / 2 + J behind the super-block's start
     int off = 0;
@@ -400,6 +407,45 @@ __global__ __launch_bounds__(64) void k_ng_qbuild(const float* __restrict__ q_sq
     // the block's padding column (BLD = 17 doubles per row): k_natgrad_small copies whole blocks out of this caller-allocated, never
     // initialised workspace -- nothing reads the padding, but it should not carry whatever the allocation held
     if (threadIdx.x < NB) for (int c = NB; c < BLD; ++c) dst[threadIdx.x * BLD + c] = 0.0;
+}
+// the same block by FOUR waves, each a quarter of the contraction (k in chunks of 32, dealt round robin), the partial blocks added in a fixed
+// order: the spread step's first launch (one wave per block walked up to 128 k behind two dependent load round trips: 12.5 us)
+__global__ __launch_bounds__(256) void k_ng_qbuild4(const float* __restrict__ q_sqrt, const float* __restrict__ dq_sqrt, int M, double gamma, double* __restrict__ qws, int ntri) {
+    __shared__ double part[3][BLK];
+    const int o = blockIdx.x, r = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int bi = 0; while ((bi + 1) * (bi + 2) / 2 <= o) ++bi;
+    const int bj = o - bi * (bi + 1) / 2;
+    const float* Lf = q_sqrt + (size_t)r * M * M; const float* Gf = dq_sqrt + (size_t)r * M * M;
+    double* dst = qws + (size_t)r * ntri * BLK + boff(bi, bj);
+    const int ri = lane & 15, g = lane >> 4;
+    const int ig = NB * bi + ri, jg = NB * bj + ri;
+    const int q = M - 1 - ig, p = M - 1 - jg;
+    int k0 = M - 1 - (NB * bj + NB - 1); if (k0 < 0) k0 = 0; k0 &= ~3;
+    f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+    for (int kb = k0 + 32 * wave; kb < M; kb += 128) {
+        double av[8], bv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int k = kb + 4 * u + g;
+            av[u] = (k < M && q >= 0 && k >= q) ? (double)Gf[(size_t)k * M + q] : 0.0;     // A[i][k] = dq[k][q]
+            bv[u] = (k < M && p >= 0 && k >= p) ? (double)Lf[(size_t)k * M + p] : 0.0;     // B[k][j] = L[k][p]
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) if (kb + 4 * u < M) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[u], acc, 0, 0, 0);
+    }
+    if (wave > 0) blk_store(part[wave - 1], acc, lane);
+    __syncthreads();
+    if (wave > 0) return;
+#pragma unroll
+    for (int w_ = 0; w_ < 3; ++w_) { const f64x4 v = blk_load(part[w_], lane); acc += v; }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {                            // acc[e] = C[g + 4e][ri]
+        const int i = NB * bi + g + 4 * e, j = NB * bj + ri;
+        double v = (i == j) ? 1.0 : 0.0;
+        if (i < M && j < M) v -= gamma * acc[e];
+        dst[(g + 4 * e) * BLD + ri] = v;
+    }
+    if (lane < NB) for (int c = NB; c < BLD; ++c) dst[lane * BLD + c] = 0.0;
 }
 __global__ __launch_bounds__(1024) void k_natgrad_small(float* q_mu, float* q_sqrt, const float* __restrict__ dq_mu, const float* __restrict__ dq_sqrt,
                                                         int M, int R, double gamma, int stop, const double* __restrict__ qws) {
@@ -561,6 +607,134 @@ __global__ __launch_bounds__(1024) void k_natgrad_small(float* q_mu, float* q_sq
     if (tid < M) q_mu[(size_t)tid * R + r] = (float)vd[tid];
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// The same step SPREAD over the chip (round 5, M <= 128): k_natgrad_small is 88 us on one CU -- factorisation 15, triangular inverse 17,
+// four matrix-vector products 22, L' = L W 28 -- of which only the factorisation is a serial chain.  Four launches instead:
+//   k_ng_qbuild   Qrev blocks, one wave per block (as before)
+//   k_ng_chol     Qrev = C C^T in LDS (chol_blocks), factor and L_pp^-T blocks to the workspace -- what k_sb_inv reads
+//   k_sb_inv      C^-1, one workgroup per 16-column block (the super-block inverse of the forward's operands, float64 output)
+//   k_ng_rows     one workgroup per 16-row block of L' = L W (a wave per tile, C^-1 staged in LDS) and its share of t = L'^T mbar
+//   k_ng_vec      t = the sum of the shares, mu' = m - gamma L' t  (csrc/backward.hip: the algebra; two products with L' instead of four)
+// (back to back in a replayed graph the launches follow each other within 0.1 us; a last-arriving workgroup doing k_ng_vec's work inside
+//  k_ng_rows read the other workgroups' output through agent-scope loads -- 26 us for the launch instead of 6 + 4)
+__global__ __launch_bounds__(1024) void k_ng_chol(const double* __restrict__ qws, double* __restrict__ fac, int Mp) {
+    const int tid = threadIdx.x, nthreads = blockDim.x, r = blockIdx.x;
+    const WsLayout w = ws_layout(Mp);
+    const int nbk = w.nbk, ntri = nbk * (nbk + 1) / 2;
+    double* sm = reinterpret_cast<double*>(smem_raw);
+    double* rinv = sm;
+    double* blk = sm + Mp + w.blk;
+    double* dinv = sm + Mp + w.dinv;
+    const double* src = qws + (size_t)r * ntri * BLK;
+    for (int i = tid; i < ntri * BLK; i += nthreads) blk[i] = src[i];
+    __syncthreads();
+    chol_blocks(blk, nbk, rinv, dinv, tid, nthreads, NoGen(), NoPost(), NoTail());
+    __syncthreads();
+    double* dst = fac + (size_t)r * w.total;
+    for (int i = tid; i < ntri * BLK; i += nthreads) dst[w.blk + i] = blk[i];
+    for (int i = tid; i < nbk * BLK; i += nthreads) dst[w.dinv + i] = dinv[i];
+}
+
+struct NgRowsArgs {
+    float* q_mu; float* q_sqrt; const float* dq_mu; const double* X64; double* Lp64; double* tpart;
+    int M, Mp, R; double gamma;
+};
+__global__ __launch_bounds__(512) void k_ng_rows(const NgRowsArgs a) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int bi = blockIdx.x, r = blockIdx.y, M = a.M, Mp = a.Mp, nbk = Mp / NB, ntri = nbk * (nbk + 1) / 2;
+    float* Lf = a.q_sqrt + (size_t)r * M * M;
+    double* Lp = a.Lp64 + (size_t)r * ntri * BLK;
+    double* tp = a.tpart + ((size_t)r * nbk + bi) * Mp;
+    // C^-1 (lower blocks, diagonal blocks included) into LDS, whole blocks at 16 bytes per lane: W[k][j] = C^-1[M-1-j][M-1-k] is read transposed and
+    // reversed -- from global memory that was sixteen 8-byte loads per lane and step, each across 16 rows
+    double* Xs = reinterpret_cast<double*>(smem_raw);
+    {
+        typedef double d2 __attribute__((ext_vector_type(2)));
+        const d2* src = reinterpret_cast<const d2*>(a.X64 + (size_t)r * ntri * BLK);
+        d2* dst = reinterpret_cast<d2*>(Xs);
+        for (int i = tid; i < ntri * BLK / 2; i += 512) dst[i] = src[i];
+    }
+    __syncthreads();
+    const int ri = lane & 15, g = lane >> 4, bj = wave;
+    f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+    if (bj <= bi) {
+        // L'(bi, bj)[i][j] = sum_{k = 16bj .. 16bi+15} L[16bi+i][k] W[k][16bj+j]
+        const int ig = NB * bi + ri, jg = NB * bj + ri, k0 = NB * bj;
+        const bool al16 = (M & 3) == 0;
+        for (int kb = k0; kb < NB * bi + NB; kb += 64) {
+            double av[16], bv[16];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int kq = kb + 16 * c + 4 * g;              // this lane's four consecutive k (MFMA step s of chunk c contracts k = kb + 16c + 4g + s)
+                float a4[4] = {0.f, 0.f, 0.f, 0.f};
+                if (ig < M && kq < NB * bi + NB && kq < M) {
+                    if (al16) { const f32x4g v = *reinterpret_cast<const f32x4g*>(Lf + (size_t)ig * M + kq); a4[0] = v[0]; a4[1] = v[1]; a4[2] = v[2]; a4[3] = v[3]; }
+                    else { for (int s_ = 0; s_ < 4; ++s_) if (kq + s_ < M) a4[s_] = Lf[(size_t)ig * M + kq + s_]; }
+                }
+#pragma unroll
+                for (int s_ = 0; s_ < 4; ++s_) {
+                    const int k = kq + s_;
+                    const bool in = k < NB * bi + NB && k < M;
+                    av[4 * c + s_] = (in && k <= ig) ? (double)a4[s_] : 0.0;
+                    double wv = 0.0;
+                    if (in && jg < M && k >= jg) { const int i2 = M - 1 - jg, k2 = M - 1 - k; wv = Xs[boff(i2 >> 4, k2 >> 4) + (i2 & 15) * BLD + (k2 & 15)]; }
+                    bv[4 * c + s_] = wv;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 16; ++u) if (kb + 16 * (u >> 2) < NB * bi + NB) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[u], acc, 0, 0, 0);
+        }
+    }
+    __syncthreads();                                         // every read of this block row of the old L is done (no other workgroup reads it)
+    // acc[e] = L'[16bi + g + 4e][16bj + ri]: the tile to q_sqrt (float32) and to the workspace (float64), and its share of t = L'^T mbar
+    double ts = 0.0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int i = NB * bi + g + 4 * e, j = NB * bj + ri;
+        const bool in = bj <= bi && i < M && j < M && j <= i;
+        const double v = in ? acc[e] : 0.0;
+        if (i < M && j < M) Lf[(size_t)i * M + j] = (float)v;                            // (tiles above the diagonal: zero, as tril() leaves them)
+        if (bj <= bi) Lp[boff(bi, bj) + (g + 4 * e) * BLD + ri] = v;
+        if (in) ts = fma(v, -(double)a.dq_mu[(size_t)i * a.R + r], ts);                // mbar = -dq_mu
+    }
+    ts += __shfl_xor(ts, 16, 64);
+    ts += __shfl_xor(ts, 32, 64);
+    if (g == 0 && NB * bj + ri < Mp) tp[NB * bj + ri] = ts;                              // t_bi[j] = sum_{i in block row bi} L'[i][j] mbar[i]
+}
+// t = the block rows' shares summed in a fixed order, mu' = m - gamma L' t (the float64 L' of k_ng_rows); one workgroup per latent GP
+__global__ __launch_bounds__(512) void k_ng_vec(const NgRowsArgs a) {
+    __shared__ double tv[128];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = blockIdx.x, M = a.M, Mp = a.Mp, nbk = Mp / NB, ntri = nbk * (nbk + 1) / 2;
+    const double* Lp = a.Lp64 + (size_t)r * ntri * BLK;
+    if (tid < Mp) {
+        double sh[8];
+#pragma unroll
+        for (int b = 0; b < 8; ++b) sh[b] = (b >= (tid >> 4) && b < nbk) ? a.tpart[((size_t)r * nbk + b) * Mp + tid] : 0.0;
+        double v = 0.0;
+#pragma unroll
+        for (int b = 0; b < 8; ++b) v += sh[b];
+        tv[tid] = v;
+    }
+    __syncthreads();
+    // rows i = wave, wave + 8, ..: lanes over j (two each), every load of a wave's rows in flight together
+    double l0[16], l1[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+        const int i = wave + 8 * u;
+        l0[u] = (i < M && lane <= i) ? Lp[boff(i >> 4, lane >> 4) + (i & 15) * BLD + (lane & 15)] : 0.0;
+        l1[u] = (i < M && lane + 64 <= i) ? Lp[boff(i >> 4, (lane + 64) >> 4) + (i & 15) * BLD + (lane & 15)] : 0.0;
+    }
+    const double t0 = lane < Mp ? tv[lane] : 0.0, t1 = lane + 64 < Mp ? tv[lane + 64] : 0.0;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+        const int i = wave + 8 * u;
+        double v = fma(l0[u], t0, l1[u] * t1);
+        for (int o_ = 32; o_ > 0; o_ >>= 1) v += __shfl_xor(v, o_, 64);
+        if (lane == 0 && i < M) a.q_mu[(size_t)i * a.R + r] = (float)((double)a.q_mu[(size_t)i * a.R + r] - a.gamma * v);
+    }
+}
+
 // host side: 0 if the shape is not covered (the caller then takes the multi-launch path)
 int natgrad_small(float* q_mu, float* q_sqrt, const float* dq_mu, const float* dq_sqrt, int M, int R, double gamma, hipStream_t st, void* ws, size_t ws_bytes);
 
@@ -590,6 +764,37 @@ int natgrad_small(float* q_mu, float* q_sqrt, const float* dq_mu, const float* d
     if ((rc = ensure_lds_attr((const void*)k_natgrad_small, lds)) != IWVI_OK) return rc;
     // step 1 (Qrev) on many CUs first, when the workspace holds the R block images
     const int nbk = Mp / NB, ntri = nbk * (nbk + 1) / 2;
+    {   // the step spread over the chip (k_ng_chol, k_sb_inv, k_ng_rows): when the workspace holds its images
+        const WsLayout w = ws_layout(Mp);
+        const size_t n_q = (size_t)R * ntri * BLK, n_fac = (size_t)R * w.total, n_t = (size_t)R * nbk * Mp;
+        const size_t need = sizeof(double) * (3 * n_q + n_fac + n_t) + 64;
+        if (ws && need <= ws_bytes && R <= IWVI_MAX_LAYERS && !dbg_opt("IWVI_NG_STOP") && !dbg_opt("IWVI_NG_ONE_WG")) {
+            double* qw = (double*)ws; double* fac = qw + n_q; double* X64 = fac + n_fac; double* Lp64 = X64 + n_q; double* tpart = Lp64 + n_q;
+            hipLaunchKernelGGL(k_ng_qbuild4, dim3(ntri, R), dim3(256), 0, st, (const float*)q_sqrt, dq_sqrt, M, gamma, qw, ntri);
+            if ((rc = check_launch("k_ng_qbuild")) != IWVI_OK) return rc;
+            const size_t lds_c = sizeof(double) * ((size_t)Mp + w.total);
+            if ((rc = ensure_lds_attr((const void*)k_ng_chol, lds_c)) != IWVI_OK) return rc;
+            hipLaunchKernelGGL(k_ng_chol, dim3(R), dim3(1024), lds_c, st, (const double*)qw, fac, Mp);
+            if ((rc = check_launch("k_ng_chol")) != IWVI_OK) return rc;
+            SbInvAll q{};
+            for (int r = 0; r < R; ++r) {
+                SbInvOne& o = q.L[q.n++];
+                o.ws = fac + (size_t)r * w.total; o.LsP = nullptr; o.nbk = nbk; o.Mp = Mp; o.M = Mp; o.first = 8 * r; o.X64 = X64 + (size_t)r * ntri * BLK;
+            }
+            const size_t lds_sb = sizeof(double) * (size_t)(8 + 8 + 28 + 4) * BLK;
+            if ((rc = ensure_lds_attr((const void*)k_sb_inv, lds_sb)) != IWVI_OK) return rc;
+            hipLaunchKernelGGL(k_sb_inv, dim3(8 * R), dim3(256), lds_sb, st, q);
+            if ((rc = check_launch("k_sb_inv")) != IWVI_OK) return rc;
+            NgRowsArgs a{q_mu, q_sqrt, dq_mu, X64, Lp64, tpart, M, Mp, R, gamma};
+            const size_t lds_r = sizeof(double) * (size_t)ntri * BLK;
+            if ((rc = ensure_lds_attr((const void*)k_ng_rows, lds_r)) != IWVI_OK) return rc;
+            hipLaunchKernelGGL(k_ng_rows, dim3(nbk, R), dim3(512), lds_r, st, a);
+            if ((rc = check_launch("k_ng_rows")) != IWVI_OK) return rc;
+            hipLaunchKernelGGL(k_ng_vec, dim3(R), dim3(512), 0, st, a);
+            rc = check_launch("k_ng_vec");
+            return rc == IWVI_OK ? 1 : rc;
+        }
+    }
     double* qws = nullptr;
     if (ws && (size_t)R * ntri * BLK * sizeof(double) <= ws_bytes && !dbg_opt("IWVI_NG_STOP")) {
         qws = (double*)ws;

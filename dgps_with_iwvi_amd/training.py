@@ -40,7 +40,7 @@ class Trainer:
         The two trained host scalars of the reference -- the final layer's kernel variance and the likelihood variance -- live
         in 1-element device tensors that Adam updates in place and every kernel reads when it runs (``variance_dev`` of the
         descriptors); the model's host copies are refreshed lazily when read.  ``use_graph=True`` (single GPU, noise drawn on the
-        device): each of the two ops of a step is captured once into a hipGraph and replayed -- no host work per launch, no
+        device): each of the two ops of a step is captured once into a hipGraph and replayed (as ONE graph when the data is not minibatched) -- no host work per launch, no
         device-to-host copy per step; the graphs are re-captured when the staircase decay changes lr / gamma.  ``check_finite``:
         one small D2H that raises when the bound or the final layer's q(u) went non-finite (the reference's Cholesky raises) -- every
         step in eager mode, every ``check_every`` steps in graph mode."""
@@ -217,10 +217,16 @@ class Trainer:
         if self.use_graph:
             if zs_ng is not None or zs_adam is not None:
                 raise ValueError("use_graph draws the noise on the device (captured graphs cannot take per-step host arguments)")
-            self._advance_outside_graph()
-            self._replay("ng", lambda: self.natgrad_op(None, _advance=False))
-            self._advance_outside_graph()
-            elbo = self._replay("adam", lambda: self.adam_op(None, _advance=False))
+            if self.model.minibatch_size is None:
+                # full-batch data: nothing host-driven separates the two ops, so the step is ONE replay (two replays on one stream start
+                # about 10 us apart: 2 % of a configs[2] step)
+                self._advance_outside_graph()
+                elbo = self._replay("step", self._both_ops)
+            else:
+                self._advance_outside_graph()
+                self._replay("ng", lambda: self.natgrad_op(None, _advance=False))
+                self._advance_outside_graph()
+                elbo = self._replay("adam", lambda: self.adam_op(None, _advance=False))
             for _, owner in self._scalars:                     # a replay runs no host code: flag the host copies here
                 owner.mark_device_variance_changed()
             if self.check_finite and self.global_step % self.check_every == 0:
@@ -228,6 +234,10 @@ class Trainer:
             return elbo
         self.natgrad_op(zs_ng)
         return self.adam_op(zs_adam)
+
+    def _both_ops(self):
+        self.natgrad_op(None, _advance=False)
+        return self.adam_op(None, _advance=False)
 
     def _advance_outside_graph(self):
         """Everything of a minibatch change that is host-driven runs here, never inside the captured op: the in-place

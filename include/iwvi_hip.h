@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define IWVI_ABI_VERSION 14
+#define IWVI_ABI_VERSION 15
 
 enum {
     IWVI_OK = 0,
@@ -423,6 +423,16 @@ int iwvi_encoder_backward(const float* XY, int64_t rows, const float* const* enc
 int iwvi_encoder_backward_act(const float* XY, int64_t rows, const float* const* enc_W, const float* const* enc_b,
                               const int32_t* dims, int n_enc, int act, const float* d_out,
                               float* const* dW, float* const* db, void* ws, void* stream);
+
+/* iwvi_lv_layer_backward followed by iwvi_encoder_backward_act, as one launch plus the reduction (the training step's form: the
+ * workgroup that back-propagates eight data rows through the encoder forms their d(means | raw) itself; same arithmetic, same sums).
+ * dims[n_enc] must be 2 * latent_dim; XY [B, dims[0]]. */
+int iwvi_lv_encoder_backward(const float* mu, const float* sigma, int ld_enc, int sigma_is_raw, const float* noise,
+                             const float* dF_next, int ld_next, int col0, const float* w,
+                             int latent_dim, int64_t B, int K, int sampled_kl,
+                             const float* XY, const float* const* enc_W, const float* const* enc_b,
+                             const int32_t* dims, int n_enc, int act,
+                             float* const* dW, float* const* db, void* ws, void* stream);
 
 /* Test log-likelihood of experiments/run_conditional_density_estimation.py:148-169, batched over the test points:
  * samples: S predictive draws per point (element (s, n) at samples[s*sample_stride + n*point_stride]); y [N].

@@ -9,6 +9,7 @@ from bench import CONFIGS
 from dgps_with_iwvi_amd import backward, synthetic
 ap = argparse.ArgumentParser(); ap.add_argument("--config", type=int, default=2); ap.add_argument("--replays", type=int, default=6)
 ap.add_argument("--no-fuse", action="store_true", help="the bound's adjoint heads by iwvi_iw_elbo_backward (two more launches) instead of the layer launch's tail")
+ap.add_argument("--no-fuse-lv", action="store_true", help="the latent-variable layer's and the encoder's adjoints as two launches (iwvi_lv_layer_backward, iwvi_encoder_backward_act)")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 spec = synthetic.make_spec(seed=0, parity=True, n_data=65536, **CONFIGS[a.config])
@@ -16,6 +17,8 @@ model = synthetic.build_model(spec, dev)
 import functools
 _vg = backward.iw_elbo_and_gradients
 backward.iw_elbo_and_gradients = functools.partial(_vg, fuse_heads=not a.no_fuse)
+if a.no_fuse_lv:
+    backward.lv_backward = functools.partial(backward.lv_backward, fused=False)
 backward.iw_elbo_and_gradients(model); backward.iw_elbo_and_gradients(model)
 torch.cuda.synchronize()
 side = torch.cuda.Stream()

@@ -225,6 +225,52 @@ def test_encoder_backward_matches_autodiff(gpu_device, dims, rows):
         _close("db%d" % i, db[i].cpu(), tb[i].grad.numpy(), rtol=1e-4)
 
 
+@pytest.mark.parametrize("Lw,B,K,with_dF,sampled", [(1, 1024, 20, True, 1), (2, 77, 7, True, 0), (3, 130, 70, False, 1)])
+def test_fused_latent_variable_and_encoder_adjoint_equals_the_two_launches(gpu_device, Lw, B, K, with_dF, sampled):
+    """iwvi_lv_encoder_backward (the training step's form: one launch) == iwvi_lv_layer_backward then iwvi_encoder_backward_act, bit for bit."""
+    import ctypes
+    from dgps_with_iwvi_amd import _abi
+    dev = gpu_device
+    rng = np.random.default_rng(Lw * B + K)
+    f32 = lambda a: torch.as_tensor(np.asarray(a, dtype=np.float32), device=dev)
+    dims = [6, 20, 20, 2 * Lw]
+    XY = f32(rng.standard_normal((B, dims[0])))
+    Ws = [f32(rng.standard_normal((a, b)) * (2.0 / (a + b)) ** 0.5) for a, b in zip(dims[:-1], dims[1:])]
+    bs = [f32(rng.standard_normal(b) * 0.1) for b in dims[1:]]
+    enc_out = f32(rng.standard_normal((B, 2 * Lw)))
+    eps = f32(rng.standard_normal((B * K, Lw)))
+    ld, col0 = Lw + 4, 3
+    dF = f32(rng.standard_normal((B * K, ld))) if with_dF else None
+    w = f32(rng.random(B * K))
+    cd = (ctypes.c_int32 * len(dims))(*dims)
+    n = len(Ws)
+    lib = _abi.lib()
+    mu_p, sg_p = ctypes.c_void_p(enc_out.data_ptr()), ctypes.c_void_p(enc_out.data_ptr() + 4 * Lw)
+
+    def outputs():
+        return [torch.empty_like(t) for t in Ws], [torch.empty_like(t) for t in bs]
+    ws = torch.empty(lib.iwvi_encoder_backward_ws_bytes(B, cd, n), dtype=torch.uint8, device=dev)
+    dW1, db1 = outputs()
+    d_enc = torch.empty(B, 2 * Lw, dtype=torch.float32, device=dev)
+    _abi.check(lib.iwvi_lv_layer_backward(mu_p, sg_p, 2 * Lw, 1, _abi.ptr(eps), _abi.ptr(dF), ld if with_dF else 0, col0, _abi.ptr(w),
+                                          Lw, B, K, sampled, _abi.ptr(d_enc), _abi.stream_ptr()))
+    _abi.check(lib.iwvi_encoder_backward_act(_abi.ptr(XY), B, _abi.ptr_array(Ws), _abi.ptr_array(bs), cd, n, _abi.ACT_TANH, _abi.ptr(d_enc),
+                                             _abi.ptr_array(dW1), _abi.ptr_array(db1), ws.data_ptr(), _abi.stream_ptr()))
+    dW2, db2 = outputs()
+    _abi.check(lib.iwvi_lv_encoder_backward(mu_p, sg_p, 2 * Lw, 1, _abi.ptr(eps), _abi.ptr(dF), ld if with_dF else 0, col0, _abi.ptr(w),
+                                            Lw, B, K, sampled, _abi.ptr(XY), _abi.ptr_array(Ws), _abi.ptr_array(bs), cd, n, _abi.ACT_TANH,
+                                            _abi.ptr_array(dW2), _abi.ptr_array(db2), ws.data_ptr(), _abi.stream_ptr()))
+    torch.cuda.synchronize()
+    for a, b in zip(dW1 + db1, dW2 + db2):
+        assert float(a.abs().max()) > 0
+        assert torch.equal(a, b)
+    # an encoder whose output is not (means | raw) of this latent dimension is refused
+    bad = (ctypes.c_int32 * len(dims))(*(dims[:-1] + [2 * Lw + 1]))
+    assert lib.iwvi_lv_encoder_backward(mu_p, sg_p, 2 * Lw, 1, _abi.ptr(eps), None, 0, 0, _abi.ptr(w), Lw, B, K, sampled, _abi.ptr(XY),
+                                        _abi.ptr_array(Ws), _abi.ptr_array(bs), bad, n, _abi.ACT_TANH, _abi.ptr_array(dW2), _abi.ptr_array(db2),
+                                        ws.data_ptr(), _abi.stream_ptr()) == -1
+
+
 def test_autograd_function_routes_the_hip_gradients(gpu_device):
     """backward.IwElbo: loss.backward() fills .grad of the model's own tensors with the HIP adjoints; a torch optimiser
     step on them changes what the kernels see."""

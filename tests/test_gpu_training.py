@@ -45,6 +45,21 @@ def test_natgrad_step_matches_oracle(gpu_device, M, R):
             _abi.set_debug_option("IWVI_NATGRAD_UNFUSED", 0)
         np.testing.assert_allclose(e_mu.cpu().numpy(), d_mu.cpu().numpy(), rtol=2e-6, atol=2e-7)
         np.testing.assert_allclose(e_sqrt.cpu().numpy(), d_sqrt.cpu().numpy(), rtol=2e-6, atol=2e-7)
+        # ... and the one-workgroup form of the step (the default spreads it over four launches: k_ng_chol, k_sb_inv, k_ng_rows)
+        f_mu, f_sqrt = _t(q_mu, gpu_device), _t(q_sqrt, gpu_device)
+        _abi.set_debug_option("IWVI_NG_ONE_WG", 1)
+        try:
+            _abi.check(_abi.lib().iwvi_natgrad_step(_abi.ptr(f_mu), _abi.ptr(f_sqrt), _abi.ptr(dg_mu), _abi.ptr(dg_sqrt), M, R, 0.05,
+                                                   ws.data_ptr(), _abi.stream_ptr()))
+        finally:
+            _abi.set_debug_option("IWVI_NG_ONE_WG", 0)
+        np.testing.assert_allclose(f_mu.cpu().numpy(), d_mu.cpu().numpy(), rtol=2e-6, atol=2e-7)
+        np.testing.assert_allclose(f_sqrt.cpu().numpy(), d_sqrt.cpu().numpy(), rtol=2e-6, atol=2e-7)
+        # the step leaves the same bits when repeated on the same inputs (fixed summation orders; the last-arriving workgroup only reads)
+        h_mu, h_sqrt = _t(q_mu, gpu_device), _t(q_sqrt, gpu_device)
+        _abi.check(_abi.lib().iwvi_natgrad_step(_abi.ptr(h_mu), _abi.ptr(h_sqrt), _abi.ptr(dg_mu), _abi.ptr(dg_sqrt), M, R, 0.05,
+                                               ws.data_ptr(), _abi.stream_ptr()))
+        assert torch.equal(h_mu, d_mu) and torch.equal(h_sqrt, d_sqrt)
 
 
 def test_adam_steps_match_oracle(gpu_device):
@@ -292,7 +307,7 @@ def test_graph_mode_follows_the_staircase_decay(gpu_device):
         vals = [float(tr.step()) for _ in range(8)]
         out.append((vals, [p.clone() for _, p, _ in tr._entries], model.layers[-1].q_sqrt.clone()))
         if use_graph:
-            assert tr._graphs["adam"][0] == 1 and tr._graphs["ng"][0] == 1      # re-captured for epoch 1
+            assert set(tr._graphs) == {"step"} and tr._graphs["step"][0] == 1   # (full-batch data: the two ops are one graph) re-captured for epoch 1
     assert out[0][0] == out[1][0], (out[0][0], out[1][0])
     for pa, pb in zip(out[0][1], out[1][1]):
         assert torch.equal(pa, pb)
