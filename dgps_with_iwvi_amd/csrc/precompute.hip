@@ -272,22 +272,23 @@ __global__ __launch_bounds__(256) void k_sb_inv(const SbInvAll a) {
     __syncthreads();
     for (int i = tid; i < BLK; i += 256) X[i] = Dv[i];            // X_0 = D_J^-1
     __syncthreads();
-    for (int t = 1; t < nb; ++t) {
-        f64x4 acc = {0.0, 0.0, 0.0, 0.0};
-        for (int u = wave; u < t; u += 4) blk_mma<false>(acc, Ls + (size_t)(t * (t - 1) / 2 + u) * BLK, X + (size_t)u * BLK, lane, 1.0);
-        blk_store(part + wave * BLK, acc, lane);
-        __syncthreads();
-        {
-            const int rr = tid >> 4, cc = tid & 15, o = rr * BLD + cc;
-            part[o] = (part[o] + part[BLK + o]) + (part[2 * BLK + o] + part[3 * BLK + o]);
+    // Right-looking: once X_u is known every block below it takes its term, S_t += L(t, u) X_u -- block t lives in the registers of wave
+    // (t - 1) & 3 (two blocks per wave at most) -- and the owner of block u + 1 closes it: X_{u+1} = -D_{u+1}^-1 S_{u+1}.  One barrier per step
+    // (round 5; the left-looking form dealt the sum of a step to the four waves and paid three barriers per step: 9.3 us for eight blocks).
+    {
+        f64x4 accA = {0.0, 0.0, 0.0, 0.0}, accB = {0.0, 0.0, 0.0, 0.0};
+        const int tA = wave + 1, tB = wave + 5;
+        for (int u = 0; u + 1 < nb; ++u) {
+            if (tA > u && tA < nb) blk_mma<false>(accA, Ls + (size_t)(tA * (tA - 1) / 2 + u) * BLK, X + (size_t)u * BLK, lane, 1.0);
+            if (tB > u && tB < nb) blk_mma<false>(accB, Ls + (size_t)(tB * (tB - 1) / 2 + u) * BLK, X + (size_t)u * BLK, lane, 1.0);
+            if (wave == (u & 3)) {                               // owner of block u + 1
+                blk_store(part + wave * BLK, (u + 1 == tA) ? accA : accB, lane);
+                f64x4 x = {0.0, 0.0, 0.0, 0.0};
+                blk_mma<false>(x, Dv + (size_t)(u + 1) * BLK, part + wave * BLK, lane, -1.0);
+                blk_store(X + (size_t)(u + 1) * BLK, x, lane);
+            }
+            __syncthreads();
         }
-        __syncthreads();
-        if (wave == 0) {
-            f64x4 x = {0.0, 0.0, 0.0, 0.0};
-            blk_mma<false>(x, Dv + (size_t)t * BLK, part, lane, -1.0);
-            blk_store(X + (size_t)t * BLK, x, lane);
-        }
-        __syncthreads();
     }
     if (L.X64) {                                                 // (one super-block: nbk <= 8)
         for (int it = tid; it < nb * BLK; it += 256) {
@@ -701,37 +702,52 @@ __global__ __launch_bounds__(512) void k_ng_rows(const NgRowsArgs a) {
     ts += __shfl_xor(ts, 32, 64);
     if (g == 0 && NB * bj + ri < Mp) tp[NB * bj + ri] = ts;                              // t_bi[j] = sum_{i in block row bi} L'[i][j] mbar[i]
 }
-// t = the block rows' shares summed in a fixed order, mu' = m - gamma L' t (the float64 L' of k_ng_rows); one workgroup per latent GP
+// t = the block rows' shares summed in a fixed order, mu' = m - gamma L' t (the float64 L' of k_ng_rows); one workgroup per latent GP, a wave per
+// block row: L'(bi, bj) T_bj on the float64 matrix cores with T_bj = [t_bj | 0 ..] -- fifteen sixteenths of the product are zeros, but a
+// lane-per-column sum needs a six-step shuffle tree per ROW (sixteen dependent trees per wave: most of the 8.4 us this kernel took)
 __global__ __launch_bounds__(512) void k_ng_vec(const NgRowsArgs a) {
-    __shared__ double tv[128];
+    __shared__ double tm[8][BLK];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = blockIdx.x, M = a.M, Mp = a.Mp, nbk = Mp / NB, ntri = nbk * (nbk + 1) / 2;
     const double* Lp = a.Lp64 + (size_t)r * ntri * BLK;
+    const int ri = lane & 15, g = lane >> 4, bi = wave;
+    // every global read of the kernel in flight before the first is used
+    double av[8][4];
+#pragma unroll
+    for (int bj = 0; bj < 8; ++bj) {
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) av[bj][kk] = (bi < nbk && bj <= bi) ? Lp[boff(bi, bj) + ri * BLD + 4 * kk + g] : 0.0;
+    }
+    float mq[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { const int i = NB * bi + g + 4 * e; mq[e] = (bi < nbk && ri == 0 && i < M) ? a.q_mu[(size_t)i * a.R + r] : 0.f; }
+    for (int i = tid; i < 8 * BLK; i += 512) (&tm[0][0])[i] = 0.0;
+    double v = 0.0;
     if (tid < Mp) {
         double sh[8];
 #pragma unroll
         for (int b = 0; b < 8; ++b) sh[b] = (b >= (tid >> 4) && b < nbk) ? a.tpart[((size_t)r * nbk + b) * Mp + tid] : 0.0;
-        double v = 0.0;
 #pragma unroll
         for (int b = 0; b < 8; ++b) v += sh[b];
-        tv[tid] = v;
     }
     __syncthreads();
-    // rows i = wave, wave + 8, ..: lanes over j (two each), every load of a wave's rows in flight together
-    double l0[16], l1[16];
+    if (tid < Mp) tm[tid >> 4][(tid & 15) * BLD] = v;            // T_bj[k][0] = t[16 bj + k]
+    __syncthreads();
+    if (bi >= nbk) return;
+    f64x4 acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-    for (int u = 0; u < 16; ++u) {
-        const int i = wave + 8 * u;
-        l0[u] = (i < M && lane <= i) ? Lp[boff(i >> 4, lane >> 4) + (i & 15) * BLD + (lane & 15)] : 0.0;
-        l1[u] = (i < M && lane + 64 <= i) ? Lp[boff(i >> 4, (lane + 64) >> 4) + (i & 15) * BLD + (lane & 15)] : 0.0;
+    for (int bj = 0; bj < 8; ++bj) {
+        if (bj <= bi) {
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[bj][kk], tm[bj][(4 * kk + g) * BLD + ri], acc, 0, 0, 0);
+        }
     }
-    const double t0 = lane < Mp ? tv[lane] : 0.0, t1 = lane + 64 < Mp ? tv[lane + 64] : 0.0;
+    if (ri == 0) {
 #pragma unroll
-    for (int u = 0; u < 16; ++u) {
-        const int i = wave + 8 * u;
-        double v = fma(l0[u], t0, l1[u] * t1);
-        for (int o_ = 32; o_ > 0; o_ >>= 1) v += __shfl_xor(v, o_, 64);
-        if (lane == 0 && i < M) a.q_mu[(size_t)i * a.R + r] = (float)((double)a.q_mu[(size_t)i * a.R + r] - a.gamma * v);
+        for (int e = 0; e < 4; ++e) {                        // acc[e] = (L' t)[16 bi + g + 4e] in the lanes of column 0
+            const int i = NB * bi + g + 4 * e;
+            if (i < M) a.q_mu[(size_t)i * a.R + r] = (float)((double)mq[e] - a.gamma * acc[e]);
+        }
     }
 }
 
