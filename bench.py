@@ -169,9 +169,9 @@ def training_leg(model, samples, iters=20, flops_forward=None):
                 "gradient_samples_per_s": samples / grad_graph_ms * 1e3,
                 "train_step_ms": step_graph_ms, "train_step_eager_ms": step_ms,
                 "note": "value + gradient: one hipGraph replay of backward.iw_elbo_and_gradients (fused forward that keeps a, streaming adjoint chain "
-                        "per layer, Cholesky adjoint; DESIGN.md section 5b); train step: training.Trainer(use_graph=True).step = NatGrad op + Adam op, "
-                        "each one graph replay, trained scalars and Adam's step count on the device; runs after the timed region and changes the "
-                        "model's parameters"}
+                        "per layer, Cholesky adjoint; DESIGN.md section 6); train step: training.Trainer(use_graph=True).step = NatGrad op + Adam op, "
+                        "ONE graph replay (the synthetic data is not minibatched; two replays otherwise), trained scalars and Adam's step count "
+                        "on the device; runs after the timed region and changes the model's parameters"}
     except Exception as e:                                   # the informational leg must not take the headline line down -- but it fails LOUDLY:
         import traceback                                     # the traceback goes to stderr and the JSON carries the error text
         traceback.print_exc()

@@ -68,7 +68,7 @@ def main():
         step_g = timed(lambda: trg.step(), a.iters)
     except Exception as e:
         print("graph-mode trainer failed: %s: %s" % (type(e).__name__, e))
-    print("config %d: forward (fused, eager) %.3f ms | value+gradient %.3f ms (%.2e samples/s) | training step %.3f ms eager, %.3f ms as two hipGraph replays"
+    print("config %d: forward (fused, eager) %.3f ms | value+gradient %.3f ms (%.2e samples/s) | training step %.3f ms eager, %.3f ms as hipGraph replays (one per step: the data is not minibatched)"
           % (a.config, fwd, grad, T / grad * 1e3, step, step_g))
 
 
