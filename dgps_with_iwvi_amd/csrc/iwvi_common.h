@@ -31,6 +31,8 @@ constexpr int IWVI_CST_SA = 65, IWVI_CST_FMEAN = 66, IWVI_CST_FR = 72;   // spli
 // units of U = 2^(2 est), sigma 2^est -> 2^7.  [U] = U (1 when the layer's solve is fp32): the Gram tile is written times U and the LsP
 // stream's Dinv blocks are packed times 1/U;  [SB] = 2^est: a_j -> the B operand of the updates, whose A blocks are 2^est (-L) in two halves
 constexpr int IWVI_CST_U = 67, IWVI_CST_SB = 68;
+// M > 240: the power-of-two scale of the split-f16 inverse blocks of the super-block solve (sb16_tri_blocks; written by k_pack_ls16)
+constexpr int IWVI_CST_SI = 69;
 
 // triangular block storage, row-block major:
 //   solve stream LsP (column-block major): column bj = [Lm(bj,bj)^-1, -Lm(bj+1,bj), .., -Lm(nbk-1,bj)],
@@ -65,7 +67,8 @@ __host__ __device__ static inline int sb16_slabs(int nbk) {
 }
 // ... and the triangular part -- a_I = (L_II)^-1 r_I -- takes split-f16 operands for every block LEFT of the diagonal (round 5): behind the
 // slabs, one 1-KiB block per (super-block I, row w = 1 .. nr - 1, q < w), rows in order, lane 16 g + i holding [h1 x 4 | h2 x 4] of
-// 2^lg (L_II)^-1 [16 w + i][16 q + 4 g .. + 3] (lg = ceil(log2 sigma); saturated at the largest f16) -- k_pack_ls16 again
+// 2^e (L_II)^-1 [16 w + i][16 q + 4 g .. + 3] -- k_pack_ls16 again.  e = min(ceil(log2 sigma), floor(log2(65504 sqrt(jitter)))): the diagonal entries
+// (>= 1 / sigma) come out >= 1, and no entry can leave the f16 range (|L_II^-1| <= 1 / sqrt(lambda_min(K_uu)) <= 1 / sqrt(jitter)); 2^e goes to cst[IWVI_CST_SI]
 __host__ __device__ static inline int sb16_tri_blocks(int nbk) {
     int n = 0;
     for (int I = 0; 8 * I < nbk; ++I) { const int nr = nbk - 8 * I < 8 ? nbk - 8 * I : 8; n += nr * (nr - 1) / 2; }

@@ -108,7 +108,7 @@ def _run_layer(c, dev, D, R, mixing, mf, full_cov=False, z=None):
     from dgps_with_iwvi_amd import features, kernels, mean_functions
     from dgps_with_iwvi_amd.layers import GPLayer
     from dgps_with_iwvi_amd.temp_workaround import SharedMixedMok
-    kern = kernels.RBF(D, variance=1.1, lengthscales=c["ls"])
+    kern = kernels.RBF(D, variance=c.get("variance", 1.1), lengthscales=c["ls"])
     feat = features.InducingPoints(c["Z"])
     mfo = {"linear": lambda: mean_functions.Linear(c["A"], c["b"]), "identity": mean_functions.Identity,
            "zero": lambda: None}[mf]()
@@ -122,7 +122,7 @@ def _run_layer(c, dev, D, R, mixing, mf, full_cov=False, z=None):
 
 
 def _oracle_layer(c, D, R, mixing, mf, full_cov=False, z=None):
-    kern = O.RBF(D, variance=1.1, lengthscales=c["ls"])
+    kern = O.RBF(D, variance=c.get("variance", 1.1), lengthscales=c["ls"])
     mfo = {"linear": lambda: O.Linear(c["A"], c["b"]), "identity": O.Identity, "zero": lambda: None}[mf]()
     layer = O.GPLayer(O.SharedMixedMok(kern, c["W"]) if mixing else kern, c["Z"], R, mfo)
     layer.q_mu, layer.q_sqrt = c["q_mu"], c["q_sqrt"]
@@ -160,6 +160,23 @@ def test_gp_layer_forward(gpu_device, M, D, R, P, mixing, mf, S, N):
     # with z = 0 the sample is exactly the mean
     s0, m0, _, _ = _run_layer(c, gpu_device, D, R, mixing, mf, z=torch.zeros(S, N, R, device=gpu_device))
     assert torch.equal(s0, m0)
+
+
+@pytest.mark.parametrize("variance", [1e4, 1e-4, 37.0])
+def test_super_block_solve_at_extreme_kernel_variances(gpu_device, variance):
+    """M > 240, split-f16 operands: the scales of the packed inverse blocks and of the published right-hand sides are powers of two fixed
+    by the kernel variance (and capped by 1 / sqrt(jitter) so that no entry can leave the f16 range: at variance 1e4 the cap is active)
+    -- the tolerances of test_gp_layer_forward hold relative to the layer's scale at variances far from 1."""
+    M, D, R, S, N = 256, 8, 2, 3, 40
+    c = dict(_layer_case(77, M, D, R, R, False, "zero", S, N), variance=variance)
+    s, m, v, kl = _run_layer(c, gpu_device, D, R, False, "zero", z=_t(c["z"], gpu_device))
+    so, mo, vo, klo = _oracle_layer(c, D, R, False, "zero", z=c["z"])
+    sd = float(np.sqrt(variance))
+    np.testing.assert_allclose(_np(m), mo, rtol=MEAN_TOL["rtol"], atol=MEAN_TOL["atol"] * sd)
+    np.testing.assert_allclose(_np(v), vo, rtol=VAR_TOL["rtol"], atol=VAR_TOL["atol"] * variance)
+    np.testing.assert_allclose(_np(s), so, rtol=2e-3, atol=2e-3 * sd)
+    assert bool(torch.isfinite(m).all()) and bool(torch.isfinite(v).all())
+    np.testing.assert_allclose(float(kl.item()), klo, rtol=1e-6)
 
 
 def test_super_block_operands_from_a_dense_state(gpu_device):
