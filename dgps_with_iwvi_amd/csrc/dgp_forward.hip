@@ -1497,7 +1497,7 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
                     }
                     // ---- a_I = (L_II)^-1 r_I.  S16 (round 5, last): only the DIAGONAL block of a row is an fp32 product -- on the row's own r(bi),
                     // still in registers, in front of the barrier --; the blocks left of it take split-f16 operands like the dense part: the
-                    // packed image holds, per lane, [h1 x 4 | h2 x 4] of s_i (L_II)^-1 (k_pack_ls16; s_i = 2^lg, lg = ceil(log2 sigma), lowered where 1/sqrt(jitter) would leave f16), every row
+                    // packed image holds, per lane, [h1 x 4 | h2 x 4] of 2^lg (L_II)^-1 (k_pack_ls16; lg = ceil(log2 sigma)), every row
                     // publishes r(bi) as [h1 x 4 | h2 x 4] of s_r r (s_r = 2^(5 - 2 lg): |r| <= sigma^2 -> <= 32) in place of k(bi), and
                     // block (w, q) costs two v_mfma_f32_16x16x32_f16 per sub-tile (A = [h1 | h1], then [h2 | h2], against B = [h1' | h2']:
                     // all four partial products) -- 32 clocks where the fp32 block took 128; 28 of a super-block's 36 blocks.  An error in
@@ -1506,8 +1506,7 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
                     if constexpr (S16) {
                         f32x4 Ti[SBT];
                         using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
-                        const float s_lg = 1024.0f / sa_sb, s_r = 32.0f / (s_lg * s_lg);     // sa_sb = 2^(10 - lg) for these layers
-                        const float s_i = cst[IWVI_CST_SI];                                  // the scale the packed inverse blocks carry (k_pack_ls16)
+                        const float s_i = 1024.0f / sa_sb, s_r = 32.0f / (s_i * s_i);        // sa_sb = 2^(10 - lg) for these layers
                         gptr4 Pt16 = (gptr4)G.LsP + G.ls16_off + (size_t)sb16_slabs(nbk) * 128 + (size_t)(offt + rw * (rw - 1) / 2) * 64 + lane;
                         if (mine) {
 #pragma unroll

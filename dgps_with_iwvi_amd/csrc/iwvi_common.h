@@ -31,8 +31,6 @@ constexpr int IWVI_CST_SA = 65, IWVI_CST_FMEAN = 66, IWVI_CST_FR = 72;   // spli
 // units of U = 2^(2 est), sigma 2^est -> 2^7.  [U] = U (1 when the layer's solve is fp32): the Gram tile is written times U and the LsP
 // stream's Dinv blocks are packed times 1/U;  [SB] = 2^est: a_j -> the B operand of the updates, whose A blocks are 2^est (-L) in two halves
 constexpr int IWVI_CST_U = 67, IWVI_CST_SB = 68;
-// M > 240: the power-of-two scale of the split-f16 inverse blocks of the super-block solve (sb16_tri_blocks; written by k_pack_ls16)
-constexpr int IWVI_CST_SI = 69;
 
 // triangular block storage, row-block major:
 //   solve stream LsP (column-block major): column bj = [Lm(bj,bj)^-1, -Lm(bj+1,bj), .., -Lm(nbk-1,bj)],
@@ -67,8 +65,11 @@ __host__ __device__ static inline int sb16_slabs(int nbk) {
 }
 // ... and the triangular part -- a_I = (L_II)^-1 r_I -- takes split-f16 operands for every block LEFT of the diagonal (round 5): behind the
 // slabs, one 1-KiB block per (super-block I, row w = 1 .. nr - 1, q < w), rows in order, lane 16 g + i holding [h1 x 4 | h2 x 4] of
-// 2^e (L_II)^-1 [16 w + i][16 q + 4 g .. + 3] -- k_pack_ls16 again.  e = min(ceil(log2 sigma), floor(log2(65504 sqrt(jitter)))): the diagonal entries
-// (>= 1 / sigma) come out >= 1, and no entry can leave the f16 range (|L_II^-1| <= 1 / sqrt(lambda_min(K_uu)) <= 1 / sqrt(jitter)); 2^e goes to cst[IWVI_CST_SI]
+// 2^lg (L_II)^-1 [16 w + i][16 q + 4 g .. + 3] (lg = ceil(log2 sigma): the diagonal entries, >= 1 / sigma, come out >= 1) -- k_pack_ls16 again.
+// |L_II^-1| <= 1 / sqrt(lambda_min(K_uu)) <= 1 / sqrt(jitter): nothing reaches the largest f16 while variance / jitter < 2^30 (variance 1000 at the default
+// jitter 1e-6); the host side of the layer API asks for the fp32 variant beyond that (settings.split16_variance_ok), the packer saturates as the last resort
+// (measured, round 5: 2^(lg - 3) -- room for variance / jitter < 2^36 -- costs a factor 1.2-1.8 in the error at configs[3] / [4], and carrying the
+// scale in the state's constants moved the five-sub-tile variant 16 B further into scratch: configs[3] +1.7 %)
 __host__ __device__ static inline int sb16_tri_blocks(int nbk) {
     int n = 0;
     for (int I = 0; 8 * I < nbk; ++I) { const int nr = nbk - 8 * I < 8 ? nbk - 8 * I : 8; n += nr * (nr - 1) / 2; }

@@ -155,7 +155,7 @@ __global__ __launch_bounds__(1024) void k_precompute(PreArgs args) {
 // the launch before left in the layer's workspace (block storage; the blocks between different super-blocks still hold L there) or, for a
 // state precomputed with IWVI_GP_WANT_DENSE / _LM, from its dense Lm.  A launch of its own: k_precompute is not touched by it
 // (at 128 VGPRs with spills, a source change anywhere in that kernel moves the M <= 128 path by +-1 us: profiles/r04_precompute_notes.txt).
-struct Ls16One { const double* blk; const double* Lm; unsigned short* dst; const float* LsP; float* cst; const float* variance_dev; float variance, jitter; int nbk, Mp, M, first; };
+struct Ls16One { const double* blk; const double* Lm; unsigned short* dst; const float* LsP; const float* variance_dev; float variance; int nbk, Mp, M, first; };
 struct Ls16All { Ls16One L[IWVI_MAX_LAYERS]; int n; };
 __global__ __launch_bounds__(256) void k_pack_ls16(const Ls16All a) {
     int li = 0;
@@ -181,10 +181,7 @@ __global__ __launch_bounds__(256) void k_pack_ls16(const Ls16All a) {
         while (w * (w + 1) / 2 <= tb) ++w;
         const int q = tb - w * (w - 1) / 2;
         const float var = L.variance_dev ? *L.variance_dev : L.variance;
-        int e_i = (int)ceilf(0.5f * log2f(fmaxf(var, 1e-30f)));
-        if (L.jitter > 0.f) { const int cap = (int)floorf(log2f(65504.f * sqrtf(L.jitter))); e_i = e_i < cap ? e_i : cap; }
-        const float si = ldexpf(1.f, e_i);
-        if (tb0 == 0 && lane == 0) L.cst[IWVI_CST_SI] = si;
+        const float si = ldexpf(1.f, (int)ceilf(0.5f * log2f(fmaxf(var, 1e-30f))));
         const float4 v = reinterpret_cast<const float4*>(L.LsP)[(size_t)(off + nr * r0 + w * (w + 1) / 2 + q) * 64 + lane];
         const float x[4] = {v.x * si, v.y * si, v.z * si, v.w * si};
         pk_f16x8 o;
@@ -956,7 +953,7 @@ extern "C" int iwvi_model_precompute(const iwvi_gp_desc* layers, int n_layers, c
                 o.blk = L.ws + ws_layout(L.Mp).blk;
                 o.Lm = (L.flags & (IWVI_GP_WANT_DENSE | IWVI_GP_WANT_LM)) ? L.Lm : nullptr;
                 o.dst = reinterpret_cast<unsigned short*>(reinterpret_cast<char*>(L.Lm) - sl.off_Lm + sl.off_Ls16);
-                o.LsP = L.LsP; o.cst = L.cst; o.jitter = (float)L.jitter;
+                o.LsP = L.LsP;
                 o.variance = L.variance; o.variance_dev = L.variance_dev;
                 o.nbk = L.nbk; o.Mp = L.Mp; o.M = L.M; o.first = grid;
                 grid += (sb16_slabs(L.nbk) + sb16_tri_blocks(L.nbk) + 3) / 4;

@@ -121,7 +121,7 @@ class GPLayer:
         d.M, d.D, d.R, d.P = M, D, R, P
         d.kern_type, d.mf_type = kern.kern_type, mf.mf_type
         d.variance, d.variance_dev = kern.desc_variance()
-        d.flags = (_abi.LAYER_F32_STAGE2 if settings.fw_f32_stage2 else 0) | (_abi.LAYER_F64_STAGE1 if self.uses_f64_stage1() else 0)
+        d.flags = (_abi.LAYER_F32_STAGE2 if (settings.fw_f32_stage2 or not settings.split16_variance_ok(M, d.variance)) else 0) | (_abi.LAYER_F64_STAGE1 if self.uses_f64_stage1() else 0)
         keep = [W]
         if W is not None:
             d.W = W.data_ptr()

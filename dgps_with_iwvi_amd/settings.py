@@ -41,6 +41,14 @@ def use_f64_stage1(input_dim, override=None):
 bw_f32_chain = bool(os.environ.get("IWVI_BW_F32_CHAIN"))
 
 
+def split16_variance_ok(num_inducing, variance):
+    """False for a GP layer whose launch must take the fp32-MFMA variant (``IWVI_LAYER_F32_STAGE2``) whatever ``fw_f32_stage2`` says: M > 240
+    and kernel variance / jitter >= 2^30.  The split-f16 image of the super-block inverses holds 2^ceil(log2 sigma) (L_II)^-1 as f16 pairs;
+    its entries are bounded by sigma / sqrt(jitter) up to a factor 2, which leaves the f16 range beyond that ratio (the packer would saturate).
+    ``variance``: the host copy (possibly a step stale for a trained, device-resident variance -- the bound has a factor 2 of slack)."""
+    return int(num_inducing) <= 240 or float(variance) < 2.0 ** 30 * float(jitter_level)
+
+
 def default_device():
     if not torch.cuda.is_available():
         return torch.device("cpu")

@@ -150,8 +150,9 @@ def draw_normal(shape, device):
     return out
 
 
-def _layer_flags(f64):
-    return (_abi.LAYER_F32_STAGE2 if settings.fw_f32_stage2 else 0) | (_abi.LAYER_F64_STAGE1 if f64 else 0)
+def _layer_flags(f64, M=0, variance=0.0):
+    f32 = settings.fw_f32_stage2 or not settings.split16_variance_ok(M, variance)
+    return (_abi.LAYER_F32_STAGE2 if f32 else 0) | (_abi.LAYER_F64_STAGE1 if f64 else 0)
 
 
 def _forward_diag(state, kern, D, R, F2, z2, W, mean_function, want=(True, True, True), f64=False):
@@ -170,7 +171,7 @@ def _forward_diag(state, kern, D, R, F2, z2, W, mean_function, want=(True, True,
     _abi.check(_abi.lib().iwvi_gp_layer_forward_ex(
         _abi.ptr(state.buf), state.M, D, R, P, kern.kern_type, kern.variance,
         _abi.ptr(F2), _abi.ptr(z2), _abi.ptr(W), mf_type, _abi.ptr(mfA), _abi.ptr(mfb),
-        _abi.ptr(outs[0]), _abi.ptr(outs[1]), _abi.ptr(outs[2]), T, 1, _layer_flags(f64), _abi.stream_ptr()))
+        _abi.ptr(outs[0]), _abi.ptr(outs[1]), _abi.ptr(outs[2]), T, 1, _layer_flags(f64, state.M, kern.desc_variance()[0]), _abi.stream_ptr()))
     return outs
 
 

@@ -165,8 +165,9 @@ def test_gp_layer_forward(gpu_device, M, D, R, P, mixing, mf, S, N):
 @pytest.mark.parametrize("variance", [1e4, 1e-4, 37.0])
 def test_super_block_solve_at_extreme_kernel_variances(gpu_device, variance):
     """M > 240, split-f16 operands: the scales of the packed inverse blocks and of the published right-hand sides are powers of two fixed
-    by the kernel variance (and capped by 1 / sqrt(jitter) so that no entry can leave the f16 range: at variance 1e4 the cap is active)
-    -- the tolerances of test_gp_layer_forward hold relative to the layer's scale at variances far from 1."""
+    by the kernel variance; their entries are bounded by sigma / sqrt(jitter), so beyond variance / jitter = 2^30 (here: 1e4 at jitter 1e-6)
+    the layer API asks for the fp32 variant (settings.split16_variance_ok).  The tolerances of test_gp_layer_forward hold relative to the
+    layer's scale at variances far from 1, on whichever variant runs."""
     M, D, R, S, N = 256, 8, 2, 3, 40
     c = dict(_layer_case(77, M, D, R, R, False, "zero", S, N), variance=variance)
     s, m, v, kl = _run_layer(c, gpu_device, D, R, False, "zero", z=_t(c["z"], gpu_device))
@@ -177,6 +178,9 @@ def test_super_block_solve_at_extreme_kernel_variances(gpu_device, variance):
     np.testing.assert_allclose(_np(s), so, rtol=2e-3, atol=2e-3 * sd)
     assert bool(torch.isfinite(m).all()) and bool(torch.isfinite(v).all())
     np.testing.assert_allclose(float(kl.item()), klo, rtol=1e-6)
+    from dgps_with_iwvi_amd import _abi
+    took_split16 = bool(_abi.lib().iwvi_debug_last_forward_variant() >> 8 & 1)
+    assert took_split16 == (variance < 1e3)
 
 
 def test_super_block_operands_from_a_dense_state(gpu_device):

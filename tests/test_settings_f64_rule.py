@@ -25,3 +25,15 @@ def test_flags_of_the_header_and_the_bindings_agree():
     val = lambda name: int(re.search(r"#define\s+%s\s+(\d+)" % name, h).group(1))
     assert val("IWVI_LAYER_F64_STAGE1") == _abi.LAYER_F64_STAGE1 and val("IWVI_GP_F64_STAGE1") == _abi.GP_F64_STAGE1
     assert val("IWVI_LAYER_F32_STAGE2") == _abi.LAYER_F32_STAGE2 and val("IWVI_GP_WANT_DENSE") == _abi.GP_WANT_DENSE and val("IWVI_GP_WANT_LM") == _abi.GP_WANT_LM
+
+
+def test_split16_variance_rule():
+    """M > 240 and variance / jitter >= 2^30: the layer asks for the fp32-MFMA variant (the split-f16 image of the super-block inverses
+    is bounded by sigma / sqrt(jitter), which leaves the f16 range there)."""
+    from dgps_with_iwvi_amd import settings
+    with settings.temp_settings(jitter=1e-6):
+        assert settings.split16_variance_ok(512, 1.0) and settings.split16_variance_ok(256, 1000.0)
+        assert not settings.split16_variance_ok(256, 1100.0) and not settings.split16_variance_ok(512, 1e6)
+        assert settings.split16_variance_ok(128, 1e9)            # M <= 240: no explicit inverses in the solve
+    with settings.temp_settings(jitter=1e-9):
+        assert not settings.split16_variance_ok(256, 2.0) and settings.split16_variance_ok(256, 0.5)
