@@ -274,6 +274,46 @@ def roofline_object(achieved, flops, launch_ms, spec, traffic, traffic_src, pmc)
             "flops_per_launch": flops, **pmc}
 
 
+def l2_operand_stream(spec, T, launch_ms):
+    """Bytes of packed operands one launch of the layer kernel pulls out of L2 (every workgroup streams every layer's images once for its
+    16 * NS samples: the factor's solve stream, the R images of tril(q_sqrt)^T, q_mu^T, the Gram operand -- csrc/iwvi_common.h: state
+    layout), over the kernel's duration.  Not a contract field: the guide's measured L2-served rate (MI355X_MICROARCH.md, 'rows shared by
+    every workgroup') is 66-73 GB/s per CU = 16.8-18.8 TB/s, which is what bounds the M = 512 config where the matrix pipe does not."""
+    from dgps_with_iwvi_amd import _abi
+    v = int(_abi.lib().iwvi_debug_last_forward_variant())
+    ns, s16 = v & 0xff, bool(v >> 8 & 1)
+    if ns < 1:
+        return None
+    tri = lambda n: n * (n + 1) // 2
+    def sb16_slabs(nbk):
+        return sum(min(nbk - 8 * I, 8) * 4 * I for I in range(1, (nbk + 7) // 8)) if nbk >= 16 else 0
+    def sb16_tri(nbk):
+        return sum(min(nbk - 8 * I, 8) * (min(nbk - 8 * I, 8) - 1) // 2 for I in range((nbk + 7) // 8)) if nbk >= 16 else 0
+    per_wg = 0
+    for l in spec["layers"]:
+        if l["type"] != "gp":
+            continue
+        M, D = l["Z"].shape
+        R = l["q_mu"].shape[1]
+        nbk, nrb, nsteps = (M + 15) // 16, (R + 15) // 16, (D + 2 + 3) // 4
+        per_wg += nbk * nsteps * 256                                                       # Z~ (Gram operand)
+        if nbk >= 16 and s16:
+            per_wg += sb16_slabs(nbk) * 2048 + sb16_tri(nbk) * 1024 + nbk * 1024          # solve: split-f16 slabs, split-f16 inverse blocks, fp32 diagonal blocks
+        else:
+            per_wg += tri(nbk) * 1024                                                      # solve stream, fp32 blocks
+        if s16:
+            slabs = sum((nbk - (bi & ~1) + 1) // 2 for bi in range(nbk))
+            per_wg += R * slabs * 2048 + nrb * ((nbk + 1) // 2) * 2048                     # tril(q_sqrt[r])^T and q_mu^T as split-f16 slabs
+        else:
+            per_wg += R * tri(nbk) * 1024 + nrb * nbk * 1024
+    nwg = (T + 16 * ns - 1) // (16 * ns)
+    total = per_wg * nwg
+    return {"bytes_per_workgroup": per_wg, "workgroups": nwg, "samples_per_workgroup": 16 * ns, "bytes_per_launch": total,
+            "TB_per_s": total / (launch_ms * 1e-3) / 1e12, "guide_measured_l2_rate_TB_per_s": [16.8, 18.8],
+            "note": "packed operands streamed from L2 by every workgroup (algorithmic: the images' sizes x workgroups), over the kernel's "
+                    "measured duration; informational -- `bound` above stays the contract's matrix-core ceiling"}
+
+
 def gemm_phase_mfma_util(model, spec, B, K):
     """MFMA utilisation INSIDE the batched conditional GEMM phases of the layer kernel (north_star: ">= 40 % MFMA utilisation on the
     batched conditional GEMMs", temp_workaround.py:51 and :68,78): per GP layer, the matrix instructions a workgroup issues in stage 1
@@ -768,6 +808,10 @@ def main():
     torch.cuda.synchronize()
     dom_ms = float(np.median([a.elapsed_time(b) for a, b in evs])) / NREP
     achieved = dom_flops / (dom_ms * 1e-3)
+    try:                                                     # (read now: the variant the timed launches took)
+        l2_stream = l2_operand_stream(spec, B * K, dom_ms)
+    except Exception as e:                                   # informational
+        l2_stream = {"error": "%s: %s" % (type(e).__name__, e)}
     gemm_util = None
     if world == 1:
         try:
@@ -899,6 +943,7 @@ def main():
         }
         if gemm_util is not None:
             res["roofline"]["gemm_phase_mfma_util"] = gemm_util
+        res["roofline"]["l2_operand_stream"] = l2_stream
         f32p, f16p = f_alg_split(spec, settings.fw_f32_stage2)
         mix_peak = (f32p + f16p) / (f32p / PEAK_MFMA_F32 + f16p / (PEAK_MFMA_F16 / 3.0))
         res["model_frac_of_mfma_peak"] = res["value"] / world * tot_flops / mix_peak          # the WHOLE step (both launches) against the mix ceiling

@@ -85,6 +85,9 @@ def test_bench_single_rank_line_has_the_contract_fields(gpu_device):
     g = r["gemm_phase_mfma_util"]
     assert 0.0 < g["value"] <= 1.0 and len(g["per_layer"]) == 2 and all(0.0 < l["stage2"]["util"] <= 1.0 for l in g["per_layer"])
     assert res["environment"]["HIP_FORCE_DEV_KERNARG"] == os.environ.get("HIP_FORCE_DEV_KERNARG", "1")   # (an inherited value wins over the package's default)
+    # round 5: the packed-operand stream every workgroup pulls out of L2 (informational; what bounds the M = 512 config)
+    l2 = r["l2_operand_stream"]
+    assert l2["workgroups"] * l2["bytes_per_workgroup"] == l2["bytes_per_launch"] and 0.0 < l2["TB_per_s"] < 20.0 and l2["samples_per_workgroup"] % 16 == 0
     # (the `no_dev_kernarg` leg -- the same loop in a fresh process without device-resident kernel arguments -- belongs to the full line only)
 
 
