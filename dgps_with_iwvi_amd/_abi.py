@@ -196,7 +196,7 @@ PROTOTYPES = {
     "iwvi_fill_normal_dev": (c_int, [c_void_p, c_int64, ctypes.c_uint64, c_void_p, c_void_p]),
 }
 
-DEBUG_OPTIONS = ("IWVI_BW_FUSED", "IWVI_CHAIN_EXIT", "IWVI_FW_SLOW_TAIL", "IWVI_NATGRAD_UNFUSED", "IWVI_NG_ONE_WG", "IWVI_NG_STOP", "IWVI_DEBUG_STOP", "IWVI_PRE_STAMP_P",
+DEBUG_OPTIONS = ("IWVI_BW_FUSED", "IWVI_CHAIN_EXIT", "IWVI_FW_SLOW_TAIL", "IWVI_FW_MAX_NS", "IWVI_NATGRAD_UNFUSED", "IWVI_NG_ONE_WG", "IWVI_NG_STOP", "IWVI_DEBUG_STOP", "IWVI_PRE_STAMP_P",
                  "IWVI_FW_NO_LEAN", "IWVI_PRE_SB_INLINE")
 
 

@@ -2845,6 +2845,7 @@ int dgp_forward_impl(const iwvi_layer_desc* layers, int n_layers, const float* X
     const size_t LDS_MAX = 160 * 1024;
     int ns = (int)((T + 16 * 256 - 1) / (16 * 256));
     if (ns > FW_MAXNS) ns = FW_MAXNS;
+    { const int cap = dbg_opt("IWVI_FW_MAX_NS"); if (cap > 0 && ns > cap) ns = cap; }   // development: fewer samples per workgroup than would fit
     if (ns < 1) ns = 1;
     size_t lds_bytes = 0;
     for (; ns >= 1; --ns) {
