@@ -274,13 +274,15 @@ def roofline_object(achieved, flops, launch_ms, spec, traffic, traffic_src, pmc)
             "flops_per_launch": flops, **pmc}
 
 
-def l2_operand_stream(spec, T, launch_ms):
+def l2_operand_stream(spec, T, launch_ms, variant=None):
     """Bytes of packed operands one launch of the layer kernel pulls out of L2 (every workgroup streams every layer's images once for its
     16 * NS samples: the factor's solve stream, the R images of tril(q_sqrt)^T, q_mu^T, the Gram operand -- csrc/iwvi_common.h: state
     layout), over the kernel's duration.  Not a contract field: the guide's measured L2-served rate (MI355X_MICROARCH.md, 'rows shared by
     every workgroup') is 66-73 GB/s per CU = 16.8-18.8 TB/s, which is what bounds the M = 512 config where the matrix pipe does not."""
-    from dgps_with_iwvi_amd import _abi
-    v = int(_abi.lib().iwvi_debug_last_forward_variant())
+    if variant is None:                                        # (bits of iwvi_debug_last_forward_variant: samples per workgroup / 16, split-f16 route)
+        from dgps_with_iwvi_amd import _abi
+        variant = int(_abi.lib().iwvi_debug_last_forward_variant())
+    v = int(variant)
     ns, s16 = v & 0xff, bool(v >> 8 & 1)
     if ns < 1:
         return None
