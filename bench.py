@@ -410,9 +410,36 @@ def no_dev_kernarg_leg(args):
         return {"error": "%s: %s" % (type(e).__name__, e)}
 
 
+def visible_gpu_count(root="/sys/class/kfd/kfd/topology/nodes"):
+    """GPUs this node shows, WITHOUT any HIP / torch.cuda call in the launcher parent (it must not initialise the GPU: its children
+    do): the KFD topology in sysfs -- a node with ``simd_count`` > 0 is a GPU -- narrowed by ``HIP_VISIBLE_DEVICES`` /
+    ``ROCR_VISIBLE_DEVICES`` / ``CUDA_VISIBLE_DEVICES`` when set.  Falls back to ``torch.cuda.device_count()`` (which does not
+    initialise HIP on this image) only where the topology is not readable."""
+    import glob
+    nodes = glob.glob(os.path.join(root, "*", "properties"))
+    n = None
+    if nodes:
+        n = 0
+        for f in nodes:
+            try:
+                with open(f) as fh:
+                    props = dict(l.split()[:2] for l in fh if len(l.split()) >= 2)
+                n += int(props.get("simd_count", "0")) > 0
+            except (OSError, ValueError):
+                n = None
+                break
+    if n is None:
+        return torch.cuda.device_count()
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([x for x in v.split(",") if x.strip() != ""]))
+    return n
+
+
 def launch_ranks(args, argv):
     """``--gpus N`` > 1 without a launcher: start the N rank processes from HERE -- a process that has not touched the GPU (no HIP
-    call so far: ``import torch`` and ``torch.cuda.device_count()`` do not initialise it on this image; nothing is re-exec'd) -- with the
+    call so far: ``import torch`` does not initialise it and the device count comes from sysfs, ``visible_gpu_count``; nothing is re-exec'd) -- with the
     environment contract of ``torch.distributed.run`` (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT), dmabuf IPC for RCCL
     and device-resident kernel arguments.  Rank 0's stdout (the one JSON line) is relayed; the other ranks' stdout goes to stderr.
     Returns the exit code: the first non-zero rank's (the others are then killed -- exactly the process groups started here), 124 on
@@ -421,7 +448,7 @@ def launch_ranks(args, argv):
     import socket
     import threading
     n = args.gpus
-    ndev = torch.cuda.device_count()
+    ndev = visible_gpu_count()
     if args.rendezvous_only:
         ndev = n
     if n > ndev and not args.oversubscribe:

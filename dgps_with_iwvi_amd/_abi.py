@@ -31,8 +31,15 @@ c_void_p, c_int, c_int64, c_float, c_double, c_size_t = (
     ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_double, ctypes.c_size_t)
 
 
+ERR_ARG, ERR_LAUNCH, ERR_UNSUPPORTED = -1, -2, -3      # enum iwvi_status (include/iwvi_hip.h)
+
+
 class IwviError(RuntimeError):
-    pass
+    """A non-zero status of the library; ``rc`` is the IWVI_ERR_* code (None when raised by the host side itself)."""
+
+    def __init__(self, msg, rc=None):
+        super().__init__(msg)
+        self.rc = rc
 
 
 class GpDesc(ctypes.Structure):
@@ -235,7 +242,7 @@ def lib():
 
 def check(rc):
     if rc != 0:
-        raise IwviError("libiwvi_hip: %s (code %d)" % (lib().iwvi_last_error().decode(), rc))
+        raise IwviError("libiwvi_hip: %s (code %d)" % (lib().iwvi_last_error().decode(), rc), rc)
 
 
 def dev_tensor(t, name="tensor", dtype=torch.float32):

@@ -51,7 +51,7 @@ def precompute_dense(layers):
     for l in layers:
         if isinstance(l, GPLayer):
             d = l.state_desc()
-            d.flags = _abi.GP_WANT_DENSE
+            d.flags |= _abi.GP_WANT_DENSE          # keep IWVI_GP_F64_STAGE1: the forward of a float64-route layer reads this state's z~ image
             descs.append(d)
     precompute_states(descs)
 
@@ -168,7 +168,7 @@ def prepare_side(model, T, stream, out=None, after=None):
         descs = []
         for i, l in gps:
             d = l.state_desc(state=out[i][1])
-            d.flags = _abi.GP_WANT_DENSE
+            d.flags |= _abi.GP_WANT_DENSE
             descs.append(d)
         precompute_states(descs)
         if 1 < len(gps) <= _abi.MAX_STACK:                       # every layer's operands in one launch
@@ -396,7 +396,7 @@ def iw_elbo_and_gradients(model, zs=None, mode_vi=None, exchange=None, K_total=N
                                               outputs_for={len(layers) - 1} if slim else None, moments=not slim)
             fused_heads = True
         except _abi.IwviError as e:
-            if "fused adjoint heads" not in str(e):
+            if e.rc != _abi.ERR_UNSUPPORTED:                     # the library's "this stack cannot fuse the heads": the two-launch form below
                 raise
     if not fused_heads:
         _, outs, _ = model._fused_forward(T, K, B, (T,), zs=zflat, sampled_kl=not mode_vi, want_layers=True, want_logw=False,

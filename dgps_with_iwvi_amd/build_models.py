@@ -86,6 +86,10 @@ def build_model(ARGS, X, Y, apply_name=True, device=None):
         model = DGP_IWVI(X, Y, layers, lik, minibatch_size=ARGS.minibatch_size,
                          num_samples=ARGS.num_IW_samples, name=name)
     model = model.to(device or settings.default_device())
+    if model.X.is_cuda and settings.f64_stage1 == "auto" and getattr(ARGS, "autotune_f64", True):
+        # the float64 stage-1 route per layer from the measured diag(Lm) ratio of the initial values (k-means inducing inputs can
+        # cluster: an 8-D layer is not well-conditioned by its dimension alone); the Trainer repeats it at every staircase epoch
+        model.f64_route_report = model.autotune_f64()
     attach_train_op(model, ARGS)
     return model
 

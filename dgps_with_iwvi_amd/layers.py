@@ -47,10 +47,11 @@ class GPLayer:
         self.name = name
         self._state = None
         self.f64_stage1 = None          # None: settings.f64_stage1 decides (auto: input dimension <= 3); True / False: this layer's own choice
+        self._f64_measured = None       # models.DGP_VI.autotune_f64: the choice measured on the factor of the current parameters
 
     def uses_f64_stage1(self):
         """Does this layer take the float64 stage-1 route (include/iwvi_hip.h: IWVI_LAYER_F64_STAGE1)?"""
-        return settings.use_f64_stage1(self._Z().shape[1], self.f64_stage1)
+        return settings.use_f64_stage1(self._Z().shape[1], self.f64_stage1, getattr(self, "_f64_measured", None))
 
     # -- plumbing -------------------------------------------------------------------------
     def _Z(self):
@@ -122,6 +123,10 @@ class GPLayer:
         d.kern_type, d.mf_type = kern.kern_type, mf.mf_type
         d.variance, d.variance_dev = kern.desc_variance()
         d.flags = (_abi.LAYER_F32_STAGE2 if (settings.fw_f32_stage2 or not settings.split16_variance_ok(M, d.variance)) else 0) | (_abi.LAYER_F64_STAGE1 if self.uses_f64_stage1() else 0)
+        if (d.flags & _abi.LAYER_F64_STAGE1) and not self.state().f64_prepared:
+            # the float64 Gram + solve read the state's plain z~ and dense Lm^-1, which only a precompute with IWVI_GP_F64_STAGE1 writes
+            raise ValueError("layer takes the float64 stage-1 route but its state was last precomputed without IWVI_GP_F64_STAGE1 "
+                             "(use GPLayer.state_desc() / precompute(), which set the bit)")
         keep = [W]
         if W is not None:
             d.W = W.data_ptr()

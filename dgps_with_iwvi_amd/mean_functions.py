@@ -1,5 +1,7 @@
 """Mean functions GPLayer.propagate adds to samples and mean (reference layers.py:46-48).
-They are evaluated inside ``iwvi_gp_layer_forward``'s epilogue; these classes only carry parameters."""
+On the hot path they are evaluated inside ``iwvi_gp_layer_forward``'s epilogue and these classes only carry parameters; ``__call__``
+(GPflow 1.x ``MeanFunction.__call__``: what the reference's ``self.mean_function(F)`` at layers.py:46 invokes) exists for user code
+that calls a mean function itself -- e.g. a custom layer following the layer protocol -- and runs as torch ops on the tensor's device."""
 import numpy as np
 import torch
 
@@ -14,10 +16,17 @@ class MeanFunction:
     def to(self, device):
         return self
 
+    def __call__(self, X):
+        raise NotImplementedError
+
 
 class Zero(MeanFunction):
     def __init__(self, output_dim=1):
         self.output_dim = output_dim
+
+    def __call__(self, X):
+        """GPflow 1.x ``Zero``: zeros of shape ``X.shape[:-1] + [output_dim]`` (default 1: it broadcasts against any P)."""
+        return torch.zeros(*X.shape[:-1], self.output_dim, dtype=X.dtype, device=X.device)
 
 
 class Identity(MeanFunction):
@@ -25,6 +34,9 @@ class Identity(MeanFunction):
 
     def __init__(self, input_dim=None):
         self.input_dim = input_dim
+
+    def __call__(self, X):
+        return X
 
 
 class Linear(MeanFunction):
@@ -43,3 +55,7 @@ class Linear(MeanFunction):
     def to(self, device):
         self.A, self.b = self.A.to(device), self.b.to(device)
         return self
+
+    def __call__(self, X):
+        """``X A + b`` on the last axis, any number of leading axes (GPflow 1.x ``Linear``)."""
+        return torch.matmul(X, self.A.to(device=X.device, dtype=X.dtype)) + self.b.to(device=X.device, dtype=X.dtype)

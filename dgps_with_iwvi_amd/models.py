@@ -122,23 +122,31 @@ class DGP_VI:
             _abi.check(_abi.lib().iwvi_gp_dense_inverse(arr, len(descs), _abi.stream_ptr()))
 
     def autotune_f64(self, threshold=300.0):
-        """Set every GP layer's ``f64_stage1`` override from the factor itself: max / min of diag(Lm) of the CURRENT parameters (one
-        precompute with the dense factor + a read-back: a synchronisation, so it is a calibration call -- after building or loading
-        a model, every so many training steps -- not part of an evaluation).  diag(Lm) spans [sqrt(jitter), sigma] -- at most 1e3 at the default jitter and unit
-        variance.  Measured (scripts/diag_ratio.py): 14 / 28 / 85 at the BASELINE stacks (8-D, M = 128 / 256 / 512), 430 at 4-D M = 128, 820-990
-        for 1-3-D inputs at any M >= 32; the default ``threshold`` 300 separates what float32 holds at the stated tolerance from what
-        it does not (profiles/r05_f64_route_error.txt).  Returns [{layer, diag_ratio, f64_stage1}]."""
-        self.precompute()
+        """Record every GP layer's MEASURED float64-route choice from the factor itself: max / min of diag(Lm) of the CURRENT parameters
+        (one precompute launch with the dense factors for all layers + ONE read-back: a synchronisation, so it is a calibration call -- after
+        building or loading a model, at every staircase epoch of a training run (``training.Trainer`` does both) -- not part of an evaluation).
+        diag(Lm) spans [sqrt(jitter), sigma] -- at most 1e3 at the default jitter and unit variance.  Measured (scripts/diag_ratio.py): 14 / 28 / 85
+        at the BASELINE stacks (8-D, M = 128 / 256 / 512), 430 at 4-D M = 128, 820-990 for 1-3-D inputs at any M >= 32; the default
+        ``threshold`` 300 separates what float32 holds at the stated tolerance from what it does not (profiles/r05_f64_route_error.txt).
+        A layer's explicit ``f64_stage1 = True / False`` still wins over the measurement.  Returns [{layer, diag_ratio, f64_stage1}]."""
+        gps = [(i, l) for i, l in enumerate(self.layers) if isinstance(l, GPLayer)]
+        self.precompute(dense=True)
+        ratios = []
+        for _, l in gps:
+            st = l.state()
+            d = torch.diagonal(st.view("Lm", torch.float64, st.Mp * st.Mp).view(st.Mp, st.Mp)[:st.M, :st.M])
+            ratios.append(d.max() / d.min())
+        ratios = torch.stack(ratios).tolist() if ratios else []    # the one device-to-host copy
         rep = []
-        for i, l in enumerate(self.layers):
-            if not isinstance(l, GPLayer):
-                continue
-            d = torch.diagonal(l.state().Lm)
-            ratio = float((d.max() / d.min()).item())
-            l.f64_stage1 = bool(ratio >= threshold)
-            rep.append(dict(layer=i, diag_ratio=ratio, f64_stage1=l.f64_stage1))
+        for (i, l), ratio in zip(gps, ratios):
+            l._f64_measured = bool(ratio >= threshold) if ratio == ratio else True      # (NaN: the float32 image of the factor broke down)
+            rep.append(dict(layer=i, diag_ratio=float(ratio), f64_stage1=l.uses_f64_stage1()))
         self.precompute()                                         # (the states as an evaluation expects them: flags of the new choice)
         return rep
+
+    def route_key(self):
+        """What a captured graph bakes in besides the shapes: each GP layer's arithmetic route (``training.Trainer`` re-captures when it moves)."""
+        return tuple((l.uses_f64_stage1(), bool(settings.fw_f32_stage2)) for l in self.layers if isinstance(l, GPLayer))
 
     def propagate(self, X, full_cov=False, inference_amorization_inputs=None,
                   is_sampled_local_regularizer=False, zs=None, _precomputed=False, _kl_parts=False, _last_sample=True):

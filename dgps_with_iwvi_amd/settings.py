@@ -21,16 +21,21 @@ fw_f32_stage2 = bool(os.environ.get("IWVI_FW_F32_STAGE2"))
 # K_uu is ill-conditioned.  "auto" (default): a layer takes it when its INPUT dimension is <= f64_auto_max_dim (inducing points crowd a
 # 1-3-dimensional box: cond(Lm) ~ 1e4, float32 loses 1e-2 .. 1e-1 of the mean there; the reference's own tests and demo are 1-D) --
 # a static rule, so no launch ever waits for a condition estimate; "on" / "off" force it for every layer; GPLayer.f64_stage1 = True / False
-# overrides per layer, and models.DGP_VI.autotune_f64() sets those per-layer overrides from the measured diag(Lm) ratio.
+# overrides per layer, and models.DGP_VI.autotune_f64() records a MEASURED choice per layer from the diag(Lm) ratio of the current parameters
+# (it ranks below the layer's explicit True / False and above the global setting; training.Trainer and build_models.build_model call it --
+# at construction and at every staircase epoch -- while this setting is "auto").
 # The 8-dimensional BASELINE stacks never take it (tests/test_gpu_f64_route.py asserts the variant bits).
 f64_stage1 = os.environ.get("IWVI_F64_STAGE1", "auto")
 f64_auto_max_dim = 3
 
 
-def use_f64_stage1(input_dim, override=None):
-    """The rule above for one GP layer of input dimension ``input_dim`` (``override``: the layer's own True / False / None)."""
+def use_f64_stage1(input_dim, override=None, measured=None):
+    """The rule above for one GP layer of input dimension ``input_dim`` (``override``: the layer's own True / False / None;
+    ``measured``: what ``autotune_f64`` found for the layer's current parameters, or None)."""
     if override is not None:
         return bool(override)
+    if measured is not None:
+        return bool(measured)
     if f64_stage1 == "on":
         return True
     if f64_stage1 == "off":

@@ -17,6 +17,7 @@ Deviations (all documented in DESIGN.md):
   * float32 per-sample arithmetic with a float64 factorisation; variances are clamped at 0.
 """
 import ctypes
+import weakref
 
 import torch
 
@@ -40,6 +41,9 @@ class SharedMixedMok:
         return self
 
 
+_STATES = weakref.WeakValueDictionary()      # state buffer address -> its GpState (precompute_states records what each launch prepared)
+
+
 class GpState:
     """Owner of one layer's per-step factorisation buffer (``iwvi_gp_desc.state``)."""
 
@@ -55,6 +59,8 @@ class GpState:
         self.Mp = (self.M + 15) // 16 * 16
         self._keep = None
         self._redo_dense = None
+        self.f64_prepared = False      # the last precompute of this buffer ran with IWVI_GP_F64_STAGE1 (dense Lm^-1 + plain z~ present)
+        _STATES[self.buf.data_ptr()] = self
 
     def view(self, name, dtype, numel):
         off = self.offsets[name]
@@ -77,7 +83,7 @@ class GpState:
         if self._redo_dense is None:
             raise RuntimeError("no precompute has run on this state yet")
         d = self._redo_dense
-        d.flags = _abi.GP_WANT_DENSE
+        d.flags |= _abi.GP_WANT_DENSE
         precompute_states([d])
         return self.view(name, torch.float64, self.Mp * self.Mp).view(self.Mp, self.Mp)[:self.M, :self.M]
 
@@ -112,6 +118,10 @@ def precompute_states(descs, encs=()):
     if not descs:
         return
     arr = (_abi.GpDesc * len(descs))(*descs)
+    for d in descs:
+        st = _STATES.get(d.state)
+        if st is not None:
+            st.f64_prepared = bool(d.flags & _abi.GP_F64_STAGE1)
     if encs:
         earr = (_abi.EncDesc * len(encs))(*encs)
         _abi.check(_abi.lib().iwvi_model_precompute(arr, len(descs), earr, len(encs), _abi.stream_ptr()))

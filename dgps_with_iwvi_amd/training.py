@@ -26,7 +26,7 @@ def staircase_decay(base, step, rate, every=1000):
 class Trainer:
     def __init__(self, model, lr=5e-3, gamma=1e-2, lr_decay=0.98, gamma_decay=0.98, fix_linear=True,
                  beta1=0.9, beta2=0.999, epsilon=1e-8, group=None, shard_weight=None, shard="n", num_data_total=None,
-                 use_graph=False, check_finite=True, check_every=100):
+                 use_graph=False, check_finite=True, check_every=100, autotune_f64=True):
         """``group`` / ``shard_weight``: data-parallel training over the ranks of a torch.distributed group (each rank's
         model holds its own minibatch rows, N-shard): gradients are merged by ``sharding.allreduce_gradients`` with
         weight B_rank / B_job (default: from the all-reduced local batch sizes) before either update, so every rank
@@ -43,8 +43,16 @@ class Trainer:
         device): each of the two ops of a step is captured once into a hipGraph and replayed (as ONE graph when the data is not minibatched) -- no host work per launch, no
         device-to-host copy per step; the graphs are re-captured when the staircase decay changes lr / gamma.  ``check_finite``:
         one small D2H that raises when the bound or the final layer's q(u) went non-finite (the reference's Cholesky raises) -- every
-        step in eager mode, every ``check_every`` steps in graph mode."""
+        step in eager mode, every ``check_every`` steps in graph mode.
+
+        ``autotune_f64`` (default on, while ``settings.f64_stage1 == "auto"``): ``model.autotune_f64()`` -- the float64 stage-1 route per layer
+        from the measured diag(Lm) ratio of the CURRENT parameters -- runs here and again at every staircase epoch (1000 steps: the graphs
+        are re-captured there anyway), so that a layer whose K_uu becomes ill-conditioned DURING training (lengthscales grow, inducing
+        inputs cluster) leaves the float32 solve; captured graphs are dropped whenever a layer's route moves (``model.route_key()``)."""
         self.model = model
+        self.autotune = bool(autotune_f64)
+        self._tuned_epoch = None
+        self.route_reports = []                                # [(global step, autotune_f64's report)]
         self.group, self.shard_weight, self.shard = group, shard_weight, shard
         import torch.distributed as dist
         # group=None means the DEFAULT group once torch.distributed is up: what counts is the number of ranks
@@ -104,8 +112,17 @@ class Trainer:
             _abi.dev_tensor(t, name)
         self._state = [tuple(torch.empty_like(t) for _ in range(3)) for _, t, _ in self._entries]
         self._adam_call(None, init=True)
+        self._autotune_if_due()
         M = self.final.num_inducing
         self._ng_ws = torch.empty(_abi.lib().iwvi_natgrad_ws_bytes(M), dtype=torch.uint8, device=dev)
+
+    def _autotune_if_due(self):
+        """Once per staircase epoch (and at construction): the measured route of every GP layer; a moved route invalidates the graphs."""
+        epoch = self.global_step // 1000
+        if not self.autotune or settings.f64_stage1 != "auto" or self._tuned_epoch == epoch:
+            return
+        self._tuned_epoch = epoch
+        self.route_reports.append((self.global_step, self.model.autotune_f64()))
 
     def _adam_call(self, grads, init=False, lr=0.0):
         n = len(self._entries)
@@ -186,7 +203,7 @@ class Trainer:
     def _replay(self, name, op):
         """Capture ``op`` (one evaluation + its update) into a hipGraph on first use -- and again whenever the staircase decay
         moves lr / gamma, which enter the update kernels by value -- then replay it."""
-        epoch = self.global_step // 1000
+        epoch = (self.global_step // 1000, self.model.route_key())
         ent = self._graphs.get(name)
         if ent is not None and ent[0] == epoch:
             ent[1].replay()
@@ -214,6 +231,7 @@ class Trainer:
     def step(self, zs_ng=None, zs_adam=None):
         """``model.train_op`` (build_models.py:297-300); returns the ELBO seen by the Adam op."""
         self.global_step += 1
+        self._autotune_if_due()
         if self.use_graph:
             if zs_ng is not None or zs_adam is not None:
                 raise ValueError("use_graph draws the noise on the device (captured graphs cannot take per-step host arguments)")
@@ -266,6 +284,8 @@ class Trainer:
         self.global_step, self.adam_t = int(state["global_step"]), int(state["adam_t"])
         self._t_dev.fill_(self.adam_t)
         self._graphs = {}
+        self._tuned_epoch = None                               # the restored parameters get their own measurement
+        self._autotune_if_due()
         for (name, _, _), (x, m, v) in zip(self._entries, self._state):
             for key, dst in (("x.", x), ("m.", m), ("v.", v)):
                 dst.copy_(torch.as_tensor(np.asarray(state[key + name]), dtype=dst.dtype, device=dst.device).reshape(dst.shape))

@@ -41,3 +41,20 @@ def test_a_dying_rank_ends_the_job_with_a_nonzero_code():
         pytest.skip("covered on the GPU by tests/test_gpu_multirank.py::test_bench_self_launch_reports_a_failing_rank")
     p = _run("--gpus", "2", "--oversubscribe", "--backend", "gloo", "--steps", "2", "--warmup", "1")   # no device here: both ranks exit 1
     assert p.returncode != 0 and "stopping the other ranks" in p.stderr and not p.stdout.strip()
+
+
+def test_device_count_comes_from_the_kfd_topology(tmp_path, monkeypatch):
+    """The launcher parent counts GPUs without a HIP / torch.cuda call: KFD nodes with simd_count > 0, narrowed by *_VISIBLE_DEVICES."""
+    sys.path.insert(0, ROOT)
+    import bench
+    for i, simd in enumerate((0, 0, 1024, 1024, 1024)):             # two CPU nodes, three GPUs
+        d = tmp_path / str(i)
+        d.mkdir()
+        (d / "properties").write_text("cpu_cores_count %d\nsimd_count %d\nmem_banks_count 1\n" % (64 if simd == 0 else 0, simd))
+    for v in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        monkeypatch.delenv(v, raising=False)
+    assert bench.visible_gpu_count(str(tmp_path)) == 3
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "0,2")
+    assert bench.visible_gpu_count(str(tmp_path)) == 2
+    import torch
+    assert bench.visible_gpu_count(str(tmp_path / "absent")) == torch.cuda.device_count()      # unreadable topology: the fallback

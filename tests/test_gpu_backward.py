@@ -80,6 +80,47 @@ def test_gp_layer_backward_matches_autodiff(gpu_device, M, T, li):
         assert torch.equal(out[k], out2[k]), k
 
 
+@pytest.mark.parametrize("Dx,M,T,li", [(3, 32, 70, 0), (2, 48, 129, 1)])
+def test_gp_layer_backward_on_a_float64_route_layer(gpu_device, Dx, M, T, li):
+    """A layer of input dimension <= 3 takes the float64 stage-1 route by the default rule: ``precompute_dense`` must keep
+    IWVI_GP_F64_STAGE1 beside IWVI_GP_WANT_DENSE (the forward reads the state's plain z~ image, which only that bit writes), and a
+    layer descriptor with IWVI_LAYER_F64_STAGE1 on a state prepared without the bit is refused."""
+    from dgps_with_iwvi_amd import synthetic, backward, _abi
+    from dgps_with_iwvi_amd.temp_workaround import precompute_states
+    spec = synthetic.make_spec(L=2, M=M, B=8, K=2, Dx=Dx, R=2, with_lv=False, seed=M + li)
+    model = synthetic.build_model(spec, gpu_device)
+    layer = model.layers[li]
+    assert layer.uses_f64_stage1()
+    rng = np.random.default_rng(T)
+    D, R = layer._Z().shape[1], layer.num_outputs
+    P = spec["layers"][li]["W"].shape[0] if spec["layers"][li]["W"] is not None else R
+    F = rng.standard_normal((T, D)).astype(np.float32)
+    z = rng.standard_normal((T, R)).astype(np.float32)
+    cs, cm, cv = (rng.standard_normal((T, P)).astype(np.float32) for _ in range(3))
+    tt = lambda a: torch.as_tensor(a, device=gpu_device)
+    # poison the state's buffer first: a forward that read an unwritten z~ image would show it
+    layer.state().buf.fill_(0xFF)
+    saved = backward.gp_forward_saved(layer, tt(F), tt(z))
+    assert layer.state().f64_prepared
+    m = CpuDGP(spec, torch.float64)
+    s, mu, v = m._conditional(dict(m.layers[li]), torch.as_tensor(F, dtype=torch.float64)[None], False, torch.as_tensor(z, dtype=torch.float64)[None])
+    gmv = saved.GMV.cpu().numpy().astype(np.float64)          # [T, 3R]: latent sample | mean | variance
+    np.testing.assert_allclose(gmv[:, R:2 * R], mu[0].numpy(), rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(gmv[:, 2 * R:], v[0].numpy(), rtol=1e-5, atol=1e-5)
+    out = backward.gp_backward(layer, saved, tt(cs), tt(cm), tt(cv), kl_weight=0.7)
+    ref = _layer_reference(spec, li, F, z, cs, cm, cv, 0.7)
+    # the adjoint chain itself is float32 (DESIGN.md section 6): its own tolerance, on a moderately conditioned K_uu
+    for name, key in (("dF", "F"), ("dq_mu", "q_mu"), ("dZ", "Z"), ("dls", "ls")):
+        _close(name, out[name].cpu(), ref[key], rtol=2e-2)
+    # the refusal: the same state refilled WITHOUT the bit
+    d = layer.state_desc()
+    d.flags &= ~_abi.GP_F64_STAGE1
+    precompute_states([d])
+    assert not layer.state().f64_prepared
+    with pytest.raises(ValueError, match="float64 stage-1 route"):
+        layer.fused_desc(tt(z), None)
+
+
 os.environ.setdefault("IWVI_BW_FUSED", "1")      # exercise the fused per-sample kernel wherever the shapes allow it (it is gated by size otherwise)
 
 

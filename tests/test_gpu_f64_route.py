@@ -144,3 +144,52 @@ def test_autotune_reads_the_factor(gpu_device):
         assert all(r["f64_stage1"] for r in rep1) and all(r["diag_ratio"] >= 300 for r in rep1), rep1
         model1.compute_log_likelihood()
         assert _variant() & F64_BIT                              # the per-layer override wins over settings "off"
+
+
+def _model_errors(model, spec, dev, zs):
+    """(max |d mean| over layers, |d ELBO| / |ELBO|) of ``model`` against the float64 oracle on the noise ``zs``."""
+    zd = [_t(z, dev) for z in zs]
+    om = build_oracle(spec)
+    ref = om.build_likelihood(oracle_noise(spec, zs))
+    _, _, means_o, _, _ = om.log_weights(oracle_noise(spec, zs))
+    elbo = float(model.compute_log_likelihood(zd))
+    fmean, _, _, _, _, means, _ = model._forward_iw(zd)
+    dm = max([float(np.abs(_np(mm) - mo).max()) for mm, mo in zip(means[:-1], means_o[:-1])] + [float(np.abs(_np(fmean) - means_o[-1]).max())])
+    return dm, abs(elbo - ref) / abs(ref)
+
+
+def test_trainer_measures_the_route_of_a_clustered_8d_stack(gpu_device):
+    """the static rule keys on the input dimension alone.  An 8-D stack whose inducing inputs are CLUSTERED (16 centres,
+    8 near-copies each -- what k-means initialisation or training can produce) has an ill-conditioned K_uu: the rule says float32, the
+    measured diag(Lm) ratio says float64.  ``training.Trainer`` (and ``build_models.build_model``) run ``autotune_f64`` at construction and at
+    every staircase epoch: the layers move to the float64 stage-1 route and the stack holds the stated tolerance (mean rtol 2e-3 + atol 1e-3
+    -> checked here as max |d mean| <= 1e-3 on |mean| ~ 1; ELBO 1e-4 relative) which the float32 solve does not."""
+    from dgps_with_iwvi_amd import synthetic
+    from dgps_with_iwvi_amd.training import Trainer
+    spec = synthetic.make_spec(seed=11, parity=True, n_data=4096, L=2, M=128, K=10, B=16, with_lv=False)
+    rng = np.random.default_rng(5)
+    for l in spec["layers"]:
+        Z = l["Z"]
+        l["Z"] = (np.repeat(Z[:16], 8, axis=0) + 1e-3 * rng.standard_normal(Z.shape)).astype(np.float32).astype(np.float64)
+    zs = synthetic.make_noise(spec, seed=1)
+    model = synthetic.build_model(spec, gpu_device)
+    assert not any(l.uses_f64_stage1() for l in model.layers)            # the static rule: 8-D -> float32
+    dm32, de32 = _model_errors(model, spec, gpu_device, zs)
+    assert not _variant() & F64_BIT
+    tr = Trainer(model, use_graph=True)
+    (step0, rep), = tr.route_reports
+    assert step0 == 0 and all(r["f64_stage1"] and r["diag_ratio"] >= 300 for r in rep), rep
+    assert all(l.uses_f64_stage1() for l in model.layers)
+    dm64, de64 = _model_errors(model, spec, gpu_device, zs)
+    assert _variant() & F64_BIT
+    assert dm64 <= 1e-3 and de64 <= 1e-4, (dm64, de64)
+    assert dm32 > 3 * dm64, (dm32, dm64)                                  # what the measured route buys on this stack
+    # an explicit per-layer choice still wins over the measurement; a moved route drops the captured graphs
+    e0 = tr.step()
+    key0 = model.route_key()
+    assert tr._graphs and all(k[0][1] == key0 for k in [(v[0],) for v in tr._graphs.values()])
+    model.layers[0].f64_stage1 = False
+    assert model.route_key() != key0
+    e1 = tr.step()                                                       # re-captured with the new route, not replayed with the old flags
+    assert all(v[0][1] == model.route_key() for v in tr._graphs.values())
+    assert np.isfinite(float(e0)) and np.isfinite(float(e1))

@@ -104,11 +104,16 @@ def _zero_inner_case():
 def test_reference_test_dgp_zero_inner_layers(gpu_device, inner_noise):
     """A first layer with RBF(variance=1e-6), Identity mean function, q_sqrt * 1e-12, Z = X and jitter 1e-18
     (``temp_settings``) passes its input through, so the 2-layer DGP's ``predict_f_full_cov`` equals the 1-layer SVGP's.
-    The reference asserts atol = rtol = 1e-5 in float64 with the inner layer's random draw left in.  Here the inner
-    layer's marginal variance (true value ~1e-15: Xs lies between the inducing inputs of a kernel with lengthscale 1) is
-    the float32 difference ``1e-6 - |a|^2``, i.e. rounding noise of order 1e-6 * 2^-24 * cond: with ``inner_noise='zero'``
-    (injected z = 0, the sample IS the mean = x exactly) the only error left is the outer layer's float32 arithmetic;
-    with the random draw the input of the outer layer is perturbed by z * sqrt(rounding noise) and the tolerance says so."""
+    The reference asserts atol = rtol = 1e-5 in float64 with the inner layer's random draw left in
+    (/root/reference/tests/test_gp_layer.py:93-96).  Both layers are 1-D, so both take the float64 stage-1 route (asserted): the
+    inner layer's marginal variance sigma^2 - |a|^2 (true value ~1e-15: Xs lies between the inducing inputs of a kernel with
+    lengthscale 1) is differenced in float64 -- measured <= 1.2e-18, i.e. the draw moves the outer layer's input by
+    |z| sqrt(var) <= 2.5e-11 -- and the outer layer's K_uf, solve and variance are float64 too; what is left is the float32
+    arithmetic behind the solve (stage 2, the mean-function product, the stored outputs).  Measured over 40 draws
+    (scripts/refcase_residual.py, round 6): max |d mean| 9.0e-6 on |mean| <= 2.65, max |d cov| / |cov|max 4.3e-6; the assert
+    holds 2x that, 2e-5 / 1e-5 -- against the reference's 1e-5, and against the 5e-2 this test needed while the inner layer
+    ran the float32 ``1e-6 - |a|^2`` (rounding noise ~1e-7 -> |dx| ~ 1e-3 at an outer slope of ~30).  ``inner_noise='zero'``
+    (injected z = 0: the sample IS the mean = x exactly) isolates the outer layer: same tolerance."""
     from dgps_with_iwvi.layers import GPLayer
     from dgps_with_iwvi.models import DGP_VI
     from dgps_with_iwvi import kernels, likelihoods, mean_functions, settings
@@ -133,18 +138,13 @@ def test_reference_test_dgp_zero_inner_layers(gpu_device, inner_noise):
         # the inner layer alone: mean == x (q_mu = 0, Identity), variance ~ 0
         s0, mean0, cov0, _ = m_dgp.layers[0].propagate(_t(Xs, gpu_device), full_cov=False, z=torch.zeros(N - 1, 1, device=gpu_device))
     assert torch.equal(mean0, _t(Xs, gpu_device)) and torch.equal(s0, mean0)
-    assert float(cov0.max()) <= 1e-6 and float(cov0.min()) >= 0.0             # clamped float32 rounding of 1e-6 - |a|^2
+    assert float(cov0.max()) <= 1e-15 and float(cov0.min()) >= 0.0            # sigma^2 - |a|^2 differenced in float64 (measured <= 1.2e-18)
     assert m2.shape == (N - 1, Dy) and v2.shape == (Dy, N - 1, N - 1)
     vs = np.abs(v1).max()
-    if inner_noise == "zero":
-        # Z = X with lengthscale 0.1 at spacing 0.11: Kuu is well conditioned, float32 keeps ~5 digits
-        np.testing.assert_allclose(_np(m2), m1, atol=2e-4, rtol=2e-4)
-        assert np.abs(_np(v2) - v1).max() <= 2e-4 * vs
-    else:
-        # inner sample = x + z * sqrt(var), var <= ~1e-7 of rounding noise -> |dx| <~ 1e-3; the outer mean has slope
-        # ~|q_mu| / lengthscale ~ 30 there
-        np.testing.assert_allclose(_np(m2), m1, atol=5e-2, rtol=5e-2)
-        assert np.abs(_np(v2) - v1).max() <= 5e-2 * vs
+    # both 1-D layers on the float64 stage-1 route; tolerance = 2x the measured residual (docstring), for either noise mode
+    assert all(l.uses_f64_stage1() for l in m_dgp.layers)
+    np.testing.assert_allclose(_np(m2), m1, atol=2e-5, rtol=2e-5)
+    assert np.abs(_np(v2) - v1).max() <= 1e-5 * vs
 
 
 # ------------------------------------------------------------------------------------------

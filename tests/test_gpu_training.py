@@ -307,7 +307,7 @@ def test_graph_mode_follows_the_staircase_decay(gpu_device):
         vals = [float(tr.step()) for _ in range(8)]
         out.append((vals, [p.clone() for _, p, _ in tr._entries], model.layers[-1].q_sqrt.clone()))
         if use_graph:
-            assert set(tr._graphs) == {"step"} and tr._graphs["step"][0] == 1   # (full-batch data: the two ops are one graph) re-captured for epoch 1
+            assert set(tr._graphs) == {"step"} and tr._graphs["step"][0][0] == 1   # (key = (decay epoch, route key); full-batch data: the two ops are one graph) re-captured for epoch 1
     assert out[0][0] == out[1][0], (out[0][0], out[1][0])
     for pa, pb in zip(out[0][1], out[1][1]):
         assert torch.equal(pa, pb)
