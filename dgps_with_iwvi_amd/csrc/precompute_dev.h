@@ -261,44 +261,8 @@ __device__ __forceinline__ void chol_blocks(double* blk, int nbk, double* rinv, 
     gen(0, nbk < 2 ? 1 : 2, wave, nw);
     __syncthreads();
     PRE_STAMP(7);
-    for (int p = 0; p < nbk; ++p) {
-        const int m = nbk - 1 - p;                       // block rows below the diagonal block
-        const int win = m < 2 ? m : 2;                   // of which the factoring wave carries this many
-        if (p == stamp_p) PRE_STAMP(10);
-        if (wave == 0) {
-            __builtin_amdgcn_s_setprio(3);               // the serial pass is the critical path: its LDS traffic goes first
-            diag_factor_window(blk, p, win, xT + (size_t)p * BLK, rinv + NB * p, lane, (stamps && p == stamp_p) ? stamps + (size_t)blockIdx.x * 16 : nullptr);
-            __builtin_amdgcn_s_setprio(0);
-            if (p == stamp_p) PRE_STAMP(11);
-        } else if ((wave & 3) != 0 || nw < 8) {
-            // the workers: every wave that does not share wave 0's SIMD (waves 4, 8, .. would slow the serial pass down)
-            const int w = (nw < 8) ? wave - 1 : wave - 1 - (wave >> 2), nwo = (nw < 8) ? nw - 1 : nw - (nw >> 2);
-            // column p+1 catches up with the factored columns k < p
-            if (p > 0) {
-                for (int b = w; b < m; b += nwo) {
-                    const int bi = p + 1 + b;
-                    double* C = blk + boff(bi, p + 1);
-                    f64x4 acc = blk_load(C, lane);
-                    for (int k = 0; k < p; ++k) blk_mma<true>(acc, blk + boff(bi, k), blk + boff(p + 1, k), lane, -1.0);
-                    blk_store(C, acc, lane);
-                }
-            }
-            int wg = w;                                  // generation starts with the workers the catch-up left idle
-            if (p > 0 && m < nwo) { wg = w - m; if (wg < 0) wg += nwo; }
-            if (p + 2 < nbk) gen(p + 2, p + 3, wg, nwo);
-            // packing column p-1: dealt to the workers that do NOT generate in this step, the idle ones first (rotated index wg: [0, ng)
-            // generate, then the idle waves, the catch-up waves last) -- generating a block costs ten times a catch-up product, and the
-            // barrier of an early pass waits for the generating waves
-            if (p > 0) {
-                const int ng = (p + 2 < nbk) ? nbk - p - 2 : 0;
-                const int rel = ng < nwo ? wg - ng : w, nrel = ng < nwo ? nwo - ng : nwo;
-                if (rel >= 0) for (int it = rel * 64 + lane; it < (nbk - p + 1) * 64; it += nrel * 64) post(p - 1, it >> 6, it & 63);
-            }
-            if (p == nbk - 1) tail(w * 64 + lane, nwo * 64);     // work nobody waits for, beside the last (otherwise idle) pass
-        }
-        __syncthreads();
-        if (p == stamp_p) PRE_STAMP(12);
-        // block rows below: finish column p (rows beyond the window) and bring column p+1 up to date with it
+    // step B of a pass, by every wave: block rows below -- finish column p (rows beyond the window) and bring column p+1 up to date with it
+    auto step_b = [&](int p, int m, int win) {
         for (int b = wave; b < m; b += nw) {
             const int bi = p + 1 + b;
             double* A = blk + boff(bi, p);
@@ -312,8 +276,61 @@ __device__ __forceinline__ void chol_blocks(double* blk, int nbk, double* rinv, 
             blk_mma<true>(acc, A, blk + boff(p + 1, p), lane, -1.0);
             blk_store(C, acc, lane);
         }
-        if (m > 0) __syncthreads();
-        if (p == stamp_p) PRE_STAMP(13);
+    };
+    // Round 6: the column loop exists TWICE, once for the factoring wave and once for everybody else (same barriers, same arithmetic, same
+    // order: bit-identical).  In one loop, everything the worker side keeps live across a step -- the Gram generation's operands, the packing's
+    // scales and addresses, the catch-up's block offsets: ~50 registers at the 128 this 1024-thread kernel may use -- was live across the
+    // diagonal pass too, and the pass (32 doubles of window + its temporaries) spilled around itself: the ISA had 17 scratch loads per step,
+    // two of them on the factoring wave's own path, in a chain that is 8 x 2.3 us of one wave's latency.
+    if (wave == 0) {
+        for (int p = 0; p < nbk; ++p) {
+            const int m = nbk - 1 - p;                       // block rows below the diagonal block
+            const int win = m < 2 ? m : 2;                   // of which the factoring wave carries this many
+            if (p == stamp_p) PRE_STAMP(10);
+            __builtin_amdgcn_s_setprio(3);                   // the serial pass is the critical path: its LDS traffic goes first
+            diag_factor_window(blk, p, win, xT + (size_t)p * BLK, rinv + NB * p, lane, (stamps && p == stamp_p) ? stamps + (size_t)blockIdx.x * 16 : nullptr);
+            __builtin_amdgcn_s_setprio(0);
+            if (p == stamp_p) PRE_STAMP(11);
+            __syncthreads();
+            if (p == stamp_p) PRE_STAMP(12);
+            step_b(p, m, win);
+            if (m > 0) __syncthreads();
+            if (p == stamp_p) PRE_STAMP(13);
+        }
+    } else {
+        for (int p = 0; p < nbk; ++p) {
+            const int m = nbk - 1 - p;
+            const int win = m < 2 ? m : 2;
+            if ((wave & 3) != 0 || nw < 8) {
+                // the workers: every wave that does not share wave 0's SIMD (waves 4, 8, .. would slow the serial pass down)
+                const int w = (nw < 8) ? wave - 1 : wave - 1 - (wave >> 2), nwo = (nw < 8) ? nw - 1 : nw - (nw >> 2);
+                // column p+1 catches up with the factored columns k < p
+                if (p > 0) {
+                    for (int b = w; b < m; b += nwo) {
+                        const int bi = p + 1 + b;
+                        double* C = blk + boff(bi, p + 1);
+                        f64x4 acc = blk_load(C, lane);
+                        for (int k = 0; k < p; ++k) blk_mma<true>(acc, blk + boff(bi, k), blk + boff(p + 1, k), lane, -1.0);
+                        blk_store(C, acc, lane);
+                    }
+                }
+                int wg = w;                                  // generation starts with the workers the catch-up left idle
+                if (p > 0 && m < nwo) { wg = w - m; if (wg < 0) wg += nwo; }
+                if (p + 2 < nbk) gen(p + 2, p + 3, wg, nwo);
+                // packing column p-1: dealt to the workers that do NOT generate in this step, the idle ones first (rotated index wg: [0, ng)
+                // generate, then the idle waves, the catch-up waves last) -- generating a block costs ten times a catch-up product, and the
+                // barrier of an early pass waits for the generating waves
+                if (p > 0) {
+                    const int ng = (p + 2 < nbk) ? nbk - p - 2 : 0;
+                    const int rel = ng < nwo ? wg - ng : w, nrel = ng < nwo ? nwo - ng : nwo;
+                    if (rel >= 0) for (int it = rel * 64 + lane; it < (nbk - p + 1) * 64; it += nrel * 64) post(p - 1, it >> 6, it & 63);
+                }
+                if (p == nbk - 1) tail(w * 64 + lane, nwo * 64);     // work nobody waits for, beside the last (otherwise idle) pass
+            }
+            __syncthreads();
+            step_b(p, m, win);
+            if (m > 0) __syncthreads();
+        }
     }
     if (tid < 64) post(nbk - 1, 0, tid);                 // the last column: its diagonal block
     __syncthreads();
