@@ -443,6 +443,9 @@ def iw_elbo_and_gradients(model, zs=None, mode_vi=None, exchange=None, K_total=N
         if mode_vi:
             raise ValueError("the K-sharded exchange is for the importance-weighted bound")
         _, _, ms = model._reduce(fin.mean, fin.var, Y, kls, [], B, K, stride_b=K, stride_k=1, mode_vi=False, want_ms=True)
+        from . import sharding
+        if sharding._RECORDER is not None and prep_stream != cur:
+            cur.wait_stream(prep_stream)                         # a segmented capture cuts the graph at the exchange: no forked work may be left open across the cut
         lse_g = _abi.dev_tensor(exchange(ms).to(ft).contiguous(), "lse_global")
     lik_host, lik_dev = model.likelihood.desc_variance()
     if not fused_heads:

@@ -79,6 +79,10 @@ constexpr int FW_SB_MIN_NBK = 16;
 #define FW_PIN_LOADS() do { } while (0)
 #endif
 constexpr int dbgSBD = IWVI_SBD, dbgSBT = IWVI_SBT;   // development builds: -DIWVI_SBD=n -DIWVI_SBT=n override the look-ahead depths of the super-block solve
+#ifndef IWVI_REBASE_ALL
+#define IWVI_REBASE_ALL 0
+#endif
+constexpr bool REBASE_ALL = IWVI_REBASE_ALL != 0;
 constexpr int FW_THREADS = 512;
 constexpr int FW_WAVES = FW_THREADS / 64;
 
@@ -790,8 +794,14 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
                                              // precomputed, noise drawn here, whole chunks): mode 1 and mode 2
     constexpr bool LEAN = LEAN_MODE == 1;    // ... and the bound's own evaluation: no per-layer outputs, the packed arrival, the half-wave tail.
                                              // Mode 2 keeps the outputs and the general tail: the forward of a value + gradient evaluation
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int gq = lane >> 4, jq = lane & 15;
+    int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int gq = lane >> 4, jq = lane & 15;
+    // Round 6 (BIG variants): the thread index becomes opaque again at every phase boundary, so that the lane-dependent tile addresses of a
+    // phase are formed IN that phase (a handful of integer instructions) instead of once, in front of the layer loop.  Hoisted, they were ~80
+    // registers live across every phase of every layer; the super-block solve and stage 2 then had to spill 12-14 of them around
+    // themselves (configs[3] / [4]: 60 / 52 B of scratch per lane = 65 / 424 MB of spill stores per launch).
+#define FW_REBASE() do { if constexpr (BIG || REBASE_ALL) { asm volatile("" : "+v"(tid)); lane = tid & 63; gq = lane >> 4; jq = lane & 15; } } while (0)
     const FwHead& g = gk.h;                                       // scalar path (first kernarg lines)
     const int XSTR = g.xstr;
     float* sm = reinterpret_cast<float*>(fw_smem);
@@ -1084,6 +1094,7 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
 
     int xt_for = -1;                                              // layer whose Gram operand x~ is already in `xt`
     for (int li = 0; li < g.n_layers; ++li) {
+        FW_REBASE();
         const FwLayer& L = LT[li];
         // the layer's 32 hot words: ONE pair of wide scalar loads from the (warmed) kernel-argument lines, then opaque registers.  Read through
         // a reference, every field was re-loaded next to each use (the compiler rematerialises loads of the kernel arguments instead of
@@ -1210,6 +1221,7 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
             // (the layer's forward-substitution stream is already on its way to LDS: prologue for the first GP
             // layer, the previous GP layer's stage 2 for the others)
             FW_STAMP(2 + li * 6 + 0);
+            FW_REBASE();
             // ---- Gram: kuf block bi = kernel(Z_bi, x), written in B-operand order ---------------------------
             DBG_WSTAMP(32);
             // float64 stage-1 route (F64 variants, layers flagged IWVI_LAYER_F64_STAGE1): the Gram tile in float64, behind the |u|^2 slots
@@ -1385,6 +1397,7 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
             __syncthreads();                                      // (the staged solve stream was complete before this layer began)
             DBG_WSTAMP(35);
             FW_STAMP(2 + li * 6 + 1);
+            FW_REBASE();
 
             // ---- stage 1: a = Lm^-1 k, right-looking blocked forward substitution, one wave per sub-tile ------
             // packed stream, column bj: [Dinv(bj), -L(bj+1,bj) .. -L(nbk-1,bj)];  a_bj = Dinv_bj r_bj, then
@@ -1744,6 +1757,7 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
             if (g.stamps && lane == 0 && li == 1) g.stamps[(size_t)blockIdx.x * 128 + 118 + wave] = clock64();
             __syncthreads();
             FW_STAMP(2 + li * 6 + 2);
+            FW_REBASE();
             // the solve is over: the next GP layer's stream leaves its registers for the staging buffer (free from here on)
 #pragma unroll
             for (int i = 0; i < LSN; ++i)
@@ -2070,6 +2084,7 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
 
             __syncthreads();
             FW_STAMP(2 + li * 6 + 3);
+            FW_REBASE();
 
             // ---- epilogue (i): per (sample, latent GP): variance, sample (temp_workaround.py:59,85,89-91) ----
             DBG_WSTAMP(40);
@@ -2096,6 +2111,7 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
             __syncthreads();
             DBG_WSTAMP(42);
             FW_STAMP(2 + li * 6 + 4);
+            FW_REBASE();
             // ---- epilogue (ii): mixing (:142-145) + linear mean function (layers.py:46-48); ahead of another GP layer
             //      as ONE small MFMA product out[p][j] = sum_k A[p][k] B[k][j],  A = [W | mfA^T],  B = [f_r(j) ; x_d(j)]:
             //      wave t owns sample sub-tile t; the result lands as 4 outputs p = 4gq .. 4gq+3 of sample 16t + jq
@@ -2293,6 +2309,7 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
     // logsumexp_k happens here from LDS and only one partial sum per workgroup crosses workgroups
     // (what this tail reads of the kernel arguments, requested together: read where they are used, each field was its own scalar-cache round
     //  trip on the one path every workgroup ends with -- fourteen of them, one after the other)
+    FW_REBASE();
     const FwElboHot Eh = opaque_block(static_cast<const FwElboHot&>(g.e));
     struct TailHot { float* out_logw; unsigned long long* rng; int Dy, yrows, cnt, nchunks; };
     const TailHot th = opaque_block(TailHot{g.out_logw, g.rng_state, g.Dy, g.lds.yrows, g.lds.cnt, g.nchunks});

@@ -22,6 +22,20 @@ import torch.distributed as dist
 from . import _abi
 
 
+# While ``training.Trainer`` records a sharded step as hipGraph SEGMENTS, every collective of the step is a cut between two segments
+# (``run_collective``): a collective is host-driven for gloo and library-driven for RCCL, neither belongs inside a captured graph here.
+_RECORDER = None
+
+
+def run_collective(fn):
+    """A collective of a training step (``fn()`` issues it on the current stream, on tensors that live as long as the step's graphs do):
+    run now -- and, while a segmented capture is recording, remembered as the cut between two graph segments (replayed in place)."""
+    if _RECORDER is None:
+        fn()
+    else:
+        _RECORDER.cut(fn)
+
+
 def split_samples(K_total, world):
     """Importance samples per rank: ceil(K/G) for the first K % G ranks, floor(K/G) for the rest."""
     if K_total < world:
@@ -212,7 +226,7 @@ def allreduce_gradients(grads, weight=None, group=None):
     flat = [grads[k].reshape(-1) for k in names]
     dtype = torch.float64 if any(t.dtype == torch.float64 for t in flat) else flat[0].dtype
     bucket = torch.cat([t.to(dtype) for t in flat]) * w
-    dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=group)
+    run_collective(lambda: dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=group))
     o = 0
     for k, t in zip(names, flat):
         n = t.numel()
@@ -275,7 +289,8 @@ def k_shard_gradients(model, zs=None, K_total=None, group=None, wrt="all"):
         if world == 1:
             return lse_from_pairs(ms[None])
         gathered = torch.empty((world,) + tuple(ms.shape), dtype=ms.dtype, device=ms.device)
-        dist.all_gather_into_tensor(gathered.view(-1), ms.contiguous().view(-1), group=group)
+        src = ms.contiguous().view(-1)
+        run_collective(lambda: dist.all_gather_into_tensor(gathered.view(-1), src, group=group))
         return lse_from_pairs(gathered)
 
     elbo, g = iw_elbo_and_gradients(model, zs, exchange=exchange, K_total=K_total, kl_weight=1.0 / world, wrt=wrt)

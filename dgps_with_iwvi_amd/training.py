@@ -23,6 +23,66 @@ def staircase_decay(base, step, rate, every=1000):
     return base * rate ** (step // every)
 
 
+class _SegmentedGraph:
+    """A training step (or one op of it) of a SHARDED job as hipGraph segments with the job's collectives between them.  Recording: the op
+    runs once under capture; at every collective (``sharding.run_collective``) the running capture ends, the collective is issued eagerly
+    (on whatever the dry capture left in its buffers: the ranks record at the same step, so the calls match up) and remembered, and a new
+    capture begins in the same memory pool.  ``replay``: the segments and the collectives in their recorded order on the current stream."""
+
+    def __init__(self):
+        self.items, self._g, self._pool, self.n_graphs, self.n_collectives = [], None, None, 0, 0
+
+    def _begin(self):
+        g = torch.cuda.CUDAGraph()
+        if self._pool is None:
+            g.capture_begin(capture_error_mode="thread_local")
+            self._pool = g.pool()
+        else:
+            g.capture_begin(pool=self._pool, capture_error_mode="thread_local")
+        self._g = g
+
+    def _end(self):
+        self._g.capture_end()
+        self.items.append(self._g)
+        self.n_graphs += 1
+        self._g = None
+
+    def cut(self, fn):
+        self._end()
+        fn()
+        self.items.append(fn)
+        self.n_collectives += 1
+        self._begin()
+
+    def record(self, op):
+        from . import sharding
+        if sharding._RECORDER is not None:
+            raise RuntimeError("a segmented capture is already recording")
+        sharding._RECORDER = self
+        try:
+            self._begin()
+            try:
+                out = op()
+            except BaseException:
+                if self._g is not None:
+                    try:
+                        self._g.capture_end()
+                    except Exception:
+                        pass
+                raise
+            self._end()
+        finally:
+            sharding._RECORDER = None
+        return out
+
+    def replay(self):
+        for it in self.items:
+            if isinstance(it, torch.cuda.CUDAGraph):
+                it.replay()
+            else:
+                it()
+
+
 class Trainer:
     def __init__(self, model, lr=5e-3, gamma=1e-2, lr_decay=0.98, gamma_decay=0.98, fix_linear=True,
                  beta1=0.9, beta2=0.999, epsilon=1e-8, group=None, shard_weight=None, shard="n", num_data_total=None,
@@ -39,9 +99,12 @@ class Trainer:
 
         The two trained host scalars of the reference -- the final layer's kernel variance and the likelihood variance -- live
         in 1-element device tensors that Adam updates in place and every kernel reads when it runs (``variance_dev`` of the
-        descriptors); the model's host copies are refreshed lazily when read.  ``use_graph=True`` (single GPU, noise drawn on the
+        descriptors); the model's host copies are refreshed lazily when read.  ``use_graph=True`` (noise drawn on the
         device): each of the two ops of a step is captured once into a hipGraph and replayed (as ONE graph when the data is not minibatched) -- no host work per launch, no
-        device-to-host copy per step; the graphs are re-captured when the staircase decay changes lr / gamma.  ``check_finite``:
+        device-to-host copy per step; the graphs are re-captured when the staircase decay changes lr / gamma.  With more than one rank the
+        step is captured as graph SEGMENTS with the job's collectives between them (``_SegmentedGraph``: N-shard: [value + gradient, bucket]
+        | all-reduce | [update; next op's value + gradient, bucket] | all-reduce | [update]; K-shard: the all-gather of the [B, 2] pairs cuts
+        each op once more) -- the same kernels in the same order as the eager sharded step, so the parameters agree bit for bit.  ``check_finite``:
         one small D2H that raises when the bound or the final layer's q(u) went non-finite (the reference's Cholesky raises) -- every
         step in eager mode, every ``check_every`` steps in graph mode.
 
@@ -69,8 +132,6 @@ class Trainer:
         self.global_step = 0
         self.adam_t = 0
         self.use_graph, self.check_finite, self.check_every = bool(use_graph), bool(check_finite), max(1, int(check_every))
-        if self.use_graph and self.world > 1:
-            raise ValueError("use_graph captures a single-GPU step; sharded training launches its collectives eagerly")
         self._graphs = {}                                      # op name -> (decay epoch, CUDAGraph, elbo tensor)
         dev = model.X.device
         self._t_dev = torch.zeros(1, dtype=torch.int64, device=dev)     # Adam's step count, on the device
@@ -216,9 +277,15 @@ class Trainer:
             with torch.cuda.stream(side):
                 if first:
                     eager = op()                               # this call's evaluation, launched eagerly (it also warms the allocator pools)
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):
-                    elbo = op()                                # recorded, not executed
+                if self.world > 1:                             # sharded: graph segments with the collectives between them
+                    torch.cuda.synchronize()
+                    g = _SegmentedGraph()
+                    elbo = g.record(op)
+                    torch.cuda.synchronize()
+                else:
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):
+                        elbo = op()                            # recorded, not executed
             torch.cuda.current_stream().wait_stream(side)
         finally:
             self._capturing = False

@@ -244,3 +244,35 @@ def test_trainer_n_shard_ranks_built_from_local_rows(gpu_device, tmp_path, rows)
         a, b = r0[k], v.detach().double().cpu().numpy().reshape(r0[k].shape)
         assert np.array_equal(a, r1[k]), k
         assert np.abs(a - b).max() <= 2e-4 * max(np.abs(b).max(), 1e-6), (k, np.abs(a - b).max(), np.abs(b).max())
+
+
+@pytest.mark.parametrize("shard", ["n", "k"])
+def test_sharded_training_step_as_graph_segments(gpu_device, tmp_path, shard):
+    """``Trainer(use_graph=True)`` with more than one rank captures a step as hipGraph SEGMENTS with the job's
+    collectives between them (N-shard: 3 segments around the 2 gradient all-reduces; K-shard: 5 around 2 all-gathers of the [B, 2] pairs
+    + 2 all-reduces).  Two gloo ranks on cuda:0: after five steps the parameters equal the eager sharded trainer's BIT FOR BIT (the same
+    kernels in the same order on the same device-drawn noise), on both ranks, and both ranks hold the same parameters."""
+    port = _free_port()
+    out = str(tmp_path / "seg_rank%d.npz")
+    worker = os.path.join(ROOT, "tests", "helpers", "sharded_graph_trainer_worker.py")
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, worker, out, shard, "5"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=ROOT))
+    for p in procs:
+        so, se = p.communicate(timeout=900)
+        assert p.returncode == 0, se[-3000:]
+    r0, r1 = np.load(out % 0), np.load(out % 1)
+    assert int(r0["n_collectives"]) == (2 if shard == "n" else 4) and int(r0["n_graphs"]) == int(r0["n_collectives"]) + 1
+    names = [k[len("eager."):] for k in r0.files if k.startswith("eager.") and k != "eager.ms"]
+    assert "q_mu" in names and "q_sqrt" in names and len(names) > 8
+    for r in (r0, r1):
+        for n in names:
+            assert np.array_equal(r["eager." + n], r["graph." + n]), (shard, n)
+        assert np.all(np.isfinite(r["eager.elbo"]))
+    for n in names:
+        if n != "elbo":
+            assert np.array_equal(r0["graph." + n], r1["graph." + n]), (shard, n)       # the ranks apply the same update
+    print("sharded step, 2 gloo ranks on one GPU (%s-shard): eager %.3f ms, graph segments %.3f ms" % (shard, float(r0["eager.ms"]), float(r0["graph.ms"])))
+    assert float(r0["graph.ms"]) <= float(r0["eager.ms"]) * 1.05          # never slower than the eager step it replaces

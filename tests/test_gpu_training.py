@@ -386,7 +386,8 @@ def test_graph_mode_host_scalars_follow_the_device_values(gpu_device):
 
 def test_trainer_counts_ranks_not_group_arguments(gpu_device):
     """``group=None`` is the default group once torch.distributed is initialised: the N-shard bookkeeping and the
-    use_graph guard follow the WORLD SIZE (1 rank: plain single-GPU training, graph capture allowed)."""
+    capture mode follow the WORLD SIZE (1 rank: plain single-GPU training, the step is ONE graph; more ranks: graph segments around the
+    collectives, tests/test_gpu_multirank.py::test_sharded_training_step_as_graph_segments)."""
     import torch.distributed as dist
     from dgps_with_iwvi_amd import synthetic
     from dgps_with_iwvi_amd.training import Trainer
