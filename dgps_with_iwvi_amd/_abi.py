@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libiwvi_hip.so")
 
 KERN_RBF, KERN_MATERN52 = 0, 1
 LAYER_GP, LAYER_LV = 0, 1
-ABI_VERSION = 15
+ABI_VERSION = 16
 GP_WANT_DENSE = 1
 GP_WANT_LM = 2
 LAYER_F32_STAGE2 = 1        # iwvi_layer_desc.flags
@@ -156,6 +156,9 @@ PROTOTYPES = {
     "iwvi_kde_loglik": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "iwvi_natgrad_ws_bytes": (c_size_t, [c_int]),
     "iwvi_natgrad_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_double, c_void_p, c_void_p]),
+    "iwvi_natgrad_ws_bytes_ex": (c_size_t, [c_int, c_int]),
+    "iwvi_natgrad_step_ex": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_double, c_void_p, c_size_t, c_void_p]),
+    "iwvi_debug_last_natgrad_route": (c_int, []),
     "iwvi_adam_step": (c_int, [ctypes.POINTER(AdamTensor), c_int, c_double, c_double, c_double, c_double, c_int64,
                                c_int, c_int, c_void_p]),
     "iwvi_adam_step_dev": (c_int, [ctypes.POINTER(AdamTensor), c_int, c_double, c_double, c_double, c_double, c_void_p, c_int, c_void_p]),
@@ -191,6 +194,11 @@ PROTOTYPES = {
                                     ctypes.POINTER(c_void_p), ctypes.POINTER(ctypes.c_int32), c_int,
                                     ctypes.POINTER(c_void_p), ctypes.POINTER(ctypes.c_int32), c_int, c_double,
                                     c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "iwvi_iw_elbo_reduce_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int64, c_int, c_int,
+                                        c_int64, c_int64,
+                                        ctypes.POINTER(c_void_p), ctypes.POINTER(ctypes.c_int32), c_int,
+                                        ctypes.POINTER(c_void_p), ctypes.POINTER(ctypes.c_int32), c_int, c_double,
+                                        c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "iwvi_lse_merge": (c_int, [c_void_p, c_int, c_int64, c_int, ctypes.POINTER(c_void_p),
                                ctypes.POINTER(ctypes.c_int32), c_int, c_double, c_void_p, c_void_p, c_void_p]),
     "iwvi_lse_merge_steps": (c_int, [c_void_p, c_int, c_int, c_int64, c_int, ctypes.POINTER(c_void_p),

@@ -2942,14 +2942,22 @@ __global__ void k_ng_q(const double* __restrict__ Phi, double gamma, double* __r
     const int i = idx / M, j = idx - i * M, ri = M - 1 - i, rj = M - 1 - j;
     Qrev[idx] = (i == j ? 1.0 : 0.0) + gamma * (Phi[(size_t)ri * M + rj] + Phi[(size_t)rj * M + ri]);
 }
+static int g_ng_route = 0;                                // diagnostic; see iwvi_debug_last_natgrad_route
+extern "C" int iwvi_debug_last_natgrad_route(void) { return g_ng_route; }
 extern "C" int iwvi_natgrad_step(float* q_mu, float* q_sqrt, const float* dq_mu, const float* dq_sqrt,
                                  int M, int R, double gamma, void* ws_, void* stream_) {
+    return iwvi_natgrad_step_ex(q_mu, q_sqrt, dq_mu, dq_sqrt, M, R, gamma, ws_, iwvi_natgrad_ws_bytes(M), stream_);
+}
+extern "C" int iwvi_natgrad_step_ex(float* q_mu, float* q_sqrt, const float* dq_mu, const float* dq_sqrt,
+                                    int M, int R, double gamma, void* ws_, size_t ws_bytes, void* stream_) {
     if (!q_mu || !q_sqrt || !dq_mu || !dq_sqrt || !ws_ || M <= 0 || M > IWVI_MAX_M || R <= 0 || R > IWVI_MAX_R) { set_error("iwvi_natgrad_step: bad argument"); return IWVI_ERR_ARG; }
+    if (ws_bytes < iwvi_natgrad_ws_bytes(M)) { set_error("iwvi_natgrad_step: workspace of %zu B, iwvi_natgrad_ws_bytes(%d) = %zu", ws_bytes, M, iwvi_natgrad_ws_bytes(M)); return IWVI_ERR_ARG; }
     hipStream_t st = (hipStream_t)stream_;
-    {   // M <= 128: the whole step in one workgroup per latent GP (csrc/precompute.hip: k_natgrad_small)
-        const int rcs = natgrad_small(q_mu, q_sqrt, dq_mu, dq_sqrt, M, R, gamma, st, ws_, iwvi_natgrad_ws_bytes(M));
-        if (rcs != 0) return rcs == 1 ? IWVI_OK : rcs;
+    {   // M <= 128: the whole step in one workgroup per latent GP, or spread over the chip (csrc/precompute.hip: natgrad_small)
+        const int rcs = natgrad_small(q_mu, q_sqrt, dq_mu, dq_sqrt, M, R, gamma, st, ws_, ws_bytes);
+        if (rcs != 0) { if (rcs > 0) g_ng_route = rcs; return rcs > 0 ? IWVI_OK : rcs; }
     }
+    g_ng_route = 0;
     char* base = (char*)ws_; size_t o = 0;
     auto mat = [&]() { double* p = (double*)(base + o); o += align256(sizeof(double) * (size_t)M * M); return p; };
     auto vec = [&]() { double* p = (double*)(base + o); o += align256(sizeof(double) * M); return p; };

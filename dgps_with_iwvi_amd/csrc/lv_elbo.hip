@@ -18,6 +18,7 @@ struct ReduceArgs {
     const float* kl[IWVI_MAX_KL]; int kl_dims[IWVI_MAX_KL]; int n_kl;
     long long B, stride_b, stride_k; int K, Dy, K_total, mode_vi;
     float lik_variance;
+    const float* lik_var_dev;        // optional device scalar read instead of lik_variance (a trained likelihood variance; iwvi_iw_elbo_reduce_dev)
     float* ms; float* logp;
     // fused final sum (last-arriving workgroup): out_elbo = sum(logp) * scale - sum(global KLs)
     double* elbo; unsigned long long* ticket; double scale;
@@ -51,8 +52,9 @@ __global__ __launch_bounds__(ELBO_THREADS) void k_elbo(ReduceArgs g) {
     const int tid = threadIdx.x, sl = tid % SEG, sg = tid / SEG;
     constexpr int PPP = ELBO_THREADS / SEG;          // points per pass
     const int K = g.K, Dy = g.Dy;
-    const float c0 = -0.5f * 1.8378770664093453f - 0.5f * logf(g.lik_variance);
-    const float inv2s = 0.5f / g.lik_variance;
+    const float likv = g.lik_var_dev ? *g.lik_var_dev : g.lik_variance;
+    const float c0 = -0.5f * 1.8378770664093453f - 0.5f * logf(likv);
+    const float inv2s = 0.5f / likv;
     for (int pp = 0; pp < ELBO_PTS; pp += PPP) {
         const long long b = (long long)blockIdx.x * ELBO_PTS + pp + sg;
         const bool live = b < g.B;                    // uniform within a segment
@@ -255,6 +257,18 @@ extern "C" int iwvi_iw_elbo_reduce(const float* fmean, const float* fvar, const 
                                    double scale, int K_total, int mode_vi,
                                    float* out_ms, float* out_logp, double* out_elbo, uint64_t* ticket,
                                    void* stream_) {
+    return iwvi_iw_elbo_reduce_dev(fmean, fvar, Y, lik_variance, nullptr, B, K, Dy, stride_b, stride_k, kl_local, kl_dims, n_kl,
+                                   kl_global, kl_global_counts, n_glob, scale, K_total, mode_vi, out_ms, out_logp, out_elbo, ticket, stream_);
+}
+
+extern "C" int iwvi_iw_elbo_reduce_dev(const float* fmean, const float* fvar, const float* Y,
+                                       float lik_variance, const float* lik_variance_dev, int64_t B, int K, int Dy,
+                                       int64_t stride_b, int64_t stride_k,
+                                       const float* const* kl_local, const int32_t* kl_dims, int n_kl,
+                                       const double* const* kl_global, const int32_t* kl_global_counts, int n_glob,
+                                       double scale, int K_total, int mode_vi,
+                                       float* out_ms, float* out_logp, double* out_elbo, uint64_t* ticket,
+                                       void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (!fmean || !fvar || !Y) { set_error("iwvi_iw_elbo_reduce: null input"); return IWVI_ERR_ARG; }
     if (B <= 0) { set_error("iwvi_iw_elbo_reduce: empty minibatch"); return IWVI_ERR_ARG; }
@@ -269,7 +283,7 @@ extern "C" int iwvi_iw_elbo_reduce(const float* fmean, const float* fvar, const 
     }
     g.stride_b = stride_b; g.stride_k = stride_k;
     g.B = B; g.K = K; g.Dy = Dy; g.K_total = K_total > 0 ? K_total : K; g.mode_vi = mode_vi;
-    g.lik_variance = lik_variance; g.ms = out_ms; g.logp = out_logp;
+    g.lik_variance = lik_variance; g.lik_var_dev = lik_variance_dev; g.ms = out_ms; g.logp = out_logp;
     g.elbo = out_elbo; g.ticket = (unsigned long long*)ticket; g.scale = scale;
     int rc;
     if (out_elbo && (rc = fill_globals(g, kl_global, kl_global_counts, n_glob)) != IWVI_OK) return rc;

@@ -808,7 +808,7 @@ int natgrad_small(float* q_mu, float* q_sqrt, const float* dq_mu, const float* d
             if ((rc = check_launch("k_ng_rows")) != IWVI_OK) return rc;
             hipLaunchKernelGGL(k_ng_vec, dim3(R), dim3(512), 0, st, a);
             rc = check_launch("k_ng_vec");
-            return rc == IWVI_OK ? 1 : rc;
+            return rc == IWVI_OK ? 2 : rc;                       // (2: the spread route; 1: one workgroup per latent GP)
         }
     }
     double* qws = nullptr;
@@ -825,6 +825,19 @@ int natgrad_small(float* q_mu, float* q_sqrt, const float* dq_mu, const float* d
 }  // namespace iwvi
 
 using namespace iwvi;
+
+extern "C" size_t iwvi_natgrad_ws_bytes_ex(int M, int R) {
+    size_t base = iwvi_natgrad_ws_bytes(M);
+    if (base == 0 || R <= 0 || R > IWVI_MAX_R) return 0;
+    const int Mp = round_up(M, NB);
+    if (Mp <= 128 && R <= IWVI_MAX_LAYERS) {                     // what natgrad_small's spread route carves: three block images, the factor's workspace, the row shares
+        const int nbk = Mp / NB, ntri = nbk * (nbk + 1) / 2;
+        const WsLayout w = ws_layout(Mp);
+        const size_t need = sizeof(double) * (3 * (size_t)R * ntri * BLK + (size_t)R * w.total + (size_t)R * nbk * Mp) + 64;
+        if (need > base) base = (need + 255) & ~(size_t)255;
+    }
+    return base;
+}
 
 extern "C" size_t iwvi_gp_state_bytes(int M, int R) {
     if (M <= 0 || R <= 0) return 0;

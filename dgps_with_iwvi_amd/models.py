@@ -345,8 +345,11 @@ class DGP_VI:
         elbo = torch.empty(1, dtype=torch.float64, device=dev)
         ms = torch.empty(B, 2, dtype=settings.float_type, device=dev) if want_ms else None
         scale = float(self.num_data) / float(B)                        # models.py:80-81, :144-145
-        _abi.check(_abi.lib().iwvi_iw_elbo_reduce(
-            _abi.ptr(fmean), _abi.ptr(fvar), _abi.ptr(Y), self.likelihood.variance, B, K, Dy,
+        # (a trained likelihood variance is read on the device: no device-to-host copy here -- there must be none inside a captured step --
+        #  and a replayed graph follows the value)
+        lik_host, lik_dev = self.likelihood.desc_variance()
+        _abi.check(_abi.lib().iwvi_iw_elbo_reduce_dev(
+            _abi.ptr(fmean), _abi.ptr(fvar), _abi.ptr(Y), lik_host, lik_dev, B, K, Dy,
             stride_b, stride_k, _abi.ptr_array(kls), kl_dims, len(kls), _abi.ptr_array(glob), glob_n, len(glob),
             scale, K_total or K, 1 if mode_vi else 0, _abi.ptr(ms), _abi.ptr(logp), _abi.ptr(elbo),
             _abi.ptr(self._words()), _abi.stream_ptr()))

@@ -35,11 +35,9 @@ class _SegmentedGraph:
     def _begin(self):
         g = torch.cuda.CUDAGraph()
         if self._pool is None:
-            g.capture_begin(capture_error_mode="thread_local")
-            self._pool = g.pool()
-        else:
-            g.capture_begin(pool=self._pool, capture_error_mode="thread_local")
-        self._g = g
+            self._pool = torch.cuda.graph_pool_handle()          # one memory pool for all segments: a buffer filled in one is read in the next
+        self._g = g                                              # (set first: a failing capture_begin is ended by record()'s handler)
+        g.capture_begin(pool=self._pool, capture_error_mode="thread_local")
 
     def _end(self):
         self._g.capture_end()
@@ -175,7 +173,8 @@ class Trainer:
         self._adam_call(None, init=True)
         self._autotune_if_due()
         M = self.final.num_inducing
-        self._ng_ws = torch.empty(_abi.lib().iwvi_natgrad_ws_bytes(M), dtype=torch.uint8, device=dev)
+        # (sized for THIS layer's R: the spread route of the step needs ~340 KB per latent GP at M = 128; include/iwvi_hip.h, ABI 16)
+        self._ng_ws = torch.empty(_abi.lib().iwvi_natgrad_ws_bytes_ex(M, self.final.num_outputs), dtype=torch.uint8, device=dev)
 
     def _autotune_if_due(self):
         """Once per staircase epoch (and at construction): the measured route of every GP layer; a moved route invalidates the graphs."""
@@ -230,8 +229,8 @@ class Trainer:
         gamma = staircase_decay(self.gamma, self.global_step, self.gamma_decay)
         dq_mu = _abi.dev_tensor(g["l%d.q_mu" % i].contiguous(), "dq_mu")
         dq_sqrt = _abi.dev_tensor(g["l%d.q_sqrt" % i].contiguous(), "dq_sqrt")
-        _abi.check(_abi.lib().iwvi_natgrad_step(_abi.ptr(f.q_mu), _abi.ptr(f.q_sqrt), _abi.ptr(dq_mu), _abi.ptr(dq_sqrt),
-                                               f.num_inducing, f.num_outputs, gamma, self._ng_ws.data_ptr(), _abi.stream_ptr()))
+        _abi.check(_abi.lib().iwvi_natgrad_step_ex(_abi.ptr(f.q_mu), _abi.ptr(f.q_sqrt), _abi.ptr(dq_mu), _abi.ptr(dq_sqrt),
+                                                  f.num_inducing, f.num_outputs, gamma, self._ng_ws.data_ptr(), self._ng_ws.numel(), _abi.stream_ptr()))
         return elbo
 
     def adam_op(self, zs=None, _advance=True):

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define IWVI_ABI_VERSION 15
+#define IWVI_ABI_VERSION 16
 
 enum {
     IWVI_OK = 0,
@@ -451,6 +451,15 @@ int iwvi_kde_loglik(const float* samples, int64_t sample_stride, int64_t point_s
 size_t iwvi_natgrad_ws_bytes(int M);
 int iwvi_natgrad_step(float* q_mu, float* q_sqrt, const float* dq_mu, const float* dq_sqrt,
                       int M, int R, double gamma, void* ws, void* stream);
+/* ABI 16: the same with the workspace sized for R latent GPs.  M <= 128: the step runs as five launches spread over the chip (their block
+ * images take ~340 KB per latent GP at M = 128) when `ws_bytes` holds them for all R, else -- as iwvi_natgrad_step does beyond the R its
+ * R-independent size happens to cover -- as one workgroup per latent GP: the same result, ~1.7x the time.  iwvi_natgrad_ws_bytes_ex(M, R)
+ * is the size that always takes the spread route; iwvi_debug_last_natgrad_route(): 0 = multi-launch (M > 128), 1 = one workgroup per
+ * latent GP, 2 = spread. */
+size_t iwvi_natgrad_ws_bytes_ex(int M, int R);
+int iwvi_natgrad_step_ex(float* q_mu, float* q_sqrt, const float* dq_mu, const float* dq_sqrt,
+                         int M, int R, double gamma, void* ws, size_t ws_bytes, void* stream);
+int iwvi_debug_last_natgrad_route(void);
 #define IWVI_ADAM_GRAD_F64 16
 typedef struct iwvi_adam_tensor {
     float* param; const float* grad; float* x; float* m; float* v; int64_t n; int32_t transform;
@@ -518,6 +527,17 @@ int iwvi_iw_elbo_reduce(const float* fmean, const float* fvar, const float* Y,
                         const double* const* kl_global_host, const int32_t* kl_global_counts_host, int n_glob,
                         double scale, int K_total, int mode_vi,
                         float* out_lse_ms, float* out_logp, double* out_elbo, uint64_t* ticket, void* stream);
+
+/* ABI 16: the same with the likelihood variance read from a 1-element device tensor when `lik_variance_dev` is not NULL (a TRAINED
+ * likelihood variance lives on the device: a captured graph of a K-sharded training step stays valid while it changes, and no
+ * device-to-host copy sits in the step); `lik_variance` is then only validated (> 0). */
+int iwvi_iw_elbo_reduce_dev(const float* fmean, const float* fvar, const float* Y,
+                            float lik_variance, const float* lik_variance_dev, int64_t B, int K, int Dy,
+                            int64_t stride_b, int64_t stride_k,
+                            const float* const* kl_local_host, const int32_t* kl_dims_host, int n_kl,
+                            const double* const* kl_global_host, const int32_t* kl_global_counts_host, int n_glob,
+                            double scale, int K_total, int mode_vi,
+                            float* out_lse_ms, float* out_logp, double* out_elbo, uint64_t* ticket, void* stream);
 
 /* Merge K-sharded partials after the RCCL exchange (not in the reference):
  *   ms_all [G, B, 2] gathered (max, sumexp) pairs -> logp [B], elbo [1] as above. */

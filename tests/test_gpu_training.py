@@ -18,10 +18,15 @@ def _t(a, dev):
     return torch.as_tensor(np.asarray(a, dtype=np.float32), device=dev)
 
 
-@pytest.mark.parametrize("M,R", [(8, 1), (40, 2), (100, 3), (128, 1), (200, 1)])      # M <= 128: one fused workgroup per latent GP; 200: the multi-launch path
+@pytest.mark.parametrize("M,R", [(8, 1), (40, 2), (100, 3), (128, 1), (128, 5), (200, 1), (256, 1), (512, 1)])      # M <= 128: spread / one workgroup per latent GP; beyond: the multi-launch path (the final layers of configs[3] / [4])
 def test_natgrad_step_matches_oracle(gpu_device, M, R):
     import ctypes
     from dgps_with_iwvi_amd import _abi
+    lib = _abi.lib()
+    # ABI 16: the workspace sized for R latent GPs always takes the spread route at M <= 128 (the R-independent size fell back
+    # to the one-workgroup kernel beyond R = 3 without saying so); the route that ran is readable
+    wsx = torch.empty(lib.iwvi_natgrad_ws_bytes_ex(M, R), dtype=torch.uint8, device=gpu_device)
+    assert wsx.numel() >= lib.iwvi_natgrad_ws_bytes(M) > 0
     rng = np.random.default_rng(M)
     q_mu = rng.standard_normal((M, R)).astype(np.float32)
     q_sqrt = (np.tril(rng.standard_normal((R, M, M))) * 0.1 + np.eye(M)).astype(np.float32)
@@ -35,6 +40,15 @@ def test_natgrad_step_matches_oracle(gpu_device, M, R):
     np.testing.assert_allclose(d_mu.cpu().numpy(), ref_mu, rtol=2e-5, atol=2e-6)
     np.testing.assert_allclose(d_sqrt.cpu().numpy(), ref_sqrt, rtol=2e-5, atol=2e-6)
     assert float(torch.triu(d_sqrt, 1).abs().max()) == 0.0
+    x_mu, x_sqrt = _t(q_mu, gpu_device), _t(q_sqrt, gpu_device)
+    _abi.check(lib.iwvi_natgrad_step_ex(_abi.ptr(x_mu), _abi.ptr(x_sqrt), _abi.ptr(dg_mu), _abi.ptr(dg_sqrt), M, R, 0.05,
+                                        wsx.data_ptr(), wsx.numel(), _abi.stream_ptr()))
+    assert lib.iwvi_debug_last_natgrad_route() == (2 if M <= 128 else 0)
+    np.testing.assert_allclose(x_mu.cpu().numpy(), ref_mu, rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(x_sqrt.cpu().numpy(), ref_sqrt, rtol=2e-5, atol=2e-6)
+    with pytest.raises(_abi.IwviError):                          # a workspace smaller than the R-independent minimum is refused, not overrun
+        _abi.check(lib.iwvi_natgrad_step_ex(_abi.ptr(x_mu), _abi.ptr(x_sqrt), _abi.ptr(dg_mu), _abi.ptr(dg_sqrt), M, R, 0.05,
+                                            wsx.data_ptr(), 1024, _abi.stream_ptr()))
     if M <= 128:                                                 # the multi-launch path (kept for M > 128) on the same inputs
         e_mu, e_sqrt = _t(q_mu, gpu_device), _t(q_sqrt, gpu_device)
         _abi.set_debug_option("IWVI_NATGRAD_UNFUSED", 1)         # (a route switch of the library: iwvi_debug_set_option, not the environment)
