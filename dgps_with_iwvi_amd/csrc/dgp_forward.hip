@@ -483,6 +483,81 @@ __device__ __forceinline__ float stage1_unrolled(AP Ap, const f32x4* kuf, f32x4*
     return ssq;
 }
 
+// ---- stage 1 of a layer with exactly eight 16-row blocks (iwvi_common.h: INV8): a = X k with the explicit inverse X = Lm^-1, a triangular
+// PRODUCT -- every wave owns one block row (waves w and w + 4 share a SIMD: rows (i, 7 - i), seven off-diagonal blocks per SIMD), nothing
+// is a chain of dependent column solves.  The diagonal block of a row is an fp32 product on the row's own k (in front of the barrier), the
+// blocks left of it take split-f16 operands exactly like the super-block solve's inverse part (M > 240): every row publishes s_r k as
+// [h1 x 4 | h2 x 4] in place of k, block (i, q) costs two v_mfma_f32_16x16x32_f16 per sub-tile.  Ab: the layer's stream (LDS or L2) + lane.
+// The wave's share of |a|^2 goes to slot 2 + wave of `asq` (epilogue (i) adds the eight in a fixed order).
+template <int NS, bool P16, class AP>
+__device__ __forceinline__ void stage1_inv8(AP Ab, f32x4* at, int wave, int gq, int jq, float sa, float* asq, gout1 o_a, long long t0, int nvalid, int Mp) {
+    constexpr int NSAMP = 16 * NS;
+    using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
+    const int rw = wave < 4 ? wave : 11 - wave;
+    const float s_i = 1024.0f / sa, s_r = 32.0f / (s_i * s_i);    // sa = 2^(10 - lg): s_i = 2^lg scales the packed X, |s_r k| <= 32
+    const f32x4 Dg = Ab[(size_t)rw * 64];
+    f32x4 Ti[7];
+#pragma unroll
+    for (int u = 0; u < 7; ++u) Ti[u] = Ab[(size_t)(8 + rw * (rw - 1) / 2 + (u < rw ? u : (rw > 0 ? rw - 1 : 0))) * 64];
+    f32x4 acc[NS], rs[NS];
+#pragma unroll
+    for (int t = 0; t < NS; ++t) acc[t] = at[(rw * 4 + gq) * NSAMP + 16 * t + jq];
+#pragma unroll
+    for (int t = 0; t < NS; ++t) {
+        rs[t] = acc[t] * s_r;
+        f16x4 h1, h2;
+        split_b16(rs[t], 1.0f, h1, h2);
+        A16 pk; pk.h1 = h1; pk.h2 = h2;
+        f32x4 w_;
+        __builtin_memcpy(&w_, &pk, 16);
+        at[(rw * 4 + gq) * NSAMP + 16 * t + jq] = w_;             // (this wave read its own block row of k: in place)
+        rs[t] = rs[t] * s_i;
+        acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+#pragma unroll
+        for (int t = 0; t < NS; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(Dg[s], rs[t][s], acc[t], 0, 0, 0);
+    }
+    __syncthreads();                                              // every row's s_r k published
+#pragma unroll
+    for (int q = 0; q < 7; ++q) {
+        if (q < rw) {                                             // (wave-uniform)
+            const A16 ah = as_a16(Ti[q]);
+            const f16x8 a1 = __builtin_shufflevector(ah.h1, ah.h1, 0, 1, 2, 3, 4, 5, 6, 7);
+            const f16x8 a2 = __builtin_shufflevector(ah.h2, ah.h2, 0, 1, 2, 3, 4, 5, 6, 7);
+            f32x4 b[NS];
+#pragma unroll
+            for (int t = 0; t < NS; ++t) b[t] = at[(q * 4 + gq) * NSAMP + 16 * t + jq];
+#pragma unroll
+            for (int t = 0; t < NS; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, __builtin_bit_cast(f16x8, b[t]), acc[t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < NS; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2, __builtin_bit_cast(f16x8, b[t]), acc[t], 0, 0, 0);
+        }
+    }
+    const float un = 1.0f / (s_r * s_i);
+    __syncthreads();                                              // every row has read the published k: its rows of the tile may take a
+    float ssq[NS];
+#pragma unroll
+    for (int t = 0; t < NS; ++t) {
+        acc[t] = acc[t] * un;
+        const int tcol = 16 * t + jq;
+        if constexpr (P16) {                                      // the two f16 planes of 2^ea a (lane (gq, jq): 8 bytes of each vector)
+            f16x4 h1, h2;
+            split_b16(acc[t], sa, h1, h2);
+            char* pl = reinterpret_cast<char*>(at) + ((size_t)((4 * rw + 2 * (gq >> 1)) * NSAMP + tcol)) * 16 + 8 * (gq & 1);
+            *reinterpret_cast<f16x4*>(pl) = h1; *reinterpret_cast<f16x4*>(pl + NSAMP * 16) = h2;
+        } else at[(rw * 4 + gq) * NSAMP + tcol] = acc[t];
+        ssq[t] = colsumsq4(acc[t]);
+        if (o_a && tcol < nvalid) *((gout4)(o_a + (size_t)(t0 + tcol) * Mp + 16 * rw + 4 * gq)) = acc[t];
+    }
+#pragma unroll
+    for (int t = 0; t < NS; ++t) {
+        const float sq = xgroup_sum_mfma(ssq[t]);
+        if (gq == 0) asq[(2 + wave) * NSAMP + 16 * t + jq] = sq;
+    }
+}
+
 // prologue copy list, entries [c_lo, c_hi): one entry per wave at a time, all DMA loads in flight together
 // The compiler orders every LDS access behind every pending LDS-DMA (an `s_waitcnt vmcnt(0)` in front of each ds_read / ds_write that follows a
 // global_load_lds): an entry read from the LDS table between two copies makes the second wait until the first has landed.  So: this wave's
@@ -1648,6 +1723,24 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
                     for (int w = 0; w < FW_WAVES; ++w) sq += asq[(2 + w) * NSAMP + tid];
                     asq[tid] = sq; asq[NSAMP + tid] = 0.f;
                 }
+            } else
+            if ((SHP && INV8) || inv8_layer(nbk)) {
+                // ---- eight blocks (the headline's M = 128): a = X k with the explicit inverse, one block row per wave (stage1_inv8)
+                {
+                    f32x4* uz = reinterpret_cast<f32x4*>(usq);      // every |u|^2 slot cleared first (stage 2 fills only some)
+                    for (int i = tid; i < (FW_WAVES * R * NSAMP) / 4; i += FW_THREADS) uz[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+                if constexpr (S16 && !BIG) {
+                    if (s2_mw0 == wave) {                         // the q_mu^T slabs of stage 2, requested now (their first read of an evaluation comes from HBM)
+                        gptr4 Pq = (gptr4)G.QmuP + lane;
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) { Qpre[u][0] = Pq[(size_t)u * 128]; Qpre[u][1] = Pq[(size_t)u * 128 + 64]; }
+                        q_pre = true;
+                    }
+                }
+                const float sa8 = cst[IWVI_CST_SA];
+                if (SHP || G.ls_off >= 0) stage1_inv8<NS, S16>(reinterpret_cast<const f32x4*>(sm + G.ls_off) + lane, at, wave, gq, jq, sa8, asq, o_a, t0, nvalid, G.Mp);
+                else stage1_inv8<NS, S16>((gptr4)G.LsP + lane, at, wave, gq, jq, sa8, asq, o_a, t0, nvalid, G.Mp);
             } else {
             if (wave >= NS) {
                 // the waves without a sub-tile of their own clear every |u|^2 slot first (stage 2 fills only some)
@@ -1672,7 +1765,7 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
                 const gptr4 Ap = (gptr4)G.LsP + lane;
                 const gout1 arow = (o_a && tcol < nvalid) ? o_a + (size_t)(t0 + tcol) * G.Mp : (gout1)nullptr;
                 float ssq = 0.f;
-                if constexpr (SHP) {
+                if constexpr (SHP && !INV8) {
                     ssq = stage1_unrolled<NS, 8, true, S16>(reinterpret_cast<const f32x4*>(sm + G.ls_off) + lane, kuf, at, tcol, gq, arow, st1_sb);
                 } else
                 if (G.ls_off >= 0 && nbk <= 8) {
@@ -2095,7 +2188,13 @@ __global__ __launch_bounds__(FW_THREADS) void k_dgp_forward(const FwArgs gk) {
                 for (int w = 0; w < FW_WAVES; ++w) u2 += usq[(w * R + r) * NSAMP + j];   // fixed order: bit-reproducible
                 const float mu = meanp[r * NSAMP + j];
                 // (float64 route: asq[j] already holds sigma^2 - |a|^2, differenced in float64)
-                const float v = (F64 && f64_l) ? fmaxf(asq[j] + u2, 0.f) : fmaxf(g_variance - (asq[j] + asq[NSAMP + j]) + u2, 0.f);
+                float a2;
+                if ((SHP && INV8) || inv8_layer(nbk)) {              // stage1_inv8: one share of |a|^2 per wave, added in a fixed order
+                    a2 = 0.f;
+#pragma unroll
+                    for (int w = 0; w < FW_WAVES; ++w) a2 += asq[(2 + w) * NSAMP + j];
+                } else a2 = asq[j] + asq[NSAMP + j];
+                const float v = (F64 && f64_l) ? fmaxf(asq[j] + u2, 0.f) : fmaxf(g_variance - a2 + u2, 0.f);
                 const float z = (j < nvalid) ? zl[r * NSAMP + j] : 0.f;
                 if (o_noise && j < nvalid) o_noise[(t0 + j) * R + r] = z;
                 const float gs = fmaf(z, sqrtf(v), mu);
@@ -2585,7 +2684,7 @@ static size_t fw_plan_lds(FwArgs& a, int nsamp, int maxR, int maxP, bool stage_z
     l.pidx = o; o += nsamp;
     {
         bool big = false;                                   // a layer with M > 128: one |a|^2 slot per wave besides the two
-        for (int i = 0; i < a.h.n_layers; ++i) if (a.L[i].type == IWVI_LAYER_GP && a.L[i].gp.nbk >= FW_SB_MIN_NBK) big = true;
+        for (int i = 0; i < a.h.n_layers; ++i) if (a.L[i].type == IWVI_LAYER_GP && (a.L[i].gp.nbk >= FW_SB_MIN_NBK || inv8_layer(a.L[i].gp.nbk))) big = true;
         l.asq = o; o += (big ? 2 + FW_WAVES : 2) * nsamp;
     }
     l.meanp = o; o += maxR * nsamp;

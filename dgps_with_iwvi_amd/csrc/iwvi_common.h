@@ -31,6 +31,23 @@ constexpr int IWVI_CST_SA = 65, IWVI_CST_FMEAN = 66, IWVI_CST_FR = 72;   // spli
 // units of U = 2^(2 est), sigma 2^est -> 2^7.  [U] = U (1 when the layer's solve is fp32): the Gram tile is written times U and the LsP
 // stream's Dinv blocks are packed times 1/U;  [SB] = 2^est: a_j -> the B operand of the updates, whose A blocks are 2^est (-L) in two halves
 constexpr int IWVI_CST_U = 67, IWVI_CST_SB = 68;
+// Round 6, layers of EXACTLY eight 16-row blocks (112 < M <= 128: the headline's M = 128): stage 1 is a triangular PRODUCT with the explicit
+// inverse X = Lm^-1 instead of a blocked substitution -- a = X k, row-block i on wave (i < 4 ? i : 11 - i), no dependent chain of eight
+// column solves on one wave (the substitution kept five waves busy, two of them on one SIMD, and three idle: 2.6-3.2 us per layer at the
+// headline shape against ~1.3).  The layer kernel is bound by such latency chains, not by its MFMA rate (scripts/ns_scaling_headline.py:
+// a workgroup of 16 samples takes 27.4 us, one of 80 takes 29.9).  LsP then holds, 1 KiB each: blocks 0-7 the diagonal blocks X(i, i) in
+// fp32 A-fragment order; blocks 8 + i (i - 1) / 2 + q the blocks X(i, q), q < i, as [h1 x 4 | h2 x 4] of 2^lg X per lane (lg = ceil(log2
+// sigma): exactly the form of the super-block solve's inverse part at M > 240, csrc/precompute.hip: k_pack_ls16).  [U] = [SB] = 1,
+// [SA] = 2^(10 - lg).  The inverse is formed in float64 beside the factorisation (csrc/precompute_dev.h: role_factor).
+// MEASURED AND NOT THE DEFAULT (round 6; profiles/r06j_inv8_stamp_phases.txt, r06k_inv8_precompute.txt, LABNOTES.md): parity-green (260 GPU
+// tests), but stage 1 takes 6100-6700 clocks on every wave against 3900 / 6300 (single / doubled SIMD) of the substitution -- the splits of
+// k and a, the published tile's LDS round trips and a 7-block row on one wave cost what the chain did -- and the factorisation with the
+// inverse formed beside it 26.9 us against 20.0.  Build with -DIWVI_INV8=1 to reproduce.
+#ifndef IWVI_INV8
+#define IWVI_INV8 0
+#endif
+constexpr bool INV8 = IWVI_INV8 != 0;
+__host__ __device__ static inline bool inv8_layer(int nbk) { return INV8 && nbk == 8; }
 
 // triangular block storage, row-block major:
 //   solve stream LsP (column-block major): column bj = [Lm(bj,bj)^-1, -Lm(bj+1,bj), .., -Lm(nbk-1,bj)],

@@ -229,6 +229,16 @@ __device__ __forceinline__ void blk_mma(f64x4& acc, const double* A, const doubl
         acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
     }
 }
+// acc(16x16) += sign * A^T * B (A read transposed): X(r, j) = -(L_rr^-T)^T S_rj of the progressive inverse (chol_blocks)
+__device__ __forceinline__ void blk_mma_tn(f64x4& acc, const double* A, const double* B, int lane, double sign) {
+    const int r = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        const double a = sign * A[(4 * kk + g) * BLD + r];
+        const double b = B[(4 * kk + g) * BLD + r];
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+    }
+}
 __device__ __forceinline__ f64x4 blk_load(const double* C, int lane) {
     const int c = lane & 15, g = lane >> 4;
     f64x4 v;
@@ -254,9 +264,16 @@ __device__ __forceinline__ void blk_store(double* C, const f64x4& v, int lane) {
 //   step p, B  one wave per block row i > p: L(i,p) = A(i,p) L_pp^-T for the rows beyond the pass's window, then
 //              C(i,p+1) -= L(i,p) L(p+1,p)^T  -- after which column p+1 is ready for its diagonal pass.
 // Two barriers per step; no trailing update ever sits on the critical path.
-template <class GEN, class POST, class TAIL>
+// PINV (round 6, layers of eight blocks whose factor itself is not asked for; iwvi_common.h: INV8): X = L^-1 is formed ROW BY ROW beside the
+// factorisation and written over the rows of L the factorisation no longer reads (row r's last use is the catch-up of column r, in
+// step r - 1):   step r, A   the workers also form S_rj = sum_{k = j .. r-1} L(r, k) X(k, j), j < r  (tbuf[j]; X(k, k) = L_kk^-1 = xT_k^T)
+//                step r, B   waves m .. m + r - 1: X(r, j) = -L_rr^-1 S_rj -> blk(r, j)        (beside the updates of column r + 1)
+//                step r + 1, A   the workers pack row r of X (pinv_pack: the layer kernel's stage-1 operand stream)
+// Only the last row is left behind the last pass: seven products, one barrier, eight blocks to pack (~0.7 us) -- the three doubling
+// steps of invert_blocks on the finished factor were 4 us of this one CU.
+template <bool PINV = false, class GEN, class POST, class TAIL, class PPACK = int>
 __device__ __forceinline__ void chol_blocks(double* blk, int nbk, double* rinv, double* xT, int tid, int nthreads, GEN gen, POST post, TAIL tail,
-                                            unsigned long long* stamps = nullptr, int stamp_p = 1) {
+                                            unsigned long long* stamps = nullptr, int stamp_p = 1, double* tbuf = nullptr, PPACK pinv_pack = PPACK()) {
     const int lane = tid & 63, wave = tid >> 6, nw = nthreads >> 6;
     gen(0, nbk < 2 ? 1 : 2, wave, nw);
     __syncthreads();
@@ -276,6 +293,14 @@ __device__ __forceinline__ void chol_blocks(double* blk, int nbk, double* rinv, 
             blk_mma<true>(acc, A, blk + boff(p + 1, p), lane, -1.0);
             blk_store(C, acc, lane);
         }
+        if constexpr (PINV) {                                // row p of X, by the waves the updates leave idle (m + p <= 7 < nw)
+            const int j = wave - m;
+            if (j >= 0 && j < p) {
+                f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+                blk_mma_tn(acc, xT + (size_t)p * BLK, tbuf + (size_t)j * BLK, lane, -1.0);
+                blk_store(blk + boff(p, j), acc, lane);
+            }
+        }
     };
     // Round 6: the column loop exists TWICE, once for the factoring wave and once for everybody else (same barriers, same arithmetic, same
     // order: bit-identical).  In one loop, everything the worker side keeps live across a step -- the Gram generation's operands, the packing's
@@ -294,7 +319,7 @@ __device__ __forceinline__ void chol_blocks(double* blk, int nbk, double* rinv, 
             __syncthreads();
             if (p == stamp_p) PRE_STAMP(12);
             step_b(p, m, win);
-            if (m > 0) __syncthreads();
+            if (m > 0 || PINV) __syncthreads();
             if (p == stamp_p) PRE_STAMP(13);
         }
     } else {
@@ -324,15 +349,29 @@ __device__ __forceinline__ void chol_blocks(double* blk, int nbk, double* rinv, 
                     const int ng = (p + 2 < nbk) ? nbk - p - 2 : 0;
                     const int rel = ng < nwo ? wg - ng : w, nrel = ng < nwo ? nwo - ng : nwo;
                     if (rel >= 0) for (int it = rel * 64 + lane; it < (nbk - p + 1) * 64; it += nrel * 64) post(p - 1, it >> 6, it & 63);
+                    if constexpr (PINV) {
+                        // row p - 1 of X is complete: pack it (p blocks), and form this row's sums S_pj, the longest (j = 0: p products) first,
+                        // on the workers counted from the END of the rotation (the generating waves are the busy ones)
+                        if (rel >= 0) for (int it = rel * 64 + lane; it < p * 64; it += nrel * 64) pinv_pack(p - 1, it >> 6, it & 63);
+                        for (int j = nwo - 1 - wg; j < p; j += nwo) {
+                            f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+                            blk_mma<true>(acc, blk + boff(p, j), xT + (size_t)j * BLK, lane, 1.0);                  // L(p, j) X(j, j),  X(j, j) = xT_j^T
+                            for (int k = j + 1; k < p; ++k) blk_mma<false>(acc, blk + boff(p, k), blk + boff(k, j), lane, 1.0);   // + L(p, k) X(k, j)
+                            blk_store(tbuf + (size_t)j * BLK, acc, lane);
+                        }
+                    }
                 }
                 if (p == nbk - 1) tail(w * 64 + lane, nwo * 64);     // work nobody waits for, beside the last (otherwise idle) pass
             }
             __syncthreads();
             step_b(p, m, win);
-            if (m > 0) __syncthreads();
+            if (m > 0 || PINV) __syncthreads();
         }
     }
     if (tid < 64) post(nbk - 1, 0, tid);                 // the last column: its diagonal block
+    if constexpr (PINV) {                                // the last row of X: one block per wave
+        for (int it = tid; it < nbk * 64; it += nthreads) pinv_pack(nbk - 1, it >> 6, it & 63);
+    }
     __syncthreads();
 }
 struct NoGen { __device__ void operator()(int, int, int, int) const {} };
@@ -430,7 +469,8 @@ __device__ __forceinline__ void role_factor(const PreLayer& Lin, int stop_after,
     }
     if (tid < 32) st_pub(L.cst + tid, (tid < D) ? (float)(1.0 / (double)L.ls[tid]) : 0.f);
     const int lg_sigma = (int)ceilf(0.5f * log2f(fmaxf(L.variance, 1e-30f)));
-    const bool st1_16 = (L.nbk <= 8) && ((L.nbk & 1) == 0);  // this layer's solve takes split-f16 off-diagonal updates (iwvi_common.h: IWVI_CST_U)
+    const bool inv8 = inv8_layer(L.nbk);                     // stage 1 as a product with the explicit inverse (iwvi_common.h: INV8)
+    const bool st1_16 = (L.nbk <= 8) && ((L.nbk & 1) == 0) && !inv8;  // this layer's solve takes split-f16 off-diagonal updates (iwvi_common.h: IWVI_CST_U)
     const int est = st1_16 ? 7 - lg_sigma : 0;
     const float st1_iu = ldexpf(1.f, -2 * est), st1_sc = ldexpf(1.f, est);
     if (tid == 32) st_pub(L.cst + IWVI_CST_SA, ldexpf(1.f, (st1_16 ? 7 : 10) - lg_sigma));   // 2^ea: the split-f16 scale of a = Lm^-1 k (|a| <= sigma); = 2^est when stage 1 writes the planes itself
@@ -557,6 +597,7 @@ __device__ __forceinline__ void role_factor(const PreLayer& Lin, int stop_after,
     // post-processing of a finished block column bj, run by the waves that do not factor: the packed float32 solve
     // stream of the column (its first block is the inverse of the diagonal block, from the factoring wave), column-block major: [L(bj,bj)^-1, -L(bj+1,bj), .., -L(nbk-1,bj)]; identity padding -> 0
     auto post = [&](int bj, int b, int ln) {
+        if (inv8) return;                                    // (the inverse route packs X = Lm^-1 behind the factorisation instead)
         // one item = one lane's four consecutive floats of a packed block (one 16-byte store): lane (g, ii) holds
         // G[ii][4g .. 4g+3]; block 0 of the column is the diagonal block's inverse, then the blocks below it
         float4* dst = reinterpret_cast<float4*>(L.LsP + (size_t)tri_upper_off(nbk, bj) * BLK16);
@@ -598,7 +639,35 @@ __device__ __forceinline__ void role_factor(const PreLayer& Lin, int stop_after,
             st_pub4(dst + it, o);
         }
     };
-    chol_blocks(blk, nbk, rinv, dinv, tid, nthreads, gen, post, tail, stamps, stamp_p);
+    // the layer kernel's stage-1 stream of the inverse route (iwvi_common.h: INV8), row r of X = Lm^-1: item b < r = block (r, b) as split-f16
+    // pairs of 2^lg X from the row's place in the block storage, item b == r = the diagonal block X(r, r) = xT_r^T in fp32
+    const bool want_L = (L.flags & (IWVI_GP_WANT_DENSE | IWVI_GP_WANT_LM)) != 0;
+    const bool pinv = inv8 && IN_LDS && !want_L;             // (the factor is asked for too: invert_blocks on the finished factor, below)
+    const float inv_si = ldexpf(1.f, lg_sigma);
+    auto pinv_pack = [&](int r, int b, int ln) {
+        const int ii = ln & 15, k0 = 4 * (ln >> 4);
+        float4* dst = reinterpret_cast<float4*>(L.LsP);
+        const bool full = (M == Mp);
+        float v[4];
+#pragma unroll
+        for (int sgm = 0; sgm < 4; ++sgm) {
+            const int kk = k0 + sgm;
+            const int i = 16 * r + ii, k = 16 * b + kk;
+            float f = (b == r) ? ((kk <= ii) ? (float)dinv[(size_t)r * BLK + kk * BLD + ii] : 0.f) : (float)blk[boff(r, b) + ii * BLD + kk];
+            if (!full && (i >= M || k >= M)) f = (i == k) ? 1.f : 0.f;            // padded rows solve to 0 against k = 0
+            v[sgm] = f;
+        }
+        if (b == r) { st_pub4(dst + (size_t)r * 64 + ln, make_float4(v[0], v[1], v[2], v[3])); return; }
+        pk_f16x8 h;
+#pragma unroll
+        for (int sgm = 0; sgm < 4; ++sgm) {
+            const float x = fminf(fmaxf(v[sgm] * inv_si, -65504.f), 65504.f);
+            const _Float16 hh = (_Float16)x; h[sgm] = hh; h[4 + sgm] = (_Float16)(x - (float)hh);
+        }
+        st_pub4(dst + (size_t)(8 + r * (r - 1) / 2 + b) * 64 + ln, as_f4(h));
+    };
+    if (pinv) chol_blocks<true>(blk, nbk, rinv, dinv, tid, nthreads, gen, post, tail, stamps, stamp_p, tbuf, pinv_pack);
+    else chol_blocks(blk, nbk, rinv, dinv, tid, nthreads, gen, post, tail, stamps, stamp_p);
     PRE_STAMP(3);
     if (stop_after == 3 || stop_after > 30) return;
     PRE_STAMP(4);
@@ -608,6 +677,40 @@ __device__ __forceinline__ void role_factor(const PreLayer& Lin, int stop_after,
         for (int idx = tid; idx < Mp * Mp; idx += nthreads) {
             const int i = idx / Mp, k = idx - i * Mp;
             L.Lm[idx] = (k <= i) ? blk_get(blk, i, k) : 0.0;
+        }
+        __syncthreads();
+    }
+    if (inv8 && !pinv) {
+        // X = Lm^-1 (float64, three doubling steps on the LDS-resident factor), packed as the layer kernel's stage-1 operand stream
+        // (iwvi_common.h: INV8): 8 diagonal blocks in fp32, the 28 blocks left of the diagonal as split-f16 pairs scaled by 2^lg
+        invert_blocks(blk, dinv, tbuf, rinv, nbk, tid, nthreads, 1, 8);
+        float4* dst = reinterpret_cast<float4*>(L.LsP);
+        const bool full = (M == Mp);
+        const float si = ldexpf(1.f, lg_sigma);
+        for (int it = tid; it < 36 * 64; it += nthreads) {
+            const int b = it >> 6, ln = it & 63, ii = ln & 15, k0 = 4 * (ln >> 4);
+            int bi, bk;
+            if (b < 8) { bi = bk = b; }
+            else { const int q = b - 8; int w = 1; while (w * (w + 1) / 2 <= q) ++w; bi = w; bk = q - w * (w - 1) / 2; }
+            float v[4];
+#pragma unroll
+            for (int sgm = 0; sgm < 4; ++sgm) {
+                const int i = 16 * bi + ii, k = 16 * bk + k0 + sgm;
+                float f = (k <= i) ? (float)inv_get(blk, dinv, i, k) : 0.f;
+                if (!full && (i >= M || k >= M)) f = (i == k) ? 1.f : 0.f;        // padded rows solve to 0 against k = 0
+                v[sgm] = f;
+            }
+            float4 o = make_float4(v[0], v[1], v[2], v[3]);
+            if (b >= 8) {
+                pk_f16x8 h;
+#pragma unroll
+                for (int sgm = 0; sgm < 4; ++sgm) {
+                    const float x = fminf(fmaxf(v[sgm] * si, -65504.f), 65504.f);
+                    const _Float16 hh = (_Float16)x; h[sgm] = hh; h[4 + sgm] = (_Float16)(x - (float)hh);
+                }
+                o = as_f4(h);
+            }
+            st_pub4(dst + it, o);
         }
         __syncthreads();
     }
@@ -652,7 +755,7 @@ __device__ __forceinline__ void role_factor(const PreLayer& Lin, int stop_after,
     }
     if (dense) {
         if (nbk >= 16) invert_blocks(blk, dinv, tbuf, rinv, nbk, tid, nthreads, 8);     // the remaining doubling steps
-        else invert_blocks(blk, dinv, tbuf, rinv, nbk, tid, nthreads);
+        else if (!inv8) invert_blocks(blk, dinv, tbuf, rinv, nbk, tid, nthreads);   // (inv8: the blocks already hold the whole inverse)
         for (int idx = tid; idx < Mp * Mp; idx += nthreads) {
             const int i = idx / Mp, k = idx - i * Mp;
             L.Linv[idx] = (k <= i) ? inv_get(blk, dinv, i, k) : 0.0;
@@ -752,7 +855,7 @@ __device__ __forceinline__ void role_pack_body(const PreLayer& L, int r, double*
     // ---- the split-f16 image of L_r^T (and, role 1, of q_mu^T) with its power-of-two scale ----------------------------------
     if (nbk & 1) return;
     const float var = L.variance_dev ? *L.variance_dev : L.variance;
-    const int ea = ((L.nbk <= 8 && (L.nbk & 1) == 0) ? 7 : 10) - (int)ceilf(0.5f * log2f(fmaxf(var, 1e-30f)));   // |a| <= sigma  ->  |a| 2^ea <= 2^10 (2^7 = 2^est where stage 1 writes the planes: role_factor)
+    const int ea = ((L.nbk <= 8 && (L.nbk & 1) == 0 && !inv8_layer(L.nbk)) ? 7 : 10) - (int)ceilf(0.5f * log2f(fmaxf(var, 1e-30f)));   // |a| <= sigma  ->  |a| 2^ea <= 2^10 (2^7 = 2^est where stage 1 writes the planes: role_factor)
     double mx = 0.0;                                             // (a wave per row, lanes along it: no division per element; max is order-free)
     for (int k = threadIdx.x >> 6; k < M; k += (int)(blockDim.x >> 6))
         for (int i = threadIdx.x & 63; i <= k; i += 64) mx = fmax(mx, fabs((double)q[(size_t)k * M + i]));
