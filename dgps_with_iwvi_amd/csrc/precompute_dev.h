@@ -283,12 +283,30 @@ __device__ __forceinline__ void chol_blocks(double* blk, int nbk, double* rinv, 
         for (int b = wave; b < m; b += nw) {
             const int bi = p + 1 + b;
             double* A = blk + boff(bi, p);
-            if (b >= win) {
-                f64x4 acc = {0.0, 0.0, 0.0, 0.0};
-                blk_mma<false>(acc, A, xT + (size_t)p * BLK, lane, 1.0);
-                blk_store(A, acc, lane);
-            }
             double* C = blk + boff(bi, p + 1);
+            if (b >= win) {
+                // Round 6: L(bi, p) = A L_pp^-T is formed TRANSPOSED -- T = L_pp^-1 A^T, the same products and sums -- because the
+                // accumulator of lane (g, c) then holds T[g + 4 e][c] = L(bi, p)[c][4 e + g], e = 0 .. 3: exactly what the lane feeds as
+                // the A operand of the update product behind it (blk_mma: A[r][4 kk + g], r = c, kk = e).  The block goes from one matrix
+                // instruction into the next in registers; before, it was stored to LDS and read back (same wave, in order: a store and a
+                // load latency on the step's chain, ~0.15 us of every step that has rows beyond the window).  Its store (later catch-ups
+                // read it) follows the update's instructions.
+                const int r = lane & 15, g = lane >> 4;
+                const double* xt = xT + (size_t)p * BLK;
+                f64x4 t = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk)
+                    t = __builtin_amdgcn_mfma_f64_16x16x4f64(xt[(4 * kk + g) * BLD + r], A[r * BLD + 4 * kk + g], t, 0, 0, 0);
+                f64x4 acc = blk_load(C, lane);
+                const double* Bp = blk + boff(p + 1, p);
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk)
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-t[kk], Bp[r * BLD + 4 * kk + g], acc, 0, 0, 0);
+                blk_store(C, acc, lane);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) A[r * BLD + 4 * e + g] = t[e];
+                continue;
+            }
             f64x4 acc = blk_load(C, lane);
             blk_mma<true>(acc, A, blk + boff(p + 1, p), lane, -1.0);
             blk_store(C, acc, lane);
