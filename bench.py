@@ -178,6 +178,38 @@ def training_leg(model, samples, iters=20, flops_forward=None):
         return {"error": "%s: %s" % (type(e).__name__, e)}
 
 
+def sharded_training_leg(model, shard, world, K_total, dist, iters=10):
+    """Informational, all ranks (world > 1): one training step of the sharded job -- NatGrad op + Adam op, ONE exchange per op's
+    evaluation (what a training loop pays: the equivalent of --xch-every 1) -- eagerly and as hipGraph segments with the collectives
+    between them (training.Trainer(use_graph=True): N-shard 3 segments around 2 gradient all-reduces, K-shard 5 around 2 all-gathers of
+    the [B, 2] pairs + 2 all-reduces).  Max over ranks of the per-step wall time between barriers.  Changes the model's parameters: runs last."""
+    try:
+        from dgps_with_iwvi_amd.training import Trainer
+        out = {}
+        for name, ug in (("train_step_eager_ms", False), ("train_step_ms", True)):
+            tr = Trainer(model, shard=shard, use_graph=ug, check_finite=False, K_total=K_total if shard == "k" else None)
+            for _ in range(3):
+                tr.step()
+            torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(iters):
+                tr.step()
+            torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+            t = torch.tensor([(time.perf_counter() - t0) / iters * 1e3], dtype=torch.float64, device=model.X.device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            out[name] = float(t.item())
+            if ug:
+                g = tr._graphs["step"][1]
+                out["graph_segments"], out["collectives_per_step"] = int(g.n_graphs), int(g.n_collectives)
+        out["note"] = ("training.Trainer(shard=%r).step on %d ranks: every op's evaluation exchanges once (xch_every = 1); the graph form replays "
+                       "hipGraph segments with the collectives issued between them" % (shard, world))
+        return out
+    except Exception as e:
+        import traceback
+        traceback.print_exc()
+        return {"error": "%s: %s" % (type(e).__name__, e)}
+
+
 def cpu_baseline(spec, seconds=12.0, dtype=torch.float64):
     """The reference-equivalent CPU path (oracle/ref_torch_cpu.py; float64 like the reference, and float32 = the
     precision the device path computes in) timed on
@@ -938,6 +970,9 @@ def main():
             pmc["pmc_profile_is_of_these_sources"] = (tj.get("csrc_sha256") == csrc_hash()) if tj.get("csrc_sha256") else None
     except Exception:
         pass
+    sharded_train = None
+    if world > 1 and not args.no_train_leg and not args.rendezvous_only:
+        sharded_train = sharded_training_leg(model, args.shard, world, K_job, dist)      # (every rank takes part in its collectives)
     if rank == 0:
         total = float(B) * (K_job if args.shard == "k" else K * world) * args.steps      # the job's samples per step x steps
         res = {
@@ -1000,6 +1035,8 @@ def main():
             res["gpu_over_cpu"] = res["value"] / res["cpu_baseline"]["value"]
         if world == 1 and not args.no_train_leg:
             res["training_step"] = training_leg(model, B * K, flops_forward=tot_flops * B * K)
+        if sharded_train is not None:
+            res["training_step"] = sharded_train
         print(json.dumps(res))
     if dist is not None:
         dist.destroy_process_group()

@@ -84,7 +84,7 @@ class _SegmentedGraph:
 class Trainer:
     def __init__(self, model, lr=5e-3, gamma=1e-2, lr_decay=0.98, gamma_decay=0.98, fix_linear=True,
                  beta1=0.9, beta2=0.999, epsilon=1e-8, group=None, shard_weight=None, shard="n", num_data_total=None,
-                 use_graph=False, check_finite=True, check_every=100, autotune_f64=True):
+                 use_graph=False, check_finite=True, check_every=100, autotune_f64=True, K_total=None):
         """``group`` / ``shard_weight``: data-parallel training over the ranks of a torch.distributed group (each rank's
         model holds its own minibatch rows, N-shard): gradients are merged by ``sharding.allreduce_gradients`` with
         weight B_rank / B_job (default: from the all-reduced local batch sizes) before either update, so every rank
@@ -111,6 +111,7 @@ class Trainer:
         are re-captured there anyway), so that a layer whose K_uu becomes ill-conditioned DURING training (lengthscales grow, inducing
         inputs cluster) leaves the float32 solve; captured graphs are dropped whenever a layer's route moves (``model.route_key()``)."""
         self.model = model
+        self.K_total = None if K_total is None else int(K_total)   # K-shard with an uneven split of the job's samples (default: num_samples x ranks)
         self.autotune = bool(autotune_f64)
         self._tuned_epoch = None
         self.route_reports = []                                # [(global step, autotune_f64's report)]
@@ -214,7 +215,7 @@ class Trainer:
         if advance:
             self.model.next_minibatch()                          # gpflow.Minibatch: a new batch per session.run (models.py:21-26)
         if self.shard == "k":
-            return k_shard_gradients(self.model, zs, group=self.group, wrt=wrt)
+            return k_shard_gradients(self.model, zs, K_total=self.K_total, group=self.group, wrt=wrt)
         elbo, g = iw_elbo_and_gradients(self.model, zs, wrt=wrt)
         g["__elbo__"] = elbo.reshape(1)                          # rides in the same bucket: the job's bound
         g = allreduce_gradients(g, weight=self.shard_weight, group=self.group)

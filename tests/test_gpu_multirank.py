@@ -23,14 +23,14 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _run_bench(world, shard, extra=(), backend="gloo", timeout=600):
+def _run_bench(world, shard, extra=(), backend="gloo", timeout=600, train_leg=False):
     port = _free_port()
     procs = []
     for rank in range(world):
         env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), IWVI_BENCH_BACKEND=backend, HSA_ENABLE_IPC_MODE_LEGACY="0")
         cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "8", "--warmup", "2", "--config", "1",
-               "--shard", shard, "--check", "--no-cpu-baseline", "--no-train-leg", *extra]
+               "--shard", shard, "--check", "--no-cpu-baseline", *(() if train_leg else ("--no-train-leg",)), *extra]
         procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=ROOT))
     outs = []
     for p in procs:
@@ -276,3 +276,14 @@ def test_sharded_training_step_as_graph_segments(gpu_device, tmp_path, shard):
             assert np.array_equal(r0["graph." + n], r1["graph." + n]), (shard, n)       # the ranks apply the same update
     print("sharded step, 2 gloo ranks on one GPU (%s-shard): eager %.3f ms, graph segments %.3f ms" % (shard, float(r0["eager.ms"]), float(r0["graph.ms"])))
     assert float(r0["graph.ms"]) <= float(r0["eager.ms"]) * 1.05          # never slower than the eager step it replaces
+
+
+@pytest.mark.parametrize("shard", ["n", "k"])
+def test_bench_two_ranks_report_the_sharded_training_step(gpu_device, shard):
+    """``bench.py --gpus N`` reports ``training_step`` of the sharded job -- one exchange per op's evaluation -- eagerly and
+    as hipGraph segments; the graph form is never slower than the eager step it replaces."""
+    res = _run_bench(2, shard, train_leg=True, timeout=900)
+    t = res["training_step"]
+    assert "error" not in t, t
+    assert t["collectives_per_step"] == (2 if shard == "n" else 4) and t["graph_segments"] == t["collectives_per_step"] + 1
+    assert 0.0 < t["train_step_ms"] <= t["train_step_eager_ms"] * 1.05, t
