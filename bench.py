@@ -567,6 +567,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-train-leg", action="store_true", help="skip the (informational) training-step timing")
+    ap.add_argument("--sharded-train-leg", action="store_true",
+                    help="with more than one rank: also time the sharded training step (eager and as hipGraph segments; informational, after the "
+                         "timed region).  Opt-in: its collectives have only ever met gloo ranks on one GPU, and a scaling run must not depend on them")
     ap.add_argument("--check", action="store_true",
                     help="after the timed region: one evaluation on INJECTED job-wide noise through the very same sharded path "
                          "(graph-free), and on rank 0 the unsharded evaluation of the whole job on the same noise; both go into the JSON")
@@ -971,7 +974,7 @@ def main():
     except Exception:
         pass
     sharded_train = None
-    if world > 1 and not args.no_train_leg and not args.rendezvous_only:
+    if world > 1 and args.sharded_train_leg and not args.rendezvous_only:
         sharded_train = sharded_training_leg(model, args.shard, world, K_job, dist)      # (every rank takes part in its collectives)
     if rank == 0:
         total = float(B) * (K_job if args.shard == "k" else K * world) * args.steps      # the job's samples per step x steps

@@ -30,7 +30,7 @@ def _run_bench(world, shard, extra=(), backend="gloo", timeout=600, train_leg=Fa
         env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), IWVI_BENCH_BACKEND=backend, HSA_ENABLE_IPC_MODE_LEGACY="0")
         cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "8", "--warmup", "2", "--config", "1",
-               "--shard", shard, "--check", "--no-cpu-baseline", *(() if train_leg else ("--no-train-leg",)), *extra]
+               "--shard", shard, "--check", "--no-cpu-baseline", "--no-train-leg", *(("--sharded-train-leg",) if train_leg else ()), *extra]
         procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=ROOT))
     outs = []
     for p in procs:
