@@ -25,12 +25,18 @@ from . import _abi
 # While ``training.Trainer`` records a sharded step as hipGraph SEGMENTS, every collective of the step is a cut between two segments
 # (``run_collective``): a collective is host-driven for gloo and library-driven for RCCL, neither belongs inside a captured graph here.
 _RECORDER = None
+# test knob: issue the collectives of a training step even on a ONE-rank group (a 1-rank RCCL communicator is the only real "nccl" backend a
+# single-GPU box offers: tests/test_gpu_multirank.py runs the segmented step against it)
+_FORCE_ONE_RANK_COLLECTIVES = False
 
 
-def run_collective(fn):
+def run_collective(fn, group=None):
     """A collective of a training step (``fn()`` issues it on the current stream, on tensors that live as long as the step's graphs do):
-    run now -- and, while a segmented capture is recording, remembered as the cut between two graph segments (replayed in place)."""
-    if _RECORDER is None:
+    run now.  While ``training.Trainer`` records a step: an RCCL ("nccl") collective is CAPTURED like any other stream work -- the step stays
+    one graph -- (it is capturable, and issued between two captures its work object would be polled by the process group's watchdog thread
+    while the next capture is open: hipErrorStreamCaptureUnsupported, seen on a 1-rank communicator); a host-driven one (gloo: the CPU tests
+    and one-GPU plumbing runs) is remembered as the cut between two graph segments and replayed in place."""
+    if _RECORDER is None or dist.get_backend(group) == "nccl":
         fn()
     else:
         _RECORDER.cut(fn)
@@ -218,7 +224,7 @@ def allreduce_gradients(grads, weight=None, group=None):
     gradient is the B_r / B weighted mean (the KL terms then count once): ONE all-reduce of one flat bucket
     (parameters are <= R*M^2 floats per layer, a few MiB in all -- a single ring pass over xGMI), then views back.
     ``weight`` = B_r / B (default 1 / world: equal local batches).  Returns the same dict, reduced in place."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size(group) == 1 and not _FORCE_ONE_RANK_COLLECTIVES):
         return grads
     world = dist.get_world_size(group)
     w = 1.0 / world if weight is None else float(weight)
@@ -226,7 +232,7 @@ def allreduce_gradients(grads, weight=None, group=None):
     flat = [grads[k].reshape(-1) for k in names]
     dtype = torch.float64 if any(t.dtype == torch.float64 for t in flat) else flat[0].dtype
     bucket = torch.cat([t.to(dtype) for t in flat]) * w
-    run_collective(lambda: dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=group))
+    run_collective(lambda: dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=group), group)
     o = 0
     for k, t in zip(names, flat):
         n = t.numel()
@@ -286,11 +292,11 @@ def k_shard_gradients(model, zs=None, K_total=None, group=None, wrt="all"):
     K_total = int(K_total or model.num_samples * world)
 
     def exchange(ms):
-        if world == 1:
+        if world == 1 and not (_FORCE_ONE_RANK_COLLECTIVES and dist.is_available() and dist.is_initialized()):
             return lse_from_pairs(ms[None])
         gathered = torch.empty((world,) + tuple(ms.shape), dtype=ms.dtype, device=ms.device)
         src = ms.contiguous().view(-1)
-        run_collective(lambda: dist.all_gather_into_tensor(gathered.view(-1), src, group=group))
+        run_collective(lambda: dist.all_gather_into_tensor(gathered.view(-1), src, group=group), group)
         return lse_from_pairs(gathered)
 
     elbo, g = iw_elbo_and_gradients(model, zs, exchange=exchange, K_total=K_total, kl_weight=1.0 / world, wrt=wrt)

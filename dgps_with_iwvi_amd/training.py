@@ -78,6 +78,9 @@ class _SegmentedGraph:
             if isinstance(it, torch.cuda.CUDAGraph):
                 it.replay()
             else:
+                # (the collectives that end up here are host-driven -- gloo -- and wait for the stream anyway; the explicit wait orders them
+                #  behind the segment by the host instead of by an event recorded right behind a multi-queue graph launch)
+                torch.cuda.current_stream().synchronize()
                 it()
 
 
@@ -277,7 +280,8 @@ class Trainer:
             with torch.cuda.stream(side):
                 if first:
                     eager = op()                               # this call's evaluation, launched eagerly (it also warms the allocator pools)
-                if self.world > 1:                             # sharded: graph segments with the collectives between them
+                from . import sharding as _sh
+                if self.world > 1 or _sh._FORCE_ONE_RANK_COLLECTIVES:   # sharded: graph segments with the collectives between them
                     torch.cuda.synchronize()
                     g = _SegmentedGraph()
                     elbo = g.record(op)

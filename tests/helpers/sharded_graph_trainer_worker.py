@@ -17,6 +17,8 @@ from dgps_with_iwvi_amd.training import Trainer      # noqa: E402
 
 
 def main():
+    import faulthandler
+    faulthandler.dump_traceback_later(int(os.environ.get("IWVI_TEST_HANG_DUMP_S", "240")), exit=True)   # a hung collective ends the test with a traceback, not a timeout
     out, shard, steps = sys.argv[1], sys.argv[2], int(sys.argv[3])
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     dist.init_process_group("gloo", rank=rank, world_size=world)

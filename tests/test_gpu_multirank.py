@@ -290,3 +290,19 @@ def test_bench_two_ranks_report_the_sharded_training_step(gpu_device, shard):
     #  -- the ratio of the two forms moves by +-15 % between runs here; on this plumbing set-up only "same ballpark" is asserted.  The worker
     #  test above, with a model whose step is launch-bound, asserts graph <= eager)
     assert 0.0 < t["train_step_ms"] <= t["train_step_eager_ms"] * 1.3, t
+
+
+@pytest.mark.parametrize("shard", ["n", "k"])
+def test_graph_training_step_on_a_real_rccl_communicator(gpu_device, shard):
+    """The graph form of a sharded training step on a real RCCL ("nccl") communicator -- one rank, the step's all-reduces / all-gathers
+    forced on.  RCCL collectives are capturable: they are recorded INSIDE the step's graph (one graph, no cut; issued between two captures
+    their work objects are polled by the process group's watchdog while the next capture is open -- hipErrorStreamCaptureUnsupported, which
+    is what this test first found).  Three steps, parameters and bounds bit-identical to the eager step."""
+    port = _free_port()
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    worker = os.path.join(ROOT, "tests", "helpers", "rccl_one_rank_segments_worker.py")
+    p = subprocess.run([sys.executable, worker, shard, "3"], env=env, capture_output=True, text=True, cwd=ROOT, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    res = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
+    assert res["same"] and res["finite"], res
+    assert res["n_collectives"] == 0 and res["n_graphs"] == 1, res           # (the collectives are nodes of the one graph)
