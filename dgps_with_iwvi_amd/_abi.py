@@ -14,9 +14,11 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libiwvi_hip.so")
 
 KERN_RBF, KERN_MATERN52 = 0, 1
 LAYER_GP, LAYER_LV = 0, 1
-ABI_VERSION = 16
+ABI_VERSION = 17
 GP_WANT_DENSE = 1
 GP_WANT_LM = 2
+GP_REUSE_FACTOR = 8
+GP_FACTOR_ONLY = 16
 LAYER_F32_STAGE2 = 1        # iwvi_layer_desc.flags
 LAYER_F64_STAGE1 = 2        # iwvi_layer_desc.flags: K_uf, Lm^-1 k, sigma^2 - |a|^2 of the layer in float64
 GP_F64_STAGE1 = 4           # iwvi_gp_desc.flags: prepare the state for it (dense float64 Lm^-1, plain z~)
@@ -212,7 +214,7 @@ PROTOTYPES = {
 }
 
 DEBUG_OPTIONS = ("IWVI_BW_FUSED", "IWVI_CHAIN_EXIT", "IWVI_FW_SLOW_TAIL", "IWVI_FW_MAX_NS", "IWVI_NATGRAD_UNFUSED", "IWVI_NG_ONE_WG", "IWVI_NG_STOP", "IWVI_DEBUG_STOP", "IWVI_PRE_STAMP_P",
-                 "IWVI_FW_NO_LEAN", "IWVI_PRE_SB_INLINE")
+                 "IWVI_FW_NO_LEAN", "IWVI_PRE_SB_INLINE", "IWVI_BW_P5_F32")
 
 
 def set_debug_option(name, value):

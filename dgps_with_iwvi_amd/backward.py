@@ -27,6 +27,11 @@ def _side_stream(device, which=0):
     return _SIDE[key]
 
 
+def prepare_stream(device):
+    """The stream the adjoint's preparation runs on (dense factors, packed operands) for the calling stream."""
+    return _side_stream(device, 2)
+
+
 class GpSaved:
     """What one GP layer's forward leaves for its adjoint."""
     __slots__ = ("F", "noise", "A", "U", "sample", "mean", "var", "T", "GMV")
@@ -149,7 +154,25 @@ def prepare_inline(model, T):
     return out
 
 
-def prepare_side(model, T, stream, out=None, after=None):
+def prefactor_dense(model, stream, after, skip_q_of=()):
+    """On ``stream``, behind the event ``after``: the dense float64 Lm and Lm^-1 of every GP layer into its second state buffer -- the part of
+    ``prepare_side`` that depends on Z and the kernel parameters only.  A training step queues it beside the natural-gradient update of its
+    first op (whose kernels leave most of the chip idle); the second op's ``prepare_side(dense_ready=...)`` then starts from it.  Layers in
+    ``skip_q_of`` get the factorisation only (IWVI_GP_FACTOR_ONLY): their q(u) is being written meanwhile."""
+    gps = [(i, l) for i, l in enumerate(model.layers) if isinstance(l, GPLayer)]
+    stream.wait_event(after)
+    with torch.cuda.stream(stream):
+        descs = []
+        for i, l in gps:
+            d = l.state_desc(state=l.state_dense())
+            d.flags |= _abi.GP_WANT_LM | (_abi.GP_FACTOR_ONLY if i in skip_q_of else 0)
+            descs.append(d)
+        precompute_states(descs)
+        arr_d = (_abi.GpDesc * len(descs))(*descs)
+        _abi.check(_abi.lib().iwvi_gp_dense_inverse(arr_d, len(descs), _abi.stream_ptr()))
+
+
+def prepare_side(model, T, stream, out=None, after=None, dense_ready=None):
     """On ``stream``, beside the forward: the dense float64 factors of every GP layer (into its second state buffer) and the
     parameter-only part of its adjoint (``iwvi_gp_layer_backward_prepare``: scaled inducing inputs, packed S_r = L_r L_r^T and
     Lm^-T).  -> {layer index: (workspace, dense state)}; the caller joins ``stream`` before the first ``gp_backward``.
@@ -164,13 +187,26 @@ def prepare_side(model, T, stream, out=None, after=None):
             stream.wait_event(after)
         else:
             stream.wait_stream(torch.cuda.current_stream())
+    import os
+    # the factorisation leaves only the dense factor, Lm^-1 comes from iwvi_gp_dense_inverse (nbk workgroups per layer): the factorising
+    # workgroups then hold their CUs for ~29 us instead of ~52 (two workgroups of the layer kernel wait for them) -- 0.268 -> 0.2635 ms per
+    # value + gradient at configs[2] (scripts/ab_bw_env.py, round 6).  IWVI_BW_DENSE=full: the factorising workgroup inverts as well
+    lm = os.environ.get("IWVI_BW_DENSE", "lm") == "lm"
     with torch.cuda.stream(stream):
         descs = []
         for i, l in gps:
             d = l.state_desc(state=out[i][1])
-            d.flags |= _abi.GP_WANT_DENSE
+            if dense_ready is not None:                          # ``prefactor_dense`` has run on these buffers; only these layers' q(u) moved since
+                if i not in dense_ready:
+                    continue
+                d.flags |= _abi.GP_REUSE_FACTOR
+            else:
+                d.flags |= _abi.GP_WANT_LM if lm else _abi.GP_WANT_DENSE
             descs.append(d)
         precompute_states(descs)
+        if lm and dense_ready is None:
+            arr_d = (_abi.GpDesc * len(descs))(*descs)
+            _abi.check(_abi.lib().iwvi_gp_dense_inverse(arr_d, len(descs), _abi.stream_ptr()))
         if 1 < len(gps) <= _abi.MAX_STACK:                       # every layer's operands in one launch
             arr = (_abi.GpBwdDesc * len(gps))()
             wsp = (ctypes.c_void_p * len(gps))()
@@ -309,7 +345,8 @@ def lv_backward(layer, XY, enc_out, eps, dF_next, col0, w, B, K, sampled_kl=True
     return dW, db
 
 
-def iw_elbo_and_gradients(model, zs=None, mode_vi=None, exchange=None, K_total=None, kl_weight=1.0, overlap=True, wrt="all", fuse_heads=True):
+def iw_elbo_and_gradients(model, zs=None, mode_vi=None, exchange=None, K_total=None, kl_weight=1.0, overlap=True, wrt="all", fuse_heads=True,
+                          prefactor=False, q_moved=None):
     """``wrt="final_q"``: only the final layer's 'l<i>.q_mu' / 'l<i>.q_sqrt' (all that the natural-gradient op of
     build_models.py:288-295 uses): same forward and bound, and of the adjoints only the final layer's two sums over samples.
 
@@ -320,6 +357,13 @@ def iw_elbo_and_gradients(model, zs=None, mode_vi=None, exchange=None, K_total=N
     (max, sum exp) pairs into the logsumexp over ALL ``K_total`` samples of the job; the gradients returned are then
     this rank's share (weights exp(L - lse)), to be SUMMED over the ranks, with the KL terms weighted ``kl_weight``
     (1 / world) so that they count once; the value returned is the job's bound.
+
+    One factorisation per training step (``training.Trainer.step``; build_models.py:288-300 runs the two ops back to back and the first one
+    moves nothing but the final layer's q(u)): ``prefactor=True`` with ``wrt="final_q"`` also queues the dense float64 factors of every GP
+    layer on the preparation stream, behind this evaluation's last launch -- beside the natural-gradient update the caller queues next; the
+    caller joins ``backward.prepare_stream(device)`` when it has.  ``q_moved={final layer index}`` with ``wrt="all"`` is the second half: the
+    caller vouches that since that evaluation only these layers' q(u) has changed, so no K_uu is factorised again -- the q(u) images of both
+    state buffers are rewritten (IWVI_GP_REUSE_FACTOR), the adjoint's operands packed, and the layer launch follows ~5 us after the op starts.
 
     The IW-ELBO of the current minibatch (models.py:112-150) and its gradient w.r.t. every parameter the
     reference trains (build_models.py:284-304): -> (elbo [0-dim float64 tensor], dict) with the names of
@@ -364,7 +408,18 @@ def iw_elbo_and_gradients(model, zs=None, mode_vi=None, exchange=None, K_total=N
     # layer kernel instead, whose workgroups then wait for its two CUs: 0.355 -> 0.382 ms at configs[2])
     n_gp = sum(isinstance(l, GPLayer) for l in layers)
     inline = (not final_q) and n_gp <= _abi.MAX_STACK and os.environ.get("IWVI_BW_PREPARE") == "inline"
-    if inline:
+    if q_moved is not None and (final_q or not overlap or inline):
+        raise ValueError("q_moved goes with wrt='all', overlap=True and the side-stream preparation")
+    if q_moved is not None:
+        # the caller's own (short) precompute + layer launch are captured FIRST: behind the previous op's last node the first successor
+        # captured continues its hardware queue, the preparation -- 12 us of work, needed 50 us later -- takes the cross-queue dispatch
+        q_moved = set(q_moved)
+        alloc = prepare_alloc(model, T)
+        after = torch.cuda.Event()
+        after.record(cur)
+        model.precompute(with_encoders=True, q_moved=q_moved)
+        prepared = prepare_side(model, T, prep_stream, out=alloc, after=after, dense_ready=q_moved)
+    elif inline:
         # IWVI_BW_PREPARE=inline: one factorisation for both passes (prepare_inline).  Measured, not the default: the inversion launch sits
         # in front of the layer kernel (17 us at M = 128) where the side stream's dense factorisation costs the layer kernel 7 us and a
         # join 10 -- configs[2] 0.318 vs 0.309 ms per value + gradient, configs[3] 8.98 vs 8.90 ms
@@ -459,6 +514,10 @@ def iw_elbo_and_gradients(model, zs=None, mode_vi=None, exchange=None, K_total=N
     if final_q:
         i = len(layers) - 1
         g = gp_backward(layers[i], fin, d_mean=d_mean, d_var=d_var, kl_weight=kl_weight, q_only=True)
+        if prefactor:
+            done = torch.cuda.Event()
+            done.record(cur)
+            prefactor_dense(model, prepare_stream(dev), done, skip_q_of={i})
         return elbo, {"l%d.q_mu" % i: g["dq_mu"], "l%d.q_sqrt" % i: g["dq_sqrt"]}
     if prep_stream != cur:
         cur.wait_stream(prep_stream)                             # dense factors and packed adjoint operands are ready
@@ -475,6 +534,10 @@ def iw_elbo_and_gradients(model, zs=None, mode_vi=None, exchange=None, K_total=N
     # therefore queued on the caller's stream behind everything else there, and the lowest layer's branch runs whole on the side stream:
     # the two branches then run side by side (configs[2]: 0.331 -> 0.307 ms per value + gradient).  IWVI_BW_BRANCH_ORDER=old: both on the side stream.
     # (M <= 128 only: at M = 256 the branches are GEMM-sized and do overlap the chains -- configs[3]: 8.88 ms this way round, 9.09 ms the other)
+    # (Round 6, measured and not kept: every branch but the lowest queued on the side stream right behind its own chain, the lowest as
+    # two chains -- 0.268 -> 0.281 ms: the first successor captured behind a chain takes over its hardware queue, so the NEXT chain pays
+    # the cross-queue dispatch; and of a branch only its reduction runs beside a chain kernel (k_gl_tril does not fit next to a chain
+    # workgroup's LDS, the float64 products need 304 registers a wave): the rest queues up in front of the lowest branch.)
     on_cur = sorted(deferred)[1] if (len(deferred) >= 2 and overlap and os.environ.get("IWVI_BW_BRANCH_ORDER") != "old"
                                      and layers[sorted(deferred)[1]].num_inducing <= 128) else -1
     finish_on_cur = None

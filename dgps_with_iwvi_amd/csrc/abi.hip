@@ -27,7 +27,7 @@ int check_launch(const char* what) {
 // ---- development route switches: set through iwvi_debug_set_option only (the library does not read the environment) -------------
 static const char* const g_opt_names[] = {
     "IWVI_BW_FUSED", "IWVI_CHAIN_EXIT", "IWVI_FW_SLOW_TAIL", "IWVI_FW_MAX_NS", "IWVI_NATGRAD_UNFUSED", "IWVI_NG_ONE_WG", "IWVI_NG_STOP", "IWVI_DEBUG_STOP", "IWVI_PRE_STAMP_P",
-    "IWVI_FW_NO_LEAN", "IWVI_PRE_SB_INLINE"};
+    "IWVI_FW_NO_LEAN", "IWVI_PRE_SB_INLINE", "IWVI_BW_P5_F32"};
 constexpr int N_OPTS = (int)(sizeof(g_opt_names) / sizeof(g_opt_names[0]));
 static int g_opt_values[N_OPTS] = {0};
 static int opt_index(const char* name) {

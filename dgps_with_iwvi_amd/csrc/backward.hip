@@ -906,6 +906,23 @@ __device__ __forceinline__ void bw_async_copy(const float* __restrict__ src, flo
                                              (__attribute__((address_space(3))) void*)(lds_dst + i0), 4, 0, 0);
     }
 }
+// products over samples on f16 operands (k_bw_chain, phase 5): the sample the e-th f16 of lane group g stands for in k-step ks.
+// A full step covers 32 samples as 4e + g; the half step that ends an odd NS covers 16 as 2e + g on lane groups 0 and 1.
+template <int NS>
+__device__ __forceinline__ int chain_smp(int ks, int e, int g) {
+    return ((NS & 1) && ks == NS / 2) ? 32 * ks + 2 * e + (g & 1) : 32 * ks + 4 * e + g;
+}
+// maximum of a non-negative value over the wave, wave-uniform: four DPP steps inside the rows of 16 lanes, then one lane of each row
+__device__ __forceinline__ float chain_wave_max(float v) {
+    int x = __float_as_int(v);
+    x = __float_as_int(fmaxf(__int_as_float(x), __int_as_float(__builtin_amdgcn_update_dpp(x, x, 0xB1, 0xF, 0xF, false))));    // quad_perm [1,0,3,2]
+    x = __float_as_int(fmaxf(__int_as_float(x), __int_as_float(__builtin_amdgcn_update_dpp(x, x, 0x4E, 0xF, 0xF, false))));    // quad_perm [2,3,0,1]
+    x = __float_as_int(fmaxf(__int_as_float(x), __int_as_float(__builtin_amdgcn_update_dpp(x, x, 0x141, 0xF, 0xF, false))));   // row_half_mirror
+    x = __float_as_int(fmaxf(__int_as_float(x), __int_as_float(__builtin_amdgcn_update_dpp(x, x, 0x140, 0xF, 0xF, false))));   // row_mirror
+    const float m0 = __int_as_float(__builtin_amdgcn_readlane(x, 0)), m1 = __int_as_float(__builtin_amdgcn_readlane(x, 16));
+    const float m2 = __int_as_float(__builtin_amdgcn_readlane(x, 32)), m3 = __int_as_float(__builtin_amdgcn_readlane(x, 48));
+    return fmaxf(fmaxf(m0, m1), fmaxf(m2, m3));
+}
 struct ChainArgs {
     const float* GMV; const float* eps; const float* W; const float* mfA; const float* dFs; const float* dFm; const float* dFv;
     float* DMU; float* DV2; float* SDV; float* dF; int P, mf_type;
@@ -930,6 +947,7 @@ struct ChainArgs {
     int q_only;                          // only dq_mu / dq_sqrt are wanted (the natural-gradient op): heads, dq_mu shares, G_r shares
     int ts;                              // float4 per tile row (16 NS, + 4 of padding where it fits)
     const float* SP16; const float* spf; int s16;   // phase 1 on split-f16 operands (a third tile holds a as two f16 planes)
+    int p5h;                             // phase 5 (products over samples) on split-f16 operands: with s16 unless the development switch IWVI_BW_P5_F32 is set
     int z_lds;                           // the scaled inducing inputs are staged in LDS for the kernel adjoint (M <= 256; beyond: read from L2)
     const float* ZtP; const float* cst; int nsteps;   // the state's K_uf operand (A-fragment order), its constant block (1/ls | centre | extent), k-steps
 };
@@ -1237,6 +1255,31 @@ __global__ __launch_bounds__(512) void k_bw_chain(ChainArgs a) {
     }
     __syncthreads();
     if (a.dbg_exit == 2) return;
+    // (s16) the third tile is free now: a once more, TRANSPOSED, as the f16 operand of the products over samples (phase 5) -- per column
+    // block bk and k-step of 32 samples two 1-KiB planes h1 | h2 of 2^ea a, lane 16g + n holding a[16bk + n][sample(ks, e, g)], e = 0..7
+    // (chain_smp: any bijection between a k-step's 32 samples and (g, e) serves as long as both operands use it; this one keeps the
+    // transposed scalar reads of a tile off each other's banks).  An odd NS ends in a half step: lanes g < 2 only, half the bytes.
+    if (a.p5h && (a.p_lm || a.p_g)) {
+        using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
+        constexpr int KS = (NS + 1) / 2, PB = (NS / 2) * 128 + (NS & 1) * 64;      // k-steps; float4 per column block
+        const float sa = a.cst[IWVI_CST_SA];
+        f32x4* tT4 = reinterpret_cast<f32x4*>(tileH);
+        for (int v = tid; v < nbk * KS * 64; v += 512) {
+            const int ln = v & 63, bs = v >> 6, bk = bs / KS, ks = bs - bk * KS, n = ln & 15, g = ln >> 4;
+            const bool half_step = (NS & 1) && ks == NS / 2;
+            if (half_step && g >= 2) continue;
+            f16x8 h1, h2;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int smp = chain_smp<NS>(ks, e, g);
+                const float x = tileA[((size_t)(bk * 4 + (n >> 2)) * TS + smp) * 4 + (n & 3)] * sa;
+                h1[e] = (_Float16)x; h2[e] = (_Float16)(x - (float)h1[e]);
+            }
+            f32x4* dst = tT4 + (size_t)bk * PB + (half_step ? (NS / 2) * 128 : ks * 128);
+            dst[ln] = __builtin_bit_cast(f32x4, h1); dst[(half_step ? 32 : 64) + ln] = __builtin_bit_cast(f32x4, h2);
+        }
+        // (visible behind the barriers that end phase 2)
+    }
 
     // ---- phase 2: dk(bi) = sum_{bk >= bi} Lm^-T(bi, bk) da(bk); row-blocks paired so that every wave streams nbk + 1 blocks
     //      IN PLACE over da: every wave holds its (at most two) result row-blocks in registers until all have read da.
@@ -1297,7 +1340,77 @@ __global__ __launch_bounds__(512) void k_bw_chain(ChainArgs a) {
     //      The contraction runs over the chunk's samples (4 per MFMA step), so both operands are read TRANSPOSED from the tiles
     //      (scalar LDS reads); the A side of a (row-block, product) pair -- NSAMP / 4 registers, for G_r scaled by 2dv_r -- is
     //      read once and reused for every bk <= bi.  Waves: row-block pair (w & 3, nbk-1-(w & 3)) x half of the 1 + R products.
-    {
+    if (a.p5h) {
+        // split-f16 form (round 6): the contraction index is the sample, so a k-step of v_mfma_f32_16x16x32_f16 takes 32 of them; x = h1 + h2 on
+        // both sides, three products (h1 h1' on one accumulator, h2 h1' + h1 h2' on another).  B = the transposed planes of 2^ea a built behind
+        // phase 1; A = the row-block of dk (item 0) or of 2dv_r o a, read transposed from the fp32 tiles once per (row-block, item), scaled by the
+        // power of two that brings ITS largest entry to [2^13, 2^14) (a wave-wide maximum: 4 DPP steps + 4 v_readlane) and split in registers.
+        // 9 MFMAs of 16 clocks per block product at NS = 5, where the fp32 form issues 20 of 32.
+        using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
+        constexpr int KS = (NS + 1) / 2, PB = (NS / 2) * 128 + (NS & 1) * 64;
+        const f32x4* tT4 = reinterpret_cast<const f32x4*>(tileH);
+        const float sa = a.cst[IWVI_CST_SA];
+        const int pr = wave & 3, half = wave >> 2;
+        const int it0 = a.p_lm ? 0 : 1, nit = R + 1 - it0;
+        const int i_lo = it0 + (half == 0 ? 0 : (nit + 1) / 2), i_hi = it0 + (half == 0 ? (nit + 1) / 2 : nit);
+        for (int pass = 0; pass < 2 && (a.p_lm || a.p_g); ++pass) {
+            const int bi = pass == 0 ? pr : nbk - 1 - pr;
+            if (bi < 0 || bi >= nbk) continue;
+            if (pass == 0 ? (pr > nbk - 1 - pr) : (nbk - 1 - pr <= pr)) continue;
+            for (int it = i_lo; it < i_hi; ++it) {
+                if (it > 0 && !a.p_g) continue;
+                const float* src = it == 0 ? tileK : tileA;
+                float x[KS][8];
+                float mx = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    const bool live = !((NS & 1) && ks == NS / 2) || gq < 2;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const int smp = chain_smp<NS>(ks, e, gq);
+                        float v = 0.f;
+                        if (live) {
+                            v = src[((size_t)(bi * 4 + (jq >> 2)) * TS + smp) * 4 + (jq & 3)];
+                            if (it > 0) v *= dv2_s[smp * R + (it - 1)];
+                        }
+                        x[ks][e] = v;
+                        mx = fmaxf(mx, fabsf(v));
+                    }
+                }
+                mx = chain_wave_max(mx);
+                int ex = ((__float_as_int(mx) >> 23) & 0xff) - 127;
+                ex = mx > 0.f ? (ex < -100 ? -100 : (ex > 100 ? 100 : ex)) : 13;
+                const float sc = __int_as_float((127 + 13 - ex) << 23);                       // |x| sc < 2^14
+                const float back = __int_as_float((127 - 13 + ex) << 23) / sa;              // (both powers of two: exact)
+                f16x8 A1[KS], A2[KS];
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float xs = x[ks][e] * sc;
+                        A1[ks][e] = (_Float16)xs; A2[ks][e] = (_Float16)(xs - (float)A1[ks][e]);
+                    }
+                float* outp = it == 0 ? a.p_lm + (size_t)blockIdx.x * M * M
+                                      : a.p_g + ((size_t)(it - 1) * a.S + blockIdx.x) * M * M;
+                for (int bk = 0; bk <= bi; ++bk) {
+                    const f32x4* Tb = tT4 + (size_t)bk * PB;
+                    f32x4 acc = {0.f, 0.f, 0.f, 0.f}, cor = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks) {
+                        f32x4 b1 = {0.f, 0.f, 0.f, 0.f}, b2 = {0.f, 0.f, 0.f, 0.f};
+                        if ((NS & 1) && ks == NS / 2) {
+                            if (lane < 32) { b1 = Tb[(NS / 2) * 128 + lane]; b2 = Tb[(NS / 2) * 128 + 32 + lane]; }
+                        } else { b1 = Tb[ks * 128 + lane]; b2 = Tb[ks * 128 + 64 + lane]; }
+                        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(A1[ks], __builtin_bit_cast(f16x8, b1), acc, 0, 0, 0);
+                        cor = __builtin_amdgcn_mfma_f32_16x16x32_f16(A2[ks], __builtin_bit_cast(f16x8, b1), cor, 0, 0, 0);
+                        cor = __builtin_amdgcn_mfma_f32_16x16x32_f16(A1[ks], __builtin_bit_cast(f16x8, b2), cor, 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) outp[(size_t)(16 * bi + 4 * gq + e) * M + 16 * bk + jq] = (acc[e] + cor[e]) * back;
+                }
+            }
+        }
+    } else {
         const int pr = wave & 3, half = wave >> 2;
         const int it0 = a.p_lm ? 0 : 1, nit = R + 1 - it0;                                                     // item 0 = dLm, 1 + r = G_r
         const int i_lo = it0 + (half == 0 ? 0 : (nit + 1) / 2), i_hi = it0 + (half == 0 ? (nit + 1) / 2 : nit);
@@ -1665,6 +1778,7 @@ static int launch_chain_ns(hipStream_t st, ChainArgs a) {
     const int DM = a.D <= 8 ? 8 : (a.D <= 16 ? 16 : 32);
     a.z_lds = chain_z_lds(a.M) ? 1 : 0;
     a.s16 = chain_s16(a.M, a.Mp) ? 1 : 0;
+    a.p5h = (a.s16 && !dbg_opt("IWVI_BW_P5_F32")) ? 1 : 0;
     a.dsz = chain_dsz(NSAMP, a.M, a.D, a.R, a.P, DM, a.M <= 256);
     a.ts = chain_ts(NSAMP, a.M, a.D, a.R, a.P);
     const size_t lds = chain_lds_bytes_ts(NSAMP, a.ts, a.M, a.D, a.R, a.P);

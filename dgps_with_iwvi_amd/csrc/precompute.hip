@@ -145,8 +145,10 @@ __global__ __launch_bounds__(1024) void k_precompute(PreArgs args) {
     const PreLayer& L = args.L[blockIdx.x];
     const int role = blockIdx.y;
     if (role == 0) {
+        if (L.flags & IWVI_GP_REUSE_FACTOR) return;         // (the state's factorisation is current: q(u) images only)
         if (L.Mp <= 128) role_factor<true>(L, args.stop_after, args.stamps, args.stamp_p); else role_factor<false>(L, args.stop_after, args.stamps, args.stamp_p);
     } else if (role <= L.R) {
+        if (L.flags & IWVI_GP_FACTOR_ONLY) return;
         role_pack_r(L, role - 1, reinterpret_cast<double*>(smem_raw));
     }
 }
@@ -893,8 +895,9 @@ extern "C" int iwvi_model_precompute(const iwvi_gp_desc* layers, int n_layers, c
             const iwvi_gp_desc& d = layers[base + l];
             PreLayer& L = a.L[l];
             { const int rc = fill_pre_layer(d, base + l, L); if (rc != IWVI_OK) return rc; }
+            if ((d.flags & IWVI_GP_REUSE_FACTOR) && (d.flags & IWVI_GP_FACTOR_ONLY)) { set_error("iwvi_gp_precompute: layer %d asks for IWVI_GP_REUSE_FACTOR and IWVI_GP_FACTOR_ONLY", base + l); return IWVI_ERR_ARG; }
             if (d.flags & IWVI_GP_F64_STAGE1) L.flags |= IWVI_GP_WANT_LM;      // the float64 route multiplies by the dense Lm^-1 (k_linv below)
-            if (L.nbk >= 16 && !(d.flags & IWVI_GP_WANT_DENSE) && !dbg_opt("IWVI_PRE_SB_INLINE")) L.flags |= IWVI_GP_SB_EXT_;   // super-block inverses by k_sb_inv
+            if (L.nbk >= 16 && !(d.flags & (IWVI_GP_WANT_DENSE | IWVI_GP_REUSE_FACTOR)) && !dbg_opt("IWVI_PRE_SB_INLINE")) L.flags |= IWVI_GP_SB_EXT_;   // super-block inverses by k_sb_inv
             size_t la = factor_lds_bytes(L.Mp);
             if (la > lds) lds = la;
             if (d.R + 1 > max_roles) max_roles = d.R + 1;
@@ -960,7 +963,7 @@ extern "C" int iwvi_model_precompute(const iwvi_gp_desc* layers, int n_layers, c
             int grid = 0;
             for (int l = 0; l < a.n; ++l) {
                 const PreLayer& L = a.L[l];
-                if (L.nbk < 16) continue;
+                if (L.nbk < 16 || (L.flags & IWVI_GP_REUSE_FACTOR)) continue;
                 const StateLayout sl = state_layout(L.M, L.R);
                 Ls16One& o = q.L[q.n++];
                 o.blk = L.ws + ws_layout(L.Mp).blk;
@@ -982,7 +985,7 @@ extern "C" int iwvi_model_precompute(const iwvi_gp_desc* layers, int n_layers, c
             int nf = 0;
             for (int l = 0; l < a.n; ++l) {
                 const iwvi_gp_desc& d = layers[base + l];
-                if (!(d.flags & IWVI_GP_F64_STAGE1)) continue;
+                if (!(d.flags & IWVI_GP_F64_STAGE1) || (d.flags & IWVI_GP_REUSE_FACTOR)) continue;
                 const PreLayer& L = a.L[l];
                 const StateLayout sl = state_layout(L.M, L.R);
                 f64l[nf] = d;

@@ -93,7 +93,7 @@ class DGP_VI:
         return self._dev_words
 
     # -- reference API ------------------------------------------------------------------------
-    def precompute(self, with_encoders=False, sample_first=None, dense=False):
+    def precompute(self, with_encoders=False, sample_first=None, dense=False, q_moved=None):
         """Gram + Cholesky + operand packing of every GP layer: one ABI call, one launch.  ``with_encoders``:
         the same launch also evaluates the encoder MLP of every latent-variable layer on the current minibatch
         (it does not depend on the factorisation, so it runs beside it instead of inside the layer kernel).
@@ -112,7 +112,19 @@ class DGP_VI:
                         encs.append(e)
                     keep.append(k)
                     l._enc_key = self._mb_key()
-        descs = [l.state_desc() for l in self.layers if isinstance(l, GPLayer)]
+        if q_moved is None:
+            descs = [l.state_desc() for l in self.layers if isinstance(l, GPLayer)]
+        else:
+            # ``q_moved`` (layer indices; the CALLER vouches for it -- training.Trainer.step between its two ops): since the last full precompute
+            # on these state buffers nothing but these layers' q(u) has changed.  Their q(u) images are rewritten (IWVI_GP_REUSE_FACTOR), every
+            # factorisation stays as it is, a layer of which nothing moved is not in the call at all; the encoders run as always.
+            descs = []
+            for i in sorted(q_moved):
+                d = self.layers[i].state_desc()
+                d.flags |= _abi.GP_REUSE_FACTOR
+                descs.append(d)
+            if dense or not descs:
+                raise ValueError("q_moved: at least one layer, and not together with dense")
         if dense:                                                    # the adjoints read the dense float64 Lm, Lm^-1
             for d in descs:                                          # ("lm": the factor only; Lm^-1 by iwvi_gp_dense_inverse)
                 d.flags |= _abi.GP_WANT_LM if dense == "lm" else _abi.GP_WANT_DENSE

@@ -87,7 +87,7 @@ class _SegmentedGraph:
 class Trainer:
     def __init__(self, model, lr=5e-3, gamma=1e-2, lr_decay=0.98, gamma_decay=0.98, fix_linear=True,
                  beta1=0.9, beta2=0.999, epsilon=1e-8, group=None, shard_weight=None, shard="n", num_data_total=None,
-                 use_graph=False, check_finite=True, check_every=100, autotune_f64=True, K_total=None):
+                 use_graph=False, check_finite=True, check_every=100, autotune_f64=True, K_total=None, one_factorisation=True):
         """``group`` / ``shard_weight``: data-parallel training over the ranks of a torch.distributed group (each rank's
         model holds its own minibatch rows, N-shard): gradients are merged by ``sharding.allreduce_gradients`` with
         weight B_rank / B_job (default: from the all-reduced local batch sizes) before either update, so every rank
@@ -112,8 +112,16 @@ class Trainer:
         ``autotune_f64`` (default on, while ``settings.f64_stage1 == "auto"``): ``model.autotune_f64()`` -- the float64 stage-1 route per layer
         from the measured diag(Lm) ratio of the CURRENT parameters -- runs here and again at every staircase epoch (1000 steps: the graphs
         are re-captured there anyway), so that a layer whose K_uu becomes ill-conditioned DURING training (lengthscales grow, inducing
-        inputs cluster) leaves the float32 solve; captured graphs are dropped whenever a layer's route moves (``model.route_key()``)."""
+        inputs cluster) leaves the float32 solve; captured graphs are dropped whenever a layer's route moves (``model.route_key()``).
+
+        ``one_factorisation`` (default on; single rank, N-layout): a step factorises every K_uu ONCE.  The natural-gradient op moves
+        nothing but the final layer's q(u) (build_models.py:288-295), so the Adam op that follows it in ``step`` re-packs that layer's q(u)
+        images (IWVI_GP_REUSE_FACTOR, ~5 us) instead of factorising every layer again, and the dense float64 factors its adjoints read
+        are formed beside the natural-gradient update of the first op, whose kernels leave the chip idle (``backward.prefactor_dense``).
+        Same kernels on the same numbers: the parameters after a step are bit-identical to ``one_factorisation=False``.  The ops called
+        on their own (``natgrad_op`` / ``adam_op``) always factorise."""
         self.model = model
+        self.one_factorisation = bool(one_factorisation)
         self.K_total = None if K_total is None else int(K_total)   # K-shard with an uneven split of the job's samples (default: num_samples x ranks)
         self.autotune = bool(autotune_f64)
         self._tuned_epoch = None
@@ -213,21 +221,27 @@ class Trainer:
                                                     self._t_dev.data_ptr(), 1, _abi.stream_ptr()))
         return keep
 
-    def _gradients(self, zs, advance=True, wrt="all"):
+    def _gradients(self, zs, advance=True, wrt="all", **one_factor):
         from .sharding import allreduce_gradients, k_shard_gradients
         if advance:
             self.model.next_minibatch()                          # gpflow.Minibatch: a new batch per session.run (models.py:21-26)
         if self.shard == "k":
             return k_shard_gradients(self.model, zs, K_total=self.K_total, group=self.group, wrt=wrt)
-        elbo, g = iw_elbo_and_gradients(self.model, zs, wrt=wrt)
+        elbo, g = iw_elbo_and_gradients(self.model, zs, wrt=wrt, **one_factor)
         g["__elbo__"] = elbo.reshape(1)                          # rides in the same bucket: the job's bound
         g = allreduce_gradients(g, weight=self.shard_weight, group=self.group)
         return g.pop("__elbo__")[0], g
 
-    def natgrad_op(self, zs=None, _advance=True):
+    def _one_factor(self):
+        """``step`` shares one factorisation between its two ops: single rank (a sharded step's collectives sit between the first op's
+        evaluation and its update -- the dense factors would be in flight across them), N-layout."""
+        from . import sharding as _sh
+        return self.one_factorisation and self.world == 1 and self.shard != "k" and not _sh._FORCE_ONE_RANK_COLLECTIVES
+
+    def natgrad_op(self, zs=None, _advance=True, _prefactor=False):
         """``op_ng``: one ELBO + gradient evaluation, natural-gradient step on the final layer's q(u).  Only that layer's
         (q_mu, q_sqrt) gradients are formed (``wrt="final_q"``): the op reads nothing else."""
-        elbo, g = self._gradients(zs, _advance, wrt="final_q")
+        elbo, g = self._gradients(zs, _advance, wrt="final_q", **({"prefactor": True} if _prefactor else {}))
         i = len(self.model.layers) - 1
         f = self.final
         gamma = staircase_decay(self.gamma, self.global_step, self.gamma_decay)
@@ -235,11 +249,14 @@ class Trainer:
         dq_sqrt = _abi.dev_tensor(g["l%d.q_sqrt" % i].contiguous(), "dq_sqrt")
         _abi.check(_abi.lib().iwvi_natgrad_step_ex(_abi.ptr(f.q_mu), _abi.ptr(f.q_sqrt), _abi.ptr(dq_mu), _abi.ptr(dq_sqrt),
                                                   f.num_inducing, f.num_outputs, gamma, self._ng_ws.data_ptr(), self._ng_ws.numel(), _abi.stream_ptr()))
+        if _prefactor:                                           # the dense factors queued beside this update: joined here (the next op starts from them)
+            from . import backward as _bw
+            torch.cuda.current_stream().wait_stream(_bw.prepare_stream(f.q_mu.device))
         return elbo
 
-    def adam_op(self, zs=None, _advance=True):
+    def adam_op(self, zs=None, _advance=True, _q_moved=False):
         """``op_adam``: one ELBO + gradient evaluation, Adam step on everything but the final layer's q(u)."""
-        elbo, g = self._gradients(zs, _advance)
+        elbo, g = self._gradients(zs, _advance, **({"q_moved": {len(self.model.layers) - 1}} if _q_moved else {}))
         self._adam_call(g, lr=staircase_decay(self.lr, self.global_step, self.lr_decay))
         for _, owner in self._scalars:                         # host copies are refreshed lazily, when somebody reads them
             owner.mark_device_variance_changed()
@@ -313,20 +330,23 @@ class Trainer:
                 elbo = self._replay("step", self._both_ops)
             else:
                 self._advance_outside_graph()
-                self._replay("ng", lambda: self.natgrad_op(None, _advance=False))
+                one = self._one_factor()
+                self._replay("ng", lambda: self.natgrad_op(None, _advance=False, _prefactor=one))
                 self._advance_outside_graph()
-                elbo = self._replay("adam", lambda: self.adam_op(None, _advance=False))
+                elbo = self._replay("adam", lambda: self.adam_op(None, _advance=False, _q_moved=one))
             for _, owner in self._scalars:                     # a replay runs no host code: flag the host copies here
                 owner.mark_device_variance_changed()
             if self.check_finite and self.global_step % self.check_every == 0:
                 self._raise_if_not_finite(elbo)
             return elbo
-        self.natgrad_op(zs_ng)
-        return self.adam_op(zs_adam)
+        one = self._one_factor()
+        self.natgrad_op(zs_ng, _prefactor=one)
+        return self.adam_op(zs_adam, _q_moved=one)
 
     def _both_ops(self):
-        self.natgrad_op(None, _advance=False)
-        return self.adam_op(None, _advance=False)
+        one = self._one_factor()
+        self.natgrad_op(None, _advance=False, _prefactor=one)
+        return self.adam_op(None, _advance=False, _q_moved=one)
 
     def _advance_outside_graph(self):
         """Everything of a minibatch change that is host-driven runs here, never inside the captured op: the in-place

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define IWVI_ABI_VERSION 16
+#define IWVI_ABI_VERSION 17
 
 enum {
     IWVI_OK = 0,
@@ -88,6 +88,15 @@ const char* iwvi_last_error(void);
  * also leaves the dense float64 Lm and Lm^-1 (as with IWVI_GP_WANT_LM + iwvi_gp_dense_inverse, launched behind it on the same stream)
  * and the plain float32 inducing inputs z~ the factorisation saw. */
 #define IWVI_GP_F64_STAGE1 4
+/* iwvi_gp_desc.flags (ABI 17), for callers that KNOW which inputs moved since the last full precompute on this state buffer -- a
+ * training step whose first op moves only the final layer's q(u) (build_models.py:288-300):
+ * IWVI_GP_REUSE_FACTOR: Z, lengthscales, variance, jitter are unchanged: the factorisation and everything derived from it stay as they
+ *   are, only the q(u) images (tril(q_sqrt)^T, q_mu^T, their split-f16 slabs and scales, kl[]) are rewritten -- ~5 us instead of ~26 at
+ *   M = 128.  A layer of which nothing moved is simply left out of the call.
+ * IWVI_GP_FACTOR_ONLY: the opposite -- the factorisation and its images only; the q(u) images are not touched (q may be written by
+ *   another stream meanwhile).  Both together: error. */
+#define IWVI_GP_REUSE_FACTOR 8
+#define IWVI_GP_FACTOR_ONLY 16
 
 typedef struct iwvi_gp_desc {
     const float* Z;            /* [M, D]  inducing inputs                        */

@@ -16,6 +16,8 @@ settings.set_seed(1)
 m = synthetic.build_model(spec, dev)
 names = {0: "whole", 10: "inputs in LDS", 11: "heads", 1: "thin sums (dq_mu, dW)", 2: "phase 1: da", 3: "phase 2: dk", 4: "products over samples", 5: "kernel adjoint"}
 base = None
+if os.environ.get("P5_F32") == "1":                          # phase 5 on fp32 operands (the form before round 6)
+    _abi.set_debug_option("IWVI_BW_P5_F32", 1)
 for ex in (10, 11, 1, 2, 3, 4, 5, 0):
     _abi.set_debug_option("IWVI_CHAIN_EXIT", ex)
     s = torch.cuda.Stream()

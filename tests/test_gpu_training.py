@@ -306,6 +306,37 @@ def test_graph_mode_training_step_equals_the_eager_one(gpu_device):
     assert out[0][2] != spec["lik_var"]                          # the likelihood variance did move (and was read back lazily)
 
 
+@pytest.mark.parametrize("case", ["full_batch_eager", "full_batch_graph", "minibatch_graph", "f64_route_graph"])
+def test_one_factorisation_per_step_is_the_same_step(gpu_device, case):
+    """Trainer(one_factorisation=True), the default: the Adam op re-packs the final layer's q(u) images instead of factorising every
+    K_uu again (IWVI_GP_REUSE_FACTOR), and its dense factors were formed beside the natural-gradient update of the first op
+    (IWVI_GP_FACTOR_ONLY on the layer whose q(u) is being written).  Same kernels on the same numbers: bounds and parameters are
+    bit-identical to the step that factorises per op -- eager and captured, full-batch (one graph) and minibatched (two graphs), and
+    with an inner layer on the float64 stage-1 route (its Lm^-1 and z~ images must survive the short precompute)."""
+    from dgps_with_iwvi_amd import synthetic, settings
+    from dgps_with_iwvi_amd.training import Trainer
+    graph = not case.endswith("eager")
+    if case == "f64_route_graph":
+        spec = synthetic.make_spec(L=2, M=32, B=64, K=5, with_lv=False, seed=31, Dx=2)
+    elif case == "minibatch_graph":
+        spec = synthetic.make_spec(L=2, M=32, B=96, K=4, with_lv=True, seed=37, n_data=96)
+    else:
+        spec = synthetic.make_spec(L=2, M=32, B=64, K=5, with_lv=True, seed=31)
+    out = []
+    for one in (False, True):
+        settings.set_seed(3)
+        model = _minibatched_lv_model(spec, gpu_device, 16) if case == "minibatch_graph" else synthetic.build_model(spec, gpu_device)
+        tr = Trainer(model, use_graph=graph, check_finite=False, one_factorisation=one)
+        if case == "f64_route_graph":
+            assert any(l.uses_f64_stage1() for l in model.layers if hasattr(l, "uses_f64_stage1"))
+        vals = [float(tr.step()) for _ in range(6)]
+        out.append((vals, [p.clone() for _, p, _ in tr._entries], model.layers[-1].q_mu.clone(), model.layers[-1].q_sqrt.clone()))
+    assert out[0][0] == out[1][0], (out[0][0], out[1][0])
+    for pa, pb in zip(out[0][1], out[1][1]):
+        assert torch.equal(pa, pb)
+    assert torch.equal(out[0][2], out[1][2]) and torch.equal(out[0][3], out[1][3])
+
+
 def test_graph_mode_follows_the_staircase_decay(gpu_device):
     """lr / gamma enter the captured update kernels by value: crossing a decay boundary (every 1000 steps, build_models.py:276-282)
     re-captures the two graphs, and the trajectory stays the eager one's bit for bit."""
