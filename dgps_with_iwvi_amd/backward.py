@@ -360,8 +360,9 @@ def iw_elbo_and_gradients(model, zs=None, mode_vi=None, exchange=None, K_total=N
 
     One factorisation per training step (``training.Trainer.step``; build_models.py:288-300 runs the two ops back to back and the first one
     moves nothing but the final layer's q(u)): ``prefactor=True`` with ``wrt="final_q"`` also queues the dense float64 factors of every GP
-    layer on the preparation stream, behind this evaluation's last launch -- beside the natural-gradient update the caller queues next; the
-    caller joins ``backward.prepare_stream(device)`` when it has.  ``q_moved={final layer index}`` with ``wrt="all"`` is the second half: the
+    layer beside the natural-gradient update the caller queues next: it leaves the event they may start from in ``model._prefactor_after``;
+    the caller queues its update, then ``prefactor_dense(model, prepare_stream(device), model._prefactor_after, skip_q_of={final})``, and
+    joins that stream.  ``q_moved={final layer index}`` with ``wrt="all"`` is the second half: the
     caller vouches that since that evaluation only these layers' q(u) has changed, so no K_uu is factorised again -- the q(u) images of both
     state buffers are rewritten (IWVI_GP_REUSE_FACTOR), the adjoint's operands packed, and the layer launch follows ~5 us after the op starts.
 
@@ -514,10 +515,10 @@ def iw_elbo_and_gradients(model, zs=None, mode_vi=None, exchange=None, K_total=N
     if final_q:
         i = len(layers) - 1
         g = gp_backward(layers[i], fin, d_mean=d_mean, d_var=d_var, kl_weight=kl_weight, q_only=True)
-        if prefactor:
-            done = torch.cuda.Event()
-            done.record(cur)
-            prefactor_dense(model, prepare_stream(dev), done, skip_q_of={i})
+        if prefactor:                                            # the point the dense factors may start from; the CALLER queues them (prefactor_dense)
+            done = torch.cuda.Event()                            # AFTER its update: the first successor captured behind these launches keeps their
+            done.record(cur)                                     # hardware queue, and that has to be the update, not the side work
+            model._prefactor_after = done
         return elbo, {"l%d.q_mu" % i: g["dq_mu"], "l%d.q_sqrt" % i: g["dq_sqrt"]}
     if prep_stream != cur:
         cur.wait_stream(prep_stream)                             # dense factors and packed adjoint operands are ready

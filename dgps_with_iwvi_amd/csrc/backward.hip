@@ -336,31 +336,50 @@ static bool launch_fast(hipStream_t st, const GemmArgs& g) {
 // out[m, n] = alpha * sum_s part[s][m][n] (+ beta * out); tri: entries above the diagonal become 0.  Either output
 // may be null (float / double).
 struct ReduceArgs { const float* part; int S, M, N; float* out; double* out64; long long ldo; double alpha, beta; int tri; long long out_batch;
-                    const float* add; double add_coef; int add_diag_inv; };   // + add_coef * (add[.] - (m == n ? 1 / add[.] : 0)): the KL gradient rides along
-__global__ __launch_bounds__(256) void k_reduce_parts(ReduceArgs r) {
-    // 64 outputs per workgroup; the S partials of an output are summed by 4 threads (contiguous quarters, in order),
-    // then combined in a fixed order: deterministic whatever the launch geometry
-    __shared__ double red[4][64];
+                    const float* add; double add_coef; int add_diag_inv;      // + add_coef * (add[.] - (m == n ? 1 / add[.] : 0)): the KL gradient rides along
+                    int frag; };                                              // > 0 (= M / 16, square, tri): the shares hold only the LOWER 16x16 blocks, each
+                                                                              // as one accumulator image (k_bw_chain, phase 5): block (bi, bk <= bi) at
+                                                                              // 256 (bi (bi + 1) / 2 + bk), float 4 lane + e of it = entry [16 bi + 4 (lane >> 4) + e][16 bk + (lane & 15)]
+// 64 outputs per workgroup; the S partials of an output are summed by 4 threads (contiguous quarters, in order), then combined in a fixed
+// order: deterministic whatever the launch geometry.  Output index -> (share offset, m, n): row-major, or by blocks for a `frag` job (the
+// blocks above the diagonal are written as zeros, like the discarded upper entries of a row-major `tri` job).
+__device__ __forceinline__ void reduce_body(const ReduceArgs& r, int b, int block_x, double (*red)[64]) {
     const int o = threadIdx.x & 63, gq = threadIdx.x >> 6;
-    const int idx = blockIdx.x * 64 + o, b = blockIdx.y;
-    const size_t MN = (size_t)r.M * r.N;
+    const int idx = block_x * 64 + o;
+    int m, n;
+    size_t MN, off;
+    bool live;
+    if (r.frag > 0) {
+        const int blk = idx >> 8, within = idx & 255, bi = blk / r.frag, bk = blk - bi * r.frag, ln = within >> 2, e = within & 3;
+        m = 16 * bi + 4 * (ln >> 4) + e; n = 16 * bk + (ln & 15);
+        MN = (size_t)(r.frag * (r.frag + 1) / 2) * 256;
+        off = (size_t)(bi * (bi + 1) / 2 + bk) * 256 + within;
+        live = idx < r.M * r.N && bk <= bi;
+    } else {
+        m = idx / r.N; n = idx - m * r.N;
+        MN = (size_t)r.M * r.N; off = (size_t)idx;
+        live = idx < r.M * r.N && !(r.tri && n > m);                         // (discarded upper entries are not read: they may be unwritten)
+    }
     const float* part = r.part + (size_t)b * r.S * MN;
     double s = 0.0;
-    if (idx < r.M * r.N && !(r.tri && (idx % r.N) > (idx / r.N))) {      // (discarded upper entries are not read: they may be unwritten)
+    if (live) {
         const int per = (r.S + 3) / 4, k0 = gq * per, k1 = (k0 + per < r.S) ? k0 + per : r.S;
 #pragma unroll 8
-        for (int k = k0; k < k1; ++k) s += (double)part[(size_t)k * MN + idx];
+        for (int k = k0; k < k1; ++k) s += (double)part[(size_t)k * MN + off];
     }
     red[gq][o] = s;
     __syncthreads();
     if (gq != 0 || idx >= r.M * r.N) return;
     s = ((red[0][o] + red[1][o]) + red[2][o]) + red[3][o];
-    const int m = idx / r.N, n = idx - m * r.N;
     s *= r.alpha;
     if (r.add) { const double v = (double)r.add[b * r.out_batch + m * r.ldo + n]; s += r.add_coef * (v - ((r.add_diag_inv && m == n) ? 1.0 / v : 0.0)); }
     if (r.tri && n > m) s = 0.0;
     if (r.out) { float* q = r.out + b * r.out_batch + m * r.ldo + n; *q = (float)(s + (r.beta != 0.0 ? r.beta * (double)*q : 0.0)); }
     if (r.out64) { double* q = r.out64 + b * r.out_batch + m * r.ldo + n; *q = s + (r.beta != 0.0 ? r.beta * *q : 0.0); }
+}
+__global__ __launch_bounds__(256) void k_reduce_parts(ReduceArgs r) {
+    __shared__ double red[4][64];
+    reduce_body(r, blockIdx.y, blockIdx.x, red);
 }
 
 // Deferred reductions: the split-K / thin products of one layer park their partial sums in disjoint slices of the
@@ -373,26 +392,7 @@ __global__ __launch_bounds__(256) void k_reduce_multi(ReduceJobs q) {
     if (job >= q.n) return;
     const ReduceArgs& r = q.j[job];
     if (b >= q.nb[job] || (int)blockIdx.x * 64 >= r.M * r.N) return;
-    const int o = threadIdx.x & 63, gq = threadIdx.x >> 6;
-    const int idx = blockIdx.x * 64 + o;
-    const size_t MN = (size_t)r.M * r.N;
-    const float* part = r.part + (size_t)b * r.S * MN;
-    double s = 0.0;
-    if (idx < r.M * r.N && !(r.tri && (idx % r.N) > (idx / r.N))) {      // (discarded upper entries are not read: they may be unwritten)
-        const int per = (r.S + 3) / 4, k0 = gq * per, k1 = (k0 + per < r.S) ? k0 + per : r.S;
-#pragma unroll 8
-        for (int k = k0; k < k1; ++k) s += (double)part[(size_t)k * MN + idx];
-    }
-    red[gq][o] = s;
-    __syncthreads();
-    if (gq != 0 || idx >= r.M * r.N) return;
-    s = ((red[0][o] + red[1][o]) + red[2][o]) + red[3][o];
-    const int m = idx / r.N, n = idx - m * r.N;
-    s *= r.alpha;
-    if (r.add) { const double v = (double)r.add[b * r.out_batch + m * r.ldo + n]; s += r.add_coef * (v - ((r.add_diag_inv && m == n) ? 1.0 / v : 0.0)); }
-    if (r.tri && n > m) s = 0.0;
-    if (r.out) { float* p = r.out + b * r.out_batch + m * r.ldo + n; *p = (float)(s + (r.beta != 0.0 ? r.beta * (double)*p : 0.0)); }
-    if (r.out64) { double* p = r.out64 + b * r.out_batch + m * r.ldo + n; *p = s + (r.beta != 0.0 ? r.beta * *p : 0.0); }
+    reduce_body(r, b, blockIdx.x, red);
 }
 struct ReduceQueue {
     float* base; size_t cap, used; ReduceJobs q; int maxblk;
@@ -1340,6 +1340,7 @@ __global__ __launch_bounds__(512) void k_bw_chain(ChainArgs a) {
     //      The contraction runs over the chunk's samples (4 per MFMA step), so both operands are read TRANSPOSED from the tiles
     //      (scalar LDS reads); the A side of a (row-block, product) pair -- NSAMP / 4 registers, for G_r scaled by 2dv_r -- is
     //      read once and reused for every bk <= bi.  Waves: row-block pair (w & 3, nbk-1-(w & 3)) x half of the 1 + R products.
+    const size_t SHF = (size_t)(nbk * (nbk + 1) / 2) * 256;     // floats of one share: the lower blocks, 256 each
     if (a.p5h) {
         // split-f16 form (round 6): the contraction index is the sample, so a k-step of v_mfma_f32_16x16x32_f16 takes 32 of them; x = h1 + h2 on
         // both sides, three products (h1 h1' on one accumulator, h2 h1' + h1 h2' on another).  B = the transposed planes of 2^ea a built behind
@@ -1390,8 +1391,10 @@ __global__ __launch_bounds__(512) void k_bw_chain(ChainArgs a) {
                         const float xs = x[ks][e] * sc;
                         A1[ks][e] = (_Float16)xs; A2[ks][e] = (_Float16)(xs - (float)A1[ks][e]);
                     }
-                float* outp = it == 0 ? a.p_lm + (size_t)blockIdx.x * M * M
-                                      : a.p_g + ((size_t)(it - 1) * a.S + blockIdx.x) * M * M;
+                // (a share = the lower blocks as accumulator images, 1 KiB each: one 16-byte store per lane -- whole cache lines -- where the dense
+                //  [M][M] addressing took four 4-byte stores into 64-byte row segments; ReduceArgs.frag)
+                f32x4* outp = reinterpret_cast<f32x4*>(it == 0 ? a.p_lm + (size_t)blockIdx.x * SHF
+                                                               : a.p_g + ((size_t)(it - 1) * a.S + blockIdx.x) * SHF) + (size_t)(bi * (bi + 1) / 2) * 64 + lane;
                 for (int bk = 0; bk <= bi; ++bk) {
                     const f32x4* Tb = tT4 + (size_t)bk * PB;
                     f32x4 acc = {0.f, 0.f, 0.f, 0.f}, cor = {0.f, 0.f, 0.f, 0.f};
@@ -1405,8 +1408,10 @@ __global__ __launch_bounds__(512) void k_bw_chain(ChainArgs a) {
                         cor = __builtin_amdgcn_mfma_f32_16x16x32_f16(A2[ks], __builtin_bit_cast(f16x8, b1), cor, 0, 0, 0);
                         cor = __builtin_amdgcn_mfma_f32_16x16x32_f16(A1[ks], __builtin_bit_cast(f16x8, b2), cor, 0, 0, 0);
                     }
+                    f32x4 o4;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) outp[(size_t)(16 * bi + 4 * gq + e) * M + 16 * bk + jq] = (acc[e] + cor[e]) * back;
+                    for (int e = 0; e < 4; ++e) o4[e] = (acc[e] + cor[e]) * back;
+                    outp[(size_t)bk * 64] = o4;
                 }
             }
         }
@@ -1429,8 +1434,8 @@ __global__ __launch_bounds__(512) void k_bw_chain(ChainArgs a) {
                     if (it > 0) v *= dv2_s[smp * R + (it - 1)];
                     av[q] = v;
                 }
-                float* outp = it == 0 ? a.p_lm + (size_t)blockIdx.x * M * M
-                                      : a.p_g + ((size_t)(it - 1) * a.S + blockIdx.x) * M * M;
+                f32x4* outp = reinterpret_cast<f32x4*>(it == 0 ? a.p_lm + (size_t)blockIdx.x * SHF
+                                                               : a.p_g + ((size_t)(it - 1) * a.S + blockIdx.x) * SHF) + (size_t)(bi * (bi + 1) / 2) * 64 + lane;
                 // (measured and rejected, round 4: two column blocks at a time with even / odd k-steps on their own accumulators -- four
                 //  independent MFMA chains instead of one of 20 dependent ones -- 35.5 -> 40 us for the two launches of configs[2])
                 for (int bk = 0; bk <= bi; ++bk) {
@@ -1440,8 +1445,7 @@ __global__ __launch_bounds__(512) void k_bw_chain(ChainArgs a) {
                         const float bv = tileA[((size_t)(bk * 4 + (jq >> 2)) * TS + 4 * q + gq) * 4 + (jq & 3)];
                         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q], bv, acc, 0, 0, 0);
                     }
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) outp[(size_t)(16 * bi + 4 * gq + e) * M + 16 * bk + jq] = acc[e];
+                    outp[(size_t)bk * 64] = acc;
                 }
             }
         }
@@ -1966,36 +1970,44 @@ __global__ __launch_bounds__(256) void k_prepare_all(const PrepAll a) {
 }
 // row m of K_uu: dZ~_uu[m, :] = 4 sum_n Sbar_mn dK_mn/dd2 (z~_m - z~_n),  dvar_m = sum_n Sbar_mn K_mn / s2,  Sbar = (S + S^T)/2
 __global__ __launch_bounds__(256) void k_kuu_bwd(const float* Zt, const double* S, int M, int D, double variance_, const float* var_dev, int kern_type, double* dZt_uu, double* dvar_m) {
-    // one WAVE per row m (lanes over n, fixed-order shuffle reductions; no LDS, no barriers, no dynamically indexed arrays)
+    // one WAVE per row m, lanes over n.  The D + 1 sums over n of a row (dZ~[m][d], the variance term) are reduced TOGETHER: every lane parks
+    // its D + 1 partial sums in LDS, then lane j < D + 1 adds the 64 partials of sum j in lane order -- one LDS round trip and a chain of 64
+    // adds for all of them, where a shuffle tree per sum was 12 cross-lane moves of a double each (D + 1 = 10 of them: 3 us of an 11 us launch).
+    // Fixed order: deterministic.  (round 6; the symmetrised S is read as S[m][n] + S[n][m]: the second one strided, from L2)
+    __shared__ double part[4][16][65];                        // (16 sums per round: one round up to D = 15)
     const double variance = var_dev ? (double)*var_dev : variance_;
-    const int lane = threadIdx.x & 63, m = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (m >= M) return;
-    constexpr int NI = (IWVI_MAX_M + 63) / 64;
-    auto wsum = [](double v) { for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64); return v; };
-    double w[NI], kv = 0.0;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, m = blockIdx.x * 4 + w;
+    if (m >= M) return;                                        // (wave-uniform; no workgroup barrier below)
+    double acc[IWVI_MAX_D + 1];
 #pragma unroll
-    for (int it = 0; it < NI; ++it) {
-        const int n = lane + 64 * it;
-        w[it] = 0.0;
-        if (n < M) {
-            double d2 = 0.0;
-            for (int d = 0; d < D; ++d) { const double e = (double)Zt[m * D + d] - (double)Zt[n * D + d]; d2 += e * e; }
-            double k, g;
-            kern_and_grad<double>(d2, kern_type, variance, k, g);
-            const double sb = 0.5 * (S[(size_t)m * M + n] + S[(size_t)n * M + m]);
-            w[it] = 4.0 * sb * g;                                  // both (m, n) and (n, m)
-            kv += sb * k / variance;
-        }
+    for (int d = 0; d <= IWVI_MAX_D; ++d) acc[d] = 0.0;
+    for (int n = lane; n < M; n += 64) {
+        double d2 = 0.0;
+        for (int d = 0; d < D; ++d) { const double e = (double)Zt[m * D + d] - (double)Zt[n * D + d]; d2 += e * e; }
+        double k, g;
+        kern_and_grad<double>(d2, kern_type, variance, k, g);
+        const double sb = 0.5 * (S[(size_t)m * M + n] + S[(size_t)n * M + m]);
+        const double wgt = 4.0 * sb * g;                        // both (m, n) and (n, m)
+        acc[IWVI_MAX_D] += sb * k / variance;
+#pragma unroll
+        for (int d = 0; d < IWVI_MAX_D; ++d) if (d < D) acc[d] += wgt * ((double)Zt[m * D + d] - (double)Zt[n * D + d]);
     }
-    kv = wsum(kv);
-    if (lane == 0) dvar_m[m] = kv;
-    for (int d = 0; d < D; ++d) {
-        const double zm = (double)Zt[m * D + d];
-        double acc = 0.0;
+    for (int j0 = 0; j0 <= D; j0 += 16) {                      // sums j0 .. j0 + 15 of (dZ~[m][0..D-1] | variance term)
 #pragma unroll
-        for (int it = 0; it < NI; ++it) { const int n = lane + 64 * it; if (n < M) acc += w[it] * (zm - (double)Zt[n * D + d]); }
-        acc = wsum(acc);
-        if (lane == 0) dZt_uu[m * D + d] = acc;
+        for (int d = 0; d <= IWVI_MAX_D; ++d) {
+            const int j = d == IWVI_MAX_D ? D : d;              // (the variance term's accumulator is the last register, its sum index is D)
+            if ((d < D || d == IWVI_MAX_D) && j >= j0 && j < j0 + 16) part[w][j - j0][lane] = acc[d];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // this wave's LDS writes have landed (its own region: no workgroup barrier)
+        __builtin_amdgcn_wave_barrier();
+        const int j = j0 + lane;
+        if (lane < 16 && j <= D) {
+            double s = 0.0;
+            for (int l = 0; l < 64; ++l) s += part[w][lane][l];
+            if (j < D) dZt_uu[m * D + j] = s; else dvar_m[m] = s;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
     }
 }
 struct FinalArgsB {
@@ -2003,6 +2015,9 @@ struct FinalArgsB {
     const float* colsumC; const float* CtF; const float* sums; const float* dinvls_x; const double* dZt_uu; const double* dvar_m;
     float* dZ; float* dls; float* dvariance; float* dq_mu; float* dq_sqrt;
     int M, D, R; double kl_weight, variance; const float* var_dev;
+    // mixing matrix / linear mean function (workgroup D + 1, when asked for): dW[p, r] = S1 + S2 + 2 W o S3 with S1 = dFs^T G, S2 = dFm^T MU,
+    // S3 = dFv^T V;  dA = F^T dFs + F^T dFm
+    const float *s1, *s2, *s3, *W; float* dW; int n_w; const float *a1, *a2; float* dA; int n_a;
 };
 // workgroup d < D: dZ[:, d] and dls[d]; workgroup D: dvariance.  One wave each, lanes over m, fixed reduction tree.
 __global__ __launch_bounds__(64) void k_bw_final(FinalArgsB f) {
@@ -2019,6 +2034,11 @@ __global__ __launch_bounds__(64) void k_bw_final(FinalArgsB f) {
         }
         s = wsum(s) + (double)f.dinvls_x[d];
         if (lane == 0 && f.dls) f.dls[d] = (float)(-s * il * il);
+    } else if (d > f.D) {                                      // (round 6: the former k_lin_combine launch) dW = S1 + S2 + 2 W o S3, dA = A1 + A2
+        for (int i = lane; i < f.n_w || i < f.n_a; i += 64) {
+            if (f.dW && i < f.n_w) f.dW[i] = (f.s1 ? f.s1[i] : 0.f) + (f.s2 ? f.s2[i] : 0.f) + (f.s3 ? 2.f * f.W[i] * f.s3[i] : 0.f);
+            if (f.dA && i < f.n_a) f.dA[i] = (f.a1 ? f.a1[i] : 0.f) + (f.a2 ? f.a2[i] : 0.f);
+        }
     } else if (f.dvariance) {
         double s = 0.0;
         for (int m = lane; m < f.M; m += 64) s += f.dvar_m[m];
@@ -2026,14 +2046,6 @@ __global__ __launch_bounds__(64) void k_bw_final(FinalArgsB f) {
         if (lane == 0) f.dvariance[0] = (float)s;
     }
 }
-// dW[p, r] = S1 + S2 + 2 W o S3 with S1 = dFs^T G, S2 = dFm^T MU, S3 = dFv^T V;  dA = F^T dFs + F^T dFm
-__global__ void k_lin_combine(const float* s1, const float* s2, const float* s3, const float* W, float* dW, int n_w,
-                              const float* a1, const float* a2, float* dA, int n_a) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (dW && i < n_w) dW[i] = (s1 ? s1[i] : 0.f) + (s2 ? s2[i] : 0.f) + (s3 ? 2.f * W[i] * s3[i] : 0.f);
-    if (dA && i < n_a) dA[i] = (a1 ? a1[i] : 0.f) + (a2 ? a2[i] : 0.f);
-}
-
 struct BwdWs {
     float *DMU, *DV2, *SDV, *DA, *DK, *Qx, *part, *LinvF, *Zt, *invls, *CtF1, *Qsum;
     double *Lbar, *T1, *T2, *S, *dZt_uu, *dvar_m;
@@ -2201,7 +2213,7 @@ struct EncBwdArgs {
     float* part; int woff[IWVI_MAX_ENC], boff[IWVI_MAX_ENC], ptot;     // part[workgroup][ptot]: this workgroup's share of (dW_l | db_l)
     LvBwdArgs lv; int fused;                                           // fused: d_out rows come from the latent-variable layer's adjoint, formed here
 };
-constexpr int ER = 8, ELD = 65;         // rows per workgroup, row stride of an activation tile in LDS
+constexpr int ER = 4, ELD = 65;         // rows per workgroup, row stride of an activation tile in LDS
 constexpr int EW_MAX = IWVI_MAX_ENC * (64 * 64 + 64);   // LDS copy of the weights and biases (widths <= 64)
 // 8 rows per workgroup (128 workgroups at B = 1024: the phase is latency-bound), activations, deltas AND the weights in LDS
 // (weights read from global memory inside the dot-product loops cost an L1 round trip per term), threads over (row, unit)
@@ -2721,12 +2733,12 @@ extern "C" int iwvi_gp_layer_backward(const iwvi_gp_bwd_desc* dp, int64_t T, voi
             ReduceQueue& qa = two_q ? rqA : rqB;
             if (!q_only) {
                 ca.p_lm = qa.take((size_t)S * M * M);
-                ReduceArgs rl{ca.p_lm, S, M, M, nullptr, w.Lbar, (long long)M, -1.0, 0.0, 1, 0, nullptr, 0.0, 0};
+                ReduceArgs rl{ca.p_lm, S, M, M, nullptr, w.Lbar, (long long)M, -1.0, 0.0, 1, 0, nullptr, 0.0, 0, nbk};      // (shares: lower blocks, accumulator images)
                 if (!ca.p_lm || !qa.push(rl, 1)) { set_error("backward: workspace too small for the chain kernel's dLm shares"); return IWVI_ERR_ARG; }
             }
             if (d.dq_sqrt) {
                 ca.p_g = rqB.take((size_t)R * S * M * M);
-                ReduceArgs rg{ca.p_g, S, M, M, w.G, nullptr, (long long)M, 1.0, 0.0, 1, (long long)M * M, nullptr, 0.0, 0};
+                ReduceArgs rg{ca.p_g, S, M, M, w.G, nullptr, (long long)M, 1.0, 0.0, 1, (long long)M * M, nullptr, 0.0, 0, nbk};
                 if (!ca.p_g || !rqB.push(rg, R)) { set_error("backward: workspace too small for the chain kernel's G_r shares"); return IWVI_ERR_ARG; }
             }
             ca.DK = nullptr;
@@ -2884,19 +2896,15 @@ extern "C" int iwvi_gp_layer_backward(const iwvi_gp_bwd_desc* dp, int64_t T, voi
         if ((rc = check_launch("k_gl_tril")) != IWVI_OK) return rc;
     }
     if (!two && (rc = chol_adjoint(st)) != IWVI_OK) return rc;     // one stream: after the single reduction, as before
-    if (lin_on) {
-        const int P = d.P;
-        const int n_w = (d.dW && d.W) ? P * R : 0, n_a = (d.dmf_A && d.mf_type == IWVI_MF_LINEAR) ? D * P : 0;
-        hipLaunchKernelGGL(k_lin_combine, dim3(((n_w > n_a ? n_w : n_a) + 255) / 256), dim3(256), 0, st, (const float*)s[0], (const float*)s[1], (const float*)s[2],
-                           d.W, n_w ? d.dW : nullptr, n_w, (const float*)a12[0], (const float*)a12[1], n_a ? d.dmf_A : nullptr, n_a);
-    }
+    const int n_w = (lin_on && d.dW && d.W) ? d.P * R : 0, n_a = (lin_on && d.dmf_A && d.mf_type == IWVI_MF_LINEAR) ? D * d.P : 0;
     if (evA) {                                             // the assembly needs chain A's dZt_uu / dvar_m
         if (hipStreamWaitEvent(stB, evA, 0) != hipSuccess) { set_error("iwvi_gp_layer_backward: stream join failed"); return IWVI_ERR_LAUNCH; }
         (void)hipEventDestroy(evA);
     }
     FinalArgsB f{d.Z, d.lengthscales, d.q_mu, d.q_sqrt, w.Zt, w.invls, w.CtF1, w.CtF1, w.Qsum + D, w.Qsum, w.dZt_uu, w.dvar_m,
-                 d.dZ, d.dls, d.dvariance, d.dq_mu, d.dq_sqrt, M, D, R, d.kl_weight, (double)d.variance, d.variance_dev};
-    hipLaunchKernelGGL(k_bw_final, dim3(D + 1), dim3(64), 0, st, f);
+                 d.dZ, d.dls, d.dvariance, d.dq_mu, d.dq_sqrt, M, D, R, d.kl_weight, (double)d.variance, d.variance_dev,
+                 s[0], s[1], s[2], d.W, n_w ? d.dW : nullptr, n_w, a12[0], a12[1], n_a ? d.dmf_A : nullptr, n_a};
+    hipLaunchKernelGGL(k_bw_final, dim3(D + 1 + (lin_on ? 1 : 0)), dim3(64), 0, st, f);
     return check_launch("k_bw_final");
 }
 

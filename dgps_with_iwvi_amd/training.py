@@ -249,9 +249,15 @@ class Trainer:
         dq_sqrt = _abi.dev_tensor(g["l%d.q_sqrt" % i].contiguous(), "dq_sqrt")
         _abi.check(_abi.lib().iwvi_natgrad_step_ex(_abi.ptr(f.q_mu), _abi.ptr(f.q_sqrt), _abi.ptr(dq_mu), _abi.ptr(dq_sqrt),
                                                   f.num_inducing, f.num_outputs, gamma, self._ng_ws.data_ptr(), self._ng_ws.numel(), _abi.stream_ptr()))
-        if _prefactor:                                           # the dense factors queued beside this update: joined here (the next op starts from them)
+        if _prefactor:
+            # the dense float64 factors the NEXT op's adjoints read, beside this update (a handful of small launches): queued behind it -- in a
+            # captured step the first successor keeps the hardware queue -- but ordered only behind the evaluation; joined here
             from . import backward as _bw
-            torch.cuda.current_stream().wait_stream(_bw.prepare_stream(f.q_mu.device))
+            ps = _bw.prepare_stream(f.q_mu.device)
+            _bw.prefactor_dense(self.model, ps, self.model._prefactor_after, skip_q_of={i})
+            if _prefactor == "join":                             # an op captured on its own must end with every stream joined; otherwise the next
+                torch.cuda.current_stream().wait_stream(ps)      # op's preparation follows on the same stream and ITS join covers this work (a
+                                                                 # join here is a cross-queue wait in front of the next op's launches: ~10 us)
         return elbo
 
     def adam_op(self, zs=None, _advance=True, _q_moved=False):
@@ -331,7 +337,7 @@ class Trainer:
             else:
                 self._advance_outside_graph()
                 one = self._one_factor()
-                self._replay("ng", lambda: self.natgrad_op(None, _advance=False, _prefactor=one))
+                self._replay("ng", lambda: self.natgrad_op(None, _advance=False, _prefactor="join" if one else False))
                 self._advance_outside_graph()
                 elbo = self._replay("adam", lambda: self.adam_op(None, _advance=False, _q_moved=one))
             for _, owner in self._scalars:                     # a replay runs no host code: flag the host copies here
@@ -340,12 +346,12 @@ class Trainer:
                 self._raise_if_not_finite(elbo)
             return elbo
         one = self._one_factor()
-        self.natgrad_op(zs_ng, _prefactor=one)
+        self.natgrad_op(zs_ng, _prefactor="open" if one else False)
         return self.adam_op(zs_adam, _q_moved=one)
 
     def _both_ops(self):
         one = self._one_factor()
-        self.natgrad_op(None, _advance=False, _prefactor=one)
+        self.natgrad_op(None, _advance=False, _prefactor="open" if one else False)
         return self.adam_op(None, _advance=False, _q_moved=one)
 
     def _advance_outside_graph(self):
