@@ -2288,17 +2288,19 @@ __global__ __launch_bounds__(256) void k_enc_bwd(EncBwdArgs a) {
         }
         __syncthreads();
     }
+    // Backward sweep, ONE barrier per layer (round 6; three before -- delta, products, copy -- and the phases between them are a handful of LDS
+    // round trips each: the launch is a chain of barriers): the thread that forms d / d input [r][i] of layer l applies the activation's
+    // derivative of layer l - 1 to it on the spot (that IS layer l - 1's delta), and the two row tiles alternate instead of being copied.
+    float* dl2 = wl + a.ptot;                                // the other delta tile (behind the weights)
+    {
+        const int dout = a.dims[a.n];                        // the last layer has no activation: its delta is d / d output
+        for (int idx = tid; idx < nrows * dout; idx += 256) { const int r = idx / dout, o = idx - r * dout; dl[r * ELD + o] = cur[r * ELD + o]; }
+        __syncthreads();
+    }
     for (int l = a.n - 1; l >= 0; --l) {
         const int din = a.dims[l], dout = a.dims[l + 1];
         const bool skip = din == dout;
-        const float* in = acts + (size_t)l * ER * ELD; const float* out = acts + (size_t)(l + 1) * ER * ELD;
-        for (int idx = tid; idx < nrows * dout; idx += 256) {
-            const int r = idx / dout, o = idx - r * dout;
-            float v = cur[r * ELD + o];
-            if (l < a.n - 1) { const float av = out[r * ELD + o] - (skip ? in[r * ELD + o] : 0.f); v *= enc_act_grad(av, a.act); }
-            dl[r * ELD + o] = v;
-        }
-        __syncthreads();
+        const float* in = acts + (size_t)l * ER * ELD;
         // this workgroup's rows' share of dW_l = in^T dl and db_l = colsum(dl), rows in a fixed order
         float* pw = a.part + (size_t)blockIdx.x * a.ptot;
         for (int idx = tid; idx < din * dout + dout; idx += 256) {
@@ -2313,15 +2315,21 @@ __global__ __launch_bounds__(256) void k_enc_bwd(EncBwdArgs a) {
                 pw[a.boff[l] + o] = acc;
             }
         }
-        for (int idx = tid; idx < nrows * din; idx += 256) {
-            const int r = idx / din, i = idx - r * din;
-            float acc = skip ? cur[r * ELD + i] : 0.f;
-            for (int o = 0; o < dout; ++o) acc = fmaf(dl[r * ELD + o], wl[a.woff[l] + i * dout + o], acc);
-            prev[r * ELD + i] = acc;
+        if (l > 0) {
+            const bool skip_b = a.dims[l - 1] == din;            // layer l - 1's residual connection
+            const float* in_b = acts + (size_t)(l - 1) * ER * ELD;
+            for (int idx = tid; idx < nrows * din; idx += 256) {
+                const int r = idx / din, i = idx - r * din;
+                float acc = skip ? cur[r * ELD + i] : 0.f;
+                for (int o = 0; o < dout; ++o) acc = fmaf(dl[r * ELD + o], wl[a.woff[l] + i * dout + o], acc);
+                prev[r * ELD + i] = acc;                         // d / d output of layer l - 1 (its residual branch reads it next round)
+                const float av = in[r * ELD + i] - (skip_b ? in_b[r * ELD + i] : 0.f);
+                dl2[r * ELD + i] = acc * enc_act_grad(av, a.act);
+            }
+            __syncthreads();
+            float* t_ = cur; cur = prev; prev = t_;
+            t_ = dl; dl = dl2; dl2 = t_;
         }
-        __syncthreads();
-        for (int idx = tid; idx < nrows * din; idx += 256) { const int r = idx / din, i = idx - r * din; cur[r * ELD + i] = prev[r * ELD + i]; }
-        __syncthreads();
     }
 }
 
@@ -3022,13 +3030,13 @@ static int enc_bwd_impl(const float* XY, int64_t rows, const float* const* enc_W
     a.ptot = off;
     const int nblk = (int)((rows + ER - 1) / ER);
     r.part = a.part; r.nblk = nblk; r.ptot = off; r.n = 2 * n_enc;
-    size_t elds = sizeof(float) * (size_t)(n_enc + 4) * ER * ELD;
+    size_t elds = sizeof(float) * (size_t)(n_enc + 5) * ER * ELD;
     for (int l = 0; l < n_enc; ++l) elds += sizeof(float) * (size_t)(dims[l] * dims[l + 1] + dims[l + 1]);
     int rc;
     {   // once per process: allow the largest encoder (hipFuncSetAttribute is not a stream operation)
         static bool done = false;
         if (!done) {
-            const size_t most = sizeof(float) * ((size_t)(IWVI_MAX_ENC + 4) * ER * ELD + EW_MAX);
+            const size_t most = sizeof(float) * ((size_t)(IWVI_MAX_ENC + 5) * ER * ELD + EW_MAX);
             hipError_t e = hipFuncSetAttribute((const void*)k_enc_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)most);
             if (e != hipSuccess) { set_error("hipFuncSetAttribute(%zu B LDS): %s", most, hipGetErrorString(e)); return IWVI_ERR_LAUNCH; }
             done = true;
