@@ -108,7 +108,7 @@ typedef struct iwvi_gp_desc {
     double jitter;             /* gpflow settings.numerics.jitter_level          */
     int32_t M, D, R;
     int32_t kern_type;         /* IWVI_KERN_*                                    */
-    int32_t flags;             /* IWVI_GP_WANT_DENSE, IWVI_GP_WANT_LM or 0       */
+    int32_t flags;             /* IWVI_GP_* bits above, or 0                     */
     const float* variance_dev; /* optional DEVICE scalar: read instead of `variance` when the launch runs (a trained
                                 * kernel variance that lives on the device keeps a captured hipGraph valid across steps) */
 } iwvi_gp_desc;
