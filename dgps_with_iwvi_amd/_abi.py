@@ -23,6 +23,7 @@ LAYER_F32_STAGE2 = 1        # iwvi_layer_desc.flags
 LAYER_F64_STAGE1 = 2        # iwvi_layer_desc.flags: K_uf, Lm^-1 k, sigma^2 - |a|^2 of the layer in float64
 GP_F64_STAGE1 = 4           # iwvi_gp_desc.flags: prepare the state for it (dense float64 Lm^-1, plain z~)
 BW_F32_CHAIN = 1            # iwvi_gp_bwd_desc.flags
+BW_OWN_QSCALE = 4
 ADAM_GRAD_F64 = 16
 MAX_STACK = 8
 MF_ZERO, MF_IDENTITY, MF_LINEAR = 0, 1, 2

@@ -172,7 +172,7 @@ def prefactor_dense(model, stream, after, skip_q_of=()):
         _abi.check(_abi.lib().iwvi_gp_dense_inverse(arr_d, len(descs), _abi.stream_ptr()))
 
 
-def prepare_side(model, T, stream, out=None, after=None, dense_ready=None):
+def prepare_side(model, T, stream, out=None, after=None, dense_ready=None, flags=0):
     """On ``stream``, beside the forward: the dense float64 factors of every GP layer (into its second state buffer) and the
     parameter-only part of its adjoint (``iwvi_gp_layer_backward_prepare``: scaled inducing inputs, packed S_r = L_r L_r^T and
     Lm^-T).  -> {layer index: (workspace, dense state)}; the caller joins ``stream`` before the first ``gp_backward``.
@@ -213,6 +213,7 @@ def prepare_side(model, T, stream, out=None, after=None, dense_ready=None):
             keeps = []
             for k, (i, l) in enumerate(gps):
                 b, keep = _param_desc(l, out[i][1])
+                b.flags |= flags
                 arr[k] = b
                 wsp[k] = out[i][0].data_ptr()
                 keeps.append(keep)
@@ -220,6 +221,7 @@ def prepare_side(model, T, stream, out=None, after=None, dense_ready=None):
         else:
             for i, l in gps:
                 b, keep = _param_desc(l, out[i][1])
+                b.flags |= flags
                 _abi.check(_abi.lib().iwvi_gp_layer_backward_prepare(ctypes.byref(b), T, out[i][0].data_ptr(), _abi.stream_ptr()))
     return out
 
@@ -419,7 +421,10 @@ def iw_elbo_and_gradients(model, zs=None, mode_vi=None, exchange=None, K_total=N
         after = torch.cuda.Event()
         after.record(cur)
         model.precompute(with_encoders=True, q_moved=q_moved)
-        prepared = prepare_side(model, T, prep_stream, out=alloc, after=after, dense_ready=q_moved)
+        # (the dense state's q(u) images are NOT refreshed: the adjoint reads nothing of them but the split-f16 scale of S_r = L_r L_r^T, which
+        #  the packing takes from L_r itself here (IWVI_BW_OWN_QSCALE) -- the preparation is k_prepare_all alone, ordered behind the start
+        #  of this op only and over long before the layer launch ends: no cross-queue join in front of the first chain)
+        prepared = prepare_side(model, T, prep_stream, out=alloc, after=after, dense_ready=set(), flags=_abi.BW_OWN_QSCALE)
     elif inline:
         # IWVI_BW_PREPARE=inline: one factorisation for both passes (prepare_inline).  Measured, not the default: the inversion launch sits
         # in front of the layer kernel (17 us at M = 128) where the side stream's dense factorisation costs the layer kernel 7 us and a

@@ -1670,11 +1670,11 @@ __global__ __launch_bounds__(512) void k_bw_chain(ChainArgs a) {
 // operands of k_bw_chain, once per evaluation: packed S_r = L_r L_r^T blocks [bi][r][bk] and the packed upper blocks of Lm^-T.
 // One workgroup per 16x16 block, one thread per entry (M^3 R flops in all: negligible, latency-bound, off the critical path).
 // SP16 (or NULL): the split-f16 image of the same S_r blocks for v_mfma_f32_16x16x32_f16 (iwvi_common.h: s16_*): slab (bi, r, kc) = the
-// blocks bk = 2kc, 2kc + 1, two planes of 64 lanes x 8 halves; scaled by 2^es_r with M max|L_r|^2 2^es_r <= 2^14 (max|L_r| from the scales
-// the factorisation launch left in the state's constant block); spf[r] = 2^-(es_r + ea), what an accumulated row-block is multiplied by.
+// blocks bk = 2kc, 2kc + 1, two planes of 64 lanes x 8 halves; scaled by 2^es_r with M max|L_r|^2 2^es_r <= 2^14 (max|L_r| taken from L_r
+// here, rounded as the precompute's q(u) role rounds it); spf[r] = 2^-(es_r + ea), what an accumulated row-block is multiplied by.
 __device__ __forceinline__ void pack_bw_body(int b, const float* __restrict__ q_sqrt, const double* __restrict__ Linv64, int Mp, int M, int R, int nbk,
                                              float* __restrict__ SP, float* __restrict__ LinvTP,
-                                             unsigned short* __restrict__ SP16, const float* __restrict__ cst, float* __restrict__ spf) {
+                                             unsigned short* __restrict__ SP16, const float* __restrict__ cst, float* __restrict__ spf, int own_qscale) {
     __shared__ float Ls[2][16][129];                         // the 16 rows of L_r of row-block bi / bk, 128 columns at a time
     const int i = threadIdx.x >> 4, k = threadIdx.x & 15;
     const int off = (16 * (k >> 2) + i) * 4 + (k & 3);       // A-fragment order: lane 16g + i holds G[i][4g + s]
@@ -1683,6 +1683,37 @@ __device__ __forceinline__ void pack_bw_body(int b, const float* __restrict__ q_
         const int bi = b / (R * nbk), r = (b / nbk) % R, bk = b % nbk;
         const int bm = bi < bk ? bi : bk, ncol = 16 * bm + 16;
         const float* Lr = q_sqrt + (size_t)r * M * M;
+        // The split-f16 image's scale: max |L_r| rounded up to a power of two -- as the precompute's q(u) role left it in the state's constant
+        // block, or (IWVI_BW_OWN_QSCALE, round 6) from L_r ITSELF, formed here by every workgroup (16 K floats, one coalesced pass; a maximum
+        // is order-free) and rounded exactly as that role rounds it: the same scale bit for bit, without tying this launch behind a precompute
+        // of the CURRENT q(u) -- a training step's second op waited a cross-queue join for it.  (+2 us of this launch: only where it is
+        // off the critical path.)  Always read from the state: the factorisation's own 2^ea (cst[IWVI_CST_SA]).
+        float max_l = 0.f;
+        if (SP16 && !own_qscale) max_l = 16384.f * cst[IWVI_CST_FR + r] * cst[IWVI_CST_SA];     // max|L_r| < 2^(14 - e_r)
+        if (SP16 && own_qscale) {
+            __shared__ float rs[4];
+            float mx = 0.f;
+            {   // 16 bytes per load, the row / column of an entry stepped along instead of divided out (M is a multiple of 16 here)
+                const float4* L4 = reinterpret_cast<const float4*>(Lr);
+                int row = (int)(threadIdx.x * 4) / M, col = (int)(threadIdx.x * 4) - row * M;
+                for (int i4 = threadIdx.x; i4 < (M * M) >> 2; i4 += 256) {
+                    const float4 v = L4[i4];
+                    if (col <= row) mx = fmaxf(mx, fabsf(v.x));
+                    if (col + 1 <= row) mx = fmaxf(mx, fabsf(v.y));
+                    if (col + 2 <= row) mx = fmaxf(mx, fabsf(v.z));
+                    if (col + 3 <= row) mx = fmaxf(mx, fabsf(v.w));
+                    col += 1024;
+                    while (col >= M) { col -= M; ++row; }
+                }
+            }
+            for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+            if ((threadIdx.x & 63) == 0) rs[threadIdx.x >> 6] = mx;
+            __syncthreads();
+            mx = fmaxf(fmaxf(rs[0], rs[1]), fmaxf(rs[2], rs[3]));
+            __syncthreads();
+            const int er = mx > 0.f ? 13 - ilogbf(mx) : 0;                                   // (precompute_dev.h: role_pack_body)
+            max_l = ldexpf(1.f, 14 - er);                                                    // max |L_r| < 2^(14 - e_r)
+        }
         float acc = 0.f;
         for (int c0 = 0; c0 < ncol; c0 += 128) {
             const int nc = ncol - c0 < 128 ? ncol - c0 : 128;
@@ -1697,7 +1728,6 @@ __device__ __forceinline__ void pack_bw_body(int b, const float* __restrict__ q_
         }
         SP[(size_t)b * 256 + off] = acc;
         if (SP16) {
-            const float max_l = 16384.f * cst[IWVI_CST_FR + r] * cst[IWVI_CST_SA];          // max|L_r| < 2^(14 - e_r)
             const int es = 14 - (int)ceilf(log2f(fmaxf((float)M * max_l * max_l, 1e-30f)));
             const float x = acc * ldexpf(1.f, es);
             const _Float16 h1 = (_Float16)x, h2 = (_Float16)(x - (float)h1);
@@ -1716,8 +1746,8 @@ __device__ __forceinline__ void pack_bw_body(int b, const float* __restrict__ q_
 }
 __global__ __launch_bounds__(256) void k_pack_bw(const float* __restrict__ q_sqrt, const double* __restrict__ Linv64, int Mp, int M, int R, int nbk,
                                                  float* __restrict__ SP, float* __restrict__ LinvTP,
-                                                 unsigned short* __restrict__ SP16, const float* __restrict__ cst, float* __restrict__ spf) {
-    pack_bw_body((int)blockIdx.x, q_sqrt, Linv64, Mp, M, R, nbk, SP, LinvTP, SP16, cst, spf);
+                                                 unsigned short* __restrict__ SP16, const float* __restrict__ cst, float* __restrict__ spf, int own_qscale) {
+    pack_bw_body((int)blockIdx.x, q_sqrt, Linv64, Mp, M, R, nbk, SP, LinvTP, SP16, cst, spf, own_qscale);
 }
 static int chain_ns_cap(long long T, int cap) {             // samples per workgroup / 16: as the forward's (every CU a workgroup), then down to a divisor of T
     int ns = (int)((T + 16 * 256 - 1) / (16 * 256));
@@ -1955,7 +1985,7 @@ __global__ __launch_bounds__(256) void k_prep(const float* Z, const float* ls, c
 struct PrepOne {
     const float* Z; const float* ls; const double* Linv64; const float* q_sqrt; const float* cst;
     float* Zt; float* invls; float* LinvF; float* SP; float* LinvTP; unsigned short* SP16; float* spf;
-    int Mp, M, D, R, nbk, nprep, npack, pad_;
+    int Mp, M, D, R, nbk, nprep, npack, own_qscale;
 };
 struct PrepAll { PrepOne L[IWVI_MAX_STACK]; int n; };
 __global__ __launch_bounds__(256) void k_prepare_all(const PrepAll a) {
@@ -1964,7 +1994,7 @@ __global__ __launch_bounds__(256) void k_prepare_all(const PrepAll a) {
         const PrepOne& L = a.L[li];
         if (b < L.nprep) { prep_body(b, L.Z, L.ls, L.Linv64, L.Mp, L.Zt, L.invls, L.LinvF, L.M, L.D); return; }
         b -= L.nprep;
-        if (b < L.npack) { pack_bw_body(b, L.q_sqrt, L.Linv64, L.Mp, L.M, L.R, L.nbk, L.SP, L.LinvTP, L.SP16, L.cst, L.spf); return; }
+        if (b < L.npack) { pack_bw_body(b, L.q_sqrt, L.Linv64, L.Mp, L.M, L.R, L.nbk, L.SP, L.LinvTP, L.SP16, L.cst, L.spf, L.own_qscale); return; }
         b -= L.npack;
     }
 }
@@ -2632,7 +2662,7 @@ extern "C" int iwvi_gp_layer_backward_prepare(const iwvi_gp_bwd_desc* dp, int64_
         const int nbk = Mp / 16;
         const bool s16 = chain_s16(M, Mp);
         hipLaunchKernelGGL(k_pack_bw, dim3((unsigned)(R * nbk * nbk + tri_blocks(nbk))), dim3(256), 0, st, d.q_sqrt, Linv64, Mp, M, R, nbk, w.SP, w.LinvTP,
-                           s16 ? w.SP16 : (unsigned short*)nullptr, (const float*)((const char*)d.state + sl.off_cst), w.spf);
+                           s16 ? w.SP16 : (unsigned short*)nullptr, (const float*)((const char*)d.state + sl.off_cst), w.spf, (d.flags & IWVI_BW_OWN_QSCALE) ? 1 : 0);
     }
     return check_launch("iwvi_gp_layer_backward_prepare");
 }
@@ -2663,6 +2693,7 @@ extern "C" int iwvi_gp_layers_backward_prepare(const iwvi_gp_bwd_desc* descs, in
         const bool chain = chain_fits(T, M, sl.Mp, D, R, d.P > 0 ? d.P : R);
         L.npack = chain ? R * L.nbk * L.nbk + tri_blocks(L.nbk) : 0;
         L.SP16 = (chain && chain_s16(M, sl.Mp)) ? w.SP16 : (unsigned short*)nullptr;
+        L.own_qscale = (d.flags & IWVI_BW_OWN_QSCALE) ? 1 : 0;
         grid += (unsigned)(L.nprep + L.npack);
     }
     hipLaunchKernelGGL(k_prepare_all, dim3(grid), dim3(256), 0, (hipStream_t)stream_, a);

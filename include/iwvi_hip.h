@@ -369,6 +369,10 @@ typedef struct iwvi_gp_bwd_desc {
 } iwvi_gp_bwd_desc;
 /* IWVI_BW_F32_CHAIN: the adjoint chain's S_r products on fp32 MFMAs instead of split-f16 operands (per call, like IWVI_LAYER_F32_STAGE2). */
 #define IWVI_BW_F32_CHAIN 1
+/* IWVI_BW_OWN_QSCALE (ABI 17; read by the two prepare entries): the q(u) scales in the state's constant block may be stale -- the state
+ * was last precomputed with IWVI_GP_FACTOR_ONLY, or q(u) has moved since --: take max |L_r| from q_sqrt itself (same value, same
+ * rounding; +2 us of the launch).  The preparation then depends on the state's factorisation only, not on a precompute of the current q(u). */
+#define IWVI_BW_OWN_QSCALE 4
 /* (both sizing entries answer for either arithmetic mode a later call may select through desc.flags: the larger workspace; u is needed
  * when either mode's adjoint reads it) */
 size_t iwvi_gp_layer_backward_ws_bytes(int64_t T, int M, int D, int R);
