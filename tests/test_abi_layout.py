@@ -45,3 +45,25 @@ def test_abi_version_constant_matches_the_header():
     with open(os.path.join(ROOT, "include", "iwvi_hip.h")) as f:
         ver = [ln for ln in f if ln.startswith("#define IWVI_ABI_VERSION")][0].split()[2]
     assert int(ver) == _abi.ABI_VERSION
+
+
+def test_flag_constants_match_the_header():
+    """Every IWVI_* flag / enum value _abi.py mirrors by hand equals the header's #define (a drifted constant is a silent wrong route)."""
+    import re
+    from dgps_with_iwvi_amd import _abi
+    defs = {}
+    with open(os.path.join(ROOT, "include", "iwvi_hip.h")) as f:
+        for ln in f:
+            m = re.match(r"#define\s+(IWVI_[A-Z0-9_]+)\s+(-?\d+)\b", ln)
+            if m:
+                defs[m.group(1)] = int(m.group(2))
+    pairs = {"GP_WANT_DENSE": "IWVI_GP_WANT_DENSE", "GP_WANT_LM": "IWVI_GP_WANT_LM", "GP_F64_STAGE1": "IWVI_GP_F64_STAGE1",
+             "GP_REUSE_FACTOR": "IWVI_GP_REUSE_FACTOR", "GP_FACTOR_ONLY": "IWVI_GP_FACTOR_ONLY",
+             "BW_F32_CHAIN": "IWVI_BW_F32_CHAIN", "BW_OWN_QSCALE": "IWVI_BW_OWN_QSCALE",
+             "MAX_STACK": "IWVI_MAX_STACK", "ERR_UNSUPPORTED": "IWVI_ERR_UNSUPPORTED"}
+    checked = 0
+    for py, c in pairs.items():
+        if hasattr(_abi, py) and c in defs:
+            assert getattr(_abi, py) == defs[c], (py, getattr(_abi, py), c, defs[c])
+            checked += 1
+    assert checked >= 6, (checked, sorted(defs)[:10])
